@@ -1,0 +1,429 @@
+// ref_driver — drives the UNMODIFIED reference nodes (compiled from /root/reference/src where
+// they lie; see oracle/Makefile) to (1) cut golden vectors for tests/golden/ and (2) time the
+// reference CPU path as bench.py's `cpu_baseline` (kind "reference").
+//
+// TEST INFRASTRUCTURE ONLY. Nothing in the product path (libsdr_amd/, include/) may link,
+// call or execute this program. It is our own code: it only *includes* the reference headers at
+// build time; no reference source text lives in this repository.
+//
+//   ref_driver golden <outdir>          write fixtures + <outdir>/manifest.json
+//   ref_driver bench <chain> <nbuf>     time a chain over <nbuf> 65536-sample buffers (1 thread)
+//
+// Wiring follows examples/sdr_fm.cc:49-53 (source -> node -> demod, direct edges); the capture
+// sink plays the role of DebugStore (src/utils.hh:799-841) but keeps every buffer.
+#include "sdr.hh"
+#include "filternode.hh"   // only for sinc_flt_kernel<> (a free template; needs no FFTW)
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <sstream>
+#include <chrono>
+
+using namespace sdr;
+typedef std::complex<int16_t> cs16;
+typedef std::complex<float> cf32;
+
+// ---------------------------------------------------------------------------------------------
+// capture sink / chunk feeder
+// ---------------------------------------------------------------------------------------------
+template <class T>
+class Capture : public Sink<T> {
+public:
+  std::vector<T> data;
+  std::vector<size_t> lens;
+  bool keep;
+  size_t total;
+  Capture() : keep(true), total(0) {}
+  virtual void config(const Config &) {}
+  virtual void process(const Buffer<T> &b, bool) {
+    lens.push_back(b.size());
+    total += b.size();
+    if (keep) { for (size_t i = 0; i < b.size(); i++) data.push_back(b[i]); }
+  }
+};
+
+template <class T>
+class Feeder : public Source {
+public:
+  void configure(double Fs, size_t maxlen) {
+    this->setConfig(Config(Config::typeId<T>(), Fs, maxlen, 1));
+  }
+  void feed(T *p, size_t n) {
+    Buffer<T> view(p, n);
+    this->send(view, false);
+  }
+};
+
+// exposes the protected design products of IQBaseBand (kernel, LUT, increment, decimation)
+class BBProbe : public IQBaseBand<int16_t> {
+public:
+  BBProbe(double Fc, double Ff, double width, size_t order, size_t sub, double oFs = 0.0)
+    : IQBaseBand<int16_t>(Fc, Ff, width, order, sub, oFs) {}
+  std::vector<int32_t> taps() const {
+    std::vector<int32_t> k;
+    for (size_t i = 0; i < _order; i++) { k.push_back(_kernel[i].real()); k.push_back(_kernel[i].imag()); }
+    return k;
+  }
+  std::vector<int32_t> lut() const {
+    std::vector<int32_t> l;
+    for (size_t i = 0; i < _lut_size; i++) { l.push_back(_lut[i].real()); l.push_back(_lut[i].imag()); }
+    return l;
+  }
+  size_t lutInc() const { return _lut_inc; }
+  bool negative() const { return 0 > _freq_shift; }
+  size_t decim() const { return _sub_sample; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// manifest writer
+// ---------------------------------------------------------------------------------------------
+static std::string g_out;
+static std::ostringstream g_manifest;
+static bool g_first = true;
+
+template <class T>
+static void dump(const std::string &name, const char *dtype, const std::vector<T> &v,
+                 const std::string &extra_json = "") {
+  std::string path = g_out + "/" + name + ".bin";
+  FILE *f = fopen(path.c_str(), "wb");
+  if (!f) { perror(path.c_str()); exit(2); }
+  if (v.size()) fwrite(&v[0], sizeof(T), v.size(), f);
+  fclose(f);
+  if (!g_first) g_manifest << ",\n";
+  g_first = false;
+  g_manifest << "  \"" << name << "\": {\"file\": \"" << name << ".bin\", \"dtype\": \"" << dtype
+             << "\", \"count\": " << v.size();
+  if (extra_json.size()) g_manifest << ", " << extra_json;
+  g_manifest << "}";
+}
+
+static std::string lens_json(const char *key, const std::vector<size_t> &l) {
+  std::ostringstream s;
+  s << "\"" << key << "\": [";
+  for (size_t i = 0; i < l.size(); i++) { if (i) s << ", "; s << l[i]; }
+  s << "]";
+  return s.str();
+}
+
+template <class T> static std::vector<int16_t> flat16(const std::vector<T> &v);
+template <> std::vector<int16_t> flat16<cs16>(const std::vector<cs16> &v) {
+  std::vector<int16_t> o; for (size_t i = 0; i < v.size(); i++) { o.push_back(v[i].real()); o.push_back(v[i].imag()); } return o;
+}
+static std::vector<float> flatf(const std::vector<cf32> &v) {
+  std::vector<float> o; for (size_t i = 0; i < v.size(); i++) { o.push_back(v[i].real()); o.push_back(v[i].imag()); } return o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// input generation with the reference's own generator (src/siggen.hh:90-157)
+// ---------------------------------------------------------------------------------------------
+struct Tone { double f, a, p; };
+
+template <class S>
+static std::vector< std::complex<S> > siggen(double Fs, size_t bs, size_t nbuf, const std::vector<Tone> &tones) {
+  IQSigGen<S> gen(Fs, bs);
+  for (size_t i = 0; i < tones.size(); i++) gen.addSine(tones[i].f, tones[i].a, tones[i].p);
+  Capture< std::complex<S> > cap;
+  gen.connect(&cap, true);
+  for (size_t b = 0; b < nbuf; b++) gen.next();
+  return cap.data;
+}
+
+static std::vector<Tone> two_tone_i16() {
+  std::vector<Tone> t; Tone a = {100e3, 8000, 0.0}, b = {-300e3, 6000, 0.3}; t.push_back(a); t.push_back(b); return t;
+}
+static std::vector<Tone> two_tone_f32() {
+  std::vector<Tone> t; Tone a = {100e3, 0.5, 0.0}, b = {-300e3, 0.3, 0.3}; t.push_back(a); t.push_back(b); return t;
+}
+
+// feed `x` to `head` in the given chunk lengths (cycled); returns number of chunks fed
+template <class T>
+static void feed_chunks(Feeder<T> &src, std::vector<T> &x, const std::vector<size_t> &chunks,
+                        std::vector<size_t> &used) {
+  size_t off = 0, c = 0;
+  while (off < x.size()) {
+    size_t n = std::min(chunks[c % chunks.size()], x.size() - off);
+    src.feed(&x[off], n);  // n may be 0
+    used.push_back(n);
+    off += n; c++;
+    if (c > 100000) break;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// golden cases
+// ---------------------------------------------------------------------------------------------
+enum Demod { D_NONE, D_FM, D_AM, D_USB };
+
+static void case_iqbb(const std::string &name, std::vector<cs16> x, double Fs, double Fc, double Ff,
+                      double width, size_t order, size_t sub, double oFs,
+                      const std::vector<size_t> &chunks, Demod demod, bool dump_design) {
+  size_t maxlen = 0; for (size_t i = 0; i < chunks.size(); i++) maxlen = std::max(maxlen, chunks[i]);
+  Feeder<cs16> src; src.configure(Fs, maxlen);
+  BBProbe bb(Fc, Ff, width, order, sub, oFs);
+  src.connect(&bb, true);
+  std::vector<size_t> used;
+  std::ostringstream par;
+  par << "\"Fs\": " << Fs << ", \"Fc\": " << Fc << ", \"Ff\": " << Ff << ", \"width\": " << width
+      << ", \"order\": " << order << ", \"sub\": " << sub << ", \"oFs\": " << oFs
+      << ", \"decim\": " << bb.decim() << ", \"lut_inc\": " << bb.lutInc()
+      << ", \"negative\": " << (bb.negative() ? 1 : 0);
+  if (dump_design) {
+    dump(name + "_taps", "i32", bb.taps(), par.str());
+    dump(name + "_lut", "i32", bb.lut());
+  }
+  if (demod == D_NONE) {
+    Capture<cs16> cap; bb.connect(&cap, true);
+    feed_chunks(src, x, chunks, used);
+    dump(name + "_out", "cs16", flat16(cap.data),
+         par.str() + ", " + lens_json("in_lens", used) + ", " + lens_json("out_lens", cap.lens));
+  } else if (demod == D_FM) {
+    FMDemod<int16_t> fm; Capture<int16_t> cap; bb.connect(&fm, true); fm.connect(&cap, true);
+    feed_chunks(src, x, chunks, used);
+    dump(name + "_fm", "i16", cap.data,
+         par.str() + ", " + lens_json("in_lens", used) + ", " + lens_json("out_lens", cap.lens));
+  } else if (demod == D_AM) {
+    AMDemod<int16_t> am; Capture<int16_t> cap; bb.connect(&am, true); am.connect(&cap, true);
+    feed_chunks(src, x, chunks, used);
+    dump(name + "_am", "i16", cap.data,
+         par.str() + ", " + lens_json("in_lens", used) + ", " + lens_json("out_lens", cap.lens));
+  } else {
+    USBDemod<int16_t> usb; Capture<int16_t> cap; bb.connect(&usb, true); usb.connect(&cap, true);
+    feed_chunks(src, x, chunks, used);
+    dump(name + "_usb", "i16", cap.data,
+         par.str() + ", " + lens_json("in_lens", used) + ", " + lens_json("out_lens", cap.lens));
+  }
+}
+
+static void case_fir_cs16(const std::string &name, std::vector<cs16> x, double Fs, size_t order,
+                          double Fcut, const std::vector<size_t> &chunks, bool with_fm) {
+  size_t maxlen = 0; for (size_t i = 0; i < chunks.size(); i++) maxlen = std::max(maxlen, chunks[i]);
+  Feeder<cs16> src; src.configure(Fs, maxlen);
+  FIRLowPass<cs16> fir(order, Fcut);
+  src.connect(&fir, true);
+  std::vector<size_t> used;
+  std::ostringstream par; par << "\"Fs\": " << Fs << ", \"order\": " << order << ", \"Fcut\": " << Fcut;
+  if (!with_fm) {
+    Capture<cs16> cap; fir.connect(&cap, true);
+    feed_chunks(src, x, chunks, used);
+    dump(name + "_out", "cs16", flat16(cap.data), par.str() + ", " + lens_json("in_lens", used));
+  } else {
+    FMDemod<int16_t> fm; Capture<int16_t> cap; fir.connect(&fm, true); fm.connect(&cap, true);
+    feed_chunks(src, x, chunks, used);
+    dump(name + "_fm", "i16", cap.data, par.str() + ", " + lens_json("in_lens", used)
+         + ", " + lens_json("out_lens", cap.lens));
+  }
+}
+
+static void golden() {
+  const double Fs = 2.4e6;
+  std::vector<size_t> c4096(1, 4096);
+
+  // G1 — inputs
+  std::vector<cs16> x16 = siggen<int16_t>(Fs, 4096, 4, two_tone_i16());
+  dump("g1_iq_cs16", "cs16", flat16(x16), "\"Fs\": 2400000, \"bufsize\": 4096, \"nbuf\": 4, "
+       "\"tones\": [[100000, 8000, 0.0], [-300000, 6000, 0.3]]");
+  std::vector<cf32> xf = siggen<float>(Fs, 4096, 3, two_tone_f32());
+  dump("g1_iq_cf32", "cf32", flatf(xf), "\"Fs\": 2400000, \"bufsize\": 4096, \"nbuf\": 3, "
+       "\"tones\": [[100000, 0.5, 0.0], [-300000, 0.3, 0.3]]");
+  // single tone inputs used by SURVEY Appendix B known answers
+  { std::vector<Tone> t; Tone a = {100e3, 8000, 0}; t.push_back(a);
+    dump("g1_iq_cs16_tone_p100k", "cs16", flat16(siggen<int16_t>(Fs, 4096, 2, t)),
+         "\"Fs\": 2400000, \"bufsize\": 4096, \"nbuf\": 2, \"tones\": [[100000, 8000, 0.0]]"); }
+  { std::vector<Tone> t; Tone a = {-100e3, 8000, 0}; t.push_back(a);
+    dump("g1_iq_cs16_tone_m100k", "cs16", flat16(siggen<int16_t>(Fs, 4096, 1, t)),
+         "\"Fs\": 2400000, \"bufsize\": 4096, \"nbuf\": 1, \"tones\": [[-100000, 8000, 0.0]]"); }
+
+  // G2/G3/G4 — IQBaseBand<int16>(Fc=Ff=100k, width 50k, order 127, /8) and demods in place
+  case_iqbb("g3_iqbb127d8", x16, Fs, 100e3, 100e3, 50e3, 127, 8, 0.0, c4096, D_NONE, true);
+  case_iqbb("g4_iqbb127d8", x16, Fs, 100e3, 100e3, 50e3, 127, 8, 0.0, c4096, D_FM, false);
+  case_iqbb("g4_iqbb127d8", x16, Fs, 100e3, 100e3, 50e3, 127, 8, 0.0, c4096, D_AM, false);
+  case_iqbb("g4_iqbb127d8", x16, Fs, 100e3, 100e3, 50e3, 127, 8, 0.0, c4096, D_USB, false);
+
+  // G2 — FIRLowPass designs
+  { size_t Ns[3] = {127, 255, 4097};
+    for (int k = 0; k < 3; k++) {
+      std::vector<double> a(Ns[k], 0.0);
+      FIRLowPassCoeffs::coeffs(a, 0, 100e3, Fs);
+      std::ostringstream nm; nm << "g2_firlp_alpha" << Ns[k];
+      dump(nm.str(), "f64", a, "\"Fs\": 2400000, \"Fcut\": 100000"); } }
+
+  // G5 — FIRLowPass<cs16> 127 / 255, plain and -> FMDemod in place
+  case_fir_cs16("g5_fir127", x16, Fs, 127, 100e3, c4096, false);
+  case_fir_cs16("g5_fir255", x16, Fs, 255, 100e3, c4096, false);
+  case_fir_cs16("g5_fir127", x16, Fs, 127, 100e3, c4096, true);
+  case_fir_cs16("g5_fir255", x16, Fs, 255, 100e3, c4096, true);
+  { // Appendix B: 2nd generator buffer of the +100k tone into a fresh FIR
+    std::vector<Tone> t; Tone a = {100e3, 8000, 0}; t.push_back(a);
+    std::vector<cs16> two = siggen<int16_t>(Fs, 4096, 2, t);
+    std::vector<cs16> second(two.begin() + 4096, two.end());
+    case_fir_cs16("g5_fir127_tone_buf2", second, Fs, 127, 100e3, c4096, false);
+    case_fir_cs16("g5_fir127_tone_buf2", second, Fs, 127, 100e3, c4096, true); }
+
+  // G6 — cf32: FIRLowPass<cf32>(127) -> SubSample(8); AM/USB float on the FIR output
+  { Feeder<cf32> src; src.configure(Fs, 4096);
+    FIRLowPass<cf32> fir(127, 100e3); src.connect(&fir, true);
+    Capture<cf32> cap; fir.connect(&cap, true);
+    for (size_t b = 0; b < 3; b++) src.feed(&xf[b * 4096], 4096);
+    dump("g6_fir127_cf32_out", "cf32", flatf(cap.data), "\"order\": 127, \"Fcut\": 100000, \"bufsize\": 4096");
+    std::vector<cf32> firout = cap.data;
+    { Feeder<cf32> s2; s2.configure(Fs, 4096); SubSample<cf32> sub(size_t(8)); s2.connect(&sub, true);
+      Capture<cf32> c2; sub.connect(&c2, true);
+      for (size_t b = 0; b < 3; b++) s2.feed(&firout[b * 4096], 4096);
+      dump("g6_fir127_cf32_sub8", "cf32", flatf(c2.data), lens_json("out_lens", c2.lens)); }
+    { Feeder<cf32> s2; s2.configure(Fs, 4096); SubSample<cf32> sub(size_t(3)); s2.connect(&sub, true);
+      Capture<cf32> c2; sub.connect(&c2, true);
+      for (size_t b = 0; b < 3; b++) s2.feed(&firout[b * 4096], 4096);
+      dump("g6_fir127_cf32_sub3", "cf32", flatf(c2.data), lens_json("out_lens", c2.lens)); }
+    { Feeder<cf32> s2; s2.configure(Fs, 4096); AMDemod<float> am; s2.connect(&am, true);
+      Capture<float> c2; am.connect(&c2, true);
+      for (size_t b = 0; b < 3; b++) s2.feed(&firout[b * 4096], 4096);
+      dump("g6_fir127_cf32_am", "f32", c2.data); }
+    { Feeder<cf32> s2; s2.configure(Fs, 4096); USBDemod<float> usb; s2.connect(&usb, true);
+      Capture<float> c2; usb.connect(&c2, true);
+      for (size_t b = 0; b < 3; b++) s2.feed(&firout[b * 4096], 4096);
+      dump("g6_fir127_cf32_usb", "f32", c2.data); }
+    { // FIRLowPass<cf32>(4097) on the first 2 buffers (config-4 comparison oracle)
+      Feeder<cf32> s3; s3.configure(Fs, 4096); FIRLowPass<cf32> f2(4097, 100e3); s3.connect(&f2, true);
+      Capture<cf32> c3; f2.connect(&c3, true);
+      for (size_t b = 0; b < 3; b++) s3.feed(&xf[b * 4096], 4096);
+      dump("g6_fir4097_cf32_out", "cf32", flatf(c3.data), "\"order\": 4097, \"Fcut\": 100000, \"bufsize\": 4096"); }
+  }
+  // SubSample<cs16> n=8 and n=3 over the raw int16 input
+  { size_t ns[2] = {8, 3};
+    for (int k = 0; k < 2; k++) {
+      Feeder<cs16> s2; s2.configure(Fs, 4096); SubSample<cs16> sub(ns[k]); s2.connect(&sub, true);
+      Capture<cs16> c2; sub.connect(&c2, true);
+      for (size_t b = 0; b < 4; b++) s2.feed(&x16[b * 4096], 4096);
+      std::ostringstream nm; nm << "g6_subsample_cs16_n" << ns[k];
+      dump(nm.str(), "cs16", flat16(c2.data), lens_json("out_lens", c2.lens)); } }
+  // standalone int16 demods over the raw input (out of place AM/USB are fully defined)
+  { Feeder<cs16> s2; s2.configure(Fs, 4096); AMDemod<int16_t> am; s2.connect(&am, true);
+    Capture<int16_t> c2; am.connect(&c2, true);
+    for (size_t b = 0; b < 4; b++) s2.feed(&x16[b * 4096], 4096);
+    dump("g4_raw_am", "i16", c2.data); }
+  { Feeder<cs16> s2; s2.configure(Fs, 4096); USBDemod<int16_t> usb; s2.connect(&usb, true);
+    Capture<int16_t> c2; usb.connect(&c2, true);
+    for (size_t b = 0; b < 4; b++) s2.feed(&x16[b * 4096], 4096);
+    dump("g4_raw_usb", "i16", c2.data); }
+  { // FMDemod out of place over the raw input: index 0 of each buffer is uninitialised memory in
+    // the reference (src/demod.hh:208,245) -> the test masks it; we zero it here for determinism.
+    Feeder<cs16> s2; s2.configure(Fs, 4096); FMDemod<int16_t> fm; s2.connect(&fm, true);
+    Capture<int16_t> c2; fm.connect(&c2, true);
+    for (size_t b = 0; b < 4; b++) s2.feed(&x16[b * 4096], 4096);
+    for (size_t b = 0; b < 4; b++) c2.data[b * 4096] = 0;
+    dump("g4_raw_fm_masked0", "i16", c2.data); }
+
+  // G7 — FFT-filter time-domain kernel h (float), the libm/float-phase sensitive part
+  { int Ns[2] = {1024, 8192};
+    for (int k = 0; k < 2; k++) {
+      int N = Ns[k]; double fmin = 50e3, fmax = 150e3; double bw = fmax - fmin, Fc = fmin + bw / 2;
+      std::vector<cf32> h;
+      for (int i = 0; i < N; i++) h.push_back(sinc_flt_kernel<float>(i, N, Fc, bw, Fs));
+      std::ostringstream nm; nm << "g7_fftfilt_h" << N;
+      dump(nm.str(), "cf32", flatf(h), "\"Fs\": 2400000, \"fmin\": 50000, \"fmax\": 150000"); } }
+
+  // G8 — edge cases
+  { std::vector<cs16> xm = siggen<int16_t>(Fs, 4096, 1, std::vector<Tone>(1, Tone{-100e3, 8000, 0}));
+    case_iqbb("g8_neg_o16_d1", xm, Fs, -100e3, -100e3, 50e3, 16, 1, 0.0, c4096, D_NONE, true); }
+  case_iqbb("g8_o21_d3", x16, Fs, 100e3, 100e3, 12.5e3, 21, 3, 0.0, c4096, D_NONE, true);
+  case_iqbb("g8_o33_d5", x16, Fs, -300e3, -300e3, 50e3, 33, 5, 0.0, c4096, D_NONE, true);
+  case_iqbb("g8_o33_d5", x16, Fs, -300e3, -300e3, 50e3, 33, 5, 0.0, c4096, D_FM, false);
+  case_iqbb("g8_o16_d4_even", x16, Fs, 100e3, 120e3, 80e3, 16, 4, 0.0, c4096, D_NONE, true);
+  case_iqbb("g8_o255_d8", x16, Fs, 100e3, 100e3, 50e3, 255, 8, 0.0, c4096, D_NONE, true);
+  case_iqbb("g8_noshift_o21_d8", x16, Fs, 0.0, 100e3, 50e3, 21, 8, 0.0, c4096, D_NONE, true);
+  case_iqbb("g8_ofs_d300", x16, Fs, 100e3, 100e3, 12.5e3, 21, 1, 8000.0, c4096, D_NONE, true);
+  { // irregular chunking incl. zero-output and zero-length calls
+    size_t cl[] = {1, 7, 8, 9, 0, 3, 4096, 5, 1000, 17, 2, 2, 2, 2048, 4000, 1};
+    std::vector<size_t> chunks(cl, cl + sizeof(cl) / sizeof(cl[0]));
+    case_iqbb("g8_irregular", x16, Fs, 100e3, 100e3, 50e3, 127, 8, 0.0, chunks, D_NONE, false);
+    case_iqbb("g8_irregular", x16, Fs, 100e3, 100e3, 50e3, 127, 8, 0.0, chunks, D_FM, false);
+    case_iqbb("g8_irregular", x16, Fs, 100e3, 100e3, 50e3, 127, 8, 0.0, chunks, D_USB, false);
+    case_fir_cs16("g8_irregular_fir127", x16, Fs, 127, 100e3, chunks, false);
+    case_fir_cs16("g8_irregular_fir127", x16, Fs, 127, 100e3, chunks, true); }
+  { // fast_atan2<int16,int16> known answers (src/math.hh:31-40), pairs (a, b) -> angle
+    int16_t ab[][2] = {{0,0},{1,0},{0,1},{-1,0},{0,-1},{1,1},{-1,1},{-1,-1},{1,-1},{32767,32767},
+      {-32768,-32768},{-32768,32767},{32767,-32768},{1000,3},{3,1000},{-3,-1000},{12345,-6789},
+      {-32768,0},{0,-32768},{32767,1},{-1,32767},{7,-7},{-20000,15000}};
+    std::vector<int16_t> v;
+    for (size_t i = 0; i < sizeof(ab) / sizeof(ab[0]); i++) {
+      v.push_back(ab[i][0]); v.push_back(ab[i][1]);
+      v.push_back(fast_atan2<int16_t, int16_t>(ab[i][0], ab[i][1])); }
+    dump("g8_fast_atan2_triples", "i16", v); }
+  { // full-scale / near-overflow input: amplitudes at 2^14 (IQSigGen's intended scale)
+    std::vector<Tone> t; Tone a = {90e3, 16384, 0.7}, b = {110e3, 16383, 2.0}; t.push_back(a); t.push_back(b);
+    std::vector<cs16> xl = siggen<int16_t>(Fs, 4096, 2, t);
+    dump("g8_iq_cs16_loud", "cs16", flat16(xl), "\"Fs\": 2400000, \"bufsize\": 4096, \"nbuf\": 2");
+    case_iqbb("g8_loud_iqbb127d8", xl, Fs, 100e3, 100e3, 50e3, 127, 8, 0.0, c4096, D_FM, false);
+    case_iqbb("g8_loud_iqbb127d8", xl, Fs, 100e3, 100e3, 50e3, 127, 8, 0.0, c4096, D_AM, false);
+    case_fir_cs16("g8_loud_fir127", xl, Fs, 127, 100e3, c4096, false); }
+}
+
+// ---------------------------------------------------------------------------------------------
+// timing of the reference CPU path (bench.py cpu_baseline kind "reference")
+// ---------------------------------------------------------------------------------------------
+static int bench(const std::string &chain, size_t nbuf) {
+  const double Fs = 2.4e6; const size_t N = 65536;
+  std::vector<cs16> x = siggen<int16_t>(Fs, N, 1, two_tone_i16());
+  std::vector<cf32> xf;
+  if (chain == "fir_cf32_sub8") xf = siggen<float>(Fs, N, 1, two_tone_f32());
+  std::vector<cs16> work(N);
+  size_t total_out = 0; long checksum = 0;
+  std::chrono::steady_clock::time_point t0, t1;
+
+#define RUN_I16(HEAD, TAILCAP, CT)                                                  \
+  { Feeder<cs16> src; src.configure(Fs, N); src.connect(&(HEAD), true);             \
+    Capture<CT> cap; cap.keep = false; (TAILCAP).connect(&cap, true);               \
+    for (size_t b = 0; b < 2; b++) { src.feed(&x[0], N); }                          \
+    t0 = std::chrono::steady_clock::now();                                          \
+    for (size_t b = 0; b < nbuf; b++) { src.feed(&x[0], N); }                       \
+    t1 = std::chrono::steady_clock::now(); total_out = cap.total; }
+
+  if (chain == "iqbb_fm") {
+    IQBaseBand<int16_t> bb(100e3, 100e3, 50e3, 127, 8); FMDemod<int16_t> fm; bb.connect(&fm, true);
+    RUN_I16(bb, fm, int16_t)
+  } else if (chain == "iqbb_usb") {
+    IQBaseBand<int16_t> bb(100e3, 100e3, 50e3, 127, 8); USBDemod<int16_t> d; bb.connect(&d, true);
+    RUN_I16(bb, d, int16_t)
+  } else if (chain == "fir127_fm") {
+    FIRLowPass<cs16> fir(127, 100e3); FMDemod<int16_t> fm; fir.connect(&fm, true);
+    RUN_I16(fir, fm, int16_t)
+  } else if (chain == "fir255_fm") {
+    FIRLowPass<cs16> fir(255, 100e3); FMDemod<int16_t> fm; fir.connect(&fm, true);
+    RUN_I16(fir, fm, int16_t)
+  } else if (chain == "fir_cf32_sub8") {
+    Feeder<cf32> src; src.configure(Fs, N);
+    FIRLowPass<cf32> fir(127, 100e3); SubSample<cf32> sub(size_t(8));
+    src.connect(&fir, true); fir.connect(&sub, true);
+    Capture<cf32> cap; cap.keep = false; sub.connect(&cap, true);
+    for (size_t b = 0; b < 2; b++) src.feed(&xf[0], N);
+    t0 = std::chrono::steady_clock::now();
+    for (size_t b = 0; b < nbuf; b++) src.feed(&xf[0], N);
+    t1 = std::chrono::steady_clock::now(); total_out = cap.total;
+  } else {
+    fprintf(stderr, "unknown chain %s\n", chain.c_str()); return 2;
+  }
+  double sec = std::chrono::duration<double>(t1 - t0).count();
+  printf("{\"chain\": \"%s\", \"buffers\": %zu, \"samples\": %zu, \"seconds\": %.6f, "
+         "\"msps\": %.4f, \"outputs\": %zu, \"threads\": 1, \"kind\": \"reference\"}\n",
+         chain.c_str(), nbuf, nbuf * N, sec, nbuf * N / sec / 1e6, total_out + (size_t)(checksum & 0));
+  return 0;
+}
+
+int main(int argc, char **argv) {
+  if (argc >= 3 && std::string(argv[1]) == "golden") {
+    g_out = argv[2];
+    g_manifest << "{\n";
+    golden();
+    g_manifest << "\n}\n";
+    std::string mp = g_out + "/manifest.json";
+    FILE *f = fopen(mp.c_str(), "w"); fputs(g_manifest.str().c_str(), f); fclose(f);
+    return 0;
+  }
+  if (argc >= 4 && std::string(argv[1]) == "bench") {
+    return bench(argv[2], (size_t)atol(argv[3]));
+  }
+  fprintf(stderr, "usage: ref_driver golden <outdir> | bench <chain> <nbuf>\n");
+  return 1;
+}

@@ -1,0 +1,258 @@
+"""Pins the CPU restatement (oracle/sdr_oracle.cc) to golden vectors cut from the compiled,
+unmodified reference (oracle/ref_driver.cc -> tests/golden/).  CPU only.
+
+Bars: bit-exact for every int16/int32 quantity and for double taps designed with the same libm;
+float paths bit-exact where the reference arithmetic is restated operation by operation.
+"""
+import numpy as np
+import pytest
+
+FS = 2.4e6
+
+
+def split(x, lens):
+    out, off = [], 0
+    for n in lens:
+        out.append(x[off:off + n])
+        off += n
+    assert off == len(x)
+    return out
+
+
+# ---- generators -------------------------------------------------------------------------------
+
+def test_iqsiggen_cs16(golden, orc):
+    g = orc.IQSigGen(FS, [(100e3, 8000, 0.0), (-300e3, 6000, 0.3)])
+    x = np.concatenate([g.next_cs16(4096) for _ in range(4)])
+    assert np.array_equal(x, golden.load("g1_iq_cs16"))
+    # SURVEY Appendix B literals
+    assert x[0].tolist() == [6866, 886] and x[3].tolist() == [1428, 174]
+    assert x[4095].tolist() == [-1428, -174] and x[4096].tolist() == [866, -2577]
+
+
+def test_iqsiggen_cf32(golden, orc):
+    g = orc.IQSigGen(FS, [(100e3, 0.5, 0.0), (-300e3, 0.3, 0.3)])
+    x = np.concatenate([g.next_cf32(4096) for _ in range(3)])
+    assert np.array_equal(x, golden.load("g1_iq_cf32"))
+
+
+def test_iqsiggen_single_tones(golden, orc):
+    g = orc.IQSigGen(FS, [(100e3, 8000, 0.0)])
+    assert np.array_equal(np.concatenate([g.next_cs16(4096) for _ in range(2)]),
+                          golden.load("g1_iq_cs16_tone_p100k"))
+    g = orc.IQSigGen(FS, [(-100e3, 8000, 0.0)])
+    assert np.array_equal(g.next_cs16(4096), golden.load("g1_iq_cs16_tone_m100k"))
+
+
+# ---- designers --------------------------------------------------------------------------------
+
+IQBB_CASES = ["g3_iqbb127d8", "g8_neg_o16_d1", "g8_o21_d3", "g8_o33_d5", "g8_o16_d4_even",
+              "g8_o255_d8", "g8_noshift_o21_d8", "g8_ofs_d300"]
+
+
+@pytest.mark.parametrize("case", IQBB_CASES)
+def test_iqbb_design(golden, orc, case):
+    m = golden.meta(case + "_taps")
+    taps = orc.iqbb_design(m["Ff"], m["width"], m["Fs"], m["order"])
+    assert np.array_equal(taps.ravel(), golden.load(case + "_taps"))
+    assert np.array_equal(orc.freqshift_lut_i16().ravel(), golden.load(case + "_lut"))
+    assert orc.freqshift_inc(m["Fc"], m["Fs"]) == m["lut_inc"]
+    assert orc.iqbb_decim(m["Fs"], m["sub"], m["oFs"]) == m["decim"]
+
+
+def test_iqbb_design_known_answers(golden, orc):
+    t = orc.iqbb_design(100e3, 50e3, FS, 127)
+    assert t[0].tolist() == [0, 0] and t[126].tolist() == [0, 0]
+    assert t[62].tolist() == [-345, 199] and t[63].tolist() == [-283, 283] and t[64].tolist() == [-200, 346]
+    assert t.sum(0).tolist() == [2, 1]
+    lut = orc.freqshift_lut_i16()
+    assert lut[0].tolist() == [65536, 0] and lut[1].tolist() == [65457, -3215]
+    assert lut[32].tolist() == [0, -65536] and lut[127].tolist() == [65457, 3215]
+    assert orc.freqshift_inc(100e3, FS) == 1365
+
+
+@pytest.mark.parametrize("N", [127, 255, 4097])
+def test_fir_lowpass_design(golden, orc, N):
+    a = orc.fir_lowpass_design(N, 100e3, FS)
+    assert np.array_equal(a, golden.load("g2_firlp_alpha%d" % N))
+    if N == 127:
+        assert a[0] == 3.8459023977995984e-20 and a[63] == 0.057890032145963485
+
+
+@pytest.mark.parametrize("N", [1024, 8192])
+def test_fftfilt_kernel_h(golden, orc, N):
+    h = orc.fftfilt_design_h(N, 50e3, 150e3, FS)
+    assert np.array_equal(h, golden.load("g7_fftfilt_h%d" % N))
+
+
+# ---- IQBaseBand<int16_t> ------------------------------------------------------------------------
+
+def run_iqbb(golden, orc, case, inp, suffix):
+    m = golden.meta(case + suffix)
+    tcase = case if (case + "_taps") in golden.manifest else "g3_iqbb127d8"
+    taps = golden.load(tcase + "_taps")
+    lut = golden.load(tcase + "_lut")
+    bb = orc.IQBaseBandI16(taps, lut, m["lut_inc"], m["negative"], m["decim"])
+    x = golden.load(inp)
+    chunks = split(x, m["in_lens"])
+    return m, [bb.process(c) for c in chunks]
+
+
+@pytest.mark.parametrize("case,inp", [
+    ("g3_iqbb127d8", "g1_iq_cs16"), ("g8_neg_o16_d1", "g1_iq_cs16_tone_m100k"),
+    ("g8_o21_d3", "g1_iq_cs16"), ("g8_o33_d5", "g1_iq_cs16"), ("g8_o16_d4_even", "g1_iq_cs16"),
+    ("g8_o255_d8", "g1_iq_cs16"), ("g8_noshift_o21_d8", "g1_iq_cs16"), ("g8_ofs_d300", "g1_iq_cs16"),
+    ("g8_irregular", "g1_iq_cs16")])
+def test_iqbb_i16(golden, orc, case, inp):
+    m, outs = run_iqbb(golden, orc, case, inp, "_out")
+    assert [len(o) for o in outs] == m["out_lens"]
+    assert np.array_equal(np.concatenate(outs), golden.load(case + "_out"))
+
+
+def test_iqbb_i16_known_answers(golden, orc):
+    m, outs = run_iqbb(golden, orc, "g3_iqbb127d8", "g1_iq_cs16", "_out")
+    assert [len(o) for o in outs] == [511, 512, 512, 512]
+    y0, y1 = outs[0].astype(np.int64), outs[1].astype(np.int64)
+    assert y0[15].tolist() == [121, -3978] and y0[510].tolist() == [1084, -3829]
+    i = np.arange(len(y0))
+    assert int((y0[:, 0] * (i + 1) + y0[:, 1] * (i + 7)).sum()) == -418559318
+    i = np.arange(len(y1))
+    assert int((y1[:, 0] * (i + 1) + y1[:, 1] * (i + 7)).sum()) == -246805328
+    _, o = run_iqbb(golden, orc, "g8_neg_o16_d1", "g1_iq_cs16_tone_m100k", "_out")
+    assert o[0][100].tolist() == [-5466, -5837] and o[0][101].tolist() == [-5560, -5747]
+
+
+@pytest.mark.parametrize("case,inp,demod", [
+    ("g4_iqbb127d8", "g1_iq_cs16", "fm"), ("g4_iqbb127d8", "g1_iq_cs16", "am"),
+    ("g4_iqbb127d8", "g1_iq_cs16", "usb"), ("g8_o33_d5", "g1_iq_cs16", "fm"),
+    ("g8_irregular", "g1_iq_cs16", "fm"), ("g8_irregular", "g1_iq_cs16", "usb"),
+    ("g8_loud_iqbb127d8", "g8_iq_cs16_loud", "fm"), ("g8_loud_iqbb127d8", "g8_iq_cs16_loud", "am")])
+def test_iqbb_demod_chain(golden, orc, case, inp, demod):
+    m, outs = run_iqbb(golden, orc, case, inp, "_" + demod)
+    fm = orc.FMDemodI16()
+    res = []
+    for y in outs:
+        if demod == "fm":
+            if len(y):               # FMDemod::process returns without send on an empty buffer
+                res.append(fm.process(y, inplace=True))
+        elif demod == "am":
+            res.append(orc.am_i16(y))
+        else:
+            res.append(orc.usb_i16(y))
+    assert [len(r) for r in res] == m["out_lens"]
+    assert np.array_equal(np.concatenate(res), golden.load(case + "_" + demod))
+
+
+def test_fm_known_answers(golden, orc):
+    f = golden.load("g4_iqbb127d8_fm").astype(np.int64)
+    b0, b1 = f[:511], f[511:1023]
+    assert b0[0] == 0 and b0[16] == 10 and b0[17] == 8 and b0[510] == -13
+    assert int((b0[1:] * (np.arange(1, 511) + 1)).sum()) == 97546
+    assert b1[0] == 1093 and b1[1] == 45 and int((b1[1:] * (np.arange(1, 512) + 1)).sum()) == 143983
+
+
+# ---- FIRFilter ----------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("case,order,inp", [
+    ("g5_fir127", 127, "g1_iq_cs16"), ("g5_fir255", 255, "g1_iq_cs16"),
+    ("g8_irregular_fir127", 127, "g1_iq_cs16"), ("g8_loud_fir127", 127, "g8_iq_cs16_loud")])
+def test_fir_cs16(golden, orc, case, order, inp):
+    m = golden.meta(case + "_out")
+    fir = orc.FIR(golden.load("g2_firlp_alpha%d" % order))
+    outs = [fir.process_cs16(c) for c in split(golden.load(inp), m["in_lens"])]
+    assert np.array_equal(np.concatenate(outs), golden.load(case + "_out"))
+
+
+@pytest.mark.parametrize("case,order", [("g5_fir127", 127), ("g5_fir255", 255), ("g8_irregular_fir127", 127)])
+def test_fir_cs16_fm_inplace(golden, orc, case, order):
+    m = golden.meta(case + "_fm")
+    fir = orc.FIR(golden.load("g2_firlp_alpha%d" % order))
+    fm = orc.FMDemodI16()
+    res = []
+    for c in split(golden.load("g1_iq_cs16"), m["in_lens"]):
+        y = fir.process_cs16(c)
+        if len(y):
+            res.append(fm.process(y, inplace=True))
+    assert [len(r) for r in res] == m["out_lens"]
+    assert np.array_equal(np.concatenate(res), golden.load(case + "_fm"))
+
+
+def test_fir_tone_known_answer(golden, orc):
+    x = golden.load("g1_iq_cs16_tone_p100k")[4096:]
+    fir = orc.FIR(golden.load("g2_firlp_alpha127"))
+    y = fir.process_cs16(x)
+    assert np.array_equal(y, golden.load("g5_fir127_tone_buf2_out"))
+    assert y[200].tolist() == [-2207, 1646] and y[201].tolist() == [-2566, 1008]
+    f = orc.FMDemodI16().process(y)
+    assert np.array_equal(f, golden.load("g5_fir127_tone_buf2_fm")) and f[200] == 543
+
+
+@pytest.mark.parametrize("order", [127, 4097])
+def test_fir_cf32(golden, orc, order):
+    fir = orc.FIR(golden.load("g2_firlp_alpha%d" % order))
+    x = golden.load("g1_iq_cf32")
+    y = np.concatenate([fir.process_cf32(x[i * 4096:(i + 1) * 4096]) for i in range(3)])
+    assert np.array_equal(y, golden.load("g6_fir%d_cf32_out" % order))
+
+
+# ---- SubSample / standalone demods --------------------------------------------------------------
+
+@pytest.mark.parametrize("n", [8, 3])
+def test_subsample(golden, orc, n):
+    s = orc.SubSample(n)
+    x = golden.load("g1_iq_cs16")
+    outs = [s.process_cs16(x[i * 4096:(i + 1) * 4096]) for i in range(4)]
+    assert [len(o) for o in outs] == golden.meta("g6_subsample_cs16_n%d" % n)["out_lens"]
+    assert np.array_equal(np.concatenate(outs), golden.load("g6_subsample_cs16_n%d" % n))
+    s = orc.SubSample(n)
+    xf = golden.load("g6_fir127_cf32_out")
+    outs = [s.process_cf32(xf[i * 4096:(i + 1) * 4096]) for i in range(3)]
+    assert [len(o) for o in outs] == golden.meta("g6_fir127_cf32_sub%d" % n)["out_lens"]
+    assert np.array_equal(np.concatenate(outs), golden.load("g6_fir127_cf32_sub%d" % n))
+
+
+def test_demods_raw(golden, orc):
+    x = golden.load("g1_iq_cs16")
+    assert np.array_equal(orc.am_i16(x), golden.load("g4_raw_am"))
+    assert np.array_equal(orc.usb_i16(x), golden.load("g4_raw_usb"))
+    fm = orc.FMDemodI16()
+    f = np.concatenate([fm.process(x[i * 4096:(i + 1) * 4096], inplace=False) for i in range(4)])
+    assert np.array_equal(f, golden.load("g4_raw_fm_masked0"))
+    xf = golden.load("g6_fir127_cf32_out")
+    assert np.array_equal(orc.am_f32(xf), golden.load("g6_fir127_cf32_am"))
+    assert np.array_equal(orc.usb_f32(xf), golden.load("g6_fir127_cf32_usb"))
+
+
+def test_fast_atan2(golden, orc):
+    t = golden.load("g8_fast_atan2_triples").reshape(-1, 3)
+    for a, b, r in t.tolist():
+        assert orc.fast_atan2_i16(a, b) == r
+    assert orc.fast_atan2_i16(1000, 3) == 8167 and orc.fast_atan2_i16(12345, -6789) == 11099
+
+
+# ---- FFT convolution: unpinned at the FFTW boundary; checked against its closed form ------------
+
+@pytest.mark.parametrize("N", [1024])
+def test_fftfilt_closed_form(golden, orc, N):
+    """y[n] = sum_k h[k] x[n-k] / (sqrt(2N) ||h||_2)  (SURVEY fact 7), float64 direct convolution."""
+    h = golden.load("g7_fftfilt_h%d" % N)
+    K = orc.fftfilt_design_K(h)
+    flt = orc.FFTFilter(K)
+    x = golden.load("g1_iq_cf32")[:4 * N]
+    y = np.concatenate([flt.process(x[i * N:(i + 1) * N]) for i in range(4)])
+    hc = h[:, 0].astype(np.float64) + 1j * h[:, 1]
+    xc = x[:, 0].astype(np.float64) + 1j * x[:, 1]
+    ref = np.convolve(xc, hc)[:4 * N] / (np.sqrt(2 * N) * np.sqrt((np.abs(hc) ** 2).sum()))
+    yc = y[:, 0].astype(np.float64) + 1j * y[:, 1]
+    assert np.abs(yc - ref).max() / np.abs(ref).max() < 1e-5
+
+
+def test_dft_helper(orc):
+    import ctypes as C
+    rng = np.random.default_rng(1)
+    n = 256
+    x = rng.standard_normal(2 * n)
+    o = np.zeros(2 * n)
+    orc.lib().orc_dft_f64(n, -1, x.ctypes.data_as(C.POINTER(C.c_double)), o.ctypes.data_as(C.POINTER(C.c_double)))
+    ref = np.fft.fft(x[0::2] + 1j * x[1::2])
+    assert np.abs((o[0::2] + 1j * o[1::2]) - ref).max() < 1e-10
