@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X-native libsdr hot path.
+
+A "step" = one pass of the hot path over one batch of synthetic input already resident in HBM:
+per GPU `--channels` (default 1024) independent complex<int16> IQ channels x `--samples` (65536)
+samples through IQBaseBand<int16>(127-tap Q14 FIR -> LUT shift -> /8) -> FMDemod, i.e. the
+north-star chain of BASELINE.json on the per-GPU shard of its config 5 (8192 channels over 8 GPUs).
+Channels are independent, so ranks shard them with no data-path collective (weak scaling);
+taps/LUT are designed on rank 0 and broadcast over RCCL at config time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload iqbb_fm|iqbb_usb|fir255_fm|fbb_f32|fftconv]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  "roofline":     achieved algorithmic HBM bytes/s of the dominant kernel vs 8 TB/s, from HIP events
+                  recorded on the stream the kernel runs on;
+  "cpu_baseline": the reference CPU path (oracle/_ref/ref_driver, the unmodified reference compiled
+                  here) or the oracle port, timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+FS = 2.4e6
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--channels", type=int, default=1024, help="channels per GPU")
+    p.add_argument("--samples", type=int, default=65536, help="samples per channel per step")
+    p.add_argument("--workload", default="iqbb_fm")
+    p.add_argument("--batches", type=int, default=3, help="distinct input batches rotated through (defeats the 256 MiB L3)")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    return p.parse_args()
+
+
+def synth_cs16(torch, C, N, dev, seed, chan0=0):
+    """Two tones per channel + small integer noise (SURVEY §8d config 3/5 recipe), generated on the GPU."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    n = torch.arange(N, device=dev, dtype=torch.float64) / FS
+    out = torch.empty((C, N, 2), dtype=torch.int16, device=dev)
+    step = 64
+    for c0 in range(0, C, step):
+        c = torch.arange(c0, min(C, c0 + step), device=dev, dtype=torch.float64) + chan0
+        f1 = (50e3 + 97.0 * c)[:, None]
+        f2 = (-200e3 - 53.0 * c)[:, None]
+        ph = (0.1 * c)[:, None]
+        a1 = 2 * torch.pi * f1 * n[None, :] + ph
+        a2 = 2 * torch.pi * f2 * n[None, :] + ph
+        re = torch.trunc(3500.0 * torch.cos(a1)) + torch.trunc(2500.0 * torch.cos(a2))
+        im = torch.trunc(3500.0 * torch.sin(a1)) + torch.trunc(2500.0 * torch.sin(a2))
+        noise = torch.randint(-64, 65, (re.shape[0], N, 2), device=dev, generator=g, dtype=torch.int32)
+        out[c0:c0 + re.shape[0], :, 0] = (re.to(torch.int32) + noise[..., 0]).to(torch.int16)
+        out[c0:c0 + re.shape[0], :, 1] = (im.to(torch.int32) + noise[..., 1]).to(torch.int16)
+    return out
+
+
+def cpu_baseline(workload, target_s):
+    """Reference CPU path on this box: the compiled, unmodified reference if oracle/_ref travelled here,
+    else the oracle port. One thread = the reference's real execution model (one Queue worker)."""
+    chain = {"iqbb_fm": "iqbb_fm", "iqbb_usb": "iqbb_usb", "fir255_fm": "fir255_fm", "fir127_fm": "fir127_fm",
+             "fbb_f32": "fir_cf32_sub8"}.get(workload)
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    cores_avail = os.cpu_count()
+    if chain and os.path.exists(ref):
+        try:
+            probe = json.loads(subprocess.run([ref, "bench", chain, "8"], capture_output=True, text=True, timeout=120).stdout)
+            nbuf = max(8, int(target_s * probe["msps"] * 1e6 / 65536))
+            r = json.loads(subprocess.run([ref, "bench", chain, str(nbuf)], capture_output=True, text=True, timeout=600).stdout)
+            return {"value": round(r["msps"], 4), "unit": "Msamples/s", "cores": 1, "kind": "reference",
+                    "sample": "%d buffers x 65536 cs16 samples, 1 channel, chain %s (reference nodes compiled -O3, "
+                              "%.1f s)" % (nbuf, chain, r["seconds"]), "host_cores_available": cores_avail}
+        except Exception as e:   # fall through to the port
+            sys.stderr.write("cpu_baseline: reference binary failed (%s), using the port\n" % e)
+    if workload not in ("iqbb_fm",):
+        return None
+    from oracle import pyoracle as orc   # bench.py's cpu_baseline leg may use the oracle
+    taps = orc.iqbb_design(100e3, 50e3, FS, 127)
+    lut = orc.freqshift_lut_i16()
+    x = orc.IQSigGen(FS, [(100e3, 8000, 0.0), (-300e3, 6000, 0.3)]).next_cs16(65536)
+    sec = orc.bench_iqbb_fm(taps, lut, 1365, False, 8, x, 8)
+    nbuf = max(8, int(target_s / (sec / 8)))
+    sec = orc.bench_iqbb_fm(taps, lut, 1365, False, 8, x, nbuf)
+    return {"value": round(nbuf * 65536 / sec / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": "%d buffers x 65536 cs16 samples, 1 channel, IQBaseBand(127,/8)->FM oracle port (%.1f s)" % (nbuf, sec),
+            "host_cores_available": cores_avail}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    import libsdr_amd as sa
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+    C, N, W, K = a.channels, a.samples, a.warmup, a.steps
+
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        ctx = sa.Context(local, stream=stream.cuda_stream)
+
+        # ---- config(): design on rank 0, broadcast over RCCL (KBs; outside the timed region) ----
+        order, D = 127, 8
+        wl = a.workload
+        if wl in ("iqbb_fm", "iqbb_usb"):
+            taps = torch.from_numpy(sa.design_iqbb_taps(100e3, 50e3, FS, order)).to(dev)
+            lut = torch.from_numpy(sa.design_freqshift_lut_i16()).to(dev)
+            if world > 1:
+                dist.broadcast(taps, 0); dist.broadcast(lut, 0)
+            node = sa.IQBaseBandI16(ctx, taps.cpu().numpy(), lut.cpu().numpy(), sa.design_freqshift_inc(100e3, FS), False, D,
+                                    channels=C, max_in=N, epilogue=sa.EPI_FM if wl == "iqbb_fm" else sa.EPI_USB)
+            in_bytes, alg_bytes = 4.0, 4.0 + 2.0 / D
+            n_out = node.out_count(N) + 1
+            outs = torch.zeros((C, n_out), dtype=torch.int16, device=dev)
+            ins = [synth_cs16(torch, C, N, dev, 1234 + b, chan0=rank * C) for b in range(a.batches)]
+            run = lambda b: node.process_dev(ins[b].data_ptr(), N, N, outs.data_ptr(), n_out)
+            dtype, kernel = "i16", "iqbb_i16_kernel"
+            desc = "IQBaseBand<int16>(127-tap Q14 FIR, LUT shift 100 kHz, /8) -> %s" % ("FMDemod" if wl == "iqbb_fm" else "USBDemod")
+        elif wl in ("fir255_fm", "fir127_fm"):
+            order = 255 if wl == "fir255_fm" else 127
+            alpha = torch.from_numpy(sa.design_fir_lowpass(order, 100e3, FS)).to(dev)
+            if world > 1:
+                dist.broadcast(alpha, 0)
+            node = sa.FIR(ctx, sa.FIR_CS16_EXACT, alpha.cpu().numpy(), channels=C, max_in=N, epilogue=sa.EPI_FM)
+            in_bytes, alg_bytes = 4.0, 6.0
+            outs = torch.zeros((C, N), dtype=torch.int16, device=dev)
+            ins = [synth_cs16(torch, C, N, dev, 1234 + b, chan0=rank * C) for b in range(a.batches)]
+            run = lambda b: node.process_dev(ins[b].data_ptr(), N, N, outs.data_ptr(), N)
+            dtype, kernel = "f64", "fir_cs16_exact_kernel"
+            desc = "FIRLowPass<complex<int16>>(%d taps, exact per-tap truncation) -> FMDemod" % order
+        elif wl == "fbb_f32":
+            alpha = sa.design_fir_lowpass(127, 100e3, FS)
+            node = sa.FloatBaseBand(ctx, 100e3, FS, alpha, 8, channels=C, max_in=N)
+            in_bytes, alg_bytes = 8.0, 9.0
+            n_out = N // 8 + 1
+            outs = torch.zeros((C, n_out, 2), dtype=torch.float32, device=dev)
+            ins = [torch.randn((C, N, 2), dtype=torch.float32, device=dev) * 0.3 for b in range(a.batches)]
+            run = lambda b: node.process_dev(ins[b].data_ptr(), N, N, outs.data_ptr(), n_out)
+            dtype, kernel = "f32", "fir_cf32_kernel"
+            desc = "float baseband: shift 100 kHz -> FIRLowPass<cf32>(127) -> /8"
+        elif wl == "fftconv":
+            alpha = sa.design_fir_lowpass(4097, 100e3, FS)
+            import numpy as np
+            tapsf = np.stack([alpha, np.zeros_like(alpha)], 1).astype(np.float32)
+            node = sa.FFTConv(ctx, sa.FFTCONV_OLS, 16384, tapsf, channels=C, max_in=N)
+            in_bytes, alg_bytes = 8.0, 16.0
+            outs = torch.zeros((C, N, 2), dtype=torch.float32, device=dev)
+            ins = [torch.randn((C, N, 2), dtype=torch.float32, device=dev) * 0.3 for b in range(a.batches)]
+            run = lambda b: node.process_dev(ins[b].data_ptr(), N, N, outs.data_ptr(), N)
+            dtype, kernel = "f32", "fftconv_kernel"
+            desc = "FFT convolution, overlap-save L=16384, 4097 taps (hop 12288)"
+        else:
+            raise SystemExit("unknown workload " + wl)
+
+        def barrier():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for i in range(W):
+            run(i % a.batches)
+        barrier()
+        timer = sa.Timer(ctx)
+        t0 = time.perf_counter()
+        timer.start()
+        for i in range(K):
+            run(i % a.batches)
+        timer.stop()
+        barrier()
+        wall = time.perf_counter() - t0
+        dev_ms = timer.elapsed_ms()
+
+    wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
+    wall = float(wall_t.item())
+
+    if rank == 0:
+        total_samples = float(C) * N * K * world
+        value = total_samples / wall / 1e6
+        per_launch_s = dev_ms / 1e3 / K
+        achieved = C * N * alg_bytes / per_launch_s / 1e9
+        res = {
+            "metric": "Msamples/s through baseband->FIR->demod chain",
+            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(wall / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": desc, "channels_per_gpu": C, "samples_per_channel_per_step": N,
+                       "global_channels": C * world, "input": "complex<int16>" if in_bytes == 4 else "complex<float>",
+                       "parallelism": "channel-sharded x%d, no data-path collective" % world},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": kernel,
+                         "algorithmic_bytes_per_sample": alg_bytes, "avg_launch_ms": round(per_launch_s * 1e3, 4),
+                         "hbm_read_frac": round(C * N * in_bytes / per_launch_s / 1e9 / HBM_PEAK_GBS, 5),
+                         "per_gpu_msamples_s": round(C * N / per_launch_s / 1e6, 2)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            cb = cpu_baseline(wl, a.cpu_seconds)
+            if cb:
+                res["cpu_baseline"] = cb
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,151 @@
+// design.hh — host-side designers of the taps / LUT / FFT kernels the GPU nodes take as inputs.
+//
+// The kernels never design anything on the device: a 1-ulp libm difference may flip a truncation
+// (SURVEY §7 "Tap / LUT / kernel provenance"), so the numbers are produced here, on the host, with
+// the same operation order as the reference designers, and pinned against golden vectors
+// (tests/test_design.py).  Reference formulas restated (file:line):
+//   IQBaseBand::_update_filter_kernel   src/baseband.hh:239-262  (Ff, Fs, width held as int32: :266-272)
+//   FreqShiftBase ctor / _update_lut_incr   src/freqshift.hh:26-36, :78-87
+//   FIRLowPassCoeffs::coeffs            src/firfilter.hh:16-32
+//   sinc_flt_kernel / FilterSource::_updateFilter   src/filternode.hh:18-28, :186-203
+// The reference's HighPass/BandPass/BandStop designers are broken and are
+// deliberately not reproduced.
+#ifndef SDR_GPU_DESIGN_HH
+#define SDR_GPU_DESIGN_HH
+
+#include <cmath>
+#include <complex>
+#include <cstdint>
+#include <cstddef>
+#include <vector>
+
+namespace sdr {
+namespace gpu {
+namespace design {
+
+static const size_t kLutSize = 128;
+
+/** Q14 complex band-pass taps of IQBaseBand<int16_t>: order x (re, im). */
+inline void iqbbTaps(double filterFreq, double width, double sampleRate, size_t order, int32_t *taps) {
+  // the reference node keeps these three in int32_t members
+  const int32_t Ff = int32_t(filterFreq), Fs = int32_t(sampleRate), W = int32_t(width);
+  std::vector< std::complex<double> > c(order);
+  const double w = (M_PI * W) / (Fs);
+  const double mid = double(order) / 2.;
+  double l1 = 0;
+  for (size_t i = 0; i < order; i++) {
+    const double arg = w * (i - mid);
+    const double sinc = (order == 2 * i) ? 4 * (w / M_PI) : std::sin(arg) / arg;
+    const std::complex<double> mod = std::exp(std::complex<double>(0.0, (-2 * M_PI * Ff * i) / Fs));
+    const double win = (0.42 - 0.5 * cos((2 * M_PI * i) / order) + 0.08 * cos((4 * M_PI * i) / order));
+    c[i] = std::complex<double>(sinc * mod.real(), sinc * mod.imag());
+    c[i] = std::complex<double>(c[i].real() * win, c[i].imag() * win);
+    l1 += std::abs(c[i]);
+  }
+  const double q = double(1 << 14);
+  for (size_t i = 0; i < order; i++) {
+    taps[2 * i] = int32_t((q * c[i].real()) / l1);
+    taps[2 * i + 1] = int32_t((q * c[i].imag()) / l1);
+  }
+}
+
+/** Decimation of IQBaseBand: explicit, or floor(Fs/oFs) (at least 1) when an output rate is given. */
+inline size_t iqbbDecimation(double sampleRate, size_t subSample, double outRate) {
+  if (outRate > 0) {
+    size_t d = size_t(int32_t(sampleRate) / outRate);
+    return d < 1 ? 1 : d;
+  }
+  return subSample;
+}
+
+/** Rotation LUT of FreqShiftBase<int16_t>: 128 x (re, im) = trunc(2^16 exp(-2 pi i k/128)). */
+inline void freqShiftLutI16(int32_t *lut) {
+  for (size_t k = 0; k < kLutSize; k++) {
+    const std::complex<double> e = std::exp(std::complex<double>(0, -(2 * M_PI * k) / kLutSize));
+    const double s = double(1 << 16);
+    lut[2 * k] = int32_t(s * e.real());
+    lut[2 * k + 1] = int32_t(s * e.imag());
+  }
+}
+
+/** Phase increment per sample in 1/256 LUT steps. */
+inline uint32_t freqShiftIncrement(double shift, double sampleRate) {
+  return uint32_t(size_t((kLutSize * (1 << 8) * std::abs(shift)) / sampleRate));
+}
+
+/** Windowed-sinc low-pass, L1-normalised (FIRLowPass(order, Fc): Fl = 0, Fu = Fc). */
+inline void firLowPass(size_t order, double upperFreq, double sampleRate, double *alpha) {
+  const double w = 2 * M_PI * upperFreq / sampleRate;
+  const double mid = double(order) / 2;
+  double l1 = 0;
+  for (size_t i = 0; i < order; i++) {
+    const double arg = w * (i - mid);
+    double v = (order == 2 * i) ? 4 * w / M_PI : std::sin(arg) / arg;
+    v *= (0.42 - 0.5 * cos((2 * M_PI * i) / order) + 0.08 * cos((4 * M_PI * i) / order));
+    alpha[i] = v;
+    l1 += std::abs(v);
+  }
+  for (size_t i = 0; i < order; i++) alpha[i] /= l1;
+}
+
+/** Time-domain kernel of the FFT filter, N complex floats. The modulation phase is rounded to
+ * float before the exponential, as in the reference (a double phase is 3e-5 off). */
+inline void fftFilterKernel(int N, double fmin, double fmax, double sampleRate, float *h) {
+  const double lo = std::max(fmin, -sampleRate / 2), hi = std::min(fmax, sampleRate / 2);
+  const double bw = hi - lo, fc = lo + bw / 2;
+  const int c = N / 2;
+  for (int i = 0; i < N; i++) {
+    std::complex<float> v;
+    if (c == i) v = M_PI * (bw / sampleRate);
+    else v = std::sin(M_PI * (bw / sampleRate) * (i - c)) / (i - c);
+    v *= std::exp(std::complex<float>(0.0, (2 * M_PI * fc * i) / sampleRate));
+    v *= (0.42 - 0.5 * cos((2 * M_PI * i) / N) + 0.08 * cos((4 * M_PI * i) / N));
+    h[2 * i] = v.real();
+    h[2 * i + 1] = v.imag();
+  }
+}
+
+/** In-place iterative radix-2 DFT in double (host only; n a power of two; sign -1 = forward). */
+inline void dft(std::vector< std::complex<double> > &a, int sign) {
+  const size_t n = a.size();
+  for (size_t i = 1, j = 0; i < n; i++) {
+    size_t bit = n >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) std::swap(a[i], a[j]);
+  }
+  for (size_t len = 2; len <= n; len <<= 1) {
+    for (size_t k = 0; k < len / 2; k++) {
+      const double ang = sign * 2.0 * M_PI * double(k) / double(len);
+      const std::complex<double> w(std::cos(ang), std::sin(ang));
+      for (size_t s = 0; s < n; s += len) {
+        const std::complex<double> u = a[s + k], t = w * a[s + k + len / 2];
+        a[s + k] = u + t;
+        a[s + k + len / 2] = u - t;
+      }
+    }
+  }
+}
+
+/** Spectrum the FilterSource multiplies with: K = DFT_2N([h, 0]) / ||K||_2, 2N complex floats.
+ * The reference computes this DFT with FFTW3f (un-vendored): any correct DFT is within float
+ * rounding of it. */
+inline void fftFilterSpectrum(int N, const float *h, float *K) {
+  std::vector< std::complex<double> > a(2 * size_t(N));
+  for (int i = 0; i < N; i++) a[i] = std::complex<double>(h[2 * i], h[2 * i + 1]);
+  dft(a, -1);
+  double e = 0;
+  for (size_t i = 0; i < a.size(); i++) {
+    K[2 * i] = float(a[i].real());
+    K[2 * i + 1] = float(a[i].imag());
+    e += K[2 * i] * K[2 * i] + K[2 * i + 1] * K[2 * i + 1];
+  }
+  const float d = float(std::sqrt(e));
+  for (size_t i = 0; i < 2 * a.size(); i++) K[i] /= d;
+}
+
+}  // namespace design
+}  // namespace gpu
+}  // namespace sdr
+
+#endif

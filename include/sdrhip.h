@@ -1,0 +1,218 @@
+/* sdrhip.h — C ABI of the MI355X-native libsdr hot path (libsdrhip.so).
+ *
+ * The reference (hmatuschek/libsdr) has no FFI: its hot path sits behind the C++ virtual node
+ * interface sdr::Sink<T>::config()/process() + sdr::Source::send() (reference src/node.hh:174-258).
+ * This header is what a binding for that interface calls; include/sdr/gpu/ *.hh holds the
+ * header-only C++ nodes (same class names, same config/ownership/allow_overwrite rules) that sit
+ * on top of it, and INTEGRATION.md shows how they drop into an existing libsdr graph.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types. Every function returns an int:
+ *     0 = SDRHIP_OK, negative = SDRHIP_E_*. Nothing throws. sdrhip_last_error() gives the text.
+ *   - A context owns one HIP stream (its own, or one adopted from the caller); all handles created
+ *     from it enqueue on that stream and are single-threaded, like a libsdr node (one Queue
+ *     worker calls process(), reference src/queue.cc:95-106).
+ *   - Complex samples are interleaved (re, im): cs16 = 2 x int16 (4 B), cf32 = 2 x float (8 B).
+ *   - Batched ("channel bank") layout is channel-major: channel c starts at base + c*stride
+ *     samples; every channel receives the same number of samples per call, because buffer
+ *     boundaries are part of the numerical contract (FMDemod skips index 0 of every buffer,
+ *     reference src/demod.hh:245; IQBaseBand's first window is D+1 long, src/baseband.hh:200).
+ *   - *_process()     : host pointers in/out (H2D + kernel + D2H, synchronous on return).
+ *     *_process_dev() : device pointers, asynchronous on the context stream.
+ *   - Taps / LUT / FFT kernels are INPUTS, designed on the host (include/sdr/gpu/design.hh
+ *     restates the reference designers); a 1-ulp libm difference must not change results.
+ *   - There is no CPU fallback: without a HIP device every create() fails with SDRHIP_E_NODEVICE.
+ */
+#ifndef SDRHIP_H
+#define SDRHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDRHIP_VERSION 100 /* 0.1.0 */
+
+enum {
+  SDRHIP_OK = 0,
+  SDRHIP_E_INVALID = -1,     /* bad argument */
+  SDRHIP_E_NODEVICE = -2,    /* no HIP device / device index out of range */
+  SDRHIP_E_HIP = -3,         /* a HIP runtime call failed (text in sdrhip_last_error) */
+  SDRHIP_E_NOMEM = -4,       /* device or host allocation failed */
+  SDRHIP_E_UNSUPPORTED = -5, /* parameter outside what the kernels implement */
+  SDRHIP_E_SIZE = -6         /* buffer larger than the plan's max_in / stride too small */
+};
+
+/* demodulator fused behind a filter node (reference src/demod.hh) */
+enum {
+  SDRHIP_EPI_NONE = 0, /* complex output, same sample type as the input */
+  SDRHIP_EPI_FM = 1,   /* FMDemod<int16_t>   (src/demod.hh:242-254, src/math.hh:31-40), in-place
+                          convention: out[0] of every call = in[0].real() */
+  SDRHIP_EPI_AM = 2,   /* AMDemod<Scalar>    (src/demod.hh:73-76) */
+  SDRHIP_EPI_USB = 3   /* USBDemod<Scalar>   (src/demod.hh:156-161) */
+};
+
+typedef struct sdrhip_ctx sdrhip_ctx;
+typedef struct sdrhip_timer sdrhip_timer;
+typedef struct sdrhip_iqbb_i16 sdrhip_iqbb_i16;
+typedef struct sdrhip_fir sdrhip_fir;
+typedef struct sdrhip_demod sdrhip_demod;
+typedef struct sdrhip_subsample sdrhip_subsample;
+typedef struct sdrhip_fftconv sdrhip_fftconv;
+typedef struct sdrhip_fbb_f32 sdrhip_fbb_f32;
+
+/* ---- library / context ------------------------------------------------------------------- */
+int sdrhip_version(void);
+const char *sdrhip_strerror(int code);
+/* text of the last failure on this thread (ctx may be NULL for create-time failures) */
+const char *sdrhip_last_error(void);
+int sdrhip_device_count(int *count);
+
+/* stream: a hipStream_t to adopt (e.g. torch.cuda.current_stream().cuda_stream) or NULL to create
+ * a private non-blocking stream. */
+int sdrhip_ctx_create(int device, void *stream, sdrhip_ctx **out);
+int sdrhip_ctx_destroy(sdrhip_ctx *ctx);
+int sdrhip_ctx_synchronize(sdrhip_ctx *ctx);
+int sdrhip_ctx_device_name(sdrhip_ctx *ctx, char *buf, size_t len);
+
+/* device memory helpers (tests and the C++ nodes; bench.py hands over torch tensors instead) */
+int sdrhip_malloc(sdrhip_ctx *ctx, size_t bytes, void **dptr);
+int sdrhip_free(sdrhip_ctx *ctx, void *dptr);
+int sdrhip_memcpy_h2d(sdrhip_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes); /* sync */
+int sdrhip_memcpy_d2h(sdrhip_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes); /* sync */
+int sdrhip_memset(sdrhip_ctx *ctx, void *dst_dev, int value, size_t bytes);                /* async */
+
+/* HIP-event timer on the context stream (bench.py's roofline leg) */
+int sdrhip_timer_create(sdrhip_ctx *ctx, sdrhip_timer **out);
+int sdrhip_timer_start(sdrhip_timer *t);
+int sdrhip_timer_stop(sdrhip_timer *t);
+int sdrhip_timer_elapsed_ms(sdrhip_timer *t, float *ms); /* synchronises on the stop event */
+int sdrhip_timer_destroy(sdrhip_timer *t);
+
+/* ---- host-side designers (no device work; same code as include/sdr/gpu/design.hh) ----------- */
+/* IQBaseBand::_update_filter_kernel (reference src/baseband.hh:239-262): order x (re,im) Q14 */
+int sdrhip_design_iqbb_taps(double filter_freq, double width, double sample_rate, int order, int32_t *taps);
+/* IQBaseBand::_reconfigure (src/baseband.hh:159-162): explicit D, or floor(Fs/out_rate) >= 1 */
+int sdrhip_design_iqbb_decim(double sample_rate, int sub_sample, double out_rate, int *decim);
+/* FreqShiftBase<int16_t> ctor (src/freqshift.hh:31-35): 128 x (re,im) */
+int sdrhip_design_freqshift_lut_i16(int32_t *lut);
+/* FreqShiftBase::_update_lut_incr (src/freqshift.hh:78-87) */
+int sdrhip_design_freqshift_inc(double shift, double sample_rate, uint32_t *inc);
+/* FIRLowPassCoeffs::coeffs (src/firfilter.hh:16-32) */
+int sdrhip_design_fir_lowpass(int order, double upper_freq, double sample_rate, double *alpha);
+/* sinc_flt_kernel<float> (src/filternode.hh:18-28,186-196): N x (re,im) float */
+int sdrhip_design_fftfilt_kernel(int n, double fmin, double fmax, double sample_rate, float *h);
+/* FilterSource::_updateFilter (src/filternode.hh:197-202): 2N x (re,im) float spectrum */
+int sdrhip_design_fftfilt_spectrum(int n, const float *h, float *spectrum);
+
+/* ---- K1: IQBaseBand<int16_t> (+ fused demodulator) ---------------------------------------- */
+/* Replaces IQBaseBand<int16_t>::_process/_filter_ring (reference src/baseband.hh:198-236) and
+ * FreqShiftBase<int16_t>::applyFrequencyShift (src/freqshift.hh:58-74), optionally followed by
+ * FMDemod/AMDemod/USBDemod<int16_t> run in place on its output (src/demod.hh).
+ *   taps     order x (re,im) int32, Q14, |component| <= 32767  (src/baseband.hh:239-262)
+ *   lut      128 x (re,im) int32                               (src/freqshift.hh:31-35)
+ *   lut_inc  phase increment in 1/256 LUT steps, 0 = no shift  (src/freqshift.hh:78-87)
+ *   negative 1 if the frequency shift is negative              (src/freqshift.hh:65)
+ *   decim    box-average decimation D >= 1                     (src/baseband.hh:212-219)
+ * Output per channel and call: sdrhip_iqbb_i16_out_count() samples — cs16 for EPI_NONE, int16
+ * otherwise. State (FIR history, decimator phase and partial sum, LUT phase, FM last angle)
+ * persists across calls exactly as the reference node's members do. */
+int sdrhip_iqbb_i16_create(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32_t *lut,
+                           uint32_t lut_inc, int negative, int decim, int channels, size_t max_in,
+                           int epilogue, sdrhip_iqbb_i16 **out);
+/* outputs the next call of n_in samples will produce (does not advance the state) */
+int sdrhip_iqbb_i16_out_count(sdrhip_iqbb_i16 *h, size_t n_in, size_t *n_out);
+/* in: channels x n_in cs16 (row stride in_stride samples); out: channels rows of out_stride
+ * elements. Strides are in elements of the respective type; 0 means "tightly packed". */
+int sdrhip_iqbb_i16_process(sdrhip_iqbb_i16 *h, const int16_t *in_host, size_t n_in, size_t in_stride,
+                            void *out_host, size_t out_stride, size_t *n_out);
+int sdrhip_iqbb_i16_process_dev(sdrhip_iqbb_i16 *h, const int16_t *in_dev, size_t n_in, size_t in_stride,
+                                void *out_dev, size_t out_stride, size_t *n_out);
+/* keep_history = 1: what IQBaseBand::_reconfigure does (counters and phases reset, FIR ring kept,
+ * src/baseband.hh:175-177); 0: a freshly constructed node (ring zeroed, :41-43). */
+int sdrhip_iqbb_i16_reset(sdrhip_iqbb_i16 *h, int keep_history);
+int sdrhip_iqbb_i16_destroy(sdrhip_iqbb_i16 *h);
+
+/* ---- K2/K3: FIRFilter<complex<int16_t>> (exact) and FIRFilter<complex<float>> ------------- */
+enum {
+  SDRHIP_FIR_CS16_EXACT = 0, /* fp64, one truncation per tap, taps walked in order: bit-exact
+                                (reference src/firfilter.hh:237-243, src/operators.hh:24-26) */
+  SDRHIP_FIR_CF32 = 1        /* complex<float>; tolerance path (<= 1e-5 rel), may reassociate */
+};
+/* alpha: `order` doubles (src/firfilter.hh:16-32). decim: SubSample<Scalar>(decim) fused behind
+ * the filter (src/subsample.hh:92-101), 1 = none. epilogue as above (FM only for CS16). */
+int sdrhip_fir_create(sdrhip_ctx *ctx, int kind, const double *alpha, int order, int decim, int channels,
+                      size_t max_in, int epilogue, sdrhip_fir **out);
+int sdrhip_fir_out_count(sdrhip_fir *h, size_t n_in, size_t *n_out);
+int sdrhip_fir_process(sdrhip_fir *h, const void *in_host, size_t n_in, size_t in_stride, void *out_host,
+                       size_t out_stride, size_t *n_out);
+int sdrhip_fir_process_dev(sdrhip_fir *h, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev,
+                           size_t out_stride, size_t *n_out);
+int sdrhip_fir_reset(sdrhip_fir *h); /* ring zeroed, as FIRFilter::config does (:193-195) */
+int sdrhip_fir_destroy(sdrhip_fir *h);
+
+/* ---- K4/K5: stand-alone demodulators ------------------------------------------------------ */
+enum { SDRHIP_T_CS16 = 0, SDRHIP_T_CF32 = 1 };
+/* kind = SDRHIP_EPI_FM|AM|USB, dtype = SDRHIP_T_*; FM exists for cs16 only (the reference's
+ * fast_atan2 has no float form, src/math.hh:9-40). inplace_fm0: 1 -> out[0] = in[0].real() per call
+ * (in-place chain), 0 -> out[0] left untouched (the reference leaves it uninitialised). */
+int sdrhip_demod_create(sdrhip_ctx *ctx, int kind, int dtype, int channels, size_t max_in, int inplace_fm0,
+                        sdrhip_demod **out);
+int sdrhip_demod_process(sdrhip_demod *h, const void *in_host, size_t n, size_t in_stride, void *out_host,
+                         size_t out_stride);
+int sdrhip_demod_process_dev(sdrhip_demod *h, const void *in_dev, size_t n, size_t in_stride, void *out_dev,
+                             size_t out_stride);
+int sdrhip_demod_reset(sdrhip_demod *h);
+int sdrhip_demod_destroy(sdrhip_demod *h);
+
+/* ---- K6: SubSample<complex<int16_t>|complex<float>> (src/subsample.hh:92-101) ------------- */
+int sdrhip_subsample_create(sdrhip_ctx *ctx, int dtype, size_t n, int channels, size_t max_in,
+                            sdrhip_subsample **out);
+int sdrhip_subsample_out_count(sdrhip_subsample *h, size_t n_in, size_t *n_out);
+int sdrhip_subsample_process(sdrhip_subsample *h, const void *in_host, size_t n_in, size_t in_stride,
+                             void *out_host, size_t out_stride, size_t *n_out);
+int sdrhip_subsample_process_dev(sdrhip_subsample *h, const void *in_dev, size_t n_in, size_t in_stride,
+                                 void *out_dev, size_t out_stride, size_t *n_out);
+int sdrhip_subsample_reset(sdrhip_subsample *h);
+int sdrhip_subsample_destroy(sdrhip_subsample *h);
+
+/* ---- K7: FFT convolution (FilterSink + FilterSource, src/filternode.hh:81-88,164-181) ----- */
+enum {
+  SDRHIP_FFTCONV_OLA = 0, /* reference mode: block N, FFT 2N, kernel = 2N-point spectrum K,
+                             out = last + IFFT(FFT([x,0]) * K)/2N  (overlap-add) */
+  SDRHIP_FFTCONV_OLS = 1  /* overlap-save with M real/complex taps, FFT size L, hop L-M+1
+                             (BASELINE config 4: L=16384, M=4097); plain causal convolution */
+};
+/* OLA: fft_size = 2N, kernel = 2N cf32 spectrum (already normalised), n_taps ignored; every call
+ *      must carry a multiple of N samples per channel.
+ * OLS: kernel = n_taps cf32 time-domain taps; any n_in. */
+int sdrhip_fftconv_create(sdrhip_ctx *ctx, int mode, int fft_size, const float *kernel, int n_taps,
+                          int channels, size_t max_in, sdrhip_fftconv **out);
+int sdrhip_fftconv_process(sdrhip_fftconv *h, const float *in_host, size_t n_in, size_t in_stride,
+                           float *out_host, size_t out_stride);
+int sdrhip_fftconv_process_dev(sdrhip_fftconv *h, const float *in_dev, size_t n_in, size_t in_stride,
+                               float *out_dev, size_t out_stride);
+int sdrhip_fftconv_reset(sdrhip_fftconv *h);
+int sdrhip_fftconv_destroy(sdrhip_fftconv *h);
+/* plain batched DFT of the library's own FFT (tests): sign -1 forward / +1 backward, unnormalised */
+int sdrhip_fft_c2c(sdrhip_ctx *ctx, int n, int sign, int batch, const float *in_dev, float *out_dev);
+
+/* ---- float baseband (BASELINE config 2; build-defined) ---------------------- */
+/* y = SubSample_D( FIR_cf32( x[n] * exp(-2*pi*i*Fc*n/Fs) ) ); the reference has no float
+ * baseband (IQBaseBand<float> does not compile, FreqShift<float> is wrong: SURVEY fact 6). */
+int sdrhip_fbb_f32_create(sdrhip_ctx *ctx, double Fc, double Fs, const double *alpha, int order, int decim,
+                          int channels, size_t max_in, sdrhip_fbb_f32 **out);
+int sdrhip_fbb_f32_out_count(sdrhip_fbb_f32 *h, size_t n_in, size_t *n_out);
+int sdrhip_fbb_f32_process(sdrhip_fbb_f32 *h, const float *in_host, size_t n_in, size_t in_stride,
+                           float *out_host, size_t out_stride, size_t *n_out);
+int sdrhip_fbb_f32_process_dev(sdrhip_fbb_f32 *h, const float *in_dev, size_t n_in, size_t in_stride,
+                               float *out_dev, size_t out_stride, size_t *n_out);
+int sdrhip_fbb_f32_reset(sdrhip_fbb_f32 *h);
+int sdrhip_fbb_f32_destroy(sdrhip_fbb_f32 *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDRHIP_H */

@@ -1,0 +1,218 @@
+// ctx.hip — context, memory helpers, timers and error reporting of libsdrhip.so.
+#include "sdrhip_internal.hpp"
+
+namespace sdrhip {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+void copy_h2d_rows(const sdrhip_ctx *ctx, void *dst_dev, size_t dst_pitch_b, const void *src_host,
+                   size_t src_pitch_b, size_t row_bytes, size_t rows) {
+  if (!rows || !row_bytes) return;
+  SDRHIP_CHECK_HIP(hipMemcpy2DAsync(dst_dev, dst_pitch_b, src_host, src_pitch_b, row_bytes, rows,
+                                    hipMemcpyHostToDevice, ctx->stream));
+}
+
+void copy_d2h_rows(const sdrhip_ctx *ctx, void *dst_host, size_t dst_pitch_b, const void *src_dev,
+                   size_t src_pitch_b, size_t row_bytes, size_t rows) {
+  if (!rows || !row_bytes) return;
+  SDRHIP_CHECK_HIP(hipMemcpy2DAsync(dst_host, dst_pitch_b, src_dev, src_pitch_b, row_bytes, rows,
+                                    hipMemcpyDeviceToHost, ctx->stream));
+  SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+}
+
+}  // namespace sdrhip
+
+using namespace sdrhip;
+
+void sdrhip_ctx::use() const { SDRHIP_CHECK_HIP(hipSetDevice(device)); }
+
+extern "C" {
+
+int sdrhip_version(void) { return SDRHIP_VERSION; }
+
+const char *sdrhip_strerror(int code) {
+  switch (code) {
+    case SDRHIP_OK: return "ok";
+    case SDRHIP_E_INVALID: return "invalid argument";
+    case SDRHIP_E_NODEVICE: return "no usable HIP device";
+    case SDRHIP_E_HIP: return "HIP runtime error";
+    case SDRHIP_E_NOMEM: return "out of memory";
+    case SDRHIP_E_UNSUPPORTED: return "unsupported parameter";
+    case SDRHIP_E_SIZE: return "buffer size / stride out of range";
+  }
+  return "unknown error";
+}
+
+const char *sdrhip_last_error(void) { return g_err; }
+
+int sdrhip_device_count(int *count) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(count, SDRHIP_E_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { n = 0; (void)hipGetLastError(); }
+    *count = n;
+  });
+}
+
+int sdrhip_ctx_create(int device, void *stream, sdrhip_ctx **out) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(out, SDRHIP_E_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+      (void)hipGetLastError();
+      SDRHIP_FAIL(SDRHIP_E_NODEVICE, "no HIP device available (%s); libsdrhip has no CPU fallback",
+                  e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    }
+    SDRHIP_REQUIRE(device >= 0 && device < n, SDRHIP_E_NODEVICE, "device %d out of range [0,%d)", device, n);
+    sdrhip_ctx *c = new sdrhip_ctx;
+    c->device = device;
+    try {
+      c->use();
+      SDRHIP_CHECK_HIP(hipGetDeviceProperties(&c->prop, device));
+      if (stream) {
+        c->stream = (hipStream_t)stream;
+        c->own_stream = false;
+      } else {
+        SDRHIP_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+      }
+    } catch (...) {
+      delete c;
+      throw;
+    }
+    *out = c;
+  });
+}
+
+int sdrhip_ctx_destroy(sdrhip_ctx *ctx) {
+  return guarded([&] {
+    if (!ctx) return;
+    ctx->use();
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+  });
+}
+
+int sdrhip_ctx_synchronize(sdrhip_ctx *ctx) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(ctx, SDRHIP_E_INVALID, "ctx is NULL");
+    ctx->use();
+    SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+int sdrhip_ctx_device_name(sdrhip_ctx *ctx, char *buf, size_t len) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(ctx && buf && len, SDRHIP_E_INVALID, "bad argument");
+    snprintf(buf, len, "%s (%s, %d CUs)", ctx->prop.name, ctx->prop.gcnArchName, ctx->prop.multiProcessorCount);
+  });
+}
+
+int sdrhip_malloc(sdrhip_ctx *ctx, size_t bytes, void **dptr) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(ctx && dptr, SDRHIP_E_INVALID, "bad argument");
+    ctx->use();
+    *dptr = nullptr;
+    if (bytes) SDRHIP_CHECK_HIP(hipMalloc(dptr, bytes));
+  });
+}
+
+int sdrhip_free(sdrhip_ctx *ctx, void *dptr) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(ctx, SDRHIP_E_INVALID, "ctx is NULL");
+    ctx->use();
+    if (dptr) {
+      SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+      SDRHIP_CHECK_HIP(hipFree(dptr));
+    }
+  });
+}
+
+int sdrhip_memcpy_h2d(sdrhip_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(ctx, SDRHIP_E_INVALID, "ctx is NULL");
+    if (!bytes) return;
+    ctx->use();
+    SDRHIP_CHECK_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+int sdrhip_memcpy_d2h(sdrhip_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(ctx, SDRHIP_E_INVALID, "ctx is NULL");
+    if (!bytes) return;
+    ctx->use();
+    SDRHIP_CHECK_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+int sdrhip_memset(sdrhip_ctx *ctx, void *dst_dev, int value, size_t bytes) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(ctx, SDRHIP_E_INVALID, "ctx is NULL");
+    if (!bytes) return;
+    ctx->use();
+    SDRHIP_CHECK_HIP(hipMemsetAsync(dst_dev, value, bytes, ctx->stream));
+  });
+}
+
+int sdrhip_timer_create(sdrhip_ctx *ctx, sdrhip_timer **out) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(ctx && out, SDRHIP_E_INVALID, "bad argument");
+    ctx->use();
+    sdrhip_timer *t = new sdrhip_timer;
+    t->ctx = ctx;
+    SDRHIP_CHECK_HIP(hipEventCreate(&t->a));
+    SDRHIP_CHECK_HIP(hipEventCreate(&t->b));
+    *out = t;
+  });
+}
+
+int sdrhip_timer_start(sdrhip_timer *t) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(t, SDRHIP_E_INVALID, "timer is NULL");
+    t->ctx->use();
+    SDRHIP_CHECK_HIP(hipEventRecord(t->a, t->ctx->stream));
+  });
+}
+
+int sdrhip_timer_stop(sdrhip_timer *t) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(t, SDRHIP_E_INVALID, "timer is NULL");
+    t->ctx->use();
+    SDRHIP_CHECK_HIP(hipEventRecord(t->b, t->ctx->stream));
+  });
+}
+
+int sdrhip_timer_elapsed_ms(sdrhip_timer *t, float *ms) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(t && ms, SDRHIP_E_INVALID, "bad argument");
+    t->ctx->use();
+    SDRHIP_CHECK_HIP(hipEventSynchronize(t->b));
+    SDRHIP_CHECK_HIP(hipEventElapsedTime(ms, t->a, t->b));
+  });
+}
+
+int sdrhip_timer_destroy(sdrhip_timer *t) {
+  return guarded([&] {
+    if (!t) return;
+    t->ctx->use();
+    (void)hipEventDestroy(t->a);
+    (void)hipEventDestroy(t->b);
+    delete t;
+  });
+}
+
+}  // extern "C"

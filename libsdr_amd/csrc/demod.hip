@@ -1,0 +1,387 @@
+// demod.hip — K4/K5 stand-alone demodulators and K6 SubSample: HBM-bound elementwise kernels.
+//
+// Replaces (reference, file:line):
+//   FMDemod<int16_t,int16_t>::_process + fast_atan2   src/demod.hh:242-254, src/math.hh:31-40
+//   AMDemod<Scalar>::process                          src/demod.hh:65-81
+//   USBDemod<Scalar>::_process                        src/demod.hh:156-161
+//   SubSample<Scalar>::_process                       src/subsample.hh:92-101
+// Each lane handles 4 consecutive samples: one 16-byte (cs16) or two 16-byte (cf32) loads, one
+// 8/16-byte store; grid-stride over the (channel, sample) plane.
+#include "sdrhip_internal.hpp"
+
+using namespace sdrhip;
+
+namespace {
+
+constexpr int TPB = 256;
+
+__device__ __forceinline__ int fm_phi(int a, int b) {
+  if (a == 0 && b == 0) return 0;
+  const int aabs = a >= 0 ? a : -a;
+  int angle;
+  if (b >= 0) angle = 4096 - 4096 * (b - aabs) / (b + aabs);
+  else angle = 12288 - 4096 * (b + aabs) / (aabs - b);
+  const short at = (short)(a >= 0 ? angle : -angle);
+  return (int)at / 2;
+}
+__device__ __forceinline__ short am_i16(int re, int im) {
+  const int m = (int)((unsigned)(re * re) + (unsigned)(im * im));
+  return (short)(int)sqrt((double)m);
+}
+__device__ __forceinline__ short usb_i16(int re, int im) { return (short)((re + im) / 2); }
+__device__ __forceinline__ int lo16(uint32_t v) { return (short)(v & 0xffffu); }
+__device__ __forceinline__ int hi16(uint32_t v) { return (short)(v >> 16); }
+
+struct DemodArgs {
+  const void *in; long in_stride; void *out; long out_stride;
+  int N, kind, fm0;
+  const short *fm_old; short *fm_new;
+};
+
+// cs16 -> int16
+__global__ __launch_bounds__(TPB) void demod_cs16_kernel(const DemodArgs a) {
+  const int c = blockIdx.y;
+  const uint32_t *in = reinterpret_cast<const uint32_t *>(a.in) + (long)c * a.in_stride;
+  short *out = reinterpret_cast<short *>(a.out) + (long)c * a.out_stride;
+  const bool vec_ok = ((reinterpret_cast<uintptr_t>(in) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 7) == 0);
+  for (int i0 = 4 * (blockIdx.x * TPB + threadIdx.x); i0 < a.N; i0 += 4 * gridDim.x * TPB) {
+    uint32_t x[4];
+    const int cnt = min(4, a.N - i0);
+    if (vec_ok && cnt == 4) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(in + i0);
+      x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+    } else {
+      for (int k = 0; k < 4; k++) x[k] = k < cnt ? in[i0 + k] : 0u;
+    }
+    short o[4];
+    if (a.kind == SDRHIP_EPI_AM) {
+      for (int k = 0; k < 4; k++) o[k] = am_i16(lo16(x[k]), hi16(x[k]));
+    } else if (a.kind == SDRHIP_EPI_USB) {
+      for (int k = 0; k < 4; k++) o[k] = usb_i16(lo16(x[k]), hi16(x[k]));
+    } else {
+      // out[i] = phi[i-1] - phi[i] (i >= 2); out[1] = last - phi[1]; out[0]: never written by FMDemod
+      int prev = 0;
+      if (i0 >= 2) { const uint32_t p = in[i0 - 1]; prev = fm_phi(lo16(p), hi16(p)); }
+      for (int k = 0; k < 4; k++) {
+        const int i = i0 + k;
+        const int phi = fm_phi(lo16(x[k]), hi16(x[k]));
+        if (i == 0) o[k] = (short)lo16(x[k]);
+        else if (i == 1) o[k] = (short)((int)a.fm_old[c] - phi);
+        else o[k] = (short)(prev - phi);
+        prev = phi;
+        if (i == a.N - 1 && a.N >= 2) a.fm_new[c] = (short)phi;
+      }
+    }
+    const bool skip0 = (a.kind == SDRHIP_EPI_FM) && !a.fm0 && i0 == 0;
+    if (vec_ok && cnt == 4 && !skip0) {
+      uint2 pk;
+      pk.x = (uint32_t)(uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16);
+      pk.y = (uint32_t)(uint16_t)o[2] | ((uint32_t)(uint16_t)o[3] << 16);
+      *reinterpret_cast<uint2 *>(out + i0) = pk;
+    } else {
+      for (int k = 0; k < cnt; k++) if (!(skip0 && k == 0)) out[i0 + k] = o[k];
+    }
+  }
+}
+
+// cf32 -> float (AM, USB)
+__global__ __launch_bounds__(TPB) void demod_cf32_kernel(const DemodArgs a) {
+  const int c = blockIdx.y;
+  const float2 *in = reinterpret_cast<const float2 *>(a.in) + (long)c * a.in_stride;
+  float *out = reinterpret_cast<float *>(a.out) + (long)c * a.out_stride;
+  const bool vec_ok = ((reinterpret_cast<uintptr_t>(in) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  for (int i0 = 4 * (blockIdx.x * TPB + threadIdx.x); i0 < a.N; i0 += 4 * gridDim.x * TPB) {
+    float2 x[4];
+    const int cnt = min(4, a.N - i0);
+    if (vec_ok && cnt == 4) {
+      const float4 v0 = *reinterpret_cast<const float4 *>(in + i0), v1 = *reinterpret_cast<const float4 *>(in + i0 + 2);
+      x[0] = make_float2(v0.x, v0.y); x[1] = make_float2(v0.z, v0.w);
+      x[2] = make_float2(v1.x, v1.y); x[3] = make_float2(v1.z, v1.w);
+    } else {
+      for (int k = 0; k < 4; k++) x[k] = k < cnt ? in[i0 + k] : make_float2(0.f, 0.f);
+    }
+    float o[4];
+    for (int k = 0; k < 4; k++)
+      o[k] = (a.kind == SDRHIP_EPI_AM) ? sqrtf(x[k].x * x[k].x + x[k].y * x[k].y) : (x[k].x + x[k].y) / 2;
+    if (vec_ok && cnt == 4) *reinterpret_cast<float4 *>(out + i0) = make_float4(o[0], o[1], o[2], o[3]);
+    else for (int k = 0; k < cnt; k++) out[i0 + k] = o[k];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6 SubSample: groups of n inputs counted from the last reset; the open group's partial sum is
+// carried between calls.
+// ---------------------------------------------------------------------------------------------
+struct SubArgs {
+  const void *in; long in_stride; void *out; long out_stride;
+  int N, n;
+  int first_rel;   // call-relative index of the first sample of the first group touched (<= 0)
+  int n_groups, n_out;
+  const void *acc_old; void *acc_new;
+};
+
+__device__ __forceinline__ int cdiv_int(int s, int n) {   // (s*n)/(n*n), wrapping, truncating
+  const int d = (int)((unsigned)n * (unsigned)n);
+  const int r = (int)((unsigned)s * (unsigned)n);
+  if (d == 0) return 0;
+  if (r == (int)0x80000000 && d == -1) return r;
+  return r / d;
+}
+
+__global__ __launch_bounds__(TPB) void subsample_cs16_kernel(const SubArgs a) {
+  const int c = blockIdx.y;
+  const uint32_t *in = reinterpret_cast<const uint32_t *>(a.in) + (long)c * a.in_stride;
+  uint32_t *out = reinterpret_cast<uint32_t *>(a.out) + (long)c * a.out_stride;
+  const int2 *acc_old = reinterpret_cast<const int2 *>(a.acc_old);
+  int2 *acc_new = reinterpret_cast<int2 *>(a.acc_new);
+  for (int g = blockIdx.x * TPB + threadIdx.x; g < a.n_groups; g += gridDim.x * TPB) {
+    const int lo = max(0, a.first_rel + g * a.n), hi = min(a.N, a.first_rel + (g + 1) * a.n);
+    int sr = 0, si = 0;
+    if (g == 0) { const int2 cy = acc_old[c]; sr = cy.x; si = cy.y; }
+    for (int i = lo; i < hi; i++) {
+      const uint32_t v = in[i];
+      sr = (int)((unsigned)sr + (unsigned)lo16(v)); si = (int)((unsigned)si + (unsigned)hi16(v));
+    }
+    const bool emits = g < a.n_out;
+    if (emits) {
+      const int yr = cdiv_int(sr, a.n), yi = cdiv_int(si, a.n);
+      out[g] = (uint32_t)(uint16_t)yr | ((uint32_t)(uint16_t)yi << 16);
+    }
+    if (g == a.n_groups - 1) acc_new[c] = emits ? make_int2(0, 0) : make_int2(sr, si);
+  }
+}
+
+__global__ __launch_bounds__(TPB) void subsample_cf32_kernel(const SubArgs a) {
+  const int c = blockIdx.y;
+  const float2 *in = reinterpret_cast<const float2 *>(a.in) + (long)c * a.in_stride;
+  float2 *out = reinterpret_cast<float2 *>(a.out) + (long)c * a.out_stride;
+  const float2 *acc_old = reinterpret_cast<const float2 *>(a.acc_old);
+  float2 *acc_new = reinterpret_cast<float2 *>(a.acc_new);
+  const float d = (float)a.n;
+  for (int g = blockIdx.x * TPB + threadIdx.x; g < a.n_groups; g += gridDim.x * TPB) {
+    const int lo = max(0, a.first_rel + g * a.n), hi = min(a.N, a.first_rel + (g + 1) * a.n);
+    float sr = 0.f, si = 0.f;
+    if (g == 0) { const float2 cy = acc_old[c]; sr = cy.x; si = cy.y; }
+    for (int i = lo; i < hi; i++) { const float2 v = in[i]; sr += v.x; si += v.y; }   // same order as the reference
+    const bool emits = g < a.n_out;
+    if (emits) out[g] = make_float2(sr / d, si / d);
+    if (g == a.n_groups - 1) acc_new[c] = emits ? make_float2(0.f, 0.f) : make_float2(sr, si);
+  }
+}
+
+}  // namespace
+
+struct sdrhip_demod {
+  sdrhip_ctx *ctx = nullptr;
+  int kind = 0, dtype = 0, C = 1, fm0 = 1, par_fm = 0;
+  size_t max_in = 0;
+  DevBuf<short> fm[2];
+  DevBuf<uint8_t> stage_in, stage_out;
+  size_t in_elem() const { return dtype == SDRHIP_T_CS16 ? 4 : 8; }
+  size_t out_elem() const { return dtype == SDRHIP_T_CS16 ? 2 : 4; }
+  void launch(const void *in_dev, size_t N, size_t in_stride, void *out_dev, size_t out_stride) {
+    ctx->use();
+    if (N == 0) return;   // FMDemod::process returns without sending on an empty buffer (src/demod.hh:231)
+    DemodArgs a;
+    a.in = in_dev; a.in_stride = (long)in_stride; a.out = out_dev; a.out_stride = (long)out_stride;
+    a.N = (int)N; a.kind = kind; a.fm0 = fm0;
+    a.fm_old = fm[par_fm].p; a.fm_new = fm[par_fm ^ 1].p;
+    const unsigned bx = (unsigned)std::min<size_t>(ceil_div(N, (size_t)4 * TPB), 4096);
+    dim3 grid(bx, C), block(TPB);
+    if (dtype == SDRHIP_T_CS16) hipLaunchKernelGGL(demod_cs16_kernel, grid, block, 0, ctx->stream, a);
+    else hipLaunchKernelGGL(demod_cf32_kernel, grid, block, 0, ctx->stream, a);
+    SDRHIP_CHECK_HIP(hipGetLastError());
+    if (kind == SDRHIP_EPI_FM && N >= 2) par_fm ^= 1;
+  }
+};
+
+struct sdrhip_subsample {
+  sdrhip_ctx *ctx = nullptr;
+  int dtype = 0, C = 1, par = 0;
+  size_t n = 1, max_in = 0, max_out = 0;
+  uint64_t n0 = 0;
+  DevBuf<uint8_t> acc[2];
+  DevBuf<uint8_t> stage_in, stage_out;
+  size_t elem() const { return dtype == SDRHIP_T_CS16 ? 4 : 8; }
+  size_t out_count(size_t N) const { return (size_t)((n0 + N) / n - n0 / n); }
+  void launch(const void *in_dev, size_t N, size_t in_stride, void *out_dev, size_t out_stride, size_t *n_out) {
+    ctx->use();
+    if (N == 0) { if (n_out) *n_out = 0; return; }
+    const size_t no = out_count(N);
+    SDRHIP_REQUIRE(out_stride >= no, SDRHIP_E_SIZE, "out_stride %zu < outputs %zu", out_stride, no);
+    SubArgs a;
+    a.in = in_dev; a.in_stride = (long)in_stride; a.out = out_dev; a.out_stride = (long)out_stride;
+    a.N = (int)N; a.n = (int)n;
+    const uint64_t g0 = n0 / n, g1 = (n0 + N - 1) / n;
+    a.first_rel = (int)((int64_t)(g0 * n) - (int64_t)n0);
+    a.n_groups = (int)(g1 - g0 + 1); a.n_out = (int)no;
+    a.acc_old = acc[par].p; a.acc_new = acc[par ^ 1].p;
+    const unsigned bx = (unsigned)std::min<size_t>(ceil_div((size_t)a.n_groups, (size_t)TPB), 4096);
+    dim3 grid(bx, C), block(TPB);
+    if (dtype == SDRHIP_T_CS16) hipLaunchKernelGGL(subsample_cs16_kernel, grid, block, 0, ctx->stream, a);
+    else hipLaunchKernelGGL(subsample_cf32_kernel, grid, block, 0, ctx->stream, a);
+    SDRHIP_CHECK_HIP(hipGetLastError());
+    par ^= 1; n0 += N;
+    if (n_out) *n_out = no;
+  }
+};
+
+extern "C" {
+
+int sdrhip_demod_create(sdrhip_ctx *ctx, int kind, int dtype, int channels, size_t max_in, int inplace_fm0,
+                        sdrhip_demod **out) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(ctx && out, SDRHIP_E_INVALID, "NULL argument");
+    *out = nullptr;
+    SDRHIP_REQUIRE(kind == SDRHIP_EPI_FM || kind == SDRHIP_EPI_AM || kind == SDRHIP_EPI_USB, SDRHIP_E_INVALID, "bad kind %d", kind);
+    SDRHIP_REQUIRE(dtype == SDRHIP_T_CS16 || dtype == SDRHIP_T_CF32, SDRHIP_E_INVALID, "bad dtype %d", dtype);
+    SDRHIP_REQUIRE(!(kind == SDRHIP_EPI_FM && dtype == SDRHIP_T_CF32), SDRHIP_E_UNSUPPORTED,
+                   "FMDemod<float> does not exist in the reference (fast_atan2 has no float form)");
+    SDRHIP_REQUIRE(channels >= 1 && channels <= 65535, SDRHIP_E_INVALID, "channels %d outside [1,65535]", channels);
+    SDRHIP_REQUIRE(max_in >= 1 && max_in < (size_t(1) << 30), SDRHIP_E_SIZE, "max_in %zu outside [1,2^30)", max_in);
+    ctx->use();
+    sdrhip_demod *h = new sdrhip_demod;
+    try {
+      h->ctx = ctx; h->kind = kind; h->dtype = dtype; h->C = channels; h->max_in = max_in; h->fm0 = inplace_fm0 ? 1 : 0;
+      for (int p = 0; p < 2; p++) { h->fm[p].alloc(channels); h->fm[p].zero(ctx->stream); }
+      SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    } catch (...) { delete h; throw; }
+    *out = h;
+  });
+}
+
+int sdrhip_demod_process_dev(sdrhip_demod *h, const void *in_dev, size_t n, size_t in_stride, void *out_dev,
+                             size_t out_stride) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
+    SDRHIP_REQUIRE(n <= h->max_in, SDRHIP_E_SIZE, "n %zu > max_in %zu", n, h->max_in);
+    if (n == 0) return;
+    SDRHIP_REQUIRE(in_dev && out_dev, SDRHIP_E_INVALID, "NULL buffer");
+    if (in_stride == 0) in_stride = n;
+    if (out_stride == 0) out_stride = n;
+    SDRHIP_REQUIRE(in_stride >= n && out_stride >= n, SDRHIP_E_SIZE, "stride smaller than n");
+    h->launch(in_dev, n, in_stride, out_dev, out_stride);
+  });
+}
+
+int sdrhip_demod_process(sdrhip_demod *h, const void *in_host, size_t n, size_t in_stride, void *out_host,
+                         size_t out_stride) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
+    SDRHIP_REQUIRE(n <= h->max_in, SDRHIP_E_SIZE, "n %zu > max_in %zu", n, h->max_in);
+    if (n == 0) return;
+    SDRHIP_REQUIRE(in_host && out_host, SDRHIP_E_INVALID, "NULL buffer");
+    h->ctx->use();
+    if (in_stride == 0) in_stride = n;
+    if (out_stride == 0) out_stride = n;
+    SDRHIP_REQUIRE(in_stride >= n && out_stride >= n, SDRHIP_E_SIZE, "stride smaller than n");
+    const size_t ib = h->in_elem(), ob = h->out_elem();
+    if (!h->stage_in.p) { h->stage_in.alloc((size_t)h->C * h->max_in * ib); h->stage_out.alloc((size_t)h->C * h->max_in * ob); }
+    copy_h2d_rows(h->ctx, h->stage_in.p, n * ib, in_host, in_stride * ib, n * ib, h->C);
+    if (h->kind == SDRHIP_EPI_FM && !h->fm0)   // index 0 is left as the caller's buffer had it
+      copy_h2d_rows(h->ctx, h->stage_out.p, n * ob, out_host, out_stride * ob, ob, h->C);
+    h->launch(h->stage_in.p, n, n, h->stage_out.p, n);
+    copy_d2h_rows(h->ctx, out_host, out_stride * ob, h->stage_out.p, n * ob, n * ob, h->C);
+    SDRHIP_CHECK_HIP(hipStreamSynchronize(h->ctx->stream));
+  });
+}
+
+int sdrhip_demod_reset(sdrhip_demod *h) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
+    h->ctx->use();
+    for (int p = 0; p < 2; p++) h->fm[p].zero(h->ctx->stream);
+  });
+}
+
+int sdrhip_demod_destroy(sdrhip_demod *h) {
+  return guarded([&] {
+    if (!h) return;
+    h->ctx->use();
+    (void)hipStreamSynchronize(h->ctx->stream);
+    delete h;
+  });
+}
+
+int sdrhip_subsample_create(sdrhip_ctx *ctx, int dtype, size_t n, int channels, size_t max_in, sdrhip_subsample **out) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(ctx && out, SDRHIP_E_INVALID, "NULL argument");
+    *out = nullptr;
+    SDRHIP_REQUIRE(dtype == SDRHIP_T_CS16 || dtype == SDRHIP_T_CF32, SDRHIP_E_INVALID, "bad dtype %d", dtype);
+    SDRHIP_REQUIRE(n >= 1 && n <= 46340, SDRHIP_E_UNSUPPORTED, "n %zu outside [1,46340]", n);
+    SDRHIP_REQUIRE(channels >= 1 && channels <= 65535, SDRHIP_E_INVALID, "channels %d outside [1,65535]", channels);
+    SDRHIP_REQUIRE(max_in >= 1 && max_in < (size_t(1) << 30), SDRHIP_E_SIZE, "max_in %zu outside [1,2^30)", max_in);
+    ctx->use();
+    sdrhip_subsample *h = new sdrhip_subsample;
+    try {
+      h->ctx = ctx; h->dtype = dtype; h->n = n; h->C = channels; h->max_in = max_in; h->max_out = max_in / n + 1;
+      for (int p = 0; p < 2; p++) { h->acc[p].alloc((size_t)channels * 8); h->acc[p].zero(ctx->stream); }
+      SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    } catch (...) { delete h; throw; }
+    *out = h;
+  });
+}
+
+int sdrhip_subsample_out_count(sdrhip_subsample *h, size_t n_in, size_t *n_out) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h && n_out, SDRHIP_E_INVALID, "NULL argument");
+    *n_out = h->out_count(n_in);
+  });
+}
+
+int sdrhip_subsample_process_dev(sdrhip_subsample *h, const void *in_dev, size_t n_in, size_t in_stride,
+                                 void *out_dev, size_t out_stride, size_t *n_out) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
+    SDRHIP_REQUIRE(n_in <= h->max_in, SDRHIP_E_SIZE, "n_in %zu > max_in %zu", n_in, h->max_in);
+    if (n_in == 0) { if (n_out) *n_out = 0; return; }
+    SDRHIP_REQUIRE(in_dev && out_dev, SDRHIP_E_INVALID, "NULL buffer");
+    if (in_stride == 0) in_stride = n_in;
+    SDRHIP_REQUIRE(in_stride >= n_in, SDRHIP_E_SIZE, "in_stride %zu < n_in %zu", in_stride, n_in);
+    if (out_stride == 0) out_stride = h->out_count(n_in);
+    h->launch(in_dev, n_in, in_stride, out_dev, out_stride, n_out);
+  });
+}
+
+int sdrhip_subsample_process(sdrhip_subsample *h, const void *in_host, size_t n_in, size_t in_stride,
+                             void *out_host, size_t out_stride, size_t *n_out) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
+    SDRHIP_REQUIRE(n_in <= h->max_in, SDRHIP_E_SIZE, "n_in %zu > max_in %zu", n_in, h->max_in);
+    if (n_in == 0) { if (n_out) *n_out = 0; return; }
+    SDRHIP_REQUIRE(in_host && out_host, SDRHIP_E_INVALID, "NULL buffer");
+    h->ctx->use();
+    if (in_stride == 0) in_stride = n_in;
+    const size_t no = h->out_count(n_in);
+    if (out_stride == 0) out_stride = no;
+    SDRHIP_REQUIRE(out_stride >= no, SDRHIP_E_SIZE, "out_stride %zu < outputs %zu", out_stride, no);
+    const size_t eb = h->elem();
+    if (!h->stage_in.p) { h->stage_in.alloc((size_t)h->C * h->max_in * eb); h->stage_out.alloc((size_t)h->C * h->max_out * eb); }
+    copy_h2d_rows(h->ctx, h->stage_in.p, n_in * eb, in_host, in_stride * eb, n_in * eb, h->C);
+    size_t produced = 0;
+    h->launch(h->stage_in.p, n_in, n_in, h->stage_out.p, h->max_out, &produced);
+    copy_d2h_rows(h->ctx, out_host, out_stride * eb, h->stage_out.p, h->max_out * eb, produced * eb, h->C);
+    SDRHIP_CHECK_HIP(hipStreamSynchronize(h->ctx->stream));
+    if (n_out) *n_out = produced;
+  });
+}
+
+int sdrhip_subsample_reset(sdrhip_subsample *h) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
+    h->ctx->use();
+    h->n0 = 0;
+    for (int p = 0; p < 2; p++) h->acc[p].zero(h->ctx->stream);
+  });
+}
+
+int sdrhip_subsample_destroy(sdrhip_subsample *h) {
+  return guarded([&] {
+    if (!h) return;
+    h->ctx->use();
+    (void)hipStreamSynchronize(h->ctx->stream);
+    delete h;
+  });
+}
+
+}  // extern "C"

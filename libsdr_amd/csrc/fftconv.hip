@@ -1,0 +1,357 @@
+// fftconv.hip — K7: FFT convolution filter with a hand-written in-LDS FFT (no rocFFT/hipFFT).
+//
+// Replaces (reference, file:line):
+//   FilterSink<float>::process      src/filternode.hh:81-88   (zero-pad + forward FFT, FFTW3f)
+//   FilterSource<float>::process    src/filternode.hh:164-181 (spectrum multiply, inverse FFT, /2N, overlap-add)
+//   FFTPlan<float> / FFT::exec      src/fftplan.hh:14-36, src/fftplan_fftw3.hh:79-142
+//
+// The reference's overlap-ADD with block N, FFT size 2N and an N-tap kernel is the causal linear
+// convolution y[n] = sum_{k<N} h[k] x[n-k]. We evaluate that same convolution by
+// overlap-SAVE: block b transforms the L samples ending at its last output and keeps the last
+// `hop` results, so blocks (and channels) are independent — no tail carried between workgroups,
+// any call length is accepted, and BASELINE config 4's (L=16384, M=4097, hop 12288) mode is the
+// same kernel with a different hop. One workgroup (1024 lanes) owns one block: L complex floats
+// live in LDS (128 KiB at L=16384), the forward transform is an in-place radix-4 DIF (result in
+// digit-reversed order), the kernel spectrum is stored pre-permuted and pre-scaled by 1/L, and
+// the inverse is the mirrored in-place DIT, so no reordering pass is ever executed.
+#include "sdrhip_internal.hpp"
+
+#include <cmath>
+#include <complex>
+
+using namespace sdrhip;
+
+namespace {
+
+constexpr int FT = 1024;       // lanes per workgroup
+constexpr int MAX_PASS = 16;
+
+struct FftDev {
+  int L, npass;
+  int radix[MAX_PASS];   // forward pass order (DIF); the inverse walks it backwards
+  const float2 *W;       // W[t] = exp(-2 pi i t / L)
+};
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a * conj(b)
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }   // a * (-i)
+__device__ __forceinline__ float2 mul_pi(float2 a) { return make_float2(-a.y, a.x); }   // a * (+i)
+
+// forward, decimation in frequency: natural order in, digit-reversed order out
+__device__ void fft_forward_dif(float2 *x, const FftDev &p, int tid) {
+  int n = p.L;
+  for (int pass = 0; pass < p.npass; pass++) {
+    const int r = p.radix[pass], s = n / r, tw = p.L / n;
+    if (r == 4) {
+      for (int b = tid; b < p.L / 4; b += FT) {
+        const int j = b & (s - 1), base = (b / s) * n + j;
+        const float2 a0 = x[base], a1 = x[base + s], a2 = x[base + 2 * s], a3 = x[base + 3 * s];
+        const float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_mi(csub(a1, a3));
+        x[base] = cadd(t0, t2);
+        x[base + s] = cmul(cadd(t1, t3), p.W[j * tw]);
+        x[base + 2 * s] = cmul(csub(t0, t2), p.W[2 * j * tw]);
+        x[base + 3 * s] = cmul(csub(t1, t3), p.W[3 * j * tw]);
+      }
+    } else {   // radix 2
+      for (int b = tid; b < p.L / 2; b += FT) {
+        const int j = b & (s - 1), base = (b / s) * n + j;
+        const float2 a0 = x[base], a1 = x[base + s];
+        x[base] = cadd(a0, a1);
+        x[base + s] = cmul(csub(a0, a1), p.W[j * tw]);
+      }
+    }
+    __syncthreads();
+    n = s;
+  }
+}
+
+// backward (unnormalised), decimation in time: digit-reversed order in, natural order out
+__device__ void fft_inverse_dit(float2 *x, const FftDev &p, int tid) {
+  int n = 1;
+  for (int pass = p.npass - 1; pass >= 0; pass--) {
+    const int r = p.radix[pass], s = n;
+    n *= r;
+    const int tw = p.L / n;
+    if (r == 4) {
+      for (int b = tid; b < p.L / 4; b += FT) {
+        const int j = b & (s - 1), base = (b / s) * n + j;
+        const float2 a0 = x[base];
+        const float2 a1 = cmulc(x[base + s], p.W[j * tw]);
+        const float2 a2 = cmulc(x[base + 2 * s], p.W[2 * j * tw]);
+        const float2 a3 = cmulc(x[base + 3 * s], p.W[3 * j * tw]);
+        const float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_pi(csub(a1, a3));
+        x[base] = cadd(t0, t2);
+        x[base + s] = cadd(t1, t3);
+        x[base + 2 * s] = csub(t0, t2);
+        x[base + 3 * s] = csub(t1, t3);
+      }
+    } else {
+      for (int b = tid; b < p.L / 2; b += FT) {
+        const int j = b & (s - 1), base = (b / s) * n + j;
+        const float2 a0 = x[base], a1 = cmulc(x[base + s], p.W[j * tw]);
+        x[base] = cadd(a0, a1);
+        x[base + s] = csub(a0, a1);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+struct ConvArgs {
+  FftDev fft;
+  const float2 *in; long in_stride;
+  const float2 *hist; int HH;        // HH = L - hop samples preceding the call
+  const float2 *Kp;                  // spectrum, digit-reversed order, pre-scaled by 1/L
+  float2 *out; long out_stride;
+  int N, hop;
+};
+
+__global__ __launch_bounds__(FT) void fftconv_kernel(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float2 xl[];
+  const int c = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+  const int L = a.fft.L;
+  const int first = blk * a.hop - a.HH;   // call-relative index of xl[0]
+  for (int i = tid; i < L; i += FT) {
+    const int rel = first + i;
+    float2 v = make_float2(0.f, 0.f);
+    if (rel >= 0) { if (rel < a.N) v = a.in[(long)c * a.in_stride + rel]; }
+    else { const int h = a.HH + rel; if (h >= 0) v = a.hist[(long)c * a.HH + h]; }
+    xl[i] = v;
+  }
+  __syncthreads();
+  fft_forward_dif(xl, a.fft, tid);
+  for (int i = tid; i < L; i += FT) xl[i] = cmul(xl[i], a.Kp[i]);
+  __syncthreads();
+  fft_inverse_dit(xl, a.fft, tid);
+  const int o0 = blk * a.hop;
+  for (int i = tid; i < a.hop; i += FT) {
+    const int o = o0 + i;
+    if (o < a.N) a.out[(long)c * a.out_stride + o] = xl[a.HH + i];
+  }
+}
+
+__global__ void hist_roll_kernel(const float2 *in, long in_stride, const float2 *hist_old, float2 *hist_new, int HH, int N) {
+  const int c = blockIdx.y;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < HH; k += gridDim.x * blockDim.x) {
+    const long qq = (long)N + k;
+    hist_new[(long)c * HH + k] = qq < HH ? hist_old[(long)c * HH + qq] : in[(long)c * in_stride + (qq - HH)];
+  }
+}
+
+// test entry: plain batched DFT through the same passes
+__global__ __launch_bounds__(FT) void fft_c2c_kernel(const FftDev p, const int *perm, int sign, const float2 *in, float2 *out) {
+  extern __shared__ __attribute__((aligned(16))) float2 xl[];
+  const int tid = threadIdx.x, L = p.L;
+  const float2 *src = in + (long)blockIdx.x * L;
+  float2 *dst = out + (long)blockIdx.x * L;
+  if (sign < 0) {
+    for (int i = tid; i < L; i += FT) xl[i] = src[i];
+    __syncthreads();
+    fft_forward_dif(xl, p, tid);
+    for (int i = tid; i < L; i += FT) dst[perm[i]] = xl[i];   // position i holds frequency perm[i]
+  } else {
+    for (int i = tid; i < L; i += FT) xl[i] = src[perm[i]];
+    __syncthreads();
+    fft_inverse_dit(xl, p, tid);
+    for (int i = tid; i < L; i += FT) dst[i] = xl[i];
+  }
+}
+
+struct FftPlan {
+  int L = 0;
+  FftDev dev{};
+  DevBuf<float2> W;
+  DevBuf<int> perm_d;
+  std::vector<int> perm;   // position -> frequency index after the forward DIF
+
+  void build(sdrhip_ctx *ctx, int L_) {
+    SDRHIP_REQUIRE(L_ >= 4 && L_ <= 16384 && (L_ & (L_ - 1)) == 0, SDRHIP_E_UNSUPPORTED,
+                   "FFT size %d: need a power of two in [4,16384]", L_);
+    L = L_;
+    int lg = 0; while ((1 << lg) < L) lg++;
+    dev.L = L; dev.npass = 0;
+    for (int k = 0; k < lg / 2; k++) dev.radix[dev.npass++] = 4;
+    if (lg & 1) dev.radix[dev.npass++] = 2;
+    std::vector<float2> w(L);
+    for (int t = 0; t < L; t++) {
+      const double ang = -2.0 * M_PI * (double)t / (double)L;
+      w[t] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+    }
+    W.alloc(L); W.upload(w.data(), L, ctx->stream);
+    dev.W = W.p;
+    perm.resize(L);
+    for (int pos = 0; pos < L; pos++) {
+      int rem = pos, n = L, k = 0, mult = 1;
+      for (int ps = 0; ps < dev.npass; ps++) {
+        const int r = dev.radix[ps], s = n / r, m = rem / s;
+        rem -= m * s; k += m * mult; mult *= r; n = s;
+      }
+      perm[pos] = k;
+    }
+    perm_d.alloc(L); perm_d.upload(perm.data(), L, ctx->stream);
+  }
+  size_t lds_bytes() const { return (size_t)L * sizeof(float2); }
+};
+
+template <class K>
+void allow_big_lds(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024)
+    SDRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+}
+
+}  // namespace
+
+struct sdrhip_fftconv {
+  sdrhip_ctx *ctx = nullptr;
+  int mode = 0, C = 1, hop = 0, HH = 0, par = 0;
+  size_t max_in = 0;
+  FftPlan plan;
+  DevBuf<float2> Kp;
+  DevBuf<float2> hist[2];
+  DevBuf<float2> stage_in, stage_out;
+
+  void launch(const float2 *in_dev, size_t N, size_t in_stride, float2 *out_dev, size_t out_stride) {
+    ctx->use();
+    if (N == 0) return;
+    ConvArgs a;
+    a.fft = plan.dev; a.in = in_dev; a.in_stride = (long)in_stride;
+    a.hist = hist[par].p; a.HH = HH; a.Kp = Kp.p;
+    a.out = out_dev; a.out_stride = (long)out_stride; a.N = (int)N; a.hop = hop;
+    const int blocks = (int)ceil_div(N, (size_t)hop);
+    allow_big_lds(fftconv_kernel, plan.lds_bytes());
+    hipLaunchKernelGGL(fftconv_kernel, dim3(blocks, C), dim3(FT), plan.lds_bytes(), ctx->stream, a);
+    SDRHIP_CHECK_HIP(hipGetLastError());
+    if (HH > 0) {
+      hipLaunchKernelGGL(hist_roll_kernel, dim3((unsigned)ceil_div((size_t)HH, (size_t)256), C), dim3(256), 0, ctx->stream,
+                         in_dev, (long)in_stride, hist[par].p, hist[par ^ 1].p, HH, (int)N);
+      SDRHIP_CHECK_HIP(hipGetLastError());
+      par ^= 1;
+    }
+  }
+};
+
+extern "C" {
+
+int sdrhip_fftconv_create(sdrhip_ctx *ctx, int mode, int fft_size, const float *kernel, int n_taps, int channels,
+                          size_t max_in, sdrhip_fftconv **out) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(ctx && kernel && out, SDRHIP_E_INVALID, "NULL argument");
+    *out = nullptr;
+    SDRHIP_REQUIRE(mode == SDRHIP_FFTCONV_OLA || mode == SDRHIP_FFTCONV_OLS, SDRHIP_E_INVALID, "bad mode %d", mode);
+    SDRHIP_REQUIRE(channels >= 1 && channels <= 65535, SDRHIP_E_INVALID, "channels %d outside [1,65535]", channels);
+    SDRHIP_REQUIRE(max_in >= 1 && max_in < (size_t(1) << 30), SDRHIP_E_SIZE, "max_in %zu outside [1,2^30)", max_in);
+    ctx->use();
+    sdrhip_fftconv *h = new sdrhip_fftconv;
+    try {
+      h->ctx = ctx; h->mode = mode; h->C = channels; h->max_in = max_in;
+      h->plan.build(ctx, fft_size);
+      const int L = fft_size;
+      std::vector< std::complex<double> > spec(L);
+      if (mode == SDRHIP_FFTCONV_OLA) {
+        // kernel = the FilterSource spectrum (2N points); its time-domain support is N taps
+        h->hop = L / 2;
+        for (int i = 0; i < L; i++) spec[i] = std::complex<double>(kernel[2 * i], kernel[2 * i + 1]);
+      } else {
+        SDRHIP_REQUIRE(n_taps >= 1 && n_taps <= L, SDRHIP_E_INVALID, "n_taps %d outside [1,%d]", n_taps, L);
+        h->hop = L - n_taps + 1;
+        // host DFT in double of the zero-padded taps (one-off)
+        std::vector< std::complex<double> > a(L, std::complex<double>(0, 0));
+        for (int i = 0; i < n_taps; i++) a[i] = std::complex<double>(kernel[2 * i], kernel[2 * i + 1]);
+        for (size_t i = 1, j = 0; i < (size_t)L; i++) {
+          size_t bit = (size_t)L >> 1;
+          for (; j & bit; bit >>= 1) j ^= bit;
+          j ^= bit;
+          if (i < j) std::swap(a[i], a[j]);
+        }
+        for (size_t len = 2; len <= (size_t)L; len <<= 1)
+          for (size_t k = 0; k < len / 2; k++) {
+            const double ang = -2.0 * M_PI * (double)k / (double)len;
+            const std::complex<double> w(std::cos(ang), std::sin(ang));
+            for (size_t s = 0; s < (size_t)L; s += len) {
+              const std::complex<double> u = a[s + k], t = w * a[s + k + len / 2];
+              a[s + k] = u + t; a[s + k + len / 2] = u - t;
+            }
+          }
+        spec = a;
+      }
+      h->HH = L - h->hop;
+      std::vector<float2> kp(L);
+      for (int pos = 0; pos < L; pos++) {
+        const std::complex<double> v = spec[h->plan.perm[pos]] / (double)L;
+        kp[pos] = make_float2((float)v.real(), (float)v.imag());
+      }
+      h->Kp.alloc(L); h->Kp.upload(kp.data(), L, ctx->stream);
+      for (int p = 0; p < 2; p++) { h->hist[p].alloc((size_t)channels * std::max(1, h->HH)); h->hist[p].zero(ctx->stream); }
+      SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    } catch (...) { delete h; throw; }
+    *out = h;
+  });
+}
+
+int sdrhip_fftconv_process_dev(sdrhip_fftconv *h, const float *in_dev, size_t n_in, size_t in_stride,
+                               float *out_dev, size_t out_stride) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
+    SDRHIP_REQUIRE(n_in <= h->max_in, SDRHIP_E_SIZE, "n_in %zu > max_in %zu", n_in, h->max_in);
+    if (n_in == 0) return;
+    SDRHIP_REQUIRE(in_dev && out_dev, SDRHIP_E_INVALID, "NULL buffer");
+    if (in_stride == 0) in_stride = n_in;
+    if (out_stride == 0) out_stride = n_in;
+    SDRHIP_REQUIRE(in_stride >= n_in && out_stride >= n_in, SDRHIP_E_SIZE, "stride smaller than n_in");
+    h->launch(reinterpret_cast<const float2 *>(in_dev), n_in, in_stride, reinterpret_cast<float2 *>(out_dev), out_stride);
+  });
+}
+
+int sdrhip_fftconv_process(sdrhip_fftconv *h, const float *in_host, size_t n_in, size_t in_stride, float *out_host,
+                           size_t out_stride) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
+    SDRHIP_REQUIRE(n_in <= h->max_in, SDRHIP_E_SIZE, "n_in %zu > max_in %zu", n_in, h->max_in);
+    if (n_in == 0) return;
+    SDRHIP_REQUIRE(in_host && out_host, SDRHIP_E_INVALID, "NULL buffer");
+    h->ctx->use();
+    if (in_stride == 0) in_stride = n_in;
+    if (out_stride == 0) out_stride = n_in;
+    SDRHIP_REQUIRE(in_stride >= n_in && out_stride >= n_in, SDRHIP_E_SIZE, "stride smaller than n_in");
+    if (!h->stage_in.p) { h->stage_in.alloc((size_t)h->C * h->max_in); h->stage_out.alloc((size_t)h->C * h->max_in); }
+    copy_h2d_rows(h->ctx, h->stage_in.p, n_in * 8, in_host, in_stride * 8, n_in * 8, h->C);
+    h->launch(h->stage_in.p, n_in, n_in, h->stage_out.p, n_in);
+    copy_d2h_rows(h->ctx, out_host, out_stride * 8, h->stage_out.p, n_in * 8, n_in * 8, h->C);
+    SDRHIP_CHECK_HIP(hipStreamSynchronize(h->ctx->stream));
+  });
+}
+
+int sdrhip_fftconv_reset(sdrhip_fftconv *h) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
+    h->ctx->use();
+    for (int p = 0; p < 2; p++) h->hist[p].zero(h->ctx->stream);
+  });
+}
+
+int sdrhip_fftconv_destroy(sdrhip_fftconv *h) {
+  return guarded([&] {
+    if (!h) return;
+    h->ctx->use();
+    (void)hipStreamSynchronize(h->ctx->stream);
+    delete h;
+  });
+}
+
+int sdrhip_fft_c2c(sdrhip_ctx *ctx, int n, int sign, int batch, const float *in_dev, float *out_dev) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(ctx && in_dev && out_dev && batch >= 1 && (sign == 1 || sign == -1), SDRHIP_E_INVALID, "bad argument");
+    ctx->use();
+    FftPlan plan;
+    plan.build(ctx, n);
+    allow_big_lds(fft_c2c_kernel, plan.lds_bytes());
+    hipLaunchKernelGGL(fft_c2c_kernel, dim3(batch), dim3(FT), plan.lds_bytes(), ctx->stream, plan.dev, plan.perm_d.p, sign,
+                       reinterpret_cast<const float2 *>(in_dev), reinterpret_cast<float2 *>(out_dev));
+    SDRHIP_CHECK_HIP(hipGetLastError());
+    SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));   // the plan's tables die with this scope
+  });
+}
+
+}  // extern "C"

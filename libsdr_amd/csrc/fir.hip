@@ -1,0 +1,440 @@
+// fir.hip — K2: FIRFilter<complex<int16_t>> (bit-exact) and K3: FIRFilter<complex<float>>
+// (tolerance path, optional SubSample<complex<float>> folded in) with demodulator epilogues.
+//
+// Replaces (reference, file:line):
+//   FIRFilter<Scalar,Coeffs>::_process          src/firfilter.hh:231-247
+//   operator*(double, complex<int16>/<float>)    src/operators.hh:16-18,24-26
+//   SubSample<complex<float>>::_process          src/subsample.hh:92-101   (K3, decim > 1)
+//   FMDemod / AMDemod / USBDemod                 src/demod.hh:242-254, :73-76, :156-161
+//
+// K2 semantics are ORDER DEPENDENT: `out += alpha[j]*x` converts back to int16
+// after every tap, so per component   acc <- trunc_toward_zero( fl64(acc + fl64(alpha[j]*x)) )
+// for j = 0..order-1 in that order. One lane owns R consecutive outputs and walks the taps
+// sequentially in fp64 with contraction off (v_mul_f64, v_add_f64, v_trunc_f64); parallelism is
+// across outputs and channels only. acc stays an integer-valued double; the int16 wrap of the
+// reference can only trigger when sum|alpha| > 1, which selects the slower WRAP variant.
+//
+// K3 may reassociate (<= 1e-5 rel): taps are convolved with the 1/D box on the host in double
+// (beta = alpha (*) box_D / D) and the filter is evaluated only at the decimated instants.
+#include "sdrhip_internal.hpp"
+
+using namespace sdrhip;
+
+namespace {
+
+constexpr int TPB = 256;
+
+// ---------------------------------------------------------------------------------------------
+// shared epilogue helpers (int16)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int fm_phi(int a, int b) {   // fast_atan2<int16,int16>(a,b)/2, src/math.hh:31-40
+  if (a == 0 && b == 0) return 0;
+  const int aabs = a >= 0 ? a : -a;
+  int angle;
+  if (b >= 0) angle = 4096 - 4096 * (b - aabs) / (b + aabs);
+  else angle = 12288 - 4096 * (b + aabs) / (aabs - b);
+  const short at = (short)(a >= 0 ? angle : -angle);
+  return (int)at / 2;
+}
+__device__ __forceinline__ short am_i16(int re, int im) {
+  const int m = (int)((unsigned)(re * re) + (unsigned)(im * im));
+  return (short)(int)sqrt((double)m);
+}
+__device__ __forceinline__ short usb_i16(int re, int im) { return (short)((re + im) / 2); }
+
+// =============================================================================================
+// K2: exact complex<int16> FIR
+// =============================================================================================
+constexpr int R2 = 4;              // consecutive outputs per lane
+constexpr int T2 = TPB * R2;       // outputs computed per tile
+constexpr int U2 = 4;              // taps per unrolled chunk (order zero-padded at the front)
+
+struct Fir16Args {
+  const uint32_t *in; long in_stride;
+  const uint32_t *hist_old; uint32_t *hist_new; int HH;   // HH = OP-1 samples before the call
+  const short *fm_old; short *fm_new;
+  const double *alpha;   // OP taps, zero padded at the front
+  int OP, N, ovl, OT;    // OT = outputs emitted per tile = T2 - ovl
+  void *out; long out_stride; int epilogue;
+};
+
+__device__ __forceinline__ uint32_t load_x16(const Fir16Args &a, int c, int rel) {
+  if (rel >= 0) return rel < a.N ? a.in[(long)c * a.in_stride + rel] : 0u;
+  const int h = a.HH + rel;
+  return h >= 0 ? a.hist_old[(long)c * a.HH + h] : 0u;
+}
+
+template <bool WRAP>
+__device__ __forceinline__ double tap_step(double acc, double alpha, double x) {
+  // fl64(alpha*x), fl64(acc + .), trunc toward zero — no FMA (x86-64 reference has none)
+  double t = __builtin_trunc(__dadd_rn(acc, __dmul_rn(alpha, x)));
+  if (WRAP) t = (double)(short)(int)t;   // int16 <- int32 <- double, as gcc/x86-64 converts
+  return t;
+}
+
+template <bool WRAP>
+__global__ __launch_bounds__(TPB) void fir_cs16_exact_kernel(const Fir16Args a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const int XS = T2 + a.OP + 8;
+  uint32_t *xs = smem;            // xs[i] = x[tb-(OP-1)+i]
+  uint32_t *ybuf = smem + XS;     // T2 packed cs16 results
+
+  const int c = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+  const int tb = tile * a.OT - a.ovl;            // index of the tile's first computed output
+  const int outs_here = min(T2, a.N - tb);
+
+  {
+    const int first = tb - (a.OP - 1);
+    const int need = min(XS, outs_here + a.OP + 8);
+    for (int i = tid; i < need; i += TPB) xs[i] = load_x16(a, c, first + i);
+  }
+  __syncthreads();
+
+  if (R2 * tid < outs_here) {
+    double are[R2], aim[R2];
+#pragma unroll
+    for (int r = 0; r < R2; r++) { are[r] = 0.0; aim[r] = 0.0; }
+    // window of converted samples: wre/wim[k] = x[R2*tid + i0 + k], k = 0 .. R2+U2-2
+    double wre[R2 + U2], wim[R2 + U2];
+    const uint32_t *px = xs + R2 * tid;
+#pragma unroll
+    for (int k = 0; k < R2; k++) {
+      const uint32_t v = px[k];
+      wre[k] = (double)(short)(v & 0xffffu); wim[k] = (double)(short)(v >> 16);
+    }
+    const double *__restrict__ al = a.alpha;
+    for (int i0 = 0; i0 < a.OP; i0 += U2) {
+#pragma unroll
+      for (int k = 0; k < U2; k++) {
+        const uint32_t v = px[i0 + R2 + k];
+        wre[R2 + k] = (double)(short)(v & 0xffffu); wim[R2 + k] = (double)(short)(v >> 16);
+      }
+#pragma unroll
+      for (int u = 0; u < U2; u++) {
+        const double al_j = al[i0 + u];     // wave-uniform -> scalar load
+#pragma unroll
+        for (int r = 0; r < R2; r++) {
+          are[r] = tap_step<WRAP>(are[r], al_j, wre[u + r]);
+          aim[r] = tap_step<WRAP>(aim[r], al_j, wim[u + r]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < R2; k++) { wre[k] = wre[k + U2]; wim[k] = wim[k + U2]; }
+    }
+#pragma unroll
+    for (int r = 0; r < R2; r++) {
+      const int yr = (int)are[r], yi = (int)aim[r];
+      ybuf[R2 * tid + r] = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
+    }
+  }
+  __syncthreads();
+
+  for (int l = a.ovl + tid; l < outs_here; l += TPB) {
+    const int j = tb + l;
+    if (j < 0 || j >= a.N) continue;
+    const uint32_t y = ybuf[l];
+    const int yr = (short)(y & 0xffffu), yi = (short)(y >> 16);
+    if (a.epilogue == SDRHIP_EPI_NONE) {
+      reinterpret_cast<uint32_t *>(a.out)[(long)c * a.out_stride + j] = y;
+    } else {
+      short o;
+      if (a.epilogue == SDRHIP_EPI_AM) o = am_i16(yr, yi);
+      else if (a.epilogue == SDRHIP_EPI_USB) o = usb_i16(yr, yi);
+      else {
+        const int phi = fm_phi(yr, yi);
+        if (j == 0) o = (short)yr;
+        else {
+          int prev;
+          if (j == 1) prev = a.fm_old[c];
+          else { const uint32_t yp = ybuf[l - 1]; prev = fm_phi((short)(yp & 0xffffu), (short)(yp >> 16)); }
+          o = (short)(prev - phi);
+        }
+        if (j == a.N - 1 && a.N >= 2) a.fm_new[c] = (short)phi;
+      }
+      reinterpret_cast<short *>(a.out)[(long)c * a.out_stride + j] = o;
+    }
+  }
+
+  if (tile == (int)gridDim.x - 1) {
+    for (int k = tid; k < a.HH; k += TPB) {
+      const long qq = (long)a.N + k;
+      a.hist_new[(long)c * a.HH + k] =
+          qq < a.HH ? a.hist_old[(long)c * a.HH + qq] : a.in[(long)c * a.in_stride + (qq - a.HH)];
+    }
+  }
+}
+
+// =============================================================================================
+// K3: complex<float> FIR, decimation folded (outputs at absolute input indices g*D + D-1)
+// =============================================================================================
+constexpr int T3 = TPB;   // one output per lane and tile pass
+
+struct Fir32Args {
+  const float2 *in; long in_stride;
+  const float2 *hist_old; float2 *hist_new; int HH;   // HH = M-1
+  const float *beta;     // M folded taps (float), beta[M-1] meets the newest sample
+  int M, D, N;
+  int first_rel;   // call-relative index of the newest sample of the first output of this call
+  int n_out;
+  void *out; long out_stride; int epilogue;
+};
+
+__device__ __forceinline__ float2 load_x32(const Fir32Args &a, int c, int rel) {
+  if (rel >= 0) return rel < a.N ? a.in[(long)c * a.in_stride + rel] : make_float2(0.f, 0.f);
+  const int h = a.HH + rel;
+  return h >= 0 ? a.hist_old[(long)c * a.HH + h] : make_float2(0.f, 0.f);
+}
+
+__global__ __launch_bounds__(TPB) void fir_cf32_kernel(const Fir32Args a) {
+  extern __shared__ __attribute__((aligned(16))) float2 smemf[];
+  float2 *xs = smemf;   // xs[i] = x[base-(M-1)+i], base = newest sample of the tile's first output
+  const int c = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+  const int j0 = tile * T3;
+  const int outs_here = min(T3, a.n_out - j0);
+  const int base = a.first_rel + j0 * a.D;
+  if (outs_here > 0) {
+    const int need = (outs_here - 1) * a.D + a.M;
+    for (int i = tid; i < need; i += TPB) xs[i] = load_x32(a, c, base - (a.M - 1) + i);
+  }
+  __syncthreads();
+  if (tid < outs_here) {
+    const float2 *px = xs + tid * a.D;
+    const float *__restrict__ b = a.beta;
+    float sr0 = 0.f, si0 = 0.f, sr1 = 0.f, si1 = 0.f;
+    int m = 0;
+    for (; m + 1 < a.M; m += 2) {
+      const float2 x0 = px[m], x1 = px[m + 1];
+      const float b0 = b[m], b1 = b[m + 1];
+      sr0 = __builtin_fmaf(b0, x0.x, sr0); si0 = __builtin_fmaf(b0, x0.y, si0);
+      sr1 = __builtin_fmaf(b1, x1.x, sr1); si1 = __builtin_fmaf(b1, x1.y, si1);
+    }
+    if (m < a.M) { const float2 x0 = px[m]; const float b0 = b[m]; sr0 = __builtin_fmaf(b0, x0.x, sr0); si0 = __builtin_fmaf(b0, x0.y, si0); }
+    const float yr = sr0 + sr1, yi = si0 + si1;
+    const int j = j0 + tid;
+    if (a.epilogue == SDRHIP_EPI_NONE) reinterpret_cast<float2 *>(a.out)[(long)c * a.out_stride + j] = make_float2(yr, yi);
+    else if (a.epilogue == SDRHIP_EPI_AM) reinterpret_cast<float *>(a.out)[(long)c * a.out_stride + j] = sqrtf(yr * yr + yi * yi);
+    else reinterpret_cast<float *>(a.out)[(long)c * a.out_stride + j] = (yr + yi) / 2;
+  }
+}
+
+// history roll for K3 (separate tiny kernel: a call may produce zero outputs, i.e. zero tiles)
+__global__ void hist_roll_cf32(const float2 *in, long in_stride, const float2 *hist_old, float2 *hist_new, int HH, int N) {
+  const int c = blockIdx.y;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < HH; k += gridDim.x * blockDim.x) {
+    const long qq = (long)N + k;
+    hist_new[(long)c * HH + k] = qq < HH ? hist_old[(long)c * HH + qq] : in[(long)c * in_stride + (qq - HH)];
+  }
+}
+
+}  // namespace
+
+struct sdrhip_fir {
+  sdrhip_ctx *ctx = nullptr;
+  int kind = 0, order = 0, D = 1, C = 1, epi = 0;
+  size_t max_in = 0, max_out = 0;
+  uint64_t n0 = 0;
+  int par = 0, par_fm = 0;
+  // K2
+  int OP = 0, HH = 0, ovl = 0;
+  bool wrap = false;
+  DevBuf<double> alpha;
+  DevBuf<uint32_t> hist16[2];
+  DevBuf<short> fm[2];
+  // K3
+  int M = 0;
+  DevBuf<float> beta;
+  DevBuf<float2> hist32[2];
+  // staging
+  DevBuf<uint8_t> stage_in, stage_out;
+
+  size_t in_elem() const { return kind == SDRHIP_FIR_CS16_EXACT ? 4 : 8; }
+  size_t out_elem() const {
+    if (kind == SDRHIP_FIR_CS16_EXACT) return epi == SDRHIP_EPI_NONE ? 4 : 2;
+    return epi == SDRHIP_EPI_NONE ? 8 : 4;
+  }
+  // SubSample emits after every D-th input counted from the last reset (src/subsample.hh:94-99)
+  size_t out_count(size_t N) const { return (size_t)((n0 + N) / (uint64_t)D - n0 / (uint64_t)D); }
+
+  void launch(const void *in_dev, size_t N, size_t in_stride, void *out_dev, size_t out_stride, size_t *n_out) {
+    ctx->use();
+    if (N == 0) { if (n_out) *n_out = 0; return; }
+    const size_t no = out_count(N);
+    SDRHIP_REQUIRE(out_stride >= no, SDRHIP_E_SIZE, "out_stride %zu < outputs %zu", out_stride, no);
+    if (kind == SDRHIP_FIR_CS16_EXACT) {
+      Fir16Args a;
+      a.in = (const uint32_t *)in_dev; a.in_stride = (long)in_stride;
+      a.hist_old = hist16[par].p; a.hist_new = hist16[par ^ 1].p; a.HH = HH;
+      a.fm_old = fm[par_fm].p; a.fm_new = fm[par_fm ^ 1].p;
+      a.alpha = alpha.p; a.OP = OP; a.N = (int)N; a.ovl = ovl; a.OT = T2 - ovl;
+      a.out = out_dev; a.out_stride = (long)out_stride; a.epilogue = epi;
+      const int tiles = (int)ceil_div(N, (size_t)a.OT);
+      const size_t lds = ((size_t)T2 + OP + 8 + T2) * 4;
+      dim3 grid(tiles, C), block(TPB);
+      if (wrap) hipLaunchKernelGGL(fir_cs16_exact_kernel<true>, grid, block, lds, ctx->stream, a);
+      else hipLaunchKernelGGL(fir_cs16_exact_kernel<false>, grid, block, lds, ctx->stream, a);
+      SDRHIP_CHECK_HIP(hipGetLastError());
+      if (epi == SDRHIP_EPI_FM && N >= 2) par_fm ^= 1;
+    } else {
+      Fir32Args a;
+      a.in = (const float2 *)in_dev; a.in_stride = (long)in_stride;
+      a.hist_old = hist32[par].p; a.hist_new = hist32[par ^ 1].p; a.HH = M - 1;
+      a.beta = beta.p; a.M = M; a.D = D; a.N = (int)N;
+      // first output of this call: group g = n0/D completes at absolute index g*D + D-1 >= n0
+      const uint64_t g = n0 / (uint64_t)D;
+      a.first_rel = (int)((int64_t)(g * D + D - 1) - (int64_t)n0);
+      a.n_out = (int)no;
+      a.out = out_dev; a.out_stride = (long)out_stride; a.epilogue = epi;
+      if (no) {
+        const int tiles = (int)ceil_div(no, (size_t)T3);
+        const size_t lds = ((size_t)(T3 - 1) * D + M) * sizeof(float2);
+        dim3 grid(tiles, C), block(TPB);
+        hipLaunchKernelGGL(fir_cf32_kernel, grid, block, lds, ctx->stream, a);
+        SDRHIP_CHECK_HIP(hipGetLastError());
+      }
+      if (M > 1) {
+        dim3 grid((unsigned)ceil_div((size_t)(M - 1), (size_t)256), C);
+        hipLaunchKernelGGL(hist_roll_cf32, grid, dim3(256), 0, ctx->stream, a.in, a.in_stride, a.hist_old, a.hist_new, M - 1, (int)N);
+        SDRHIP_CHECK_HIP(hipGetLastError());
+      }
+    }
+    par ^= 1;
+    n0 += N;
+    if (n_out) *n_out = no;
+  }
+};
+
+extern "C" {
+
+int sdrhip_fir_create(sdrhip_ctx *ctx, int kind, const double *alpha, int order, int decim, int channels,
+                      size_t max_in, int epilogue, sdrhip_fir **out) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(ctx && alpha && out, SDRHIP_E_INVALID, "NULL argument");
+    *out = nullptr;
+    SDRHIP_REQUIRE(kind == SDRHIP_FIR_CS16_EXACT || kind == SDRHIP_FIR_CF32, SDRHIP_E_INVALID, "bad kind %d", kind);
+    SDRHIP_REQUIRE(order >= 1 && order <= 8192, SDRHIP_E_UNSUPPORTED, "order %d outside [1,8192]", order);
+    SDRHIP_REQUIRE(decim >= 1, SDRHIP_E_INVALID, "decim %d < 1", decim);
+    SDRHIP_REQUIRE(channels >= 1 && channels <= 65535, SDRHIP_E_INVALID, "channels %d outside [1,65535]", channels);
+    SDRHIP_REQUIRE(max_in >= 1 && max_in < (size_t(1) << 30), SDRHIP_E_SIZE, "max_in %zu outside [1,2^30)", max_in);
+    SDRHIP_REQUIRE(epilogue >= SDRHIP_EPI_NONE && epilogue <= SDRHIP_EPI_USB, SDRHIP_E_INVALID, "bad epilogue %d", epilogue);
+    if (kind == SDRHIP_FIR_CS16_EXACT)
+      SDRHIP_REQUIRE(decim == 1, SDRHIP_E_UNSUPPORTED, "the exact int16 FIR does not decimate (chain a SubSample)");
+    else
+      SDRHIP_REQUIRE(epilogue != SDRHIP_EPI_FM, SDRHIP_E_UNSUPPORTED,
+                     "FMDemod<float> does not exist in the reference (fast_atan2 has no float form)");
+    ctx->use();
+    sdrhip_fir *h = new sdrhip_fir;
+    try {
+      h->ctx = ctx; h->kind = kind; h->order = order; h->D = decim; h->C = channels; h->epi = epilogue;
+      h->max_in = max_in; h->max_out = max_in / decim + 1;
+      if (kind == SDRHIP_FIR_CS16_EXACT) {
+        h->OP = (int)ceil_div((size_t)order, (size_t)U2) * U2;
+        h->HH = h->OP - 1;
+        h->ovl = epilogue == SDRHIP_EPI_FM ? 1 : 0;
+        SDRHIP_REQUIRE(((size_t)T2 + h->OP + 8 + T2) * 4 <= 64 * 1024, SDRHIP_E_UNSUPPORTED, "order %d exceeds the LDS tile", order);
+        std::vector<double> ap(h->OP, 0.0);
+        double P = 0, Q = 0;   // sum of the positive / |negative| taps
+        for (int i = 0; i < order; i++) {
+          ap[h->OP - order + i] = alpha[i];
+          if (alpha[i] >= 0) P += alpha[i]; else Q -= alpha[i];
+        }
+        // Truncation toward zero never grows a partial sum, so |acc| <= sum |alpha_k x_k| with
+        // x in [-32768, 32767]. The int16 wrap of the reference can only trigger if a partial sum
+        // can reach +32768 or go below -32768; otherwise acc stays in range and the wrap is skipped.
+        const bool pos_ok = 32767.0 * P + 32768.0 * Q < 32768.0 - 1e-6;
+        const bool neg_ok = 32768.0 * P + 32767.0 * Q < 32769.0 - 1e-6;
+        h->wrap = !(pos_ok && neg_ok) || !(P == P && Q == Q);
+        h->alpha.alloc(h->OP); h->alpha.upload(ap.data(), h->OP, ctx->stream);
+        for (int p = 0; p < 2; p++) {
+          h->hist16[p].alloc((size_t)channels * h->HH); h->hist16[p].zero(ctx->stream);
+          h->fm[p].alloc(channels); h->fm[p].zero(ctx->stream);
+        }
+      } else {
+        // beta[m] = (1/D) * sum_k alpha[m-k], k in [0,D): FIR followed by the D-sample box average
+        h->M = order + decim - 1;
+        SDRHIP_REQUIRE(((size_t)(T3 - 1) * decim + h->M) * 8 <= 64 * 1024, SDRHIP_E_UNSUPPORTED,
+                       "order %d with decim %d exceeds the LDS tile", order, decim);
+        std::vector<float> b(h->M);
+        for (int m = 0; m < h->M; m++) {
+          double s = 0;
+          for (int k = 0; k < decim; k++) { const int i = m - k; if (i >= 0 && i < order) s += alpha[i]; }
+          b[m] = (float)(s / decim);
+        }
+        h->beta.alloc(h->M); h->beta.upload(b.data(), h->M, ctx->stream);
+        for (int p = 0; p < 2; p++) {
+          h->hist32[p].alloc((size_t)channels * std::max(1, h->M - 1)); h->hist32[p].zero(ctx->stream);
+        }
+      }
+      SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    } catch (...) { delete h; throw; }
+    *out = h;
+  });
+}
+
+int sdrhip_fir_out_count(sdrhip_fir *h, size_t n_in, size_t *n_out) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h && n_out, SDRHIP_E_INVALID, "NULL argument");
+    *n_out = h->out_count(n_in);
+  });
+}
+
+int sdrhip_fir_process_dev(sdrhip_fir *h, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev,
+                           size_t out_stride, size_t *n_out) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
+    SDRHIP_REQUIRE(n_in <= h->max_in, SDRHIP_E_SIZE, "n_in %zu > max_in %zu", n_in, h->max_in);
+    if (n_in == 0) { if (n_out) *n_out = 0; return; }
+    SDRHIP_REQUIRE(in_dev && out_dev, SDRHIP_E_INVALID, "NULL buffer");
+    if (in_stride == 0) in_stride = n_in;
+    SDRHIP_REQUIRE(in_stride >= n_in, SDRHIP_E_SIZE, "in_stride %zu < n_in %zu", in_stride, n_in);
+    if (out_stride == 0) out_stride = h->out_count(n_in);
+    h->launch(in_dev, n_in, in_stride, out_dev, out_stride, n_out);
+  });
+}
+
+int sdrhip_fir_process(sdrhip_fir *h, const void *in_host, size_t n_in, size_t in_stride, void *out_host,
+                       size_t out_stride, size_t *n_out) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
+    SDRHIP_REQUIRE(n_in <= h->max_in, SDRHIP_E_SIZE, "n_in %zu > max_in %zu", n_in, h->max_in);
+    if (n_in == 0) { if (n_out) *n_out = 0; return; }
+    SDRHIP_REQUIRE(in_host && out_host, SDRHIP_E_INVALID, "NULL buffer");
+    h->ctx->use();
+    if (in_stride == 0) in_stride = n_in;
+    const size_t no = h->out_count(n_in);
+    if (out_stride == 0) out_stride = no;
+    SDRHIP_REQUIRE(out_stride >= no, SDRHIP_E_SIZE, "out_stride %zu < outputs %zu", out_stride, no);
+    const size_t ib = h->in_elem(), ob = h->out_elem();
+    if (!h->stage_in.p) {
+      h->stage_in.alloc((size_t)h->C * h->max_in * ib);
+      h->stage_out.alloc((size_t)h->C * h->max_out * ob);
+    }
+    copy_h2d_rows(h->ctx, h->stage_in.p, n_in * ib, in_host, in_stride * ib, n_in * ib, h->C);
+    size_t produced = 0;
+    h->launch(h->stage_in.p, n_in, n_in, h->stage_out.p, h->max_out, &produced);
+    copy_d2h_rows(h->ctx, out_host, out_stride * ob, h->stage_out.p, h->max_out * ob, produced * ob, h->C);
+    SDRHIP_CHECK_HIP(hipStreamSynchronize(h->ctx->stream));
+    if (n_out) *n_out = produced;
+  });
+}
+
+int sdrhip_fir_reset(sdrhip_fir *h) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
+    h->ctx->use();
+    h->n0 = 0;
+    for (int p = 0; p < 2; p++) {
+      h->hist16[p].zero(h->ctx->stream); h->hist32[p].zero(h->ctx->stream); h->fm[p].zero(h->ctx->stream);
+    }
+  });
+}
+
+int sdrhip_fir_destroy(sdrhip_fir *h) {
+  return guarded([&] {
+    if (!h) return;
+    h->ctx->use();
+    (void)hipStreamSynchronize(h->ctx->stream);
+    delete h;
+  });
+}
+
+}  // extern "C"

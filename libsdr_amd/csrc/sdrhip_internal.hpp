@@ -1,0 +1,116 @@
+// sdrhip_internal.hpp — shared plumbing of libsdrhip.so (context, error handling, device buffers).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "sdrhip.h"
+
+namespace sdrhip {
+
+void set_error(const char *fmt, ...);
+
+struct Failure {
+  int code;
+};
+
+#define SDRHIP_FAIL(code_, ...)                 \
+  do {                                          \
+    ::sdrhip::set_error(__VA_ARGS__);           \
+    throw ::sdrhip::Failure{code_};             \
+  } while (0)
+
+#define SDRHIP_CHECK_HIP(expr)                                                              \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) {                                                                 \
+      int c_ = (e_ == hipErrorOutOfMemory) ? SDRHIP_E_NOMEM                                 \
+               : (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? SDRHIP_E_NODEVICE \
+                                                                         : SDRHIP_E_HIP;    \
+      SDRHIP_FAIL(c_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    }                                                                                       \
+  } while (0)
+
+#define SDRHIP_REQUIRE(cond, code_, ...) \
+  do {                                   \
+    if (!(cond)) SDRHIP_FAIL(code_, __VA_ARGS__); \
+  } while (0)
+
+// wraps every extern "C" entry point: C++ failures become error codes, nothing escapes
+template <class F>
+static inline int guarded(F &&f) {
+  try {
+    f();
+    return SDRHIP_OK;
+  } catch (const Failure &e) {
+    return e.code;
+  } catch (const std::bad_alloc &) {
+    set_error("host allocation failed");
+    return SDRHIP_E_NOMEM;
+  } catch (...) {
+    set_error("unexpected C++ exception");
+    return SDRHIP_E_INVALID;
+  }
+}
+
+}  // namespace sdrhip
+
+struct sdrhip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipDeviceProp_t prop;
+  void use() const;  // hipSetDevice
+};
+
+struct sdrhip_timer {
+  sdrhip_ctx *ctx;
+  hipEvent_t a, b;
+};
+
+namespace sdrhip {
+
+// RAII device allocation bound to a context
+template <class T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  DevBuf() {}
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { release(); }
+  void alloc(size_t count) {
+    release();
+    n = count;
+    if (count) SDRHIP_CHECK_HIP(hipMalloc((void **)&p, count * sizeof(T)));
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  void zero(hipStream_t s) {
+    if (p) SDRHIP_CHECK_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s));
+  }
+  void upload(const T *h, size_t count, hipStream_t s) {
+    SDRHIP_CHECK_HIP(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, s));
+    SDRHIP_CHECK_HIP(hipStreamSynchronize(s));
+  }
+};
+
+// staging for the host-pointer entry points: 2-D copies between a strided host layout and a
+// packed device layout
+void copy_h2d_rows(const sdrhip_ctx *ctx, void *dst_dev, size_t dst_pitch_b, const void *src_host,
+                   size_t src_pitch_b, size_t row_bytes, size_t rows);
+void copy_d2h_rows(const sdrhip_ctx *ctx, void *dst_host, size_t dst_pitch_b, const void *src_dev,
+                   size_t src_pitch_b, size_t row_bytes, size_t rows);
+
+static inline size_t ceil_div(size_t a, size_t b) { return (a + b - 1) / b; }
+
+}  // namespace sdrhip

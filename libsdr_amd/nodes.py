@@ -1,0 +1,388 @@
+"""Thin numpy-facing wrappers over the C ABI (libsdr_amd.abi) — the Python mirror of the C++ nodes in
+include/sdr/gpu/*.hh, used by tests/ and bench.py.
+
+Every class maps 1:1 to a handle type of include/sdrhip.h; `process(x)` takes/returns numpy arrays in
+the channel-major layout [channels, n, 2] (complex as (re, im)), `process_dev(ptr, ...)` takes raw
+device pointers (e.g. torch tensors' data_ptr()). No CPU fallback exists: constructing a Context
+without a HIP device raises SdrHipError(E_NODEVICE).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from .abi import (EPI_NONE, EPI_FM, EPI_AM, EPI_USB, FIR_CS16_EXACT, FIR_CF32, T_CS16, T_CF32,
+                  FFTCONV_OLA, FFTCONV_OLS, check)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ---- designers (host only; identical code to include/sdr/gpu/design.hh) -----------------------
+
+def design_iqbb_taps(Ff, width, Fs, order):
+    t = np.zeros((order, 2), np.int32)
+    check(abi.lib().sdrhip_design_iqbb_taps(Ff, width, Fs, order, t.ctypes.data_as(C.POINTER(C.c_int32))))
+    return t
+
+
+def design_iqbb_decim(Fs, sub, oFs=0.0):
+    d = C.c_int(0)
+    check(abi.lib().sdrhip_design_iqbb_decim(Fs, sub, oFs, C.byref(d)))
+    return d.value
+
+
+def design_freqshift_lut_i16():
+    t = np.zeros((128, 2), np.int32)
+    check(abi.lib().sdrhip_design_freqshift_lut_i16(t.ctypes.data_as(C.POINTER(C.c_int32))))
+    return t
+
+
+def design_freqshift_inc(F, Fs):
+    v = C.c_uint32(0)
+    check(abi.lib().sdrhip_design_freqshift_inc(F, Fs, C.byref(v)))
+    return v.value
+
+
+def design_fir_lowpass(order, Fu, Fs):
+    a = np.zeros(order, np.float64)
+    check(abi.lib().sdrhip_design_fir_lowpass(order, Fu, Fs, a.ctypes.data_as(C.POINTER(C.c_double))))
+    return a
+
+
+def design_fftfilt_kernel(N, fmin, fmax, Fs):
+    h = np.zeros((N, 2), np.float32)
+    check(abi.lib().sdrhip_design_fftfilt_kernel(N, fmin, fmax, Fs, h.ctypes.data_as(C.POINTER(C.c_float))))
+    return h
+
+
+def design_fftfilt_spectrum(h):
+    h = np.ascontiguousarray(h, np.float32).reshape(-1, 2)
+    K = np.zeros((2 * h.shape[0], 2), np.float32)
+    check(abi.lib().sdrhip_design_fftfilt_spectrum(h.shape[0], h.ctypes.data_as(C.POINTER(C.c_float)),
+                                                   K.ctypes.data_as(C.POINTER(C.c_float))))
+    return K
+
+
+# ---- context ------------------------------------------------------------------------------------
+
+def device_count():
+    n = C.c_int(0)
+    check(abi.lib().sdrhip_device_count(C.byref(n)))
+    return n.value
+
+
+class Context:
+    def __init__(self, device=0, stream=None):
+        self._h = C.c_void_p()
+        check(abi.lib().sdrhip_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h)))
+        self.device = device
+
+    @property
+    def handle(self):
+        return self._h
+
+    def synchronize(self):
+        check(abi.lib().sdrhip_ctx_synchronize(self._h))
+
+    def device_name(self):
+        b = C.create_string_buffer(256)
+        check(abi.lib().sdrhip_ctx_device_name(self._h, b, 256))
+        return b.value.decode()
+
+    def malloc(self, nbytes):
+        p = C.c_void_p()
+        check(abi.lib().sdrhip_malloc(self._h, nbytes, C.byref(p)))
+        return p.value
+
+    def free(self, p):
+        check(abi.lib().sdrhip_free(self._h, C.c_void_p(p)))
+
+    def h2d(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        check(abi.lib().sdrhip_memcpy_h2d(self._h, C.c_void_p(dptr), _ptr(arr), arr.nbytes))
+
+    def d2h(self, arr, dptr):
+        assert arr.flags["C_CONTIGUOUS"]
+        check(abi.lib().sdrhip_memcpy_d2h(self._h, _ptr(arr), C.c_void_p(dptr), arr.nbytes))
+
+    def memset(self, dptr, value, nbytes):
+        check(abi.lib().sdrhip_memset(self._h, C.c_void_p(dptr), value, nbytes))
+
+    def close(self):
+        if self._h:
+            abi.lib().sdrhip_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Timer:
+    """HIP events on the context's stream."""
+
+    def __init__(self, ctx):
+        self._h = C.c_void_p()
+        check(abi.lib().sdrhip_timer_create(ctx.handle, C.byref(self._h)))
+
+    def start(self):
+        check(abi.lib().sdrhip_timer_start(self._h))
+
+    def stop(self):
+        check(abi.lib().sdrhip_timer_stop(self._h))
+
+    def elapsed_ms(self):
+        ms = C.c_float(0)
+        check(abi.lib().sdrhip_timer_elapsed_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        if self._h:
+            abi.lib().sdrhip_timer_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+class _Node:
+    _destroy = None
+
+    def __init__(self):
+        self._h = C.c_void_p()
+
+    def close(self):
+        if self._h:
+            getattr(abi.lib(), self._destroy)(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _as3(x, dtype, comps=2):
+    x = np.ascontiguousarray(x, dtype)
+    if x.ndim == 2:
+        x = x[None]
+    assert x.ndim == 3 and x.shape[2] == comps, x.shape
+    return x
+
+
+class IQBaseBandI16(_Node):
+    """K1 — IQBaseBand<int16_t> (+ fused FM/AM/USB). Mirrors sdr::gpu::IQBaseBand<int16_t>."""
+    _destroy = "sdrhip_iqbb_i16_destroy"
+
+    def __init__(self, ctx, taps, lut, lut_inc, negative, decim, channels=1, max_in=65536, epilogue=EPI_NONE):
+        super().__init__()
+        taps = np.ascontiguousarray(taps, np.int32).reshape(-1, 2)
+        lut = np.ascontiguousarray(lut, np.int32).reshape(128, 2)
+        self.ctx, self.channels, self.decim, self.epilogue, self.max_in = ctx, channels, decim, epilogue, max_in
+        check(abi.lib().sdrhip_iqbb_i16_create(ctx.handle, taps.ctypes.data_as(C.POINTER(C.c_int32)), taps.shape[0],
+                                               lut.ctypes.data_as(C.POINTER(C.c_int32)), lut_inc, int(bool(negative)),
+                                               decim, channels, max_in, epilogue, C.byref(self._h)))
+
+    def out_count(self, n_in):
+        n = C.c_size_t(0)
+        check(abi.lib().sdrhip_iqbb_i16_out_count(self._h, n_in, C.byref(n)))
+        return n.value
+
+    def process(self, x):
+        x = _as3(x, np.int16)
+        assert x.shape[0] == self.channels
+        n_in = x.shape[1]
+        no = self.out_count(n_in)
+        if self.epilogue == EPI_NONE:
+            out = np.zeros((self.channels, no, 2), np.int16)
+        else:
+            out = np.zeros((self.channels, no), np.int16)
+        got = C.c_size_t(0)
+        check(abi.lib().sdrhip_iqbb_i16_process(self._h, _ptr(x), n_in, n_in, _ptr(out), no, C.byref(got)))
+        assert got.value == no
+        return out
+
+    def process_dev(self, in_ptr, n_in, in_stride, out_ptr, out_stride):
+        got = C.c_size_t(0)
+        check(abi.lib().sdrhip_iqbb_i16_process_dev(self._h, C.c_void_p(in_ptr), n_in, in_stride, C.c_void_p(out_ptr),
+                                                    out_stride, C.byref(got)))
+        return got.value
+
+    def reset(self, keep_history=False):
+        check(abi.lib().sdrhip_iqbb_i16_reset(self._h, int(keep_history)))
+
+
+class FIR(_Node):
+    """K2/K3 — FIRFilter<complex<int16>> exact / FIRFilter<complex<float>> (+ folded SubSample, + demod)."""
+    _destroy = "sdrhip_fir_destroy"
+
+    def __init__(self, ctx, kind, alpha, decim=1, channels=1, max_in=65536, epilogue=EPI_NONE):
+        super().__init__()
+        alpha = np.ascontiguousarray(alpha, np.float64)
+        self.ctx, self.kind, self.channels, self.decim, self.epilogue = ctx, kind, channels, decim, epilogue
+        check(abi.lib().sdrhip_fir_create(ctx.handle, kind, alpha.ctypes.data_as(C.POINTER(C.c_double)), alpha.shape[0],
+                                          decim, channels, max_in, epilogue, C.byref(self._h)))
+
+    def out_count(self, n_in):
+        n = C.c_size_t(0)
+        check(abi.lib().sdrhip_fir_out_count(self._h, n_in, C.byref(n)))
+        return n.value
+
+    def process(self, x):
+        it = np.int16 if self.kind == FIR_CS16_EXACT else np.float32
+        x = _as3(x, it)
+        n_in = x.shape[1]
+        no = self.out_count(n_in)
+        out = np.zeros((self.channels, no, 2) if self.epilogue == EPI_NONE else (self.channels, no), it)
+        got = C.c_size_t(0)
+        check(abi.lib().sdrhip_fir_process(self._h, _ptr(x), n_in, n_in, _ptr(out), no, C.byref(got)))
+        assert got.value == no
+        return out
+
+    def process_dev(self, in_ptr, n_in, in_stride, out_ptr, out_stride):
+        got = C.c_size_t(0)
+        check(abi.lib().sdrhip_fir_process_dev(self._h, C.c_void_p(in_ptr), n_in, in_stride, C.c_void_p(out_ptr),
+                                               out_stride, C.byref(got)))
+        return got.value
+
+    def reset(self):
+        check(abi.lib().sdrhip_fir_reset(self._h))
+
+
+class Demod(_Node):
+    """K4/K5 — stand-alone FMDemod<int16_t> / AMDemod / USBDemod."""
+    _destroy = "sdrhip_demod_destroy"
+
+    def __init__(self, ctx, kind, dtype=T_CS16, channels=1, max_in=65536, inplace_fm0=True):
+        super().__init__()
+        self.ctx, self.kind, self.dtype, self.channels = ctx, kind, dtype, channels
+        check(abi.lib().sdrhip_demod_create(ctx.handle, kind, dtype, channels, max_in, int(inplace_fm0), C.byref(self._h)))
+
+    def process(self, x, out=None):
+        it = np.int16 if self.dtype == T_CS16 else np.float32
+        x = _as3(x, it)
+        n = x.shape[1]
+        if out is None:
+            out = np.zeros((self.channels, n), it)
+        check(abi.lib().sdrhip_demod_process(self._h, _ptr(x), n, n, _ptr(out), n))
+        return out
+
+    def process_dev(self, in_ptr, n, in_stride, out_ptr, out_stride):
+        check(abi.lib().sdrhip_demod_process_dev(self._h, C.c_void_p(in_ptr), n, in_stride, C.c_void_p(out_ptr), out_stride))
+
+    def reset(self):
+        check(abi.lib().sdrhip_demod_reset(self._h))
+
+
+class SubSample(_Node):
+    """K6 — SubSample<complex<int16>|complex<float>>."""
+    _destroy = "sdrhip_subsample_destroy"
+
+    def __init__(self, ctx, dtype, n, channels=1, max_in=65536):
+        super().__init__()
+        self.ctx, self.dtype, self.n, self.channels = ctx, dtype, n, channels
+        check(abi.lib().sdrhip_subsample_create(ctx.handle, dtype, n, channels, max_in, C.byref(self._h)))
+
+    def out_count(self, n_in):
+        n = C.c_size_t(0)
+        check(abi.lib().sdrhip_subsample_out_count(self._h, n_in, C.byref(n)))
+        return n.value
+
+    def process(self, x):
+        it = np.int16 if self.dtype == T_CS16 else np.float32
+        x = _as3(x, it)
+        n_in = x.shape[1]
+        no = self.out_count(n_in)
+        out = np.zeros((self.channels, no, 2), it)
+        got = C.c_size_t(0)
+        check(abi.lib().sdrhip_subsample_process(self._h, _ptr(x), n_in, n_in, _ptr(out), no, C.byref(got)))
+        assert got.value == no
+        return out
+
+    def process_dev(self, in_ptr, n_in, in_stride, out_ptr, out_stride):
+        got = C.c_size_t(0)
+        check(abi.lib().sdrhip_subsample_process_dev(self._h, C.c_void_p(in_ptr), n_in, in_stride, C.c_void_p(out_ptr),
+                                                     out_stride, C.byref(got)))
+        return got.value
+
+    def reset(self):
+        check(abi.lib().sdrhip_subsample_reset(self._h))
+
+
+class FFTConv(_Node):
+    """K7 — FilterSink+FilterSource (mode OLA, kernel = 2N spectrum) or overlap-save with taps (mode OLS)."""
+    _destroy = "sdrhip_fftconv_destroy"
+
+    def __init__(self, ctx, mode, fft_size, kernel, channels=1, max_in=65536):
+        super().__init__()
+        kernel = np.ascontiguousarray(kernel, np.float32).reshape(-1, 2)
+        self.ctx, self.mode, self.fft_size, self.channels = ctx, mode, fft_size, channels
+        check(abi.lib().sdrhip_fftconv_create(ctx.handle, mode, fft_size, kernel.ctypes.data_as(C.POINTER(C.c_float)),
+                                              kernel.shape[0], channels, max_in, C.byref(self._h)))
+
+    def process(self, x):
+        x = _as3(x, np.float32)
+        n = x.shape[1]
+        out = np.zeros_like(x)
+        check(abi.lib().sdrhip_fftconv_process(self._h, _ptr(x), n, n, _ptr(out), n))
+        return out
+
+    def process_dev(self, in_ptr, n, in_stride, out_ptr, out_stride):
+        check(abi.lib().sdrhip_fftconv_process_dev(self._h, C.c_void_p(in_ptr), n, in_stride, C.c_void_p(out_ptr), out_stride))
+
+    def reset(self):
+        check(abi.lib().sdrhip_fftconv_reset(self._h))
+
+
+class FloatBaseBand(_Node):
+    """Build-defined float baseband (BASELINE config 2): shift -> FIR(cf32) -> /D."""
+    _destroy = "sdrhip_fbb_f32_destroy"
+
+    def __init__(self, ctx, Fc, Fs, alpha, decim, channels=1, max_in=65536):
+        super().__init__()
+        alpha = np.ascontiguousarray(alpha, np.float64)
+        self.ctx, self.channels, self.decim = ctx, channels, decim
+        check(abi.lib().sdrhip_fbb_f32_create(ctx.handle, Fc, Fs, alpha.ctypes.data_as(C.POINTER(C.c_double)),
+                                              alpha.shape[0], decim, channels, max_in, C.byref(self._h)))
+
+    def out_count(self, n_in):
+        n = C.c_size_t(0)
+        check(abi.lib().sdrhip_fbb_f32_out_count(self._h, n_in, C.byref(n)))
+        return n.value
+
+    def process(self, x):
+        x = _as3(x, np.float32)
+        n_in = x.shape[1]
+        no = self.out_count(n_in)
+        out = np.zeros((self.channels, no, 2), np.float32)
+        got = C.c_size_t(0)
+        check(abi.lib().sdrhip_fbb_f32_process(self._h, _ptr(x), n_in, n_in, _ptr(out), no, C.byref(got)))
+        assert got.value == no
+        return out
+
+    def process_dev(self, in_ptr, n_in, in_stride, out_ptr, out_stride):
+        got = C.c_size_t(0)
+        check(abi.lib().sdrhip_fbb_f32_process_dev(self._h, C.c_void_p(in_ptr), n_in, in_stride, C.c_void_p(out_ptr),
+                                                   out_stride, C.byref(got)))
+        return got.value
+
+    def reset(self):
+        check(abi.lib().sdrhip_fbb_f32_reset(self._h))
+
+
+def fft_c2c(ctx, x, sign):
+    """Batched DFT with the library's own in-LDS FFT (test hook)."""
+    x = np.ascontiguousarray(x, np.float32)
+    batch, n = x.shape[0], x.shape[1]
+    din, dout = ctx.malloc(x.nbytes), ctx.malloc(x.nbytes)
+    try:
+        ctx.h2d(din, x)
+        check(abi.lib().sdrhip_fft_c2c(ctx.handle, n, sign, batch, C.c_void_p(din), C.c_void_p(dout)))
+        out = np.zeros_like(x)
+        ctx.d2h(out, dout)
+    finally:
+        ctx.free(din)
+        ctx.free(dout)
+    return out

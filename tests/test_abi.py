@@ -1,0 +1,76 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/sdrhip.h declares,
+its host-only designers match the golden vectors, and it fails loudly (no CPU fallback) when there
+is no GPU.  No device compute here."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from libsdr_amd import abi, nodes
+
+
+def test_library_exports_every_declared_symbol():
+    L = abi.lib()
+    declared = abi.header_functions()
+    assert len(declared) >= 60
+    missing = [f for f in declared if not hasattr(L, f)]
+    assert not missing, missing
+    # the binding declares a prototype for every header function and nothing else
+    assert sorted(L._declared) == declared
+    assert L.sdrhip_version() == 100
+
+
+def test_library_is_hip_code_for_gfx950():
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", abi.SO_PATH], capture_output=True, text=True)
+    blob = open(abi.SO_PATH, "rb").read()
+    assert b"gfx950" in blob, out.stdout[:200]
+    for k in (b"iqbb_i16_kernel", b"fir_cs16_exact_kernel", b"fftconv_kernel"):
+        assert k in blob
+
+
+def test_strerror_and_errors_without_device():
+    L = abi.lib()
+    assert L.sdrhip_strerror(0) == b"ok" and b"device" in L.sdrhip_strerror(abi.E_NODEVICE)
+    if nodes.device_count() == 0:
+        with pytest.raises(abi.SdrHipError) as e:
+            nodes.Context(0)
+        assert e.value.code == abi.E_NODEVICE and "no CPU fallback" in str(e.value)
+
+
+@pytest.mark.parametrize("case", ["g3_iqbb127d8", "g8_neg_o16_d1", "g8_o21_d3", "g8_o33_d5", "g8_o16_d4_even",
+                                  "g8_o255_d8", "g8_noshift_o21_d8", "g8_ofs_d300"])
+def test_product_designers_iqbb(golden, case):
+    m = golden.meta(case + "_taps")
+    assert np.array_equal(nodes.design_iqbb_taps(m["Ff"], m["width"], m["Fs"], m["order"]).ravel(), golden.load(case + "_taps"))
+    assert np.array_equal(nodes.design_freqshift_lut_i16().ravel(), golden.load(case + "_lut"))
+    assert nodes.design_freqshift_inc(m["Fc"], m["Fs"]) == m["lut_inc"]
+    assert nodes.design_iqbb_decim(m["Fs"], m["sub"], m["oFs"]) == m["decim"]
+
+
+@pytest.mark.parametrize("N", [127, 255, 4097])
+def test_product_designers_fir(golden, N):
+    assert np.array_equal(nodes.design_fir_lowpass(N, 100e3, 2.4e6), golden.load("g2_firlp_alpha%d" % N))
+
+
+@pytest.mark.parametrize("N", [1024, 8192])
+def test_product_designers_fftfilt(golden, orc, N):
+    h = nodes.design_fftfilt_kernel(N, 50e3, 150e3, 2.4e6)
+    assert np.array_equal(h, golden.load("g7_fftfilt_h%d" % N))
+    K = nodes.design_fftfilt_spectrum(h)
+    Ko = orc.fftfilt_design_K(h)
+    assert np.abs(K - Ko).max() <= 1e-6 * np.abs(Ko).max()
+
+
+def test_no_oracle_in_product_path():
+    """The product (libsdr_amd/, include/) must never reach into oracle/."""
+    root = abi.ROOT
+    for base in ("libsdr_amd", "include"):
+        for dp, _, fs in os.walk(os.path.join(root, base)):
+            for f in fs:
+                if f.endswith((".py", ".hip", ".hpp", ".hh", ".h", ".cc", "Makefile")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    assert "pyoracle" not in txt and "liboracle" not in txt and "sdr_oracle" not in txt, f
+    needed = subprocess.run(["ldd", abi.SO_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in needed

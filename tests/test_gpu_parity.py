@@ -1,0 +1,380 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against (a) golden vectors cut from the
+compiled reference and (b) the CPU oracle on seeded inputs. Bit-exact for every int16 path;
+max|y - y_ref| / max|y_ref| <= 1e-5 for float / FFT paths (BASELINE.json north_star).
+Run with `pytest -m gpu` on an MI355X."""
+import numpy as np
+import pytest
+
+import libsdr_amd as sa
+
+pytestmark = pytest.mark.gpu
+
+FS = 2.4e6
+RTOL = 1e-5
+
+
+def split(x, lens):
+    out, off = [], 0
+    for n in lens:
+        out.append(x[off:off + n])
+        off += n
+    return out
+
+
+def rel_err(y, ref):
+    y, ref = np.asarray(y, np.float64), np.asarray(ref, np.float64)
+    return np.abs(y - ref).max() / max(np.abs(ref).max(), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = sa.Context(0)
+    yield c
+    c.close()
+
+
+def iqbb_from_case(ctx, golden, case, suffix, epilogue, channels=1, max_in=4096):
+    m = golden.meta(case + suffix)
+    tcase = case if (case + "_taps") in golden.manifest else "g3_iqbb127d8"
+    node = sa.IQBaseBandI16(ctx, golden.load(tcase + "_taps"), golden.load(tcase + "_lut"), m["lut_inc"], m["negative"],
+                            m["decim"], channels=channels, max_in=max_in, epilogue=epilogue)
+    return m, node
+
+
+# ---- K1 against golden vectors ----------------------------------------------------------------------
+
+@pytest.mark.parametrize("case,inp", [
+    ("g3_iqbb127d8", "g1_iq_cs16"), ("g8_neg_o16_d1", "g1_iq_cs16_tone_m100k"), ("g8_o21_d3", "g1_iq_cs16"),
+    ("g8_o33_d5", "g1_iq_cs16"), ("g8_o16_d4_even", "g1_iq_cs16"), ("g8_o255_d8", "g1_iq_cs16"),
+    ("g8_noshift_o21_d8", "g1_iq_cs16"), ("g8_ofs_d300", "g1_iq_cs16"), ("g8_irregular", "g1_iq_cs16")])
+def test_iqbb_golden(ctx, golden, case, inp):
+    m, node = iqbb_from_case(ctx, golden, case, "_out", sa.EPI_NONE)
+    outs = [node.process(c)[0] for c in split(golden.load(inp), m["in_lens"])]
+    assert [len(o) for o in outs] == m["out_lens"]
+    assert np.array_equal(np.concatenate(outs), golden.load(case + "_out"))
+
+
+@pytest.mark.parametrize("case,inp,demod", [
+    ("g4_iqbb127d8", "g1_iq_cs16", "fm"), ("g4_iqbb127d8", "g1_iq_cs16", "am"), ("g4_iqbb127d8", "g1_iq_cs16", "usb"),
+    ("g8_o33_d5", "g1_iq_cs16", "fm"), ("g8_irregular", "g1_iq_cs16", "fm"), ("g8_irregular", "g1_iq_cs16", "usb"),
+    ("g8_loud_iqbb127d8", "g8_iq_cs16_loud", "fm"), ("g8_loud_iqbb127d8", "g8_iq_cs16_loud", "am")])
+def test_iqbb_demod_golden(ctx, golden, case, inp, demod):
+    epi = {"fm": sa.EPI_FM, "am": sa.EPI_AM, "usb": sa.EPI_USB}[demod]
+    m, node = iqbb_from_case(ctx, golden, case, "_" + demod, epi)
+    outs = [node.process(c)[0] for c in split(golden.load(inp), m["in_lens"])]
+    if demod == "fm":   # FMDemod does not send on an empty buffer
+        outs = [o for o in outs if len(o)]
+    assert [len(o) for o in outs] == m["out_lens"]
+    assert np.array_equal(np.concatenate(outs), golden.load(case + "_" + demod))
+
+
+# ---- K1 batched against the oracle -------------------------------------------------------------------
+
+def synth_channels(orc, C, N, seed=0x5D2):
+    """SURVEY §8d config-3 style channels: two tones + uniform integer noise, per channel."""
+    x = np.zeros((C, N, 2), np.int16)
+    for c in range(C):
+        g = orc.IQSigGen(FS, [(50e3 + 97 * c, 7000, 0.1 * c), (-200e3 - 53 * c, 5000, 0.1 * c)])
+        s = g.next_cs16(N).astype(np.int32)
+        rng = np.random.default_rng(seed + c)
+        s += rng.integers(-64, 65, size=s.shape)
+        x[c] = s.astype(np.int16)
+    return x
+
+
+@pytest.mark.parametrize("epi", [sa.EPI_NONE, sa.EPI_FM, sa.EPI_AM, sa.EPI_USB])
+@pytest.mark.parametrize("order,decim,Fc", [(127, 8, 100e3), (21, 8, -100e3), (33, 5, 100e3), (16, 1, 50e3)])
+def test_iqbb_batched_vs_oracle(ctx, orc, epi, order, decim, Fc):
+    C, chunks = 5, [8192, 3000, 1, 7, 5000, 8192]
+    taps = sa.design_iqbb_taps(Fc, 50e3, FS, order)
+    lut = sa.design_freqshift_lut_i16()
+    inc = sa.design_freqshift_inc(Fc, FS)
+    x = synth_channels(orc, C, sum(chunks))
+    node = sa.IQBaseBandI16(ctx, taps, lut, inc, Fc < 0, decim, channels=C, max_in=8192, epilogue=epi)
+    refs = [(orc.IQBaseBandI16(taps, lut, inc, Fc < 0, decim), orc.FMDemodI16()) for _ in range(C)]
+    off = 0
+    for n in chunks:
+        y = node.process(x[:, off:off + n])
+        for c in range(C):
+            bb, fm = refs[c]
+            r = bb.process(x[c, off:off + n])
+            if epi == sa.EPI_FM:
+                r = fm.process(r) if len(r) else np.zeros(0, np.int16)
+            elif epi == sa.EPI_AM:
+                r = orc.am_i16(r)
+            elif epi == sa.EPI_USB:
+                r = orc.usb_i16(r)
+            assert y[c].shape == r.shape, (c, n, y[c].shape, r.shape)
+            assert np.array_equal(y[c], r), (c, n, off)
+        off += n
+
+
+def test_iqbb_random_fullscale_vs_oracle(ctx, orc):
+    """Full-range random int16 input (worst case for the int32 accumulators and the >>14/>>16 steps)."""
+    rng = np.random.default_rng(7)
+    C, N = 3, 20000
+    x = rng.integers(-32768, 32768, size=(C, N, 2)).astype(np.int16)
+    taps = sa.design_iqbb_taps(100e3, 50e3, FS, 127)
+    lut = sa.design_freqshift_lut_i16()
+    node = sa.IQBaseBandI16(ctx, taps, lut, 1365, False, 8, channels=C, max_in=N, epilogue=sa.EPI_NONE)
+    y = node.process(x)
+    for c in range(C):
+        assert np.array_equal(y[c], orc.IQBaseBandI16(taps, lut, 1365, False, 8).process(x[c]))
+
+
+def test_iqbb_reset_semantics(ctx, orc, golden):
+    m, node = iqbb_from_case(ctx, golden, "g3_iqbb127d8", "_out", sa.EPI_NONE)
+    x = golden.load("g1_iq_cs16")
+    first = node.process(x[:4096])[0]
+    node.reset(keep_history=False)
+    assert np.array_equal(node.process(x[:4096])[0], first)
+    # _reconfigure keeps the ring (src/baseband.hh:175-177): same as the oracle's reset()
+    bb = orc.IQBaseBandI16(golden.load("g3_iqbb127d8_taps"), golden.load("g3_iqbb127d8_lut"), 1365, 0, 8)
+    bb.process(x[:4096]); bb.reset()
+    node.reset(keep_history=False); node.process(x[:4096]); node.reset(keep_history=True)
+    assert np.array_equal(node.process(x[4096:8192])[0], bb.process(x[4096:8192]))
+
+
+# ---- K1 at the BASELINE size: properties + sampled oracle comparison ------------------------------------
+
+def test_iqbb_full_size_properties(ctx, orc):
+    C, N, D = 1024, 65536, 8
+    taps = sa.design_iqbb_taps(100e3, 50e3, FS, 127)
+    lut = sa.design_freqshift_lut_i16()
+    base = synth_channels(orc, 8, N)
+    x = np.ascontiguousarray(base[np.arange(C) % 8])          # channel c carries pattern c % 8
+    node = sa.IQBaseBandI16(ctx, taps, lut, 1365, False, D, channels=C, max_in=N, epilogue=sa.EPI_FM)
+    y1 = node.process(x)
+    y2 = node.process(x)
+    assert y1.shape == (C, 8191) and y2.shape == (C, 8192)
+    # invariance under channel batching: identical inputs -> identical outputs, wherever the channel sits
+    for k in range(8):
+        assert (y1[k::8] == y1[k]).all() and (y2[k::8] == y2[k]).all()
+    # the 8 distinct patterns against the oracle, both calls (state carried)
+    for k in range(8):
+        bb, fm = orc.IQBaseBandI16(taps, lut, 1365, False, D), orc.FMDemodI16()
+        assert np.array_equal(y1[k], fm.process(bb.process(x[k])))
+        assert np.array_equal(y2[k], fm.process(bb.process(x[k])))
+    # re-chunking invariance of the complex output (K1 is invariant, FM is not)
+    n1 = sa.IQBaseBandI16(ctx, taps, lut, 1365, False, D, channels=C, max_in=N, epilogue=sa.EPI_NONE)
+    n2 = sa.IQBaseBandI16(ctx, taps, lut, 1365, False, D, channels=C, max_in=N, epilogue=sa.EPI_NONE)
+    whole = n1.process(x)
+    parts = np.concatenate([n2.process(x[:, :30001]), n2.process(x[:, 30001:])], axis=1)
+    assert np.array_equal(whole, parts)
+
+
+# ---- K2: exact int16 FIR --------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("case,order,inp", [("g5_fir127", 127, "g1_iq_cs16"), ("g5_fir255", 255, "g1_iq_cs16"),
+                                            ("g8_irregular_fir127", 127, "g1_iq_cs16"), ("g8_loud_fir127", 127, "g8_iq_cs16_loud")])
+def test_fir_cs16_golden(ctx, golden, case, order, inp):
+    m = golden.meta(case + "_out")
+    node = sa.FIR(ctx, sa.FIR_CS16_EXACT, golden.load("g2_firlp_alpha%d" % order), max_in=4096)
+    outs = [node.process(c)[0] for c in split(golden.load(inp), m["in_lens"])]
+    assert np.array_equal(np.concatenate(outs), golden.load(case + "_out"))
+
+
+@pytest.mark.parametrize("case,order", [("g5_fir127", 127), ("g5_fir255", 255), ("g8_irregular_fir127", 127)])
+def test_fir_cs16_fm_golden(ctx, golden, case, order):
+    m = golden.meta(case + "_fm")
+    node = sa.FIR(ctx, sa.FIR_CS16_EXACT, golden.load("g2_firlp_alpha%d" % order), max_in=4096, epilogue=sa.EPI_FM)
+    outs = [node.process(c)[0] for c in split(golden.load("g1_iq_cs16"), m["in_lens"])]
+    outs = [o for o in outs if len(o)]
+    assert [len(o) for o in outs] == m["out_lens"]
+    assert np.array_equal(np.concatenate(outs), golden.load(case + "_fm"))
+
+
+@pytest.mark.parametrize("order", [255, 16, 1])
+def test_fir_cs16_batched_vs_oracle(ctx, orc, order):
+    C, chunks = 4, [4096, 1000, 3, 4096]
+    alpha = sa.design_fir_lowpass(order, 100e3, FS)
+    x = synth_channels(orc, C, sum(chunks))
+    rng = np.random.default_rng(3)
+    x[3] = rng.integers(-32768, 32768, size=x[3].shape).astype(np.int16)   # full-range channel
+    node = sa.FIR(ctx, sa.FIR_CS16_EXACT, alpha, channels=C, max_in=4096, epilogue=sa.EPI_FM)
+    refs = [(orc.FIR(alpha), orc.FMDemodI16()) for _ in range(C)]
+    off = 0
+    for n in chunks:
+        y = node.process(x[:, off:off + n])
+        for c in range(C):
+            f, fm = refs[c]
+            assert np.array_equal(y[c], fm.process(f.process_cs16(x[c, off:off + n]))), (c, n)
+        off += n
+
+
+def test_fir_cs16_wrap_variant(ctx, orc):
+    """sum|alpha| > 1 can push a partial sum past int16: the reference wraps per tap, so do we."""
+    rng = np.random.default_rng(5)
+    alpha = rng.uniform(-0.3, 0.3, 31)
+    x = rng.integers(-32768, 32768, size=(2, 3000, 2)).astype(np.int16)
+    node = sa.FIR(ctx, sa.FIR_CS16_EXACT, alpha, channels=2, max_in=3000)
+    y = node.process(x)
+    for c in range(2):
+        assert np.array_equal(y[c], orc.FIR(alpha).process_cs16(x[c]))
+
+
+# ---- K3: float FIR (+ folded SubSample, + float demods) --------------------------------------------------
+
+def test_fir_cf32_golden(ctx, golden):
+    x = golden.load("g1_iq_cf32")
+    node = sa.FIR(ctx, sa.FIR_CF32, golden.load("g2_firlp_alpha127"), max_in=4096)
+    y = np.concatenate([node.process(x[i * 4096:(i + 1) * 4096])[0] for i in range(3)])
+    assert rel_err(y, golden.load("g6_fir127_cf32_out")) <= RTOL
+
+
+@pytest.mark.parametrize("n", [8, 3])
+def test_fir_cf32_decimated_golden(ctx, golden, n):
+    x = golden.load("g1_iq_cf32")
+    node = sa.FIR(ctx, sa.FIR_CF32, golden.load("g2_firlp_alpha127"), decim=n, max_in=4096)
+    outs = [node.process(x[i * 4096:(i + 1) * 4096])[0] for i in range(3)]
+    assert [len(o) for o in outs] == golden.meta("g6_fir127_cf32_sub%d" % n)["out_lens"]
+    assert rel_err(np.concatenate(outs), golden.load("g6_fir127_cf32_sub%d" % n)) <= RTOL
+
+
+@pytest.mark.parametrize("demod", ["am", "usb"])
+def test_fir_cf32_demod_golden(ctx, golden, demod):
+    x = golden.load("g1_iq_cf32")
+    node = sa.FIR(ctx, sa.FIR_CF32, golden.load("g2_firlp_alpha127"), max_in=4096,
+                  epilogue=sa.EPI_AM if demod == "am" else sa.EPI_USB)
+    y = np.concatenate([node.process(x[i * 4096:(i + 1) * 4096])[0] for i in range(3)])
+    assert rel_err(y, golden.load("g6_fir127_cf32_" + demod)) <= RTOL
+
+
+def test_fir_cf32_4097_golden(ctx, golden):
+    x = golden.load("g1_iq_cf32")
+    node = sa.FIR(ctx, sa.FIR_CF32, golden.load("g2_firlp_alpha4097"), max_in=4096)
+    y = np.concatenate([node.process(x[i * 4096:(i + 1) * 4096])[0] for i in range(3)])
+    assert rel_err(y, golden.load("g6_fir4097_cf32_out")) <= RTOL
+
+
+# ---- K4/K5/K6 stand-alone -------------------------------------------------------------------------------
+
+def test_demods_standalone_golden(ctx, golden):
+    x = golden.load("g1_iq_cs16")
+    for kind, name in ((sa.EPI_AM, "g4_raw_am"), (sa.EPI_USB, "g4_raw_usb")):
+        node = sa.Demod(ctx, kind, sa.T_CS16, max_in=4096)
+        y = np.concatenate([node.process(x[i * 4096:(i + 1) * 4096])[0] for i in range(4)])
+        assert np.array_equal(y, golden.load(name))
+    node = sa.Demod(ctx, sa.EPI_FM, sa.T_CS16, max_in=4096, inplace_fm0=False)
+    y = np.concatenate([node.process(x[i * 4096:(i + 1) * 4096])[0] for i in range(4)])   # out[0] stays the caller's 0
+    assert np.array_equal(y, golden.load("g4_raw_fm_masked0"))
+    xf = golden.load("g6_fir127_cf32_out")
+    for kind, name in ((sa.EPI_AM, "g6_fir127_cf32_am"), (sa.EPI_USB, "g6_fir127_cf32_usb")):
+        node = sa.Demod(ctx, kind, sa.T_CF32, max_in=3 * 4096)
+        assert np.array_equal(node.process(xf)[0], golden.load(name))
+
+
+def test_demod_fm_odd_sizes_vs_oracle(ctx, orc):
+    rng = np.random.default_rng(11)
+    x = rng.integers(-32768, 32768, size=(3, 1237, 2)).astype(np.int16)
+    node = sa.Demod(ctx, sa.EPI_FM, sa.T_CS16, channels=3, max_in=2000, inplace_fm0=True)
+    fms = [orc.FMDemodI16() for _ in range(3)]
+    for lo, hi in ((0, 1), (1, 2), (2, 700), (700, 1237)):
+        y = node.process(x[:, lo:hi])
+        for c in range(3):
+            assert np.array_equal(y[c], fms[c].process(x[c, lo:hi]))
+
+
+@pytest.mark.parametrize("n", [8, 3])
+def test_subsample_golden(ctx, golden, n):
+    x = golden.load("g1_iq_cs16")
+    node = sa.SubSample(ctx, sa.T_CS16, n, max_in=4096)
+    outs = [node.process(x[i * 4096:(i + 1) * 4096])[0] for i in range(4)]
+    assert [len(o) for o in outs] == golden.meta("g6_subsample_cs16_n%d" % n)["out_lens"]
+    assert np.array_equal(np.concatenate(outs), golden.load("g6_subsample_cs16_n%d" % n))
+    xf = golden.load("g6_fir127_cf32_out")
+    node = sa.SubSample(ctx, sa.T_CF32, n, max_in=4096)
+    outs = [node.process(xf[i * 4096:(i + 1) * 4096])[0] for i in range(3)]
+    assert np.array_equal(np.concatenate(outs), golden.load("g6_fir127_cf32_sub%d" % n))   # same op order: exact
+
+
+# ---- K7: FFT and FFT convolution ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n", [16, 64, 2048, 8192, 16384])
+def test_fft_vs_numpy(ctx, n):
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((3, n, 2)).astype(np.float32)
+    xc = x[..., 0].astype(np.float64) + 1j * x[..., 1]
+    for sign, ref in ((-1, np.fft.fft(xc, axis=1)), (+1, np.fft.ifft(xc, axis=1) * n)):
+        y = sa.fft_c2c(ctx, x, sign)
+        yc = y[..., 0].astype(np.float64) + 1j * y[..., 1]
+        assert np.abs(yc - ref).max() / np.abs(ref).max() < 2e-6, (n, sign)
+
+
+@pytest.mark.parametrize("N", [1024, 8192])
+def test_fftconv_reference_mode_vs_oracle(ctx, golden, orc, N):
+    """FilterSink+FilterSource (overlap-add, 2N-point FFT, N taps) — oracle is FFTW-unpinned; both are
+    also held to the closed form y = h (*) x / (sqrt(2N) ||h||)."""
+    h = golden.load("g7_fftfilt_h%d" % N)
+    K = sa.design_fftfilt_spectrum(h)
+    nblk = 12288 // N if N <= 4096 else 1
+    x = golden.load("g1_iq_cf32")[:nblk * N]
+    node = sa.FFTConv(ctx, sa.FFTCONV_OLA, 2 * N, K, max_in=nblk * N)
+    y = node.process(x)[0]
+    flt = orc.FFTFilter(orc.fftfilt_design_K(h))
+    ref = np.concatenate([flt.process(x[i * N:(i + 1) * N]) for i in range(nblk)])
+    assert rel_err(y, ref) <= RTOL
+    hc = h[:, 0].astype(np.float64) + 1j * h[:, 1]
+    xc = x[:, 0].astype(np.float64) + 1j * x[:, 1]
+    closed = np.convolve(xc, hc)[:len(xc)] / (np.sqrt(2 * N) * np.sqrt((np.abs(hc) ** 2).sum()))
+    yc = y[:, 0].astype(np.float64) + 1j * y[:, 1]
+    assert np.abs(yc - closed).max() / np.abs(closed).max() <= RTOL
+
+
+def test_fftconv_ols_4097_vs_reference_fir(ctx, golden):
+    """BASELINE config 4: L=16384, 4097 real taps by overlap-save vs the reference's time-domain
+    FIRLowPass<cf32>(4097) output (golden), streaming over 3 calls."""
+    a = golden.load("g2_firlp_alpha4097")
+    taps = np.stack([a, np.zeros_like(a)], axis=1).astype(np.float32)
+    node = sa.FFTConv(ctx, sa.FFTCONV_OLS, 16384, taps, max_in=4096)
+    x = golden.load("g1_iq_cf32")
+    y = np.concatenate([node.process(x[i * 4096:(i + 1) * 4096])[0] for i in range(3)])
+    assert rel_err(y, golden.load("g6_fir4097_cf32_out")) <= RTOL
+
+
+def test_fftconv_matches_time_domain_kernel(ctx, golden):
+    """config 4 'fftplan filter vs FIRFilter': both GPU paths agree on a long multi-channel stream."""
+    a = golden.load("g2_firlp_alpha4097")
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((3, 40000, 2)).astype(np.float32)
+    taps = np.stack([a, np.zeros_like(a)], axis=1).astype(np.float32)
+    f1 = sa.FFTConv(ctx, sa.FFTCONV_OLS, 16384, taps, channels=3, max_in=40000)
+    f2 = sa.FIR(ctx, sa.FIR_CF32, a, channels=3, max_in=40000)
+    assert rel_err(f1.process(x), f2.process(x)) <= RTOL
+
+
+# ---- float baseband (config 2) -----------------------------------------------------------------------------
+
+def test_float_baseband_vs_oracle(ctx, golden, orc):
+    alpha = golden.load("g2_firlp_alpha127")
+    x = golden.load("g1_iq_cf32")
+    node = sa.FloatBaseBand(ctx, 100e3, FS, alpha, 8, max_in=4096)
+    fir, sub = orc.FIR(alpha), orc.SubSample(8)
+    for i in range(3):
+        xs = x[i * 4096:(i + 1) * 4096]
+        y = node.process(xs)[0]
+        ref = sub.process_cf32(fir.process_cf32(orc.freqshift_cf32(xs, i * 4096, 100e3, FS)))
+        assert y.shape == ref.shape and rel_err(y, ref) <= RTOL
+
+
+# ---- error behaviour -----------------------------------------------------------------------------------------
+
+def test_error_codes(ctx, golden):
+    taps, lut = golden.load("g3_iqbb127d8_taps"), golden.load("g3_iqbb127d8_lut")
+    with pytest.raises(sa.SdrHipError) as e:
+        sa.IQBaseBandI16(ctx, taps, lut, 1365, 0, 0)
+    assert e.value.code == sa.abi.E_INVALID
+    with pytest.raises(sa.SdrHipError) as e:
+        sa.IQBaseBandI16(ctx, taps, lut, 1365, 0, 5000)
+    assert e.value.code == sa.abi.E_UNSUPPORTED
+    node = sa.IQBaseBandI16(ctx, taps, lut, 1365, 0, 8, max_in=128)
+    with pytest.raises(sa.SdrHipError) as e:
+        node.process(np.zeros((1, 129, 2), np.int16))
+    assert e.value.code == sa.abi.E_SIZE
+    assert node.process(np.zeros((1, 0, 2), np.int16)).shape == (1, 0, 2)
+    with pytest.raises(sa.SdrHipError) as e:
+        sa.Demod(ctx, sa.EPI_FM, sa.T_CF32)
+    assert e.value.code == sa.abi.E_UNSUPPORTED
+    with pytest.raises(sa.SdrHipError) as e:
+        sa.Context(99)
+    assert e.value.code == sa.abi.E_NODEVICE
