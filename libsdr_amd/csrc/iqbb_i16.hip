@@ -335,7 +335,7 @@ int sdrhip_iqbb_i16_create(sdrhip_ctx *ctx, const int32_t *taps, int order, cons
       h->ctx = ctx; h->order = order; h->D = decim; h->C = channels; h->epi = epilogue;
       h->negative = negative ? 1 : 0; h->inc = lut_inc; h->max_in = max_in;
       h->OP = (int)ceil_div((size_t)order, (size_t)TAPC) * TAPC;
-      h->HH = h->OP - 1;
+      h->HH = h->OP;   // one more than the FIR needs: reset(keep_history) must see the whole ring
       h->CG = CG; h->ovl = ovl; h->OG = CG - ovl;
       h->fast8 = (decim == R);
       const size_t XS = TI + h->OP + 8;
@@ -414,9 +414,28 @@ int sdrhip_iqbb_i16_reset(sdrhip_iqbb_i16 *h, int keep_history) {
   return guarded([&] {
     SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
     h->ctx->use();
+    hipStream_t st = h->ctx->stream;
+    for (int p = 0; p < 2; p++) { h->acc[p].zero(st); h->fm[p].zero(st); }
+    if (!keep_history) {
+      for (int p = 0; p < 2; p++) h->hist[p].zero(st);
+    } else if (h->n0 % (uint64_t)h->order != 0) {
+      // IQBaseBand::_reconfigure resets _ring_offset but leaves the ring contents where they are
+      // (src/baseband.hh:175-177), so the node afterwards reads the old ring ROTATED: with
+      // P = (samples so far) mod order the apparent history, oldest first, is ring[1..order-1],
+      // ring[i] = t[order-P+i] (i < P) or t[i-P] (i >= P), t = the last `order` samples in time order.
+      const int order = h->order, HH = h->HH, P = (int)(h->n0 % (uint64_t)order);
+      std::vector<uint32_t> old((size_t)h->C * HH), neu((size_t)h->C * HH, 0u);
+      SDRHIP_CHECK_HIP(hipMemcpyAsync(old.data(), h->hist[h->par].p, old.size() * 4, hipMemcpyDeviceToHost, st));
+      SDRHIP_CHECK_HIP(hipStreamSynchronize(st));
+      for (int c = 0; c < h->C; c++) {
+        const uint32_t *t = old.data() + (size_t)c * HH + (HH - order);
+        uint32_t *d = neu.data() + (size_t)c * HH + (HH - (order - 1));
+        for (int k = 0; k + 1 < order; k++) { const int i = k + 1; d[k] = i < P ? t[order - P + i] : t[i - P]; }
+      }
+      SDRHIP_CHECK_HIP(hipMemcpyAsync(h->hist[h->par].p, neu.data(), neu.size() * 4, hipMemcpyHostToDevice, st));
+      SDRHIP_CHECK_HIP(hipStreamSynchronize(st));
+    }
     h->n0 = 0;
-    for (int p = 0; p < 2; p++) { h->acc[p].zero(h->ctx->stream); h->fm[p].zero(h->ctx->stream); }
-    if (!keep_history) for (int p = 0; p < 2; p++) h->hist[p].zero(h->ctx->stream);
   });
 }
 
