@@ -163,7 +163,7 @@ def main():
         elif wl == "fftconv":
             alpha = sa.design_fir_lowpass(4097, 100e3, FS)
             import numpy as np
-            tapsf = np.stack([alpha, np.zeros_like(alpha)], 1).astype(np.float32)
+            tapsf = np.stack([alpha[::-1], np.zeros_like(alpha)], 1).astype(np.float32)   # h[k] = alpha[order-1-k]
             node = sa.FFTConv(ctx, sa.FFTCONV_OLS, 16384, tapsf, channels=C, max_in=N)
             in_bytes, alg_bytes = 8.0, 16.0
             outs = torch.zeros((C, N, 2), dtype=torch.float32, device=dev)

@@ -325,7 +325,9 @@ def test_fftconv_ols_4097_vs_reference_fir(ctx, golden):
     """BASELINE config 4: L=16384, 4097 real taps by overlap-save vs the reference's time-domain
     FIRLowPass<cf32>(4097) output (golden), streaming over 3 calls."""
     a = golden.load("g2_firlp_alpha4097")
-    taps = np.stack([a, np.zeros_like(a)], axis=1).astype(np.float32)
+    # FIRFilter pairs alpha[order-1] with the newest sample (src/firfilter.hh:237-243), so the causal
+    # convolution kernel is h[k] = alpha[order-1-k]
+    taps = np.stack([a[::-1], np.zeros_like(a)], axis=1).astype(np.float32)
     node = sa.FFTConv(ctx, sa.FFTCONV_OLS, 16384, taps, max_in=4096)
     x = golden.load("g1_iq_cf32")
     y = np.concatenate([node.process(x[i * 4096:(i + 1) * 4096])[0] for i in range(3)])
@@ -337,7 +339,7 @@ def test_fftconv_matches_time_domain_kernel(ctx, golden):
     a = golden.load("g2_firlp_alpha4097")
     rng = np.random.default_rng(2)
     x = rng.standard_normal((3, 40000, 2)).astype(np.float32)
-    taps = np.stack([a, np.zeros_like(a)], axis=1).astype(np.float32)
+    taps = np.stack([a[::-1], np.zeros_like(a)], axis=1).astype(np.float32)
     f1 = sa.FFTConv(ctx, sa.FFTCONV_OLS, 16384, taps, channels=3, max_in=40000)
     f2 = sa.FIR(ctx, sa.FIR_CF32, a, channels=3, max_in=40000)
     assert rel_err(f1.process(x), f2.process(x)) <= RTOL
