@@ -42,6 +42,7 @@ def parse():
     p.add_argument("--workload", default="iqbb_fm")
     p.add_argument("--batches", type=int, default=3, help="distinct input batches rotated through (defeats the 256 MiB L3)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--gather", action="store_true", help="also gather the demodulated output on rank 0 every step (RCCL)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     return p.parse_args()
 
@@ -104,6 +105,7 @@ def main():
     import torch
     import torch.distributed as dist
     import libsdr_amd as sa
+    from libsdr_amd import shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -127,8 +129,7 @@ def main():
         if wl in ("iqbb_fm", "iqbb_usb"):
             taps = torch.from_numpy(sa.design_iqbb_taps(100e3, 50e3, FS, order)).to(dev)
             lut = torch.from_numpy(sa.design_freqshift_lut_i16()).to(dev)
-            if world > 1:
-                dist.broadcast(taps, 0); dist.broadcast(lut, 0)
+            shard.broadcast_design([taps, lut], src=0)
             node = sa.IQBaseBandI16(ctx, taps.cpu().numpy(), lut.cpu().numpy(), sa.design_freqshift_inc(100e3, FS), False, D,
                                     channels=C, max_in=N, epilogue=sa.EPI_FM if wl == "iqbb_fm" else sa.EPI_USB)
             in_bytes, alg_bytes = 4.0, 4.0 + 2.0 / D
@@ -141,8 +142,7 @@ def main():
         elif wl in ("fir255_fm", "fir127_fm"):
             order = 255 if wl == "fir255_fm" else 127
             alpha = torch.from_numpy(sa.design_fir_lowpass(order, 100e3, FS)).to(dev)
-            if world > 1:
-                dist.broadcast(alpha, 0)
+            shard.broadcast_design([alpha], src=0)
             node = sa.FIR(ctx, sa.FIR_CS16_EXACT, alpha.cpu().numpy(), channels=C, max_in=N, epilogue=sa.EPI_FM)
             in_bytes, alg_bytes = 4.0, 6.0
             outs = torch.zeros((C, N), dtype=torch.int16, device=dev)
@@ -187,6 +187,8 @@ def main():
         timer.start()
         for i in range(K):
             run(i % a.batches)
+            if a.gather and world > 1:
+                shard.gather_output(outs, C * world, dst=0)
         timer.stop()
         barrier()
         wall = time.perf_counter() - t0
@@ -209,7 +211,7 @@ def main():
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": desc, "channels_per_gpu": C, "samples_per_channel_per_step": N,
                        "global_channels": C * world, "input": "complex<int16>" if in_bytes == 4 else "complex<float>",
-                       "parallelism": "channel-sharded x%d, no data-path collective" % world},
+                       "parallelism": "channel-sharded x%d, %s" % (world, "output gathered on rank 0 per step (RCCL)" if a.gather else "no data-path collective")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": kernel,
                          "algorithmic_bytes_per_sample": alg_bytes, "avg_launch_ms": round(per_launch_s * 1e3, 4),

@@ -13,7 +13,7 @@ namespace sdr {
 class SDRError : public std::exception, public std::stringstream {
 public:
   SDRError() {}
-  SDRError(const SDRError &o) : std::exception(), std::basic_ios<char>(), std::stringstream() { this->str(o.str()); }
+  SDRError(const SDRError &o) : std::basic_ios<char>(), std::exception(), std::stringstream() { this->str(o.str()); }
   virtual ~SDRError() throw() {}
   virtual const char *what() const throw() {
     _text = this->str();

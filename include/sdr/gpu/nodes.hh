@@ -1,0 +1,560 @@
+// nodes.hh — MI355X nodes behind libsdr's node API (header-only; link with -lsdrhip).
+//
+// Every class here is an ordinary sdr::Sink<T> + sdr::Source with the reference node's name,
+// constructor arguments, config()/process() behaviour, ownership and error rules, so it can replace
+// the CPU node in an existing graph:
+//   sdr::gpu::IQBaseBand<int16_t>           <->  sdr::IQBaseBand<int16_t>            reference src/baseband.hh:22-293
+//   sdr::gpu::FIRLowPass<complex<int16|float>>  <->  sdr::FIRLowPass<...>            src/firfilter.hh:117-289
+//   sdr::gpu::FMDemod<int16_t>, AMDemod<S>, USBDemod<S>  <->  same names             src/demod.hh:18-264
+//   sdr::gpu::SubSample<complex<...>>       <->  sdr::SubSample<...>                 src/subsample.hh:16-116
+//   sdr::gpu::FilterNode<float>             <->  sdr::FilterNode<float>              src/filternode.hh:232-284
+//   sdr::gpu::ChannelBank<int16_t>          many IQBaseBand(+demod) channels in ONE batched kernel launch;
+//                                           sink(c)/source(c) per channel like Combine::sink(i) (src/combine.hh:66-150)
+// Rules reproduced: config() returns silently while the upstream Config is incomplete and throws
+// ConfigError on a type mismatch; the output buffer is owned by the node, allocated in config(),
+// reused only when isUnused(), otherwise the input is dropped; a node writes into its input only
+// when allow_overwrite; views (out.head(n)) are sent, never copies; process() never throws (device
+// errors are logged at LOG_ERROR and the buffer is dropped).
+//
+// The header compiles against this repository's core (include/sdr/node.hh) or, when the
+// reference's own node.hh was included first, against the reference core unchanged.
+#ifndef SDR_GPU_NODES_HH
+#define SDR_GPU_NODES_HH
+
+#if !defined(__SDR_NODE_HH__) && !defined(SDR_CORE_NODE_HH)
+#include "../node.hh"
+#include "../logger.hh"
+#endif
+
+#include <algorithm>
+#include <complex>
+#include <cstring>
+#include <list>
+#include <map>
+#include <vector>
+
+#include "../../sdrhip.h"
+#include "design.hh"
+
+namespace sdr {
+namespace gpu {
+
+typedef std::complex<int16_t> cs16;
+typedef std::complex<float> cf32;
+
+/** One shared device context per HIP device. Throws ConfigError when there is no GPU (no CPU fallback). */
+class Device {
+public:
+  static sdrhip_ctx *get(int device = 0) {
+    static std::map<int, sdrhip_ctx *> ctxs;
+    std::map<int, sdrhip_ctx *>::iterator it = ctxs.find(device);
+    if (it != ctxs.end()) return it->second;
+    sdrhip_ctx *c = 0;
+    const int rc = sdrhip_ctx_create(device, 0, &c);
+    if (rc != SDRHIP_OK) {
+      ConfigError err;
+      err << "sdr::gpu: can not open HIP device " << device << ": " << sdrhip_strerror(rc) << " (" << sdrhip_last_error() << ")";
+      throw err;
+    }
+    ctxs[device] = c;
+    return c;
+  }
+};
+
+namespace detail {
+inline void configCheck(int rc, const char *what) {
+  if (rc == SDRHIP_OK) return;
+  ConfigError err;
+  err << "Can not configure " << what << ": " << sdrhip_strerror(rc) << " (" << sdrhip_last_error() << ")";
+  throw err;
+}
+inline bool processOk(int rc, const char *what) {
+  if (rc == SDRHIP_OK) return true;
+  LogMessage msg(LOG_ERROR);
+  msg << what << ": drop buffer: " << sdrhip_strerror(rc) << " (" << sdrhip_last_error() << ")";
+  Logger::get().log(msg);
+  return false;
+}
+template <class T> struct TypeTag;
+template <> struct TypeTag<cs16> { enum { dtype = SDRHIP_T_CS16, fir = SDRHIP_FIR_CS16_EXACT }; typedef int16_t Real; };
+template <> struct TypeTag<cf32> { enum { dtype = SDRHIP_T_CF32, fir = SDRHIP_FIR_CF32 }; typedef float Real; };
+template <class S> struct RealTag;
+template <> struct RealTag<int16_t> { enum { dtype = SDRHIP_T_CS16 }; };
+template <> struct RealTag<float> { enum { dtype = SDRHIP_T_CF32 }; };
+}  // namespace detail
+
+// =================================================================================================
+// IQBaseBand<int16_t>
+// =================================================================================================
+template <class Scalar> class IQBaseBand;
+
+template <>
+class IQBaseBand<int16_t> : public Sink<cs16>, public Source {
+public:
+  IQBaseBand(double Fc, double width, size_t order, size_t sub_sample, double oFs = 0.0, int device = 0)
+    : _Fc(Fc), _Ff(Fc), _shift(Fc), _Fs(0), _width(width), _order(std::max(size_t(1), order)), _sub_sample(sub_sample),
+      _oFs(oFs), _sourceBs(0), _epilogue(SDRHIP_EPI_NONE), _device(device), _plan(0) {}
+  IQBaseBand(double Fc, double Ff, double width, size_t order, size_t sub_sample, double oFs = 0.0, int device = 0)
+    : _Fc(Fc), _Ff(Ff), _shift(Fc), _Fs(0), _width(width), _order(std::max(size_t(1), order)), _sub_sample(sub_sample),
+      _oFs(oFs), _sourceBs(0), _epilogue(SDRHIP_EPI_NONE), _device(device), _plan(0) {}
+  virtual ~IQBaseBand() {
+    if (_plan) sdrhip_iqbb_i16_destroy(_plan);
+    _buffer.unref();
+  }
+
+  /** Extension: fuse FMDemod / AMDemod / USBDemod<int16_t> (run in place on the node's output, as
+   * `baseband.connect(&demod, true)` does in examples/sdr_fm.cc:51) into the same kernel launch.
+   * The node then is a source of int16_t. Call before connecting / configuring. */
+  void setDemod(int epilogue) { _epilogue = epilogue; if (_Fs) _reconfigure(); }
+
+  inline size_t order() const { return _order; }
+  void setOrder(size_t o) { _order = std::max(size_t(1), o); if (_Fs) _reconfigure(); }
+  inline double centerFrequency() const { return _Fc; }
+  void setCenterFrequency(double Fc) { _Fc = int32_t(Fc); _shift = _Fc; if (_Fs) _reconfigure(); }
+  inline double filterFrequency() const { return _Ff; }
+  void setFilterFrequency(double Ff) { _Ff = int32_t(Ff); if (_Fs) _reconfigure(); }
+  inline double filterWidth() const { return _width; }
+  void setFilterWidth(double width) { _width = int32_t(width); if (_Fs) _reconfigure(); }
+  size_t subSample() const { return _sub_sample; }
+  void setSubsample(size_t sub_sample) { _sub_sample = std::max(size_t(1), sub_sample); if (_Fs) _reconfigure(); }
+  void setOutputSampleRate(double Fs) { _oFs = Fs; if (_Fs) _reconfigure(); }
+
+  virtual void config(const Config &src_cfg) {
+    if (!src_cfg.hasType() || !src_cfg.hasSampleRate() || !src_cfg.hasBufferSize()) return;
+    if (Config::typeId<cs16>() != src_cfg.type()) {
+      ConfigError err;
+      err << "Can not configure IQBaseBand: Invalid type " << src_cfg.type() << ", expected " << Config::typeId<cs16>();
+      throw err;
+    }
+    _Fs = int32_t(src_cfg.sampleRate());
+    _sourceBs = src_cfg.bufferSize();
+    _reconfigure();
+  }
+
+  virtual void process(const Buffer<cs16> &buffer, bool allow_overwrite) {
+    if (!_plan) return;
+    if (allow_overwrite) _process(buffer, buffer);
+    else if (_buffer.isUnused()) _process(buffer, _buffer);
+    // else: output buffer still in use downstream -> the input is dropped (src/baseband.hh:141-150)
+  }
+
+protected:
+  void _reconfigure() {
+    const size_t D = design::iqbbDecimation(_Fs, _sub_sample, _oFs);
+    _sub_sample = D;
+    std::vector<int32_t> taps(2 * _order), lut(2 * design::kLutSize);
+    design::iqbbTaps(_Ff, _width, _Fs, _order, taps.data());
+    design::freqShiftLutI16(lut.data());
+    const uint32_t inc = design::freqShiftIncrement(_shift, double(_Fs));
+    if (_plan) { sdrhip_iqbb_i16_destroy(_plan); _plan = 0; }
+    detail::configCheck(sdrhip_iqbb_i16_create(Device::get(_device), taps.data(), int(_order), lut.data(), inc, 0 > _shift,
+                                               int(D), 1, _sourceBs, _epilogue, &_plan), "IQBaseBand");
+    size_t buffer_size = _sourceBs / D;
+    if (_sourceBs % D) buffer_size += 1;
+    _buffer.unref();
+    _buffer = Buffer<cs16>(buffer_size);
+
+    LogMessage msg(LOG_DEBUG);
+    msg << "Configured gpu::IQBaseBand node:" << std::endl << " sample-rate " << _Fs << "Hz" << std::endl
+        << " center freq " << _Fc << "Hz" << std::endl << " width " << _width << "Hz" << std::endl
+        << " in buffer size " << _sourceBs << std::endl << " sub-sample by " << D << std::endl
+        << " out buffer size " << buffer_size;
+    Logger::get().log(msg);
+
+    const double oRate = double(size_t(_Fs) / D);   // the reference divides int32 by size_t (src/baseband.hh:192-193)
+    if (_epilogue == SDRHIP_EPI_NONE) this->setConfig(Config(Config::typeId<cs16>(), oRate, buffer_size, 1));
+    else this->setConfig(Config(Config::typeId<int16_t>(), oRate, buffer_size, 1));
+  }
+
+  void _process(const Buffer<cs16> &in, const Buffer<cs16> &out) {
+    size_t n = 0;
+    if (!detail::processOk(sdrhip_iqbb_i16_process(_plan, reinterpret_cast<const int16_t *>(in.data()), in.size(), 0,
+                                                   out.data(), out.size() * (_epilogue == SDRHIP_EPI_NONE ? 1 : 2), &n),
+                           "gpu::IQBaseBand"))
+      return;
+    if (_epilogue == SDRHIP_EPI_NONE) this->send(out.head(n), true);
+    else if (_epilogue == SDRHIP_EPI_FM) { if (n) this->send(Buffer<int16_t>(out).head(n), false); }   // FMDemod: no send when empty
+    else this->send(Buffer<int16_t>(out).head(n), _epilogue == SDRHIP_EPI_AM);
+  }
+
+  int32_t _Fc, _Ff;
+  double _shift;
+  int32_t _Fs, _width;
+  size_t _order, _sub_sample;
+  double _oFs;
+  size_t _sourceBs;
+  int _epilogue, _device;
+  sdrhip_iqbb_i16 *_plan;
+  Buffer<cs16> _buffer;
+};
+
+// =================================================================================================
+// FIRLowPass<complex<int16_t>> (bit-exact) / FIRLowPass<complex<float>>
+// =================================================================================================
+template <class Scalar>
+class FIRLowPass : public Sink<Scalar>, public Source {
+public:
+  FIRLowPass(size_t order, double Fc, int device = 0)
+    : _enabled(true), _order(std::max(size_t(1), order)), _Fu(Fc), _Fs(0), _bs(0), _device(device), _plan(0) {}
+  virtual ~FIRLowPass() {
+    if (_plan) sdrhip_fir_destroy(_plan);
+    _buffer.unref();
+  }
+  inline bool enabled() const { return _enabled; }
+  inline void enable(bool enable) { _enabled = enable; }
+  inline size_t order() const { return _order; }
+  virtual void setOrder(size_t order) { order = std::max(size_t(1), order); if (order == _order) return; _order = order; if (_Fs) _plan_(); }
+  inline double freq() const { return _Fu; }
+  inline void setFreq(double freq) { _Fu = freq; if (_Fs) _plan_(); }
+
+  virtual void config(const Config &src_cfg) {
+    if (!src_cfg.hasType() || !src_cfg.hasSampleRate() || !src_cfg.hasBufferSize()) return;
+    if (Config::typeId<Scalar>() != src_cfg.type()) {
+      ConfigError err;
+      err << "Can not configure FIRLowPass: Invalid type " << src_cfg.type() << ", expected " << Config::typeId<Scalar>();
+      throw err;
+    }
+    _Fs = src_cfg.sampleRate();
+    _bs = src_cfg.bufferSize();
+    _plan_();   // a fresh plan = zeroed ring, as FIRFilter::config does (src/firfilter.hh:193-195)
+    if (!_buffer.isEmpty()) _buffer.unref();
+    _buffer = Buffer<Scalar>(_bs);
+    this->setConfig(Config(src_cfg.type(), src_cfg.sampleRate(), src_cfg.bufferSize(), 1));
+  }
+
+  virtual void process(const Buffer<Scalar> &buffer, bool allow_overwrite) {
+    if (!_enabled) { this->send(buffer, allow_overwrite); return; }
+    if (!_plan) return;
+    if (allow_overwrite) _process(buffer, buffer);
+    else if (_buffer.isUnused()) _process(buffer, _buffer);
+  }
+
+protected:
+  void _plan_() {
+    std::vector<double> alpha(_order);
+    design::firLowPass(_order, _Fu, _Fs, alpha.data());
+    if (_plan) { sdrhip_fir_destroy(_plan); _plan = 0; }
+    detail::configCheck(sdrhip_fir_create(Device::get(_device), detail::TypeTag<Scalar>::fir, alpha.data(), int(_order), 1, 1,
+                                          _bs, SDRHIP_EPI_NONE, &_plan), "FIRLowPass");
+  }
+  void _process(const Buffer<Scalar> &in, const Buffer<Scalar> &out) {
+    size_t n = 0;
+    if (!detail::processOk(sdrhip_fir_process(_plan, in.data(), in.size(), 0, out.data(), out.size(), &n), "gpu::FIRLowPass")) return;
+    this->send(out.head(in.size()), true);
+  }
+  bool _enabled;
+  size_t _order;
+  double _Fu, _Fs;
+  size_t _bs;
+  int _device;
+  sdrhip_fir *_plan;
+  Buffer<Scalar> _buffer;
+};
+
+// =================================================================================================
+// demodulators
+// =================================================================================================
+namespace detail {
+template <class InC, class OutR>
+class DemodBase : public Sink<InC>, public Source {
+public:
+  DemodBase(int kind, const char *name, int device) : _kind(kind), _name(name), _device(device), _plan(0), _can_overwrite(true) {}
+  virtual ~DemodBase() {
+    if (_plan) sdrhip_demod_destroy(_plan);
+    _buffer.unref();
+  }
+  virtual void config(const Config &src_cfg) {
+    if (!src_cfg.hasType() || !src_cfg.hasBufferSize()) return;
+    if (Config::typeId<InC>() != src_cfg.type()) {
+      ConfigError err;
+      err << "Can not configure " << _name << ": Invalid type " << src_cfg.type() << ", expected " << Config::typeId<InC>();
+      throw err;
+    }
+    if (_plan) { sdrhip_demod_destroy(_plan); _plan = 0; }
+    configCheck(sdrhip_demod_create(Device::get(_device), _kind, TypeTag<InC>::dtype, 1, src_cfg.bufferSize(), 0, &_plan), _name);
+    if (!_buffer.isEmpty()) _buffer.unref();
+    _buffer = Buffer<OutR>(src_cfg.bufferSize());
+    this->setConfig(Config(Config::typeId<OutR>(), src_cfg.sampleRate(), src_cfg.bufferSize(),
+                           _kind == SDRHIP_EPI_AM ? src_cfg.numBuffers() : 1));
+  }
+  virtual void process(const Buffer<InC> &buffer, bool allow_overwrite) {
+    if (!_plan) return;
+    if (_kind == SDRHIP_EPI_FM && 0 == buffer.size()) return;            // src/demod.hh:231
+    Buffer<OutR> out = (allow_overwrite && _can_overwrite) ? Buffer<OutR>(buffer) : _buffer;
+    // in place the output aliases the input bytes, so FM's untouched out[0] is in[0].real()
+    if (!processOk(sdrhip_demod_process(_plan, buffer.data(), buffer.size(), 0, out.data(), 0), _name)) return;
+    this->send(out.head(buffer.size()), _kind == SDRHIP_EPI_AM);        // AM sends with allow_overwrite=true (:80)
+  }
+
+protected:
+  int _kind;
+  const char *_name;
+  int _device;
+  sdrhip_demod *_plan;
+  bool _can_overwrite;
+  Buffer<OutR> _buffer;
+};
+}  // namespace detail
+
+template <class iScalar, class oScalar = iScalar> class FMDemod;
+template <>
+class FMDemod<int16_t, int16_t> : public detail::DemodBase<cs16, int16_t> {
+public:
+  explicit FMDemod(int device = 0) : detail::DemodBase<cs16, int16_t>(SDRHIP_EPI_FM, "FMDemod", device) {}
+};
+template <class Scalar>
+class AMDemod : public detail::DemodBase<std::complex<Scalar>, Scalar> {
+public:
+  explicit AMDemod(int device = 0) : detail::DemodBase<std::complex<Scalar>, Scalar>(SDRHIP_EPI_AM, "AMDemod", device) {}
+};
+template <class Scalar>
+class USBDemod : public detail::DemodBase<std::complex<Scalar>, Scalar> {
+public:
+  explicit USBDemod(int device = 0) : detail::DemodBase<std::complex<Scalar>, Scalar>(SDRHIP_EPI_USB, "USBDemod", device) {}
+};
+
+// =================================================================================================
+// SubSample<complex<int16_t>|complex<float>>
+// =================================================================================================
+template <class Scalar>
+class SubSample : public Sink<Scalar>, public Source {
+public:
+  explicit SubSample(size_t n, int device = 0) : _n(n), _oFs(0), _device(device), _plan(0) {}
+  explicit SubSample(double Fs, int device = 0) : _n(1), _oFs(Fs), _device(device), _plan(0) {}
+  virtual ~SubSample() {
+    if (_plan) sdrhip_subsample_destroy(_plan);
+    _buffer.unref();
+  }
+  virtual void config(const Config &src_cfg) {
+    if (!src_cfg.hasType() || !src_cfg.hasBufferSize()) return;
+    if (Config::typeId<Scalar>() != src_cfg.type()) {
+      ConfigError err;
+      err << "Can not configure SubSample node: Invalid buffer type " << src_cfg.type() << ", expected " << Config::typeId<Scalar>();
+      throw err;
+    }
+    if (_oFs > 0) _n = size_t(std::max(1.0, src_cfg.sampleRate() / _oFs));
+    size_t out_size = src_cfg.bufferSize() / _n;
+    if (src_cfg.bufferSize() % _n) out_size += 1;
+    if (_plan) { sdrhip_subsample_destroy(_plan); _plan = 0; }
+    detail::configCheck(sdrhip_subsample_create(Device::get(_device), detail::TypeTag<Scalar>::dtype, _n, 1, src_cfg.bufferSize(), &_plan),
+                        "SubSample");
+    _buffer.unref();
+    _buffer = Buffer<Scalar>(out_size);
+    this->setConfig(Config(src_cfg.type(), src_cfg.sampleRate() / _n, out_size, 1));
+  }
+  virtual void process(const Buffer<Scalar> &buffer, bool allow_overwrite) {
+    if (!_plan) return;
+    if (allow_overwrite) _process(buffer, buffer);
+    else if (_buffer.isUnused()) _process(buffer, _buffer);
+  }
+
+protected:
+  void _process(const Buffer<Scalar> &in, const Buffer<Scalar> &out) {
+    size_t n = 0;
+    if (!detail::processOk(sdrhip_subsample_process(_plan, in.data(), in.size(), 0, out.data(), out.size(), &n), "gpu::SubSample")) return;
+    this->send(out.head(n), true);
+  }
+  size_t _n;
+  double _oFs;
+  int _device;
+  sdrhip_subsample *_plan;
+  Buffer<Scalar> _buffer;
+};
+
+// =================================================================================================
+// FilterNode<float>: FFT filter bank (one forward transform's worth of input, several band filters)
+// =================================================================================================
+template <class Scalar> class FilterNode;
+
+template <>
+class FilterNode<float> {
+public:
+  /** One band of the bank: a Source of complex<float> buffers (role of FilterSource, src/filternode.hh:105-227). */
+  class Band : public Source {
+  public:
+    Band(size_t block, double fmin, double fmax, int device) : _block(block), _fmin(fmin), _fmax(fmax), _device(device), _plan(0) {}
+    virtual ~Band() {
+      if (_plan) sdrhip_fftconv_destroy(_plan);
+      _buffer.unref();
+    }
+    void setFreq(double fmin, double fmax) { _fmin = fmin; _fmax = fmax; if (_cfg.hasSampleRate()) configure(_cfg); }
+    void configure(const Config &cfg) {
+      _cfg = cfg;
+      std::vector<float> h(2 * _block), K(4 * _block);
+      design::fftFilterKernel(int(_block), _fmin, _fmax, cfg.sampleRate(), h.data());
+      design::fftFilterSpectrum(int(_block), h.data(), K.data());
+      if (_plan) { sdrhip_fftconv_destroy(_plan); _plan = 0; }
+      detail::configCheck(sdrhip_fftconv_create(Device::get(_device), SDRHIP_FFTCONV_OLA, int(2 * _block), K.data(), 0, 1,
+                                                cfg.bufferSize(), &_plan), "FFT filter");
+      _buffer.unref();
+      _buffer = Buffer<cf32>(cfg.bufferSize());
+      this->setConfig(Config(Config::typeId<cf32>(), cfg.sampleRate(), cfg.bufferSize(), 1));
+    }
+    void run(const Buffer<cf32> &in) {
+      if (!_plan || !_buffer.isUnused()) return;
+      if (!detail::processOk(sdrhip_fftconv_process(_plan, reinterpret_cast<const float *>(in.data()), in.size(), 0,
+                                                    reinterpret_cast<float *>(_buffer.data()), 0), "gpu::FilterNode")) return;
+      this->send(_buffer.head(in.size()), false);
+    }
+
+  protected:
+    size_t _block;
+    double _fmin, _fmax;
+    int _device;
+    Config _cfg;
+    sdrhip_fftconv *_plan;
+    Buffer<cf32> _buffer;
+  };
+
+  explicit FilterNode(size_t block_size = 1024, int device = 0) : _block(block_size), _device(device), _sink(this) {}
+  virtual ~FilterNode() { for (std::list<Band *>::iterator b = _bands.begin(); b != _bands.end(); ++b) delete *b; }
+
+  /** The input of the bank. Unlike the reference (whose BufferNode crashes: SURVEY fact 7) any buffer size is accepted. */
+  Sink<cf32> *sink() { return &_sink; }
+  /** Adds a band [fmin, fmax]; the returned Source emits the filtered stream. */
+  Band *addFilter(double fmin, double fmax) {
+    if (fmax < fmin) std::swap(fmin, fmax);
+    _bands.push_back(new Band(_block, fmin, fmax, _device));
+    if (_cfg.hasSampleRate()) _bands.back()->configure(_cfg);
+    return _bands.back();
+  }
+
+protected:
+  class In : public Sink<cf32> {
+  public:
+    explicit In(FilterNode *p) : _p(p) {}
+    virtual void config(const Config &src_cfg) {
+      if (Config::Type_UNDEFINED == src_cfg.type() || 0 == src_cfg.sampleRate() || 0 == src_cfg.bufferSize()) return;
+      if (Config::typeId<cf32>() != src_cfg.type()) {
+        ConfigError err;
+        err << "Can not configure filter-sink: Invalid type " << src_cfg.type() << ", expected " << Config::typeId<cf32>();
+        throw err;
+      }
+      _p->_cfg = src_cfg;
+      for (std::list<Band *>::iterator b = _p->_bands.begin(); b != _p->_bands.end(); ++b) (*b)->configure(src_cfg);
+    }
+    virtual void process(const Buffer<cf32> &buffer, bool) {
+      for (std::list<Band *>::iterator b = _p->_bands.begin(); b != _p->_bands.end(); ++b) (*b)->run(buffer);
+    }
+    FilterNode *_p;
+  };
+  size_t _block;
+  int _device;
+  Config _cfg;
+  In _sink;
+  std::list<Band *> _bands;
+};
+
+// =================================================================================================
+// ChannelBank<int16_t>: C independent IQBaseBand<int16_t>(+demod) channels, one batched launch
+// =================================================================================================
+template <class Scalar> class ChannelBank;
+
+template <>
+class ChannelBank<int16_t> {
+public:
+  class Out : public Source {
+  public:
+    void configure(const Config &c) { this->setConfig(c); }
+    void emit(const RawBuffer &b, bool aw) { this->send(b, aw); }
+  };
+
+  /** All channels share the band-select parameters (taps / LUT are broadcast read-only data). */
+  ChannelBank(size_t channels, double Fc, double Ff, double width, size_t order, size_t sub_sample, int epilogue = SDRHIP_EPI_NONE,
+              int device = 0)
+    : _C(channels), _Fc(Fc), _Ff(Ff), _width(width), _order(std::max(size_t(1), order)), _D(sub_sample), _epilogue(epilogue),
+      _device(device), _plan(0), _bs(0), _have(0), _ins(channels, In(this)), _outs(channels), _pending(channels, false) {
+    for (size_t c = 0; c < _C; c++) _ins[c]._index = c;
+  }
+  virtual ~ChannelBank() {
+    if (_plan) sdrhip_iqbb_i16_destroy(_plan);
+    _stageOut.unref();
+    _stageIn.unref();
+  }
+  Sink<cs16> *sink(size_t c) { return &_ins[c]; }
+  Source *source(size_t c) { return &_outs[c]; }
+  size_t channels() const { return _C; }
+
+protected:
+  class In : public Sink<cs16> {
+  public:
+    explicit In(ChannelBank *p) : _p(p), _index(0) {}
+    virtual void config(const Config &cfg) { _p->_config(cfg); }
+    virtual void process(const Buffer<cs16> &b, bool) { _p->_deliver(_index, b); }
+    ChannelBank *_p;
+    size_t _index;
+  };
+
+  void _config(const Config &cfg) {
+    if (!cfg.hasType() || !cfg.hasSampleRate() || !cfg.hasBufferSize()) return;
+    if (Config::typeId<cs16>() != cfg.type()) {
+      ConfigError err;
+      err << "Can not configure ChannelBank: Invalid type " << cfg.type() << ", expected " << Config::typeId<cs16>();
+      throw err;
+    }
+    if (_plan && cfg == _cfg) return;   // every channel's source pushes the same Config
+    _cfg = cfg;
+    _bs = cfg.bufferSize();
+    const int32_t Fs = int32_t(cfg.sampleRate());
+    std::vector<int32_t> taps(2 * _order), lut(2 * design::kLutSize);
+    design::iqbbTaps(_Ff, _width, Fs, _order, taps.data());
+    design::freqShiftLutI16(lut.data());
+    if (_plan) { sdrhip_iqbb_i16_destroy(_plan); _plan = 0; }
+    detail::configCheck(sdrhip_iqbb_i16_create(Device::get(_device), taps.data(), int(_order), lut.data(),
+                                               design::freqShiftIncrement(_Fc, double(Fs)), 0 > _Fc, int(_D), int(_C), _bs, _epilogue,
+                                               &_plan), "ChannelBank");
+    _outStride = _bs / _D + 2;
+    _stageIn.unref(); _stageOut.unref();
+    _stageIn = Buffer<cs16>(_C * _bs);
+    _stageOut = Buffer<cs16>(_C * _outStride);
+    std::fill(_pending.begin(), _pending.end(), false);
+    _have = 0;
+    const double oRate = double(size_t(Fs) / _D);
+    for (size_t c = 0; c < _C; c++)
+      _outs[c].configure(Config(_epilogue == SDRHIP_EPI_NONE ? Config::typeId<cs16>() : Config::typeId<int16_t>(), oRate, _outStride, 1));
+  }
+
+  /** Collects one buffer per channel (all of the same length: buffer boundaries are part of the
+   * numerical contract), then launches once for the whole bank. */
+  void _deliver(size_t c, const Buffer<cs16> &b) {
+    if (!_plan || b.size() > _bs) return;
+    if (_have == 0) _len = b.size();
+    if (_pending[c] || b.size() != _len) {
+      LogMessage msg(LOG_WARNING);
+      msg << "gpu::ChannelBank: channel " << c << " delivered out of step; buffer dropped";
+      Logger::get().log(msg);
+      return;
+    }
+    memcpy(_stageIn.data() + c * _bs * sizeof(cs16), b.data(), b.size() * sizeof(cs16));
+    _pending[c] = true;
+    if (++_have < _C) return;
+    _have = 0;
+    std::fill(_pending.begin(), _pending.end(), false);
+    size_t n = 0;
+    const size_t per = _epilogue == SDRHIP_EPI_NONE ? 1 : 2;   // int16 elements fit twice into a cs16 row
+    if (!detail::processOk(sdrhip_iqbb_i16_process(_plan, reinterpret_cast<const int16_t *>(_stageIn.data()), _len, _bs,
+                                                   _stageOut.data(), _outStride * per, &n), "gpu::ChannelBank")) return;
+    for (size_t ch = 0; ch < _C; ch++) {
+      if (_epilogue == SDRHIP_EPI_NONE) _outs[ch].emit(_stageOut.sub(ch * _outStride, n), false);
+      else if (!(_epilogue == SDRHIP_EPI_FM && n == 0))
+        _outs[ch].emit(Buffer<int16_t>(_stageOut).sub(ch * _outStride * 2, n), false);
+    }
+  }
+
+  size_t _C;
+  double _Fc, _Ff, _width;
+  size_t _order, _D;
+  int _epilogue, _device;
+  sdrhip_iqbb_i16 *_plan;
+  Config _cfg;
+  size_t _bs, _have, _len, _outStride;
+  std::vector<In> _ins;
+  std::vector<Out> _outs;
+  std::vector<bool> _pending;
+  Buffer<cs16> _stageIn, _stageOut;
+};
+
+}  // namespace gpu
+}  // namespace sdr
+
+#endif

@@ -1,0 +1,43 @@
+"""Channel sharding across the GPUs of one node: independent IQ channels are split into
+contiguous blocks, one process per GPU; the only exchanges are a broadcast of the read-only design
+(taps / LUT / FFT kernel, a few KB, at config time) and an optional gather of demodulated output on a
+root. `torch.distributed` backend "nccl" is RCCL over xGMI on ROCm; the same code runs on "gloo" (CPU)
+in tests/test_dist_gloo.py. No compute lives here."""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total_channels, world, rank):
+    """Contiguous block [lo, hi) of channels owned by `rank`; sizes differ by at most one."""
+    base, rem = divmod(total_channels, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def broadcast_design(tensors, src=0):
+    """Broadcasts design tensors (designed on `src`) so that every rank filters with bit-identical taps."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        for t in tensors:
+            dist.broadcast(t, src)
+    return tensors
+
+
+def gather_output(local, total_channels, dst=0, async_op=False):
+    """Gathers per-rank output rows [channels_local, n] onto `dst` as [total_channels, n] (row order =
+    global channel order). Ranks may own different numbers of channels. Returns (tensor_or_None, work)."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return local, None
+    rank = dist.get_rank()
+    dtype = local.dtype
+    if dtype == torch.int16:   # gloo has no int16 collectives; bytes travel the same on RCCL
+        local = local.contiguous().view(torch.uint8)
+    sizes = [shard_range(total_channels, world, r) for r in range(world)]
+    if rank == dst:
+        parts = [torch.empty((hi - lo,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device) for lo, hi in sizes]
+        work = dist.gather(local, parts, dst=dst, async_op=async_op)
+        if async_op:
+            return parts, work
+        return torch.cat(parts, 0).view(dtype), None
+    work = dist.gather(local, None, dst=dst, async_op=async_op)
+    return None, work

@@ -1,0 +1,199 @@
+// test_gpu_nodes.cc — the MI355X nodes (include/sdr/gpu/nodes.hh) wired into real graphs with this
+// repository's sdr:: core, compared bit-exactly with the CPU oracle (oracle/sdr_oracle.h; test side
+// only). Graph shapes follow examples/sdr_fm.cc:49-53 and SURVEY §3.2/§3.3. Needs an MI355X.
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <vector>
+
+#include "sdr/sdr.hh"
+#include "sdr_oracle.h"
+
+using namespace sdr;
+typedef std::complex<int16_t> cs16;
+typedef std::complex<float> cf32;
+
+static int failures = 0;
+#define CHECK(c) do { if (!(c)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #c); failures++; } } while (0)
+
+static const double FS = 2.4e6;
+
+struct Feeder : public Source {
+  void cfg(Config::Type t, size_t bs) { setConfig(Config(t, FS, bs, 1)); }
+  template <class T> void feed(T *p, size_t n) { Buffer<T> b(p, n); send(b, false); }
+};
+
+static std::vector<cs16> tones(size_t n, double f1 = 100e3) {
+  IQSigGen<int16_t> gen(FS, n); gen.addSine(f1, 8000, 0.0); gen.addSine(-300e3, 6000, 0.3);
+  Recorder<cs16> r; gen.connect(&r, true); gen.next();
+  return r.data;
+}
+
+// IQSigGen -> gpu::IQBaseBand -> gpu::FMDemod (direct edges, FM in place over the baseband's buffer)
+static void testBasebandFmChain() {
+  const size_t N = 4096, NB = 4;
+  IQSigGen<int16_t> gen(FS, N); gen.addSine(100e3, 8000, 0.0); gen.addSine(-300e3, 6000, 0.3);
+  gpu::IQBaseBand<int16_t> bb(100e3, 100e3, 50e3, 127, 8);
+  gpu::FMDemod<int16_t> fm;
+  Recorder<cs16> raw; Recorder<int16_t> out;
+  gen.connect(&raw, true); gen.connect(&bb, true); bb.connect(&fm, true); fm.connect(&out, true);
+  for (size_t b = 0; b < NB; b++) gen.next();
+  CHECK(out.lens.size() == NB && out.lens[0] == 511 && out.lens[1] == 512);
+  CHECK(bb.Source::sampleRate() == 300000.0 && fm.type() == Config::Type_s16);
+  // oracle
+  std::vector<int32_t> taps(2 * 127), lut(256);
+  orc_iqbb_design(100e3, 50e3, FS, 127, taps.data()); orc_freqshift_lut_i16(lut.data());
+  void *o = orc_iqbb_i16_create(taps.data(), 127, lut.data(), orc_freqshift_inc(100e3, FS), 0, 8);
+  std::vector<int16_t> ref; int16_t last = 0;
+  for (size_t b = 0; b < NB; b++) {
+    std::vector<int16_t> y(2 * 520);
+    size_t n = orc_iqbb_i16_process(o, (const int16_t *)&raw.data[b * N], N, y.data());
+    std::vector<int16_t> f(n); f[0] = y[0];
+    orc_fm_i16(y.data(), n, f.data(), &last);
+    ref.insert(ref.end(), f.begin(), f.end());
+  }
+  orc_iqbb_i16_destroy(o);
+  CHECK(ref.size() == out.data.size() && 0 == memcmp(ref.data(), out.data.data(), ref.size() * 2));
+  // fused variant: one kernel launch per buffer, same numbers
+  IQSigGen<int16_t> gen2(FS, N); gen2.addSine(100e3, 8000, 0.0); gen2.addSine(-300e3, 6000, 0.3);
+  gpu::IQBaseBand<int16_t> fused(100e3, 100e3, 50e3, 127, 8); fused.setDemod(SDRHIP_EPI_FM);
+  Recorder<int16_t> out2; gen2.connect(&fused, true); fused.connect(&out2, true);
+  for (size_t b = 0; b < NB; b++) gen2.next();
+  CHECK(out2.data == out.data);
+}
+
+// config 1 on the Queue: generator idle-driven, queued edge into the FIR, direct edge FIR -> FM
+static void testFirFmOnQueue() {
+  const size_t N = 8192, NB = 6;
+  IQSigGen<int16_t> gen(FS, N, NB * N / FS - 0.5 / FS); gen.addSine(100e3, 8000, 0.0); gen.addSine(-300e3, 6000, 0.3);
+  gpu::FIRLowPass<cs16> fir(127, 100e3);
+  gpu::FMDemod<int16_t> fm;
+  Recorder<int16_t> out;
+  gen.connect(&fir, false); fir.connect(&fm, true); fm.connect(&out, true);
+  Queue::get().addIdle(&gen, &IQSigGen<int16_t>::next);
+  Queue::get().start(); Queue::get().wait();
+  Queue::get().remIdle(&gen);
+  CHECK(out.data.size() == NB * N);
+  IQSigGen<int16_t> g2(FS, N); g2.addSine(100e3, 8000, 0.0); g2.addSine(-300e3, 6000, 0.3);
+  Recorder<cs16> raw; g2.connect(&raw, true);
+  std::vector<double> a(127); orc_fir_lowpass_design(127, 100e3, FS, a.data());
+  void *f = orc_fir_create(a.data(), 127);
+  std::vector<int16_t> ref; int16_t last = 0;
+  for (size_t b = 0; b < NB; b++) {
+    g2.next();
+    std::vector<int16_t> y(2 * N), o(N);
+    orc_fir_cs16_process(f, (const int16_t *)&raw.data[b * N], N, y.data());
+    o[0] = y[0]; orc_fm_i16(y.data(), N, o.data(), &last);
+    ref.insert(ref.end(), o.begin(), o.end());
+  }
+  orc_fir_destroy(f);
+  CHECK(ref.size() == out.data.size() && 0 == memcmp(ref.data(), out.data.data(), ref.size() * 2));
+}
+
+// ownership rules: in place when allowed, own buffer otherwise, drop while the own buffer is referenced
+static void testOwnership() {
+  std::vector<cs16> x = tones(4096);
+  Feeder src; src.cfg(Config::Type_cs16, 4096);
+  gpu::IQBaseBand<int16_t> bb(100e3, 100e3, 50e3, 21, 8);
+  struct Hold : public Sink<cs16> {
+    RawBuffer kept; bool keep = false; size_t calls = 0; const char *last_ptr = 0; bool aw = false;
+    virtual void config(const Config &) {}
+    virtual void process(const Buffer<cs16> &b, bool a) { calls++; last_ptr = b.data(); aw = a; if (keep) { kept = b; kept.ref(); } }
+  } hold;
+  src.connect(&bb, true); bb.connect(&hold, true);
+  src.feed(x.data(), 4096);
+  CHECK(hold.calls == 1 && hold.aw && hold.last_ptr != (const char *)x.data());   // own buffer, downstream may overwrite
+  hold.keep = true; src.feed(x.data(), 4096); CHECK(hold.calls == 2);
+  src.feed(x.data(), 4096); CHECK(hold.calls == 2);                               // still referenced -> dropped
+  hold.kept.unref(); hold.keep = false;
+  src.feed(x.data(), 4096); CHECK(hold.calls == 3);
+  Buffer<cs16> mine(4096); memcpy(mine.data(), x.data(), 4096 * 4);
+  bb.handleBuffer(mine, true);                                                     // allow_overwrite -> in place
+  CHECK(hold.calls == 4 && hold.last_ptr == mine.data());
+  mine.unref();
+  // wrong type -> ConfigError, incomplete config -> silent
+  Feeder bad; bad.cfg(Config::Type_cf32, 64);
+  bool thrown = false;
+  try { bad.connect(&bb, true); } catch (ConfigError &e) { thrown = std::string(e.what()).find("Invalid type") != std::string::npos; }
+  CHECK(thrown);
+  Feeder empty; gpu::FMDemod<int16_t> fm; empty.connect(&fm, true);
+}
+
+// 16 channels through the ChannelBank = 16 independent single nodes
+static void testChannelBank() {
+  const size_t C = 16, N = 4096;
+  gpu::ChannelBank<int16_t> bank(C, 100e3, 100e3, 50e3, 127, 8, SDRHIP_EPI_USB);
+  std::vector<Feeder> src(C); std::vector< Recorder<int16_t> > rec(C);
+  std::vector< std::vector<cs16> > x(C);
+  for (size_t c = 0; c < C; c++) {
+    x[c] = tones(2 * N, 90e3 + 1500.0 * c);
+    src[c].cfg(Config::Type_cs16, N);
+    src[c].connect(bank.sink(c), true); bank.source(c)->connect(&rec[c], true);
+  }
+  for (int k = 0; k < 2; k++) for (size_t c = 0; c < C; c++) src[c].feed(&x[c][k * N], N);
+  std::vector<int32_t> taps(2 * 127), lut(256);
+  orc_iqbb_design(100e3, 50e3, FS, 127, taps.data()); orc_freqshift_lut_i16(lut.data());
+  for (size_t c = 0; c < C; c++) {
+    void *o = orc_iqbb_i16_create(taps.data(), 127, lut.data(), orc_freqshift_inc(100e3, FS), 0, 8);
+    std::vector<int16_t> ref;
+    for (int k = 0; k < 2; k++) {
+      std::vector<int16_t> y(2 * 520), u(520);
+      size_t n = orc_iqbb_i16_process(o, (const int16_t *)&x[c][k * N], N, y.data());
+      orc_usb_i16(y.data(), n, u.data()); ref.insert(ref.end(), u.begin(), u.begin() + n);
+    }
+    orc_iqbb_i16_destroy(o);
+    CHECK(ref == rec[c].data);
+  }
+}
+
+// float nodes: FIRLowPass<cf32> -> SubSample<cf32>(8) and the FFT filter bank vs direct convolution
+static void testFloatNodes() {
+  const size_t N = 4096;
+  IQSigGen<float> gen(FS, N); gen.addSine(100e3, 0.5, 0.0); gen.addSine(-300e3, 0.3, 0.3);
+  Recorder<cf32> raw; gpu::FIRLowPass<cf32> fir(127, 100e3); gpu::SubSample<cf32> sub(size_t(8)); Recorder<cf32> out;
+  gpu::FilterNode<float> bank(1024); Recorder<cf32> band;
+  gen.connect(&raw, true); gen.connect(&fir, true); fir.connect(&sub, true); sub.connect(&out, true);
+  gen.connect(bank.sink(), true); bank.addFilter(50e3, 150e3)->connect(&band, true);
+  for (int b = 0; b < 3; b++) gen.next();
+  CHECK(out.data.size() == 3 * N / 8 && band.data.size() == 3 * N);
+  std::vector<double> a(127); orc_fir_lowpass_design(127, 100e3, FS, a.data());
+  void *f = orc_fir_create(a.data(), 127); void *s = orc_subsample_create(8);
+  std::vector<float> y(2 * 3 * N), d(2 * 3 * N / 8);
+  orc_fir_cf32_process(f, (const float *)raw.data.data(), 3 * N, y.data());
+  orc_subsample_cf32_process(s, y.data(), 3 * N, d.data());
+  double err = 0, mx = 0;
+  for (size_t i = 0; i < out.data.size(); i++) {
+    err = std::max(err, (double)std::abs(out.data[i] - cf32(d[2 * i], d[2 * i + 1]))); mx = std::max(mx, (double)std::abs(cf32(d[2 * i], d[2 * i + 1])));
+  }
+  CHECK(err / mx <= 1e-5);
+  orc_fir_destroy(f); orc_subsample_destroy(s);
+  std::vector<float> h(2 * 1024), K(4 * 1024), fo(2 * 1024);
+  orc_fftfilt_design_h(1024, 50e3, 150e3, FS, h.data()); orc_fftfilt_design_K(1024, h.data(), K.data());
+  void *ff = orc_fftfilt_create(1024, K.data());
+  err = 0; mx = 0;
+  for (size_t blk = 0; blk < 3 * N / 1024; blk++) {
+    orc_fftfilt_process(ff, (const float *)&raw.data[blk * 1024], fo.data());
+    for (size_t i = 0; i < 1024; i++) {
+      const cf32 r(fo[2 * i], fo[2 * i + 1]);
+      err = std::max(err, (double)std::abs(band.data[blk * 1024 + i] - r)); mx = std::max(mx, (double)std::abs(r));
+    }
+  }
+  CHECK(err / mx <= 1e-5);
+  orc_fftfilt_destroy(ff);
+}
+
+int main() {
+  Logger::get().addHandler(new StreamLogHandler(std::cerr, LOG_WARNING));
+  try {
+    testBasebandFmChain();
+    testFirFmOnQueue();
+    testOwnership();
+    testChannelBank();
+    testFloatNodes();
+  } catch (std::exception &e) {
+    std::printf("FAIL: exception: %s\n", e.what());
+    return 2;
+  }
+  std::printf("%s (%d failures)\n", failures ? "FAILED" : "OK", failures);
+  return failures ? 1 : 0;
+}
