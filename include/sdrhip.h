@@ -122,6 +122,10 @@ int sdrhip_design_fftfilt_spectrum(int n, const float *h, float *spectrum);
 int sdrhip_iqbb_i16_create(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32_t *lut,
                            uint32_t lut_inc, int negative, int decim, int channels, size_t max_in,
                            int epilogue, sdrhip_iqbb_i16 **out);
+/* which kernel formulation the plan selected: 0 = VALU v_dot2c_i32_i16 (any decim/order), 1 = int8-MFMA
+ * block-Toeplitz GEMM (decim 8, order <= 129); both are bit-exact. Environment variable
+ * SDRHIP_IQBB_PATH=valu|mfma forces one at create time (tests). */
+int sdrhip_iqbb_i16_path(sdrhip_iqbb_i16 *h, int *path);
 /* outputs the next call of n_in samples will produce (does not advance the state) */
 int sdrhip_iqbb_i16_out_count(sdrhip_iqbb_i16 *h, size_t n_in, size_t *n_out);
 /* in: channels x n_in cs16 (row stride in_stride samples); out: channels rows of out_stride

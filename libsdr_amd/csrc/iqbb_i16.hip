@@ -18,6 +18,8 @@
 // 16-sample register window over an LDS-staged tile; taps arrive through the scalar cache.
 #include "sdrhip_internal.hpp"
 
+#include <cstdlib>
+
 using namespace sdrhip;
 
 namespace {
@@ -29,6 +31,8 @@ constexpr int TAPC = 8;        // taps per unrolled chunk (order is zero-padded 
 constexpr int MAX_ORDER = 2048;
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
 
 struct IqbbArgs {
   const uint32_t *in; long in_stride;            // cs16 packed as one dword per sample
@@ -44,7 +48,10 @@ struct IqbbArgs {
   int n_out;        // groups that complete in this call (always the first n_out of them)
   int extra0;       // absolute sample 0 joins group 0 (src/baseband.hh:200,212: D+1 first window)
   int CG, OG, ovl;  // groups computed / emitted per tile; FM recomputes one leading group
+  int CGr;          // CG rounded up to 4: ybuf[CGr] is followed by the FM angle cache [CGr]
   void *out; long out_stride; int epilogue;
+  const v4i *tapfrag; int cre, cim;
+  int tiles, tpw;   // tiles per channel in this call; consecutive tiles walked by one workgroup (MFMA path)   // MFMA path: tap fragments, 128*sum(a) per component
 };
 
 __device__ __forceinline__ uint32_t load_x(const IqbbArgs &a, int c, int rel) {
@@ -59,15 +66,18 @@ __device__ __forceinline__ int dot2(uint32_t x, uint32_t k, int acc) {
 
 __device__ __forceinline__ int mulw(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
 
-// FreqShiftBase<int16_t>::applyFrequencyShift at absolute index n (low 32 bits suffice)
+// FreqShiftBase<int16_t>::applyFrequencyShift at absolute index n (low 32 bits suffice).
+// Full-rate 24-bit multiplies: only the low 15 bits of n*inc matter; |LUT| < 2^23 (checked at create,
+// the reference's is <= 2^16) and r = S>>14 lies in [-2^17, 2^17), so v_mul_i32_i24's low 32 bits equal
+// the reference's wrapping 32-bit products.
 __device__ __forceinline__ int2 rotate(const IqbbArgs &a, const int2 *lut_s, int2 r, uint32_t n_lo) {
   if (a.inc == 0) return r;
-  uint32_t idx = ((n_lo * a.inc) & 32767u) >> 8;
+  uint32_t idx = (__umul24(n_lo & 32767u, a.inc & 32767u) & 32767u) >> 8;
   if (a.negative) idx = 127u - idx;
   const int2 L = lut_s[idx];
   int2 v;
-  v.x = (int)((unsigned)mulw(L.x, r.x) - (unsigned)mulw(L.y, r.y)) >> 16;
-  v.y = (int)((unsigned)mulw(L.x, r.y) + (unsigned)mulw(L.y, r.x)) >> 16;
+  v.x = (int)((unsigned)__mul24(L.x, r.x) - (unsigned)__mul24(L.y, r.y)) >> 16;
+  v.y = (int)((unsigned)__mul24(L.x, r.y) + (unsigned)__mul24(L.y, r.x)) >> 16;
   return v;
 }
 
@@ -80,13 +90,24 @@ __device__ __forceinline__ int box_div(int s, int D) {
   return r / n;
 }
 
+// trunc(num/den) for |num| <= 4096*den, 0 < den < 2^16 (the only divisions fast_atan2 makes): float
+// estimate (|q| <= 4096, error < 1) + one exact remainder correction, instead of the generic 32-bit sequence
+__device__ __forceinline__ int div_small(int num, int den) {
+  const unsigned nu = (unsigned)(num < 0 ? -num : num), de = (unsigned)den;
+  unsigned q = (unsigned)((float)nu * __frcp_rn((float)de));
+  int r = (int)(nu - __umul24(q, de));
+  if (r < 0) { q -= 1; r += (int)de; }
+  if (r >= (int)de) q += 1;
+  return num < 0 ? -(int)q : (int)q;
+}
+
 // fast_atan2<int16_t,int16_t>(a, b) / 2   (src/math.hh:31-40, src/demod.hh:246)
 __device__ __forceinline__ int fm_phi(int a, int b) {
   if (a == 0 && b == 0) return 0;
   const int aabs = a >= 0 ? a : -a;
   int angle;
-  if (b >= 0) angle = 4096 - 4096 * (b - aabs) / (b + aabs);
-  else angle = 12288 - 4096 * (b + aabs) / (aabs - b);
+  if (b >= 0) angle = 4096 - div_small(4096 * (b - aabs), b + aabs);
+  else angle = 12288 - div_small(4096 * (b + aabs), aabs - b);
   const short at = (short)(a >= 0 ? angle : -angle);
   return (int)at / 2;
 }
@@ -98,6 +119,68 @@ __device__ __forceinline__ short am_i16(int re, int im) {
 
 __device__ __forceinline__ short usb_i16(int re, int im) { return (short)((re + im) / 2); }
 
+// one decimation group is complete (or left open at the end of the call): carry, first-sample quirk,
+// truncating division, state
+__device__ __forceinline__ void finalize_group(const IqbbArgs &a, int c, const int2 *lut_s, uint32_t *ybuf, int ql, int q, int2 s, int D) {
+  if (q == 0) {
+    const int2 carry = a.acc_old[c];
+    s.x = (int)((unsigned)s.x + (unsigned)carry.x);
+    s.y = (int)((unsigned)s.y + (unsigned)carry.y);
+    if (a.extra0) {   // absolute sample 0: one slow FIR evaluation per channel and stream start
+      int er = 0, ei = 0;
+      for (int i = 0; i < a.OP; i++) {
+        const uint32_t x = load_x(a, c, -(a.OP - 1) + i);
+        const uint2 k = a.taps[i];
+        er = dot2(x, k.x, er); ei = dot2(x, k.y, ei);
+      }
+      const int2 v = rotate(a, lut_s, make_int2(er >> 14, ei >> 14), a.n0_lo);
+      s.x = (int)((unsigned)s.x + (unsigned)v.x);
+      s.y = (int)((unsigned)s.y + (unsigned)v.y);
+    }
+  }
+  const bool emits = q < a.n_out;
+  if (emits) {
+    const int yr = (short)box_div(s.x, D), yi = (short)box_div(s.y, D);
+    ybuf[ql] = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
+    if (a.epilogue == SDRHIP_EPI_FM) reinterpret_cast<int *>(ybuf + a.CGr)[ql] = fm_phi(yr, yi);   // angle cache
+  }
+  if (q == a.n_groups - 1) a.acc_new[c] = emits ? make_int2(0, 0) : s;
+}
+
+// store / demodulate the tile's outputs (ybuf complete), and let the channel's last tile roll the history
+__device__ __forceinline__ void epilogue_and_roll(const IqbbArgs &a, int c, int tile, int tid, int q0, int groups_here,
+                                                  const uint32_t *ybuf) {
+  for (int ql = a.ovl + tid; ql < groups_here; ql += TPB) {
+    const int j = q0 + ql;   // output index within this call
+    if (j >= a.n_out) continue;
+    const uint32_t y = ybuf[ql];
+    const int yr = (short)(y & 0xffffu), yi = (short)(y >> 16);
+    if (a.epilogue == SDRHIP_EPI_NONE) {
+      reinterpret_cast<uint32_t *>(a.out)[(long)c * a.out_stride + j] = y;
+    } else {
+      short o;
+      if (a.epilogue == SDRHIP_EPI_AM) o = am_i16(yr, yi);
+      else if (a.epilogue == SDRHIP_EPI_USB) o = usb_i16(yr, yi);
+      else {
+        const int *phib = reinterpret_cast<const int *>(ybuf + a.CGr);
+        const int phi = phib[ql];
+        if (j == 0) o = (short)yr;             // index 0 is never written by FMDemod (in place)
+        else o = (short)((j == 1 ? (int)a.fm_old[c] : phib[ql - 1]) - phi);   // y[0] is never looked at: the
+                                                                              // previous call's last angle
+        if (j == a.n_out - 1 && a.n_out >= 2) a.fm_new[c] = (short)phi;
+      }
+      reinterpret_cast<short *>(a.out)[(long)c * a.out_stride + j] = o;
+    }
+  }
+  if (tile == a.tiles - 1) {
+    for (int k = tid; k < a.HH; k += TPB) {
+      const long qq = (long)a.N + k;   // index into concat(hist_old, in)
+      a.hist_new[(long)c * a.HH + k] =
+          qq < a.HH ? a.hist_old[(long)c * a.HH + qq] : a.in[(long)c * a.in_stride + (qq - a.HH)];
+    }
+  }
+}
+
 template <bool FAST8>
 __global__ __launch_bounds__(TPB) void iqbb_i16_kernel(const IqbbArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -105,7 +188,7 @@ __global__ __launch_bounds__(TPB) void iqbb_i16_kernel(const IqbbArgs a) {
   uint32_t *xs = smem;                                  // staged samples, x[tb-(OP-1) ...]
   int2 *lut_s = reinterpret_cast<int2 *>(smem + XS);    // 128 entries
   uint32_t *ybuf = smem + XS + 256;                     // CG packed cs16 results
-  int2 *vbuf = reinterpret_cast<int2 *>(ybuf + ((a.CG + 3) & ~3));  // generic path only: TI entries
+  int2 *vbuf = reinterpret_cast<int2 *>(ybuf + 2 * a.CGr);  // generic path only: TI entries
 
   const int c = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
   const int q0 = tile * a.OG - a.ovl;    // first group (relative to the call's first group) of this tile
@@ -183,65 +266,112 @@ __global__ __launch_bounds__(TPB) void iqbb_i16_kernel(const IqbbArgs a) {
         s.y = (int)((unsigned)s.y + (unsigned)v.y);
       }
     }
-    if (q == 0) {
-      const int2 carry = a.acc_old[c];
-      s.x = (int)((unsigned)s.x + (unsigned)carry.x);
-      s.y = (int)((unsigned)s.y + (unsigned)carry.y);
-      if (a.extra0) {   // absolute sample 0: one slow FIR evaluation per channel and stream start
-        int er = 0, ei = 0;
-        for (int i = 0; i < a.OP; i++) {
-          const uint32_t x = load_x(a, c, -(a.OP - 1) + i);
-          const uint2 k = a.taps[i];
-          er = dot2(x, k.x, er); ei = dot2(x, k.y, ei);
-        }
-        const int2 v = rotate(a, lut_s, make_int2(er >> 14, ei >> 14), a.n0_lo);
-        s.x = (int)((unsigned)s.x + (unsigned)v.x);
-        s.y = (int)((unsigned)s.y + (unsigned)v.y);
-      }
+    finalize_group(a, c, lut_s, ybuf, ql, q, s, a.D);
+  }
+  __syncthreads();
+  epilogue_and_roll(a, c, tile, tid, q0, groups_here, ybuf);
+}
+
+// =================================================================================================
+// MFMA formulation (D == 8): the FIR as a block-Toeplitz int8 GEMM on the matrix cores.
+//
+//   Dmat[m = (t, comp)][n = block] = sum_k TapT[m][k] * U[k][n]
+// A block is 16 consecutive samples of the channel, a wave owns 32 consecutive blocks (512 samples);
+// U[k][n] is element k of the block's window in the interleaved (re,im) int16 element stream and
+// TapT[m][k] = a_comp[k - 2t] the Toeplitz matrix of the interleaved tap vectors (re: Kr,-Ki ...;
+// im: Ki,Kr ...). int16 x int16 products are made exact on v_mfma_i32_32x32x32_i8 by byte planes:
+//   u = 256*uh + ul' + 128 (uh = u>>8, ul' = (u&255)-128),   a = 256*ah + al (al in [-128,127])
+//   S = 65536*sum(ah*uh) + 256*sum(ah*ul' + al*uh) + sum(al*ul') + 128*sum(a)      (mod 2^32)
+// i.e. 4 MFMAs per 32-deep K step into 3 accumulators; int32 ring arithmetic makes the recombination
+// bit-exact. The tap fragments are wave-invariant and stay in registers (2 planes x S steps x 4 VGPR),
+// the sample planes are staged once per workgroup into LDS and read as conflict-free 16-byte rows.
+// Result layout (32x32 C/D map): lane (n = l&31, h = l>>5), register r -> comp = r&1,
+// t = ((r&3)>>1) + 4*(r>>2) + 2h: a lane holds (re,im) pairs of 8 samples of its block, 4 per decimation
+// group; the other 4 sit in lane l^32.
+// =================================================================================================
+constexpr int MF_BLK = 16;    // samples per block (one column)
+constexpr int MF_WAVE = 512;  // samples per wave tile (32 blocks)
+
+template <int S>
+__global__ __launch_bounds__(TPB, 2) void iqbb_i16_mfma_kernel(const IqbbArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const int PLW = (2 * (TI + a.OP) + 64 + 15) / 16 * 4;    // dwords per byte plane
+  uint32_t *lo = smem, *hi = smem + PLW;
+  int2 *lut_s = reinterpret_cast<int2 *>(smem + 2 * PLW);
+  uint32_t *ybuf = smem + 2 * PLW + 256;
+
+  const int c = blockIdx.y, tid = threadIdx.x;
+  const int w = tid >> 6, l = tid & 63, n = l & 31, h = l >> 5;
+  // tap fragments: wave-invariant, loaded once and kept in registers across the tiles this workgroup walks
+  v4i Ah[S], Al[S];
+#pragma unroll
+  for (int s = 0; s < S; s++) { Ah[s] = a.tapfrag[(2 * s) * 64 + l]; Al[s] = a.tapfrag[(2 * s + 1) * 64 + l]; }
+  if (tid < 128) lut_s[tid] = a.lut[tid];
+
+  for (int it = 0; it < a.tpw; it++) {
+  const int tile = blockIdx.x * a.tpw + it;
+  if (tile >= a.tiles) break;
+  const int q0 = tile * a.OG - a.ovl;
+  const int tb = a.base0_rel + q0 * a.D;
+  const int groups_here = min(a.CG, a.n_groups - q0);
+
+  // ---- stage: two samples -> 4 bytes of the low plane (offset to signed) and 4 of the high plane ----
+  {
+    const int first = tb - (a.OP - 1);
+    const int pairs = (groups_here * 8 + a.OP + 2) / 2;
+    for (int p = tid; p < pairs; p += TPB) {
+      const uint32_t x0 = load_x(a, c, first + 2 * p), x1 = load_x(a, c, first + 2 * p + 1);
+      lo[p] = __builtin_amdgcn_perm(x1, x0, 0x06040200u) ^ 0x80808080u;
+      hi[p] = __builtin_amdgcn_perm(x1, x0, 0x07050301u);
     }
-    const bool emits = q < a.n_out;
-    if (emits) {
-      const int yr = box_div(s.x, a.D), yi = box_div(s.y, a.D);
-      ybuf[ql] = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
-    }
-    if (q == a.n_groups - 1) a.acc_new[c] = emits ? make_int2(0, 0) : s;
   }
   __syncthreads();
 
-  // ---- epilogue: store / demodulate --------------------------------------------------------------
-  for (int ql = a.ovl + tid; ql < groups_here; ql += TPB) {
-    const int j = q0 + ql;   // output index within this call
-    if (j >= a.n_out) continue;
-    const uint32_t y = ybuf[ql];
-    const int yr = (short)(y & 0xffffu), yi = (short)(y >> 16);
-    if (a.epilogue == SDRHIP_EPI_NONE) {
-      reinterpret_cast<uint32_t *>(a.out)[(long)c * a.out_stride + j] = y;
-    } else {
-      short o;
-      if (a.epilogue == SDRHIP_EPI_AM) o = am_i16(yr, yi);
-      else if (a.epilogue == SDRHIP_EPI_USB) o = usb_i16(yr, yi);
-      else {
-        const int phi = fm_phi(yr, yi);
-        if (j == 0) o = (short)yr;             // index 0 is never written by FMDemod (in place)
-        else {
-          int prev;
-          if (j == 1) prev = a.fm_old[c];      // y[0] is never looked at; last angle of the previous call
-          else { const uint32_t yp = ybuf[ql - 1]; prev = fm_phi((short)(yp & 0xffffu), (short)(yp >> 16)); }
-          o = (short)(prev - phi);
-        }
-        if (j == a.n_out - 1 && a.n_out >= 2) a.fm_new[c] = (short)phi;
+  if (64 * w < groups_here) {   // wave-uniform
+    v16i acc_hh = {0}, acc_mid = {0}, acc_ll;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc_ll[r] = (r & 1) ? a.cim : a.cre;   // + 128*sum(a) rides in as C
+    const char *pl = reinterpret_cast<const char *>(lo) + 1024 * w + 32 * n + 16 * h;
+    const char *ph = reinterpret_cast<const char *>(hi) + 1024 * w + 32 * n + 16 * h;
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+      const v4i ul = *reinterpret_cast<const v4i *>(pl + 32 * s);
+      const v4i uh = *reinterpret_cast<const v4i *>(ph + 32 * s);
+      acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[s], uh, acc_hh, 0, 0, 0);
+      acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[s], ul, acc_mid, 0, 0, 0);
+      acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[s], uh, acc_mid, 0, 0, 0);
+      acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[s], ul, acc_ll, 0, 0, 0);
+    }
+    // ---- recombine, >>14, rotate, mask, partial box sums (4 samples per group in this lane) --------
+    int2 part[2];
+    part[0] = make_int2(0, 0); part[1] = make_int2(0, 0);
+    const int rel0 = tb + MF_WAVE * w + MF_BLK * n + 2 * h;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+#pragma unroll
+      for (int tt = 0; tt < 2; tt++) {
+        const int rr = 4 * q + 2 * tt;
+        const unsigned sre = ((unsigned)acc_hh[rr] << 16) + ((unsigned)acc_mid[rr] << 8) + (unsigned)acc_ll[rr];
+        const unsigned sim = ((unsigned)acc_hh[rr + 1] << 16) + ((unsigned)acc_mid[rr + 1] << 8) + (unsigned)acc_ll[rr + 1];
+        const int rel = rel0 + 4 * q + tt;
+        int2 v = rotate(a, lut_s, make_int2((int)sre >> 14, (int)sim >> 14), a.n0_lo + (uint32_t)rel);
+        if (rel < 0 || rel >= a.N) v = make_int2(0, 0);
+        part[q >> 1].x = (int)((unsigned)part[q >> 1].x + (unsigned)v.x);
+        part[q >> 1].y = (int)((unsigned)part[q >> 1].y + (unsigned)v.y);
       }
-      reinterpret_cast<short *>(a.out)[(long)c * a.out_stride + j] = o;
     }
+    // lane h=0 finishes group 0 of its block, lane h=1 group 1: swap the partial the other one needs
+    const int2 give = h ? part[0] : part[1];
+    int2 mine = h ? part[1] : part[0];
+    mine.x = (int)((unsigned)mine.x + (unsigned)__shfl_xor(give.x, 32));
+    mine.y = (int)((unsigned)mine.y + (unsigned)__shfl_xor(give.y, 32));
+    const int ql = 64 * w + 2 * n + h;
+    const int q = q0 + ql;
+    if (ql < groups_here && q >= 0) finalize_group(a, c, lut_s, ybuf, ql, q, mine, 8);
   }
-
-  // ---- the last tile of a channel also rolls the FIR history forward ---------------------------
-  if (tile == (int)gridDim.x - 1) {
-    for (int k = tid; k < a.HH; k += TPB) {
-      const long qq = (long)a.N + k;   // index into concat(hist_old, in)
-      a.hist_new[(long)c * a.HH + k] =
-          qq < a.HH ? a.hist_old[(long)c * a.HH + qq] : a.in[(long)c * a.in_stride + (qq - a.HH)];
-    }
+  __syncthreads();
+  epilogue_and_roll(a, c, tile, tid, q0, groups_here, ybuf);
+  __syncthreads();   // planes and ybuf are reused by the next tile
   }
 }
 
@@ -256,6 +386,8 @@ struct sdrhip_iqbb_i16 {
   int par = 0, par_fm = 0;
   int CG = 0, OG = 0, ovl = 0;
   bool fast8 = false;
+  int path = 0, S = 0, cre = 0, cim = 0;   // path 1 = int8-MFMA formulation with S K-steps
+  DevBuf<v4i> tapfrag;
   size_t lds_bytes = 0;
   DevBuf<uint2> taps;
   DevBuf<int2> lut;
@@ -296,11 +428,24 @@ struct sdrhip_iqbb_i16 {
     a.taps = taps.p; a.lut = lut.p; a.inc = inc; a.negative = negative;
     a.OP = OP; a.D = D; a.N = (int)N; a.n0_lo = (uint32_t)n0;
     a.base0_rel = g.base0_rel; a.n_groups = g.n_groups; a.n_out = g.n_out; a.extra0 = g.extra0;
-    a.CG = CG; a.OG = OG; a.ovl = ovl;
+    a.CG = CG; a.OG = OG; a.ovl = ovl; a.CGr = (CG + 3) & ~3;
     a.out = out_dev; a.out_stride = (long)out_stride; a.epilogue = epi;
+    a.tapfrag = tapfrag.p; a.cre = cre; a.cim = cim;
     const int tiles = (int)ceil_div((size_t)g.n_groups, (size_t)OG);
-    dim3 grid(tiles, C), block(TPB);
-    if (fast8) hipLaunchKernelGGL(iqbb_i16_kernel<true>, grid, block, lds_bytes, ctx->stream, a);
+    // MFMA path: one workgroup walks `tpw` consecutive tiles so that the tap fragments are fetched once;
+    // keep >= ~8 workgroups per CU in flight for balance
+    int tpw = 1;
+    if (path == 1) { tpw = 8; while (tpw > 1 && (size_t)ceil_div((size_t)tiles, (size_t)tpw) * C < 2048) tpw >>= 1; }
+    a.tiles = tiles; a.tpw = tpw;
+    dim3 grid((unsigned)ceil_div((size_t)tiles, (size_t)tpw), C), block(TPB);
+    if (path == 1) {
+      switch (S) {
+        case 2: hipLaunchKernelGGL(iqbb_i16_mfma_kernel<2>, grid, block, lds_bytes, ctx->stream, a); break;
+        case 3: hipLaunchKernelGGL(iqbb_i16_mfma_kernel<3>, grid, block, lds_bytes, ctx->stream, a); break;
+        case 5: hipLaunchKernelGGL(iqbb_i16_mfma_kernel<5>, grid, block, lds_bytes, ctx->stream, a); break;
+        default: hipLaunchKernelGGL(iqbb_i16_mfma_kernel<9>, grid, block, lds_bytes, ctx->stream, a); break;
+      }
+    } else if (fast8) hipLaunchKernelGGL(iqbb_i16_kernel<true>, grid, block, lds_bytes, ctx->stream, a);
     else hipLaunchKernelGGL(iqbb_i16_kernel<false>, grid, block, lds_bytes, ctx->stream, a);
     SDRHIP_CHECK_HIP(hipGetLastError());
     par ^= 1;
@@ -329,17 +474,38 @@ int sdrhip_iqbb_i16_create(sdrhip_ctx *ctx, const int32_t *taps, int order, cons
     for (int i = 0; i < 2 * order; i++)
       SDRHIP_REQUIRE(taps[i] >= -32767 && taps[i] <= 32767, SDRHIP_E_UNSUPPORTED,
                      "tap %d = %d does not fit the packed int16 path", i / 2, taps[i]);
+    for (int i = 0; i < 256; i++)
+      SDRHIP_REQUIRE(lut[i] > -(1 << 23) && lut[i] < (1 << 23), SDRHIP_E_UNSUPPORTED, "LUT entry %d = %d exceeds 24 bits", i / 2, lut[i]);
     ctx->use();
     sdrhip_iqbb_i16 *h = new sdrhip_iqbb_i16;
     try {
       h->ctx = ctx; h->order = order; h->D = decim; h->C = channels; h->epi = epilogue;
       h->negative = negative ? 1 : 0; h->inc = lut_inc; h->max_in = max_in;
-      h->OP = (int)ceil_div((size_t)order, (size_t)TAPC) * TAPC;
+      // path: the int8-MFMA formulation needs D == 8, order <= 129 and tap high bytes that fit int8
+      bool mfma_ok = (decim == R) && (order <= 129);
+      auto high_byte = [](int v) { const int al = ((v + 128) & 255) - 128; return (v - al) >> 8; };
+      for (int i = 0; i < 2 * order && mfma_ok; i++)   // both v and -v are packed (Kr, -Ki / Ki, Kr)
+        if (high_byte(taps[i]) > 127 || high_byte(-taps[i]) > 127) mfma_ok = false;
+      const char *force = getenv("SDRHIP_IQBB_PATH");   // "valu" / "mfma": test hook
+      if (force && !strcmp(force, "valu")) mfma_ok = false;
+      if (force && !strcmp(force, "mfma")) SDRHIP_REQUIRE(mfma_ok, SDRHIP_E_UNSUPPORTED, "MFMA path needs decim 8 and order <= 129");
+      h->path = mfma_ok ? 1 : 0;
+      if (h->path == 1) {
+        h->S = order <= 17 ? 2 : order <= 33 ? 3 : order <= 65 ? 5 : 9;
+        h->OP = 16 * (h->S - 1) + 1;
+      } else {
+        h->OP = (int)ceil_div((size_t)order, (size_t)TAPC) * TAPC;
+      }
       h->HH = h->OP;   // one more than the FIR needs: reset(keep_history) must see the whole ring
       h->CG = CG; h->ovl = ovl; h->OG = CG - ovl;
       h->fast8 = (decim == R);
-      const size_t XS = TI + h->OP + 8;
-      h->lds_bytes = (XS + 256 + ((CG + 3) & ~3)) * 4 + (h->fast8 ? 0 : (size_t)TI * 8);
+      if (h->path == 1) {
+        const size_t PLW = (2 * (size_t)(TI + h->OP) + 64 + 15) / 16 * 4;
+        h->lds_bytes = (2 * PLW + 256 + 2 * ((CG + 3) & ~3)) * 4;
+      } else {
+        const size_t XS = TI + h->OP + 8;
+        h->lds_bytes = (XS + 256 + 2 * ((CG + 3) & ~3)) * 4 + (h->fast8 ? 0 : (size_t)TI * 8);
+      }
       SDRHIP_REQUIRE(h->lds_bytes <= 64 * 1024, SDRHIP_E_UNSUPPORTED, "LDS budget exceeded (%zu B)", h->lds_bytes);
       // taps: zero-padded at the FRONT (older samples) so that the newest sample still meets K[order-1]
       std::vector<uint2> tp(h->OP, make_uint2(0, 0));
@@ -348,6 +514,33 @@ int sdrhip_iqbb_i16_create(sdrhip_ctx *ctx, const int32_t *taps, int order, cons
         const int kr = taps[2 * i], ki = taps[2 * i + 1];
         tp[pad + i].x = ((uint32_t)(uint16_t)(int16_t)kr) | ((uint32_t)(uint16_t)(int16_t)(-ki) << 16);
         tp[pad + i].y = ((uint32_t)(uint16_t)(int16_t)ki) | ((uint32_t)(uint16_t)(int16_t)kr << 16);
+      }
+      if (h->path == 1) {
+        // interleaved tap vectors a_comp[2i+c] and their Toeplitz fragments:
+        // lane (m = l&31, hh = l>>5), byte j of K-step s holds TapT[m][k = 32s+16hh+j] = a_comp[k-2t], m = 2t+comp
+        const int OPm = h->OP;
+        std::vector<int> are(2 * OPm, 0), aim(2 * OPm, 0);
+        for (int i = 0; i < order; i++) {
+          const int kr = taps[2 * i], ki = taps[2 * i + 1];
+          are[2 * (pad + i)] = kr; are[2 * (pad + i) + 1] = -ki;
+          aim[2 * (pad + i)] = ki; aim[2 * (pad + i) + 1] = kr;
+        }
+        unsigned sre = 0, sim = 0;
+        for (int k = 0; k < 2 * OPm; k++) { sre += (unsigned)are[k]; sim += (unsigned)aim[k]; }
+        h->cre = (int)(128u * sre); h->cim = (int)(128u * sim);
+        std::vector<int8_t> frag((size_t)h->S * 2 * 64 * 16, 0);
+        for (int st = 0; st < h->S; st++)
+          for (int l = 0; l < 64; l++)
+            for (int j = 0; j < 16; j++) {
+              const int m = l & 31, hh = l >> 5, t = m >> 1, comp = m & 1;
+              const int idx = 32 * st + 16 * hh + j - 2 * t;
+              const int v = (idx >= 0 && idx < 2 * OPm) ? (comp ? aim[idx] : are[idx]) : 0;
+              const int al = ((v + 128) & 255) - 128, ah = (v - al) >> 8;
+              frag[(((size_t)(2 * st) * 64 + l) * 16) + j] = (int8_t)ah;
+              frag[(((size_t)(2 * st + 1) * 64 + l) * 16) + j] = (int8_t)al;
+            }
+        h->tapfrag.alloc((size_t)h->S * 2 * 64);
+        h->tapfrag.upload(reinterpret_cast<const v4i *>(frag.data()), (size_t)h->S * 2 * 64, ctx->stream);
       }
       h->taps.alloc(h->OP); h->taps.upload(tp.data(), h->OP, ctx->stream);
       h->lut.alloc(128); h->lut.upload(reinterpret_cast<const int2 *>(lut), 128, ctx->stream);
@@ -360,6 +553,13 @@ int sdrhip_iqbb_i16_create(sdrhip_ctx *ctx, const int32_t *taps, int order, cons
       SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     } catch (...) { delete h; throw; }
     *out = h;
+  });
+}
+
+int sdrhip_iqbb_i16_path(sdrhip_iqbb_i16 *h, int *path) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h && path, SDRHIP_E_INVALID, "NULL argument");
+    *path = h->path;
   });
 }
 

@@ -185,6 +185,13 @@ class IQBaseBandI16(_Node):
                                                lut.ctypes.data_as(C.POINTER(C.c_int32)), lut_inc, int(bool(negative)),
                                                decim, channels, max_in, epilogue, C.byref(self._h)))
 
+    @property
+    def path(self):
+        """0 = VALU dot2 kernel, 1 = int8-MFMA kernel."""
+        v = C.c_int(0)
+        check(abi.lib().sdrhip_iqbb_i16_path(self._h, C.byref(v)))
+        return v.value
+
     def out_count(self, n_in):
         n = C.c_size_t(0)
         check(abi.lib().sdrhip_iqbb_i16_out_count(self._h, n_in, C.byref(n)))

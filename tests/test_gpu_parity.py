@@ -33,6 +33,17 @@ def ctx():
     c.close()
 
 
+@pytest.fixture(params=["auto", "valu"])
+def k1path(request, monkeypatch):
+    """K1 has two bit-exact formulations: the int8-MFMA kernel (picked automatically for decim 8, order <= 129)
+    and the VALU dot2 kernel (everything else); every K1 test runs with both selections."""
+    if request.param == "valu":
+        monkeypatch.setenv("SDRHIP_IQBB_PATH", "valu")
+    else:
+        monkeypatch.delenv("SDRHIP_IQBB_PATH", raising=False)
+    return request.param
+
+
 def iqbb_from_case(ctx, golden, case, suffix, epilogue, channels=1, max_in=4096):
     m = golden.meta(case + suffix)
     tcase = case if (case + "_taps") in golden.manifest else "g3_iqbb127d8"
@@ -47,7 +58,7 @@ def iqbb_from_case(ctx, golden, case, suffix, epilogue, channels=1, max_in=4096)
     ("g3_iqbb127d8", "g1_iq_cs16"), ("g8_neg_o16_d1", "g1_iq_cs16_tone_m100k"), ("g8_o21_d3", "g1_iq_cs16"),
     ("g8_o33_d5", "g1_iq_cs16"), ("g8_o16_d4_even", "g1_iq_cs16"), ("g8_o255_d8", "g1_iq_cs16"),
     ("g8_noshift_o21_d8", "g1_iq_cs16"), ("g8_ofs_d300", "g1_iq_cs16"), ("g8_irregular", "g1_iq_cs16")])
-def test_iqbb_golden(ctx, golden, case, inp):
+def test_iqbb_golden(ctx, golden, case, inp, k1path):
     m, node = iqbb_from_case(ctx, golden, case, "_out", sa.EPI_NONE)
     outs = [node.process(c)[0] for c in split(golden.load(inp), m["in_lens"])]
     assert [len(o) for o in outs] == m["out_lens"]
@@ -58,7 +69,7 @@ def test_iqbb_golden(ctx, golden, case, inp):
     ("g4_iqbb127d8", "g1_iq_cs16", "fm"), ("g4_iqbb127d8", "g1_iq_cs16", "am"), ("g4_iqbb127d8", "g1_iq_cs16", "usb"),
     ("g8_o33_d5", "g1_iq_cs16", "fm"), ("g8_irregular", "g1_iq_cs16", "fm"), ("g8_irregular", "g1_iq_cs16", "usb"),
     ("g8_loud_iqbb127d8", "g8_iq_cs16_loud", "fm"), ("g8_loud_iqbb127d8", "g8_iq_cs16_loud", "am")])
-def test_iqbb_demod_golden(ctx, golden, case, inp, demod):
+def test_iqbb_demod_golden(ctx, golden, case, inp, demod, k1path):
     epi = {"fm": sa.EPI_FM, "am": sa.EPI_AM, "usb": sa.EPI_USB}[demod]
     m, node = iqbb_from_case(ctx, golden, case, "_" + demod, epi)
     outs = [node.process(c)[0] for c in split(golden.load(inp), m["in_lens"])]
@@ -83,8 +94,9 @@ def synth_channels(orc, C, N, seed=0x5D2):
 
 
 @pytest.mark.parametrize("epi", [sa.EPI_NONE, sa.EPI_FM, sa.EPI_AM, sa.EPI_USB])
-@pytest.mark.parametrize("order,decim,Fc", [(127, 8, 100e3), (21, 8, -100e3), (33, 5, 100e3), (16, 1, 50e3)])
-def test_iqbb_batched_vs_oracle(ctx, orc, epi, order, decim, Fc):
+@pytest.mark.parametrize("order,decim,Fc", [(127, 8, 100e3), (21, 8, -100e3), (33, 5, 100e3), (16, 1, 50e3),
+                                             (129, 8, 0.0), (64, 8, 30e3), (9, 8, -250e3), (1, 8, 100e3)])
+def test_iqbb_batched_vs_oracle(ctx, orc, epi, order, decim, Fc, k1path):
     C, chunks = 5, [8192, 3000, 1, 7, 5000, 8192]
     taps = sa.design_iqbb_taps(Fc, 50e3, FS, order)
     lut = sa.design_freqshift_lut_i16()
@@ -109,7 +121,7 @@ def test_iqbb_batched_vs_oracle(ctx, orc, epi, order, decim, Fc):
         off += n
 
 
-def test_iqbb_random_fullscale_vs_oracle(ctx, orc):
+def test_iqbb_random_fullscale_vs_oracle(ctx, orc, k1path):
     """Full-range random int16 input (worst case for the int32 accumulators and the >>14/>>16 steps)."""
     rng = np.random.default_rng(7)
     C, N = 3, 20000
@@ -122,7 +134,19 @@ def test_iqbb_random_fullscale_vs_oracle(ctx, orc):
         assert np.array_equal(y[c], orc.IQBaseBandI16(taps, lut, 1365, False, 8).process(x[c]))
 
 
-def test_iqbb_reset_semantics(ctx, orc, golden):
+def test_iqbb_path_selection(ctx, golden, monkeypatch):
+    monkeypatch.delenv("SDRHIP_IQBB_PATH", raising=False)
+    taps, lut = golden.load("g3_iqbb127d8_taps"), golden.load("g3_iqbb127d8_lut")
+    assert sa.IQBaseBandI16(ctx, taps, lut, 1365, 0, 8).path == 1          # north-star chain -> MFMA
+    assert sa.IQBaseBandI16(ctx, taps, lut, 1365, 0, 5).path == 0          # other decimations -> VALU
+    assert sa.IQBaseBandI16(ctx, golden.load("g8_o255_d8_taps"), lut, 1365, 0, 8).path == 0   # order > 129
+    big = np.array(taps).reshape(-1, 2).copy(); big[5, 0] = 32700          # high byte would not fit int8
+    assert sa.IQBaseBandI16(ctx, big, lut, 1365, 0, 8).path == 0
+    monkeypatch.setenv("SDRHIP_IQBB_PATH", "valu")
+    assert sa.IQBaseBandI16(ctx, taps, lut, 1365, 0, 8).path == 0
+
+
+def test_iqbb_reset_semantics(ctx, orc, golden, k1path):
     m, node = iqbb_from_case(ctx, golden, "g3_iqbb127d8", "_out", sa.EPI_NONE)
     x = golden.load("g1_iq_cs16")
     first = node.process(x[:4096])[0]
@@ -137,7 +161,7 @@ def test_iqbb_reset_semantics(ctx, orc, golden):
 
 # ---- K1 at the BASELINE size: properties + sampled oracle comparison ------------------------------------
 
-def test_iqbb_full_size_properties(ctx, orc):
+def test_iqbb_full_size_properties(ctx, orc, k1path):
     C, N, D = 1024, 65536, 8
     taps = sa.design_iqbb_taps(100e3, 50e3, FS, 127)
     lut = sa.design_freqshift_lut_i16()
