@@ -292,40 +292,73 @@ __global__ __launch_bounds__(TPB) void iqbb_i16_kernel(const IqbbArgs a) {
 constexpr int MF_BLK = 16;    // samples per block (one column)
 constexpr int MF_WAVE = 512;  // samples per wave tile (32 blocks)
 
-template <int S>
-__global__ __launch_bounds__(TPB, 2) void iqbb_i16_mfma_kernel(const IqbbArgs a) {
+template <int S, bool TLDS>
+__global__ __launch_bounds__(TPB, TLDS ? 4 : 2) void iqbb_i16_mfma_kernel(const IqbbArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int PLW = (2 * (TI + a.OP) + 64 + 15) / 16 * 4;    // dwords per byte plane
   uint32_t *lo = smem, *hi = smem + PLW;
   int2 *lut_s = reinterpret_cast<int2 *>(smem + 2 * PLW);
   uint32_t *ybuf = smem + 2 * PLW + 256;
+  v4i *taps_s = reinterpret_cast<v4i *>(ybuf + 2 * a.CGr);   // TLDS: [S][2][64] fragments
 
   const int c = blockIdx.y, tid = threadIdx.x;
   const int w = tid >> 6, l = tid & 63, n = l & 31, h = l >> 5;
-  // tap fragments: wave-invariant, loaded once and kept in registers across the tiles this workgroup walks
+  // tap fragments: wave-invariant, fetched once per workgroup and kept across the tiles it walks — in
+  // registers (72 VGPRs at S=9, 2 waves/SIMD) or in LDS (TLDS: 4 waves/SIMD, twice the LDS reads)
   v4i Ah[S], Al[S];
+  if (TLDS) {
+    for (int i = tid; i < S * 2 * 64; i += TPB) taps_s[i] = a.tapfrag[i];
+  } else {
 #pragma unroll
-  for (int s = 0; s < S; s++) { Ah[s] = a.tapfrag[(2 * s) * 64 + l]; Al[s] = a.tapfrag[(2 * s + 1) * 64 + l]; }
+    for (int s = 0; s < S; s++) { Ah[s] = a.tapfrag[(2 * s) * 64 + l]; Al[s] = a.tapfrag[(2 * s + 1) * 64 + l]; }
+  }
   if (tid < 128) lut_s[tid] = a.lut[tid];
 
-  for (int it = 0; it < a.tpw; it++) {
-  const int tile = blockIdx.x * a.tpw + it;
-  if (tile >= a.tiles) break;
+  // Software pipeline over the tiles this workgroup walks: the global loads of tile i+1 are issued into
+  // registers before the MFMA/epilogue work of tile i and written to the LDS planes after it.
+  constexpr int NPF = (TI + 129 + 2 + 2 * TPB - 1) / (2 * TPB);   // sample pairs per lane and tile (OP <= 129)
+  uint32_t px0[NPF], px1[NPF];
+  auto fetch = [&](int tile_) {
+    const int q0_ = tile_ * a.OG - a.ovl;
+    const int first = a.base0_rel + q0_ * 8 - (a.OP - 1);
+    const int pairs = (min(a.CG, a.n_groups - q0_) * 8 + a.OP + 2) / 2;
+    if (first >= 0 && first + 2 * pairs <= a.N) {   // interior tile: no history, no end of call
+      const uint32_t *src = a.in + (long)c * a.in_stride + first;
+#pragma unroll
+      for (int k = 0; k < NPF; k++) {
+        const int p = tid + k * TPB;
+        if (p < pairs) { px0[k] = src[2 * p]; px1[k] = src[2 * p + 1]; }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NPF; k++) {
+        const int p = tid + k * TPB;
+        if (p < pairs) { px0[k] = load_x(a, c, first + 2 * p); px1[k] = load_x(a, c, first + 2 * p + 1); }
+      }
+    }
+  };
+  const int tile_end = min((int)(blockIdx.x + 1) * a.tpw, a.tiles);
+  int tile = blockIdx.x * a.tpw;
+  if (tile < tile_end) fetch(tile);
+  for (; tile < tile_end; tile++) {
   const int q0 = tile * a.OG - a.ovl;
   const int tb = a.base0_rel + q0 * a.D;
   const int groups_here = min(a.CG, a.n_groups - q0);
 
   // ---- stage: two samples -> 4 bytes of the low plane (offset to signed) and 4 of the high plane ----
   {
-    const int first = tb - (a.OP - 1);
     const int pairs = (groups_here * 8 + a.OP + 2) / 2;
-    for (int p = tid; p < pairs; p += TPB) {
-      const uint32_t x0 = load_x(a, c, first + 2 * p), x1 = load_x(a, c, first + 2 * p + 1);
-      lo[p] = __builtin_amdgcn_perm(x1, x0, 0x06040200u) ^ 0x80808080u;
-      hi[p] = __builtin_amdgcn_perm(x1, x0, 0x07050301u);
+#pragma unroll
+    for (int k = 0; k < NPF; k++) {
+      const int p = tid + k * TPB;
+      if (p < pairs) {
+        lo[p] = __builtin_amdgcn_perm(px1[k], px0[k], 0x06040200u) ^ 0x80808080u;
+        hi[p] = __builtin_amdgcn_perm(px1[k], px0[k], 0x07050301u);
+      }
     }
   }
   __syncthreads();
+  if (tile + 1 < tile_end) fetch(tile + 1);   // in flight during the matrix and epilogue work below
 
   if (64 * w < groups_here) {   // wave-uniform
     v16i acc_hh = {0}, acc_mid = {0}, acc_ll;
@@ -337,28 +370,47 @@ __global__ __launch_bounds__(TPB, 2) void iqbb_i16_mfma_kernel(const IqbbArgs a)
     for (int s = 0; s < S; s++) {
       const v4i ul = *reinterpret_cast<const v4i *>(pl + 32 * s);
       const v4i uh = *reinterpret_cast<const v4i *>(ph + 32 * s);
+      if (TLDS) { Ah[s] = taps_s[(2 * s) * 64 + l]; Al[s] = taps_s[(2 * s + 1) * 64 + l]; }
       acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[s], uh, acc_hh, 0, 0, 0);
       acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[s], ul, acc_mid, 0, 0, 0);
       acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[s], uh, acc_mid, 0, 0, 0);
       acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[s], ul, acc_ll, 0, 0, 0);
     }
     // ---- recombine, >>14, rotate, mask, partial box sums (4 samples per group in this lane) --------
+    const int rel0 = tb + MF_WAVE * w + MF_BLK * n + 2 * h;
+    const bool edge = (tb < 0) || (tb + groups_here * 8 > a.N);   // tile touches the call's borders (scalar)
+    int2 rv[8];   // sample k = 2q+tt sits at rel0 + 4q + tt
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int rr = 4 * (k >> 1) + 2 * (k & 1);
+      const unsigned sre = ((((unsigned)acc_hh[rr] << 8) + (unsigned)acc_mid[rr]) << 8) + (unsigned)acc_ll[rr];
+      const unsigned sim = ((((unsigned)acc_hh[rr + 1] << 8) + (unsigned)acc_mid[rr + 1]) << 8) + (unsigned)acc_ll[rr + 1];
+      rv[k] = make_int2((int)sre >> 14, (int)sim >> 14);
+    }
+    if (a.inc != 0) {   // scalar branch, hoisted out of the per-sample work: 8 independent LUT reads in flight
+      const uint32_t cnt0 = (a.n0_lo + (uint32_t)rel0) * a.inc;   // phase counter of the lane's first sample (mod 2^15 below)
+      int2 L[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        uint32_t idx = ((cnt0 + (uint32_t)(4 * (k >> 1) + (k & 1)) * a.inc) & 32767u) >> 8;
+        if (a.negative) idx = 127u - idx;
+        L[k] = lut_s[idx];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int2 r = rv[k];
+        rv[k].x = (int)((unsigned)__mul24(L[k].x, r.x) - (unsigned)__mul24(L[k].y, r.y)) >> 16;
+        rv[k].y = (int)((unsigned)__mul24(L[k].x, r.y) + (unsigned)__mul24(L[k].y, r.x)) >> 16;
+      }
+    }
     int2 part[2];
     part[0] = make_int2(0, 0); part[1] = make_int2(0, 0);
-    const int rel0 = tb + MF_WAVE * w + MF_BLK * n + 2 * h;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-#pragma unroll
-      for (int tt = 0; tt < 2; tt++) {
-        const int rr = 4 * q + 2 * tt;
-        const unsigned sre = ((unsigned)acc_hh[rr] << 16) + ((unsigned)acc_mid[rr] << 8) + (unsigned)acc_ll[rr];
-        const unsigned sim = ((unsigned)acc_hh[rr + 1] << 16) + ((unsigned)acc_mid[rr + 1] << 8) + (unsigned)acc_ll[rr + 1];
-        const int rel = rel0 + 4 * q + tt;
-        int2 v = rotate(a, lut_s, make_int2((int)sre >> 14, (int)sim >> 14), a.n0_lo + (uint32_t)rel);
-        if (rel < 0 || rel >= a.N) v = make_int2(0, 0);
-        part[q >> 1].x = (int)((unsigned)part[q >> 1].x + (unsigned)v.x);
-        part[q >> 1].y = (int)((unsigned)part[q >> 1].y + (unsigned)v.y);
-      }
+    for (int k = 0; k < 8; k++) {
+      int2 v = rv[k];
+      if (edge) { const int rel = rel0 + 4 * (k >> 1) + (k & 1); if (rel < 0 || rel >= a.N) v = make_int2(0, 0); }
+      part[k >> 2].x = (int)((unsigned)part[k >> 2].x + (unsigned)v.x);
+      part[k >> 2].y = (int)((unsigned)part[k >> 2].y + (unsigned)v.y);
     }
     // lane h=0 finishes group 0 of its block, lane h=1 group 1: swap the partial the other one needs
     const int2 give = h ? part[0] : part[1];
@@ -371,7 +423,8 @@ __global__ __launch_bounds__(TPB, 2) void iqbb_i16_mfma_kernel(const IqbbArgs a)
   }
   __syncthreads();
   epilogue_and_roll(a, c, tile, tid, q0, groups_here, ybuf);
-  __syncthreads();   // planes and ybuf are reused by the next tile
+  // no barrier here: the next tile's plane writes follow every wave's last plane read (barrier above), and
+  // its ybuf writes follow the barrier after its staging
   }
 }
 
@@ -387,6 +440,7 @@ struct sdrhip_iqbb_i16 {
   int CG = 0, OG = 0, ovl = 0;
   bool fast8 = false;
   int path = 0, S = 0, cre = 0, cim = 0;   // path 1 = int8-MFMA formulation with S K-steps
+  bool taps_lds = true;                    // MFMA path: tap fragments in LDS (4 waves/SIMD) or registers
   DevBuf<v4i> tapfrag;
   size_t lds_bytes = 0;
   DevBuf<uint2> taps;
@@ -439,12 +493,15 @@ struct sdrhip_iqbb_i16 {
     a.tiles = tiles; a.tpw = tpw;
     dim3 grid((unsigned)ceil_div((size_t)tiles, (size_t)tpw), C), block(TPB);
     if (path == 1) {
+#define SDRHIP_MF(S_) do { if (taps_lds) hipLaunchKernelGGL((iqbb_i16_mfma_kernel<S_, true>), grid, block, lds_bytes, ctx->stream, a); \
+                            else hipLaunchKernelGGL((iqbb_i16_mfma_kernel<S_, false>), grid, block, lds_bytes, ctx->stream, a); } while (0)
       switch (S) {
-        case 2: hipLaunchKernelGGL(iqbb_i16_mfma_kernel<2>, grid, block, lds_bytes, ctx->stream, a); break;
-        case 3: hipLaunchKernelGGL(iqbb_i16_mfma_kernel<3>, grid, block, lds_bytes, ctx->stream, a); break;
-        case 5: hipLaunchKernelGGL(iqbb_i16_mfma_kernel<5>, grid, block, lds_bytes, ctx->stream, a); break;
-        default: hipLaunchKernelGGL(iqbb_i16_mfma_kernel<9>, grid, block, lds_bytes, ctx->stream, a); break;
+        case 2: SDRHIP_MF(2); break;
+        case 3: SDRHIP_MF(3); break;
+        case 5: SDRHIP_MF(5); break;
+        default: SDRHIP_MF(9); break;
       }
+#undef SDRHIP_MF
     } else if (fast8) hipLaunchKernelGGL(iqbb_i16_kernel<true>, grid, block, lds_bytes, ctx->stream, a);
     else hipLaunchKernelGGL(iqbb_i16_kernel<false>, grid, block, lds_bytes, ctx->stream, a);
     SDRHIP_CHECK_HIP(hipGetLastError());
@@ -501,7 +558,9 @@ int sdrhip_iqbb_i16_create(sdrhip_ctx *ctx, const int32_t *taps, int order, cons
       h->fast8 = (decim == R);
       if (h->path == 1) {
         const size_t PLW = (2 * (size_t)(TI + h->OP) + 64 + 15) / 16 * 4;
-        h->lds_bytes = (2 * PLW + 256 + 2 * ((CG + 3) & ~3)) * 4;
+        const char *tv = getenv("SDRHIP_IQBB_TAPS");   // "reg" / "lds": tuning hook
+        h->taps_lds = !(tv && !strcmp(tv, "reg"));
+        h->lds_bytes = (2 * PLW + 256 + 2 * ((CG + 3) & ~3)) * 4 + (h->taps_lds ? (size_t)h->S * 2 * 64 * 16 : 0);
       } else {
         const size_t XS = TI + h->OP + 8;
         h->lds_bytes = (XS + 256 + 2 * ((CG + 3) & ~3)) * 4 + (h->fast8 ? 0 : (size_t)TI * 8);
