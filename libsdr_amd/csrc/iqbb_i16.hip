@@ -290,16 +290,14 @@ __global__ __launch_bounds__(TPB) void iqbb_i16_kernel(const IqbbArgs a) {
 // group; the other 4 sit in lane l^32.
 // =================================================================================================
 constexpr int MF_BLK = 16;    // samples per block (one column)
-constexpr int MF_WAVE = 512;  // samples per wave tile (32 blocks)
 
 template <int S, bool TLDS>
 __global__ __launch_bounds__(TPB, TLDS ? 4 : 2) void iqbb_i16_mfma_kernel(const IqbbArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int PLW = (2 * (TI + a.OP) + 64 + 15) / 16 * 4;    // dwords per byte plane
-  uint32_t *lo = smem, *hi = smem + PLW;
-  int2 *lut_s = reinterpret_cast<int2 *>(smem + 2 * PLW);
-  uint32_t *ybuf = smem + 2 * PLW + 256;
-  v4i *taps_s = reinterpret_cast<v4i *>(ybuf + 2 * a.CGr);   // TLDS: [S][2][64] fragments
+  // two plane pairs (double buffer): tile i+1 is written while slower waves still read tile i
+  int2 *lut_s = reinterpret_cast<int2 *>(smem + 4 * PLW);
+  v4i *taps_s = reinterpret_cast<v4i *>(smem + 4 * PLW + 256);   // TLDS: [S][2][64] fragments
 
   const int c = blockIdx.y, tid = threadIdx.x;
   const int w = tid >> 6, l = tid & 63, n = l & 31, h = l >> 5;
@@ -315,7 +313,7 @@ __global__ __launch_bounds__(TPB, TLDS ? 4 : 2) void iqbb_i16_mfma_kernel(const 
   if (tid < 128) lut_s[tid] = a.lut[tid];
 
   // Software pipeline over the tiles this workgroup walks: the global loads of tile i+1 are issued into
-  // registers before the MFMA/epilogue work of tile i and written to the LDS planes after it.
+  // registers before the MFMA/epilogue work of tile i and written to the other LDS plane pair after it.
   constexpr int NPF = (TI + 129 + 2 + 2 * TPB - 1) / (2 * TPB);   // sample pairs per lane and tile (OP <= 129)
   uint32_t px0[NPF], px1[NPF];
   auto fetch = [&](int tile_) {
@@ -340,91 +338,136 @@ __global__ __launch_bounds__(TPB, TLDS ? 4 : 2) void iqbb_i16_mfma_kernel(const 
   const int tile_end = min((int)(blockIdx.x + 1) * a.tpw, a.tiles);
   int tile = blockIdx.x * a.tpw;
   if (tile < tile_end) fetch(tile);
-  for (; tile < tile_end; tile++) {
-  const int q0 = tile * a.OG - a.ovl;
-  const int tb = a.base0_rel + q0 * a.D;
-  const int groups_here = min(a.CG, a.n_groups - q0);
+  const int OGw = 64 - a.ovl;   // groups a wave emits; with FM its first group only supplies the previous angle
+  for (int it = 0; tile < tile_end; tile++, it++) {
+    const int q0 = tile * a.OG - a.ovl;
+    const int tb = a.base0_rel + q0 * 8;
+    const int groups_here = min(a.CG, a.n_groups - q0);
+    uint32_t *lo = smem + (it & 1) * 2 * PLW, *hi = lo + PLW;
 
-  // ---- stage: two samples -> 4 bytes of the low plane (offset to signed) and 4 of the high plane ----
-  {
-    const int pairs = (groups_here * 8 + a.OP + 2) / 2;
+    // ---- stage: two samples -> 4 bytes of the low plane (offset to signed) and 4 of the high plane ----
+    {
+      const int pairs = (groups_here * 8 + a.OP + 2) / 2;
 #pragma unroll
-    for (int k = 0; k < NPF; k++) {
-      const int p = tid + k * TPB;
-      if (p < pairs) {
-        lo[p] = __builtin_amdgcn_perm(px1[k], px0[k], 0x06040200u) ^ 0x80808080u;
-        hi[p] = __builtin_amdgcn_perm(px1[k], px0[k], 0x07050301u);
+      for (int k = 0; k < NPF; k++) {
+        const int p = tid + k * TPB;
+        if (p < pairs) {
+          lo[p] = __builtin_amdgcn_perm(px1[k], px0[k], 0x06040200u) ^ 0x80808080u;
+          hi[p] = __builtin_amdgcn_perm(px1[k], px0[k], 0x07050301u);
+        }
       }
     }
-  }
-  __syncthreads();
-  if (tile + 1 < tile_end) fetch(tile + 1);   // in flight during the matrix and epilogue work below
+    __syncthreads();   // the only barrier per tile: planes[it&1] complete; planes[(it+1)&1] were last read before it
+    if (tile + 1 < tile_end) fetch(tile + 1);   // in flight during the matrix and epilogue work below
 
-  if (64 * w < groups_here) {   // wave-uniform
-    v16i acc_hh = {0}, acc_mid = {0}, acc_ll;
+    const int gw = w * OGw;   // this wave's first group within the tile
+    if (gw + a.ovl < groups_here) {   // wave-uniform: the wave has at least one group of its own
+      v16i acc_hh = {0}, acc_mid = {0}, acc_ll;
 #pragma unroll
-    for (int r = 0; r < 16; r++) acc_ll[r] = (r & 1) ? a.cim : a.cre;   // + 128*sum(a) rides in as C
-    const char *pl = reinterpret_cast<const char *>(lo) + 1024 * w + 32 * n + 16 * h;
-    const char *ph = reinterpret_cast<const char *>(hi) + 1024 * w + 32 * n + 16 * h;
+      for (int r = 0; r < 16; r++) acc_ll[r] = (r & 1) ? a.cim : a.cre;   // + 128*sum(a) rides in as C
+      const char *pl = reinterpret_cast<const char *>(lo) + 16 * gw + 32 * n + 16 * h;   // 2 B per sample and plane
+      const char *ph = reinterpret_cast<const char *>(hi) + 16 * gw + 32 * n + 16 * h;
 #pragma unroll
-    for (int s = 0; s < S; s++) {
-      const v4i ul = *reinterpret_cast<const v4i *>(pl + 32 * s);
-      const v4i uh = *reinterpret_cast<const v4i *>(ph + 32 * s);
-      if (TLDS) { Ah[s] = taps_s[(2 * s) * 64 + l]; Al[s] = taps_s[(2 * s + 1) * 64 + l]; }
-      acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[s], uh, acc_hh, 0, 0, 0);
-      acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[s], ul, acc_mid, 0, 0, 0);
-      acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[s], uh, acc_mid, 0, 0, 0);
-      acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[s], ul, acc_ll, 0, 0, 0);
-    }
-    // ---- recombine, >>14, rotate, mask, partial box sums (4 samples per group in this lane) --------
-    const int rel0 = tb + MF_WAVE * w + MF_BLK * n + 2 * h;
-    const bool edge = (tb < 0) || (tb + groups_here * 8 > a.N);   // tile touches the call's borders (scalar)
-    int2 rv[8];   // sample k = 2q+tt sits at rel0 + 4q + tt
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const int rr = 4 * (k >> 1) + 2 * (k & 1);
-      const unsigned sre = ((((unsigned)acc_hh[rr] << 8) + (unsigned)acc_mid[rr]) << 8) + (unsigned)acc_ll[rr];
-      const unsigned sim = ((((unsigned)acc_hh[rr + 1] << 8) + (unsigned)acc_mid[rr + 1]) << 8) + (unsigned)acc_ll[rr + 1];
-      rv[k] = make_int2((int)sre >> 14, (int)sim >> 14);
-    }
-    if (a.inc != 0) {   // scalar branch, hoisted out of the per-sample work: 8 independent LUT reads in flight
-      const uint32_t cnt0 = (a.n0_lo + (uint32_t)rel0) * a.inc;   // phase counter of the lane's first sample (mod 2^15 below)
-      int2 L[8];
+      for (int s = 0; s < S; s++) {
+        const v4i ul = *reinterpret_cast<const v4i *>(pl + 32 * s);
+        const v4i uh = *reinterpret_cast<const v4i *>(ph + 32 * s);
+        if (TLDS) { Ah[s] = taps_s[(2 * s) * 64 + l]; Al[s] = taps_s[(2 * s + 1) * 64 + l]; }
+        acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[s], uh, acc_hh, 0, 0, 0);
+        acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[s], ul, acc_mid, 0, 0, 0);
+        acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[s], uh, acc_mid, 0, 0, 0);
+        acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[s], ul, acc_ll, 0, 0, 0);
+      }
+      // ---- recombine, >>14, rotate, mask, partial box sums (4 samples per group in this lane) --------
+      const int rel0 = tb + 8 * gw + MF_BLK * n + 2 * h;
+      const bool edge = (tb < 0) || (tb + groups_here * 8 > a.N);   // tile touches the call's borders (scalar)
+      int2 rv[8];   // sample k = 2q+tt sits at rel0 + 4q + tt
 #pragma unroll
       for (int k = 0; k < 8; k++) {
-        uint32_t idx = ((cnt0 + (uint32_t)(4 * (k >> 1) + (k & 1)) * a.inc) & 32767u) >> 8;
-        if (a.negative) idx = 127u - idx;
-        L[k] = lut_s[idx];
+        const int rr = 4 * (k >> 1) + 2 * (k & 1);
+        const unsigned sre = ((((unsigned)acc_hh[rr] << 8) + (unsigned)acc_mid[rr]) << 8) + (unsigned)acc_ll[rr];
+        const unsigned sim = ((((unsigned)acc_hh[rr + 1] << 8) + (unsigned)acc_mid[rr + 1]) << 8) + (unsigned)acc_ll[rr + 1];
+        rv[k] = make_int2((int)sre >> 14, (int)sim >> 14);
       }
+      if (a.inc != 0) {   // scalar branch, hoisted out of the per-sample work: 8 independent LUT reads in flight
+        const uint32_t cnt0 = (a.n0_lo + (uint32_t)rel0) * a.inc;   // phase counter of the lane's first sample (mod 2^15 below)
+        int2 L[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          uint32_t idx = ((cnt0 + (uint32_t)(4 * (k >> 1) + (k & 1)) * a.inc) & 32767u) >> 8;
+          if (a.negative) idx = 127u - idx;
+          L[k] = lut_s[idx];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const int2 r = rv[k];
+          rv[k].x = (int)((unsigned)__mul24(L[k].x, r.x) - (unsigned)__mul24(L[k].y, r.y)) >> 16;
+          rv[k].y = (int)((unsigned)__mul24(L[k].x, r.y) + (unsigned)__mul24(L[k].y, r.x)) >> 16;
+        }
+      }
+      int2 part[2];
+      part[0] = make_int2(0, 0); part[1] = make_int2(0, 0);
 #pragma unroll
       for (int k = 0; k < 8; k++) {
-        const int2 r = rv[k];
-        rv[k].x = (int)((unsigned)__mul24(L[k].x, r.x) - (unsigned)__mul24(L[k].y, r.y)) >> 16;
-        rv[k].y = (int)((unsigned)__mul24(L[k].x, r.y) + (unsigned)__mul24(L[k].y, r.x)) >> 16;
+        int2 v = rv[k];
+        if (edge) { const int rel = rel0 + 4 * (k >> 1) + (k & 1); if (rel < 0 || rel >= a.N) v = make_int2(0, 0); }
+        part[k >> 2].x = (int)((unsigned)part[k >> 2].x + (unsigned)v.x);
+        part[k >> 2].y = (int)((unsigned)part[k >> 2].y + (unsigned)v.y);
+      }
+      // lane h=0 finishes group 0 of its block, lane h=1 group 1: swap the partial the other one needs
+      const int2 give = h ? part[0] : part[1];
+      int2 sum = h ? part[1] : part[0];
+      sum.x = (int)((unsigned)sum.x + (unsigned)__shfl_xor(give.x, 32));
+      sum.y = (int)((unsigned)sum.y + (unsigned)__shfl_xor(give.y, 32));
+
+      // ---- wave-local group epilogue: lane (n,h) owns group glw = 2n+h of the wave ----------------------
+      const int glw = 2 * n + h;
+      const int ql = gw + glw, q = q0 + ql;   // q = output index within the call when the group completes
+      const bool live = (ql < groups_here) && (q >= 0);
+      if (live && q == 0) {
+        const int2 carry = a.acc_old[c];
+        sum.x = (int)((unsigned)sum.x + (unsigned)carry.x);
+        sum.y = (int)((unsigned)sum.y + (unsigned)carry.y);
+        if (a.extra0) {   // absolute sample 0: one slow FIR evaluation per channel and stream start
+          int er = 0, ei = 0;
+          for (int i = 0; i < a.OP; i++) {
+            const uint32_t x = load_x(a, c, -(a.OP - 1) + i);
+            const uint2 k = a.taps[i];
+            er = dot2(x, k.x, er); ei = dot2(x, k.y, ei);
+          }
+          const int2 v = rotate(a, lut_s, make_int2(er >> 14, ei >> 14), a.n0_lo);
+          sum.x = (int)((unsigned)sum.x + (unsigned)v.x);
+          sum.y = (int)((unsigned)sum.y + (unsigned)v.y);
+        }
+      }
+      const bool own = live && (glw >= a.ovl);            // the FM overlap slot belongs to the previous wave / tile
+      const bool emits = live && (q < a.n_out);
+      const int yr = (short)box_div(sum.x, 8), yi = (short)box_div(sum.y, 8);
+      if (own && q == a.n_groups - 1) a.acc_new[c] = emits ? make_int2(0, 0) : sum;
+      if (a.epilogue == SDRHIP_EPI_NONE) {
+        if (own && emits) reinterpret_cast<uint32_t *>(a.out)[(long)c * a.out_stride + q] = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
+      } else {
+        short o;
+        if (a.epilogue == SDRHIP_EPI_AM) o = am_i16(yr, yi);
+        else if (a.epilogue == SDRHIP_EPI_USB) o = usb_i16(yr, yi);
+        else {
+          const int phi = fm_phi(yr, yi);
+          // previous group's angle: lane (n,0) for h=1, lane (n-1,1) for h=0
+          const int prev = __shfl(phi, h ? l - 32 : l + 31);
+          if (q == 0) o = (short)yr;             // index 0 is never written by FMDemod (in place)
+          else o = (short)((q == 1 ? (int)a.fm_old[c] : prev) - phi);   // y[0] is never looked at
+          if (own && emits && q == a.n_out - 1 && a.n_out >= 2) a.fm_new[c] = (short)phi;
+        }
+        if (own && emits) reinterpret_cast<short *>(a.out)[(long)c * a.out_stride + q] = o;
       }
     }
-    int2 part[2];
-    part[0] = make_int2(0, 0); part[1] = make_int2(0, 0);
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      int2 v = rv[k];
-      if (edge) { const int rel = rel0 + 4 * (k >> 1) + (k & 1); if (rel < 0 || rel >= a.N) v = make_int2(0, 0); }
-      part[k >> 2].x = (int)((unsigned)part[k >> 2].x + (unsigned)v.x);
-      part[k >> 2].y = (int)((unsigned)part[k >> 2].y + (unsigned)v.y);
+    // the channel's last tile rolls the FIR history forward
+    if (tile == a.tiles - 1) {
+      for (int k = tid; k < a.HH; k += TPB) {
+        const long qq = (long)a.N + k;   // index into concat(hist_old, in)
+        a.hist_new[(long)c * a.HH + k] =
+            qq < a.HH ? a.hist_old[(long)c * a.HH + qq] : a.in[(long)c * a.in_stride + (qq - a.HH)];
+      }
     }
-    // lane h=0 finishes group 0 of its block, lane h=1 group 1: swap the partial the other one needs
-    const int2 give = h ? part[0] : part[1];
-    int2 mine = h ? part[1] : part[0];
-    mine.x = (int)((unsigned)mine.x + (unsigned)__shfl_xor(give.x, 32));
-    mine.y = (int)((unsigned)mine.y + (unsigned)__shfl_xor(give.y, 32));
-    const int ql = 64 * w + 2 * n + h;
-    const int q = q0 + ql;
-    if (ql < groups_here && q >= 0) finalize_group(a, c, lut_s, ybuf, ql, q, mine, 8);
-  }
-  __syncthreads();
-  epilogue_and_roll(a, c, tile, tid, q0, groups_here, ybuf);
-  // no barrier here: the next tile's plane writes follow every wave's last plane read (barrier above), and
-  // its ybuf writes follow the barrier after its staging
   }
 }
 
@@ -555,12 +598,13 @@ int sdrhip_iqbb_i16_create(sdrhip_ctx *ctx, const int32_t *taps, int order, cons
       }
       h->HH = h->OP;   // one more than the FIR needs: reset(keep_history) must see the whole ring
       h->CG = CG; h->ovl = ovl; h->OG = CG - ovl;
+      if (h->path == 1) { h->OG = 4 * (64 - ovl); h->CG = h->OG + ovl; }   // every wave recomputes its own FM overlap group
       h->fast8 = (decim == R);
       if (h->path == 1) {
         const size_t PLW = (2 * (size_t)(TI + h->OP) + 64 + 15) / 16 * 4;
         const char *tv = getenv("SDRHIP_IQBB_TAPS");   // "reg" / "lds": tuning hook
         h->taps_lds = !(tv && !strcmp(tv, "reg"));
-        h->lds_bytes = (2 * PLW + 256 + 2 * ((CG + 3) & ~3)) * 4 + (h->taps_lds ? (size_t)h->S * 2 * 64 * 16 : 0);
+        h->lds_bytes = (4 * PLW + 256) * 4 + (h->taps_lds ? (size_t)h->S * 2 * 64 * 16 : 0);
       } else {
         const size_t XS = TI + h->OP + 8;
         h->lds_bytes = (XS + 256 + 2 * ((CG + 3) & ~3)) * 4 + (h->fast8 ? 0 : (size_t)TI * 8);
