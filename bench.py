@@ -137,7 +137,8 @@ def main():
             outs = torch.zeros((C, n_out), dtype=torch.int16, device=dev)
             ins = [synth_cs16(torch, C, N, dev, 1234 + b, chan0=rank * C) for b in range(a.batches)]
             run = lambda b: node.process_dev(ins[b].data_ptr(), N, N, outs.data_ptr(), n_out)
-            dtype, kernel = "i16", "iqbb_i16_kernel"
+            dtype = "i16"
+            kernel = "iqbb_i16_mfma_kernel" if node.path == 1 else "iqbb_i16_kernel"
             desc = "IQBaseBand<int16>(127-tap Q14 FIR, LUT shift 100 kHz, /8) -> %s" % ("FMDemod" if wl == "iqbb_fm" else "USBDemod")
         elif wl in ("fir255_fm", "fir127_fm"):
             order = 255 if wl == "fir255_fm" else 127

@@ -94,7 +94,7 @@ __device__ __forceinline__ int box_div(int s, int D) {
 // estimate (|q| <= 4096, error < 1) + one exact remainder correction, instead of the generic 32-bit sequence
 __device__ __forceinline__ int div_small(int num, int den) {
   const unsigned nu = (unsigned)(num < 0 ? -num : num), de = (unsigned)den;
-  unsigned q = (unsigned)((float)nu * __frcp_rn((float)de));
+  unsigned q = (unsigned)((float)nu * __builtin_amdgcn_rcpf((float)de));   // v_rcp_f32: 1 ulp, |q| <= 4096
   int r = (int)(nu - __umul24(q, de));
   if (r < 0) { q -= 1; r += (int)de; }
   if (r >= (int)de) q += 1;
@@ -103,11 +103,12 @@ __device__ __forceinline__ int div_small(int num, int den) {
 
 // fast_atan2<int16_t,int16_t>(a, b) / 2   (src/math.hh:31-40, src/demod.hh:246)
 __device__ __forceinline__ int fm_phi(int a, int b) {
-  if (a == 0 && b == 0) return 0;
   const int aabs = a >= 0 ? a : -a;
-  int angle;
-  if (b >= 0) angle = 4096 - div_small(4096 * (b - aabs), b + aabs);
-  else angle = 12288 - div_small(4096 * (b + aabs), aabs - b);
+  // b >= 0: pi/4 - pi/4*(b-|a|)/(b+|a|);  b < 0: 3pi/4 - pi/4*(b+|a|)/(|a|-b)   — one division either way
+  const int num = 4096 * (b >= 0 ? b - aabs : b + aabs);
+  const int den = b >= 0 ? b + aabs : aabs - b;
+  int angle = (b >= 0 ? 4096 : 12288) - div_small(num, den | (den == 0));
+  if (a == 0 && b == 0) angle = 0;
   const short at = (short)(a >= 0 ? angle : -angle);
   return (int)at / 2;
 }
@@ -294,7 +295,7 @@ constexpr int MF_BLK = 16;    // samples per block (one column)
 template <int S, bool TLDS>
 __global__ __launch_bounds__(TPB, TLDS ? 4 : 2) void iqbb_i16_mfma_kernel(const IqbbArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  const int PLW = (2 * (TI + a.OP) + 64 + 15) / 16 * 4;    // dwords per byte plane
+  const int PLW = (2 * (TI + a.OP) + 64 + 31) / 32 * 8;    // dwords per byte plane
   // two plane pairs (double buffer): tile i+1 is written while slower waves still read tile i
   int2 *lut_s = reinterpret_cast<int2 *>(smem + 4 * PLW);
   v4i *taps_s = reinterpret_cast<v4i *>(smem + 4 * PLW + 256);   // TLDS: [S][2][64] fragments
@@ -314,24 +315,28 @@ __global__ __launch_bounds__(TPB, TLDS ? 4 : 2) void iqbb_i16_mfma_kernel(const 
 
   // Software pipeline over the tiles this workgroup walks: the global loads of tile i+1 are issued into
   // registers before the MFMA/epilogue work of tile i and written to the other LDS plane pair after it.
-  constexpr int NPF = (TI + 129 + 2 + 2 * TPB - 1) / (2 * TPB);   // sample pairs per lane and tile (OP <= 129)
-  uint32_t px0[NPF], px1[NPF];
+  constexpr int NQ = (TI + 129 + 2 + 4 * TPB - 1) / (4 * TPB);   // sample quads per lane and tile (OP <= 129)
+  struct __attribute__((packed, aligned(4))) Quad { uint32_t v[4]; };   // 16-byte load from a 4-byte aligned address
+  Quad px[NQ];
   auto fetch = [&](int tile_) {
     const int q0_ = tile_ * a.OG - a.ovl;
     const int first = a.base0_rel + q0_ * 8 - (a.OP - 1);
-    const int pairs = (min(a.CG, a.n_groups - q0_) * 8 + a.OP + 2) / 2;
-    if (first >= 0 && first + 2 * pairs <= a.N) {   // interior tile: no history, no end of call
+    const int quads = (min(a.CG, a.n_groups - q0_) * 8 + a.OP + 4) / 4;
+    if (first >= 0 && first + 4 * quads <= a.N) {   // interior tile: no history, no end of call
       const uint32_t *src = a.in + (long)c * a.in_stride + first;
 #pragma unroll
-      for (int k = 0; k < NPF; k++) {
+      for (int k = 0; k < NQ; k++) {
         const int p = tid + k * TPB;
-        if (p < pairs) { px0[k] = src[2 * p]; px1[k] = src[2 * p + 1]; }
+        if (p < quads) px[k] = *reinterpret_cast<const Quad *>(src + 4 * p);
       }
     } else {
 #pragma unroll
-      for (int k = 0; k < NPF; k++) {
+      for (int k = 0; k < NQ; k++) {
         const int p = tid + k * TPB;
-        if (p < pairs) { px0[k] = load_x(a, c, first + 2 * p); px1[k] = load_x(a, c, first + 2 * p + 1); }
+        if (p < quads) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) px[k].v[j] = load_x(a, c, first + 4 * p + j);
+        }
       }
     }
   };
@@ -345,15 +350,24 @@ __global__ __launch_bounds__(TPB, TLDS ? 4 : 2) void iqbb_i16_mfma_kernel(const 
     const int groups_here = min(a.CG, a.n_groups - q0);
     uint32_t *lo = smem + (it & 1) * 2 * PLW, *hi = lo + PLW;
 
-    // ---- stage: two samples -> 4 bytes of the low plane (offset to signed) and 4 of the high plane ----
+    // ---- stage: four samples -> 8 bytes of the low plane (offset to signed) and 8 of the high plane ----
     {
-      const int pairs = (groups_here * 8 + a.OP + 2) / 2;
+      const int quads = (groups_here * 8 + a.OP + 4) / 4;
 #pragma unroll
-      for (int k = 0; k < NPF; k++) {
+      for (int k = 0; k < NQ; k++) {
         const int p = tid + k * TPB;
-        if (p < pairs) {
-          lo[p] = __builtin_amdgcn_perm(px1[k], px0[k], 0x06040200u) ^ 0x80808080u;
-          hi[p] = __builtin_amdgcn_perm(px1[k], px0[k], 0x07050301u);
+        if (p < quads) {
+          // 16-byte chunks (8 samples) are de-interleaved by parity (even chunks in the first half of the
+          // plane, odd in the second): a lane's K steps then walk consecutive chunks and the 16 lanes a
+          // ds_read_b128 services together cover one contiguous 256-byte bank row instead of every other slot
+          const int d = (((p >> 1) & 1) * (PLW >> 1)) + ((p >> 2) << 2) + ((p & 1) << 1);
+          uint2 l2, h2;
+          l2.x = __builtin_amdgcn_perm(px[k].v[1], px[k].v[0], 0x06040200u) ^ 0x80808080u;
+          l2.y = __builtin_amdgcn_perm(px[k].v[3], px[k].v[2], 0x06040200u) ^ 0x80808080u;
+          h2.x = __builtin_amdgcn_perm(px[k].v[1], px[k].v[0], 0x07050301u);
+          h2.y = __builtin_amdgcn_perm(px[k].v[3], px[k].v[2], 0x07050301u);
+          *reinterpret_cast<uint2 *>(lo + d) = l2;
+          *reinterpret_cast<uint2 *>(hi + d) = h2;
         }
       }
     }
@@ -365,12 +379,14 @@ __global__ __launch_bounds__(TPB, TLDS ? 4 : 2) void iqbb_i16_mfma_kernel(const 
       v16i acc_hh = {0}, acc_mid = {0}, acc_ll;
 #pragma unroll
       for (int r = 0; r < 16; r++) acc_ll[r] = (r & 1) ? a.cim : a.cre;   // + 128*sum(a) rides in as C
-      const char *pl = reinterpret_cast<const char *>(lo) + 16 * gw + 32 * n + 16 * h;   // 2 B per sample and plane
-      const char *ph = reinterpret_cast<const char *>(hi) + 16 * gw + 32 * n + 16 * h;
+      // chunk (16 B = 8 samples of one plane) gw + 2(n+s) + h of the tile, in the parity-split layout
+      const int coff = ((gw + h) & 1) * (2 * PLW) + 16 * (((gw + h) >> 1) + n);
+      const char *pl = reinterpret_cast<const char *>(lo) + coff;
+      const char *ph = reinterpret_cast<const char *>(hi) + coff;
 #pragma unroll
       for (int s = 0; s < S; s++) {
-        const v4i ul = *reinterpret_cast<const v4i *>(pl + 32 * s);
-        const v4i uh = *reinterpret_cast<const v4i *>(ph + 32 * s);
+        const v4i ul = *reinterpret_cast<const v4i *>(pl + 16 * s);
+        const v4i uh = *reinterpret_cast<const v4i *>(ph + 16 * s);
         if (TLDS) { Ah[s] = taps_s[(2 * s) * 64 + l]; Al[s] = taps_s[(2 * s + 1) * 64 + l]; }
         acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[s], uh, acc_hh, 0, 0, 0);
         acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[s], ul, acc_mid, 0, 0, 0);
@@ -390,11 +406,11 @@ __global__ __launch_bounds__(TPB, TLDS ? 4 : 2) void iqbb_i16_mfma_kernel(const 
       }
       if (a.inc != 0) {   // scalar branch, hoisted out of the per-sample work: 8 independent LUT reads in flight
         const uint32_t cnt0 = (a.n0_lo + (uint32_t)rel0) * a.inc;   // phase counter of the lane's first sample (mod 2^15 below)
+        const uint32_t negx = a.negative ? 127u : 0u;
         int2 L[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-          uint32_t idx = ((cnt0 + (uint32_t)(4 * (k >> 1) + (k & 1)) * a.inc) & 32767u) >> 8;
-          if (a.negative) idx = 127u - idx;
+          const uint32_t idx = (((cnt0 + (uint32_t)(4 * (k >> 1) + (k & 1)) * a.inc) & 32767u) >> 8) ^ negx;   // 127-idx == idx^127
           L[k] = lut_s[idx];
         }
 #pragma unroll
@@ -533,6 +549,7 @@ struct sdrhip_iqbb_i16 {
     // keep >= ~8 workgroups per CU in flight for balance
     int tpw = 1;
     if (path == 1) { tpw = 8; while (tpw > 1 && (size_t)ceil_div((size_t)tiles, (size_t)tpw) * C < 2048) tpw >>= 1; }
+    { const char *t = getenv("SDRHIP_IQBB_TPW"); if (t && path == 1) tpw = std::max(1, atoi(t)); }   // tuning hook
     a.tiles = tiles; a.tpw = tpw;
     dim3 grid((unsigned)ceil_div((size_t)tiles, (size_t)tpw), C), block(TPB);
     if (path == 1) {
@@ -601,7 +618,7 @@ int sdrhip_iqbb_i16_create(sdrhip_ctx *ctx, const int32_t *taps, int order, cons
       if (h->path == 1) { h->OG = 4 * (64 - ovl); h->CG = h->OG + ovl; }   // every wave recomputes its own FM overlap group
       h->fast8 = (decim == R);
       if (h->path == 1) {
-        const size_t PLW = (2 * (size_t)(TI + h->OP) + 64 + 15) / 16 * 4;
+        const size_t PLW = (2 * (size_t)(TI + h->OP) + 64 + 31) / 32 * 8;
         const char *tv = getenv("SDRHIP_IQBB_TAPS");   // "reg" / "lds": tuning hook
         h->taps_lds = !(tv && !strcmp(tv, "reg"));
         h->lds_bytes = (4 * PLW + 256) * 4 + (h->taps_lds ? (size_t)h->S * 2 * 64 * 16 : 0);
