@@ -15,12 +15,22 @@ namespace {
 
 constexpr int TPB = 256;
 
-__device__ __forceinline__ int fm_phi(int a, int b) {
-  if (a == 0 && b == 0) return 0;
+// trunc(num/den) for |num| <= 4096*den, 0 < den < 2^16 (the only divisions fast_atan2 makes): float
+// estimate (|q| <= 4096, error < 1) + one exact remainder correction, instead of the generic 32-bit sequence
+__device__ __forceinline__ int div_small(int num, int den) {
+  const unsigned nu = (unsigned)(num < 0 ? -num : num), de = (unsigned)den;
+  unsigned q = (unsigned)((float)nu * __builtin_amdgcn_rcpf((float)de));   // v_rcp_f32: 1 ulp, |q| <= 4096
+  int r = (int)(nu - __umul24(q, de));
+  if (r < 0) { q -= 1; r += (int)de; }
+  if (r >= (int)de) q += 1;
+  return num < 0 ? -(int)q : (int)q;
+}
+__device__ __forceinline__ int fm_phi(int a, int b) {   // fast_atan2<int16,int16>(a,b)/2, src/math.hh:31-40
   const int aabs = a >= 0 ? a : -a;
-  int angle;
-  if (b >= 0) angle = 4096 - 4096 * (b - aabs) / (b + aabs);
-  else angle = 12288 - 4096 * (b + aabs) / (aabs - b);
+  const int num = 4096 * (b >= 0 ? b - aabs : b + aabs);
+  const int den = b >= 0 ? b + aabs : aabs - b;
+  int angle = (b >= 0 ? 4096 : 12288) - div_small(num, den | (den == 0));
+  if (a == 0 && b == 0) angle = 0;
   const short at = (short)(a >= 0 ? angle : -angle);
   return (int)at / 2;
 }
