@@ -100,6 +100,21 @@ def cpu_baseline(workload, target_s):
             "host_cores_available": cores_avail}
 
 
+def measured_traffic(kernel):
+    """Per-launch HBM bytes of `kernel` from the committed rocprofv3 PMC passes (profiles/*_pmc.json, newest
+    round first; collected in separate --pmc runs of this same command and corrected as MI355X_MICROARCH.md
+    prescribes: FETCH_SIZE x2 on gfx950, KiB units). None if no profile of that kernel is committed."""
+    import glob
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
+        try:
+            d = json.load(open(fn)).get(kernel, {}).get("derived")
+            if d:
+                return {"bytes": d["hbm_traffic_bytes_per_launch"], "source": os.path.basename(fn)}
+        except Exception:
+            pass
+    return None
+
+
 def main():
     a = parse()
     import torch
@@ -215,10 +230,15 @@ def main():
                        "parallelism": "channel-sharded x%d, %s" % (world, "output gathered on rank 0 per step (RCCL)" if a.gather else "no data-path collective")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": kernel,
+                         "algorithmic_bytes_per_launch": C * N * alg_bytes,
                          "algorithmic_bytes_per_sample": alg_bytes, "avg_launch_ms": round(per_launch_s * 1e3, 4),
                          "hbm_read_frac": round(C * N * in_bytes / per_launch_s / 1e9 / HBM_PEAK_GBS, 5),
                          "per_gpu_msamples_s": round(C * N / per_launch_s / 1e6, 2)},
         }
+        tr = measured_traffic(kernel) if (C, N) == (1024, 65536) else None
+        if tr:
+            res["roofline"]["traffic"] = tr["bytes"]
+            res["roofline"]["traffic_source"] = "profiles/" + tr["source"]
         if world == 1 and not a.no_cpu_baseline:
             cb = cpu_baseline(wl, a.cpu_seconds)
             if cb:
