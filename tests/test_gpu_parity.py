@@ -33,12 +33,14 @@ def ctx():
     c.close()
 
 
-@pytest.fixture(params=["auto", "valu"])
+@pytest.fixture(params=["auto", "valu", "mfma16"])
 def k1path(request, monkeypatch):
     """K1 has two bit-exact formulations: the int8-MFMA kernel (picked automatically for decim 8, order <= 129)
     and the VALU dot2 kernel (everything else); every K1 test runs with both selections."""
     if request.param == "valu":
         monkeypatch.setenv("SDRHIP_IQBB_PATH", "valu")
+    elif request.param == "mfma16":
+        monkeypatch.setenv("SDRHIP_IQBB_PATH", "mfma16")
     else:
         monkeypatch.delenv("SDRHIP_IQBB_PATH", raising=False)
     return request.param
@@ -95,7 +97,7 @@ def synth_channels(orc, C, N, seed=0x5D2):
 
 @pytest.mark.parametrize("epi", [sa.EPI_NONE, sa.EPI_FM, sa.EPI_AM, sa.EPI_USB])
 @pytest.mark.parametrize("order,decim,Fc", [(127, 8, 100e3), (21, 8, -100e3), (33, 5, 100e3), (16, 1, 50e3),
-                                             (129, 8, 0.0), (64, 8, 30e3), (9, 8, -250e3), (1, 8, 100e3)])
+                                             (129, 8, 0.0), (64, 8, 30e3), (9, 8, -250e3), (1, 8, 100e3), (150, 8, 70e3)])
 def test_iqbb_batched_vs_oracle(ctx, orc, epi, order, decim, Fc, k1path):
     C, chunks = 5, [8192, 3000, 1, 7, 5000, 8192]
     taps = sa.design_iqbb_taps(Fc, 50e3, FS, order)
@@ -144,6 +146,9 @@ def test_iqbb_path_selection(ctx, golden, monkeypatch):
     assert sa.IQBaseBandI16(ctx, big, lut, 1365, 0, 8).path == 0
     monkeypatch.setenv("SDRHIP_IQBB_PATH", "valu")
     assert sa.IQBaseBandI16(ctx, taps, lut, 1365, 0, 8).path == 0
+    monkeypatch.setenv("SDRHIP_IQBB_PATH", "mfma16")
+    assert sa.IQBaseBandI16(ctx, taps, lut, 1365, 0, 8).path == 2
+    assert sa.IQBaseBandI16(ctx, taps, lut, 1365, 0, 5).path == 0          # a preference, not a requirement
 
 
 def test_iqbb_reset_semantics(ctx, orc, golden, k1path):
