@@ -66,6 +66,9 @@ def lib():
             "orc_fftfilt_destroy": (None, [vp]),
             "orc_dft_f64": (None, [C.c_int, C.c_int, f64p, f64p]),
             "orc_freqshift_cf32": (None, [f32p, C.c_size_t, C.c_uint64, C.c_double, C.c_double, f32p]),
+            "orc_autocast_cu8_cs16": (None, [C.POINTER(C.c_uint8), C.c_size_t, i16p]),
+            "orc_fmdeemph_alpha": (C.c_int, [C.c_double]),
+            "orc_fmdeemph_i16": (None, [i16p, C.c_size_t, C.c_int, i16p, i16p]),
             "orc_bench_iqbb_fm": (C.c_double, [i32p, C.c_int, i32p, C.c_uint32, C.c_int, C.c_int, i16p,
                                                C.c_size_t, C.c_size_t, C.POINTER(C.c_long)]),
         }
@@ -293,6 +296,26 @@ def freqshift_cf32(x, n0, Fc, Fs):
     o = np.zeros_like(x)
     lib().orc_freqshift_cf32(_p(x, C.c_float), x.shape[0], n0, Fc, Fs, _p(o, C.c_float))
     return o
+
+
+def autocast_cu8_cs16(x):
+    """AutoCast<complex<int16>> on complex<uint8> input; x: [..., 2] uint8 -> [..., 2] int16."""
+    x = np.ascontiguousarray(x, np.uint8)
+    o = np.zeros(x.shape, np.int16)
+    lib().orc_autocast_cu8_cs16(_p(x, C.c_uint8), x.size, _p(o, C.c_int16))
+    return o
+
+
+class FMDeemphI16:
+    def __init__(self, sample_rate):
+        self.alpha = int(lib().orc_fmdeemph_alpha(sample_rate))
+        self.avg = np.zeros(1, np.int16)
+
+    def process(self, x):
+        x = np.ascontiguousarray(x, np.int16)
+        o = np.zeros_like(x)
+        lib().orc_fmdeemph_i16(_p(x, C.c_int16), x.size, self.alpha, _p(self.avg, C.c_int16), _p(o, C.c_int16))
+        return o
 
 
 def bench_iqbb_fm(taps, lut, lut_inc, negative, decim, x, nbuf):

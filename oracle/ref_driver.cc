@@ -360,6 +360,67 @@ static void golden() {
     case_fir_cs16("g8_loud_fir127", xl, Fs, 127, 100e3, c4096, false); }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// "next" rows: AutoCast cu8 -> cs16 in front of the path, FMDeemph behind it
+//   cu8 source -> AutoCast<cs16> -> IQBaseBand<int16> -> FMDemod -> FMDeemph     (examples/sdr_fm.cc:38-53)
+// ---------------------------------------------------------------------------------------------
+static void golden_next() {
+  typedef std::complex<uint8_t> cu8;
+  const double Fs = 1e6; const size_t N = 4096, NB = 3;
+  // synthetic RTL-SDR style bytes: two tones around 127 plus a deterministic dither
+  std::vector<cu8> x(N * NB);
+  uint32_t lcg = 12345u;
+  for (size_t i = 0; i < x.size(); i++) {
+    lcg = lcg * 1664525u + 1013904223u;
+    const int d0 = (int)((lcg >> 24) & 3) - 1, d1 = (int)((lcg >> 16) & 3) - 1;
+    const double a = 2 * M_PI * (100e3 + 3e3 * std::sin(2 * M_PI * 1e3 * i / Fs) / 1.0) * i / Fs, b = 2 * M_PI * (-250e3) * i / Fs + 0.3;
+    int re = 127 + (int)std::lround(90 * std::cos(a) + 25 * std::cos(b)) + d0;
+    int im = 127 + (int)std::lround(90 * std::sin(a) + 25 * std::sin(b)) + d1;
+    re = std::min(255, std::max(0, re)); im = std::min(255, std::max(0, im));
+    x[i] = cu8((uint8_t)re, (uint8_t)im);
+  }
+  { std::vector<uint8_t> flat; for (size_t i = 0; i < x.size(); i++) { flat.push_back(x[i].real()); flat.push_back(x[i].imag()); }
+    // a few extreme bytes pin the int8 reinterpretation of AutoCast (src/autocast.hh:187-194)
+    uint8_t ext[] = {0, 127, 128, 200, 255, 1, 126, 129};
+    for (int k = 0; k < 8; k++) flat[k] = ext[k];
+    for (size_t i = 0; i < 4; i++) x[i] = cu8(flat[2 * i], flat[2 * i + 1]);
+    dump("g9_iq_cu8", "u8", flat, "\"Fs\": 1000000, \"bufsize\": 4096, \"nbuf\": 3"); }
+  // AutoCast alone
+  { Feeder<cu8> src; src.configure(Fs, N); AutoCast<cs16> cast; src.connect(&cast, true);
+    Capture<cs16> cap; cast.connect(&cap, true);
+    for (size_t b = 0; b < NB; b++) src.feed(&x[b * N], N);
+    dump("g9_autocast_cs16", "cs16", flat16(cap.data)); }
+  // the sdr_fm chain: orders 21 (the example's) and 127, /8; FM in place; de-emphasis at 125 kS/s
+  size_t orders[2] = {21, 127};
+  for (int k = 0; k < 2; k++) {
+    Feeder<cu8> src; src.configure(Fs, N); AutoCast<cs16> cast; BBProbe bb(100e3, 100e3, 50e3, orders[k], 8);
+    FMDemod<int16_t> fm; FMDeemph<int16_t> de; Capture<int16_t> capfm, capde;
+    src.connect(&cast, true); cast.connect(&bb, true); bb.connect(&fm, true); fm.connect(&capfm, true); fm.connect(&de, true); de.connect(&capde, true);
+    for (size_t b = 0; b < NB; b++) src.feed(&x[b * N], N);
+    std::ostringstream nm; nm << "g9_cu8_iqbb" << orders[k] << "d8";
+    std::ostringstream par; par << "\"Fs\": " << Fs << ", \"Fc\": 100000, \"Ff\": 100000, \"width\": 50000, \"order\": " << orders[k]
+        << ", \"decim\": " << bb.decim() << ", \"lut_inc\": " << bb.lutInc() << ", \"negative\": 0";
+    dump(nm.str() + "_taps", "i32", bb.taps(), par.str());
+    // bb sends with allow_overwrite to its only sink, so FMDemod runs in place: index 0 = y[0].real()
+    dump(nm.str() + "_fm", "i16", capfm.data, lens_json("out_lens", capfm.lens));
+    dump(nm.str() + "_fm_deemph", "i16", capde.data, lens_json("out_lens", capde.lens));
+  }
+  // FMDeemph alone on a known int16 stream (the masked FM output above would carry garbage at index 0)
+  { std::vector<int16_t> y(3 * 512);
+    uint32_t l2 = 777u;
+    for (size_t i = 0; i < y.size(); i++) { l2 = l2 * 1664525u + 1013904223u; y[i] = (int16_t)(2000 * std::sin(2 * M_PI * i / 97.0) + (int)((l2 >> 20) & 255) - 128); }
+    y[5] = 32767; y[6] = -32768; y[7] = 0;
+    dump("g9_deemph_in", "i16", y);
+    double rates[2] = {125e3, 48e3};
+    for (int k = 0; k < 2; k++) {
+      Feeder<int16_t> src; src.setConfig(Config(Config::Type_s16, rates[k], 512, 1));
+      FMDeemph<int16_t> de; src.connect(&de, true); Capture<int16_t> cap; de.connect(&cap, true);
+      for (int b = 0; b < 3; b++) src.feed(&y[b * 512], 512);
+      std::ostringstream nm; nm << "g9_deemph_out_" << (int)rates[k];
+      dump(nm.str(), "i16", cap.data); } }
+}
+
 // ---------------------------------------------------------------------------------------------
 // timing of the reference CPU path (bench.py cpu_baseline kind "reference")
 // ---------------------------------------------------------------------------------------------
@@ -416,6 +477,7 @@ int main(int argc, char **argv) {
     g_out = argv[2];
     g_manifest << "{\n";
     golden();
+    golden_next();
     g_manifest << "\n}\n";
     std::string mp = g_out + "/manifest.json";
     FILE *f = fopen(mp.c_str(), "w"); fputs(g_manifest.str().c_str(), f); fclose(f);

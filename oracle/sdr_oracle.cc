@@ -459,6 +459,31 @@ void orc_freqshift_cf32(const float *in, size_t n, uint64_t n0, double Fc, doubl
 }
 
 // ===============================================================================================
+// "next" rows: AutoCast cu8 -> cs16 (src/autocast.hh:187-194) and FMDeemph<int16_t> (src/demod.hh:305-351)
+// ===============================================================================================
+void orc_autocast_cu8_cs16(const uint8_t *in, size_t n_bytes, int16_t *out) {
+  for (size_t i = 0; i < n_bytes; i++) {
+    const int8_t b = (int8_t)in[i];                       // the reference reads the unsigned bytes through an int8_t*
+    out[i] = wrap16((int32_t)((uint32_t)((int32_t)b - 127) << 8));
+  }
+}
+
+int orc_fmdeemph_alpha(double sample_rate) {
+  return (int)round(1.0 / ((1.0 - exp(-1.0 / (sample_rate * 75e-6)))));
+}
+
+void orc_fmdeemph_i16(const int16_t *in, size_t n, int alpha, int16_t *avg, int16_t *out) {
+  int16_t a = *avg;
+  for (size_t i = 0; i < n; i++) {
+    const int16_t diff = wrap16((int32_t)in[i] - (int32_t)a);
+    if (diff > 0) a = wrap16((int32_t)a + ((int32_t)diff + alpha / 2) / alpha);
+    else a = wrap16((int32_t)a + ((int32_t)diff - alpha / 2) / alpha);
+    out[i] = a;
+  }
+  *avg = a;
+}
+
+// ===============================================================================================
 // cpu_baseline helper (kind "port"): IQBaseBand -> FMDemod in place, one thread
 // ===============================================================================================
 double orc_bench_iqbb_fm(const int32_t *taps, int order, const int32_t *lut, uint32_t inc, int negative,

@@ -88,6 +88,14 @@ void orc_dft_f64(int n, int sign, const double *in, double *out);
  * rounded to float.  PARITY UNPINNED (there is nothing in the reference to pin it to). */
 void orc_freqshift_cf32(const float *in, size_t n, uint64_t n0, double Fc, double Fs, float *out);
 
+/* ---- "next" rows ------------------------------------------------------------------ */
+/* AutoCast< complex<int16> > fed complex<uint8> (src/autocast.hh:62,187-194): every byte is read as int8,
+ * (int16(b) - 127) << 8 wrapped to int16. n_bytes = 2 x samples. */
+void orc_autocast_cu8_cs16(const uint8_t *in, size_t n_bytes, int16_t *out);
+/* FMDeemph<int16_t> (src/demod.hh:305-306 alpha, :342-351 recursion); *avg is the node's _avg */
+int orc_fmdeemph_alpha(double sample_rate);
+void orc_fmdeemph_i16(const int16_t *in, size_t n, int alpha, int16_t *avg, int16_t *out);
+
 /* ---- throughput helper for bench.py cpu_baseline (kind "port") ------------------------------ */
 /* runs IQBaseBand(127,/8)->FM on `nbuf` buffers of `n` samples; returns seconds */
 double orc_bench_iqbb_fm(const int32_t *taps, int order, const int32_t *lut, uint32_t inc, int negative,

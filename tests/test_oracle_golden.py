@@ -256,3 +256,38 @@ def test_dft_helper(orc):
     orc.lib().orc_dft_f64(n, -1, x.ctypes.data_as(C.POINTER(C.c_double)), o.ctypes.data_as(C.POINTER(C.c_double)))
     ref = np.fft.fft(x[0::2] + 1j * x[1::2])
     assert np.abs((o[0::2] + 1j * o[1::2]) - ref).max() < 1e-10
+
+
+# ---- "next" rows: AutoCast cu8 -> cs16 in front, FMDeemph behind ---------------------------
+
+def test_autocast_cu8(golden, orc):
+    u = golden.load("g9_iq_cu8").reshape(-1, 2)
+    y = orc.autocast_cu8_cs16(u)
+    assert np.array_equal(y, golden.load("g9_autocast_cs16"))
+    # SURVEY §8f literals: (0,127)->(-32512,0), (128,200)->(256,18688), (255,1)->(-32768,-32256)
+    assert y[0].tolist() == [-32512, 0] and y[1].tolist() == [256, 18688] and y[2].tolist() == [-32768, -32256]
+
+
+@pytest.mark.parametrize("rate", [125000, 48000])
+def test_fmdeemph(golden, orc, rate):
+    x = golden.load("g9_deemph_in")
+    de = orc.FMDeemphI16(float(rate))
+    assert de.alpha == (4 if rate == 48000 else 10)
+    y = np.concatenate([de.process(x[i * 512:(i + 1) * 512]) for i in range(3)])
+    assert np.array_equal(y, golden.load("g9_deemph_out_%d" % rate))
+
+
+@pytest.mark.parametrize("order", [21, 127])
+def test_sdr_fm_chain_cu8(golden, orc, order):
+    """cu8 -> AutoCast -> IQBaseBand(order, /8) -> FMDemod (in place) -> FMDeemph: the DSP of examples/sdr_fm.cc."""
+    name = "g9_cu8_iqbb%dd8" % order
+    m = golden.meta(name + "_taps")
+    u = golden.load("g9_iq_cu8").reshape(-1, 2)
+    bb = orc.IQBaseBandI16(golden.load(name + "_taps"), orc.freqshift_lut_i16(), m["lut_inc"], 0, 8)
+    fm, de = orc.FMDemodI16(), orc.FMDeemphI16(1e6 / 8)
+    f_all, d_all = [], []
+    for b in range(3):
+        f = fm.process(bb.process(orc.autocast_cu8_cs16(u[b * 4096:(b + 1) * 4096])))
+        f_all.append(f); d_all.append(de.process(f))
+    assert np.array_equal(np.concatenate(f_all), golden.load(name + "_fm"))
+    assert np.array_equal(np.concatenate(d_all), golden.load(name + "_fm_deemph"))
