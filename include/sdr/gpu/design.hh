@@ -88,6 +88,11 @@ inline void firLowPass(size_t order, double upperFreq, double sampleRate, double
   for (size_t i = 0; i < order; i++) alpha[i] /= l1;
 }
 
+/** FMDeemph filter constant (reference src/demod.hh:305-306). */
+inline int fmDeemphAlpha(double sampleRate) {
+  return int(round(1.0 / ((1.0 - exp(-1.0 / (sampleRate * 75e-6))))));
+}
+
 /** Time-domain kernel of the FFT filter, N complex floats. The modulation phase is rounded to
  * float before the exponential, as in the reference (a double phase is 3e-5 off). */
 inline void fftFilterKernel(int N, double fmin, double fmax, double sampleRate, float *h) {

@@ -86,18 +86,20 @@ template <> struct RealTag<float> { enum { dtype = SDRHIP_T_CF32 }; };
 // =================================================================================================
 // IQBaseBand<int16_t>
 // =================================================================================================
-template <class Scalar> class IQBaseBand;
-
-template <>
-class IQBaseBand<int16_t> : public Sink<cs16>, public Source {
+namespace detail {
+/** IQBaseBand on the int16 kernels; SIn = int16_t (complex<int16_t> in) or uint8_t (complex<uint8_t> in, with
+ * AutoCast< complex<int16_t> > fused into the load: the cast -> baseband pair of examples/sdr_fm.cc:49-50). */
+template <class SIn>
+class IQBB16 : public Sink< std::complex<SIn> >, public Source {
 public:
-  IQBaseBand(double Fc, double width, size_t order, size_t sub_sample, double oFs = 0.0, int device = 0)
+  typedef std::complex<SIn> CIn;
+  IQBB16(double Fc, double width, size_t order, size_t sub_sample, double oFs = 0.0, int device = 0)
     : _Fc(Fc), _Ff(Fc), _shift(Fc), _Fs(0), _width(width), _order(std::max(size_t(1), order)), _sub_sample(sub_sample),
       _oFs(oFs), _sourceBs(0), _epilogue(SDRHIP_EPI_NONE), _device(device), _plan(0) {}
-  IQBaseBand(double Fc, double Ff, double width, size_t order, size_t sub_sample, double oFs = 0.0, int device = 0)
+  IQBB16(double Fc, double Ff, double width, size_t order, size_t sub_sample, double oFs = 0.0, int device = 0)
     : _Fc(Fc), _Ff(Ff), _shift(Fc), _Fs(0), _width(width), _order(std::max(size_t(1), order)), _sub_sample(sub_sample),
       _oFs(oFs), _sourceBs(0), _epilogue(SDRHIP_EPI_NONE), _device(device), _plan(0) {}
-  virtual ~IQBaseBand() {
+  virtual ~IQBB16() {
     if (_plan) sdrhip_iqbb_i16_destroy(_plan);
     _buffer.unref();
   }
@@ -121,9 +123,9 @@ public:
 
   virtual void config(const Config &src_cfg) {
     if (!src_cfg.hasType() || !src_cfg.hasSampleRate() || !src_cfg.hasBufferSize()) return;
-    if (Config::typeId<cs16>() != src_cfg.type()) {
+    if (Config::typeId<CIn>() != src_cfg.type()) {
       ConfigError err;
-      err << "Can not configure IQBaseBand: Invalid type " << src_cfg.type() << ", expected " << Config::typeId<cs16>();
+      err << "Can not configure IQBaseBand: Invalid type " << src_cfg.type() << ", expected " << Config::typeId<CIn>();
       throw err;
     }
     _Fs = int32_t(src_cfg.sampleRate());
@@ -131,9 +133,9 @@ public:
     _reconfigure();
   }
 
-  virtual void process(const Buffer<cs16> &buffer, bool allow_overwrite) {
+  virtual void process(const Buffer<CIn> &buffer, bool allow_overwrite) {
     if (!_plan) return;
-    if (allow_overwrite) _process(buffer, buffer);
+    if (allow_overwrite && sizeof(CIn) == sizeof(cs16)) _process(buffer, Buffer<cs16>(buffer));   // in place needs equal sample sizes
     else if (_buffer.isUnused()) _process(buffer, _buffer);
     // else: output buffer still in use downstream -> the input is dropped (src/baseband.hh:141-150)
   }
@@ -147,8 +149,9 @@ protected:
     design::freqShiftLutI16(lut.data());
     const uint32_t inc = design::freqShiftIncrement(_shift, double(_Fs));
     if (_plan) { sdrhip_iqbb_i16_destroy(_plan); _plan = 0; }
-    detail::configCheck(sdrhip_iqbb_i16_create(Device::get(_device), taps.data(), int(_order), lut.data(), inc, 0 > _shift,
+    configCheck(sdrhip_iqbb_i16_create(Device::get(_device), taps.data(), int(_order), lut.data(), inc, 0 > _shift,
                                                int(D), 1, _sourceBs, _epilogue, &_plan), "IQBaseBand");
+    if (sizeof(SIn) == 1) configCheck(sdrhip_iqbb_i16_set_input_format(_plan, SDRHIP_IN_CU8), "IQBaseBand");
     size_t buffer_size = _sourceBs / D;
     if (_sourceBs % D) buffer_size += 1;
     _buffer.unref();
@@ -166,9 +169,9 @@ protected:
     else this->setConfig(Config(Config::typeId<int16_t>(), oRate, buffer_size, 1));
   }
 
-  void _process(const Buffer<cs16> &in, const Buffer<cs16> &out) {
+  void _process(const Buffer<CIn> &in, const Buffer<cs16> &out) {
     size_t n = 0;
-    if (!detail::processOk(sdrhip_iqbb_i16_process(_plan, reinterpret_cast<const int16_t *>(in.data()), in.size(), 0,
+    if (!processOk(sdrhip_iqbb_i16_process(_plan, reinterpret_cast<const int16_t *>(in.data()), in.size(), 0,
                                                    out.data(), out.size() * (_epilogue == SDRHIP_EPI_NONE ? 1 : 2), &n),
                            "gpu::IQBaseBand"))
       return;
@@ -186,6 +189,27 @@ protected:
   int _epilogue, _device;
   sdrhip_iqbb_i16 *_plan;
   Buffer<cs16> _buffer;
+};
+}  // namespace detail
+
+template <class Scalar> class IQBaseBand;
+/** Drop-in for sdr::IQBaseBand<int16_t>. */
+template <>
+class IQBaseBand<int16_t> : public detail::IQBB16<int16_t> {
+public:
+  IQBaseBand(double Fc, double width, size_t order, size_t sub_sample, double oFs = 0.0, int device = 0)
+    : detail::IQBB16<int16_t>(Fc, width, order, sub_sample, oFs, device) {}
+  IQBaseBand(double Fc, double Ff, double width, size_t order, size_t sub_sample, double oFs = 0.0, int device = 0)
+    : detail::IQBB16<int16_t>(Fc, Ff, width, order, sub_sample, oFs, device) {}
+};
+/** AutoCast< complex<int16_t> > + IQBaseBand<int16_t> in one node: sinks complex<uint8_t> (RTL-SDR bytes). */
+template <>
+class IQBaseBand<uint8_t> : public detail::IQBB16<uint8_t> {
+public:
+  IQBaseBand(double Fc, double width, size_t order, size_t sub_sample, double oFs = 0.0, int device = 0)
+    : detail::IQBB16<uint8_t>(Fc, width, order, sub_sample, oFs, device) {}
+  IQBaseBand(double Fc, double Ff, double width, size_t order, size_t sub_sample, double oFs = 0.0, int device = 0)
+    : detail::IQBB16<uint8_t>(Fc, Ff, width, order, sub_sample, oFs, device) {}
 };
 
 // =================================================================================================
@@ -311,6 +335,49 @@ template <class Scalar>
 class USBDemod : public detail::DemodBase<std::complex<Scalar>, Scalar> {
 public:
   explicit USBDemod(int device = 0) : detail::DemodBase<std::complex<Scalar>, Scalar>(SDRHIP_EPI_USB, "USBDemod", device) {}
+};
+
+/** FMDeemph<int16_t> (reference src/demod.hh:272-362). */
+template <class Scalar> class FMDeemph;
+template <>
+class FMDeemph<int16_t> : public Sink<int16_t>, public Source {
+public:
+  explicit FMDeemph(bool enabled = true, int device = 0) : _enabled(enabled), _device(device), _plan(0) {}
+  virtual ~FMDeemph() {
+    if (_plan) sdrhip_deemph_i16_destroy(_plan);
+    _buffer.unref();
+  }
+  inline bool isEnabled() const { return _enabled; }
+  inline void enable(bool enabled) { _enabled = enabled; }
+  virtual void config(const Config &src_cfg) {
+    if (!src_cfg.hasType() || !src_cfg.hasSampleRate() || !src_cfg.hasBufferSize()) return;
+    if (Config::typeId<int16_t>() != src_cfg.type()) {
+      ConfigError err;
+      err << "Can not configure FMDeemph: Invalid type " << src_cfg.type() << ", expected " << Config::typeId<int16_t>();
+      throw err;
+    }
+    if (_plan) { sdrhip_deemph_i16_destroy(_plan); _plan = 0; }   // a fresh plan: average reset to 0 (:308)
+    detail::configCheck(sdrhip_deemph_i16_create(Device::get(_device), design::fmDeemphAlpha(src_cfg.sampleRate()), 1,
+                                                 src_cfg.bufferSize(), &_plan), "FMDeemph");
+    _buffer.unref();
+    _buffer = Buffer<int16_t>(src_cfg.bufferSize());
+    this->setConfig(Config(src_cfg.type(), src_cfg.sampleRate(), src_cfg.bufferSize(), 1));
+  }
+  virtual void process(const Buffer<int16_t> &buffer, bool allow_overwrite) {
+    if (!_enabled) { this->send(buffer, allow_overwrite); return; }
+    if (!_plan) return;
+    const Buffer<int16_t> &out = allow_overwrite ? buffer : _buffer;
+    if (!detail::processOk(sdrhip_deemph_i16_process(_plan, reinterpret_cast<const int16_t *>(buffer.data()), buffer.size(), 0,
+                                                     reinterpret_cast<int16_t *>(out.data()), 0), "gpu::FMDeemph")) return;
+    if (allow_overwrite) this->send(buffer, allow_overwrite);
+    else this->send(_buffer.head(buffer.size()), false);
+  }
+
+protected:
+  bool _enabled;
+  int _device;
+  sdrhip_deemph *_plan;
+  Buffer<int16_t> _buffer;
 };
 
 // =================================================================================================

@@ -135,6 +135,12 @@ int sdrhip_iqbb_i16_process(sdrhip_iqbb_i16 *h, const int16_t *in_host, size_t n
                             void *out_host, size_t out_stride, size_t *n_out);
 int sdrhip_iqbb_i16_process_dev(sdrhip_iqbb_i16 *h, const int16_t *in_dev, size_t n_in, size_t in_stride,
                                 void *out_dev, size_t out_stride, size_t *n_out);
+/* Input sample format ("next" row). SDRHIP_IN_CU8: the buffers hold complex<uint8_t> (2 B per
+ * sample, e.g. RTL-SDR) and AutoCast< complex<int16_t> > (reference src/autocast.hh:62,187-194: each byte read
+ * as int8, (int16(b)-127)<<8) is applied while loading, as examples/sdr_fm.cc:49-50 chains the two nodes.
+ * Strides stay in samples. Allowed before the first buffer or right after a reset. */
+enum { SDRHIP_IN_CS16 = 0, SDRHIP_IN_CU8 = 1 };
+int sdrhip_iqbb_i16_set_input_format(sdrhip_iqbb_i16 *h, int format);
 /* keep_history = 1: what IQBaseBand::_reconfigure does (counters and phases reset, FIR ring kept,
  * src/baseband.hh:175-177); 0: a freshly constructed node (ring zeroed, :41-43). */
 int sdrhip_iqbb_i16_reset(sdrhip_iqbb_i16 *h, int keep_history);
@@ -171,6 +177,19 @@ int sdrhip_demod_process_dev(sdrhip_demod *h, const void *in_dev, size_t n, size
                              size_t out_stride);
 int sdrhip_demod_reset(sdrhip_demod *h);
 int sdrhip_demod_destroy(sdrhip_demod *h);
+
+/* ---- FMDeemph<int16_t> ("next" row; reference src/demod.hh:272-362) ------------ */
+/* avg += (x - avg +/- alpha/2) / alpha per sample, a nonlinear integer recursion: one lane per channel.
+ * alpha = round(1/(1-exp(-1/(Fs*75us)))) (src/demod.hh:305-306) from sdrhip_design_fmdeemph_alpha. */
+typedef struct sdrhip_deemph sdrhip_deemph;
+int sdrhip_design_fmdeemph_alpha(double sample_rate, int *alpha);
+int sdrhip_deemph_i16_create(sdrhip_ctx *ctx, int alpha, int channels, size_t max_in, sdrhip_deemph **out);
+int sdrhip_deemph_i16_process(sdrhip_deemph *h, const int16_t *in_host, size_t n, size_t in_stride, int16_t *out_host,
+                              size_t out_stride);
+int sdrhip_deemph_i16_process_dev(sdrhip_deemph *h, const int16_t *in_dev, size_t n, size_t in_stride, int16_t *out_dev,
+                                  size_t out_stride);
+int sdrhip_deemph_i16_reset(sdrhip_deemph *h);
+int sdrhip_deemph_i16_destroy(sdrhip_deemph *h);
 
 /* ---- K6: SubSample<complex<int16_t>|complex<float>> (src/subsample.hh:92-101) ------------- */
 int sdrhip_subsample_create(sdrhip_ctx *ctx, int dtype, size_t n, int channels, size_t max_in,

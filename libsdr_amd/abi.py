@@ -17,6 +17,7 @@ OK, E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_UNSUPPORTED, E_SIZE = 0, -1, -2, -3
 EPI_NONE, EPI_FM, EPI_AM, EPI_USB = 0, 1, 2, 3
 FIR_CS16_EXACT, FIR_CF32 = 0, 1
 T_CS16, T_CF32 = 0, 1
+IN_CS16, IN_CU8 = 0, 1
 FFTCONV_OLA, FFTCONV_OLS = 0, 1
 
 
@@ -91,6 +92,13 @@ def lib():
             "sdrhip_demod_process_dev": (C.c_int, [vp, vp, sz, sz, vp, sz]),
             "sdrhip_demod_reset": (C.c_int, [vp]),
             "sdrhip_demod_destroy": (C.c_int, [vp]),
+            "sdrhip_design_fmdeemph_alpha": (C.c_int, [C.c_double, C.POINTER(C.c_int)]),
+            "sdrhip_deemph_i16_create": (C.c_int, [vp, C.c_int, C.c_int, sz, pvp]),
+            "sdrhip_deemph_i16_process": (C.c_int, [vp, vp, sz, sz, vp, sz]),
+            "sdrhip_deemph_i16_process_dev": (C.c_int, [vp, vp, sz, sz, vp, sz]),
+            "sdrhip_deemph_i16_reset": (C.c_int, [vp]),
+            "sdrhip_deemph_i16_destroy": (C.c_int, [vp]),
+            "sdrhip_iqbb_i16_set_input_format": (C.c_int, [vp, C.c_int]),
             "sdrhip_subsample_create": (C.c_int, [vp, C.c_int, sz, C.c_int, sz, pvp]),
             "sdrhip_subsample_out_count": (C.c_int, [vp, sz, psz]),
             "sdrhip_subsample_process": (C.c_int, [vp, vp, sz, sz, vp, sz, psz]),

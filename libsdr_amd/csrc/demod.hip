@@ -179,6 +179,53 @@ __global__ __launch_bounds__(TPB) void subsample_cf32_kernel(const SubArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// FMDeemph<int16_t> (src/demod.hh:342-351): avg += (x - avg +/- alpha/2) / alpha, all in int with an int16
+// wrap of the difference and of the average. The recursion is nonlinear, so time cannot be split: one lane
+// walks one channel; a 64-lane workgroup moves 64 channels x 128 samples at a time through LDS so that
+// global loads and stores stay coalesced along the channel rows.
+// ---------------------------------------------------------------------------------------------
+constexpr int DE_CH = 64, DE_N = 128, DE_LD = DE_N + 2;
+
+struct DeemphArgs {
+  const short *in; long in_stride; short *out; long out_stride;
+  int N, C, alpha;
+  short *avg;   // one per channel, updated in place (each channel has exactly one lane)
+};
+
+__global__ __launch_bounds__(DE_CH) void deemph_i16_kernel(const DeemphArgs a) {
+  __shared__ short tile[DE_CH * DE_LD];
+  const int c0 = blockIdx.x * DE_CH, lane = threadIdx.x;
+  const int nch = min(DE_CH, a.C - c0);
+  int avg = lane < nch ? (int)a.avg[c0 + lane] : 0;
+  const int half = a.alpha / 2;
+  for (int n0 = 0; n0 < a.N; n0 += DE_N) {
+    const int cnt = min(DE_N, a.N - n0);
+    for (int idx = lane; idx < nch * DE_N; idx += DE_CH) {
+      const int ch = idx / DE_N, i = idx % DE_N;
+      if (i < cnt) tile[ch * DE_LD + i] = a.in[(long)(c0 + ch) * a.in_stride + n0 + i];
+    }
+    __syncthreads();
+    if (lane < nch) {
+      short *row = tile + lane * DE_LD;
+      for (int i = 0; i < cnt; i++) {
+        const int diff = (short)((int)row[i] - avg);
+        const int q = div_small(diff > 0 ? diff + half : diff - half, a.alpha);
+        avg = (short)(avg + q);
+        row[i] = (short)avg;
+      }
+    }
+    __syncthreads();
+    for (int idx = lane; idx < nch * DE_N; idx += DE_CH) {
+      const int ch = idx / DE_N, i = idx % DE_N;
+      if (i < cnt) a.out[(long)(c0 + ch) * a.out_stride + n0 + i] = tile[ch * DE_LD + i];
+    }
+    __syncthreads();
+  }
+  if (lane < nch) a.avg[c0 + lane] = (short)avg;
+}
+
 }  // namespace
 
 struct sdrhip_demod {
@@ -233,6 +280,24 @@ struct sdrhip_subsample {
     SDRHIP_CHECK_HIP(hipGetLastError());
     par ^= 1; n0 += N;
     if (n_out) *n_out = no;
+  }
+};
+
+
+struct sdrhip_deemph {
+  sdrhip_ctx *ctx = nullptr;
+  int alpha = 1, C = 1;
+  size_t max_in = 0;
+  DevBuf<short> avg;
+  DevBuf<short> stage_in, stage_out;
+  void launch(const short *in_dev, size_t N, size_t in_stride, short *out_dev, size_t out_stride) {
+    ctx->use();
+    if (N == 0) return;
+    DeemphArgs a;
+    a.in = in_dev; a.in_stride = (long)in_stride; a.out = out_dev; a.out_stride = (long)out_stride;
+    a.N = (int)N; a.C = C; a.alpha = alpha; a.avg = avg.p;
+    hipLaunchKernelGGL(deemph_i16_kernel, dim3((unsigned)ceil_div((size_t)C, (size_t)DE_CH)), dim3(DE_CH), 0, ctx->stream, a);
+    SDRHIP_CHECK_HIP(hipGetLastError());
   }
 };
 
@@ -305,6 +370,74 @@ int sdrhip_demod_reset(sdrhip_demod *h) {
 }
 
 int sdrhip_demod_destroy(sdrhip_demod *h) {
+  return guarded([&] {
+    if (!h) return;
+    h->ctx->use();
+    (void)hipStreamSynchronize(h->ctx->stream);
+    delete h;
+  });
+}
+
+int sdrhip_deemph_i16_create(sdrhip_ctx *ctx, int alpha, int channels, size_t max_in, sdrhip_deemph **out) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(ctx && out, SDRHIP_E_INVALID, "NULL argument");
+    *out = nullptr;
+    SDRHIP_REQUIRE(alpha >= 1 && alpha <= 32767, SDRHIP_E_INVALID, "alpha %d outside [1,32767]", alpha);
+    SDRHIP_REQUIRE(channels >= 1 && channels <= (1 << 20), SDRHIP_E_INVALID, "channels %d out of range", channels);
+    SDRHIP_REQUIRE(max_in >= 1 && max_in < (size_t(1) << 30), SDRHIP_E_SIZE, "max_in %zu outside [1,2^30)", max_in);
+    ctx->use();
+    sdrhip_deemph *h = new sdrhip_deemph;
+    try {
+      h->ctx = ctx; h->alpha = alpha; h->C = channels; h->max_in = max_in;
+      h->avg.alloc(channels); h->avg.zero(ctx->stream);
+      SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    } catch (...) { delete h; throw; }
+    *out = h;
+  });
+}
+
+int sdrhip_deemph_i16_process_dev(sdrhip_deemph *h, const int16_t *in_dev, size_t n, size_t in_stride, int16_t *out_dev,
+                                  size_t out_stride) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
+    SDRHIP_REQUIRE(n <= h->max_in, SDRHIP_E_SIZE, "n %zu > max_in %zu", n, h->max_in);
+    if (n == 0) return;
+    SDRHIP_REQUIRE(in_dev && out_dev, SDRHIP_E_INVALID, "NULL buffer");
+    if (in_stride == 0) in_stride = n;
+    if (out_stride == 0) out_stride = n;
+    SDRHIP_REQUIRE(in_stride >= n && out_stride >= n, SDRHIP_E_SIZE, "stride smaller than n");
+    h->launch(in_dev, n, in_stride, out_dev, out_stride);
+  });
+}
+
+int sdrhip_deemph_i16_process(sdrhip_deemph *h, const int16_t *in_host, size_t n, size_t in_stride, int16_t *out_host,
+                              size_t out_stride) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
+    SDRHIP_REQUIRE(n <= h->max_in, SDRHIP_E_SIZE, "n %zu > max_in %zu", n, h->max_in);
+    if (n == 0) return;
+    SDRHIP_REQUIRE(in_host && out_host, SDRHIP_E_INVALID, "NULL buffer");
+    h->ctx->use();
+    if (in_stride == 0) in_stride = n;
+    if (out_stride == 0) out_stride = n;
+    SDRHIP_REQUIRE(in_stride >= n && out_stride >= n, SDRHIP_E_SIZE, "stride smaller than n");
+    if (!h->stage_in.p) { h->stage_in.alloc((size_t)h->C * h->max_in); h->stage_out.alloc((size_t)h->C * h->max_in); }
+    copy_h2d_rows(h->ctx, h->stage_in.p, n * 2, in_host, in_stride * 2, n * 2, h->C);
+    h->launch(h->stage_in.p, n, n, h->stage_out.p, n);
+    copy_d2h_rows(h->ctx, out_host, out_stride * 2, h->stage_out.p, n * 2, n * 2, h->C);
+    SDRHIP_CHECK_HIP(hipStreamSynchronize(h->ctx->stream));
+  });
+}
+
+int sdrhip_deemph_i16_reset(sdrhip_deemph *h) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
+    h->ctx->use();
+    h->avg.zero(h->ctx->stream);
+  });
+}
+
+int sdrhip_deemph_i16_destroy(sdrhip_deemph *h) {
   return guarded([&] {
     if (!h) return;
     h->ctx->use();

@@ -43,6 +43,13 @@ int sdrhip_design_fir_lowpass(int order, double upper_freq, double sample_rate, 
   });
 }
 
+int sdrhip_design_fmdeemph_alpha(double sample_rate, int *alpha) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(alpha && sample_rate > 0, SDRHIP_E_INVALID, "bad argument");
+    *alpha = dz::fmDeemphAlpha(sample_rate);
+  });
+}
+
 int sdrhip_design_fftfilt_kernel(int n, double fmin, double fmax, double sample_rate, float *h) {
   return guarded([&] {
     SDRHIP_REQUIRE(h && n >= 2 && sample_rate != 0, SDRHIP_E_INVALID, "bad argument");

@@ -35,7 +35,8 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 struct IqbbArgs {
-  const uint32_t *in; long in_stride;            // cs16 packed as one dword per sample
+  const uint32_t *in; long in_stride;            // cs16 packed as one dword per sample (or cu8: one ushort, in_cu8)
+  int in_cu8;                                    // input is complex<uint8> and AutoCast<cs16> is applied on load
   const uint32_t *hist_old; uint32_t *hist_new;  // C x HH samples preceding the call
   const int2 *acc_old; int2 *acc_new;            // partial box sum of the open group
   const short *fm_old; short *fm_new;            // FMDemod::_last_value
@@ -54,8 +55,17 @@ struct IqbbArgs {
   int tiles, tpw;   // tiles per channel in this call; consecutive tiles walked by one workgroup (MFMA path)   // MFMA path: tap fragments, 128*sum(a) per component
 };
 
+// AutoCast< complex<int16_t> > on a complex<uint8_t> sample (reference src/autocast.hh:62,187-194): each byte is
+// read as int8 and becomes (int16(b) - 127) << 8, i.e. low byte 0 and high byte (b + 129) mod 256
+__device__ __forceinline__ uint32_t cast_cu8(uint32_t u16) {
+  return (((u16 & 0xffu) + 129u) & 0xffu) << 8 | ((((u16 >> 8) & 0xffu) + 129u) & 0xffu) << 24;
+}
+__device__ __forceinline__ uint32_t raw_x(const IqbbArgs &a, int c, long rel) {   // 0 <= rel < N
+  if (a.in_cu8) return cast_cu8(reinterpret_cast<const uint16_t *>(a.in)[(long)c * a.in_stride + rel]);
+  return a.in[(long)c * a.in_stride + rel];
+}
 __device__ __forceinline__ uint32_t load_x(const IqbbArgs &a, int c, int rel) {
-  if (rel >= 0) return rel < a.N ? a.in[(long)c * a.in_stride + rel] : 0u;
+  if (rel >= 0) return rel < a.N ? raw_x(a, c, rel) : 0u;
   const int h = a.HH + rel;
   return h >= 0 ? a.hist_old[(long)c * a.HH + h] : 0u;
 }
@@ -177,7 +187,7 @@ __device__ __forceinline__ void epilogue_and_roll(const IqbbArgs &a, int c, int 
     for (int k = tid; k < a.HH; k += TPB) {
       const long qq = (long)a.N + k;   // index into concat(hist_old, in)
       a.hist_new[(long)c * a.HH + k] =
-          qq < a.HH ? a.hist_old[(long)c * a.HH + qq] : a.in[(long)c * a.in_stride + (qq - a.HH)];
+          qq < a.HH ? a.hist_old[(long)c * a.HH + qq] : raw_x(a, c, qq - a.HH);
     }
   }
 }
@@ -322,7 +332,7 @@ __global__ __launch_bounds__(TPB, TLDS ? 4 : 2) void iqbb_i16_mfma_kernel(const 
     const int q0_ = tile_ * a.OG - a.ovl;
     const int first = a.base0_rel + q0_ * 8 - (a.OP - 1);
     const int quads = (min(a.CG, a.n_groups - q0_) * 8 + a.OP + 4) / 4;
-    if (first >= 0 && first + 4 * quads <= a.N) {   // interior tile: no history, no end of call
+    if (!a.in_cu8 && first >= 0 && first + 4 * quads <= a.N) {   // interior tile: no history, no end of call
       const uint32_t *src = a.in + (long)c * a.in_stride + first;
 #pragma unroll
       for (int k = 0; k < NQ; k++) {
@@ -481,7 +491,7 @@ __global__ __launch_bounds__(TPB, TLDS ? 4 : 2) void iqbb_i16_mfma_kernel(const 
       for (int k = tid; k < a.HH; k += TPB) {
         const long qq = (long)a.N + k;   // index into concat(hist_old, in)
         a.hist_new[(long)c * a.HH + k] =
-            qq < a.HH ? a.hist_old[(long)c * a.HH + qq] : a.in[(long)c * a.in_stride + (qq - a.HH)];
+            qq < a.HH ? a.hist_old[(long)c * a.HH + qq] : raw_x(a, c, qq - a.HH);
       }
     }
   }
@@ -519,7 +529,7 @@ __global__ __launch_bounds__(TPB, 3) void iqbb_i16_mfma16_kernel(const IqbbArgs 
     const int q0_ = tile_ * a.OG - a.ovl;
     const int first = a.base0_rel + q0_ * 8 - (a.OP - 1);
     const int quads = (min(a.CG, a.n_groups - q0_) * 8 + a.OP + 4) / 4;
-    if (first >= 0 && first + 4 * quads <= a.N) {
+    if (!a.in_cu8 && first >= 0 && first + 4 * quads <= a.N) {
       const uint32_t *src = a.in + (long)c * a.in_stride + first;
 #pragma unroll
       for (int k = 0; k < NQ; k++) {
@@ -704,7 +714,7 @@ __global__ __launch_bounds__(TPB, 3) void iqbb_i16_mfma16_kernel(const IqbbArgs 
       for (int k = tid; k < a.HH; k += TPB) {
         const long qq = (long)a.N + k;
         a.hist_new[(long)c * a.HH + k] =
-            qq < a.HH ? a.hist_old[(long)c * a.HH + qq] : a.in[(long)c * a.in_stride + (qq - a.HH)];
+            qq < a.HH ? a.hist_old[(long)c * a.HH + qq] : raw_x(a, c, qq - a.HH);
       }
     }
   }
@@ -721,6 +731,7 @@ struct sdrhip_iqbb_i16 {
   int par = 0, par_fm = 0;
   int CG = 0, OG = 0, ovl = 0;
   bool fast8 = false;
+  int in_cu8 = 0;
   int path = 0, S = 0, cre = 0, cim = 0;   // path 1 = int8-MFMA formulation with S K-steps
   bool taps_lds = true;                    // MFMA path: tap fragments in LDS (4 waves/SIMD) or registers
   DevBuf<v4i> tapfrag;
@@ -756,7 +767,7 @@ struct sdrhip_iqbb_i16 {
     const Geometry g = geometry(N);
     SDRHIP_REQUIRE(out_stride >= (size_t)g.n_out, SDRHIP_E_SIZE, "out_stride %zu < outputs %d", out_stride, g.n_out);
     IqbbArgs a;
-    a.in = in_dev; a.in_stride = (long)in_stride;
+    a.in = in_dev; a.in_stride = (long)in_stride; a.in_cu8 = in_cu8;
     a.hist_old = hist[par].p; a.hist_new = hist[par ^ 1].p; a.HH = HH;
     a.acc_old = acc[par].p; a.acc_new = acc[par ^ 1].p;
     const bool fm_flip = (epi == SDRHIP_EPI_FM && g.n_out >= 2);
@@ -966,13 +977,23 @@ int sdrhip_iqbb_i16_process(sdrhip_iqbb_i16 *h, const int16_t *in_host, size_t n
       h->stage_in.alloc((size_t)h->C * h->max_in);
       h->stage_out.alloc((size_t)h->C * h->max_out);
     }
-    copy_h2d_rows(h->ctx, h->stage_in.p, n_in * 4, in_host, in_stride * 4, n_in * 4, h->C);
+    const size_t ib = h->in_cu8 ? 2 : 4;
+    copy_h2d_rows(h->ctx, h->stage_in.p, n_in * ib, in_host, in_stride * ib, n_in * ib, h->C);
     const size_t eb = h->out_elem_bytes();
     size_t produced = 0;
     h->launch(h->stage_in.p, n_in, n_in, h->stage_out.p, h->max_out * 4 / eb, &produced);
     copy_d2h_rows(h->ctx, out_host, out_stride * eb, h->stage_out.p, h->max_out * 4, produced * eb, h->C);
     SDRHIP_CHECK_HIP(hipStreamSynchronize(h->ctx->stream));
     if (n_out) *n_out = produced;
+  });
+}
+
+int sdrhip_iqbb_i16_set_input_format(sdrhip_iqbb_i16 *h, int format) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
+    SDRHIP_REQUIRE(format == SDRHIP_IN_CS16 || format == SDRHIP_IN_CU8, SDRHIP_E_INVALID, "bad input format %d", format);
+    SDRHIP_REQUIRE(h->n0 == 0, SDRHIP_E_INVALID, "the input format can only change before the first buffer / after a reset");
+    h->in_cu8 = format == SDRHIP_IN_CU8;
   });
 }
 

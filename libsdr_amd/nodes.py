@@ -51,6 +51,12 @@ def design_fir_lowpass(order, Fu, Fs):
     return a
 
 
+def design_fmdeemph_alpha(Fs):
+    v = C.c_int(0)
+    check(abi.lib().sdrhip_design_fmdeemph_alpha(Fs, C.byref(v)))
+    return v.value
+
+
 def design_fftfilt_kernel(N, fmin, fmax, Fs):
     h = np.zeros((N, 2), np.float32)
     check(abi.lib().sdrhip_design_fftfilt_kernel(N, fmin, fmax, Fs, h.ctypes.data_as(C.POINTER(C.c_float))))
@@ -198,7 +204,7 @@ class IQBaseBandI16(_Node):
         return n.value
 
     def process(self, x):
-        x = _as3(x, np.int16)
+        x = _as3(x, np.uint8 if getattr(self, "_cu8", False) else np.int16)
         assert x.shape[0] == self.channels
         n_in = x.shape[1]
         no = self.out_count(n_in)
@@ -219,6 +225,11 @@ class IQBaseBandI16(_Node):
 
     def reset(self, keep_history=False):
         check(abi.lib().sdrhip_iqbb_i16_reset(self._h, int(keep_history)))
+
+    def set_input_format(self, fmt):
+        """abi.IN_CS16 (default) or abi.IN_CU8 (complex<uint8> buffers, AutoCast<cs16> fused into the load)."""
+        check(abi.lib().sdrhip_iqbb_i16_set_input_format(self._h, fmt))
+        self._cu8 = fmt == abi.IN_CU8
 
 
 class FIR(_Node):
@@ -281,6 +292,31 @@ class Demod(_Node):
 
     def reset(self):
         check(abi.lib().sdrhip_demod_reset(self._h))
+
+
+class FMDeemphI16(_Node):
+    """FMDeemph<int16_t>: sequential integer IIR per channel."""
+    _destroy = "sdrhip_deemph_i16_destroy"
+
+    def __init__(self, ctx, alpha, channels=1, max_in=65536):
+        super().__init__()
+        self.ctx, self.channels = ctx, channels
+        check(abi.lib().sdrhip_deemph_i16_create(ctx.handle, alpha, channels, max_in, C.byref(self._h)))
+
+    def process(self, x):
+        x = np.ascontiguousarray(x, np.int16)
+        if x.ndim == 1:
+            x = x[None]
+        n = x.shape[1]
+        out = np.zeros_like(x)
+        check(abi.lib().sdrhip_deemph_i16_process(self._h, _ptr(x), n, n, _ptr(out), n))
+        return out
+
+    def process_dev(self, in_ptr, n, in_stride, out_ptr, out_stride):
+        check(abi.lib().sdrhip_deemph_i16_process_dev(self._h, C.c_void_p(in_ptr), n, in_stride, C.c_void_p(out_ptr), out_stride))
+
+    def reset(self):
+        check(abi.lib().sdrhip_deemph_i16_reset(self._h))
 
 
 class SubSample(_Node):

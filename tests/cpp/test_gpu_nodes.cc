@@ -3,6 +3,7 @@
 // only). Graph shapes follow examples/sdr_fm.cc:49-53 and SURVEY §3.2/§3.3. Needs an MI355X.
 #include <cstdio>
 #include <cstring>
+#include <string>
 #include <iostream>
 #include <vector>
 
@@ -182,7 +183,34 @@ static void testFloatNodes() {
   orc_fftfilt_destroy(ff);
 }
 
-int main() {
+// the whole DSP of examples/sdr_fm.cc:38-53 on the GPU: cu8 -> [AutoCast+IQBaseBand] -> FMDemod -> FMDeemph,
+// against the golden vector cut from the reference chain
+static std::string g_golden = "tests/golden";
+template <class T> static std::vector<T> slurp(const std::string &name) {
+  std::vector<T> v; FILE *f = fopen((g_golden + "/" + name).c_str(), "rb");
+  if (!f) return v;
+  T tmp[1024]; size_t n;
+  while ((n = fread(tmp, sizeof(T), 1024, f)) > 0) v.insert(v.end(), tmp, tmp + n);
+  fclose(f); return v;
+}
+static void testSdrFmChainCu8() {
+  typedef std::complex<uint8_t> cu8;
+  std::vector<uint8_t> raw = slurp<uint8_t>("g9_iq_cu8.bin");
+  std::vector<int16_t> ref = slurp<int16_t>("g9_cu8_iqbb21d8_fm_deemph.bin");
+  CHECK(raw.size() == 3 * 4096 * 2 && ref.size() == 3 * 512 - 1);
+  struct U8Feeder : public Source { void cfg() { setConfig(Config(Config::Type_cu8, 1e6, 4096, 1)); }
+                                     void feed(cu8 *p, size_t n) { Buffer<cu8> b(p, n); send(b, false); } } src;
+  src.cfg();
+  gpu::IQBaseBand<uint8_t> bb(100e3, 100e3, 50e3, 21, 8);
+  gpu::FMDemod<int16_t> fm; gpu::FMDeemph<int16_t> de; Recorder<int16_t> out;
+  src.connect(&bb, true); bb.connect(&fm, true); fm.connect(&de, true); de.connect(&out, true);
+  CHECK(de.sampleRate() == 125000.0);
+  for (int b = 0; b < 3; b++) src.feed(reinterpret_cast<cu8 *>(&raw[b * 8192]), 4096);
+  CHECK(out.data == ref);
+}
+
+int main(int argc, char **argv) {
+  if (argc > 1) g_golden = argv[1];
   Logger::get().addHandler(new StreamLogHandler(std::cerr, LOG_WARNING));
   try {
     testBasebandFmChain();
@@ -190,6 +218,7 @@ int main() {
     testOwnership();
     testChannelBank();
     testFloatNodes();
+    testSdrFmChainCu8();
   } catch (std::exception &e) {
     std::printf("FAIL: exception: %s\n", e.what());
     return 2;

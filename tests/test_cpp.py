@@ -51,7 +51,7 @@ def test_gpu_nodes_compile_against_reference_core():
 @pytest.mark.gpu
 def test_gpu_nodes_in_graphs():
     exe = _build("test_gpu_nodes.cc", "test_gpu_nodes", _gpu_link_flags())
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK (0 failures)" in r.stdout, r.stdout + r.stderr
 
 

@@ -164,6 +164,63 @@ def test_iqbb_reset_semantics(ctx, orc, golden, k1path):
     assert np.array_equal(node.process(x[4096:8192])[0], bb.process(x[4096:8192]))
 
 
+# ---- "next" rows: cu8 input with AutoCast fused into the K1 load, FMDeemph behind the demodulator ----
+
+@pytest.mark.parametrize("order", [21, 127])
+def test_sdr_fm_chain_cu8_golden(ctx, golden, order, k1path):
+    """cu8 -> [AutoCast + IQBaseBand + FMDemod in one launch] -> FMDeemph, against the reference chain."""
+    name = "g9_cu8_iqbb%dd8" % order
+    m = golden.meta(name + "_taps")
+    u = golden.load("g9_iq_cu8").reshape(-1, 2)
+    node = sa.IQBaseBandI16(ctx, golden.load(name + "_taps"), sa.design_freqshift_lut_i16(), m["lut_inc"], 0, 8,
+                            max_in=4096, epilogue=sa.EPI_FM)
+    node.set_input_format(sa.abi.IN_CU8)
+    alpha = sa.design_fmdeemph_alpha(1e6 / 8)
+    assert alpha == 10
+    de = sa.FMDeemphI16(ctx, alpha, max_in=4096)
+    f = [node.process(u[b * 4096:(b + 1) * 4096])[0] for b in range(3)]
+    assert np.array_equal(np.concatenate(f), golden.load(name + "_fm"))
+    d = np.concatenate([de.process(x)[0] for x in f])
+    assert np.array_equal(d, golden.load(name + "_fm_deemph"))
+
+
+def test_cu8_batched_random_vs_oracle(ctx, orc, k1path):
+    rng = np.random.default_rng(21)
+    C, chunks = 3, [4096, 1, 777, 4096]
+    u = rng.integers(0, 256, size=(C, sum(chunks), 2), dtype=np.uint8)
+    taps = sa.design_iqbb_taps(-100e3, 50e3, FS, 127)
+    lut, inc = sa.design_freqshift_lut_i16(), sa.design_freqshift_inc(-100e3, FS)
+    node = sa.IQBaseBandI16(ctx, taps, lut, inc, True, 8, channels=C, max_in=4096, epilogue=sa.EPI_NONE)
+    node.set_input_format(sa.abi.IN_CU8)
+    refs = [orc.IQBaseBandI16(taps, lut, inc, True, 8) for _ in range(C)]
+    off = 0
+    for n in chunks:
+        y = node.process(u[:, off:off + n])
+        for c in range(C):
+            assert np.array_equal(y[c], refs[c].process(orc.autocast_cu8_cs16(u[c, off:off + n])))
+        off += n
+    with pytest.raises(sa.SdrHipError):
+        node.set_input_format(sa.abi.IN_CS16)       # only before the first buffer / after a reset
+
+
+@pytest.mark.parametrize("rate", [125000, 48000])
+def test_fmdeemph_golden_and_batched(ctx, golden, orc, rate):
+    x = golden.load("g9_deemph_in")
+    alpha = sa.design_fmdeemph_alpha(float(rate))
+    de = sa.FMDeemphI16(ctx, alpha, max_in=512)
+    y = np.concatenate([de.process(x[i * 512:(i + 1) * 512])[0] for i in range(3)])
+    assert np.array_equal(y, golden.load("g9_deemph_out_%d" % rate))
+    rng = np.random.default_rng(rate)
+    C = 70                                             # more channels than one 64-lane workgroup, odd sizes
+    z = rng.integers(-32768, 32768, size=(C, 333), dtype=np.int16)
+    de = sa.FMDeemphI16(ctx, alpha, channels=C, max_in=400)
+    refs = [orc.FMDeemphI16(float(rate)) for _ in range(C)]
+    for lo, hi in ((0, 1), (1, 200), (200, 333)):
+        got = de.process(z[:, lo:hi])
+        for c in range(C):
+            assert np.array_equal(got[c], refs[c].process(z[c, lo:hi]))
+
+
 # ---- K1 at the BASELINE size: properties + sampled oracle comparison ------------------------------------
 
 def test_iqbb_full_size_properties(ctx, orc, k1path):
