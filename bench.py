@@ -42,6 +42,8 @@ def parse():
     p.add_argument("--workload", default="iqbb_fm")
     p.add_argument("--batches", type=int, default=3, help="distinct input batches rotated through (defeats the 256 MiB L3)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for single-GPU dry runs)")
+    p.add_argument("--force-device", type=int, default=-1, help="dry runs only: put every rank on this device")
     p.add_argument("--gather", action="store_true", help="also gather the demodulated output on rank 0 every step (RCCL)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     return p.parse_args()
@@ -127,11 +129,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if a.force_device >= 0:
+        local = a.force_device
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(a.backend)
     C, N, W, K = a.channels, a.samples, a.warmup, a.steps
 
     stream = torch.cuda.Stream(device=dev)

@@ -733,7 +733,6 @@ struct sdrhip_iqbb_i16 {
   bool fast8 = false;
   int in_cu8 = 0;
   int path = 0, S = 0, cre = 0, cim = 0;   // path 1 = int8-MFMA formulation with S K-steps
-  bool taps_lds = true;                    // MFMA path: tap fragments in LDS (4 waves/SIMD) or registers
   DevBuf<v4i> tapfrag;
   size_t lds_bytes = 0;
   DevBuf<uint2> taps;
@@ -798,8 +797,7 @@ struct sdrhip_iqbb_i16 {
       }
 #undef SDRHIP_MF16
     } else if (path == 1) {
-#define SDRHIP_MF(S_) do { if (taps_lds) hipLaunchKernelGGL((iqbb_i16_mfma_kernel<S_, true>), grid, block, lds_bytes, ctx->stream, a); \
-                            else hipLaunchKernelGGL((iqbb_i16_mfma_kernel<S_, false>), grid, block, lds_bytes, ctx->stream, a); } while (0)
+#define SDRHIP_MF(S_) hipLaunchKernelGGL((iqbb_i16_mfma_kernel<S_, true>), grid, block, lds_bytes, ctx->stream, a)
       switch (S) {
         case 2: SDRHIP_MF(2); break;
         case 3: SDRHIP_MF(3); break;
@@ -875,9 +873,7 @@ int sdrhip_iqbb_i16_create(sdrhip_ctx *ctx, const int32_t *taps, int order, cons
         h->lds_bytes = (4 * PLW + 256) * 4;
       } else if (h->path == 1) {
         const size_t PLW = (2 * (size_t)(TI + h->OP) + 64 + 31) / 32 * 8;
-        const char *tv = getenv("SDRHIP_IQBB_TAPS");   // "reg" / "lds": tuning hook
-        h->taps_lds = !(tv && !strcmp(tv, "reg"));
-        h->lds_bytes = (4 * PLW + 256) * 4 + (h->taps_lds ? (size_t)h->S * 2 * 64 * 16 : 0);
+        h->lds_bytes = (4 * PLW + 256) * 4 + (size_t)h->S * 2 * 64 * 16;
       } else {
         const size_t XS = TI + h->OP + 8;
         h->lds_bytes = (XS + 256 + 2 * ((CG + 3) & ~3)) * 4 + (h->fast8 ? 0 : (size_t)TI * 8);
