@@ -46,6 +46,11 @@ def lib():
             "orc_iqbb_i16_process": (C.c_size_t, [vp, i16p, C.c_size_t, i16p]),
             "orc_iqbb_i16_reset": (None, [vp]),
             "orc_iqbb_i16_destroy": (None, [vp]),
+            "orc_bb_design": (None, [C.c_double, C.c_double, C.c_double, C.c_int, i32p]),
+            "orc_bb_i16_create": (vp, [i32p, C.c_int, i32p, C.c_uint32, C.c_int, C.c_int]),
+            "orc_bb_i16_process": (C.c_size_t, [vp, i16p, C.c_size_t, i16p]),
+            "orc_bb_i16_reset": (None, [vp]),
+            "orc_bb_i16_destroy": (None, [vp]),
             "orc_fir_create": (vp, [f64p, C.c_int]),
             "orc_fir_cs16_process": (None, [vp, i16p, C.c_size_t, i16p]),
             "orc_fir_cf32_process": (None, [vp, f32p, C.c_size_t, f32p]),
@@ -169,6 +174,37 @@ class IQBaseBandI16:
     def __del__(self):
         if self._h:
             lib().orc_iqbb_i16_destroy(self._h)
+            self._h = None
+
+
+def bb_design(Ff, width, Fs, order):
+    t = np.zeros(2 * order, np.int32)
+    lib().orc_bb_design(Ff, width, Fs, order, _p(t, C.c_int32))
+    return t.reshape(-1, 2)
+
+
+class BaseBandI16:
+    """BaseBand<int16_t>, the real-input variant: int16 samples in, cs16 out."""
+
+    def __init__(self, taps, lut, lut_inc, negative, decim):
+        taps = np.ascontiguousarray(taps, np.int32).reshape(-1, 2)
+        lut = np.ascontiguousarray(lut, np.int32).reshape(128, 2)
+        self.order, self.decim = taps.shape[0], decim
+        self._h = lib().orc_bb_i16_create(_p(taps, C.c_int32), self.order, _p(lut, C.c_int32),
+                                          lut_inc, int(negative), decim)
+
+    def process(self, x):
+        x = np.ascontiguousarray(x, np.int16).reshape(-1)
+        out = np.zeros((x.shape[0] // max(self.decim, 1) + 2, 2), np.int16)
+        n = lib().orc_bb_i16_process(self._h, _p(x, C.c_int16), x.shape[0], _p(out, C.c_int16))
+        return out[:n].copy()
+
+    def reset(self):
+        lib().orc_bb_i16_reset(self._h)
+
+    def __del__(self):
+        if self._h:
+            lib().orc_bb_i16_destroy(self._h)
             self._h = None
 
 

@@ -76,6 +76,20 @@ public:
   size_t decim() const { return _sub_sample; }
 };
 
+
+// same for the real-input BaseBand<int16_t> (src/baseband.hh:305-529)
+class RBProbe : public BaseBand<int16_t> {
+public:
+  RBProbe(double Fc, double Ff, double width, size_t order, size_t sub) : BaseBand<int16_t>(Fc, Ff, width, order, sub) {}
+  std::vector<int32_t> taps() const {
+    std::vector<int32_t> k;
+    for (size_t i = 0; i < _order; i++) { k.push_back(_kernel[i].real()); k.push_back(_kernel[i].imag()); }
+    return k;
+  }
+  size_t lutInc() const { return FreqShiftBase<int16_t>::_lut_inc; }
+  bool negative() const { return 0 > FreqShiftBase<int16_t>::_freq_shift; }
+};
+
 // ---------------------------------------------------------------------------------------------
 // manifest writer
 // ---------------------------------------------------------------------------------------------
@@ -421,6 +435,52 @@ static void golden_next() {
       dump(nm.str(), "i16", cap.data); } }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// "next" row 3: the real-input BaseBand<int16_t>  (src/baseband.hh:305-529)
+// ---------------------------------------------------------------------------------------------
+static void case_bb_real(const std::string &name, std::vector<int16_t> x, double Fs, double Fc, double Ff, double width,
+                         size_t order, size_t sub, const std::vector<size_t> &chunks) {
+  size_t maxlen = 0; for (size_t i = 0; i < chunks.size(); i++) maxlen = std::max(maxlen, chunks[i]);
+  Feeder<int16_t> src; src.configure(Fs, maxlen);
+  RBProbe bb(Fc, Ff, width, order, sub);
+  src.connect(&bb, true);
+  Capture<cs16> cap; bb.connect(&cap, true);
+  std::vector<size_t> used;
+  feed_chunks(src, x, chunks, used);
+  std::ostringstream par;
+  par << "\"Fs\": " << Fs << ", \"Fc\": " << Fc << ", \"Ff\": " << Ff << ", \"width\": " << width
+      << ", \"order\": " << order << ", \"decim\": " << sub << ", \"lut_inc\": " << bb.lutInc()
+      << ", \"negative\": " << (bb.negative() ? 1 : 0);
+  dump(name + "_taps", "i32", bb.taps(), par.str());
+  dump(name + "_out", "cs16", flat16(cap.data),
+       par.str() + ", " + lens_json("in_lens", used) + ", " + lens_json("out_lens", cap.lens));
+}
+
+static void golden_real() {
+  const double Fs = 1e6; const size_t N = 4096, NB = 3;
+  std::vector<int16_t> x(N * NB), loud(N * NB);
+  uint32_t lcg = 4242u;
+  for (size_t i = 0; i < x.size(); i++) {
+    lcg = lcg * 1664525u + 1013904223u;
+    const double v = 9000 * std::cos(2 * M_PI * 100e3 * i / Fs) + 5000 * std::cos(2 * M_PI * 230e3 * i / Fs + 0.4)
+                   + 2000 * std::sin(2 * M_PI * 101.5e3 * i / Fs);
+    x[i] = (int16_t)((int)v + (int)((lcg >> 22) & 63) - 32);
+    loud[i] = (int16_t)(((i / 3) & 1) ? 32767 : -32768);   // full-scale square wave
+  }
+  x[0] = 32767; x[1] = -32768; x[2] = 0;
+  dump("g10_real_in", "i16", x, "\"Fs\": 1000000, \"bufsize\": 4096, \"nbuf\": 3");
+  dump("g10_real_loud_in", "i16", loud);
+  std::vector<size_t> c4096(1, 4096), ragged, c1(1, 1000);
+  size_t r[] = {1000, 7, 0, 4096, 333, 1, 2048}; ragged.assign(r, r + 7);
+  case_bb_real("g10_bb21d8", x, Fs, 100e3, 100e3, 50e3, 21, 8, c4096);
+  case_bb_real("g10_bb127d8_neg_ragged", x, Fs, -100e3, 100e3, 50e3, 127, 8, ragged);
+  case_bb_real("g10_bb64d5", x, Fs, 100e3, 100e3, 80e3, 64, 5, c4096);      // even order: the centre tap is 1 (:470)
+  case_bb_real("g10_bb16d1_noshift", x, Fs, 0, 230e3, 50e3, 16, 1, c1);
+  case_bb_real("g10_bb1d3", x, Fs, 230e3, 230e3, 50e3, 1, 3, ragged);       // order 1: the single tap is 65536 (17 bits)
+  case_bb_real("g10_bb127d8_loud", loud, Fs, 100e3, 100e3, 300e3, 127, 8, c4096);
+}
+
 // ---------------------------------------------------------------------------------------------
 // timing of the reference CPU path (bench.py cpu_baseline kind "reference")
 // ---------------------------------------------------------------------------------------------
@@ -478,6 +538,7 @@ int main(int argc, char **argv) {
     g_manifest << "{\n";
     golden();
     golden_next();
+    golden_real();
     g_manifest << "\n}\n";
     std::string mp = g_out + "/manifest.json";
     FILE *f = fopen(mp.c_str(), "w"); fputs(g_manifest.str().c_str(), f); fclose(f);

@@ -484,6 +484,92 @@ void orc_fmdeemph_i16(const int16_t *in, size_t n, int alpha, int16_t *avg, int1
 }
 
 // ===============================================================================================
+// "next" row 3: BaseBand<int16_t>, the REAL-input variant (src/baseband.hh:305-529)
+//   design  _update_filter_kernel :464-491  (Fs, Ff, width are doubles here; centre tap of an even order is 1;
+//           +Ff modulation; Blackman on (i+1)/(order+2); Q16 = Traits<int16_t>::shift, src/traits.cc:22)
+//   stream  _process :425-445, _filter_ring :448-460  (ring of int32 holding the real samples; complex<int32>
+//           taps x real sample, wrapping; >>16; LUT rotation as IQBaseBand; D-sample windows from sample 0)
+// ===============================================================================================
+void orc_bb_design(double Ff, double width, double Fs, int order, int32_t *taps) {
+  std::vector< std::complex<double> > a(order);
+  const double w = (2 * M_PI * width) / (2 * Fs);
+  const double M = double(order) / 2;
+  double norm = 0;
+  for (size_t i = 0; i < (size_t)order; i++) {
+    if ((size_t)order == (2 * i)) a[i] = 1;
+    else a[i] = std::sin(w * (i - M)) / (w * (i - M));
+  }
+  for (size_t i = 0; i < (size_t)order; i++) {
+    a[i] = a[i] * std::exp(std::complex<double>(0, (2 * M_PI * Ff * i) / Fs));
+    a[i] *= (0.42 - 0.5 * cos((2 * M_PI * (i + 1)) / (order + 2)) + 0.08 * cos((4 * M_PI * (i + 1)) / (order + 2)));
+    norm += std::abs(a[i]);
+  }
+  for (int i = 0; i < order; i++) {
+    std::complex<double> k = (double(1 << 16) * a[i]) / norm;
+    taps[2 * i] = (int32_t)k.real();
+    taps[2 * i + 1] = (int32_t)k.imag();
+  }
+}
+
+struct RBB {
+  int order, decim, negative; uint32_t inc;
+  std::vector<C32> k, lut; std::vector<int32_t> ring;
+  size_t off, count, lut_count; C32 last;
+};
+
+void *orc_bb_i16_create(const int32_t *taps, int order, const int32_t *lut, uint32_t inc, int negative, int decim) {
+  RBB *s = new RBB;
+  s->order = order; s->decim = decim; s->negative = negative; s->inc = inc;
+  s->k.resize(order); s->ring.assign(order, 0); s->lut.resize(128);
+  for (int i = 0; i < order; i++) { s->k[i].re = taps[2 * i]; s->k[i].im = taps[2 * i + 1]; }
+  for (int i = 0; i < 128; i++) { s->lut[i].re = lut[2 * i]; s->lut[i].im = lut[2 * i + 1]; }
+  s->off = 0; s->count = 0; s->lut_count = 0; s->last = C32{0, 0};
+  return s;
+}
+void orc_bb_i16_destroy(void *h) { delete (RBB *)h; }
+void orc_bb_i16_reset(void *h) {   // config() :391-393 + setSampleRate -> _update_lut_incr; the ring keeps its content
+  RBB *s = (RBB *)h; s->off = 0; s->count = 0; s->lut_count = 0; s->last = C32{0, 0};
+}
+
+size_t orc_bb_i16_process(void *h, const int16_t *in, size_t n, int16_t *out) {
+  RBB *s = (RBB *)h;
+  const size_t order = (size_t)s->order, D = (size_t)s->decim;
+  size_t j = 0;
+  for (size_t i = 0; i < n; i++) {
+    s->ring[s->off] = in[i];
+    C32 acc = {0, 0};
+    size_t idx = s->off + 1; if (idx == order) idx = 0;
+    for (size_t t = 0; t < order; t++, idx++) {
+      if (idx == order) idx = 0;
+      // complex<int32> * int32 (libstdc++ operator*(complex, scalar): both parts times the scalar)
+      acc.re = addw(acc.re, mulw(s->k[t].re, s->ring[idx]));
+      acc.im = addw(acc.im, mulw(s->k[t].im, s->ring[idx]));
+    }
+    C32 v = {acc.re >> 16, acc.im >> 16};
+    if (s->inc != 0) {
+      size_t li = s->lut_count >> 8;
+      if (s->negative) li = 128 - li - 1;
+      const C32 L = s->lut[li];
+      C32 p;
+      p.re = subw(mulw(L.re, v.re), mulw(L.im, v.im));
+      p.im = addw(mulw(L.re, v.im), mulw(L.im, v.re));
+      v.re = p.re >> 16; v.im = p.im >> 16;
+      s->lut_count += s->inc;
+      while (s->lut_count >= (128u << 8)) s->lut_count -= (128u << 8);
+    }
+    s->last.re = addw(s->last.re, v.re); s->last.im = addw(s->last.im, v.im);
+    s->count++;
+    s->off++; if (s->off == order) s->off = 0;
+    if (D == s->count) {
+      C32 q = cdiv_int(s->last, (int32_t)D);
+      out[2 * j] = wrap16(q.re); out[2 * j + 1] = wrap16(q.im);
+      s->last = C32{0, 0}; s->count = 0; j++;
+    }
+  }
+  return j;
+}
+
+// ===============================================================================================
 // cpu_baseline helper (kind "port"): IQBaseBand -> FMDemod in place, one thread
 // ===============================================================================================
 double orc_bench_iqbb_fm(const int32_t *taps, int order, const int32_t *lut, uint32_t inc, int negative,

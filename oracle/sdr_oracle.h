@@ -92,6 +92,13 @@ void orc_freqshift_cf32(const float *in, size_t n, uint64_t n0, double Fc, doubl
 /* AutoCast< complex<int16> > fed complex<uint8> (src/autocast.hh:62,187-194): every byte is read as int8,
  * (int16(b) - 127) << 8 wrapped to int16. n_bytes = 2 x samples. */
 void orc_autocast_cu8_cs16(const uint8_t *in, size_t n_bytes, int16_t *out);
+/* "next" row 3: BaseBand<int16_t> real-input variant (src/baseband.hh:305-529) */
+void orc_bb_design(double Ff, double width, double Fs, int order, int32_t *taps);
+void *orc_bb_i16_create(const int32_t *taps, int order, const int32_t *lut, uint32_t lut_inc, int negative, int decim);
+size_t orc_bb_i16_process(void *h, const int16_t *in /* n real */, size_t n, int16_t *out /* cs16 */);
+void orc_bb_i16_reset(void *h);
+void orc_bb_i16_destroy(void *h);
+
 /* FMDeemph<int16_t> (src/demod.hh:305-306 alpha, :342-351 recursion); *avg is the node's _avg */
 int orc_fmdeemph_alpha(double sample_rate);
 void orc_fmdeemph_i16(const int16_t *in, size_t n, int alpha, int16_t *avg, int16_t *out);

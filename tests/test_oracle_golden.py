@@ -291,3 +291,28 @@ def test_sdr_fm_chain_cu8(golden, orc, order):
         f_all.append(f); d_all.append(de.process(f))
     assert np.array_equal(np.concatenate(f_all), golden.load(name + "_fm"))
     assert np.array_equal(np.concatenate(d_all), golden.load(name + "_fm_deemph"))
+
+
+# ---- "next" row 3: BaseBand<int16_t>, real input (src/baseband.hh:305-529) -----------------------------------
+
+BB_REAL_CASES = [("g10_bb21d8", "g10_real_in"), ("g10_bb127d8_neg_ragged", "g10_real_in"), ("g10_bb64d5", "g10_real_in"),
+                 ("g10_bb16d1_noshift", "g10_real_in"), ("g10_bb1d3", "g10_real_in"), ("g10_bb127d8_loud", "g10_real_loud_in")]
+
+
+@pytest.mark.parametrize("case,inp", BB_REAL_CASES)
+def test_bb_real_design(golden, orc, case, inp):
+    m = golden.meta(case + "_taps")
+    assert np.array_equal(orc.bb_design(m["Ff"], m["width"], m["Fs"], m["order"]), golden.load(case + "_taps").reshape(-1, 2))
+    assert orc.freqshift_inc(m["Fc"], m["Fs"]) == m["lut_inc"]
+
+
+@pytest.mark.parametrize("case,inp", BB_REAL_CASES)
+def test_bb_real_i16(golden, orc, case, inp):
+    m = golden.meta(case + "_out")
+    bb = orc.BaseBandI16(golden.load(case + "_taps"), orc.freqshift_lut_i16(), m["lut_inc"], m["negative"], m["decim"])
+    x = golden.load(inp)
+    outs, off = [], 0
+    for n in m["in_lens"]:
+        outs.append(bb.process(x[off:off + n])); off += n
+    assert [len(o) for o in outs] == m["out_lens"]
+    assert np.array_equal(np.concatenate(outs), golden.load(case + "_out"))
