@@ -5,6 +5,7 @@
 // the same operation order as the reference designers, and pinned against golden vectors
 // (tests/test_design.py).  Reference formulas restated (file:line):
 //   IQBaseBand::_update_filter_kernel   src/baseband.hh:239-262  (Ff, Fs, width held as int32: :266-272)
+//   BaseBand::_update_filter_kernel     src/baseband.hh:464-491  (real-input node, Q16)
 //   FreqShiftBase ctor / _update_lut_incr   src/freqshift.hh:26-36, :78-87
 //   FIRLowPassCoeffs::coeffs            src/firfilter.hh:16-32
 //   sinc_flt_kernel / FilterSource::_updateFilter   src/filternode.hh:18-28, :186-203
@@ -46,6 +47,29 @@ inline void iqbbTaps(double filterFreq, double width, double sampleRate, size_t 
   for (size_t i = 0; i < order; i++) {
     taps[2 * i] = int32_t((q * c[i].real()) / l1);
     taps[2 * i + 1] = int32_t((q * c[i].imag()) / l1);
+  }
+}
+
+/** Q16 complex band-pass taps of the real-input BaseBand<int16_t> (reference src/baseband.hh:464-491). */
+inline void bbTaps(double filterFreq, double width, double sampleRate, size_t order, int32_t *taps) {
+  std::vector< std::complex<double> > c(order);
+  const double w = (2 * M_PI * width) / (2 * sampleRate);
+  const double mid = double(order) / 2;
+  double l1 = 0;
+  for (size_t i = 0; i < order; i++) {
+    // note: the centre tap of an even order is 1, not the sinc limit times anything
+    if (order == (2 * i)) c[i] = 1;
+    else c[i] = std::sin(w * (i - mid)) / (w * (i - mid));
+  }
+  for (size_t i = 0; i < order; i++) {
+    c[i] = c[i] * std::exp(std::complex<double>(0, (2 * M_PI * filterFreq * i) / sampleRate));
+    c[i] *= (0.42 - 0.5 * cos((2 * M_PI * (i + 1)) / (order + 2)) + 0.08 * cos((4 * M_PI * (i + 1)) / (order + 2)));
+    l1 += std::abs(c[i]);
+  }
+  for (size_t i = 0; i < order; i++) {
+    const std::complex<double> k = (double(1 << 16) * c[i]) / l1;
+    taps[2 * i] = int32_t(k.real());
+    taps[2 * i + 1] = int32_t(k.imag());
   }
 }
 

@@ -213,6 +213,80 @@ public:
 };
 
 // =================================================================================================
+// BaseBand<int16_t>: the REAL-input baseband node (reference src/baseband.hh:305-529)
+// =================================================================================================
+template <class Scalar> class BaseBand;
+/** Drop-in for sdr::BaseBand<int16_t>: sinks int16_t, sources complex<int16_t> at Fs/sub_sample. Never works in
+ * place (the reference's process() ignores allow_overwrite, :408-419); drops the input while the output buffer is
+ * still in use downstream. */
+template <>
+class BaseBand<int16_t> : public Sink<int16_t>, public Source {
+public:
+  BaseBand(double Fc, double width, size_t order, size_t sub_sample)
+    : _shift(Fc), _Ff(Fc), _width(width), _Fs(0), _order(std::max(size_t(1), order)), _sub_sample(sub_sample), _sourceBs(0),
+      _epilogue(SDRHIP_EPI_NONE), _device(0), _plan(0) {}
+  BaseBand(double Fc, double Ff, double width, size_t order, size_t sub_sample, int device = 0)
+    : _shift(Fc), _Ff(Ff), _width(width), _Fs(0), _order(std::max(size_t(1), order)), _sub_sample(sub_sample), _sourceBs(0),
+      _epilogue(SDRHIP_EPI_NONE), _device(device), _plan(0) {}
+  virtual ~BaseBand() {
+    if (_plan) sdrhip_iqbb_i16_destroy(_plan);
+    _buffer.unref();
+  }
+  /** Extension, as IQBaseBand::setDemod: fuse FM / AM / USB<int16_t> into the launch. */
+  void setDemod(int epilogue) { _epilogue = epilogue; if (_Fs) _reconfigure(); }
+  inline double sampleRate() const { return _Fs; }
+  inline double frequencyShift() const { return _shift; }
+  void setFrequencyShift(double F) { _shift = F; if (_Fs) _reconfigure(); }
+
+  virtual void config(const Config &src_cfg) {
+    if (!src_cfg.hasType() || !src_cfg.hasSampleRate() || !src_cfg.hasBufferSize()) return;
+    if (Config::typeId<int16_t>() != src_cfg.type()) {
+      ConfigError err;
+      err << "Can not configure BaseBand: Invalid type " << src_cfg.type() << ", expected " << Config::typeId<int16_t>();
+      throw err;
+    }
+    _Fs = src_cfg.sampleRate();
+    _sourceBs = src_cfg.bufferSize();
+    _reconfigure();
+  }
+
+  virtual void process(const Buffer<int16_t> &buffer, bool allow_overwrite) {
+    (void)allow_overwrite;
+    if (!_plan || !_buffer.isUnused()) return;
+    size_t n = 0;
+    if (!detail::processOk(sdrhip_iqbb_i16_process(_plan, reinterpret_cast<const int16_t *>(buffer.data()), buffer.size(), 0, _buffer.data(),
+                                                   _buffer.size() * (_epilogue == SDRHIP_EPI_NONE ? 1 : 2), &n), "gpu::BaseBand"))
+      return;
+    if (_epilogue == SDRHIP_EPI_NONE) this->send(_buffer.head(n), true);
+    else if (_epilogue == SDRHIP_EPI_FM) { if (n) this->send(Buffer<int16_t>(_buffer).head(n), false); }
+    else this->send(Buffer<int16_t>(_buffer).head(n), _epilogue == SDRHIP_EPI_AM);
+  }
+
+protected:
+  void _reconfigure() {
+    std::vector<int32_t> taps(2 * _order), lut(2 * design::kLutSize);
+    design::bbTaps(_Ff, _width, _Fs, _order, taps.data());
+    design::freqShiftLutI16(lut.data());
+    const uint32_t inc = design::freqShiftIncrement(_shift, _Fs);
+    if (_plan) { sdrhip_iqbb_i16_destroy(_plan); _plan = 0; }
+    detail::configCheck(sdrhip_bb_i16_create(Device::get(_device), taps.data(), int(_order), lut.data(), inc, 0 > _shift,
+                                             int(_sub_sample), 1, _sourceBs, _epilogue, &_plan), "BaseBand");
+    size_t buffer_size = _sourceBs / _sub_sample;
+    if (_sourceBs % _sub_sample) buffer_size += 1;
+    _buffer.unref();
+    _buffer = Buffer<cs16>(buffer_size);
+    if (_epilogue == SDRHIP_EPI_NONE) this->setConfig(Config(Config::typeId<cs16>(), _Fs / _sub_sample, buffer_size, 1));
+    else this->setConfig(Config(Config::typeId<int16_t>(), _Fs / _sub_sample, buffer_size, 1));
+  }
+
+  double _shift, _Ff, _width, _Fs;
+  size_t _order, _sub_sample, _sourceBs;
+  int _epilogue, _device;
+  sdrhip_iqbb_i16 *_plan;
+  Buffer<cs16> _buffer;
+};
+
+// =================================================================================================
 // FIRLowPass<complex<int16_t>> (bit-exact) / FIRLowPass<complex<float>>
 // =================================================================================================
 template <class Scalar>

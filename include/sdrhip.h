@@ -94,6 +94,10 @@ int sdrhip_timer_destroy(sdrhip_timer *t);
 /* ---- host-side designers (no device work; same code as include/sdr/gpu/design.hh) ----------- */
 /* IQBaseBand::_update_filter_kernel (reference src/baseband.hh:239-262): order x (re,im) Q14 */
 int sdrhip_design_iqbb_taps(double filter_freq, double width, double sample_rate, int order, int32_t *taps);
+/* BaseBand<int16_t>::_update_filter_kernel, the REAL-input node (src/baseband.hh:464-491): order x (re,im) Q16;
+ * differs from the IQ designer: double-valued Fs/Ff/width, +Ff modulation, Blackman on (i+1)/(order+2),
+ * centre tap of an even order = 1 */
+int sdrhip_design_bb_taps(double filter_freq, double width, double sample_rate, int order, int32_t *taps);
 /* IQBaseBand::_reconfigure (src/baseband.hh:159-162): explicit D, or floor(Fs/out_rate) >= 1 */
 int sdrhip_design_iqbb_decim(double sample_rate, int sub_sample, double out_rate, int *decim);
 /* FreqShiftBase<int16_t> ctor (src/freqshift.hh:31-35): 128 x (re,im) */
@@ -141,6 +145,15 @@ int sdrhip_iqbb_i16_process_dev(sdrhip_iqbb_i16 *h, const int16_t *in_dev, size_
  * Strides stay in samples. Allowed before the first buffer or right after a reset. */
 enum { SDRHIP_IN_CS16 = 0, SDRHIP_IN_CU8 = 1 };
 int sdrhip_iqbb_i16_set_input_format(sdrhip_iqbb_i16 *h, int format);
+/* "next" row: BaseBand<int16_t>, the real-input node (reference src/baseband.hh:305-529:
+ * _process :425-445, _filter_ring :448-460). Same handle type and the same process / out_count / reset /
+ * destroy calls as above, with these differences: the input rows hold n_in REAL int16 samples (2 B per sample,
+ * strides in samples); taps are Q16 (sdrhip_design_bb_taps; any |component| < 2^23); the FIR result is shifted by
+ * Traits<int16_t>::shift = 16; decimation windows are the D samples {gD .. gD+D-1} from the first sample on
+ * (no D+1 first window). Output: cs16 (or the demodulated int16 with an epilogue). */
+int sdrhip_bb_i16_create(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32_t *lut,
+                         uint32_t lut_inc, int negative, int decim, int channels, size_t max_in,
+                         int epilogue, sdrhip_iqbb_i16 **out);
 /* keep_history = 1: what IQBaseBand::_reconfigure does (counters and phases reset, FIR ring kept,
  * src/baseband.hh:175-177); 0: a freshly constructed node (ring zeroed, :41-43). */
 int sdrhip_iqbb_i16_reset(sdrhip_iqbb_i16 *h, int keep_history);

@@ -67,6 +67,7 @@ def lib():
             "sdrhip_timer_elapsed_ms": (C.c_int, [vp, f32p]),
             "sdrhip_timer_destroy": (C.c_int, [vp]),
             "sdrhip_design_iqbb_taps": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_int, i32p]),
+            "sdrhip_design_bb_taps": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_int, i32p]),
             "sdrhip_design_iqbb_decim": (C.c_int, [C.c_double, C.c_int, C.c_double, C.POINTER(C.c_int)]),
             "sdrhip_design_freqshift_lut_i16": (C.c_int, [i32p]),
             "sdrhip_design_freqshift_inc": (C.c_int, [C.c_double, C.c_double, C.POINTER(C.c_uint32)]),
@@ -75,6 +76,8 @@ def lib():
             "sdrhip_design_fftfilt_spectrum": (C.c_int, [C.c_int, f32p, f32p]),
             "sdrhip_iqbb_i16_create": (C.c_int, [vp, i32p, C.c_int, i32p, C.c_uint32, C.c_int, C.c_int, C.c_int,
                                                  sz, C.c_int, pvp]),
+            "sdrhip_bb_i16_create": (C.c_int, [vp, i32p, C.c_int, i32p, C.c_uint32, C.c_int, C.c_int, C.c_int,
+                                               sz, C.c_int, pvp]),
             "sdrhip_iqbb_i16_path": (C.c_int, [vp, C.POINTER(C.c_int)]),
             "sdrhip_iqbb_i16_out_count": (C.c_int, [vp, sz, psz]),
             "sdrhip_iqbb_i16_process": (C.c_int, [vp, vp, sz, sz, vp, sz, psz]),

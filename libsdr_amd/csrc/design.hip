@@ -15,6 +15,13 @@ int sdrhip_design_iqbb_taps(double filter_freq, double width, double sample_rate
   });
 }
 
+int sdrhip_design_bb_taps(double filter_freq, double width, double sample_rate, int order, int32_t *taps) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(taps && order >= 1 && sample_rate != 0, SDRHIP_E_INVALID, "bad argument");
+    dz::bbTaps(filter_freq, width, sample_rate, (size_t)order, taps);
+  });
+}
+
 int sdrhip_design_iqbb_decim(double sample_rate, int sub_sample, double out_rate, int *decim) {
   return guarded([&] {
     SDRHIP_REQUIRE(decim && sub_sample >= 1, SDRHIP_E_INVALID, "bad argument");

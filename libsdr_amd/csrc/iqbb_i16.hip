@@ -37,6 +37,7 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 struct IqbbArgs {
   const uint32_t *in; long in_stride;            // cs16 packed as one dword per sample (or cu8: one ushort, in_cu8)
   int in_cu8;                                    // input is complex<uint8> and AutoCast<cs16> is applied on load
+  int in_real;                                   // real-input BaseBand<int16_t>: one int16 per sample, taps are raw (Kr, Ki) int32
   const uint32_t *hist_old; uint32_t *hist_new;  // C x HH samples preceding the call
   const int2 *acc_old; int2 *acc_new;            // partial box sum of the open group
   const short *fm_old; short *fm_new;            // FMDemod::_last_value
@@ -62,6 +63,7 @@ __device__ __forceinline__ uint32_t cast_cu8(uint32_t u16) {
 }
 __device__ __forceinline__ uint32_t raw_x(const IqbbArgs &a, int c, long rel) {   // 0 <= rel < N
   if (a.in_cu8) return cast_cu8(reinterpret_cast<const uint16_t *>(a.in)[(long)c * a.in_stride + rel]);
+  if (a.in_real) return (uint32_t)(int)reinterpret_cast<const short *>(a.in)[(long)c * a.in_stride + rel];   // sign-extended
   return a.in[(long)c * a.in_stride + rel];
 }
 __device__ __forceinline__ uint32_t load_x(const IqbbArgs &a, int c, int rel) {
@@ -192,7 +194,10 @@ __device__ __forceinline__ void epilogue_and_roll(const IqbbArgs &a, int c, int 
   }
 }
 
-template <bool FAST8>
+// REAL = the real-input BaseBand<int16_t> (src/baseband.hh:425-460): the staged dwords are sign-extended real
+// samples, a tap is a raw (Kr, Ki) int32 pair (Q16, up to 17 bits) and one v_mad_i32_i24 per component replaces
+// the dot2 (its low 32 bits equal the reference's wrapping int32 product for |K| < 2^23); >>16 instead of >>14.
+template <bool FAST8, bool REAL>
 __global__ __launch_bounds__(TPB) void iqbb_i16_kernel(const IqbbArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int XS = TI + a.OP + 8;
@@ -238,8 +243,13 @@ __global__ __launch_bounds__(TPB) void iqbb_i16_kernel(const IqbbArgs a) {
         const uint2 k = tp[i0 + u];   // wave-uniform -> scalar loads
 #pragma unroll
         for (int r = 0; r < R; r++) {
-          sre[r] = dot2(w[u + r], k.x, sre[r]);
-          sim[r] = dot2(w[u + r], k.y, sim[r]);
+          if (REAL) {
+            sre[r] = (int)((unsigned)__mul24((int)k.x, (int)w[u + r]) + (unsigned)sre[r]);
+            sim[r] = (int)((unsigned)__mul24((int)k.y, (int)w[u + r]) + (unsigned)sim[r]);
+          } else {
+            sre[r] = dot2(w[u + r], k.x, sre[r]);
+            sim[r] = dot2(w[u + r], k.y, sim[r]);
+          }
         }
       }
 #pragma unroll
@@ -249,7 +259,8 @@ __global__ __launch_bounds__(TPB) void iqbb_i16_kernel(const IqbbArgs a) {
 #pragma unroll
     for (int r = 0; r < R; r++) {
       const int rel = tb + R * tid + r;
-      int2 v = rotate(a, lut_s, make_int2(sre[r] >> 14, sim[r] >> 14), a.n0_lo + (uint32_t)rel);
+      constexpr int FSH = REAL ? 16 : 14;   // Traits<int16_t>::shift vs the literal 14 of IQBaseBand (:235, :459)
+      int2 v = rotate(a, lut_s, make_int2(sre[r] >> FSH, sim[r] >> FSH), a.n0_lo + (uint32_t)rel);
       const bool valid = (rel >= 0) && (rel < a.N);
       if (!valid) v = make_int2(0, 0);
       if (FAST8) {
@@ -731,7 +742,7 @@ struct sdrhip_iqbb_i16 {
   int par = 0, par_fm = 0;
   int CG = 0, OG = 0, ovl = 0;
   bool fast8 = false;
-  int in_cu8 = 0;
+  int in_cu8 = 0, real = 0;
   int path = 0, S = 0, cre = 0, cim = 0;   // path 1 = int8-MFMA formulation with S K-steps
   DevBuf<v4i> tapfrag;
   size_t lds_bytes = 0;
@@ -747,7 +758,8 @@ struct sdrhip_iqbb_i16 {
   struct Geometry { uint64_t g_first; int n_groups, n_out, base0_rel, extra0; };
   Geometry geometry(size_t N) const {
     Geometry g{};
-    const uint64_t D64 = (uint64_t)D, shift1 = D > 1 ? 1 : 0;
+    // IQBaseBand closes its first window after D+1 samples (:200,:212); the real BaseBand after D (:431-438)
+    const uint64_t D64 = (uint64_t)D, shift1 = (D > 1 && !real) ? 1 : 0;
     auto group_of = [&](uint64_t n) -> uint64_t { return n < shift1 ? 0 : (n - shift1) / D64; };
     const uint64_t gf = group_of(n0), gl = group_of(n0 + N - 1);
     const uint64_t last_end = (gl + 1) * D64 - 1 + shift1;
@@ -766,7 +778,7 @@ struct sdrhip_iqbb_i16 {
     const Geometry g = geometry(N);
     SDRHIP_REQUIRE(out_stride >= (size_t)g.n_out, SDRHIP_E_SIZE, "out_stride %zu < outputs %d", out_stride, g.n_out);
     IqbbArgs a;
-    a.in = in_dev; a.in_stride = (long)in_stride; a.in_cu8 = in_cu8;
+    a.in = in_dev; a.in_stride = (long)in_stride; a.in_cu8 = in_cu8; a.in_real = real;
     a.hist_old = hist[par].p; a.hist_new = hist[par ^ 1].p; a.HH = HH;
     a.acc_old = acc[par].p; a.acc_new = acc[par ^ 1].p;
     const bool fm_flip = (epi == SDRHIP_EPI_FM && g.n_out >= 2);
@@ -805,8 +817,11 @@ struct sdrhip_iqbb_i16 {
         default: SDRHIP_MF(9); break;
       }
 #undef SDRHIP_MF
-    } else if (fast8) hipLaunchKernelGGL(iqbb_i16_kernel<true>, grid, block, lds_bytes, ctx->stream, a);
-    else hipLaunchKernelGGL(iqbb_i16_kernel<false>, grid, block, lds_bytes, ctx->stream, a);
+    } else if (real) {
+      if (fast8) hipLaunchKernelGGL((iqbb_i16_kernel<true, true>), grid, block, lds_bytes, ctx->stream, a);
+      else hipLaunchKernelGGL((iqbb_i16_kernel<false, true>), grid, block, lds_bytes, ctx->stream, a);
+    } else if (fast8) hipLaunchKernelGGL((iqbb_i16_kernel<true, false>), grid, block, lds_bytes, ctx->stream, a);
+    else hipLaunchKernelGGL((iqbb_i16_kernel<false, false>), grid, block, lds_bytes, ctx->stream, a);
     SDRHIP_CHECK_HIP(hipGetLastError());
     par ^= 1;
     if (fm_flip) par_fm ^= 1;
@@ -815,11 +830,11 @@ struct sdrhip_iqbb_i16 {
   }
 };
 
-extern "C" {
+namespace {
 
-int sdrhip_iqbb_i16_create(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32_t *lut, uint32_t lut_inc,
-                           int negative, int decim, int channels, size_t max_in, int epilogue,
-                           sdrhip_iqbb_i16 **out) {
+int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32_t *lut, uint32_t lut_inc,
+                    int negative, int decim, int channels, size_t max_in, int epilogue, bool real,
+                    sdrhip_iqbb_i16 **out) {
   return guarded([&] {
     SDRHIP_REQUIRE(ctx && taps && lut && out, SDRHIP_E_INVALID, "NULL argument");
     *out = nullptr;
@@ -831,24 +846,27 @@ int sdrhip_iqbb_i16_create(sdrhip_ctx *ctx, const int32_t *taps, int order, cons
     const int ovl = epilogue == SDRHIP_EPI_FM ? 1 : 0;
     const int CG = TI / decim;
     SDRHIP_REQUIRE(CG - ovl >= 1, SDRHIP_E_UNSUPPORTED, "decim %d too large (max %d)", decim, TI / (1 + ovl));
-    for (int i = 0; i < 2 * order; i++)
-      SDRHIP_REQUIRE(taps[i] >= -32767 && taps[i] <= 32767, SDRHIP_E_UNSUPPORTED,
-                     "tap %d = %d does not fit the packed int16 path", i / 2, taps[i]);
+    for (int i = 0; i < 2 * order; i++) {
+      if (real) SDRHIP_REQUIRE(taps[i] > -(1 << 23) && taps[i] < (1 << 23), SDRHIP_E_UNSUPPORTED,
+                               "tap %d = %d exceeds 24 bits", i / 2, taps[i]);
+      else SDRHIP_REQUIRE(taps[i] >= -32767 && taps[i] <= 32767, SDRHIP_E_UNSUPPORTED,
+                          "tap %d = %d does not fit the packed int16 path", i / 2, taps[i]);
+    }
     for (int i = 0; i < 256; i++)
       SDRHIP_REQUIRE(lut[i] > -(1 << 23) && lut[i] < (1 << 23), SDRHIP_E_UNSUPPORTED, "LUT entry %d = %d exceeds 24 bits", i / 2, lut[i]);
     ctx->use();
     sdrhip_iqbb_i16 *h = new sdrhip_iqbb_i16;
     try {
       h->ctx = ctx; h->order = order; h->D = decim; h->C = channels; h->epi = epilogue;
-      h->negative = negative ? 1 : 0; h->inc = lut_inc; h->max_in = max_in;
+      h->negative = negative ? 1 : 0; h->inc = lut_inc; h->max_in = max_in; h->real = real ? 1 : 0;
       // path: the int8-MFMA formulations need D == 8, order <= 129 (32x32x32) / 153 (16x16x64) and tap high bytes that fit int8
-      bool mfma_ok = (decim == R) && (order <= 129);
+      bool mfma_ok = !real && (decim == R) && (order <= 129);
       auto high_byte = [](int v) { const int al = ((v + 128) & 255) - 128; return (v - al) >> 8; };
       for (int i = 0; i < 2 * order && mfma_ok; i++)   // both v and -v are packed (Kr, -Ki / Ki, Kr)
         if (high_byte(taps[i]) > 127 || high_byte(-taps[i]) > 127) mfma_ok = false;
       const char *force = getenv("SDRHIP_IQBB_PATH");   // "valu" / "mfma" / "mfma16": test hook
       if (force && !strcmp(force, "valu")) mfma_ok = false;
-      bool mfma16_ok = (decim == R) && (order <= 153);
+      bool mfma16_ok = !real && (decim == R) && (order <= 153);
       for (int i = 0; i < 2 * order && mfma16_ok; i++)
         if (high_byte(taps[i]) > 127 || high_byte(-taps[i]) > 127) mfma16_ok = false;
       if (force && !strcmp(force, "valu")) mfma16_ok = false;
@@ -884,6 +902,7 @@ int sdrhip_iqbb_i16_create(sdrhip_ctx *ctx, const int32_t *taps, int order, cons
       const int pad = h->OP - order;
       for (int i = 0; i < order; i++) {
         const int kr = taps[2 * i], ki = taps[2 * i + 1];
+        if (real) { tp[pad + i].x = (uint32_t)kr; tp[pad + i].y = (uint32_t)ki; continue; }
         tp[pad + i].x = ((uint32_t)(uint16_t)(int16_t)kr) | ((uint32_t)(uint16_t)(int16_t)(-ki) << 16);
         tp[pad + i].y = ((uint32_t)(uint16_t)(int16_t)ki) | ((uint32_t)(uint16_t)(int16_t)kr << 16);
       }
@@ -927,6 +946,22 @@ int sdrhip_iqbb_i16_create(sdrhip_ctx *ctx, const int32_t *taps, int order, cons
     } catch (...) { delete h; throw; }
     *out = h;
   });
+}
+
+}  // namespace
+
+extern "C" {
+
+int sdrhip_iqbb_i16_create(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32_t *lut, uint32_t lut_inc,
+                           int negative, int decim, int channels, size_t max_in, int epilogue,
+                           sdrhip_iqbb_i16 **out) {
+  return create_baseband(ctx, taps, order, lut, lut_inc, negative, decim, channels, max_in, epilogue, false, out);
+}
+
+int sdrhip_bb_i16_create(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32_t *lut, uint32_t lut_inc,
+                         int negative, int decim, int channels, size_t max_in, int epilogue,
+                         sdrhip_iqbb_i16 **out) {
+  return create_baseband(ctx, taps, order, lut, lut_inc, negative, decim, channels, max_in, epilogue, true, out);
 }
 
 int sdrhip_iqbb_i16_path(sdrhip_iqbb_i16 *h, int *path) {
@@ -973,7 +1008,7 @@ int sdrhip_iqbb_i16_process(sdrhip_iqbb_i16 *h, const int16_t *in_host, size_t n
       h->stage_in.alloc((size_t)h->C * h->max_in);
       h->stage_out.alloc((size_t)h->C * h->max_out);
     }
-    const size_t ib = h->in_cu8 ? 2 : 4;
+    const size_t ib = (h->in_cu8 || h->real) ? 2 : 4;
     copy_h2d_rows(h->ctx, h->stage_in.p, n_in * ib, in_host, in_stride * ib, n_in * ib, h->C);
     const size_t eb = h->out_elem_bytes();
     size_t produced = 0;
@@ -988,6 +1023,7 @@ int sdrhip_iqbb_i16_set_input_format(sdrhip_iqbb_i16 *h, int format) {
   return guarded([&] {
     SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
     SDRHIP_REQUIRE(format == SDRHIP_IN_CS16 || format == SDRHIP_IN_CU8, SDRHIP_E_INVALID, "bad input format %d", format);
+    SDRHIP_REQUIRE(!h->real, SDRHIP_E_INVALID, "the real-input baseband takes int16 samples only");
     SDRHIP_REQUIRE(h->n0 == 0, SDRHIP_E_INVALID, "the input format can only change before the first buffer / after a reset");
     h->in_cu8 = format == SDRHIP_IN_CU8;
   });

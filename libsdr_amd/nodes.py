@@ -27,6 +27,13 @@ def design_iqbb_taps(Ff, width, Fs, order):
     return t
 
 
+def design_bb_taps(Ff, width, Fs, order):
+    """Q16 taps of the real-input BaseBand<int16_t> (reference src/baseband.hh:464-491)."""
+    t = np.zeros((order, 2), np.int32)
+    check(abi.lib().sdrhip_design_bb_taps(Ff, width, Fs, order, t.ctypes.data_as(C.POINTER(C.c_int32))))
+    return t
+
+
 def design_iqbb_decim(Fs, sub, oFs=0.0):
     d = C.c_int(0)
     check(abi.lib().sdrhip_design_iqbb_decim(Fs, sub, oFs, C.byref(d)))
@@ -230,6 +237,33 @@ class IQBaseBandI16(_Node):
         """abi.IN_CS16 (default) or abi.IN_CU8 (complex<uint8> buffers, AutoCast<cs16> fused into the load)."""
         check(abi.lib().sdrhip_iqbb_i16_set_input_format(self._h, fmt))
         self._cu8 = fmt == abi.IN_CU8
+
+
+class BaseBandI16(IQBaseBandI16):
+    """BaseBand<int16_t>, the real-input node (reference src/baseband.hh:305-529): int16 samples in, cs16 (or the
+    demodulated int16) out. Shares the handle type and every call except create with IQBaseBandI16."""
+
+    def __init__(self, ctx, taps, lut, lut_inc, negative, decim, channels=1, max_in=65536, epilogue=EPI_NONE):
+        _Node.__init__(self)
+        taps = np.ascontiguousarray(taps, np.int32).reshape(-1, 2)
+        lut = np.ascontiguousarray(lut, np.int32).reshape(128, 2)
+        self.ctx, self.channels, self.decim, self.epilogue, self.max_in = ctx, channels, decim, epilogue, max_in
+        check(abi.lib().sdrhip_bb_i16_create(ctx.handle, taps.ctypes.data_as(C.POINTER(C.c_int32)), taps.shape[0],
+                                             lut.ctypes.data_as(C.POINTER(C.c_int32)), lut_inc, int(bool(negative)),
+                                             decim, channels, max_in, epilogue, C.byref(self._h)))
+
+    def process(self, x):
+        x = np.ascontiguousarray(x, np.int16)
+        if x.ndim == 1:
+            x = x[None, :]
+        assert x.ndim == 2 and x.shape[0] == self.channels
+        n_in = x.shape[1]
+        no = self.out_count(n_in)
+        out = np.zeros((self.channels, no, 2) if self.epilogue == EPI_NONE else (self.channels, no), np.int16)
+        got = C.c_size_t(0)
+        check(abi.lib().sdrhip_iqbb_i16_process(self._h, _ptr(x), n_in, n_in, _ptr(out), no, C.byref(got)))
+        assert got.value == no
+        return out
 
 
 class FIR(_Node):

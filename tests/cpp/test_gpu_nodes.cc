@@ -209,6 +209,27 @@ static void testSdrFmChainCu8() {
   CHECK(out.data == ref);
 }
 
+// real-input BaseBand<int16_t> node against the golden vector cut from the reference node (order 21, /8)
+static void testRealBaseBand() {
+  std::vector<int16_t> x = slurp<int16_t>("g10_real_in.bin"), ref = slurp<int16_t>("g10_bb21d8_out.bin");
+  CHECK(x.size() == 3 * 4096 && ref.size() == 2 * 3 * 512);
+  struct S16Feeder : public Source { void cfg() { setConfig(Config(Config::Type_s16, 1e6, 4096, 1)); }
+                                     void feed(int16_t *p, size_t n) { Buffer<int16_t> b(p, n); send(b, false); } } src;
+  src.cfg();
+  gpu::BaseBand<int16_t> bb(100e3, 100e3, 50e3, 21, 8);
+  Recorder<cs16> out;
+  src.connect(&bb, true); bb.connect(&out, true);
+  CHECK(bb.type() == Config::Type_cs16 && bb.Source::sampleRate() == 125000.0);
+  for (int b = 0; b < 3; b++) src.feed(&x[b * 4096], 4096);
+  CHECK(out.data.size() * 2 == ref.size() && 0 == memcmp(out.data.data(), ref.data(), ref.size() * 2));
+  // a wrong input type is a ConfigError, as in the reference (:371-377)
+  struct CFeeder : public Source { void cfg() { setConfig(Config(Config::Type_cs16, 1e6, 4096, 1)); } } bad;
+  gpu::BaseBand<int16_t> bb2(100e3, 50e3, 21, 8);
+  bool thrown = false;
+  try { bad.cfg(); bad.connect(&bb2, true); } catch (ConfigError &) { thrown = true; }
+  CHECK(thrown);
+}
+
 int main(int argc, char **argv) {
   if (argc > 1) g_golden = argv[1];
   Logger::get().addHandler(new StreamLogHandler(std::cerr, LOG_WARNING));
@@ -219,6 +240,7 @@ int main(int argc, char **argv) {
     testChannelBank();
     testFloatNodes();
     testSdrFmChainCu8();
+    testRealBaseBand();
   } catch (std::exception &e) {
     std::printf("FAIL: exception: %s\n", e.what());
     return 2;

@@ -203,6 +203,64 @@ def test_cu8_batched_random_vs_oracle(ctx, orc, k1path):
         node.set_input_format(sa.abi.IN_CS16)       # only before the first buffer / after a reset
 
 
+# ---- "next" row 3: BaseBand<int16_t>, real input (reference src/baseband.hh:305-529) ----------------------------
+
+BB_REAL_CASES = [("g10_bb21d8", "g10_real_in"), ("g10_bb127d8_neg_ragged", "g10_real_in"), ("g10_bb64d5", "g10_real_in"),
+                 ("g10_bb16d1_noshift", "g10_real_in"), ("g10_bb1d3", "g10_real_in"), ("g10_bb127d8_loud", "g10_real_loud_in")]
+
+
+@pytest.mark.parametrize("case,inp", BB_REAL_CASES)
+def test_bb_real_golden(ctx, golden, case, inp):
+    m = golden.meta(case + "_out")
+    assert np.array_equal(sa.design_bb_taps(m["Ff"], m["width"], m["Fs"], m["order"]), golden.load(case + "_taps").reshape(-1, 2))
+    bb = sa.BaseBandI16(ctx, golden.load(case + "_taps"), sa.design_freqshift_lut_i16(), m["lut_inc"], m["negative"], m["decim"],
+                        max_in=4096)
+    x = golden.load(inp)
+    outs, off = [], 0
+    for n in m["in_lens"]:
+        outs.append(bb.process(x[off:off + n])[0]); off += n
+    assert [len(o) for o in outs] == m["out_lens"]
+    assert np.array_equal(np.concatenate(outs), golden.load(case + "_out"))
+
+
+@pytest.mark.parametrize("epi", [sa.EPI_NONE, sa.EPI_FM, sa.EPI_USB])
+@pytest.mark.parametrize("order,decim,Fc", [(127, 8, 100e3), (33, 5, -80e3), (16, 1, 0.0), (255, 12, 100e3)])
+def test_bb_real_batched_vs_oracle(ctx, orc, epi, order, decim, Fc):
+    """5 channels of full-scale random real samples in ragged calls; demodulators chained as the reference would."""
+    Fs, C = 1e6, 5
+    rng = np.random.default_rng(order * 7 + decim)
+    taps, lut, inc = orc.bb_design(abs(Fc) if Fc else 120e3, 60e3, Fs, order), orc.freqshift_lut_i16(), orc.freqshift_inc(Fc, Fs)
+    bb = sa.BaseBandI16(ctx, taps, lut, inc, Fc < 0, decim, channels=C, max_in=3000, epilogue=epi)
+    refs = [orc.BaseBandI16(taps, lut, inc, Fc < 0, decim) for _ in range(C)]
+    fms = [orc.FMDemodI16() for _ in range(C)]
+    for n in (3000, 1, 0, 777, 2048, 13):
+        x = rng.integers(-32768, 32768, (C, n), dtype=np.int16)
+        y = bb.process(x)
+        for c in range(C):
+            r = refs[c].process(x[c])
+            if epi == sa.EPI_FM:
+                r = fms[c].process(r)
+                assert np.array_equal(y[c], r)              # index 0 = y[0].re, what the in-place buffer holds
+            elif epi == sa.EPI_USB:
+                assert np.array_equal(y[c], orc.usb_i16(r))
+            else:
+                assert np.array_equal(y[c], r)
+
+
+def test_bb_real_reset_semantics(ctx, orc):
+    Fs, order = 1e6, 21
+    rng = np.random.default_rng(5)
+    taps, lut, inc = orc.bb_design(100e3, 50e3, Fs, order), orc.freqshift_lut_i16(), orc.freqshift_inc(100e3, Fs)
+    bb = sa.BaseBandI16(ctx, taps, lut, inc, 0, 8, max_in=1000)
+    ref = orc.BaseBandI16(taps, lut, inc, 0, 8)
+    x = rng.integers(-20000, 20000, (3, 1000), dtype=np.int16)
+    assert np.array_equal(bb.process(x[0])[0], ref.process(x[0]))
+    bb.reset(keep_history=True); ref.reset()            # what config() does: counters reset, ring kept (and rotated)
+    assert np.array_equal(bb.process(x[1])[0], ref.process(x[1]))
+    bb.reset(keep_history=False); ref = orc.BaseBandI16(taps, lut, inc, 0, 8)
+    assert np.array_equal(bb.process(x[2])[0], ref.process(x[2]))
+
+
 @pytest.mark.parametrize("rate", [125000, 48000])
 def test_fmdeemph_golden_and_batched(ctx, golden, orc, rate):
     x = golden.load("g9_deemph_in")
