@@ -11,6 +11,7 @@
 #include "node.hh"
 #include "siggen.hh"
 #include "utils.hh"
+#include "wavfile.hh"
 #include "gpu/design.hh"
 #include "gpu/nodes.hh"
 #endif

@@ -481,6 +481,55 @@ static void golden_real() {
   case_bb_real("g10_bb127d8_loud", loud, Fs, 100e3, 100e3, 300e3, 127, 8, c4096);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// "next" row 4: WAV files as the reference writes / reads them (src/wavfile.hh, src/wavfile.cc)
+// and the sdr_rec NFM chain (examples/sdr_rec.cc:46-48,66-97) run file to file
+// ---------------------------------------------------------------------------------------------
+static std::vector<uint8_t> file_bytes(const std::string &path) {
+  std::vector<uint8_t> v; FILE *f = fopen(path.c_str(), "rb"); if (!f) return v;
+  uint8_t tmp[4096]; size_t n; while ((n = fread(tmp, 1, sizeof(tmp), f)) > 0) v.insert(v.end(), tmp, tmp + n);
+  fclose(f); return v;
+}
+
+static void golden_wav() {
+  typedef std::complex<uint8_t> cu8;
+  const std::string tmp = g_out + "/_tmp.wav", tmp2 = g_out + "/_tmp2.wav";
+  // (1) files written by the reference WavSink
+  { std::vector<cs16> x = siggen<int16_t>(2.4e6, 1000, 1, two_tone_i16());
+    { Feeder<cs16> src; src.configure(2.4e6, 600); WavSink<cs16> sink(tmp); src.connect(&sink, true);
+      src.feed(&x[0], 600); src.feed(&x[600], 400); sink.close(); }
+    dump("g11_wav_cs16", "u8", file_bytes(tmp), "\"Fs\": 2400000, \"frames\": 1000, \"in_lens\": [600, 400]"); }
+  { std::vector<int16_t> y(777); for (size_t i = 0; i < y.size(); i++) y[i] = (int16_t)(12000 * std::sin(2 * M_PI * i / 50.0));
+    { Feeder<int16_t> src; src.configure(22050, 777); WavSink<int16_t> sink(tmp); src.connect(&sink, true);
+      src.feed(&y[0], 777); }   // closed by the destructor
+    dump("g11_wav_s16", "u8", file_bytes(tmp), "\"Fs\": 22050, \"frames\": 777"); }
+  // (2) a cu8 recording (the g9 bytes) and what the reference WavSource makes of it
+  { std::vector<uint8_t> raw = file_bytes(g_out + "/g9_iq_cu8.bin");
+    { Feeder<cu8> src; src.configure(1e6, 4096); WavSink<cu8> sink(tmp); src.connect(&sink, true);
+      for (size_t b = 0; b < 3; b++) src.feed(reinterpret_cast<cu8 *>(&raw[b * 8192]), 4096); }
+    dump("g11_wav_cu8", "u8", file_bytes(tmp), "\"Fs\": 1000000, \"frames\": 12288");
+    WavSource rd(tmp, 5000); Capture<cu8> cap; rd.connect(&cap, true);
+    int eos = 0; struct Flag { int *p; void hit() { (*p)++; } } flag = {&eos}; rd.addEOS(&flag, &Flag::hit);
+    for (int k = 0; k < 5; k++) rd.next();
+    std::vector<uint8_t> got; for (size_t i = 0; i < cap.data.size(); i++) { got.push_back(cap.data[i].real()); got.push_back(cap.data[i].imag()); }
+    std::ostringstream ex; ex << lens_json("out_lens", cap.lens) << ", \"eos\": " << eos << ", \"type\": " << (int)rd.type()
+                              << ", \"Fs\": " << rd.sampleRate() << ", \"same_as_input\": " << (got == raw ? 1 : 0);
+    dump("g11_wavsource_cu8_readback", "u8", std::vector<uint8_t>(), ex.str());   // facts only; the data is g9_iq_cu8
+    // (3) the NFM chain of sdr_rec, file to file, direct edges
+    { WavSource src(tmp, 4096); AutoCast<cs16> cast; IQBaseBand<int16_t> bb(0, 0, 12.5e3, 16, 1, 12e3);
+      FMDemod<int16_t> fm; FMDeemph<int16_t> de; WavSink<int16_t> sink(tmp2);
+      src.connect(&cast, true); cast.connect(&bb, true); bb.connect(&fm, true); fm.connect(&de, true); de.connect(&sink, true);
+      for (int k = 0; k < 4; k++) src.next(); }
+    dump("g11_chain_nfm_wav", "u8", file_bytes(tmp2));
+    { WavSource src(tmp, 4096); AutoCast<cs16> cast; IQBaseBand<int16_t> bb(0, 1500, 3e3, 16, 1, 12e3);
+      USBDemod<int16_t> usb; WavSink<int16_t> sink(tmp2);
+      src.connect(&cast, true); cast.connect(&bb, true); bb.connect(&usb, true); usb.connect(&sink, true);
+      for (int k = 0; k < 4; k++) src.next(); }
+    dump("g11_chain_usb_wav", "u8", file_bytes(tmp2)); }
+  remove(tmp.c_str()); remove(tmp2.c_str());
+}
+
 // ---------------------------------------------------------------------------------------------
 // timing of the reference CPU path (bench.py cpu_baseline kind "reference")
 // ---------------------------------------------------------------------------------------------
@@ -539,6 +588,7 @@ int main(int argc, char **argv) {
     golden();
     golden_next();
     golden_real();
+    golden_wav();
     g_manifest << "\n}\n";
     std::string mp = g_out + "/manifest.json";
     FILE *f = fopen(mp.c_str(), "w"); fputs(g_manifest.str().c_str(), f); fclose(f);
