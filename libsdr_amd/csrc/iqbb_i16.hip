@@ -305,33 +305,34 @@ __global__ __launch_bounds__(TPB) void iqbb_i16_kernel(const IqbbArgs a) {
 //   u = 256*uh + ul' + 128 (uh = u>>8, ul' = (u&255)-128),   a = 256*ah + al (al in [-128,127])
 //   S = 65536*sum(ah*uh) + 256*sum(ah*ul' + al*uh) + sum(al*ul') + 128*sum(a)      (mod 2^32)
 // i.e. 4 MFMAs per 32-deep K step into 3 accumulators; int32 ring arithmetic makes the recombination
-// bit-exact. The tap fragments are wave-invariant and stay in registers (2 planes x S steps x 4 VGPR),
-// the sample planes are staged once per workgroup into LDS and read as conflict-free 16-byte rows.
+// bit-exact. The tap fragments are wave-invariant and live in LDS ([S][2][64] x 16 B, fetched once per
+// workgroup), the sample planes are staged once per tile into LDS and read as conflict-free 16-byte rows.
 // Result layout (32x32 C/D map): lane (n = l&31, h = l>>5), register r -> comp = r&1,
 // t = ((r&3)>>1) + 4*(r>>2) + 2h: a lane holds (re,im) pairs of 8 samples of its block, 4 per decimation
 // group; the other 4 sit in lane l^32.
 // =================================================================================================
 constexpr int MF_BLK = 16;    // samples per block (one column)
 
-template <int S, bool TLDS>
-__global__ __launch_bounds__(TPB, TLDS ? 4 : 2) void iqbb_i16_mfma_kernel(const IqbbArgs a) {
+// full-rate 24-bit integer multiplies as instructions: the compiler keeps explicit sign-extension code around
+// v_mad_i32_i24 operands it cannot prove to be 24-bit, which these operands (LUT entries, FIR results) are
+__device__ __forceinline__ int mul24a(int x, int y) { int d; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; }
+__device__ __forceinline__ int mad24a(int x, int y, int z) { int d; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z)); return d; }
+
+template <int S, bool ROT>
+__global__ __launch_bounds__(TPB, 4) void iqbb_i16_mfma_kernel(const IqbbArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int PLW = (2 * (TI + a.OP) + 64 + 31) / 32 * 8;    // dwords per byte plane
-  // two plane pairs (double buffer): tile i+1 is written while slower waves still read tile i
-  int2 *lut_s = reinterpret_cast<int2 *>(smem + 4 * PLW);
-  v4i *taps_s = reinterpret_cast<v4i *>(smem + 4 * PLW + 256);   // TLDS: [S][2][64] fragments
+  // LDS: rotation table at offset 0 (a table read then needs no base add) | two plane pairs (double buffer:
+  // tile i+1 is written while slower waves still read tile i) | tap fragments [S][2][64]
+  int2 *lut_s = reinterpret_cast<int2 *>(smem);
+  uint32_t *planes = smem + 256;
+  v4i *taps_s = reinterpret_cast<v4i *>(smem + 256 + 4 * PLW);
 
   const int c = blockIdx.y, tid = threadIdx.x;
   const int w = tid >> 6, l = tid & 63, n = l & 31, h = l >> 5;
-  // tap fragments: wave-invariant, fetched once per workgroup and kept across the tiles it walks — in
-  // registers (72 VGPRs at S=9, 2 waves/SIMD) or in LDS (TLDS: 4 waves/SIMD, twice the LDS reads)
-  v4i Ah[S], Al[S];
-  if (TLDS) {
-    for (int i = tid; i < S * 2 * 64; i += TPB) taps_s[i] = a.tapfrag[i];
-  } else {
-#pragma unroll
-    for (int s = 0; s < S; s++) { Ah[s] = a.tapfrag[(2 * s) * 64 + l]; Al[s] = a.tapfrag[(2 * s + 1) * 64 + l]; }
-  }
+  // tap fragments are wave-invariant: fetched once per workgroup into LDS and read per K step (keeping them in
+  // 72 VGPRs halves the occupancy and measured slower)
+  for (int i = tid; i < S * 2 * 64; i += TPB) taps_s[i] = a.tapfrag[i];
   if (tid < 128) lut_s[tid] = a.lut[tid];
 
   // Software pipeline over the tiles this workgroup walks: the global loads of tile i+1 are issued into
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(TPB, TLDS ? 4 : 2) void iqbb_i16_mfma_kernel(const 
     const int q0 = tile * a.OG - a.ovl;
     const int tb = a.base0_rel + q0 * 8;
     const int groups_here = min(a.CG, a.n_groups - q0);
-    uint32_t *lo = smem + (it & 1) * 2 * PLW, *hi = lo + PLW;
+    uint32_t *lo = planes + (it & 1) * 2 * PLW, *hi = lo + PLW;
 
     // ---- stage: four samples -> 8 bytes of the low plane (offset to signed) and 8 of the high plane ----
     {
@@ -393,7 +394,23 @@ __global__ __launch_bounds__(TPB, TLDS ? 4 : 2) void iqbb_i16_mfma_kernel(const 
       }
     }
     __syncthreads();   // the only barrier per tile: planes[it&1] complete; planes[(it+1)&1] were last read before it
-    if (tile + 1 < tile_end) fetch(tile + 1);   // in flight during the matrix and epilogue work below
+    // The next tile's samples are only pulled towards L2 here — one dword per 64-byte line into a scratch
+    // register — and loaded into registers after the K loop, so that 12 VGPRs of prefetch are not live across it.
+    // The compiler does not know the asm is a load: `touch` stays tied to it until the explicit wait below.
+    uint32_t touch = 0;
+    if (tile + 1 < tile_end) {
+      const int q0_ = (tile + 1) * a.OG - a.ovl;
+      const long first = (long)a.base0_rel + (long)q0_ * 8 - (a.OP - 1) + 16L * tid;   // one 64-byte line per lane
+      if (!a.in_cu8 && first >= 0 && first < (long)a.N && 16 * tid < TI + a.OP + 16) {
+        const uint32_t *pa = a.in + (long)c * a.in_stride + first;
+        asm volatile("global_load_dword %0, %1, off" : "+v"(touch) : "v"(pa) : "memory");
+      }
+    }
+    const bool wave_has_work = (w * OGw + a.ovl < groups_here);
+    if (!wave_has_work) {   // (a wave without groups in a ragged last tile)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(touch) : : "memory");
+      if (tile + 1 < tile_end) fetch(tile + 1);
+    }
 
     const int gw = w * OGw;   // this wave's first group within the tile
     if (gw + a.ovl < groups_here) {   // wave-uniform: the wave has at least one group of its own
@@ -408,11 +425,11 @@ __global__ __launch_bounds__(TPB, TLDS ? 4 : 2) void iqbb_i16_mfma_kernel(const 
       for (int s = 0; s < S; s++) {
         const v4i ul = *reinterpret_cast<const v4i *>(pl + 16 * s);
         const v4i uh = *reinterpret_cast<const v4i *>(ph + 16 * s);
-        if (TLDS) { Ah[s] = taps_s[(2 * s) * 64 + l]; Al[s] = taps_s[(2 * s + 1) * 64 + l]; }
-        acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[s], uh, acc_hh, 0, 0, 0);
-        acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[s], ul, acc_mid, 0, 0, 0);
-        acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[s], uh, acc_mid, 0, 0, 0);
-        acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[s], ul, acc_ll, 0, 0, 0);
+        const v4i Ah = taps_s[(2 * s) * 64 + l], Al = taps_s[(2 * s + 1) * 64 + l];
+        acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, uh, acc_hh, 0, 0, 0);
+        acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, ul, acc_mid, 0, 0, 0);
+        acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, uh, acc_mid, 0, 0, 0);
+        acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, ul, acc_ll, 0, 0, 0);
       }
       // ---- recombine, >>14, rotate, mask, partial box sums (4 samples per group in this lane) --------
       const int rel0 = tb + 8 * gw + MF_BLK * n + 2 * h;
@@ -421,24 +438,30 @@ __global__ __launch_bounds__(TPB, TLDS ? 4 : 2) void iqbb_i16_mfma_kernel(const 
 #pragma unroll
       for (int k = 0; k < 8; k++) {
         const int rr = 4 * (k >> 1) + 2 * (k & 1);
-        const unsigned sre = ((((unsigned)acc_hh[rr] << 8) + (unsigned)acc_mid[rr]) << 8) + (unsigned)acc_ll[rr];
-        const unsigned sim = ((((unsigned)acc_hh[rr + 1] << 8) + (unsigned)acc_mid[rr + 1]) << 8) + (unsigned)acc_ll[rr + 1];
+        // two v_lshl_add_u32 per component; the empty asm keeps the compiler from re-associating into 2 shifts + add3
+        unsigned tre = ((unsigned)acc_hh[rr] << 8) + (unsigned)acc_mid[rr];
+        unsigned tim = ((unsigned)acc_hh[rr + 1] << 8) + (unsigned)acc_mid[rr + 1];
+        asm("" : "+v"(tre)); asm("" : "+v"(tim));
+        const unsigned sre = (tre << 8) + (unsigned)acc_ll[rr], sim = (tim << 8) + (unsigned)acc_ll[rr + 1];
         rv[k] = make_int2((int)sre >> 14, (int)sim >> 14);
       }
-      if (a.inc != 0) {   // scalar branch, hoisted out of the per-sample work: 8 independent LUT reads in flight
+      // the accumulators are dead now: the loads ride through the rest of the epilogue (the touch landed long ago)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(touch) : : "memory");
+      if (tile + 1 < tile_end) fetch(tile + 1);
+      if (ROT) {   // 8 independent table reads in flight
         const uint32_t cnt0 = (a.n0_lo + (uint32_t)rel0) * a.inc;   // phase counter of the lane's first sample (mod 2^15 below)
-        const uint32_t negx = a.negative ? 127u : 0u;
+        const uint32_t negx = a.negative ? (127u << 3) : 0u;
         int2 L[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-          const uint32_t idx = (((cnt0 + (uint32_t)(4 * (k >> 1) + (k & 1)) * a.inc) & 32767u) >> 8) ^ negx;   // 127-idx == idx^127
-          L[k] = lut_s[idx];
+          const uint32_t off = (((cnt0 + (uint32_t)(4 * (k >> 1) + (k & 1)) * a.inc) >> 5) & (127u << 3)) ^ negx;
+          L[k] = *reinterpret_cast<const int2 *>(reinterpret_cast<const char *>(lut_s) + off);
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
           const int2 r = rv[k];
-          rv[k].x = (int)((unsigned)__mul24(L[k].x, r.x) - (unsigned)__mul24(L[k].y, r.y)) >> 16;
-          rv[k].y = (int)((unsigned)__mul24(L[k].x, r.y) + (unsigned)__mul24(L[k].y, r.x)) >> 16;
+          rv[k].x = mad24a(L[k].x, r.x, -mul24a(L[k].y, r.y)) >> 16;
+          rv[k].y = mad24a(L[k].x, r.y, mul24a(L[k].y, r.x)) >> 16;
         }
       }
       int2 part[2];
@@ -507,6 +530,7 @@ __global__ __launch_bounds__(TPB, TLDS ? 4 : 2) void iqbb_i16_mfma_kernel(const 
     }
   }
 }
+
 
 // =================================================================================================
 // MFMA formulation, 16x16x64 tiles with an in-wave software pipeline (path 2; D == 8, order <= 153).
@@ -809,7 +833,8 @@ struct sdrhip_iqbb_i16 {
       }
 #undef SDRHIP_MF16
     } else if (path == 1) {
-#define SDRHIP_MF(S_) hipLaunchKernelGGL((iqbb_i16_mfma_kernel<S_, true>), grid, block, lds_bytes, ctx->stream, a)
+#define SDRHIP_MF(S_) do { if (inc != 0) hipLaunchKernelGGL((iqbb_i16_mfma_kernel<S_, true>), grid, block, lds_bytes, ctx->stream, a); \
+                            else hipLaunchKernelGGL((iqbb_i16_mfma_kernel<S_, false>), grid, block, lds_bytes, ctx->stream, a); } while (0)
       switch (S) {
         case 2: SDRHIP_MF(2); break;
         case 3: SDRHIP_MF(3); break;
