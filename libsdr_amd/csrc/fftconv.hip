@@ -21,6 +21,10 @@
 
 using namespace sdrhip;
 
+// float tolerance path (<= 1e-5 relative): fused multiply-adds are welcome here (the library is built with
+// -ffp-contract=off for the bit-exact fp64 FIR)
+#pragma clang fp contract(fast)
+
 namespace {
 
 constexpr int FT = 1024;       // lanes per workgroup
@@ -39,27 +43,91 @@ __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(
 __device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }   // a * (-i)
 __device__ __forceinline__ float2 mul_pi(float2 a) { return make_float2(-a.y, a.x); }   // a * (+i)
 
+// LDS index of element i: 4 pad elements after every 64, so that the stride-4 radix-16 pass (lanes 64 elements
+// = 512 B apart) spreads over the banks instead of hitting one
+__device__ __forceinline__ int PAD(int i) { return i + ((i >> 6) << 2); }
+
+// in-place 16-point DFT, v[m] <- sum_k v[k] exp(SIGN 2 pi i k m / 16), as 4 x 4 (k = a + 4b, m = c + 4d)
+template <int SIGN>
+__device__ __forceinline__ void dft16(float2 *v) {
+  constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, H = 0.70710678118654752f;
+  // step 1: for each a, the 4-point DFT over b of (v[a], v[a+4], v[a+8], v[a+12]) -> Y_a[c] kept at v[a + 4c]
+#pragma unroll
+  for (int a = 0; a < 4; a++) {
+    const float2 x0 = v[a], x1 = v[a + 4], x2 = v[a + 8], x3 = v[a + 12];
+    const float2 t0 = cadd(x0, x2), t1 = csub(x0, x2), t2 = cadd(x1, x3);
+    const float2 t3 = SIGN < 0 ? mul_mi(csub(x1, x3)) : mul_pi(csub(x1, x3));
+    v[a] = cadd(t0, t2); v[a + 4] = cadd(t1, t3); v[a + 8] = csub(t0, t2); v[a + 12] = csub(t1, t3);
+  }
+  // step 2: Z_a[c] = W16^(a c) Y_a[c]   (W16 = exp(SIGN 2 pi i / 16)); a c in {1,2,3,2,4,6,3,6,9}
+  auto tw = [](float2 z, float wr, float wi) { return make_float2(z.x * wr - z.y * (SIGN * wi), z.x * (SIGN * wi) + z.y * wr); };
+  v[1 + 4] = tw(v[1 + 4], C1, S1);           // a=1,c=1: W^1 = (cos pi/8, SIGN sin pi/8)
+  v[1 + 8] = tw(v[1 + 8], H, H);             // a=1,c=2: W^2
+  v[1 + 12] = tw(v[1 + 12], S1, C1);         // a=1,c=3: W^3
+  v[2 + 4] = tw(v[2 + 4], H, H);             // a=2,c=1: W^2
+  v[2 + 8] = SIGN < 0 ? mul_mi(v[2 + 8]) : mul_pi(v[2 + 8]);   // a=2,c=2: W^4 = SIGN i
+  v[2 + 12] = tw(v[2 + 12], -H, H);          // a=2,c=3: W^6
+  v[3 + 4] = tw(v[3 + 4], S1, C1);           // a=3,c=1: W^3
+  v[3 + 8] = tw(v[3 + 8], -H, H);            // a=3,c=2: W^6
+  v[3 + 12] = tw(v[3 + 12], -C1, -S1);       // a=3,c=3: W^9 = -W^1
+  // step 3: for each c, the 4-point DFT over a of Z_a[c] (at v[a + 4c]) -> X[c + 4d]
+  float2 o[16];
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const float2 x0 = v[4 * c], x1 = v[4 * c + 1], x2 = v[4 * c + 2], x3 = v[4 * c + 3];
+    const float2 t0 = cadd(x0, x2), t1 = csub(x0, x2), t2 = cadd(x1, x3);
+    const float2 t3 = SIGN < 0 ? mul_mi(csub(x1, x3)) : mul_pi(csub(x1, x3));
+    o[c] = cadd(t0, t2); o[c + 4] = cadd(t1, t3); o[c + 8] = csub(t0, t2); o[c + 12] = csub(t1, t3);
+  }
+#pragma unroll
+  for (int m = 0; m < 16; m++) v[m] = o[m];
+}
+
+// twiddles W^(j k), k = 1..15, from four exact table entries (k = 1, 2, 4, 8) and at most three products each
+__device__ __forceinline__ void twiddles16(const float2 *W, int L, int jt, float2 *w) {
+  const int m = L - 1;
+  w[1] = W[jt & m]; w[2] = W[(2 * jt) & m]; w[4] = W[(4 * jt) & m]; w[8] = W[(8 * jt) & m];
+  w[3] = cmul(w[1], w[2]); w[5] = cmul(w[1], w[4]); w[6] = cmul(w[2], w[4]); w[7] = cmul(w[3], w[4]);
+  w[9] = cmul(w[1], w[8]); w[10] = cmul(w[2], w[8]); w[11] = cmul(w[3], w[8]); w[12] = cmul(w[4], w[8]);
+  w[13] = cmul(w[5], w[8]); w[14] = cmul(w[6], w[8]); w[15] = cmul(w[7], w[8]);
+}
+
 // forward, decimation in frequency: natural order in, digit-reversed order out
 __device__ void fft_forward_dif(float2 *x, const FftDev &p, int tid) {
   int n = p.L;
   for (int pass = 0; pass < p.npass; pass++) {
     const int r = p.radix[pass], s = n / r, tw = p.L / n;
-    if (r == 4) {
+    if (r == 16) {
+      for (int b = tid; b < p.L / 16; b += FT) {
+        const int j = b & (s - 1), base = (b / s) * n + j;
+        float2 v[16], w[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = x[PAD(base + k * s)];
+        dft16<-1>(v);
+        if (s > 1) {
+          twiddles16(p.W, p.L, j * tw, w);
+#pragma unroll
+          for (int k = 1; k < 16; k++) v[k] = cmul(v[k], w[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[PAD(base + k * s)] = v[k];
+      }
+    } else if (r == 4) {
       for (int b = tid; b < p.L / 4; b += FT) {
         const int j = b & (s - 1), base = (b / s) * n + j;
-        const float2 a0 = x[base], a1 = x[base + s], a2 = x[base + 2 * s], a3 = x[base + 3 * s];
+        const float2 a0 = x[PAD(base)], a1 = x[PAD(base + s)], a2 = x[PAD(base + 2 * s)], a3 = x[PAD(base + 3 * s)];
         const float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_mi(csub(a1, a3));
-        x[base] = cadd(t0, t2);
-        x[base + s] = cmul(cadd(t1, t3), p.W[j * tw]);
-        x[base + 2 * s] = cmul(csub(t0, t2), p.W[2 * j * tw]);
-        x[base + 3 * s] = cmul(csub(t1, t3), p.W[3 * j * tw]);
+        x[PAD(base)] = cadd(t0, t2);
+        x[PAD(base + s)] = cmul(cadd(t1, t3), p.W[j * tw]);
+        x[PAD(base + 2 * s)] = cmul(csub(t0, t2), p.W[2 * j * tw]);
+        x[PAD(base + 3 * s)] = cmul(csub(t1, t3), p.W[3 * j * tw]);
       }
     } else {   // radix 2
       for (int b = tid; b < p.L / 2; b += FT) {
         const int j = b & (s - 1), base = (b / s) * n + j;
-        const float2 a0 = x[base], a1 = x[base + s];
-        x[base] = cadd(a0, a1);
-        x[base + s] = cmul(csub(a0, a1), p.W[j * tw]);
+        const float2 a0 = x[PAD(base)], a1 = x[PAD(base + s)];
+        x[PAD(base)] = cadd(a0, a1);
+        x[PAD(base + s)] = cmul(csub(a0, a1), p.W[j * tw]);
       }
     }
     __syncthreads();
@@ -74,25 +142,40 @@ __device__ void fft_inverse_dit(float2 *x, const FftDev &p, int tid) {
     const int r = p.radix[pass], s = n;
     n *= r;
     const int tw = p.L / n;
-    if (r == 4) {
+    if (r == 16) {
+      for (int b = tid; b < p.L / 16; b += FT) {
+        const int j = b & (s - 1), base = (b / s) * n + j;
+        float2 v[16], w[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = x[PAD(base + k * s)];
+        if (s > 1) {
+          twiddles16(p.W, p.L, j * tw, w);
+#pragma unroll
+          for (int k = 1; k < 16; k++) v[k] = cmulc(v[k], w[k]);
+        }
+        dft16<1>(v);
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[PAD(base + k * s)] = v[k];
+      }
+    } else if (r == 4) {
       for (int b = tid; b < p.L / 4; b += FT) {
         const int j = b & (s - 1), base = (b / s) * n + j;
-        const float2 a0 = x[base];
-        const float2 a1 = cmulc(x[base + s], p.W[j * tw]);
-        const float2 a2 = cmulc(x[base + 2 * s], p.W[2 * j * tw]);
-        const float2 a3 = cmulc(x[base + 3 * s], p.W[3 * j * tw]);
+        const float2 a0 = x[PAD(base)];
+        const float2 a1 = cmulc(x[PAD(base + s)], p.W[j * tw]);
+        const float2 a2 = cmulc(x[PAD(base + 2 * s)], p.W[2 * j * tw]);
+        const float2 a3 = cmulc(x[PAD(base + 3 * s)], p.W[3 * j * tw]);
         const float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_pi(csub(a1, a3));
-        x[base] = cadd(t0, t2);
-        x[base + s] = cadd(t1, t3);
-        x[base + 2 * s] = csub(t0, t2);
-        x[base + 3 * s] = csub(t1, t3);
+        x[PAD(base)] = cadd(t0, t2);
+        x[PAD(base + s)] = cadd(t1, t3);
+        x[PAD(base + 2 * s)] = csub(t0, t2);
+        x[PAD(base + 3 * s)] = csub(t1, t3);
       }
     } else {
       for (int b = tid; b < p.L / 2; b += FT) {
         const int j = b & (s - 1), base = (b / s) * n + j;
-        const float2 a0 = x[base], a1 = cmulc(x[base + s], p.W[j * tw]);
-        x[base] = cadd(a0, a1);
-        x[base + s] = csub(a0, a1);
+        const float2 a0 = x[PAD(base)], a1 = cmulc(x[PAD(base + s)], p.W[j * tw]);
+        x[PAD(base)] = cadd(a0, a1);
+        x[PAD(base + s)] = csub(a0, a1);
       }
     }
     __syncthreads();
@@ -118,17 +201,17 @@ __global__ __launch_bounds__(FT) void fftconv_kernel(const ConvArgs a) {
     float2 v = make_float2(0.f, 0.f);
     if (rel >= 0) { if (rel < a.N) v = a.in[(long)c * a.in_stride + rel]; }
     else { const int h = a.HH + rel; if (h >= 0) v = a.hist[(long)c * a.HH + h]; }
-    xl[i] = v;
+    xl[PAD(i)] = v;
   }
   __syncthreads();
   fft_forward_dif(xl, a.fft, tid);
-  for (int i = tid; i < L; i += FT) xl[i] = cmul(xl[i], a.Kp[i]);
+  for (int i = tid; i < L; i += FT) xl[PAD(i)] = cmul(xl[PAD(i)], a.Kp[i]);
   __syncthreads();
   fft_inverse_dit(xl, a.fft, tid);
   const int o0 = blk * a.hop;
   for (int i = tid; i < a.hop; i += FT) {
     const int o = o0 + i;
-    if (o < a.N) a.out[(long)c * a.out_stride + o] = xl[a.HH + i];
+    if (o < a.N) a.out[(long)c * a.out_stride + o] = xl[PAD(a.HH + i)];
   }
 }
 
@@ -147,15 +230,15 @@ __global__ __launch_bounds__(FT) void fft_c2c_kernel(const FftDev p, const int *
   const float2 *src = in + (long)blockIdx.x * L;
   float2 *dst = out + (long)blockIdx.x * L;
   if (sign < 0) {
-    for (int i = tid; i < L; i += FT) xl[i] = src[i];
+    for (int i = tid; i < L; i += FT) xl[PAD(i)] = src[i];
     __syncthreads();
     fft_forward_dif(xl, p, tid);
-    for (int i = tid; i < L; i += FT) dst[perm[i]] = xl[i];   // position i holds frequency perm[i]
+    for (int i = tid; i < L; i += FT) dst[perm[i]] = xl[PAD(i)];   // position i holds frequency perm[i]
   } else {
-    for (int i = tid; i < L; i += FT) xl[i] = src[perm[i]];
+    for (int i = tid; i < L; i += FT) xl[PAD(i)] = src[perm[i]];
     __syncthreads();
     fft_inverse_dit(xl, p, tid);
-    for (int i = tid; i < L; i += FT) dst[i] = xl[i];
+    for (int i = tid; i < L; i += FT) dst[i] = xl[PAD(i)];
   }
 }
 
@@ -172,8 +255,11 @@ struct FftPlan {
     L = L_;
     int lg = 0; while ((1 << lg) < L) lg++;
     dev.L = L; dev.npass = 0;
-    for (int k = 0; k < lg / 2; k++) dev.radix[dev.npass++] = 4;
-    if (lg & 1) dev.radix[dev.npass++] = 2;
+    // radix-16 passes (one LDS round trip per 4 bits) first, then what is left of log2 L
+    int left = lg;
+    while (left >= 4) { dev.radix[dev.npass++] = 16; left -= 4; }
+    if (left >= 2) { dev.radix[dev.npass++] = 4; left -= 2; }
+    if (left) dev.radix[dev.npass++] = 2;
     std::vector<float2> w(L);
     for (int t = 0; t < L; t++) {
       const double ang = -2.0 * M_PI * (double)t / (double)L;
@@ -192,7 +278,7 @@ struct FftPlan {
     }
     perm_d.alloc(L); perm_d.upload(perm.data(), L, ctx->stream);
   }
-  size_t lds_bytes() const { return (size_t)L * sizeof(float2); }
+  size_t lds_bytes() const { return (size_t)(L + (L >> 6) * 4) * sizeof(float2); }
 };
 
 template <class K>
