@@ -215,6 +215,157 @@ __global__ __launch_bounds__(FT) void fftconv_kernel(const ConvArgs a) {
   }
 }
 
+// Fused form of the same convolution (plans whose first pass is radix 16 and that have at least two passes, i.e.
+// every L >= 32): the first forward pass takes its 16 inputs per butterfly straight from global memory (history /
+// call input / zeros) and the last inverse pass stores its outputs straight to global memory — lanes walk
+// consecutive j, so both are coalesced — and the last forward pass, the spectrum product and the first inverse pass
+// (same element groups: stride 1) are one LDS round trip. 6 LDS reads + 6 writes of the block instead of 11 + 11.
+__device__ __forceinline__ float2 conv_fetch(const ConvArgs &a, int c, int rel) {
+  if (rel >= 0) return rel < a.N ? a.in[(long)c * a.in_stride + rel] : make_float2(0.f, 0.f);
+  const int h = a.HH + rel;
+  return h >= 0 ? a.hist[(long)c * a.HH + h] : make_float2(0.f, 0.f);
+}
+
+__global__ __launch_bounds__(FT) void fftconv_fused_kernel(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float2 xl[];
+  const int c = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+  const FftDev &p = a.fft;
+  const int L = p.L, np = p.npass;
+  const int first = blk * a.hop - a.HH;   // call-relative index of element 0
+  // ---- forward pass 0 (radix 16, stride L/16): global -> registers -> LDS ----
+  {
+    const int s = L / 16;
+    for (int j = tid; j < s; j += FT) {
+      float2 v[16], w[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) v[k] = conv_fetch(a, c, first + j + k * s);
+      dft16<-1>(v);
+      twiddles16(p.W, L, j, w);
+#pragma unroll
+      for (int k = 1; k < 16; k++) v[k] = cmul(v[k], w[k]);
+#pragma unroll
+      for (int k = 0; k < 16; k++) xl[PAD(j + k * s)] = v[k];
+    }
+    __syncthreads();
+  }
+  // ---- forward passes 1 .. np-2 in LDS ----
+  int n = L / 16;
+  for (int pass = 1; pass + 1 < np; pass++) {
+    const int r = p.radix[pass], s = n / r, tw = L / n;
+    if (r == 16) {
+      for (int b = tid; b < L / 16; b += FT) {
+        const int j = b & (s - 1), base = (b / s) * n + j;
+        float2 v[16], w[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = xl[PAD(base + k * s)];
+        dft16<-1>(v);
+        twiddles16(p.W, L, j * tw, w);
+#pragma unroll
+        for (int k = 1; k < 16; k++) v[k] = cmul(v[k], w[k]);
+#pragma unroll
+        for (int k = 0; k < 16; k++) xl[PAD(base + k * s)] = v[k];
+      }
+    } else {   // radix 4 (a radix-2 pass can only be the last one)
+      for (int b = tid; b < L / 4; b += FT) {
+        const int j = b & (s - 1), base = (b / s) * n + j;
+        const float2 a0 = xl[PAD(base)], a1 = xl[PAD(base + s)], a2 = xl[PAD(base + 2 * s)], a3 = xl[PAD(base + 3 * s)];
+        const float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_mi(csub(a1, a3));
+        xl[PAD(base)] = cadd(t0, t2);
+        xl[PAD(base + s)] = cmul(cadd(t1, t3), p.W[j * tw]);
+        xl[PAD(base + 2 * s)] = cmul(csub(t0, t2), p.W[2 * j * tw]);
+        xl[PAD(base + 3 * s)] = cmul(csub(t1, t3), p.W[3 * j * tw]);
+      }
+    }
+    __syncthreads();
+    n = s;
+  }
+  // ---- last forward pass (stride 1, no twiddles) x spectrum x first inverse pass ----
+  {
+    const int r = p.radix[np - 1];
+    if (r == 16) {
+      for (int b = tid; b < L / 16; b += FT) {
+        float2 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = xl[PAD(16 * b + k)];
+        dft16<-1>(v);
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = cmul(v[k], a.Kp[16 * b + k]);
+        dft16<1>(v);
+#pragma unroll
+        for (int k = 0; k < 16; k++) xl[PAD(16 * b + k)] = v[k];
+      }
+    } else if (r == 4) {
+      for (int b = tid; b < L / 4; b += FT) {
+        const float2 a0 = xl[PAD(4 * b)], a1 = xl[PAD(4 * b + 1)], a2 = xl[PAD(4 * b + 2)], a3 = xl[PAD(4 * b + 3)];
+        float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_mi(csub(a1, a3));
+        const float2 y0 = cmul(cadd(t0, t2), a.Kp[4 * b]), y1 = cmul(cadd(t1, t3), a.Kp[4 * b + 1]);
+        const float2 y2 = cmul(csub(t0, t2), a.Kp[4 * b + 2]), y3 = cmul(csub(t1, t3), a.Kp[4 * b + 3]);
+        t0 = cadd(y0, y2); t1 = csub(y0, y2); t2 = cadd(y1, y3); t3 = mul_pi(csub(y1, y3));
+        xl[PAD(4 * b)] = cadd(t0, t2); xl[PAD(4 * b + 1)] = cadd(t1, t3);
+        xl[PAD(4 * b + 2)] = csub(t0, t2); xl[PAD(4 * b + 3)] = csub(t1, t3);
+      }
+    } else {
+      for (int b = tid; b < L / 2; b += FT) {
+        const float2 a0 = xl[PAD(2 * b)], a1 = xl[PAD(2 * b + 1)];
+        const float2 y0 = cmul(cadd(a0, a1), a.Kp[2 * b]), y1 = cmul(csub(a0, a1), a.Kp[2 * b + 1]);
+        xl[PAD(2 * b)] = cadd(y0, y1); xl[PAD(2 * b + 1)] = csub(y0, y1);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- inverse passes np-2 .. 1 in LDS ----
+  n = p.radix[np - 1];
+  for (int pass = np - 2; pass >= 1; pass--) {
+    const int r = p.radix[pass], s = n;
+    n *= r;
+    const int tw = L / n;
+    if (r == 16) {
+      for (int b = tid; b < L / 16; b += FT) {
+        const int j = b & (s - 1), base = (b / s) * n + j;
+        float2 v[16], w[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = xl[PAD(base + k * s)];
+        twiddles16(p.W, L, j * tw, w);
+#pragma unroll
+        for (int k = 1; k < 16; k++) v[k] = cmulc(v[k], w[k]);
+        dft16<1>(v);
+#pragma unroll
+        for (int k = 0; k < 16; k++) xl[PAD(base + k * s)] = v[k];
+      }
+    } else {
+      for (int b = tid; b < L / 4; b += FT) {
+        const int j = b & (s - 1), base = (b / s) * n + j;
+        const float2 a0 = xl[PAD(base)];
+        const float2 a1 = cmulc(xl[PAD(base + s)], p.W[j * tw]);
+        const float2 a2 = cmulc(xl[PAD(base + 2 * s)], p.W[2 * j * tw]);
+        const float2 a3 = cmulc(xl[PAD(base + 3 * s)], p.W[3 * j * tw]);
+        const float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_pi(csub(a1, a3));
+        xl[PAD(base)] = cadd(t0, t2); xl[PAD(base + s)] = cadd(t1, t3);
+        xl[PAD(base + 2 * s)] = csub(t0, t2); xl[PAD(base + 3 * s)] = csub(t1, t3);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- last inverse pass (radix 16, stride L/16): LDS -> registers -> global (only the hop kept samples) ----
+  {
+    const int s = L / 16, o0 = blk * a.hop;
+    for (int j = tid; j < s; j += FT) {
+      float2 v[16], w[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) v[k] = xl[PAD(j + k * s)];
+      twiddles16(p.W, L, j, w);
+#pragma unroll
+      for (int k = 1; k < 16; k++) v[k] = cmulc(v[k], w[k]);
+      dft16<1>(v);
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        const int i = j + k * s - a.HH, o = o0 + i;
+        if (i >= 0 && o < a.N) a.out[(long)c * a.out_stride + o] = v[k];
+      }
+    }
+  }
+}
+
 __global__ void hist_roll_kernel(const float2 *in, long in_stride, const float2 *hist_old, float2 *hist_new, int HH, int N) {
   const int c = blockIdx.y;
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < HH; k += gridDim.x * blockDim.x) {
@@ -306,8 +457,13 @@ struct sdrhip_fftconv {
     a.hist = hist[par].p; a.HH = HH; a.Kp = Kp.p;
     a.out = out_dev; a.out_stride = (long)out_stride; a.N = (int)N; a.hop = hop;
     const int blocks = (int)ceil_div(N, (size_t)hop);
-    allow_big_lds(fftconv_kernel, plan.lds_bytes());
-    hipLaunchKernelGGL(fftconv_kernel, dim3(blocks, C), dim3(FT), plan.lds_bytes(), ctx->stream, a);
+    if (plan.dev.npass >= 2 && plan.dev.radix[0] == 16) {
+      allow_big_lds(fftconv_fused_kernel, plan.lds_bytes());
+      hipLaunchKernelGGL(fftconv_fused_kernel, dim3(blocks, C), dim3(FT), plan.lds_bytes(), ctx->stream, a);
+    } else {
+      allow_big_lds(fftconv_kernel, plan.lds_bytes());
+      hipLaunchKernelGGL(fftconv_kernel, dim3(blocks, C), dim3(FT), plan.lds_bytes(), ctx->stream, a);
+    }
     SDRHIP_CHECK_HIP(hipGetLastError());
     if (HH > 0) {
       hipLaunchKernelGGL(hist_roll_kernel, dim3((unsigned)ceil_div((size_t)HH, (size_t)256), C), dim3(256), 0, ctx->stream,
