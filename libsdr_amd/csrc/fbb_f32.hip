@@ -4,33 +4,14 @@
 // and FreqShift<float> truncates samples to int16 (src/utils.hh:497-504, src/operators.hh:40-42;
 // SURVEY fact 6). The reference-pinned sub-steps are the cf32 FIR (src/firfilter.hh:231-247) and
 // SubSample<cf32> (src/subsample.hh:92-101), both provided by fir.hip (K3); the frequency shift is
-// defined here: the phasor is a closed form of the absolute sample index evaluated in float64
-// (no recurrence drift), the product is rounded to float once. PARITY UNPINNED for the shift.
+// defined by this build: the phasor is a closed form of the absolute sample index in float64
+// (oracle orc_freqshift_cf32); it is applied inside the FIR kernel's staging loop (fir.hip,
+// fir_cf32_rt_kernel: closed form per lane and tile, constant float64 rotation in between), so the
+// whole chain is ONE launch with 8 B read + 1 B written per input sample. PARITY UNPINNED for the shift.
 #include "sdrhip_internal.hpp"
+#include <cstdlib>
 
 using namespace sdrhip;
-
-namespace {
-
-constexpr int TPB = 256;
-
-__global__ __launch_bounds__(TPB) void freqshift_cf32_kernel(const float2 *in, long in_stride, float2 *out, long out_stride,
-                                                            int N, unsigned long long n0, double fc, double fs) {
-  const int c = blockIdx.y;
-  for (int i = blockIdx.x * TPB + threadIdx.x; i < N; i += gridDim.x * TPB) {
-    const float2 x = in[(long)c * in_stride + i];
-    // same expression as the float64 closed form it is checked against (oracle orc_freqshift_cf32)
-    const double turns = fmod(__ddiv_rn(__dmul_rn(fc, (double)(n0 + (unsigned long long)i)), fs), 1.0);
-    const double ph = __dmul_rn(-2.0 * M_PI, turns);
-    double s, co;
-    sincos(ph, &s, &co);
-    const double xr = x.x, xi = x.y;
-    out[(long)c * out_stride + i] = make_float2((float)__dsub_rn(__dmul_rn(xr, co), __dmul_rn(xi, s)),
-                                                (float)__dadd_rn(__dmul_rn(xr, s), __dmul_rn(xi, co)));
-  }
-}
-
-}  // namespace
 
 struct sdrhip_fbb_f32 {
   sdrhip_ctx *ctx = nullptr;
@@ -39,7 +20,6 @@ struct sdrhip_fbb_f32 {
   int C = 1;
   size_t max_in = 0;
   unsigned long long n0 = 0;
-  DevBuf<float2> shifted;
   DevBuf<float2> stage_in, stage_out;
   size_t max_out = 0;
 };
@@ -58,7 +38,7 @@ int sdrhip_fbb_f32_create(sdrhip_ctx *ctx, double Fc, double Fs, const double *a
       h->ctx = ctx; h->fc = Fc; h->fs = Fs; h->C = channels; h->max_in = max_in;
       int rc = sdrhip_fir_create(ctx, SDRHIP_FIR_CF32, alpha, order, decim, channels, max_in, SDRHIP_EPI_NONE, &h->fir);
       if (rc != SDRHIP_OK) throw Failure{rc};
-      h->shifted.alloc((size_t)channels * max_in);
+      if (!getenv("SDRHIP_FBB_NOSHIFT")) fir_set_shift(h->fir, Fc, Fs);   // the shift rides in the FIR's staging: one kernel, no intermediate buffer
       h->max_out = max_in / decim + 1;
     } catch (...) { if (h->fir) sdrhip_fir_destroy(h->fir); delete h; throw; }
     *out = h;
@@ -79,12 +59,7 @@ int sdrhip_fbb_f32_process_dev(sdrhip_fbb_f32 *h, const float *in_dev, size_t n_
     SDRHIP_REQUIRE(in_dev && out_dev, SDRHIP_E_INVALID, "NULL buffer");
     h->ctx->use();
     if (in_stride == 0) in_stride = n_in;
-    const unsigned bx = (unsigned)std::min<size_t>(ceil_div(n_in, (size_t)TPB), 4096);
-    hipLaunchKernelGGL(freqshift_cf32_kernel, dim3(bx, h->C), dim3(TPB), 0, h->ctx->stream,
-                       reinterpret_cast<const float2 *>(in_dev), (long)in_stride, h->shifted.p, (long)n_in, (int)n_in,
-                       h->n0, h->fc, h->fs);
-    SDRHIP_CHECK_HIP(hipGetLastError());
-    int rc = sdrhip_fir_process_dev(h->fir, h->shifted.p, n_in, n_in, out_dev, out_stride, n_out);
+    int rc = sdrhip_fir_process_dev(h->fir, in_dev, n_in, in_stride, out_dev, out_stride, n_out);
     if (rc != SDRHIP_OK) throw Failure{rc};
     h->n0 += n_in;
   });

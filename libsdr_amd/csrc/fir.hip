@@ -187,6 +187,12 @@ struct Fir32Args {
   int first_rel;   // call-relative index of the newest sample of the first output of this call
   int n_out;
   void *out; long out_stride; int epilogue;
+  // register-tiled kernel
+  const float *betap;      // beta with (R-1)*D zeros on either side
+  unsigned rd_magic;       // ceil(2^32 / (R*D)): i / (R*D) = umulhi(i, rd_magic) for the tile's i
+  // fused frequency shift (float baseband, fbb_f32.hip): x[n] * exp(-2 pi i fc n / fs), n = absolute sample index
+  int shift_on; double fc, fs; unsigned long long n0;
+  double step_re, step_im; // exp(-2 pi i fc TPB / fs)
 };
 
 __device__ __forceinline__ float2 load_x32(const Fir32Args &a, int c, int rel) {
@@ -227,6 +233,123 @@ __global__ __launch_bounds__(TPB) void fir_cf32_kernel(const Fir32Args a) {
   }
 }
 
+// Register-tiled form: a lane owns R consecutive outputs (R*D input samples apart from its neighbour's) and walks
+// its window once — every sample it reads from LDS feeds R accumulator pairs (the taps are lane-uniform: scalar
+// loads from the zero-padded copy of beta), 2R FMAs per 8-byte LDS read instead of 2. One pad element per R*D
+// samples makes the lane stride R*D+1 elements, i.e. an odd number of 8-byte bank pairs: conflict-free.
+// The float baseband's frequency shift (fbb_f32.hip) is applied while staging: each lane evaluates the phasor of
+// its first sample in float64 (the oracle's closed form) and advances it by a constant float64 rotation.
+// DC > 0: the decimation is the compile-time constant DC — the R tap streams of a chunk of U steps are then ONE
+// window of U + (R-1)*DC consecutive taps with compile-time indices (wide scalar loads, no per-step tap loads)
+template <int R, int DC>
+__global__ __launch_bounds__(TPB) void fir_cf32_rt_kernel(const Fir32Args a) {
+  extern __shared__ __attribute__((aligned(16))) float2 smemf[];
+  float2 *xs = smemf;
+  const int c = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+  const int D = DC > 0 ? DC : a.D;
+  const int RD = R * D;
+  const int j0 = tile * (TPB * R);
+  const int outs_here = min(TPB * R, a.n_out - j0);
+  const int w0 = a.first_rel + j0 * D - (a.M - 1);   // call-relative index of xs[0]
+  const int need = (outs_here - 1) * D + a.M;
+  // staging, 16 elements per lane in flight: an interior tile (no history, no end of call) issues 16 unconditional
+  // coalesced loads before the first wait; per-element bounds logic would make every load a branch with its own wait
+  const bool interior = (w0 >= 0) && (w0 + need <= a.N);
+  const float2 *src = a.in + (long)c * a.in_stride + w0;
+  double zr = 1.0, zi = 0.0;
+  if (a.shift_on) {
+    const double n = (double)((long long)a.n0 + (long long)(w0 + tid));   // (negative before the stream start: those samples are zero)
+    const double turns = fmod(__ddiv_rn(__dmul_rn(a.fc, n), a.fs), 1.0);
+    sincos(__dmul_rn(-2.0 * M_PI, turns), &zi, &zr);
+  }
+  for (int i0 = tid; i0 < need; i0 += 16 * TPB) {
+    float2 v[16];
+    if (interior) {
+#pragma unroll
+      for (int k = 0; k < 16; k++) { const int i = i0 + k * TPB; if (i < need) v[k] = src[i]; }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; k++) { const int i = i0 + k * TPB; if (i < need) v[k] = load_x32(a, c, w0 + i); }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int i = i0 + k * TPB;
+      if (i < need) {
+        float2 y = v[k];
+        if (a.shift_on) {
+          const float fr = (float)zr, fi = (float)zi;
+          y = make_float2(v[k].x * fr - v[k].y * fi, v[k].x * fi + v[k].y * fr);
+          const double t = zr * a.step_re - zi * a.step_im;
+          zi = zr * a.step_im + zi * a.step_re; zr = t;
+        }
+        const int q = DC > 0 ? i / (R * (DC > 0 ? DC : 1)) : (int)__umulhi((unsigned)i, a.rd_magic);
+        xs[i + q] = y;
+      }
+    }
+  }
+  __syncthreads();
+  if (R * tid < outs_here) {
+    float sr[R], si[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) { sr[r] = 0.f; si[r] = 0.f; }
+    const float2 *px = xs + tid * (RD + 1);
+    const float *__restrict__ bp = a.betap + (R - 1) * D;   // bp[t] = beta[t], zero for t in [-(R-1)D, 0) and [M, M+(R-1)D)
+    const int steps = a.M + (R - 1) * D;
+    if (DC > 0) {
+      constexpr int U = 16, PADZ = (R - 1) * (DC > 0 ? DC : 1), WN = U + PADZ;   // (R*DC is a multiple of U for the instantiated DC)
+      const float2 *pu = px;
+      for (int u0 = 0; u0 < steps; u0 += U) {
+        float tw[WN];   // taps u0-PADZ .. u0+U-1: lane-uniform, one window for all R streams
+#pragma unroll
+        for (int k = 0; k < WN; k++) tw[k] = bp[u0 - PADZ + k];
+        float2 x[U];
+#pragma unroll
+        for (int uu = 0; uu < U; uu++) x[uu] = pu[uu];
+#pragma unroll
+        for (int uu = 0; uu < U; uu++) {
+#pragma unroll
+          for (int r = 0; r < R; r++) {
+            const float b = tw[uu - r * (DC > 0 ? DC : 1) + PADZ];
+            sr[r] = __builtin_fmaf(b, x[uu].x, sr[r]); si[r] = __builtin_fmaf(b, x[uu].y, si[r]);
+          }
+        }
+        pu += U;
+        if (((u0 + U) % (R * (DC > 0 ? DC : 1))) == 0) pu += 1;   // the pad element after every R*D samples
+      }
+    } else {
+    constexpr int U = 8;   // steps per chunk
+    int udiv = 0, umod = 0;
+    for (int u0 = 0; u0 < steps; u0 += U) {   // (betap carries 16 zeros behind the padded taps; a sample read past the
+      float tb[U][R];                          //  window meets only those)
+      float2 x[U];
+#pragma unroll
+      for (int uu = 0; uu < U; uu++) {
+#pragma unroll
+        for (int r = 0; r < R; r++) tb[uu][r] = bp[u0 + uu - r * D];   // lane-uniform
+        x[uu] = px[u0 + uu + udiv];
+        if (++umod == RD) { umod = 0; udiv++; }
+      }
+#pragma unroll
+      for (int uu = 0; uu < U; uu++) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          sr[r] = __builtin_fmaf(tb[uu][r], x[uu].x, sr[r]); si[r] = __builtin_fmaf(tb[uu][r], x[uu].y, si[r]);
+        }
+      }
+    }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const int j = j0 + R * tid + r;
+      if (j < a.n_out) {
+        if (a.epilogue == SDRHIP_EPI_NONE) reinterpret_cast<float2 *>(a.out)[(long)c * a.out_stride + j] = make_float2(sr[r], si[r]);
+        else if (a.epilogue == SDRHIP_EPI_AM) reinterpret_cast<float *>(a.out)[(long)c * a.out_stride + j] = sqrtf(sr[r] * sr[r] + si[r] * si[r]);
+        else reinterpret_cast<float *>(a.out)[(long)c * a.out_stride + j] = (sr[r] + si[r]) / 2;
+      }
+    }
+  }
+}
+
 // history roll for K3 (separate tiny kernel: a call may produce zero outputs, i.e. zero tiles)
 __global__ void hist_roll_cf32(const float2 *in, long in_stride, const float2 *hist_old, float2 *hist_new, int HH, int N) {
   const int c = blockIdx.y;
@@ -251,8 +374,11 @@ struct sdrhip_fir {
   DevBuf<uint32_t> hist16[2];
   DevBuf<short> fm[2];
   // K3
-  int M = 0;
-  DevBuf<float> beta;
+  int M = 0, R = 1;
+  DevBuf<float> beta, betap;
+  size_t lds3 = 0;
+  // fused frequency shift (set by the float baseband)
+  bool shift_on = false; double fc = 0, fs = 1;
   DevBuf<float2> hist32[2];
   // staging
   DevBuf<uint8_t> stage_in, stage_out;
@@ -294,11 +420,16 @@ struct sdrhip_fir {
       a.first_rel = (int)((int64_t)(g * D + D - 1) - (int64_t)n0);
       a.n_out = (int)no;
       a.out = out_dev; a.out_stride = (long)out_stride; a.epilogue = epi;
+      a.betap = betap.p; a.rd_magic = (unsigned)((0x100000000ull + (uint64_t)(R * D) - 1) / (uint64_t)(R * D));
+      a.shift_on = shift_on ? 1 : 0; a.fc = fc; a.fs = fs; a.n0 = n0;
+      { const double t = std::fmod(fc * (double)TPB / fs, 1.0), ph = -2.0 * M_PI * t; a.step_re = std::cos(ph); a.step_im = std::sin(ph); }
       if (no) {
-        const int tiles = (int)ceil_div(no, (size_t)T3);
-        const size_t lds = ((size_t)(T3 - 1) * D + M) * sizeof(float2);
+        const int tiles = (int)ceil_div(no, (size_t)TPB * R);
         dim3 grid(tiles, C), block(TPB);
-        hipLaunchKernelGGL(fir_cf32_kernel, grid, block, lds, ctx->stream, a);
+        if (R == 4 && D == 8) hipLaunchKernelGGL((fir_cf32_rt_kernel<4, 8>), grid, block, lds3, ctx->stream, a);
+        else if (R == 4) hipLaunchKernelGGL((fir_cf32_rt_kernel<4, 0>), grid, block, lds3, ctx->stream, a);
+        else if (R == 2) hipLaunchKernelGGL((fir_cf32_rt_kernel<2, 0>), grid, block, lds3, ctx->stream, a);
+        else hipLaunchKernelGGL((fir_cf32_rt_kernel<1, 0>), grid, block, lds3, ctx->stream, a);
         SDRHIP_CHECK_HIP(hipGetLastError());
       }
       if (M > 1) {
@@ -312,6 +443,10 @@ struct sdrhip_fir {
     if (n_out) *n_out = no;
   }
 };
+
+namespace sdrhip {
+void fir_set_shift(sdrhip_fir *h, double fc, double fs) { h->shift_on = true; h->fc = fc; h->fs = fs; }
+}  // namespace sdrhip
 
 extern "C" {
 
@@ -361,8 +496,17 @@ int sdrhip_fir_create(sdrhip_ctx *ctx, int kind, const double *alpha, int order,
       } else {
         // beta[m] = (1/D) * sum_k alpha[m-k], k in [0,D): FIR followed by the D-sample box average
         h->M = order + decim - 1;
-        SDRHIP_REQUIRE(((size_t)(T3 - 1) * decim + h->M) * 8 <= 64 * 1024, SDRHIP_E_UNSUPPORTED,
-                       "order %d with decim %d exceeds the LDS tile", order, decim);
+        // outputs per lane: as many as keep the tile (TPB*R outputs, (TPB*R-1)*D + M samples + pads) within 144 KB
+        auto tile_bytes = [&](int R_) { const size_t need = ((size_t)TPB * R_ - 1) * decim + h->M; return (need + need / ((size_t)R_ * decim) + 2 + 16) * 8; };
+        h->R = 4;
+        while (h->R > 1 && tile_bytes(h->R) > 72 * 1024) h->R >>= 1;
+        SDRHIP_REQUIRE(tile_bytes(h->R) <= 144 * 1024, SDRHIP_E_UNSUPPORTED, "order %d with decim %d exceeds the LDS tile", order, decim);
+        h->lds3 = tile_bytes(h->R);
+        if (h->lds3 > 64 * 1024) {
+          const void *fns[4] = {(const void *)fir_cf32_rt_kernel<4, 8>, (const void *)fir_cf32_rt_kernel<4, 0>,
+                                (const void *)fir_cf32_rt_kernel<2, 0>, (const void *)fir_cf32_rt_kernel<1, 0>};
+          for (int k = 0; k < 4; k++) SDRHIP_CHECK_HIP(hipFuncSetAttribute(fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds3));
+        }
         std::vector<float> b(h->M);
         for (int m = 0; m < h->M; m++) {
           double s = 0;
@@ -370,6 +514,10 @@ int sdrhip_fir_create(sdrhip_ctx *ctx, int kind, const double *alpha, int order,
           b[m] = (float)(s / decim);
         }
         h->beta.alloc(h->M); h->beta.upload(b.data(), h->M, ctx->stream);
+        { const int padz = (h->R - 1) * decim;
+          std::vector<float> bpad((size_t)h->M + 2 * padz + 16, 0.f);
+          for (int m = 0; m < h->M; m++) bpad[padz + m] = b[m];
+          h->betap.alloc(bpad.size()); h->betap.upload(bpad.data(), bpad.size(), ctx->stream); }
         for (int p = 0; p < 2; p++) {
           h->hist32[p].alloc((size_t)channels * std::max(1, h->M - 1)); h->hist32[p].zero(ctx->stream);
         }

@@ -113,4 +113,7 @@ void copy_d2h_rows(const sdrhip_ctx *ctx, void *dst_host, size_t dst_pitch_b, co
 
 static inline size_t ceil_div(size_t a, size_t b) { return (a + b - 1) / b; }
 
+// fir.hip: turn on the frequency shift fused into the cf32 FIR's staging (used by the float baseband, fbb_f32.hip)
+void fir_set_shift(sdrhip_fir *h, double fc, double fs);
+
 }  // namespace sdrhip
