@@ -9,7 +9,6 @@
 // fir_cf32_rt_kernel: closed form per lane and tile, constant float64 rotation in between), so the
 // whole chain is ONE launch with 8 B read + 1 B written per input sample. PARITY UNPINNED for the shift.
 #include "sdrhip_internal.hpp"
-#include <cstdlib>
 
 using namespace sdrhip;
 
@@ -38,7 +37,7 @@ int sdrhip_fbb_f32_create(sdrhip_ctx *ctx, double Fc, double Fs, const double *a
       h->ctx = ctx; h->fc = Fc; h->fs = Fs; h->C = channels; h->max_in = max_in;
       int rc = sdrhip_fir_create(ctx, SDRHIP_FIR_CF32, alpha, order, decim, channels, max_in, SDRHIP_EPI_NONE, &h->fir);
       if (rc != SDRHIP_OK) throw Failure{rc};
-      if (!getenv("SDRHIP_FBB_NOSHIFT")) fir_set_shift(h->fir, Fc, Fs);   // the shift rides in the FIR's staging: one kernel, no intermediate buffer
+      fir_set_shift(h->fir, Fc, Fs);   // the shift rides in the FIR's staging: one kernel, no intermediate buffer
       h->max_out = max_in / decim + 1;
     } catch (...) { if (h->fir) sdrhip_fir_destroy(h->fir); delete h; throw; }
     *out = h;
