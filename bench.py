@@ -8,7 +8,7 @@ north-star chain of BASELINE.json on the per-GPU shard of its config 5 (8192 cha
 Channels are independent, so ranks shard them with no data-path collective (weak scaling);
 taps/LUT are designed on rank 0 and broadcast over RCCL at config time.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload iqbb_fm|iqbb_usb|fir255_fm|fbb_f32|fftconv]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload iqbb_fm|iqbb_usb|iqbb_fm_cu8|fir255_fm|fbb_f32|fftconv]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
@@ -148,20 +148,26 @@ def main():
         # ---- config(): design on rank 0, broadcast over RCCL (KBs; outside the timed region) ----
         order, D = 127, 8
         wl = a.workload
-        if wl in ("iqbb_fm", "iqbb_usb"):
+        if wl in ("iqbb_fm", "iqbb_usb", "iqbb_fm_cu8"):
             taps = torch.from_numpy(sa.design_iqbb_taps(100e3, 50e3, FS, order)).to(dev)
             lut = torch.from_numpy(sa.design_freqshift_lut_i16()).to(dev)
             shard.broadcast_design([taps, lut], src=0)
             node = sa.IQBaseBandI16(ctx, taps.cpu().numpy(), lut.cpu().numpy(), sa.design_freqshift_inc(100e3, FS), False, D,
-                                    channels=C, max_in=N, epilogue=sa.EPI_FM if wl == "iqbb_fm" else sa.EPI_USB)
+                                    channels=C, max_in=N, epilogue=sa.EPI_USB if wl == "iqbb_usb" else sa.EPI_FM)
             in_bytes, alg_bytes = 4.0, 4.0 + 2.0 / D
             n_out = node.out_count(N) + 1
             outs = torch.zeros((C, n_out), dtype=torch.int16, device=dev)
             ins = [synth_cs16(torch, C, N, dev, 1234 + b, chan0=rank * C) for b in range(a.batches)]
+            if wl == "iqbb_fm_cu8":   # RTL-SDR bytes: the same signal as offset-binary complex<uint8>, AutoCast fused into the load
+                node.set_input_format(sa.abi.IN_CU8)
+                ins = [((x.to(torch.int32) >> 6) + 127).clamp_(0, 255).to(torch.uint8) for x in ins]
+                in_bytes, alg_bytes = 2.0, 2.0 + 2.0 / D
             run = lambda b: node.process_dev(ins[b].data_ptr(), N, N, outs.data_ptr(), n_out)
             dtype = "i16"
             kernel = "iqbb_i16_mfma_kernel" if node.path == 1 else "iqbb_i16_kernel"
-            desc = "IQBaseBand<int16>(127-tap Q14 FIR, LUT shift 100 kHz, /8) -> %s" % ("FMDemod" if wl == "iqbb_fm" else "USBDemod")
+            desc = "IQBaseBand<int16>(127-tap Q14 FIR, LUT shift 100 kHz, /8) -> %s" % ("USBDemod" if wl == "iqbb_usb" else "FMDemod")
+            if wl == "iqbb_fm_cu8":
+                desc = "complex<uint8> -> AutoCast + " + desc
         elif wl in ("fir255_fm", "fir127_fm"):
             order = 255 if wl == "fir255_fm" else 127
             alpha = torch.from_numpy(sa.design_fir_lowpass(order, 100e3, FS)).to(dev)
@@ -181,7 +187,7 @@ def main():
             outs = torch.zeros((C, n_out, 2), dtype=torch.float32, device=dev)
             ins = [torch.randn((C, N, 2), dtype=torch.float32, device=dev) * 0.3 for b in range(a.batches)]
             run = lambda b: node.process_dev(ins[b].data_ptr(), N, N, outs.data_ptr(), n_out)
-            dtype, kernel = "f32", "fir_cf32_kernel"
+            dtype, kernel = "f32", "fir_cf32_rt_kernel"
             desc = "float baseband: shift 100 kHz -> FIRLowPass<cf32>(127) -> /8"
         elif wl == "fftconv":
             alpha = sa.design_fir_lowpass(4097, 100e3, FS)
@@ -192,7 +198,7 @@ def main():
             outs = torch.zeros((C, N, 2), dtype=torch.float32, device=dev)
             ins = [torch.randn((C, N, 2), dtype=torch.float32, device=dev) * 0.3 for b in range(a.batches)]
             run = lambda b: node.process_dev(ins[b].data_ptr(), N, N, outs.data_ptr(), N)
-            dtype, kernel = "f32", "fftconv_kernel"
+            dtype, kernel = "f32", "fftconv_fused_kernel"
             desc = "FFT convolution, overlap-save L=16384, 4097 taps (hop 12288)"
         else:
             raise SystemExit("unknown workload " + wl)
@@ -233,7 +239,7 @@ def main():
             "ms_per_step": round(wall / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": desc, "channels_per_gpu": C, "samples_per_channel_per_step": N,
-                       "global_channels": C * world, "input": "complex<int16>" if in_bytes == 4 else "complex<float>",
+                       "global_channels": C * world, "input": {2.0: "complex<uint8>", 4.0: "complex<int16>"}.get(in_bytes, "complex<float>"),
                        "parallelism": "channel-sharded x%d, %s" % (world, "output gathered on rank 0 per step (RCCL)" if a.gather else "no data-path collective")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": kernel,

@@ -318,15 +318,25 @@ constexpr int MF_BLK = 16;    // samples per block (one column)
 __device__ __forceinline__ int mul24a(int x, int y) { int d; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; }
 __device__ __forceinline__ int mad24a(int x, int y, int z) { int d; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z)); return d; }
 
-template <int S, bool ROT>
-__global__ __launch_bounds__(TPB, 4) void iqbb_i16_mfma_kernel(const IqbbArgs a) {
+// per byte (b + 129) mod 256: the high byte AutoCast< complex<int16_t> > gives a complex<uint8_t> component
+__device__ __forceinline__ uint32_t add129_bytes(uint32_t x) {
+  const uint32_t y = x ^ 0x80808080u;   // + 128
+  return ((y & 0x7f7f7f7fu) + 0x01010101u) ^ (y & 0x80808080u);   // + 1 without carries between bytes
+}
+
+// CU8: the input is complex<uint8_t> (SDRHIP_IN_CU8). After AutoCast every sample is 256 * uh exactly, so the low
+// byte plane and both of its products vanish: S = 65536 * sum(ah*uh) + 256 * sum(al*uh) — two MFMAs per K step into
+// two accumulators, one plane to stage, read and keep in LDS, 2 bytes per sample from HBM; 5 waves per SIMD fit.
+template <int S, bool ROT, bool CU8>
+__global__ __launch_bounds__(TPB, CU8 ? 5 : 4) void iqbb_i16_mfma_kernel(const IqbbArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int PLW = (2 * (TI + a.OP) + 64 + 31) / 32 * 8;    // dwords per byte plane
   // LDS: rotation table at offset 0 (a table read then needs no base add) | two plane pairs (double buffer:
-  // tile i+1 is written while slower waves still read tile i) | tap fragments [S][2][64]
+  // tile i+1 is written while slower waves still read tile i; CU8: two single planes) | tap fragments [S][2][64]
+  constexpr int NPL = CU8 ? 1 : 2;   // byte planes per buffer
   int2 *lut_s = reinterpret_cast<int2 *>(smem);
   uint32_t *planes = smem + 256;
-  v4i *taps_s = reinterpret_cast<v4i *>(smem + 256 + 4 * PLW);
+  v4i *taps_s = reinterpret_cast<v4i *>(smem + 256 + 2 * NPL * PLW);
 
   const int c = blockIdx.y, tid = threadIdx.x;
   const int w = tid >> 6, l = tid & 63, n = l & 31, h = l >> 5;
@@ -344,7 +354,25 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_mfma_kernel(const IqbbArgs a)
     const int q0_ = tile_ * a.OG - a.ovl;
     const int first = a.base0_rel + q0_ * 8 - (a.OP - 1);
     const int quads = (min(a.CG, a.n_groups - q0_) * 8 + a.OP + 4) / 4;
-    if (!a.in_cu8 && first >= 0 && first + 4 * quads <= a.N) {   // interior tile: no history, no end of call
+    const bool interior = first >= 0 && first + 4 * quads <= a.N;   // no history, no end of call
+    if (CU8) {   // px[k].v[0..1] = the 8 high-plane bytes of 4 samples
+      struct __attribute__((packed, aligned(2))) Oct { uint32_t v[2]; };   // 8-byte load from a 2-byte aligned address
+      const uint16_t *src = reinterpret_cast<const uint16_t *>(a.in) + (long)c * a.in_stride + first;
+#pragma unroll
+      for (int k = 0; k < NQ; k++) {
+        const int p = tid + k * TPB;
+        if (p < quads) {
+          if (interior) {
+            const Oct o = *reinterpret_cast<const Oct *>(src + 4 * p);
+            px[k].v[0] = add129_bytes(o.v[0]); px[k].v[1] = add129_bytes(o.v[1]);
+          } else {
+            const uint32_t x0 = load_x(a, c, first + 4 * p), x1 = load_x(a, c, first + 4 * p + 1);
+            const uint32_t x2 = load_x(a, c, first + 4 * p + 2), x3 = load_x(a, c, first + 4 * p + 3);
+            px[k].v[0] = __builtin_amdgcn_perm(x1, x0, 0x07050301u); px[k].v[1] = __builtin_amdgcn_perm(x3, x2, 0x07050301u);
+          }
+        }
+      }
+    } else if (interior && !a.in_cu8) {
       const uint32_t *src = a.in + (long)c * a.in_stride + first;
 #pragma unroll
       for (int k = 0; k < NQ; k++) {
@@ -370,7 +398,7 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_mfma_kernel(const IqbbArgs a)
     const int q0 = tile * a.OG - a.ovl;
     const int tb = a.base0_rel + q0 * 8;
     const int groups_here = min(a.CG, a.n_groups - q0);
-    uint32_t *lo = planes + (it & 1) * 2 * PLW, *hi = lo + PLW;
+    uint32_t *lo = planes + (it & 1) * NPL * PLW, *hi = lo + (NPL - 1) * PLW;
 
     // ---- stage: four samples -> 8 bytes of the low plane (offset to signed) and 8 of the high plane ----
     {
@@ -383,13 +411,17 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_mfma_kernel(const IqbbArgs a)
           // plane, odd in the second): a lane's K steps then walk consecutive chunks and the 16 lanes a
           // ds_read_b128 services together cover one contiguous 256-byte bank row instead of every other slot
           const int d = (((p >> 1) & 1) * (PLW >> 1)) + ((p >> 2) << 2) + ((p & 1) << 1);
-          uint2 l2, h2;
-          l2.x = __builtin_amdgcn_perm(px[k].v[1], px[k].v[0], 0x06040200u) ^ 0x80808080u;
-          l2.y = __builtin_amdgcn_perm(px[k].v[3], px[k].v[2], 0x06040200u) ^ 0x80808080u;
-          h2.x = __builtin_amdgcn_perm(px[k].v[1], px[k].v[0], 0x07050301u);
-          h2.y = __builtin_amdgcn_perm(px[k].v[3], px[k].v[2], 0x07050301u);
-          *reinterpret_cast<uint2 *>(lo + d) = l2;
-          *reinterpret_cast<uint2 *>(hi + d) = h2;
+          if (CU8) {
+            *reinterpret_cast<uint2 *>(hi + d) = make_uint2(px[k].v[0], px[k].v[1]);
+          } else {
+            uint2 l2, h2;
+            l2.x = __builtin_amdgcn_perm(px[k].v[1], px[k].v[0], 0x06040200u) ^ 0x80808080u;
+            l2.y = __builtin_amdgcn_perm(px[k].v[3], px[k].v[2], 0x06040200u) ^ 0x80808080u;
+            h2.x = __builtin_amdgcn_perm(px[k].v[1], px[k].v[0], 0x07050301u);
+            h2.y = __builtin_amdgcn_perm(px[k].v[3], px[k].v[2], 0x07050301u);
+            *reinterpret_cast<uint2 *>(lo + d) = l2;
+            *reinterpret_cast<uint2 *>(hi + d) = h2;
+          }
         }
       }
     }
@@ -400,9 +432,12 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_mfma_kernel(const IqbbArgs a)
     uint32_t touch = 0;
     if (tile + 1 < tile_end) {
       const int q0_ = (tile + 1) * a.OG - a.ovl;
-      const long first = (long)a.base0_rel + (long)q0_ * 8 - (a.OP - 1) + 16L * tid;   // one 64-byte line per lane
-      if (!a.in_cu8 && first >= 0 && first < (long)a.N && 16 * tid < TI + a.OP + 16) {
-        const uint32_t *pa = a.in + (long)c * a.in_stride + first;
+      constexpr int LINE = CU8 ? 32 : 16;   // samples per 64-byte line
+      const long first = (long)a.base0_rel + (long)q0_ * 8 - (a.OP - 1) + (long)LINE * tid;   // one line per lane
+      if ((CU8 || !a.in_cu8) && first >= 0 && first < (long)a.N && LINE * tid < TI + a.OP + LINE) {
+        const void *pa = CU8 ? (const void *)((reinterpret_cast<const uint16_t *>(a.in) + (long)c * a.in_stride + first))
+                             : (const void *)(a.in + (long)c * a.in_stride + first);
+        pa = (const void *)((uintptr_t)pa & ~(uintptr_t)3);
         asm volatile("global_load_dword %0, %1, off" : "+v"(touch) : "v"(pa) : "memory");
       }
     }
@@ -414,22 +449,28 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_mfma_kernel(const IqbbArgs a)
 
     const int gw = w * OGw;   // this wave's first group within the tile
     if (gw + a.ovl < groups_here) {   // wave-uniform: the wave has at least one group of its own
-      v16i acc_hh = {0}, acc_mid = {0}, acc_ll;
+      v16i acc_hh = {0}, acc_mid = {0}, acc_ll = {0};
+      if (!CU8) {
 #pragma unroll
-      for (int r = 0; r < 16; r++) acc_ll[r] = (r & 1) ? a.cim : a.cre;   // + 128*sum(a) rides in as C
+        for (int r = 0; r < 16; r++) acc_ll[r] = (r & 1) ? a.cim : a.cre;   // + 128*sum(a) rides in as C
+      }
       // chunk (16 B = 8 samples of one plane) gw + 2(n+s) + h of the tile, in the parity-split layout
       const int coff = ((gw + h) & 1) * (2 * PLW) + 16 * (((gw + h) >> 1) + n);
       const char *pl = reinterpret_cast<const char *>(lo) + coff;
       const char *ph = reinterpret_cast<const char *>(hi) + coff;
 #pragma unroll
       for (int s = 0; s < S; s++) {
-        const v4i ul = *reinterpret_cast<const v4i *>(pl + 16 * s);
         const v4i uh = *reinterpret_cast<const v4i *>(ph + 16 * s);
         const v4i Ah = taps_s[(2 * s) * 64 + l], Al = taps_s[(2 * s + 1) * 64 + l];
         acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, uh, acc_hh, 0, 0, 0);
-        acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, ul, acc_mid, 0, 0, 0);
-        acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, uh, acc_mid, 0, 0, 0);
-        acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, ul, acc_ll, 0, 0, 0);
+        if (CU8) {
+          acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, uh, acc_mid, 0, 0, 0);
+        } else {
+          const v4i ul = *reinterpret_cast<const v4i *>(pl + 16 * s);
+          acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, ul, acc_mid, 0, 0, 0);
+          acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, uh, acc_mid, 0, 0, 0);
+          acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, ul, acc_ll, 0, 0, 0);
+        }
       }
       // ---- recombine, >>14, rotate, mask, partial box sums (4 samples per group in this lane) --------
       const int rel0 = tb + 8 * gw + MF_BLK * n + 2 * h;
@@ -441,9 +482,13 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_mfma_kernel(const IqbbArgs a)
         // two v_lshl_add_u32 per component; the empty asm keeps the compiler from re-associating into 2 shifts + add3
         unsigned tre = ((unsigned)acc_hh[rr] << 8) + (unsigned)acc_mid[rr];
         unsigned tim = ((unsigned)acc_hh[rr + 1] << 8) + (unsigned)acc_mid[rr + 1];
-        asm("" : "+v"(tre)); asm("" : "+v"(tim));
-        const unsigned sre = (tre << 8) + (unsigned)acc_ll[rr], sim = (tim << 8) + (unsigned)acc_ll[rr + 1];
-        rv[k] = make_int2((int)sre >> 14, (int)sim >> 14);
+        if (CU8) {   // S = t << 8 exactly
+          rv[k] = make_int2((int)(tre << 8) >> 14, (int)(tim << 8) >> 14);
+        } else {
+          asm("" : "+v"(tre)); asm("" : "+v"(tim));
+          const unsigned sre = (tre << 8) + (unsigned)acc_ll[rr], sim = (tim << 8) + (unsigned)acc_ll[rr + 1];
+          rv[k] = make_int2((int)sre >> 14, (int)sim >> 14);
+        }
       }
       // the accumulators are dead now: the loads ride through the rest of the epilogue (the touch landed long ago)
       asm volatile("s_waitcnt vmcnt(0)" : "+v"(touch) : : "memory");
@@ -833,8 +878,12 @@ struct sdrhip_iqbb_i16 {
       }
 #undef SDRHIP_MF16
     } else if (path == 1) {
-#define SDRHIP_MF(S_) do { if (inc != 0) hipLaunchKernelGGL((iqbb_i16_mfma_kernel<S_, true>), grid, block, lds_bytes, ctx->stream, a); \
-                            else hipLaunchKernelGGL((iqbb_i16_mfma_kernel<S_, false>), grid, block, lds_bytes, ctx->stream, a); } while (0)
+      // complex<uint8> input: the one-plane instantiation (its LDS: two single planes instead of two pairs)
+      const size_t lds1 = in_cu8 ? lds_bytes - 2 * (((2 * (size_t)(TI + OP) + 64 + 31) / 32 * 8) * 4) : lds_bytes;
+#define SDRHIP_MF(S_) do { if (in_cu8 && inc != 0) hipLaunchKernelGGL((iqbb_i16_mfma_kernel<S_, true, true>), grid, block, lds1, ctx->stream, a); \
+                            else if (in_cu8) hipLaunchKernelGGL((iqbb_i16_mfma_kernel<S_, false, true>), grid, block, lds1, ctx->stream, a); \
+                            else if (inc != 0) hipLaunchKernelGGL((iqbb_i16_mfma_kernel<S_, true, false>), grid, block, lds1, ctx->stream, a); \
+                            else hipLaunchKernelGGL((iqbb_i16_mfma_kernel<S_, false, false>), grid, block, lds1, ctx->stream, a); } while (0)
       switch (S) {
         case 2: SDRHIP_MF(2); break;
         case 3: SDRHIP_MF(3); break;
