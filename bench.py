@@ -8,7 +8,7 @@ north-star chain of BASELINE.json on the per-GPU shard of its config 5 (8192 cha
 Channels are independent, so ranks shard them with no data-path collective (weak scaling);
 taps/LUT are designed on rank 0 and broadcast over RCCL at config time.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload iqbb_fm|iqbb_usb|iqbb_fm_cu8|fir255_fm|fbb_f32|fftconv]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload iqbb_fm|iqbb_usb|iqbb_fm_cu8|fir255_fm|fbb_f32|fftconv|fm_demod|subsample8]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
@@ -200,6 +200,21 @@ def main():
             run = lambda b: node.process_dev(ins[b].data_ptr(), N, N, outs.data_ptr(), N)
             dtype, kernel = "f32", "fftconv_fused_kernel"
             desc = "FFT convolution, overlap-save L=16384, 4097 taps (hop 12288)"
+        elif wl in ("fm_demod", "subsample8"):
+            ins = [synth_cs16(torch, C, N, dev, 1234 + b, chan0=rank * C) for b in range(a.batches)]
+            if wl == "fm_demod":
+                node = sa.Demod(ctx, sa.EPI_FM, sa.T_CS16, channels=C, max_in=N)
+                in_bytes, alg_bytes = 4.0, 6.0
+                outs = torch.zeros((C, N), dtype=torch.int16, device=dev)
+                run = lambda b: node.process_dev(ins[b].data_ptr(), N, N, outs.data_ptr(), N)
+                kernel, desc = "demod_cs16_kernel", "FMDemod<int16> alone (complex<int16> -> int16)"
+            else:
+                node = sa.SubSample(ctx, sa.T_CS16, 8, channels=C, max_in=N)
+                in_bytes, alg_bytes = 4.0, 4.5
+                outs = torch.zeros((C, N // 8 + 1, 2), dtype=torch.int16, device=dev)
+                run = lambda b: node.process_dev(ins[b].data_ptr(), N, N, outs.data_ptr(), N // 8 + 1)
+                kernel, desc = "subsample_cs16_kernel", "SubSample<complex<int16>>(8) alone"
+            dtype = "i16"
         else:
             raise SystemExit("unknown workload " + wl)
 
