@@ -287,6 +287,12 @@ __global__ __launch_bounds__(TPB) void fir_cf32_rt_kernel(const Fir32Args a) {
       }
     }
   }
+  // a lane whose last outputs fall beyond the call still walks its whole window against zero taps: what it reads
+  // behind the staged samples must be finite (0 * NaN would poison its valid accumulators)
+  for (int i = need + tid; i < need + (R - 1) * D + 16; i += TPB) {
+    const int q = DC > 0 ? i / (R * (DC > 0 ? DC : 1)) : (int)__umulhi((unsigned)i, a.rd_magic);
+    xs[i + q] = make_float2(0.f, 0.f);
+  }
   __syncthreads();
   if (R * tid < outs_here) {
     float sr[R], si[R];
@@ -497,7 +503,7 @@ int sdrhip_fir_create(sdrhip_ctx *ctx, int kind, const double *alpha, int order,
         // beta[m] = (1/D) * sum_k alpha[m-k], k in [0,D): FIR followed by the D-sample box average
         h->M = order + decim - 1;
         // outputs per lane: as many as keep the tile (TPB*R outputs, (TPB*R-1)*D + M samples + pads) within 144 KB
-        auto tile_bytes = [&](int R_) { const size_t need = ((size_t)TPB * R_ - 1) * decim + h->M; return (need + need / ((size_t)R_ * decim) + 2 + 16) * 8; };
+        auto tile_bytes = [&](int R_) { const size_t need = ((size_t)TPB * R_ - 1) * decim + h->M; return (need + (size_t)(R_ - 1) * decim + 16 + (need + (size_t)(R_ - 1) * decim + 16) / ((size_t)R_ * decim) + 2) * 8; };
         h->R = 4;
         while (h->R > 1 && tile_bytes(h->R) > 72 * 1024) h->R >>= 1;
         SDRHIP_REQUIRE(tile_bytes(h->R) <= 144 * 1024, SDRHIP_E_UNSUPPORTED, "order %d with decim %d exceeds the LDS tile", order, decim);

@@ -503,6 +503,64 @@ def test_float_baseband_vs_oracle(ctx, golden, orc):
         assert y.shape == ref.shape and rel_err(y, ref) <= RTOL
 
 
+@pytest.mark.parametrize("D,epi", [(8, sa.EPI_NONE), (3, sa.EPI_NONE), (8, sa.EPI_AM), (1, sa.EPI_USB), (16, sa.EPI_NONE)])
+def test_fir_cf32_long_calls_vs_oracle(ctx, golden, orc, D, epi):
+    """Calls long enough for interior tiles of the register-tiled kernel (a tile is 1024 outputs = 1024*D samples):
+    3 channels, ragged call lengths, decimation 8 (specialised instance), 3 and 16 (generic), 1."""
+    alpha = golden.load("g2_firlp_alpha127")
+    rng = np.random.default_rng(D)
+    C = 3
+    node = sa.FIR(ctx, sa.FIR_CF32, alpha, decim=D, channels=C, max_in=40000, epilogue=epi)
+    firs, subs = [orc.FIR(alpha) for _ in range(C)], [orc.SubSample(D) for _ in range(C)]
+    for n in (40000, 1, 33333, 8192 * 2 + 5):
+        x = (rng.standard_normal((C, n, 2)) * 0.3).astype(np.float32)
+        y = node.process(x)
+        for c in range(C):
+            ref = firs[c].process_cf32(x[c])
+            if D > 1:
+                ref = subs[c].process_cf32(ref)
+            if epi == sa.EPI_AM:
+                ref = orc.am_f32(ref)
+            elif epi == sa.EPI_USB:
+                ref = orc.usb_f32(ref)
+            assert y[c].shape == ref.shape
+            if ref.size:
+                assert rel_err(y[c], ref) <= RTOL
+
+
+def test_float_baseband_full_buffers_vs_oracle(ctx, golden, orc):
+    """BASELINE config 2 at its buffer size: 65536-sample calls (interior tiles, phasor advanced across tiles and calls)."""
+    alpha = golden.load("g2_firlp_alpha127")
+    rng = np.random.default_rng(11)
+    C, N = 2, 65536
+    node = sa.FloatBaseBand(ctx, 100e3, FS, alpha, 8, channels=C, max_in=N)
+    firs, subs = [orc.FIR(alpha) for _ in range(C)], [orc.SubSample(8) for _ in range(C)]
+    n0 = 0
+    for n in (N, N, 12345):
+        x = (rng.standard_normal((C, n, 2)) * 0.3).astype(np.float32)
+        y = node.process(x)
+        for c in range(C):
+            ref = subs[c].process_cf32(firs[c].process_cf32(orc.freqshift_cf32(x[c], n0, 100e3, FS)))
+            assert y[c].shape == ref.shape and rel_err(y[c], ref) <= RTOL
+        n0 += n
+
+
+def test_fftconv_config4_many_channels(ctx, golden, orc):
+    """BASELINE config 4 (ii) at C = 64, N = 65536: the fused overlap-save kernel against the time-domain oracle FIR
+    on three of the channels, and against itself run one channel at a time."""
+    a = golden.load("g2_firlp_alpha4097")
+    taps = np.stack([a[::-1], np.zeros_like(a)], axis=1).astype(np.float32)
+    rng = np.random.default_rng(4)
+    C, N = 64, 65536
+    x = (rng.standard_normal((C, N, 2)) * 0.3).astype(np.float32)
+    y = sa.FFTConv(ctx, sa.FFTCONV_OLS, 16384, taps, channels=C, max_in=N).process(x)
+    for c in (0, 31, 63):
+        ref = orc.FIR(a).process_cf32(x[c])
+        assert rel_err(y[c], ref) <= RTOL
+    one = sa.FFTConv(ctx, sa.FFTCONV_OLS, 16384, taps, channels=1, max_in=N)
+    assert np.array_equal(one.process(x[5:6])[0], y[5])
+
+
 # ---- error behaviour -----------------------------------------------------------------------------------------
 
 def test_error_codes(ctx, golden):
