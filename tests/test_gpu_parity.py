@@ -261,6 +261,30 @@ def test_bb_real_reset_semantics(ctx, orc):
     assert np.array_equal(bb.process(x[2])[0], ref.process(x[2]))
 
 
+@pytest.mark.parametrize("epi", [sa.EPI_NONE, sa.EPI_FM])
+def test_cu8_long_calls_vs_oracle(ctx, orc, epi, k1path):
+    """complex<uint8> calls long enough for interior tiles (2048 samples each) of the one-plane MFMA instantiation:
+    odd call lengths move the 2-byte aligned 8-byte loads over every alignment."""
+    rng = np.random.default_rng(33)
+    C, chunks = 2, [20000, 13333, 7, 9999]
+    u = rng.integers(0, 256, size=(C, sum(chunks), 2), dtype=np.uint8)
+    taps = sa.design_iqbb_taps(100e3, 50e3, FS, 127)
+    lut, inc = sa.design_freqshift_lut_i16(), sa.design_freqshift_inc(100e3, FS)
+    node = sa.IQBaseBandI16(ctx, taps, lut, inc, False, 8, channels=C, max_in=20000, epilogue=epi)
+    node.set_input_format(sa.abi.IN_CU8)
+    refs = [orc.IQBaseBandI16(taps, lut, inc, False, 8) for _ in range(C)]
+    fms = [orc.FMDemodI16() for _ in range(C)]
+    off = 0
+    for n in chunks:
+        y = node.process(u[:, off:off + n])
+        for c in range(C):
+            r = refs[c].process(orc.autocast_cu8_cs16(u[c, off:off + n]))
+            if epi == sa.EPI_FM:
+                r = fms[c].process(r)
+            assert np.array_equal(y[c], r)
+        off += n
+
+
 @pytest.mark.parametrize("rate", [125000, 48000])
 def test_fmdeemph_golden_and_batched(ctx, golden, orc, rate):
     x = golden.load("g9_deemph_in")
