@@ -263,6 +263,19 @@ def main():
                          "hbm_read_frac": round(C * N * in_bytes / per_launch_s / 1e9 / HBM_PEAK_GBS, 5),
                          "per_gpu_msamples_s": round(C * N / per_launch_s / 1e6, 2)},
         }
+        if rank == 0:   # what this box's HBM delivers to a pure read of the same buffers, beside the nominal peak
+            try:
+                import ctypes
+                gbs = ctypes.c_double(0.0)
+                buf = torch.ones(1 << 28, dtype=torch.int32, device=dev)   # 1 GiB: four times the 256 MiB Infinity Cache
+                rc = sa.abi.lib().sdrhip_bench_stream_read(ctx.handle, ctypes.c_void_p(buf.data_ptr()), buf.numel() * buf.element_size(),
+                                                           5, ctypes.byref(gbs))
+                del buf
+                if rc == 0 and gbs.value > 0:
+                    res["roofline"]["stream_read_gbs"] = round(gbs.value, 1)
+                    res["roofline"]["frac_of_stream_read"] = round(achieved / gbs.value, 5)
+            except Exception as e:   # measurement aid only
+                res["roofline"]["stream_read_error"] = str(e)[:80]
         tr = measured_traffic(kernel) if (C, N) == (1024, 65536) else None
         if tr:
             res["roofline"]["traffic"] = tr["bytes"]

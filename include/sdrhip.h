@@ -91,6 +91,10 @@ int sdrhip_timer_stop(sdrhip_timer *t);
 int sdrhip_timer_elapsed_ms(sdrhip_timer *t, float *ms); /* synchronises on the stop event */
 int sdrhip_timer_destroy(sdrhip_timer *t);
 
+/* Stream-read microbenchmark (measurement aid for bench.py, SURVEY §8d "stream-read microbenchmark on the box"):
+ * reads `bytes` of device memory `iters` times with 16-byte loads and reports GB/s. */
+int sdrhip_bench_stream_read(sdrhip_ctx *ctx, const void *dev, size_t bytes, int iters, double *gb_per_s);
+
 /* ---- host-side designers (no device work; same code as include/sdr/gpu/design.hh) ----------- */
 /* IQBaseBand::_update_filter_kernel (reference src/baseband.hh:239-262): order x (re,im) Q14 */
 int sdrhip_design_iqbb_taps(double filter_freq, double width, double sample_rate, int order, int32_t *taps);

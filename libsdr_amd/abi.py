@@ -66,6 +66,7 @@ def lib():
             "sdrhip_timer_stop": (C.c_int, [vp]),
             "sdrhip_timer_elapsed_ms": (C.c_int, [vp, f32p]),
             "sdrhip_timer_destroy": (C.c_int, [vp]),
+            "sdrhip_bench_stream_read": (C.c_int, [vp, vp, sz, C.c_int, C.POINTER(C.c_double)]),
             "sdrhip_design_iqbb_taps": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_int, i32p]),
             "sdrhip_design_bb_taps": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_int, i32p]),
             "sdrhip_design_iqbb_decim": (C.c_int, [C.c_double, C.c_int, C.c_double, C.POINTER(C.c_int)]),

@@ -33,6 +33,19 @@ using namespace sdrhip;
 
 void sdrhip_ctx::use() const { SDRHIP_CHECK_HIP(hipSetDevice(device)); }
 
+namespace {
+// stream-read microbenchmark: what this box's HBM delivers to a pure 16-byte-per-lane read (the practical ceiling
+// beside the nominal 8 TB/s in bench.py's roofline object)
+__global__ __launch_bounds__(256) void stream_read_kernel(const uint4 *p, size_t n16, uint32_t *sink) {
+  uint32_t acc = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+    const uint4 v = p[i];
+    acc ^= v.x ^ v.y ^ v.z ^ v.w;
+  }
+  if (acc == 0x9e3779b9u) sink[0] = acc;   // (keeps the loads alive; practically never taken)
+}
+}  // namespace
+
 extern "C" {
 
 int sdrhip_version(void) { return SDRHIP_VERSION; }
@@ -212,6 +225,28 @@ int sdrhip_timer_destroy(sdrhip_timer *t) {
     (void)hipEventDestroy(t->a);
     (void)hipEventDestroy(t->b);
     delete t;
+  });
+}
+
+int sdrhip_bench_stream_read(sdrhip_ctx *ctx, const void *dev, size_t bytes, int iters, double *gb_per_s) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(ctx && dev && gb_per_s && bytes >= 16 && iters >= 1, SDRHIP_E_INVALID, "bad argument");
+    ctx->use();
+    uint32_t *sink = nullptr;
+    SDRHIP_CHECK_HIP(hipMalloc(&sink, 4));
+    hipEvent_t e0, e1;
+    SDRHIP_CHECK_HIP(hipEventCreate(&e0)); SDRHIP_CHECK_HIP(hipEventCreate(&e1));
+    const unsigned grid = 256 * 32;
+    hipLaunchKernelGGL(stream_read_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const uint4 *)dev, bytes / 16, sink);
+    SDRHIP_CHECK_HIP(hipEventRecord(e0, ctx->stream));
+    for (int k = 0; k < iters; k++)
+      hipLaunchKernelGGL(stream_read_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const uint4 *)dev, bytes / 16, sink);
+    SDRHIP_CHECK_HIP(hipEventRecord(e1, ctx->stream));
+    SDRHIP_CHECK_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    SDRHIP_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *gb_per_s = (double)(bytes / 16 * 16) * iters / (ms * 1e-3) / 1e9;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(sink);
   });
 }
 
