@@ -226,11 +226,18 @@ __device__ __forceinline__ float2 conv_fetch(const ConvArgs &a, int c, int rel) 
   return h >= 0 ? a.hist[(long)c * a.HH + h] : make_float2(0.f, 0.f);
 }
 
+// LG > 0: the plan (L = 2^LG: radix-16 passes, then 4 and/or 2) is a compile-time constant — strides, pad offsets and
+// the per-pass butterfly maps fold into immediates and shifts (instantiated for the BASELINE size 16384); LG = 0: the
+// plan is read from the arguments
+constexpr int plan_npass(int lg) { return lg / 4 + ((lg % 4) >= 2 ? 1 : 0) + ((lg % 4) & 1); }
+constexpr int plan_radix(int lg, int pass) { return pass < lg / 4 ? 16 : ((lg % 4) >= 2 && pass == lg / 4) ? 4 : 2; }
+template <int LG>
 __global__ __launch_bounds__(FT) void fftconv_fused_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float2 xl[];
   const int c = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
   const FftDev &p = a.fft;
-  const int L = p.L, np = p.npass;
+  const int L = LG ? (1 << LG) : p.L, np = LG ? plan_npass(LG) : p.npass;
+  auto radix_at = [&](int q) { return LG ? plan_radix(LG, q) : p.radix[q]; };
   const int first = blk * a.hop - a.HH;   // call-relative index of element 0
   // ---- forward pass 0 (radix 16, stride L/16): global -> registers -> LDS ----
   {
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(FT) void fftconv_fused_kernel(const ConvArgs a) {
   // ---- forward passes 1 .. np-2 in LDS ----
   int n = L / 16;
   for (int pass = 1; pass + 1 < np; pass++) {
-    const int r = p.radix[pass], s = n / r, tw = L / n;
+    const int r = radix_at(pass), s = n / r, tw = L / n;
     if (r == 16) {
       for (int b = tid; b < L / 16; b += FT) {
         const int j = b & (s - 1), base = (b / s) * n + j;
@@ -281,7 +288,7 @@ __global__ __launch_bounds__(FT) void fftconv_fused_kernel(const ConvArgs a) {
   }
   // ---- last forward pass (stride 1, no twiddles) x spectrum x first inverse pass ----
   {
-    const int r = p.radix[np - 1];
+    const int r = radix_at(np - 1);
     if (r == 16) {
       for (int b = tid; b < L / 16; b += FT) {
         float2 v[16];
@@ -314,9 +321,9 @@ __global__ __launch_bounds__(FT) void fftconv_fused_kernel(const ConvArgs a) {
     __syncthreads();
   }
   // ---- inverse passes np-2 .. 1 in LDS ----
-  n = p.radix[np - 1];
+  n = radix_at(np - 1);
   for (int pass = np - 2; pass >= 1; pass--) {
-    const int r = p.radix[pass], s = n;
+    const int r = radix_at(pass), s = n;
     n *= r;
     const int tw = L / n;
     if (r == 16) {
@@ -457,9 +464,12 @@ struct sdrhip_fftconv {
     a.hist = hist[par].p; a.HH = HH; a.Kp = Kp.p;
     a.out = out_dev; a.out_stride = (long)out_stride; a.N = (int)N; a.hop = hop;
     const int blocks = (int)ceil_div(N, (size_t)hop);
-    if (plan.dev.npass >= 2 && plan.dev.radix[0] == 16) {
-      allow_big_lds(fftconv_fused_kernel, plan.lds_bytes());
-      hipLaunchKernelGGL(fftconv_fused_kernel, dim3(blocks, C), dim3(FT), plan.lds_bytes(), ctx->stream, a);
+    if (plan.L == 16384) {
+      allow_big_lds(fftconv_fused_kernel<14>, plan.lds_bytes());
+      hipLaunchKernelGGL(fftconv_fused_kernel<14>, dim3(blocks, C), dim3(FT), plan.lds_bytes(), ctx->stream, a);
+    } else if (plan.dev.npass >= 2 && plan.dev.radix[0] == 16) {
+      allow_big_lds(fftconv_fused_kernel<0>, plan.lds_bytes());
+      hipLaunchKernelGGL(fftconv_fused_kernel<0>, dim3(blocks, C), dim3(FT), plan.lds_bytes(), ctx->stream, a);
     } else {
       allow_big_lds(fftconv_kernel, plan.lds_bytes());
       hipLaunchKernelGGL(fftconv_kernel, dim3(blocks, C), dim3(FT), plan.lds_bytes(), ctx->stream, a);
