@@ -53,6 +53,7 @@ struct IqbbArgs {
   int CGr;          // CG rounded up to 4: ybuf[CGr] is followed by the FM angle cache [CGr]
   void *out; long out_stride; int epilogue;
   const v4i *tapfrag; int cre, cim;
+  unsigned ah_mask;   // bit s: the high-byte tap fragments of K step s are not all zero (small outer taps: |a| < 128)
   int tiles, tpw;   // tiles per channel in this call; consecutive tiles walked by one workgroup (MFMA path)   // MFMA path: tap fragments, 128*sum(a) per component
 };
 
@@ -460,14 +461,22 @@ __global__ __launch_bounds__(TPB, CU8 ? 5 : 4) void iqbb_i16_mfma_kernel(const I
       const char *ph = reinterpret_cast<const char *>(hi) + coff;
 #pragma unroll
       for (int s = 0; s < S; s++) {
+        // the outer taps of a windowed sinc are small: where every tap a K step touches has a zero high byte, its
+        // two high-plane products are skipped (scalar branch on a mask made at create time; 4 of 9 steps for the
+        // 127-tap north-star filter)
+        const bool has_ah = (a.ah_mask >> s) & 1;
         const v4i uh = *reinterpret_cast<const v4i *>(ph + 16 * s);
-        const v4i Ah = taps_s[(2 * s) * 64 + l], Al = taps_s[(2 * s + 1) * 64 + l];
-        acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, uh, acc_hh, 0, 0, 0);
+        const v4i Al = taps_s[(2 * s + 1) * 64 + l];
         if (CU8) {
+          if (has_ah) acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(taps_s[(2 * s) * 64 + l], uh, acc_hh, 0, 0, 0);
           acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, uh, acc_mid, 0, 0, 0);
         } else {
           const v4i ul = *reinterpret_cast<const v4i *>(pl + 16 * s);
-          acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, ul, acc_mid, 0, 0, 0);
+          if (has_ah) {
+            const v4i Ah = taps_s[(2 * s) * 64 + l];
+            acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, uh, acc_hh, 0, 0, 0);
+            acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, ul, acc_mid, 0, 0, 0);
+          }
           acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, uh, acc_mid, 0, 0, 0);
           acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, ul, acc_ll, 0, 0, 0);
         }
@@ -813,6 +822,7 @@ struct sdrhip_iqbb_i16 {
   bool fast8 = false;
   int in_cu8 = 0, real = 0;
   int path = 0, S = 0, cre = 0, cim = 0;   // path 1 = int8-MFMA formulation with S K-steps
+  unsigned ah_mask = 0;
   DevBuf<v4i> tapfrag;
   size_t lds_bytes = 0;
   DevBuf<uint2> taps;
@@ -857,7 +867,10 @@ struct sdrhip_iqbb_i16 {
     a.base0_rel = g.base0_rel; a.n_groups = g.n_groups; a.n_out = g.n_out; a.extra0 = g.extra0;
     a.CG = CG; a.OG = OG; a.ovl = ovl; a.CGr = (CG + 3) & ~3;
     a.out = out_dev; a.out_stride = (long)out_stride; a.epilogue = epi;
-    a.tapfrag = tapfrag.p; a.cre = cre; a.cim = cim;
+    a.tapfrag = tapfrag.p; a.cre = cre; a.cim = cim; a.ah_mask = ah_mask;
+#ifdef SDRHIP_AH_FULL
+    a.ah_mask = ~0u;   // tuning: never skip
+#endif
     const int tiles = (int)ceil_div((size_t)g.n_groups, (size_t)OG);
     // MFMA path: one workgroup walks `tpw` consecutive tiles so that the tap fragments are fetched once;
     // keep >= ~8 workgroups per CU in flight for balance
@@ -1003,6 +1016,7 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
               const int v = (idx >= 0 && idx < 2 * OPm) ? (comp ? aim[idx] : are[idx]) : 0;
               const int al = ((v + 128) & 255) - 128, ah = (v - al) >> 8;
               frag[(((size_t)(2 * st) * 64 + l) * 16) + j] = (int8_t)ah;
+              if (ah != 0) h->ah_mask |= 1u << st;
               frag[(((size_t)(2 * st + 1) * 64 + l) * 16) + j] = (int8_t)al;
             }
         h->tapfrag.alloc((size_t)h->S * 2 * 64);
