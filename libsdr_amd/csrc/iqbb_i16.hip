@@ -467,18 +467,19 @@ __global__ __launch_bounds__(TPB, CU8 ? 5 : 4) void iqbb_i16_mfma_kernel(const I
         const bool has_ah = (a.ah_mask >> s) & 1;
         const v4i uh = *reinterpret_cast<const v4i *>(ph + 16 * s);
         const v4i Al = taps_s[(2 * s + 1) * 64 + l];
+        // (the unconditional low-plane products come first: step 0 writes acc_mid with C = 0, so that only acc_hh
+        // needs an explicit zero — a conditional first write makes the compiler materialise zeros on the other path)
+        acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, uh, acc_mid, 0, 0, 0);
         if (CU8) {
           if (has_ah) acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(taps_s[(2 * s) * 64 + l], uh, acc_hh, 0, 0, 0);
-          acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, uh, acc_mid, 0, 0, 0);
         } else {
           const v4i ul = *reinterpret_cast<const v4i *>(pl + 16 * s);
+          acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, ul, acc_ll, 0, 0, 0);
           if (has_ah) {
             const v4i Ah = taps_s[(2 * s) * 64 + l];
             acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, uh, acc_hh, 0, 0, 0);
             acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, ul, acc_mid, 0, 0, 0);
           }
-          acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, uh, acc_mid, 0, 0, 0);
-          acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, ul, acc_ll, 0, 0, 0);
         }
       }
       // ---- recombine, >>14, rotate, mask, partial box sums (4 samples per group in this lane) --------
