@@ -348,7 +348,7 @@ __global__ __launch_bounds__(TPB, CU8 ? 5 : 4) void iqbb_i16_mfma_kernel(const I
 
   // Software pipeline over the tiles this workgroup walks: the global loads of tile i+1 are issued into
   // registers before the MFMA/epilogue work of tile i and written to the other LDS plane pair after it.
-  constexpr int NQ = (TI + 129 + 2 + 4 * TPB - 1) / (4 * TPB);   // sample quads per lane and tile (OP <= 129)
+  constexpr int NQ = (TI + 16 * (S - 1) + 1 + 2 + 4 * TPB - 1) / (4 * TPB);   // sample quads per lane and tile (OP = 16(S-1)+1)
   struct __attribute__((packed, aligned(4))) Quad { uint32_t v[4]; };   // 16-byte load from a 4-byte aligned address
   Quad px[NQ];
   auto fetch = [&](int tile_) {
@@ -902,7 +902,8 @@ struct sdrhip_iqbb_i16 {
         case 2: SDRHIP_MF(2); break;
         case 3: SDRHIP_MF(3); break;
         case 5: SDRHIP_MF(5); break;
-        default: SDRHIP_MF(9); break;
+        case 9: SDRHIP_MF(9); break;
+        default: SDRHIP_MF(17); break;
       }
 #undef SDRHIP_MF
     } else if (real) {
@@ -947,8 +948,8 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
     try {
       h->ctx = ctx; h->order = order; h->D = decim; h->C = channels; h->epi = epilogue;
       h->negative = negative ? 1 : 0; h->inc = lut_inc; h->max_in = max_in; h->real = real ? 1 : 0;
-      // path: the int8-MFMA formulations need D == 8, order <= 129 (32x32x32) / 153 (16x16x64) and tap high bytes that fit int8
-      bool mfma_ok = !real && (decim == R) && (order <= 129);
+      // path: the int8-MFMA formulations need D == 8, order <= 257 (32x32x32) / 153 (16x16x64) and tap high bytes that fit int8
+      bool mfma_ok = !real && (decim == R) && (order <= 257);
       auto high_byte = [](int v) { const int al = ((v + 128) & 255) - 128; return (v - al) >> 8; };
       for (int i = 0; i < 2 * order && mfma_ok; i++)   // both v and -v are packed (Kr, -Ki / Ki, Kr)
         if (high_byte(taps[i]) > 127 || high_byte(-taps[i]) > 127) mfma_ok = false;
@@ -965,7 +966,7 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
         h->S = (2 * order + 14 + 63) / 64;
         h->OP = 32 * h->S - 7;
       } else if (h->path == 1) {
-        h->S = order <= 17 ? 2 : order <= 33 ? 3 : order <= 65 ? 5 : 9;
+        h->S = order <= 17 ? 2 : order <= 33 ? 3 : order <= 65 ? 5 : order <= 129 ? 9 : 17;
         h->OP = 16 * (h->S - 1) + 1;
       } else {
         h->OP = (int)ceil_div((size_t)order, (size_t)TAPC) * TAPC;

@@ -35,7 +35,7 @@ def ctx():
 
 @pytest.fixture(params=["auto", "valu", "mfma16"])
 def k1path(request, monkeypatch):
-    """K1 has two bit-exact formulations: the int8-MFMA kernel (picked automatically for decim 8, order <= 129)
+    """K1 has two bit-exact formulations: the int8-MFMA kernel (picked automatically for decim 8, order <= 257)
     and the VALU dot2 kernel (everything else); every K1 test runs with both selections."""
     if request.param == "valu":
         monkeypatch.setenv("SDRHIP_IQBB_PATH", "valu")
@@ -97,7 +97,7 @@ def synth_channels(orc, C, N, seed=0x5D2):
 
 @pytest.mark.parametrize("epi", [sa.EPI_NONE, sa.EPI_FM, sa.EPI_AM, sa.EPI_USB])
 @pytest.mark.parametrize("order,decim,Fc", [(127, 8, 100e3), (21, 8, -100e3), (33, 5, 100e3), (16, 1, 50e3),
-                                             (129, 8, 0.0), (64, 8, 30e3), (9, 8, -250e3), (1, 8, 100e3), (150, 8, 70e3)])
+                                             (129, 8, 0.0), (64, 8, 30e3), (9, 8, -250e3), (1, 8, 100e3), (150, 8, 70e3), (257, 8, 100e3), (200, 8, -40e3)])
 def test_iqbb_batched_vs_oracle(ctx, orc, epi, order, decim, Fc, k1path):
     C, chunks = 5, [8192, 3000, 1, 7, 5000, 8192]
     taps = sa.design_iqbb_taps(Fc, 50e3, FS, order)
@@ -141,7 +141,8 @@ def test_iqbb_path_selection(ctx, golden, monkeypatch):
     taps, lut = golden.load("g3_iqbb127d8_taps"), golden.load("g3_iqbb127d8_lut")
     assert sa.IQBaseBandI16(ctx, taps, lut, 1365, 0, 8).path == 1          # north-star chain -> MFMA
     assert sa.IQBaseBandI16(ctx, taps, lut, 1365, 0, 5).path == 0          # other decimations -> VALU
-    assert sa.IQBaseBandI16(ctx, golden.load("g8_o255_d8_taps"), lut, 1365, 0, 8).path == 0   # order > 129
+    assert sa.IQBaseBandI16(ctx, golden.load("g8_o255_d8_taps"), lut, 1365, 0, 8).path == 1   # 17 K steps
+    assert sa.IQBaseBandI16(ctx, sa.design_iqbb_taps(100e3, 50e3, FS, 300), lut, 1365, 0, 8).path == 0   # order > 257
     big = np.array(taps).reshape(-1, 2).copy(); big[5, 0] = 32700          # high byte would not fit int8
     assert sa.IQBaseBandI16(ctx, big, lut, 1365, 0, 8).path == 0
     monkeypatch.setenv("SDRHIP_IQBB_PATH", "valu")
