@@ -588,6 +588,136 @@ __global__ __launch_bounds__(TPB, CU8 ? 5 : 4) void iqbb_i16_mfma_kernel(const I
 
 
 // =================================================================================================
+// Path 3: the 32x32x32 formulation for ANY decimation D. The matrix part is path 1's (every input sample's FIR
+// value is needed whatever D is), but the box windows no longer line up with lanes: the rotated samples go to LDS
+// (vbuf, one pad entry per 16 so that the lanes' 128-byte stride spreads over the banks) and the windows are summed
+// from there by the grouping code of the VALU kernel (finalize_group / epilogue_and_roll), one tile per workgroup.
+// =================================================================================================
+__device__ __forceinline__ int PADV(int p) { return p + (p >> 4); }
+
+template <int S, bool ROT>
+__global__ __launch_bounds__(TPB, 3) void iqbb_i16_mfmag_kernel(const IqbbArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const int PLW = (2 * (TI + a.OP) + 64 + 31) / 32 * 8;    // dwords per byte plane
+  // LDS: rotation table | one plane pair | tap fragments [S][2][64] | vbuf (TI + TI/16 int2) | ybuf (+ FM angle cache)
+  int2 *lut_s = reinterpret_cast<int2 *>(smem);
+  uint32_t *lo = smem + 256, *hi = lo + PLW;
+  v4i *taps_s = reinterpret_cast<v4i *>(smem + 256 + 2 * PLW);
+  int2 *vbuf = reinterpret_cast<int2 *>(smem + 256 + 2 * PLW + S * 2 * 64 * 4);
+  uint32_t *ybuf = reinterpret_cast<uint32_t *>(vbuf + TI + TI / 16 + 2);
+
+  const int c = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+  const int w = tid >> 6, l = tid & 63, n = l & 31, h = l >> 5;
+  const int q0 = tile * a.OG - a.ovl;    // first group (relative to the call's first group) of this tile
+  const int tb = a.base0_rel + q0 * a.D; // call-relative index of the tile's first sample
+  const int groups_here = min(a.CG, a.n_groups - q0);
+  for (int i = tid; i < S * 2 * 64; i += TPB) taps_s[i] = a.tapfrag[i];
+  if (tid < 128) lut_s[tid] = a.lut[tid];
+
+  // ---- stage the tile's TI + OP samples as byte planes (parity-split 16-byte chunks, as path 1) ----
+  {
+    constexpr int NQ = (TI + 16 * (S - 1) + 1 + 2 + 4 * TPB - 1) / (4 * TPB);
+    struct __attribute__((packed, aligned(4))) Quad { uint32_t v[4]; };
+    const int first = tb - (a.OP - 1);
+    const int quads = (TI + a.OP + 4) / 4;
+    const bool interior = !a.in_cu8 && first >= 0 && first + 4 * quads <= a.N;
+    const uint32_t *src = a.in + (long)c * a.in_stride + first;
+    Quad px[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; k++) {
+      const int p = tid + k * TPB;
+      if (p < quads) {
+        if (interior) px[k] = *reinterpret_cast<const Quad *>(src + 4 * p);
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; j++) px[k].v[j] = load_x(a, c, first + 4 * p + j);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NQ; k++) {
+      const int p = tid + k * TPB;
+      if (p < quads) {
+        const int d = (((p >> 1) & 1) * (PLW >> 1)) + ((p >> 2) << 2) + ((p & 1) << 1);
+        uint2 l2, h2;
+        l2.x = __builtin_amdgcn_perm(px[k].v[1], px[k].v[0], 0x06040200u) ^ 0x80808080u;
+        l2.y = __builtin_amdgcn_perm(px[k].v[3], px[k].v[2], 0x06040200u) ^ 0x80808080u;
+        h2.x = __builtin_amdgcn_perm(px[k].v[1], px[k].v[0], 0x07050301u);
+        h2.y = __builtin_amdgcn_perm(px[k].v[3], px[k].v[2], 0x07050301u);
+        *reinterpret_cast<uint2 *>(lo + d) = l2;
+        *reinterpret_cast<uint2 *>(hi + d) = h2;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- the FIR at this wave's 512 samples (blocks 32w .. 32w+31 of the tile) ----
+  {
+    v16i acc_hh = {0}, acc_mid = {0}, acc_ll;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc_ll[r] = (r & 1) ? a.cim : a.cre;   // + 128*sum(a) rides in as C
+    const int cw = 64 * w;   // the wave's first chunk (8 samples) within the tile
+    const int coff = ((cw + h) & 1) * (2 * PLW) + 16 * (((cw + h) >> 1) + n);
+    const char *pl = reinterpret_cast<const char *>(lo) + coff;
+    const char *ph = reinterpret_cast<const char *>(hi) + coff;
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+      const bool has_ah = (a.ah_mask >> s) & 1;
+      const v4i uh = *reinterpret_cast<const v4i *>(ph + 16 * s);
+      const v4i ul = *reinterpret_cast<const v4i *>(pl + 16 * s);
+      const v4i Al = taps_s[(2 * s + 1) * 64 + l];
+      acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, uh, acc_mid, 0, 0, 0);
+      acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, ul, acc_ll, 0, 0, 0);
+      if (has_ah) {
+        const v4i Ah = taps_s[(2 * s) * 64 + l];
+        acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, uh, acc_hh, 0, 0, 0);
+        acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, ul, acc_mid, 0, 0, 0);
+      }
+    }
+    // recombine, >>14, rotate, mask samples outside the call, park in vbuf
+    const int pos0 = 512 * w + MF_BLK * n + 2 * h;   // sample k = 2q+tt of this lane sits at pos0 + 4q + tt of the tile
+    uint32_t cnt0 = 0;
+    if (ROT) cnt0 = (a.n0_lo + (uint32_t)(tb + pos0)) * a.inc;
+    const uint32_t negx = a.negative ? (127u << 3) : 0u;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int rr = 4 * (k >> 1) + 2 * (k & 1), dk = 4 * (k >> 1) + (k & 1);
+      unsigned tre = ((unsigned)acc_hh[rr] << 8) + (unsigned)acc_mid[rr];
+      unsigned tim = ((unsigned)acc_hh[rr + 1] << 8) + (unsigned)acc_mid[rr + 1];
+      asm("" : "+v"(tre)); asm("" : "+v"(tim));
+      const unsigned sre = (tre << 8) + (unsigned)acc_ll[rr], sim = (tim << 8) + (unsigned)acc_ll[rr + 1];
+      int2 v = make_int2((int)sre >> 14, (int)sim >> 14);
+      if (ROT) {
+        const uint32_t off = (((cnt0 + (uint32_t)dk * a.inc) >> 5) & (127u << 3)) ^ negx;
+        const int2 L = *reinterpret_cast<const int2 *>(reinterpret_cast<const char *>(lut_s) + off);
+        const int2 r = v;
+        v.x = mad24a(L.x, r.x, -mul24a(L.y, r.y)) >> 16;
+        v.y = mad24a(L.x, r.y, mul24a(L.y, r.x)) >> 16;
+      }
+      const int rel = tb + pos0 + dk;
+      if (rel < 0 || rel >= a.N) v = make_int2(0, 0);
+      vbuf[PADV(pos0 + dk)] = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- box sums per group, truncating division, state (as the VALU kernel) ----
+  for (int ql = tid; ql < groups_here; ql += TPB) {
+    const int q = q0 + ql;
+    if (q < 0) continue;                      // tile 0's overlap slot precedes the call
+    int2 s = make_int2(0, 0);
+    for (int k = 0; k < a.D; k++) {
+      const int2 v = vbuf[PADV(ql * a.D + k)];
+      s.x = (int)((unsigned)s.x + (unsigned)v.x);
+      s.y = (int)((unsigned)s.y + (unsigned)v.y);
+    }
+    finalize_group(a, c, lut_s, ybuf, ql, q, s, a.D);
+  }
+  __syncthreads();
+  epilogue_and_roll(a, c, tile, tid, q0, groups_here, ybuf);
+}
+
+// =================================================================================================
 // MFMA formulation, 16x16x64 tiles with an in-wave software pipeline (path 2; D == 8, order <= 153).
 //
 // Same byte-plane algebra as above, but a block is ONE decimation group (8 samples), a sub-tile is 16
@@ -876,11 +1006,23 @@ struct sdrhip_iqbb_i16 {
     // MFMA path: one workgroup walks `tpw` consecutive tiles so that the tap fragments are fetched once;
     // keep >= ~8 workgroups per CU in flight for balance
     int tpw = 1;
-    if (path >= 1) { tpw = 8; while (tpw > 1 && (size_t)ceil_div((size_t)tiles, (size_t)tpw) * C < 2048) tpw >>= 1; }
-    { const char *t = getenv("SDRHIP_IQBB_TPW"); if (t && path >= 1) tpw = std::max(1, atoi(t)); }   // tuning hook
+    if (path == 1 || path == 2) { tpw = 8; while (tpw > 1 && (size_t)ceil_div((size_t)tiles, (size_t)tpw) * C < 2048) tpw >>= 1; }
+    { const char *t = getenv("SDRHIP_IQBB_TPW"); if (t && (path == 1 || path == 2)) tpw = std::max(1, atoi(t)); }   // tuning hook
     a.tiles = tiles; a.tpw = tpw;
     dim3 grid((unsigned)ceil_div((size_t)tiles, (size_t)tpw), C), block(TPB);
-    if (path == 2) {
+    if (path == 3) {
+      dim3 grid3((unsigned)tiles, C);
+#define SDRHIP_MFG(S_) do { if (inc != 0) hipLaunchKernelGGL((iqbb_i16_mfmag_kernel<S_, true>), grid3, block, lds_bytes, ctx->stream, a); \
+                             else hipLaunchKernelGGL((iqbb_i16_mfmag_kernel<S_, false>), grid3, block, lds_bytes, ctx->stream, a); } while (0)
+      switch (S) {
+        case 2: SDRHIP_MFG(2); break;
+        case 3: SDRHIP_MFG(3); break;
+        case 5: SDRHIP_MFG(5); break;
+        case 9: SDRHIP_MFG(9); break;
+        default: SDRHIP_MFG(17); break;
+      }
+#undef SDRHIP_MFG
+    } else if (path == 2) {
 #define SDRHIP_MF16(S_) do { if (inc != 0) hipLaunchKernelGGL((iqbb_i16_mfma16_kernel<S_, true>), grid, block, lds_bytes, ctx->stream, a); \
                               else hipLaunchKernelGGL((iqbb_i16_mfma16_kernel<S_, false>), grid, block, lds_bytes, ctx->stream, a); } while (0)
       switch (S) {
@@ -960,12 +1102,19 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
         if (high_byte(taps[i]) > 127 || high_byte(-taps[i]) > 127) mfma16_ok = false;
       if (force && !strcmp(force, "valu")) mfma16_ok = false;
       h->path = mfma_ok ? 1 : (mfma16_ok ? 2 : 0);   // 32x32x32 measured 4 % faster than 16x16x64 at 127 taps
+      // path 3: the same matrix part for any decimation, windows summed through LDS; worth it from ~33 taps on
+      // (below that the VALU kernel's 2*order dot2 per sample are no more than the epilogue both paths share)
+      bool mfmag_ok = !real && decim != R && order <= 257 && TI / decim - ovl >= 1;
+      for (int i = 0; i < 2 * order && mfmag_ok; i++)
+        if (high_byte(taps[i]) > 127 || high_byte(-taps[i]) > 127) mfmag_ok = false;
+      if (force && !strcmp(force, "valu")) mfmag_ok = false;
+      if (h->path == 0 && mfmag_ok && (order > 33 || (force && !strcmp(force, "mfmag")))) h->path = 3;
       // a forced formulation is a preference: plans it cannot serve fall back to the default choice
       if (force && !strcmp(force, "mfma16") && mfma16_ok) h->path = 2;
       if (h->path == 2) {
         h->S = (2 * order + 14 + 63) / 64;
         h->OP = 32 * h->S - 7;
-      } else if (h->path == 1) {
+      } else if (h->path == 1 || h->path == 3) {
         h->S = order <= 17 ? 2 : order <= 33 ? 3 : order <= 65 ? 5 : order <= 129 ? 9 : 17;
         h->OP = 16 * (h->S - 1) + 1;
       } else {
@@ -973,11 +1122,19 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
       }
       h->HH = h->OP;   // one more than the FIR needs: reset(keep_history) must see the whole ring
       h->CG = CG; h->ovl = ovl; h->OG = CG - ovl;
-      if (h->path >= 1) { h->OG = 4 * (64 - ovl); h->CG = h->OG + ovl; }   // every wave recomputes its own FM overlap group
+      if (h->path == 1 || h->path == 2) { h->OG = 4 * (64 - ovl); h->CG = h->OG + ovl; }   // every wave recomputes its own FM overlap group
       h->fast8 = (decim == R);
       if (h->path == 2) {
         const size_t PLW = (2 * (size_t)(TI + h->OP) + 64 + 15) / 16 * 4;
         h->lds_bytes = (4 * PLW + 256) * 4;
+      } else if (h->path == 3) {
+        const size_t PLW = (2 * (size_t)(TI + h->OP) + 64 + 31) / 32 * 8;
+        h->lds_bytes = (2 * PLW + 256) * 4 + (size_t)h->S * 2 * 64 * 16 + (size_t)(TI + TI / 16 + 2) * 8 + 2 * (size_t)((CG + 3) & ~3) * 4;
+        if (h->lds_bytes > 64 * 1024) {   // (decimation 1 with 17 K steps): back to the VALU kernel
+          h->path = 0; h->OP = (int)ceil_div((size_t)order, (size_t)TAPC) * TAPC; h->HH = h->OP;
+          const size_t XS = TI + h->OP + 8;
+          h->lds_bytes = (XS + 256 + 2 * ((CG + 3) & ~3)) * 4 + (h->fast8 ? 0 : (size_t)TI * 8);
+        }
       } else if (h->path == 1) {
         const size_t PLW = (2 * (size_t)(TI + h->OP) + 64 + 31) / 32 * 8;
         h->lds_bytes = (4 * PLW + 256) * 4 + (size_t)h->S * 2 * 64 * 16;
@@ -995,7 +1152,7 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
         tp[pad + i].x = ((uint32_t)(uint16_t)(int16_t)kr) | ((uint32_t)(uint16_t)(int16_t)(-ki) << 16);
         tp[pad + i].y = ((uint32_t)(uint16_t)(int16_t)ki) | ((uint32_t)(uint16_t)(int16_t)kr << 16);
       }
-      if (h->path >= 1) {
+      if (h->path >= 1) {   // (a path 3 plan that fell back to the VALU kernel above has path 0 by now)
         // interleaved tap vectors a_comp[2i+c] and their Toeplitz fragments, TapT[m][k] = a_comp[k-2t], m = 2t+comp:
         // 32x32x32: lane (m = l&31, hh = l>>5), byte j of K-step s <-> k = 32s+16hh+j
         // 16x16x64: lane (m = l&15, g  = l>>4), byte j of K-step s <-> k = 64s+16g+j

@@ -33,14 +33,14 @@ def ctx():
     c.close()
 
 
-@pytest.fixture(params=["auto", "valu", "mfma16"])
+@pytest.fixture(params=["auto", "valu", "mfma16", "mfmag"])
 def k1path(request, monkeypatch):
     """K1 has two bit-exact formulations: the int8-MFMA kernel (picked automatically for decim 8, order <= 257)
     and the VALU dot2 kernel (everything else); every K1 test runs with both selections."""
     if request.param == "valu":
         monkeypatch.setenv("SDRHIP_IQBB_PATH", "valu")
-    elif request.param == "mfma16":
-        monkeypatch.setenv("SDRHIP_IQBB_PATH", "mfma16")
+    elif request.param in ("mfma16", "mfmag"):   # preferences: plans they cannot serve fall back to the default choice
+        monkeypatch.setenv("SDRHIP_IQBB_PATH", request.param)
     else:
         monkeypatch.delenv("SDRHIP_IQBB_PATH", raising=False)
     return request.param
@@ -140,7 +140,8 @@ def test_iqbb_path_selection(ctx, golden, monkeypatch):
     monkeypatch.delenv("SDRHIP_IQBB_PATH", raising=False)
     taps, lut = golden.load("g3_iqbb127d8_taps"), golden.load("g3_iqbb127d8_lut")
     assert sa.IQBaseBandI16(ctx, taps, lut, 1365, 0, 8).path == 1          # north-star chain -> MFMA
-    assert sa.IQBaseBandI16(ctx, taps, lut, 1365, 0, 5).path == 0          # other decimations -> VALU
+    assert sa.IQBaseBandI16(ctx, taps, lut, 1365, 0, 5).path == 3          # other decimations, long filter -> MFMA + LDS windows
+    assert sa.IQBaseBandI16(ctx, golden.load("g8_o21_d3_taps"), lut, 1365, 0, 3).path == 0   # short filter -> VALU
     assert sa.IQBaseBandI16(ctx, golden.load("g8_o255_d8_taps"), lut, 1365, 0, 8).path == 1   # 17 K steps
     assert sa.IQBaseBandI16(ctx, sa.design_iqbb_taps(100e3, 50e3, FS, 300), lut, 1365, 0, 8).path == 0   # order > 257
     big = np.array(taps).reshape(-1, 2).copy(); big[5, 0] = 32700          # high byte would not fit int8
@@ -149,7 +150,10 @@ def test_iqbb_path_selection(ctx, golden, monkeypatch):
     assert sa.IQBaseBandI16(ctx, taps, lut, 1365, 0, 8).path == 0
     monkeypatch.setenv("SDRHIP_IQBB_PATH", "mfma16")
     assert sa.IQBaseBandI16(ctx, taps, lut, 1365, 0, 8).path == 2
-    assert sa.IQBaseBandI16(ctx, taps, lut, 1365, 0, 5).path == 0          # a preference, not a requirement
+    assert sa.IQBaseBandI16(ctx, taps, lut, 1365, 0, 5).path == 3          # a preference, not a requirement
+    monkeypatch.setenv("SDRHIP_IQBB_PATH", "mfmag")
+    assert sa.IQBaseBandI16(ctx, golden.load("g8_o21_d3_taps"), lut, 1365, 0, 3).path == 3
+    assert sa.IQBaseBandI16(ctx, taps, lut, 1365, 0, 8).path == 1
 
 
 def test_iqbb_reset_semantics(ctx, orc, golden, k1path):
