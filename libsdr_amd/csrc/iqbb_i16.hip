@@ -54,6 +54,7 @@ struct IqbbArgs {
   void *out; long out_stride; int epilogue;
   const v4i *tapfrag; int cre, cim;
   unsigned ah_mask;   // bit s: the high-byte tap fragments of K step s are not all zero (small outer taps: |a| < 128)
+  int lpg;          // path 3: lanes that share one box window
   int tiles, tpw;   // tiles per channel in this call; consecutive tiles walked by one workgroup (MFMA path)   // MFMA path: tap fragments, 128*sum(a) per component
 };
 
@@ -702,16 +703,26 @@ __global__ __launch_bounds__(TPB, 3) void iqbb_i16_mfmag_kernel(const IqbbArgs a
   __syncthreads();
 
   // ---- box sums per group, truncating division, state (as the VALU kernel) ----
-  for (int ql = tid; ql < groups_here; ql += TPB) {
-    const int q = q0 + ql;
-    if (q < 0) continue;                      // tile 0's overlap slot precedes the call
-    int2 s = make_int2(0, 0);
-    for (int k = 0; k < a.D; k++) {
-      const int2 v = vbuf[PADV(ql * a.D + k)];
-      s.x = (int)((unsigned)s.x + (unsigned)v.x);
-      s.y = (int)((unsigned)s.y + (unsigned)v.y);
+  // `lpg` lanes (a power of two <= 64, about D/8) share one window: strided partial sums, then a butterfly over them
+  {
+    const int lpg = a.lpg, sub = tid & (lpg - 1), gpp = TPB / lpg;
+    for (int g0 = 0; g0 < groups_here; g0 += gpp) {
+      const int ql = g0 + tid / lpg, q = q0 + ql;
+      int2 s = make_int2(0, 0);
+      if (ql < groups_here) {
+        for (int k = sub; k < a.D; k += lpg) {
+          const int2 v = vbuf[PADV(ql * a.D + k)];
+          s.x = (int)((unsigned)s.x + (unsigned)v.x);
+          s.y = (int)((unsigned)s.y + (unsigned)v.y);
+        }
+      }
+      for (int m = lpg >> 1; m >= 1; m >>= 1) {
+        s.x = (int)((unsigned)s.x + (unsigned)__shfl_xor(s.x, m));
+        s.y = (int)((unsigned)s.y + (unsigned)__shfl_xor(s.y, m));
+      }
+      if (sub == 0 && ql < groups_here && q >= 0)   // (tile 0's overlap slot precedes the call)
+        finalize_group(a, c, lut_s, ybuf, ql, q, s, a.D);
     }
-    finalize_group(a, c, lut_s, ybuf, ql, q, s, a.D);
   }
   __syncthreads();
   epilogue_and_roll(a, c, tile, tid, q0, groups_here, ybuf);
@@ -1009,6 +1020,7 @@ struct sdrhip_iqbb_i16 {
     if (path == 1 || path == 2) { tpw = 8; while (tpw > 1 && (size_t)ceil_div((size_t)tiles, (size_t)tpw) * C < 2048) tpw >>= 1; }
     { const char *t = getenv("SDRHIP_IQBB_TPW"); if (t && (path == 1 || path == 2)) tpw = std::max(1, atoi(t)); }   // tuning hook
     a.tiles = tiles; a.tpw = tpw;
+    a.lpg = 1; while (a.lpg < 64 && a.lpg * 8 < D) a.lpg <<= 1;
     dim3 grid((unsigned)ceil_div((size_t)tiles, (size_t)tpw), C), block(TPB);
     if (path == 3) {
       dim3 grid3((unsigned)tiles, C);

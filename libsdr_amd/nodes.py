@@ -200,7 +200,7 @@ class IQBaseBandI16(_Node):
 
     @property
     def path(self):
-        """0 = VALU dot2 kernel, 1 = int8-MFMA kernel."""
+        """0 = VALU dot2 kernel, 1 = int8-MFMA 32x32x32 (decim 8), 2 = int8-MFMA 16x16x64 (decim 8), 3 = int8-MFMA, any decim."""
         v = C.c_int(0)
         check(abi.lib().sdrhip_iqbb_i16_path(self._h, C.byref(v)))
         return v.value
