@@ -97,7 +97,7 @@ def synth_channels(orc, C, N, seed=0x5D2):
 
 @pytest.mark.parametrize("epi", [sa.EPI_NONE, sa.EPI_FM, sa.EPI_AM, sa.EPI_USB])
 @pytest.mark.parametrize("order,decim,Fc", [(127, 8, 100e3), (21, 8, -100e3), (33, 5, 100e3), (16, 1, 50e3),
-                                             (129, 8, 0.0), (64, 8, 30e3), (9, 8, -250e3), (1, 8, 100e3), (150, 8, 70e3), (257, 8, 100e3), (200, 8, -40e3)])
+                                             (129, 8, 0.0), (64, 8, 30e3), (9, 8, -250e3), (1, 8, 100e3), (150, 8, 70e3), (257, 8, 100e3), (200, 8, -40e3), (129, 5, 100e3), (200, 3, -60e3), (64, 12, 30e3)])
 def test_iqbb_batched_vs_oracle(ctx, orc, epi, order, decim, Fc, k1path):
     C, chunks = 5, [8192, 3000, 1, 7, 5000, 8192]
     taps = sa.design_iqbb_taps(Fc, 50e3, FS, order)
