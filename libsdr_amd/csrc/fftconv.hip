@@ -217,6 +217,11 @@ __global__ __launch_bounds__(FT) void fftconv_kernel(const ConvArgs a) {
   }
 }
 
+// value of the neighbouring lane (lane ^ 1): DPP quad_perm [1,0,3,2]
+__device__ __forceinline__ float lane_xor1(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true));
+}
+
 // Fused form of the same convolution (plans whose first pass is radix 16 and that have at least two passes, i.e.
 // every L >= 32): the first forward pass takes its 16 inputs per butterfly straight from global memory (history /
 // call input / zeros) and the last inverse pass stores its outputs straight to global memory — lanes walk
@@ -244,10 +249,29 @@ __global__ __launch_bounds__(FT) void fftconv_fused_kernel(const ConvArgs a) {
   // ---- forward pass 0 (radix 16, stride L/16): global -> registers -> LDS ----
   {
     const int s = L / 16;
+    // interior, 16-byte aligned block: a lane pair loads 16 bytes per lane (elements j&~1, (j&~1)+1 of every other k)
+    // and swaps halves — 8 dwordx4 loads per lane instead of 16 dwordx2 (the per-CU load/store issue rate, not
+    // HBM, bounded these phases)
+    const float2 *src = a.in + (long)c * a.in_stride + first;
+    const bool vec_in = first >= 0 && first + L <= a.N && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && (s & 1) == 0 && s >= FT;
     for (int j = tid; j < s; j += FT) {
       float2 v[16], w[16];
+      if (vec_in) {
+        const int odd = j & 1, je = j & ~1;
 #pragma unroll
-      for (int k = 0; k < 16; k++) v[k] = conv_fetch(a, c, first + j + k * s);
+        for (int m = 0; m < 8; m++) {
+          const float4 q = *reinterpret_cast<const float4 *>(src + je + (2 * m + odd) * s);   // (E[k], O[k]), k = 2m + odd
+          // even lane keeps E[2m] = q.xy and needs E[2m+1] = the odd lane's q.xy; odd lane keeps O[2m+1] = q.zw and
+          // needs O[2m] = the even lane's q.zw
+          const float gx = odd ? q.x : q.z, gy = odd ? q.y : q.w;
+          const float rx = lane_xor1(gx), ry = lane_xor1(gy);
+          v[2 * m] = odd ? make_float2(rx, ry) : make_float2(q.x, q.y);
+          v[2 * m + 1] = odd ? make_float2(q.z, q.w) : make_float2(rx, ry);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = conv_fetch(a, c, first + j + k * s);
+      }
       dft16<-1>(v);
       twiddles16(p, 0, s, j, w);
 #pragma unroll
@@ -366,10 +390,26 @@ __global__ __launch_bounds__(FT) void fftconv_fused_kernel(const ConvArgs a) {
 #pragma unroll
       for (int k = 1; k < 16; k++) v[k] = cmulc(v[k], w[k]);
       dft16<1>(v);
+      float2 *dst = a.out + (long)c * a.out_stride + o0 - a.HH;   // element i of the block goes to dst[i] (i >= HH)
+      const bool vec_out = ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) && (s & 1) == 0 && (a.HH & 1) == 0 && s >= FT &&
+                           o0 + (L - a.HH) <= a.N;
+      if (vec_out) {   // lane pairs swap halves and store 16 bytes per lane: 8 dwordx4 stores instead of 16 dwordx2
+        const int odd = j & 1, je = j & ~1;
 #pragma unroll
-      for (int k = 0; k < 16; k++) {
-        const int i = j + k * s - a.HH, o = o0 + i;
-        if (i >= 0 && o < a.N) a.out[(long)c * a.out_stride + o] = v[k];
+        for (int m = 0; m < 8; m++) {
+          // even lane stores (E[2m], O[2m]), odd lane stores (E[2m+1], O[2m+1])
+          const float2 give = odd ? v[2 * m] : v[2 * m + 1];
+          const float rx = lane_xor1(give.x), ry = lane_xor1(give.y);
+          const float4 q = odd ? make_float4(rx, ry, v[2 * m + 1].x, v[2 * m + 1].y) : make_float4(v[2 * m].x, v[2 * m].y, rx, ry);
+          const int i = je + (2 * m + odd) * s;
+          if (i >= a.HH) *reinterpret_cast<float4 *>(dst + i) = q;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          const int i = j + k * s - a.HH, o = o0 + i;
+          if (i >= 0 && o < a.N) a.out[(long)c * a.out_stride + o] = v[k];
+        }
       }
     }
   }
