@@ -290,6 +290,25 @@ def test_cu8_long_calls_vs_oracle(ctx, orc, epi, k1path):
         off += n
 
 
+def test_cu8_other_decimation_vs_oracle(ctx, orc, k1path):
+    """complex<uint8> input through the any-decimation MFMA path (65 taps, D = 5) and, with k1path = valu, the VALU kernel."""
+    rng = np.random.default_rng(8)
+    C, chunks = 2, [9000, 4101, 3]
+    u = rng.integers(0, 256, size=(C, sum(chunks), 2), dtype=np.uint8)
+    taps = sa.design_iqbb_taps(-60e3, 40e3, FS, 65)
+    lut, inc = sa.design_freqshift_lut_i16(), sa.design_freqshift_inc(-60e3, FS)
+    node = sa.IQBaseBandI16(ctx, taps, lut, inc, True, 5, channels=C, max_in=9000, epilogue=sa.EPI_USB)
+    node.set_input_format(sa.abi.IN_CU8)
+    assert node.path == (0 if k1path == "valu" else 3)
+    refs = [orc.IQBaseBandI16(taps, lut, inc, True, 5) for _ in range(C)]
+    off = 0
+    for n in chunks:
+        y = node.process(u[:, off:off + n])
+        for c in range(C):
+            assert np.array_equal(y[c], orc.usb_i16(refs[c].process(orc.autocast_cu8_cs16(u[c, off:off + n]))))
+        off += n
+
+
 @pytest.mark.parametrize("rate", [125000, 48000])
 def test_fmdeemph_golden_and_batched(ctx, golden, orc, rate):
     x = golden.load("g9_deemph_in")
@@ -505,6 +524,23 @@ def test_fftconv_ols_4097_vs_reference_fir(ctx, golden):
     x = golden.load("g1_iq_cf32")
     y = np.concatenate([node.process(x[i * 4096:(i + 1) * 4096])[0] for i in range(3)])
     assert rel_err(y, golden.load("g6_fir4097_cf32_out")) <= RTOL
+
+
+def test_fftconv_ols_even_taps_odd_hop(ctx, orc):
+    """Overlap-save with an even tap count: hop = L - n_taps + 1 is odd, so blocks start on every alignment (the
+    16-byte load/store variants of the first and last pass must step aside)."""
+    rng = np.random.default_rng(12)
+    n_taps, L, C = 1000, 16384, 3
+    h = (rng.standard_normal((n_taps, 2)) * 0.05).astype(np.float32)
+    x = (rng.standard_normal((C, 40000, 2)) * 0.3).astype(np.float32)
+    node = sa.FFTConv(ctx, sa.FFTCONV_OLS, L, h, channels=C, max_in=40000)
+    y = np.concatenate([node.process(x[:, :25000]), node.process(x[:, 25000:])], axis=1)
+    hc = h[:, 0].astype(np.float64) + 1j * h[:, 1]
+    for c in range(C):
+        xc = x[c, :, 0].astype(np.float64) + 1j * x[c, :, 1]
+        ref = np.convolve(xc, hc)[:40000]
+        got = y[c, :, 0] + 1j * y[c, :, 1]
+        assert np.abs(got - ref).max() / np.abs(ref).max() <= RTOL
 
 
 def test_fftconv_matches_time_domain_kernel(ctx, golden):
