@@ -593,13 +593,15 @@ def test_fir_cf32_long_calls_vs_oracle(ctx, golden, orc, D, epi):
                 assert rel_err(y[c], ref) <= RTOL
 
 
-def test_float_baseband_full_buffers_vs_oracle(ctx, golden, orc):
-    """BASELINE config 2 at its buffer size: 65536-sample calls (interior tiles, phasor advanced across tiles and calls)."""
+@pytest.mark.parametrize("D", [8, 5])
+def test_float_baseband_full_buffers_vs_oracle(ctx, golden, orc, D):
+    """BASELINE config 2 at its buffer size: 65536-sample calls (interior tiles, phasor advanced across tiles and calls);
+    D = 5 takes the generic-decimation instance of the kernel."""
     alpha = golden.load("g2_firlp_alpha127")
     rng = np.random.default_rng(11)
     C, N = 2, 65536
-    node = sa.FloatBaseBand(ctx, 100e3, FS, alpha, 8, channels=C, max_in=N)
-    firs, subs = [orc.FIR(alpha) for _ in range(C)], [orc.SubSample(8) for _ in range(C)]
+    node = sa.FloatBaseBand(ctx, 100e3, FS, alpha, D, channels=C, max_in=N)
+    firs, subs = [orc.FIR(alpha) for _ in range(C)], [orc.SubSample(D) for _ in range(C)]
     n0 = 0
     for n in (N, N, 12345):
         x = (rng.standard_normal((C, n, 2)) * 0.3).astype(np.float32)
