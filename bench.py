@@ -41,6 +41,7 @@ def parse():
     p.add_argument("--samples", type=int, default=65536, help="samples per channel per step")
     p.add_argument("--workload", default="iqbb_fm")
     p.add_argument("--decim", type=int, default=8, help="iqbb_* workloads: decimation D (8 = the BASELINE configs)")
+    p.add_argument("--order", type=int, default=127, help="iqbb_* workloads: FIR order (127 = the BASELINE configs)")
     p.add_argument("--batches", type=int, default=3, help="distinct input batches rotated through (defeats the 256 MiB L3)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for single-GPU dry runs)")
@@ -166,7 +167,7 @@ def main():
         ctx = sa.Context(local, stream=stream.cuda_stream)
 
         # ---- config(): design on rank 0, broadcast over RCCL (KBs; outside the timed region) ----
-        order, D = 127, a.decim
+        order, D = a.order, a.decim
         wl = a.workload
         if wl in ("iqbb_fm", "iqbb_usb", "iqbb_fm_cu8"):
             taps = torch.from_numpy(sa.design_iqbb_taps(100e3, 50e3, FS, order)).to(dev)
@@ -185,7 +186,7 @@ def main():
             run = lambda b: node.process_dev(ins[b].data_ptr(), N, N, outs.data_ptr(), n_out)
             dtype = "i16"
             kernel = {1: "iqbb_i16_mfma_kernel", 2: "iqbb_i16_mfma16_kernel", 3: "iqbb_i16_mfmag_kernel"}.get(node.path, "iqbb_i16_kernel")
-            desc = "IQBaseBand<int16>(127-tap Q14 FIR, LUT shift 100 kHz, /%d) -> %s" % (D, "USBDemod" if wl == "iqbb_usb" else "FMDemod")
+            desc = "IQBaseBand<int16>(%d-tap Q14 FIR, LUT shift 100 kHz, /%d) -> %s" % (order, D, "USBDemod" if wl == "iqbb_usb" else "FMDemod")
             if wl == "iqbb_fm_cu8":
                 desc = "complex<uint8> -> AutoCast + " + desc
         elif wl in ("fir255_fm", "fir127_fm"):

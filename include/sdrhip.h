@@ -133,7 +133,7 @@ int sdrhip_iqbb_i16_create(sdrhip_ctx *ctx, const int32_t *taps, int order, cons
 /* which kernel formulation the plan selected: 0 = VALU v_dot2c_i32_i16 (any decim/order), 1 = int8-MFMA
  * block-Toeplitz GEMM on 32x32x32 tiles (decim 8, order <= 257), 2 = the same on 16x16x64 tiles with an
  * in-wave MFMA/VALU pipeline (decim 8, order <= 153), 3 = the 32x32x32 matrix part for any other decimation with
- * the box windows summed through LDS (order 34..257; shorter filters stay on the VALU kernel); all bit-exact. Environment variable
+ * the box windows summed through LDS (order <= 257); all bit-exact. Environment variable
  * SDRHIP_IQBB_PATH=valu|mfma|mfma16|mfmag states a preference at create time (tests, tuning). */
 int sdrhip_iqbb_i16_path(sdrhip_iqbb_i16 *h, int *path);
 /* outputs the next call of n_in samples will produce (does not advance the state) */

@@ -1114,13 +1114,13 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
         if (high_byte(taps[i]) > 127 || high_byte(-taps[i]) > 127) mfma16_ok = false;
       if (force && !strcmp(force, "valu")) mfma16_ok = false;
       h->path = mfma_ok ? 1 : (mfma16_ok ? 2 : 0);   // 32x32x32 measured 4 % faster than 16x16x64 at 127 taps
-      // path 3: the same matrix part for any decimation, windows summed through LDS; worth it from ~33 taps on
-      // (below that the VALU kernel's 2*order dot2 per sample are no more than the epilogue both paths share)
+      // path 3: the same matrix part for any decimation, windows summed through LDS (measured ahead of the VALU
+      // kernel at every order tried, 9 ... 257 taps)
       bool mfmag_ok = !real && decim != R && order <= 257 && TI / decim - ovl >= 1;
       for (int i = 0; i < 2 * order && mfmag_ok; i++)
         if (high_byte(taps[i]) > 127 || high_byte(-taps[i]) > 127) mfmag_ok = false;
       if (force && !strcmp(force, "valu")) mfmag_ok = false;
-      if (h->path == 0 && mfmag_ok && (order > 33 || (force && !strcmp(force, "mfmag")))) h->path = 3;
+      if (h->path == 0 && mfmag_ok) h->path = 3;
       // a forced formulation is a preference: plans it cannot serve fall back to the default choice
       if (force && !strcmp(force, "mfma16") && mfma16_ok) h->path = 2;
       if (h->path == 2) {

@@ -141,7 +141,7 @@ def test_iqbb_path_selection(ctx, golden, monkeypatch):
     taps, lut = golden.load("g3_iqbb127d8_taps"), golden.load("g3_iqbb127d8_lut")
     assert sa.IQBaseBandI16(ctx, taps, lut, 1365, 0, 8).path == 1          # north-star chain -> MFMA
     assert sa.IQBaseBandI16(ctx, taps, lut, 1365, 0, 5).path == 3          # other decimations, long filter -> MFMA + LDS windows
-    assert sa.IQBaseBandI16(ctx, golden.load("g8_o21_d3_taps"), lut, 1365, 0, 3).path == 0   # short filter -> VALU
+    assert sa.IQBaseBandI16(ctx, golden.load("g8_o21_d3_taps"), lut, 1365, 0, 3).path == 3
     assert sa.IQBaseBandI16(ctx, golden.load("g8_o255_d8_taps"), lut, 1365, 0, 8).path == 1   # 17 K steps
     assert sa.IQBaseBandI16(ctx, sa.design_iqbb_taps(100e3, 50e3, FS, 300), lut, 1365, 0, 8).path == 0   # order > 257
     big = np.array(taps).reshape(-1, 2).copy(); big[5, 0] = 32700          # high byte would not fit int8
