@@ -607,23 +607,21 @@ __global__ __launch_bounds__(TPB, 3) void iqbb_i16_mfmag_kernel(const IqbbArgs a
   int2 *vbuf = reinterpret_cast<int2 *>(smem + 256 + 2 * PLW + S * 2 * 64 * 4);
   uint32_t *ybuf = reinterpret_cast<uint32_t *>(vbuf + TI + TI / 16 + 2);
 
-  const int c = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+  const int c = blockIdx.y, tid = threadIdx.x;
   const int w = tid >> 6, l = tid & 63, n = l & 31, h = l >> 5;
-  const int q0 = tile * a.OG - a.ovl;    // first group (relative to the call's first group) of this tile
-  const int tb = a.base0_rel + q0 * a.D; // call-relative index of the tile's first sample
-  const int groups_here = min(a.CG, a.n_groups - q0);
   for (int i = tid; i < S * 2 * 64; i += TPB) taps_s[i] = a.tapfrag[i];
   if (tid < 128) lut_s[tid] = a.lut[tid];
 
-  // ---- stage the tile's TI + OP samples as byte planes (parity-split 16-byte chunks, as path 1) ----
-  {
-    constexpr int NQ = (TI + 16 * (S - 1) + 1 + 2 + 4 * TPB - 1) / (4 * TPB);
-    struct __attribute__((packed, aligned(4))) Quad { uint32_t v[4]; };
-    const int first = tb - (a.OP - 1);
-    const int quads = (TI + a.OP + 4) / 4;
+  // a workgroup walks `tpw` consecutive tiles; the next tile's samples are loaded into registers while this one is
+  // computed (16-byte loads, all in flight), so that HBM latency is not paid once per tile
+  constexpr int NQ = (TI + 16 * (S - 1) + 1 + 2 + 4 * TPB - 1) / (4 * TPB);
+  struct __attribute__((packed, aligned(4))) Quad { uint32_t v[4]; };
+  const int quads = (TI + a.OP + 4) / 4;
+  Quad px[NQ];
+  auto fetch = [&](int tile_) {
+    const int first = a.base0_rel + (tile_ * a.OG - a.ovl) * a.D - (a.OP - 1);
     const bool interior = !a.in_cu8 && first >= 0 && first + 4 * quads <= a.N;
     const uint32_t *src = a.in + (long)c * a.in_stride + first;
-    Quad px[NQ];
 #pragma unroll
     for (int k = 0; k < NQ; k++) {
       const int p = tid + k * TPB;
@@ -635,6 +633,17 @@ __global__ __launch_bounds__(TPB, 3) void iqbb_i16_mfmag_kernel(const IqbbArgs a
         }
       }
     }
+  };
+  const int tile_end = min((int)(blockIdx.x + 1) * a.tpw, a.tiles);
+  int tile = blockIdx.x * a.tpw;
+  if (tile < tile_end) fetch(tile);
+  for (; tile < tile_end; tile++) {
+  const int q0 = tile * a.OG - a.ovl;    // first group (relative to the call's first group) of this tile
+  const int tb = a.base0_rel + q0 * a.D; // call-relative index of the tile's first sample
+  const int groups_here = min(a.CG, a.n_groups - q0);
+
+  // ---- stage the tile's TI + OP samples as byte planes (parity-split 16-byte chunks, as path 1) ----
+  {
 #pragma unroll
     for (int k = 0; k < NQ; k++) {
       const int p = tid + k * TPB;
@@ -651,6 +660,7 @@ __global__ __launch_bounds__(TPB, 3) void iqbb_i16_mfmag_kernel(const IqbbArgs a
     }
   }
   __syncthreads();
+  if (tile + 1 < tile_end) fetch(tile + 1);   // in flight during the matrix work and the window sums below
 
   // ---- the FIR at this wave's 512 samples (blocks 32w .. 32w+31 of the tile) ----
   {
@@ -726,6 +736,7 @@ __global__ __launch_bounds__(TPB, 3) void iqbb_i16_mfmag_kernel(const IqbbArgs a
   }
   __syncthreads();
   epilogue_and_roll(a, c, tile, tid, q0, groups_here, ybuf);
+  }   // (the next tile's planes / vbuf / ybuf writes are each separated from this tile's reads by one of its barriers)
 }
 
 // =================================================================================================
@@ -1023,7 +1034,10 @@ struct sdrhip_iqbb_i16 {
     a.lpg = 1; while (a.lpg < 64 && a.lpg * 8 < D) a.lpg <<= 1;
     dim3 grid((unsigned)ceil_div((size_t)tiles, (size_t)tpw), C), block(TPB);
     if (path == 3) {
-      dim3 grid3((unsigned)tiles, C);
+      int tpw3 = 8; while (tpw3 > 1 && (size_t)ceil_div((size_t)tiles, (size_t)tpw3) * C < 2048) tpw3 >>= 1;
+      { const char *t = getenv("SDRHIP_IQBB_TPW"); if (t) tpw3 = std::max(1, atoi(t)); }   // tuning hook
+      a.tpw = tpw3;
+      dim3 grid3((unsigned)ceil_div((size_t)tiles, (size_t)tpw3), C);
 #define SDRHIP_MFG(S_) do { if (inc != 0) hipLaunchKernelGGL((iqbb_i16_mfmag_kernel<S_, true>), grid3, block, lds_bytes, ctx->stream, a); \
                              else hipLaunchKernelGGL((iqbb_i16_mfmag_kernel<S_, false>), grid3, block, lds_bytes, ctx->stream, a); } while (0)
       switch (S) {
