@@ -596,7 +596,7 @@ __global__ __launch_bounds__(TPB, CU8 ? 5 : 4) void iqbb_i16_mfma_kernel(const I
 // =================================================================================================
 __device__ __forceinline__ int PADV(int p) { return p + (p >> 4); }
 
-template <int S, bool ROT>
+template <int S, bool ROT, bool CU8>   // CU8: complex<uint8> input, one byte plane (see path 1)
 __global__ __launch_bounds__(TPB, 3) void iqbb_i16_mfmag_kernel(const IqbbArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int PLW = (2 * (TI + a.OP) + 64 + 31) / 32 * 8;    // dwords per byte plane
@@ -620,13 +620,32 @@ __global__ __launch_bounds__(TPB, 3) void iqbb_i16_mfmag_kernel(const IqbbArgs a
   Quad px[NQ];
   auto fetch = [&](int tile_) {
     const int first = a.base0_rel + (tile_ * a.OG - a.ovl) * a.D - (a.OP - 1);
-    const bool interior = !a.in_cu8 && first >= 0 && first + 4 * quads <= a.N;
+    const bool interior = first >= 0 && first + 4 * quads <= a.N;
+    if (CU8) {   // px[k].v[0..1] = the 8 high-plane bytes of 4 samples
+      struct __attribute__((packed, aligned(2))) Oct { uint32_t v[2]; };
+      const uint16_t *src8 = reinterpret_cast<const uint16_t *>(a.in) + (long)c * a.in_stride + first;
+#pragma unroll
+      for (int k = 0; k < NQ; k++) {
+        const int p = tid + k * TPB;
+        if (p < quads) {
+          if (interior) {
+            const Oct o = *reinterpret_cast<const Oct *>(src8 + 4 * p);
+            px[k].v[0] = add129_bytes(o.v[0]); px[k].v[1] = add129_bytes(o.v[1]);
+          } else {
+            const uint32_t x0 = load_x(a, c, first + 4 * p), x1 = load_x(a, c, first + 4 * p + 1);
+            const uint32_t x2 = load_x(a, c, first + 4 * p + 2), x3 = load_x(a, c, first + 4 * p + 3);
+            px[k].v[0] = __builtin_amdgcn_perm(x1, x0, 0x07050301u); px[k].v[1] = __builtin_amdgcn_perm(x3, x2, 0x07050301u);
+          }
+        }
+      }
+      return;
+    }
     const uint32_t *src = a.in + (long)c * a.in_stride + first;
 #pragma unroll
     for (int k = 0; k < NQ; k++) {
       const int p = tid + k * TPB;
       if (p < quads) {
-        if (interior) px[k] = *reinterpret_cast<const Quad *>(src + 4 * p);
+        if (interior && !a.in_cu8) px[k] = *reinterpret_cast<const Quad *>(src + 4 * p);
         else {
 #pragma unroll
           for (int j = 0; j < 4; j++) px[k].v[j] = load_x(a, c, first + 4 * p + j);
@@ -649,13 +668,17 @@ __global__ __launch_bounds__(TPB, 3) void iqbb_i16_mfmag_kernel(const IqbbArgs a
       const int p = tid + k * TPB;
       if (p < quads) {
         const int d = (((p >> 1) & 1) * (PLW >> 1)) + ((p >> 2) << 2) + ((p & 1) << 1);
-        uint2 l2, h2;
-        l2.x = __builtin_amdgcn_perm(px[k].v[1], px[k].v[0], 0x06040200u) ^ 0x80808080u;
-        l2.y = __builtin_amdgcn_perm(px[k].v[3], px[k].v[2], 0x06040200u) ^ 0x80808080u;
-        h2.x = __builtin_amdgcn_perm(px[k].v[1], px[k].v[0], 0x07050301u);
-        h2.y = __builtin_amdgcn_perm(px[k].v[3], px[k].v[2], 0x07050301u);
-        *reinterpret_cast<uint2 *>(lo + d) = l2;
-        *reinterpret_cast<uint2 *>(hi + d) = h2;
+        if (CU8) {
+          *reinterpret_cast<uint2 *>(hi + d) = make_uint2(px[k].v[0], px[k].v[1]);
+        } else {
+          uint2 l2, h2;
+          l2.x = __builtin_amdgcn_perm(px[k].v[1], px[k].v[0], 0x06040200u) ^ 0x80808080u;
+          l2.y = __builtin_amdgcn_perm(px[k].v[3], px[k].v[2], 0x06040200u) ^ 0x80808080u;
+          h2.x = __builtin_amdgcn_perm(px[k].v[1], px[k].v[0], 0x07050301u);
+          h2.y = __builtin_amdgcn_perm(px[k].v[3], px[k].v[2], 0x07050301u);
+          *reinterpret_cast<uint2 *>(lo + d) = l2;
+          *reinterpret_cast<uint2 *>(hi + d) = h2;
+        }
       }
     }
   }
@@ -664,9 +687,11 @@ __global__ __launch_bounds__(TPB, 3) void iqbb_i16_mfmag_kernel(const IqbbArgs a
 
   // ---- the FIR at this wave's 512 samples (blocks 32w .. 32w+31 of the tile) ----
   {
-    v16i acc_hh = {0}, acc_mid = {0}, acc_ll;
+    v16i acc_hh = {0}, acc_mid = {0}, acc_ll = {0};
+    if (!CU8) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) acc_ll[r] = (r & 1) ? a.cim : a.cre;   // + 128*sum(a) rides in as C
+      for (int r = 0; r < 16; r++) acc_ll[r] = (r & 1) ? a.cim : a.cre;   // + 128*sum(a) rides in as C
+    }
     const int cw = 64 * w;   // the wave's first chunk (8 samples) within the tile
     const int coff = ((cw + h) & 1) * (2 * PLW) + 16 * (((cw + h) >> 1) + n);
     const char *pl = reinterpret_cast<const char *>(lo) + coff;
@@ -675,14 +700,18 @@ __global__ __launch_bounds__(TPB, 3) void iqbb_i16_mfmag_kernel(const IqbbArgs a
     for (int s = 0; s < S; s++) {
       const bool has_ah = (a.ah_mask >> s) & 1;
       const v4i uh = *reinterpret_cast<const v4i *>(ph + 16 * s);
-      const v4i ul = *reinterpret_cast<const v4i *>(pl + 16 * s);
       const v4i Al = taps_s[(2 * s + 1) * 64 + l];
       acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, uh, acc_mid, 0, 0, 0);
-      acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, ul, acc_ll, 0, 0, 0);
-      if (has_ah) {
-        const v4i Ah = taps_s[(2 * s) * 64 + l];
-        acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, uh, acc_hh, 0, 0, 0);
-        acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, ul, acc_mid, 0, 0, 0);
+      if (CU8) {
+        if (has_ah) acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(taps_s[(2 * s) * 64 + l], uh, acc_hh, 0, 0, 0);
+      } else {
+        const v4i ul = *reinterpret_cast<const v4i *>(pl + 16 * s);
+        acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, ul, acc_ll, 0, 0, 0);
+        if (has_ah) {
+          const v4i Ah = taps_s[(2 * s) * 64 + l];
+          acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, uh, acc_hh, 0, 0, 0);
+          acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, ul, acc_mid, 0, 0, 0);
+        }
       }
     }
     // recombine, >>14, rotate, mask samples outside the call, park in vbuf
@@ -695,9 +724,14 @@ __global__ __launch_bounds__(TPB, 3) void iqbb_i16_mfmag_kernel(const IqbbArgs a
       const int rr = 4 * (k >> 1) + 2 * (k & 1), dk = 4 * (k >> 1) + (k & 1);
       unsigned tre = ((unsigned)acc_hh[rr] << 8) + (unsigned)acc_mid[rr];
       unsigned tim = ((unsigned)acc_hh[rr + 1] << 8) + (unsigned)acc_mid[rr + 1];
-      asm("" : "+v"(tre)); asm("" : "+v"(tim));
-      const unsigned sre = (tre << 8) + (unsigned)acc_ll[rr], sim = (tim << 8) + (unsigned)acc_ll[rr + 1];
-      int2 v = make_int2((int)sre >> 14, (int)sim >> 14);
+      int2 v;
+      if (CU8) {   // S = t << 8 exactly
+        v = make_int2((int)(tre << 8) >> 14, (int)(tim << 8) >> 14);
+      } else {
+        asm("" : "+v"(tre)); asm("" : "+v"(tim));
+        const unsigned sre = (tre << 8) + (unsigned)acc_ll[rr], sim = (tim << 8) + (unsigned)acc_ll[rr + 1];
+        v = make_int2((int)sre >> 14, (int)sim >> 14);
+      }
       if (ROT) {
         const uint32_t off = (((cnt0 + (uint32_t)dk * a.inc) >> 5) & (127u << 3)) ^ negx;
         const int2 L = *reinterpret_cast<const int2 *>(reinterpret_cast<const char *>(lut_s) + off);
@@ -1038,8 +1072,10 @@ struct sdrhip_iqbb_i16 {
       { const char *t = getenv("SDRHIP_IQBB_TPW"); if (t) tpw3 = std::max(1, atoi(t)); }   // tuning hook
       a.tpw = tpw3;
       dim3 grid3((unsigned)ceil_div((size_t)tiles, (size_t)tpw3), C);
-#define SDRHIP_MFG(S_) do { if (inc != 0) hipLaunchKernelGGL((iqbb_i16_mfmag_kernel<S_, true>), grid3, block, lds_bytes, ctx->stream, a); \
-                             else hipLaunchKernelGGL((iqbb_i16_mfmag_kernel<S_, false>), grid3, block, lds_bytes, ctx->stream, a); } while (0)
+#define SDRHIP_MFG(S_) do { if (in_cu8 && inc != 0) hipLaunchKernelGGL((iqbb_i16_mfmag_kernel<S_, true, true>), grid3, block, lds_bytes, ctx->stream, a); \
+                             else if (in_cu8) hipLaunchKernelGGL((iqbb_i16_mfmag_kernel<S_, false, true>), grid3, block, lds_bytes, ctx->stream, a); \
+                             else if (inc != 0) hipLaunchKernelGGL((iqbb_i16_mfmag_kernel<S_, true, false>), grid3, block, lds_bytes, ctx->stream, a); \
+                             else hipLaunchKernelGGL((iqbb_i16_mfmag_kernel<S_, false, false>), grid3, block, lds_bytes, ctx->stream, a); } while (0)
       switch (S) {
         case 2: SDRHIP_MFG(2); break;
         case 3: SDRHIP_MFG(3); break;
