@@ -35,8 +35,9 @@ def ctx():
 
 @pytest.fixture(params=["auto", "valu", "mfma16", "mfmag"])
 def k1path(request, monkeypatch):
-    """K1 has two bit-exact formulations: the int8-MFMA kernel (picked automatically for decim 8, order <= 257)
-    and the VALU dot2 kernel (everything else); every K1 test runs with both selections."""
+    """K1 has four bit-exact kernels: int8-MFMA on 32x32x32 tiles for decimation 8 (path 1, picked automatically up to
+    257 taps) and for any other decimation (path 3), the 16x16x64 shape (path 2, on request) and the VALU dot2 kernel
+    (path 0: real input, taps that do not fit, longer filters); every K1 test runs under each selection."""
     if request.param == "valu":
         monkeypatch.setenv("SDRHIP_IQBB_PATH", "valu")
     elif request.param in ("mfma16", "mfmag"):   # preferences: plans they cannot serve fall back to the default choice
