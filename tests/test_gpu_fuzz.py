@@ -1,0 +1,104 @@
+"""Seeded random sweep of K1 plans against the oracle: order, decimation, shift (sign / zero), epilogue, input format,
+channel count and ragged call lengths are drawn at random; whatever kernel the plan picks (VALU, MFMA 32x32x32 for
+D = 8, MFMA for any D, one-plane cu8 instantiations) must reproduce the reference arithmetic bit for bit."""
+import numpy as np
+import pytest
+
+import libsdr_amd as sa
+
+pytestmark = pytest.mark.gpu
+FS = 2.4e6
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = sa.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_iqbb_random_plans(ctx, orc, seed):
+    rng = np.random.default_rng(1000 + seed)
+    order = int(rng.choice([1, 2, 7, 16, 21, 33, 64, 65, 100, 127, 129, 130, 200, 257, 300]))
+    D = int(rng.choice([1, 2, 3, 5, 8, 8, 8, 12, 16, 83, 125, 300]))
+    Fc = float(rng.choice([0.0, 100e3, -100e3, 37e3, -250e3, 1.1e6]))
+    epi = int(rng.choice([sa.EPI_NONE, sa.EPI_FM, sa.EPI_AM, sa.EPI_USB]))
+    cu8 = bool(rng.integers(0, 2))
+    C = int(rng.choice([1, 2, 5]))
+    taps = sa.design_iqbb_taps(float(rng.choice([0.0, 100e3, -60e3])), float(rng.choice([12.5e3, 50e3, 200e3])), FS, order)
+    lut, inc = sa.design_freqshift_lut_i16(), sa.design_freqshift_inc(Fc, FS)
+    max_in = 9000
+    node = sa.IQBaseBandI16(ctx, taps, lut, inc, Fc < 0, D, channels=C, max_in=max_in, epilogue=epi)
+    if cu8:
+        node.set_input_format(sa.abi.IN_CU8)
+    refs = [orc.IQBaseBandI16(taps, lut, inc, Fc < 0, D) for _ in range(C)]
+    fms = [orc.FMDemodI16() for _ in range(C)]
+    lens = [int(x) for x in rng.choice([0, 1, 2, 7, 129, 1000, 2048, 4097, 8191, 9000], size=5)]
+    for n in lens:
+        if cu8:
+            x = rng.integers(0, 256, (C, n, 2), dtype=np.uint8)
+        else:
+            x = rng.integers(-32768, 32768, (C, n, 2), dtype=np.int16)
+        y = node.process(x)
+        for c in range(C):
+            r = refs[c].process(orc.autocast_cu8_cs16(x[c]) if cu8 else x[c])
+            if epi == sa.EPI_FM:
+                r = fms[c].process(r)
+            elif epi == sa.EPI_AM:
+                r = orc.am_i16(r)
+            elif epi == sa.EPI_USB:
+                r = orc.usb_i16(r)
+            assert y[c].shape == r.shape, (seed, order, D, Fc, epi, cu8, n, node.path)
+            assert np.array_equal(y[c], r), (seed, order, D, Fc, epi, cu8, n, node.path)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fir_cf32_random_plans(ctx, orc, seed):
+    """complex<float> FIR (+ folded SubSample, + AM / USB) at random orders, decimations and call lengths: <= 1e-5 relative."""
+    rng = np.random.default_rng(2000 + seed)
+    order = int(rng.choice([1, 2, 16, 63, 127, 255, 1000]))
+    D = int(rng.choice([1, 2, 3, 8, 8, 16, 50]))
+    epi = int(rng.choice([sa.EPI_NONE, sa.EPI_AM, sa.EPI_USB]))
+    C = int(rng.choice([1, 3]))
+    alpha = sa.design_fir_lowpass(order, float(rng.choice([50e3, 100e3, 400e3])), FS)
+    node = sa.FIR(ctx, sa.FIR_CF32, alpha, decim=D, channels=C, max_in=20000, epilogue=epi)
+    firs, subs = [orc.FIR(alpha) for _ in range(C)], [orc.SubSample(D) for _ in range(C)]
+    for n in [int(v) for v in rng.choice([0, 1, 5, 999, 4096, 12345, 20000], size=4)]:
+        x = (rng.standard_normal((C, n, 2)) * 0.3).astype(np.float32)
+        y = node.process(x)
+        for c in range(C):
+            ref = firs[c].process_cf32(x[c])
+            if D > 1:
+                ref = subs[c].process_cf32(ref)
+            if epi == sa.EPI_AM:
+                ref = orc.am_f32(ref)
+            elif epi == sa.EPI_USB:
+                ref = orc.usb_f32(ref)
+            assert y[c].shape == ref.shape, (seed, order, D, epi, n)
+            if ref.size:
+                err = np.abs(y[c].astype(np.float64) - ref).max() / max(np.abs(ref).max(), 1e-30)
+                assert err <= 1e-5, (seed, order, D, epi, n, err)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fftconv_random_plans(ctx, seed):
+    """Overlap-save at random FFT sizes / tap counts / call lengths against numpy's direct convolution (float64)."""
+    rng = np.random.default_rng(3000 + seed)
+    L = int(rng.choice([64, 256, 2048, 4096, 16384]))
+    n_taps = int(rng.integers(1, L // 2 + 1))
+    C = int(rng.choice([1, 2]))
+    h = (rng.standard_normal((n_taps, 2)) / np.sqrt(n_taps)).astype(np.float32)
+    node = sa.FFTConv(ctx, sa.FFTCONV_OLS, L, h, channels=C, max_in=30000)
+    lens = [int(v) for v in rng.choice([1, 100, 4097, 16384, 30000], size=3)]
+    x = (rng.standard_normal((C, sum(lens), 2)) * 0.3).astype(np.float32)
+    ys, off = [], 0
+    for n in lens:
+        ys.append(node.process(x[:, off:off + n])); off += n
+    y = np.concatenate(ys, axis=1)
+    hc = h[:, 0].astype(np.float64) + 1j * h[:, 1]
+    for c in range(C):
+        xc = x[c, :, 0].astype(np.float64) + 1j * x[c, :, 1]
+        ref = np.convolve(xc, hc)[:x.shape[1]]
+        got = y[c, :, 0] + 1j * y[c, :, 1]
+        assert np.abs(got - ref).max() / np.abs(ref).max() <= 1e-5, (seed, L, n_taps, lens)
