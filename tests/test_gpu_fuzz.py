@@ -102,3 +102,78 @@ def test_fftconv_random_plans(ctx, seed):
         ref = np.convolve(xc, hc)[:x.shape[1]]
         got = y[c, :, 0] + 1j * y[c, :, 1]
         assert np.abs(got - ref).max() / np.abs(ref).max() <= 1e-5, (seed, L, n_taps, lens)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fir_cs16_exact_random_plans(ctx, orc, seed):
+    """Exact per-tap-truncating complex<int16> FIR (+ FM / AM / USB) at random orders and ragged calls: bit-exact, including
+    tap sets whose partial sums can leave int16 (the wrap variant)."""
+    rng = np.random.default_rng(4000 + seed)
+    order = int(rng.choice([1, 3, 16, 63, 127, 255]))
+    epi = int(rng.choice([sa.EPI_NONE, sa.EPI_FM, sa.EPI_AM, sa.EPI_USB]))
+    C = int(rng.choice([1, 3]))
+    alpha = sa.design_fir_lowpass(order, float(rng.choice([50e3, 100e3, 600e3])), FS)
+    if seed % 4 == 3:
+        alpha = alpha * 2.5            # sum |alpha| > 1: partial sums may wrap
+    node = sa.FIR(ctx, sa.FIR_CS16_EXACT, alpha, channels=C, max_in=6000, epilogue=epi)
+    firs, fms = [orc.FIR(alpha) for _ in range(C)], [orc.FMDemodI16() for _ in range(C)]
+    for n in [int(v) for v in rng.choice([0, 1, 2, 777, 2048, 6000], size=4)]:
+        x = rng.integers(-32768, 32768, (C, n, 2), dtype=np.int16)
+        y = node.process(x)
+        for c in range(C):
+            r = firs[c].process_cs16(x[c])
+            if epi == sa.EPI_FM:
+                r = fms[c].process(r)
+            elif epi == sa.EPI_AM:
+                r = orc.am_i16(r)
+            elif epi == sa.EPI_USB:
+                r = orc.usb_i16(r)
+            assert y[c].shape == r.shape and np.array_equal(y[c], r), (seed, order, epi, n)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_real_baseband_random_plans(ctx, orc, seed):
+    rng = np.random.default_rng(5000 + seed)
+    order = int(rng.choice([1, 2, 21, 64, 127, 300]))
+    D = int(rng.choice([1, 3, 8, 12, 125]))
+    Fc = float(rng.choice([0.0, 100e3, -100e3, 333e3]))
+    epi = int(rng.choice([sa.EPI_NONE, sa.EPI_FM, sa.EPI_AM, sa.EPI_USB]))
+    C = int(rng.choice([1, 4]))
+    taps = sa.design_bb_taps(float(rng.choice([50e3, 100e3, 230e3])), float(rng.choice([20e3, 80e3])), 1e6, order)
+    lut, inc = sa.design_freqshift_lut_i16(), sa.design_freqshift_inc(Fc, 1e6)
+    node = sa.BaseBandI16(ctx, taps, lut, inc, Fc < 0, D, channels=C, max_in=5000, epilogue=epi)
+    refs, fms = [orc.BaseBandI16(taps, lut, inc, Fc < 0, D) for _ in range(C)], [orc.FMDemodI16() for _ in range(C)]
+    for n in [int(v) for v in rng.choice([0, 1, 9, 1000, 4097, 5000], size=4)]:
+        x = rng.integers(-32768, 32768, (C, n), dtype=np.int16)
+        y = node.process(x)
+        for c in range(C):
+            r = refs[c].process(x[c])
+            if epi == sa.EPI_FM:
+                r = fms[c].process(r)
+            elif epi == sa.EPI_AM:
+                r = orc.am_i16(r)
+            elif epi == sa.EPI_USB:
+                r = orc.usb_i16(r)
+            assert y[c].shape == r.shape and np.array_equal(y[c], r), (seed, order, D, Fc, epi, n)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_subsample_and_demods_random(ctx, orc, seed):
+    rng = np.random.default_rng(6000 + seed)
+    C, n_sub = int(rng.choice([1, 3])), int(rng.choice([1, 2, 3, 8, 100]))
+    sub = sa.SubSample(ctx, sa.T_CS16, n_sub, channels=C, max_in=5000)
+    subf = sa.SubSample(ctx, sa.T_CF32, n_sub, channels=C, max_in=5000)
+    fm = sa.Demod(ctx, sa.EPI_FM, sa.T_CS16, channels=C, max_in=5000, inplace_fm0=True)
+    refs, refsf, fms = [orc.SubSample(n_sub) for _ in range(C)], [orc.SubSample(n_sub) for _ in range(C)], [orc.FMDemodI16() for _ in range(C)]
+    for n in [int(v) for v in rng.choice([0, 1, 7, 1001, 4096, 5000], size=4)]:
+        x = rng.integers(-32768, 32768, (C, n, 2), dtype=np.int16)
+        xf = (rng.standard_normal((C, n, 2)) * 0.5).astype(np.float32)
+        y, yf = sub.process(x), subf.process(xf)
+        for c in range(C):
+            assert np.array_equal(y[c], refs[c].process_cs16(x[c]))
+            rf = refsf[c].process_cf32(xf[c])
+            assert yf[c].shape == rf.shape and (rf.size == 0 or np.abs(yf[c] - rf).max() <= 1e-5 * max(np.abs(rf).max(), 1e-30))
+        if n:
+            z = fm.process(x)
+            for c in range(C):
+                assert np.array_equal(z[c], fms[c].process(x[c]))
