@@ -1,10 +1,15 @@
 """Seeded random sweep of K1 plans against the oracle: order, decimation, shift (sign / zero), epilogue, input format,
 channel count and ragged call lengths are drawn at random; whatever kernel the plan picks (VALU, MFMA 32x32x32 for
 D = 8, MFMA for any D, one-plane cu8 instantiations) must reproduce the reference arithmetic bit for bit."""
+import os
+
 import numpy as np
 import pytest
 
 import libsdr_amd as sa
+
+# SDRHIP_FUZZ_EXTRA=N adds N more seeds to every sweep (soak runs; the default set is what CI needs)
+EXTRA = int(os.environ.get("SDRHIP_FUZZ_EXTRA", "0"))
 
 pytestmark = pytest.mark.gpu
 FS = 2.4e6
@@ -17,7 +22,7 @@ def ctx():
     c.close()
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(40 + EXTRA))
 def test_iqbb_random_plans(ctx, orc, seed):
     rng = np.random.default_rng(1000 + seed)
     order = int(rng.choice([1, 2, 7, 16, 21, 33, 64, 65, 100, 127, 129, 130, 200, 257, 300]))
@@ -53,7 +58,7 @@ def test_iqbb_random_plans(ctx, orc, seed):
             assert np.array_equal(y[c], r), (seed, order, D, Fc, epi, cu8, n, node.path)
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(16 + EXTRA))
 def test_fir_cf32_random_plans(ctx, orc, seed):
     """complex<float> FIR (+ folded SubSample, + AM / USB) at random orders, decimations and call lengths: <= 1e-5 relative."""
     rng = np.random.default_rng(2000 + seed)
@@ -81,7 +86,7 @@ def test_fir_cf32_random_plans(ctx, orc, seed):
                 assert err <= 1e-5, (seed, order, D, epi, n, err)
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(8 + EXTRA // 4))
 def test_fftconv_random_plans(ctx, seed):
     """Overlap-save at random FFT sizes / tap counts / call lengths against numpy's direct convolution (float64)."""
     rng = np.random.default_rng(3000 + seed)
@@ -104,7 +109,7 @@ def test_fftconv_random_plans(ctx, seed):
         assert np.abs(got - ref).max() / np.abs(ref).max() <= 1e-5, (seed, L, n_taps, lens)
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(10 + EXTRA))
 def test_fir_cs16_exact_random_plans(ctx, orc, seed):
     """Exact per-tap-truncating complex<int16> FIR (+ FM / AM / USB) at random orders and ragged calls: bit-exact, including
     tap sets whose partial sums can leave int16 (the wrap variant)."""
@@ -131,7 +136,7 @@ def test_fir_cs16_exact_random_plans(ctx, orc, seed):
             assert y[c].shape == r.shape and np.array_equal(y[c], r), (seed, order, epi, n)
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(10 + EXTRA))
 def test_real_baseband_random_plans(ctx, orc, seed):
     rng = np.random.default_rng(5000 + seed)
     order = int(rng.choice([1, 2, 21, 64, 127, 300]))
@@ -157,7 +162,7 @@ def test_real_baseband_random_plans(ctx, orc, seed):
             assert y[c].shape == r.shape and np.array_equal(y[c], r), (seed, order, D, Fc, epi, n)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(6 + EXTRA))
 def test_subsample_and_demods_random(ctx, orc, seed):
     rng = np.random.default_rng(6000 + seed)
     C, n_sub = int(rng.choice([1, 3])), int(rng.choice([1, 2, 3, 8, 100]))
