@@ -82,7 +82,8 @@ def test_fir_cf32_random_plans(ctx, orc, seed):
                 ref = orc.usb_f32(ref)
             assert y[c].shape == ref.shape, (seed, order, D, epi, n)
             if ref.size:
-                err = np.abs(y[c].astype(np.float64) - ref).max() / max(np.abs(ref).max(), 1e-30)
+                # relative to the stream's scale (inputs ~0.3): a one-sample output of USB's (re+im)/2 can cancel to ~0
+                err = np.abs(y[c].astype(np.float64) - ref).max() / max(np.abs(ref).max(), 0.05)
                 assert err <= 1e-5, (seed, order, D, epi, n, err)
 
 
