@@ -73,6 +73,16 @@ def synth_cs16(torch, C, N, dev, seed, chan0=0):
     return out
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(workload, target_s):
     """Reference CPU path on this box: the compiled, unmodified reference if oracle/_ref travelled here,
     else the oracle port. One thread = the reference's real execution model (one Queue worker)."""
@@ -87,7 +97,7 @@ def cpu_baseline(workload, target_s):
             r = json.loads(subprocess.run([ref, "bench", chain, str(nbuf)], capture_output=True, text=True, timeout=600).stdout)
             res = {"value": round(r["msps"], 4), "unit": "Msamples/s", "cores": 1, "kind": "reference",
                    "sample": "%d buffers x 65536 cs16 samples, 1 channel, chain %s (reference nodes compiled -O3, "
-                             "%.1f s)" % (nbuf, chain, r["seconds"]), "host_cores_available": cores_avail}
+                             "%.1f s)" % (nbuf, chain, r["seconds"]), "host_cores_available": cores_avail, "cpu_model": cpu_model()}
             # one channel (= one reference graph) per host core, all cores at once, ~5 s
             try:
                 try:
