@@ -48,14 +48,33 @@ def parse():
     p.add_argument("--force-device", type=int, default=-1, help="dry runs only: put every rank on this device")
     p.add_argument("--gather", action="store_true", help="also gather the demodulated output on rank 0 every step (RCCL)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    p.add_argument("--sustain-seconds", type=float, default=2.0,
+                   help="after the timed steps: this many seconds of back-to-back launches for the sustained-clock figure (0 = skip)")
+    p.add_argument("--dump-output", default="", help="rank 0 saves the last step's (gathered) output rows as .npy (tests)")
     return p.parse_args()
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as a CHILD `torch.distributed.run`
+    (one process per GPU, rendezvous on 127.0.0.1) and hand back its exit code. This runs before torch or
+    HIP is touched in this process, and it is a child process, never an exec."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env, cwd=ROOT)
 
 
 def synth_cs16(torch, C, N, dev, seed, chan0=0):
     """Two tones per channel + small integer noise (SURVEY §8d config 3/5 recipe), generated on the GPU."""
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed)
     n = torch.arange(N, device=dev, dtype=torch.float64) / FS
+    ni = torch.arange(N, device=dev, dtype=torch.int64)[None, :]
+    M32 = 0xFFFFFFFF
     out = torch.empty((C, N, 2), dtype=torch.int16, device=dev)
     step = 64
     for c0 in range(0, C, step):
@@ -67,9 +86,14 @@ def synth_cs16(torch, C, N, dev, seed, chan0=0):
         a2 = 2 * torch.pi * f2 * n[None, :] + ph
         re = torch.trunc(3500.0 * torch.cos(a1)) + torch.trunc(2500.0 * torch.cos(a2))
         im = torch.trunc(3500.0 * torch.sin(a1)) + torch.trunc(2500.0 * torch.sin(a2))
-        noise = torch.randint(-64, 65, (re.shape[0], N, 2), device=dev, generator=g, dtype=torch.int32)
-        out[c0:c0 + re.shape[0], :, 0] = (re.to(torch.int32) + noise[..., 0]).to(torch.int16)
-        out[c0:c0 + re.shape[0], :, 1] = (im.to(torch.int32) + noise[..., 1]).to(torch.int16)
+        # integer noise in [-64, 64]: a hash of (global channel, sample, seed), so a channel's stream does not
+        # depend on which rank generates it (the 2-rank test compares with the single-process run bit for bit)
+        h = (c.to(torch.int64)[:, None] * 0x9E3779B1 + ni * 0x85EBCA77 + seed * 0xC2B2AE3D) & M32
+        h = ((h ^ (h >> 15)) * 0x2C1B3C6D) & M32
+        h = ((h ^ (h >> 12)) * 0x297A2D39) & M32
+        h = h ^ (h >> 15)
+        out[c0:c0 + re.shape[0], :, 0] = (re.to(torch.int64) + (h & 0xFFFF) % 129 - 64).to(torch.int16)
+        out[c0:c0 + re.shape[0], :, 1] = (im.to(torch.int64) + (h >> 16) % 129 - 64).to(torch.int16)
     return out
 
 
@@ -150,6 +174,8 @@ def measured_traffic(kernel):
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(a))
     import torch
     import torch.distributed as dist
     import libsdr_amd as sa
@@ -162,6 +188,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     if a.force_device >= 0:
         local = a.force_device
+    if world != a.gpus and rank == 0:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d; reporting the ranks that run\n" % (a.gpus, world))
+    if local >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d wants device %d but only %d visible (dry runs: --backend gloo --force-device 0)"
+                         % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -258,18 +289,42 @@ def main():
             run(i % a.batches)
         barrier()
         timer = sa.Timer(ctx)
+        gathered = None
         t0 = time.perf_counter()
         timer.start()
         for i in range(K):
             run(i % a.batches)
             if a.gather and world > 1:
-                shard.gather_output(outs, C * world, dst=0)
+                gathered, _ = shard.gather_output(outs, C * world, dst=0)
         timer.stop()
         barrier()
         wall = time.perf_counter() - t0
         dev_ms = timer.elapsed_ms()
+        if a.dump_output and rank == 0:
+            import numpy as np
+            torch.cuda.synchronize()
+            np.save(a.dump_output, (gathered if gathered is not None else outs).cpu().numpy())
 
-    wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        # ---- sustained figure: >= --sustain-seconds of back-to-back launches on the same stream, so that the
+        # clock the chip HOLDS under this load (DVFS) is what is measured, not a few-ms burst (every rank runs it;
+        # rank 0 reports its own) ----
+        sustained = None
+        if a.sustain_seconds > 0:
+            chunk = max(K, 20)
+            tot_ms, launches, t1 = 0.0, 0, time.perf_counter()
+            while time.perf_counter() - t1 < a.sustain_seconds:
+                timer.start()
+                for i in range(chunk):
+                    run(i % a.batches)
+                timer.stop()
+                tot_ms += timer.elapsed_ms()   # waits for the chunk; the next one follows within microseconds
+                launches += chunk
+            last_ms = timer.elapsed_ms() / chunk
+            sustained = {"ms_per_launch": tot_ms / launches, "launches": launches, "last_chunk_ms_per_launch": last_ms}
+            barrier()
+
+    host_coll = world > 1 and a.backend != "nccl"
+    wall_t = torch.tensor([wall], dtype=torch.float64, device="cpu" if host_coll else dev)
     if world > 1:
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
     wall = float(wall_t.item())
@@ -292,8 +347,16 @@ def main():
                          "algorithmic_bytes_per_launch": C * N * alg_bytes,
                          "algorithmic_bytes_per_sample": alg_bytes, "avg_launch_ms": round(per_launch_s * 1e3, 4),
                          "hbm_read_frac": round(C * N * in_bytes / per_launch_s / 1e9 / HBM_PEAK_GBS, 5),
-                         "per_gpu_msamples_s": round(C * N / per_launch_s / 1e6, 2)},
+                         "per_gpu_msamples_s": round(C * N / per_launch_s / 1e6, 2),
+                         "ranks_seen": dist.get_world_size() if world > 1 else 1},
         }
+        if sustained:
+            rf = res["roofline"]
+            rf["sustained_ms_per_launch"] = round(sustained["ms_per_launch"], 4)
+            rf["sustained_frac"] = round(C * N * alg_bytes / (sustained["ms_per_launch"] / 1e3) / 1e9 / HBM_PEAK_GBS, 5)
+            rf["sustained_launches"] = sustained["launches"]
+            rf["sustained_last_chunk_ms_per_launch"] = round(sustained["last_chunk_ms_per_launch"], 4)
+            rf["sustained_per_gpu_msamples_s"] = round(C * N / (sustained["ms_per_launch"] / 1e3) / 1e6, 2)
         if rank == 0:   # what this box's HBM delivers to a pure read of the same buffers, beside the nominal peak
             try:
                 import ctypes

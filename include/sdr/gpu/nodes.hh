@@ -671,6 +671,15 @@ protected:
     if (++_have < _C) return;
     _have = 0;
     std::fill(_pending.begin(), _pending.end(), false);
+    // the per-channel outputs are views of _stageOut: while a consumer (e.g. a queued edge) still holds one of the
+    // last round, this round is dropped, as every node drops its input while its output buffer is in use
+    // (src/baseband.hh:141-150)
+    if (!_stageOut.isUnused()) {
+      LogMessage msg(LOG_WARNING);
+      msg << "gpu::ChannelBank: output of the last round still in use downstream; round dropped";
+      Logger::get().log(msg);
+      return;
+    }
     size_t n = 0;
     const size_t per = _epilogue == SDRHIP_EPI_NONE ? 1 : 2;   // int16 elements fit twice into a cs16 row
     if (!detail::processOk(sdrhip_iqbb_i16_process(_plan, reinterpret_cast<const int16_t *>(_stageIn.data()), _len, _bs,

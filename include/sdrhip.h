@@ -17,8 +17,12 @@
  *     samples; every channel receives the same number of samples per call, because buffer
  *     boundaries are part of the numerical contract (FMDemod skips index 0 of every buffer,
  *     reference src/demod.hh:245; IQBaseBand's first window is D+1 long, src/baseband.hh:200).
- *   - *_process()     : host pointers in/out (H2D + kernel + D2H, synchronous on return).
- *     *_process_dev() : device pointers, asynchronous on the context stream.
+ *   - *_process()     : host pointers in/out (H2D + kernel + D2H, synchronous on return); the output may
+ *                       alias the input (the reference nodes run in place when allow_overwrite), because
+ *                       the data is staged through separate device buffers.
+ *     *_process_dev() : device pointers, asynchronous on the context stream. The output range must NOT
+ *                       overlap the input range: the kernels are tile-parallel and would race silently;
+ *                       an overlap is rejected with SDRHIP_E_INVALID.
  *   - Taps / LUT / FFT kernels are INPUTS, designed on the host (include/sdr/gpu/design.hh
  *     restates the reference designers); a 1-ulp libm difference must not change results.
  *   - There is no CPU fallback: without a HIP device every create() fails with SDRHIP_E_NODEVICE.
@@ -227,8 +231,11 @@ enum {
   SDRHIP_FFTCONV_OLS = 1  /* overlap-save with M real/complex taps, FFT size L, hop L-M+1
                              (BASELINE config 4: L=16384, M=4097); plain causal convolution */
 };
-/* OLA: fft_size = 2N, kernel = 2N cf32 spectrum (already normalised), n_taps ignored; every call
- *      must carry a multiple of N samples per channel.
+/* OLA: fft_size = 2N, kernel = 2N cf32 spectrum (already normalised), n_taps ignored. The result is the
+ *      reference's overlap-add stream y = IDFT(DFT([x,0]) * K)/2N summed over blocks, i.e. the causal
+ *      convolution with the N-tap kernel behind K; it is evaluated by overlap-save underneath, so a call
+ *      may carry ANY number of samples (the reference's FilterSink insists on exactly N per buffer,
+ *      src/filternode.hh:69-74 — a multiple of N gives its blocks exactly).
  * OLS: kernel = n_taps cf32 time-domain taps; any n_in. */
 int sdrhip_fftconv_create(sdrhip_ctx *ctx, int mode, int fft_size, const float *kernel, int n_taps,
                           int channels, size_t max_in, sdrhip_fftconv **out);

@@ -335,6 +335,7 @@ int sdrhip_demod_process_dev(sdrhip_demod *h, const void *in_dev, size_t n, size
     if (in_stride == 0) in_stride = n;
     if (out_stride == 0) out_stride = n;
     SDRHIP_REQUIRE(in_stride >= n && out_stride >= n, SDRHIP_E_SIZE, "stride smaller than n");
+    require_disjoint(in_dev, in_stride, n, h->in_elem(), out_dev, out_stride, n, h->out_elem(), (size_t)h->C);
     h->launch(in_dev, n, in_stride, out_dev, out_stride);
   });
 }
@@ -406,6 +407,7 @@ int sdrhip_deemph_i16_process_dev(sdrhip_deemph *h, const int16_t *in_dev, size_
     if (in_stride == 0) in_stride = n;
     if (out_stride == 0) out_stride = n;
     SDRHIP_REQUIRE(in_stride >= n && out_stride >= n, SDRHIP_E_SIZE, "stride smaller than n");
+    require_disjoint(in_dev, in_stride, n, 2, out_dev, out_stride, n, 2, (size_t)h->C);
     h->launch(in_dev, n, in_stride, out_dev, out_stride);
   });
 }
@@ -482,6 +484,7 @@ int sdrhip_subsample_process_dev(sdrhip_subsample *h, const void *in_dev, size_t
     if (in_stride == 0) in_stride = n_in;
     SDRHIP_REQUIRE(in_stride >= n_in, SDRHIP_E_SIZE, "in_stride %zu < n_in %zu", in_stride, n_in);
     if (out_stride == 0) out_stride = h->out_count(n_in);
+    require_disjoint(in_dev, in_stride, n_in, h->elem(), out_dev, out_stride, h->out_count(n_in), h->elem(), (size_t)h->C);
     h->launch(in_dev, n_in, in_stride, out_dev, out_stride, n_out);
   });
 }

@@ -612,6 +612,7 @@ int sdrhip_fftconv_process_dev(sdrhip_fftconv *h, const float *in_dev, size_t n_
     if (in_stride == 0) in_stride = n_in;
     if (out_stride == 0) out_stride = n_in;
     SDRHIP_REQUIRE(in_stride >= n_in && out_stride >= n_in, SDRHIP_E_SIZE, "stride smaller than n_in");
+    require_disjoint(in_dev, in_stride, n_in, 8, out_dev, out_stride, n_in, 8, (size_t)h->C);
     h->launch(reinterpret_cast<const float2 *>(in_dev), n_in, in_stride, reinterpret_cast<float2 *>(out_dev), out_stride);
   });
 }

@@ -556,6 +556,11 @@ int sdrhip_fir_process_dev(sdrhip_fir *h, const void *in_dev, size_t n_in, size_
     if (in_stride == 0) in_stride = n_in;
     SDRHIP_REQUIRE(in_stride >= n_in, SDRHIP_E_SIZE, "in_stride %zu < n_in %zu", in_stride, n_in);
     if (out_stride == 0) out_stride = h->out_count(n_in);
+    {
+      const size_t ie = h->kind == SDRHIP_FIR_CS16_EXACT ? 4 : 8;
+      const size_t oe = h->kind == SDRHIP_FIR_CS16_EXACT ? (h->epi == SDRHIP_EPI_NONE ? 4 : 2) : (h->epi == SDRHIP_EPI_NONE ? 8 : 4);
+      require_disjoint(in_dev, in_stride, n_in, ie, out_dev, out_stride, h->out_count(n_in), oe, (size_t)h->C);
+    }
     h->launch(in_dev, n_in, in_stride, out_dev, out_stride, n_out);
   });
 }

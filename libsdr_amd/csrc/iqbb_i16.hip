@@ -1297,6 +1297,8 @@ int sdrhip_iqbb_i16_process_dev(sdrhip_iqbb_i16 *h, const int16_t *in_dev, size_
     if (in_stride == 0) in_stride = n_in;
     SDRHIP_REQUIRE(in_stride >= n_in, SDRHIP_E_SIZE, "in_stride %zu < n_in %zu", in_stride, n_in);
     if (out_stride == 0) out_stride = (size_t)h->geometry(n_in).n_out;
+    require_disjoint(in_dev, in_stride, n_in, (h->in_cu8 || h->real) ? 2 : 4, out_dev, out_stride, (size_t)h->geometry(n_in).n_out,
+                     h->epi == SDRHIP_EPI_NONE ? 4 : 2, (size_t)h->C);
     h->launch(reinterpret_cast<const uint32_t *>(in_dev), n_in, in_stride, out_dev, out_stride, n_out);
   });
 }

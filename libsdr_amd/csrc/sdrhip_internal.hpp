@@ -113,6 +113,19 @@ void copy_d2h_rows(const sdrhip_ctx *ctx, void *dst_host, size_t dst_pitch_b, co
 
 static inline size_t ceil_div(size_t a, size_t b) { return (a + b - 1) / b; }
 
+// *_process_dev contract (sdrhip.h): the kernels are tile-parallel (a workgroup reads neighbouring tiles' inputs and
+// the last one rolls the history from the input), so an output range that overlaps the input range would race
+// silently. rows x row_elems elements of elem bytes at a row stride of `stride` elements.
+static inline void require_disjoint(const void *in, size_t in_stride, size_t in_row, size_t in_elem, const void *out,
+                                    size_t out_stride, size_t out_row, size_t out_elem, size_t rows) {
+  if (!rows || !in_row || !out_row) return;
+  const uintptr_t a0 = (uintptr_t)in, a1 = a0 + ((rows - 1) * in_stride + in_row) * in_elem;
+  const uintptr_t b0 = (uintptr_t)out, b1 = b0 + ((rows - 1) * out_stride + out_row) * out_elem;
+  SDRHIP_REQUIRE(a1 <= b0 || b1 <= a0, SDRHIP_E_INVALID,
+                 "process_dev: the output range overlaps the input range (in place is only supported by the host-pointer "
+                 "*_process entry points, which stage through separate device buffers)");
+}
+
 // fir.hip: turn on the frequency shift fused into the cf32 FIR's staging (used by the float baseband, fbb_f32.hip)
 void fir_set_shift(sdrhip_fir *h, double fc, double fs);
 

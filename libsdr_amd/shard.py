@@ -14,11 +14,22 @@ def shard_range(total_channels, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _host_staged(t):
+    """gloo (CPU dry runs, tests) moves host memory only: device tensors are staged through the host there.
+    On RCCL ("nccl") device tensors travel as they are, over xGMI."""
+    return t.is_cuda and dist.get_backend() != "nccl"
+
+
 def broadcast_design(tensors, src=0):
     """Broadcasts design tensors (designed on `src`) so that every rank filters with bit-identical taps."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         for t in tensors:
-            dist.broadcast(t, src)
+            if _host_staged(t):
+                h = t.cpu()
+                dist.broadcast(h, src)
+                t.copy_(h)
+            else:
+                dist.broadcast(t, src)
     return tensors
 
 
@@ -30,6 +41,9 @@ def gather_output(local, total_channels, dst=0, async_op=False):
         return local, None
     rank = dist.get_rank()
     dtype = local.dtype
+    dev = local.device
+    if _host_staged(local):
+        local = local.cpu()
     if dtype == torch.int16:   # gloo has no int16 collectives; bytes travel the same on RCCL
         local = local.contiguous().view(torch.uint8)
     sizes = [shard_range(total_channels, world, r) for r in range(world)]
@@ -38,6 +52,6 @@ def gather_output(local, total_channels, dst=0, async_op=False):
         work = dist.gather(local, parts, dst=dst, async_op=async_op)
         if async_op:
             return parts, work
-        return torch.cat(parts, 0).view(dtype), None
+        return torch.cat(parts, 0).view(dtype).to(dev), None
     work = dist.gather(local, None, dst=dst, async_op=async_op)
     return None, work

@@ -147,6 +147,38 @@ static void testChannelBank() {
   }
 }
 
+// the bank's outputs are views of one stage buffer: while a consumer still references a view of the last round
+// (what a queued edge does until the Queue worker has delivered it), the next round is dropped — the rule every node
+// follows for its own output buffer (reference src/baseband.hh:141-150)
+static void testChannelBankDropsWhileOutputInUse() {
+  const size_t C = 4, N = 4096;
+  gpu::ChannelBank<int16_t> bank(C, 100e3, 100e3, 50e3, 21, 8);
+  struct Hold : public Sink<cs16> {
+    RawBuffer kept; bool keep = false; size_t calls = 0; std::vector<cs16> first;
+    virtual void config(const Config &) {}
+    virtual void process(const Buffer<cs16> &b, bool) {
+      calls++;
+      if (keep) { kept = b; kept.ref(); first.assign(b.data() ? reinterpret_cast<const cs16 *>(b.data()) : 0, reinterpret_cast<const cs16 *>(b.data()) + b.size()); }
+    }
+  };
+  std::vector<Hold> hold(C); std::vector<Feeder> src(C);
+  std::vector<cs16> x = tones(3 * N);
+  for (size_t c = 0; c < C; c++) {
+    src[c].cfg(Config::Type_cs16, N);
+    src[c].connect(bank.sink(c), true); bank.source(c)->connect(&hold[c], true);
+  }
+  hold[2].keep = true;
+  for (size_t c = 0; c < C; c++) src[c].feed(&x[0], N);
+  CHECK(hold[0].calls == 1 && hold[2].calls == 1 && hold[2].first.size() == 511);
+  hold[2].keep = false;
+  for (size_t c = 0; c < C; c++) src[c].feed(&x[N], N);            // view of round 1 still referenced -> round dropped
+  CHECK(hold[0].calls == 1 && hold[3].calls == 1);
+  CHECK(0 == memcmp(hold[2].kept.data(), hold[2].first.data(), hold[2].first.size() * sizeof(cs16)));   // not clobbered
+  hold[2].kept.unref();
+  for (size_t c = 0; c < C; c++) src[c].feed(&x[2 * N], N);
+  CHECK(hold[0].calls == 2 && hold[3].calls == 2);
+}
+
 // float nodes: FIRLowPass<cf32> -> SubSample<cf32>(8) and the FFT filter bank vs direct convolution
 static void testFloatNodes() {
   const size_t N = 4096;
@@ -238,6 +270,7 @@ int main(int argc, char **argv) {
     testFirFmOnQueue();
     testOwnership();
     testChannelBank();
+    testChannelBankDropsWhileOutputInUse();
     testFloatNodes();
     testSdrFmChainCu8();
     testRealBaseBand();
