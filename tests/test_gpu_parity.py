@@ -629,7 +629,151 @@ def test_fftconv_config4_many_channels(ctx, golden, orc):
     assert np.array_equal(one.process(x[5:6])[0], y[5])
 
 
+# ---- the other BASELINE configs at their batch size (1024 channels x 65536 samples per call) -------------------
+# Grid-dimension / stride / >2^31-byte-offset bugs only show at full size: 8 distinct channel patterns are tiled over
+# the 1024 channels; batching invariance (equal inputs -> equal outputs wherever the channel sits) plus the 8 patterns
+# against the oracle over two calls (state carried).
+
+def _tiled(base, C):
+    return np.ascontiguousarray(base[np.arange(C) % base.shape[0]])
+
+
+def test_fir255_fm_full_size(ctx, orc):
+    """BASELINE config 3: 1024 int16 IQ channels, FIRLowPass<cs16>(255) -> FMDemod, 65536 samples per call."""
+    C, N = 1024, 65536
+    alpha = sa.design_fir_lowpass(255, 100e3, FS)
+    base = synth_channels(orc, 8, 2 * N)
+    x = _tiled(base, C)
+    node = sa.FIR(ctx, sa.FIR_CS16_EXACT, alpha, channels=C, max_in=N, epilogue=sa.EPI_FM)
+    ys = [node.process(x[:, :N]), node.process(x[:, N:])]
+    for y in ys:
+        assert y.shape == (C, N)
+        for k in range(8):
+            assert (y[k::8] == y[k]).all()
+    for k in range(8):
+        f, fm = orc.FIR(alpha), orc.FMDemodI16()
+        for i, y in enumerate(ys):
+            assert np.array_equal(y[k], fm.process(f.process_cs16(base[k, i * N:(i + 1) * N]))), (k, i)
+
+
+def test_float_baseband_full_size(ctx, golden, orc):
+    """BASELINE config 2's chain (shift -> FIRLowPass<cf32>(127) -> /8) at 1024 channels x 65536 samples per call."""
+    C, N, D = 1024, 65536, 8
+    alpha = golden.load("g2_firlp_alpha127")
+    rng = np.random.default_rng(21)
+    base = (rng.standard_normal((8, 2 * N, 2)) * 0.3).astype(np.float32)
+    x = _tiled(base, C)
+    node = sa.FloatBaseBand(ctx, 100e3, FS, alpha, D, channels=C, max_in=N)
+    ys = [node.process(x[:, :N]), node.process(x[:, N:])]
+    for y in ys:
+        for k in range(8):
+            assert np.array_equal(y[k::8], np.broadcast_to(y[k], y[k::8].shape))
+    for k in range(8):
+        fir, sub = orc.FIR(alpha), orc.SubSample(D)
+        for i, y in enumerate(ys):
+            ref = sub.process_cf32(fir.process_cf32(orc.freqshift_cf32(base[k, i * N:(i + 1) * N], i * N, 100e3, FS)))
+            assert y[k].shape == ref.shape and rel_err(y[k], ref) <= RTOL, (k, i)
+
+
+def test_fir_cf32_decimated_full_size(ctx, golden, orc):
+    """K3 alone (FIRLowPass<cf32>(127) -> SubSample(8)) at 1024 channels x 65536 samples per call."""
+    C, N, D = 1024, 65536, 8
+    alpha = golden.load("g2_firlp_alpha127")
+    rng = np.random.default_rng(22)
+    base = (rng.standard_normal((8, 2 * N, 2)) * 0.3).astype(np.float32)
+    x = _tiled(base, C)
+    node = sa.FIR(ctx, sa.FIR_CF32, alpha, decim=D, channels=C, max_in=N)
+    ys = [node.process(x[:, :N]), node.process(x[:, N:])]
+    for y in ys:
+        for k in range(8):
+            assert np.array_equal(y[k::8], np.broadcast_to(y[k], y[k::8].shape))
+    for k in range(8):
+        fir, sub = orc.FIR(alpha), orc.SubSample(D)
+        for i, y in enumerate(ys):
+            ref = sub.process_cf32(fir.process_cf32(base[k, i * N:(i + 1) * N]))
+            assert y[k].shape == ref.shape and rel_err(y[k], ref) <= RTOL, (k, i)
+
+
+def test_fftconv_config4_full_size(ctx, golden, orc):
+    """BASELINE config 4 (ii) at 1024 channels x 65536: overlap-save L = 16384, 4097 taps, against the time-domain
+    oracle FIR on 3 of the 8 patterns (2 calls, history carried) and batching invariance over all channels."""
+    a = golden.load("g2_firlp_alpha4097")
+    taps = np.stack([a[::-1], np.zeros_like(a)], axis=1).astype(np.float32)
+    rng = np.random.default_rng(23)
+    C, N = 1024, 65536
+    base = (rng.standard_normal((8, 2 * N, 2)) * 0.3).astype(np.float32)
+    x = _tiled(base, C)
+    node = sa.FFTConv(ctx, sa.FFTCONV_OLS, 16384, taps, channels=C, max_in=N)
+    ys = [node.process(x[:, :N]), node.process(x[:, N:])]
+    del x
+    for y in ys:
+        for k in range(8):
+            assert np.array_equal(y[k::8], np.broadcast_to(y[k], y[k::8].shape))
+    for k in (0, 3, 7):
+        f = orc.FIR(a)
+        for i, y in enumerate(ys):
+            assert rel_err(y[k], f.process_cf32(base[k, i * N:(i + 1) * N])) <= RTOL, (k, i)
+
+
+def test_fftconv_reference_mode_full_size(ctx, orc):
+    """BASELINE config 4 (i) at 1024 channels: the reference's overlap-add mode (block 8192, FFT 16384, 8192-tap
+    FilterSource kernel 50..150 kHz), 8 blocks per call, against the oracle's FilterSink/FilterSource restatement."""
+    Nb, C, N = 8192, 1024, 65536
+    h = sa.design_fftfilt_kernel(Nb, 50e3, 150e3, FS)
+    K = sa.design_fftfilt_spectrum(h)
+    rng = np.random.default_rng(24)
+    base = (rng.standard_normal((8, 2 * N, 2)) * 0.3).astype(np.float32)
+    x = _tiled(base, C)
+    node = sa.FFTConv(ctx, sa.FFTCONV_OLA, 2 * Nb, K, channels=C, max_in=N)
+    ys = [node.process(x[:, :N]), node.process(x[:, N:])]
+    del x
+    for y in ys:
+        for k in range(8):
+            assert np.array_equal(y[k::8], np.broadcast_to(y[k], y[k::8].shape))
+    for k in (1, 6):
+        f = orc.FFTFilter(orc.fftfilt_design_K(h))
+        for i, y in enumerate(ys):
+            ref = np.concatenate([f.process(base[k, i * N + b * Nb:i * N + (b + 1) * Nb]) for b in range(N // Nb)])
+            assert rel_err(y[k], ref) <= RTOL, (k, i)
+
+
+def test_iqbb_usb_full_size(ctx, orc):
+    """BASELINE config 5's per-GPU shard: 1024 channels, IQBaseBand<int16>(127, /8) -> USBDemod, 65536 per call."""
+    C, N, D = 1024, 65536, 8
+    taps = sa.design_iqbb_taps(100e3, 50e3, FS, 127)
+    lut = sa.design_freqshift_lut_i16()
+    base = synth_channels(orc, 8, 2 * N)
+    x = _tiled(base, C)
+    node = sa.IQBaseBandI16(ctx, taps, lut, 1365, False, D, channels=C, max_in=N, epilogue=sa.EPI_USB)
+    ys = [node.process(x[:, :N]), node.process(x[:, N:])]
+    for k in range(8):
+        bb = orc.IQBaseBandI16(taps, lut, 1365, False, D)
+        for i, y in enumerate(ys):
+            assert (y[k::8] == y[k]).all()
+            assert np.array_equal(y[k], orc.usb_i16(bb.process(base[k, i * N:(i + 1) * N]))), (k, i)
+
+
 # ---- error behaviour -----------------------------------------------------------------------------------------
+
+def test_process_dev_rejects_overlapping_ranges(ctx, golden):
+    """sdrhip.h: *_process_dev output must not overlap the input (tile-parallel kernels would race): E_INVALID."""
+    taps, lut = golden.load("g3_iqbb127d8_taps"), golden.load("g3_iqbb127d8_lut")
+    n = 4096
+    buf = ctx.malloc(2 * n * 8)
+    try:
+        bb = sa.IQBaseBandI16(ctx, taps, lut, 1365, 0, 8, max_in=n)
+        fir = sa.FIR(ctx, sa.FIR_CS16_EXACT, golden.load("g2_firlp_alpha127"), max_in=n)
+        dem = sa.Demod(ctx, sa.EPI_USB, sa.T_CS16, max_in=n)
+        for call in (lambda: bb.process_dev(buf, n, n, buf, n), lambda: fir.process_dev(buf, n, n, buf + 4 * (n - 1), n),
+                     lambda: dem.process_dev(buf, n, n, buf, n)):
+            with pytest.raises(sa.SdrHipError) as e:
+                call()
+            assert e.value.code == sa.abi.E_INVALID and "overlap" in str(e.value)
+        assert bb.process_dev(buf, n, n, buf + 4 * n, n) == 511      # adjacent, disjoint ranges are fine
+        ctx.synchronize()
+    finally:
+        ctx.free(buf)
+
 
 def test_error_codes(ctx, golden):
     taps, lut = golden.load("g3_iqbb127d8_taps"), golden.load("g3_iqbb127d8_lut")
