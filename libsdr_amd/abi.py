@@ -11,6 +11,8 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 SO_PATH = os.path.join(_HERE, "libsdrhip.so")
+if os.environ.get("SDRHIP_LIB"):   # tuning hook: A/B an earlier build of the library on the same box (tools/k1_variants.sh)
+    SO_PATH = os.path.abspath(os.environ["SDRHIP_LIB"])
 HEADER = os.path.join(ROOT, "include", "sdrhip.h")
 
 OK, E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_UNSUPPORTED, E_SIZE = 0, -1, -2, -3, -4, -5, -6

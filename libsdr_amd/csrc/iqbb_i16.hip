@@ -320,6 +320,75 @@ constexpr int MF_BLK = 16;    // samples per block (one column)
 __device__ __forceinline__ int mul24a(int x, int y) { int d; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; }
 __device__ __forceinline__ int mad24a(int x, int y, int z) { int d; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z)); return d; }
 
+__device__ __forceinline__ unsigned mulu24a(unsigned x, unsigned y) { unsigned d; asm("v_mul_u32_u24 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; }
+__device__ __forceinline__ unsigned lshl8_add(unsigned x, unsigned y) { unsigned d; asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(d) : "v"(x), "v"(y)); return d; }
+__device__ __forceinline__ int sub32(int x, int y) { return (int)((unsigned)x - (unsigned)y); }
+// acc + (x >> 16): SDWA picks the sign-extended high half of x, so the shift of the rotation and the box-sum add are one instruction
+__device__ __forceinline__ int add_hi16(int x, int acc) {
+  int d;
+  asm("v_add_u32_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(d) : "v"(x), "v"(acc));
+  return d;
+}
+// (short)trunc(s / 8) for |s| < 2^29
+__device__ __forceinline__ int div8_i16(int s) {
+  const int t = (int)((unsigned)s + __builtin_amdgcn_ubfe((unsigned)s, 29, 3));
+  return __builtin_amdgcn_sbfe(t, 3, 16);
+}
+// Lane (n, h) of a wave (n = l & 31, h = l >> 5) owns group 2n + h: the value of the previous group, 2n + h - 1, sits in
+// lane (n, 0) for h = 1 and in lane (n - 1, 1) for h = 0 (lane 0 gets lane 63's: its own group is the wave's overlap slot).
+__device__ __forceinline__ int prev_group_value(int v, int h) {
+  // v_permlane32_swap: lanes 32..63 of the first operand <-> lanes 0..31 of the second; with both = v the first
+  // result carries the lower half's values in both halves, the second the upper half's
+  const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+  const int hi_shr = __builtin_amdgcn_update_dpp(0, (int)sw[1], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+  return h ? (int)sw[0] : hi_shr;
+}
+
+// Path 1's per-lane epilogue core: the lane's 8 samples (accumulator registers 2j / 2j+1 = re / im of sample j, planes hh,
+// mid, ll) -> recombine -> >>14 -> rotate by LUT[idx(n)] -> sum of the (product >> 16) = the decimation window's sum.
+// The rotation table sits at LDS offset 0 (dynamic LDS starts there: the kernel has no static LDS), so a table
+// read's address is the byte offset itself.
+template <bool ROT, bool CU8, bool EDGE>
+__device__ __forceinline__ int2 group_sum(const IqbbArgs &a, const v16i &acc_hh, const v16i &acc_mid, const v16i &acc_ll, int rel0) {
+  typedef int v2i __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) const v2i lds_v2i;
+  int2 L[8];
+  if (ROT) {   // 8 independent table reads in flight while the accumulators are recombined
+    // phase counter of the lane's first sample; only its low 15 bits matter, so a 24-bit multiply is exact enough
+    const uint32_t cnt0 = mulu24a(a.n0_lo + (uint32_t)rel0, a.inc);
+    const uint32_t negx = a.negative ? (127u << 3) : 0u;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint32_t off = (((cnt0 + (uint32_t)j * a.inc) >> 5) & (127u << 3)) ^ negx;   // j * inc: wave-uniform
+      const v2i e = *reinterpret_cast<lds_v2i *>((uintptr_t)off);
+      L[j] = make_int2(e.x, e.y);
+    }
+  }
+  int2 sum = make_int2(0, 0);
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    // two v_lshl_add_u32 per component, written as instructions (the compiler re-associates the source form into two
+    // shifts + add3)
+    const unsigned tre = lshl8_add((unsigned)acc_hh[2 * j], (unsigned)acc_mid[2 * j]);
+    const unsigned tim = lshl8_add((unsigned)acc_hh[2 * j + 1], (unsigned)acc_mid[2 * j + 1]);
+    int rr, ri;
+    if (CU8) {   // S = t << 8 exactly
+      rr = (int)(tre << 8) >> 14; ri = (int)(tim << 8) >> 14;
+    } else {
+      rr = (int)lshl8_add(tre, (unsigned)acc_ll[2 * j]) >> 14; ri = (int)lshl8_add(tim, (unsigned)acc_ll[2 * j + 1]) >> 14;
+    }
+    if (EDGE) { const int rel = rel0 + j; if (rel < 0 || rel >= a.N) { rr = 0; ri = 0; } }   // outside the call: r = 0 -> v = 0
+    if (ROT) {
+      const int x = sub32(mul24a(L[j].x, rr), mul24a(L[j].y, ri));
+      const int y = mad24a(L[j].x, ri, mul24a(L[j].y, rr));
+      sum.x = add_hi16(x, sum.x); sum.y = add_hi16(y, sum.y);   // += (x >> 16): one SDWA add each
+    } else {
+      sum.x = (int)((unsigned)sum.x + (unsigned)rr); sum.y = (int)((unsigned)sum.y + (unsigned)ri);
+    }
+  }
+  return sum;
+}
+
 // per byte (b + 129) mod 256: the high byte AutoCast< complex<int16_t> > gives a complex<uint8_t> component
 __device__ __forceinline__ uint32_t add129_bytes(uint32_t x) {
   const uint32_t y = x ^ 0x80808080u;   // + 128
@@ -329,6 +398,57 @@ __device__ __forceinline__ uint32_t add129_bytes(uint32_t x) {
 // CU8: the input is complex<uint8_t> (SDRHIP_IN_CU8). After AutoCast every sample is 256 * uh exactly, so the low
 // byte plane and both of its products vanish: S = 65536 * sum(ah*uh) + 256 * sum(al*uh) — two MFMAs per K step into
 // two accumulators, one plane to stage, read and keep in LDS, 2 bytes per sample from HBM; 5 waves per SIMD fit.
+
+// Path 1's group epilogue: lane (n, h) holds the window sum of group glw = 2n + h of its wave; carry / first-sample
+// quirk for the call's first group, truncating division by 8, state for the next call, demodulator, store.
+__device__ __forceinline__ void group_finish(const IqbbArgs &a, const int2 *lut_s, int c, int n, int h, int gw, int q0,
+                                             int groups_here, int2 sum) {
+  const int glw = 2 * n + h;
+  const int ql = gw + glw, q = q0 + ql;   // q = output index within the call when the group completes
+  const bool live = (ql < groups_here) && (q >= 0);
+  if (q0 + gw <= 0 && live && q == 0) {   // (scalar test first: only the wave that holds the call's first group)
+    const int2 carry = a.acc_old[c];
+    sum.x = (int)((unsigned)sum.x + (unsigned)carry.x);
+    sum.y = (int)((unsigned)sum.y + (unsigned)carry.y);
+    if (a.extra0) {   // absolute sample 0: one slow FIR evaluation per channel and stream start
+      int er = 0, ei = 0;
+      for (int i = 0; i < a.OP; i++) {
+        const uint32_t x = load_x(a, c, -(a.OP - 1) + i);
+        const uint2 k = a.taps[i];
+        er = dot2(x, k.x, er); ei = dot2(x, k.y, ei);
+      }
+      const int2 v = rotate(a, lut_s, make_int2(er >> 14, ei >> 14), a.n0_lo);
+      sum.x = (int)((unsigned)sum.x + (unsigned)v.x);
+      sum.y = (int)((unsigned)sum.y + (unsigned)v.y);
+    }
+  }
+  const bool own = live && (glw >= a.ovl);            // the FM overlap slot belongs to the previous wave / tile
+  const bool emits = live && (q < a.n_out);
+  // libstdc++'s (s*8)/(8*8) (src/baseband.hh:214): |s| <= 9 * 2^17 here (a window of 16-bit rotated values, or of
+  // 18-bit FIR values when there is no shift), so nothing wraps and it is trunc(s / 8): bias 7 for negative sums
+  // (bits 31..29 of s), arithmetic shift, and the int16 wrap of the assignment in the same bit-field extract
+  const int yr = div8_i16(sum.x), yi = div8_i16(sum.y);
+  if (own && q == a.n_groups - 1) a.acc_new[c] = emits ? make_int2(0, 0) : sum;
+  if (a.epilogue == SDRHIP_EPI_NONE) {
+    if (own && emits) reinterpret_cast<uint32_t *>(a.out)[(long)c * a.out_stride + q] = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
+  } else {
+    short o;
+    if (a.epilogue == SDRHIP_EPI_AM) o = am_i16(yr, yi);
+    else if (a.epilogue == SDRHIP_EPI_USB) o = usb_i16(yr, yi);
+    else {
+      const int phi = fm_phi(yr, yi);
+      // previous group's angle: lane (n,0) for h=1, lane (n-1,1) for h=0 — one v_permlane32_swap (both halves'
+      // values in both halves) and one wave_shr:1 DPP move, no LDS round trip
+      const int prev = prev_group_value(phi, h);
+      if (q == 0) o = (short)yr;             // index 0 is never written by FMDemod (in place)
+      else o = (short)((q == 1 ? (int)a.fm_old[c] : prev) - phi);   // y[0] is never looked at
+      if (own && emits && q == a.n_out - 1 && a.n_out >= 2) a.fm_new[c] = (short)phi;
+    }
+    if (own && emits) reinterpret_cast<short *>(a.out)[(long)c * a.out_stride + q] = o;
+  }
+
+}
+
 template <int S, bool ROT, bool CU8>
 __global__ __launch_bounds__(TPB, CU8 ? 5 : 4) void iqbb_i16_mfma_kernel(const IqbbArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -353,6 +473,10 @@ __global__ __launch_bounds__(TPB, CU8 ? 5 : 4) void iqbb_i16_mfma_kernel(const I
   struct __attribute__((packed, aligned(4))) Quad { uint32_t v[4]; };   // 16-byte load from a 4-byte aligned address
   Quad px[NQ];
   auto fetch = [&](int tile_) {
+#ifdef K1_ABL_NOFETCH   // tuning ablation (results wrong): no global loads
+    for (int k = 0; k < NQ; k++) for (int j = 0; j < 4; j++) px[k].v[j] = tile_ + k + j;
+    return;
+#endif
     const int q0_ = tile_ * a.OG - a.ovl;
     const int first = a.base0_rel + q0_ * 8 - (a.OP - 1);
     const int quads = (min(a.CG, a.n_groups - q0_) * 8 + a.OP + 4) / 4;
@@ -431,18 +555,36 @@ __global__ __launch_bounds__(TPB, CU8 ? 5 : 4) void iqbb_i16_mfma_kernel(const I
     // The next tile's samples are only pulled towards L2 here — one dword per 64-byte line into a scratch
     // register — and loaded into registers after the K loop, so that 12 VGPRs of prefetch are not live across it.
     // The compiler does not know the asm is a load: `touch` stays tied to it until the explicit wait below.
+    // The touch runs K1_TOUCH_AHEAD tiles ahead (default 2): a tile period is longer than an HBM round trip under
+    // load, so the register loads after the K loop find their lines in L2 — with one tile of lead they still waited
+    // on HBM, and a workgroup has only that one tile of loads in flight (measured: the kernel without any arithmetic
+    // took 104 of the 160 us).
     uint32_t touch = 0;
-    if (tile + 1 < tile_end) {
-      const int q0_ = (tile + 1) * a.OG - a.ovl;
+    auto touch_tile = [&](int tile_) {
+      if (tile_ >= tile_end) return;
+      const int q0_ = tile_ * a.OG - a.ovl;
       constexpr int LINE = CU8 ? 32 : 16;   // samples per 64-byte line
       const long first = (long)a.base0_rel + (long)q0_ * 8 - (a.OP - 1) + (long)LINE * tid;   // one line per lane
-      if ((CU8 || !a.in_cu8) && first >= 0 && first < (long)a.N && LINE * tid < TI + a.OP + LINE) {
+#ifndef K1_ABL_NOFETCH
+      if ((CU8 || !a.in_cu8) && first >= 0 && first < (long)a.N && LINE * tid < TI + a.OP + LINE)
+#else
+      if (false)
+#endif
+      {
         const void *pa = CU8 ? (const void *)((reinterpret_cast<const uint16_t *>(a.in) + (long)c * a.in_stride + first))
                              : (const void *)(a.in + (long)c * a.in_stride + first);
         pa = (const void *)((uintptr_t)pa & ~(uintptr_t)3);
         asm volatile("global_load_dword %0, %1, off" : "+v"(touch) : "v"(pa) : "memory");
       }
+    };
+#ifndef K1_TOUCH_AHEAD
+#define K1_TOUCH_AHEAD 2
+#endif
+    if (it == 0) {
+#pragma unroll
+      for (int d = 1; d < K1_TOUCH_AHEAD; d++) touch_tile(tile + d);
     }
+    touch_tile(tile + K1_TOUCH_AHEAD);
     const bool wave_has_work = (w * OGw + a.ovl < groups_here);
     if (!wave_has_work) {   // (a wave without groups in a ragged last tile)
       asm volatile("s_waitcnt vmcnt(0)" : "+v"(touch) : : "memory");
@@ -460,6 +602,9 @@ __global__ __launch_bounds__(TPB, CU8 ? 5 : 4) void iqbb_i16_mfma_kernel(const I
       const int coff = ((gw + h) & 1) * (2 * PLW) + 16 * (((gw + h) >> 1) + n);
       const char *pl = reinterpret_cast<const char *>(lo) + coff;
       const char *ph = reinterpret_cast<const char *>(hi) + coff;
+#ifdef K1_ABL_NOKLOOP   // tuning ablation (results wrong): no LDS operand reads, no MFMAs
+      acc_mid[0] = *reinterpret_cast<const int *>(ph); acc_ll[1] = *reinterpret_cast<const int *>(pl);
+#else
 #pragma unroll
       for (int s = 0; s < S; s++) {
         // the outer taps of a windowed sinc are small: where every tap a K step touches has a zero high byte, its
@@ -468,6 +613,12 @@ __global__ __launch_bounds__(TPB, CU8 ? 5 : 4) void iqbb_i16_mfma_kernel(const I
         const bool has_ah = (a.ah_mask >> s) & 1;
         const v4i uh = *reinterpret_cast<const v4i *>(ph + 16 * s);
         const v4i Al = taps_s[(2 * s + 1) * 64 + l];
+#ifdef K1_ABL_NOMFMA    // tuning ablation (results wrong): the LDS operand reads stay, the matrix instructions go
+        acc_mid[s] += uh.x ^ uh.y ^ uh.z ^ uh.w ^ Al.x ^ Al.y ^ Al.z ^ Al.w;
+        { const v4i ul = *reinterpret_cast<const v4i *>(pl + 16 * s); acc_ll[s] += ul.x ^ ul.y ^ ul.z ^ ul.w; }
+        if (has_ah) { const v4i Ah = taps_s[(2 * s) * 64 + l]; acc_hh[s] += Ah.x ^ Ah.y ^ Ah.z ^ Ah.w; }
+        continue;
+#endif
         // (the unconditional low-plane products come first: step 0 writes acc_mid with C = 0, so that only acc_hh
         // needs an explicit zero — a conditional first write makes the compiler materialise zeros on the other path)
         acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, uh, acc_mid, 0, 0, 0);
@@ -483,98 +634,180 @@ __global__ __launch_bounds__(TPB, CU8 ? 5 : 4) void iqbb_i16_mfma_kernel(const I
           }
         }
       }
-      // ---- recombine, >>14, rotate, mask, partial box sums (4 samples per group in this lane) --------
-      const int rel0 = tb + 8 * gw + MF_BLK * n + 2 * h;
+#endif
+      // ---- epilogue, all in this lane: the tap fragments' rows are permuted at create time so that lane (n, h)
+      // holds the WHOLE decimation group glw = 2n + h of the wave — sample j = 0..7 of it in accumulator registers
+      // 2j (re) and 2j+1 (im): recombine -> >>14 -> rotate -> the box sum takes the products' high halves ----
+      const int rel0 = tb + 8 * gw + MF_BLK * n + 8 * h;   // call-relative index of the lane's first sample
       const bool edge = (tb < 0) || (tb + groups_here * 8 > a.N);   // tile touches the call's borders (scalar)
-      int2 rv[8];   // sample k = 2q+tt sits at rel0 + 4q + tt
+      int2 sum;
+      // (two copies of the sample loop behind a scalar branch: written as one loop with `if (edge)` inside, the
+      // compiler if-converts the border test into 8 compares + selects per sample on every tile)
+#ifdef K1_ABL_NOEPI   // tuning ablation (results wrong): no recombination / rotation / window sum
+      sum = make_int2(0, 0);
 #pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const int rr = 4 * (k >> 1) + 2 * (k & 1);
-        // two v_lshl_add_u32 per component; the empty asm keeps the compiler from re-associating into 2 shifts + add3
-        unsigned tre = ((unsigned)acc_hh[rr] << 8) + (unsigned)acc_mid[rr];
-        unsigned tim = ((unsigned)acc_hh[rr + 1] << 8) + (unsigned)acc_mid[rr + 1];
-        if (CU8) {   // S = t << 8 exactly
-          rv[k] = make_int2((int)(tre << 8) >> 14, (int)(tim << 8) >> 14);
-        } else {
-          asm("" : "+v"(tre)); asm("" : "+v"(tim));
-          const unsigned sre = (tre << 8) + (unsigned)acc_ll[rr], sim = (tim << 8) + (unsigned)acc_ll[rr + 1];
-          rv[k] = make_int2((int)sre >> 14, (int)sim >> 14);
-        }
-      }
+      for (int r = 0; r < 16; r += 2) { sum.x += acc_hh[r] ^ acc_mid[r] ^ acc_ll[r]; sum.y += acc_hh[r + 1] ^ acc_mid[r + 1] ^ acc_ll[r + 1]; }
+#else
+      if (edge) sum = group_sum<ROT, CU8, true>(a, acc_hh, acc_mid, acc_ll, rel0);
+      else sum = group_sum<ROT, CU8, false>(a, acc_hh, acc_mid, acc_ll, rel0);
+#endif
       // the accumulators are dead now: the loads ride through the rest of the epilogue (the touch landed long ago)
       asm volatile("s_waitcnt vmcnt(0)" : "+v"(touch) : : "memory");
       if (tile + 1 < tile_end) fetch(tile + 1);
-      if (ROT) {   // 8 independent table reads in flight
-        const uint32_t cnt0 = (a.n0_lo + (uint32_t)rel0) * a.inc;   // phase counter of the lane's first sample (mod 2^15 below)
-        const uint32_t negx = a.negative ? (127u << 3) : 0u;
-        int2 L[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-          const uint32_t off = (((cnt0 + (uint32_t)(4 * (k >> 1) + (k & 1)) * a.inc) >> 5) & (127u << 3)) ^ negx;
-          L[k] = *reinterpret_cast<const int2 *>(reinterpret_cast<const char *>(lut_s) + off);
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-          const int2 r = rv[k];
-          rv[k].x = mad24a(L[k].x, r.x, -mul24a(L[k].y, r.y)) >> 16;
-          rv[k].y = mad24a(L[k].x, r.y, mul24a(L[k].y, r.x)) >> 16;
-        }
-      }
-      int2 part[2];
-      part[0] = make_int2(0, 0); part[1] = make_int2(0, 0);
-#pragma unroll
-      for (int k = 0; k < 8; k++) {
-        int2 v = rv[k];
-        if (edge) { const int rel = rel0 + 4 * (k >> 1) + (k & 1); if (rel < 0 || rel >= a.N) v = make_int2(0, 0); }
-        part[k >> 2].x = (int)((unsigned)part[k >> 2].x + (unsigned)v.x);
-        part[k >> 2].y = (int)((unsigned)part[k >> 2].y + (unsigned)v.y);
-      }
-      // lane h=0 finishes group 0 of its block, lane h=1 group 1: swap the partial the other one needs
-      const int2 give = h ? part[0] : part[1];
-      int2 sum = h ? part[1] : part[0];
-      sum.x = (int)((unsigned)sum.x + (unsigned)__shfl_xor(give.x, 32));
-      sum.y = (int)((unsigned)sum.y + (unsigned)__shfl_xor(give.y, 32));
 
-      // ---- wave-local group epilogue: lane (n,h) owns group glw = 2n+h of the wave ----------------------
-      const int glw = 2 * n + h;
-      const int ql = gw + glw, q = q0 + ql;   // q = output index within the call when the group completes
-      const bool live = (ql < groups_here) && (q >= 0);
-      if (live && q == 0) {
-        const int2 carry = a.acc_old[c];
-        sum.x = (int)((unsigned)sum.x + (unsigned)carry.x);
-        sum.y = (int)((unsigned)sum.y + (unsigned)carry.y);
-        if (a.extra0) {   // absolute sample 0: one slow FIR evaluation per channel and stream start
-          int er = 0, ei = 0;
-          for (int i = 0; i < a.OP; i++) {
-            const uint32_t x = load_x(a, c, -(a.OP - 1) + i);
-            const uint2 k = a.taps[i];
-            er = dot2(x, k.x, er); ei = dot2(x, k.y, ei);
-          }
-          const int2 v = rotate(a, lut_s, make_int2(er >> 14, ei >> 14), a.n0_lo);
-          sum.x = (int)((unsigned)sum.x + (unsigned)v.x);
-          sum.y = (int)((unsigned)sum.y + (unsigned)v.y);
+      group_finish(a, lut_s, c, n, h, gw, q0, groups_here, sum);
+    }
+    // the channel's last tile rolls the FIR history forward
+    if (tile == a.tiles - 1) {
+      for (int k = tid; k < a.HH; k += TPB) {
+        const long qq = (long)a.N + k;   // index into concat(hist_old, in)
+        a.hist_new[(long)c * a.HH + k] =
+            qq < a.HH ? a.hist_old[(long)c * a.HH + qq] : raw_x(a, c, qq - a.HH);
+      }
+    }
+  }
+}
+
+
+// =================================================================================================
+// Path 1, complex<int16> input: the same matrix part and epilogue as iqbb_i16_mfma_kernel, fed by LDS-DMA.
+//
+// Measured on the register-staged kernel above (ablation builds, one box): without any arithmetic it still takes
+// 104 us of its 160 us, without any global load 105 us — a workgroup has ONE tile of loads in flight, issued after
+// its K loop and waited for before the next staging pass, so HBM latency sits on the critical path of every tile
+// and the 12 prefetch registers cannot be doubled at 127 VGPRs. Here the next tile's raw samples travel global ->
+// LDS by `global_load_lds_dwordx4` (no VGPR destination, nothing to wait for until the tile is needed), issued
+// BEFORE the K loop of the current tile, so a tile has a whole K loop + epilogue to land:
+//   loop:  barrier B1 (raw[i] landed: every wave's vmcnt(0); planes free: every wave is past K loop i-1)
+//          raw[i] -> byte planes (ds_read_b128, 4 v_perm, 2 ds_write_b64 per 4 samples)
+//          barrier B2 (planes[i] complete; raw free)
+//          DMA raw[i+1]  (asynchronous)         K loop i            epilogue i
+// LDS: table | one plane pair | raw tile | tap fragments = 37.6 KB -> 4 workgroups per CU as before.
+// Tiles that touch the call's borders (history, zeros, end of input) fill the raw buffer by ordinary loads.
+// =================================================================================================
+template <int S, bool ROT>
+__global__ __launch_bounds__(TPB, 4) void iqbb_i16_mfma_dma_kernel(const IqbbArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  constexpr int OPc = 16 * (S - 1) + 1;
+  constexpr int PLW = (2 * (TI + OPc) + 64 + 31) / 32 * 8;    // dwords per byte plane
+  constexpr int QUADS = (TI + OPc + 4) / 4;                   // 16-byte pieces (4 samples) of a tile's window
+  constexpr int RAWQ = (QUADS + 63) / 64 * 64;                // raw buffer in pieces: whole wave-instructions
+  constexpr int NQ = (QUADS + TPB - 1) / TPB;
+  int2 *lut_s = reinterpret_cast<int2 *>(smem);
+  uint32_t *lo = smem + 256, *hi = lo + PLW;
+  uint4 *raw = reinterpret_cast<uint4 *>(smem + 256 + 2 * PLW);
+  v4i *taps_s = reinterpret_cast<v4i *>(smem + 256 + 2 * PLW + 4 * RAWQ);
+
+  const int c = blockIdx.y, tid = threadIdx.x;
+  const int w = tid >> 6, l = tid & 63, n = l & 31, h = l >> 5;
+  for (int i = tid; i < S * 2 * 64; i += TPB) taps_s[i] = a.tapfrag[i];
+  if (tid < 128) lut_s[tid] = a.lut[tid];
+
+  const int tile_end = min((int)(blockIdx.x + 1) * a.tpw, a.tiles);
+  int tile = blockIdx.x * a.tpw;
+  const uint32_t *row = a.in + (long)c * a.in_stride;
+
+  // raw[p] = samples first + 4p .. first + 4p + 3 of the tile's window (first = tile start - (OP - 1))
+  auto stage_raw = [&](int tile_) {
+    const int q0_ = tile_ * a.OG - a.ovl;
+    const int first = a.base0_rel + q0_ * 8 - (a.OP - 1);
+    const bool interior = first >= 0 && first + 4 * QUADS <= a.N;   // no history, no end of call (scalar)
+    if (interior) {
+#ifndef K1_ABL_NOFETCH
+#pragma unroll
+      for (int k = 0; k < NQ; k++) {
+        const int p = tid + k * TPB;
+        if (p < QUADS)   // destination: wave-uniform base + 16 * lane
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(row + first + 4 * p),
+                                           (__attribute__((address_space(3))) void *)(raw + (p - l)), 16, 0, 0);
+      }
+#endif
+    } else {
+#pragma unroll
+      for (int k = 0; k < NQ; k++) {
+        const int p = tid + k * TPB;
+        if (p < QUADS)
+          raw[p] = make_uint4(load_x(a, c, first + 4 * p), load_x(a, c, first + 4 * p + 1), load_x(a, c, first + 4 * p + 2),
+                              load_x(a, c, first + 4 * p + 3));
+      }
+    }
+  };
+  if (tile < tile_end) stage_raw(tile);
+  const int OGw = 64 - a.ovl;   // groups a wave emits; with FM its first group only supplies the previous angle
+  for (; tile < tile_end; tile++) {
+    const int q0 = tile * a.OG - a.ovl;
+    const int tb = a.base0_rel + q0 * 8;
+    const int groups_here = min(a.CG, a.n_groups - q0);
+
+    __syncthreads();   // B1: the tile's raw samples have landed (vmcnt(0) of every wave) and the planes are free
+    // ---- four samples -> 8 bytes of the low plane (offset to signed) and 8 of the high plane ----
+#pragma unroll
+    for (int k = 0; k < NQ; k++) {
+      const int p = tid + k * TPB;
+      if (p < QUADS) {
+        const uint4 x = raw[p];
+        // 16-byte chunks (8 samples) are de-interleaved by parity (even chunks in the first half of the plane, odd in
+        // the second): a lane's K steps then walk consecutive chunks and the 16 lanes a ds_read_b128 services together
+        // cover one contiguous 256-byte bank row instead of every other slot
+        const int d = (((p >> 1) & 1) * (PLW >> 1)) + ((p >> 2) << 2) + ((p & 1) << 1);
+        uint2 l2, h2;
+        l2.x = __builtin_amdgcn_perm(x.y, x.x, 0x06040200u) ^ 0x80808080u;
+        l2.y = __builtin_amdgcn_perm(x.w, x.z, 0x06040200u) ^ 0x80808080u;
+        h2.x = __builtin_amdgcn_perm(x.y, x.x, 0x07050301u);
+        h2.y = __builtin_amdgcn_perm(x.w, x.z, 0x07050301u);
+        *reinterpret_cast<uint2 *>(lo + d) = l2;
+        *reinterpret_cast<uint2 *>(hi + d) = h2;
+      }
+    }
+    __syncthreads();   // B2: planes complete, raw buffer free
+    if (tile + 1 < tile_end) stage_raw(tile + 1);   // in flight during this tile's K loop and epilogue
+
+    const int gw = w * OGw;   // this wave's first group within the tile
+    if (gw + a.ovl < groups_here) {   // wave-uniform: the wave has at least one group of its own
+      v16i acc_hh = {0}, acc_mid = {0}, acc_ll = {0};
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc_ll[r] = (r & 1) ? a.cim : a.cre;   // + 128*sum(a) rides in as C
+      // chunk (16 B = 8 samples of one plane) gw + 2(n+s) + h of the tile, in the parity-split layout
+      const int coff = ((gw + h) & 1) * (2 * PLW) + 16 * (((gw + h) >> 1) + n);
+      const char *pl = reinterpret_cast<const char *>(lo) + coff;
+      const char *ph = reinterpret_cast<const char *>(hi) + coff;
+#ifdef K1_ABL_NOKLOOP   // tuning ablation (results wrong): no LDS operand reads, no MFMAs
+      acc_mid[0] = *reinterpret_cast<const int *>(ph); acc_ll[1] = *reinterpret_cast<const int *>(pl);
+#else
+#pragma unroll
+      for (int s = 0; s < S; s++) {
+        // the outer taps of a windowed sinc are small: where every tap a K step touches has a zero high byte, its
+        // two high-plane products are skipped (scalar branch on a mask made at create time; 4 of 9 steps for the
+        // 127-tap north-star filter)
+        const bool has_ah = (a.ah_mask >> s) & 1;
+        const v4i uh = *reinterpret_cast<const v4i *>(ph + 16 * s);
+        const v4i Al = taps_s[(2 * s + 1) * 64 + l];
+        const v4i ul = *reinterpret_cast<const v4i *>(pl + 16 * s);
+        // (the unconditional low-plane products come first: step 0 writes acc_mid with C = 0, so that only acc_hh
+        // needs an explicit zero)
+        acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, uh, acc_mid, 0, 0, 0);
+        acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, ul, acc_ll, 0, 0, 0);
+        if (has_ah) {
+          const v4i Ah = taps_s[(2 * s) * 64 + l];
+          acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, uh, acc_hh, 0, 0, 0);
+          acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, ul, acc_mid, 0, 0, 0);
         }
       }
-      const bool own = live && (glw >= a.ovl);            // the FM overlap slot belongs to the previous wave / tile
-      const bool emits = live && (q < a.n_out);
-      const int yr = (short)box_div(sum.x, 8), yi = (short)box_div(sum.y, 8);
-      if (own && q == a.n_groups - 1) a.acc_new[c] = emits ? make_int2(0, 0) : sum;
-      if (a.epilogue == SDRHIP_EPI_NONE) {
-        if (own && emits) reinterpret_cast<uint32_t *>(a.out)[(long)c * a.out_stride + q] = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
-      } else {
-        short o;
-        if (a.epilogue == SDRHIP_EPI_AM) o = am_i16(yr, yi);
-        else if (a.epilogue == SDRHIP_EPI_USB) o = usb_i16(yr, yi);
-        else {
-          const int phi = fm_phi(yr, yi);
-          // previous group's angle: lane (n,0) for h=1, lane (n-1,1) for h=0
-          const int prev = __shfl(phi, h ? l - 32 : l + 31);
-          if (q == 0) o = (short)yr;             // index 0 is never written by FMDemod (in place)
-          else o = (short)((q == 1 ? (int)a.fm_old[c] : prev) - phi);   // y[0] is never looked at
-          if (own && emits && q == a.n_out - 1 && a.n_out >= 2) a.fm_new[c] = (short)phi;
-        }
-        if (own && emits) reinterpret_cast<short *>(a.out)[(long)c * a.out_stride + q] = o;
-      }
+#endif
+      // ---- epilogue, all in this lane (see iqbb_i16_mfma_kernel): lane (n, h) holds the whole group 2n + h ----
+      const int rel0 = tb + 8 * gw + MF_BLK * n + 8 * h;   // call-relative index of the lane's first sample
+      const bool edge = (tb < 0) || (tb + groups_here * 8 > a.N);   // tile touches the call's borders (scalar)
+      int2 sum;
+#ifdef K1_ABL_NOEPI   // tuning ablation (results wrong): no recombination / rotation / window sum
+      sum = make_int2(0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) { sum.x += acc_hh[r] ^ acc_mid[r] ^ acc_ll[r]; sum.y += acc_hh[r + 1] ^ acc_mid[r + 1] ^ acc_ll[r + 1]; }
+      (void)rel0; (void)edge;
+#else
+      if (edge) sum = group_sum<ROT, false, true>(a, acc_hh, acc_mid, acc_ll, rel0);
+      else sum = group_sum<ROT, false, false>(a, acc_hh, acc_mid, acc_ll, rel0);
+#endif
+      group_finish(a, lut_s, c, n, h, gw, q0, groups_here, sum);
     }
     // the channel's last tile rolls the FIR history forward
     if (tile == a.tiles - 1) {
@@ -1007,6 +1240,7 @@ struct sdrhip_iqbb_i16 {
   int par = 0, par_fm = 0;
   int CG = 0, OG = 0, ovl = 0;
   bool fast8 = false;
+  bool use_dma = true;   // path 1, cs16 input: LDS-DMA fed kernel (SDRHIP_IQBB_DMA=0: the register-staged one, tuning)
   int in_cu8 = 0, real = 0;
   int path = 0, S = 0, cre = 0, cim = 0;   // path 1 = int8-MFMA formulation with S K-steps
   unsigned ah_mask = 0;
@@ -1095,6 +1329,20 @@ struct sdrhip_iqbb_i16 {
         default: SDRHIP_MF16(5); break;
       }
 #undef SDRHIP_MF16
+    } else if (path == 1 && !in_cu8 && use_dma) {
+      // complex<int16> input: raw tiles by LDS-DMA (LDS: table | one plane pair | raw tile | tap fragments)
+      const size_t PLWd = (2 * (size_t)(TI + OP) + 64 + 31) / 32 * 8, quads = (TI + OP + 4) / 4;
+      const size_t ldsd = (256 + 2 * PLWd + 4 * ((quads + 63) / 64 * 64)) * 4 + (size_t)S * 2 * 64 * 16;
+#define SDRHIP_MFD(S_) do { if (inc != 0) hipLaunchKernelGGL((iqbb_i16_mfma_dma_kernel<S_, true>), grid, block, ldsd, ctx->stream, a); \
+                             else hipLaunchKernelGGL((iqbb_i16_mfma_dma_kernel<S_, false>), grid, block, ldsd, ctx->stream, a); } while (0)
+      switch (S) {
+        case 2: SDRHIP_MFD(2); break;
+        case 3: SDRHIP_MFD(3); break;
+        case 5: SDRHIP_MFD(5); break;
+        case 9: SDRHIP_MFD(9); break;
+        default: SDRHIP_MFD(17); break;
+      }
+#undef SDRHIP_MFD
     } else if (path == 1) {
       // complex<uint8> input: the one-plane instantiation (its LDS: two single planes instead of two pairs)
       const size_t lds1 = in_cu8 ? lds_bytes - 2 * (((2 * (size_t)(TI + OP) + 64 + 31) / 32 * 8) * 4) : lds_bytes;
@@ -1157,6 +1405,7 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
       auto high_byte = [](int v) { const int al = ((v + 128) & 255) - 128; return (v - al) >> 8; };
       for (int i = 0; i < 2 * order && mfma_ok; i++)   // both v and -v are packed (Kr, -Ki / Ki, Kr)
         if (high_byte(taps[i]) > 127 || high_byte(-taps[i]) > 127) mfma_ok = false;
+      { const char *d = getenv("SDRHIP_IQBB_DMA"); if (d && d[0] == '0') h->use_dma = false; }
       const char *force = getenv("SDRHIP_IQBB_PATH");   // "valu" / "mfma" / "mfma16": test hook
       if (force && !strcmp(force, "valu")) mfma_ok = false;
       bool mfma16_ok = !real && (decim == R) && (order <= 153);
@@ -1232,7 +1481,14 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
         for (int st = 0; st < h->S; st++)
           for (int l = 0; l < 64; l++)
             for (int j = 0; j < 16; j++) {
-              const int m = h->path == 2 ? (l & 15) : (l & 31), hh = h->path == 2 ? (l >> 4) : (l >> 5), t = m >> 1, comp = m & 1;
+              const int m = h->path == 2 ? (l & 15) : (l & 31), hh = h->path == 2 ? (l >> 4) : (l >> 5);
+              int t = m >> 1, comp = m & 1;
+              if (h->path == 1) {   // row permutation: the 32x32 C/D map gives lane half hC = (m>>2)&1 the rows m with register
+                                    // r = (m&3) + 4*(m>>3); row m carries sample t = 8*hC + (r>>1), component r&1, so that
+                                    // a lane ends up with one whole decimation group (8 consecutive samples)
+                const int hC = (m >> 2) & 1, r = (m & 3) + 4 * (m >> 3);
+                t = 8 * hC + (r >> 1); comp = r & 1;
+              }
               const int idx = (h->path == 2 ? 64 : 32) * st + 16 * hh + j - 2 * t;
               const int v = (idx >= 0 && idx < 2 * OPm) ? (comp ? aim[idx] : are[idx]) : 0;
               const int al = ((v + 128) & 255) - 128, ah = (v - al) >> 8;
