@@ -56,6 +56,7 @@ struct IqbbArgs {
   unsigned ah_mask;   // bit s: the high-byte tap fragments of K step s are not all zero (small outer taps: |a| < 128)
   int lpg;          // path 3: lanes that share one box window
   int tiles, tpw;   // tiles per channel in this call; consecutive tiles walked by one workgroup (MFMA path)   // MFMA path: tap fragments, 128*sum(a) per component
+  int border, bt_hi;   // border launch beside the hot kernel: blockIdx.x 0 -> tile 0, k >= 1 -> tile bt_hi + k - 1, one tile each
 };
 
 // AutoCast< complex<int16_t> > on a complex<uint8_t> sample (reference src/autocast.hh:62,187-194): each byte is
@@ -321,7 +322,6 @@ __device__ __forceinline__ int mul24a(int x, int y) { int d; asm("v_mul_i32_i24 
 __device__ __forceinline__ int mad24a(int x, int y, int z) { int d; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z)); return d; }
 
 __device__ __forceinline__ unsigned mulu24a(unsigned x, unsigned y) { unsigned d; asm("v_mul_u32_u24 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; }
-__device__ __forceinline__ unsigned lshl8_add(unsigned x, unsigned y) { unsigned d; asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(d) : "v"(x), "v"(y)); return d; }
 __device__ __forceinline__ int sub32(int x, int y) { return (int)((unsigned)x - (unsigned)y); }
 // acc + (x >> 16): SDWA picks the sign-extended high half of x, so the shift of the rotation and the box-sum add are one instruction
 __device__ __forceinline__ int add_hi16(int x, int acc) {
@@ -367,15 +367,17 @@ __device__ __forceinline__ int2 group_sum(const IqbbArgs &a, const v16i &acc_hh,
   int2 sum = make_int2(0, 0);
 #pragma unroll
   for (int j = 0; j < 8; j++) {
-    // two v_lshl_add_u32 per component, written as instructions (the compiler re-associates the source form into two
-    // shifts + add3)
-    const unsigned tre = lshl8_add((unsigned)acc_hh[2 * j], (unsigned)acc_mid[2 * j]);
-    const unsigned tim = lshl8_add((unsigned)acc_hh[2 * j + 1], (unsigned)acc_mid[2 * j + 1]);
+    // two v_lshl_add_u32 per component; the empty asm keeps the compiler from re-associating into 2 shifts + add3.
+    // (The first level must stay compiler-generated code: it reads MFMA results, and only the compiler pads the
+    // MFMA -> VALU read hazard; an asm v_lshl_add_u32 there reads stale accumulators.)
+    unsigned tre = ((unsigned)acc_hh[2 * j] << 8) + (unsigned)acc_mid[2 * j];
+    unsigned tim = ((unsigned)acc_hh[2 * j + 1] << 8) + (unsigned)acc_mid[2 * j + 1];
     int rr, ri;
     if (CU8) {   // S = t << 8 exactly
       rr = (int)(tre << 8) >> 14; ri = (int)(tim << 8) >> 14;
     } else {
-      rr = (int)lshl8_add(tre, (unsigned)acc_ll[2 * j]) >> 14; ri = (int)lshl8_add(tim, (unsigned)acc_ll[2 * j + 1]) >> 14;
+      asm("" : "+v"(tre)); asm("" : "+v"(tim));
+      rr = (int)((tre << 8) + (unsigned)acc_ll[2 * j]) >> 14; ri = (int)((tim << 8) + (unsigned)acc_ll[2 * j + 1]) >> 14;
     }
     if (EDGE) { const int rel = rel0 + j; if (rel < 0 || rel >= a.N) { rr = 0; ri = 0; } }   // outside the call: r = 0 -> v = 0
     if (ROT) {
@@ -703,8 +705,9 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_mfma_dma_kernel(const IqbbArg
   for (int i = tid; i < S * 2 * 64; i += TPB) taps_s[i] = a.tapfrag[i];
   if (tid < 128) lut_s[tid] = a.lut[tid];
 
-  const int tile_end = min((int)(blockIdx.x + 1) * a.tpw, a.tiles);
+  int tile_end = min((int)(blockIdx.x + 1) * a.tpw, a.tiles);
   int tile = blockIdx.x * a.tpw;
+  if (a.border) { tile = blockIdx.x == 0 ? 0 : a.bt_hi + (int)blockIdx.x - 1; tile_end = tile + 1; }
   const uint32_t *row = a.in + (long)c * a.in_stride;
 
   // raw[p] = samples first + 4p .. first + 4p + 3 of the tile's window (first = tile start - (OP - 1))
@@ -816,6 +819,174 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_mfma_dma_kernel(const IqbbArg
         a.hist_new[(long)c * a.HH + k] =
             qq < a.HH ? a.hist_old[(long)c * a.HH + qq] : raw_x(a, c, qq - a.HH);
       }
+    }
+  }
+}
+
+
+// =================================================================================================
+// Path 1's HOT kernel (complex<int16> input, D = 8): only tiles whose windows lie wholly inside the call (no
+// history, no end of input, no first-group carry, every group complete) — everything else goes to the general
+// kernel above in a second, small launch. What the r2a counters showed for the general kernel per wave-tile:
+// 285 vector + 154 scalar instructions (36 spilled SGPRs: the cold paths' arguments stay live through the loop)
+// and 49 % of the wave cycles parked at s_waitcnt / s_barrier. Here
+//   * each WAVE runs its own pipeline, no workgroup barrier in the loop: its 640-sample window (512 + the 128-sample
+//     halo; the halo is loaded twice, by two waves) comes in by LDS-DMA into a wave-private raw area, is split into
+//     wave-private byte planes by the same wave, and only that wave reads them; the DMA for the next tile is issued
+//     right after the split and has the whole K loop + epilogue to land. Only the tap fragments and the rotation
+//     table are shared (read-only after the prologue barrier).
+//   * the K loop is straight-line code: the steps that need the taps' high plane are a compile-time range
+//     [S0, S0 + NH) (centred: the big taps of a windowed sinc), operand reads of step s+1 are issued before the
+//     MFMAs of step s.
+//   * the demodulator is a template parameter; no border tests, no state writes.
+// LDS: table 1 KB | tap fragments | per wave {raw 3 KB, planes 2 x 1296 B}.
+// =================================================================================================
+struct HotArgs {
+  const uint32_t *in; long in_stride;   // cs16, one dword per sample
+  void *out; long out_stride;
+  const v4i *tapfrag; const int2 *lut;
+  uint32_t inc, n0_lo; int negative;
+  int base0_rel, OG, ovl;               // as IqbbArgs
+  int t_lo, t_hi, tpw;                  // hot tiles [t_lo, t_hi), walked tpw at a time by one workgroup
+  int cre, cim;
+};
+
+constexpr int HOT_WIN = 512 + 128;                 // samples a wave stages per tile (OP - 1 = 128 halo: S = 9)
+constexpr int HOT_PLB = 2 * HOT_WIN + 32;          // bytes per byte plane (+ one chunk pair: the parity halves stay 16-byte aligned)
+constexpr int HOT_RAWB = HOT_WIN * 4;               // raw area: 160 pieces of 16 bytes = two DMA wave-instructions + 32 lanes of a third
+
+template <int S, int S0, int NH, bool ROT, int EPI>
+__global__ __launch_bounds__(TPB, 4) void iqbb_i16_hot_kernel(const HotArgs a) {
+  static_assert(S == 9, "window geometry (HOT_WIN) is the 127-tap one");
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  int2 *lut_s = reinterpret_cast<int2 *>(smem);
+  v4i *taps_s = reinterpret_cast<v4i *>(smem + 256);
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 31, h = l >> 5;
+  char *wbase = reinterpret_cast<char *>(smem + 256 + S * 2 * 64 * 4) + w * (HOT_RAWB + 2 * HOT_PLB);
+  uint4 *raw = reinterpret_cast<uint4 *>(wbase);
+  char *lo = wbase + HOT_RAWB, *hi = lo + HOT_PLB;
+  const int c = blockIdx.y;
+  for (int i = tid; i < S * 2 * 64; i += TPB) taps_s[i] = a.tapfrag[i];
+  if (tid < 128) lut_s[tid] = a.lut[tid];
+
+  const int OGw = 64 - a.ovl, gw = w * OGw;
+  const uint32_t *row = a.in + (long)c * a.in_stride;
+  int tile = a.t_lo + blockIdx.x * a.tpw;
+  const int tile_end = min(tile + a.tpw, a.t_hi);
+  // the wave's window for tile t starts at sample base0_rel + (t * OG - ovl + gw) * 8 - 128 of the call
+  auto dma = [&](int tile_) {
+    const uint32_t *src = row + (a.base0_rel + (tile_ * a.OG - a.ovl + gw) * 8 - (HOT_WIN - 512));
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      if (k < 2 || l < (HOT_WIN / 4 - 128))   // 160 pieces of 16 bytes: two full wave-instructions and 32 lanes of a third
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 4 * (l + 64 * k)),
+                                         (__attribute__((address_space(3))) void *)(raw + 64 * k), 16, 0, 0);
+    }
+  };
+  if (tile < tile_end) dma(tile);
+  __syncthreads();   // tap fragments and table in place (the only workgroup barrier)
+
+  // plane byte offsets of this lane's pieces: chunk j = p >> 1 (8 samples), parity-split halves, 8 bytes per piece
+  const int HALF = HOT_PLB / 2;
+  int dofs[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) { const int p = l + 64 * k, j = p >> 1; dofs[k] = (j & 1) * HALF + (j >> 1) * 16 + (p & 1) * 8; }
+  const int coff = h * HALF + 16 * n;   // chunk 2(n + s) + h of the wave's window
+  const uint32_t negx = a.negative ? (127u << 3) : 0u;
+
+  for (; tile < tile_end; tile++) {
+    const int q0 = tile * a.OG - a.ovl;
+    // ---- the wave's raw window -> its byte planes ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own DMA (and older stores) retired
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      if (k < 2 || l < (HOT_WIN / 4 - 128)) {
+        const uint4 x = raw[l + 64 * k];
+        uint2 l2, h2;
+        l2.x = __builtin_amdgcn_perm(x.y, x.x, 0x06040200u) ^ 0x80808080u;
+        l2.y = __builtin_amdgcn_perm(x.w, x.z, 0x06040200u) ^ 0x80808080u;
+        h2.x = __builtin_amdgcn_perm(x.y, x.x, 0x07050301u);
+        h2.y = __builtin_amdgcn_perm(x.w, x.z, 0x07050301u);
+        *reinterpret_cast<uint2 *>(lo + dofs[k]) = l2;
+        *reinterpret_cast<uint2 *>(hi + dofs[k]) = h2;
+      }
+    }
+    // (LDS operations of one wave execute in order: the plane reads below see these writes, and the raw reads above
+    // have returned — the permutes consumed them — before the next DMA can overwrite the raw area. The empty asm
+    // statements keep the COMPILER from moving the DMA above the raw reads or the plane reads above the plane writes:
+    // no barrier or fence instruction separates them any more.)
+    asm volatile("" ::: "memory");
+    if (tile + 1 < tile_end) dma(tile + 1);
+    asm volatile("" ::: "memory");
+
+    // ---- K loop: operands of step s+1 in flight while the MFMAs of step s issue ----
+    v16i acc_hh = {0}, acc_mid = {0}, acc_ll = {0};
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc_ll[r] = (r & 1) ? a.cim : a.cre;   // + 128*sum(a) rides in as C
+    const char *pl = lo + coff, *ph = hi + coff;
+    v4i uh = *reinterpret_cast<const v4i *>(ph), ul = *reinterpret_cast<const v4i *>(pl);
+    v4i Al = taps_s[64 + l], Ah = Al;
+    if (S0 == 0) Ah = taps_s[l];
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+      v4i uh_n = uh, ul_n = ul, Al_n = Al, Ah_n = Ah;
+      if (s + 1 < S) {
+        uh_n = *reinterpret_cast<const v4i *>(ph + 16 * (s + 1));
+        ul_n = *reinterpret_cast<const v4i *>(pl + 16 * (s + 1));
+        Al_n = taps_s[(2 * (s + 1) + 1) * 64 + l];
+        if (s + 1 >= S0 && s + 1 < S0 + NH) Ah_n = taps_s[(2 * (s + 1)) * 64 + l];
+      }
+      acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, uh, acc_mid, 0, 0, 0);
+      acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, ul, acc_ll, 0, 0, 0);
+      if (s >= S0 && s < S0 + NH) {
+        acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, uh, acc_hh, 0, 0, 0);
+        acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, ul, acc_mid, 0, 0, 0);
+      }
+      uh = uh_n; ul = ul_n; Al = Al_n; Ah = Ah_n;
+    }
+
+    // ---- epilogue: lane (n, h) owns group 2n + h of the wave ----
+    const int rel0 = a.base0_rel + (q0 + gw) * 8 + MF_BLK * n + 8 * h;
+    int2 L[8];
+    if (ROT) {
+      typedef int v2i __attribute__((ext_vector_type(2)));
+      typedef __attribute__((address_space(3))) const v2i lds_v2i;
+      const uint32_t cnt0 = mulu24a(a.n0_lo + (uint32_t)rel0, a.inc);
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const uint32_t off = (((cnt0 + (uint32_t)j * a.inc) >> 5) & (127u << 3)) ^ negx;
+        const v2i e = *reinterpret_cast<lds_v2i *>((uintptr_t)off);
+        L[j] = make_int2(e.x, e.y);
+      }
+    }
+    int2 sum = make_int2(0, 0);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      unsigned tre = ((unsigned)acc_hh[2 * j] << 8) + (unsigned)acc_mid[2 * j];   // (compiler code: it pads the MFMA -> VALU hazard)
+      unsigned tim = ((unsigned)acc_hh[2 * j + 1] << 8) + (unsigned)acc_mid[2 * j + 1];
+      asm("" : "+v"(tre)); asm("" : "+v"(tim));   // no re-association into 2 shifts + add3
+      const int rr = (int)((tre << 8) + (unsigned)acc_ll[2 * j]) >> 14, ri = (int)((tim << 8) + (unsigned)acc_ll[2 * j + 1]) >> 14;
+      if (ROT) {
+        const int x = sub32(mul24a(L[j].x, rr), mul24a(L[j].y, ri));
+        const int y = mad24a(L[j].x, ri, mul24a(L[j].y, rr));
+        sum.x = add_hi16(x, sum.x); sum.y = add_hi16(y, sum.y);
+      } else {
+        sum.x = (int)((unsigned)sum.x + (unsigned)rr); sum.y = (int)((unsigned)sum.y + (unsigned)ri);
+      }
+    }
+    const int glw = 2 * n + h;
+    const long q = (long)c * a.out_stride + q0 + gw + glw;
+    const int yr = div8_i16(sum.x), yi = div8_i16(sum.y);
+    if (EPI == SDRHIP_EPI_NONE) {
+      reinterpret_cast<uint32_t *>(a.out)[q] = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
+    } else if (EPI == SDRHIP_EPI_AM) {
+      reinterpret_cast<short *>(a.out)[q] = am_i16(yr, yi);
+    } else if (EPI == SDRHIP_EPI_USB) {
+      reinterpret_cast<short *>(a.out)[q] = usb_i16(yr, yi);
+    } else {
+      const int phi = fm_phi(yr, yi);
+      const int prev = prev_group_value(phi, h);
+      if (glw >= 1) reinterpret_cast<short *>(a.out)[q] = (short)(prev - phi);   // group 0 only supplies the previous angle
     }
   }
 }
@@ -1231,6 +1402,32 @@ __global__ __launch_bounds__(TPB, 3) void iqbb_i16_mfma16_kernel(const IqbbArgs 
 
 }  // namespace
 
+namespace {
+template <int S0, int NH, bool ROT>
+void launch_hot_e(int epi, dim3 grid, dim3 block, size_t lds, hipStream_t st, const HotArgs &ha) {
+  switch (epi) {
+    case SDRHIP_EPI_FM: hipLaunchKernelGGL((iqbb_i16_hot_kernel<9, S0, NH, ROT, SDRHIP_EPI_FM>), grid, block, lds, st, ha); break;
+    case SDRHIP_EPI_AM: hipLaunchKernelGGL((iqbb_i16_hot_kernel<9, S0, NH, ROT, SDRHIP_EPI_AM>), grid, block, lds, st, ha); break;
+    case SDRHIP_EPI_USB: hipLaunchKernelGGL((iqbb_i16_hot_kernel<9, S0, NH, ROT, SDRHIP_EPI_USB>), grid, block, lds, st, ha); break;
+    default: hipLaunchKernelGGL((iqbb_i16_hot_kernel<9, S0, NH, ROT, SDRHIP_EPI_NONE>), grid, block, lds, st, ha); break;
+  }
+}
+template <int S0, int NH>
+void launch_hot_r(bool rot, int epi, dim3 grid, dim3 block, size_t lds, hipStream_t st, const HotArgs &ha) {
+  if (rot) launch_hot_e<S0, NH, true>(epi, grid, block, lds, st, ha);
+  else launch_hot_e<S0, NH, false>(epi, grid, block, lds, st, ha);
+}
+// range index r: the K steps [S0, S0 + NH) that run the taps' high plane
+void launch_hot(int r, bool rot, int epi, dim3 grid, dim3 block, size_t lds, hipStream_t st, const HotArgs &ha) {
+  switch (r) {
+    case 0: launch_hot_r<3, 3>(rot, epi, grid, block, lds, st, ha); break;
+    case 1: launch_hot_r<2, 5>(rot, epi, grid, block, lds, st, ha); break;
+    case 2: launch_hot_r<1, 7>(rot, epi, grid, block, lds, st, ha); break;
+    default: launch_hot_r<0, 9>(rot, epi, grid, block, lds, st, ha); break;
+  }
+}
+}  // namespace
+
 struct sdrhip_iqbb_i16 {
   sdrhip_ctx *ctx = nullptr;
   int order = 0, OP = 0, HH = 0, D = 1, C = 1, epi = 0, negative = 0;
@@ -1241,6 +1438,8 @@ struct sdrhip_iqbb_i16 {
   int CG = 0, OG = 0, ovl = 0;
   bool fast8 = false;
   bool use_dma = true;   // path 1, cs16 input: LDS-DMA fed kernel (SDRHIP_IQBB_DMA=0: the register-staged one, tuning)
+  bool use_hot = true;   // ... with the hot kernel for the interior tiles (SDRHIP_IQBB_HOT=0: general kernel only, tuning/tests)
+  int hot_range = -1;    // which compile-time high-plane K-step range of the hot kernel covers ah_mask (-1: none)
   int in_cu8 = 0, real = 0;
   int path = 0, S = 0, cre = 0, cim = 0;   // path 1 = int8-MFMA formulation with S K-steps
   unsigned ah_mask = 0;
@@ -1298,7 +1497,7 @@ struct sdrhip_iqbb_i16 {
     int tpw = 1;
     if (path == 1 || path == 2) { tpw = 8; while (tpw > 1 && (size_t)ceil_div((size_t)tiles, (size_t)tpw) * C < 2048) tpw >>= 1; }
     { const char *t = getenv("SDRHIP_IQBB_TPW"); if (t && (path == 1 || path == 2)) tpw = std::max(1, atoi(t)); }   // tuning hook
-    a.tiles = tiles; a.tpw = tpw;
+    a.tiles = tiles; a.tpw = tpw; a.border = 0; a.bt_hi = 0;
     a.lpg = 1; while (a.lpg < 64 && a.lpg * 8 < D) a.lpg <<= 1;
     dim3 grid((unsigned)ceil_div((size_t)tiles, (size_t)tpw), C), block(TPB);
     if (path == 3) {
@@ -1333,6 +1532,35 @@ struct sdrhip_iqbb_i16 {
       // complex<int16> input: raw tiles by LDS-DMA (LDS: table | one plane pair | raw tile | tap fragments)
       const size_t PLWd = (2 * (size_t)(TI + OP) + 64 + 31) / 32 * 8, quads = (TI + OP + 4) / 4;
       const size_t ldsd = (256 + 2 * PLWd + 4 * ((quads + 63) / 64 * 64)) * 4 + (size_t)S * 2 * 64 * 16;
+      // Hot tiles [1, t_hi): every wave window inside the input, every group complete and emitted, not the call's
+      // first tile (carry, FM's first outputs) and not its last (history roll, state): one lean kernel for them,
+      // the general kernel for the rest (tile 0 and tiles t_hi .. tiles-1, one workgroup each).
+      int t_hi = 0;
+      if (S == 9 && hot_range >= 0 && use_hot) {
+        const long OGw = 64 - ovl;
+        auto hot_ok = [&](long t) {
+          const long q0 = t * OG - ovl, last = (long)g.base0_rel + q0 * 8 + 3 * OGw * 8 + 512;
+          return t >= 1 && t < tiles - 1 && last <= (long)N && q0 + 3 * OGw + 63 < (long)g.n_out && (long)g.base0_rel + q0 * 8 - 128 >= 0;
+        };
+        long t = tiles - 2;
+        while (t >= 1 && !hot_ok(t)) t--;
+        if (t >= 2) t_hi = (int)t + 1;   // (hot_ok is monotone below the end of the call)
+      }
+      if (t_hi > 0) {
+        HotArgs ha;
+        ha.in = in_dev; ha.in_stride = (long)in_stride; ha.out = out_dev; ha.out_stride = (long)out_stride;
+        ha.tapfrag = tapfrag.p; ha.lut = lut.p; ha.inc = inc; ha.n0_lo = (uint32_t)n0; ha.negative = negative;
+        ha.base0_rel = g.base0_rel; ha.OG = OG; ha.ovl = ovl; ha.t_lo = 1; ha.t_hi = t_hi; ha.cre = cre; ha.cim = cim;
+        const int nhot = t_hi - 1;
+        int htpw = 8; while (htpw > 1 && (size_t)ceil_div((size_t)nhot, (size_t)htpw) * C < 2048) htpw >>= 1;
+        { const char *t = getenv("SDRHIP_IQBB_TPW"); if (t) htpw = std::max(1, atoi(t)); }   // tuning hook
+        ha.tpw = htpw;
+        const dim3 hgrid((unsigned)ceil_div((size_t)nhot, (size_t)htpw), C);
+        const size_t hlds = 1024 + (size_t)S * 2 * 64 * 16 + 4 * (size_t)(HOT_RAWB + 2 * HOT_PLB);
+        launch_hot(hot_range, inc != 0, epi, hgrid, block, hlds, ctx->stream, ha);
+        a.border = 1; a.bt_hi = t_hi; a.tpw = 1;
+        grid = dim3((unsigned)(1 + tiles - t_hi), C);
+      }
 #define SDRHIP_MFD(S_) do { if (inc != 0) hipLaunchKernelGGL((iqbb_i16_mfma_dma_kernel<S_, true>), grid, block, ldsd, ctx->stream, a); \
                              else hipLaunchKernelGGL((iqbb_i16_mfma_dma_kernel<S_, false>), grid, block, ldsd, ctx->stream, a); } while (0)
       switch (S) {
@@ -1406,6 +1634,7 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
       for (int i = 0; i < 2 * order && mfma_ok; i++)   // both v and -v are packed (Kr, -Ki / Ki, Kr)
         if (high_byte(taps[i]) > 127 || high_byte(-taps[i]) > 127) mfma_ok = false;
       { const char *d = getenv("SDRHIP_IQBB_DMA"); if (d && d[0] == '0') h->use_dma = false; }
+      { const char *d = getenv("SDRHIP_IQBB_HOT"); if (d && d[0] == '0') h->use_hot = false; }
       const char *force = getenv("SDRHIP_IQBB_PATH");   // "valu" / "mfma" / "mfma16": test hook
       if (force && !strcmp(force, "valu")) mfma_ok = false;
       bool mfma16_ok = !real && (decim == R) && (order <= 153);
@@ -1496,6 +1725,10 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
               if (ah != 0) h->ah_mask |= 1u << st;
               frag[(((size_t)(2 * st + 1) * 64 + l) * 16) + j] = (int8_t)al;
             }
+        if (h->path == 1 && h->S == 9) {   // smallest centred range [S0, S0+NH) of the hot kernel that covers the mask
+          const unsigned ranges[4] = {0x7u << 3, 0x1fu << 2, 0x7fu << 1, 0x1ffu};
+          for (int r = 0; r < 4 && h->hot_range < 0; r++) if ((h->ah_mask & ~ranges[r]) == 0) h->hot_range = r;
+        }
         h->tapfrag.alloc((size_t)h->S * 2 * 64);
         h->tapfrag.upload(reinterpret_cast<const v4i *>(frag.data()), (size_t)h->S * 2 * 64, ctx->stream);
       }
