@@ -841,13 +841,17 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_mfma_dma_kernel(const IqbbArg
 //   * the demodulator is a template parameter; no border tests, no state writes.
 // LDS: table 1 KB | tap fragments | per wave {raw 3 KB, planes 2 x 1296 B}.
 // =================================================================================================
+#ifdef K1_STAMPS
+__device__ unsigned long long g_k1_stamps[32768 * 8];   // per wave of one launch: 5 phase totals, 1 marker
+#endif
 struct HotArgs {
   const uint32_t *in; long in_stride;   // cs16, one dword per sample
   void *out; long out_stride;
   const v4i *tapfrag; const int2 *lut;
   uint32_t inc, n0_lo; int negative;
   int base0_rel, OG, ovl;               // as IqbbArgs
-  int t_lo, t_hi, tpw;                  // hot tiles [t_lo, t_hi), walked tpw at a time by one workgroup
+  int t_lo, t_hi, tpw;                  // hot tiles [t_lo, t_hi); a work unit = tpw consecutive ones of a channel
+  int G, U, dq, dr;                     // units per channel, units in all, gridDim.x / G and gridDim.x % G (persistent grid)
   int cre, cim;
 };
 
@@ -862,28 +866,37 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_hot_kernel(const HotArgs a) {
   int2 *lut_s = reinterpret_cast<int2 *>(smem);
   v4i *taps_s = reinterpret_cast<v4i *>(smem + 256);
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 31, h = l >> 5;
-  char *wbase = reinterpret_cast<char *>(smem + 256 + S * 2 * 64 * 4) + w * (HOT_RAWB + 2 * HOT_PLB);
+  // tap fragments in LDS: the S low-plane fragments, then only the NH high-plane fragments of steps [S0, S0 + NH)
+  char *wbase = reinterpret_cast<char *>(smem + 256 + (S + NH) * 64 * 4) + w * (HOT_RAWB + 2 * HOT_PLB);
   uint4 *raw = reinterpret_cast<uint4 *>(wbase);
   char *lo = wbase + HOT_RAWB, *hi = lo + HOT_PLB;
-  const int c = blockIdx.y;
-  for (int i = tid; i < S * 2 * 64; i += TPB) taps_s[i] = a.tapfrag[i];
+  for (int i = tid; i < S * 64; i += TPB) taps_s[i] = a.tapfrag[(2 * (i >> 6) + 1) * 64 + (i & 63)];
+  for (int i = tid; i < NH * 64; i += TPB) taps_s[S * 64 + i] = a.tapfrag[(2 * (S0 + (i >> 6))) * 64 + (i & 63)];
   if (tid < 128) lut_s[tid] = a.lut[tid];
 
   const int OGw = 64 - a.ovl, gw = w * OGw;
-  const uint32_t *row = a.in + (long)c * a.in_stride;
-  int tile = a.t_lo + blockIdx.x * a.tpw;
-  const int tile_end = min(tile + a.tpw, a.t_hi);
-  // the wave's window for tile t starts at sample base0_rel + (t * OG - ovl + gw) * 8 - 128 of the call
-  auto dma = [&](int tile_) {
-    const uint32_t *src = row + (a.base0_rel + (tile_ * a.OG - a.ovl + gw) * 8 - (HOT_WIN - 512));
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      if (k < 2 || l < (HOT_WIN / 4 - 128))   // 160 pieces of 16 bytes: two full wave-instructions and 32 lanes of a third
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 4 * (l + 64 * k)),
-                                         (__attribute__((address_space(3))) void *)(raw + 64 * k), 16, 0, 0);
-    }
+  // PERSISTENT grid: gridDim.x workgroups (4 per CU) stay resident and walk the work units u = blockIdx.x,
+  // blockIdx.x + gridDim.x, ...; unit u = (channel u / G, tile group u % G of `tpw` consecutive hot tiles). With one
+  // workgroup per unit the waves of a workgroup — no barrier holds them together any more — finished up to 2x apart,
+  // the workgroup's LDS and its fast waves' register slots stayed allocated until the slowest wave was done, and only
+  // ~3 of the 4 workgroups per CU were resident in steady state (2.74 waves per SIMD on average, measured with
+  // s_memrealtime stamps). All units are the same length, so the static assignment balances.
+  int u = blockIdx.x;
+  int c = u / a.G, g = u - c * a.G;   // (one division per wave, at start; afterwards (c, g) advance by (dq, dr))
+  int tile = a.t_lo + g * a.tpw, tile_end = min(tile + a.tpw, a.t_hi);
+  // piece k (0..2) of a wave window: one DMA wave-instruction, 64 (the last: 32) lanes x 16 bytes. The window of
+  // tile t starts at sample base0_rel + (t * OG - ovl + gw) * 8 - 128 of the channel's row.
+  auto dma_piece = [&](int c_, int tile_, int k) {
+    const uint32_t *src = a.in + (long)c_ * a.in_stride + (a.base0_rel + (tile_ * a.OG - a.ovl + gw) * 8 - (HOT_WIN - 512));
+#ifndef K1_ABL_NOFETCH
+    if (k < 2 || l < (HOT_WIN / 4 - 128))   // 160 pieces of 16 bytes: two full wave-instructions and 32 lanes of a third
+#else
+    if (false)
+#endif
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 4 * (l + 64 * k)),
+                                       (__attribute__((address_space(3))) void *)(raw + 64 * k), 16, 0, 0);
   };
-  if (tile < tile_end) dma(tile);
+  if (u < a.U) { dma_piece(c, tile, 0); dma_piece(c, tile, 1); dma_piece(c, tile, 2); }
   __syncthreads();   // tap fragments and table in place (the only workgroup barrier)
 
   // plane byte offsets of this lane's pieces: chunk j = p >> 1 (8 samples), parity-split halves, 8 bytes per piece
@@ -894,13 +907,50 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_hot_kernel(const HotArgs a) {
   const int coff = h * HALF + 16 * n;   // chunk 2(n + s) + h of the wave's window
   const uint32_t negx = a.negative ? (127u << 3) : 0u;
 
-  for (; tile < tile_end; tile++) {
+#ifdef K1_STAMPS   // diagnostic build: shader-clock stamps at the phase boundaries, summed per phase per wave
+  unsigned long long st_acc[5] = {0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
+  const unsigned long long st_r0 = __builtin_amdgcn_s_memrealtime();
+  unsigned st_tiles = 0;
+#define K1_STAMP(i_) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i_] += t_ - st_t; st_t = t_; } while (0)
+#else
+#define K1_STAMP(i_) do { } while (0)
+#endif
+  unsigned prio_it = 0;
+  const unsigned prio_slot = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 3u;   // HW_REG_HW_ID[3:0]: the wave's slot in its SIMD
+  while (u < a.U) {
+    // the step after this one: next tile of the unit, or the first tile of the workgroup's next unit
+    int nu = u, nc = c, ng = g, ntile = tile + 1, ntile_end = tile_end;
+    if (ntile >= tile_end) {
+      nu = u + (int)gridDim.x; nc = c + a.dq; ng = g + a.dr;
+      if (ng >= a.G) { ng -= a.G; nc++; }
+      ntile = a.t_lo + ng * a.tpw; ntile_end = min(ntile + a.tpw, a.t_hi);
+    }
+    const bool more = nu < a.U;
     const int q0 = tile * a.OG - a.ovl;
+#ifndef K1_PRIO_ROT
+#define K1_PRIO_ROT 1
+#endif
+    // Fairness: the SIMD arbitrates its waves by priority, then AGE, and in a persistent grid the ages never change —
+    // the oldest wave of a SIMD ran at full speed and was done after 64 us, the youngest starved and finished alone
+    // at 120 us (s_memrealtime stamps). The priority rotates over the SIMD's four wave slots, one step per tile.
+    if (K1_PRIO_ROT) {
+      switch ((prio_it++ + prio_slot) & 3u) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+      }
+    }
     // ---- the wave's raw window -> its byte planes ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own DMA (and older stores) retired
+    K1_STAMP(0);
 #pragma unroll
     for (int k = 0; k < 3; k++) {
+#ifndef K1_ABL_NOCONV
       if (k < 2 || l < (HOT_WIN / 4 - 128)) {
+#else
+      if (false) {
+#endif
         const uint4 x = raw[l + 64 * k];
         uint2 l2, h2;
         l2.x = __builtin_amdgcn_perm(x.y, x.x, 0x06040200u) ^ 0x80808080u;
@@ -915,8 +965,7 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_hot_kernel(const HotArgs a) {
     // have returned — the permutes consumed them — before the next DMA can overwrite the raw area. The empty asm
     // statements keep the COMPILER from moving the DMA above the raw reads or the plane reads above the plane writes:
     // no barrier or fence instruction separates them any more.)
-    asm volatile("" ::: "memory");
-    if (tile + 1 < tile_end) dma(tile + 1);
+    K1_STAMP(1);
     asm volatile("" ::: "memory");
 
     // ---- K loop: operands of step s+1 in flight while the MFMAs of step s issue ----
@@ -925,16 +974,20 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_hot_kernel(const HotArgs a) {
     for (int r = 0; r < 16; r++) acc_ll[r] = (r & 1) ? a.cim : a.cre;   // + 128*sum(a) rides in as C
     const char *pl = lo + coff, *ph = hi + coff;
     v4i uh = *reinterpret_cast<const v4i *>(ph), ul = *reinterpret_cast<const v4i *>(pl);
-    v4i Al = taps_s[64 + l], Ah = Al;
-    if (S0 == 0) Ah = taps_s[l];
+    v4i Al = taps_s[l], Ah = Al;
+    if (S0 == 0) Ah = taps_s[S * 64 + l];
+#ifdef K1_ABL_NOKLOOP
+    acc_mid[0] = uh.x ^ ul.x ^ Al.x ^ Ah.x;
+    if (more) { dma_piece(nc, ntile, 0); dma_piece(nc, ntile, 1); dma_piece(nc, ntile, 2); }
+#else
 #pragma unroll
     for (int s = 0; s < S; s++) {
       v4i uh_n = uh, ul_n = ul, Al_n = Al, Ah_n = Ah;
       if (s + 1 < S) {
         uh_n = *reinterpret_cast<const v4i *>(ph + 16 * (s + 1));
         ul_n = *reinterpret_cast<const v4i *>(pl + 16 * (s + 1));
-        Al_n = taps_s[(2 * (s + 1) + 1) * 64 + l];
-        if (s + 1 >= S0 && s + 1 < S0 + NH) Ah_n = taps_s[(2 * (s + 1)) * 64 + l];
+        Al_n = taps_s[(s + 1) * 64 + l];
+        if (s + 1 >= S0 && s + 1 < S0 + NH) Ah_n = taps_s[(S + s + 1 - S0) * 64 + l];
       }
       acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, uh, acc_mid, 0, 0, 0);
       acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, ul, acc_ll, 0, 0, 0);
@@ -943,12 +996,27 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_hot_kernel(const HotArgs a) {
         acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, ul, acc_mid, 0, 0, 0);
       }
       uh = uh_n; ul = ul_n; Al = Al_n; Ah = Ah_n;
+      // the next step's three DMA instructions, spread over the K loop (the raw area is free: it was split above)
+      if (more && (s == 1 || s == 4 || s == 7)) {
+        asm volatile("" ::: "memory");
+        dma_piece(nc, ntile, (s - 1) / 3);
+        asm volatile("" ::: "memory");
+      }
     }
+#endif
+#ifdef K1_STAMPS
+    asm volatile("s_nop 0" : "+v"(acc_hh), "+v"(acc_mid), "+v"(acc_ll));   // the accumulators are complete before the stamp
+#endif
+    K1_STAMP(2);
 
     // ---- epilogue: lane (n, h) owns group 2n + h of the wave ----
     const int rel0 = a.base0_rel + (q0 + gw) * 8 + MF_BLK * n + 8 * h;
     int2 L[8];
+#ifdef K1_ABL_NOEPI
+    if (false) {
+#else
     if (ROT) {
+#endif
       typedef int v2i __attribute__((ext_vector_type(2)));
       typedef __attribute__((address_space(3))) const v2i lds_v2i;
       const uint32_t cnt0 = mulu24a(a.n0_lo + (uint32_t)rel0, a.inc);
@@ -960,6 +1028,10 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_hot_kernel(const HotArgs a) {
       }
     }
     int2 sum = make_int2(0, 0);
+#ifdef K1_ABL_NOEPI
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) { sum.x += acc_hh[r] ^ acc_mid[r] ^ acc_ll[r]; sum.y += acc_hh[r + 1] ^ acc_mid[r + 1] ^ acc_ll[r + 1]; }
+#else
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       unsigned tre = ((unsigned)acc_hh[2 * j] << 8) + (unsigned)acc_mid[2 * j];   // (compiler code: it pads the MFMA -> VALU hazard)
@@ -974,6 +1046,11 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_hot_kernel(const HotArgs a) {
         sum.x = (int)((unsigned)sum.x + (unsigned)rr); sum.y = (int)((unsigned)sum.y + (unsigned)ri);
       }
     }
+#endif
+#ifdef K1_STAMPS
+    asm volatile("" : "+v"(sum.x), "+v"(sum.y));
+#endif
+    K1_STAMP(3);
     const int glw = 2 * n + h;
     const long q = (long)c * a.out_stride + q0 + gw + glw;
     const int yr = div8_i16(sum.x), yi = div8_i16(sum.y);
@@ -988,9 +1065,22 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_hot_kernel(const HotArgs a) {
       const int prev = prev_group_value(phi, h);
       if (glw >= 1) reinterpret_cast<short *>(a.out)[q] = (short)(prev - phi);   // group 0 only supplies the previous angle
     }
+    K1_STAMP(4);
+#ifdef K1_STAMPS
+    st_tiles++;
+#endif
+    u = nu; c = nc; g = ng; tile = ntile; tile_end = ntile_end;
   }
+#ifdef K1_STAMPS
+  if (l == 0) {
+    const unsigned wv = (blockIdx.x * 4 + w) & 32767u;
+    for (int i = 0; i < 5; i++) g_k1_stamps[wv * 8 + i] = st_acc[i];
+    g_k1_stamps[wv * 8 + 5] = (unsigned long long)st_tiles | ((unsigned long long)__builtin_amdgcn_s_getreg((15 << 11) | 4) << 32);
+    g_k1_stamps[wv * 8 + 6] = st_r0;
+    g_k1_stamps[wv * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
-
 
 // =================================================================================================
 // Path 3: the 32x32x32 formulation for ANY decimation D. The matrix part is path 1's (every input sample's FIR
@@ -1552,11 +1642,17 @@ struct sdrhip_iqbb_i16 {
         ha.tapfrag = tapfrag.p; ha.lut = lut.p; ha.inc = inc; ha.n0_lo = (uint32_t)n0; ha.negative = negative;
         ha.base0_rel = g.base0_rel; ha.OG = OG; ha.ovl = ovl; ha.t_lo = 1; ha.t_hi = t_hi; ha.cre = cre; ha.cim = cim;
         const int nhot = t_hi - 1;
-        int htpw = 8; while (htpw > 1 && (size_t)ceil_div((size_t)nhot, (size_t)htpw) * C < 2048) htpw >>= 1;
+        // persistent grid of 4 workgroups per CU; units of at most 4 tiles so that the static split leaves a short tail
+        const int nwg = 4 * ctx->prop.multiProcessorCount;
+        int htpw = 4; while (htpw > 1 && (size_t)ceil_div((size_t)nhot, (size_t)htpw) * C < 4 * (size_t)nwg) htpw >>= 1;
         { const char *t = getenv("SDRHIP_IQBB_TPW"); if (t) htpw = std::max(1, atoi(t)); }   // tuning hook
         ha.tpw = htpw;
-        const dim3 hgrid((unsigned)ceil_div((size_t)nhot, (size_t)htpw), C);
-        const size_t hlds = 1024 + (size_t)S * 2 * 64 * 16 + 4 * (size_t)(HOT_RAWB + 2 * HOT_PLB);
+        ha.G = (int)ceil_div((size_t)nhot, (size_t)htpw); ha.U = ha.G * C;
+        const int gx = std::min(nwg, ha.U);
+        ha.dq = gx / ha.G; ha.dr = gx % ha.G;
+        const dim3 hgrid((unsigned)gx, 1);
+        static const int hot_nh[4] = {3, 5, 7, 9};
+        const size_t hlds = 1024 + (size_t)(S + hot_nh[hot_range < 0 ? 3 : hot_range]) * 64 * 16 + 4 * (size_t)(HOT_RAWB + 2 * HOT_PLB);
         launch_hot(hot_range, inc != 0, epi, hgrid, block, hlds, ctx->stream, ha);
         a.border = 1; a.bt_hi = t_hi; a.tpw = 1;
         grid = dim3((unsigned)(1 + tiles - t_hi), C);
@@ -1868,3 +1964,9 @@ int sdrhip_iqbb_i16_destroy(sdrhip_iqbb_i16 *h) {
 }
 
 }  // extern "C"
+
+#ifdef K1_STAMPS
+extern "C" int sdrhip_debug_k1_stamps(unsigned long long *out, int words) {   // diagnostic builds only (tools/build_variant.sh)
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k1_stamps), (size_t)words * 8) == hipSuccess ? 0 : -3;
+}
+#endif
