@@ -56,7 +56,7 @@ struct IqbbArgs {
   unsigned ah_mask;   // bit s: the high-byte tap fragments of K step s are not all zero (small outer taps: |a| < 128)
   int lpg;          // path 3: lanes that share one box window
   int tiles, tpw;   // tiles per channel in this call; consecutive tiles walked by one workgroup (MFMA path)   // MFMA path: tap fragments, 128*sum(a) per component
-  int border, bt_hi;   // border launch beside the hot kernel: blockIdx.x 0 -> tile 0, k >= 1 -> tile bt_hi + k - 1, one tile each
+  int border, bt_hi;   // border launch beside the hot kernel: one workgroup per channel walks tile 0, then tiles bt_hi .. tiles-1
 };
 
 // AutoCast< complex<int16_t> > on a complex<uint8_t> sample (reference src/autocast.hh:62,187-194): each byte is
@@ -671,6 +671,16 @@ __global__ __launch_bounds__(TPB, CU8 ? 5 : 4) void iqbb_i16_mfma_kernel(const I
 }
 
 
+// A wave slice (tile t, wave w of the tile's workgroup: 64 groups, the first of them FM's overlap slot) is "hot" when
+// nothing about it touches the call's borders: its 640-sample window lies inside the input, none of its groups is
+// the call's first (carry, the D+1 first window, FM's out[0] / out[1] rules) and all of them complete and are emitted.
+// The hot kernel computes exactly these slices; the general kernel, in its border launch, exactly the others.
+__device__ __forceinline__ bool slice_is_hot(int base0_rel, int OG, int ovl, int N, int n_out, int tile, int w) {
+  const int qf = tile * OG - ovl + w * (64 - ovl);   // the slice's first group (output index within the call)
+  const int ws = base0_rel + qf * 8 - 128;           // its window's first sample
+  return ws >= 0 && ws + 640 <= N && qf >= 1 && qf + 63 < n_out;
+}
+
 // =================================================================================================
 // Path 1, complex<int16> input: the same matrix part and epilogue as iqbb_i16_mfma_kernel, fed by LDS-DMA.
 //
@@ -707,7 +717,10 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_mfma_dma_kernel(const IqbbArg
 
   int tile_end = min((int)(blockIdx.x + 1) * a.tpw, a.tiles);
   int tile = blockIdx.x * a.tpw;
-  if (a.border) { tile = blockIdx.x == 0 ? 0 : a.bt_hi + (int)blockIdx.x - 1; tile_end = tile + 1; }
+  // border launch: ONE workgroup per channel walks tile 0 and then the tiles bt_hi .. tiles-1 (the next tile's raw
+  // samples are staged during the current one's compute, the tap fragments are fetched once)
+  if (a.border) { tile = 0; tile_end = a.tiles; }
+  auto next_tile = [&](int t) { return (a.border && t == 0) ? a.bt_hi : t + 1; };
   const uint32_t *row = a.in + (long)c * a.in_stride;
 
   // raw[p] = samples first + 4p .. first + 4p + 3 of the tile's window (first = tile start - (OP - 1))
@@ -726,18 +739,36 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_mfma_dma_kernel(const IqbbArg
       }
 #endif
     } else {
+      // border tile: history / input / zeros per sample, branch-free — every load is issued unconditionally from a
+      // clamped address and masked afterwards, so that all of a lane's 12 loads are in flight together (per-sample
+      // branches made each load its own round trip: 28 us for the 2 border tiles of 1024 channels)
+      const uint32_t *hrow = a.hist_old + (long)c * a.HH;
+      uint32_t v[NQ][4];
+#pragma unroll
+      for (int k = 0; k < NQ; k++) {
+        const int p = min(tid + k * TPB, QUADS - 1);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int rel = first + 4 * p + j, hh = a.HH + rel;
+          const uint32_t *src = rel >= 0 ? row + min(rel, a.N - 1) : hrow + max(hh, 0);
+          v[k][j] = *src;
+        }
+      }
 #pragma unroll
       for (int k = 0; k < NQ; k++) {
         const int p = tid + k * TPB;
-        if (p < QUADS)
-          raw[p] = make_uint4(load_x(a, c, first + 4 * p), load_x(a, c, first + 4 * p + 1), load_x(a, c, first + 4 * p + 2),
-                              load_x(a, c, first + 4 * p + 3));
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int rel = first + 4 * min(p, QUADS - 1) + j;
+          if (rel >= a.N || a.HH + rel < 0) v[k][j] = 0u;
+        }
+        if (p < QUADS) raw[p] = make_uint4(v[k][0], v[k][1], v[k][2], v[k][3]);
       }
     }
   };
   if (tile < tile_end) stage_raw(tile);
   const int OGw = 64 - a.ovl;   // groups a wave emits; with FM its first group only supplies the previous angle
-  for (; tile < tile_end; tile++) {
+  for (; tile < tile_end; tile = next_tile(tile)) {
     const int q0 = tile * a.OG - a.ovl;
     const int tb = a.base0_rel + q0 * 8;
     const int groups_here = min(a.CG, a.n_groups - q0);
@@ -763,10 +794,12 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_mfma_dma_kernel(const IqbbArg
       }
     }
     __syncthreads();   // B2: planes complete, raw buffer free
-    if (tile + 1 < tile_end) stage_raw(tile + 1);   // in flight during this tile's K loop and epilogue
+    if (next_tile(tile) < tile_end) stage_raw(next_tile(tile));   // in flight during this tile's K loop and epilogue
 
     const int gw = w * OGw;   // this wave's first group within the tile
-    if (gw + a.ovl < groups_here) {   // wave-uniform: the wave has at least one group of its own
+    // (border launch: the slices the hot kernel computes are only staged here, not computed)
+    const bool mine = !(a.border && slice_is_hot(a.base0_rel, a.OG, a.ovl, a.N, a.n_out, tile, w));
+    if (mine && gw + a.ovl < groups_here) {   // wave-uniform: the wave has at least one group of its own
       v16i acc_hh = {0}, acc_mid = {0}, acc_ll = {0};
 #pragma unroll
       for (int r = 0; r < 16; r++) acc_ll[r] = (r & 1) ? a.cim : a.cre;   // + 128*sum(a) rides in as C
@@ -852,6 +885,7 @@ struct HotArgs {
   int base0_rel, OG, ovl;               // as IqbbArgs
   int t_lo, t_hi, tpw;                  // hot tiles [t_lo, t_hi); a work unit = tpw consecutive ones of a channel
   int G, U, dq, dr;                     // units per channel, units in all, gridDim.x / G and gridDim.x % G (persistent grid)
+  int N, n_out;                         // samples per channel in this call, groups emitted (slice_is_hot)
   int cre, cim;
 };
 
@@ -884,6 +918,17 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_hot_kernel(const HotArgs a) {
   int u = blockIdx.x;
   int c = u / a.G, g = u - c * a.G;   // (one division per wave, at start; afterwards (c, g) advance by (dq, dr))
   int tile = a.t_lo + g * a.tpw, tile_end = min(tile + a.tpw, a.t_hi);
+  // (a wave walks only its hot slices — slice_is_hot — of these tiles; the others belong to the border launch)
+  auto skip_cold = [&](int &u_, int &c_, int &g_, int &tile_, int &tile_end_) {
+    while (u_ < a.U && !slice_is_hot(a.base0_rel, a.OG, a.ovl, a.N, a.n_out, tile_, w)) {
+      if (++tile_ >= tile_end_) {
+        u_ += (int)gridDim.x; c_ += a.dq; g_ += a.dr;
+        if (g_ >= a.G) { g_ -= a.G; c_++; }
+        tile_ = a.t_lo + g_ * a.tpw; tile_end_ = min(tile_ + a.tpw, a.t_hi);
+      }
+    }
+  };
+  skip_cold(u, c, g, tile, tile_end);
   // piece k (0..2) of a wave window: one DMA wave-instruction, 64 (the last: 32) lanes x 16 bytes. The window of
   // tile t starts at sample base0_rel + (t * OG - ovl + gw) * 8 - 128 of the channel's row.
   auto dma_piece = [&](int c_, int tile_, int k) {
@@ -925,6 +970,7 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_hot_kernel(const HotArgs a) {
       if (ng >= a.G) { ng -= a.G; nc++; }
       ntile = a.t_lo + ng * a.tpw; ntile_end = min(ntile + a.tpw, a.t_hi);
     }
+    skip_cold(nu, nc, ng, ntile, ntile_end);
     const bool more = nu < a.U;
     const int q0 = tile * a.OG - a.ovl;
 #ifndef K1_PRIO_ROT
@@ -1625,23 +1671,26 @@ struct sdrhip_iqbb_i16 {
       // Hot tiles [1, t_hi): every wave window inside the input, every group complete and emitted, not the call's
       // first tile (carry, FM's first outputs) and not its last (history roll, state): one lean kernel for them,
       // the general kernel for the rest (tile 0 and tiles t_hi .. tiles-1, one workgroup each).
+      // The hot kernel computes every hot wave slice (slice_is_hot) of every tile; the general kernel follows with a
+      // border launch over the tiles that hold the other slices — tile 0 and the tiles from t_hi on, one workgroup
+      // each, in which only the cold slices are computed (and the last tile rolls the history).
       int t_hi = 0;
-      if (S == 9 && hot_range >= 0 && use_hot) {
-        const long OGw = 64 - ovl;
-        auto hot_ok = [&](long t) {
-          const long q0 = t * OG - ovl, last = (long)g.base0_rel + q0 * 8 + 3 * OGw * 8 + 512;
-          return t >= 1 && t < tiles - 1 && last <= (long)N && q0 + 3 * OGw + 63 < (long)g.n_out && (long)g.base0_rel + q0 * 8 - 128 >= 0;
+      if (S == 9 && hot_range >= 0 && use_hot && tiles >= 3) {
+        auto host_hot = [&](long t, long w) {
+          const long qf = t * OG - ovl + w * (64 - ovl), ws = (long)g.base0_rel + qf * 8 - 128;
+          return ws >= 0 && ws + 640 <= (long)N && qf >= 1 && qf + 63 < (long)g.n_out;
         };
-        long t = tiles - 2;
-        while (t >= 1 && !hot_ok(t)) t--;
-        if (t >= 2) t_hi = (int)t + 1;   // (hot_ok is monotone below the end of the call)
+        long t = tiles - 1;   // the last tile always goes to the border launch (history roll, state)
+        while (t >= 2 && !(host_hot(t - 1, 0) && host_hot(t - 1, 1) && host_hot(t - 1, 2) && host_hot(t - 1, 3))) t--;
+        if (t >= 2) t_hi = (int)t;
       }
       if (t_hi > 0) {
         HotArgs ha;
         ha.in = in_dev; ha.in_stride = (long)in_stride; ha.out = out_dev; ha.out_stride = (long)out_stride;
         ha.tapfrag = tapfrag.p; ha.lut = lut.p; ha.inc = inc; ha.n0_lo = (uint32_t)n0; ha.negative = negative;
-        ha.base0_rel = g.base0_rel; ha.OG = OG; ha.ovl = ovl; ha.t_lo = 1; ha.t_hi = t_hi; ha.cre = cre; ha.cim = cim;
-        const int nhot = t_hi - 1;
+        ha.base0_rel = g.base0_rel; ha.OG = OG; ha.ovl = ovl; ha.t_lo = 0; ha.t_hi = tiles; ha.cre = cre; ha.cim = cim;
+        ha.N = (int)N; ha.n_out = g.n_out;
+        const int nhot = tiles;
         // persistent grid of 4 workgroups per CU; units of at most 4 tiles so that the static split leaves a short tail
         const int nwg = 4 * ctx->prop.multiProcessorCount;
         int htpw = 4; while (htpw > 1 && (size_t)ceil_div((size_t)nhot, (size_t)htpw) * C < 4 * (size_t)nwg) htpw >>= 1;
@@ -1655,7 +1704,7 @@ struct sdrhip_iqbb_i16 {
         const size_t hlds = 1024 + (size_t)(S + hot_nh[hot_range < 0 ? 3 : hot_range]) * 64 * 16 + 4 * (size_t)(HOT_RAWB + 2 * HOT_PLB);
         launch_hot(hot_range, inc != 0, epi, hgrid, block, hlds, ctx->stream, ha);
         a.border = 1; a.bt_hi = t_hi; a.tpw = 1;
-        grid = dim3((unsigned)(1 + tiles - t_hi), C);
+        grid = dim3(1, C);
       }
 #define SDRHIP_MFD(S_) do { if (inc != 0) hipLaunchKernelGGL((iqbb_i16_mfma_dma_kernel<S_, true>), grid, block, ldsd, ctx->stream, a); \
                              else hipLaunchKernelGGL((iqbb_i16_mfma_dma_kernel<S_, false>), grid, block, ldsd, ctx->stream, a); } while (0)
