@@ -157,16 +157,18 @@ def cpu_baseline(workload, target_s):
             "host_cores_available": cores_avail}
 
 
-def measured_traffic(kernel):
-    """Per-launch HBM bytes of `kernel` from the committed rocprofv3 PMC passes (profiles/*_pmc.json, newest
-    round first; collected in separate --pmc runs of this same command and corrected as MI355X_MICROARCH.md
-    prescribes: FETCH_SIZE x2 on gfx950, KiB units). None if no profile of that kernel is committed."""
+def measured_traffic(kernels):
+    """Per-step HBM bytes of the step's kernels (one step = one launch of each) from the committed rocprofv3 PMC
+    passes (profiles/*_pmc.json, newest round first; collected in separate --pmc runs of this same command and
+    corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE x2 on gfx950, KiB units). None if no profile holding
+    every one of these kernels is committed."""
     import glob
     for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
         try:
-            d = json.load(open(fn)).get(kernel, {}).get("derived")
-            if d:
-                return {"bytes": d["hbm_traffic_bytes_per_launch"], "source": os.path.basename(fn)}
+            js = json.load(open(fn))
+            ds = [js.get(k, {}).get("derived") for k in kernels]
+            if all(ds):
+                return {"bytes": sum(d["hbm_traffic_bytes_per_launch"] for d in ds), "source": os.path.basename(fn)}
         except Exception:
             pass
     return None
@@ -226,7 +228,8 @@ def main():
                 in_bytes, alg_bytes = 2.0, 2.0 + 2.0 / D
             run = lambda b: node.process_dev(ins[b].data_ptr(), N, N, outs.data_ptr(), n_out)
             dtype = "i16"
-            kernel = {1: "iqbb_i16_mfma_kernel", 2: "iqbb_i16_mfma16_kernel", 3: "iqbb_i16_mfmag_kernel"}.get(node.path, "iqbb_i16_kernel")
+            kernels = node.kernel_names   # dominant first; path 1 on cs16 input = hot kernel + the small border launch
+            kernel = kernels[0]
             desc = "IQBaseBand<int16>(%d-tap Q14 FIR, LUT shift 100 kHz, /%d) -> %s" % (order, D, "USBDemod" if wl == "iqbb_usb" else "FMDemod")
             if wl == "iqbb_fm_cu8":
                 desc = "complex<uint8> -> AutoCast + " + desc
@@ -240,6 +243,7 @@ def main():
             ins = [synth_cs16(torch, C, N, dev, 1234 + b, chan0=rank * C) for b in range(a.batches)]
             run = lambda b: node.process_dev(ins[b].data_ptr(), N, N, outs.data_ptr(), N)
             dtype, kernel = "f64", "fir_cs16_exact_kernel"
+            kernels = [kernel]
             desc = "FIRLowPass<complex<int16>>(%d taps, exact per-tap truncation) -> FMDemod" % order
         elif wl == "fbb_f32":
             alpha = sa.design_fir_lowpass(127, 100e3, FS)
@@ -250,6 +254,7 @@ def main():
             ins = [torch.randn((C, N, 2), dtype=torch.float32, device=dev) * 0.3 for b in range(a.batches)]
             run = lambda b: node.process_dev(ins[b].data_ptr(), N, N, outs.data_ptr(), n_out)
             dtype, kernel = "f32", "fir_cf32_rt_kernel"
+            kernels = [kernel]
             desc = "float baseband: shift 100 kHz -> FIRLowPass<cf32>(127) -> /8"
         elif wl == "fftconv":
             alpha = sa.design_fir_lowpass(4097, 100e3, FS)
@@ -261,6 +266,7 @@ def main():
             ins = [torch.randn((C, N, 2), dtype=torch.float32, device=dev) * 0.3 for b in range(a.batches)]
             run = lambda b: node.process_dev(ins[b].data_ptr(), N, N, outs.data_ptr(), N)
             dtype, kernel = "f32", "fftconv_fused_kernel"
+            kernels = [kernel]
             desc = "FFT convolution, overlap-save L=16384, 4097 taps (hop 12288)"
         elif wl in ("fm_demod", "subsample8"):
             ins = [synth_cs16(torch, C, N, dev, 1234 + b, chan0=rank * C) for b in range(a.batches)]
@@ -277,6 +283,7 @@ def main():
                 run = lambda b: node.process_dev(ins[b].data_ptr(), N, N, outs.data_ptr(), N // 8 + 1)
                 kernel, desc = "subsample_cs16_kernel", "SubSample<complex<int16>>(8) alone"
             dtype = "i16"
+            kernels = [kernel]
         else:
             raise SystemExit("unknown workload " + wl)
 
@@ -343,7 +350,7 @@ def main():
                        "global_channels": C * world, "input": {2.0: "complex<uint8>", 4.0: "complex<int16>"}.get(in_bytes, "complex<float>"),
                        "parallelism": "channel-sharded x%d, %s" % (world, "output gathered on rank 0 per step (RCCL)" if a.gather else "no data-path collective")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": kernel,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": kernel, "kernels_per_step": kernels,
                          "algorithmic_bytes_per_launch": C * N * alg_bytes,
                          "algorithmic_bytes_per_sample": alg_bytes, "avg_launch_ms": round(per_launch_s * 1e3, 4),
                          "hbm_read_frac": round(C * N * in_bytes / per_launch_s / 1e9 / HBM_PEAK_GBS, 5),
@@ -370,7 +377,7 @@ def main():
                     res["roofline"]["frac_of_stream_read"] = round(achieved / gbs.value, 5)
             except Exception as e:   # measurement aid only
                 res["roofline"]["stream_read_error"] = str(e)[:80]
-        tr = measured_traffic(kernel) if (C, N) == (1024, 65536) else None
+        tr = measured_traffic(kernels) if (C, N) == (1024, 65536) else None
         if tr:
             res["roofline"]["traffic"] = tr["bytes"]
             res["roofline"]["traffic_source"] = "profiles/" + tr["source"]

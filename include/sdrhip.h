@@ -135,11 +135,17 @@ int sdrhip_iqbb_i16_create(sdrhip_ctx *ctx, const int32_t *taps, int order, cons
                            uint32_t lut_inc, int negative, int decim, int channels, size_t max_in,
                            int epilogue, sdrhip_iqbb_i16 **out);
 /* which kernel formulation the plan selected: 0 = VALU v_dot2c_i32_i16 (any decim/order), 1 = int8-MFMA
- * block-Toeplitz GEMM on 32x32x32 tiles (decim 8, order <= 257), 2 = the same on 16x16x64 tiles with an
+ * block-Toeplitz GEMM on 32x32x32 tiles (decim 8, order <= 257; LDS-DMA fed, see kernel_names), 2 = the same on 16x16x64 tiles with an
  * in-wave MFMA/VALU pipeline (decim 8, order <= 153), 3 = the 32x32x32 matrix part for any other decimation with
  * the box windows summed through LDS (order <= 257); all bit-exact. Environment variable
  * SDRHIP_IQBB_PATH=valu|mfma|mfma16|mfmag states a preference at create time (tests, tuning). */
 int sdrhip_iqbb_i16_path(sdrhip_iqbb_i16 *h, int *path);
+/* Names of the kernels a call of this plan launches, dominant one first, comma separated (measurement aid: what to
+ * look for in a rocprofv3 kernel trace). Path 1 with complex<int16> input is two launches: "iqbb_i16_hot_kernel"
+ * (persistent grid; every wave slice that touches no border of the call) and "iqbb_i16_mfma_dma_kernel" (one
+ * workgroup per channel: the call's first and last slices, state, history roll). SDRHIP_IQBB_HOT=0 /
+ * SDRHIP_IQBB_DMA=0 at create time fall back to the single general launch (tests, tuning). */
+int sdrhip_iqbb_i16_kernel_names(sdrhip_iqbb_i16 *h, char *buf, size_t len);
 /* outputs the next call of n_in samples will produce (does not advance the state) */
 int sdrhip_iqbb_i16_out_count(sdrhip_iqbb_i16 *h, size_t n_in, size_t *n_out);
 /* in: channels x n_in cs16 (row stride in_stride samples); out: channels rows of out_stride

@@ -82,6 +82,7 @@ def lib():
             "sdrhip_bb_i16_create": (C.c_int, [vp, i32p, C.c_int, i32p, C.c_uint32, C.c_int, C.c_int, C.c_int,
                                                sz, C.c_int, pvp]),
             "sdrhip_iqbb_i16_path": (C.c_int, [vp, C.POINTER(C.c_int)]),
+            "sdrhip_iqbb_i16_kernel_names": (C.c_int, [vp, C.c_char_p, sz]),
             "sdrhip_iqbb_i16_out_count": (C.c_int, [vp, sz, psz]),
             "sdrhip_iqbb_i16_process": (C.c_int, [vp, vp, sz, sz, vp, sz, psz]),
             "sdrhip_iqbb_i16_process_dev": (C.c_int, [vp, vp, sz, sz, vp, sz, psz]),

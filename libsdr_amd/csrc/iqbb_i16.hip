@@ -1914,6 +1914,19 @@ int sdrhip_iqbb_i16_path(sdrhip_iqbb_i16 *h, int *path) {
   });
 }
 
+int sdrhip_iqbb_i16_kernel_names(sdrhip_iqbb_i16 *h, char *buf, size_t len) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h && buf && len, SDRHIP_E_INVALID, "NULL argument");
+    const char *nm = "iqbb_i16_kernel";
+    if (h->path == 3) nm = "iqbb_i16_mfmag_kernel";
+    else if (h->path == 2) nm = "iqbb_i16_mfma16_kernel";
+    else if (h->path == 1 && (h->in_cu8 || !h->use_dma)) nm = "iqbb_i16_mfma_kernel";
+    else if (h->path == 1 && h->S == 9 && h->hot_range >= 0 && h->use_hot) nm = "iqbb_i16_hot_kernel,iqbb_i16_mfma_dma_kernel";
+    else if (h->path == 1) nm = "iqbb_i16_mfma_dma_kernel";
+    snprintf(buf, len, "%s", nm);
+  });
+}
+
 int sdrhip_iqbb_i16_out_count(sdrhip_iqbb_i16 *h, size_t n_in, size_t *n_out) {
   return guarded([&] {
     SDRHIP_REQUIRE(h && n_out, SDRHIP_E_INVALID, "NULL argument");

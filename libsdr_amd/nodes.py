@@ -205,6 +205,13 @@ class IQBaseBandI16(_Node):
         check(abi.lib().sdrhip_iqbb_i16_path(self._h, C.byref(v)))
         return v.value
 
+    @property
+    def kernel_names(self):
+        """Kernels a call launches, dominant first (what to look for in a rocprofv3 kernel trace)."""
+        b = C.create_string_buffer(256)
+        check(abi.lib().sdrhip_iqbb_i16_kernel_names(self._h, b, 256))
+        return b.value.decode().split(",")
+
     def out_count(self, n_in):
         n = C.c_size_t(0)
         check(abi.lib().sdrhip_iqbb_i16_out_count(self._h, n_in, C.byref(n)))
