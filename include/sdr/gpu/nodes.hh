@@ -112,11 +112,17 @@ public:
   inline size_t order() const { return _order; }
   void setOrder(size_t o) { _order = std::max(size_t(1), o); if (_Fs) _reconfigure(); }
   inline double centerFrequency() const { return _Fc; }
-  void setCenterFrequency(double Fc) { _Fc = int32_t(Fc); _shift = _Fc; if (_Fs) _reconfigure(); }
+  /** As the reference (src/baseband.hh:84-86 -> src/freqshift.hh:52-54,78-87): new LUT increment and sign, the LUT
+   * phase restarts; filter history, decimator state and the kernel go on unchanged. */
+  void setCenterFrequency(double Fc) {
+    _Fc = int32_t(Fc); _shift = _Fc;
+    if (_plan) configCheck(sdrhip_iqbb_i16_set_shift(_plan, design::freqShiftIncrement(_shift, double(_Fs)), 0 > _shift), "IQBaseBand");
+  }
   inline double filterFrequency() const { return _Ff; }
-  void setFilterFrequency(double Ff) { _Ff = int32_t(Ff); if (_Fs) _reconfigure(); }
+  /** As the reference (:92-104): only the filter kernel is recomputed, all streaming state goes on. */
+  void setFilterFrequency(double Ff) { _Ff = int32_t(Ff); _retap(); }
   inline double filterWidth() const { return _width; }
-  void setFilterWidth(double width) { _width = int32_t(width); if (_Fs) _reconfigure(); }
+  void setFilterWidth(double width) { _width = int32_t(width); _retap(); }
   size_t subSample() const { return _sub_sample; }
   void setSubsample(size_t sub_sample) { _sub_sample = std::max(size_t(1), sub_sample); if (_Fs) _reconfigure(); }
   void setOutputSampleRate(double Fs) { _oFs = Fs; if (_Fs) _reconfigure(); }
@@ -141,6 +147,23 @@ public:
   }
 
 protected:
+  /** _update_filter_kernel() on a configured node: swap the kernel, keep every bit of streaming state. */
+  void _retap() {
+    if (!_plan) return;
+    std::vector<int32_t> taps(2 * _order);
+    design::iqbbTaps(_Ff, _width, _Fs, _order, taps.data());
+    const int rc = sdrhip_iqbb_i16_set_taps(_plan, taps.data());
+    if (rc == SDRHIP_E_UNSUPPORTED) {   // the new kernel does not fit the plan's formulation: a fresh plan (state is lost)
+      LogMessage msg(LOG_WARNING);
+      msg << "gpu::IQBaseBand: new filter kernel needs a new device plan; filter history is reset";
+      Logger::get().log(msg);
+      _planOrder = 0; _reconfigure();
+    } else configCheck(rc, "IQBaseBand");
+  }
+
+  /** IQBaseBand::_reconfigure (src/baseband.hh:156-194): kernel and LUT increment recomputed, counters and phases reset,
+   * the FIR ring's CONTENTS kept where they lie (sdrhip_iqbb_i16_reset(keep_history = 1) reproduces the rotated ring);
+   * a new device plan (zeroed history) only when the geometry changes (order, decimation, buffer size, demodulator). */
   void _reconfigure() {
     const size_t D = design::iqbbDecimation(_Fs, _sub_sample, _oFs);
     _sub_sample = D;
@@ -148,10 +171,26 @@ protected:
     design::iqbbTaps(_Ff, _width, _Fs, _order, taps.data());
     design::freqShiftLutI16(lut.data());
     const uint32_t inc = design::freqShiftIncrement(_shift, double(_Fs));
-    if (_plan) { sdrhip_iqbb_i16_destroy(_plan); _plan = 0; }
-    configCheck(sdrhip_iqbb_i16_create(Device::get(_device), taps.data(), int(_order), lut.data(), inc, 0 > _shift,
-                                               int(D), 1, _sourceBs, _epilogue, &_plan), "IQBaseBand");
-    if (sizeof(SIn) == 1) configCheck(sdrhip_iqbb_i16_set_input_format(_plan, SDRHIP_IN_CU8), "IQBaseBand");
+    bool reuse = _plan && _planOrder == _order && _planD == D && _planBs == _sourceBs && _planEpi == _epilogue;
+    if (reuse) {
+      const int rc = sdrhip_iqbb_i16_set_taps(_plan, taps.data());
+      if (rc == SDRHIP_E_UNSUPPORTED) reuse = false;
+      else {
+        configCheck(rc, "IQBaseBand");
+        configCheck(sdrhip_iqbb_i16_set_shift(_plan, inc, 0 > _shift), "IQBaseBand");
+        // (a fused demodulator is reconfigured — FM's last angle zeroed — only if the Config we propagate changes)
+        const double oRateNow = double(size_t(_Fs) / D);
+        const bool same_cfg = this->_config.hasSampleRate() && this->_config.sampleRate() == oRateNow;
+        configCheck(sdrhip_iqbb_i16_reset(_plan, same_cfg ? 3 : 1), "IQBaseBand");
+      }
+    }
+    if (!reuse) {
+      if (_plan) { sdrhip_iqbb_i16_destroy(_plan); _plan = 0; }
+      configCheck(sdrhip_iqbb_i16_create(Device::get(_device), taps.data(), int(_order), lut.data(), inc, 0 > _shift,
+                                                 int(D), 1, _sourceBs, _epilogue, &_plan), "IQBaseBand");
+      if (sizeof(SIn) == 1) configCheck(sdrhip_iqbb_i16_set_input_format(_plan, SDRHIP_IN_CU8), "IQBaseBand");
+      _planOrder = _order; _planD = D; _planBs = _sourceBs; _planEpi = _epilogue;
+    }
     size_t buffer_size = _sourceBs / D;
     if (_sourceBs % D) buffer_size += 1;
     _buffer.unref();
@@ -188,6 +227,8 @@ protected:
   size_t _sourceBs;
   int _epilogue, _device;
   sdrhip_iqbb_i16 *_plan;
+  size_t _planOrder = 0, _planD = 0, _planBs = 0;   // geometry the device plan was made for
+  int _planEpi = 0;
   Buffer<cs16> _buffer;
 };
 }  // namespace detail

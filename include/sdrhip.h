@@ -169,8 +169,19 @@ int sdrhip_iqbb_i16_set_input_format(sdrhip_iqbb_i16 *h, int format);
 int sdrhip_bb_i16_create(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32_t *lut,
                          uint32_t lut_inc, int negative, int decim, int channels, size_t max_in,
                          int epilogue, sdrhip_iqbb_i16 **out);
+/* Mid-stream retuning with the reference's semantics (src/baseband.hh:82-112), for plans of either create call:
+ *   set_taps   setFilterFrequency / setFilterWidth -> _update_filter_kernel(): only the kernel changes (same order);
+ *              FIR history, decimator phase and partial sum, LUT phase and FM angle go on as they are.
+ *              SDRHIP_E_UNSUPPORTED when the new taps cannot run on the plan's kernel formulation (create a new plan).
+ *   set_shift  setCenterFrequency -> setFrequencyShift -> _update_lut_incr() (src/freqshift.hh:52-54,78-87): new
+ *              increment and sign, and the LUT phase counter restarts at 0 with the next sample; nothing else changes.
+ * setSubsample / setOutputSampleRate / config() run _reconfigure: set_taps + set_shift + reset(keep_history = 1). */
+int sdrhip_iqbb_i16_set_taps(sdrhip_iqbb_i16 *h, const int32_t *taps);
+int sdrhip_iqbb_i16_set_shift(sdrhip_iqbb_i16 *h, uint32_t lut_inc, int negative);
 /* keep_history = 1: what IQBaseBand::_reconfigure does (counters and phases reset, FIR ring kept,
- * src/baseband.hh:175-177); 0: a freshly constructed node (ring zeroed, :41-43). */
+ * src/baseband.hh:175-177); 0: a freshly constructed node (ring zeroed, :41-43). With a fused FMDemod: | 2 also
+ * keeps the demodulator's last angle — the FMDemod node behind a reconfigured baseband is only reset when the Config
+ * it receives changes (src/node.cc:98-105, src/demod.hh:210); 1 alone resets it (a changed output Config). */
 int sdrhip_iqbb_i16_reset(sdrhip_iqbb_i16 *h, int keep_history);
 int sdrhip_iqbb_i16_destroy(sdrhip_iqbb_i16 *h);
 

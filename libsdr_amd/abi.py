@@ -83,6 +83,8 @@ def lib():
                                                sz, C.c_int, pvp]),
             "sdrhip_iqbb_i16_path": (C.c_int, [vp, C.POINTER(C.c_int)]),
             "sdrhip_iqbb_i16_kernel_names": (C.c_int, [vp, C.c_char_p, sz]),
+            "sdrhip_iqbb_i16_set_taps": (C.c_int, [vp, i32p]),
+            "sdrhip_iqbb_i16_set_shift": (C.c_int, [vp, C.c_uint32, C.c_int]),
             "sdrhip_iqbb_i16_out_count": (C.c_int, [vp, sz, psz]),
             "sdrhip_iqbb_i16_process": (C.c_int, [vp, vp, sz, sz, vp, sz, psz]),
             "sdrhip_iqbb_i16_process_dev": (C.c_int, [vp, vp, sz, sz, vp, sz, psz]),

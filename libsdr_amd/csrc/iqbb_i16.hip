@@ -1570,6 +1570,7 @@ struct sdrhip_iqbb_i16 {
   uint32_t inc = 0;
   size_t max_in = 0;
   uint64_t n0 = 0;
+  uint64_t phase0 = 0;   // absolute sample index at which the LUT phase counter was last restarted (set_shift)
   int par = 0, par_fm = 0;
   int CG = 0, OG = 0, ovl = 0;
   bool fast8 = false;
@@ -1589,6 +1590,64 @@ struct sdrhip_iqbb_i16 {
   DevBuf<uint32_t> stage_in;
   DevBuf<uint32_t> stage_out;
   size_t max_out = 0;
+
+
+  // (re)loads the tap-dependent device data: packed taps (VALU kernel, the slow first-sample evaluation), the
+  // Toeplitz byte-plane fragments, their constant term and high-plane step mask (MFMA paths). create and retap.
+  void load_taps(const int32_t *taps) {
+    ah_mask = 0; hot_range = -1;
+    // taps: zero-padded at the FRONT (older samples) so that the newest sample still meets K[order-1]
+    std::vector<uint2> tp(OP, make_uint2(0, 0));
+    const int pad = OP - order;
+    for (int i = 0; i < order; i++) {
+      const int kr = taps[2 * i], ki = taps[2 * i + 1];
+      if (real) { tp[pad + i].x = (uint32_t)kr; tp[pad + i].y = (uint32_t)ki; continue; }
+      tp[pad + i].x = ((uint32_t)(uint16_t)(int16_t)kr) | ((uint32_t)(uint16_t)(int16_t)(-ki) << 16);
+      tp[pad + i].y = ((uint32_t)(uint16_t)(int16_t)ki) | ((uint32_t)(uint16_t)(int16_t)kr << 16);
+    }
+    if (path >= 1) {   // (a path 3 plan that fell back to the VALU kernel above has path 0 by now)
+      // interleaved tap vectors a_comp[2i+c] and their Toeplitz fragments, TapT[m][k] = a_comp[k-2t], m = 2t+comp:
+      // 32x32x32: lane (m = l&31, hh = l>>5), byte j of K-step s <-> k = 32s+16hh+j
+      // 16x16x64: lane (m = l&15, g  = l>>4), byte j of K-step s <-> k = 64s+16g+j
+      const int OPm = OP;
+      std::vector<int> are(2 * OPm, 0), aim(2 * OPm, 0);
+      for (int i = 0; i < order; i++) {
+        const int kr = taps[2 * i], ki = taps[2 * i + 1];
+        are[2 * (pad + i)] = kr; are[2 * (pad + i) + 1] = -ki;
+        aim[2 * (pad + i)] = ki; aim[2 * (pad + i) + 1] = kr;
+      }
+      unsigned sre = 0, sim = 0;
+      for (int k = 0; k < 2 * OPm; k++) { sre += (unsigned)are[k]; sim += (unsigned)aim[k]; }
+      cre = (int)(128u * sre); cim = (int)(128u * sim);
+      std::vector<int8_t> frag((size_t)S * 2 * 64 * 16, 0);
+      for (int st = 0; st < S; st++)
+        for (int l = 0; l < 64; l++)
+          for (int j = 0; j < 16; j++) {
+            const int m = path == 2 ? (l & 15) : (l & 31), hh = path == 2 ? (l >> 4) : (l >> 5);
+            int t = m >> 1, comp = m & 1;
+            if (path == 1) {   // row permutation: the 32x32 C/D map gives lane half hC = (m>>2)&1 the rows m with register
+                                  // r = (m&3) + 4*(m>>3); row m carries sample t = 8*hC + (r>>1), component r&1, so that
+                                  // a lane ends up with one whole decimation group (8 consecutive samples)
+              const int hC = (m >> 2) & 1, r = (m & 3) + 4 * (m >> 3);
+              t = 8 * hC + (r >> 1); comp = r & 1;
+            }
+            const int idx = (path == 2 ? 64 : 32) * st + 16 * hh + j - 2 * t;
+            const int v = (idx >= 0 && idx < 2 * OPm) ? (comp ? aim[idx] : are[idx]) : 0;
+            const int al = ((v + 128) & 255) - 128, ah = (v - al) >> 8;
+            frag[(((size_t)(2 * st) * 64 + l) * 16) + j] = (int8_t)ah;
+            if (ah != 0) ah_mask |= 1u << st;
+            frag[(((size_t)(2 * st + 1) * 64 + l) * 16) + j] = (int8_t)al;
+          }
+      if (path == 1 && S == 9) {   // smallest centred range [S0, S0+NH) of the hot kernel that covers the mask
+        const unsigned ranges[4] = {0x7u << 3, 0x1fu << 2, 0x7fu << 1, 0x1ffu};
+        for (int r = 0; r < 4 && hot_range < 0; r++) if ((ah_mask & ~ranges[r]) == 0) hot_range = r;
+      }
+      if (!tapfrag.p) tapfrag.alloc((size_t)S * 2 * 64);
+      tapfrag.upload(reinterpret_cast<const v4i *>(frag.data()), (size_t)S * 2 * 64, ctx->stream);
+    }
+    if (!this->taps.p) this->taps.alloc(OP);
+    this->taps.upload(tp.data(), OP, ctx->stream);
+  }
 
   struct Geometry { uint64_t g_first; int n_groups, n_out, base0_rel, extra0; };
   Geometry geometry(size_t N) const {
@@ -1619,7 +1678,7 @@ struct sdrhip_iqbb_i16 {
     const bool fm_flip = (epi == SDRHIP_EPI_FM && g.n_out >= 2);
     a.fm_old = fm[par_fm].p; a.fm_new = fm[par_fm ^ 1].p;
     a.taps = taps.p; a.lut = lut.p; a.inc = inc; a.negative = negative;
-    a.OP = OP; a.D = D; a.N = (int)N; a.n0_lo = (uint32_t)n0;
+    a.OP = OP; a.D = D; a.N = (int)N; a.n0_lo = (uint32_t)(n0 - phase0);   // (the kernels use n0_lo for the LUT phase only)
     a.base0_rel = g.base0_rel; a.n_groups = g.n_groups; a.n_out = g.n_out; a.extra0 = g.extra0;
     a.CG = CG; a.OG = OG; a.ovl = ovl; a.CGr = (CG + 3) & ~3;
     a.out = out_dev; a.out_stride = (long)out_stride; a.epilogue = epi;
@@ -1687,7 +1746,7 @@ struct sdrhip_iqbb_i16 {
       if (t_hi > 0) {
         HotArgs ha;
         ha.in = in_dev; ha.in_stride = (long)in_stride; ha.out = out_dev; ha.out_stride = (long)out_stride;
-        ha.tapfrag = tapfrag.p; ha.lut = lut.p; ha.inc = inc; ha.n0_lo = (uint32_t)n0; ha.negative = negative;
+        ha.tapfrag = tapfrag.p; ha.lut = lut.p; ha.inc = inc; ha.n0_lo = (uint32_t)(n0 - phase0); ha.negative = negative;
         ha.base0_rel = g.base0_rel; ha.OG = OG; ha.ovl = ovl; ha.t_lo = 0; ha.t_hi = tiles; ha.cre = cre; ha.cim = cim;
         ha.N = (int)N; ha.n_out = g.n_out;
         const int nhot = tiles;
@@ -1828,56 +1887,7 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
         h->lds_bytes = (XS + 256 + 2 * ((CG + 3) & ~3)) * 4 + (h->fast8 ? 0 : (size_t)TI * 8);
       }
       SDRHIP_REQUIRE(h->lds_bytes <= 64 * 1024, SDRHIP_E_UNSUPPORTED, "LDS budget exceeded (%zu B)", h->lds_bytes);
-      // taps: zero-padded at the FRONT (older samples) so that the newest sample still meets K[order-1]
-      std::vector<uint2> tp(h->OP, make_uint2(0, 0));
-      const int pad = h->OP - order;
-      for (int i = 0; i < order; i++) {
-        const int kr = taps[2 * i], ki = taps[2 * i + 1];
-        if (real) { tp[pad + i].x = (uint32_t)kr; tp[pad + i].y = (uint32_t)ki; continue; }
-        tp[pad + i].x = ((uint32_t)(uint16_t)(int16_t)kr) | ((uint32_t)(uint16_t)(int16_t)(-ki) << 16);
-        tp[pad + i].y = ((uint32_t)(uint16_t)(int16_t)ki) | ((uint32_t)(uint16_t)(int16_t)kr << 16);
-      }
-      if (h->path >= 1) {   // (a path 3 plan that fell back to the VALU kernel above has path 0 by now)
-        // interleaved tap vectors a_comp[2i+c] and their Toeplitz fragments, TapT[m][k] = a_comp[k-2t], m = 2t+comp:
-        // 32x32x32: lane (m = l&31, hh = l>>5), byte j of K-step s <-> k = 32s+16hh+j
-        // 16x16x64: lane (m = l&15, g  = l>>4), byte j of K-step s <-> k = 64s+16g+j
-        const int OPm = h->OP;
-        std::vector<int> are(2 * OPm, 0), aim(2 * OPm, 0);
-        for (int i = 0; i < order; i++) {
-          const int kr = taps[2 * i], ki = taps[2 * i + 1];
-          are[2 * (pad + i)] = kr; are[2 * (pad + i) + 1] = -ki;
-          aim[2 * (pad + i)] = ki; aim[2 * (pad + i) + 1] = kr;
-        }
-        unsigned sre = 0, sim = 0;
-        for (int k = 0; k < 2 * OPm; k++) { sre += (unsigned)are[k]; sim += (unsigned)aim[k]; }
-        h->cre = (int)(128u * sre); h->cim = (int)(128u * sim);
-        std::vector<int8_t> frag((size_t)h->S * 2 * 64 * 16, 0);
-        for (int st = 0; st < h->S; st++)
-          for (int l = 0; l < 64; l++)
-            for (int j = 0; j < 16; j++) {
-              const int m = h->path == 2 ? (l & 15) : (l & 31), hh = h->path == 2 ? (l >> 4) : (l >> 5);
-              int t = m >> 1, comp = m & 1;
-              if (h->path == 1) {   // row permutation: the 32x32 C/D map gives lane half hC = (m>>2)&1 the rows m with register
-                                    // r = (m&3) + 4*(m>>3); row m carries sample t = 8*hC + (r>>1), component r&1, so that
-                                    // a lane ends up with one whole decimation group (8 consecutive samples)
-                const int hC = (m >> 2) & 1, r = (m & 3) + 4 * (m >> 3);
-                t = 8 * hC + (r >> 1); comp = r & 1;
-              }
-              const int idx = (h->path == 2 ? 64 : 32) * st + 16 * hh + j - 2 * t;
-              const int v = (idx >= 0 && idx < 2 * OPm) ? (comp ? aim[idx] : are[idx]) : 0;
-              const int al = ((v + 128) & 255) - 128, ah = (v - al) >> 8;
-              frag[(((size_t)(2 * st) * 64 + l) * 16) + j] = (int8_t)ah;
-              if (ah != 0) h->ah_mask |= 1u << st;
-              frag[(((size_t)(2 * st + 1) * 64 + l) * 16) + j] = (int8_t)al;
-            }
-        if (h->path == 1 && h->S == 9) {   // smallest centred range [S0, S0+NH) of the hot kernel that covers the mask
-          const unsigned ranges[4] = {0x7u << 3, 0x1fu << 2, 0x7fu << 1, 0x1ffu};
-          for (int r = 0; r < 4 && h->hot_range < 0; r++) if ((h->ah_mask & ~ranges[r]) == 0) h->hot_range = r;
-        }
-        h->tapfrag.alloc((size_t)h->S * 2 * 64);
-        h->tapfrag.upload(reinterpret_cast<const v4i *>(frag.data()), (size_t)h->S * 2 * 64, ctx->stream);
-      }
-      h->taps.alloc(h->OP); h->taps.upload(tp.data(), h->OP, ctx->stream);
+      h->load_taps(taps);
       h->lut.alloc(128); h->lut.upload(reinterpret_cast<const int2 *>(lut), 128, ctx->stream);
       for (int p = 0; p < 2; p++) {
         h->hist[p].alloc((size_t)channels * h->HH); h->hist[p].zero(ctx->stream);
@@ -1992,7 +2002,12 @@ int sdrhip_iqbb_i16_reset(sdrhip_iqbb_i16 *h, int keep_history) {
     SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
     h->ctx->use();
     hipStream_t st = h->ctx->stream;
-    for (int p = 0; p < 2; p++) { h->acc[p].zero(st); h->fm[p].zero(st); }
+    // bit 0 of keep_history: the FIR ring survives (rotated, below); bit 1: so does the fused FMDemod's last angle
+    // — IQBaseBand::_reconfigure does not touch the FMDemod node behind it, whose config() (and with it the reset of
+    // _last_value, src/demod.hh:210) only runs when the Config the baseband propagates CHANGES (src/node.cc:98-105)
+    const bool keep_fm = (keep_history & 2) != 0;
+    keep_history &= 1;
+    for (int p = 0; p < 2; p++) { h->acc[p].zero(st); if (!keep_fm) h->fm[p].zero(st); }
     if (!keep_history) {
       for (int p = 0; p < 2; p++) h->hist[p].zero(st);
     } else if (h->n0 % (uint64_t)h->order != 0) {
@@ -2012,7 +2027,31 @@ int sdrhip_iqbb_i16_reset(sdrhip_iqbb_i16 *h, int keep_history) {
       SDRHIP_CHECK_HIP(hipMemcpyAsync(h->hist[h->par].p, neu.data(), neu.size() * 4, hipMemcpyHostToDevice, st));
       SDRHIP_CHECK_HIP(hipStreamSynchronize(st));
     }
-    h->n0 = 0;
+    h->n0 = 0; h->phase0 = 0;
+  });
+}
+
+int sdrhip_iqbb_i16_set_taps(sdrhip_iqbb_i16 *h, const int32_t *taps) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h && taps, SDRHIP_E_INVALID, "NULL argument");
+    auto high_byte = [](int v) { const int al = ((v + 128) & 255) - 128; return (v - al) >> 8; };
+    for (int i = 0; i < 2 * h->order; i++) {
+      if (h->real) SDRHIP_REQUIRE(taps[i] > -(1 << 23) && taps[i] < (1 << 23), SDRHIP_E_UNSUPPORTED, "tap %d = %d exceeds 24 bits", i / 2, taps[i]);
+      else SDRHIP_REQUIRE(taps[i] >= -32767 && taps[i] <= 32767, SDRHIP_E_UNSUPPORTED, "tap %d = %d does not fit the packed int16 path", i / 2, taps[i]);
+      if (h->path >= 1)
+        SDRHIP_REQUIRE(high_byte(taps[i]) <= 127 && high_byte(-taps[i]) <= 127, SDRHIP_E_UNSUPPORTED,
+                       "tap %d = %d does not fit the plan's int8 byte planes: create a new plan", i / 2, taps[i]);
+    }
+    h->ctx->use();
+    h->load_taps(taps);   // stream-ordered after the launches already enqueued
+  });
+}
+
+int sdrhip_iqbb_i16_set_shift(sdrhip_iqbb_i16 *h, uint32_t lut_inc, int negative) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
+    h->inc = lut_inc; h->negative = negative ? 1 : 0;
+    h->phase0 = h->n0;   // _lut_count = 0 (src/freqshift.hh:86): the phase is a closed form of (n - phase0)
   });
 }
 

@@ -237,8 +237,17 @@ class IQBaseBandI16(_Node):
                                                     out_stride, C.byref(got)))
         return got.value
 
-    def reset(self, keep_history=False):
-        check(abi.lib().sdrhip_iqbb_i16_reset(self._h, int(keep_history)))
+    def reset(self, keep_history=False, keep_fm=False):
+        check(abi.lib().sdrhip_iqbb_i16_reset(self._h, int(bool(keep_history)) | (2 if keep_fm else 0)))
+
+    def set_taps(self, taps):
+        """setFilterFrequency / setFilterWidth of the reference node: the kernel only."""
+        taps = np.ascontiguousarray(taps, np.int32).reshape(-1, 2)
+        check(abi.lib().sdrhip_iqbb_i16_set_taps(self._h, taps.ctypes.data_as(C.POINTER(C.c_int32))))
+
+    def set_shift(self, lut_inc, negative):
+        """setCenterFrequency of the reference node: increment, sign, LUT phase restarts."""
+        check(abi.lib().sdrhip_iqbb_i16_set_shift(self._h, lut_inc, int(bool(negative))))
 
     def set_input_format(self, fmt):
         """abi.IN_CS16 (default) or abi.IN_CU8 (complex<uint8> buffers, AutoCast<cs16> fused into the load)."""

@@ -45,6 +45,8 @@ def lib():
             "orc_iqbb_i16_create": (vp, [i32p, C.c_int, i32p, C.c_uint32, C.c_int, C.c_int]),
             "orc_iqbb_i16_process": (C.c_size_t, [vp, i16p, C.c_size_t, i16p]),
             "orc_iqbb_i16_reset": (None, [vp]),
+            "orc_iqbb_i16_set_taps": (None, [vp, C.POINTER(C.c_int32)]),
+            "orc_iqbb_i16_set_shift": (None, [vp, C.c_uint32, C.c_int]),
             "orc_iqbb_i16_destroy": (None, [vp]),
             "orc_bb_design": (None, [C.c_double, C.c_double, C.c_double, C.c_int, i32p]),
             "orc_bb_i16_create": (vp, [i32p, C.c_int, i32p, C.c_uint32, C.c_int, C.c_int]),
@@ -170,6 +172,13 @@ class IQBaseBandI16:
 
     def reset(self):
         lib().orc_iqbb_i16_reset(self._h)
+
+    def set_taps(self, taps):
+        taps = np.ascontiguousarray(taps, np.int32).reshape(self.order, 2)
+        lib().orc_iqbb_i16_set_taps(self._h, _p(taps, C.c_int32))
+
+    def set_shift(self, lut_inc, negative):
+        lib().orc_iqbb_i16_set_shift(self._h, lut_inc, int(negative))
 
     def __del__(self):
         if self._h:

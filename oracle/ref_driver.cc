@@ -528,6 +528,33 @@ static void golden_wav() {
       for (int k = 0; k < 4; k++) src.next(); }
     dump("g11_chain_usb_wav", "u8", file_bytes(tmp2)); }
   remove(tmp.c_str()); remove(tmp2.c_str());
+
+  // G12 — the reference node retuned MID-STREAM (src/baseband.hh:82-112): setCenterFrequency only restarts the LUT
+  // phase with the new increment (src/freqshift.hh:52-54,78-87), setFilterFrequency / setFilterWidth only swap the
+  // kernel, setSubsample runs _reconfigure (counters reset, ring contents kept where they lie, :156-177).
+  const double Fs = 2.4e6;
+  std::vector<cs16> x16 = siggen<int16_t>(Fs, 4096, 4, two_tone_i16());   // = g1_iq_cs16
+  for (int fm = 0; fm < 2; fm++) {
+    Feeder<cs16> src; src.configure(Fs, 4096);
+    BBProbe bb(100e3, 100e3, 50e3, 127, 8);
+    src.connect(&bb, true);
+    Capture<cs16> cap; Capture<int16_t> capf; FMDemod<int16_t> dem;
+    if (fm) { bb.connect(&dem, true); dem.connect(&capf, true); } else bb.connect(&cap, true);
+    std::vector<size_t> used;
+    size_t off = 0;
+    auto feed = [&](size_t n) { src.feed(&x16[off], n); used.push_back(n); off += n; };
+    feed(4096); feed(3000);
+    bb.setCenterFrequency(-150e3);
+    feed(2000);
+    bb.setFilterFrequency(-150e3); bb.setFilterWidth(30e3);
+    feed(3192);
+    bb.setSubsample(8);
+    feed(4096);
+    const std::string ev = "\"Fs\": 2400000, \"order\": 127, \"decim\": 8, \"events\": [[\"feed\", 4096], [\"feed\", 3000], "
+        "[\"center\", -150000], [\"feed\", 2000], [\"filter\", -150000, 30000], [\"feed\", 3192], [\"reconfigure\"], [\"feed\", 4096]]";
+    if (fm) dump("g12_retune_fm", "i16", capf.data, ev + ", " + lens_json("in_lens", used) + ", " + lens_json("out_lens", capf.lens));
+    else dump("g12_retune_out", "cs16", flat16(cap.data), ev + ", " + lens_json("in_lens", used) + ", " + lens_json("out_lens", cap.lens));
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

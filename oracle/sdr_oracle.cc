@@ -244,6 +244,17 @@ void *orc_iqbb_i16_create(const int32_t *taps, int order, const int32_t *lut, ui
   return s;
 }
 void orc_iqbb_i16_destroy(void *h) { delete (IQBB *)h; }
+// setFilterFrequency / setFilterWidth (src/baseband.hh:92-104): _update_filter_kernel() only — the kernel is swapped,
+// ring, ring offset, decimator state and LUT phase go on as they are
+void orc_iqbb_i16_set_taps(void *h, const int32_t *taps) {
+  IQBB *s = (IQBB *)h;
+  for (int i = 0; i < s->order; i++) { s->k[i].re = taps[2 * i]; s->k[i].im = taps[2 * i + 1]; }
+}
+// setCenterFrequency (src/baseband.hh:84-86) -> setFrequencyShift -> _update_lut_incr (src/freqshift.hh:52-54,78-87):
+// new increment and sign, the LUT phase counter restarts at 0; nothing else changes
+void orc_iqbb_i16_set_shift(void *h, uint32_t inc, int negative) {
+  IQBB *s = (IQBB *)h; s->inc = inc; s->negative = negative; s->lut_count = 0;
+}
 void orc_iqbb_i16_reset(void *h) {   // _reconfigure (:175-177) + setSampleRate -> _update_lut_incr
   IQBB *s = (IQBB *)h; s->off = 0; s->count = 0; s->lut_count = 0; s->last = C32{0, 0};
 }

@@ -49,6 +49,8 @@ void *orc_iqbb_i16_create(const int32_t *taps, int order, const int32_t *lut, ui
 /* returns number of complex outputs; in/out may alias (reference runs in place) */
 size_t orc_iqbb_i16_process(void *h, const int16_t *in, size_t n, int16_t *out);
 void orc_iqbb_i16_reset(void *h);   /* what _reconfigure does: counters, NOT the ring */
+void orc_iqbb_i16_set_taps(void *h, const int32_t *taps);               /* setFilterFrequency / setFilterWidth: kernel only */
+void orc_iqbb_i16_set_shift(void *h, uint32_t lut_inc, int negative);   /* setCenterFrequency: increment, sign, LUT phase = 0 */
 void orc_iqbb_i16_destroy(void *h);
 
 /* ---- FIRFilter<complex<int16>> / <complex<float>> (src/firfilter.hh:231-247) --------------- */

@@ -262,6 +262,34 @@ static void testRealBaseBand() {
   CHECK(thrown);
 }
 
+// the node retuned between buffers, against the golden vector cut from the reference node doing the same
+// (setCenterFrequency: LUT phase restarts only; setFilterFrequency / setFilterWidth: kernel only; setSubsample: _reconfigure)
+static void testRetuneMidStream() {
+  std::vector<int16_t> xin = slurp<int16_t>("g1_iq_cs16.bin"), ref = slurp<int16_t>("g12_retune_out.bin"), reff = slurp<int16_t>("g12_retune_fm.bin");
+  CHECK(xin.size() == 2 * 16384 && ref.size() == 2 * 2046 && reff.size() == 2046);
+  for (int fused = 0; fused < 3; fused++) {   // 0: complex out; 1: gpu::FMDemod behind the node; 2: FM fused into the launch
+    Feeder src; src.cfg(Config::Type_cs16, 4096);
+    gpu::IQBaseBand<int16_t> bb(100e3, 100e3, 50e3, 127, 8);
+    gpu::FMDemod<int16_t> fm; Recorder<cs16> out; Recorder<int16_t> outf;
+    if (fused == 2) bb.setDemod(SDRHIP_EPI_FM);
+    src.connect(&bb, true);
+    if (fused == 0) bb.connect(&out, true);
+    else if (fused == 1) { bb.connect(&fm, true); fm.connect(&outf, true); }
+    else bb.connect(&outf, true);
+    cs16 *x = reinterpret_cast<cs16 *>(xin.data());
+    size_t off = 0;
+    src.feed(x + off, 4096); off += 4096; src.feed(x + off, 3000); off += 3000;
+    bb.setCenterFrequency(-150e3);
+    src.feed(x + off, 2000); off += 2000;
+    bb.setFilterFrequency(-150e3); bb.setFilterWidth(30e3);
+    src.feed(x + off, 3192); off += 3192;
+    bb.setSubsample(8);
+    src.feed(x + off, 4096);
+    if (fused == 0) CHECK(out.data.size() * 2 == ref.size() && 0 == memcmp(out.data.data(), ref.data(), ref.size() * 2));
+    else CHECK(outf.data == reff);
+  }
+}
+
 int main(int argc, char **argv) {
   if (argc > 1) g_golden = argv[1];
   Logger::get().addHandler(new StreamLogHandler(std::cerr, LOG_WARNING));
@@ -274,6 +302,7 @@ int main(int argc, char **argv) {
     testFloatNodes();
     testSdrFmChainCu8();
     testRealBaseBand();
+    testRetuneMidStream();
   } catch (std::exception &e) {
     std::printf("FAIL: exception: %s\n", e.what());
     return 2;

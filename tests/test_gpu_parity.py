@@ -170,6 +170,36 @@ def test_iqbb_reset_semantics(ctx, orc, golden, k1path):
     assert np.array_equal(node.process(x[4096:8192])[0], bb.process(x[4096:8192]))
 
 
+class _GpuRetune:
+    def __init__(self, ctx, Ff, width, Fc, epi, order=127, D=8):
+        self.order = order
+        self.node = sa.IQBaseBandI16(ctx, sa.design_iqbb_taps(Ff, width, FS, order), sa.design_freqshift_lut_i16(),
+                                     sa.design_freqshift_inc(Fc, FS), Fc < 0, D, max_in=4096, epilogue=epi)
+
+    def process(self, x):
+        return self.node.process(x)[0]
+
+    def set_shift_hz(self, Fc):
+        self.node.set_shift(sa.design_freqshift_inc(Fc, FS), Fc < 0)
+
+    def set_filter(self, Ff, width):
+        self.node.set_taps(sa.design_iqbb_taps(Ff, width, FS, self.order))
+
+    def reconfigure(self):
+        self.node.reset(keep_history=True, keep_fm=True)   # (the FMDemod behind the baseband sees no Config change)
+
+
+@pytest.mark.parametrize("which,epi", [("g12_retune_out", sa.EPI_NONE), ("g12_retune_fm", sa.EPI_FM)])
+def test_iqbb_retune_midstream_golden(ctx, golden, which, epi, k1path):
+    """The reference node retuned between buffers (setCenterFrequency: LUT phase restarts only; setFilterFrequency /
+    setFilterWidth: kernel only; setSubsample: _reconfigure with the ring kept) — set_shift / set_taps / reset(keep)."""
+    from test_oracle_golden import replay_retune
+    m = golden.meta(which)
+    outs = replay_retune(m, golden.load("g1_iq_cs16"), lambda Ff, w, Fc: _GpuRetune(ctx, Ff, w, Fc, epi))
+    assert [len(o) for o in outs] == m["out_lens"]
+    assert np.array_equal(np.concatenate(outs), golden.load(which))
+
+
 # ---- "next" rows (SURVEY §8f): cu8 input with AutoCast fused into the K1 load, FMDeemph behind the demodulator ----
 
 @pytest.mark.parametrize("order", [21, 127])

@@ -316,3 +316,57 @@ def test_bb_real_i16(golden, orc, case, inp):
         outs.append(bb.process(x[off:off + n])); off += n
     assert [len(o) for o in outs] == m["out_lens"]
     assert np.array_equal(np.concatenate(outs), golden.load(case + "_out"))
+
+
+# ---- mid-stream retuning (src/baseband.hh:82-112): the reference node's setters between buffers -------------------
+
+def replay_retune(m, x, make_node, demod=None):
+    """Replays the manifest's event list ("feed n" / "center Fc" / "filter Ff width" / "reconfigure") on a node made by
+    make_node(taps, lut_inc, negative) with set_taps / set_shift / reset; returns the outputs per feed."""
+    Fs, order, Fc, Ff, width = float(m["Fs"]), m["order"], 100e3, 100e3, 50e3
+    node, outs, off = None, [], 0
+    for ev in m["events"]:
+        if ev[0] == "feed":
+            if node is None:
+                node = make_node(Ff, width, Fc)
+            y = node.process(x[off:off + ev[1]])
+            outs.append(demod(y) if demod else y)
+            off += ev[1]
+        elif ev[0] == "center":
+            Fc = float(int(ev[1]))
+            node.set_shift_hz(Fc)
+        elif ev[0] == "filter":
+            Ff, width = float(int(ev[1])), float(int(ev[2]))
+            node.set_filter(Ff, width)
+        elif ev[0] == "reconfigure":
+            node.set_filter(Ff, width); node.set_shift_hz(Fc); node.reconfigure()
+    return outs
+
+
+class _OrcRetune:
+    def __init__(self, orc, Ff, width, Fc, order=127, D=8):
+        self.orc, self.order = orc, order
+        self.bb = orc.IQBaseBandI16(orc.iqbb_design(Ff, width, FS, order), orc.freqshift_lut_i16(), orc.freqshift_inc(Fc, FS), Fc < 0, D)
+
+    def process(self, x):
+        return self.bb.process(x)
+
+    def set_shift_hz(self, Fc):
+        self.bb.set_shift(self.orc.freqshift_inc(Fc, FS), Fc < 0)
+
+    def set_filter(self, Ff, width):
+        self.bb.set_taps(self.orc.iqbb_design(Ff, width, FS, self.order))
+
+    def reconfigure(self):
+        self.bb.reset()
+
+
+def test_iqbb_retune_midstream(golden, orc):
+    m = golden.meta("g12_retune_out")
+    outs = replay_retune(m, golden.load("g1_iq_cs16"), lambda Ff, w, Fc: _OrcRetune(orc, Ff, w, Fc))
+    assert [len(o) for o in outs] == m["out_lens"]
+    assert np.array_equal(np.concatenate(outs), golden.load("g12_retune_out"))
+    fm = orc.FMDemodI16()
+    outs = replay_retune(golden.meta("g12_retune_fm"), golden.load("g1_iq_cs16"), lambda Ff, w, Fc: _OrcRetune(orc, Ff, w, Fc),
+                         demod=lambda y: fm.process(y))
+    assert np.array_equal(np.concatenate(outs), golden.load("g12_retune_fm"))
