@@ -628,10 +628,17 @@ protected:
 };
 
 // =================================================================================================
-// ChannelBank<int16_t>: C independent IQBaseBand<int16_t>(+demod) channels, one batched launch
+// ChannelBank<int16_t>: C independent IQBaseBand<int16_t>(+demod) channels, one batched launch per device
 // =================================================================================================
 template <class Scalar> class ChannelBank;
 
+/** Many independent channels behind one port per channel — sink(c) / source(c), the reference's own pattern for
+ * multi-input nodes (Combine::sink(i), src/combine.hh:66-150). The channels are split into contiguous blocks over
+ * the given devices (one rank each, sdrhip_comm_*): every device filters its block in one batched launch, no data
+ * path collective; the demodulated rows are gathered on rank 0's device (RCCL over xGMI when the devices differ)
+ * and leave in one device-to-host copy — BASELINE config 5's shape, driven from C++ in one process. The staging
+ * buffers are pinned (registered), so each device's copies are plain DMA on its own stream and run beside the
+ * other devices' kernels. */
 template <>
 class ChannelBank<int16_t> {
 public:
@@ -641,21 +648,32 @@ public:
     void emit(const RawBuffer &b, bool aw) { this->send(b, aw); }
   };
 
-  /** All channels share the band-select parameters (taps / LUT are broadcast read-only data). */
+  /** All channels share the band-select parameters (taps / LUT are read-only data, designed once on the host). */
   ChannelBank(size_t channels, double Fc, double Ff, double width, size_t order, size_t sub_sample, int epilogue = SDRHIP_EPI_NONE,
               int device = 0)
     : _C(channels), _Fc(Fc), _Ff(Ff), _width(width), _order(std::max(size_t(1), order)), _D(sub_sample), _epilogue(epilogue),
-      _device(device), _plan(0), _bs(0), _have(0), _ins(channels, In(this)), _outs(channels), _pending(channels, false) {
+      _devices(1, device), _comm(0), _gather(0), _bs(0), _have(0), _ins(channels, In(this)), _outs(channels), _pending(channels, false) {
+    for (size_t c = 0; c < _C; c++) _ins[c]._index = c;
+  }
+  /** The same bank over several devices: rank r (device devices[r]) owns the r-th contiguous block of channels. */
+  ChannelBank(size_t channels, double Fc, double Ff, double width, size_t order, size_t sub_sample, int epilogue,
+              const std::vector<int> &devices)
+    : _C(channels), _Fc(Fc), _Ff(Ff), _width(width), _order(std::max(size_t(1), order)), _D(sub_sample), _epilogue(epilogue),
+      _devices(devices.empty() ? std::vector<int>(1, 0) : devices), _comm(0), _gather(0), _bs(0), _have(0), _ins(channels, In(this)),
+      _outs(channels), _pending(channels, false) {
     for (size_t c = 0; c < _C; c++) _ins[c]._index = c;
   }
   virtual ~ChannelBank() {
-    if (_plan) sdrhip_iqbb_i16_destroy(_plan);
+    _release();
     _stageOut.unref();
     _stageIn.unref();
   }
   Sink<cs16> *sink(size_t c) { return &_ins[c]; }
   Source *source(size_t c) { return &_outs[c]; }
   size_t channels() const { return _C; }
+  size_t ranks() const { return _devices.size(); }
+  /** "rccl" or "same-device copies" once configured (sdrhip_comm_transport). */
+  const char *transport() const { const char *n = ""; if (_comm) sdrhip_comm_transport(_comm, &n); return n; }
 
 protected:
   class In : public Sink<cs16> {
@@ -666,6 +684,25 @@ protected:
     ChannelBank *_p;
     size_t _index;
   };
+  struct Rank {
+    sdrhip_ctx *ctx; sdrhip_iqbb_i16 *plan; size_t c0, c1; void *din, *dout;
+    Rank() : ctx(0), plan(0), c0(0), c1(0), din(0), dout(0) {}
+  };
+
+  void _release() {
+    if (_comm) sdrhip_comm_synchronize(_comm);
+    for (size_t r = 0; r < _ranks.size(); r++) {
+      if (_ranks[r].plan) sdrhip_iqbb_i16_destroy(_ranks[r].plan);
+      if (_ranks[r].din) sdrhip_free(_ranks[r].ctx, _ranks[r].din);
+      if (_ranks[r].dout) sdrhip_free(_ranks[r].ctx, _ranks[r].dout);
+    }
+    if (_gather) sdrhip_free(_ranks[0].ctx, _gather);
+    _gather = 0;
+    _ranks.clear();
+    if (!_stageIn.isEmpty()) sdrhip_host_unregister(_stageIn.data());
+    if (!_stageOut.isEmpty()) sdrhip_host_unregister(_stageOut.data());
+    if (_comm) { sdrhip_comm_destroy(_comm); _comm = 0; }
+  }
 
   void _config(const Config &cfg) {
     if (!cfg.hasType() || !cfg.hasSampleRate() || !cfg.hasBufferSize()) return;
@@ -674,21 +711,34 @@ protected:
       err << "Can not configure ChannelBank: Invalid type " << cfg.type() << ", expected " << Config::typeId<cs16>();
       throw err;
     }
-    if (_plan && cfg == _cfg) return;   // every channel's source pushes the same Config
+    if (_comm && cfg == _cfg) return;   // every channel's source pushes the same Config
     _cfg = cfg;
     _bs = cfg.bufferSize();
     const int32_t Fs = int32_t(cfg.sampleRate());
     std::vector<int32_t> taps(2 * _order), lut(2 * design::kLutSize);
     design::iqbbTaps(_Ff, _width, Fs, _order, taps.data());
     design::freqShiftLutI16(lut.data());
-    if (_plan) { sdrhip_iqbb_i16_destroy(_plan); _plan = 0; }
-    detail::configCheck(sdrhip_iqbb_i16_create(Device::get(_device), taps.data(), int(_order), lut.data(),
-                                               design::freqShiftIncrement(_Fc, double(Fs)), 0 > _Fc, int(_D), int(_C), _bs, _epilogue,
-                                               &_plan), "ChannelBank");
-    _outStride = _bs / _D + 2;
+    _release();
     _stageIn.unref(); _stageOut.unref();
+    _outStride = _bs / _D + 2;
     _stageIn = Buffer<cs16>(_C * _bs);
     _stageOut = Buffer<cs16>(_C * _outStride);
+    detail::configCheck(sdrhip_host_register(_stageIn.data(), _C * _bs * sizeof(cs16)), "ChannelBank");
+    detail::configCheck(sdrhip_host_register(_stageOut.data(), _C * _outStride * sizeof(cs16)), "ChannelBank");
+    const size_t R = std::min(_devices.size(), _C);
+    detail::configCheck(sdrhip_comm_create(_devices.data(), int(R), &_comm), "ChannelBank");
+    _ranks.assign(R, Rank());
+    for (size_t r = 0; r < R; r++) {   // contiguous blocks, sizes differ by at most one
+      Rank &k = _ranks[r];
+      k.c0 = r * (_C / R) + std::min(r, _C % R);
+      k.c1 = k.c0 + _C / R + (r < _C % R ? 1 : 0);
+      detail::configCheck(sdrhip_comm_ctx(_comm, int(r), &k.ctx), "ChannelBank");
+      detail::configCheck(sdrhip_iqbb_i16_create(k.ctx, taps.data(), int(_order), lut.data(), design::freqShiftIncrement(_Fc, double(Fs)),
+                                                 0 > _Fc, int(_D), int(k.c1 - k.c0), _bs, _epilogue, &k.plan), "ChannelBank");
+      detail::configCheck(sdrhip_malloc(k.ctx, (k.c1 - k.c0) * _bs * sizeof(cs16), &k.din), "ChannelBank");
+      detail::configCheck(sdrhip_malloc(k.ctx, (k.c1 - k.c0) * _outStride * sizeof(cs16), &k.dout), "ChannelBank");
+    }
+    if (R > 1) detail::configCheck(sdrhip_malloc(_ranks[0].ctx, _C * _outStride * sizeof(cs16), &_gather), "ChannelBank");
     std::fill(_pending.begin(), _pending.end(), false);
     _have = 0;
     const double oRate = double(size_t(Fs) / _D);
@@ -697,9 +747,9 @@ protected:
   }
 
   /** Collects one buffer per channel (all of the same length: buffer boundaries are part of the
-   * numerical contract), then launches once for the whole bank. */
+   * numerical contract), then launches once per device for the whole bank. */
   void _deliver(size_t c, const Buffer<cs16> &b) {
-    if (!_plan || b.size() > _bs) return;
+    if (!_comm || b.size() > _bs) return;
     if (_have == 0) _len = b.size();
     if (_pending[c] || b.size() != _len) {
       LogMessage msg(LOG_WARNING);
@@ -723,8 +773,23 @@ protected:
     }
     size_t n = 0;
     const size_t per = _epilogue == SDRHIP_EPI_NONE ? 1 : 2;   // int16 elements fit twice into a cs16 row
-    if (!detail::processOk(sdrhip_iqbb_i16_process(_plan, reinterpret_cast<const int16_t *>(_stageIn.data()), _len, _bs,
-                                                   _stageOut.data(), _outStride * per, &n), "gpu::ChannelBank")) return;
+    const size_t R = _ranks.size(), rowB = _outStride * sizeof(cs16);
+    bool ok = true;
+    std::vector<const void *> send(R); std::vector<size_t> bytes(R);
+    for (size_t r = 0; r < R && ok; r++) {   // every rank: H2D of its block and its batched launch, all asynchronous
+      Rank &k = _ranks[r];
+      ok = detail::processOk(sdrhip_memcpy_h2d_async(k.ctx, k.din, _stageIn.data() + k.c0 * _bs * sizeof(cs16),
+                                                     (k.c1 - k.c0) * _bs * sizeof(cs16)), "gpu::ChannelBank") &&
+           detail::processOk(sdrhip_iqbb_i16_process_dev(k.plan, reinterpret_cast<const int16_t *>(k.din), _len, _bs, k.dout,
+                                                         _outStride * per, &n), "gpu::ChannelBank");
+      send[r] = k.dout; bytes[r] = (k.c1 - k.c0) * rowB;
+    }
+    if (ok && R > 1)   // rows gathered on rank 0's device in channel order (RCCL over xGMI), then one copy to the host
+      ok = detail::processOk(sdrhip_comm_gather(_comm, send.data(), bytes.data(), _gather, 0), "gpu::ChannelBank") &&
+           detail::processOk(sdrhip_memcpy_d2h_async(_ranks[0].ctx, _stageOut.data(), _gather, _C * rowB), "gpu::ChannelBank");
+    else if (ok)
+      ok = detail::processOk(sdrhip_memcpy_d2h_async(_ranks[0].ctx, _stageOut.data(), _ranks[0].dout, _C * rowB), "gpu::ChannelBank");
+    if (!detail::processOk(sdrhip_comm_synchronize(_comm), "gpu::ChannelBank") || !ok) return;
     for (size_t ch = 0; ch < _C; ch++) {
       if (_epilogue == SDRHIP_EPI_NONE) _outs[ch].emit(_stageOut.sub(ch * _outStride, n), false);
       else if (!(_epilogue == SDRHIP_EPI_FM && n == 0))
@@ -735,8 +800,11 @@ protected:
   size_t _C;
   double _Fc, _Ff, _width;
   size_t _order, _D;
-  int _epilogue, _device;
-  sdrhip_iqbb_i16 *_plan;
+  int _epilogue;
+  std::vector<int> _devices;
+  sdrhip_comm *_comm;
+  std::vector<Rank> _ranks;
+  void *_gather;
   Config _cfg;
   size_t _bs, _have, _len, _outStride;
   std::vector<In> _ins;

@@ -278,6 +278,40 @@ int sdrhip_fbb_f32_process_dev(sdrhip_fbb_f32 *h, const float *in_dev, size_t n_
 int sdrhip_fbb_f32_reset(sdrhip_fbb_f32 *h);
 int sdrhip_fbb_f32_destroy(sdrhip_fbb_f32 *h);
 
+/* ---- one process, several GPUs (BASELINE config 5 from the C++ side) ----------------------------- */
+/* The reference composes many inputs through one port per input (Combine::sink(i), reference src/combine.hh:66-150);
+ * here the independent channels of such a bank are split into contiguous blocks, one per device. The data path has
+ * no collective; the two exchanges are a broadcast of the read-only design (taps / LUT / FFT kernel, KBs, at config
+ * time) and one gather of the demodulated output per step. `devices[r]` is the HIP device of rank r. Collectives
+ * are RCCL over xGMI (librccl is opened with dlopen at the first create that needs it) when the ranks sit on
+ * distinct devices; ranks that all share one device (single-GPU boxes: tests) use device-to-device copies on that
+ * device instead — RCCL refuses two ranks on one device. Every call is asynchronous on the ranks' streams. */
+typedef struct sdrhip_comm sdrhip_comm;
+int sdrhip_comm_create(const int *devices, int nranks, sdrhip_comm **out);
+int sdrhip_comm_size(sdrhip_comm *c, int *nranks);
+/* rank r's context (its own stream on devices[r]); borrowed, lives as long as the comm: create the rank's plans on it */
+int sdrhip_comm_ctx(sdrhip_comm *c, int rank, sdrhip_ctx **ctx);
+int sdrhip_comm_transport(sdrhip_comm *c, const char **name); /* "rccl" or "same-device copies" */
+/* bufs_dev[root] -> bufs_dev[r] for every rank r (bytes each) */
+int sdrhip_comm_broadcast(sdrhip_comm *c, void *const *bufs_dev, size_t bytes, int root);
+/* rank r's bytes[r] bytes at send_dev[r] -> recv_dev (on the root's device), concatenated in rank order */
+int sdrhip_comm_gather(sdrhip_comm *c, const void *const *send_dev, const size_t *bytes, void *recv_dev, int root);
+int sdrhip_comm_synchronize(sdrhip_comm *c);
+int sdrhip_comm_destroy(sdrhip_comm *c);
+
+/* ---- pinned host memory, asynchronous copies (staging of the many-channel nodes) --------------------------------- */
+/* The *_process entry points take pageable host memory and let the runtime stage it. A node that owns its staging
+ * buffers (gpu::ChannelBank) allocates them pinned, so that H2D / D2H run as plain DMA on the rank's stream and the
+ * devices of a multi-GPU bank copy and compute at the same time. host_register pins memory the caller owns. */
+int sdrhip_host_alloc(size_t bytes, void **hptr);
+int sdrhip_host_free(void *hptr);
+int sdrhip_host_register(void *hptr, size_t bytes);
+int sdrhip_host_unregister(void *hptr);
+int sdrhip_memcpy_h2d_async(sdrhip_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int sdrhip_memcpy_d2h_async(sdrhip_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+int sdrhip_memcpy2d_d2h_async(sdrhip_ctx *ctx, void *dst_host, size_t dst_pitch, const void *src_dev, size_t src_pitch,
+                              size_t row_bytes, size_t rows);
+
 #ifdef __cplusplus
 }
 #endif

@@ -126,6 +126,21 @@ def lib():
             "sdrhip_fbb_f32_process_dev": (C.c_int, [vp, vp, sz, sz, vp, sz, psz]),
             "sdrhip_fbb_f32_reset": (C.c_int, [vp]),
             "sdrhip_fbb_f32_destroy": (C.c_int, [vp]),
+            "sdrhip_comm_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, pvp]),
+            "sdrhip_comm_size": (C.c_int, [vp, C.POINTER(C.c_int)]),
+            "sdrhip_comm_ctx": (C.c_int, [vp, C.c_int, pvp]),
+            "sdrhip_comm_transport": (C.c_int, [vp, C.POINTER(C.c_char_p)]),
+            "sdrhip_comm_broadcast": (C.c_int, [vp, pvp, sz, C.c_int]),
+            "sdrhip_comm_gather": (C.c_int, [vp, pvp, psz, vp, C.c_int]),
+            "sdrhip_comm_synchronize": (C.c_int, [vp]),
+            "sdrhip_comm_destroy": (C.c_int, [vp]),
+            "sdrhip_host_alloc": (C.c_int, [sz, pvp]),
+            "sdrhip_host_free": (C.c_int, [vp]),
+            "sdrhip_host_register": (C.c_int, [vp, sz]),
+            "sdrhip_host_unregister": (C.c_int, [vp]),
+            "sdrhip_memcpy_h2d_async": (C.c_int, [vp, vp, vp, sz]),
+            "sdrhip_memcpy_d2h_async": (C.c_int, [vp, vp, vp, sz]),
+            "sdrhip_memcpy2d_d2h_async": (C.c_int, [vp, vp, sz, vp, sz, sz, sz]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)

@@ -2,6 +2,7 @@
 // repository's sdr:: core, compared bit-exactly with the CPU oracle (oracle/sdr_oracle.h; test side
 // only). Graph shapes follow examples/sdr_fm.cc:49-53 and SURVEY §3.2/§3.3. Needs an MI355X.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <iostream>
@@ -179,6 +180,76 @@ static void testChannelBankDropsWhileOutputInUse() {
   CHECK(hold[0].calls == 2 && hold[3].calls == 2);
 }
 
+// BASELINE config 5 from the C++ side: the bank split over several ranks (both on device 0 here: the GPU boxes of the
+// test pool have one device; with distinct devices the same calls go through RCCL) equals the one-device bank
+static void testChannelBankMultiRank() {
+  const size_t C = 10, N = 4096;
+  for (int epi = 0; epi < 2; epi++) {
+    const int e = epi ? SDRHIP_EPI_FM : SDRHIP_EPI_USB;
+    gpu::ChannelBank<int16_t> one(C, 100e3, 100e3, 50e3, 127, 8, e);
+    gpu::ChannelBank<int16_t> three(C, 100e3, 100e3, 50e3, 127, 8, e, std::vector<int>(3, 0));   // blocks of 4, 3, 3 channels
+    std::vector<Feeder> s1(C), s3(C); std::vector< Recorder<int16_t> > r1(C), r3(C);
+    std::vector< std::vector<cs16> > x(C);
+    for (size_t c = 0; c < C; c++) {
+      x[c] = tones(3 * N, 80e3 + 2500.0 * c);
+      s1[c].cfg(Config::Type_cs16, N); s3[c].cfg(Config::Type_cs16, N);
+      s1[c].connect(one.sink(c), true); one.source(c)->connect(&r1[c], true);
+      s3[c].connect(three.sink(c), true); three.source(c)->connect(&r3[c], true);
+    }
+    CHECK(three.ranks() == 3 && std::string(three.transport()) == "same-device copies");
+    for (int k = 0; k < 3; k++) for (size_t c = 0; c < C; c++) { s1[c].feed(&x[c][k * N], N); s3[c].feed(&x[c][k * N], N); }
+    for (size_t c = 0; c < C; c++) CHECK(r1[c].data.size() == 1535 && r1[c].data == r3[c].data);
+  }
+}
+
+// the C ABI's comm calls directly: broadcast of a design buffer, gather of ragged blocks; two ranks on device 0, and one
+// rank forced through RCCL (SDRHIP_COMM_FORCE_RCCL=1: dlopen, ncclCommInitAll, grouped send/recv on a 1-rank communicator)
+static void testCommCalls() {
+  for (int rccl = 0; rccl < 2; rccl++) {
+    const int nr = rccl ? 1 : 2;
+    int devs[2] = {0, 0};
+    if (rccl) setenv("SDRHIP_COMM_FORCE_RCCL", "1", 1);
+    sdrhip_comm *cm = 0;
+    const int rc = sdrhip_comm_create(devs, nr, &cm);
+    if (rccl) unsetenv("SDRHIP_COMM_FORCE_RCCL");
+    CHECK(rc == SDRHIP_OK);
+    if (rc != SDRHIP_OK) { std::printf("  comm_create: %s\n", sdrhip_last_error()); continue; }
+    const char *tr = ""; sdrhip_comm_transport(cm, &tr);
+    CHECK(std::string(tr) == (rccl ? "rccl" : "same-device copies"));
+    std::vector<sdrhip_ctx *> ctx(nr); std::vector<void *> buf(nr), blk(nr);
+    std::vector<uint32_t> design(1000); for (size_t i = 0; i < design.size(); i++) design[i] = uint32_t(i * 2654435761u);
+    const size_t blkn[2] = {300, 177};
+    void *all = 0;
+    for (int r = 0; r < nr; r++) {
+      sdrhip_comm_ctx(cm, r, &ctx[r]);
+      sdrhip_malloc(ctx[r], design.size() * 4, &buf[r]); sdrhip_malloc(ctx[r], blkn[r] * 4, &blk[r]);
+      sdrhip_memset(ctx[r], buf[r], 0, design.size() * 4);
+      std::vector<uint32_t> v(blkn[r]); for (size_t i = 0; i < v.size(); i++) v[i] = uint32_t(1000 * (r + 1) + i);
+      sdrhip_memcpy_h2d(ctx[r], blk[r], v.data(), v.size() * 4);
+    }
+    sdrhip_malloc(ctx[0], (blkn[0] + blkn[1]) * 4, &all);
+    sdrhip_memcpy_h2d(ctx[0], buf[0], design.data(), design.size() * 4);
+    CHECK(sdrhip_comm_broadcast(cm, buf.data(), design.size() * 4, 0) == SDRHIP_OK);
+    std::vector<size_t> bytes(nr); for (int r = 0; r < nr; r++) bytes[r] = blkn[r] * 4;
+    std::vector<const void *> send(blk.begin(), blk.end());
+    CHECK(sdrhip_comm_gather(cm, send.data(), bytes.data(), all, 0) == SDRHIP_OK);
+    CHECK(sdrhip_comm_synchronize(cm) == SDRHIP_OK);
+    for (int r = 0; r < nr; r++) {
+      std::vector<uint32_t> got(design.size());
+      sdrhip_memcpy_d2h(ctx[r], got.data(), buf[r], got.size() * 4);
+      CHECK(got == design);
+    }
+    size_t tot = 0; for (int r = 0; r < nr; r++) tot += blkn[r];
+    std::vector<uint32_t> g(tot); sdrhip_memcpy_d2h(ctx[0], g.data(), all, tot * 4);
+    bool okg = true; size_t o = 0;
+    for (int r = 0; r < nr; r++) for (size_t i = 0; i < blkn[r]; i++, o++) okg = okg && g[o] == uint32_t(1000 * (r + 1) + i);
+    CHECK(okg);
+    for (int r = 0; r < nr; r++) { sdrhip_free(ctx[r], buf[r]); sdrhip_free(ctx[r], blk[r]); }
+    sdrhip_free(ctx[0], all);
+    CHECK(sdrhip_comm_destroy(cm) == SDRHIP_OK);
+  }
+}
+
 // float nodes: FIRLowPass<cf32> -> SubSample<cf32>(8) and the FFT filter bank vs direct convolution
 static void testFloatNodes() {
   const size_t N = 4096;
@@ -299,6 +370,8 @@ int main(int argc, char **argv) {
     testOwnership();
     testChannelBank();
     testChannelBankDropsWhileOutputInUse();
+    testChannelBankMultiRank();
+    testCommCalls();
     testFloatNodes();
     testSdrFmChainCu8();
     testRealBaseBand();
