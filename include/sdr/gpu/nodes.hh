@@ -554,54 +554,85 @@ public:
   /** One band of the bank: a Source of complex<float> buffers (role of FilterSource, src/filternode.hh:105-227). */
   class Band : public Source {
   public:
-    Band(size_t block, double fmin, double fmax, int device) : _block(block), _fmin(fmin), _fmax(fmax), _device(device), _plan(0) {}
-    virtual ~Band() {
-      if (_plan) sdrhip_fftconv_destroy(_plan);
-      _buffer.unref();
+    Band(FilterNode *p, size_t index, double fmin, double fmax) : _p(p), _index(index), _fmin(fmin), _fmax(fmax) {}
+    virtual ~Band() { _buffer.unref(); }
+    /** FilterSource::setFreq (:132-139): only this band's kernel is recomputed; the overlap history goes on. */
+    void setFreq(double fmin, double fmax) {
+      if (fmax < fmin) std::swap(fmin, fmax);
+      _fmin = fmin; _fmax = fmax;
+      _p->_bandChanged(_index);
     }
-    void setFreq(double fmin, double fmax) { _fmin = fmin; _fmax = fmax; if (_cfg.hasSampleRate()) configure(_cfg); }
-    void configure(const Config &cfg) {
-      _cfg = cfg;
-      std::vector<float> h(2 * _block), K(4 * _block);
-      design::fftFilterKernel(int(_block), _fmin, _fmax, cfg.sampleRate(), h.data());
-      design::fftFilterSpectrum(int(_block), h.data(), K.data());
-      if (_plan) { sdrhip_fftconv_destroy(_plan); _plan = 0; }
-      detail::configCheck(sdrhip_fftconv_create(Device::get(_device), SDRHIP_FFTCONV_OLA, int(2 * _block), K.data(), 0, 1,
-                                                cfg.bufferSize(), &_plan), "FFT filter");
-      _buffer.unref();
-      _buffer = Buffer<cf32>(cfg.bufferSize());
-      this->setConfig(Config(Config::typeId<cf32>(), cfg.sampleRate(), cfg.bufferSize(), 1));
-    }
-    void run(const Buffer<cf32> &in) {
-      if (!_plan || !_buffer.isUnused()) return;
-      if (!detail::processOk(sdrhip_fftconv_process(_plan, reinterpret_cast<const float *>(in.data()), in.size(), 0,
-                                                    reinterpret_cast<float *>(_buffer.data()), 0), "gpu::FilterNode")) return;
-      this->send(_buffer.head(in.size()), false);
-    }
+    double fmin() const { return _fmin; }
+    double fmax() const { return _fmax; }
 
   protected:
-    size_t _block;
+    friend class FilterNode;
+    FilterNode *_p;
+    size_t _index;
     double _fmin, _fmax;
-    int _device;
-    Config _cfg;
-    sdrhip_fftconv *_plan;
     Buffer<cf32> _buffer;
   };
 
-  explicit FilterNode(size_t block_size = 1024, int device = 0) : _block(block_size), _device(device), _sink(this) {}
-  virtual ~FilterNode() { for (std::list<Band *>::iterator b = _bands.begin(); b != _bands.end(); ++b) delete *b; }
+  explicit FilterNode(size_t block_size = 1024, int device = 0) : _block(block_size), _device(device), _plan(0), _sink(this) {}
+  virtual ~FilterNode() {
+    if (_plan) sdrhip_fftconv_destroy(_plan);
+    for (size_t b = 0; b < _bands.size(); b++) delete _bands[b];
+  }
 
   /** The input of the bank. Unlike the reference (whose BufferNode crashes: SURVEY fact 7) any buffer size is accepted. */
   Sink<cf32> *sink() { return &_sink; }
-  /** Adds a band [fmin, fmax]; the returned Source emits the filtered stream. */
+  /** Adds a band [fmin, fmax]; the returned Source emits the filtered stream. Adding a band to a configured bank makes
+   * a new device plan (the bands' overlap history restarts). */
   Band *addFilter(double fmin, double fmax) {
     if (fmax < fmin) std::swap(fmin, fmax);
-    _bands.push_back(new Band(_block, fmin, fmax, _device));
-    if (_cfg.hasSampleRate()) _bands.back()->configure(_cfg);
+    _bands.push_back(new Band(this, _bands.size(), fmin, fmax));
+    if (_cfg.hasSampleRate()) _configure(_cfg);
     return _bands.back();
   }
 
 protected:
+  void _kernelOf(const Band *b, float *K) const {   // sinc_flt_kernel + FilterSource::_updateFilter (:18-28,186-203)
+    std::vector<float> h(2 * _block);
+    design::fftFilterKernel(int(_block), b->_fmin, b->_fmax, _cfg.sampleRate(), h.data());
+    design::fftFilterSpectrum(int(_block), h.data(), K);
+  }
+  /** ONE device plan for all bands: one upload and one forward FFT per input block feed every band
+   * (FilterSink -> FilterSource fan-out, src/filternode.hh:81-88,257-270). */
+  void _configure(const Config &cfg) {
+    _cfg = cfg;
+    if (_plan) { sdrhip_fftconv_destroy(_plan); _plan = 0; }
+    if (_bands.empty()) return;
+    std::vector<float> K(4 * _block * _bands.size());
+    for (size_t b = 0; b < _bands.size(); b++) _kernelOf(_bands[b], K.data() + b * 4 * _block);
+    detail::configCheck(sdrhip_fftconv_create_bank(Device::get(_device), SDRHIP_FFTCONV_OLA, int(2 * _block), K.data(), 0,
+                                                   int(_bands.size()), 1, cfg.bufferSize(), &_plan), "FFT filter");
+    _stage.resize(2 * cfg.bufferSize() * _bands.size());
+    for (size_t b = 0; b < _bands.size(); b++) {
+      _bands[b]->_buffer.unref();
+      _bands[b]->_buffer = Buffer<cf32>(cfg.bufferSize());
+      _bands[b]->setConfig(Config(Config::typeId<cf32>(), cfg.sampleRate(), cfg.bufferSize(), 1));
+    }
+  }
+  void _bandChanged(size_t index) {
+    if (!_plan) return;
+    std::vector<float> K(4 * _block);
+    _kernelOf(_bands[index], K.data());
+    detail::configCheck(sdrhip_fftconv_set_kernel(_plan, int(index), K.data()), "FFT filter");
+  }
+  void _run(const Buffer<cf32> &in) {
+    if (!_plan || in.size() * 2 * _bands.size() > _stage.size()) return;
+    // a band whose output buffer is still referenced downstream drops this block (src/baseband.hh:141-150 rule); the
+    // bank still runs, so that every band's overlap history stays aligned with the input
+    if (!detail::processOk(sdrhip_fftconv_process(_plan, reinterpret_cast<const float *>(in.data()), in.size(), 0, _stage.data(), 0),
+                           "gpu::FilterNode")) return;
+    for (size_t b = 0; b < _bands.size(); b++) {
+      Band *bd = _bands[b];
+      if (!bd->_buffer.isUnused()) continue;
+      memcpy(bd->_buffer.data(), _stage.data() + b * 2 * in.size(), in.size() * sizeof(cf32));
+      bd->send(bd->_buffer.head(in.size()), false);
+    }
+  }
+
   class In : public Sink<cf32> {
   public:
     explicit In(FilterNode *p) : _p(p) {}
@@ -612,19 +643,19 @@ protected:
         err << "Can not configure filter-sink: Invalid type " << src_cfg.type() << ", expected " << Config::typeId<cf32>();
         throw err;
       }
-      _p->_cfg = src_cfg;
-      for (std::list<Band *>::iterator b = _p->_bands.begin(); b != _p->_bands.end(); ++b) (*b)->configure(src_cfg);
+      _p->_configure(src_cfg);
     }
-    virtual void process(const Buffer<cf32> &buffer, bool) {
-      for (std::list<Band *>::iterator b = _p->_bands.begin(); b != _p->_bands.end(); ++b) (*b)->run(buffer);
-    }
+    virtual void process(const Buffer<cf32> &buffer, bool) { _p->_run(buffer); }
     FilterNode *_p;
   };
+  friend class Band;
   size_t _block;
   int _device;
   Config _cfg;
+  sdrhip_fftconv *_plan;
   In _sink;
-  std::list<Band *> _bands;
+  std::vector<Band *> _bands;
+  std::vector<float> _stage;
 };
 
 // =================================================================================================

@@ -256,6 +256,18 @@ enum {
  * OLS: kernel = n_taps cf32 time-domain taps; any n_in. */
 int sdrhip_fftconv_create(sdrhip_ctx *ctx, int mode, int fft_size, const float *kernel, int n_taps,
                           int channels, size_t max_in, sdrhip_fftconv **out);
+/* Filter bank (FilterNode, reference src/filternode.hh:232-284): n_bands kernels behind ONE forward transform per
+ * input block, as FilterSink's spectrum feeds every FilterSource (:81-88,257-270). `kernels` holds the bands' kernels
+ * back to back (OLA: 2N cf32 each; OLS: n_taps cf32 each). process / process_dev then write n_bands x channels rows:
+ * band b's channel c at row b*channels + c (row stride out_stride). Plans whose FFT does not fit the CU's LDS twice
+ * (fft_size 16384) transform the input once per band instead. set_kernel swaps one band's kernel between calls
+ * (FilterSource::setFreq -> _updateFilter, :132-139,186-203) and keeps the stream going; the convolution is evaluated by
+ * overlap-save, so the block after the swap is the NEW kernel applied to the input history, where the reference's
+ * overlap-add adds the OLD kernel's tail to the new kernel's head — a one-block transient, stated here, not hidden. */
+int sdrhip_fftconv_create_bank(sdrhip_ctx *ctx, int mode, int fft_size, const float *kernels, int n_taps, int n_bands,
+                               int channels, size_t max_in, sdrhip_fftconv **out);
+int sdrhip_fftconv_bands(sdrhip_fftconv *h, int *n_bands);
+int sdrhip_fftconv_set_kernel(sdrhip_fftconv *h, int band, const float *kernel);
 int sdrhip_fftconv_process(sdrhip_fftconv *h, const float *in_host, size_t n_in, size_t in_stride,
                            float *out_host, size_t out_stride);
 int sdrhip_fftconv_process_dev(sdrhip_fftconv *h, const float *in_dev, size_t n_in, size_t in_stride,

@@ -126,6 +126,9 @@ def lib():
             "sdrhip_fbb_f32_process_dev": (C.c_int, [vp, vp, sz, sz, vp, sz, psz]),
             "sdrhip_fbb_f32_reset": (C.c_int, [vp]),
             "sdrhip_fbb_f32_destroy": (C.c_int, [vp]),
+            "sdrhip_fftconv_create_bank": (C.c_int, [vp, C.c_int, C.c_int, f32p, C.c_int, C.c_int, C.c_int, sz, pvp]),
+            "sdrhip_fftconv_bands": (C.c_int, [vp, C.POINTER(C.c_int)]),
+            "sdrhip_fftconv_set_kernel": (C.c_int, [vp, C.c_int, f32p]),
             "sdrhip_comm_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, pvp]),
             "sdrhip_comm_size": (C.c_int, [vp, C.POINTER(C.c_int)]),
             "sdrhip_comm_ctx": (C.c_int, [vp, C.c_int, pvp]),

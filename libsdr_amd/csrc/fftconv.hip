@@ -188,9 +188,11 @@ struct ConvArgs {
   FftDev fft;
   const float2 *in; long in_stride;
   const float2 *hist; int HH;        // HH = L - hop samples preceding the call
-  const float2 *Kp;                  // spectrum, digit-reversed order, pre-scaled by 1/L
+  const float2 *Kp;                  // spectra (band b at Kp + b*L), digit-reversed order, pre-scaled by 1/L
   float2 *out; long out_stride;
   int N, hop;
+  int nb; long out_band;             // filter bank: bands sharing ONE forward transform; band b's rows start at out + b*out_band
+  int lds_elems;                     // padded elements of one LDS image (the bank keeps the forward image and works in a second one)
 };
 
 __global__ __launch_bounds__(FT) void fftconv_kernel(const ConvArgs a) {
@@ -207,13 +209,17 @@ __global__ __launch_bounds__(FT) void fftconv_kernel(const ConvArgs a) {
   }
   __syncthreads();
   fft_forward_dif(xl, a.fft, tid);
-  for (int i = tid; i < L; i += FT) xl[PAD(i)] = cmul(xl[PAD(i)], a.Kp[i]);
-  __syncthreads();
-  fft_inverse_dit(xl, a.fft, tid);
-  const int o0 = blk * a.hop;
-  for (int i = tid; i < a.hop; i += FT) {
-    const int o = o0 + i;
-    if (o < a.N) a.out[(long)c * a.out_stride + o] = xl[PAD(a.HH + i)];
+  float2 *xw = a.nb > 1 ? xl + a.lds_elems : xl;
+  for (int band = 0; band < a.nb; band++) {
+    for (int i = tid; i < L; i += FT) xw[PAD(i)] = cmul(xl[PAD(i)], a.Kp[(long)band * L + i]);
+    __syncthreads();
+    fft_inverse_dit(xw, a.fft, tid);
+    const int o0 = blk * a.hop;
+    for (int i = tid; i < a.hop; i += FT) {
+      const int o = o0 + i;
+      if (o < a.N) a.out[(long)band * a.out_band + (long)c * a.out_stride + o] = xw[PAD(a.HH + i)];
+    }
+    __syncthreads();
   }
 }
 
@@ -312,6 +318,13 @@ __global__ __launch_bounds__(FT) void fftconv_fused_kernel(const ConvArgs a) {
     __syncthreads();
     n = s;
   }
+  // ---- filter bank: the forward image stays in xs; every band multiplies it by its own spectrum and runs the inverse
+  // transform in the work image xw (one band: xw == xs, in place as before). One forward transform per input block,
+  // as FilterSink feeds every FilterSource from one FFT (reference src/filternode.hh:81-88,257-270). ----
+  float2 *xs = xl, *xw = a.nb > 1 ? xl + a.lds_elems : xl;
+  for (int band = 0; band < a.nb; band++) {
+  const float2 *kp = a.Kp + (long)band * L;
+  float2 *outb = a.out + (long)band * a.out_band;
   // ---- last forward pass (stride 1, no twiddles) x spectrum x first inverse pass ----
   {
     const int r = radix_at(np - 1);
@@ -319,29 +332,29 @@ __global__ __launch_bounds__(FT) void fftconv_fused_kernel(const ConvArgs a) {
       for (int b = tid; b < L / 16; b += FT) {
         float2 v[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) v[k] = xl[PAD(16 * b + k)];
+        for (int k = 0; k < 16; k++) v[k] = xs[PAD(16 * b + k)];
         dft16<-1>(v);
 #pragma unroll
-        for (int k = 0; k < 16; k++) v[k] = cmul(v[k], a.Kp[16 * b + k]);
+        for (int k = 0; k < 16; k++) v[k] = cmul(v[k], kp[16 * b + k]);
         dft16<1>(v);
 #pragma unroll
-        for (int k = 0; k < 16; k++) xl[PAD(16 * b + k)] = v[k];
+        for (int k = 0; k < 16; k++) xw[PAD(16 * b + k)] = v[k];
       }
     } else if (r == 4) {
       for (int b = tid; b < L / 4; b += FT) {
-        const float2 a0 = xl[PAD(4 * b)], a1 = xl[PAD(4 * b + 1)], a2 = xl[PAD(4 * b + 2)], a3 = xl[PAD(4 * b + 3)];
+        const float2 a0 = xs[PAD(4 * b)], a1 = xs[PAD(4 * b + 1)], a2 = xs[PAD(4 * b + 2)], a3 = xs[PAD(4 * b + 3)];
         float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_mi(csub(a1, a3));
-        const float2 y0 = cmul(cadd(t0, t2), a.Kp[4 * b]), y1 = cmul(cadd(t1, t3), a.Kp[4 * b + 1]);
-        const float2 y2 = cmul(csub(t0, t2), a.Kp[4 * b + 2]), y3 = cmul(csub(t1, t3), a.Kp[4 * b + 3]);
+        const float2 y0 = cmul(cadd(t0, t2), kp[4 * b]), y1 = cmul(cadd(t1, t3), kp[4 * b + 1]);
+        const float2 y2 = cmul(csub(t0, t2), kp[4 * b + 2]), y3 = cmul(csub(t1, t3), kp[4 * b + 3]);
         t0 = cadd(y0, y2); t1 = csub(y0, y2); t2 = cadd(y1, y3); t3 = mul_pi(csub(y1, y3));
-        xl[PAD(4 * b)] = cadd(t0, t2); xl[PAD(4 * b + 1)] = cadd(t1, t3);
-        xl[PAD(4 * b + 2)] = csub(t0, t2); xl[PAD(4 * b + 3)] = csub(t1, t3);
+        xw[PAD(4 * b)] = cadd(t0, t2); xw[PAD(4 * b + 1)] = cadd(t1, t3);
+        xw[PAD(4 * b + 2)] = csub(t0, t2); xw[PAD(4 * b + 3)] = csub(t1, t3);
       }
     } else {
       for (int b = tid; b < L / 2; b += FT) {
-        const float2 a0 = xl[PAD(2 * b)], a1 = xl[PAD(2 * b + 1)];
-        const float2 y0 = cmul(cadd(a0, a1), a.Kp[2 * b]), y1 = cmul(csub(a0, a1), a.Kp[2 * b + 1]);
-        xl[PAD(2 * b)] = cadd(y0, y1); xl[PAD(2 * b + 1)] = csub(y0, y1);
+        const float2 a0 = xs[PAD(2 * b)], a1 = xs[PAD(2 * b + 1)];
+        const float2 y0 = cmul(cadd(a0, a1), kp[2 * b]), y1 = cmul(csub(a0, a1), kp[2 * b + 1]);
+        xw[PAD(2 * b)] = cadd(y0, y1); xw[PAD(2 * b + 1)] = csub(y0, y1);
       }
     }
     __syncthreads();
@@ -357,24 +370,24 @@ __global__ __launch_bounds__(FT) void fftconv_fused_kernel(const ConvArgs a) {
         const int j = b & (s - 1), base = (b / s) * n + j;
         float2 v[16], w[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) v[k] = xl[PAD(base + k * s)];
+        for (int k = 0; k < 16; k++) v[k] = xw[PAD(base + k * s)];
         twiddles16(p, pass, s, j, w);
 #pragma unroll
         for (int k = 1; k < 16; k++) v[k] = cmulc(v[k], w[k]);
         dft16<1>(v);
 #pragma unroll
-        for (int k = 0; k < 16; k++) xl[PAD(base + k * s)] = v[k];
+        for (int k = 0; k < 16; k++) xw[PAD(base + k * s)] = v[k];
       }
     } else {
       for (int b = tid; b < L / 4; b += FT) {
         const int j = b & (s - 1), base = (b / s) * n + j;
-        const float2 a0 = xl[PAD(base)];
-        const float2 a1 = cmulc(xl[PAD(base + s)], p.W[j * tw]);
-        const float2 a2 = cmulc(xl[PAD(base + 2 * s)], p.W[2 * j * tw]);
-        const float2 a3 = cmulc(xl[PAD(base + 3 * s)], p.W[3 * j * tw]);
+        const float2 a0 = xw[PAD(base)];
+        const float2 a1 = cmulc(xw[PAD(base + s)], p.W[j * tw]);
+        const float2 a2 = cmulc(xw[PAD(base + 2 * s)], p.W[2 * j * tw]);
+        const float2 a3 = cmulc(xw[PAD(base + 3 * s)], p.W[3 * j * tw]);
         const float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_pi(csub(a1, a3));
-        xl[PAD(base)] = cadd(t0, t2); xl[PAD(base + s)] = cadd(t1, t3);
-        xl[PAD(base + 2 * s)] = csub(t0, t2); xl[PAD(base + 3 * s)] = csub(t1, t3);
+        xw[PAD(base)] = cadd(t0, t2); xw[PAD(base + s)] = cadd(t1, t3);
+        xw[PAD(base + 2 * s)] = csub(t0, t2); xw[PAD(base + 3 * s)] = csub(t1, t3);
       }
     }
     __syncthreads();
@@ -385,12 +398,12 @@ __global__ __launch_bounds__(FT) void fftconv_fused_kernel(const ConvArgs a) {
     for (int j = tid; j < s; j += FT) {
       float2 v[16], w[16];
 #pragma unroll
-      for (int k = 0; k < 16; k++) v[k] = xl[PAD(j + k * s)];
+      for (int k = 0; k < 16; k++) v[k] = xw[PAD(j + k * s)];
       twiddles16(p, 0, s, j, w);
 #pragma unroll
       for (int k = 1; k < 16; k++) v[k] = cmulc(v[k], w[k]);
       dft16<1>(v);
-      float2 *dst = a.out + (long)c * a.out_stride + o0 - a.HH;   // element i of the block goes to dst[i] (i >= HH)
+      float2 *dst = outb + (long)c * a.out_stride + o0 - a.HH;   // element i of the block goes to dst[i] (i >= HH)
       const bool vec_out = ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) && (s & 1) == 0 && (a.HH & 1) == 0 && s >= FT &&
                            o0 + (L - a.HH) <= a.N;
       if (vec_out) {   // lane pairs swap halves and store 16 bytes per lane: 8 dwordx4 stores instead of 16 dwordx2
@@ -408,10 +421,12 @@ __global__ __launch_bounds__(FT) void fftconv_fused_kernel(const ConvArgs a) {
 #pragma unroll
         for (int k = 0; k < 16; k++) {
           const int i = j + k * s - a.HH, o = o0 + i;
-          if (i >= 0 && o < a.N) a.out[(long)c * a.out_stride + o] = v[k];
+          if (i >= 0 && o < a.N) outb[(long)c * a.out_stride + o] = v[k];
         }
       }
     }
+  }
+  if (band + 1 < a.nb) __syncthreads();   // the work image is read out before the next band's middle pass overwrites it
   }
 }
 
@@ -510,29 +525,77 @@ void allow_big_lds(K kernel, size_t bytes) {
 struct sdrhip_fftconv {
   sdrhip_ctx *ctx = nullptr;
   int mode = 0, C = 1, hop = 0, HH = 0, par = 0;
+  int B = 1;            // bands of the bank (spectra sharing one forward transform)
+  int n_taps = 0;
   size_t max_in = 0;
   FftPlan plan;
   DevBuf<float2> Kp;
   DevBuf<float2> hist[2];
   DevBuf<float2> stage_in, stage_out;
 
-  void launch(const float2 *in_dev, size_t N, size_t in_stride, float2 *out_dev, size_t out_stride) {
+  // spectrum of one band -> the device layout (digit-reversed position order, pre-scaled by 1/L)
+  void load_kernel(int band, const float *kernel) {
+    const int L = plan.L;
+    std::vector< std::complex<double> > spec(L);
+    if (mode == SDRHIP_FFTCONV_OLA) {
+      // kernel = the FilterSource spectrum (2N points); its time-domain support is N taps
+      for (int i = 0; i < L; i++) spec[i] = std::complex<double>(kernel[2 * i], kernel[2 * i + 1]);
+    } else {
+      // host DFT in double of the zero-padded taps (one-off)
+      std::vector< std::complex<double> > a(L, std::complex<double>(0, 0));
+      for (int i = 0; i < n_taps; i++) a[i] = std::complex<double>(kernel[2 * i], kernel[2 * i + 1]);
+      for (size_t i = 1, j = 0; i < (size_t)L; i++) {
+        size_t bit = (size_t)L >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(a[i], a[j]);
+      }
+      for (size_t len = 2; len <= (size_t)L; len <<= 1)
+        for (size_t k = 0; k < len / 2; k++) {
+          const double ang = -2.0 * M_PI * (double)k / (double)len;
+          const std::complex<double> w(std::cos(ang), std::sin(ang));
+          for (size_t s = 0; s < (size_t)L; s += len) {
+            const std::complex<double> u = a[s + k], t = w * a[s + k + len / 2];
+            a[s + k] = u + t; a[s + k + len / 2] = u - t;
+          }
+        }
+      spec = a;
+    }
+    std::vector<float2> kp(L);
+    for (int pos = 0; pos < L; pos++) {
+      const std::complex<double> v = spec[plan.perm[pos]] / (double)L;
+      kp[pos] = make_float2((float)v.real(), (float)v.imag());
+    }
+    SDRHIP_CHECK_HIP(hipMemcpyAsync(Kp.p + (size_t)band * L, kp.data(), (size_t)L * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
+    SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  }
+
+  // bands a launch can serve from one forward transform: the forward image and one work image must fit the CU's LDS
+  int bands_per_launch() const { return 2 * plan.lds_bytes() <= 160 * 1024 ? B : 1; }
+
+  // out_band: elements between band b's and band b+1's rows
+  void launch(const float2 *in_dev, size_t N, size_t in_stride, float2 *out_dev, size_t out_stride, size_t out_band) {
     ctx->use();
     if (N == 0) return;
+    const int bpl = bands_per_launch();
+    for (int b0 = 0; b0 < B; b0 += bpl) {   // (a plan too large for two LDS images transforms the input once per band)
     ConvArgs a;
+    a.nb = std::min(bpl, B - b0); a.out_band = (long)out_band; a.lds_elems = (int)(plan.lds_bytes() / sizeof(float2));
+    const size_t lds = (a.nb > 1 ? 2 : 1) * plan.lds_bytes();
     a.fft = plan.dev; a.in = in_dev; a.in_stride = (long)in_stride;
-    a.hist = hist[par].p; a.HH = HH; a.Kp = Kp.p;
-    a.out = out_dev; a.out_stride = (long)out_stride; a.N = (int)N; a.hop = hop;
+    a.hist = hist[par].p; a.HH = HH; a.Kp = Kp.p + (size_t)b0 * plan.L;
+    a.out = out_dev + (size_t)b0 * out_band; a.out_stride = (long)out_stride; a.N = (int)N; a.hop = hop;
     const int blocks = (int)ceil_div(N, (size_t)hop);
     if (plan.L == 16384) {
-      allow_big_lds(fftconv_fused_kernel<14>, plan.lds_bytes());
-      hipLaunchKernelGGL(fftconv_fused_kernel<14>, dim3(blocks, C), dim3(FT), plan.lds_bytes(), ctx->stream, a);
+      allow_big_lds(fftconv_fused_kernel<14>, lds);
+      hipLaunchKernelGGL(fftconv_fused_kernel<14>, dim3(blocks, C), dim3(FT), lds, ctx->stream, a);
     } else if (plan.dev.npass >= 2 && plan.dev.radix[0] == 16) {
-      allow_big_lds(fftconv_fused_kernel<0>, plan.lds_bytes());
-      hipLaunchKernelGGL(fftconv_fused_kernel<0>, dim3(blocks, C), dim3(FT), plan.lds_bytes(), ctx->stream, a);
+      allow_big_lds(fftconv_fused_kernel<0>, lds);
+      hipLaunchKernelGGL(fftconv_fused_kernel<0>, dim3(blocks, C), dim3(FT), lds, ctx->stream, a);
     } else {
-      allow_big_lds(fftconv_kernel, plan.lds_bytes());
-      hipLaunchKernelGGL(fftconv_kernel, dim3(blocks, C), dim3(FT), plan.lds_bytes(), ctx->stream, a);
+      allow_big_lds(fftconv_kernel, lds);
+      hipLaunchKernelGGL(fftconv_kernel, dim3(blocks, C), dim3(FT), lds, ctx->stream, a);
+    }
     }
     SDRHIP_CHECK_HIP(hipGetLastError());
     if (HH > 0) {
@@ -546,59 +609,56 @@ struct sdrhip_fftconv {
 
 extern "C" {
 
-int sdrhip_fftconv_create(sdrhip_ctx *ctx, int mode, int fft_size, const float *kernel, int n_taps, int channels,
-                          size_t max_in, sdrhip_fftconv **out) {
+int sdrhip_fftconv_create_bank(sdrhip_ctx *ctx, int mode, int fft_size, const float *kernels, int n_taps, int n_bands,
+                               int channels, size_t max_in, sdrhip_fftconv **out) {
   return guarded([&] {
-    SDRHIP_REQUIRE(ctx && kernel && out, SDRHIP_E_INVALID, "NULL argument");
+    SDRHIP_REQUIRE(ctx && kernels && out, SDRHIP_E_INVALID, "NULL argument");
     *out = nullptr;
     SDRHIP_REQUIRE(mode == SDRHIP_FFTCONV_OLA || mode == SDRHIP_FFTCONV_OLS, SDRHIP_E_INVALID, "bad mode %d", mode);
     SDRHIP_REQUIRE(channels >= 1 && channels <= 65535, SDRHIP_E_INVALID, "channels %d outside [1,65535]", channels);
+    SDRHIP_REQUIRE(n_bands >= 1 && n_bands <= 256, SDRHIP_E_INVALID, "n_bands %d outside [1,256]", n_bands);
     SDRHIP_REQUIRE(max_in >= 1 && max_in < (size_t(1) << 30), SDRHIP_E_SIZE, "max_in %zu outside [1,2^30)", max_in);
     ctx->use();
     sdrhip_fftconv *h = new sdrhip_fftconv;
     try {
-      h->ctx = ctx; h->mode = mode; h->C = channels; h->max_in = max_in;
+      h->ctx = ctx; h->mode = mode; h->C = channels; h->max_in = max_in; h->B = n_bands;
       h->plan.build(ctx, fft_size);
       const int L = fft_size;
-      std::vector< std::complex<double> > spec(L);
-      if (mode == SDRHIP_FFTCONV_OLA) {
-        // kernel = the FilterSource spectrum (2N points); its time-domain support is N taps
-        h->hop = L / 2;
-        for (int i = 0; i < L; i++) spec[i] = std::complex<double>(kernel[2 * i], kernel[2 * i + 1]);
-      } else {
+      if (mode == SDRHIP_FFTCONV_OLA) { h->hop = L / 2; h->n_taps = L / 2; }
+      else {
         SDRHIP_REQUIRE(n_taps >= 1 && n_taps <= L, SDRHIP_E_INVALID, "n_taps %d outside [1,%d]", n_taps, L);
-        h->hop = L - n_taps + 1;
-        // host DFT in double of the zero-padded taps (one-off)
-        std::vector< std::complex<double> > a(L, std::complex<double>(0, 0));
-        for (int i = 0; i < n_taps; i++) a[i] = std::complex<double>(kernel[2 * i], kernel[2 * i + 1]);
-        for (size_t i = 1, j = 0; i < (size_t)L; i++) {
-          size_t bit = (size_t)L >> 1;
-          for (; j & bit; bit >>= 1) j ^= bit;
-          j ^= bit;
-          if (i < j) std::swap(a[i], a[j]);
-        }
-        for (size_t len = 2; len <= (size_t)L; len <<= 1)
-          for (size_t k = 0; k < len / 2; k++) {
-            const double ang = -2.0 * M_PI * (double)k / (double)len;
-            const std::complex<double> w(std::cos(ang), std::sin(ang));
-            for (size_t s = 0; s < (size_t)L; s += len) {
-              const std::complex<double> u = a[s + k], t = w * a[s + k + len / 2];
-              a[s + k] = u + t; a[s + k + len / 2] = u - t;
-            }
-          }
-        spec = a;
+        h->hop = L - n_taps + 1; h->n_taps = n_taps;
       }
       h->HH = L - h->hop;
-      std::vector<float2> kp(L);
-      for (int pos = 0; pos < L; pos++) {
-        const std::complex<double> v = spec[h->plan.perm[pos]] / (double)L;
-        kp[pos] = make_float2((float)v.real(), (float)v.imag());
-      }
-      h->Kp.alloc(L); h->Kp.upload(kp.data(), L, ctx->stream);
+      h->Kp.alloc((size_t)L * n_bands);
+      const size_t per_band = mode == SDRHIP_FFTCONV_OLA ? (size_t)2 * L : (size_t)2 * n_taps;   // floats per band in `kernels`
+      for (int b = 0; b < n_bands; b++) h->load_kernel(b, kernels + (size_t)b * per_band);
       for (int p = 0; p < 2; p++) { h->hist[p].alloc((size_t)channels * std::max(1, h->HH)); h->hist[p].zero(ctx->stream); }
       SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     } catch (...) { delete h; throw; }
     *out = h;
+  });
+}
+
+int sdrhip_fftconv_create(sdrhip_ctx *ctx, int mode, int fft_size, const float *kernel, int n_taps, int channels,
+                          size_t max_in, sdrhip_fftconv **out) {
+  return sdrhip_fftconv_create_bank(ctx, mode, fft_size, kernel, n_taps, 1, channels, max_in, out);
+}
+
+int sdrhip_fftconv_bands(sdrhip_fftconv *h, int *n_bands) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h && n_bands, SDRHIP_E_INVALID, "NULL argument");
+    *n_bands = h->B;
+  });
+}
+
+int sdrhip_fftconv_set_kernel(sdrhip_fftconv *h, int band, const float *kernel) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h && kernel, SDRHIP_E_INVALID, "NULL argument");
+    SDRHIP_REQUIRE(band >= 0 && band < h->B, SDRHIP_E_INVALID, "band %d outside [0,%d)", band, h->B);
+    h->ctx->use();
+    SDRHIP_CHECK_HIP(hipStreamSynchronize(h->ctx->stream));   // launches in flight still read the old spectrum
+    h->load_kernel(band, kernel);
   });
 }
 
@@ -612,8 +672,9 @@ int sdrhip_fftconv_process_dev(sdrhip_fftconv *h, const float *in_dev, size_t n_
     if (in_stride == 0) in_stride = n_in;
     if (out_stride == 0) out_stride = n_in;
     SDRHIP_REQUIRE(in_stride >= n_in && out_stride >= n_in, SDRHIP_E_SIZE, "stride smaller than n_in");
-    require_disjoint(in_dev, in_stride, n_in, 8, out_dev, out_stride, n_in, 8, (size_t)h->C);
-    h->launch(reinterpret_cast<const float2 *>(in_dev), n_in, in_stride, reinterpret_cast<float2 *>(out_dev), out_stride);
+    require_disjoint(in_dev, in_stride, n_in, 8, out_dev, out_stride, n_in, 8, (size_t)h->C * h->B);
+    h->launch(reinterpret_cast<const float2 *>(in_dev), n_in, in_stride, reinterpret_cast<float2 *>(out_dev), out_stride,
+              (size_t)h->C * out_stride);
   });
 }
 
@@ -628,10 +689,10 @@ int sdrhip_fftconv_process(sdrhip_fftconv *h, const float *in_host, size_t n_in,
     if (in_stride == 0) in_stride = n_in;
     if (out_stride == 0) out_stride = n_in;
     SDRHIP_REQUIRE(in_stride >= n_in && out_stride >= n_in, SDRHIP_E_SIZE, "stride smaller than n_in");
-    if (!h->stage_in.p) { h->stage_in.alloc((size_t)h->C * h->max_in); h->stage_out.alloc((size_t)h->C * h->max_in); }
+    if (!h->stage_in.p) { h->stage_in.alloc((size_t)h->C * h->max_in); h->stage_out.alloc((size_t)h->B * h->C * h->max_in); }
     copy_h2d_rows(h->ctx, h->stage_in.p, n_in * 8, in_host, in_stride * 8, n_in * 8, h->C);
-    h->launch(h->stage_in.p, n_in, n_in, h->stage_out.p, n_in);
-    copy_d2h_rows(h->ctx, out_host, out_stride * 8, h->stage_out.p, n_in * 8, n_in * 8, h->C);
+    h->launch(h->stage_in.p, n_in, n_in, h->stage_out.p, n_in, (size_t)h->C * n_in);
+    copy_d2h_rows(h->ctx, out_host, out_stride * 8, h->stage_out.p, n_in * 8, n_in * 8, (size_t)h->B * h->C);
     SDRHIP_CHECK_HIP(hipStreamSynchronize(h->ctx->stream));
   });
 }

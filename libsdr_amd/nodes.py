@@ -405,22 +405,31 @@ class SubSample(_Node):
 
 
 class FFTConv(_Node):
-    """K7 — FilterSink+FilterSource (mode OLA, kernel = 2N spectrum) or overlap-save with taps (mode OLS)."""
+    """K7 — FilterSink+FilterSource (mode OLA, kernel = 2N spectrum) or overlap-save with taps (mode OLS).
+    `kernels` may be a list of equally sized kernels: a filter bank behind one forward transform per block
+    (FilterNode); process() then returns [bands, channels, n, 2]."""
     _destroy = "sdrhip_fftconv_destroy"
 
     def __init__(self, ctx, mode, fft_size, kernel, channels=1, max_in=65536):
         super().__init__()
-        kernel = np.ascontiguousarray(kernel, np.float32).reshape(-1, 2)
-        self.ctx, self.mode, self.fft_size, self.channels = ctx, mode, fft_size, channels
-        check(abi.lib().sdrhip_fftconv_create(ctx.handle, mode, fft_size, kernel.ctypes.data_as(C.POINTER(C.c_float)),
-                                              kernel.shape[0], channels, max_in, C.byref(self._h)))
+        bank = isinstance(kernel, (list, tuple))
+        ks = [np.ascontiguousarray(k, np.float32).reshape(-1, 2) for k in (kernel if bank else [kernel])]
+        assert all(k.shape == ks[0].shape for k in ks)
+        self.ctx, self.mode, self.fft_size, self.channels, self.bands, self._bank = ctx, mode, fft_size, channels, len(ks), bank
+        allk = np.ascontiguousarray(np.stack(ks))
+        check(abi.lib().sdrhip_fftconv_create_bank(ctx.handle, mode, fft_size, allk.ctypes.data_as(C.POINTER(C.c_float)),
+                                                   ks[0].shape[0], len(ks), channels, max_in, C.byref(self._h)))
 
     def process(self, x):
         x = _as3(x, np.float32)
         n = x.shape[1]
-        out = np.zeros_like(x)
+        out = np.zeros((self.bands,) + x.shape, np.float32)
         check(abi.lib().sdrhip_fftconv_process(self._h, _ptr(x), n, n, _ptr(out), n))
-        return out
+        return out if self._bank else out[0]
+
+    def set_kernel(self, band, kernel):
+        kernel = np.ascontiguousarray(kernel, np.float32).reshape(-1, 2)
+        check(abi.lib().sdrhip_fftconv_set_kernel(self._h, band, kernel.ctypes.data_as(C.POINTER(C.c_float))))
 
     def process_dev(self, in_ptr, n, in_stride, out_ptr, out_stride):
         check(abi.lib().sdrhip_fftconv_process_dev(self._h, C.c_void_p(in_ptr), n, in_stride, C.c_void_p(out_ptr), out_stride))

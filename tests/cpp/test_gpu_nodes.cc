@@ -257,7 +257,9 @@ static void testFloatNodes() {
   Recorder<cf32> raw; gpu::FIRLowPass<cf32> fir(127, 100e3); gpu::SubSample<cf32> sub(size_t(8)); Recorder<cf32> out;
   gpu::FilterNode<float> bank(1024); Recorder<cf32> band;
   gen.connect(&raw, true); gen.connect(&fir, true); fir.connect(&sub, true); sub.connect(&out, true);
+  Recorder<cf32> band2;
   gen.connect(bank.sink(), true); bank.addFilter(50e3, 150e3)->connect(&band, true);
+  bank.addFilter(-350e3, -250e3)->connect(&band2, true);   // a second band behind the same forward transform
   for (int b = 0; b < 3; b++) gen.next();
   CHECK(out.data.size() == 3 * N / 8 && band.data.size() == 3 * N);
   std::vector<double> a(127); orc_fir_lowpass_design(127, 100e3, FS, a.data());
@@ -280,6 +282,19 @@ static void testFloatNodes() {
     for (size_t i = 0; i < 1024; i++) {
       const cf32 r(fo[2 * i], fo[2 * i + 1]);
       err = std::max(err, (double)std::abs(band.data[blk * 1024 + i] - r)); mx = std::max(mx, (double)std::abs(r));
+    }
+  }
+  CHECK(err / mx <= 1e-5);
+  orc_fftfilt_destroy(ff);
+  orc_fftfilt_design_h(1024, -350e3, -250e3, FS, h.data()); orc_fftfilt_design_K(1024, h.data(), K.data());
+  ff = orc_fftfilt_create(1024, K.data());
+  err = 0; mx = 0;
+  CHECK(band2.data.size() == 3 * N);
+  for (size_t blk = 0; blk < 3 * N / 1024 && band2.data.size() == 3 * N; blk++) {
+    orc_fftfilt_process(ff, (const float *)&raw.data[blk * 1024], fo.data());
+    for (size_t i = 0; i < 1024; i++) {
+      const cf32 r(fo[2 * i], fo[2 * i + 1]);
+      err = std::max(err, (double)std::abs(band2.data[blk * 1024 + i] - r)); mx = std::max(mx, (double)std::abs(r));
     }
   }
   CHECK(err / mx <= 1e-5);

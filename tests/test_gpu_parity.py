@@ -544,6 +544,36 @@ def test_fftconv_reference_mode_vs_oracle(ctx, golden, orc, N):
     assert np.abs(yc - closed).max() / np.abs(closed).max() <= RTOL
 
 
+@pytest.mark.parametrize("N", [1024, 8192])
+def test_fftconv_filter_bank(ctx, golden, orc, N):
+    """FilterNode's shape: several band kernels behind ONE forward transform per block (src/filternode.hh:81-88,257-270).
+    The bank's rows equal the single-band plans' bit for bit and the oracle within 1e-5; N = 8192 (FFT 16384) does not fit
+    the LDS twice and takes the per-band launches."""
+    bands = [(50e3, 150e3), (-400e3, -250e3), (-20e3, 20e3)]
+    Ks = [sa.design_fftfilt_spectrum(sa.design_fftfilt_kernel(N, lo, hi, FS)) for lo, hi in bands]
+    nblk = 4 if N == 1024 else 2
+    rng = np.random.default_rng(31)
+    x = (rng.standard_normal((2, nblk * N, 2)) * 0.3).astype(np.float32)
+    bank = sa.FFTConv(ctx, sa.FFTCONV_OLA, 2 * N, Ks, channels=2, max_in=nblk * N)
+    y = np.concatenate([bank.process(x[:, :N]), bank.process(x[:, N:])], axis=2)     # two calls: history carried
+    assert y.shape == (3, 2, nblk * N, 2)
+    for b, K in enumerate(Ks):
+        one = sa.FFTConv(ctx, sa.FFTCONV_OLA, 2 * N, K, channels=2, max_in=nblk * N)
+        assert np.array_equal(np.concatenate([one.process(x[:, :N]), one.process(x[:, N:])], axis=1), y[b])
+        flt = orc.FFTFilter(K)
+        ref = np.concatenate([flt.process(x[1, i * N:(i + 1) * N]) for i in range(nblk)])
+        assert rel_err(y[b, 1], ref) <= RTOL
+    # a band retuned between calls: from the second block on it equals a plan made with the new kernel from the start
+    # (overlap-save: history is INPUT, so one block of transient — see sdrhip.h)
+    K2 = sa.design_fftfilt_spectrum(sa.design_fftfilt_kernel(N, 100e3, 300e3, FS))
+    bank2 = sa.FFTConv(ctx, sa.FFTCONV_OLA, 2 * N, Ks, channels=2, max_in=nblk * N)
+    bank2.process(x[:, :N]); bank2.set_kernel(1, K2)
+    y2 = bank2.process(x[:, N:])
+    fresh = sa.FFTConv(ctx, sa.FFTCONV_OLA, 2 * N, [Ks[0], K2, Ks[2]], channels=2, max_in=nblk * N)
+    fresh.process(x[:, :N])
+    assert np.array_equal(y2, fresh.process(x[:, N:]))
+
+
 def test_fftconv_ols_4097_vs_reference_fir(ctx, golden):
     """BASELINE config 4: L=16384, 4097 real taps by overlap-save vs the reference's time-domain
     FIRLowPass<cf32>(4097) output (golden), streaming over 3 calls."""
