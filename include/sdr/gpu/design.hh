@@ -92,6 +92,16 @@ inline void freqShiftLutI16(int32_t *lut) {
   }
 }
 
+/** Rotation LUT of FreqShiftBase<int8_t> (Traits<int8_t>::shift = 8, compute type int16): trunc(2^8 exp(-2 pi i k/128)). */
+inline void freqShiftLutI8(int32_t *lut) {
+  for (size_t k = 0; k < kLutSize; k++) {
+    const std::complex<double> e = std::exp(std::complex<double>(0, -(2 * M_PI * k) / kLutSize));
+    const double s = double(1 << 8);
+    lut[2 * k] = int32_t(int16_t(s * e.real()));
+    lut[2 * k + 1] = int32_t(int16_t(s * e.imag()));
+  }
+}
+
 /** Phase increment per sample in 1/256 LUT steps. */
 inline uint32_t freqShiftIncrement(double shift, double sampleRate) {
   return uint32_t(size_t((kLutSize * (1 << 8) * std::abs(shift)) / sampleRate));

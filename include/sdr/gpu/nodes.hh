@@ -78,6 +78,7 @@ inline bool processOk(int rc, const char *what) {
 template <class T> struct TypeTag;
 template <> struct TypeTag<cs16> { enum { dtype = SDRHIP_T_CS16, fir = SDRHIP_FIR_CS16_EXACT }; typedef int16_t Real; };
 template <> struct TypeTag<cf32> { enum { dtype = SDRHIP_T_CF32, fir = SDRHIP_FIR_CF32 }; typedef float Real; };
+template <> struct TypeTag< std::complex<int8_t> > { enum { dtype = SDRHIP_T_CS8 }; typedef int8_t Real; };
 template <class S> struct RealTag;
 template <> struct RealTag<int16_t> { enum { dtype = SDRHIP_T_CS16 }; };
 template <> struct RealTag<float> { enum { dtype = SDRHIP_T_CF32 }; };
@@ -89,10 +90,18 @@ template <> struct RealTag<float> { enum { dtype = SDRHIP_T_CF32 }; };
 namespace detail {
 /** IQBaseBand on the int16 kernels; SIn = int16_t (complex<int16_t> in) or uint8_t (complex<uint8_t> in, with
  * AutoCast< complex<int16_t> > fused into the load: the cast -> baseband pair of examples/sdr_fm.cc:49-50). */
+/** Sample types per input scalar: int16_t and uint8_t (AutoCast fused) produce complex<int16_t>; int8_t is
+ * IQBaseBand<int8_t>, which produces complex<int8_t> (reference src/baseband.hh:22-31, src/sdr.hh:225-240). */
+template <class S> struct BbIo { typedef cs16 COut; enum { int8 = 0, cu8 = 0 }; };
+template <> struct BbIo<uint8_t> { typedef cs16 COut; enum { int8 = 0, cu8 = 1 }; };
+template <> struct BbIo<int8_t> { typedef std::complex<int8_t> COut; enum { int8 = 1, cu8 = 0 }; };
+
 template <class SIn>
 class IQBB16 : public Sink< std::complex<SIn> >, public Source {
 public:
   typedef std::complex<SIn> CIn;
+  typedef typename BbIo<SIn>::COut COut;
+  enum { kInt8 = BbIo<SIn>::int8, kCu8 = BbIo<SIn>::cu8 };
   IQBB16(double Fc, double width, size_t order, size_t sub_sample, double oFs = 0.0, int device = 0)
     : _Fc(Fc), _Ff(Fc), _shift(Fc), _Fs(0), _width(width), _order(std::max(size_t(1), order)), _sub_sample(sub_sample),
       _oFs(oFs), _sourceBs(0), _epilogue(SDRHIP_EPI_NONE), _device(device), _plan(0) {}
@@ -141,7 +150,7 @@ public:
 
   virtual void process(const Buffer<CIn> &buffer, bool allow_overwrite) {
     if (!_plan) return;
-    if (allow_overwrite && sizeof(CIn) == sizeof(cs16)) _process(buffer, Buffer<cs16>(buffer));   // in place needs equal sample sizes
+    if (allow_overwrite && sizeof(CIn) == sizeof(COut)) _process(buffer, Buffer<COut>(buffer));   // in place needs equal sample sizes
     else if (_buffer.isUnused()) _process(buffer, _buffer);
     // else: output buffer still in use downstream -> the input is dropped (src/baseband.hh:141-150)
   }
@@ -169,7 +178,7 @@ protected:
     _sub_sample = D;
     std::vector<int32_t> taps(2 * _order), lut(2 * design::kLutSize);
     design::iqbbTaps(_Ff, _width, _Fs, _order, taps.data());
-    design::freqShiftLutI16(lut.data());
+    if (kInt8) design::freqShiftLutI8(lut.data()); else design::freqShiftLutI16(lut.data());
     const uint32_t inc = design::freqShiftIncrement(_shift, double(_Fs));
     bool reuse = _plan && _planOrder == _order && _planD == D && _planBs == _sourceBs && _planEpi == _epilogue;
     if (reuse) {
@@ -186,15 +195,17 @@ protected:
     }
     if (!reuse) {
       if (_plan) { sdrhip_iqbb_i16_destroy(_plan); _plan = 0; }
-      configCheck(sdrhip_iqbb_i16_create(Device::get(_device), taps.data(), int(_order), lut.data(), inc, 0 > _shift,
-                                                 int(D), 1, _sourceBs, _epilogue, &_plan), "IQBaseBand");
-      if (sizeof(SIn) == 1) configCheck(sdrhip_iqbb_i16_set_input_format(_plan, SDRHIP_IN_CU8), "IQBaseBand");
+      if (kInt8) configCheck(sdrhip_iqbb_i8_create(Device::get(_device), taps.data(), int(_order), lut.data(), inc, 0 > _shift,
+                                                   int(D), 1, _sourceBs, _epilogue, &_plan), "IQBaseBand");
+      else configCheck(sdrhip_iqbb_i16_create(Device::get(_device), taps.data(), int(_order), lut.data(), inc, 0 > _shift,
+                                              int(D), 1, _sourceBs, _epilogue, &_plan), "IQBaseBand");
+      if (kCu8) configCheck(sdrhip_iqbb_i16_set_input_format(_plan, SDRHIP_IN_CU8), "IQBaseBand");
       _planOrder = _order; _planD = D; _planBs = _sourceBs; _planEpi = _epilogue;
     }
     size_t buffer_size = _sourceBs / D;
     if (_sourceBs % D) buffer_size += 1;
     _buffer.unref();
-    _buffer = Buffer<cs16>(buffer_size);
+    _buffer = Buffer<COut>(buffer_size);
 
     LogMessage msg(LOG_DEBUG);
     msg << "Configured gpu::IQBaseBand node:" << std::endl << " sample-rate " << _Fs << "Hz" << std::endl
@@ -204,14 +215,15 @@ protected:
     Logger::get().log(msg);
 
     const double oRate = double(size_t(_Fs) / D);   // the reference divides int32 by size_t (src/baseband.hh:192-193)
-    if (_epilogue == SDRHIP_EPI_NONE) this->setConfig(Config(Config::typeId<cs16>(), oRate, buffer_size, 1));
+    if (_epilogue == SDRHIP_EPI_NONE) this->setConfig(Config(Config::typeId<COut>(), oRate, buffer_size, 1));
     else this->setConfig(Config(Config::typeId<int16_t>(), oRate, buffer_size, 1));
   }
 
-  void _process(const Buffer<CIn> &in, const Buffer<cs16> &out) {
+  void _process(const Buffer<CIn> &in, const Buffer<COut> &out) {
     size_t n = 0;
+    // (out_stride in output elements: the demodulators' int16 fits sizeof(COut) / 2 times into a complex output sample)
     if (!processOk(sdrhip_iqbb_i16_process(_plan, reinterpret_cast<const int16_t *>(in.data()), in.size(), 0,
-                                                   out.data(), out.size() * (_epilogue == SDRHIP_EPI_NONE ? 1 : 2), &n),
+                                                   out.data(), out.size() * (_epilogue == SDRHIP_EPI_NONE ? 1 : sizeof(COut) / 2), &n),
                            "gpu::IQBaseBand"))
       return;
     if (_epilogue == SDRHIP_EPI_NONE) this->send(out.head(n), true);
@@ -229,7 +241,7 @@ protected:
   sdrhip_iqbb_i16 *_plan;
   size_t _planOrder = 0, _planD = 0, _planBs = 0;   // geometry the device plan was made for
   int _planEpi = 0;
-  Buffer<cs16> _buffer;
+  Buffer<COut> _buffer;
 };
 }  // namespace detail
 
@@ -242,6 +254,16 @@ public:
     : detail::IQBB16<int16_t>(Fc, width, order, sub_sample, oFs, device) {}
   IQBaseBand(double Fc, double Ff, double width, size_t order, size_t sub_sample, double oFs = 0.0, int device = 0)
     : detail::IQBB16<int16_t>(Fc, Ff, width, order, sub_sample, oFs, device) {}
+};
+/** Drop-in for sdr::IQBaseBand<int8_t>, the baseband of the reference's documentation example (src/sdr.hh:225-240):
+ * sinks and sources complex<int8_t>. */
+template <>
+class IQBaseBand<int8_t> : public detail::IQBB16<int8_t> {
+public:
+  IQBaseBand(double Fc, double width, size_t order, size_t sub_sample, double oFs = 0.0, int device = 0)
+    : detail::IQBB16<int8_t>(Fc, width, order, sub_sample, oFs, device) {}
+  IQBaseBand(double Fc, double Ff, double width, size_t order, size_t sub_sample, double oFs = 0.0, int device = 0)
+    : detail::IQBB16<int8_t>(Fc, Ff, width, order, sub_sample, oFs, device) {}
 };
 /** AutoCast< complex<int16_t> > + IQBaseBand<int16_t> in one node: sinks complex<uint8_t> (RTL-SDR bytes). */
 template <>
@@ -440,6 +462,13 @@ template <>
 class FMDemod<int16_t, int16_t> : public detail::DemodBase<cs16, int16_t> {
 public:
   explicit FMDemod(int device = 0) : detail::DemodBase<cs16, int16_t>(SDRHIP_EPI_FM, "FMDemod", device) {}
+};
+/** FMDemod<int8_t,int16_t> (reference src/demod.hh:173-262 with src/math.hh:12-21): complex<int8_t> in, int16_t out,
+ * in place when allowed (an output element covers exactly its input sample). */
+template <>
+class FMDemod<int8_t, int16_t> : public detail::DemodBase<std::complex<int8_t>, int16_t> {
+public:
+  explicit FMDemod(int device = 0) : detail::DemodBase<std::complex<int8_t>, int16_t>(SDRHIP_EPI_FM, "FMDemod", device) {}
 };
 template <class Scalar>
 class AMDemod : public detail::DemodBase<std::complex<Scalar>, Scalar> {

@@ -169,6 +169,17 @@ int sdrhip_iqbb_i16_set_input_format(sdrhip_iqbb_i16 *h, int format);
 int sdrhip_bb_i16_create(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32_t *lut,
                          uint32_t lut_inc, int negative, int decim, int channels, size_t max_in,
                          int epilogue, sdrhip_iqbb_i16 **out);
+/* "next" row: IQBaseBand<int8_t>, the baseband of the reference's documentation example
+ * (src/sdr.hh:225-240: IQBaseBand<int8_t> -> FMDemod<int8_t,int16_t>). Same handle type and calls. Input rows hold
+ * complex<int8_t> (2 B per sample). The filter, window sum and division are the int16 node's (the class computes in
+ * int32 for every Scalar, src/baseband.hh:28-31); the frequency shift it inherits from FreqShiftBase<int8_t> computes
+ * in complex<int16_t>: the FIR value wraps to int16 at the call, `lut` is sdrhip_design_freqshift_lut_i8 (2^8 scale),
+ * the product wraps to int16 and is shifted by 8 (src/freqshift.hh:18-22,58-74, src/traits.cc:11). Output:
+ * complex<int8_t> (2 B; EPI_NONE) or, with EPI_FM, FMDemod<int8_t,int16_t>'s int16 run in place (out[0] of a call =
+ * the two bytes of its first complex<int8_t> output). VALU kernel. */
+int sdrhip_design_freqshift_lut_i8(int32_t *lut);
+int sdrhip_iqbb_i8_create(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32_t *lut, uint32_t lut_inc,
+                          int negative, int decim, int channels, size_t max_in, int epilogue, sdrhip_iqbb_i16 **out);
 /* Mid-stream retuning with the reference's semantics (src/baseband.hh:82-112), for plans of either create call:
  *   set_taps   setFilterFrequency / setFilterWidth -> _update_filter_kernel(): only the kernel changes (same order);
  *              FIR history, decimator phase and partial sum, LUT phase and FM angle go on as they are.
@@ -204,7 +215,7 @@ int sdrhip_fir_reset(sdrhip_fir *h); /* ring zeroed, as FIRFilter::config does (
 int sdrhip_fir_destroy(sdrhip_fir *h);
 
 /* ---- K4/K5: stand-alone demodulators ------------------------------------------------------ */
-enum { SDRHIP_T_CS16 = 0, SDRHIP_T_CF32 = 1 };
+enum { SDRHIP_T_CS16 = 0, SDRHIP_T_CF32 = 1, SDRHIP_T_CS8 = 2 /* complex<int8_t>: FMDemod<int8_t,int16_t> only */ };
 /* kind = SDRHIP_EPI_FM|AM|USB, dtype = SDRHIP_T_*; FM exists for cs16 only (the reference's
  * fast_atan2 has no float form, src/math.hh:9-40). inplace_fm0: 1 -> out[0] = in[0].real() per call
  * (in-place chain), 0 -> out[0] left untouched (the reference leaves it uninitialised). */

@@ -18,7 +18,7 @@ HEADER = os.path.join(ROOT, "include", "sdrhip.h")
 OK, E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_UNSUPPORTED, E_SIZE = 0, -1, -2, -3, -4, -5, -6
 EPI_NONE, EPI_FM, EPI_AM, EPI_USB = 0, 1, 2, 3
 FIR_CS16_EXACT, FIR_CF32 = 0, 1
-T_CS16, T_CF32 = 0, 1
+T_CS16, T_CF32, T_CS8 = 0, 1, 2
 IN_CS16, IN_CU8 = 0, 1
 FFTCONV_OLA, FFTCONV_OLS = 0, 1
 
@@ -82,6 +82,8 @@ def lib():
             "sdrhip_bb_i16_create": (C.c_int, [vp, i32p, C.c_int, i32p, C.c_uint32, C.c_int, C.c_int, C.c_int,
                                                sz, C.c_int, pvp]),
             "sdrhip_iqbb_i16_path": (C.c_int, [vp, C.POINTER(C.c_int)]),
+            "sdrhip_design_freqshift_lut_i8": (C.c_int, [i32p]),
+            "sdrhip_iqbb_i8_create": (C.c_int, [vp, i32p, C.c_int, i32p, C.c_uint32, C.c_int, C.c_int, C.c_int, sz, C.c_int, pvp]),
             "sdrhip_iqbb_i16_kernel_names": (C.c_int, [vp, C.c_char_p, sz]),
             "sdrhip_iqbb_i16_set_taps": (C.c_int, [vp, i32p]),
             "sdrhip_iqbb_i16_set_shift": (C.c_int, [vp, C.c_uint32, C.c_int]),

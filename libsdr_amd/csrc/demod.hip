@@ -94,6 +94,25 @@ __global__ __launch_bounds__(TPB) void demod_cs16_kernel(const DemodArgs a) {
   }
 }
 
+// complex<int8_t> -> int16: FMDemod<int8_t,int16_t> (reference src/demod.hh:242-254 with fast_atan2<int8_t,int16_t>,
+// src/math.hh:12-21 — the formula of the int16 form on int8 inputs). In place an output element (2 B) covers exactly its
+// input sample (2 B): out[0] of a call, which FMDemod never writes, is the two bytes of in[0].
+__global__ __launch_bounds__(TPB) void demod_cs8_fm_kernel(const DemodArgs a) {
+  const int c = blockIdx.y;
+  const uint16_t *in = reinterpret_cast<const uint16_t *>(a.in) + (long)c * a.in_stride;
+  short *out = reinterpret_cast<short *>(a.out) + (long)c * a.out_stride;
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < a.N; i += gridDim.x * TPB) {
+    const uint32_t x = in[i];
+    const int phi = fm_phi((int)(signed char)(x & 0xffu), (int)(signed char)(x >> 8));
+    short o;
+    if (i == 0) o = (short)x;
+    else if (i == 1) o = (short)((int)a.fm_old[c] - phi);
+    else { const uint32_t p = in[i - 1]; o = (short)(fm_phi((int)(signed char)(p & 0xffu), (int)(signed char)(p >> 8)) - phi); }
+    if (i == a.N - 1 && a.N >= 2) a.fm_new[c] = (short)phi;
+    if (!(i == 0 && !a.fm0)) out[i] = o;
+  }
+}
+
 // cf32 -> float (AM, USB)
 __global__ __launch_bounds__(TPB) void demod_cf32_kernel(const DemodArgs a) {
   const int c = blockIdx.y;
@@ -234,8 +253,8 @@ struct sdrhip_demod {
   size_t max_in = 0;
   DevBuf<short> fm[2];
   DevBuf<uint8_t> stage_in, stage_out;
-  size_t in_elem() const { return dtype == SDRHIP_T_CS16 ? 4 : 8; }
-  size_t out_elem() const { return dtype == SDRHIP_T_CS16 ? 2 : 4; }
+  size_t in_elem() const { return dtype == SDRHIP_T_CS16 ? 4 : dtype == SDRHIP_T_CS8 ? 2 : 8; }
+  size_t out_elem() const { return dtype == SDRHIP_T_CF32 ? 4 : 2; }
   void launch(const void *in_dev, size_t N, size_t in_stride, void *out_dev, size_t out_stride) {
     ctx->use();
     if (N == 0) return;   // FMDemod::process returns without sending on an empty buffer (src/demod.hh:231)
@@ -246,6 +265,7 @@ struct sdrhip_demod {
     const unsigned bx = (unsigned)std::min<size_t>(ceil_div(N, (size_t)4 * TPB), 4096);
     dim3 grid(bx, C), block(TPB);
     if (dtype == SDRHIP_T_CS16) hipLaunchKernelGGL(demod_cs16_kernel, grid, block, 0, ctx->stream, a);
+    else if (dtype == SDRHIP_T_CS8) hipLaunchKernelGGL(demod_cs8_fm_kernel, grid, block, 0, ctx->stream, a);
     else hipLaunchKernelGGL(demod_cf32_kernel, grid, block, 0, ctx->stream, a);
     SDRHIP_CHECK_HIP(hipGetLastError());
     if (kind == SDRHIP_EPI_FM && N >= 2) par_fm ^= 1;
@@ -309,9 +329,11 @@ int sdrhip_demod_create(sdrhip_ctx *ctx, int kind, int dtype, int channels, size
     SDRHIP_REQUIRE(ctx && out, SDRHIP_E_INVALID, "NULL argument");
     *out = nullptr;
     SDRHIP_REQUIRE(kind == SDRHIP_EPI_FM || kind == SDRHIP_EPI_AM || kind == SDRHIP_EPI_USB, SDRHIP_E_INVALID, "bad kind %d", kind);
-    SDRHIP_REQUIRE(dtype == SDRHIP_T_CS16 || dtype == SDRHIP_T_CF32, SDRHIP_E_INVALID, "bad dtype %d", dtype);
+    SDRHIP_REQUIRE(dtype == SDRHIP_T_CS16 || dtype == SDRHIP_T_CF32 || dtype == SDRHIP_T_CS8, SDRHIP_E_INVALID, "bad dtype %d", dtype);
     SDRHIP_REQUIRE(!(kind == SDRHIP_EPI_FM && dtype == SDRHIP_T_CF32), SDRHIP_E_UNSUPPORTED,
                    "FMDemod<float> does not exist in the reference (fast_atan2 has no float form)");
+    SDRHIP_REQUIRE(!(dtype == SDRHIP_T_CS8 && kind != SDRHIP_EPI_FM), SDRHIP_E_UNSUPPORTED,
+                   "complex<int8_t> input: only FMDemod<int8_t,int16_t> is implemented");
     SDRHIP_REQUIRE(channels >= 1 && channels <= 65535, SDRHIP_E_INVALID, "channels %d outside [1,65535]", channels);
     SDRHIP_REQUIRE(max_in >= 1 && max_in < (size_t(1) << 30), SDRHIP_E_SIZE, "max_in %zu outside [1,2^30)", max_in);
     ctx->use();

@@ -36,6 +36,13 @@ int sdrhip_design_freqshift_lut_i16(int32_t *lut) {
   });
 }
 
+int sdrhip_design_freqshift_lut_i8(int32_t *lut) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(lut, SDRHIP_E_INVALID, "lut is NULL");
+    dz::freqShiftLutI8(lut);
+  });
+}
+
 int sdrhip_design_freqshift_inc(double shift, double sample_rate, uint32_t *inc) {
   return guarded([&] {
     SDRHIP_REQUIRE(inc && sample_rate != 0, SDRHIP_E_INVALID, "bad argument");

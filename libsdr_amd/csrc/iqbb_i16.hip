@@ -38,6 +38,7 @@ struct IqbbArgs {
   const uint32_t *in; long in_stride;            // cs16 packed as one dword per sample (or cu8: one ushort, in_cu8)
   int in_cu8;                                    // input is complex<uint8> and AutoCast<cs16> is applied on load
   int in_real;                                   // real-input BaseBand<int16_t>: one int16 per sample, taps are raw (Kr, Ki) int32
+  int i8;                                        // IQBaseBand<int8_t> (VALU kernel only): complex<int8> in and out, the frequency shift in int16 (see rotate)
   const uint32_t *hist_old; uint32_t *hist_new;  // C x HH samples preceding the call
   const int2 *acc_old; int2 *acc_new;            // partial box sum of the open group
   const short *fm_old; short *fm_new;            // FMDemod::_last_value
@@ -67,6 +68,10 @@ __device__ __forceinline__ uint32_t cast_cu8(uint32_t u16) {
 __device__ __forceinline__ uint32_t raw_x(const IqbbArgs &a, int c, long rel) {   // 0 <= rel < N
   if (a.in_cu8) return cast_cu8(reinterpret_cast<const uint16_t *>(a.in)[(long)c * a.in_stride + rel]);
   if (a.in_real) return (uint32_t)(int)reinterpret_cast<const short *>(a.in)[(long)c * a.in_stride + rel];   // sign-extended
+  if (a.i8) {   // complex<int8_t>: both bytes sign-extended to the packed (re, im) int16 pair the FIR works on
+    const uint32_t u = reinterpret_cast<const uint16_t *>(a.in)[(long)c * a.in_stride + rel];
+    return ((uint32_t)(int)(signed char)(u & 0xffu) & 0xffffu) | ((uint32_t)(int)(signed char)(u >> 8) << 16);
+  }
   return a.in[(long)c * a.in_stride + rel];
 }
 __device__ __forceinline__ uint32_t load_x(const IqbbArgs &a, int c, int rel) {
@@ -86,6 +91,20 @@ __device__ __forceinline__ int mulw(int a, int b) { return (int)((unsigned)a * (
 // the reference's is <= 2^16) and r = S>>14 lies in [-2^17, 2^17), so v_mul_i32_i24's low 32 bits equal
 // the reference's wrapping 32-bit products.
 __device__ __forceinline__ int2 rotate(const IqbbArgs &a, const int2 *lut_s, int2 r, uint32_t n_lo) {
+  if (a.i8) {
+    // FreqShiftBase<int8_t> computes in complex<int16_t> (src/freqshift.hh:18-22, src/traits.hh:58-73): the FIR value
+    // is converted (wrapped) to int16 at the call, the LUT is 2^8 * exp(..), the product wraps to int16 and is shifted
+    // by Traits<int8_t>::shift = 8 (src/freqshift.hh:58-74, src/traits.cc:11)
+    r.x = (short)r.x; r.y = (short)r.y;
+    if (a.inc == 0) return r;
+    uint32_t idx = (__umul24(n_lo & 32767u, a.inc & 32767u) & 32767u) >> 8;
+    if (a.negative) idx = 127u - idx;
+    const int2 L = lut_s[idx];
+    int2 v;
+    v.x = (int)(short)(mulw(L.x, r.x) - mulw(L.y, r.y)) >> 8;
+    v.y = (int)(short)(mulw(L.x, r.y) + mulw(L.y, r.x)) >> 8;
+    return v;
+  }
   if (a.inc == 0) return r;
   uint32_t idx = (__umul24(n_lo & 32767u, a.inc & 32767u) & 32767u) >> 8;
   if (a.negative) idx = 127u - idx;
@@ -156,7 +175,8 @@ __device__ __forceinline__ void finalize_group(const IqbbArgs &a, int c, const i
   }
   const bool emits = q < a.n_out;
   if (emits) {
-    const int yr = (short)box_div(s.x, D), yi = (short)box_div(s.y, D);
+    int yr = (short)box_div(s.x, D), yi = (short)box_div(s.y, D);
+    if (a.i8) { yr = (signed char)yr; yi = (signed char)yi; }   // the int8 node's output type (kept sign-extended in ybuf)
     ybuf[ql] = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
     if (a.epilogue == SDRHIP_EPI_FM) reinterpret_cast<int *>(ybuf + a.CGr)[ql] = fm_phi(yr, yi);   // angle cache
   }
@@ -172,7 +192,8 @@ __device__ __forceinline__ void epilogue_and_roll(const IqbbArgs &a, int c, int 
     const uint32_t y = ybuf[ql];
     const int yr = (short)(y & 0xffffu), yi = (short)(y >> 16);
     if (a.epilogue == SDRHIP_EPI_NONE) {
-      reinterpret_cast<uint32_t *>(a.out)[(long)c * a.out_stride + j] = y;
+      if (a.i8) reinterpret_cast<uint16_t *>(a.out)[(long)c * a.out_stride + j] = (uint16_t)((yr & 0xff) | ((yi & 0xff) << 8));   // complex<int8_t>
+      else reinterpret_cast<uint32_t *>(a.out)[(long)c * a.out_stride + j] = y;
     } else {
       short o;
       if (a.epilogue == SDRHIP_EPI_AM) o = am_i16(yr, yi);
@@ -180,7 +201,8 @@ __device__ __forceinline__ void epilogue_and_roll(const IqbbArgs &a, int c, int 
       else {
         const int *phib = reinterpret_cast<const int *>(ybuf + a.CGr);
         const int phi = phib[ql];
-        if (j == 0) o = (short)yr;             // index 0 is never written by FMDemod (in place)
+        if (j == 0) o = a.i8 ? (short)((yr & 0xff) | ((yi & 0xff) << 8))   // FMDemod<int8_t,int16_t> in place: out[0] = the 2 bytes of in[0]
+                             : (short)yr;             // index 0 is never written by FMDemod (in place)
         else o = (short)((j == 1 ? (int)a.fm_old[c] : phib[ql - 1]) - phi);   // y[0] is never looked at: the
                                                                               // previous call's last angle
         if (j == a.n_out - 1 && a.n_out >= 2) a.fm_new[c] = (short)phi;
@@ -1577,7 +1599,7 @@ struct sdrhip_iqbb_i16 {
   bool use_dma = true;   // path 1, cs16 input: LDS-DMA fed kernel (SDRHIP_IQBB_DMA=0: the register-staged one, tuning)
   bool use_hot = true;   // ... with the hot kernel for the interior tiles (SDRHIP_IQBB_HOT=0: general kernel only, tuning/tests)
   int hot_range = -1;    // which compile-time high-plane K-step range of the hot kernel covers ah_mask (-1: none)
-  int in_cu8 = 0, real = 0;
+  int in_cu8 = 0, real = 0, i8 = 0;   // input kinds: complex<uint8> with AutoCast, real int16 (BaseBand), complex<int8> (IQBaseBand<int8_t>)
   int path = 0, S = 0, cre = 0, cim = 0;   // path 1 = int8-MFMA formulation with S K-steps
   unsigned ah_mask = 0;
   DevBuf<v4i> tapfrag;
@@ -1664,7 +1686,8 @@ struct sdrhip_iqbb_i16 {
     g.extra0 = (n0 == 0 && shift1) ? 1 : 0;
     return g;
   }
-  size_t out_elem_bytes() const { return epi == SDRHIP_EPI_NONE ? 4 : 2; }
+  size_t out_elem_bytes() const { return epi == SDRHIP_EPI_NONE ? (i8 ? 2 : 4) : 2; }
+  size_t in_elem_bytes() const { return (in_cu8 || real || i8) ? 2 : 4; }
 
   void launch(const uint32_t *in_dev, size_t N, size_t in_stride, void *out_dev, size_t out_stride, size_t *n_out) {
     ctx->use();
@@ -1672,7 +1695,7 @@ struct sdrhip_iqbb_i16 {
     const Geometry g = geometry(N);
     SDRHIP_REQUIRE(out_stride >= (size_t)g.n_out, SDRHIP_E_SIZE, "out_stride %zu < outputs %d", out_stride, g.n_out);
     IqbbArgs a;
-    a.in = in_dev; a.in_stride = (long)in_stride; a.in_cu8 = in_cu8; a.in_real = real;
+    a.in = in_dev; a.in_stride = (long)in_stride; a.in_cu8 = in_cu8; a.in_real = real; a.i8 = i8;
     a.hist_old = hist[par].p; a.hist_new = hist[par ^ 1].p; a.HH = HH;
     a.acc_old = acc[par].p; a.acc_new = acc[par ^ 1].p;
     const bool fm_flip = (epi == SDRHIP_EPI_FM && g.n_out >= 2);
@@ -1807,7 +1830,7 @@ namespace {
 
 int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32_t *lut, uint32_t lut_inc,
                     int negative, int decim, int channels, size_t max_in, int epilogue, bool real,
-                    sdrhip_iqbb_i16 **out) {
+                    sdrhip_iqbb_i16 **out, bool i8 = false) {
   return guarded([&] {
     SDRHIP_REQUIRE(ctx && taps && lut && out, SDRHIP_E_INVALID, "NULL argument");
     *out = nullptr;
@@ -1831,9 +1854,11 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
     sdrhip_iqbb_i16 *h = new sdrhip_iqbb_i16;
     try {
       h->ctx = ctx; h->order = order; h->D = decim; h->C = channels; h->epi = epilogue;
-      h->negative = negative ? 1 : 0; h->inc = lut_inc; h->max_in = max_in; h->real = real ? 1 : 0;
+      h->negative = negative ? 1 : 0; h->inc = lut_inc; h->max_in = max_in; h->real = real ? 1 : 0; h->i8 = i8 ? 1 : 0;
+      SDRHIP_REQUIRE(!i8 || epilogue == SDRHIP_EPI_NONE || epilogue == SDRHIP_EPI_FM, SDRHIP_E_UNSUPPORTED,
+                     "the int8 chain is IQBaseBand<int8_t> (-> FMDemod<int8_t,int16_t>): epilogue NONE or FM");
       // path: the int8-MFMA formulations need D == 8, order <= 257 (32x32x32) / 153 (16x16x64) and tap high bytes that fit int8
-      bool mfma_ok = !real && (decim == R) && (order <= 257);
+      bool mfma_ok = !real && !i8 && (decim == R) && (order <= 257);
       auto high_byte = [](int v) { const int al = ((v + 128) & 255) - 128; return (v - al) >> 8; };
       for (int i = 0; i < 2 * order && mfma_ok; i++)   // both v and -v are packed (Kr, -Ki / Ki, Kr)
         if (high_byte(taps[i]) > 127 || high_byte(-taps[i]) > 127) mfma_ok = false;
@@ -1841,14 +1866,14 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
       { const char *d = getenv("SDRHIP_IQBB_HOT"); if (d && d[0] == '0') h->use_hot = false; }
       const char *force = getenv("SDRHIP_IQBB_PATH");   // "valu" / "mfma" / "mfma16": test hook
       if (force && !strcmp(force, "valu")) mfma_ok = false;
-      bool mfma16_ok = !real && (decim == R) && (order <= 153);
+      bool mfma16_ok = !real && !i8 && (decim == R) && (order <= 153);
       for (int i = 0; i < 2 * order && mfma16_ok; i++)
         if (high_byte(taps[i]) > 127 || high_byte(-taps[i]) > 127) mfma16_ok = false;
       if (force && !strcmp(force, "valu")) mfma16_ok = false;
       h->path = mfma_ok ? 1 : (mfma16_ok ? 2 : 0);   // 32x32x32 measured 4 % faster than 16x16x64 at 127 taps
       // path 3: the same matrix part for any decimation, windows summed through LDS (measured ahead of the VALU
       // kernel at every order tried, 9 ... 257 taps)
-      bool mfmag_ok = !real && decim != R && order <= 257 && TI / decim - ovl >= 1;
+      bool mfmag_ok = !real && !i8 && decim != R && order <= 257 && TI / decim - ovl >= 1;
       for (int i = 0; i < 2 * order && mfmag_ok; i++)
         if (high_byte(taps[i]) > 127 || high_byte(-taps[i]) > 127) mfmag_ok = false;
       if (force && !strcmp(force, "valu")) mfmag_ok = false;
@@ -1917,6 +1942,12 @@ int sdrhip_bb_i16_create(sdrhip_ctx *ctx, const int32_t *taps, int order, const 
   return create_baseband(ctx, taps, order, lut, lut_inc, negative, decim, channels, max_in, epilogue, true, out);
 }
 
+int sdrhip_iqbb_i8_create(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32_t *lut, uint32_t lut_inc,
+                          int negative, int decim, int channels, size_t max_in, int epilogue,
+                          sdrhip_iqbb_i16 **out) {
+  return create_baseband(ctx, taps, order, lut, lut_inc, negative, decim, channels, max_in, epilogue, false, out, true);
+}
+
 int sdrhip_iqbb_i16_path(sdrhip_iqbb_i16 *h, int *path) {
   return guarded([&] {
     SDRHIP_REQUIRE(h && path, SDRHIP_E_INVALID, "NULL argument");
@@ -1954,8 +1985,8 @@ int sdrhip_iqbb_i16_process_dev(sdrhip_iqbb_i16 *h, const int16_t *in_dev, size_
     if (in_stride == 0) in_stride = n_in;
     SDRHIP_REQUIRE(in_stride >= n_in, SDRHIP_E_SIZE, "in_stride %zu < n_in %zu", in_stride, n_in);
     if (out_stride == 0) out_stride = (size_t)h->geometry(n_in).n_out;
-    require_disjoint(in_dev, in_stride, n_in, (h->in_cu8 || h->real) ? 2 : 4, out_dev, out_stride, (size_t)h->geometry(n_in).n_out,
-                     h->epi == SDRHIP_EPI_NONE ? 4 : 2, (size_t)h->C);
+    require_disjoint(in_dev, in_stride, n_in, h->in_elem_bytes(), out_dev, out_stride, (size_t)h->geometry(n_in).n_out,
+                     h->out_elem_bytes(), (size_t)h->C);
     h->launch(reinterpret_cast<const uint32_t *>(in_dev), n_in, in_stride, out_dev, out_stride, n_out);
   });
 }
@@ -1976,7 +2007,7 @@ int sdrhip_iqbb_i16_process(sdrhip_iqbb_i16 *h, const int16_t *in_host, size_t n
       h->stage_in.alloc((size_t)h->C * h->max_in);
       h->stage_out.alloc((size_t)h->C * h->max_out);
     }
-    const size_t ib = (h->in_cu8 || h->real) ? 2 : 4;
+    const size_t ib = h->in_elem_bytes();
     copy_h2d_rows(h->ctx, h->stage_in.p, n_in * ib, in_host, in_stride * ib, n_in * ib, h->C);
     const size_t eb = h->out_elem_bytes();
     size_t produced = 0;
@@ -1991,7 +2022,7 @@ int sdrhip_iqbb_i16_set_input_format(sdrhip_iqbb_i16 *h, int format) {
   return guarded([&] {
     SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
     SDRHIP_REQUIRE(format == SDRHIP_IN_CS16 || format == SDRHIP_IN_CU8, SDRHIP_E_INVALID, "bad input format %d", format);
-    SDRHIP_REQUIRE(!h->real, SDRHIP_E_INVALID, "the real-input baseband takes int16 samples only");
+    SDRHIP_REQUIRE(!h->real && !h->i8, SDRHIP_E_INVALID, "the real-input and the int8 baseband take their own sample type only");
     SDRHIP_REQUIRE(h->n0 == 0, SDRHIP_E_INVALID, "the input format can only change before the first buffer / after a reset");
     h->in_cu8 = format == SDRHIP_IN_CU8;
   });

@@ -282,6 +282,37 @@ class BaseBandI16(IQBaseBandI16):
         return out
 
 
+def design_freqshift_lut_i8():
+    t = np.zeros((128, 2), np.int32)
+    check(abi.lib().sdrhip_design_freqshift_lut_i8(t.ctypes.data_as(C.POINTER(C.c_int32))))
+    return t
+
+
+class IQBaseBandI8(IQBaseBandI16):
+    """IQBaseBand<int8_t> (the documentation example's baseband, reference src/sdr.hh:225-240): complex<int8> in,
+    complex<int8> out — or, with EPI_FM, FMDemod<int8_t,int16_t>'s int16. Same handle type as IQBaseBandI16."""
+
+    def __init__(self, ctx, taps, lut, lut_inc, negative, decim, channels=1, max_in=65536, epilogue=EPI_NONE):
+        _Node.__init__(self)
+        taps = np.ascontiguousarray(taps, np.int32).reshape(-1, 2)
+        lut = np.ascontiguousarray(lut, np.int32).reshape(128, 2)
+        self.ctx, self.channels, self.decim, self.epilogue, self.max_in = ctx, channels, decim, epilogue, max_in
+        check(abi.lib().sdrhip_iqbb_i8_create(ctx.handle, taps.ctypes.data_as(C.POINTER(C.c_int32)), taps.shape[0],
+                                              lut.ctypes.data_as(C.POINTER(C.c_int32)), lut_inc, int(bool(negative)),
+                                              decim, channels, max_in, epilogue, C.byref(self._h)))
+
+    def process(self, x):
+        x = _as3(x, np.int8)
+        assert x.shape[0] == self.channels
+        n_in = x.shape[1]
+        no = self.out_count(n_in)
+        out = np.zeros((self.channels, no, 2), np.int8) if self.epilogue == EPI_NONE else np.zeros((self.channels, no), np.int16)
+        got = C.c_size_t(0)
+        check(abi.lib().sdrhip_iqbb_i16_process(self._h, _ptr(x), n_in, n_in, _ptr(out), no, C.byref(got)))
+        assert got.value == no
+        return out
+
+
 class FIR(_Node):
     """K2/K3 — FIRFilter<complex<int16>> exact / FIRFilter<complex<float>> (+ folded SubSample, + demod)."""
     _destroy = "sdrhip_fir_destroy"
@@ -329,11 +360,11 @@ class Demod(_Node):
         check(abi.lib().sdrhip_demod_create(ctx.handle, kind, dtype, channels, max_in, int(inplace_fm0), C.byref(self._h)))
 
     def process(self, x, out=None):
-        it = np.int16 if self.dtype == T_CS16 else np.float32
+        it = np.int16 if self.dtype == T_CS16 else np.int8 if self.dtype == abi.T_CS8 else np.float32
         x = _as3(x, it)
         n = x.shape[1]
         if out is None:
-            out = np.zeros((self.channels, n), it)
+            out = np.zeros((self.channels, n), np.float32 if self.dtype == T_CF32 else np.int16)
         check(abi.lib().sdrhip_demod_process(self._h, _ptr(x), n, n, _ptr(out), n))
         return out
 

@@ -45,6 +45,11 @@ def lib():
             "orc_iqbb_i16_create": (vp, [i32p, C.c_int, i32p, C.c_uint32, C.c_int, C.c_int]),
             "orc_iqbb_i16_process": (C.c_size_t, [vp, i16p, C.c_size_t, i16p]),
             "orc_iqbb_i16_reset": (None, [vp]),
+            "orc_freqshift_lut_i8": (None, [C.POINTER(C.c_int32)]),
+            "orc_iqbb_i8_create": (vp, [C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32), C.c_uint32, C.c_int, C.c_int]),
+            "orc_iqbb_i8_process": (C.c_size_t, [vp, C.POINTER(C.c_int8), C.c_size_t, C.POINTER(C.c_int8)]),
+            "orc_iqbb_i8_destroy": (None, [vp]),
+            "orc_fm_i8": (None, [C.POINTER(C.c_int8), C.c_size_t, C.POINTER(C.c_int16), C.POINTER(C.c_int16)]),
             "orc_iqbb_i16_set_taps": (None, [vp, C.POINTER(C.c_int32)]),
             "orc_iqbb_i16_set_shift": (None, [vp, C.c_uint32, C.c_int]),
             "orc_iqbb_i16_destroy": (None, [vp]),
@@ -184,6 +189,47 @@ class IQBaseBandI16:
         if self._h:
             lib().orc_iqbb_i16_destroy(self._h)
             self._h = None
+
+
+def freqshift_lut_i8():
+    t = np.zeros(256, np.int32)
+    lib().orc_freqshift_lut_i8(_p(t, C.c_int32))
+    return t.reshape(128, 2)
+
+
+class IQBaseBandI8:
+    """IQBaseBand<int8_t> (compute type int16): complex<int8> in, complex<int8> out."""
+
+    def __init__(self, taps, lut, lut_inc, negative, decim):
+        taps = np.ascontiguousarray(taps, np.int32).reshape(-1, 2)
+        lut = np.ascontiguousarray(lut, np.int32).reshape(128, 2)
+        self.order, self.decim = taps.shape[0], decim
+        self._h = lib().orc_iqbb_i8_create(_p(taps, C.c_int32), self.order, _p(lut, C.c_int32), lut_inc, int(negative), decim)
+
+    def process(self, x):
+        x = np.ascontiguousarray(x, np.int8).reshape(-1, 2)
+        out = np.zeros((x.shape[0] // max(self.decim, 1) + 2, 2), np.int8)
+        n = lib().orc_iqbb_i8_process(self._h, _p(x, C.c_int8), x.shape[0], _p(out, C.c_int8))
+        return out[:n].copy()
+
+    def __del__(self):
+        if self._h:
+            lib().orc_iqbb_i8_destroy(self._h)
+            self._h = None
+
+
+class FMDemodI8:
+    """FMDemod<int8_t,int16_t> run in place: out[0] = the two bytes of in[0]."""
+
+    def __init__(self):
+        self.last = C.c_int16(0)
+
+    def process(self, y):
+        y = np.ascontiguousarray(y, np.int8).reshape(-1, 2)
+        out = y.copy().view(np.int16).reshape(-1)
+        if len(y):
+            lib().orc_fm_i8(_p(y, C.c_int8), y.shape[0], _p(out, C.c_int16), C.byref(self.last))
+        return out
 
 
 def bb_design(Ff, width, Fs, order):

@@ -529,10 +529,52 @@ static void golden_wav() {
     dump("g11_chain_usb_wav", "u8", file_bytes(tmp2)); }
   remove(tmp.c_str()); remove(tmp2.c_str());
 
+  // G13 — the int8 chain of the reference's documentation example (src/sdr.hh:225-240): IQBaseBand<int8_t> ->
+  // FMDemod<int8_t,int16_t>. Its compute type is int16 (Traits<int8_t>::SScalar), so the Q14 kernel products wrap and
+  // what comes out is a few noisy bits — parity is what is asked, not usefulness. Inputs: full-range pseudo-random
+  // complex<int8> (an LCG written out here) so that every wrap is exercised.
+  const double Fs = 2.4e6;
+  {
+    typedef std::complex<int8_t> cs8;
+    std::vector<cs8> x8(3 * 4096);
+    uint32_t lcg = 12345u;
+    for (size_t i = 0; i < x8.size(); i++) {
+      lcg = lcg * 1664525u + 1013904223u; const int8_t re = (int8_t)(lcg >> 24);
+      lcg = lcg * 1664525u + 1013904223u; const int8_t im = (int8_t)(lcg >> 24);
+      x8[i] = cs8(re, im);
+    }
+    { std::vector<int8_t> f; for (size_t i = 0; i < x8.size(); i++) { f.push_back(x8[i].real()); f.push_back(x8[i].imag()); }
+      dump("g13_iq_cs8", "i8", f, "\"Fs\": 2400000, \"bufsize\": 4096, \"nbuf\": 3"); }
+    struct P8 { const char *name; double Fc, Ff, width; size_t order, sub; double oFs; };
+    const P8 cases[3] = {{"g13_i8_o21_d8", 100e3, 100e3, 50e3, 21, 8, 0.0}, {"g13_i8_doc_o16", 0.0, 0.0, 100e3, 16, 0, 100e3},
+                         {"g13_i8_neg_o33_d5", -300e3, -300e3, 50e3, 33, 5, 0.0}};
+    for (int k = 0; k < 3; k++) for (int fm = 0; fm < 2; fm++) {
+      const P8 &c = cases[k];
+      Feeder<cs8> src; src.configure(Fs, 4096);
+      IQBaseBand<int8_t> bb(c.Fc, c.Ff, c.width, c.order, c.sub, c.oFs);
+      src.connect(&bb, true);
+      std::ostringstream par;
+      par << "\"Fs\": " << Fs << ", \"Fc\": " << c.Fc << ", \"Ff\": " << c.Ff << ", \"width\": " << c.width << ", \"order\": " << c.order
+          << ", \"sub\": " << c.sub << ", \"oFs\": " << c.oFs << ", \"decim\": " << bb.subSample();
+      std::vector<size_t> used;
+      const size_t chunks[4] = {4096, 1000, 3096, 4096};
+      size_t off = 0;
+      if (!fm) {
+        Capture<cs8> cap; bb.connect(&cap, true);
+        for (int q = 0; q < 4; q++) { src.feed(&x8[off], chunks[q]); used.push_back(chunks[q]); off += chunks[q]; }
+        std::vector<int8_t> f; for (size_t i = 0; i < cap.data.size(); i++) { f.push_back(cap.data[i].real()); f.push_back(cap.data[i].imag()); }
+        dump(std::string(c.name) + "_out", "i8", f, par.str() + ", " + lens_json("in_lens", used) + ", " + lens_json("out_lens", cap.lens));
+      } else {
+        FMDemod<int8_t, int16_t> dem; Capture<int16_t> cap; bb.connect(&dem, true); dem.connect(&cap, true);
+        for (int q = 0; q < 4; q++) { src.feed(&x8[off], chunks[q]); used.push_back(chunks[q]); off += chunks[q]; }
+        dump(std::string(c.name) + "_fm", "i16", cap.data, par.str() + ", " + lens_json("in_lens", used) + ", " + lens_json("out_lens", cap.lens));
+      }
+    }
+  }
+
   // G12 — the reference node retuned MID-STREAM (src/baseband.hh:82-112): setCenterFrequency only restarts the LUT
   // phase with the new increment (src/freqshift.hh:52-54,78-87), setFilterFrequency / setFilterWidth only swap the
   // kernel, setSubsample runs _reconfigure (counters reset, ring contents kept where they lie, :156-177).
-  const double Fs = 2.4e6;
   std::vector<cs16> x16 = siggen<int16_t>(Fs, 4096, 4, two_tone_i16());   // = g1_iq_cs16
   for (int fm = 0; fm < 2; fm++) {
     Feeder<cs16> src; src.configure(Fs, 4096);

@@ -224,6 +224,93 @@ void orc_iqsiggen_next_cf32(void *gp, size_t n, float *out) {
 }
 
 // ===============================================================================================
+// The int8 chain of the documentation example (src/sdr.hh:225-240): IQBaseBand<int8_t> -> FMDemod<int8_t,int16_t>.
+// IQBaseBand's own compute type is int32 for every Scalar (src/baseband.hh:28-31): ring, kernel, FIR sum, running
+// window sum and its division are exactly the int16 node's. What differs is the frequency shift it inherits from
+// FreqShiftBase<int8_t>, whose compute type is Traits<int8_t>::SScalar = int16 (src/freqshift.hh:18-22, src/traits.hh:
+// 58-73): the FIR value is CONVERTED to complex<int16_t> when it is passed to applyFrequencyShift (wrap mod 2^16, also
+// when the shift is zero), the LUT holds 2^8 * exp(..) as int16, the complex product is stored to complex<int16_t>
+// (wrap) and then shifted by Traits<int8_t>::shift = 8 (src/freqshift.hh:58-74, src/traits.cc:11). The output is the
+// window average wrapped to int8.
+// ===============================================================================================
+static inline int32_t wrap8(int32_t v) { return (int32_t)(int8_t)(uint8_t)(uint32_t)v; }
+
+void orc_freqshift_lut_i8(int32_t *lut) {   // FreqShiftBase<int8_t> ctor (src/freqshift.hh:31-35): 2^8 * exp(-2 pi i k/128) -> int16
+  for (size_t i = 0; i < 128; i++) {
+    std::complex<double> v = double(1 << 8) * std::exp(std::complex<double>(0, -(2 * M_PI * i) / 128));
+    lut[2 * i] = (int32_t)(int16_t)v.real();
+    lut[2 * i + 1] = (int32_t)(int16_t)v.imag();
+  }
+}
+
+struct IQBB8 {
+  int order, decim, negative; uint32_t inc;
+  std::vector<C32> k, ring, lut;   // (the LUT's int16 values kept in int32 fields)
+  size_t off, count, lut_count; C32 last;
+};
+
+void *orc_iqbb_i8_create(const int32_t *taps, int order, const int32_t *lut, uint32_t inc, int negative, int decim) {
+  IQBB8 *s = new IQBB8;
+  s->order = order; s->decim = decim; s->negative = negative; s->inc = inc;
+  s->k.resize(order); s->ring.assign(order, C32{0, 0}); s->lut.resize(128);
+  for (int i = 0; i < order; i++) { s->k[i].re = taps[2 * i]; s->k[i].im = taps[2 * i + 1]; }
+  for (int i = 0; i < 128; i++) { s->lut[i].re = wrap16(lut[2 * i]); s->lut[i].im = wrap16(lut[2 * i + 1]); }
+  s->off = 0; s->count = 0; s->lut_count = 0; s->last = C32{0, 0};
+  return s;
+}
+void orc_iqbb_i8_destroy(void *h) { delete (IQBB8 *)h; }
+
+size_t orc_iqbb_i8_process(void *h, const int8_t *in, size_t n, int8_t *out) {
+  IQBB8 *s = (IQBB8 *)h;
+  const size_t order = (size_t)s->order, D = (size_t)s->decim;
+  size_t j = 0;
+  for (size_t i = 0; i < n; i++) {
+    s->ring[s->off] = C32{in[2 * i], in[2 * i + 1]};
+    C32 acc = {0, 0};
+    size_t idx = s->off + 1; if (idx == order) idx = 0;
+    for (size_t t = 0; t < order; t++, idx++) {
+      if (idx == order) idx = 0;
+      const C32 a = s->k[t], b = s->ring[idx];
+      acc.re = addw(acc.re, subw(mulw(a.re, b.re), mulw(a.im, b.im)));
+      acc.im = addw(acc.im, addw(mulw(a.re, b.im), mulw(a.im, b.re)));
+    }
+    C32 v = {wrap16(acc.re >> 14), wrap16(acc.im >> 14)};   // complex<int32> -> complex<int16> at the call (:206)
+    if (s->inc != 0) {
+      size_t li = s->lut_count >> 8;
+      if (s->negative) li = 128 - li - 1;
+      const C32 L = s->lut[li];
+      const int32_t pre = wrap16(subw(mulw(L.re, v.re), mulw(L.im, v.im)));   // complex<int16> * complex<int16>
+      const int32_t pim = wrap16(addw(mulw(L.re, v.im), mulw(L.im, v.re)));
+      v.re = pre >> 8; v.im = pim >> 8;
+      s->lut_count += s->inc;
+      while (s->lut_count >= (128u << 8)) s->lut_count -= (128u << 8);
+    }
+    s->last.re = addw(s->last.re, v.re); s->last.im = addw(s->last.im, v.im);
+    s->off++; if (s->off == order) s->off = 0;
+    if (D == s->count) {
+      C32 q = cdiv_int(s->last, (int32_t)D);
+      out[2 * j] = (int8_t)wrap8(q.re); out[2 * j + 1] = (int8_t)wrap8(q.im);
+      s->last = C32{0, 0}; s->count = 0; j++;
+    } else if (D == 1) {
+      out[2 * j] = (int8_t)wrap8(s->last.re); out[2 * j + 1] = (int8_t)wrap8(s->last.im);
+      s->last = C32{0, 0}; s->count = 0; j++;
+    }
+    s->count++;
+  }
+  return j;
+}
+
+// FMDemod<int8_t,int16_t>::_process (src/demod.hh:242-254) with fast_atan2<int8_t,int16_t> (src/math.hh:12-21: the
+// same formula as the int16 form); in place, out[i] (2 bytes) covers exactly sample i (2 bytes)
+void orc_fm_i8(const int8_t *in, size_t n, int16_t *out, int16_t *last) {
+  for (size_t i = 1; i < n; i++) {
+    const int16_t phi = (int16_t)(orc_fast_atan2_i16(in[2 * i], in[2 * i + 1]) / 2);
+    out[i] = wrap16((int32_t)*last - (int32_t)phi);
+    *last = phi;
+  }
+}
+
+// ===============================================================================================
 // IQBaseBand<int16_t>::_process (src/baseband.hh:198-223), _filter_ring (:226-236),
 // FreqShiftBase::applyFrequencyShift (src/freqshift.hh:58-74)
 // ===============================================================================================

@@ -48,6 +48,12 @@ void *orc_iqbb_i16_create(const int32_t *taps, int order, const int32_t *lut, ui
                           int negative, int decim);
 /* returns number of complex outputs; in/out may alias (reference runs in place) */
 size_t orc_iqbb_i16_process(void *h, const int16_t *in, size_t n, int16_t *out);
+/* IQBaseBand<int8_t> -> FMDemod<int8_t,int16_t> (the documentation example's chain, src/sdr.hh:225-240) */
+void orc_freqshift_lut_i8(int32_t *lut);
+void *orc_iqbb_i8_create(const int32_t *taps, int order, const int32_t *lut, uint32_t lut_inc, int negative, int decim);
+size_t orc_iqbb_i8_process(void *h, const int8_t *in, size_t n, int8_t *out);
+void orc_iqbb_i8_destroy(void *h);
+void orc_fm_i8(const int8_t *in, size_t n, int16_t *out, int16_t *last);
 void orc_iqbb_i16_reset(void *h);   /* what _reconfigure does: counters, NOT the ring */
 void orc_iqbb_i16_set_taps(void *h, const int32_t *taps);               /* setFilterFrequency / setFilterWidth: kernel only */
 void orc_iqbb_i16_set_shift(void *h, uint32_t lut_inc, int negative);   /* setCenterFrequency: increment, sign, LUT phase = 0 */

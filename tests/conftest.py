@@ -11,7 +11,7 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
-_DT = {"u8": np.uint8, "i16": np.int16, "cs16": np.int16, "i32": np.int32, "f32": np.float32, "cf32": np.float32,
+_DT = {"u8": np.uint8, "i8": np.int8, "i16": np.int16, "cs16": np.int16, "i32": np.int32, "f32": np.float32, "cf32": np.float32,
        "f64": np.float64}
 
 

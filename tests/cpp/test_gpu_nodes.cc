@@ -376,6 +376,27 @@ static void testRetuneMidStream() {
   }
 }
 
+// the documentation example's chain (reference src/sdr.hh:225-240) on the GPU nodes: IQBaseBand<int8_t>(0, 100e3, 16, 0, 100e3)
+// -> FMDemod<int8_t,int16_t>, against the golden vector cut from the reference chain
+static void testInt8Chain() {
+  typedef std::complex<int8_t> cs8;
+  std::vector<int8_t> raw = slurp<int8_t>("g13_iq_cs8.bin");
+  std::vector<int16_t> ref = slurp<int16_t>("g13_i8_doc_o16_fm.bin");
+  CHECK(raw.size() == 2 * 3 * 4096 && ref.size() == 511);
+  struct S8Feeder : public Source { void cfg() { setConfig(Config(Config::Type_cs8, FS, 4096, 1)); }
+                                    void feed(cs8 *p, size_t n) { Buffer<cs8> b(p, n); send(b, false); } } src;
+  src.cfg();
+  gpu::IQBaseBand<int8_t> bb(0.0, 100e3, 16, 0, 100e3);
+  gpu::FMDemod<int8_t, int16_t> fm; Recorder<int16_t> out;
+  src.connect(&bb, true); bb.connect(&fm, true); fm.connect(&out, true);
+  CHECK(bb.type() == Config::Type_cs8 && fm.type() == Config::Type_s16 && bb.subSample() == 24);
+  cs8 *x = reinterpret_cast<cs8 *>(raw.data());
+  const size_t chunks[4] = {4096, 1000, 3096, 4096};
+  size_t off = 0;
+  for (int k = 0; k < 4; k++) { src.feed(x + off, chunks[k]); off += chunks[k]; }
+  CHECK(out.data == ref);
+}
+
 int main(int argc, char **argv) {
   if (argc > 1) g_golden = argv[1];
   Logger::get().addHandler(new StreamLogHandler(std::cerr, LOG_WARNING));
@@ -391,6 +412,7 @@ int main(int argc, char **argv) {
     testSdrFmChainCu8();
     testRealBaseBand();
     testRetuneMidStream();
+    testInt8Chain();
   } catch (std::exception &e) {
     std::printf("FAIL: exception: %s\n", e.what());
     return 2;

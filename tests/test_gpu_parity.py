@@ -170,6 +170,44 @@ def test_iqbb_reset_semantics(ctx, orc, golden, k1path):
     assert np.array_equal(node.process(x[4096:8192])[0], bb.process(x[4096:8192]))
 
 
+# ---- the int8 chain (reference src/sdr.hh:225-240): IQBaseBand<int8_t> -> FMDemod<int8_t,int16_t> ------
+
+@pytest.mark.parametrize("case", ["g13_i8_o21_d8", "g13_i8_doc_o16", "g13_i8_neg_o33_d5"])
+def test_iqbb_i8_chain_golden(ctx, golden, case):
+    m = golden.meta(case + "_out")
+    x = golden.load("g13_iq_cs8").reshape(-1, 2)
+    Fs = float(int(m["Fs"]))
+    taps, lut, inc = sa.design_iqbb_taps(m["Ff"], m["width"], Fs, m["order"]), sa.design_freqshift_lut_i8(), sa.design_freqshift_inc(m["Fc"], Fs)
+    node = sa.IQBaseBandI8(ctx, taps, lut, inc, m["Fc"] < 0, m["decim"], max_in=4096)
+    outs = [node.process(c)[0] for c in split(x, m["in_lens"])]
+    assert [len(o) for o in outs] == m["out_lens"]
+    assert np.array_equal(np.concatenate(outs).ravel(), golden.load(case + "_out"))
+    # FM fused into the launch, and the stand-alone FMDemod<int8_t,int16_t> behind the complex<int8> output
+    fused = sa.IQBaseBandI8(ctx, taps, lut, inc, m["Fc"] < 0, m["decim"], max_in=4096, epilogue=sa.EPI_FM)
+    assert np.array_equal(np.concatenate([fused.process(c)[0] for c in split(x, m["in_lens"])]), golden.load(case + "_fm"))
+    dem = sa.Demod(ctx, sa.EPI_FM, sa.abi.T_CS8, max_in=4096)
+    fm = [dem.process(o)[0] for o in outs]
+    assert np.array_equal(np.concatenate(fm), golden.load(case + "_fm"))
+
+
+def test_iqbb_i8_batched_random_vs_oracle(ctx, orc):
+    rng = np.random.default_rng(17)
+    C, chunks = 5, [4096, 777, 1, 3000]
+    x = rng.integers(-128, 128, size=(C, sum(chunks), 2)).astype(np.int8)
+    for order, D, Fc in ((21, 8, 100e3), (127, 8, -250e3), (16, 3, 0.0), (64, 1, 50e3)):
+        taps, lut, inc = sa.design_iqbb_taps(Fc, 50e3, FS, order), sa.design_freqshift_lut_i8(), sa.design_freqshift_inc(Fc, FS)
+        node = sa.IQBaseBandI8(ctx, taps, lut, inc, Fc < 0, D, channels=C, max_in=4096, epilogue=sa.EPI_FM)
+        refs = [(orc.IQBaseBandI8(taps, lut, inc, Fc < 0, D), orc.FMDemodI8()) for _ in range(C)]
+        off = 0
+        for n in chunks:
+            y = node.process(x[:, off:off + n])
+            for c in range(C):
+                r = refs[c][0].process(x[c, off:off + n])
+                r = refs[c][1].process(r) if len(r) else np.zeros(0, np.int16)
+                assert np.array_equal(y[c], r), (order, D, c, n)
+            off += n
+
+
 class _GpuRetune:
     def __init__(self, ctx, Ff, width, Fc, epi, order=127, D=8):
         self.order = order

@@ -370,3 +370,24 @@ def test_iqbb_retune_midstream(golden, orc):
     outs = replay_retune(golden.meta("g12_retune_fm"), golden.load("g1_iq_cs16"), lambda Ff, w, Fc: _OrcRetune(orc, Ff, w, Fc),
                          demod=lambda y: fm.process(y))
     assert np.array_equal(np.concatenate(outs), golden.load("g12_retune_fm"))
+
+
+# ---- the int8 chain (src/sdr.hh:225-240): IQBaseBand<int8_t> -> FMDemod<int8_t,int16_t> -------------
+
+I8_CASES = ["g13_i8_o21_d8", "g13_i8_doc_o16", "g13_i8_neg_o33_d5"]
+
+
+@pytest.mark.parametrize("case", I8_CASES)
+def test_iqbb_i8_chain(golden, orc, case):
+    m = golden.meta(case + "_out")
+    x = golden.load("g13_iq_cs8").reshape(-1, 2)
+    Fs = float(int(m["Fs"]))   # (the node stores Fs, Fc, Ff, width as int32)
+    mk = lambda: orc.IQBaseBandI8(orc.iqbb_design(m["Ff"], m["width"], Fs, m["order"]), orc.freqshift_lut_i8(),
+                                  orc.freqshift_inc(m["Fc"], Fs), m["Fc"] < 0, m["decim"])
+    bb = mk()
+    outs = [bb.process(c) for c in split(x, m["in_lens"])]
+    assert [len(o) for o in outs] == m["out_lens"]
+    assert np.array_equal(np.concatenate(outs).ravel(), golden.load(case + "_out"))
+    bb, fm = mk(), orc.FMDemodI8()
+    outs = [fm.process(bb.process(c)) for c in split(x, m["in_lens"])]
+    assert np.array_equal(np.concatenate(outs), golden.load(case + "_fm"))
