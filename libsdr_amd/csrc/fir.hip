@@ -192,8 +192,12 @@ struct Fir32Args {
   const float *betap;      // beta with (R-1)*D zeros on either side
   unsigned rd_magic;       // ceil(2^32 / (R*D)): i / (R*D) = umulhi(i, rd_magic) for the tile's i
   // fused frequency shift (float baseband, fbb_f32.hip): x[n] * exp(-2 pi i fc n / fs), n = absolute sample index
-  int shift_on; double fc, fs; unsigned long long n0;
-  double step_re, step_im; // exp(-2 pi i fc TPB / fs)
+  // The phase of sample i of a tile (absolute index n = n_tile + i, i = t + TPB*k) splits into three exact factors:
+  // exp(-iw n) = P[tile] * E[t] * W[k]. E (per lane) and W (lane-uniform) are tables made once from float64 values,
+  // P[tile] = exp(-iw n_tile) is evaluated in float64 per call by a tiny kernel and multiplies the OUTPUT (the filter is
+  // linear), so staging a sample costs 8 float32 operations and no lane evaluates sincos or carries a float64 phasor.
+  int shift_on;
+  const float2 *etab, *wtab, *ptab;
 };
 
 __device__ __forceinline__ float2 load_x32(const Fir32Args &a, int c, int rel) {
@@ -257,34 +261,46 @@ __global__ __launch_bounds__(TPB) void fir_cf32_rt_kernel(const Fir32Args a) {
   // coalesced loads before the first wait; per-element bounds logic would make every load a branch with its own wait
   const bool interior = (w0 >= 0) && (w0 + need <= a.N);
   const float2 *src = a.in + (long)c * a.in_stride + w0;
-  double zr = 1.0, zi = 0.0;
-  if (a.shift_on) {
-    const double n = (double)((long long)a.n0 + (long long)(w0 + tid));   // (negative before the stream start: those samples are zero)
-    const double turns = fmod(__ddiv_rn(__dmul_rn(a.fc, n), a.fs), 1.0);
-    sincos(__dmul_rn(-2.0 * M_PI, turns), &zi, &zr);
-  }
-  for (int i0 = tid; i0 < need; i0 += 16 * TPB) {
-    float2 v[16];
-    if (interior) {
-#pragma unroll
-      for (int k = 0; k < 16; k++) { const int i = i0 + k * TPB; if (i < need) v[k] = src[i]; }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 16; k++) { const int i = i0 + k * TPB; if (i < need) v[k] = load_x32(a, c, w0 + i); }
+  float2 E = make_float2(1.f, 0.f);
+  if (a.shift_on) E = a.etab[tid];
+  // staging by rows of TPB consecutive samples. The first FR rows are complete in every full tile whatever M is, so an
+  // interior full tile (no history, no end of call) issues FR unconditional coalesced loads before its first wait;
+  // the remaining rows (and every row of a border tile) go four at a time through clamped, branch-free loads that
+  // are masked afterwards — per-element bounds branches would make every load its own round trip.
+  auto put = [&](float2 v, int row, int i) {
+    if (a.shift_on) {
+      const float2 W = a.wtab[row];   // lane-uniform
+      const float zr = E.x * W.x - E.y * W.y, zi = E.x * W.y + E.y * W.x;
+      v = make_float2(v.x * zr - v.y * zi, v.x * zi + v.y * zr);
     }
+    const int q = DC > 0 ? i / (R * (DC > 0 ? DC : 1)) : (int)__umulhi((unsigned)i, a.rd_magic);
+    xs[i + q] = v;
+  };
+  constexpr int FR = DC > 0 ? ((TPB * R - 1) * (DC > 0 ? DC : 1) + 1) / TPB : 0;
+  int row0 = 0;
+  if (FR > 0 && interior && outs_here == TPB * R) {
+    float2 v[FR > 0 ? FR : 1];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-      const int i = i0 + k * TPB;
-      if (i < need) {
-        float2 y = v[k];
-        if (a.shift_on) {
-          const float fr = (float)zr, fi = (float)zi;
-          y = make_float2(v[k].x * fr - v[k].y * fi, v[k].x * fi + v[k].y * fr);
-          const double t = zr * a.step_re - zi * a.step_im;
-          zi = zr * a.step_im + zi * a.step_re; zr = t;
-        }
-        const int q = DC > 0 ? i / (R * (DC > 0 ? DC : 1)) : (int)__umulhi((unsigned)i, a.rd_magic);
-        xs[i + q] = y;
+    for (int k = 0; k < FR; k++) v[k] = src[tid + k * TPB];
+#pragma unroll
+    for (int k = 0; k < FR; k++) put(v[k], k, tid + k * TPB);
+    row0 = FR;
+  }
+  {
+    const float2 *hrow = a.hist_old + (long)c * a.HH, *irow = a.in + (long)c * a.in_stride;
+    for (int row = row0; row * TPB < need; row += 4) {
+      float2 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int rel = w0 + tid + (row + k) * TPB, hh = a.HH + rel;
+        const float2 *p = rel >= 0 ? irow + min(rel, a.N - 1) : hrow + max(hh, 0);
+        v[k] = *p;
+        if (rel >= a.N || hh < 0) v[k] = make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int i = tid + (row + k) * TPB;
+        if (i < need) put(v[k], row + k, i);
       }
     }
   }
@@ -345,6 +361,11 @@ __global__ __launch_bounds__(TPB) void fir_cf32_rt_kernel(const Fir32Args a) {
       }
     }
     }
+    if (a.shift_on) {   // the tile's phase factor (see Fir32Args)
+      const float2 P = a.ptab[tile];
+#pragma unroll
+      for (int r = 0; r < R; r++) { const float yr = sr[r] * P.x - si[r] * P.y, yi = sr[r] * P.y + si[r] * P.x; sr[r] = yr; si[r] = yi; }
+    }
 #pragma unroll
     for (int r = 0; r < R; r++) {
       const int j = j0 + R * tid + r;
@@ -355,6 +376,17 @@ __global__ __launch_bounds__(TPB) void fir_cf32_rt_kernel(const Fir32Args a) {
       }
     }
   }
+}
+
+// per-tile phase factors of the fused frequency shift: P[t] = exp(-2 pi i frac(fc (n_first + t * step) / fs)), float64
+__global__ void tile_phasor_kernel(float2 *ptab, int tiles, long long n_first, long long step, double fc, double fs) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= tiles) return;
+  const double n = (double)(n_first + (long long)t * step);
+  const double turns = fmod(__ddiv_rn(__dmul_rn(fc, n), fs), 1.0);
+  double sn, cs;
+  sincos(__dmul_rn(-2.0 * M_PI, turns), &sn, &cs);
+  ptab[t] = make_float2((float)cs, (float)sn);
 }
 
 // history roll for K3 (separate tiny kernel: a call may produce zero outputs, i.e. zero tiles)
@@ -386,6 +418,7 @@ struct sdrhip_fir {
   size_t lds3 = 0;
   // fused frequency shift (set by the float baseband)
   bool shift_on = false; double fc = 0, fs = 1;
+  DevBuf<float2> etab, wtab, ptab;   // phase tables of the fused shift (see Fir32Args)
   DevBuf<float2> hist32[2];
   // staging
   DevBuf<uint8_t> stage_in, stage_out;
@@ -428,10 +461,15 @@ struct sdrhip_fir {
       a.n_out = (int)no;
       a.out = out_dev; a.out_stride = (long)out_stride; a.epilogue = epi;
       a.betap = betap.p; a.rd_magic = (unsigned)((0x100000000ull + (uint64_t)(R * D) - 1) / (uint64_t)(R * D));
-      a.shift_on = shift_on ? 1 : 0; a.fc = fc; a.fs = fs; a.n0 = n0;
-      { const double t = std::fmod(fc * (double)TPB / fs, 1.0), ph = -2.0 * M_PI * t; a.step_re = std::cos(ph); a.step_im = std::sin(ph); }
+      a.shift_on = shift_on ? 1 : 0; a.etab = etab.p; a.wtab = wtab.p; a.ptab = ptab.p;
       if (no) {
         const int tiles = (int)ceil_div(no, (size_t)TPB * R);
+        if (shift_on) {   // sample 0 of tile t is absolute index n0 + first_rel - (M-1) + t * TPB*R*D
+          if (ptab.n < (size_t)tiles) ptab.alloc((size_t)tiles + 64);
+          a.ptab = ptab.p;
+          hipLaunchKernelGGL(tile_phasor_kernel, dim3((unsigned)ceil_div((size_t)tiles, (size_t)64)), dim3(64), 0, ctx->stream, ptab.p, tiles,
+                             (long long)n0 + a.first_rel - (M - 1), (long long)TPB * R * D, fc, fs);
+        }
         dim3 grid(tiles, C), block(TPB);
         if (R == 4 && D == 8) hipLaunchKernelGGL((fir_cf32_rt_kernel<4, 8>), grid, block, lds3, ctx->stream, a);
         else if (R == 2 && D == 8) hipLaunchKernelGGL((fir_cf32_rt_kernel<2, 8>), grid, block, lds3, ctx->stream, a);
@@ -453,7 +491,19 @@ struct sdrhip_fir {
 };
 
 namespace sdrhip {
-void fir_set_shift(sdrhip_fir *h, double fc, double fs) { h->shift_on = true; h->fc = fc; h->fs = fs; }
+void fir_set_shift(sdrhip_fir *h, double fc, double fs) {
+  h->shift_on = true; h->fc = fc; h->fs = fs;
+  h->ctx->use();
+  auto ph = [&](double t) {   // exp(-2 pi i frac(fc t / fs)), the oracle's closed form, rounded to float once
+    const double a = -2.0 * M_PI * std::fmod(fc * t / fs, 1.0);
+    return make_float2((float)std::cos(a), (float)std::sin(a));
+  };
+  std::vector<float2> e(TPB), w(256);
+  for (int t = 0; t < TPB; t++) e[t] = ph((double)t);
+  for (int k = 0; k < 256; k++) w[k] = ph((double)TPB * k);
+  h->etab.alloc(TPB); h->etab.upload(e.data(), TPB, h->ctx->stream);
+  h->wtab.alloc(256); h->wtab.upload(w.data(), 256, h->ctx->stream);
+}
 }  // namespace sdrhip
 
 extern "C" {
