@@ -244,7 +244,10 @@ __device__ __forceinline__ float2 conv_fetch(const ConvArgs &a, int c, int rel) 
 // plan is read from the arguments
 constexpr int plan_npass(int lg) { return lg / 4 + ((lg % 4) >= 2 ? 1 : 0) + ((lg % 4) & 1); }
 constexpr int plan_radix(int lg, int pass) { return pass < lg / 4 ? 16 : ((lg % 4) >= 2 && pass == lg / 4) ? 4 : 2; }
-template <int LG>
+// BANK: several bands behind one forward transform (forward image kept, one work image); false = the single-band
+// kernel exactly as before (in place, no band loop — the 1024-lane workgroup sits at the 128-VGPR cap and any extra
+// live value spills: the runtime band loop alone cost 36 %)
+template <int LG, bool BANK>
 __global__ __launch_bounds__(FT) void fftconv_fused_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float2 xl[];
   const int c = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
@@ -321,10 +324,11 @@ __global__ __launch_bounds__(FT) void fftconv_fused_kernel(const ConvArgs a) {
   // ---- filter bank: the forward image stays in xs; every band multiplies it by its own spectrum and runs the inverse
   // transform in the work image xw (one band: xw == xs, in place as before). One forward transform per input block,
   // as FilterSink feeds every FilterSource from one FFT (reference src/filternode.hh:81-88,257-270). ----
-  float2 *xs = xl, *xw = a.nb > 1 ? xl + a.lds_elems : xl;
-  for (int band = 0; band < a.nb; band++) {
-  const float2 *kp = a.Kp + (long)band * L;
-  float2 *outb = a.out + (long)band * a.out_band;
+  float2 *xs = xl, *xw = BANK ? xl + a.lds_elems : xl;
+  const int nb = BANK ? a.nb : 1;
+  for (int band = 0; band < nb; band++) {
+  const float2 *kp = BANK ? a.Kp + (long)band * L : a.Kp;
+  float2 *outb = BANK ? a.out + (long)band * a.out_band : a.out;
   // ---- last forward pass (stride 1, no twiddles) x spectrum x first inverse pass ----
   {
     const int r = radix_at(np - 1);
@@ -426,7 +430,7 @@ __global__ __launch_bounds__(FT) void fftconv_fused_kernel(const ConvArgs a) {
       }
     }
   }
-  if (band + 1 < a.nb) __syncthreads();   // the work image is read out before the next band's middle pass overwrites it
+  if (BANK && band + 1 < nb) __syncthreads();   // the work image is read out before the next band's middle pass overwrites it
   }
 }
 
@@ -586,12 +590,15 @@ struct sdrhip_fftconv {
     a.hist = hist[par].p; a.HH = HH; a.Kp = Kp.p + (size_t)b0 * plan.L;
     a.out = out_dev + (size_t)b0 * out_band; a.out_stride = (long)out_stride; a.N = (int)N; a.hop = hop;
     const int blocks = (int)ceil_div(N, (size_t)hop);
-    if (plan.L == 16384) {
-      allow_big_lds(fftconv_fused_kernel<14>, lds);
-      hipLaunchKernelGGL(fftconv_fused_kernel<14>, dim3(blocks, C), dim3(FT), lds, ctx->stream, a);
+    if (plan.L == 16384) {   // (never a bank: two images of 16384 points do not fit the LDS)
+      allow_big_lds(fftconv_fused_kernel<14, false>, lds);
+      hipLaunchKernelGGL((fftconv_fused_kernel<14, false>), dim3(blocks, C), dim3(FT), lds, ctx->stream, a);
+    } else if (plan.dev.npass >= 2 && plan.dev.radix[0] == 16 && a.nb > 1) {
+      allow_big_lds(fftconv_fused_kernel<0, true>, lds);
+      hipLaunchKernelGGL((fftconv_fused_kernel<0, true>), dim3(blocks, C), dim3(FT), lds, ctx->stream, a);
     } else if (plan.dev.npass >= 2 && plan.dev.radix[0] == 16) {
-      allow_big_lds(fftconv_fused_kernel<0>, lds);
-      hipLaunchKernelGGL(fftconv_fused_kernel<0>, dim3(blocks, C), dim3(FT), lds, ctx->stream, a);
+      allow_big_lds(fftconv_fused_kernel<0, false>, lds);
+      hipLaunchKernelGGL((fftconv_fused_kernel<0, false>), dim3(blocks, C), dim3(FT), lds, ctx->stream, a);
     } else {
       allow_big_lds(fftconv_kernel, lds);
       hipLaunchKernelGGL(fftconv_kernel, dim3(blocks, C), dim3(FT), lds, ctx->stream, a);
