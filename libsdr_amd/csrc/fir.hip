@@ -198,6 +198,8 @@ struct Fir32Args {
   // linear), so staging a sample costs 8 float32 operations and no lane evaluates sincos or carries a float64 phasor.
   int shift_on;
   const float2 *etab, *wtab, *ptab;
+  float2 parg[32]; int p_in_args;   // calls of up to 32 tiles carry their tile factors in the arguments (host float64): no table kernel
+  int roll;                         // the call's last tile also rolls the FIR history forward (hist_new <- concat(hist_old, in))
 };
 
 __device__ __forceinline__ float2 load_x32(const Fir32Args &a, int c, int rel) {
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(TPB) void fir_cf32_rt_kernel(const Fir32Args a) {
     }
     }
     if (a.shift_on) {   // the tile's phase factor (see Fir32Args)
-      const float2 P = a.ptab[tile];
+      const float2 P = a.p_in_args ? a.parg[tile] : a.ptab[tile];
 #pragma unroll
       for (int r = 0; r < R; r++) { const float yr = sr[r] * P.x - si[r] * P.y, yi = sr[r] * P.y + si[r] * P.x; sr[r] = yr; si[r] = yi; }
     }
@@ -374,6 +376,12 @@ __global__ __launch_bounds__(TPB) void fir_cf32_rt_kernel(const Fir32Args a) {
         else if (a.epilogue == SDRHIP_EPI_AM) reinterpret_cast<float *>(a.out)[(long)c * a.out_stride + j] = sqrtf(sr[r] * sr[r] + si[r] * si[r]);
         else reinterpret_cast<float *>(a.out)[(long)c * a.out_stride + j] = (sr[r] + si[r]) / 2;
       }
+    }
+  }
+  if (a.roll && tile == (int)gridDim.x - 1) {   // (hist_old is only read, by this launch's border tiles; hist_new only written here)
+    for (int k = tid; k < a.HH; k += TPB) {
+      const long qq = (long)a.N + k;
+      a.hist_new[(long)c * a.HH + k] = qq < a.HH ? a.hist_old[(long)c * a.HH + qq] : a.in[(long)c * a.in_stride + (qq - a.HH)];
     }
   }
 }
@@ -464,11 +472,21 @@ struct sdrhip_fir {
       a.shift_on = shift_on ? 1 : 0; a.etab = etab.p; a.wtab = wtab.p; a.ptab = ptab.p;
       if (no) {
         const int tiles = (int)ceil_div(no, (size_t)TPB * R);
+        a.p_in_args = 0; a.roll = M > 1 ? 1 : 0;
         if (shift_on) {   // sample 0 of tile t is absolute index n0 + first_rel - (M-1) + t * TPB*R*D
-          if (ptab.n < (size_t)tiles) ptab.alloc((size_t)tiles + 64);
-          a.ptab = ptab.p;
-          hipLaunchKernelGGL(tile_phasor_kernel, dim3((unsigned)ceil_div((size_t)tiles, (size_t)64)), dim3(64), 0, ctx->stream, ptab.p, tiles,
-                             (long long)n0 + a.first_rel - (M - 1), (long long)TPB * R * D, fc, fs);
+          const long long n_first = (long long)n0 + a.first_rel - (M - 1), step = (long long)TPB * R * D;
+          if (tiles <= 32) {
+            a.p_in_args = 1;
+            for (int t = 0; t < tiles; t++) {
+              const double ph = -2.0 * M_PI * std::fmod(fc * (double)(n_first + t * step) / fs, 1.0);
+              a.parg[t] = make_float2((float)std::cos(ph), (float)std::sin(ph));
+            }
+          } else {
+            if (ptab.n < (size_t)tiles) ptab.alloc((size_t)tiles + 64);
+            a.ptab = ptab.p;
+            hipLaunchKernelGGL(tile_phasor_kernel, dim3((unsigned)ceil_div((size_t)tiles, (size_t)64)), dim3(64), 0, ctx->stream, ptab.p, tiles,
+                               n_first, step, fc, fs);
+          }
         }
         dim3 grid(tiles, C), block(TPB);
         if (R == 4 && D == 8) hipLaunchKernelGGL((fir_cf32_rt_kernel<4, 8>), grid, block, lds3, ctx->stream, a);
@@ -478,7 +496,7 @@ struct sdrhip_fir {
         else hipLaunchKernelGGL((fir_cf32_rt_kernel<1, 0>), grid, block, lds3, ctx->stream, a);
         SDRHIP_CHECK_HIP(hipGetLastError());
       }
-      if (M > 1) {
+      if (M > 1 && !no) {   // (a call that completes no output launches no tile: the history still rolls)
         dim3 grid((unsigned)ceil_div((size_t)(M - 1), (size_t)256), C);
         hipLaunchKernelGGL(hist_roll_cf32, grid, dim3(256), 0, ctx->stream, a.in, a.in_stride, a.hist_old, a.hist_new, M - 1, (int)N);
         SDRHIP_CHECK_HIP(hipGetLastError());
