@@ -51,3 +51,12 @@ names = ["wait DMA", "raw->planes", "K loop", "recombine/rotate/sum", "finish/de
 print("launch %.1f us; waves %d, wave-tiles %.0f; cycles per wave %.0f, per wave-tile %.0f" % (dt * 1e6, waves, tiles, tot / waves, tot / tiles))
 for n_, c_ in zip(names, v[:5]):
     print("  %-24s %6.1f %%   %8.0f cycles per wave-tile" % (n_, 100.0 * c_ / tot, c_ / tiles))
+
+# where does the spread of wave lifetimes come from? by wave slot of the SIMD, by SIMD, by CU (HW_ID fields)
+slot, simd, cu, se = hwid & 15, (hwid >> 4) & 3, (hwid >> 8) & 15, (hwid >> 13) & 7
+for name, key in (("slot", slot), ("simd", simd), ("se", se), ("cu", cu)):
+    print("life by %-4s:" % name, " ".join("%d:%.0f" % (v_, life[key == v_].mean()) for v_ in np.unique(key)))
+cukey = se * 16 + cu
+m = np.array([life[cukey == v_].mean() for v_ in np.unique(cukey)])
+print("per-CU mean life: min %.1f max %.1f std %.1f us over %d (se,cu) groups; within-CU std %.1f us" %
+      (m.min(), m.max(), m.std(), len(m), np.mean([life[cukey == v_].std() for v_ in np.unique(cukey)])))
