@@ -911,6 +911,7 @@ struct HotArgs {
   int cre, cim;
 };
 
+constexpr bool hot_wide_table(int nh) { return nh <= 5; }   // 4 KB rotation table while 4 workgroups per CU still fit
 constexpr int HOT_WIN = 512 + 128;                 // samples a wave stages per tile (OP - 1 = 128 halo: S = 9)
 constexpr int HOT_PLB = 2 * HOT_WIN + 32;          // bytes per byte plane (+ one chunk pair: the parity halves stay 16-byte aligned)
 constexpr int HOT_RAWB = HOT_WIN * 4;               // raw area: 160 pieces of 16 bytes = two DMA wave-instructions + 32 lanes of a third
@@ -919,16 +920,28 @@ template <int S, int S0, int NH, bool ROT, int EPI>
 __global__ __launch_bounds__(TPB, 4) void iqbb_i16_hot_kernel(const HotArgs a) {
   static_assert(S == 9, "window geometry (HOT_WIN) is the 127-tap one");
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  // Rotation table at LDS offset 0. WIDE (the high-plane range leaves room: NH <= 5): 256 entries of 16 bytes
+  // {Lx, Ly, -Ly, 0}, the 128-entry table twice — a table address is then byte 1 of the phase counter << 4 with no
+  // mask (one SDWA shift), and the complex product needs no subtraction. Otherwise 128 entries {Lx, Ly}. A negative
+  // shift reads the table backwards: it is stored reversed.
+  constexpr bool WIDE = hot_wide_table(NH);
+  constexpr int TBLW = WIDE ? 1024 : 256;   // dwords
   int2 *lut_s = reinterpret_cast<int2 *>(smem);
-  v4i *taps_s = reinterpret_cast<v4i *>(smem + 256);
-  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 31, h = l >> 5;
+  v4i *taps_s = reinterpret_cast<v4i *>(smem + TBLW);
+  // (the wave index is wave-uniform but the compiler cannot know: through readfirstlane the slice bookkeeping — tile
+  // indices, window addresses, the hot test — runs on the scalar unit instead of 80 vector instructions per tile)
+  const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, n = l & 31, h = l >> 5;
   // tap fragments in LDS: the S low-plane fragments, then only the NH high-plane fragments of steps [S0, S0 + NH)
-  char *wbase = reinterpret_cast<char *>(smem + 256 + (S + NH) * 64 * 4) + w * (HOT_RAWB + 2 * HOT_PLB);
+  char *wbase = reinterpret_cast<char *>(smem + TBLW + (S + NH) * 64 * 4) + w * (HOT_RAWB + 2 * HOT_PLB);
   uint4 *raw = reinterpret_cast<uint4 *>(wbase);
   char *lo = wbase + HOT_RAWB, *hi = lo + HOT_PLB;
   for (int i = tid; i < S * 64; i += TPB) taps_s[i] = a.tapfrag[(2 * (i >> 6) + 1) * 64 + (i & 63)];
   for (int i = tid; i < NH * 64; i += TPB) taps_s[S * 64 + i] = a.tapfrag[(2 * (S0 + (i >> 6))) * 64 + (i & 63)];
-  if (tid < 128) lut_s[tid] = a.lut[tid];
+  {
+    const int2 e = a.lut[(tid & 127) ^ (a.negative ? 127 : 0)];
+    if (WIDE) reinterpret_cast<v4i *>(smem)[tid] = v4i{e.x, e.y, -e.y, 0};
+    else if (tid < 128) lut_s[tid] = e;
+  }
 
   const int OGw = 64 - a.ovl, gw = w * OGw;
   // PERSISTENT grid: gridDim.x workgroups (4 per CU) stay resident and walk the work units u = blockIdx.x,
@@ -972,7 +985,10 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_hot_kernel(const HotArgs a) {
 #pragma unroll
   for (int k = 0; k < 3; k++) { const int p = l + 64 * k, j = p >> 1; dofs[k] = (j & 1) * HALF + (j >> 1) * 16 + (p & 1) * 8; }
   const int coff = h * HALF + 16 * n;   // chunk 2(n + s) + h of the wave's window
-  const uint32_t negx = a.negative ? (127u << 3) : 0u;
+  // phase counters of the lane's samples 0 and 1 relative to the wave's first sample, as a 16-bit pair (only bits 8..14
+  // of a counter pick the table entry); the wave's part is scalar and joins per tile in one v_pk_add_u16 per sample pair
+  const uint32_t lane_cnt = (uint32_t)(MF_BLK * n + 8 * h) * a.inc;
+  const uint32_t lane_pair = (lane_cnt & 0xffffu) | ((lane_cnt + a.inc) << 16);
 
 #ifdef K1_STAMPS   // diagnostic build: shader-clock stamps at the phase boundaries, summed per phase per wave
   unsigned long long st_acc[5] = {0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
@@ -1078,21 +1094,32 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_hot_kernel(const HotArgs a) {
     K1_STAMP(2);
 
     // ---- epilogue: lane (n, h) owns group 2n + h of the wave ----
-    const int rel0 = a.base0_rel + (q0 + gw) * 8 + MF_BLK * n + 8 * h;
-    int2 L[8];
+    const uint32_t wave_cnt = (a.n0_lo + (uint32_t)(a.base0_rel + (q0 + gw) * 8)) * a.inc;   // scalar unit
+    int L[8][3];
 #ifdef K1_ABL_NOEPI
     if (false) {
 #else
     if (ROT) {
 #endif
       typedef int v2i __attribute__((ext_vector_type(2)));
-      typedef __attribute__((address_space(3))) const v2i lds_v2i;
-      const uint32_t cnt0 = mulu24a(a.n0_lo + (uint32_t)rel0, a.inc);
 #pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const uint32_t off = (((cnt0 + (uint32_t)j * a.inc) >> 5) & (127u << 3)) ^ negx;
-        const v2i e = *reinterpret_cast<lds_v2i *>((uintptr_t)off);
-        L[j] = make_int2(e.x, e.y);
+      for (int jj = 0; jj < 4; jj++) {
+        const uint32_t wc = (wave_cnt + 2u * jj * a.inc) & 0xffffu, wpair = wc | (wc << 16);
+        uint32_t pr, o0, o1;
+        asm("v_pk_add_u16 %0, %1, %2" : "=v"(pr) : "v"(lane_pair), "s"(wpair));
+        if (WIDE) {
+          asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(o0) : "s"(4), "v"(pr));
+          asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(o1) : "s"(4), "v"(pr));
+          const v4i e0 = *reinterpret_cast<__attribute__((address_space(3))) const v4i *>((uintptr_t)o0);
+          const v4i e1 = *reinterpret_cast<__attribute__((address_space(3))) const v4i *>((uintptr_t)o1);
+          L[2 * jj][0] = e0.x; L[2 * jj][1] = e0.y; L[2 * jj][2] = e0.z;
+          L[2 * jj + 1][0] = e1.x; L[2 * jj + 1][1] = e1.y; L[2 * jj + 1][2] = e1.z;
+        } else {
+          o0 = (pr >> 5) & (127u << 3); o1 = (pr >> 21) & (127u << 3);
+          const v2i e0 = *reinterpret_cast<__attribute__((address_space(3))) const v2i *>((uintptr_t)o0);
+          const v2i e1 = *reinterpret_cast<__attribute__((address_space(3))) const v2i *>((uintptr_t)o1);
+          L[2 * jj][0] = e0.x; L[2 * jj][1] = e0.y; L[2 * jj + 1][0] = e1.x; L[2 * jj + 1][1] = e1.y;
+        }
       }
     }
     int2 sum = make_int2(0, 0);
@@ -1107,8 +1134,8 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_hot_kernel(const HotArgs a) {
       asm("" : "+v"(tre)); asm("" : "+v"(tim));   // no re-association into 2 shifts + add3
       const int rr = (int)((tre << 8) + (unsigned)acc_ll[2 * j]) >> 14, ri = (int)((tim << 8) + (unsigned)acc_ll[2 * j + 1]) >> 14;
       if (ROT) {
-        const int x = sub32(mul24a(L[j].x, rr), mul24a(L[j].y, ri));
-        const int y = mad24a(L[j].x, ri, mul24a(L[j].y, rr));
+        const int x = WIDE ? mad24a(L[j][0], rr, mul24a(L[j][2], ri)) : sub32(mul24a(L[j][0], rr), mul24a(L[j][1], ri));
+        const int y = mad24a(L[j][0], ri, mul24a(L[j][1], rr));
         sum.x = add_hi16(x, sum.x); sum.y = add_hi16(y, sum.y);
       } else {
         sum.x = (int)((unsigned)sum.x + (unsigned)rr); sum.y = (int)((unsigned)sum.y + (unsigned)ri);
@@ -1783,7 +1810,8 @@ struct sdrhip_iqbb_i16 {
         ha.dq = gx / ha.G; ha.dr = gx % ha.G;
         const dim3 hgrid((unsigned)gx, 1);
         static const int hot_nh[4] = {3, 5, 7, 9};
-        const size_t hlds = 1024 + (size_t)(S + hot_nh[hot_range < 0 ? 3 : hot_range]) * 64 * 16 + 4 * (size_t)(HOT_RAWB + 2 * HOT_PLB);
+        const int hnh = hot_nh[hot_range < 0 ? 3 : hot_range];
+        const size_t hlds = (hot_wide_table(hnh) ? 4096 : 1024) + (size_t)(S + hnh) * 64 * 16 + 4 * (size_t)(HOT_RAWB + 2 * HOT_PLB);
         launch_hot(hot_range, inc != 0, epi, hgrid, block, hlds, ctx->stream, ha);
         a.border = 1; a.bt_hi = t_hi; a.tpw = 1;
         grid = dim3(1, C);
