@@ -966,15 +966,22 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_hot_kernel(const HotArgs a) {
   skip_cold(u, c, g, tile, tile_end);
   // piece k (0..2) of a wave window: one DMA wave-instruction, 64 (the last: 32) lanes x 16 bytes. The window of
   // tile t starts at sample base0_rel + (t * OG - ovl + gw) * 8 - 128 of the channel's row.
+  const uint32_t lane_byte = 16u * (uint32_t)l;
   auto dma_piece = [&](int c_, int tile_, int k) {
-    const uint32_t *src = a.in + (long)c_ * a.in_stride + (a.base0_rel + (tile_ * a.OG - a.ovl + gw) * 8 - (HOT_WIN - 512));
+    // (scalar base + the lane's 32-bit byte offset: the address needs no vector arithmetic per piece)
+    const char *src = reinterpret_cast<const char *>(a.in + (long)c_ * a.in_stride + (a.base0_rel + (tile_ * a.OG - a.ovl + gw) * 8 - (HOT_WIN - 512)));
 #ifndef K1_ABL_NOFETCH
     if (k < 2 || l < (HOT_WIN / 4 - 128))   // 160 pieces of 16 bytes: two full wave-instructions and 32 lanes of a third
 #else
     if (false)
 #endif
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 4 * (l + 64 * k)),
-                                       (__attribute__((address_space(3))) void *)(raw + 64 * k), 16, 0, 0);
+    {   // (the instruction's immediate offset applies to the global AND the LDS address: piece k is +1024 bytes in both)
+      const auto *g = (const __attribute__((address_space(1))) void *)(src + lane_byte);
+      auto *d = (__attribute__((address_space(3))) void *)raw;
+      if (k == 0) __builtin_amdgcn_global_load_lds(g, d, 16, 0, 0);
+      else if (k == 1) __builtin_amdgcn_global_load_lds(g, d, 16, 1024, 0);
+      else __builtin_amdgcn_global_load_lds(g, d, 16, 2048, 0);
+    }
   };
   if (u < a.U) { dma_piece(c, tile, 0); dma_piece(c, tile, 1); dma_piece(c, tile, 2); }
   __syncthreads();   // tap fragments and table in place (the only workgroup barrier)
@@ -1017,7 +1024,7 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_hot_kernel(const HotArgs a) {
     // Fairness: the SIMD arbitrates its waves by priority, then AGE, and in a persistent grid the ages never change —
     // the oldest wave of a SIMD ran at full speed and was done after 64 us, the youngest starved and finished alone
     // at 120 us (s_memrealtime stamps). The priority rotates over the SIMD's four wave slots, one step per tile.
-    if (K1_PRIO_ROT) {
+    if (K1_PRIO_ROT == 1) {
       switch ((prio_it++ + prio_slot) & 3u) {
         case 0: __builtin_amdgcn_s_setprio(0); break;
         case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -1053,6 +1060,9 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_hot_kernel(const HotArgs a) {
     asm volatile("" ::: "memory");
 
     // ---- K loop: operands of step s+1 in flight while the MFMAs of step s issue ----
+    if (K1_PRIO_ROT == 2) __builtin_amdgcn_s_setprio(3);
+    if (K1_PRIO_ROT == 3) { if ((prio_it + prio_slot) & 1u) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); }
+    if (K1_PRIO_ROT == 4) __builtin_amdgcn_s_setprio(0);
     v16i acc_hh = {0}, acc_mid = {0}, acc_ll = {0};
 #pragma unroll
     for (int r = 0; r < 16; r++) acc_ll[r] = (r & 1) ? a.cim : a.cre;   // + 128*sum(a) rides in as C
@@ -1094,6 +1104,9 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_hot_kernel(const HotArgs a) {
     K1_STAMP(2);
 
     // ---- epilogue: lane (n, h) owns group 2n + h of the wave ----
+    if (K1_PRIO_ROT == 2) __builtin_amdgcn_s_setprio(0);
+    if (K1_PRIO_ROT == 3) { if ((prio_it++ + prio_slot) & 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+    if (K1_PRIO_ROT == 4) __builtin_amdgcn_s_setprio(3);
     const uint32_t wave_cnt = (a.n0_lo + (uint32_t)(a.base0_rel + (q0 + gw) * 8)) * a.inc;   // scalar unit
     int L[8][3];
 #ifdef K1_ABL_NOEPI
