@@ -370,7 +370,9 @@ __device__ __forceinline__ int prev_group_value(int v, int h) {
 // mid, ll) -> recombine -> >>14 -> rotate by LUT[idx(n)] -> sum of the (product >> 16) = the decimation window's sum.
 // The rotation table sits at LDS offset 0 (dynamic LDS starts there: the kernel has no static LDS), so a table
 // read's address is the byte offset itself.
-template <bool ROT, bool CU8, bool EDGE>
+// TBL: the table's layout at LDS offset 0 — 0: 128 x {Lx, Ly} in table order (a negative shift reads entry 127 - i);
+// 1: the same stored reversed for a negative shift; 2: 16-byte entries {Lx, Ly, -Ly, 0}, stored reversed (hot kernel)
+template <bool ROT, bool CU8, bool EDGE, int TBL = 0>
 __device__ __forceinline__ int2 group_sum(const IqbbArgs &a, const v16i &acc_hh, const v16i &acc_mid, const v16i &acc_ll, int rel0) {
   typedef int v2i __attribute__((ext_vector_type(2)));
   typedef __attribute__((address_space(3))) const v2i lds_v2i;
@@ -378,10 +380,11 @@ __device__ __forceinline__ int2 group_sum(const IqbbArgs &a, const v16i &acc_hh,
   if (ROT) {   // 8 independent table reads in flight while the accumulators are recombined
     // phase counter of the lane's first sample; only its low 15 bits matter, so a 24-bit multiply is exact enough
     const uint32_t cnt0 = mulu24a(a.n0_lo + (uint32_t)rel0, a.inc);
-    const uint32_t negx = a.negative ? (127u << 3) : 0u;
+    const uint32_t negx = (TBL == 0 && a.negative) ? (127u << 3) : 0u;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      const uint32_t off = (((cnt0 + (uint32_t)j * a.inc) >> 5) & (127u << 3)) ^ negx;   // j * inc: wave-uniform
+      const uint32_t cj = cnt0 + (uint32_t)j * a.inc;   // j * inc: wave-uniform
+      const uint32_t off = TBL == 2 ? ((cj >> 4) & (127u << 4)) : ((cj >> 5) & (127u << 3)) ^ negx;
       const v2i e = *reinterpret_cast<lds_v2i *>((uintptr_t)off);
       L[j] = make_int2(e.x, e.y);
     }
@@ -720,7 +723,7 @@ __device__ __forceinline__ bool slice_is_hot(int base0_rel, int OG, int ovl, int
 // Tiles that touch the call's borders (history, zeros, end of input) fill the raw buffer by ordinary loads.
 // =================================================================================================
 template <int S, bool ROT>
-__global__ __launch_bounds__(TPB, 4) void iqbb_i16_mfma_dma_kernel(const IqbbArgs a) {
+__device__ __forceinline__ void iqbb_i16_mfma_dma_body(const IqbbArgs &a, const int bx, const int c) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   constexpr int OPc = 16 * (S - 1) + 1;
   constexpr int PLW = (2 * (TI + OPc) + 64 + 31) / 32 * 8;    // dwords per byte plane
@@ -732,13 +735,13 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_mfma_dma_kernel(const IqbbArg
   uint4 *raw = reinterpret_cast<uint4 *>(smem + 256 + 2 * PLW);
   v4i *taps_s = reinterpret_cast<v4i *>(smem + 256 + 2 * PLW + 4 * RAWQ);
 
-  const int c = blockIdx.y, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   const int w = tid >> 6, l = tid & 63, n = l & 31, h = l >> 5;
   for (int i = tid; i < S * 2 * 64; i += TPB) taps_s[i] = a.tapfrag[i];
   if (tid < 128) lut_s[tid] = a.lut[tid];
 
-  int tile_end = min((int)(blockIdx.x + 1) * a.tpw, a.tiles);
-  int tile = blockIdx.x * a.tpw;
+  int tile_end = min((bx + 1) * a.tpw, a.tiles);
+  int tile = bx * a.tpw;
   // border launch: ONE workgroup per channel walks tile 0 and then the tiles bt_hi .. tiles-1 (the next tile's raw
   // samples are staged during the current one's compute, the tap fragments are fetched once)
   if (a.border) { tile = 0; tile_end = a.tiles; }
@@ -877,7 +880,10 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_mfma_dma_kernel(const IqbbArg
     }
   }
 }
-
+template <int S, bool ROT>
+__global__ __launch_bounds__(TPB, 4) void iqbb_i16_mfma_dma_kernel(const IqbbArgs a) {
+  iqbb_i16_mfma_dma_body<S, ROT>(a, (int)blockIdx.x, (int)blockIdx.y);
+}
 
 // =================================================================================================
 // Path 1's HOT kernel (complex<int16> input, D = 8): only tiles whose windows lie wholly inside the call (no
@@ -908,6 +914,7 @@ struct HotArgs {
   int t_lo, t_hi, tpw;                  // hot tiles [t_lo, t_hi); a work unit = tpw consecutive ones of a channel
   int G, U, dq, dr;                     // units per channel, units in all, gridDim.x / G and gridDim.x % G (persistent grid)
   int N, n_out;                         // samples per channel in this call, groups emitted (slice_is_hot)
+  int C;                                // channels (cold phase)
   int cre, cim;
 };
 
@@ -917,7 +924,7 @@ constexpr int HOT_PLB = 2 * HOT_WIN + 32;          // bytes per byte plane (+ on
 constexpr int HOT_RAWB = HOT_WIN * 4;               // raw area: 160 pieces of 16 bytes = two DMA wave-instructions + 32 lanes of a third
 
 template <int S, int S0, int NH, bool ROT, int EPI>
-__global__ __launch_bounds__(TPB, 4) void iqbb_i16_hot_kernel(const HotArgs a) {
+__device__ __forceinline__ void iqbb_i16_hot_body(const HotArgs &a, const int bx, const int gx, const IqbbArgs *cold) {
   static_assert(S == 9, "window geometry (HOT_WIN) is the 127-tap one");
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   // Rotation table at LDS offset 0. WIDE (the high-plane range leaves room: NH <= 5): 256 entries of 16 bytes
@@ -944,20 +951,20 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_hot_kernel(const HotArgs a) {
   }
 
   const int OGw = 64 - a.ovl, gw = w * OGw;
-  // PERSISTENT grid: gridDim.x workgroups (4 per CU) stay resident and walk the work units u = blockIdx.x,
-  // blockIdx.x + gridDim.x, ...; unit u = (channel u / G, tile group u % G of `tpw` consecutive hot tiles). With one
+  // PERSISTENT grid: gx workgroups (4 per CU) stay resident and walk the work units u = bx,
+  // bx + gx, ...; unit u = (channel u / G, tile group u % G of `tpw` consecutive hot tiles). With one
   // workgroup per unit the waves of a workgroup — no barrier holds them together any more — finished up to 2x apart,
   // the workgroup's LDS and its fast waves' register slots stayed allocated until the slowest wave was done, and only
   // ~3 of the 4 workgroups per CU were resident in steady state (2.74 waves per SIMD on average, measured with
   // s_memrealtime stamps). All units are the same length, so the static assignment balances.
-  int u = blockIdx.x;
+  int u = bx;
   int c = u / a.G, g = u - c * a.G;   // (one division per wave, at start; afterwards (c, g) advance by (dq, dr))
   int tile = a.t_lo + g * a.tpw, tile_end = min(tile + a.tpw, a.t_hi);
   // (a wave walks only its hot slices — slice_is_hot — of these tiles; the others belong to the border launch)
   auto skip_cold = [&](int &u_, int &c_, int &g_, int &tile_, int &tile_end_) {
     while (u_ < a.U && !slice_is_hot(a.base0_rel, a.OG, a.ovl, a.N, a.n_out, tile_, w)) {
       if (++tile_ >= tile_end_) {
-        u_ += (int)gridDim.x; c_ += a.dq; g_ += a.dr;
+        u_ += gx; c_ += a.dq; g_ += a.dr;
         if (g_ >= a.G) { g_ -= a.G; c_++; }
         tile_ = a.t_lo + g_ * a.tpw; tile_end_ = min(tile_ + a.tpw, a.t_hi);
       }
@@ -967,23 +974,26 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_hot_kernel(const HotArgs a) {
   // piece k (0..2) of a wave window: one DMA wave-instruction, 64 (the last: 32) lanes x 16 bytes. The window of
   // tile t starts at sample base0_rel + (t * OG - ovl + gw) * 8 - 128 of the channel's row.
   const uint32_t lane_byte = 16u * (uint32_t)l;
-  auto dma_piece = [&](int c_, int tile_, int k) {
-    // (scalar base + the lane's 32-bit byte offset: the address needs no vector arithmetic per piece)
-    const char *src = reinterpret_cast<const char *>(a.in + (long)c_ * a.in_stride + (a.base0_rel + (tile_ * a.OG - a.ovl + gw) * 8 - (HOT_WIN - 512)));
+  // the lane's global pointer into the window of (channel, tile): scalar base + the lane's 32-bit byte offset, ONE
+  // 64-bit vector add per tile; the pieces differ by the instruction's immediate offset
+  auto dma_src = [&](int c_, int tile_) {
+    return reinterpret_cast<const char *>(a.in + (long)c_ * a.in_stride + (a.base0_rel + (tile_ * a.OG - a.ovl + gw) * 8 - (HOT_WIN - 512))) + lane_byte;
+  };
+  auto dma_piece = [&](const char *src, int k) {
 #ifndef K1_ABL_NOFETCH
     if (k < 2 || l < (HOT_WIN / 4 - 128))   // 160 pieces of 16 bytes: two full wave-instructions and 32 lanes of a third
 #else
     if (false)
 #endif
     {   // (the instruction's immediate offset applies to the global AND the LDS address: piece k is +1024 bytes in both)
-      const auto *g = (const __attribute__((address_space(1))) void *)(src + lane_byte);
+      const auto *g = (const __attribute__((address_space(1))) void *)src;
       auto *d = (__attribute__((address_space(3))) void *)raw;
       if (k == 0) __builtin_amdgcn_global_load_lds(g, d, 16, 0, 0);
       else if (k == 1) __builtin_amdgcn_global_load_lds(g, d, 16, 1024, 0);
       else __builtin_amdgcn_global_load_lds(g, d, 16, 2048, 0);
     }
   };
-  if (u < a.U) { dma_piece(c, tile, 0); dma_piece(c, tile, 1); dma_piece(c, tile, 2); }
+  if (u < a.U) { const char *s0 = dma_src(c, tile); dma_piece(s0, 0); dma_piece(s0, 1); dma_piece(s0, 2); }
   __syncthreads();   // tap fragments and table in place (the only workgroup barrier)
 
   // plane byte offsets of this lane's pieces: chunk j = p >> 1 (8 samples), parity-split halves, 8 bytes per piece
@@ -1011,12 +1021,14 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_hot_kernel(const HotArgs a) {
     // the step after this one: next tile of the unit, or the first tile of the workgroup's next unit
     int nu = u, nc = c, ng = g, ntile = tile + 1, ntile_end = tile_end;
     if (ntile >= tile_end) {
-      nu = u + (int)gridDim.x; nc = c + a.dq; ng = g + a.dr;
+      nu = u + gx; nc = c + a.dq; ng = g + a.dr;
       if (ng >= a.G) { ng -= a.G; nc++; }
       ntile = a.t_lo + ng * a.tpw; ntile_end = min(ntile + a.tpw, a.t_hi);
     }
     skip_cold(nu, nc, ng, ntile, ntile_end);
     const bool more = nu < a.U;
+    const char *nsrc = dma_src(nc, ntile);   // (held in two vector registers through the K loop)
+    asm volatile("" : "+v"(nsrc));
     const int q0 = tile * a.OG - a.ovl;
 #ifndef K1_PRIO_ROT
 #define K1_PRIO_ROT 1
@@ -1072,7 +1084,7 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_hot_kernel(const HotArgs a) {
     if (S0 == 0) Ah = taps_s[S * 64 + l];
 #ifdef K1_ABL_NOKLOOP
     acc_mid[0] = uh.x ^ ul.x ^ Al.x ^ Ah.x;
-    if (more) { dma_piece(nc, ntile, 0); dma_piece(nc, ntile, 1); dma_piece(nc, ntile, 2); }
+    if (more) { dma_piece(nsrc, 0); dma_piece(nsrc, 1); dma_piece(nsrc, 2); }
 #else
 #pragma unroll
     for (int s = 0; s < S; s++) {
@@ -1093,7 +1105,7 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_hot_kernel(const HotArgs a) {
       // the next step's three DMA instructions, spread over the K loop (the raw area is free: it was split above)
       if (more && (s == 1 || s == 4 || s == 7)) {
         asm volatile("" ::: "memory");
-        dma_piece(nc, ntile, (s - 1) / 3);
+        dma_piece(nsrc, (s - 1) / 3);
         asm volatile("" ::: "memory");
       }
     }
@@ -1179,15 +1191,98 @@ __global__ __launch_bounds__(TPB, 4) void iqbb_i16_hot_kernel(const HotArgs a) {
 #endif
     u = nu; c = nc; g = ng; tile = ntile; tile_end = ntile_end;
   }
+  // ---- the call's COLD slices (cold != nullptr: the one-launch form) --------------------------------------------
+  // The slices slice_is_hot() rejects — history in the window, the call's first group, incomplete or unemitted
+  // groups, the end of the input — are a few per channel (2 of 130 on the headline workload). Each workgroup, done
+  // with its hot units, takes the channels bx, bx + gx, ...: wave w computes slice w of tile 0 and of the tiles from
+  // bt_hi on where that slice is cold, out of the same LDS-resident tap fragments and table (a separate border
+  // launch had to fetch them again per channel: 16 us per step), with the general kernel's epilogue (edge masks,
+  // carry, first-sample quirk, state); then the workgroup rolls the channel's FIR history.
+  if (cold != nullptr) {
+    const IqbbArgs &b = *cold;
+    for (int cc = bx; cc < a.C; cc += gx) {
+      for (int t = 0; t < b.tiles; t = (t == 0 ? max(b.bt_hi, 1) : t + 1)) {
+        const int q0 = t * a.OG - a.ovl, groups_here = min(b.CG, b.n_groups - q0);
+        if (slice_is_hot(a.base0_rel, a.OG, a.ovl, a.N, a.n_out, t, w) || gw + a.ovl >= groups_here) continue;
+        // the wave's window by ordinary loads: history / input / zeros per sample, every load issued from a clamped
+        // address and masked afterwards (all 10 in flight together)
+        const int first = a.base0_rel + (q0 + gw) * 8 - (HOT_WIN - 512);
+        const uint32_t *row = a.in + (long)cc * a.in_stride, *hrow = b.hist_old + (long)cc * b.HH;
+        uint32_t v[3][4];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const int pp = min(l + 64 * k, HOT_WIN / 4 - 1);
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int rel = first + 4 * pp + j, hh = b.HH + rel;
+            const uint32_t *src = rel >= 0 ? row + min(rel, a.N - 1) : hrow + max(hh, 0);
+            v[k][j] = *src;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const int pp = min(l + 64 * k, HOT_WIN / 4 - 1);
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int rel = first + 4 * pp + j;
+            if (rel >= a.N || b.HH + rel < 0) v[k][j] = 0u;
+          }
+          if (k < 2 || l < (HOT_WIN / 4 - 128)) {
+            uint2 l2, h2;
+            l2.x = __builtin_amdgcn_perm(v[k][1], v[k][0], 0x06040200u) ^ 0x80808080u;
+            l2.y = __builtin_amdgcn_perm(v[k][3], v[k][2], 0x06040200u) ^ 0x80808080u;
+            h2.x = __builtin_amdgcn_perm(v[k][1], v[k][0], 0x07050301u);
+            h2.y = __builtin_amdgcn_perm(v[k][3], v[k][2], 0x07050301u);
+            *reinterpret_cast<uint2 *>(lo + dofs[k]) = l2;
+            *reinterpret_cast<uint2 *>(hi + dofs[k]) = h2;
+          }
+        }
+        asm volatile("" ::: "memory");   // (one wave's LDS operations execute in order: the reads below see these writes)
+        v16i acc_hh = {0}, acc_mid = {0}, acc_ll = {0};
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc_ll[r] = (r & 1) ? a.cim : a.cre;
+        const char *pl = lo + coff, *ph = hi + coff;
+#pragma unroll
+        for (int s_ = 0; s_ < S; s_++) {
+          const v4i uh = *reinterpret_cast<const v4i *>(ph + 16 * s_), ul = *reinterpret_cast<const v4i *>(pl + 16 * s_);
+          const v4i Al = taps_s[s_ * 64 + l];
+          acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, uh, acc_mid, 0, 0, 0);
+          acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, ul, acc_ll, 0, 0, 0);
+          if (s_ >= S0 && s_ < S0 + NH) {
+            const v4i Ah = taps_s[(S + s_ - S0) * 64 + l];
+            acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, uh, acc_hh, 0, 0, 0);
+            acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, ul, acc_mid, 0, 0, 0);
+          }
+        }
+        const int tb = a.base0_rel + q0 * 8, rel0 = tb + 8 * gw + MF_BLK * n + 8 * h;
+        const int2 sum = group_sum<ROT, false, true, WIDE ? 2 : 1>(b, acc_hh, acc_mid, acc_ll, rel0);
+        group_finish(b, b.lut, cc, n, h, gw, q0, groups_here, sum);   // (its one table user, the stream's first sample, reads global memory)
+        asm volatile("" ::: "memory");
+      }
+      for (int k = tid; k < b.HH; k += TPB) {   // the FIR history for the next call
+        const long qq = (long)a.N + k;   // index into concat(hist_old, in)
+        b.hist_new[(long)cc * b.HH + k] = qq < b.HH ? b.hist_old[(long)cc * b.HH + qq] : raw_x(b, cc, qq - b.HH);
+      }
+    }
+  }
 #ifdef K1_STAMPS
   if (l == 0) {
-    const unsigned wv = (blockIdx.x * 4 + w) & 32767u;
+    const unsigned wv = ((unsigned)bx * 4 + w) & 32767u;
     for (int i = 0; i < 5; i++) g_k1_stamps[wv * 8 + i] = st_acc[i];
     g_k1_stamps[wv * 8 + 5] = (unsigned long long)st_tiles | ((unsigned long long)__builtin_amdgcn_s_getreg((15 << 11) | 4) << 32);
     g_k1_stamps[wv * 8 + 6] = st_r0;
     g_k1_stamps[wv * 8 + 7] = __builtin_amdgcn_s_memrealtime();
   }
 #endif
+}
+template <int S, int S0, int NH, bool ROT, int EPI>
+__global__ __launch_bounds__(TPB, 4) void iqbb_i16_hot_kernel(const HotArgs a) {
+  iqbb_i16_hot_body<S, S0, NH, ROT, EPI>(a, (int)blockIdx.x, (int)gridDim.x, nullptr);
+}
+// One launch per call: the hot grid, then each workgroup's share of the cold slices (see the cold phase above).
+template <int S, int S0, int NH, bool ROT, int EPI>
+__global__ __launch_bounds__(TPB, 4) void iqbb_i16_hotb_kernel(const HotArgs a, const IqbbArgs b) {
+  iqbb_i16_hot_body<S, S0, NH, ROT, EPI>(a, (int)blockIdx.x, (int)gridDim.x, &b);
 }
 
 // =================================================================================================
@@ -1601,27 +1696,31 @@ __global__ __launch_bounds__(TPB, 3) void iqbb_i16_mfma16_kernel(const IqbbArgs 
 }  // namespace
 
 namespace {
+// b != nullptr: the one-launch form (hot grid + cold phase); otherwise the hot grid alone, the border launch follows
 template <int S0, int NH, bool ROT>
-void launch_hot_e(int epi, dim3 grid, dim3 block, size_t lds, hipStream_t st, const HotArgs &ha) {
+void launch_hot_e(int epi, dim3 grid, dim3 block, size_t lds, hipStream_t st, const HotArgs &ha, const IqbbArgs *b, int C) {
+#define SDRHIP_HOT(E_) do { if (b) hipLaunchKernelGGL((iqbb_i16_hotb_kernel<9, S0, NH, ROT, E_>), grid, block, lds, st, ha, *b); \
+                            else hipLaunchKernelGGL((iqbb_i16_hot_kernel<9, S0, NH, ROT, E_>), grid, block, lds, st, ha); } while (0)
   switch (epi) {
-    case SDRHIP_EPI_FM: hipLaunchKernelGGL((iqbb_i16_hot_kernel<9, S0, NH, ROT, SDRHIP_EPI_FM>), grid, block, lds, st, ha); break;
-    case SDRHIP_EPI_AM: hipLaunchKernelGGL((iqbb_i16_hot_kernel<9, S0, NH, ROT, SDRHIP_EPI_AM>), grid, block, lds, st, ha); break;
-    case SDRHIP_EPI_USB: hipLaunchKernelGGL((iqbb_i16_hot_kernel<9, S0, NH, ROT, SDRHIP_EPI_USB>), grid, block, lds, st, ha); break;
-    default: hipLaunchKernelGGL((iqbb_i16_hot_kernel<9, S0, NH, ROT, SDRHIP_EPI_NONE>), grid, block, lds, st, ha); break;
+    case SDRHIP_EPI_FM: SDRHIP_HOT(SDRHIP_EPI_FM); break;
+    case SDRHIP_EPI_AM: SDRHIP_HOT(SDRHIP_EPI_AM); break;
+    case SDRHIP_EPI_USB: SDRHIP_HOT(SDRHIP_EPI_USB); break;
+    default: SDRHIP_HOT(SDRHIP_EPI_NONE); break;
   }
+#undef SDRHIP_HOT
 }
 template <int S0, int NH>
-void launch_hot_r(bool rot, int epi, dim3 grid, dim3 block, size_t lds, hipStream_t st, const HotArgs &ha) {
-  if (rot) launch_hot_e<S0, NH, true>(epi, grid, block, lds, st, ha);
-  else launch_hot_e<S0, NH, false>(epi, grid, block, lds, st, ha);
+void launch_hot_r(bool rot, int epi, dim3 grid, dim3 block, size_t lds, hipStream_t st, const HotArgs &ha, const IqbbArgs *b, int C) {
+  if (rot) launch_hot_e<S0, NH, true>(epi, grid, block, lds, st, ha, b, C);
+  else launch_hot_e<S0, NH, false>(epi, grid, block, lds, st, ha, b, C);
 }
 // range index r: the K steps [S0, S0 + NH) that run the taps' high plane
-void launch_hot(int r, bool rot, int epi, dim3 grid, dim3 block, size_t lds, hipStream_t st, const HotArgs &ha) {
+void launch_hot(int r, bool rot, int epi, dim3 grid, dim3 block, size_t lds, hipStream_t st, const HotArgs &ha, const IqbbArgs *b, int C) {
   switch (r) {
-    case 0: launch_hot_r<3, 3>(rot, epi, grid, block, lds, st, ha); break;
-    case 1: launch_hot_r<2, 5>(rot, epi, grid, block, lds, st, ha); break;
-    case 2: launch_hot_r<1, 7>(rot, epi, grid, block, lds, st, ha); break;
-    default: launch_hot_r<0, 9>(rot, epi, grid, block, lds, st, ha); break;
+    case 0: launch_hot_r<3, 3>(rot, epi, grid, block, lds, st, ha, b, C); break;
+    case 1: launch_hot_r<2, 5>(rot, epi, grid, block, lds, st, ha, b, C); break;
+    case 2: launch_hot_r<1, 7>(rot, epi, grid, block, lds, st, ha, b, C); break;
+    default: launch_hot_r<0, 9>(rot, epi, grid, block, lds, st, ha, b, C); break;
   }
 }
 }  // namespace
@@ -1637,6 +1736,7 @@ struct sdrhip_iqbb_i16 {
   int CG = 0, OG = 0, ovl = 0;
   bool fast8 = false;
   bool use_dma = true;   // path 1, cs16 input: LDS-DMA fed kernel (SDRHIP_IQBB_DMA=0: the register-staged one, tuning)
+  bool fuse_border = true;   // hot grid and border walk in one launch (SDRHIP_IQBB_FUSE=0: two launches, tuning/tests)
   bool use_hot = true;   // ... with the hot kernel for the interior tiles (SDRHIP_IQBB_HOT=0: general kernel only, tuning/tests)
   int hot_range = -1;    // which compile-time high-plane K-step range of the hot kernel covers ah_mask (-1: none)
   int in_cu8 = 0, real = 0, i8 = 0;   // input kinds: complex<uint8> with AutoCast, real int16 (BaseBand), complex<int8> (IQBaseBand<int8_t>)
@@ -1811,7 +1911,7 @@ struct sdrhip_iqbb_i16 {
         ha.in = in_dev; ha.in_stride = (long)in_stride; ha.out = out_dev; ha.out_stride = (long)out_stride;
         ha.tapfrag = tapfrag.p; ha.lut = lut.p; ha.inc = inc; ha.n0_lo = (uint32_t)(n0 - phase0); ha.negative = negative;
         ha.base0_rel = g.base0_rel; ha.OG = OG; ha.ovl = ovl; ha.t_lo = 0; ha.t_hi = tiles; ha.cre = cre; ha.cim = cim;
-        ha.N = (int)N; ha.n_out = g.n_out;
+        ha.N = (int)N; ha.n_out = g.n_out; ha.C = C;
         const int nhot = tiles;
         // persistent grid of 4 workgroups per CU; units of at most 4 tiles so that the static split leaves a short tail
         const int nwg = 4 * ctx->prop.multiProcessorCount;
@@ -1825,9 +1925,18 @@ struct sdrhip_iqbb_i16 {
         static const int hot_nh[4] = {3, 5, 7, 9};
         const int hnh = hot_nh[hot_range < 0 ? 3 : hot_range];
         const size_t hlds = (hot_wide_table(hnh) ? 4096 : 1024) + (size_t)(S + hnh) * 64 * 16 + 4 * (size_t)(HOT_RAWB + 2 * HOT_PLB);
-        launch_hot(hot_range, inc != 0, epi, hgrid, block, hlds, ctx->stream, ha);
         a.border = 1; a.bt_hi = t_hi; a.tpw = 1;
         grid = dim3(1, C);
+        if (fuse_border) {   // one launch: the hot workgroups finish with the cold slices
+          launch_hot(hot_range, inc != 0, epi, hgrid, block, hlds, ctx->stream, ha, &a, C);
+          SDRHIP_CHECK_HIP(hipGetLastError());
+          par ^= 1;
+          if (fm_flip) par_fm ^= 1;
+          n0 += N;
+          if (n_out) *n_out = (size_t)g.n_out;
+          return;
+        }
+        launch_hot(hot_range, inc != 0, epi, hgrid, block, hlds, ctx->stream, ha, nullptr, C);
       }
 #define SDRHIP_MFD(S_) do { if (inc != 0) hipLaunchKernelGGL((iqbb_i16_mfma_dma_kernel<S_, true>), grid, block, ldsd, ctx->stream, a); \
                              else hipLaunchKernelGGL((iqbb_i16_mfma_dma_kernel<S_, false>), grid, block, ldsd, ctx->stream, a); } while (0)
@@ -1905,6 +2014,7 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
         if (high_byte(taps[i]) > 127 || high_byte(-taps[i]) > 127) mfma_ok = false;
       { const char *d = getenv("SDRHIP_IQBB_DMA"); if (d && d[0] == '0') h->use_dma = false; }
       { const char *d = getenv("SDRHIP_IQBB_HOT"); if (d && d[0] == '0') h->use_hot = false; }
+      { const char *d = getenv("SDRHIP_IQBB_FUSE"); if (d && d[0] == '0') h->fuse_border = false; }
       const char *force = getenv("SDRHIP_IQBB_PATH");   // "valu" / "mfma" / "mfma16": test hook
       if (force && !strcmp(force, "valu")) mfma_ok = false;
       bool mfma16_ok = !real && !i8 && (decim == R) && (order <= 153);
@@ -2003,7 +2113,7 @@ int sdrhip_iqbb_i16_kernel_names(sdrhip_iqbb_i16 *h, char *buf, size_t len) {
     if (h->path == 3) nm = "iqbb_i16_mfmag_kernel";
     else if (h->path == 2) nm = "iqbb_i16_mfma16_kernel";
     else if (h->path == 1 && (h->in_cu8 || !h->use_dma)) nm = "iqbb_i16_mfma_kernel";
-    else if (h->path == 1 && h->S == 9 && h->hot_range >= 0 && h->use_hot) nm = "iqbb_i16_hot_kernel,iqbb_i16_mfma_dma_kernel";
+    else if (h->path == 1 && h->S == 9 && h->hot_range >= 0 && h->use_hot) nm = h->fuse_border ? "iqbb_i16_hotb_kernel" : "iqbb_i16_hot_kernel,iqbb_i16_mfma_dma_kernel";
     else if (h->path == 1) nm = "iqbb_i16_mfma_dma_kernel";
     snprintf(buf, len, "%s", nm);
   });
