@@ -7,6 +7,7 @@
 //   SubSample<Scalar>::_process                       src/subsample.hh:92-101
 // Each lane handles 4 consecutive samples: one 16-byte (cs16) or two 16-byte (cf32) loads, one
 // 8/16-byte store; grid-stride over the (channel, sample) plane.
+#include "fm_phi.hpp"
 #include "sdrhip_internal.hpp"
 
 using namespace sdrhip;
@@ -24,15 +25,6 @@ __device__ __forceinline__ int div_small(int num, int den) {
   if (r < 0) { q -= 1; r += (int)de; }
   if (r >= (int)de) q += 1;
   return num < 0 ? -(int)q : (int)q;
-}
-__device__ __forceinline__ int fm_phi(int a, int b) {   // fast_atan2<int16,int16>(a,b)/2, src/math.hh:31-40
-  const int aabs = a >= 0 ? a : -a;
-  const int num = 4096 * (b >= 0 ? b - aabs : b + aabs);
-  const int den = b >= 0 ? b + aabs : aabs - b;
-  int angle = (b >= 0 ? 4096 : 12288) - div_small(num, den | (den == 0));
-  if (a == 0 && b == 0) angle = 0;
-  const short at = (short)(a >= 0 ? angle : -angle);
-  return (int)at / 2;
 }
 __device__ __forceinline__ short am_i16(int re, int im) {
   const int m = (int)((unsigned)(re * re) + (unsigned)(im * im));

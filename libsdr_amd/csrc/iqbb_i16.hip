@@ -16,6 +16,7 @@
 // The FIR is the hot loop: per input sample 2*order v_dot2_i32_i16 (packed (re,im) int16 sample
 // against taps packed (Kr,-Ki) and (Ki,Kr)); each lane owns 8 consecutive samples and slides a
 // 16-sample register window over an LDS-staged tile; taps arrive through the scalar cache.
+#include "fm_phi.hpp"
 #include "sdrhip_internal.hpp"
 
 #include <cstdlib>
@@ -135,17 +136,6 @@ __device__ __forceinline__ int div_small(int num, int den) {
   return num < 0 ? -(int)q : (int)q;
 }
 
-// fast_atan2<int16_t,int16_t>(a, b) / 2   (src/math.hh:31-40, src/demod.hh:246)
-__device__ __forceinline__ int fm_phi(int a, int b) {
-  const int aabs = a >= 0 ? a : -a;
-  // b >= 0: pi/4 - pi/4*(b-|a|)/(b+|a|);  b < 0: 3pi/4 - pi/4*(b+|a|)/(|a|-b)   — one division either way
-  const int num = 4096 * (b >= 0 ? b - aabs : b + aabs);
-  const int den = b >= 0 ? b + aabs : aabs - b;
-  int angle = (b >= 0 ? 4096 : 12288) - div_small(num, den | (den == 0));
-  if (a == 0 && b == 0) angle = 0;
-  const short at = (short)(a >= 0 ? angle : -angle);
-  return (int)at / 2;
-}
 
 __device__ __forceinline__ short am_i16(int re, int im) {
   const int m = (int)((unsigned)mulw(re, re) + (unsigned)mulw(im, im));

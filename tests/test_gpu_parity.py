@@ -7,6 +7,13 @@ import pytest
 
 import libsdr_amd as sa
 
+try:   # torch brings its own HIP runtime: it only finds the GPU when it initialises before libsdrhip.so does
+    import torch
+    if torch.cuda.device_count() > 0:
+        torch.cuda.init()
+except Exception:   # pragma: no cover
+    torch = None
+
 pytestmark = pytest.mark.gpu
 
 FS = 2.4e6
@@ -33,12 +40,22 @@ def ctx():
     c.close()
 
 
-@pytest.fixture(params=["auto", "valu", "mfma16", "mfmag"])
+@pytest.fixture(params=["auto", "valu", "mfma16", "mfmag", "twolaunch", "general"])
 def k1path(request, monkeypatch):
     """K1 has four bit-exact kernels: int8-MFMA on 32x32x32 tiles for decimation 8 (path 1, picked automatically up to
     257 taps) and for any other decimation (path 3), the 16x16x64 shape (path 2, on request) and the VALU dot2 kernel
-    (path 0: real input, taps that do not fit, longer filters); every K1 test runs under each selection."""
-    if request.param == "valu":
+    (path 0: real input, taps that do not fit, longer filters); every K1 test runs under each selection. Path 1 itself
+    has three forms for 127-tap plans: hot grid + cold phase in one launch (the default), hot grid + border launch
+    ("twolaunch") and the general kernel alone ("general")."""
+    monkeypatch.delenv("SDRHIP_IQBB_FUSE", raising=False)
+    monkeypatch.delenv("SDRHIP_IQBB_HOT", raising=False)
+    if request.param == "twolaunch":
+        monkeypatch.delenv("SDRHIP_IQBB_PATH", raising=False)
+        monkeypatch.setenv("SDRHIP_IQBB_FUSE", "0")
+    elif request.param == "general":
+        monkeypatch.delenv("SDRHIP_IQBB_PATH", raising=False)
+        monkeypatch.setenv("SDRHIP_IQBB_HOT", "0")
+    elif request.param == "valu":
         monkeypatch.setenv("SDRHIP_IQBB_PATH", "valu")
     elif request.param in ("mfma16", "mfmag"):   # preferences: plans they cannot serve fall back to the default choice
         monkeypatch.setenv("SDRHIP_IQBB_PATH", request.param)
@@ -892,3 +909,37 @@ def test_error_codes(ctx, golden):
     with pytest.raises(sa.SdrHipError) as e:
         sa.Context(99)
     assert e.value.code == sa.abi.E_NODEVICE
+
+
+# ---- fast_atan2 over its whole domain ---------------------------------------------------------------------
+
+def test_fm_angle_every_int16_pair(ctx):
+    """fm_phi (libsdr_amd/csrc/fm_phi.hpp: one float-estimated division + an exact remainder test) against the
+    reference's formula (src/math.hh:31-40, src/demod.hh:246) in exact 64-bit integer arithmetic, for EVERY (a, b) in
+    int16 x int16 — 2^32 pairs through the stand-alone FMDemod<int16_t> kernel: every second sample is (0, 0), whose
+    angle is 0, so output 2k+1 is -angle(pair k)."""
+    dev = torch.device("cuda:0")
+    NA = 1024                                   # a-values per call: 2^26 pairs, 2^27 samples
+    n = 2 * NA * 65536
+    node = sa.Demod(ctx, sa.EPI_FM, sa.T_CS16, max_in=n, inplace_fm0=False)
+    b = (torch.arange(65536, device=dev, dtype=torch.int64) - 32768).repeat(NA)
+    x = torch.zeros(n, dtype=torch.int32, device=dev)
+    y = torch.empty(n, dtype=torch.int16, device=dev)
+    for a0 in range(-32768, 32768, NA):
+        a = (torch.arange(NA, device=dev, dtype=torch.int64) + a0).repeat_interleave(65536)
+        x[1::2] = ((a & 0xffff) | ((b & 0xffff) << 16)).to(torch.int32)   # (int64 -> int32 wraps: the packed dword)
+        torch.cuda.synchronize()
+        node.reset()
+        node.process_dev(x.data_ptr(), n, n, y.data_ptr(), n)
+        ctx.synchronize()
+        aabs = a.abs()
+        num = 4096 * torch.where(b >= 0, b - aabs, b + aabs)
+        den = torch.where(b >= 0, b + aabs, aabs - b)
+        q = torch.div(num, den.clamp(min=1), rounding_mode="trunc")
+        angle = torch.where(b >= 0, 4096, 12288) - q
+        angle = torch.where((a == 0) & (b == 0), torch.zeros_like(angle), angle)
+        angle = torch.where(a >= 0, angle, -angle)
+        phi = torch.div(angle, 2, rounding_mode="trunc")
+        got = y[1::2].to(torch.int64)
+        bad = (got != -phi).nonzero()
+        assert bad.numel() == 0, (a0, int(a[bad[0, 0]]), int(b[bad[0, 0]]), int(got[bad[0, 0]]), int(-phi[bad[0, 0]]))
