@@ -8,7 +8,7 @@ north-star chain of BASELINE.json on the per-GPU shard of its config 5 (8192 cha
 Channels are independent, so ranks shard them with no data-path collective (weak scaling);
 taps/LUT are designed on rank 0 and broadcast over RCCL at config time.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload iqbb_fm|iqbb_usb|iqbb_fm_cu8|fir255_fm|fbb_f32|fftconv|fm_demod|subsample8]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload iqbb_fm|iqbb_usb|iqbb_fm_cu8|bb_real_fm|fir255_fm|fbb_f32|fftconv|fm_demod|subsample8]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
@@ -233,6 +233,19 @@ def main():
             desc = "IQBaseBand<int16>(%d-tap Q14 FIR, LUT shift 100 kHz, /%d) -> %s" % (order, D, "USBDemod" if wl == "iqbb_usb" else "FMDemod")
             if wl == "iqbb_fm_cu8":
                 desc = "complex<uint8> -> AutoCast + " + desc
+        elif wl == "bb_real_fm":   # the real-input BaseBand<int16_t> (2 bytes per sample in)
+            taps = sa.design_bb_taps(100e3, 50e3, FS, order)
+            node = sa.BaseBandI16(ctx, taps, sa.design_freqshift_lut_i16(), sa.design_freqshift_inc(100e3, FS), False, D,
+                                  channels=C, max_in=N, epilogue=sa.EPI_FM)
+            in_bytes, alg_bytes = 2.0, 2.0 + 2.0 / D
+            n_out = node.out_count(N) + 1
+            outs = torch.zeros((C, n_out), dtype=torch.int16, device=dev)
+            ins = [synth_cs16(torch, C, N, dev, 1234 + b, chan0=rank * C)[..., 0].contiguous() for b in range(a.batches)]
+            run = lambda b: node.process_dev(ins[b].data_ptr(), N, N, outs.data_ptr(), n_out)
+            dtype = "i16"
+            kernels = node.kernel_names
+            kernel = kernels[0]
+            desc = "BaseBand<int16> real input (%d-tap Q16 FIR, LUT shift 100 kHz, /%d) -> FMDemod" % (order, D)
         elif wl in ("fir255_fm", "fir127_fm"):
             order = 255 if wl == "fir255_fm" else 127
             alpha = torch.from_numpy(sa.design_fir_lowpass(order, 100e3, FS)).to(dev)
@@ -347,7 +360,7 @@ def main():
             "ms_per_step": round(wall / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": desc, "channels_per_gpu": C, "samples_per_channel_per_step": N,
-                       "global_channels": C * world, "input": {2.0: "complex<uint8>", 4.0: "complex<int16>"}.get(in_bytes, "complex<float>"),
+                       "global_channels": C * world, "input": "int16 (real)" if wl == "bb_real_fm" else {2.0: "complex<uint8>", 4.0: "complex<int16>"}.get(in_bytes, "complex<float>"),
                        "parallelism": "channel-sharded x%d, %s" % (world, "output gathered on rank 0 per step (RCCL)" if a.gather else "no data-path collective")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": kernel, "kernels_per_step": kernels,

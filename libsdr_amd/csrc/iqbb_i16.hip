@@ -362,7 +362,7 @@ __device__ __forceinline__ int prev_group_value(int v, int h) {
 // read's address is the byte offset itself.
 // TBL: the table's layout at LDS offset 0 — 0: 128 x {Lx, Ly} in table order (a negative shift reads entry 127 - i);
 // 1: the same stored reversed for a negative shift; 2: 16-byte entries {Lx, Ly, -Ly, 0}, stored reversed (hot kernel)
-template <bool ROT, bool CU8, bool EDGE, int TBL = 0>
+template <bool ROT, bool CU8, bool EDGE, int TBL = 0, int FSH = 14>   // FSH: the FIR's right shift (16: real-input BaseBand)
 __device__ __forceinline__ int2 group_sum(const IqbbArgs &a, const v16i &acc_hh, const v16i &acc_mid, const v16i &acc_ll, int rel0) {
   typedef int v2i __attribute__((ext_vector_type(2)));
   typedef __attribute__((address_space(3))) const v2i lds_v2i;
@@ -389,10 +389,10 @@ __device__ __forceinline__ int2 group_sum(const IqbbArgs &a, const v16i &acc_hh,
     unsigned tim = ((unsigned)acc_hh[2 * j + 1] << 8) + (unsigned)acc_mid[2 * j + 1];
     int rr, ri;
     if (CU8) {   // S = t << 8 exactly
-      rr = (int)(tre << 8) >> 14; ri = (int)(tim << 8) >> 14;
+      rr = (int)(tre << 8) >> FSH; ri = (int)(tim << 8) >> FSH;
     } else {
       asm("" : "+v"(tre)); asm("" : "+v"(tim));
-      rr = (int)((tre << 8) + (unsigned)acc_ll[2 * j]) >> 14; ri = (int)((tim << 8) + (unsigned)acc_ll[2 * j + 1]) >> 14;
+      rr = (int)((tre << 8) + (unsigned)acc_ll[2 * j]) >> FSH; ri = (int)((tim << 8) + (unsigned)acc_ll[2 * j + 1]) >> FSH;
     }
     if (EDGE) { const int rel = rel0 + j; if (rel < 0 || rel >= a.N) { rr = 0; ri = 0; } }   // outside the call: r = 0 -> v = 0
     if (ROT) {
@@ -873,6 +873,119 @@ __device__ __forceinline__ void iqbb_i16_mfma_dma_body(const IqbbArgs &a, const 
 template <int S, bool ROT>
 __global__ __launch_bounds__(TPB, 4) void iqbb_i16_mfma_dma_kernel(const IqbbArgs a) {
   iqbb_i16_mfma_dma_body<S, ROT>(a, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// =================================================================================================
+// Path 4: the real-input BaseBand<int16_t> (src/baseband.hh:425-460), D = 8, on the matrix cores.
+//
+// The element stream is the real sample stream itself (one int16 per sample), a tap is a complex Q16 value, so
+//   Dmat[m = (t, comp)][n = block] = sum_k TapT[m][k] * U[k][n],   TapT[m][k] = K_comp[k - t]
+// with the same 32 x 32 tiles (16 samples x 2 components per block, 32 blocks per wave), the same byte-plane
+// products and the same lane-owned decimation groups as path 1 — only the window of a block advances by 16 elements
+// instead of 32 (a K step's operand is the 16-byte chunk n + 2s + h of a plane: consecutive lanes, consecutive
+// chunks, conflict-free without the parity split), a 127-tap filter needs 5 K steps instead of 9, the FIR's shift
+// is Traits<int16_t>::shift = 16, and the taps must fit two byte planes (|K| < 2^15: a Q16 tap reaches that only for
+// filters wider than half the band; those stay on the VALU kernel).
+// Wave-autonomous like the hot kernel: a wave stages its own 512 + 32S - 16 sample window (its start is 8-sample
+// aligned only: a private copy keeps every operand read 16-byte aligned) into private byte planes — no workgroup
+// barrier in the loop; the next tile's window is loaded into registers before the K loop and written after the
+// epilogue. LDS: table 1 KB | tap fragments [S][2][64] x 16 B | per wave 2 planes of 512 + 32S bytes.
+// =================================================================================================
+template <int S, bool ROT>
+__global__ __launch_bounds__(TPB, 4) void bb_real_mfma_kernel(const IqbbArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  constexpr int WINB = 512 + 32 * S;   // bytes per plane = samples in a wave's window (OP - 1 = 32S - 16 of them the halo, 16 spare)
+  constexpr int NPC = WINB / 8;        // 8-sample pieces (one 16-byte global load each)
+  int2 *lut_s = reinterpret_cast<int2 *>(smem);
+  v4i *taps_s = reinterpret_cast<v4i *>(smem + 256);
+  const int c = blockIdx.y, tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, n = l & 31, h = l >> 5;
+  char *lo = reinterpret_cast<char *>(smem + 256 + S * 2 * 64 * 4) + w * 2 * WINB, *hi = lo + WINB;
+  for (int i = tid; i < S * 2 * 64; i += TPB) taps_s[i] = a.tapfrag[i];
+  if (tid < 128) lut_s[tid] = a.lut[tid];
+
+  const int OGw = 64 - a.ovl, gw = w * OGw;
+  const short *row = reinterpret_cast<const short *>(a.in) + (long)c * a.in_stride;
+  struct __attribute__((packed, aligned(2))) Oct { uint32_t v[4]; };   // 16-byte load from a 2-byte aligned address
+  uint32_t px[2][4];
+  auto fetch = [&](int tile_) {
+    const int ws = a.base0_rel + (tile_ * a.OG - a.ovl + gw) * 8 - (a.OP - 1);   // the window's first sample
+    const bool interior = ws >= 0 && ws + WINB <= a.N;                            // (scalar)
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int p = l + 64 * k;
+      if (p < NPC) {
+        if (interior) {
+          const Oct o = *reinterpret_cast<const Oct *>(row + ws + 8 * p);
+#pragma unroll
+          for (int j = 0; j < 4; j++) px[k][j] = o.v[j];
+        } else {   // history / zeros beyond the call: per sample (load_x sign-extends a real sample into a dword)
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            px[k][j] = (load_x(a, c, ws + 8 * p + 2 * j) & 0xffffu) | (load_x(a, c, ws + 8 * p + 2 * j + 1) << 16);
+        }
+      }
+    }
+  };
+  auto split = [&]() {   // 8 samples -> 8 bytes of the low plane (offset to signed) and 8 of the high plane
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int p = l + 64 * k;
+      if (p < NPC) {
+        uint2 l2, h2;
+        l2.x = __builtin_amdgcn_perm(px[k][1], px[k][0], 0x06040200u) ^ 0x80808080u;
+        l2.y = __builtin_amdgcn_perm(px[k][3], px[k][2], 0x06040200u) ^ 0x80808080u;
+        h2.x = __builtin_amdgcn_perm(px[k][1], px[k][0], 0x07050301u);
+        h2.y = __builtin_amdgcn_perm(px[k][3], px[k][2], 0x07050301u);
+        *reinterpret_cast<uint2 *>(lo + 8 * p) = l2;
+        *reinterpret_cast<uint2 *>(hi + 8 * p) = h2;
+      }
+    }
+  };
+  const int tile_end = min((int)(blockIdx.x + 1) * a.tpw, a.tiles);
+  int tile = blockIdx.x * a.tpw;
+  auto has_work = [&](int tile_) { return tile_ < tile_end && gw + a.ovl < min(a.CG, a.n_groups - (tile_ * a.OG - a.ovl)); };
+  if (has_work(tile)) fetch(tile);
+  __syncthreads();   // tap fragments and table in place (the only workgroup barrier)
+  for (; tile < tile_end; tile++) {
+    const int q0 = tile * a.OG - a.ovl, tb = a.base0_rel + q0 * 8;
+    const int groups_here = min(a.CG, a.n_groups - q0);
+    if (gw + a.ovl < groups_here) {   // wave-uniform: the wave has at least one group of its own
+      split();
+      asm volatile("" ::: "memory");   // (one wave's LDS operations execute in order: the reads below see these writes)
+      if (has_work(tile + 1)) fetch(tile + 1);   // in flight during the K loop and the epilogue
+      v16i acc_hh = {0}, acc_mid = {0}, acc_ll = {0};
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc_ll[r] = (r & 1) ? a.cim : a.cre;   // + 128*sum(K) rides in as C
+      const char *pl = lo + 16 * (n + h), *ph = hi + 16 * (n + h);
+#pragma unroll
+      for (int s = 0; s < S; s++) {
+        const bool has_ah = (a.ah_mask >> s) & 1;   // K steps whose taps all have a zero high byte skip two products
+        const v4i uh = *reinterpret_cast<const v4i *>(ph + 32 * s), ul = *reinterpret_cast<const v4i *>(pl + 32 * s);
+        const v4i Al = taps_s[(2 * s + 1) * 64 + l];
+        acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, uh, acc_mid, 0, 0, 0);
+        acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, ul, acc_ll, 0, 0, 0);
+        if (has_ah) {
+          const v4i Ah = taps_s[(2 * s) * 64 + l];
+          acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, uh, acc_hh, 0, 0, 0);
+          acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, ul, acc_mid, 0, 0, 0);
+        }
+      }
+      const int rel0 = tb + 8 * gw + MF_BLK * n + 8 * h;   // call-relative index of the lane's first sample
+      const bool edge = (tb < 0) || (tb + groups_here * 8 > a.N);
+      int2 sum;
+      if (edge) sum = group_sum<ROT, false, true, 0, 16>(a, acc_hh, acc_mid, acc_ll, rel0);
+      else sum = group_sum<ROT, false, false, 0, 16>(a, acc_hh, acc_mid, acc_ll, rel0);
+      group_finish(a, lut_s, c, n, h, gw, q0, groups_here, sum);
+      asm volatile("" ::: "memory");
+    }
+    if (tile == a.tiles - 1) {   // the channel's last tile rolls the FIR history forward
+      for (int k = tid; k < a.HH; k += TPB) {
+        const long qq = (long)a.N + k;   // index into concat(hist_old, in)
+        a.hist_new[(long)c * a.HH + k] = qq < a.HH ? a.hist_old[(long)c * a.HH + qq] : raw_x(a, c, qq - a.HH);
+      }
+    }
+  }
 }
 
 // =================================================================================================
@@ -1757,7 +1870,30 @@ struct sdrhip_iqbb_i16 {
       tp[pad + i].x = ((uint32_t)(uint16_t)(int16_t)kr) | ((uint32_t)(uint16_t)(int16_t)(-ki) << 16);
       tp[pad + i].y = ((uint32_t)(uint16_t)(int16_t)ki) | ((uint32_t)(uint16_t)(int16_t)kr << 16);
     }
-    if (path >= 1) {   // (a path 3 plan that fell back to the VALU kernel above has path 0 by now)
+    if (path == 4) {
+      // real input: TapT[m = (t, comp)][k] = K_comp[k - t] over the real sample stream (window of a block = OP - 1 + 16
+      // elements, OP = 32S - 15), rows permuted as for path 1; lane (m = l&31, hh = l>>5), byte j of K step s <-> k = 32s+16hh+j
+      std::vector<int> kre(OP, 0), kim(OP, 0);
+      unsigned sre = 0, sim = 0;
+      for (int i = 0; i < order; i++) { kre[pad + i] = taps[2 * i]; kim[pad + i] = taps[2 * i + 1]; sre += (unsigned)taps[2 * i]; sim += (unsigned)taps[2 * i + 1]; }
+      cre = (int)(128u * sre); cim = (int)(128u * sim);
+      std::vector<int8_t> frag((size_t)S * 2 * 64 * 16, 0);
+      for (int st = 0; st < S; st++)
+        for (int l = 0; l < 64; l++)
+          for (int j = 0; j < 16; j++) {
+            const int m = l & 31, hh = l >> 5;
+            const int hC = (m >> 2) & 1, r = (m & 3) + 4 * (m >> 3);
+            const int t = 8 * hC + (r >> 1), comp = r & 1;
+            const int idx = 32 * st + 16 * hh + j - t;
+            const int v = (idx >= 0 && idx < OP) ? (comp ? kim[idx] : kre[idx]) : 0;
+            const int al = ((v + 128) & 255) - 128, ah = (v - al) >> 8;
+            frag[(((size_t)(2 * st) * 64 + l) * 16) + j] = (int8_t)ah;
+            if (ah != 0) ah_mask |= 1u << st;
+            frag[(((size_t)(2 * st + 1) * 64 + l) * 16) + j] = (int8_t)al;
+          }
+      if (!tapfrag.p) tapfrag.alloc((size_t)S * 2 * 64);
+      tapfrag.upload(reinterpret_cast<const v4i *>(frag.data()), (size_t)S * 2 * 64, ctx->stream);
+    } else if (path >= 1) {   // (a path 3 plan that fell back to the VALU kernel above has path 0 by now)
       // interleaved tap vectors a_comp[2i+c] and their Toeplitz fragments, TapT[m][k] = a_comp[k-2t], m = 2t+comp:
       // 32x32x32: lane (m = l&31, hh = l>>5), byte j of K-step s <-> k = 32s+16hh+j
       // 16x16x64: lane (m = l&15, g  = l>>4), byte j of K-step s <-> k = 64s+16g+j
@@ -1843,12 +1979,27 @@ struct sdrhip_iqbb_i16 {
     // MFMA path: one workgroup walks `tpw` consecutive tiles so that the tap fragments are fetched once;
     // keep >= ~8 workgroups per CU in flight for balance
     int tpw = 1;
-    if (path == 1 || path == 2) { tpw = 8; while (tpw > 1 && (size_t)ceil_div((size_t)tiles, (size_t)tpw) * C < 2048) tpw >>= 1; }
-    { const char *t = getenv("SDRHIP_IQBB_TPW"); if (t && (path == 1 || path == 2)) tpw = std::max(1, atoi(t)); }   // tuning hook
+    if (path == 1 || path == 2 || path == 4) { tpw = 8; while (tpw > 1 && (size_t)ceil_div((size_t)tiles, (size_t)tpw) * C < 2048) tpw >>= 1; }
+    { const char *t = getenv("SDRHIP_IQBB_TPW"); if (t && (path == 1 || path == 2 || path == 4)) tpw = std::max(1, atoi(t)); }   // tuning hook
     a.tiles = tiles; a.tpw = tpw; a.border = 0; a.bt_hi = 0;
     a.lpg = 1; while (a.lpg < 64 && a.lpg * 8 < D) a.lpg <<= 1;
     dim3 grid((unsigned)ceil_div((size_t)tiles, (size_t)tpw), C), block(TPB);
-    if (path == 3) {
+    if (path == 4) {
+#define SDRHIP_MFR(S_) do { if (inc != 0) hipLaunchKernelGGL((bb_real_mfma_kernel<S_, true>), grid, block, lds_bytes, ctx->stream, a); \
+                             else hipLaunchKernelGGL((bb_real_mfma_kernel<S_, false>), grid, block, lds_bytes, ctx->stream, a); } while (0)
+      switch (S) {
+        case 1: SDRHIP_MFR(1); break;
+        case 2: SDRHIP_MFR(2); break;
+        case 3: SDRHIP_MFR(3); break;
+        case 4: SDRHIP_MFR(4); break;
+        case 5: SDRHIP_MFR(5); break;
+        case 6: SDRHIP_MFR(6); break;
+        case 7: SDRHIP_MFR(7); break;
+        case 8: SDRHIP_MFR(8); break;
+        default: SDRHIP_MFR(9); break;
+      }
+#undef SDRHIP_MFR
+    } else if (path == 3) {
       int tpw3 = 8; while (tpw3 > 1 && (size_t)ceil_div((size_t)tiles, (size_t)tpw3) * C < 2048) tpw3 >>= 1;
       { const char *t = getenv("SDRHIP_IQBB_TPW"); if (t) tpw3 = std::max(1, atoi(t)); }   // tuning hook
       a.tpw = tpw3;
@@ -2021,7 +2172,16 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
       if (h->path == 0 && mfmag_ok) h->path = 3;
       // a forced formulation is a preference: plans it cannot serve fall back to the default choice
       if (force && !strcmp(force, "mfma16") && mfma16_ok) h->path = 2;
-      if (h->path == 2) {
+      // path 4: real input on the matrix cores — D == 8, at most 9 K steps, taps that fit two byte planes
+      if (real && !i8 && decim == R && order <= 273 && !(force && !strcmp(force, "valu"))) {
+        bool fits = true;
+        for (int i = 0; i < 2 * order && fits; i++) if (high_byte(taps[i]) > 127 || high_byte(-taps[i]) > 127) fits = false;   // (the rule set_taps applies)
+        if (fits) h->path = 4;
+      }
+      if (h->path == 4) {
+        h->S = (order + 15 + 31) / 32;
+        h->OP = 32 * h->S - 15;
+      } else if (h->path == 2) {
         h->S = (2 * order + 14 + 63) / 64;
         h->OP = 32 * h->S - 7;
       } else if (h->path == 1 || h->path == 3) {
@@ -2032,9 +2192,11 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
       }
       h->HH = h->OP;   // one more than the FIR needs: reset(keep_history) must see the whole ring
       h->CG = CG; h->ovl = ovl; h->OG = CG - ovl;
-      if (h->path == 1 || h->path == 2) { h->OG = 4 * (64 - ovl); h->CG = h->OG + ovl; }   // every wave recomputes its own FM overlap group
+      if (h->path == 1 || h->path == 2 || h->path == 4) { h->OG = 4 * (64 - ovl); h->CG = h->OG + ovl; }   // every wave recomputes its own FM overlap group
       h->fast8 = (decim == R);
-      if (h->path == 2) {
+      if (h->path == 4) {
+        h->lds_bytes = 1024 + (size_t)h->S * 2 * 64 * 16 + 4 * 2 * (size_t)(512 + 32 * h->S);
+      } else if (h->path == 2) {
         const size_t PLW = (2 * (size_t)(TI + h->OP) + 64 + 15) / 16 * 4;
         h->lds_bytes = (4 * PLW + 256) * 4;
       } else if (h->path == 3) {
@@ -2100,7 +2262,8 @@ int sdrhip_iqbb_i16_kernel_names(sdrhip_iqbb_i16 *h, char *buf, size_t len) {
   return guarded([&] {
     SDRHIP_REQUIRE(h && buf && len, SDRHIP_E_INVALID, "NULL argument");
     const char *nm = "iqbb_i16_kernel";
-    if (h->path == 3) nm = "iqbb_i16_mfmag_kernel";
+    if (h->path == 4) nm = "bb_real_mfma_kernel";
+    else if (h->path == 3) nm = "iqbb_i16_mfmag_kernel";
     else if (h->path == 2) nm = "iqbb_i16_mfma16_kernel";
     else if (h->path == 1 && (h->in_cu8 || !h->use_dma)) nm = "iqbb_i16_mfma_kernel";
     else if (h->path == 1 && h->S == 9 && h->hot_range >= 0 && h->use_hot) nm = h->fuse_border ? "iqbb_i16_hotb_kernel" : "iqbb_i16_hot_kernel,iqbb_i16_mfma_dma_kernel";

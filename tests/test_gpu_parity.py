@@ -300,12 +300,25 @@ BB_REAL_CASES = [("g10_bb21d8", "g10_real_in"), ("g10_bb127d8_neg_ragged", "g10_
                  ("g10_bb16d1_noshift", "g10_real_in"), ("g10_bb1d3", "g10_real_in"), ("g10_bb127d8_loud", "g10_real_loud_in")]
 
 
+@pytest.fixture(params=["auto", "valu"])
+def bbpath(request, monkeypatch):
+    """The real-input node has two bit-exact kernels: the int8-MFMA formulation (path 4: decimation 8, taps within two byte
+    planes, up to 273 taps) and the VALU kernel (everything else, and on request)."""
+    if request.param == "valu":
+        monkeypatch.setenv("SDRHIP_IQBB_PATH", "valu")
+    else:
+        monkeypatch.delenv("SDRHIP_IQBB_PATH", raising=False)
+    return request.param
+
+
 @pytest.mark.parametrize("case,inp", BB_REAL_CASES)
-def test_bb_real_golden(ctx, golden, case, inp):
+def test_bb_real_golden(ctx, golden, case, inp, bbpath):
     m = golden.meta(case + "_out")
     assert np.array_equal(sa.design_bb_taps(m["Ff"], m["width"], m["Fs"], m["order"]), golden.load(case + "_taps").reshape(-1, 2))
     bb = sa.BaseBandI16(ctx, golden.load(case + "_taps"), sa.design_freqshift_lut_i16(), m["lut_inc"], m["negative"], m["decim"],
                         max_in=4096)
+    if bbpath == "auto" and m["decim"] == 8:
+        assert bb.kernel_names == ["bb_real_mfma_kernel"]
     x = golden.load(inp)
     outs, off = [], 0
     for n in m["in_lens"]:
@@ -316,7 +329,7 @@ def test_bb_real_golden(ctx, golden, case, inp):
 
 @pytest.mark.parametrize("epi", [sa.EPI_NONE, sa.EPI_FM, sa.EPI_USB])
 @pytest.mark.parametrize("order,decim,Fc", [(127, 8, 100e3), (33, 5, -80e3), (16, 1, 0.0), (255, 12, 100e3)])
-def test_bb_real_batched_vs_oracle(ctx, orc, epi, order, decim, Fc):
+def test_bb_real_batched_vs_oracle(ctx, orc, epi, order, decim, Fc, bbpath):
     """5 channels of full-scale random real samples in ragged calls; demodulators chained as the reference would."""
     Fs, C = 1e6, 5
     rng = np.random.default_rng(order * 7 + decim)
@@ -338,7 +351,7 @@ def test_bb_real_batched_vs_oracle(ctx, orc, epi, order, decim, Fc):
                 assert np.array_equal(y[c], r)
 
 
-def test_bb_real_reset_semantics(ctx, orc):
+def test_bb_real_reset_semantics(ctx, orc, bbpath):
     Fs, order = 1e6, 21
     rng = np.random.default_rng(5)
     taps, lut, inc = orc.bb_design(100e3, 50e3, Fs, order), orc.freqshift_lut_i16(), orc.freqshift_inc(100e3, Fs)
@@ -350,6 +363,60 @@ def test_bb_real_reset_semantics(ctx, orc):
     assert np.array_equal(bb.process(x[1])[0], ref.process(x[1]))
     bb.reset(keep_history=False); ref = orc.BaseBandI16(taps, lut, inc, 0, 8)
     assert np.array_equal(bb.process(x[2])[0], ref.process(x[2]))
+
+
+@pytest.mark.parametrize("epi", [sa.EPI_NONE, sa.EPI_FM, sa.EPI_AM])
+@pytest.mark.parametrize("order,Fc", [(127, 100e3), (64, -60e3), (9, 0.0), (273, 100e3)])
+def test_bb_real_long_calls_vs_oracle(ctx, orc, epi, order, Fc, bbpath):
+    """Real-input calls long enough for interior tiles of the MFMA formulation (2016- or 2048-sample tiles, windows by
+    2-byte aligned 16-byte loads: odd call lengths move them over every alignment), retuned mid-stream, state carried."""
+    Fs, C, chunks = 1e6, 3, [20000, 13333, 7, 1, 9999, 4097]
+    rng = np.random.default_rng(order + 17)
+    taps, lut, inc = orc.bb_design(abs(Fc) if Fc else 120e3, 60e3, Fs, order), orc.freqshift_lut_i16(), orc.freqshift_inc(Fc, Fs)
+    bb = sa.BaseBandI16(ctx, taps, lut, inc, Fc < 0, 8, channels=C, max_in=max(chunks), epilogue=epi)
+    if bbpath == "auto":
+        assert bb.kernel_names == ["bb_real_mfma_kernel"]
+    refs = [orc.BaseBandI16(taps, lut, inc, Fc < 0, 8) for _ in range(C)]
+    fms = [orc.FMDemodI16() for _ in range(C)]
+    for n in chunks:
+        x = rng.integers(-32768, 32768, (C, n), dtype=np.int16)
+        y = bb.process(x)
+        for c in range(C):
+            r = refs[c].process(x[c])
+            if epi == sa.EPI_FM:
+                assert np.array_equal(y[c], fms[c].process(r))
+            elif epi == sa.EPI_AM:
+                assert np.array_equal(y[c], orc.am_i16(r))
+            else:
+                assert np.array_equal(y[c], r)
+
+
+def test_bb_real_wide_taps_fall_back(ctx, orc):
+    """Q16 taps beyond two byte planes (only very short filters reach 2^15) keep the VALU kernel — and stay bit-exact."""
+    Fs = 1e6
+    taps = orc.bb_design(200e3, 900e3, Fs, 4)
+    assert np.abs(taps).max() >= 32640
+    lut, inc = orc.freqshift_lut_i16(), orc.freqshift_inc(200e3, Fs)
+    bb = sa.BaseBandI16(ctx, taps, lut, inc, False, 8, max_in=5000)
+    assert bb.kernel_names == ["iqbb_i16_kernel"]
+    x = np.random.default_rng(3).integers(-32768, 32768, 5000, dtype=np.int16)
+    assert np.array_equal(bb.process(x)[0], orc.BaseBandI16(taps, lut, inc, False, 8).process(x))
+
+
+def test_bb_real_full_size_properties(ctx, orc):
+    """1024 channels x 65536 real samples (the BASELINE batch): batching invariance + 8 oracle comparisons over 2 calls."""
+    C, N, D = 1024, 65536, 8
+    taps, lut, inc = orc.bb_design(100e3, 50e3, FS, 127), orc.freqshift_lut_i16(), orc.freqshift_inc(100e3, FS)
+    base = np.ascontiguousarray(synth_channels(orc, 8, N)[..., 0])
+    x = np.ascontiguousarray(base[np.arange(C) % 8])
+    node = sa.BaseBandI16(ctx, taps, lut, inc, False, D, channels=C, max_in=N, epilogue=sa.EPI_FM)
+    assert node.kernel_names == ["bb_real_mfma_kernel"]
+    y1, y2 = node.process(x), node.process(x)
+    for k in range(8):
+        assert (y1[k::8] == y1[k]).all() and (y2[k::8] == y2[k]).all()
+        bb, fm = orc.BaseBandI16(taps, lut, inc, False, D), orc.FMDemodI16()
+        assert np.array_equal(y1[k], fm.process(bb.process(x[k])))
+        assert np.array_equal(y2[k], fm.process(bb.process(x[k])))
 
 
 @pytest.mark.parametrize("epi", [sa.EPI_NONE, sa.EPI_FM])
