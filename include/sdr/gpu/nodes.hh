@@ -8,6 +8,7 @@
 //   sdr::gpu::FMDemod<int16_t>, AMDemod<S>, USBDemod<S>  <->  same names             src/demod.hh:18-264
 //   sdr::gpu::SubSample<complex<...>>       <->  sdr::SubSample<...>                 src/subsample.hh:16-116
 //   sdr::gpu::FilterNode<float>             <->  sdr::FilterNode<float>              src/filternode.hh:232-284
+//   sdr::gpu::FFT, FFTPlan<float|double>    <->  sdr::FFT, sdr::FFTPlan<...>        src/fftplan.hh, src/fftplan_fftw3.hh
 //   sdr::gpu::ChannelBank<int16_t>          many IQBaseBand(+demod) channels in ONE batched kernel launch;
 //                                           sink(c)/source(c) per channel like Combine::sink(i) (src/combine.hh:66-150)
 // Rules reproduced: config() returns silently while the upstream Config is incomplete and throws
@@ -871,6 +872,74 @@ protected:
   std::vector<Out> _outs;
   std::vector<bool> _pending;
   Buffer<cs16> _stageIn, _stageOut;
+};
+
+// =================================================================================================
+// FFT::exec / FFTPlan<float|double> on host buffers (reference src/fftplan.hh:14-36, src/fftplan_fftw3.hh:12-142)
+// =================================================================================================
+/** The reference's FFT module: the same Direction enum, exec<Scalar>(in, out, dir) and exec<Scalar>(inplace, dir). */
+template <class Scalar> class FFTPlan;
+
+class FFT {
+public:
+  typedef enum { FORWARD, BACKWARD } Direction;
+  template <class Scalar>
+  static void exec(const Buffer< std::complex<Scalar> > &in, const Buffer< std::complex<Scalar> > &out, FFT::Direction dir, int device = 0) {
+    FFTPlan<Scalar> plan(in, out, dir, device); plan();
+  }
+  template <class Scalar>
+  static void exec(const Buffer< std::complex<Scalar> > &inplace, FFT::Direction dir, int device = 0) {
+    FFTPlan<Scalar> plan(inplace, dir, device); plan();
+  }
+};
+
+/** FFTPlan<float> and FFTPlan<double>: same constructors and error texts as the FFTW-backed reference classes; the
+ * transform is the library's own (unnormalised either way, like FFTW). Sizes: a power of two, up to 16384 (float) /
+ * 8192 (double) — FFTW takes any size; a size the device plan cannot serve is a ConfigError at construction. */
+template <class Scalar>
+class FFTPlan {
+public:
+  FFTPlan(const Buffer< std::complex<Scalar> > &in, const Buffer< std::complex<Scalar> > &out, FFT::Direction dir, int device = 0)
+    : _in(in), _out(out), _sign(dir == FFT::BACKWARD ? 1 : -1), _device(device) {
+    if (in.size() != out.size()) {
+      ConfigError err;
+      err << "Can not construct FFT plan: input & output buffers are of different size!";
+      throw err;
+    }
+    if (in.isEmpty() || out.isEmpty()) {
+      ConfigError err;
+      err << "Can not construct FFT plan: input or output buffer is empty!";
+      throw err;
+    }
+    _check();
+  }
+  FFTPlan(const Buffer< std::complex<Scalar> > &inplace, FFT::Direction dir, int device = 0)
+    : _in(inplace), _out(inplace), _sign(dir == FFT::BACKWARD ? 1 : -1), _device(device) {
+    if (inplace.isEmpty()) {
+      ConfigError err;
+      err << "Can not construct FFT plan: Buffer is empty!";
+      throw err;
+    }
+    _check();
+  }
+  virtual ~FFTPlan() {}
+  /** Performs the transformation. */
+  void operator() () {
+    detail::configCheck(sdrhip_fft_exec(Device::get(_device), _dtype(), int(_in.size()), _sign, _in.data(), _out.data()), "FFT plan");
+  }
+
+protected:
+  static int _dtype() { return sizeof(Scalar) == 8 ? SDRHIP_T_CF64 : SDRHIP_T_CF32; }
+  void _check() const {
+    const size_t n = _in.size(), nmax = sizeof(Scalar) == 8 ? 8192 : 16384;
+    if (n < 4 || n > nmax || (n & (n - 1))) {
+      ConfigError err;
+      err << "Can not construct FFT plan: the device plan needs a power of two in [4, " << nmax << "], got " << n;
+      throw err;
+    }
+  }
+  Buffer< std::complex<Scalar> > _in, _out;
+  int _sign, _device;
 };
 
 }  // namespace gpu

@@ -218,7 +218,8 @@ int sdrhip_fir_reset(sdrhip_fir *h); /* ring zeroed, as FIRFilter::config does (
 int sdrhip_fir_destroy(sdrhip_fir *h);
 
 /* ---- K4/K5: stand-alone demodulators ------------------------------------------------------ */
-enum { SDRHIP_T_CS16 = 0, SDRHIP_T_CF32 = 1, SDRHIP_T_CS8 = 2 /* complex<int8_t>: FMDemod<int8_t,int16_t> only */ };
+enum { SDRHIP_T_CS16 = 0, SDRHIP_T_CF32 = 1, SDRHIP_T_CS8 = 2 /* complex<int8_t>: FMDemod<int8_t,int16_t> only */,
+       SDRHIP_T_CF64 = 3 /* complex<double>: sdrhip_fft_exec only */ };
 /* kind = SDRHIP_EPI_FM|AM|USB, dtype = SDRHIP_T_*; FM exists for cs16 only (the reference's
  * fast_atan2 has no float form, src/math.hh:9-40). inplace_fm0: 1 -> out[0] = in[0].real() per call
  * (in-place chain), 0 -> out[0] left untouched (the reference leaves it uninitialised). */
@@ -290,6 +291,13 @@ int sdrhip_fftconv_reset(sdrhip_fftconv *h);
 int sdrhip_fftconv_destroy(sdrhip_fftconv *h);
 /* plain batched DFT of the library's own FFT (tests): sign -1 forward / +1 backward, unnormalised */
 int sdrhip_fft_c2c(sdrhip_ctx *ctx, int n, int sign, int batch, const float *in_dev, float *out_dev);
+/* FFTPlan<double> (reference src/fftplan_fftw3.hh:12-76): the same on complex<double>, n a power of two in [2, 8192]
+ * (in-LDS radix-2, double arithmetic, twiddles from a host table made in long double). */
+int sdrhip_fft_c2c_f64(sdrhip_ctx *ctx, int n, int sign, int batch, const double *in_dev, double *out_dev);
+/* FFT::exec / FFTPlan<Scalar>::operator() on HOST buffers (reference src/fftplan.hh:22-36): one transform of n points,
+ * dtype SDRHIP_T_CF32 or SDRHIP_T_CF64, sign -1 = FFT::FORWARD, +1 = FFT::BACKWARD, unnormalised like FFTW. in == out
+ * (the in-place plan) is allowed. */
+int sdrhip_fft_exec(sdrhip_ctx *ctx, int dtype, int n, int sign, const void *in_host, void *out_host);
 
 /* ---- float baseband (BASELINE config 2; build-defined) ---------------------- */
 /* y = SubSample_D( FIR_cf32( x[n] * exp(-2*pi*i*Fc*n/Fs) ) ); the reference has no float

@@ -18,7 +18,7 @@ HEADER = os.path.join(ROOT, "include", "sdrhip.h")
 OK, E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_UNSUPPORTED, E_SIZE = 0, -1, -2, -3, -4, -5, -6
 EPI_NONE, EPI_FM, EPI_AM, EPI_USB = 0, 1, 2, 3
 FIR_CS16_EXACT, FIR_CF32 = 0, 1
-T_CS16, T_CF32, T_CS8 = 0, 1, 2
+T_CS16, T_CF32, T_CS8, T_CF64 = 0, 1, 2, 3
 IN_CS16, IN_CU8 = 0, 1
 FFTCONV_OLA, FFTCONV_OLS = 0, 1
 
@@ -122,6 +122,8 @@ def lib():
             "sdrhip_fftconv_reset": (C.c_int, [vp]),
             "sdrhip_fftconv_destroy": (C.c_int, [vp]),
             "sdrhip_fft_c2c": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+            "sdrhip_fft_c2c_f64": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+            "sdrhip_fft_exec": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
             "sdrhip_fbb_f32_create": (C.c_int, [vp, C.c_double, C.c_double, f64p, C.c_int, C.c_int, C.c_int, sz, pvp]),
             "sdrhip_fbb_f32_out_count": (C.c_int, [vp, sz, psz]),
             "sdrhip_fbb_f32_process": (C.c_int, [vp, vp, sz, sz, vp, sz, psz]),

@@ -461,6 +461,32 @@ __global__ __launch_bounds__(FT) void fft_c2c_kernel(const FftDev p, const int *
   }
 }
 
+// FFTPlan<double> (reference src/fftplan_fftw3.hh:12-76: fftw_plan_dft_1d on complex<double>, unnormalised either way):
+// one workgroup per transform, the block in LDS as double2, bit-reversed load + in-place radix-2 decimation in time,
+// twiddles exp(-2 pi i k / L) from a table made on the host in long double. No BASELINE configuration runs it (the
+// filter bank is the float plan); it is there so that a caller of FFT::exec<double> finds it — L <= 8192 (128 KB of LDS).
+__global__ __launch_bounds__(FT) void fft_c2c_f64_kernel(int L, int lg, const double2 *W, int sign, const double2 *in, double2 *out) {
+  extern __shared__ __attribute__((aligned(16))) double2 xd[];
+  const int tid = threadIdx.x;
+  const double2 *src = in + (long)blockIdx.x * L;
+  double2 *dst = out + (long)blockIdx.x * L;
+  for (int i = tid; i < L; i += FT) xd[__builtin_bitreverse32((unsigned)i) >> (32 - lg)] = src[i];
+  __syncthreads();
+  for (int half = 1, st = L / 2; half < L; half <<= 1, st >>= 1) {
+    for (int b = tid; b < L / 2; b += FT) {
+      const int j = b & (half - 1), base = ((b - j) << 1) + j;
+      double2 w = W[j * st];
+      if (sign > 0) w.y = -w.y;
+      const double2 u = xd[base], v = xd[base + half];
+      const double tr = __dsub_rn(__dmul_rn(v.x, w.x), __dmul_rn(v.y, w.y)), ti = __dadd_rn(__dmul_rn(v.x, w.y), __dmul_rn(v.y, w.x));
+      xd[base] = make_double2(u.x + tr, u.y + ti);
+      xd[base + half] = make_double2(u.x - tr, u.y - ti);
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < L; i += FT) dst[i] = xd[i];
+}
+
 struct FftPlan {
   int L = 0;
   FftDev dev{};
@@ -718,6 +744,46 @@ int sdrhip_fftconv_destroy(sdrhip_fftconv *h) {
     h->ctx->use();
     (void)hipStreamSynchronize(h->ctx->stream);
     delete h;
+  });
+}
+
+int sdrhip_fft_c2c_f64(sdrhip_ctx *ctx, int n, int sign, int batch, const double *in_dev, double *out_dev) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(ctx && in_dev && out_dev && batch >= 1 && (sign == 1 || sign == -1), SDRHIP_E_INVALID, "bad argument");
+    SDRHIP_REQUIRE(n >= 2 && n <= 8192 && (n & (n - 1)) == 0, SDRHIP_E_UNSUPPORTED, "double FFT size %d: need a power of two in [2,8192]", n);
+    ctx->use();
+    int lg = 0; while ((1 << lg) < n) lg++;
+    std::vector<double2> w(n / 2);
+    for (int k = 0; k < n / 2; k++) {
+      const long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)n;
+      w[k] = make_double2((double)cosl(ang), (double)sinl(ang));
+    }
+    DevBuf<double2> W;
+    W.alloc(n / 2); W.upload(w.data(), n / 2, ctx->stream);
+    const size_t lds = (size_t)n * sizeof(double2);
+    allow_big_lds(fft_c2c_f64_kernel, lds);
+    hipLaunchKernelGGL(fft_c2c_f64_kernel, dim3(batch), dim3(FT), lds, ctx->stream, n, lg, W.p, sign,
+                       reinterpret_cast<const double2 *>(in_dev), reinterpret_cast<double2 *>(out_dev));
+    SDRHIP_CHECK_HIP(hipGetLastError());
+    SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));   // the table dies with this scope
+  });
+}
+
+int sdrhip_fft_exec(sdrhip_ctx *ctx, int dtype, int n, int sign, const void *in_host, void *out_host) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(ctx && in_host && out_host, SDRHIP_E_INVALID, "NULL argument");
+    SDRHIP_REQUIRE(dtype == SDRHIP_T_CF32 || dtype == SDRHIP_T_CF64, SDRHIP_E_INVALID, "FFT dtype %d: complex<float> or complex<double>", dtype);
+    ctx->use();
+    const size_t bytes = (size_t)n * (dtype == SDRHIP_T_CF64 ? 16 : 8);
+    DevBuf<char> din, dout;
+    din.alloc(bytes); dout.alloc(bytes);
+    SDRHIP_CHECK_HIP(hipMemcpyAsync(din.p, in_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    int rc;
+    if (dtype == SDRHIP_T_CF64) rc = sdrhip_fft_c2c_f64(ctx, n, sign, 1, reinterpret_cast<const double *>(din.p), reinterpret_cast<double *>(dout.p));
+    else rc = sdrhip_fft_c2c(ctx, n, sign, 1, reinterpret_cast<const float *>(din.p), reinterpret_cast<float *>(dout.p));
+    if (rc != SDRHIP_OK) throw Failure{rc};   // (the message is already set)
+    SDRHIP_CHECK_HIP(hipMemcpyAsync(out_host, dout.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   });
 }
 

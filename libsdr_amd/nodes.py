@@ -519,3 +519,29 @@ def fft_c2c(ctx, x, sign):
         ctx.free(din)
         ctx.free(dout)
     return out
+
+
+def fft_c2c_f64(ctx, x, sign):
+    """Batched DFT on complex<double> (FFTPlan<double>): x is (batch, n, 2) float64."""
+    x = np.ascontiguousarray(x, np.float64)
+    batch, n = x.shape[0], x.shape[1]
+    din, dout = ctx.malloc(x.nbytes), ctx.malloc(x.nbytes)
+    try:
+        ctx.h2d(din, x)
+        check(abi.lib().sdrhip_fft_c2c_f64(ctx.handle, n, sign, batch, C.c_void_p(din), C.c_void_p(dout)))
+        out = np.zeros_like(x)
+        ctx.d2h(out, dout)
+    finally:
+        ctx.free(din)
+        ctx.free(dout)
+    return out
+
+
+def fft_exec(ctx, x, sign):
+    """FFT::exec on a host buffer: x complex64 or complex128, one transform."""
+    x = np.ascontiguousarray(x)
+    assert x.dtype in (np.complex64, np.complex128) and x.ndim == 1
+    out = np.empty_like(x)
+    check(abi.lib().sdrhip_fft_exec(ctx.handle, abi.T_CF64 if x.dtype == np.complex128 else abi.T_CF32, x.shape[0], sign,
+                                    _ptr(x), _ptr(out)))
+    return out

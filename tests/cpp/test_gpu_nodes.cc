@@ -397,6 +397,41 @@ static void testInt8Chain() {
   CHECK(out.data == ref);
 }
 
+// FFT::exec / FFTPlan<float|double> on host buffers against a direct O(n^2) DFT in long double
+template <class Scalar>
+static void testFftPlanOf(size_t n, double tol) {
+  typedef std::complex<Scalar> CS;
+  Buffer<CS> in(n), out(n);
+  for (size_t i = 0; i < n; i++) in[i] = CS(Scalar(std::sin(0.37 * i) + 0.25 * std::cos(1.9 * i)), Scalar(std::cos(0.11 * i * i)));
+  gpu::FFT::exec<Scalar>(in, out, gpu::FFT::FORWARD);
+  double worst = 0, scale = 0;
+  for (size_t k = 0; k < n; k += (n > 256 ? 37 : 1)) {   // sampled bins for the larger sizes
+    std::complex<long double> acc(0, 0);
+    for (size_t i = 0; i < n; i++) {
+      const long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)((i * k) % n) / (long double)n;
+      acc += std::complex<long double>(in[i].real(), in[i].imag()) * std::complex<long double>(cosl(ang), sinl(ang));
+    }
+    worst = std::max(worst, (double)std::abs(acc - std::complex<long double>(out[k].real(), out[k].imag())));
+    scale = std::max(scale, (double)std::abs(acc));
+  }
+  CHECK(worst <= tol * scale);
+  gpu::FFTPlan<Scalar> back(out, gpu::FFT::BACKWARD);   // the in-place plan: backward of the spectrum = n * x
+  back();
+  double werr = 0;
+  for (size_t i = 0; i < n; i++) werr = std::max(werr, (double)std::abs(out[i] / Scalar(n) - in[i]));
+  CHECK(werr <= 20 * tol);
+}
+static void testFftPlan() {
+  testFftPlanOf<float>(64, 2e-6); testFftPlanOf<float>(4096, 2e-6);
+  testFftPlanOf<double>(64, 1e-13); testFftPlanOf<double>(8192, 1e-13);
+  bool threw = false;
+  try { Buffer< std::complex<double> > a(1000), b(1000); gpu::FFTPlan<double> p(a, b, gpu::FFT::FORWARD); } catch (ConfigError &) { threw = true; }
+  CHECK(threw);   // not a power of two: ConfigError at construction
+  threw = false;
+  try { Buffer< std::complex<float> > a(64), b(128); gpu::FFTPlan<float> p(a, b, gpu::FFT::FORWARD); } catch (ConfigError &) { threw = true; }
+  CHECK(threw);   // sizes differ (the reference's check)
+}
+
 int main(int argc, char **argv) {
   if (argc > 1) g_golden = argv[1];
   Logger::get().addHandler(new StreamLogHandler(std::cerr, LOG_WARNING));
@@ -413,6 +448,7 @@ int main(int argc, char **argv) {
     testRealBaseBand();
     testRetuneMidStream();
     testInt8Chain();
+    testFftPlan();
   } catch (std::exception &e) {
     std::printf("FAIL: exception: %s\n", e.what());
     return 2;

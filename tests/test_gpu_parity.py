@@ -646,6 +646,30 @@ def test_fft_vs_numpy(ctx, n):
         assert np.abs(yc - ref).max() / np.abs(ref).max() < 2e-6, (n, sign)
 
 
+@pytest.mark.parametrize("n", [2, 4, 64, 1024, 8192])
+def test_fft_double_vs_numpy(ctx, n):
+    """FFTPlan<double> (reference src/fftplan_fftw3.hh:12-76; FFTW is not in /root/reference: held to numpy's double FFT)."""
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((3, n, 2))
+    xc = x[..., 0] + 1j * x[..., 1]
+    for sign, ref in ((-1, np.fft.fft(xc, axis=1)), (+1, np.fft.ifft(xc, axis=1) * n)):
+        y = sa.fft_c2c_f64(ctx, x, sign)
+        assert np.abs(y[..., 0] + 1j * y[..., 1] - ref).max() / np.abs(ref).max() < 1e-13, (n, sign)
+
+
+@pytest.mark.parametrize("dt,tol", [(np.complex64, 2e-6), (np.complex128, 1e-13)])
+def test_fft_exec_host_buffers(ctx, dt, tol):
+    """FFT::exec on host buffers, forward then backward = n * x."""
+    rng = np.random.default_rng(9)
+    x = (rng.standard_normal(4096) + 1j * rng.standard_normal(4096)).astype(dt)
+    X = sa.fft_exec(ctx, x, -1)
+    assert np.abs(X - np.fft.fft(x.astype(np.complex128))).max() / np.abs(X).max() < tol
+    back = sa.fft_exec(ctx, X, +1)
+    assert np.abs(back / 4096 - x).max() < tol * 10
+    with pytest.raises(sa.abi.SdrHipError):
+        sa.fft_exec(ctx, x[:1000], -1)
+
+
 @pytest.mark.parametrize("N", [1024, 8192])
 def test_fftconv_reference_mode_vs_oracle(ctx, golden, orc, N):
     """FilterSink+FilterSource (overlap-add, 2N-point FFT, N taps) — oracle is FFTW-unpinned; both are
