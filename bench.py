@@ -8,7 +8,7 @@ north-star chain of BASELINE.json on the per-GPU shard of its config 5 (8192 cha
 Channels are independent, so ranks shard them with no data-path collective (weak scaling);
 taps/LUT are designed on rank 0 and broadcast over RCCL at config time.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload iqbb_fm|iqbb_usb|iqbb_fm_cu8|bb_real_fm|fir255_fm|fbb_f32|fftconv|fm_demod|subsample8]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload iqbb_fm|iqbb_usb|iqbb_fm_cu8|bb_real_fm|fir255_fm|fbb_f32|fftconv|fftbank|fm_demod|subsample8]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
@@ -269,10 +269,24 @@ def main():
             dtype, kernel = "f32", "fir_cf32_rt_kernel"
             kernels = [kernel]
             desc = "float baseband: shift 100 kHz -> FIRLowPass<cf32>(127) -> /8"
+        elif wl == "fftbank":   # FilterNode<float>: 4 bands behind ONE forward transform per block (2048-point, overlap-add)
+            import numpy as np
+            bands = [(50e3, 150e3), (-350e3, -250e3), (200e3, 300e3), (-120e3, -20e3)]
+            Ks = [sa.design_fftfilt_spectrum(sa.design_fftfilt_kernel(1024, lo_, hi_, FS)) for lo_, hi_ in bands]
+            node = sa.FFTConv(ctx, sa.FFTCONV_OLA, 2048, Ks, channels=C, max_in=N)
+            in_bytes, alg_bytes = 8.0, 8.0 + 8.0 * len(bands)
+            outs = torch.zeros((len(bands), C, N, 2), dtype=torch.float32, device=dev)
+            ins = [torch.randn((C, N, 2), dtype=torch.float32, device=dev) * 0.3 for b in range(a.batches)]
+            run = lambda b: node.process_dev(ins[b].data_ptr(), N, N, outs.data_ptr(), N)
+            dtype, kernel = "f32", "fftconv_fused_kernel"
+            kernels = [kernel]
+            desc = "FFT filter bank: 2048-point overlap-add, 1024-sample blocks, %d bands behind one forward transform" % len(bands)
         elif wl == "fftconv":
             alpha = sa.design_fir_lowpass(4097, 100e3, FS)
             import numpy as np
             tapsf = np.stack([alpha[::-1], np.zeros_like(alpha)], 1).astype(np.float32)   # h[k] = alpha[order-1-k]
+            if N == 65536:
+                N = 6 * 12288   # whole blocks per call (hop = 16384 - 4096): a ragged last block is a full transform for a third of a hop
             node = sa.FFTConv(ctx, sa.FFTCONV_OLS, 16384, tapsf, channels=C, max_in=N)
             in_bytes, alg_bytes = 8.0, 16.0
             outs = torch.zeros((C, N, 2), dtype=torch.float32, device=dev)

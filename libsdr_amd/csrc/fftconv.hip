@@ -38,12 +38,60 @@ struct FftDev {
   int toff[MAX_PASS];
 };
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a * conj(b)
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }   // a * (-i)
-__device__ __forceinline__ float2 mul_pi(float2 a) { return make_float2(-a.y, a.x); }   // a * (+i)
+// Complex arithmetic on register PAIRS: one packed instruction handles (re, im) together, and the op_sel / neg modifiers
+// of the packed forms (which 32-bit half of each source feeds the low and the high result, negated or not) fold the
+// multiplications by +-i into the add that follows. Written as instructions: left to the compiler's SLP vectoriser the
+// same arithmetic came out as 3 packed instructions per complex product (each computing a half that is thrown away) and
+// one v_mov_b32 per 4 arithmetic instructions to re-pair halves — 1 924 vector instructions per wave and block of the
+// 16384-point filter where the kernel is bound by vector issue (r08's counters: 61 % busy, no other unit above 30 %).
+typedef float v2f __attribute__((ext_vector_type(2)));
+#define PK2(name_, text_)                                                                                             \
+  __device__ __forceinline__ float2 name_(float2 a, float2 b) {                                                        \
+    v2f d;                                                                                                             \
+    asm(text_ : "=v"(d) : "v"(__builtin_bit_cast(v2f, a)), "v"(__builtin_bit_cast(v2f, b)));                           \
+    return __builtin_bit_cast(float2, d);                                                                              \
+  }
+PK2(cadd, "v_pk_add_f32 %0, %1, %2")
+PK2(csub, "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]")
+PK2(cadd_mi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")   // a + (-i) b = (a.x + b.y, a.y - b.x)
+PK2(cadd_pi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]")   // a + (+i) b = (a.x - b.y, a.y + b.x)
+PK2(pk_mul_xx, "v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]")              // (a.x b.x, a.y b.x)
+#undef PK2
+// a * b = (a.x b.x - a.y b.y, a.y b.x + a.x b.y) and a * conj(b): a packed multiply and a packed fused multiply-add
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  const float2 t = pk_mul_xx(a, b);
+  v2f d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]"
+      : "=v"(d) : "v"(__builtin_bit_cast(v2f, a)), "v"(__builtin_bit_cast(v2f, b)), "v"(__builtin_bit_cast(v2f, t)));
+  return __builtin_bit_cast(float2, d);
+}
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) {
+  const float2 t = pk_mul_xx(a, b);
+  v2f d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]"
+      : "=v"(d) : "v"(__builtin_bit_cast(v2f, a)), "v"(__builtin_bit_cast(v2f, b)), "v"(__builtin_bit_cast(v2f, t)));
+  return __builtin_bit_cast(float2, d);
+}
+// the same with a wave-uniform constant factor in a scalar register pair
+template <bool CONJ>
+__device__ __forceinline__ float2 cmul_k(float2 a, float wr, float wi) {
+  const v2f w = {wr, wi};
+  v2f t, d;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(t) : "v"(__builtin_bit_cast(v2f, a)), "s"(w));
+  if (CONJ) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(d) : "v"(__builtin_bit_cast(v2f, a)), "s"(w), "v"(t));
+  else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(__builtin_bit_cast(v2f, a)), "s"(w), "v"(t));
+  return __builtin_bit_cast(float2, d);
+}
+__device__ __forceinline__ float2 mul_mi(float2 a) { return cadd_mi(make_float2(0.f, 0.f), a); }   // a * (-i)
+__device__ __forceinline__ float2 mul_pi(float2 a) { return cadd_pi(make_float2(0.f, 0.f), a); }   // a * (+i)
+// the radix-4 butterfly every pass is made of: (x0..x3) -> (X0..X3), X_m = sum_k x_k exp(SIGN 2 pi i k m / 4); 8 packed adds
+template <int SIGN>
+__device__ __forceinline__ void bfly4(float2 x0, float2 x1, float2 x2, float2 x3, float2 &X0, float2 &X1, float2 &X2, float2 &X3) {
+  const float2 t0 = cadd(x0, x2), t1 = csub(x0, x2), t2 = cadd(x1, x3), d = csub(x1, x3);
+  X0 = cadd(t0, t2); X2 = csub(t0, t2);
+  if (SIGN < 0) { X1 = cadd_mi(t1, d); X3 = cadd_pi(t1, d); }   // t1 -+ i d
+  else { X1 = cadd_pi(t1, d); X3 = cadd_mi(t1, d); }
+}
 
 // LDS index of element i: 4 pad elements after every 64, so that the stride-4 radix-16 pass (lanes 64 elements
 // = 512 B apart) spreads over the banks instead of hitting one
@@ -55,32 +103,23 @@ __device__ __forceinline__ void dft16(float2 *v) {
   constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, H = 0.70710678118654752f;
   // step 1: for each a, the 4-point DFT over b of (v[a], v[a+4], v[a+8], v[a+12]) -> Y_a[c] kept at v[a + 4c]
 #pragma unroll
-  for (int a = 0; a < 4; a++) {
-    const float2 x0 = v[a], x1 = v[a + 4], x2 = v[a + 8], x3 = v[a + 12];
-    const float2 t0 = cadd(x0, x2), t1 = csub(x0, x2), t2 = cadd(x1, x3);
-    const float2 t3 = SIGN < 0 ? mul_mi(csub(x1, x3)) : mul_pi(csub(x1, x3));
-    v[a] = cadd(t0, t2); v[a + 4] = cadd(t1, t3); v[a + 8] = csub(t0, t2); v[a + 12] = csub(t1, t3);
-  }
-  // step 2: Z_a[c] = W16^(a c) Y_a[c]   (W16 = exp(SIGN 2 pi i / 16)); a c in {1,2,3,2,4,6,3,6,9}
-  auto tw = [](float2 z, float wr, float wi) { return make_float2(z.x * wr - z.y * (SIGN * wi), z.x * (SIGN * wi) + z.y * wr); };
-  v[1 + 4] = tw(v[1 + 4], C1, S1);           // a=1,c=1: W^1 = (cos pi/8, SIGN sin pi/8)
-  v[1 + 8] = tw(v[1 + 8], H, H);             // a=1,c=2: W^2
-  v[1 + 12] = tw(v[1 + 12], S1, C1);         // a=1,c=3: W^3
-  v[2 + 4] = tw(v[2 + 4], H, H);             // a=2,c=1: W^2
+  for (int a = 0; a < 4; a++) bfly4<SIGN>(v[a], v[a + 4], v[a + 8], v[a + 12], v[a], v[a + 4], v[a + 8], v[a + 12]);
+  // step 2: Z_a[c] = W16^(a c) Y_a[c]   (W16 = exp(SIGN 2 pi i / 16)); a c in {1,2,3,2,4,6,3,6,9}: the factor is
+  // (wr, SIGN wi), i.e. the constant (wr, wi) or its conjugate
+  constexpr bool CJ = SIGN < 0;
+  v[1 + 4] = cmul_k<CJ>(v[1 + 4], C1, S1);           // a=1,c=1: W^1 = (cos pi/8, SIGN sin pi/8)
+  v[1 + 8] = cmul_k<CJ>(v[1 + 8], H, H);             // a=1,c=2: W^2
+  v[1 + 12] = cmul_k<CJ>(v[1 + 12], S1, C1);         // a=1,c=3: W^3
+  v[2 + 4] = cmul_k<CJ>(v[2 + 4], H, H);             // a=2,c=1: W^2
   v[2 + 8] = SIGN < 0 ? mul_mi(v[2 + 8]) : mul_pi(v[2 + 8]);   // a=2,c=2: W^4 = SIGN i
-  v[2 + 12] = tw(v[2 + 12], -H, H);          // a=2,c=3: W^6
-  v[3 + 4] = tw(v[3 + 4], S1, C1);           // a=3,c=1: W^3
-  v[3 + 8] = tw(v[3 + 8], -H, H);            // a=3,c=2: W^6
-  v[3 + 12] = tw(v[3 + 12], -C1, -S1);       // a=3,c=3: W^9 = -W^1
+  v[2 + 12] = cmul_k<CJ>(v[2 + 12], -H, H);          // a=2,c=3: W^6
+  v[3 + 4] = cmul_k<CJ>(v[3 + 4], S1, C1);           // a=3,c=1: W^3
+  v[3 + 8] = cmul_k<CJ>(v[3 + 8], -H, H);            // a=3,c=2: W^6
+  v[3 + 12] = cmul_k<CJ>(v[3 + 12], -C1, -S1);       // a=3,c=3: W^9 = -W^1
   // step 3: for each c, the 4-point DFT over a of Z_a[c] (at v[a + 4c]) -> X[c + 4d]
   float2 o[16];
 #pragma unroll
-  for (int c = 0; c < 4; c++) {
-    const float2 x0 = v[4 * c], x1 = v[4 * c + 1], x2 = v[4 * c + 2], x3 = v[4 * c + 3];
-    const float2 t0 = cadd(x0, x2), t1 = csub(x0, x2), t2 = cadd(x1, x3);
-    const float2 t3 = SIGN < 0 ? mul_mi(csub(x1, x3)) : mul_pi(csub(x1, x3));
-    o[c] = cadd(t0, t2); o[c + 4] = cadd(t1, t3); o[c + 8] = csub(t0, t2); o[c + 12] = csub(t1, t3);
-  }
+  for (int c = 0; c < 4; c++) bfly4<SIGN>(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3], o[c], o[c + 4], o[c + 8], o[c + 12]);
 #pragma unroll
   for (int m = 0; m < 16; m++) v[m] = o[m];
 }
@@ -90,6 +129,17 @@ __device__ __forceinline__ void dft16(float2 *v) {
 // products cost a quarter of the kernel (ablation: 0.80 -> 0.61 ms).
 __device__ __forceinline__ void twiddles16(const FftDev &p, int q, int s, int j, float2 *w) {
   const float2 *t = p.T + p.toff[q] + j;
+#ifndef K7_TW_ALL
+  if (s >= 256) {   // the big first / last pass: its table (15 s entries) does not stay in L1 — 4 loads and 11 products (2 packed
+                    // instructions each) instead of 15 loads through L2
+    const float2 w1 = t[0], w2 = t[s], w4 = t[3 * s], w8 = t[7 * s];
+    w[1] = w1; w[2] = w2; w[4] = w4; w[8] = w8;
+    w[3] = cmul(w1, w2); w[5] = cmul(w4, w1); w[6] = cmul(w4, w2); w[7] = cmul(w4, w[3]);
+    w[9] = cmul(w8, w1); w[10] = cmul(w8, w2); w[11] = cmul(w8, w[3]); w[12] = cmul(w8, w4);
+    w[13] = cmul(w8, w[5]); w[14] = cmul(w8, w[6]); w[15] = cmul(w8, w[7]);
+    return;
+  }
+#endif
 #pragma unroll
   for (int k = 1; k < 16; k++) w[k] = t[(k - 1) * s];
 }
@@ -118,11 +168,12 @@ __device__ void fft_forward_dif(float2 *x, const FftDev &p, int tid) {
       for (int b = tid; b < p.L / 4; b += FT) {
         const int j = b & (s - 1), base = (b / s) * n + j;
         const float2 a0 = x[PAD(base)], a1 = x[PAD(base + s)], a2 = x[PAD(base + 2 * s)], a3 = x[PAD(base + 3 * s)];
-        const float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_mi(csub(a1, a3));
-        x[PAD(base)] = cadd(t0, t2);
-        x[PAD(base + s)] = cmul(cadd(t1, t3), p.W[j * tw]);
-        x[PAD(base + 2 * s)] = cmul(csub(t0, t2), p.W[2 * j * tw]);
-        x[PAD(base + 3 * s)] = cmul(csub(t1, t3), p.W[3 * j * tw]);
+        float2 X0, X1, X2, X3;
+        bfly4<-1>(a0, a1, a2, a3, X0, X1, X2, X3);
+        x[PAD(base)] = X0;
+        x[PAD(base + s)] = cmul(X1, p.W[j * tw]);
+        x[PAD(base + 2 * s)] = cmul(X2, p.W[2 * j * tw]);
+        x[PAD(base + 3 * s)] = cmul(X3, p.W[3 * j * tw]);
       }
     } else {   // radix 2
       for (int b = tid; b < p.L / 2; b += FT) {
@@ -166,11 +217,9 @@ __device__ void fft_inverse_dit(float2 *x, const FftDev &p, int tid) {
         const float2 a1 = cmulc(x[PAD(base + s)], p.W[j * tw]);
         const float2 a2 = cmulc(x[PAD(base + 2 * s)], p.W[2 * j * tw]);
         const float2 a3 = cmulc(x[PAD(base + 3 * s)], p.W[3 * j * tw]);
-        const float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_pi(csub(a1, a3));
-        x[PAD(base)] = cadd(t0, t2);
-        x[PAD(base + s)] = cadd(t1, t3);
-        x[PAD(base + 2 * s)] = csub(t0, t2);
-        x[PAD(base + 3 * s)] = csub(t1, t3);
+        float2 X0, X1, X2, X3;
+        bfly4<1>(a0, a1, a2, a3, X0, X1, X2, X3);
+        x[PAD(base)] = X0; x[PAD(base + s)] = X1; x[PAD(base + 2 * s)] = X2; x[PAD(base + 3 * s)] = X3;
       }
     } else {
       for (int b = tid; b < p.L / 2; b += FT) {
@@ -247,16 +296,28 @@ constexpr int plan_radix(int lg, int pass) { return pass < lg / 4 ? 16 : ((lg % 
 // BANK: several bands behind one forward transform (forward image kept, one work image); false = the single-band
 // kernel exactly as before (in place, no band loop — the 1024-lane workgroup sits at the 128-VGPR cap and any extra
 // live value spills: the runtime band loop alone cost 36 %)
-template <int LG, bool BANK>
-__global__ __launch_bounds__(FT) void fftconv_fused_kernel(const ConvArgs a) {
+// NT: lanes per workgroup — L / 16 (one radix-16 butterfly per lane and pass), at least one wave, at most 1024: a 2048-point
+// filter-bank block on 1024 lanes kept 7 of 8 lanes idle in the radix-16 passes and, one workgroup at a time per CU pair of
+// images, nothing overlapped its latencies
+template <int LG, bool BANK, int NT>
+__global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
+  constexpr int FT = NT;   // (shadows the file-wide workgroup size)
   extern __shared__ __attribute__((aligned(16))) float2 xl[];
-  const int c = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
   const FftDev &p = a.fft;
   const int L = LG ? (1 << LG) : p.L, np = LG ? plan_npass(LG) : p.npass;
   auto radix_at = [&](int q) { return LG ? plan_radix(LG, q) : p.radix[q]; };
+  // (one workgroup per (channel, block). A persistent grid — the resident workgroups walking the units in a loop —
+  // measured 4.5 % SLOWER: a 16384-point block fills the CU's LDS, so either way one workgroup runs per CU, but the
+  // dispatcher starts the next workgroup's waves while the last one's stores drain, and the loop's closing barrier does not)
+  const int tid0 = threadIdx.x, c = blockIdx.y, blk = blockIdx.x;
+  // (every phase starts from an opaque copy of the lane index: the lane's LDS and table addresses of all passes are
+  // otherwise computed up front and, kept live across the phases, spill — 49 to 93 registers in the run-time-plan kernels)
+  // (the compile-time 16384-point plan fits without: there the hoisted addresses are worth 5 %)
+  auto lane = [&]() { int t = tid0; if (LG == 0) asm volatile("" : "+v"(t)); return t; };
   const int first = blk * a.hop - a.HH;   // call-relative index of element 0
   // ---- forward pass 0 (radix 16, stride L/16): global -> registers -> LDS ----
   {
+    const int tid = lane();
     const int s = L / 16;
     // interior, 16-byte aligned block: a lane pair loads 16 bytes per lane (elements j&~1, (j&~1)+1 of every other k)
     // and swaps halves — 8 dwordx4 loads per lane instead of 16 dwordx2 (the per-CU load/store issue rate, not
@@ -293,6 +354,7 @@ __global__ __launch_bounds__(FT) void fftconv_fused_kernel(const ConvArgs a) {
   // ---- forward passes 1 .. np-2 in LDS ----
   int n = L / 16;
   for (int pass = 1; pass + 1 < np; pass++) {
+    const int tid = lane();
     const int r = radix_at(pass), s = n / r, tw = L / n;
     if (r == 16) {
       for (int b = tid; b < L / 16; b += FT) {
@@ -311,11 +373,12 @@ __global__ __launch_bounds__(FT) void fftconv_fused_kernel(const ConvArgs a) {
       for (int b = tid; b < L / 4; b += FT) {
         const int j = b & (s - 1), base = (b / s) * n + j;
         const float2 a0 = xl[PAD(base)], a1 = xl[PAD(base + s)], a2 = xl[PAD(base + 2 * s)], a3 = xl[PAD(base + 3 * s)];
-        const float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_mi(csub(a1, a3));
-        xl[PAD(base)] = cadd(t0, t2);
-        xl[PAD(base + s)] = cmul(cadd(t1, t3), p.W[j * tw]);
-        xl[PAD(base + 2 * s)] = cmul(csub(t0, t2), p.W[2 * j * tw]);
-        xl[PAD(base + 3 * s)] = cmul(csub(t1, t3), p.W[3 * j * tw]);
+        float2 X0, X1, X2, X3;
+        bfly4<-1>(a0, a1, a2, a3, X0, X1, X2, X3);
+        xl[PAD(base)] = X0;
+        xl[PAD(base + s)] = cmul(X1, p.W[j * tw]);
+        xl[PAD(base + 2 * s)] = cmul(X2, p.W[2 * j * tw]);
+        xl[PAD(base + 3 * s)] = cmul(X3, p.W[3 * j * tw]);
       }
     }
     __syncthreads();
@@ -331,6 +394,7 @@ __global__ __launch_bounds__(FT) void fftconv_fused_kernel(const ConvArgs a) {
   float2 *outb = BANK ? a.out + (long)band * a.out_band : a.out;
   // ---- last forward pass (stride 1, no twiddles) x spectrum x first inverse pass ----
   {
+    const int tid = lane();
     const int r = radix_at(np - 1);
     if (r == 16) {
       for (int b = tid; b < L / 16; b += FT) {
@@ -347,12 +411,10 @@ __global__ __launch_bounds__(FT) void fftconv_fused_kernel(const ConvArgs a) {
     } else if (r == 4) {
       for (int b = tid; b < L / 4; b += FT) {
         const float2 a0 = xs[PAD(4 * b)], a1 = xs[PAD(4 * b + 1)], a2 = xs[PAD(4 * b + 2)], a3 = xs[PAD(4 * b + 3)];
-        float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_mi(csub(a1, a3));
-        const float2 y0 = cmul(cadd(t0, t2), kp[4 * b]), y1 = cmul(cadd(t1, t3), kp[4 * b + 1]);
-        const float2 y2 = cmul(csub(t0, t2), kp[4 * b + 2]), y3 = cmul(csub(t1, t3), kp[4 * b + 3]);
-        t0 = cadd(y0, y2); t1 = csub(y0, y2); t2 = cadd(y1, y3); t3 = mul_pi(csub(y1, y3));
-        xw[PAD(4 * b)] = cadd(t0, t2); xw[PAD(4 * b + 1)] = cadd(t1, t3);
-        xw[PAD(4 * b + 2)] = csub(t0, t2); xw[PAD(4 * b + 3)] = csub(t1, t3);
+        float2 X0, X1, X2, X3, Z0, Z1, Z2, Z3;
+        bfly4<-1>(a0, a1, a2, a3, X0, X1, X2, X3);
+        bfly4<1>(cmul(X0, kp[4 * b]), cmul(X1, kp[4 * b + 1]), cmul(X2, kp[4 * b + 2]), cmul(X3, kp[4 * b + 3]), Z0, Z1, Z2, Z3);
+        xw[PAD(4 * b)] = Z0; xw[PAD(4 * b + 1)] = Z1; xw[PAD(4 * b + 2)] = Z2; xw[PAD(4 * b + 3)] = Z3;
       }
     } else {
       for (int b = tid; b < L / 2; b += FT) {
@@ -366,6 +428,7 @@ __global__ __launch_bounds__(FT) void fftconv_fused_kernel(const ConvArgs a) {
   // ---- inverse passes np-2 .. 1 in LDS ----
   n = radix_at(np - 1);
   for (int pass = np - 2; pass >= 1; pass--) {
+    const int tid = lane();
     const int r = radix_at(pass), s = n;
     n *= r;
     const int tw = L / n;
@@ -389,15 +452,16 @@ __global__ __launch_bounds__(FT) void fftconv_fused_kernel(const ConvArgs a) {
         const float2 a1 = cmulc(xw[PAD(base + s)], p.W[j * tw]);
         const float2 a2 = cmulc(xw[PAD(base + 2 * s)], p.W[2 * j * tw]);
         const float2 a3 = cmulc(xw[PAD(base + 3 * s)], p.W[3 * j * tw]);
-        const float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_pi(csub(a1, a3));
-        xw[PAD(base)] = cadd(t0, t2); xw[PAD(base + s)] = cadd(t1, t3);
-        xw[PAD(base + 2 * s)] = csub(t0, t2); xw[PAD(base + 3 * s)] = csub(t1, t3);
+        float2 X0, X1, X2, X3;
+        bfly4<1>(a0, a1, a2, a3, X0, X1, X2, X3);
+        xw[PAD(base)] = X0; xw[PAD(base + s)] = X1; xw[PAD(base + 2 * s)] = X2; xw[PAD(base + 3 * s)] = X3;
       }
     }
     __syncthreads();
   }
   // ---- last inverse pass (radix 16, stride L/16): LDS -> registers -> global (only the hop kept samples) ----
   {
+    const int tid = lane();
     const int s = L / 16, o0 = blk * a.hop;
     for (int j = tid; j < s; j += FT) {
       float2 v[16], w[16];
@@ -616,15 +680,26 @@ struct sdrhip_fftconv {
     a.hist = hist[par].p; a.HH = HH; a.Kp = Kp.p + (size_t)b0 * plan.L;
     a.out = out_dev + (size_t)b0 * out_band; a.out_stride = (long)out_stride; a.N = (int)N; a.hop = hop;
     const int blocks = (int)ceil_div(N, (size_t)hop);
+    auto fused = [&](auto kernel, int nt) {
+      allow_big_lds(kernel, lds);
+      hipLaunchKernelGGL(kernel, dim3(blocks, C), dim3(nt), lds, ctx->stream, a);
+    };
+    const bool fusable = plan.dev.npass >= 2 && plan.dev.radix[0] == 16;
+    int nt = plan.L / 16 >= 1024 ? 1024 : plan.L / 16 >= 512 ? 512 : plan.L / 16 >= 256 ? 256 : plan.L / 16 >= 128 ? 128 : 64;
+    { const char *e = getenv("SDRHIP_K7_NT"); if (e) nt = atoi(e); }   // tuning hook
+#define SDRHIP_FUSED(BANK_) do { switch (nt) { \
+      case 1024: fused(fftconv_fused_kernel<0, BANK_, 1024>, 1024); break; \
+      case 512: fused(fftconv_fused_kernel<0, BANK_, 512>, 512); break; \
+      case 256: fused(fftconv_fused_kernel<0, BANK_, 256>, 256); break; \
+      case 128: fused(fftconv_fused_kernel<0, BANK_, 128>, 128); break; \
+      default: fused(fftconv_fused_kernel<0, BANK_, 64>, 64); break; } } while (0)
     if (plan.L == 16384) {   // (never a bank: two images of 16384 points do not fit the LDS)
-      allow_big_lds(fftconv_fused_kernel<14, false>, lds);
-      hipLaunchKernelGGL((fftconv_fused_kernel<14, false>), dim3(blocks, C), dim3(FT), lds, ctx->stream, a);
-    } else if (plan.dev.npass >= 2 && plan.dev.radix[0] == 16 && a.nb > 1) {
-      allow_big_lds(fftconv_fused_kernel<0, true>, lds);
-      hipLaunchKernelGGL((fftconv_fused_kernel<0, true>), dim3(blocks, C), dim3(FT), lds, ctx->stream, a);
-    } else if (plan.dev.npass >= 2 && plan.dev.radix[0] == 16) {
-      allow_big_lds(fftconv_fused_kernel<0, false>, lds);
-      hipLaunchKernelGGL((fftconv_fused_kernel<0, false>), dim3(blocks, C), dim3(FT), lds, ctx->stream, a);
+      fused(fftconv_fused_kernel<14, false, 1024>, 1024);
+    } else if (fusable && a.nb > 1) {
+      SDRHIP_FUSED(true);
+    } else if (fusable) {
+      SDRHIP_FUSED(false);
+#undef SDRHIP_FUSED
     } else {
       allow_big_lds(fftconv_kernel, lds);
       hipLaunchKernelGGL(fftconv_kernel, dim3(blocks, C), dim3(FT), lds, ctx->stream, a);
@@ -705,7 +780,7 @@ int sdrhip_fftconv_process_dev(sdrhip_fftconv *h, const float *in_dev, size_t n_
     if (in_stride == 0) in_stride = n_in;
     if (out_stride == 0) out_stride = n_in;
     SDRHIP_REQUIRE(in_stride >= n_in && out_stride >= n_in, SDRHIP_E_SIZE, "stride smaller than n_in");
-    require_disjoint(in_dev, in_stride, n_in, 8, out_dev, out_stride, n_in, 8, (size_t)h->C * h->B);
+    require_disjoint(in_dev, in_stride, n_in, 8, out_dev, out_stride, n_in, 8, (size_t)h->C, (size_t)h->C * h->B);
     h->launch(reinterpret_cast<const float2 *>(in_dev), n_in, in_stride, reinterpret_cast<float2 *>(out_dev), out_stride,
               (size_t)h->C * out_stride);
   });

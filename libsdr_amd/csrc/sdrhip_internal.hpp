@@ -117,10 +117,11 @@ static inline size_t ceil_div(size_t a, size_t b) { return (a + b - 1) / b; }
 // the last one rolls the history from the input), so an output range that overlaps the input range would race
 // silently. rows x row_elems elements of elem bytes at a row stride of `stride` elements.
 static inline void require_disjoint(const void *in, size_t in_stride, size_t in_row, size_t in_elem, const void *out,
-                                    size_t out_stride, size_t out_row, size_t out_elem, size_t rows) {
+                                    size_t out_stride, size_t out_row, size_t out_elem, size_t rows, size_t out_rows = 0) {
+  if (!out_rows) out_rows = rows;   // (a filter bank writes bands x channels rows from channels rows of input)
   if (!rows || !in_row || !out_row) return;
   const uintptr_t a0 = (uintptr_t)in, a1 = a0 + ((rows - 1) * in_stride + in_row) * in_elem;
-  const uintptr_t b0 = (uintptr_t)out, b1 = b0 + ((rows - 1) * out_stride + out_row) * out_elem;
+  const uintptr_t b0 = (uintptr_t)out, b1 = b0 + ((out_rows - 1) * out_stride + out_row) * out_elem;
   SDRHIP_REQUIRE(a1 <= b0 || b1 <= a0, SDRHIP_E_INVALID,
                  "process_dev: the output range overlaps the input range (in place is only supported by the host-pointer "
                  "*_process entry points, which stage through separate device buffers)");
