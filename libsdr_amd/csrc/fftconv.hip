@@ -129,10 +129,22 @@ __device__ __forceinline__ void dft16(float2 *v) {
 // products cost a quarter of the kernel (ablation: 0.80 -> 0.61 ms).
 __device__ __forceinline__ void twiddles16(const FftDev &p, int q, int s, int j, float2 *w) {
   const float2 *t = p.T + p.toff[q] + j;
+#ifndef K7_TW_MIN
+#define K7_TW_MIN 4
+#endif
+#ifndef K7_TW_LOADS
+#define K7_TW_LOADS 2
+#endif
 #ifndef K7_TW_ALL
-  if (s >= 256) {   // the big first / last pass: its table (15 s entries) does not stay in L1 — 4 loads and 11 products (2 packed
+  if (s >= K7_TW_MIN) {   // the big first / last pass: its table (15 s entries) does not stay in L1 — 4 loads and 11 products (2 packed
                     // instructions each) instead of 15 loads through L2
+#if K7_TW_LOADS == 1
+    const float2 w1 = t[0], w2 = cmul(w1, w1), w4 = cmul(w2, w2), w8 = cmul(w4, w4);
+#elif K7_TW_LOADS == 2
+    const float2 w1 = t[0], w2 = cmul(w1, w1), w4 = t[3 * s], w8 = cmul(w4, w4);
+#else
     const float2 w1 = t[0], w2 = t[s], w4 = t[3 * s], w8 = t[7 * s];
+#endif
     w[1] = w1; w[2] = w2; w[4] = w4; w[8] = w8;
     w[3] = cmul(w1, w2); w[5] = cmul(w4, w1); w[6] = cmul(w4, w2); w[7] = cmul(w4, w[3]);
     w[9] = cmul(w8, w1); w[10] = cmul(w8, w2); w[11] = cmul(w8, w[3]); w[12] = cmul(w8, w4);
