@@ -253,7 +253,7 @@ struct ConvArgs {
   float2 *out; long out_stride;
   int N, hop;
   int nb; long out_band;             // filter bank: bands sharing ONE forward transform; band b's rows start at out + b*out_band
-  int lds_elems;                     // padded elements of one LDS image (the bank keeps the forward image and works in a second one)
+  int lds_elems;                     // padded elements of one LDS image
 };
 
 __global__ __launch_bounds__(FT) void fftconv_kernel(const ConvArgs a) {
@@ -396,17 +396,71 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
     __syncthreads();
     n = s;
   }
-  // ---- filter bank: the forward image stays in xs; every band multiplies it by its own spectrum and runs the inverse
-  // transform in the work image xw (one band: xw == xs, in place as before). One forward transform per input block,
-  // as FilterSink feeds every FilterSource from one FFT (reference src/filternode.hh:81-88,257-270). ----
-  float2 *xs = xl, *xw = BANK ? xl + a.lds_elems : xl;
+  // ---- filter bank (BANK): one forward transform per input block for all bands, as FilterSink feeds every FilterSource
+  // from one FFT (reference src/filternode.hh:81-88,257-270). The workgroup has L / 16 lanes, so the last forward pass
+  // leaves exactly 16 spectrum values per lane: they stay in REGISTERS across the bands (32 of them), every band
+  // multiplies them by its own spectrum, runs the first inverse pass on them and writes the ONE LDS image the rest of
+  // its inverse transform works in — the second image a bank used to need halved the workgroups per CU. ----
+  float2 *xw = xl;
   const int nb = BANK ? a.nb : 1;
+  float2 fwd[16];
+  if (BANK) {
+    const int tid = lane();
+    const int r = radix_at(np - 1);
+    if (r == 16) {
+#pragma unroll
+      for (int k = 0; k < 16; k++) fwd[k] = xl[PAD(16 * tid + k)];
+      dft16<-1>(fwd);
+    } else if (r == 4) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int b = tid + q * FT;
+        bfly4<-1>(xl[PAD(4 * b)], xl[PAD(4 * b + 1)], xl[PAD(4 * b + 2)], xl[PAD(4 * b + 3)], fwd[4 * q], fwd[4 * q + 1], fwd[4 * q + 2], fwd[4 * q + 3]);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int b = tid + q * FT;
+        const float2 a0 = xl[PAD(2 * b)], a1 = xl[PAD(2 * b + 1)];
+        fwd[2 * q] = cadd(a0, a1); fwd[2 * q + 1] = csub(a0, a1);
+      }
+    }
+    __syncthreads();   // every lane holds its part of the spectrum: the image is free
+  }
   for (int band = 0; band < nb; band++) {
   const float2 *kp = BANK ? a.Kp + (long)band * L : a.Kp;
   float2 *outb = BANK ? a.out + (long)band * a.out_band : a.out;
   // ---- last forward pass (stride 1, no twiddles) x spectrum x first inverse pass ----
-  {
+  if (BANK) {
     const int tid = lane();
+    const int r = radix_at(np - 1);
+    if (r == 16) {
+      float2 v[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) v[k] = cmul(fwd[k], kp[16 * tid + k]);
+      dft16<1>(v);
+#pragma unroll
+      for (int k = 0; k < 16; k++) xw[PAD(16 * tid + k)] = v[k];
+    } else if (r == 4) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int b = tid + q * FT;
+        float2 Z0, Z1, Z2, Z3;
+        bfly4<1>(cmul(fwd[4 * q], kp[4 * b]), cmul(fwd[4 * q + 1], kp[4 * b + 1]), cmul(fwd[4 * q + 2], kp[4 * b + 2]), cmul(fwd[4 * q + 3], kp[4 * b + 3]), Z0, Z1, Z2, Z3);
+        xw[PAD(4 * b)] = Z0; xw[PAD(4 * b + 1)] = Z1; xw[PAD(4 * b + 2)] = Z2; xw[PAD(4 * b + 3)] = Z3;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int b = tid + q * FT;
+        const float2 y0 = cmul(fwd[2 * q], kp[2 * b]), y1 = cmul(fwd[2 * q + 1], kp[2 * b + 1]);
+        xw[PAD(2 * b)] = cadd(y0, y1); xw[PAD(2 * b + 1)] = csub(y0, y1);
+      }
+    }
+    __syncthreads();
+  } else {
+    const int tid = lane();
+    const float2 *xs = xl;
     const int r = radix_at(np - 1);
     if (r == 16) {
       for (int b = tid; b < L / 16; b += FT) {
@@ -677,7 +731,9 @@ struct sdrhip_fftconv {
   }
 
   // bands a launch can serve from one forward transform: the forward image and one work image must fit the CU's LDS
-  int bands_per_launch() const { return 2 * plan.lds_bytes() <= 160 * 1024 ? B : 1; }
+  // bands a launch can serve from one forward transform: the bank kernel keeps the spectrum in registers, 16 values per
+  // lane of an L/16-lane workgroup (L = 1024 .. 8192; 16384 points sit at the register cap of a 1024-lane workgroup)
+  int bands_per_launch() const { return (plan.L >= 1024 && plan.L <= 8192) ? B : 1; }
 
   // out_band: elements between band b's and band b+1's rows
   void launch(const float2 *in_dev, size_t N, size_t in_stride, float2 *out_dev, size_t out_stride, size_t out_band) {
@@ -687,7 +743,7 @@ struct sdrhip_fftconv {
     for (int b0 = 0; b0 < B; b0 += bpl) {   // (a plan too large for two LDS images transforms the input once per band)
     ConvArgs a;
     a.nb = std::min(bpl, B - b0); a.out_band = (long)out_band; a.lds_elems = (int)(plan.lds_bytes() / sizeof(float2));
-    const size_t lds = (a.nb > 1 ? 2 : 1) * plan.lds_bytes();
+    const size_t lds = plan.lds_bytes();
     a.fft = plan.dev; a.in = in_dev; a.in_stride = (long)in_stride;
     a.hist = hist[par].p; a.HH = HH; a.Kp = Kp.p + (size_t)b0 * plan.L;
     a.out = out_dev + (size_t)b0 * out_band; a.out_stride = (long)out_stride; a.N = (int)N; a.hop = hop;
@@ -698,7 +754,7 @@ struct sdrhip_fftconv {
     };
     const bool fusable = plan.dev.npass >= 2 && plan.dev.radix[0] == 16;
     int nt = plan.L / 16 >= 1024 ? 1024 : plan.L / 16 >= 512 ? 512 : plan.L / 16 >= 256 ? 256 : plan.L / 16 >= 128 ? 128 : 64;
-    { const char *e = getenv("SDRHIP_K7_NT"); if (e) nt = atoi(e); }   // tuning hook
+    { const char *e = getenv("SDRHIP_K7_NT"); if (e && a.nb == 1) nt = atoi(e); }   // tuning hook (the bank kernel needs L / 16 lanes)
 #define SDRHIP_FUSED(BANK_) do { switch (nt) { \
       case 1024: fused(fftconv_fused_kernel<0, BANK_, 1024>, 1024); break; \
       case 512: fused(fftconv_fused_kernel<0, BANK_, 512>, 512); break; \
