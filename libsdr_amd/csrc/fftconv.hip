@@ -762,7 +762,7 @@ struct sdrhip_fftconv {
       case 128: fused(fftconv_fused_kernel<0, BANK_, 128>, 128); break; \
       default: fused(fftconv_fused_kernel<0, BANK_, 64>, 64); break; } } while (0)
     if (plan.L == 16384) {   // (never a bank: two images of 16384 points do not fit the LDS)
-      fused(fftconv_fused_kernel<14, false, 1024>, 1024);
+      fused(fftconv_fused_kernel<14, false, 1024>, 1024);   // (512 / 256 lanes measured 0.78x / 0.59x)
     } else if (fusable && a.nb > 1) {
       SDRHIP_FUSED(true);
     } else if (fusable) {
