@@ -40,16 +40,21 @@ def ctx():
     c.close()
 
 
-@pytest.fixture(params=["auto", "valu", "mfma16", "mfmag", "twolaunch", "general"])
+@pytest.fixture(params=["auto", "valu", "mfma16", "mfmag", "twolaunch", "general", "regstaged"])
 def k1path(request, monkeypatch):
     """K1 has four bit-exact kernels: int8-MFMA on 32x32x32 tiles for decimation 8 (path 1, picked automatically up to
     257 taps) and for any other decimation (path 3), the 16x16x64 shape (path 2, on request) and the VALU dot2 kernel
     (path 0: real input, taps that do not fit, longer filters); every K1 test runs under each selection. Path 1 itself
     has three forms for 127-tap plans: hot grid + cold phase in one launch (the default), hot grid + border launch
-    ("twolaunch") and the general kernel alone ("general")."""
+    ("twolaunch") and the general kernel alone ("general"); "regstaged" is round 1's kernel (still the one complex<uint8> input runs: a
+    wave-autonomous one-plane variant measured no faster)."""
     monkeypatch.delenv("SDRHIP_IQBB_FUSE", raising=False)
     monkeypatch.delenv("SDRHIP_IQBB_HOT", raising=False)
-    if request.param == "twolaunch":
+    monkeypatch.delenv("SDRHIP_IQBB_DMA", raising=False)
+    if request.param == "regstaged":   # round 1's register-staged kernel (cs16 and cu8 input), one barrier per tile
+        monkeypatch.delenv("SDRHIP_IQBB_PATH", raising=False)
+        monkeypatch.setenv("SDRHIP_IQBB_DMA", "0")
+    elif request.param == "twolaunch":
         monkeypatch.delenv("SDRHIP_IQBB_PATH", raising=False)
         monkeypatch.setenv("SDRHIP_IQBB_FUSE", "0")
     elif request.param == "general":
