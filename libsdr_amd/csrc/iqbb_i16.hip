@@ -689,7 +689,8 @@ __global__ __launch_bounds__(TPB, CU8 ? 5 : 4) void iqbb_i16_mfma_kernel(const I
 // A wave slice (tile t, wave w of the tile's workgroup: 64 groups, the first of them FM's overlap slot) is "hot" when
 // nothing about it touches the call's borders: its 640-sample window lies inside the input, none of its groups is
 // the call's first (carry, the D+1 first window, FM's out[0] / out[1] rules) and all of them complete and are emitted.
-// The hot kernel computes exactly these slices; the general kernel, in its border launch, exactly the others.
+// The hot loop computes exactly these slices; the others are the cold phase's (one launch) or, with SDRHIP_IQBB_FUSE=0,
+// the general kernel's in a border launch.
 __device__ __forceinline__ bool slice_is_hot(int base0_rel, int OG, int ovl, int N, int n_out, int tile, int w) {
   const int qf = tile * OG - ovl + w * (64 - ovl);   // the slice's first group (output index within the call)
   const int ws = base0_rel + qf * 8 - 128;           // its window's first sample
@@ -990,8 +991,9 @@ __global__ __launch_bounds__(TPB, 4) void bb_real_mfma_kernel(const IqbbArgs a) 
 
 // =================================================================================================
 // Path 1's HOT kernel (complex<int16> input, D = 8): only tiles whose windows lie wholly inside the call (no
-// history, no end of input, no first-group carry, every group complete) — everything else goes to the general
-// kernel above in a second, small launch. What the r2a counters showed for the general kernel per wave-tile:
+// history, no end of input, no first-group carry, every group complete) — everything else is its cold phase's (the
+// one-launch form iqbb_i16_hotb_kernel) or the general kernel's in a border launch (SDRHIP_IQBB_FUSE=0).
+// What the r2a counters showed for the general kernel per wave-tile:
 // 285 vector + 154 scalar instructions (36 spilled SGPRs: the cold paths' arguments stay live through the loop)
 // and 49 % of the wave cycles parked at s_waitcnt / s_barrier. Here
 //   * each WAVE runs its own pipeline, no workgroup barrier in the loop: its 640-sample window (512 + the 128-sample
@@ -1003,7 +1005,7 @@ __global__ __launch_bounds__(TPB, 4) void bb_real_mfma_kernel(const IqbbArgs a) 
 //     [S0, S0 + NH) (centred: the big taps of a windowed sinc), operand reads of step s+1 are issued before the
 //     MFMAs of step s.
 //   * the demodulator is a template parameter; no border tests, no state writes.
-// LDS: table 1 KB | tap fragments | per wave {raw 3 KB, planes 2 x 1296 B}.
+// LDS: table 4 KB (1 KB when all 9 K steps carry the high tap plane) | tap fragments | per wave {raw 2.5 KB, planes 2 x 1312 B}.
 // =================================================================================================
 #ifdef K1_STAMPS
 __device__ unsigned long long g_k1_stamps[32768 * 8];   // per wave of one launch: 5 phase totals, 1 marker
