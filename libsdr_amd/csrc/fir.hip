@@ -247,6 +247,10 @@ __global__ __launch_bounds__(TPB) void fir_cf32_rt_kernel(const Fir32Args a) {
   const int c = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
   const int D = DC > 0 ? DC : a.D;
   const int RD = R * D;
+  // pad elements per R*D samples: 1 keeps the lanes' stride an odd number of 8-byte bank pairs; the compile-time-D path takes
+  // 2 — the stride (R*D + 2) * 8 bytes is then a multiple of 16, so a lane reads its window by ds_read_b128 (two samples
+  // per LDS instruction), and 36-dword strides still spread the 16 lanes of a b128 group over all banks
+  constexpr int PD = DC > 0 ? 2 : 1;
   const int j0 = tile * (TPB * R);
   const int outs_here = min(TPB * R, a.n_out - j0);
   const int w0 = a.first_rel + j0 * D - (a.M - 1);   // call-relative index of xs[0]
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(TPB) void fir_cf32_rt_kernel(const Fir32Args a) {
       v = make_float2(v.x * zr - v.y * zi, v.x * zi + v.y * zr);
     }
     const int q = DC > 0 ? i / (R * (DC > 0 ? DC : 1)) : (int)__umulhi((unsigned)i, a.rd_magic);
-    xs[i + q] = v;
+    xs[i + PD * q] = v;
   };
   constexpr int FR = DC > 0 ? ((TPB * R - 1) * (DC > 0 ? DC : 1) + 1) / TPB : 0;
   int row0 = 0;
@@ -302,14 +306,14 @@ __global__ __launch_bounds__(TPB) void fir_cf32_rt_kernel(const Fir32Args a) {
   // behind the staged samples must be finite (0 * NaN would poison its valid accumulators)
   for (int i = need + tid; i < need + (R - 1) * D + 16; i += TPB) {
     const int q = DC > 0 ? i / (R * (DC > 0 ? DC : 1)) : (int)__umulhi((unsigned)i, a.rd_magic);
-    xs[i + q] = make_float2(0.f, 0.f);
+    xs[i + PD * q] = make_float2(0.f, 0.f);
   }
   __syncthreads();
   if (R * tid < outs_here) {
     float sr[R], si[R];
 #pragma unroll
     for (int r = 0; r < R; r++) { sr[r] = 0.f; si[r] = 0.f; }
-    const float2 *px = xs + tid * (RD + 1);
+    const float2 *px = xs + tid * (RD + PD);
     const float *__restrict__ bp = a.betap + (R - 1) * D;   // bp[t] = beta[t], zero for t in [-(R-1)D, 0) and [M, M+(R-1)D)
     const int steps = a.M + (R - 1) * D;
     if (DC > 0) {
@@ -321,7 +325,10 @@ __global__ __launch_bounds__(TPB) void fir_cf32_rt_kernel(const Fir32Args a) {
         for (int k = 0; k < WN; k++) tw[k] = bp[u0 - PADZ + k];
         float2 x[U];
 #pragma unroll
-        for (int uu = 0; uu < U; uu++) x[uu] = pu[uu];
+        for (int uu = 0; uu < U; uu += 2) {   // (chunks start 16-byte aligned: see PD)
+          const float4 v = *reinterpret_cast<const float4 *>(pu + uu);
+          x[uu] = make_float2(v.x, v.y); x[uu + 1] = make_float2(v.z, v.w);
+        }
 #pragma unroll
         for (int uu = 0; uu < U; uu++) {
 #pragma unroll
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(TPB) void fir_cf32_rt_kernel(const Fir32Args a) {
           }
         }
         pu += U;
-        if (((u0 + U) % (R * (DC > 0 ? DC : 1))) == 0) pu += 1;   // the pad element after every R*D samples
+        if (((u0 + U) % (R * (DC > 0 ? DC : 1))) == 0) pu += PD;   // the pad elements after every R*D samples
       }
     } else {
     constexpr int U = 8;   // steps per chunk
@@ -564,7 +571,7 @@ int sdrhip_fir_create(sdrhip_ctx *ctx, int kind, const double *alpha, int order,
       } else {
         // beta[m] = (1/D) * sum_k alpha[m-k], k in [0,D): FIR followed by the D-sample box average
         h->M = order + decim - 1;
-        auto tile_bytes = [&](int R_) { const size_t need = ((size_t)TPB * R_ - 1) * decim + h->M; return (need + (size_t)(R_ - 1) * decim + 16 + (need + (size_t)(R_ - 1) * decim + 16) / ((size_t)R_ * decim) + 2) * 8; };
+        auto tile_bytes = [&](int R_) { const size_t need = ((size_t)TPB * R_ - 1) * decim + h->M; return (need + (size_t)(R_ - 1) * decim + 16 + (decim == 8 ? 2 : 1) * ((need + (size_t)(R_ - 1) * decim + 16) / ((size_t)R_ * decim) + 2)) * 8; };
         h->R = 4;
         if (const char *e = getenv("SDRHIP_FIR_R")) h->R = std::max(1, std::min(4, atoi(e)));   // tuning hook
         // as many outputs per lane as keep the tile under 40 KB (4 workgroups = 16 waves per CU): more waves in
