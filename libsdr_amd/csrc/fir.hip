@@ -190,6 +190,7 @@ struct Fir32Args {
   // linear), so staging a sample costs 8 float32 operations and no lane evaluates sincos or carries a float64 phasor.
   int shift_on;
   const float2 *etab, *wtab, *ptab;
+  const float2 *etab2;              // E2[t] = the phasor of sample 2t (staging two samples per lane and load)
   float2 parg[32]; int p_in_args;   // calls of up to 32 tiles carry their tile factors in the arguments (host float64): no table kernel
   int roll;                         // the call's last tile also rolls the FIR history forward (hist_new <- concat(hist_old, in))
 };
@@ -276,7 +277,29 @@ __global__ __launch_bounds__(TPB) void fir_cf32_rt_kernel(const Fir32Args a) {
   };
   constexpr int FR = DC > 0 ? ((TPB * R - 1) * (DC > 0 ? DC : 1) + 1) / TPB : 0;
   int row0 = 0;
-  if (FR > 0 && interior && outs_here == TPB * R) {
+  if (FR > 1 && PD == 2 && interior && outs_here == TPB * R && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+    // 16-byte aligned interior full tile: two samples per lane and load (dwordx4), two per LDS store (b128) — half the
+    // vector-memory and LDS instructions of the staging pass. Sample 2t + 512 kk carries E2[t] * W[2 kk], its neighbour
+    // that times the one-sample rotation.
+    float4 v[FR / 2 > 0 ? FR / 2 : 1];
+#pragma unroll
+    for (int kk = 0; kk < FR / 2; kk++) v[kk] = *reinterpret_cast<const float4 *>(src + 2 * tid + 2 * TPB * kk);
+    float2 E2 = make_float2(1.f, 0.f), w1 = make_float2(1.f, 0.f);
+    if (a.shift_on) { E2 = a.etab2[tid]; w1 = a.etab[1]; }
+#pragma unroll
+    for (int kk = 0; kk < FR / 2; kk++) {
+      float4 o = v[kk];
+      if (a.shift_on) {
+        const float2 W = a.wtab[2 * kk];   // lane-uniform
+        const float z0r = E2.x * W.x - E2.y * W.y, z0i = E2.x * W.y + E2.y * W.x;
+        const float z1r = z0r * w1.x - z0i * w1.y, z1i = z0r * w1.y + z0i * w1.x;
+        o = make_float4(v[kk].x * z0r - v[kk].y * z0i, v[kk].x * z0i + v[kk].y * z0r, v[kk].z * z1r - v[kk].w * z1i, v[kk].z * z1i + v[kk].w * z1r);
+      }
+      const int i = 2 * tid + 2 * TPB * kk;
+      *reinterpret_cast<float4 *>(xs + i + PD * (i / (R * (DC > 0 ? DC : 1)))) = o;
+    }
+    row0 = 2 * (FR / 2);   // (an odd last full row goes through the clamped loads below with the partial ones)
+  } else if (FR > 0 && interior && outs_here == TPB * R) {
     float2 v[FR > 0 ? FR : 1];
 #pragma unroll
     for (int k = 0; k < FR; k++) v[k] = src[tid + k * TPB];
@@ -425,7 +448,7 @@ struct sdrhip_fir {
   size_t lds3 = 0;
   // fused frequency shift (set by the float baseband)
   bool shift_on = false; double fc = 0, fs = 1;
-  DevBuf<float2> etab, wtab, ptab;   // phase tables of the fused shift (see Fir32Args)
+  DevBuf<float2> etab, etab2, wtab, ptab;   // phase tables of the fused shift (see Fir32Args)
   DevBuf<float2> hist32[2];
   // staging
   DevBuf<uint8_t> stage_in, stage_out;
@@ -468,7 +491,7 @@ struct sdrhip_fir {
       a.n_out = (int)no;
       a.out = out_dev; a.out_stride = (long)out_stride; a.epilogue = epi;
       a.betap = betap.p; a.rd_magic = (unsigned)((0x100000000ull + (uint64_t)(R * D) - 1) / (uint64_t)(R * D));
-      a.shift_on = shift_on ? 1 : 0; a.etab = etab.p; a.wtab = wtab.p; a.ptab = ptab.p;
+      a.shift_on = shift_on ? 1 : 0; a.etab = etab.p; a.wtab = wtab.p; a.ptab = ptab.p; a.etab2 = etab2.p;
       if (no) {
         const int tiles = (int)ceil_div(no, (size_t)TPB * R);
         a.p_in_args = 0; a.roll = M > 1 ? 1 : 0;
@@ -515,10 +538,11 @@ void fir_set_shift(sdrhip_fir *h, double fc, double fs) {
     const double a = -2.0 * M_PI * std::fmod(fc * t / fs, 1.0);
     return make_float2((float)std::cos(a), (float)std::sin(a));
   };
-  std::vector<float2> e(TPB), w(256);
-  for (int t = 0; t < TPB; t++) e[t] = ph((double)t);
+  std::vector<float2> e(TPB), e2(TPB), w(256);
+  for (int t = 0; t < TPB; t++) { e[t] = ph((double)t); e2[t] = ph((double)(2 * t)); }
   for (int k = 0; k < 256; k++) w[k] = ph((double)TPB * k);
   h->etab.alloc(TPB); h->etab.upload(e.data(), TPB, h->ctx->stream);
+  h->etab2.alloc(TPB); h->etab2.upload(e2.data(), TPB, h->ctx->stream);
   h->wtab.alloc(256); h->wtab.upload(w.data(), 256, h->ctx->stream);
 }
 }  // namespace sdrhip
