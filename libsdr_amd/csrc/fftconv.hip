@@ -249,6 +249,7 @@ struct ConvArgs {
   FftDev fft;
   const float2 *in; long in_stride;
   const float2 *hist; int HH;        // HH = L - hop samples preceding the call
+  float2 *hist_new;                  // fused kernel: the channel's last block also writes the history of the next call (NULL: not this launch)
   const float2 *Kp;                  // spectra (band b at Kp + b*L), digit-reversed order, pre-scaled by 1/L
   float2 *out; long out_stride;
   int N, hop;
@@ -562,6 +563,14 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
   }
   if (BANK && band + 1 < nb) __syncthreads();   // the work image is read out before the next band's middle pass overwrites it
   }
+  // the channel's last block rolls the overlap history forward (hist_new <- the last HH samples of concat(hist, in); `hist`
+  // is only read, by this launch's first blocks): no separate launch
+  if (a.hist_new != nullptr && blk == (int)gridDim.x - 1) {
+    for (int k = tid0; k < a.HH; k += FT) {
+      const long qq = (long)a.N + k;
+      a.hist_new[(long)c * a.HH + k] = qq < a.HH ? a.hist[(long)c * a.HH + qq] : a.in[(long)c * a.in_stride + (qq - a.HH)];
+    }
+  }
 }
 
 __global__ void hist_roll_kernel(const float2 *in, long in_stride, const float2 *hist_old, float2 *hist_new, int HH, int N) {
@@ -740,15 +749,18 @@ struct sdrhip_fftconv {
     ctx->use();
     if (N == 0) return;
     const int bpl = bands_per_launch();
+    bool rolled = false;
     for (int b0 = 0; b0 < B; b0 += bpl) {   // (a plan too large for two LDS images transforms the input once per band)
     ConvArgs a;
     a.nb = std::min(bpl, B - b0); a.out_band = (long)out_band; a.lds_elems = (int)(plan.lds_bytes() / sizeof(float2));
     const size_t lds = plan.lds_bytes();
     a.fft = plan.dev; a.in = in_dev; a.in_stride = (long)in_stride;
     a.hist = hist[par].p; a.HH = HH; a.Kp = Kp.p + (size_t)b0 * plan.L;
+    a.hist_new = nullptr;
     a.out = out_dev + (size_t)b0 * out_band; a.out_stride = (long)out_stride; a.N = (int)N; a.hop = hop;
     const int blocks = (int)ceil_div(N, (size_t)hop);
     auto fused = [&](auto kernel, int nt) {
+      if (HH > 0 && b0 + bpl >= B) { a.hist_new = hist[par ^ 1].p; rolled = true; }   // the call's last launch
       allow_big_lds(kernel, lds);
       hipLaunchKernelGGL(kernel, dim3(blocks, C), dim3(nt), lds, ctx->stream, a);
     };
@@ -774,7 +786,8 @@ struct sdrhip_fftconv {
     }
     }
     SDRHIP_CHECK_HIP(hipGetLastError());
-    if (HH > 0) {
+    if (HH > 0 && rolled) par ^= 1;
+    else if (HH > 0) {
       hipLaunchKernelGGL(hist_roll_kernel, dim3((unsigned)ceil_div((size_t)HH, (size_t)256), C), dim3(256), 0, ctx->stream,
                          in_dev, (long)in_stride, hist[par].p, hist[par ^ 1].p, HH, (int)N);
       SDRHIP_CHECK_HIP(hipGetLastError());
