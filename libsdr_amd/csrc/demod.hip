@@ -40,31 +40,41 @@ struct DemodArgs {
   const short *fm_old; short *fm_new;
 };
 
-// cs16 -> int16
+// cs16 -> int16. A lane owns SP consecutive samples (SP = 4 or 8: 16-byte loads, 8-byte stores): FM needs the angle of the
+// sample before its first one, so a lane evaluates SP + 1 angles for SP outputs — the stand-alone FM demodulator is bound
+// by that arithmetic (32 vector instructions per angle), not by HBM: 8 samples per lane make it 9/8 instead of 5/4.
+template <int SP>
 __global__ __launch_bounds__(TPB) void demod_cs16_kernel(const DemodArgs a) {
   const int c = blockIdx.y;
   const uint32_t *in = reinterpret_cast<const uint32_t *>(a.in) + (long)c * a.in_stride;
   short *out = reinterpret_cast<short *>(a.out) + (long)c * a.out_stride;
   const bool vec_ok = ((reinterpret_cast<uintptr_t>(in) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 7) == 0);
-  for (int i0 = 4 * (blockIdx.x * TPB + threadIdx.x); i0 < a.N; i0 += 4 * gridDim.x * TPB) {
-    uint32_t x[4];
-    const int cnt = min(4, a.N - i0);
-    if (vec_ok && cnt == 4) {
-      const uint4 v = *reinterpret_cast<const uint4 *>(in + i0);
-      x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+  for (int i0 = SP * (blockIdx.x * TPB + threadIdx.x); i0 < a.N; i0 += SP * gridDim.x * TPB) {
+    uint32_t x[SP];
+    const int cnt = min(SP, a.N - i0);
+    if (vec_ok && cnt == SP) {
+#pragma unroll
+      for (int q = 0; q < SP / 4; q++) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(in + i0 + 4 * q);
+        x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+      }
     } else {
-      for (int k = 0; k < 4; k++) x[k] = k < cnt ? in[i0 + k] : 0u;
+#pragma unroll
+      for (int k = 0; k < SP; k++) x[k] = k < cnt ? in[i0 + k] : 0u;
     }
-    short o[4];
+    short o[SP];
     if (a.kind == SDRHIP_EPI_AM) {
-      for (int k = 0; k < 4; k++) o[k] = am_i16(lo16(x[k]), hi16(x[k]));
+#pragma unroll
+      for (int k = 0; k < SP; k++) o[k] = am_i16(lo16(x[k]), hi16(x[k]));
     } else if (a.kind == SDRHIP_EPI_USB) {
-      for (int k = 0; k < 4; k++) o[k] = usb_i16(lo16(x[k]), hi16(x[k]));
+#pragma unroll
+      for (int k = 0; k < SP; k++) o[k] = usb_i16(lo16(x[k]), hi16(x[k]));
     } else {
       // out[i] = phi[i-1] - phi[i] (i >= 2); out[1] = last - phi[1]; out[0]: never written by FMDemod
       int prev = 0;
       if (i0 >= 2) { const uint32_t p = in[i0 - 1]; prev = fm_phi(lo16(p), hi16(p)); }
-      for (int k = 0; k < 4; k++) {
+#pragma unroll
+      for (int k = 0; k < SP; k++) {
         const int i = i0 + k;
         const int phi = fm_phi(lo16(x[k]), hi16(x[k]));
         if (i == 0) o[k] = (short)lo16(x[k]);
@@ -75,11 +85,14 @@ __global__ __launch_bounds__(TPB) void demod_cs16_kernel(const DemodArgs a) {
       }
     }
     const bool skip0 = (a.kind == SDRHIP_EPI_FM) && !a.fm0 && i0 == 0;
-    if (vec_ok && cnt == 4 && !skip0) {
-      uint2 pk;
-      pk.x = (uint32_t)(uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16);
-      pk.y = (uint32_t)(uint16_t)o[2] | ((uint32_t)(uint16_t)o[3] << 16);
-      *reinterpret_cast<uint2 *>(out + i0) = pk;
+    if (vec_ok && cnt == SP && !skip0) {
+#pragma unroll
+      for (int q = 0; q < SP / 4; q++) {
+        uint2 pk;
+        pk.x = (uint32_t)(uint16_t)o[4 * q] | ((uint32_t)(uint16_t)o[4 * q + 1] << 16);
+        pk.y = (uint32_t)(uint16_t)o[4 * q + 2] | ((uint32_t)(uint16_t)o[4 * q + 3] << 16);
+        *reinterpret_cast<uint2 *>(out + i0 + 4 * q) = pk;
+      }
     } else {
       for (int k = 0; k < cnt; k++) if (!(skip0 && k == 0)) out[i0 + k] = o[k];
     }
@@ -254,9 +267,11 @@ struct sdrhip_demod {
     a.in = in_dev; a.in_stride = (long)in_stride; a.out = out_dev; a.out_stride = (long)out_stride;
     a.N = (int)N; a.kind = kind; a.fm0 = fm0;
     a.fm_old = fm[par_fm].p; a.fm_new = fm[par_fm ^ 1].p;
-    const unsigned bx = (unsigned)std::min<size_t>(ceil_div(N, (size_t)4 * TPB), 4096);
+    const bool fm8 = dtype == SDRHIP_T_CS16 && kind == SDRHIP_EPI_FM && N >= (size_t)8 * TPB;   // (AM / USB have no angle to repeat)
+    const unsigned bx = (unsigned)std::min<size_t>(ceil_div(N, (size_t)(fm8 ? 8 : 4) * TPB), 4096);
     dim3 grid(bx, C), block(TPB);
-    if (dtype == SDRHIP_T_CS16) hipLaunchKernelGGL(demod_cs16_kernel, grid, block, 0, ctx->stream, a);
+    if (fm8) hipLaunchKernelGGL(demod_cs16_kernel<8>, grid, block, 0, ctx->stream, a);
+    else if (dtype == SDRHIP_T_CS16) hipLaunchKernelGGL(demod_cs16_kernel<4>, grid, block, 0, ctx->stream, a);
     else if (dtype == SDRHIP_T_CS8) hipLaunchKernelGGL(demod_cs8_fm_kernel, grid, block, 0, ctx->stream, a);
     else hipLaunchKernelGGL(demod_cf32_kernel, grid, block, 0, ctx->stream, a);
     SDRHIP_CHECK_HIP(hipGetLastError());
