@@ -308,7 +308,7 @@ def main():
                 in_bytes, alg_bytes = 4.0, 4.5
                 outs = torch.zeros((C, N // 8 + 1, 2), dtype=torch.int16, device=dev)
                 run = lambda b: node.process_dev(ins[b].data_ptr(), N, N, outs.data_ptr(), N // 8 + 1)
-                kernel, desc = "subsample_cs16_kernel", "SubSample<complex<int16>>(8) alone"
+                kernel, desc = "subsample8_cs16_kernel", "SubSample<complex<int16>>(8) alone"
             dtype = "i16"
             kernels = [kernel]
         else:

@@ -185,6 +185,27 @@ __global__ __launch_bounds__(TPB) void subsample_cs16_kernel(const SubArgs a) {
   }
 }
 
+// n == 8, the call starts on a group boundary, whole groups only, 16-byte aligned rows: a lane loads 4 samples (16 bytes,
+// consecutive lanes consecutive quads: every wave-load is 1 KB contiguous — the general kernel's lanes walk 32-byte
+// strides with 4-byte loads), lane pairs add their halves of a group through DPP (int32 sums are order-free) and the
+// even lane stores the average.
+__global__ __launch_bounds__(TPB) void subsample8_cs16_kernel(const SubArgs a) {
+  const int c = blockIdx.y;
+  const uint32_t *in = reinterpret_cast<const uint32_t *>(a.in) + (long)c * a.in_stride;
+  uint32_t *out = reinterpret_cast<uint32_t *>(a.out) + (long)c * a.out_stride;
+  const int quads = 2 * a.n_out;
+  for (int q = blockIdx.x * TPB + threadIdx.x; q < quads; q += gridDim.x * TPB) {   // (quads is even: lane pairs stay together)
+    const uint4 v = *reinterpret_cast<const uint4 *>(in + 4 * q);
+    const int sr = lo16(v.x) + lo16(v.y) + lo16(v.z) + lo16(v.w), si = hi16(v.x) + hi16(v.y) + hi16(v.z) + hi16(v.w);
+    const int pr = __builtin_amdgcn_update_dpp(0, sr, 0xB1, 0xf, 0xf, true), pi = __builtin_amdgcn_update_dpp(0, si, 0xB1, 0xf, 0xf, true);
+    if (!(q & 1)) {
+      const int yr = cdiv_int(sr + pr, 8), yi = cdiv_int(si + pi, 8);
+      out[q >> 1] = (uint32_t)(uint16_t)yr | ((uint32_t)(uint16_t)yi << 16);
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<int2 *>(a.acc_new)[c] = make_int2(0, 0);   // (no open group)
+}
+
 __global__ __launch_bounds__(TPB) void subsample_cf32_kernel(const SubArgs a) {
   const int c = blockIdx.y;
   const float2 *in = reinterpret_cast<const float2 *>(a.in) + (long)c * a.in_stride;
@@ -302,7 +323,12 @@ struct sdrhip_subsample {
     a.acc_old = acc[par].p; a.acc_new = acc[par ^ 1].p;
     const unsigned bx = (unsigned)std::min<size_t>(ceil_div((size_t)a.n_groups, (size_t)TPB), 4096);
     dim3 grid(bx, C), block(TPB);
-    if (dtype == SDRHIP_T_CS16) hipLaunchKernelGGL(subsample_cs16_kernel, grid, block, 0, ctx->stream, a);
+    const bool fast8 = dtype == SDRHIP_T_CS16 && n == 8 && a.first_rel == 0 && N % 8 == 0 && in_stride % 4 == 0 &&
+                       (reinterpret_cast<uintptr_t>(in_dev) & 15) == 0;   // whole groups, no carry in or out
+    if (fast8) {
+      const unsigned bq = (unsigned)std::min<size_t>(ceil_div((size_t)2 * no, (size_t)TPB), 8192);
+      hipLaunchKernelGGL(subsample8_cs16_kernel, dim3(bq, C), block, 0, ctx->stream, a);
+    } else if (dtype == SDRHIP_T_CS16) hipLaunchKernelGGL(subsample_cs16_kernel, grid, block, 0, ctx->stream, a);
     else hipLaunchKernelGGL(subsample_cf32_kernel, grid, block, 0, ctx->stream, a);
     SDRHIP_CHECK_HIP(hipGetLastError());
     par ^= 1; n0 += N;

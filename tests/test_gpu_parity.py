@@ -625,6 +625,20 @@ def test_demod_fm_odd_sizes_vs_oracle(ctx, orc):
             assert np.array_equal(y[c], fms[c].process(x[c, lo:hi]))
 
 
+def test_subsample8_fast_and_general_calls_vs_oracle(ctx, orc):
+    """SubSample<cs16>(8): calls that start on a group boundary and hold whole groups take the coalesced kernel, the others
+    the general one; full-scale samples, state carried across both kinds of call, 3 channels."""
+    rng = np.random.default_rng(77)
+    C, chunks = 3, [4096, 13, 8000, 3, 4096, 8, 65536, 5, 3, 16]
+    node = sa.SubSample(ctx, sa.T_CS16, 8, channels=C, max_in=65536)
+    refs = [orc.SubSample(8) for _ in range(C)]
+    for n in chunks:
+        x = rng.integers(-32768, 32768, (C, n, 2), dtype=np.int16)
+        y = node.process(x)
+        for c in range(C):
+            assert np.array_equal(y[c], refs[c].process_cs16(x[c]))
+
+
 @pytest.mark.parametrize("n", [8, 3])
 def test_subsample_golden(ctx, golden, n):
     x = golden.load("g1_iq_cs16")
