@@ -289,9 +289,11 @@ struct sdrhip_demod {
     a.N = (int)N; a.kind = kind; a.fm0 = fm0;
     a.fm_old = fm[par_fm].p; a.fm_new = fm[par_fm ^ 1].p;
     const bool fm8 = dtype == SDRHIP_T_CS16 && kind == SDRHIP_EPI_FM && N >= (size_t)8 * TPB;   // (AM / USB have no angle to repeat)
-    const unsigned bx = (unsigned)std::min<size_t>(ceil_div(N, (size_t)(fm8 ? 8 : 4) * TPB), 4096);
+    const bool fm16 = fm8 && N >= (size_t)16 * TPB;   // (17 angles per 16 outputs: +3 % over 8 per lane)
+    const unsigned bx = (unsigned)std::min<size_t>(ceil_div(N, (size_t)(fm16 ? 16 : fm8 ? 8 : 4) * TPB), 4096);
     dim3 grid(bx, C), block(TPB);
-    if (fm8) hipLaunchKernelGGL(demod_cs16_kernel<8>, grid, block, 0, ctx->stream, a);
+    if (fm16) hipLaunchKernelGGL(demod_cs16_kernel<16>, grid, block, 0, ctx->stream, a);
+    else if (fm8) hipLaunchKernelGGL(demod_cs16_kernel<8>, grid, block, 0, ctx->stream, a);
     else if (dtype == SDRHIP_T_CS16) hipLaunchKernelGGL(demod_cs16_kernel<4>, grid, block, 0, ctx->stream, a);
     else if (dtype == SDRHIP_T_CS8) hipLaunchKernelGGL(demod_cs8_fm_kernel, grid, block, 0, ctx->stream, a);
     else hipLaunchKernelGGL(demod_cf32_kernel, grid, block, 0, ctx->stream, a);
