@@ -82,3 +82,13 @@ def test_two_ranks_through_hip_nodes_match_single_process(tmp_path, workload):
     a, b = np.load(two), np.load(one)
     assert a.shape == b.shape and a.dtype == np.int16 and np.array_equal(a, b)
     assert np.count_nonzero(a) > a.size // 2   # real demodulated output, not zeros
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["iqbb_fm_cu8", "bb_real_fm", "fir255_fm", "fbb_f32", "fftconv", "fftbank", "fm_demod", "subsample8"])
+def test_every_other_workload_emits_its_line(workload):
+    """The `--workload` options beside the headline (the other BASELINE configurations and the stand-alone kernels): each
+    runs on a small batch and prints one JSON line whose roofline names the kernel it timed."""
+    d = _bench(["--workload", workload, "--channels", "16", "--samples", "24576", "--steps", "2", "--warmup", "1",
+                "--no-cpu-baseline", "--sustain-seconds", "0"])
+    assert d["value"] > 0 and d["config"]["workload"] and d["roofline"]["kernel"] and 0 < d["roofline"]["frac"] < 1
