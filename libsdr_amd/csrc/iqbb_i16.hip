@@ -688,13 +688,16 @@ __global__ __launch_bounds__(TPB, CU8 ? 5 : 4) void iqbb_i16_mfma_kernel(const I
 
 // A wave slice (tile t, wave w of the tile's workgroup: 64 groups, the first of them FM's overlap slot) is "hot" when
 // nothing about it touches the call's borders: its 640-sample window lies inside the input, none of its groups is
-// the call's first (carry, the D+1 first window, FM's out[0] / out[1] rules) and all of them complete and are emitted.
+// the call's first (carry, the D+1 first window, FM's out[0] / out[1] rules) nor its last emitted one (state for the next
+// call), and all of them complete and are emitted.
 // The hot loop computes exactly these slices; the others are the cold phase's (one launch) or, with SDRHIP_IQBB_FUSE=0,
 // the general kernel's in a border launch.
 __device__ __forceinline__ bool slice_is_hot(int base0_rel, int OG, int ovl, int N, int n_out, int tile, int w) {
   const int qf = tile * OG - ovl + w * (64 - ovl);   // the slice's first group (output index within the call)
   const int ws = base0_rel + qf * 8 - 128;           // its window's first sample
-  return ws >= 0 && ws + 640 <= N && qf >= 1 && qf + 63 < n_out;
+  // (the slice that holds the call's LAST emitted group is never hot: that group hands the demodulator's angle and the
+  // window carry to the next call — state only the general epilogue writes; found by test_one_launch_kernel_random_long_calls)
+  return ws >= 0 && ws + 640 <= N && qf >= 1 && qf + 63 < n_out - 1;
 }
 
 // =================================================================================================
@@ -2043,7 +2046,7 @@ struct sdrhip_iqbb_i16 {
       if (S == 9 && hot_range >= 0 && use_hot && tiles >= 3) {
         auto host_hot = [&](long t, long w) {
           const long qf = t * OG - ovl + w * (64 - ovl), ws = (long)g.base0_rel + qf * 8 - 128;
-          return ws >= 0 && ws + 640 <= (long)N && qf >= 1 && qf + 63 < (long)g.n_out;
+          return ws >= 0 && ws + 640 <= (long)N && qf >= 1 && qf + 63 < (long)g.n_out - 1;   // (= slice_is_hot)
         };
         long t = tiles - 1;   // the last tile always goes to the border launch (history roll, state)
         while (t >= 2 && !(host_hot(t - 1, 0) && host_hot(t - 1, 1) && host_hot(t - 1, 2) && host_hot(t - 1, 3))) t--;

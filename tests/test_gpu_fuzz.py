@@ -183,3 +183,35 @@ def test_subsample_and_demods_random(ctx, orc, seed):
             z = fm.process(x)
             for c in range(C):
                 assert np.array_equal(z[c], fms[c].process(x[c]))
+
+
+@pytest.mark.parametrize("seed", range(24 + EXTRA))
+def test_one_launch_kernel_random_long_calls(ctx, orc, seed):
+    """The 127-tap / decimation-8 plan's one-launch kernel (hot loop + cold phase): random long ragged calls (the last tile
+    ends in every way, calls too short for a hot tile in between), channel counts, epilogues, shift signs and filter
+    widths (narrow: few K steps carry the taps' high plane; wide: all nine), state carried from call to call."""
+    rng = np.random.default_rng(7000 + seed)
+    order = int(rng.choice([127, 127, 127, 113, 128, 129]))
+    Fc = float(rng.choice([100e3, -100e3, 0.0, 333e3]))
+    epi = int(rng.choice([sa.EPI_NONE, sa.EPI_FM, sa.EPI_FM, sa.EPI_AM, sa.EPI_USB]))
+    width = float(rng.choice([12.5e3, 50e3, 200e3, 600e3]))
+    C = int(rng.choice([1, 3, 7, 33]))
+    taps = sa.design_iqbb_taps(float(rng.choice([0.0, 100e3, -60e3])), width, FS, order)
+    lut, inc = sa.design_freqshift_lut_i16(), sa.design_freqshift_inc(Fc, FS)
+    lens = [int(rng.integers(4000, 70000)) for _ in range(3)] + [int(rng.choice([1, 500, 2047, 4031, 4032, 4033, 65536]))] + [int(rng.integers(4000, 30000))]
+    rng.shuffle(lens)
+    node = sa.IQBaseBandI16(ctx, taps, lut, inc, Fc < 0, 8, channels=C, max_in=max(lens), epilogue=epi)
+    refs = [orc.IQBaseBandI16(taps, lut, inc, Fc < 0, 8) for _ in range(C)]
+    fms = [orc.FMDemodI16() for _ in range(C)]
+    for n in lens:
+        x = rng.integers(-32768, 32768, (C, n, 2), dtype=np.int16)
+        y = node.process(x)
+        for c in range(C):
+            r = refs[c].process(x[c])
+            if epi == sa.EPI_FM:
+                r = fms[c].process(r)
+            elif epi == sa.EPI_AM:
+                r = orc.am_i16(r)
+            elif epi == sa.EPI_USB:
+                r = orc.usb_i16(r)
+            assert y[c].shape == r.shape and np.array_equal(y[c], r), (seed, order, Fc, epi, width, C, n, node.kernel_names)

@@ -513,6 +513,28 @@ def test_iqbb_full_size_properties(ctx, orc, k1path):
     assert np.array_equal(whole, parts)
 
 
+@pytest.mark.parametrize("epi,n_out", [(sa.EPI_FM, 630), (sa.EPI_FM, 693), (sa.EPI_NONE, 576), (sa.EPI_USB, 640), (sa.EPI_FM, 631)])
+@pytest.mark.parametrize("tail", [0, 1, 5])
+def test_iqbb_last_group_at_a_slice_end(ctx, orc, epi, n_out, tail, k1path):
+    """The call's last emitted group carries state to the next call (FMDemod's last angle, the open window's carry). Call
+    lengths that put it on the LAST group of a 64-group wave slice (FM: slices start at 252 t - 1 + 63 w) — the case in
+    which round 2's hot kernel first took that slice for an interior one — and one beside it; `tail` extra samples leave
+    a partial window open. The second call shows whether the state arrived."""
+    taps, lut, inc = sa.design_iqbb_taps(100e3, 50e3, FS, 127), sa.design_freqshift_lut_i16(), sa.design_freqshift_inc(100e3, FS)
+    rng = np.random.default_rng(n_out + tail)
+    lens = [8 * n_out + 1 + tail, 5000, 8 * n_out - tail, 4096]   # (the first window of a stream closes after D + 1 samples)
+    node = sa.IQBaseBandI16(ctx, taps, lut, inc, False, 8, channels=2, max_in=max(lens), epilogue=epi)
+    refs = [orc.IQBaseBandI16(taps, lut, inc, False, 8) for _ in range(2)]
+    fms = [orc.FMDemodI16() for _ in range(2)]
+    for n in lens:
+        x = rng.integers(-32768, 32768, (2, n, 2), dtype=np.int16)
+        y = node.process(x)
+        for c in range(2):
+            r = refs[c].process(x[c])
+            r = fms[c].process(r) if epi == sa.EPI_FM else orc.usb_i16(r) if epi == sa.EPI_USB else r
+            assert np.array_equal(y[c], r), (n, c)
+
+
 # ---- K2: exact int16 FIR --------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("case,order,inp", [("g5_fir127", 127, "g1_iq_cs16"), ("g5_fir255", 255, "g1_iq_cs16"),
