@@ -110,6 +110,33 @@ def test_fftconv_random_plans(ctx, seed):
         assert np.abs(got - ref).max() / np.abs(ref).max() <= 1e-5, (seed, L, n_taps, lens)
 
 
+@pytest.mark.parametrize("seed", range(12 + EXTRA // 4))
+def test_fftconv_bank_random_plans(ctx, seed):
+    """Filter banks (one forward transform per block, the spectrum held in registers across the bands for L = 1024 .. 8192,
+    one launch per band elsewhere) at random sizes, band counts, channel counts and ragged call lengths against numpy's
+    direct convolution per band; the overlap history is rolled by the channel's last block."""
+    rng = np.random.default_rng(5000 + seed)
+    L = int(rng.choice([32, 128, 512, 1024, 2048, 2048, 4096, 8192]))
+    n_taps = int(rng.integers(1, L // 2 + 1))
+    B = int(rng.choice([2, 3, 4]))
+    C = int(rng.choice([1, 3]))
+    hs = [(rng.standard_normal((n_taps, 2)) / np.sqrt(n_taps)).astype(np.float32) for _ in range(B)]
+    node = sa.FFTConv(ctx, sa.FFTCONV_OLS, L, hs, channels=C, max_in=20000)
+    lens = [int(v) for v in rng.choice([1, 100, L - n_taps + 1, 4097, 12345, 20000], size=4)]
+    x = (rng.standard_normal((C, sum(lens), 2)) * 0.3).astype(np.float32)
+    ys, off = [], 0
+    for n in lens:
+        ys.append(node.process(x[:, off:off + n])); off += n
+    y = np.concatenate(ys, axis=2)   # [bands, channels, n, 2]
+    for b in range(B):
+        hc = hs[b][:, 0].astype(np.float64) + 1j * hs[b][:, 1]
+        for c in range(C):
+            xc = x[c, :, 0].astype(np.float64) + 1j * x[c, :, 1]
+            ref = np.convolve(xc, hc)[:x.shape[1]]
+            got = y[b, c, :, 0] + 1j * y[b, c, :, 1]
+            assert np.abs(got - ref).max() / np.abs(ref).max() <= 1e-5, (seed, L, n_taps, B, C, lens, b, c)
+
+
 @pytest.mark.parametrize("seed", range(10 + EXTRA))
 def test_fir_cs16_exact_random_plans(ctx, orc, seed):
     """Exact per-tap-truncating complex<int16> FIR (+ FM / AM / USB) at random orders and ragged calls: bit-exact, including
@@ -215,3 +242,33 @@ def test_one_launch_kernel_random_long_calls(ctx, orc, seed):
             elif epi == sa.EPI_USB:
                 r = orc.usb_i16(r)
             assert y[c].shape == r.shape and np.array_equal(y[c], r), (seed, order, Fc, epi, width, C, n, node.kernel_names)
+
+
+@pytest.mark.parametrize("seed", range(16 + EXTRA))
+def test_bb_real_mfma_random_long_calls(ctx, orc, seed):
+    """The real-input BaseBand<int16> at decimation 8 on the matrix cores (1 .. 9 K steps by order), long ragged calls."""
+    rng = np.random.default_rng(9000 + seed)
+    order = int(rng.choice([5, 17, 21, 33, 64, 100, 127, 128, 160, 200, 255, 273]))
+    Fc = float(rng.choice([100e3, -100e3, 0.0, 41e3]))
+    epi = int(rng.choice([sa.EPI_NONE, sa.EPI_FM, sa.EPI_AM, sa.EPI_USB]))
+    C = int(rng.choice([1, 2, 5]))
+    Fs = 1e6
+    taps = orc.bb_design(float(rng.choice([60e3, 120e3, 200e3])), float(rng.choice([20e3, 60e3, 150e3])), Fs, order)
+    lut, inc = orc.freqshift_lut_i16(), orc.freqshift_inc(Fc, Fs)
+    lens = [int(rng.integers(2000, 40000)) for _ in range(3)] + [int(rng.choice([0, 1, 7, 2015, 2016, 2017, 2048]))]
+    rng.shuffle(lens)
+    bb = sa.BaseBandI16(ctx, taps, lut, inc, Fc < 0, 8, channels=C, max_in=max(max(lens), 1), epilogue=epi)
+    refs = [orc.BaseBandI16(taps, lut, inc, Fc < 0, 8) for _ in range(C)]
+    fms = [orc.FMDemodI16() for _ in range(C)]
+    for n in lens:
+        x = rng.integers(-32768, 32768, (C, n), dtype=np.int16)
+        y = bb.process(x)
+        for c in range(C):
+            r = refs[c].process(x[c])
+            if epi == sa.EPI_FM:
+                r = fms[c].process(r)
+            elif epi == sa.EPI_AM:
+                r = orc.am_i16(r)
+            elif epi == sa.EPI_USB:
+                r = orc.usb_i16(r)
+            assert y[c].shape == r.shape and np.array_equal(y[c], r), (seed, order, Fc, epi, C, n, bb.kernel_names)
