@@ -216,7 +216,8 @@ def test_subsample_and_demods_random(ctx, orc, seed):
 def test_one_launch_kernel_random_long_calls(ctx, orc, seed):
     """The 127-tap / decimation-8 plan's one-launch kernel (hot loop + cold phase): random long ragged calls (the last tile
     ends in every way, calls too short for a hot tile in between), channel counts, epilogues, shift signs and filter
-    widths (narrow: few K steps carry the taps' high plane; wide: all nine), state carried from call to call."""
+    widths (narrow: few K steps carry the taps' high plane; wide: all nine), retuned between buffers (shift, filter), state
+    carried from call to call."""
     rng = np.random.default_rng(7000 + seed)
     order = int(rng.choice([127, 127, 127, 113, 128, 129]))
     Fc = float(rng.choice([100e3, -100e3, 0.0, 333e3]))
@@ -231,6 +232,17 @@ def test_one_launch_kernel_random_long_calls(ctx, orc, seed):
     refs = [orc.IQBaseBandI16(taps, lut, inc, Fc < 0, 8) for _ in range(C)]
     fms = [orc.FMDemodI16() for _ in range(C)]
     for n in lens:
+        ev = int(rng.integers(0, 4))   # between buffers: retune the shift, swap the filter, both, or nothing (src/baseband.hh:82-112)
+        if ev & 1:
+            Fc2 = float(rng.choice([100e3, -100e3, 0.0, 333e3, -41e3]))
+            node.set_shift(sa.design_freqshift_inc(Fc2, FS), Fc2 < 0)
+            for r_ in refs:
+                r_.set_shift(sa.design_freqshift_inc(Fc2, FS), Fc2 < 0)
+        if ev & 2:
+            t2 = sa.design_iqbb_taps(float(rng.choice([0.0, 100e3, -60e3])), float(rng.choice([12.5e3, 50e3, 200e3, 600e3])), FS, order)
+            node.set_taps(t2)
+            for r_ in refs:
+                r_.set_taps(t2)
         x = rng.integers(-32768, 32768, (C, n, 2), dtype=np.int16)
         y = node.process(x)
         for c in range(C):
@@ -241,7 +253,7 @@ def test_one_launch_kernel_random_long_calls(ctx, orc, seed):
                 r = orc.am_i16(r)
             elif epi == sa.EPI_USB:
                 r = orc.usb_i16(r)
-            assert y[c].shape == r.shape and np.array_equal(y[c], r), (seed, order, Fc, epi, width, C, n, node.kernel_names)
+            assert y[c].shape == r.shape and np.array_equal(y[c], r), (seed, order, Fc, epi, width, C, n, ev, node.kernel_names)
 
 
 @pytest.mark.parametrize("seed", range(16 + EXTRA))
