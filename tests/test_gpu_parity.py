@@ -647,6 +647,23 @@ def test_demod_fm_odd_sizes_vs_oracle(ctx, orc):
             assert np.array_equal(y[c], fms[c].process(x[c, lo:hi]))
 
 
+@pytest.mark.parametrize("inplace_fm0", [True, False])
+def test_fm_demod_long_rows_state_carried(ctx, orc, inplace_fm0):
+    """Stand-alone FMDemod<int16> on rows long enough for the 8- and 16-samples-per-lane forms (>= 2048 / 4096 samples),
+    mixed with short calls: the last angle travels from call to call whatever form ran."""
+    rng = np.random.default_rng(12)
+    C = 3
+    node = sa.Demod(ctx, sa.EPI_FM, sa.T_CS16, channels=C, max_in=70000, inplace_fm0=inplace_fm0)
+    fms = [orc.FMDemodI16() for _ in range(C)]
+    for n in [5000, 2048, 3000, 4096, 100, 9001, 1, 65536, 2047, 4095, 70000]:
+        x = rng.integers(-32768, 32768, (C, n, 2), dtype=np.int16)
+        y = node.process(x)
+        for c in range(C):
+            r = fms[c].process(x[c])
+            lo = 0 if inplace_fm0 else 1            # out[0] is never written by FMDemod: only the in-place convention defines it
+            assert np.array_equal(y[c][lo:], r[lo:]), (n, c)
+
+
 def test_subsample8_fast_and_general_calls_vs_oracle(ctx, orc):
     """SubSample<cs16>(8): calls that start on a group boundary and hold whole groups take the coalesced kernel, the others
     the general one; full-scale samples, state carried across both kinds of call, 3 channels."""
