@@ -233,6 +233,10 @@ def test_one_launch_kernel_random_long_calls(ctx, orc, seed):
     fms = [orc.FMDemodI16() for _ in range(C)]
     for n in lens:
         ev = int(rng.integers(0, 4))   # between buffers: retune the shift, swap the filter, both, or nothing (src/baseband.hh:82-112)
+        if rng.integers(0, 4) == 0:    # ... or _reconfigure (:156-194): counters restart, the FIR ring stays (rotated); FMDemod goes on
+            node.reset(keep_history=True, keep_fm=True)
+            for r_ in refs:
+                r_.reset()
         if ev & 1:
             Fc2 = float(rng.choice([100e3, -100e3, 0.0, 333e3, -41e3]))
             node.set_shift(sa.design_freqshift_inc(Fc2, FS), Fc2 < 0)
