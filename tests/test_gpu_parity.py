@@ -535,6 +535,22 @@ def test_iqbb_last_group_at_a_slice_end(ctx, orc, epi, n_out, tail, k1path):
             assert np.array_equal(y[c], r), (n, c)
 
 
+def test_iqbb_more_channels_than_workgroups(ctx, orc):
+    """1 300 channels on a chip whose persistent grid has 1 024 workgroups: the hot ranges and the cold phase both wrap
+    around the grid (channels bx, bx + gx). 13 distinct patterns tiled over the channels, two calls."""
+    C, D = 1300, 8
+    taps, lut, inc = sa.design_iqbb_taps(100e3, 50e3, FS, 127), sa.design_freqshift_lut_i16(), sa.design_freqshift_inc(-100e3, FS)
+    rng = np.random.default_rng(99)
+    node = sa.IQBaseBandI16(ctx, taps, lut, inc, True, D, channels=C, max_in=9000, epilogue=sa.EPI_FM)
+    refs = [(orc.IQBaseBandI16(taps, lut, inc, True, D), orc.FMDemodI16()) for _ in range(13)]
+    for n in (9000, 6111):
+        base = rng.integers(-32768, 32768, (13, n, 2), dtype=np.int16)
+        y = node.process(np.ascontiguousarray(base[np.arange(C) % 13]))
+        for k in range(13):
+            r = refs[k][1].process(refs[k][0].process(base[k]))
+            assert (y[k::13] == y[k]).all() and np.array_equal(y[k], r), (n, k)
+
+
 # ---- K2: exact int16 FIR --------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("case,order,inp", [("g5_fir127", 127, "g1_iq_cs16"), ("g5_fir255", 255, "g1_iq_cs16"),
