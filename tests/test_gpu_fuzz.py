@@ -288,3 +288,33 @@ def test_bb_real_mfma_random_long_calls(ctx, orc, seed):
             elif epi == sa.EPI_USB:
                 r = orc.usb_i16(r)
             assert y[c].shape == r.shape and np.array_equal(y[c], r), (seed, order, Fc, epi, C, n, bb.kernel_names)
+
+
+@pytest.mark.parametrize("seed", range(10 + EXTRA // 2))
+def test_float_baseband_random_calls(ctx, orc, seed):
+    """The float baseband (shift fused into the register-tiled FIR's staging, decimation folded): random shift, decimation,
+    channel count and ragged call lengths — odd lengths move the rows over every alignment of the 16-byte staging loads and
+    the phase tables over every tile offset. <= 1e-5 against the float64-phasor oracle chain."""
+    rng = np.random.default_rng(11000 + seed)
+    Fc = float(rng.choice([100e3, -100e3, 37e3, 1.1e6, 0.0]))
+    D = int(rng.choice([8, 8, 8, 5, 1, 16]))
+    C = int(rng.choice([1, 2, 5]))
+    order = int(rng.choice([127, 63, 255]))
+    alpha = sa.design_fir_lowpass(order, 100e3, FS)
+    lens = [int(rng.integers(1, 40000)) for _ in range(4)] + [int(rng.choice([4096, 8192, 1, 2, 3]))]
+    rng.shuffle(lens)
+    node = sa.FloatBaseBand(ctx, Fc, FS, alpha, D, channels=C, max_in=max(lens))
+    firs, subs = [orc.FIR(alpha) for _ in range(C)], [orc.SubSample(D) for _ in range(C)]
+    n0 = 0
+    for n in lens:
+        x = (rng.standard_normal((C, n, 2)) * 0.3).astype(np.float32)
+        y = node.process(x)
+        for c in range(C):
+            ref = firs[c].process_cf32(orc.freqshift_cf32(x[c], n0, Fc, FS))
+            if D > 1:
+                ref = subs[c].process_cf32(ref)
+            assert y[c].shape == ref.shape, (seed, Fc, D, C, order, n)
+            if ref.size:
+                err = np.abs(y[c].astype(np.float64) - ref).max() / max(np.abs(ref).max(), 0.05)
+                assert err <= 1e-5, (seed, Fc, D, C, order, n, err)
+        n0 += n
