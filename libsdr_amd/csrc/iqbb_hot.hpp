@@ -1,0 +1,542 @@
+// iqbb_hot.hpp — K1's HOT kernel: IQBaseBand<int16_t> (D = 8) as the int8-MFMA block-Toeplitz GEMM, one launch per
+// call, for EVERY filter length path 1 serves (S = 2, 3, 5, 9, 17 K steps: orders up to 17 / 33 / 65 / 129 / 257) and
+// for complex<int16> and complex<uint8> (AutoCast fused) input.
+//
+// Replaces (reference, file:line): IQBaseBand<int16_t>::_process / _filter_ring  src/baseband.hh:198-236,
+// FreqShiftBase<int16_t>::applyFrequencyShift  src/freqshift.hh:58-74, FM/AM/USB demodulators  src/demod.hh:73-76,
+// 156-161,242-254 (+ src/math.hh:31-40), AutoCast<complex<int16>> on complex<uint8>  src/autocast.hh:62,187-194.
+//
+// Structure (algebra: iqbb_i16.hip, "MFMA formulation"):
+//   * A wave slice = 512 consecutive samples of one channel (64 decimation groups; lane (n, h) ends up owning group
+//     2n + h). A slice is HOT when nothing about it touches the call's borders (slice_is_hot): its window of
+//     512 + 16(S-1) samples lies inside the input, none of its groups is the call's first or last emitted one.
+//   * Hot loop, wave-autonomous, no workgroup barrier: the wave's raw window comes in by LDS-DMA
+//     (global_load_lds_dwordx4) into one of TWO wave-private window buffers, is split IN PLACE into the byte planes
+//     the MFMA operands are read from (cs16: low plane | high plane; cu8: the one high plane, (b + 129) mod 256), and
+//     only this wave reads them. While slice i is split, multiplied and finished in buffer i&1, the DMA of slice i+1
+//     lands in the other buffer: it is issued at the top of iteration i and has a whole slice period to arrive
+//     (round 2's single raw area could only be refilled after the split, half a period before it was needed).
+//   * The K-step range that needs the taps' high byte plane is a compile-time parameter [S0, S0 + NH): the K loop is
+//     straight-line code with the operands of step s+1 in flight while step s's MFMAs issue.
+//   * Persistent grid of (virtual) 4-wave workgroups, static equal-length work units, rotating wave priority.
+//     A real workgroup is NW waves (4, 8 or 16): NW/4 virtual workgroups sharing one LDS copy of the tap fragments and
+//     the rotation table — long filters' fragments (17-34 KB) would otherwise cap the CU at 2 waves per SIMD.
+//   * Cold phase, same launch: every virtual workgroup, done with its units, takes the channels vb, vb + vgx, ...:
+//     wave w computes slice w of tile 0 and of the tiles from bt_hi on where that slice is cold — window by clamped
+//     ordinary loads (history / input / zeros), the same LDS-resident tap fragments and table, the general epilogue
+//     (group_sum<EDGE> + group_finish: edge masks, carry, first-sample quirk, state) — and rolls the FIR history.
+#pragma once
+#include "iqbb_common.hpp"
+
+#include <type_traits>
+
+namespace sdrhip {
+
+// ---- geometry shared by host and device ----------------------------------------------------------------------
+constexpr int hot_win(int S) { return 512 + 16 * (S - 1); }                    // samples in a wave window
+constexpr int hot_plb(int S) { return 2 * hot_win(S) + 32; }                   // bytes per byte plane (+ one chunk pair: both parity halves 16-byte aligned)
+constexpr int hot_bufb(int S, bool cu8) { return cu8 ? hot_plb(S) : 2 * hot_plb(S); }   // one window buffer
+constexpr int hot_lds_bytes(int S, int NH, bool cu8, int NW, bool wide) {
+  return (wide ? 4096 : 1024) + (S + NH) * 1024 + NW * 2 * hot_bufb(S, cu8);
+}
+constexpr int hot_lds_cap(int NW) { return NW == 4 ? 40960 : NW == 8 ? 81920 : 163840; }   // 4 waves per SIMD: 160 KB / workgroups per CU
+// 4 KB rotation table ({Lx, Ly, -Ly, 0} x 256: one SDWA shift makes the address, no subtraction) while it fits
+constexpr bool hot_wide(int S, int NH, bool cu8, int NW) { return hot_lds_bytes(S, NH, cu8, NW, true) <= hot_lds_cap(NW); }
+
+struct HotRange { int S0, NH, NW; };
+// per S: centred high-plane ranges, narrowest first; the last one covers every step
+constexpr HotRange hot_ranges_2[] = {{0, 2, 4}};
+constexpr HotRange hot_ranges_3[] = {{0, 3, 4}};
+constexpr HotRange hot_ranges_5[] = {{1, 3, 4}, {0, 5, 4}};
+constexpr HotRange hot_ranges_9[] = {{3, 3, 4}, {2, 5, 4}, {1, 7, 4}, {0, 9, 4}};
+constexpr HotRange hot_ranges_17[] = {{6, 5, 8}, {4, 9, 8}, {0, 17, 16}};
+inline const HotRange *hot_ranges(int S, int *count) {
+  switch (S) {
+    case 2: *count = 1; return hot_ranges_2;
+    case 3: *count = 1; return hot_ranges_3;
+    case 5: *count = 2; return hot_ranges_5;
+    case 9: *count = 4; return hot_ranges_9;
+    case 17: *count = 3; return hot_ranges_17;
+    default: *count = 0; return nullptr;
+  }
+}
+
+struct HotLaunch { unsigned grid; hipStream_t stream; };
+// one function per translation unit (iqbb_hot_s*.hip): `range` indexes hot_ranges(S)
+void hot_launch_s2(bool cu8, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
+void hot_launch_s3(bool cu8, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
+void hot_launch_s5(bool cu8, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
+void hot_launch_s9_cs16(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
+void hot_launch_s9_cu8(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
+void hot_launch_s17_cs16(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
+void hot_launch_s17_cu8(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
+
+}  // namespace sdrhip
+
+namespace {
+
+// A wave slice (tile t, wave w of the tile's 4 waves: 64 groups, the first of them FM's overlap slot) is "hot" when
+// nothing about it touches the call's borders: its window lies inside the input, none of its groups is the call's first
+// (carry, the D+1 first window, FM's out[0] / out[1] rules) nor its last emitted one (that group hands the demodulator's
+// angle and the window carry to the next call — state only the cold phase's epilogue writes; found by
+// test_one_launch_kernel_random_long_calls), and all of them complete and are emitted.
+__host__ __device__ __forceinline__ bool slice_is_hot(int halo, int base0_rel, int OG, int ovl, int N, int n_out, int tile, int w) {
+  const int qf = tile * OG - ovl + w * (64 - ovl);   // the slice's first group (output index within the call)
+  const int ws = base0_rel + qf * 8 - halo;          // its window's first sample (N < 2^30: no overflow)
+  return ws >= 0 && ws + 512 + halo <= N && qf >= 1 && qf + 63 < n_out - 1;
+}
+
+template <int S, int S0, int NH, bool ROT, int EPI, bool CU8, int NW>
+__device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &b) {
+  static_assert(S >= 2 && S0 >= 0 && NH >= 1 && S0 + NH <= S, "high-plane range inside the K loop");
+  static_assert(NW == 4 || NW == 8 || NW == 16, "4-wave virtual workgroups");
+  constexpr int HALO = 16 * (S - 1), WIN = hot_win(S), PLB = hot_plb(S), HALF = PLB / 2, BUFB = hot_bufb(S, CU8);
+  constexpr int NPIECE = (CU8 ? 2 * WIN : 4 * WIN) / 16;        // 16-byte pieces of the raw window (cs16: 4 samples, cu8: 8)
+  constexpr int NDMA = (NPIECE + 63) / 64;                     // DMA wave-instructions per window
+  constexpr int LASTL = NPIECE - 64 * (NDMA - 1);              // lanes of the last one
+  static_assert(NDMA <= 3, "immediate offsets 0 / 1024 / 2048");
+  constexpr bool WIDE = hot_wide(S, NH, CU8, NW);
+  static_assert(hot_lds_bytes(S, NH, CU8, NW, WIDE) <= hot_lds_cap(NW), "LDS budget for 4 waves per SIMD");
+  constexpr int TBLW = WIDE ? 1024 : 256;   // dwords
+  constexpr int TPBH = 64 * NW;
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  // Rotation table at LDS offset 0. WIDE: 256 entries of 16 bytes {Lx, Ly, -Ly, 0}, the 128-entry table twice — a table
+  // address is then byte 1 of the phase counter << 4 with no mask, and the complex product needs no subtraction.
+  // Otherwise 128 entries {Lx, Ly}. A negative shift reads the table backwards: it is stored reversed.
+  int2 *lut_s = reinterpret_cast<int2 *>(smem);
+  v4i *taps_s = reinterpret_cast<v4i *>(smem + TBLW);
+  // (the wave index is wave-uniform but the compiler cannot know: through readfirstlane the slice bookkeeping runs on
+  // the scalar unit)
+  const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, n = l & 31, h = l >> 5;
+  const int wv = w & 3;                                                   // slice of a tile this wave computes
+  const int bx = (int)blockIdx.x * (NW / 4) + (w >> 2), gx = (int)gridDim.x * (NW / 4);   // virtual workgroup, virtual grid
+  // tap fragments in LDS: the S low-plane fragments, then only the NH high-plane fragments of steps [S0, S0 + NH)
+  char *wbase = reinterpret_cast<char *>(smem + TBLW + (S + NH) * 64 * 4) + w * (2 * BUFB);
+  for (int i = tid; i < S * 64; i += TPBH) taps_s[i] = a.tapfrag[(2 * (i >> 6) + 1) * 64 + (i & 63)];
+  for (int i = tid; i < NH * 64; i += TPBH) taps_s[S * 64 + i] = a.tapfrag[(2 * (S0 + (i >> 6))) * 64 + (i & 63)];
+  if (tid < 256) {
+    const int2 e = a.lut[(tid & 127) ^ (a.negative ? 127 : 0)];
+    if (WIDE) reinterpret_cast<v4i *>(smem)[tid] = v4i{e.x, e.y, -e.y, 0};
+    else if (tid < 128) lut_s[tid] = e;
+  }
+
+  const int OGw = 64 - a.ovl, gw = wv * OGw;
+  // PERSISTENT grid: gx virtual workgroups (4 per CU) stay resident and walk the work units u = bx, bx + gx, ...;
+  // unit u = (channel u / G, tile group u % G of `tpw` consecutive tiles). All units are the same length, so the static
+  // assignment balances (one workgroup per unit left ~3 of 4 workgroups per CU resident: the unsynchronised waves of a
+  // workgroup finish up to 2x apart and its LDS stays allocated until the slowest is done).
+  int u = bx;
+  int c = u / a.G, g = u - c * a.G;   // (one division per wave, at start; afterwards (c, g) advance by (dq, dr))
+  int tile = a.t_lo + g * a.tpw, tile_end = min(tile + a.tpw, a.t_hi);
+  auto skip_cold = [&](int &u_, int &c_, int &g_, int &tile_, int &tile_end_) {
+    while (u_ < a.U && !slice_is_hot(HALO, a.base0_rel, a.OG, a.ovl, a.N, a.n_out, tile_, wv)) {
+      if (++tile_ >= tile_end_) {
+        u_ += gx; c_ += a.dq; g_ += a.dr;
+        if (g_ >= a.G) { g_ -= a.G; c_++; }
+        tile_ = a.t_lo + g_ * a.tpw; tile_end_ = min(tile_ + a.tpw, a.t_hi);
+      }
+    }
+  };
+  skip_cold(u, c, g, tile, tile_end);
+  // The window of tile t starts at sample base0_rel + (t * OG - ovl + gw) * 8 - HALO of the channel's row. The lane's
+  // global pointer: scalar base + the lane's 32-bit byte offset, ONE 64-bit vector add per slice; the DMA pieces differ
+  // by the instruction's immediate offset, which applies to the global AND the LDS address alike.
+  const uint32_t lane_byte = 16u * (uint32_t)l;
+  constexpr int SB = CU8 ? 2 : 4;   // bytes per input sample
+  auto dma_src = [&](int c_, int tile_) {
+    return reinterpret_cast<const char *>(a.in) + ((long)c_ * a.in_stride + (a.base0_rel + (tile_ * a.OG - a.ovl + gw) * 8 - HALO)) * SB + lane_byte;
+  };
+  // The DMA is issued from inline asm, not through __builtin_amdgcn_global_load_lds: the compiler's wait-count pass
+  // puts an `s_waitcnt vmcnt(0)` in front of every LDS access that MAY alias an LDS-DMA destination it knows of, and
+  // it cannot tell the two window buffers apart — the prefetch would be waited for right after it was issued. What the
+  // compiler does not see it does not wait for; the waits for these loads are the explicit counted ones below (an
+  // untracked load only ever makes a compiler-generated vmcnt wait longer, never shorter: VMEM retires in order).
+  // LDS address = M0 + instruction offset + 16 * lane; SALU write of M0 -> LDS-DMA needs one wait state.
+  auto dma_issue = [&](const char *src, char *buf) {
+#ifndef K1_ABL_NOFETCH
+    const unsigned ldsb = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)buf);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    if (NDMA == 1) {
+      if (l < LASTL) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(ldsb) : "memory", "m0");
+    } else if (NDMA == 2) {
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(ldsb) : "memory", "m0");
+      if (l < LASTL) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:1024" :: "v"(src), "s"(ldsb) : "memory", "m0");
+    } else {
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024" :: "v"(src), "s"(ldsb) : "memory", "m0");
+      if (l < LASTL) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:2048" :: "v"(src), "s"(ldsb) : "memory", "m0");
+    }
+#pragma clang diagnostic pop
+#endif
+  };
+  if (u < a.U) dma_issue(dma_src(c, tile), wbase);
+  __syncthreads();   // tap fragments and table in place (the only workgroup barrier)
+
+  // plane byte offsets of this lane's pieces. cs16: piece p = 4 samples = half of chunk j = p >> 1 (a chunk = 8 samples =
+  // 16 bytes of a plane); cu8: piece p = chunk p. Chunks are de-interleaved by parity (even chunks in the first half of
+  // the plane, odd in the second): a lane's K steps walk consecutive chunks and the 16 lanes a ds_read_b128 services
+  // together cover one contiguous 256-byte bank row.
+  int dofs[NDMA];
+#pragma unroll
+  for (int k = 0; k < NDMA; k++) {
+    const int p = l + 64 * k;
+    if (CU8) dofs[k] = (p & 1) * HALF + (p >> 1) * 16;
+    else { const int j = p >> 1; dofs[k] = (j & 1) * HALF + (j >> 1) * 16 + (p & 1) * 8; }
+  }
+  const int coff = h * HALF + 16 * n;   // chunk 2(n + s) + h of the wave's window
+  // phase counters of the lane's samples 0 and 1 relative to the wave's first sample, as a 16-bit pair (only bits 8..14
+  // of a counter pick the table entry); the wave's part is scalar and joins per slice in one v_pk_add_u16 per sample pair
+  const uint32_t lane_cnt = (uint32_t)(MF_BLK * n + 8 * h) * a.inc;
+  const uint32_t lane_pair = (lane_cnt & 0xffffu) | ((lane_cnt + a.inc) << 16);
+
+  // + 128*sum(a) rides into the low-plane accumulator as the first MFMA's C operand: a 16-register block that must
+  // stay in vector registers (left to itself the compiler keeps it in 16 scalar registers, spills them, and pays 16
+  // v_readlane + 16 v_mov per slice)
+  v16i cinit;
+#pragma unroll
+  for (int r = 0; r < 16; r++) cinit[r] = (r & 1) ? a.cim : a.cre;
+  asm volatile("" : "+v"(cinit));
+
+#ifdef K1_STAMPS   // diagnostic build: shader-clock stamps at the phase boundaries, summed per phase per wave
+  unsigned long long st_acc[5] = {0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
+  const unsigned long long st_r0 = __builtin_amdgcn_s_memrealtime();
+  unsigned st_tiles = 0;
+#define K1_STAMP(i_) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i_] += t_ - st_t; st_t = t_; } while (0)
+#else
+#define K1_STAMP(i_) do { } while (0)
+#endif
+#ifndef K1_PRIO_ROT
+#define K1_PRIO_ROT 1
+#endif
+  unsigned prio_it = 0;
+  const unsigned prio_slot = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 3u;   // HW_REG_HW_ID[3:0]: the wave's slot in its SIMD
+
+  // one slice out of window buffer PAR (compile-time: the buffer's offset folds into the LDS instructions' immediates)
+  auto slice = [&](auto par_) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(par_)::value;
+    char *cb = wbase + PAR * BUFB, *nb = wbase + (1 - PAR) * BUFB;
+    // the step after this one: next tile of the unit, or the first tile of the workgroup's next unit
+    int nu = u, nc = c, ng = g, ntile = tile + 1, ntile_end = tile_end;
+    if (ntile >= tile_end) {
+      nu = u + gx; nc = c + a.dq; ng = g + a.dr;
+      if (ng >= a.G) { ng -= a.G; nc++; }
+      ntile = a.t_lo + ng * a.tpw; ntile_end = min(ntile + a.tpw, a.t_hi);
+    }
+    skip_cold(nu, nc, ng, ntile, ntile_end);
+    const bool more = nu < a.U;
+    const int q0 = tile * a.OG - a.ovl;
+    // Fairness: the SIMD arbitrates its waves by priority, then AGE, and in a persistent grid the ages never change —
+    // the oldest wave of a SIMD ran at full speed and was done after 64 us, the youngest starved and finished alone
+    // at 120 us (s_memrealtime stamps). The priority rotates over the SIMD's four wave slots, one step per slice.
+    if (K1_PRIO_ROT == 1) {
+      switch ((prio_it++ + prio_slot) & 3u) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+      }
+    }
+    // ---- the next slice's window starts its journey into the other buffer (its planes were last read in the previous
+    // slice's K loop); then wait for this slice's own window: everything older than those NDMA instructions ----
+    if (more) {
+      dma_issue(dma_src(nc, ntile), nb);
+      if (NDMA == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else if (NDMA == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    K1_STAMP(0);
+    // ---- raw window -> byte planes, in place: every read of the wave is issued before its first write, and the LDS
+    // executes one wave's instructions in order ----
+    {
+      uint4 x[NDMA];
+#pragma unroll
+      for (int k = 0; k < NDMA; k++)
+        if (k < NDMA - 1 || l < LASTL) x[k] = *reinterpret_cast<const uint4 *>(cb + 16 * (l + 64 * k));
+      asm volatile("" ::: "memory");
+#ifndef K1_ABL_NOCONV
+#pragma unroll
+      for (int k = 0; k < NDMA; k++) {
+        if (k < NDMA - 1 || l < LASTL) {
+          if (CU8) {   // AutoCast: high byte (b + 129) mod 256, low byte 0 (no low plane at all)
+            *reinterpret_cast<uint4 *>(cb + dofs[k]) = make_uint4(add129_bytes(x[k].x), add129_bytes(x[k].y), add129_bytes(x[k].z), add129_bytes(x[k].w));
+          } else {
+            uint2 l2, h2;
+            l2.x = __builtin_amdgcn_perm(x[k].y, x[k].x, 0x06040200u) ^ 0x80808080u;
+            l2.y = __builtin_amdgcn_perm(x[k].w, x[k].z, 0x06040200u) ^ 0x80808080u;
+            h2.x = __builtin_amdgcn_perm(x[k].y, x[k].x, 0x07050301u);
+            h2.y = __builtin_amdgcn_perm(x[k].w, x[k].z, 0x07050301u);
+            *reinterpret_cast<uint2 *>(cb + dofs[k]) = l2;
+            *reinterpret_cast<uint2 *>(cb + PLB + dofs[k]) = h2;
+          }
+        }
+      }
+#endif
+    }
+    // (the plane reads below see these writes: same wave, in order. The empty asm statements keep the COMPILER from
+    // moving LDS accesses across: no barrier or fence instruction separates them.)
+    K1_STAMP(1);
+    asm volatile("" ::: "memory");
+
+    // ---- K loop: operands of step s+1 in flight while the MFMAs of step s issue ----
+    v16i acc_hh = {0}, acc_mid = {0}, acc_ll = {0};
+    if (!CU8) acc_ll = cinit;
+    const char *pl = cb + coff, *ph = cb + (CU8 ? 0 : PLB) + coff;
+    v4i uh = *reinterpret_cast<const v4i *>(ph), ul = uh;
+    if (!CU8) ul = *reinterpret_cast<const v4i *>(pl);
+    v4i Al = taps_s[l], Ah = Al;
+    if (S0 == 0) Ah = taps_s[S * 64 + l];
+#ifdef K1_ABL_NOKLOOP
+    acc_mid[0] = uh.x ^ ul.x ^ Al.x ^ Ah.x;
+#else
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+      v4i uh_n = uh, ul_n = ul, Al_n = Al, Ah_n = Ah;
+      if (s + 1 < S) {
+        uh_n = *reinterpret_cast<const v4i *>(ph + 16 * (s + 1));
+        if (!CU8) ul_n = *reinterpret_cast<const v4i *>(pl + 16 * (s + 1));
+        Al_n = taps_s[(s + 1) * 64 + l];
+        if (s + 1 >= S0 && s + 1 < S0 + NH) Ah_n = taps_s[(S + s + 1 - S0) * 64 + l];
+      }
+      acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, uh, acc_mid, 0, 0, 0);
+      if (!CU8) acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, ul, acc_ll, 0, 0, 0);
+      if (s >= S0 && s < S0 + NH) {
+        acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, uh, acc_hh, 0, 0, 0);
+        if (!CU8) acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, ul, acc_mid, 0, 0, 0);
+      }
+      uh = uh_n; ul = ul_n; Al = Al_n; Ah = Ah_n;
+    }
+#endif
+#ifdef K1_STAMPS
+    asm volatile("s_nop 0" : "+v"(acc_hh), "+v"(acc_mid), "+v"(acc_ll));   // the accumulators are complete before the stamp
+#endif
+    K1_STAMP(2);
+
+    // ---- epilogue: lane (n, h) owns group 2n + h of the wave ----
+    const uint32_t wave_cnt = (a.n0_lo + (uint32_t)(a.base0_rel + (q0 + gw) * 8)) * a.inc;   // scalar unit
+    int L[8][3];
+#ifdef K1_ABL_NOEPI
+    if (false) {
+#else
+    if (ROT) {
+#endif
+      typedef int v2i __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++) {
+        const uint32_t wc = (wave_cnt + 2u * jj * a.inc) & 0xffffu, wpair = wc | (wc << 16);
+        uint32_t pr, o0, o1;
+        asm("v_pk_add_u16 %0, %1, %2" : "=v"(pr) : "v"(lane_pair), "s"(wpair));
+        if (WIDE) {
+          asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(o0) : "s"(4), "v"(pr));
+          asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(o1) : "s"(4), "v"(pr));
+          const v4i e0 = *reinterpret_cast<__attribute__((address_space(3))) const v4i *>((uintptr_t)o0);
+          const v4i e1 = *reinterpret_cast<__attribute__((address_space(3))) const v4i *>((uintptr_t)o1);
+          L[2 * jj][0] = e0.x; L[2 * jj][1] = e0.y; L[2 * jj][2] = e0.z;
+          L[2 * jj + 1][0] = e1.x; L[2 * jj + 1][1] = e1.y; L[2 * jj + 1][2] = e1.z;
+        } else {
+          o0 = (pr >> 5) & (127u << 3); o1 = (pr >> 21) & (127u << 3);
+          const v2i e0 = *reinterpret_cast<__attribute__((address_space(3))) const v2i *>((uintptr_t)o0);
+          const v2i e1 = *reinterpret_cast<__attribute__((address_space(3))) const v2i *>((uintptr_t)o1);
+          L[2 * jj][0] = e0.x; L[2 * jj][1] = e0.y; L[2 * jj + 1][0] = e1.x; L[2 * jj + 1][1] = e1.y;
+        }
+      }
+    }
+    int2 sum = make_int2(0, 0);
+#ifdef K1_ABL_NOEPI
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) { sum.x += acc_hh[r] ^ acc_mid[r] ^ acc_ll[r]; sum.y += acc_hh[r + 1] ^ acc_mid[r + 1] ^ acc_ll[r + 1]; }
+#else
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      unsigned tre = ((unsigned)acc_hh[2 * j] << 8) + (unsigned)acc_mid[2 * j];   // (compiler code: it pads the MFMA -> VALU hazard)
+      unsigned tim = ((unsigned)acc_hh[2 * j + 1] << 8) + (unsigned)acc_mid[2 * j + 1];
+      int rr, ri;
+      if (CU8) {   // S = t << 8 exactly
+        rr = (int)(tre << 8) >> 14; ri = (int)(tim << 8) >> 14;
+      } else {
+        asm("" : "+v"(tre)); asm("" : "+v"(tim));   // no re-association into 2 shifts + add3
+        rr = (int)((tre << 8) + (unsigned)acc_ll[2 * j]) >> 14; ri = (int)((tim << 8) + (unsigned)acc_ll[2 * j + 1]) >> 14;
+      }
+      if (ROT) {
+        const int x = WIDE ? mad24a(L[j][0], rr, mul24a(L[j][2], ri)) : sub32(mul24a(L[j][0], rr), mul24a(L[j][1], ri));
+        const int y = mad24a(L[j][0], ri, mul24a(L[j][1], rr));
+        sum.x = add_hi16(x, sum.x); sum.y = add_hi16(y, sum.y);
+      } else {
+        sum.x = (int)((unsigned)sum.x + (unsigned)rr); sum.y = (int)((unsigned)sum.y + (unsigned)ri);
+      }
+    }
+#endif
+#ifdef K1_STAMPS
+    asm volatile("" : "+v"(sum.x), "+v"(sum.y));
+#endif
+    K1_STAMP(3);
+    const int glw = 2 * n + h;
+    const long q = (long)c * a.out_stride + q0 + gw + glw;
+    // libstdc++'s (s*8)/(8*8) (src/baseband.hh:214): |s| <= 9 * 2^17 (a window of 16-bit rotated values, or of 18-bit FIR
+    // values when there is no shift), so nothing wraps and it is trunc(s / 8) + the int16 wrap of the assignment
+    const int yr = div8_i16(sum.x), yi = div8_i16(sum.y);
+    if (EPI == SDRHIP_EPI_NONE) {
+      reinterpret_cast<uint32_t *>(a.out)[q] = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
+    } else if (EPI == SDRHIP_EPI_AM) {
+      reinterpret_cast<short *>(a.out)[q] = am_i16(yr, yi);
+    } else if (EPI == SDRHIP_EPI_USB) {
+      reinterpret_cast<short *>(a.out)[q] = usb_i16(yr, yi);
+    } else {
+      const int phi = fm_phi(yr, yi);
+      const int prev = prev_group_value(phi, h);
+      if (glw >= 1) reinterpret_cast<short *>(a.out)[q] = (short)(prev - phi);   // group 0 only supplies the previous angle
+    }
+    K1_STAMP(4);
+#ifdef K1_STAMPS
+    st_tiles++;
+#endif
+    u = nu; c = nc; g = ng; tile = ntile; tile_end = ntile_end;
+  };
+  while (u < a.U) {
+    slice(std::integral_constant<int, 0>{});
+    if (!(u < a.U)) break;
+    slice(std::integral_constant<int, 1>{});
+  }
+
+  // ---- the call's COLD slices --------------------------------------------------------------------------------
+  // The slices slice_is_hot() rejects — history in the window, the call's first group, incomplete or unemitted
+  // groups, the end of the input — are a few per channel (2 of 130 on the headline workload).
+  {
+    char *cb = wbase;
+    for (int cc = bx; cc < a.C; cc += gx) {
+      for (int t = 0; t < b.tiles; t = (t == 0 ? max(b.bt_hi, 1) : t + 1)) {
+        const int q0 = t * a.OG - a.ovl, groups_here = min(b.CG, b.n_groups - q0);
+        if (slice_is_hot(HALO, a.base0_rel, a.OG, a.ovl, a.N, a.n_out, t, wv) || gw + a.ovl >= groups_here) continue;
+        // the wave's window by ordinary loads: history / input / zeros per sample, every load issued from a clamped
+        // address and masked afterwards (all in flight together)
+        const int first = a.base0_rel + (q0 + gw) * 8 - HALO;
+        const uint32_t *hrow = b.hist_old + (long)cc * b.HH;
+        if (CU8) {
+          const uint16_t *row = reinterpret_cast<const uint16_t *>(a.in) + (long)cc * a.in_stride;
+          uint32_t v[NDMA][8];
+#pragma unroll
+          for (int k = 0; k < NDMA; k++) {
+            const int pp = min(l + 64 * k, NPIECE - 1);
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[k][j] = row[max(min(first + 8 * pp + j, a.N - 1), 0)];
+          }
+#pragma unroll
+          for (int k = 0; k < NDMA; k++) {
+            const int pp = min(l + 64 * k, NPIECE - 1);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+              const int rel = first + 8 * pp + j;
+              // the sample's two high-plane bytes: AutoCast of the input bytes, or bytes 1 and 3 of a history dword
+              uint32_t hb = ((v[k][j] + 0x81u) & 0xffu) | ((v[k][j] + 0x8100u) & 0xff00u);
+              if (rel >= a.N) hb = 0u;
+              if (first < 0) {   // (wave-uniform: only the call's first slices reach into the history)
+                const uint32_t xh = hrow[max(b.HH + rel, 0)];
+                if (rel < 0) hb = (b.HH + rel >= 0) ? (((xh >> 8) & 0xffu) | ((xh >> 16) & 0xff00u)) : 0u;
+              }
+              v[k][j] = hb;
+            }
+            if (k < NDMA - 1 || l < LASTL)
+              *reinterpret_cast<uint4 *>(cb + dofs[k]) = make_uint4(v[k][0] | (v[k][1] << 16), v[k][2] | (v[k][3] << 16),
+                                                                    v[k][4] | (v[k][5] << 16), v[k][6] | (v[k][7] << 16));
+          }
+        } else {
+          const uint32_t *row = reinterpret_cast<const uint32_t *>(a.in) + (long)cc * a.in_stride;
+          uint32_t v[NDMA][4];
+#pragma unroll
+          for (int k = 0; k < NDMA; k++) {
+            const int pp = min(l + 64 * k, NPIECE - 1);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              const int rel = first + 4 * pp + j, hh = b.HH + rel;
+              const uint32_t *src = rel >= 0 ? row + min(rel, a.N - 1) : hrow + max(hh, 0);
+              v[k][j] = *src;
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < NDMA; k++) {
+            const int pp = min(l + 64 * k, NPIECE - 1);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              const int rel = first + 4 * pp + j;
+              if (rel >= a.N || b.HH + rel < 0) v[k][j] = 0u;
+            }
+            if (k < NDMA - 1 || l < LASTL) {
+              uint2 l2, h2;
+              l2.x = __builtin_amdgcn_perm(v[k][1], v[k][0], 0x06040200u) ^ 0x80808080u;
+              l2.y = __builtin_amdgcn_perm(v[k][3], v[k][2], 0x06040200u) ^ 0x80808080u;
+              h2.x = __builtin_amdgcn_perm(v[k][1], v[k][0], 0x07050301u);
+              h2.y = __builtin_amdgcn_perm(v[k][3], v[k][2], 0x07050301u);
+              *reinterpret_cast<uint2 *>(cb + dofs[k]) = l2;
+              *reinterpret_cast<uint2 *>(cb + PLB + dofs[k]) = h2;
+            }
+          }
+        }
+        asm volatile("" ::: "memory");   // (one wave's LDS operations execute in order: the reads below see these writes)
+        v16i acc_hh = {0}, acc_mid = {0}, acc_ll = {0};
+        if (!CU8) {
+#pragma unroll
+          for (int r = 0; r < 16; r++) acc_ll[r] = (r & 1) ? a.cim : a.cre;
+        }
+        const char *pl = cb + coff, *ph = cb + (CU8 ? 0 : PLB) + coff;
+#pragma unroll
+        for (int s_ = 0; s_ < S; s_++) {
+          const v4i uh = *reinterpret_cast<const v4i *>(ph + 16 * s_);
+          const v4i Al = taps_s[s_ * 64 + l];
+          acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, uh, acc_mid, 0, 0, 0);
+          if (!CU8) {
+            const v4i ul = *reinterpret_cast<const v4i *>(pl + 16 * s_);
+            acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, ul, acc_ll, 0, 0, 0);
+            if (s_ >= S0 && s_ < S0 + NH) {
+              const v4i Ah = taps_s[(S + s_ - S0) * 64 + l];
+              acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, uh, acc_hh, 0, 0, 0);
+              acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, ul, acc_mid, 0, 0, 0);
+            }
+          } else if (s_ >= S0 && s_ < S0 + NH) {
+            acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(taps_s[(S + s_ - S0) * 64 + l], uh, acc_hh, 0, 0, 0);
+          }
+        }
+        const int tb = a.base0_rel + q0 * 8, rel0 = tb + 8 * gw + MF_BLK * n + 8 * h;
+        const int2 sum = group_sum<ROT, CU8, true, WIDE ? 2 : 1>(b, acc_hh, acc_mid, acc_ll, rel0);
+        group_finish(b, b.lut, cc, n, h, gw, q0, groups_here, sum);   // (its one table user, the stream's first sample, reads global memory)
+        asm volatile("" ::: "memory");
+      }
+      for (int k = tid & 255; k < b.HH; k += 256) {   // the FIR history for the next call (this virtual workgroup's channel)
+        const long qq = (long)a.N + k;   // index into concat(hist_old, in)
+        b.hist_new[(long)cc * b.HH + k] = qq < b.HH ? b.hist_old[(long)cc * b.HH + qq] : raw_x(b, cc, qq - b.HH);
+      }
+    }
+  }
+#ifdef K1_STAMPS
+  if (l == 0 && a.stamps) {
+    const unsigned wv_ = ((unsigned)bx * 4 + wv) & 32767u;
+    for (int i = 0; i < 5; i++) a.stamps[wv_ * 8 + i] = st_acc[i];
+    a.stamps[wv_ * 8 + 5] = (unsigned long long)st_tiles | ((unsigned long long)__builtin_amdgcn_s_getreg((15 << 11) | 4) << 32);
+    a.stamps[wv_ * 8 + 6] = st_r0;
+    a.stamps[wv_ * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
+}
+
+// One launch per call: the hot grid, then each virtual workgroup's share of the cold slices.
+template <int S, int S0, int NH, bool ROT, int EPI, bool CU8, int NW>
+__global__ __launch_bounds__(64 * NW, 4) void iqbb_hot_kernel(const HotArgs a, const IqbbArgs b) {
+  iqbb_hot_body<S, S0, NH, ROT, EPI, CU8, NW>(a, b);
+}
+
+template <int S, int S0, int NH, bool CU8, int NW>
+void hot_launch_one(bool rot, int epi, const HotLaunch &hl, const HotArgs &ha, const IqbbArgs &b) {
+  const size_t lds = (size_t)hot_lds_bytes(S, NH, CU8, NW, hot_wide(S, NH, CU8, NW));
+  const dim3 grid(hl.grid, 1), block(64 * NW);
+#define SDRHIP_HOT(R_, E_) hipLaunchKernelGGL((iqbb_hot_kernel<S, S0, NH, R_, E_, CU8, NW>), grid, block, lds, hl.stream, ha, b)
+#define SDRHIP_HOT_E(R_) do { switch (epi) { \
+    case SDRHIP_EPI_FM: SDRHIP_HOT(R_, SDRHIP_EPI_FM); break; \
+    case SDRHIP_EPI_AM: SDRHIP_HOT(R_, SDRHIP_EPI_AM); break; \
+    case SDRHIP_EPI_USB: SDRHIP_HOT(R_, SDRHIP_EPI_USB); break; \
+    default: SDRHIP_HOT(R_, SDRHIP_EPI_NONE); break; } } while (0)
+  if (rot) SDRHIP_HOT_E(true); else SDRHIP_HOT_E(false);
+#undef SDRHIP_HOT_E
+#undef SDRHIP_HOT
+}
+
+}  // namespace

@@ -16,455 +16,10 @@
 // The FIR is the hot loop: per input sample 2*order v_dot2_i32_i16 (packed (re,im) int16 sample
 // against taps packed (Kr,-Ki) and (Ki,Kr)); each lane owns 8 consecutive samples and slides a
 // 16-sample register window over an LDS-staged tile; taps arrive through the scalar cache.
-#include "fm_phi.hpp"
-#include "sdrhip_internal.hpp"
-
-#include <cstdlib>
-
-using namespace sdrhip;
+#include "iqbb_common.hpp"
+#include "iqbb_hot.hpp"
 
 namespace {
-
-constexpr int TPB = 256;       // threads per workgroup (4 waves)
-constexpr int R = 8;           // consecutive input samples per lane
-constexpr int TI = TPB * R;    // input samples per tile
-constexpr int TAPC = 8;        // taps per unrolled chunk (order is zero-padded at the front to a multiple)
-constexpr int MAX_ORDER = 2048;
-
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
-
-struct IqbbArgs {
-  const uint32_t *in; long in_stride;            // cs16 packed as one dword per sample (or cu8: one ushort, in_cu8)
-  int in_cu8;                                    // input is complex<uint8> and AutoCast<cs16> is applied on load
-  int in_real;                                   // real-input BaseBand<int16_t>: one int16 per sample, taps are raw (Kr, Ki) int32
-  int i8;                                        // IQBaseBand<int8_t> (VALU kernel only): complex<int8> in and out, the frequency shift in int16 (see rotate)
-  const uint32_t *hist_old; uint32_t *hist_new;  // C x HH samples preceding the call
-  const int2 *acc_old; int2 *acc_new;            // partial box sum of the open group
-  const short *fm_old; short *fm_new;            // FMDemod::_last_value
-  const uint2 *taps;                             // OP x {pack(Kr,-Ki), pack(Ki,Kr)}
-  const int2 *lut; uint32_t inc; int negative;
-  int OP, HH, D, N;
-  uint32_t n0_lo;   // absolute index of the call's first sample, low 32 bits (LUT phase)
-  int base0_rel;    // index (relative to the call start) of the first sample of the first group
-  int n_groups;     // groups touched by this call
-  int n_out;        // groups that complete in this call (always the first n_out of them)
-  int extra0;       // absolute sample 0 joins group 0 (src/baseband.hh:200,212: D+1 first window)
-  int CG, OG, ovl;  // groups computed / emitted per tile; FM recomputes one leading group
-  int CGr;          // CG rounded up to 4: ybuf[CGr] is followed by the FM angle cache [CGr]
-  void *out; long out_stride; int epilogue;
-  const v4i *tapfrag; int cre, cim;
-  unsigned ah_mask;   // bit s: the high-byte tap fragments of K step s are not all zero (small outer taps: |a| < 128)
-  int lpg;          // path 3: lanes that share one box window
-  int tiles, tpw;   // tiles per channel in this call; consecutive tiles walked by one workgroup (MFMA path)   // MFMA path: tap fragments, 128*sum(a) per component
-  int border, bt_hi;   // border launch beside the hot kernel: one workgroup per channel walks tile 0, then tiles bt_hi .. tiles-1
-};
-
-// AutoCast< complex<int16_t> > on a complex<uint8_t> sample (reference src/autocast.hh:62,187-194): each byte is
-// read as int8 and becomes (int16(b) - 127) << 8, i.e. low byte 0 and high byte (b + 129) mod 256
-__device__ __forceinline__ uint32_t cast_cu8(uint32_t u16) {
-  return (((u16 & 0xffu) + 129u) & 0xffu) << 8 | ((((u16 >> 8) & 0xffu) + 129u) & 0xffu) << 24;
-}
-__device__ __forceinline__ uint32_t raw_x(const IqbbArgs &a, int c, long rel) {   // 0 <= rel < N
-  if (a.in_cu8) return cast_cu8(reinterpret_cast<const uint16_t *>(a.in)[(long)c * a.in_stride + rel]);
-  if (a.in_real) return (uint32_t)(int)reinterpret_cast<const short *>(a.in)[(long)c * a.in_stride + rel];   // sign-extended
-  if (a.i8) {   // complex<int8_t>: both bytes sign-extended to the packed (re, im) int16 pair the FIR works on
-    const uint32_t u = reinterpret_cast<const uint16_t *>(a.in)[(long)c * a.in_stride + rel];
-    return ((uint32_t)(int)(signed char)(u & 0xffu) & 0xffffu) | ((uint32_t)(int)(signed char)(u >> 8) << 16);
-  }
-  return a.in[(long)c * a.in_stride + rel];
-}
-__device__ __forceinline__ uint32_t load_x(const IqbbArgs &a, int c, int rel) {
-  if (rel >= 0) return rel < a.N ? raw_x(a, c, rel) : 0u;
-  const int h = a.HH + rel;
-  return h >= 0 ? a.hist_old[(long)c * a.HH + h] : 0u;
-}
-
-__device__ __forceinline__ int dot2(uint32_t x, uint32_t k, int acc) {
-  return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, x), __builtin_bit_cast(s16x2, k), acc, false);
-}
-
-__device__ __forceinline__ int mulw(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
-
-// FreqShiftBase<int16_t>::applyFrequencyShift at absolute index n (low 32 bits suffice).
-// Full-rate 24-bit multiplies: only the low 15 bits of n*inc matter; |LUT| < 2^23 (checked at create,
-// the reference's is <= 2^16) and r = S>>14 lies in [-2^17, 2^17), so v_mul_i32_i24's low 32 bits equal
-// the reference's wrapping 32-bit products.
-__device__ __forceinline__ int2 rotate(const IqbbArgs &a, const int2 *lut_s, int2 r, uint32_t n_lo) {
-  if (a.i8) {
-    // FreqShiftBase<int8_t> computes in complex<int16_t> (src/freqshift.hh:18-22, src/traits.hh:58-73): the FIR value
-    // is converted (wrapped) to int16 at the call, the LUT is 2^8 * exp(..), the product wraps to int16 and is shifted
-    // by Traits<int8_t>::shift = 8 (src/freqshift.hh:58-74, src/traits.cc:11)
-    r.x = (short)r.x; r.y = (short)r.y;
-    if (a.inc == 0) return r;
-    uint32_t idx = (__umul24(n_lo & 32767u, a.inc & 32767u) & 32767u) >> 8;
-    if (a.negative) idx = 127u - idx;
-    const int2 L = lut_s[idx];
-    int2 v;
-    v.x = (int)(short)(mulw(L.x, r.x) - mulw(L.y, r.y)) >> 8;
-    v.y = (int)(short)(mulw(L.x, r.y) + mulw(L.y, r.x)) >> 8;
-    return v;
-  }
-  if (a.inc == 0) return r;
-  uint32_t idx = (__umul24(n_lo & 32767u, a.inc & 32767u) & 32767u) >> 8;
-  if (a.negative) idx = 127u - idx;
-  const int2 L = lut_s[idx];
-  int2 v;
-  v.x = (int)((unsigned)__mul24(L.x, r.x) - (unsigned)__mul24(L.y, r.y)) >> 16;
-  v.y = (int)((unsigned)__mul24(L.x, r.y) + (unsigned)__mul24(L.y, r.x)) >> 16;
-  return v;
-}
-
-// libstdc++ complex<int32>::operator/=(complex<int32>(D,0)): (a*D)/(D*D), wrapping, truncating
-__device__ __forceinline__ int box_div(int s, int D) {
-  const int n = mulw(D, D);
-  const int r = mulw(s, D);
-  if (n == 0) return 0;
-  if (r == (int)0x80000000 && n == -1) return r;
-  return r / n;
-}
-
-// trunc(num/den) for |num| <= 4096*den, 0 < den < 2^16 (the only divisions fast_atan2 makes): float
-// estimate (|q| <= 4096, error < 1) + one exact remainder correction, instead of the generic 32-bit sequence
-__device__ __forceinline__ int div_small(int num, int den) {
-  const unsigned nu = (unsigned)(num < 0 ? -num : num), de = (unsigned)den;
-  unsigned q = (unsigned)((float)nu * __builtin_amdgcn_rcpf((float)de));   // v_rcp_f32: 1 ulp, |q| <= 4096
-  int r = (int)(nu - __umul24(q, de));
-  if (r < 0) { q -= 1; r += (int)de; }
-  if (r >= (int)de) q += 1;
-  return num < 0 ? -(int)q : (int)q;
-}
-
-
-__device__ __forceinline__ short am_i16(int re, int im) {
-  const int m = (int)((unsigned)mulw(re, re) + (unsigned)mulw(im, im));
-  return (short)(int)sqrt((double)m);
-}
-
-__device__ __forceinline__ short usb_i16(int re, int im) { return (short)((re + im) / 2); }
-
-// one decimation group is complete (or left open at the end of the call): carry, first-sample quirk,
-// truncating division, state
-__device__ __forceinline__ void finalize_group(const IqbbArgs &a, int c, const int2 *lut_s, uint32_t *ybuf, int ql, int q, int2 s, int D) {
-  if (q == 0) {
-    const int2 carry = a.acc_old[c];
-    s.x = (int)((unsigned)s.x + (unsigned)carry.x);
-    s.y = (int)((unsigned)s.y + (unsigned)carry.y);
-    if (a.extra0) {   // absolute sample 0: one slow FIR evaluation per channel and stream start
-      int er = 0, ei = 0;
-      for (int i = 0; i < a.OP; i++) {
-        const uint32_t x = load_x(a, c, -(a.OP - 1) + i);
-        const uint2 k = a.taps[i];
-        er = dot2(x, k.x, er); ei = dot2(x, k.y, ei);
-      }
-      const int2 v = rotate(a, lut_s, make_int2(er >> 14, ei >> 14), a.n0_lo);
-      s.x = (int)((unsigned)s.x + (unsigned)v.x);
-      s.y = (int)((unsigned)s.y + (unsigned)v.y);
-    }
-  }
-  const bool emits = q < a.n_out;
-  if (emits) {
-    int yr = (short)box_div(s.x, D), yi = (short)box_div(s.y, D);
-    if (a.i8) { yr = (signed char)yr; yi = (signed char)yi; }   // the int8 node's output type (kept sign-extended in ybuf)
-    ybuf[ql] = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
-    if (a.epilogue == SDRHIP_EPI_FM) reinterpret_cast<int *>(ybuf + a.CGr)[ql] = fm_phi(yr, yi);   // angle cache
-  }
-  if (q == a.n_groups - 1) a.acc_new[c] = emits ? make_int2(0, 0) : s;
-}
-
-// store / demodulate the tile's outputs (ybuf complete), and let the channel's last tile roll the history
-__device__ __forceinline__ void epilogue_and_roll(const IqbbArgs &a, int c, int tile, int tid, int q0, int groups_here,
-                                                  const uint32_t *ybuf) {
-  for (int ql = a.ovl + tid; ql < groups_here; ql += TPB) {
-    const int j = q0 + ql;   // output index within this call
-    if (j >= a.n_out) continue;
-    const uint32_t y = ybuf[ql];
-    const int yr = (short)(y & 0xffffu), yi = (short)(y >> 16);
-    if (a.epilogue == SDRHIP_EPI_NONE) {
-      if (a.i8) reinterpret_cast<uint16_t *>(a.out)[(long)c * a.out_stride + j] = (uint16_t)((yr & 0xff) | ((yi & 0xff) << 8));   // complex<int8_t>
-      else reinterpret_cast<uint32_t *>(a.out)[(long)c * a.out_stride + j] = y;
-    } else {
-      short o;
-      if (a.epilogue == SDRHIP_EPI_AM) o = am_i16(yr, yi);
-      else if (a.epilogue == SDRHIP_EPI_USB) o = usb_i16(yr, yi);
-      else {
-        const int *phib = reinterpret_cast<const int *>(ybuf + a.CGr);
-        const int phi = phib[ql];
-        if (j == 0) o = a.i8 ? (short)((yr & 0xff) | ((yi & 0xff) << 8))   // FMDemod<int8_t,int16_t> in place: out[0] = the 2 bytes of in[0]
-                             : (short)yr;             // index 0 is never written by FMDemod (in place)
-        else o = (short)((j == 1 ? (int)a.fm_old[c] : phib[ql - 1]) - phi);   // y[0] is never looked at: the
-                                                                              // previous call's last angle
-        if (j == a.n_out - 1 && a.n_out >= 2) a.fm_new[c] = (short)phi;
-      }
-      reinterpret_cast<short *>(a.out)[(long)c * a.out_stride + j] = o;
-    }
-  }
-  if (tile == a.tiles - 1) {
-    for (int k = tid; k < a.HH; k += TPB) {
-      const long qq = (long)a.N + k;   // index into concat(hist_old, in)
-      a.hist_new[(long)c * a.HH + k] =
-          qq < a.HH ? a.hist_old[(long)c * a.HH + qq] : raw_x(a, c, qq - a.HH);
-    }
-  }
-}
-
-// REAL = the real-input BaseBand<int16_t> (src/baseband.hh:425-460): the staged dwords are sign-extended real
-// samples, a tap is a raw (Kr, Ki) int32 pair (Q16, up to 17 bits) and one v_mad_i32_i24 per component replaces
-// the dot2 (its low 32 bits equal the reference's wrapping int32 product for |K| < 2^23); >>16 instead of >>14.
-template <bool FAST8, bool REAL>
-__global__ __launch_bounds__(TPB) void iqbb_i16_kernel(const IqbbArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  const int XS = TI + a.OP + 8;
-  uint32_t *xs = smem;                                  // staged samples, x[tb-(OP-1) ...]
-  int2 *lut_s = reinterpret_cast<int2 *>(smem + XS);    // 128 entries
-  uint32_t *ybuf = smem + XS + 256;                     // CG packed cs16 results
-  int2 *vbuf = reinterpret_cast<int2 *>(ybuf + 2 * a.CGr);  // generic path only: TI entries
-
-  const int c = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
-  const int q0 = tile * a.OG - a.ovl;    // first group (relative to the call's first group) of this tile
-  const int tb = a.base0_rel + q0 * a.D; // call-relative index of the tile's first sample
-  const int groups_here = min(a.CG, a.n_groups - q0);
-
-  // ---- stage samples (history / input / zeros) and the LUT into LDS ---------------------------
-  {
-    const int first = tb - (a.OP - 1);
-    const int need = min(XS, groups_here * a.D + a.OP + 8);
-    for (int i = tid; i < need; i += TPB) xs[i] = load_x(a, c, first + i);
-    if (tid < 128) lut_s[tid] = a.lut[tid];
-  }
-  __syncthreads();
-
-  // ---- FIR at 8 consecutive samples per lane ---------------------------------------------------
-  int2 gsum = make_int2(0, 0);
-  if (R * tid < groups_here * a.D) {
-    int sre[R], sim[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) { sre[r] = 0; sim[r] = 0; }
-    const uint4 *win = reinterpret_cast<const uint4 *>(xs + R * tid);
-    uint32_t w[16];
-    {
-      const uint4 p0 = win[0], p1 = win[1];
-      w[0] = p0.x; w[1] = p0.y; w[2] = p0.z; w[3] = p0.w;
-      w[4] = p1.x; w[5] = p1.y; w[6] = p1.z; w[7] = p1.w;
-    }
-    const uint2 *__restrict__ tp = a.taps;
-    for (int i0 = 0; i0 < a.OP; i0 += TAPC) {
-      const uint4 p2 = win[i0 / 4 + 2], p3 = win[i0 / 4 + 3];
-      w[8] = p2.x; w[9] = p2.y; w[10] = p2.z; w[11] = p2.w;
-      w[12] = p3.x; w[13] = p3.y; w[14] = p3.z; w[15] = p3.w;
-#pragma unroll
-      for (int u = 0; u < TAPC; u++) {
-        const uint2 k = tp[i0 + u];   // wave-uniform -> scalar loads
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-          if (REAL) {
-            sre[r] = (int)((unsigned)__mul24((int)k.x, (int)w[u + r]) + (unsigned)sre[r]);
-            sim[r] = (int)((unsigned)__mul24((int)k.y, (int)w[u + r]) + (unsigned)sim[r]);
-          } else {
-            sre[r] = dot2(w[u + r], k.x, sre[r]);
-            sim[r] = dot2(w[u + r], k.y, sim[r]);
-          }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++) w[u] = w[u + 8];
-    }
-    // ---- >>14, rotate, mask samples outside this call -----------------------------------------
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      const int rel = tb + R * tid + r;
-      constexpr int FSH = REAL ? 16 : 14;   // Traits<int16_t>::shift vs the literal 14 of IQBaseBand (:235, :459)
-      int2 v = rotate(a, lut_s, make_int2(sre[r] >> FSH, sim[r] >> FSH), a.n0_lo + (uint32_t)rel);
-      const bool valid = (rel >= 0) && (rel < a.N);
-      if (!valid) v = make_int2(0, 0);
-      if (FAST8) {
-        gsum.x = (int)((unsigned)gsum.x + (unsigned)v.x);
-        gsum.y = (int)((unsigned)gsum.y + (unsigned)v.y);
-      } else {
-        vbuf[R * tid + r] = v;
-      }
-    }
-  }
-  if (!FAST8) __syncthreads();
-
-  // ---- box average per group -----------------------------------------------------------------------
-  for (int ql = tid; ql < groups_here; ql += TPB) {
-    const int q = q0 + ql;
-    if (q < 0) continue;                      // tile 0's overlap slot precedes the call
-    int2 s;
-    if (FAST8) {
-      s = gsum;                               // lane == group
-    } else {
-      s = make_int2(0, 0);
-      for (int k = 0; k < a.D; k++) {
-        const int2 v = vbuf[ql * a.D + k];
-        s.x = (int)((unsigned)s.x + (unsigned)v.x);
-        s.y = (int)((unsigned)s.y + (unsigned)v.y);
-      }
-    }
-    finalize_group(a, c, lut_s, ybuf, ql, q, s, a.D);
-  }
-  __syncthreads();
-  epilogue_and_roll(a, c, tile, tid, q0, groups_here, ybuf);
-}
-
-// =================================================================================================
-// MFMA formulation (D == 8): the FIR as a block-Toeplitz int8 GEMM on the matrix cores.
-//
-//   Dmat[m = (t, comp)][n = block] = sum_k TapT[m][k] * U[k][n]
-// A block is 16 consecutive samples of the channel, a wave owns 32 consecutive blocks (512 samples);
-// U[k][n] is element k of the block's window in the interleaved (re,im) int16 element stream and
-// TapT[m][k] = a_comp[k - 2t] the Toeplitz matrix of the interleaved tap vectors (re: Kr,-Ki ...;
-// im: Ki,Kr ...). int16 x int16 products are made exact on v_mfma_i32_32x32x32_i8 by byte planes:
-//   u = 256*uh + ul' + 128 (uh = u>>8, ul' = (u&255)-128),   a = 256*ah + al (al in [-128,127])
-//   S = 65536*sum(ah*uh) + 256*sum(ah*ul' + al*uh) + sum(al*ul') + 128*sum(a)      (mod 2^32)
-// i.e. 4 MFMAs per 32-deep K step into 3 accumulators; int32 ring arithmetic makes the recombination
-// bit-exact. The tap fragments are wave-invariant and live in LDS ([S][2][64] x 16 B, fetched once per
-// workgroup), the sample planes are staged once per tile into LDS and read as conflict-free 16-byte rows.
-// Result layout (32x32 C/D map): lane (n = l&31, h = l>>5), register r -> comp = r&1,
-// t = ((r&3)>>1) + 4*(r>>2) + 2h: a lane holds (re,im) pairs of 8 samples of its block, 4 per decimation
-// group; the other 4 sit in lane l^32.
-// =================================================================================================
-constexpr int MF_BLK = 16;    // samples per block (one column)
-
-// full-rate 24-bit integer multiplies as instructions: the compiler keeps explicit sign-extension code around
-// v_mad_i32_i24 operands it cannot prove to be 24-bit, which these operands (LUT entries, FIR results) are
-__device__ __forceinline__ int mul24a(int x, int y) { int d; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; }
-__device__ __forceinline__ int mad24a(int x, int y, int z) { int d; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z)); return d; }
-
-__device__ __forceinline__ unsigned mulu24a(unsigned x, unsigned y) { unsigned d; asm("v_mul_u32_u24 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; }
-__device__ __forceinline__ int sub32(int x, int y) { return (int)((unsigned)x - (unsigned)y); }
-// acc + (x >> 16): SDWA picks the sign-extended high half of x, so the shift of the rotation and the box-sum add are one instruction
-__device__ __forceinline__ int add_hi16(int x, int acc) {
-  int d;
-  asm("v_add_u32_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(d) : "v"(x), "v"(acc));
-  return d;
-}
-// (short)trunc(s / 8) for |s| < 2^29
-__device__ __forceinline__ int div8_i16(int s) {
-  const int t = (int)((unsigned)s + __builtin_amdgcn_ubfe((unsigned)s, 29, 3));
-  return __builtin_amdgcn_sbfe(t, 3, 16);
-}
-// Lane (n, h) of a wave (n = l & 31, h = l >> 5) owns group 2n + h: the value of the previous group, 2n + h - 1, sits in
-// lane (n, 0) for h = 1 and in lane (n - 1, 1) for h = 0 (lane 0 gets lane 63's: its own group is the wave's overlap slot).
-__device__ __forceinline__ int prev_group_value(int v, int h) {
-  // v_permlane32_swap: lanes 32..63 of the first operand <-> lanes 0..31 of the second; with both = v the first
-  // result carries the lower half's values in both halves, the second the upper half's
-  const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
-  const int hi_shr = __builtin_amdgcn_update_dpp(0, (int)sw[1], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-  return h ? (int)sw[0] : hi_shr;
-}
-
-// Path 1's per-lane epilogue core: the lane's 8 samples (accumulator registers 2j / 2j+1 = re / im of sample j, planes hh,
-// mid, ll) -> recombine -> >>14 -> rotate by LUT[idx(n)] -> sum of the (product >> 16) = the decimation window's sum.
-// The rotation table sits at LDS offset 0 (dynamic LDS starts there: the kernel has no static LDS), so a table
-// read's address is the byte offset itself.
-// TBL: the table's layout at LDS offset 0 — 0: 128 x {Lx, Ly} in table order (a negative shift reads entry 127 - i);
-// 1: the same stored reversed for a negative shift; 2: 16-byte entries {Lx, Ly, -Ly, 0}, stored reversed (hot kernel)
-template <bool ROT, bool CU8, bool EDGE, int TBL = 0, int FSH = 14>   // FSH: the FIR's right shift (16: real-input BaseBand)
-__device__ __forceinline__ int2 group_sum(const IqbbArgs &a, const v16i &acc_hh, const v16i &acc_mid, const v16i &acc_ll, int rel0) {
-  typedef int v2i __attribute__((ext_vector_type(2)));
-  typedef __attribute__((address_space(3))) const v2i lds_v2i;
-  int2 L[8];
-  if (ROT) {   // 8 independent table reads in flight while the accumulators are recombined
-    // phase counter of the lane's first sample; only its low 15 bits matter, so a 24-bit multiply is exact enough
-    const uint32_t cnt0 = mulu24a(a.n0_lo + (uint32_t)rel0, a.inc);
-    const uint32_t negx = (TBL == 0 && a.negative) ? (127u << 3) : 0u;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const uint32_t cj = cnt0 + (uint32_t)j * a.inc;   // j * inc: wave-uniform
-      const uint32_t off = TBL == 2 ? ((cj >> 4) & (127u << 4)) : ((cj >> 5) & (127u << 3)) ^ negx;
-      const v2i e = *reinterpret_cast<lds_v2i *>((uintptr_t)off);
-      L[j] = make_int2(e.x, e.y);
-    }
-  }
-  int2 sum = make_int2(0, 0);
-#pragma unroll
-  for (int j = 0; j < 8; j++) {
-    // two v_lshl_add_u32 per component; the empty asm keeps the compiler from re-associating into 2 shifts + add3.
-    // (The first level must stay compiler-generated code: it reads MFMA results, and only the compiler pads the
-    // MFMA -> VALU read hazard; an asm v_lshl_add_u32 there reads stale accumulators.)
-    unsigned tre = ((unsigned)acc_hh[2 * j] << 8) + (unsigned)acc_mid[2 * j];
-    unsigned tim = ((unsigned)acc_hh[2 * j + 1] << 8) + (unsigned)acc_mid[2 * j + 1];
-    int rr, ri;
-    if (CU8) {   // S = t << 8 exactly
-      rr = (int)(tre << 8) >> FSH; ri = (int)(tim << 8) >> FSH;
-    } else {
-      asm("" : "+v"(tre)); asm("" : "+v"(tim));
-      rr = (int)((tre << 8) + (unsigned)acc_ll[2 * j]) >> FSH; ri = (int)((tim << 8) + (unsigned)acc_ll[2 * j + 1]) >> FSH;
-    }
-    if (EDGE) { const int rel = rel0 + j; if (rel < 0 || rel >= a.N) { rr = 0; ri = 0; } }   // outside the call: r = 0 -> v = 0
-    if (ROT) {
-      const int x = sub32(mul24a(L[j].x, rr), mul24a(L[j].y, ri));
-      const int y = mad24a(L[j].x, ri, mul24a(L[j].y, rr));
-      sum.x = add_hi16(x, sum.x); sum.y = add_hi16(y, sum.y);   // += (x >> 16): one SDWA add each
-    } else {
-      sum.x = (int)((unsigned)sum.x + (unsigned)rr); sum.y = (int)((unsigned)sum.y + (unsigned)ri);
-    }
-  }
-  return sum;
-}
-
-// per byte (b + 129) mod 256: the high byte AutoCast< complex<int16_t> > gives a complex<uint8_t> component
-__device__ __forceinline__ uint32_t add129_bytes(uint32_t x) {
-  const uint32_t y = x ^ 0x80808080u;   // + 128
-  return ((y & 0x7f7f7f7fu) + 0x01010101u) ^ (y & 0x80808080u);   // + 1 without carries between bytes
-}
-
-// CU8: the input is complex<uint8_t> (SDRHIP_IN_CU8). After AutoCast every sample is 256 * uh exactly, so the low
-// byte plane and both of its products vanish: S = 65536 * sum(ah*uh) + 256 * sum(al*uh) — two MFMAs per K step into
-// two accumulators, one plane to stage, read and keep in LDS, 2 bytes per sample from HBM; 5 waves per SIMD fit.
-
-// Path 1's group epilogue: lane (n, h) holds the window sum of group glw = 2n + h of its wave; carry / first-sample
-// quirk for the call's first group, truncating division by 8, state for the next call, demodulator, store.
-__device__ __forceinline__ void group_finish(const IqbbArgs &a, const int2 *lut_s, int c, int n, int h, int gw, int q0,
-                                             int groups_here, int2 sum) {
-  const int glw = 2 * n + h;
-  const int ql = gw + glw, q = q0 + ql;   // q = output index within the call when the group completes
-  const bool live = (ql < groups_here) && (q >= 0);
-  if (q0 + gw <= 0 && live && q == 0) {   // (scalar test first: only the wave that holds the call's first group)
-    const int2 carry = a.acc_old[c];
-    sum.x = (int)((unsigned)sum.x + (unsigned)carry.x);
-    sum.y = (int)((unsigned)sum.y + (unsigned)carry.y);
-    if (a.extra0) {   // absolute sample 0: one slow FIR evaluation per channel and stream start
-      int er = 0, ei = 0;
-      for (int i = 0; i < a.OP; i++) {
-        const uint32_t x = load_x(a, c, -(a.OP - 1) + i);
-        const uint2 k = a.taps[i];
-        er = dot2(x, k.x, er); ei = dot2(x, k.y, ei);
-      }
-      const int2 v = rotate(a, lut_s, make_int2(er >> 14, ei >> 14), a.n0_lo);
-      sum.x = (int)((unsigned)sum.x + (unsigned)v.x);
-      sum.y = (int)((unsigned)sum.y + (unsigned)v.y);
-    }
-  }
-  const bool own = live && (glw >= a.ovl);            // the FM overlap slot belongs to the previous wave / tile
-  const bool emits = live && (q < a.n_out);
-  // libstdc++'s (s*8)/(8*8) (src/baseband.hh:214): |s| <= 9 * 2^17 here (a window of 16-bit rotated values, or of
-  // 18-bit FIR values when there is no shift), so nothing wraps and it is trunc(s / 8): bias 7 for negative sums
-  // (bits 31..29 of s), arithmetic shift, and the int16 wrap of the assignment in the same bit-field extract
-  const int yr = div8_i16(sum.x), yi = div8_i16(sum.y);
-  if (own && q == a.n_groups - 1) a.acc_new[c] = emits ? make_int2(0, 0) : sum;
-  if (a.epilogue == SDRHIP_EPI_NONE) {
-    if (own && emits) reinterpret_cast<uint32_t *>(a.out)[(long)c * a.out_stride + q] = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
-  } else {
-    short o;
-    if (a.epilogue == SDRHIP_EPI_AM) o = am_i16(yr, yi);
-    else if (a.epilogue == SDRHIP_EPI_USB) o = usb_i16(yr, yi);
-    else {
-      const int phi = fm_phi(yr, yi);
-      // previous group's angle: lane (n,0) for h=1, lane (n-1,1) for h=0 — one v_permlane32_swap (both halves'
-      // values in both halves) and one wave_shr:1 DPP move, no LDS round trip
-      const int prev = prev_group_value(phi, h);
-      if (q == 0) o = (short)yr;             // index 0 is never written by FMDemod (in place)
-      else o = (short)((q == 1 ? (int)a.fm_old[c] : prev) - phi);   // y[0] is never looked at
-      if (own && emits && q == a.n_out - 1 && a.n_out >= 2) a.fm_new[c] = (short)phi;
-    }
-    if (own && emits) reinterpret_cast<short *>(a.out)[(long)c * a.out_stride + q] = o;
-  }
-
-}
 
 template <int S, bool ROT, bool CU8>
 __global__ __launch_bounds__(TPB, CU8 ? 5 : 4) void iqbb_i16_mfma_kernel(const IqbbArgs a) {
@@ -686,20 +241,6 @@ __global__ __launch_bounds__(TPB, CU8 ? 5 : 4) void iqbb_i16_mfma_kernel(const I
 }
 
 
-// A wave slice (tile t, wave w of the tile's workgroup: 64 groups, the first of them FM's overlap slot) is "hot" when
-// nothing about it touches the call's borders: its 640-sample window lies inside the input, none of its groups is
-// the call's first (carry, the D+1 first window, FM's out[0] / out[1] rules) nor its last emitted one (state for the next
-// call), and all of them complete and are emitted.
-// The hot loop computes exactly these slices; the others are the cold phase's (one launch) or, with SDRHIP_IQBB_FUSE=0,
-// the general kernel's in a border launch.
-__device__ __forceinline__ bool slice_is_hot(int base0_rel, int OG, int ovl, int N, int n_out, int tile, int w) {
-  const int qf = tile * OG - ovl + w * (64 - ovl);   // the slice's first group (output index within the call)
-  const int ws = base0_rel + qf * 8 - 128;           // its window's first sample
-  // (the slice that holds the call's LAST emitted group is never hot: that group hands the demodulator's angle and the
-  // window carry to the next call — state only the general epilogue writes; found by test_one_launch_kernel_random_long_calls)
-  return ws >= 0 && ws + 640 <= N && qf >= 1 && qf + 63 < n_out - 1;
-}
-
 // =================================================================================================
 // Path 1, complex<int16> input: the same matrix part and epilogue as iqbb_i16_mfma_kernel, fed by LDS-DMA.
 //
@@ -734,12 +275,9 @@ __device__ __forceinline__ void iqbb_i16_mfma_dma_body(const IqbbArgs &a, const 
   for (int i = tid; i < S * 2 * 64; i += TPB) taps_s[i] = a.tapfrag[i];
   if (tid < 128) lut_s[tid] = a.lut[tid];
 
-  int tile_end = min((bx + 1) * a.tpw, a.tiles);
+  const int tile_end = min((bx + 1) * a.tpw, a.tiles);
   int tile = bx * a.tpw;
-  // border launch: ONE workgroup per channel walks tile 0 and then the tiles bt_hi .. tiles-1 (the next tile's raw
-  // samples are staged during the current one's compute, the tap fragments are fetched once)
-  if (a.border) { tile = 0; tile_end = a.tiles; }
-  auto next_tile = [&](int t) { return (a.border && t == 0) ? a.bt_hi : t + 1; };
+  auto next_tile = [&](int t) { return t + 1; };
   const uint32_t *row = a.in + (long)c * a.in_stride;
 
   // raw[p] = samples first + 4p .. first + 4p + 3 of the tile's window (first = tile start - (OP - 1))
@@ -816,9 +354,7 @@ __device__ __forceinline__ void iqbb_i16_mfma_dma_body(const IqbbArgs &a, const 
     if (next_tile(tile) < tile_end) stage_raw(next_tile(tile));   // in flight during this tile's K loop and epilogue
 
     const int gw = w * OGw;   // this wave's first group within the tile
-    // (border launch: the slices the hot kernel computes are only staged here, not computed)
-    const bool mine = !(a.border && slice_is_hot(a.base0_rel, a.OG, a.ovl, a.N, a.n_out, tile, w));
-    if (mine && gw + a.ovl < groups_here) {   // wave-uniform: the wave has at least one group of its own
+    if (gw + a.ovl < groups_here) {   // wave-uniform: the wave has at least one group of its own
       v16i acc_hh = {0}, acc_mid = {0}, acc_ll = {0};
 #pragma unroll
       for (int r = 0; r < 16; r++) acc_ll[r] = (r & 1) ? a.cim : a.cre;   // + 128*sum(a) rides in as C
@@ -992,406 +528,6 @@ __global__ __launch_bounds__(TPB, 4) void bb_real_mfma_kernel(const IqbbArgs a) 
   }
 }
 
-// =================================================================================================
-// Path 1's HOT kernel (complex<int16> input, D = 8): only tiles whose windows lie wholly inside the call (no
-// history, no end of input, no first-group carry, every group complete) — everything else is its cold phase's (the
-// one-launch form iqbb_i16_hotb_kernel) or the general kernel's in a border launch (SDRHIP_IQBB_FUSE=0).
-// What the r2a counters showed for the general kernel per wave-tile:
-// 285 vector + 154 scalar instructions (36 spilled SGPRs: the cold paths' arguments stay live through the loop)
-// and 49 % of the wave cycles parked at s_waitcnt / s_barrier. Here
-//   * each WAVE runs its own pipeline, no workgroup barrier in the loop: its 640-sample window (512 + the 128-sample
-//     halo; the halo is loaded twice, by two waves) comes in by LDS-DMA into a wave-private raw area, is split into
-//     wave-private byte planes by the same wave, and only that wave reads them; the DMA for the next tile is issued
-//     right after the split and has the whole K loop + epilogue to land. Only the tap fragments and the rotation
-//     table are shared (read-only after the prologue barrier).
-//   * the K loop is straight-line code: the steps that need the taps' high plane are a compile-time range
-//     [S0, S0 + NH) (centred: the big taps of a windowed sinc), operand reads of step s+1 are issued before the
-//     MFMAs of step s.
-//   * the demodulator is a template parameter; no border tests, no state writes.
-// LDS: table 4 KB (1 KB when all 9 K steps carry the high tap plane) | tap fragments | per wave {raw 2.5 KB, planes 2 x 1312 B}.
-// =================================================================================================
-#ifdef K1_STAMPS
-__device__ unsigned long long g_k1_stamps[32768 * 8];   // per wave of one launch: 5 phase totals, 1 marker
-#endif
-struct HotArgs {
-  const uint32_t *in; long in_stride;   // cs16, one dword per sample
-  void *out; long out_stride;
-  const v4i *tapfrag; const int2 *lut;
-  uint32_t inc, n0_lo; int negative;
-  int base0_rel, OG, ovl;               // as IqbbArgs
-  int t_lo, t_hi, tpw;                  // hot tiles [t_lo, t_hi); a work unit = tpw consecutive ones of a channel
-  int G, U, dq, dr;                     // units per channel, units in all, gridDim.x / G and gridDim.x % G (persistent grid)
-  int N, n_out;                         // samples per channel in this call, groups emitted (slice_is_hot)
-  int C;                                // channels (cold phase)
-  int cre, cim;
-};
-
-constexpr bool hot_wide_table(int nh) { return nh <= 5; }   // 4 KB rotation table while 4 workgroups per CU still fit
-constexpr int HOT_WIN = 512 + 128;                 // samples a wave stages per tile (OP - 1 = 128 halo: S = 9)
-constexpr int HOT_PLB = 2 * HOT_WIN + 32;          // bytes per byte plane (+ one chunk pair: the parity halves stay 16-byte aligned)
-constexpr int HOT_RAWB = HOT_WIN * 4;               // raw area: 160 pieces of 16 bytes = two DMA wave-instructions + 32 lanes of a third
-
-template <int S, int S0, int NH, bool ROT, int EPI>
-__device__ __forceinline__ void iqbb_i16_hot_body(const HotArgs &a, const int bx, const int gx, const IqbbArgs *cold) {
-  static_assert(S == 9, "window geometry (HOT_WIN) is the 127-tap one");
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  // Rotation table at LDS offset 0. WIDE (the high-plane range leaves room: NH <= 5): 256 entries of 16 bytes
-  // {Lx, Ly, -Ly, 0}, the 128-entry table twice — a table address is then byte 1 of the phase counter << 4 with no
-  // mask (one SDWA shift), and the complex product needs no subtraction. Otherwise 128 entries {Lx, Ly}. A negative
-  // shift reads the table backwards: it is stored reversed.
-  constexpr bool WIDE = hot_wide_table(NH);
-  constexpr int TBLW = WIDE ? 1024 : 256;   // dwords
-  int2 *lut_s = reinterpret_cast<int2 *>(smem);
-  v4i *taps_s = reinterpret_cast<v4i *>(smem + TBLW);
-  // (the wave index is wave-uniform but the compiler cannot know: through readfirstlane the slice bookkeeping — tile
-  // indices, window addresses, the hot test — runs on the scalar unit instead of 80 vector instructions per tile)
-  const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, n = l & 31, h = l >> 5;
-  // tap fragments in LDS: the S low-plane fragments, then only the NH high-plane fragments of steps [S0, S0 + NH)
-  char *wbase = reinterpret_cast<char *>(smem + TBLW + (S + NH) * 64 * 4) + w * (HOT_RAWB + 2 * HOT_PLB);
-  uint4 *raw = reinterpret_cast<uint4 *>(wbase);
-  char *lo = wbase + HOT_RAWB, *hi = lo + HOT_PLB;
-  for (int i = tid; i < S * 64; i += TPB) taps_s[i] = a.tapfrag[(2 * (i >> 6) + 1) * 64 + (i & 63)];
-  for (int i = tid; i < NH * 64; i += TPB) taps_s[S * 64 + i] = a.tapfrag[(2 * (S0 + (i >> 6))) * 64 + (i & 63)];
-  {
-    const int2 e = a.lut[(tid & 127) ^ (a.negative ? 127 : 0)];
-    if (WIDE) reinterpret_cast<v4i *>(smem)[tid] = v4i{e.x, e.y, -e.y, 0};
-    else if (tid < 128) lut_s[tid] = e;
-  }
-
-  const int OGw = 64 - a.ovl, gw = w * OGw;
-  // PERSISTENT grid: gx workgroups (4 per CU) stay resident and walk the work units u = bx,
-  // bx + gx, ...; unit u = (channel u / G, tile group u % G of `tpw` consecutive hot tiles). With one
-  // workgroup per unit the waves of a workgroup — no barrier holds them together any more — finished up to 2x apart,
-  // the workgroup's LDS and its fast waves' register slots stayed allocated until the slowest wave was done, and only
-  // ~3 of the 4 workgroups per CU were resident in steady state (2.74 waves per SIMD on average, measured with
-  // s_memrealtime stamps). All units are the same length, so the static assignment balances.
-  int u = bx;
-  int c = u / a.G, g = u - c * a.G;   // (one division per wave, at start; afterwards (c, g) advance by (dq, dr))
-  int tile = a.t_lo + g * a.tpw, tile_end = min(tile + a.tpw, a.t_hi);
-  // (a wave walks only its hot slices — slice_is_hot — of these tiles; the others belong to the border launch)
-  auto skip_cold = [&](int &u_, int &c_, int &g_, int &tile_, int &tile_end_) {
-    while (u_ < a.U && !slice_is_hot(a.base0_rel, a.OG, a.ovl, a.N, a.n_out, tile_, w)) {
-      if (++tile_ >= tile_end_) {
-        u_ += gx; c_ += a.dq; g_ += a.dr;
-        if (g_ >= a.G) { g_ -= a.G; c_++; }
-        tile_ = a.t_lo + g_ * a.tpw; tile_end_ = min(tile_ + a.tpw, a.t_hi);
-      }
-    }
-  };
-  skip_cold(u, c, g, tile, tile_end);
-  // piece k (0..2) of a wave window: one DMA wave-instruction, 64 (the last: 32) lanes x 16 bytes. The window of
-  // tile t starts at sample base0_rel + (t * OG - ovl + gw) * 8 - 128 of the channel's row.
-  const uint32_t lane_byte = 16u * (uint32_t)l;
-  // the lane's global pointer into the window of (channel, tile): scalar base + the lane's 32-bit byte offset, ONE
-  // 64-bit vector add per tile; the pieces differ by the instruction's immediate offset
-  auto dma_src = [&](int c_, int tile_) {
-    return reinterpret_cast<const char *>(a.in + (long)c_ * a.in_stride + (a.base0_rel + (tile_ * a.OG - a.ovl + gw) * 8 - (HOT_WIN - 512))) + lane_byte;
-  };
-  auto dma_piece = [&](const char *src, int k) {
-#ifndef K1_ABL_NOFETCH
-    if (k < 2 || l < (HOT_WIN / 4 - 128))   // 160 pieces of 16 bytes: two full wave-instructions and 32 lanes of a third
-#else
-    if (false)
-#endif
-    {   // (the instruction's immediate offset applies to the global AND the LDS address: piece k is +1024 bytes in both)
-      const auto *g = (const __attribute__((address_space(1))) void *)src;
-      auto *d = (__attribute__((address_space(3))) void *)raw;
-      if (k == 0) __builtin_amdgcn_global_load_lds(g, d, 16, 0, 0);
-      else if (k == 1) __builtin_amdgcn_global_load_lds(g, d, 16, 1024, 0);
-      else __builtin_amdgcn_global_load_lds(g, d, 16, 2048, 0);
-    }
-  };
-  if (u < a.U) { const char *s0 = dma_src(c, tile); dma_piece(s0, 0); dma_piece(s0, 1); dma_piece(s0, 2); }
-  __syncthreads();   // tap fragments and table in place (the only workgroup barrier)
-
-  // plane byte offsets of this lane's pieces: chunk j = p >> 1 (8 samples), parity-split halves, 8 bytes per piece
-  const int HALF = HOT_PLB / 2;
-  int dofs[3];
-#pragma unroll
-  for (int k = 0; k < 3; k++) { const int p = l + 64 * k, j = p >> 1; dofs[k] = (j & 1) * HALF + (j >> 1) * 16 + (p & 1) * 8; }
-  const int coff = h * HALF + 16 * n;   // chunk 2(n + s) + h of the wave's window
-  // phase counters of the lane's samples 0 and 1 relative to the wave's first sample, as a 16-bit pair (only bits 8..14
-  // of a counter pick the table entry); the wave's part is scalar and joins per tile in one v_pk_add_u16 per sample pair
-  const uint32_t lane_cnt = (uint32_t)(MF_BLK * n + 8 * h) * a.inc;
-  const uint32_t lane_pair = (lane_cnt & 0xffffu) | ((lane_cnt + a.inc) << 16);
-
-#ifdef K1_STAMPS   // diagnostic build: shader-clock stamps at the phase boundaries, summed per phase per wave
-  unsigned long long st_acc[5] = {0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
-  const unsigned long long st_r0 = __builtin_amdgcn_s_memrealtime();
-  unsigned st_tiles = 0;
-#define K1_STAMP(i_) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i_] += t_ - st_t; st_t = t_; } while (0)
-#else
-#define K1_STAMP(i_) do { } while (0)
-#endif
-  unsigned prio_it = 0;
-  const unsigned prio_slot = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 3u;   // HW_REG_HW_ID[3:0]: the wave's slot in its SIMD
-  while (u < a.U) {
-    // the step after this one: next tile of the unit, or the first tile of the workgroup's next unit
-    int nu = u, nc = c, ng = g, ntile = tile + 1, ntile_end = tile_end;
-    if (ntile >= tile_end) {
-      nu = u + gx; nc = c + a.dq; ng = g + a.dr;
-      if (ng >= a.G) { ng -= a.G; nc++; }
-      ntile = a.t_lo + ng * a.tpw; ntile_end = min(ntile + a.tpw, a.t_hi);
-    }
-    skip_cold(nu, nc, ng, ntile, ntile_end);
-    const bool more = nu < a.U;
-    const char *nsrc = dma_src(nc, ntile);   // (held in two vector registers through the K loop)
-    asm volatile("" : "+v"(nsrc));
-    const int q0 = tile * a.OG - a.ovl;
-#ifndef K1_PRIO_ROT
-#define K1_PRIO_ROT 1
-#endif
-    // Fairness: the SIMD arbitrates its waves by priority, then AGE, and in a persistent grid the ages never change —
-    // the oldest wave of a SIMD ran at full speed and was done after 64 us, the youngest starved and finished alone
-    // at 120 us (s_memrealtime stamps). The priority rotates over the SIMD's four wave slots, one step per tile.
-    if (K1_PRIO_ROT == 1) {
-      switch ((prio_it++ + prio_slot) & 3u) {
-        case 0: __builtin_amdgcn_s_setprio(0); break;
-        case 1: __builtin_amdgcn_s_setprio(1); break;
-        case 2: __builtin_amdgcn_s_setprio(2); break;
-        default: __builtin_amdgcn_s_setprio(3); break;
-      }
-    }
-    // ---- the wave's raw window -> its byte planes ----
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own DMA (and older stores) retired
-    K1_STAMP(0);
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-#ifndef K1_ABL_NOCONV
-      if (k < 2 || l < (HOT_WIN / 4 - 128)) {
-#else
-      if (false) {
-#endif
-        const uint4 x = raw[l + 64 * k];
-        uint2 l2, h2;
-        l2.x = __builtin_amdgcn_perm(x.y, x.x, 0x06040200u) ^ 0x80808080u;
-        l2.y = __builtin_amdgcn_perm(x.w, x.z, 0x06040200u) ^ 0x80808080u;
-        h2.x = __builtin_amdgcn_perm(x.y, x.x, 0x07050301u);
-        h2.y = __builtin_amdgcn_perm(x.w, x.z, 0x07050301u);
-        *reinterpret_cast<uint2 *>(lo + dofs[k]) = l2;
-        *reinterpret_cast<uint2 *>(hi + dofs[k]) = h2;
-      }
-    }
-    // (LDS operations of one wave execute in order: the plane reads below see these writes, and the raw reads above
-    // have returned — the permutes consumed them — before the next DMA can overwrite the raw area. The empty asm
-    // statements keep the COMPILER from moving the DMA above the raw reads or the plane reads above the plane writes:
-    // no barrier or fence instruction separates them any more.)
-    K1_STAMP(1);
-    asm volatile("" ::: "memory");
-
-    // ---- K loop: operands of step s+1 in flight while the MFMAs of step s issue ----
-    if (K1_PRIO_ROT == 2) __builtin_amdgcn_s_setprio(3);
-    if (K1_PRIO_ROT == 3) { if ((prio_it + prio_slot) & 1u) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); }
-    if (K1_PRIO_ROT == 4) __builtin_amdgcn_s_setprio(0);
-    v16i acc_hh = {0}, acc_mid = {0}, acc_ll = {0};
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc_ll[r] = (r & 1) ? a.cim : a.cre;   // + 128*sum(a) rides in as C
-    const char *pl = lo + coff, *ph = hi + coff;
-    v4i uh = *reinterpret_cast<const v4i *>(ph), ul = *reinterpret_cast<const v4i *>(pl);
-    v4i Al = taps_s[l], Ah = Al;
-    if (S0 == 0) Ah = taps_s[S * 64 + l];
-#ifdef K1_ABL_NOKLOOP
-    acc_mid[0] = uh.x ^ ul.x ^ Al.x ^ Ah.x;
-    if (more) { dma_piece(nsrc, 0); dma_piece(nsrc, 1); dma_piece(nsrc, 2); }
-#else
-#pragma unroll
-    for (int s = 0; s < S; s++) {
-      v4i uh_n = uh, ul_n = ul, Al_n = Al, Ah_n = Ah;
-      if (s + 1 < S) {
-        uh_n = *reinterpret_cast<const v4i *>(ph + 16 * (s + 1));
-        ul_n = *reinterpret_cast<const v4i *>(pl + 16 * (s + 1));
-        Al_n = taps_s[(s + 1) * 64 + l];
-        if (s + 1 >= S0 && s + 1 < S0 + NH) Ah_n = taps_s[(S + s + 1 - S0) * 64 + l];
-      }
-      acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, uh, acc_mid, 0, 0, 0);
-      acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, ul, acc_ll, 0, 0, 0);
-      if (s >= S0 && s < S0 + NH) {
-        acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, uh, acc_hh, 0, 0, 0);
-        acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, ul, acc_mid, 0, 0, 0);
-      }
-      uh = uh_n; ul = ul_n; Al = Al_n; Ah = Ah_n;
-      // the next step's three DMA instructions, spread over the K loop (the raw area is free: it was split above)
-      if (more && (s == 1 || s == 4 || s == 7)) {
-        asm volatile("" ::: "memory");
-        dma_piece(nsrc, (s - 1) / 3);
-        asm volatile("" ::: "memory");
-      }
-    }
-#endif
-#ifdef K1_STAMPS
-    asm volatile("s_nop 0" : "+v"(acc_hh), "+v"(acc_mid), "+v"(acc_ll));   // the accumulators are complete before the stamp
-#endif
-    K1_STAMP(2);
-
-    // ---- epilogue: lane (n, h) owns group 2n + h of the wave ----
-    if (K1_PRIO_ROT == 2) __builtin_amdgcn_s_setprio(0);
-    if (K1_PRIO_ROT == 3) { if ((prio_it++ + prio_slot) & 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-    if (K1_PRIO_ROT == 4) __builtin_amdgcn_s_setprio(3);
-    const uint32_t wave_cnt = (a.n0_lo + (uint32_t)(a.base0_rel + (q0 + gw) * 8)) * a.inc;   // scalar unit
-    int L[8][3];
-#ifdef K1_ABL_NOEPI
-    if (false) {
-#else
-    if (ROT) {
-#endif
-      typedef int v2i __attribute__((ext_vector_type(2)));
-#pragma unroll
-      for (int jj = 0; jj < 4; jj++) {
-        const uint32_t wc = (wave_cnt + 2u * jj * a.inc) & 0xffffu, wpair = wc | (wc << 16);
-        uint32_t pr, o0, o1;
-        asm("v_pk_add_u16 %0, %1, %2" : "=v"(pr) : "v"(lane_pair), "s"(wpair));
-        if (WIDE) {
-          asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(o0) : "s"(4), "v"(pr));
-          asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(o1) : "s"(4), "v"(pr));
-          const v4i e0 = *reinterpret_cast<__attribute__((address_space(3))) const v4i *>((uintptr_t)o0);
-          const v4i e1 = *reinterpret_cast<__attribute__((address_space(3))) const v4i *>((uintptr_t)o1);
-          L[2 * jj][0] = e0.x; L[2 * jj][1] = e0.y; L[2 * jj][2] = e0.z;
-          L[2 * jj + 1][0] = e1.x; L[2 * jj + 1][1] = e1.y; L[2 * jj + 1][2] = e1.z;
-        } else {
-          o0 = (pr >> 5) & (127u << 3); o1 = (pr >> 21) & (127u << 3);
-          const v2i e0 = *reinterpret_cast<__attribute__((address_space(3))) const v2i *>((uintptr_t)o0);
-          const v2i e1 = *reinterpret_cast<__attribute__((address_space(3))) const v2i *>((uintptr_t)o1);
-          L[2 * jj][0] = e0.x; L[2 * jj][1] = e0.y; L[2 * jj + 1][0] = e1.x; L[2 * jj + 1][1] = e1.y;
-        }
-      }
-    }
-    int2 sum = make_int2(0, 0);
-#ifdef K1_ABL_NOEPI
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) { sum.x += acc_hh[r] ^ acc_mid[r] ^ acc_ll[r]; sum.y += acc_hh[r + 1] ^ acc_mid[r + 1] ^ acc_ll[r + 1]; }
-#else
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      unsigned tre = ((unsigned)acc_hh[2 * j] << 8) + (unsigned)acc_mid[2 * j];   // (compiler code: it pads the MFMA -> VALU hazard)
-      unsigned tim = ((unsigned)acc_hh[2 * j + 1] << 8) + (unsigned)acc_mid[2 * j + 1];
-      asm("" : "+v"(tre)); asm("" : "+v"(tim));   // no re-association into 2 shifts + add3
-      const int rr = (int)((tre << 8) + (unsigned)acc_ll[2 * j]) >> 14, ri = (int)((tim << 8) + (unsigned)acc_ll[2 * j + 1]) >> 14;
-      if (ROT) {
-        const int x = WIDE ? mad24a(L[j][0], rr, mul24a(L[j][2], ri)) : sub32(mul24a(L[j][0], rr), mul24a(L[j][1], ri));
-        const int y = mad24a(L[j][0], ri, mul24a(L[j][1], rr));
-        sum.x = add_hi16(x, sum.x); sum.y = add_hi16(y, sum.y);
-      } else {
-        sum.x = (int)((unsigned)sum.x + (unsigned)rr); sum.y = (int)((unsigned)sum.y + (unsigned)ri);
-      }
-    }
-#endif
-#ifdef K1_STAMPS
-    asm volatile("" : "+v"(sum.x), "+v"(sum.y));
-#endif
-    K1_STAMP(3);
-    const int glw = 2 * n + h;
-    const long q = (long)c * a.out_stride + q0 + gw + glw;
-    const int yr = div8_i16(sum.x), yi = div8_i16(sum.y);
-    if (EPI == SDRHIP_EPI_NONE) {
-      reinterpret_cast<uint32_t *>(a.out)[q] = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
-    } else if (EPI == SDRHIP_EPI_AM) {
-      reinterpret_cast<short *>(a.out)[q] = am_i16(yr, yi);
-    } else if (EPI == SDRHIP_EPI_USB) {
-      reinterpret_cast<short *>(a.out)[q] = usb_i16(yr, yi);
-    } else {
-      const int phi = fm_phi(yr, yi);
-      const int prev = prev_group_value(phi, h);
-      if (glw >= 1) reinterpret_cast<short *>(a.out)[q] = (short)(prev - phi);   // group 0 only supplies the previous angle
-    }
-    K1_STAMP(4);
-#ifdef K1_STAMPS
-    st_tiles++;
-#endif
-    u = nu; c = nc; g = ng; tile = ntile; tile_end = ntile_end;
-  }
-  // ---- the call's COLD slices (cold != nullptr: the one-launch form) --------------------------------------------
-  // The slices slice_is_hot() rejects — history in the window, the call's first group, incomplete or unemitted
-  // groups, the end of the input — are a few per channel (2 of 130 on the headline workload). Each workgroup, done
-  // with its hot units, takes the channels bx, bx + gx, ...: wave w computes slice w of tile 0 and of the tiles from
-  // bt_hi on where that slice is cold, out of the same LDS-resident tap fragments and table (a separate border
-  // launch had to fetch them again per channel: 16 us per step), with the general kernel's epilogue (edge masks,
-  // carry, first-sample quirk, state); then the workgroup rolls the channel's FIR history.
-  if (cold != nullptr) {
-    const IqbbArgs &b = *cold;
-    for (int cc = bx; cc < a.C; cc += gx) {
-      for (int t = 0; t < b.tiles; t = (t == 0 ? max(b.bt_hi, 1) : t + 1)) {
-        const int q0 = t * a.OG - a.ovl, groups_here = min(b.CG, b.n_groups - q0);
-        if (slice_is_hot(a.base0_rel, a.OG, a.ovl, a.N, a.n_out, t, w) || gw + a.ovl >= groups_here) continue;
-        // the wave's window by ordinary loads: history / input / zeros per sample, every load issued from a clamped
-        // address and masked afterwards (all 10 in flight together)
-        const int first = a.base0_rel + (q0 + gw) * 8 - (HOT_WIN - 512);
-        const uint32_t *row = a.in + (long)cc * a.in_stride, *hrow = b.hist_old + (long)cc * b.HH;
-        uint32_t v[3][4];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-          const int pp = min(l + 64 * k, HOT_WIN / 4 - 1);
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const int rel = first + 4 * pp + j, hh = b.HH + rel;
-            const uint32_t *src = rel >= 0 ? row + min(rel, a.N - 1) : hrow + max(hh, 0);
-            v[k][j] = *src;
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-          const int pp = min(l + 64 * k, HOT_WIN / 4 - 1);
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const int rel = first + 4 * pp + j;
-            if (rel >= a.N || b.HH + rel < 0) v[k][j] = 0u;
-          }
-          if (k < 2 || l < (HOT_WIN / 4 - 128)) {
-            uint2 l2, h2;
-            l2.x = __builtin_amdgcn_perm(v[k][1], v[k][0], 0x06040200u) ^ 0x80808080u;
-            l2.y = __builtin_amdgcn_perm(v[k][3], v[k][2], 0x06040200u) ^ 0x80808080u;
-            h2.x = __builtin_amdgcn_perm(v[k][1], v[k][0], 0x07050301u);
-            h2.y = __builtin_amdgcn_perm(v[k][3], v[k][2], 0x07050301u);
-            *reinterpret_cast<uint2 *>(lo + dofs[k]) = l2;
-            *reinterpret_cast<uint2 *>(hi + dofs[k]) = h2;
-          }
-        }
-        asm volatile("" ::: "memory");   // (one wave's LDS operations execute in order: the reads below see these writes)
-        v16i acc_hh = {0}, acc_mid = {0}, acc_ll = {0};
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc_ll[r] = (r & 1) ? a.cim : a.cre;
-        const char *pl = lo + coff, *ph = hi + coff;
-#pragma unroll
-        for (int s_ = 0; s_ < S; s_++) {
-          const v4i uh = *reinterpret_cast<const v4i *>(ph + 16 * s_), ul = *reinterpret_cast<const v4i *>(pl + 16 * s_);
-          const v4i Al = taps_s[s_ * 64 + l];
-          acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, uh, acc_mid, 0, 0, 0);
-          acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, ul, acc_ll, 0, 0, 0);
-          if (s_ >= S0 && s_ < S0 + NH) {
-            const v4i Ah = taps_s[(S + s_ - S0) * 64 + l];
-            acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, uh, acc_hh, 0, 0, 0);
-            acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, ul, acc_mid, 0, 0, 0);
-          }
-        }
-        const int tb = a.base0_rel + q0 * 8, rel0 = tb + 8 * gw + MF_BLK * n + 8 * h;
-        const int2 sum = group_sum<ROT, false, true, WIDE ? 2 : 1>(b, acc_hh, acc_mid, acc_ll, rel0);
-        group_finish(b, b.lut, cc, n, h, gw, q0, groups_here, sum);   // (its one table user, the stream's first sample, reads global memory)
-        asm volatile("" ::: "memory");
-      }
-      for (int k = tid; k < b.HH; k += TPB) {   // the FIR history for the next call
-        const long qq = (long)a.N + k;   // index into concat(hist_old, in)
-        b.hist_new[(long)cc * b.HH + k] = qq < b.HH ? b.hist_old[(long)cc * b.HH + qq] : raw_x(b, cc, qq - b.HH);
-      }
-    }
-  }
-#ifdef K1_STAMPS
-  if (l == 0) {
-    const unsigned wv = ((unsigned)bx * 4 + w) & 32767u;
-    for (int i = 0; i < 5; i++) g_k1_stamps[wv * 8 + i] = st_acc[i];
-    g_k1_stamps[wv * 8 + 5] = (unsigned long long)st_tiles | ((unsigned long long)__builtin_amdgcn_s_getreg((15 << 11) | 4) << 32);
-    g_k1_stamps[wv * 8 + 6] = st_r0;
-    g_k1_stamps[wv * 8 + 7] = __builtin_amdgcn_s_memrealtime();
-  }
-#endif
-}
-template <int S, int S0, int NH, bool ROT, int EPI>
-__global__ __launch_bounds__(TPB, 4) void iqbb_i16_hot_kernel(const HotArgs a) {
-  iqbb_i16_hot_body<S, S0, NH, ROT, EPI>(a, (int)blockIdx.x, (int)gridDim.x, nullptr);
-}
-// One launch per call: the hot grid, then each workgroup's share of the cold slices (see the cold phase above).
-template <int S, int S0, int NH, bool ROT, int EPI>
-__global__ __launch_bounds__(TPB, 4) void iqbb_i16_hotb_kernel(const HotArgs a, const IqbbArgs b) {
-  iqbb_i16_hot_body<S, S0, NH, ROT, EPI>(a, (int)blockIdx.x, (int)gridDim.x, &b);
-}
 
 // =================================================================================================
 // Path 3: the 32x32x32 formulation for ANY decimation D. The matrix part is path 1's (every input sample's FIR
@@ -1804,31 +940,14 @@ __global__ __launch_bounds__(TPB, 3) void iqbb_i16_mfma16_kernel(const IqbbArgs 
 }  // namespace
 
 namespace {
-// b != nullptr: the one-launch form (hot grid + cold phase); otherwise the hot grid alone, the border launch follows
-template <int S0, int NH, bool ROT>
-void launch_hot_e(int epi, dim3 grid, dim3 block, size_t lds, hipStream_t st, const HotArgs &ha, const IqbbArgs *b, int C) {
-#define SDRHIP_HOT(E_) do { if (b) hipLaunchKernelGGL((iqbb_i16_hotb_kernel<9, S0, NH, ROT, E_>), grid, block, lds, st, ha, *b); \
-                            else hipLaunchKernelGGL((iqbb_i16_hot_kernel<9, S0, NH, ROT, E_>), grid, block, lds, st, ha); } while (0)
-  switch (epi) {
-    case SDRHIP_EPI_FM: SDRHIP_HOT(SDRHIP_EPI_FM); break;
-    case SDRHIP_EPI_AM: SDRHIP_HOT(SDRHIP_EPI_AM); break;
-    case SDRHIP_EPI_USB: SDRHIP_HOT(SDRHIP_EPI_USB); break;
-    default: SDRHIP_HOT(SDRHIP_EPI_NONE); break;
-  }
-#undef SDRHIP_HOT
-}
-template <int S0, int NH>
-void launch_hot_r(bool rot, int epi, dim3 grid, dim3 block, size_t lds, hipStream_t st, const HotArgs &ha, const IqbbArgs *b, int C) {
-  if (rot) launch_hot_e<S0, NH, true>(epi, grid, block, lds, st, ha, b, C);
-  else launch_hot_e<S0, NH, false>(epi, grid, block, lds, st, ha, b, C);
-}
-// range index r: the K steps [S0, S0 + NH) that run the taps' high plane
-void launch_hot(int r, bool rot, int epi, dim3 grid, dim3 block, size_t lds, hipStream_t st, const HotArgs &ha, const IqbbArgs *b, int C) {
-  switch (r) {
-    case 0: launch_hot_r<3, 3>(rot, epi, grid, block, lds, st, ha, b, C); break;
-    case 1: launch_hot_r<2, 5>(rot, epi, grid, block, lds, st, ha, b, C); break;
-    case 2: launch_hot_r<1, 7>(rot, epi, grid, block, lds, st, ha, b, C); break;
-    default: launch_hot_r<0, 9>(rot, epi, grid, block, lds, st, ha, b, C); break;
+// the hot kernels live in one translation unit per filter-length class (iqbb_hot_s*.hip)
+void launch_hot(int S, bool cu8, int range, bool rot, int epi, const HotLaunch &hl, const HotArgs &ha, const IqbbArgs &b) {
+  switch (S) {
+    case 2: hot_launch_s2(cu8, range, rot, epi, hl, ha, b); break;
+    case 3: hot_launch_s3(cu8, range, rot, epi, hl, ha, b); break;
+    case 5: hot_launch_s5(cu8, range, rot, epi, hl, ha, b); break;
+    case 9: if (cu8) hot_launch_s9_cu8(range, rot, epi, hl, ha, b); else hot_launch_s9_cs16(range, rot, epi, hl, ha, b); break;
+    default: if (cu8) hot_launch_s17_cu8(range, rot, epi, hl, ha, b); else hot_launch_s17_cs16(range, rot, epi, hl, ha, b); break;
   }
 }
 }  // namespace
@@ -1844,8 +963,7 @@ struct sdrhip_iqbb_i16 {
   int CG = 0, OG = 0, ovl = 0;
   bool fast8 = false;
   bool use_dma = true;   // path 1, cs16 input: LDS-DMA fed kernel (SDRHIP_IQBB_DMA=0: the register-staged one, tuning)
-  bool fuse_border = true;   // hot grid and border walk in one launch (SDRHIP_IQBB_FUSE=0: two launches, tuning/tests)
-  bool use_hot = true;   // ... with the hot kernel for the interior tiles (SDRHIP_IQBB_HOT=0: general kernel only, tuning/tests)
+  bool use_hot = true;   // path 1, calls of >= 3 tiles: the hot kernel (SDRHIP_IQBB_HOT=0: the general kernels only, tuning/tests)
   int hot_range = -1;    // which compile-time high-plane K-step range of the hot kernel covers ah_mask (-1: none)
   int in_cu8 = 0, real = 0, i8 = 0;   // input kinds: complex<uint8> with AutoCast, real int16 (BaseBand), complex<int8> (IQBaseBand<int8_t>)
   int path = 0, S = 0, cre = 0, cim = 0;   // path 1 = int8-MFMA formulation with S K-steps
@@ -1860,6 +978,9 @@ struct sdrhip_iqbb_i16 {
   DevBuf<uint32_t> stage_in;
   DevBuf<uint32_t> stage_out;
   size_t max_out = 0;
+#ifdef K1_STAMPS
+  DevBuf<unsigned long long> k1_stamps;   // diagnostic builds: per-wave phase totals of the hot kernel
+#endif
 
 
   // (re)loads the tap-dependent device data: packed taps (VALU kernel, the slow first-sample evaluation), the
@@ -1931,9 +1052,11 @@ struct sdrhip_iqbb_i16 {
             if (ah != 0) ah_mask |= 1u << st;
             frag[(((size_t)(2 * st + 1) * 64 + l) * 16) + j] = (int8_t)al;
           }
-      if (path == 1 && S == 9) {   // smallest centred range [S0, S0+NH) of the hot kernel that covers the mask
-        const unsigned ranges[4] = {0x7u << 3, 0x1fu << 2, 0x7fu << 1, 0x1ffu};
-        for (int r = 0; r < 4 && hot_range < 0; r++) if ((ah_mask & ~ranges[r]) == 0) hot_range = r;
+      if (path == 1) {   // smallest centred range [S0, S0+NH) of the hot kernel that covers the mask
+        int nr = 0;
+        const HotRange *rg = hot_ranges(S, &nr);
+        for (int r = 0; r < nr && hot_range < 0; r++)
+          if ((ah_mask & ~(((1u << rg[r].NH) - 1u) << rg[r].S0)) == 0) hot_range = r;
       }
       if (!tapfrag.p) tapfrag.alloc((size_t)S * 2 * 64);
       tapfrag.upload(reinterpret_cast<const v4i *>(frag.data()), (size_t)S * 2 * 64, ctx->stream);
@@ -1959,6 +1082,45 @@ struct sdrhip_iqbb_i16 {
   }
   size_t out_elem_bytes() const { return epi == SDRHIP_EPI_NONE ? (i8 ? 2 : 4) : 2; }
   size_t in_elem_bytes() const { return (in_cu8 || real || i8) ? 2 : 4; }
+
+  // Path 1's hot kernel (iqbb_hot.hpp): one launch for the whole call — a persistent grid over the wave slices that
+  // touch no border of the call, then the same workgroups' share of the cold slices (tile 0 and the tiles from t_hi on).
+  // false: the call is too short to have a tile of hot slices; the general kernel runs it.
+  bool launch_hot_call(IqbbArgs &a, const Geometry &g, const uint32_t *in_dev, size_t N, size_t in_stride, void *out_dev,
+                       size_t out_stride, int tiles) {
+    const int halo = 16 * (S - 1);
+    auto host_hot = [&](int t, int w) { return slice_is_hot(halo, g.base0_rel, OG, ovl, (int)N, g.n_out, t, w); };
+    long t = tiles - 1;   // the last tile always holds cold slices (history roll, state)
+    while (t >= 2 && !(host_hot((int)t - 1, 0) && host_hot((int)t - 1, 1) && host_hot((int)t - 1, 2) && host_hot((int)t - 1, 3))) t--;
+    if (t < 2) return false;
+    int nr = 0;
+    const HotRange *rg = hot_ranges(S, &nr);
+    const int NW = rg[hot_range].NW;
+    HotArgs ha;
+    ha.in = in_dev; ha.in_stride = (long)in_stride; ha.out = out_dev; ha.out_stride = (long)out_stride;
+    ha.tapfrag = tapfrag.p; ha.lut = lut.p; ha.inc = inc; ha.n0_lo = (uint32_t)(n0 - phase0); ha.negative = negative;
+    ha.base0_rel = g.base0_rel; ha.OG = OG; ha.ovl = ovl; ha.t_lo = 0; ha.t_hi = tiles; ha.cre = cre; ha.cim = cim;
+    ha.N = (int)N; ha.n_out = g.n_out; ha.C = C; ha.stamps = nullptr;
+#ifdef K1_STAMPS
+    if (!k1_stamps.p) { k1_stamps.alloc(32768 * 8); k1_stamps.zero(ctx->stream); }
+    ha.stamps = k1_stamps.p;
+#endif
+    // persistent grid of 4 virtual (4-wave) workgroups per CU = 4 waves per SIMD; a real workgroup is NW / 4 of them.
+    // Units of at most 4 tiles so that the static split leaves a short tail.
+    const int nvwg = 4 * ctx->prop.multiProcessorCount;
+    int htpw = 4; while (htpw > 1 && (size_t)ceil_div((size_t)tiles, (size_t)htpw) * C < 4 * (size_t)nvwg) htpw >>= 1;
+    { const char *e = getenv("SDRHIP_IQBB_TPW"); if (e) htpw = std::max(1, atoi(e)); }   // tuning hook
+    ha.tpw = htpw;
+    ha.G = (int)ceil_div((size_t)tiles, (size_t)htpw); ha.U = ha.G * C;
+    const int vper = NW / 4;
+    const int grid = (int)ceil_div((size_t)std::min(nvwg, std::max(ha.U, C)), (size_t)vper);   // (every channel's cold slices need a taker too)
+    const int gx = grid * vper;   // virtual workgroups
+    ha.dq = gx / ha.G; ha.dr = gx % ha.G;
+    a.bt_hi = (int)t; a.tpw = 1;
+    HotLaunch hl{(unsigned)grid, ctx->stream};
+    launch_hot(S, in_cu8 != 0, hot_range, inc != 0, epi, hl, ha, a);
+    return true;
+  }
 
   void launch(const uint32_t *in_dev, size_t N, size_t in_stride, void *out_dev, size_t out_stride, size_t *n_out) {
     ctx->use();
@@ -1986,7 +1148,7 @@ struct sdrhip_iqbb_i16 {
     int tpw = 1;
     if (path == 1 || path == 2 || path == 4) { tpw = 8; while (tpw > 1 && (size_t)ceil_div((size_t)tiles, (size_t)tpw) * C < 2048) tpw >>= 1; }
     { const char *t = getenv("SDRHIP_IQBB_TPW"); if (t && (path == 1 || path == 2 || path == 4)) tpw = std::max(1, atoi(t)); }   // tuning hook
-    a.tiles = tiles; a.tpw = tpw; a.border = 0; a.bt_hi = 0;
+    a.tiles = tiles; a.tpw = tpw; a.bt_hi = 0;
     a.lpg = 1; while (a.lpg < 64 && a.lpg * 8 < D) a.lpg <<= 1;
     dim3 grid((unsigned)ceil_div((size_t)tiles, (size_t)tpw), C), block(TPB);
     if (path == 4) {
@@ -2032,58 +1194,13 @@ struct sdrhip_iqbb_i16 {
         default: SDRHIP_MF16(5); break;
       }
 #undef SDRHIP_MF16
+    } else if (path == 1 && use_dma && use_hot && hot_range >= 0 && tiles >= 3 && launch_hot_call(a, g, in_dev, N, in_stride, out_dev, out_stride, tiles)) {
+      // (complex<int16> or complex<uint8> input, any filter length of path 1: the hot kernel took the whole call)
     } else if (path == 1 && !in_cu8 && use_dma) {
-      // complex<int16> input: raw tiles by LDS-DMA (LDS: table | one plane pair | raw tile | tap fragments)
+      // complex<int16> input, calls too short for the hot kernel (or SDRHIP_IQBB_HOT=0): the general kernel, raw tiles
+      // by LDS-DMA (LDS: table | one plane pair | raw tile | tap fragments)
       const size_t PLWd = (2 * (size_t)(TI + OP) + 64 + 31) / 32 * 8, quads = (TI + OP + 4) / 4;
       const size_t ldsd = (256 + 2 * PLWd + 4 * ((quads + 63) / 64 * 64)) * 4 + (size_t)S * 2 * 64 * 16;
-      // Hot tiles [1, t_hi): every wave window inside the input, every group complete and emitted, not the call's
-      // first tile (carry, FM's first outputs) and not its last (history roll, state): one lean kernel for them,
-      // the general kernel for the rest (tile 0 and tiles t_hi .. tiles-1, one workgroup each).
-      // The hot kernel computes every hot wave slice (slice_is_hot) of every tile; the general kernel follows with a
-      // border launch over the tiles that hold the other slices — tile 0 and the tiles from t_hi on, one workgroup
-      // each, in which only the cold slices are computed (and the last tile rolls the history).
-      int t_hi = 0;
-      if (S == 9 && hot_range >= 0 && use_hot && tiles >= 3) {
-        auto host_hot = [&](long t, long w) {
-          const long qf = t * OG - ovl + w * (64 - ovl), ws = (long)g.base0_rel + qf * 8 - 128;
-          return ws >= 0 && ws + 640 <= (long)N && qf >= 1 && qf + 63 < (long)g.n_out - 1;   // (= slice_is_hot)
-        };
-        long t = tiles - 1;   // the last tile always goes to the border launch (history roll, state)
-        while (t >= 2 && !(host_hot(t - 1, 0) && host_hot(t - 1, 1) && host_hot(t - 1, 2) && host_hot(t - 1, 3))) t--;
-        if (t >= 2) t_hi = (int)t;
-      }
-      if (t_hi > 0) {
-        HotArgs ha;
-        ha.in = in_dev; ha.in_stride = (long)in_stride; ha.out = out_dev; ha.out_stride = (long)out_stride;
-        ha.tapfrag = tapfrag.p; ha.lut = lut.p; ha.inc = inc; ha.n0_lo = (uint32_t)(n0 - phase0); ha.negative = negative;
-        ha.base0_rel = g.base0_rel; ha.OG = OG; ha.ovl = ovl; ha.t_lo = 0; ha.t_hi = tiles; ha.cre = cre; ha.cim = cim;
-        ha.N = (int)N; ha.n_out = g.n_out; ha.C = C;
-        const int nhot = tiles;
-        // persistent grid of 4 workgroups per CU; units of at most 4 tiles so that the static split leaves a short tail
-        const int nwg = 4 * ctx->prop.multiProcessorCount;
-        int htpw = 4; while (htpw > 1 && (size_t)ceil_div((size_t)nhot, (size_t)htpw) * C < 4 * (size_t)nwg) htpw >>= 1;
-        { const char *t = getenv("SDRHIP_IQBB_TPW"); if (t) htpw = std::max(1, atoi(t)); }   // tuning hook
-        ha.tpw = htpw;
-        ha.G = (int)ceil_div((size_t)nhot, (size_t)htpw); ha.U = ha.G * C;
-        const int gx = std::min(nwg, ha.U);
-        ha.dq = gx / ha.G; ha.dr = gx % ha.G;
-        const dim3 hgrid((unsigned)gx, 1);
-        static const int hot_nh[4] = {3, 5, 7, 9};
-        const int hnh = hot_nh[hot_range < 0 ? 3 : hot_range];
-        const size_t hlds = (hot_wide_table(hnh) ? 4096 : 1024) + (size_t)(S + hnh) * 64 * 16 + 4 * (size_t)(HOT_RAWB + 2 * HOT_PLB);
-        a.border = 1; a.bt_hi = t_hi; a.tpw = 1;
-        grid = dim3(1, C);
-        if (fuse_border) {   // one launch: the hot workgroups finish with the cold slices
-          launch_hot(hot_range, inc != 0, epi, hgrid, block, hlds, ctx->stream, ha, &a, C);
-          SDRHIP_CHECK_HIP(hipGetLastError());
-          par ^= 1;
-          if (fm_flip) par_fm ^= 1;
-          n0 += N;
-          if (n_out) *n_out = (size_t)g.n_out;
-          return;
-        }
-        launch_hot(hot_range, inc != 0, epi, hgrid, block, hlds, ctx->stream, ha, nullptr, C);
-      }
 #define SDRHIP_MFD(S_) do { if (inc != 0) hipLaunchKernelGGL((iqbb_i16_mfma_dma_kernel<S_, true>), grid, block, ldsd, ctx->stream, a); \
                              else hipLaunchKernelGGL((iqbb_i16_mfma_dma_kernel<S_, false>), grid, block, ldsd, ctx->stream, a); } while (0)
       switch (S) {
@@ -2160,7 +1277,6 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
         if (high_byte(taps[i]) > 127 || high_byte(-taps[i]) > 127) mfma_ok = false;
       { const char *d = getenv("SDRHIP_IQBB_DMA"); if (d && d[0] == '0') h->use_dma = false; }
       { const char *d = getenv("SDRHIP_IQBB_HOT"); if (d && d[0] == '0') h->use_hot = false; }
-      { const char *d = getenv("SDRHIP_IQBB_FUSE"); if (d && d[0] == '0') h->fuse_border = false; }
       const char *force = getenv("SDRHIP_IQBB_PATH");   // "valu" / "mfma" / "mfma16": test hook
       if (force && !strcmp(force, "valu")) mfma_ok = false;
       bool mfma16_ok = !real && !i8 && (decim == R) && (order <= 153);
@@ -2270,8 +1386,8 @@ int sdrhip_iqbb_i16_kernel_names(sdrhip_iqbb_i16 *h, char *buf, size_t len) {
     if (h->path == 4) nm = "bb_real_mfma_kernel";
     else if (h->path == 3) nm = "iqbb_i16_mfmag_kernel";
     else if (h->path == 2) nm = "iqbb_i16_mfma16_kernel";
+    else if (h->path == 1 && h->use_dma && h->use_hot && h->hot_range >= 0) nm = "iqbb_hot_kernel";   // (calls of < 3 tiles: the general kernel)
     else if (h->path == 1 && (h->in_cu8 || !h->use_dma)) nm = "iqbb_i16_mfma_kernel";
-    else if (h->path == 1 && h->S == 9 && h->hot_range >= 0 && h->use_hot) nm = h->fuse_border ? "iqbb_i16_hotb_kernel" : "iqbb_i16_hot_kernel,iqbb_i16_mfma_dma_kernel";
     else if (h->path == 1) nm = "iqbb_i16_mfma_dma_kernel";
     snprintf(buf, len, "%s", nm);
   });
@@ -2407,7 +1523,9 @@ int sdrhip_iqbb_i16_destroy(sdrhip_iqbb_i16 *h) {
 }  // extern "C"
 
 #ifdef K1_STAMPS
-extern "C" int sdrhip_debug_k1_stamps(unsigned long long *out, int words) {   // diagnostic builds only (tools/build_variant.sh)
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k1_stamps), (size_t)words * 8) == hipSuccess ? 0 : -3;
+extern "C" int sdrhip_debug_k1_stamps(sdrhip_iqbb_i16 *h, unsigned long long *out, int words) {   // diagnostic builds only (tools/build_variant.sh)
+  if (!h || !h->k1_stamps.p) return -3;
+  (void)hipStreamSynchronize(h->ctx->stream);
+  return hipMemcpy(out, h->k1_stamps.p, (size_t)words * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
 }
 #endif

@@ -212,14 +212,7 @@ def test_subsample_and_demods_random(ctx, orc, seed):
                 assert np.array_equal(z[c], fms[c].process(x[c]))
 
 
-@pytest.mark.parametrize("seed", range(24 + EXTRA))
-def test_one_launch_kernel_random_long_calls(ctx, orc, seed):
-    """The 127-tap / decimation-8 plan's one-launch kernel (hot loop + cold phase): random long ragged calls (the last tile
-    ends in every way, calls too short for a hot tile in between), channel counts, epilogues, shift signs and filter
-    widths (narrow: few K steps carry the taps' high plane; wide: all nine), retuned between buffers (shift, filter), state
-    carried from call to call."""
-    rng = np.random.default_rng(7000 + seed)
-    order = int(rng.choice([127, 127, 127, 113, 128, 129]))
+def _hot_fuzz(ctx, orc, rng, order, cu8):
     Fc = float(rng.choice([100e3, -100e3, 0.0, 333e3]))
     epi = int(rng.choice([sa.EPI_NONE, sa.EPI_FM, sa.EPI_FM, sa.EPI_AM, sa.EPI_USB]))
     width = float(rng.choice([12.5e3, 50e3, 200e3, 600e3]))
@@ -229,6 +222,9 @@ def test_one_launch_kernel_random_long_calls(ctx, orc, seed):
     lens = [int(rng.integers(4000, 70000)) for _ in range(3)] + [int(rng.choice([1, 500, 2047, 4031, 4032, 4033, 65536]))] + [int(rng.integers(4000, 30000))]
     rng.shuffle(lens)
     node = sa.IQBaseBandI16(ctx, taps, lut, inc, Fc < 0, 8, channels=C, max_in=max(lens), epilogue=epi)
+    if cu8:
+        node.set_input_format(sa.abi.IN_CU8)
+    assert node.kernel_names == ["iqbb_hot_kernel"]
     refs = [orc.IQBaseBandI16(taps, lut, inc, Fc < 0, 8) for _ in range(C)]
     fms = [orc.FMDemodI16() for _ in range(C)]
     for n in lens:
@@ -247,17 +243,40 @@ def test_one_launch_kernel_random_long_calls(ctx, orc, seed):
             node.set_taps(t2)
             for r_ in refs:
                 r_.set_taps(t2)
-        x = rng.integers(-32768, 32768, (C, n, 2), dtype=np.int16)
+        if cu8:
+            x = rng.integers(0, 256, (C, n, 2), dtype=np.uint8)
+        else:
+            x = rng.integers(-32768, 32768, (C, n, 2), dtype=np.int16)
         y = node.process(x)
         for c in range(C):
-            r = refs[c].process(x[c])
+            r = refs[c].process(orc.autocast_cu8_cs16(x[c]) if cu8 else x[c])
             if epi == sa.EPI_FM:
                 r = fms[c].process(r)
             elif epi == sa.EPI_AM:
                 r = orc.am_i16(r)
             elif epi == sa.EPI_USB:
                 r = orc.usb_i16(r)
-            assert y[c].shape == r.shape and np.array_equal(y[c], r), (seed, order, Fc, epi, width, C, n, ev, node.kernel_names)
+            assert y[c].shape == r.shape and np.array_equal(y[c], r), (order, cu8, Fc, epi, width, C, n, ev)
+
+
+@pytest.mark.parametrize("seed", range(24 + EXTRA))
+def test_one_launch_kernel_random_long_calls(ctx, orc, seed):
+    """The 127-tap / decimation-8 plan's hot kernel (hot loop + cold phase in one launch): random long ragged calls (the
+    last tile ends in every way, calls too short for a hot tile in between), channel counts, epilogues, shift signs and
+    filter widths (narrow: few K steps carry the taps' high plane; wide: all nine), retuned between buffers (shift,
+    filter), state carried from call to call."""
+    rng = np.random.default_rng(7000 + seed)
+    _hot_fuzz(ctx, orc, rng, int(rng.choice([127, 127, 127, 113, 128, 129])), False)
+
+
+@pytest.mark.parametrize("cu8", [False, True])
+@pytest.mark.parametrize("seed", range(20 + EXTRA))
+def test_hot_kernel_every_length_class_random_long_calls(ctx, orc, seed, cu8):
+    """The same sweep over every filter-length class of the hot kernel (2, 3, 5, 9, 17 K steps: the reference's own plans
+    are order 16, examples/sdr_rec.cc:68, and 21, examples/sdr_fm.cc:40) and both input kinds (complex<int16>;
+    complex<uint8> with AutoCast fused, src/autocast.hh:187-194)."""
+    rng = np.random.default_rng(17000 + 2 * seed + int(cu8))
+    _hot_fuzz(ctx, orc, rng, int(rng.choice([3, 16, 17, 21, 33, 34, 64, 65, 66, 100, 127, 130, 200, 255, 257])), cu8)
 
 
 @pytest.mark.parametrize("seed", range(16 + EXTRA))

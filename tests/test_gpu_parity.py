@@ -40,23 +40,20 @@ def ctx():
     c.close()
 
 
-@pytest.fixture(params=["auto", "valu", "mfma16", "mfmag", "twolaunch", "general", "regstaged"])
+@pytest.fixture(params=["auto", "valu", "mfma16", "mfmag", "general", "regstaged"])
 def k1path(request, monkeypatch):
-    """K1 has four bit-exact kernels: int8-MFMA on 32x32x32 tiles for decimation 8 (path 1, picked automatically up to
+    """K1 has four bit-exact formulations: int8-MFMA on 32x32x32 tiles for decimation 8 (path 1, picked automatically up to
     257 taps) and for any other decimation (path 3), the 16x16x64 shape (path 2, on request) and the VALU dot2 kernel
-    (path 0: real input, taps that do not fit, longer filters); every K1 test runs under each selection. Path 1 itself
-    has three forms for 127-tap plans: hot grid + cold phase in one launch (the default), hot grid + border launch
-    ("twolaunch") and the general kernel alone ("general"); "regstaged" is round 1's kernel (still the one complex<uint8> input runs: a
-    wave-autonomous one-plane variant measured no faster)."""
-    monkeypatch.delenv("SDRHIP_IQBB_FUSE", raising=False)
+    (path 0: the int8 chain, taps that do not fit, longer filters); every K1 test runs under each selection. Path 1 itself
+    has three kernels: the hot kernel (one launch: persistent grid over the call's interior wave slices + cold phase; the
+    default for calls of >= 3 tiles, every filter length, complex<int16> and complex<uint8> input), the general LDS-DMA
+    kernel ("general": SDRHIP_IQBB_HOT=0, and what short calls run) and round 1's register-staged kernel ("regstaged":
+    SDRHIP_IQBB_DMA=0, also the general kernel of complex<uint8> input)."""
     monkeypatch.delenv("SDRHIP_IQBB_HOT", raising=False)
     monkeypatch.delenv("SDRHIP_IQBB_DMA", raising=False)
-    if request.param == "regstaged":   # round 1's register-staged kernel (cs16 and cu8 input), one barrier per tile
+    if request.param == "regstaged":
         monkeypatch.delenv("SDRHIP_IQBB_PATH", raising=False)
         monkeypatch.setenv("SDRHIP_IQBB_DMA", "0")
-    elif request.param == "twolaunch":
-        monkeypatch.delenv("SDRHIP_IQBB_PATH", raising=False)
-        monkeypatch.setenv("SDRHIP_IQBB_FUSE", "0")
     elif request.param == "general":
         monkeypatch.delenv("SDRHIP_IQBB_PATH", raising=False)
         monkeypatch.setenv("SDRHIP_IQBB_HOT", "0")
