@@ -198,7 +198,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   asm volatile("" : "+v"(cinit));
 
 #ifdef K1_STAMPS   // diagnostic build: shader-clock stamps at the phase boundaries, summed per phase per wave
-  unsigned long long st_acc[5] = {0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
+  unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
   const unsigned long long st_r0 = __builtin_amdgcn_s_memrealtime();
   unsigned st_tiles = 0;
 #define K1_STAMP(i_) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i_] += t_ - st_t; st_t = t_; } while (0)
@@ -238,6 +238,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
     }
     // ---- the next slice's window starts its journey into the other buffer (its planes were last read in the previous
     // slice's K loop); then wait for this slice's own window: everything older than those NDMA instructions ----
+    K1_STAMP(0);
     if (more) {
       dma_issue(dma_src(nc, ntile), nb);
       if (NDMA == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
@@ -246,7 +247,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    K1_STAMP(0);
+    K1_STAMP(1);
     // ---- raw window -> byte planes, in place: every read of the wave is issued before its first write, and the LDS
     // executes one wave's instructions in order ----
     {
@@ -276,7 +277,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
     }
     // (the plane reads below see these writes: same wave, in order. The empty asm statements keep the COMPILER from
     // moving LDS accesses across: no barrier or fence instruction separates them.)
-    K1_STAMP(1);
+    K1_STAMP(2);
     asm volatile("" ::: "memory");
 
     // ---- K loop: operands of step s+1 in flight while the MFMAs of step s issue ----
@@ -311,7 +312,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
 #ifdef K1_STAMPS
     asm volatile("s_nop 0" : "+v"(acc_hh), "+v"(acc_mid), "+v"(acc_ll));   // the accumulators are complete before the stamp
 #endif
-    K1_STAMP(2);
+    K1_STAMP(3);
 
     // ---- epilogue: lane (n, h) owns group 2n + h of the wave ----
     const uint32_t wave_cnt = (a.n0_lo + (uint32_t)(a.base0_rel + (q0 + gw) * 8)) * a.inc;   // scalar unit
@@ -370,7 +371,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
 #ifdef K1_STAMPS
     asm volatile("" : "+v"(sum.x), "+v"(sum.y));
 #endif
-    K1_STAMP(3);
+    K1_STAMP(4);
     const int glw = 2 * n + h;
     const long q = (long)c * a.out_stride + q0 + gw + glw;
     // libstdc++'s (s*8)/(8*8) (src/baseband.hh:214): |s| <= 9 * 2^17 (a window of 16-bit rotated values, or of 18-bit FIR
@@ -387,7 +388,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       const int prev = prev_group_value(phi, h);
       if (glw >= 1) reinterpret_cast<short *>(a.out)[q] = (short)(prev - phi);   // group 0 only supplies the previous angle
     }
-    K1_STAMP(4);
+    K1_STAMP(5);
 #ifdef K1_STAMPS
     st_tiles++;
 #endif
@@ -508,19 +509,21 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
     }
   }
 #ifdef K1_STAMPS
-  if (l == 0 && a.stamps) {
-    const unsigned wv_ = ((unsigned)bx * 4 + wv) & 32767u;
-    for (int i = 0; i < 5; i++) a.stamps[wv_ * 8 + i] = st_acc[i];
-    a.stamps[wv_ * 8 + 5] = (unsigned long long)st_tiles | ((unsigned long long)__builtin_amdgcn_s_getreg((15 << 11) | 4) << 32);
-    a.stamps[wv_ * 8 + 6] = st_r0;
-    a.stamps[wv_ * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+  if (l == 0 && a.stamps) {   // 16 words per wave: 6 phase totals, -, -, slices, HW_ID, first and last realtime stamp
+    unsigned long long *o = a.stamps + (size_t)((((unsigned)bx * 4 + wv) & 32767u) * 16);
+    for (int i = 0; i < 6; i++) o[i] = st_acc[i];
+    o[8] = st_tiles; o[9] = __builtin_amdgcn_s_getreg((15 << 11) | 4);
+    o[10] = st_r0; o[11] = __builtin_amdgcn_s_memrealtime();
   }
 #endif
 }
 
 // One launch per call: the hot grid, then each virtual workgroup's share of the cold slices.
 template <int S, int S0, int NH, bool ROT, int EPI, bool CU8, int NW>
-__global__ __launch_bounds__(64 * NW, 4) void iqbb_hot_kernel(const HotArgs a, const IqbbArgs b) {
+#ifndef K1_MINWAVES
+#define K1_MINWAVES 4
+#endif
+__global__ __launch_bounds__(64 * NW, K1_MINWAVES) void iqbb_hot_kernel(const HotArgs a, const IqbbArgs b) {
   iqbb_hot_body<S, S0, NH, ROT, EPI, CU8, NW>(a, b);
 }
 

@@ -1102,12 +1102,14 @@ struct sdrhip_iqbb_i16 {
     ha.base0_rel = g.base0_rel; ha.OG = OG; ha.ovl = ovl; ha.t_lo = 0; ha.t_hi = tiles; ha.cre = cre; ha.cim = cim;
     ha.N = (int)N; ha.n_out = g.n_out; ha.C = C; ha.stamps = nullptr;
 #ifdef K1_STAMPS
-    if (!k1_stamps.p) { k1_stamps.alloc(32768 * 8); k1_stamps.zero(ctx->stream); }
+    if (!k1_stamps.p) { k1_stamps.alloc(32768 * 16); k1_stamps.zero(ctx->stream); }
     ha.stamps = k1_stamps.p;
 #endif
     // persistent grid of 4 virtual (4-wave) workgroups per CU = 4 waves per SIMD; a real workgroup is NW / 4 of them.
     // Units of at most 4 tiles so that the static split leaves a short tail.
-    const int nvwg = 4 * ctx->prop.multiProcessorCount;
+    int wgpcu = 4;
+    { const char *e = getenv("SDRHIP_IQBB_WGPCU"); if (e) wgpcu = std::max(1, atoi(e)); }   // tuning hook (builds with -DK1_MINWAVES=5)
+    const int nvwg = wgpcu * ctx->prop.multiProcessorCount;
     int htpw = 4; while (htpw > 1 && (size_t)ceil_div((size_t)tiles, (size_t)htpw) * C < 4 * (size_t)nvwg) htpw >>= 1;
     { const char *e = getenv("SDRHIP_IQBB_TPW"); if (e) htpw = std::max(1, atoi(e)); }   // tuning hook
     ha.tpw = htpw;
