@@ -125,27 +125,39 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   // unit u = (channel u / G, tile group u % G of `tpw` consecutive tiles). All units are the same length, so the static
   // assignment balances (one workgroup per unit left ~3 of 4 workgroups per CU resident: the unsynchronised waves of a
   // workgroup finish up to 2x apart and its LDS stays allocated until the slowest is done).
+  // For a given slice index wv the hot tiles of a channel are ONE range [hl, hh) — slice_is_hot's conditions are
+  // monotone in the tile — the same for every channel: found once per wave, so that the loop below tests tile numbers
+  // instead of evaluating the conditions per slice.
+  int hl = a.t_lo, hh = a.t_hi;
+  while (hl < hh && !slice_is_hot(HALO, a.base0_rel, a.OG, a.ovl, a.N, a.n_out, hl, wv)) hl++;
+  while (hh > hl && !slice_is_hot(HALO, a.base0_rel, a.OG, a.ovl, a.N, a.n_out, hh - 1, wv)) hh--;
   int u = bx;
   int c = u / a.G, g = u - c * a.G;   // (one division per wave, at start; afterwards (c, g) advance by (dq, dr))
-  int tile = a.t_lo + g * a.tpw, tile_end = min(tile + a.tpw, a.t_hi);
-  auto skip_cold = [&](int &u_, int &c_, int &g_, int &tile_, int &tile_end_) {
-    while (u_ < a.U && !slice_is_hot(HALO, a.base0_rel, a.OG, a.ovl, a.N, a.n_out, tile_, wv)) {
-      if (++tile_ >= tile_end_) {
-        u_ += gx; c_ += a.dq; g_ += a.dr;
-        if (g_ >= a.G) { g_ -= a.G; c_++; }
-        tile_ = a.t_lo + g_ * a.tpw; tile_end_ = min(tile_ + a.tpw, a.t_hi);
-      }
-    }
+  int tile = max(a.t_lo + g * a.tpw, hl), tend = min(a.t_lo + g * a.tpw + a.tpw, hh);
+  // advance (u, c, g) to the next unit that holds a hot tile of this wave's slice (units wholly outside [hl, hh) — the
+  // first or last unit of a channel, at most — are skipped)
+  auto next_unit = [&](int &u_, int &c_, int &g_, int &tile_, int &tend_) {
+    do {
+      u_ += gx; c_ += a.dq; g_ += a.dr;
+      if (g_ >= a.G) { g_ -= a.G; c_++; }
+      tile_ = max(a.t_lo + g_ * a.tpw, hl); tend_ = min(a.t_lo + g_ * a.tpw + a.tpw, hh);
+    } while (u_ < a.U && tile_ >= tend_);
   };
-  skip_cold(u, c, g, tile, tile_end);
+  if (u < a.U && tile >= tend) next_unit(u, c, g, tile, tend);
+  // Per channel: scalar bases of the wave's input window and output row; per slice they advance by whole tiles.
   // The window of tile t starts at sample base0_rel + (t * OG - ovl + gw) * 8 - HALO of the channel's row. The lane's
   // global pointer: scalar base + the lane's 32-bit byte offset, ONE 64-bit vector add per slice; the DMA pieces differ
   // by the instruction's immediate offset, which applies to the global AND the LDS address alike.
   const uint32_t lane_byte = 16u * (uint32_t)l;
-  constexpr int SB = CU8 ? 2 : 4;   // bytes per input sample
-  auto dma_src = [&](int c_, int tile_) {
-    return reinterpret_cast<const char *>(a.in) + ((long)c_ * a.in_stride + (a.base0_rel + (tile_ * a.OG - a.ovl + gw) * 8 - HALO)) * SB + lane_byte;
-  };
+  constexpr int SB = CU8 ? 2 : 4;                              // bytes per input sample
+  constexpr int OB = EPI == SDRHIP_EPI_NONE ? 4 : 2;           // bytes per output element
+  const int tile_in_bytes = a.OG * 8 * SB, tile_out_bytes = a.OG * OB;
+  const uint32_t tile_cnt = (uint32_t)(a.OG * 8) * a.inc;      // LUT phase counter advance per tile
+  const uint32_t cnt0 = (a.n0_lo + (uint32_t)(a.base0_rel + (gw - a.ovl) * 8)) * a.inc;   // ... of the wave's first sample in tile 0
+  auto chan_src = [&](int c_) { return reinterpret_cast<const char *>(a.in) + ((long)c_ * a.in_stride + (a.base0_rel + (gw - a.ovl) * 8 - HALO)) * SB; };
+  auto chan_out = [&](int c_) { return reinterpret_cast<char *>(a.out) + ((long)c_ * a.out_stride + (gw - a.ovl)) * OB; };
+  const char *srcb = chan_src(c);
+  char *outb = chan_out(c);
   // The DMA is issued from inline asm, not through __builtin_amdgcn_global_load_lds: the compiler's wait-count pass
   // puts an `s_waitcnt vmcnt(0)` in front of every LDS access that MAY alias an LDS-DMA destination it knows of, and
   // it cannot tell the two window buffers apart — the prefetch would be waited for right after it was issued. What the
@@ -169,7 +181,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
 #pragma clang diagnostic pop
 #endif
   };
-  if (u < a.U) dma_issue(dma_src(c, tile), wbase);
+  if (u < a.U) dma_issue(srcb + (long)tile * tile_in_bytes + lane_byte, wbase);
   __syncthreads();   // tap fragments and table in place (the only workgroup barrier)
 
   // plane byte offsets of this lane's pieces. cs16: piece p = 4 samples = half of chunk j = p >> 1 (a chunk = 8 samples =
@@ -215,32 +227,31 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   auto slice = [&](auto par_) __attribute__((always_inline)) {
     constexpr int PAR = decltype(par_)::value;
     char *cb = wbase + PAR * BUFB, *nb = wbase + (1 - PAR) * BUFB;
-    // the step after this one: next tile of the unit, or the first tile of the workgroup's next unit
-    int nu = u, nc = c, ng = g, ntile = tile + 1, ntile_end = tile_end;
-    if (ntile >= tile_end) {
-      nu = u + gx; nc = c + a.dq; ng = g + a.dr;
-      if (ng >= a.G) { ng -= a.G; nc++; }
-      ntile = a.t_lo + ng * a.tpw; ntile_end = min(ntile + a.tpw, a.t_hi);
+    // the step after this one: next tile of the unit, or the first hot tile of the workgroup's next unit
+    int nu = u, nc = c, ng = g, ntile = tile + 1, ntend = tend;
+    const char *nsrcb = srcb;
+    char *noutb = outb;
+    if (ntile >= tend) {
+      next_unit(nu, nc, ng, ntile, ntend);
+      nsrcb = chan_src(nc); noutb = chan_out(nc);
     }
-    skip_cold(nu, nc, ng, ntile, ntile_end);
     const bool more = nu < a.U;
-    const int q0 = tile * a.OG - a.ovl;
     // Fairness: the SIMD arbitrates its waves by priority, then AGE, and in a persistent grid the ages never change —
     // the oldest wave of a SIMD ran at full speed and was done after 64 us, the youngest starved and finished alone
     // at 120 us (s_memrealtime stamps). The priority rotates over the SIMD's four wave slots, one step per slice.
-    if (K1_PRIO_ROT == 1) {
-      switch ((prio_it++ + prio_slot) & 3u) {
-        case 0: __builtin_amdgcn_s_setprio(0); break;
-        case 1: __builtin_amdgcn_s_setprio(1); break;
-        case 2: __builtin_amdgcn_s_setprio(2); break;
-        default: __builtin_amdgcn_s_setprio(3); break;
-      }
+    if (K1_PRIO_ROT == 1) {   // (s_setprio takes an immediate: a two-level branch tree, 5-6 scalar instructions executed)
+      const unsigned pv = prio_it++ + prio_slot;
+      asm volatile("s_bitcmp1_b32 %0, 1\n\ts_cbranch_scc1 2f\n\ts_bitcmp1_b32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n\ts_branch 4f\n"
+                   "1:\n\ts_setprio 1\n\ts_branch 4f\n"
+                   "2:\n\ts_bitcmp1_b32 %0, 0\n\ts_cbranch_scc1 3f\n\ts_setprio 2\n\ts_branch 4f\n"
+                   "3:\n\ts_setprio 3\n"
+                   "4:" :: "s"(pv) : "scc");
     }
     // ---- the next slice's window starts its journey into the other buffer (its planes were last read in the previous
     // slice's K loop); then wait for this slice's own window: everything older than those NDMA instructions ----
     K1_STAMP(0);
-    if (more) {
-      dma_issue(dma_src(nc, ntile), nb);
+    if (__builtin_expect(more, 1)) {
+      dma_issue(nsrcb + (long)ntile * tile_in_bytes + lane_byte, nb);
       if (NDMA == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
       else if (NDMA == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
@@ -315,7 +326,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
     K1_STAMP(3);
 
     // ---- epilogue: lane (n, h) owns group 2n + h of the wave ----
-    const uint32_t wave_cnt = (a.n0_lo + (uint32_t)(a.base0_rel + (q0 + gw) * 8)) * a.inc;   // scalar unit
+    const uint32_t wave_cnt = cnt0 + (uint32_t)tile * tile_cnt;   // scalar unit
     int L[8][3];
 #ifdef K1_ABL_NOEPI
     if (false) {
@@ -373,26 +384,26 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
 #endif
     K1_STAMP(4);
     const int glw = 2 * n + h;
-    const long q = (long)c * a.out_stride + q0 + gw + glw;
+    char *orow = outb + (long)tile * tile_out_bytes;   // (scalar) the wave's first group of this slice
     // libstdc++'s (s*8)/(8*8) (src/baseband.hh:214): |s| <= 9 * 2^17 (a window of 16-bit rotated values, or of 18-bit FIR
     // values when there is no shift), so nothing wraps and it is trunc(s / 8) + the int16 wrap of the assignment
     const int yr = div8_i16(sum.x), yi = div8_i16(sum.y);
     if (EPI == SDRHIP_EPI_NONE) {
-      reinterpret_cast<uint32_t *>(a.out)[q] = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
+      reinterpret_cast<uint32_t *>(orow)[glw] = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
     } else if (EPI == SDRHIP_EPI_AM) {
-      reinterpret_cast<short *>(a.out)[q] = am_i16(yr, yi);
+      reinterpret_cast<short *>(orow)[glw] = am_i16(yr, yi);
     } else if (EPI == SDRHIP_EPI_USB) {
-      reinterpret_cast<short *>(a.out)[q] = usb_i16(yr, yi);
+      reinterpret_cast<short *>(orow)[glw] = usb_i16(yr, yi);
     } else {
       const int phi = fm_phi(yr, yi);
       const int prev = prev_group_value(phi, h);
-      if (glw >= 1) reinterpret_cast<short *>(a.out)[q] = (short)(prev - phi);   // group 0 only supplies the previous angle
+      if (glw >= 1) reinterpret_cast<short *>(orow)[glw] = (short)(prev - phi);   // group 0 only supplies the previous angle
     }
     K1_STAMP(5);
 #ifdef K1_STAMPS
     st_tiles++;
 #endif
-    u = nu; c = nc; g = ng; tile = ntile; tile_end = ntile_end;
+    u = nu; c = nc; g = ng; tile = ntile; tend = ntend; srcb = nsrcb; outb = noutb;
   };
   while (u < a.U) {
     slice(std::integral_constant<int, 0>{});
