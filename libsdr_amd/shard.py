@@ -33,11 +33,17 @@ def broadcast_design(tensors, src=0):
     return tensors
 
 
-def gather_output(local, total_channels, dst=0, async_op=False):
+def gather_output(local, total_channels, dst=0, out=None):
     """Gathers per-rank output rows [channels_local, n] onto `dst` as [total_channels, n] (row order =
-    global channel order). Ranks may own different numbers of channels. Returns (tensor_or_None, work)."""
+    global channel order). Ranks may own different numbers of channels. `out` (on `dst`): a preallocated
+    [total_channels, n] tensor the rows land in. Returns (tensor_or_None, None). This is the blocking form (tests, gloo
+    dry runs); bench.py's RCCL path issues `dist.gather(..., async_op=True)` on a side stream straight into row views
+    of its preallocated tensor."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     if world == 1:
+        if out is not None:
+            out.copy_(local)
+            return out, None
         return local, None
     rank = dist.get_rank()
     dtype = local.dtype
@@ -49,9 +55,11 @@ def gather_output(local, total_channels, dst=0, async_op=False):
     sizes = [shard_range(total_channels, world, r) for r in range(world)]
     if rank == dst:
         parts = [torch.empty((hi - lo,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device) for lo, hi in sizes]
-        work = dist.gather(local, parts, dst=dst, async_op=async_op)
-        if async_op:
-            return parts, work
-        return torch.cat(parts, 0).view(dtype).to(dev), None
-    work = dist.gather(local, None, dst=dst, async_op=async_op)
-    return None, work
+        dist.gather(local, parts, dst=dst)
+        full = torch.cat(parts, 0).view(dtype)
+        if out is not None:
+            out.copy_(full.to(out.device))
+            return out, None
+        return full.to(dev), None
+    dist.gather(local, None, dst=dst)
+    return None, None

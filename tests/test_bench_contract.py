@@ -85,10 +85,41 @@ def test_two_ranks_through_hip_nodes_match_single_process(tmp_path, workload):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("workload", ["iqbb_fm_cu8", "bb_real_fm", "fir255_fm", "fbb_f32", "fftconv", "fftbank", "fm_demod", "subsample8"])
-def test_every_other_workload_emits_its_line(workload):
-    """The `--workload` options beside the headline (the other BASELINE configurations and the stand-alone kernels): each
-    runs on a small batch and prints one JSON line whose roofline names the kernel it timed."""
-    d = _bench(["--workload", workload, "--channels", "16", "--samples", "24576", "--steps", "2", "--warmup", "1",
-                "--no-cpu-baseline", "--sustain-seconds", "0"])
+@pytest.mark.parametrize("workload", ["iqbb_fm", "iqbb_usb", "iqbb_fm_cu8", "bb_real_fm", "fir255_fm", "fbb_f32", "fftconv", "fftbank", "fm_demod", "subsample8"])
+def test_every_workload_emits_its_line_and_verifies(workload):
+    """Every `--workload` (the BASELINE configurations and the stand-alone kernels) runs on a small batch, prints one JSON
+    line whose roofline names the kernel it timed, and the LAST timed step's output of the sampled channels equals the
+    CPU oracle's (bit-exact for int16, <= 1e-5 for float / FFT): `verified` ties the number to the work."""
+    d = _bench(["--workload", workload, "--channels", "16", "--samples", "32768", "--steps", "3", "--warmup", "2",
+                "--no-cpu-baseline", "--sustain-seconds", "0", "--verify-channels", "4"])
     assert d["value"] > 0 and d["config"]["workload"] and d["roofline"]["kernel"] and 0 < d["roofline"]["frac"] < 1
+    assert d["verified"] is True, d.get("verify")
+    assert d["config"]["workload_key"].startswith(workload)
+    assert "value_sustained" not in d   # (no sustained pass was asked for)
+
+
+@pytest.mark.gpu
+def test_short_timed_region_reports_the_sustained_value():
+    d = _bench(["--channels", "64", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--sustain-seconds", "0.3", "--verify-channels", "2"])
+    assert d["verified"] is True and d["value_sustained"] > 0 and d["roofline"]["sustained_frac"] > 0
+
+
+@pytest.mark.gpu
+def test_config2_single_channel_latency_line():
+    """BASELINE config 2 as SURVEY §8d states it: one complex<float> channel, per-buffer latency beside Msamples/s."""
+    d = _bench(["--workload", "fbb_f32", "--channels", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--sustain-seconds", "0"])
+    assert d["verified"] is True and d["roofline"]["per_buffer_us"] > 0 and d["roofline"]["real_time_factor"] > 1
+
+
+def test_traffic_is_keyed_by_workload(tmp_path, monkeypatch):
+    """A PMC profile only counts for the workload it was cut on (a kernel name is shared by many workloads)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    (prof / "r99_pmc.json").write_text(json.dumps({"_meta": {"workload_key": "iqbb_fm/order127/d8/C1024/N65536"},
+                                                   "iqbb_hot_kernel": {"derived": {"hbm_traffic_bytes_per_launch": 3.0e8}}}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.measured_traffic("iqbb_fm/order127/d8/C1024/N65536", ["iqbb_hot_kernel"])["bytes"] == 3.0e8
+    assert bench.measured_traffic("iqbb_fm_cu8/order127/d8/C1024/N65536", ["iqbb_hot_kernel"]) is None
+    assert bench.measured_traffic("iqbb_fm/order127/d8/C1024/N65536", ["iqbb_hot_kernel", "other_kernel"]) is None

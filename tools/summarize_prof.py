@@ -42,7 +42,19 @@ for k, cs in pmc.items():
         out[k]["derived"] = {"hbm_read_bytes_per_launch": 2.0 * f, "hbm_write_bytes_per_launch": w,
                              "hbm_traffic_bytes_per_launch": 2.0 * f + w,
                              "note": "FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request), WRITE_SIZE as read; KiB units"}
+# which workload the passes ran: bench.py's own JSON line in the kernel-trace pass (bench.py's measured_traffic() only
+# accepts a profile for the workload it was cut on)
+meta = {}
+try:
+    for line in open(os.path.join(src, "trace.log")):
+        if line.startswith("{"):
+            d = json.loads(line)
+            meta = {"workload_key": d["config"].get("workload_key"), "workload": d["config"]["workload"],
+                    "kernels_per_step": d["roofline"].get("kernels_per_step"), "verified": d.get("verified")}
+except Exception as e:
+    meta = {"error": str(e)[:100]}
+out["_meta"] = meta
 json.dump(out, open(os.path.join("profiles", tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
 for r in rows[:6]:
     print(r[:4])
-print(json.dumps({k: v.get("derived") for k, v in out.items()}, indent=1))
+print(json.dumps({k: v.get("derived") for k, v in out.items() if k != "_meta"}, indent=1), meta)
