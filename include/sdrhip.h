@@ -141,10 +141,13 @@ int sdrhip_iqbb_i16_create(sdrhip_ctx *ctx, const int32_t *taps, int order, cons
  * SDRHIP_IQBB_PATH=valu|mfma|mfma16|mfmag states a preference at create time (tests, tuning). */
 int sdrhip_iqbb_i16_path(sdrhip_iqbb_i16 *h, int *path);
 /* Names of the kernels a call of this plan launches, dominant one first, comma separated (measurement aid: what to
- * look for in a rocprofv3 kernel trace). Path 1 with complex<int16> input is two launches: "iqbb_i16_hot_kernel"
- * (persistent grid; every wave slice that touches no border of the call) and "iqbb_i16_mfma_dma_kernel" (one
- * workgroup per channel: the call's first and last slices, state, history roll). SDRHIP_IQBB_HOT=0 /
- * SDRHIP_IQBB_DMA=0 at create time fall back to the single general launch (tests, tuning). */
+ * look for in a rocprofv3 kernel trace). Path 1 (decim 8, order <= 257, complex<int16> or complex<uint8> input) runs
+ * ONE launch per call, "iqbb_hot_kernel": a persistent grid over the wave slices that touch no border of the call,
+ * whose workgroups finish with the call's first and last slices, the state and the history roll (calls of fewer than
+ * 3 tiles, about 6000 samples, run the general kernel "iqbb_i16_mfma_dma_kernel" / "iqbb_i16_mfma_kernel" instead).
+ * Tuning / test variables read at create time: SDRHIP_IQBB_HOT=0 (general kernels only), SDRHIP_IQBB_DMA=0 (round 1's
+ * register-staged general kernel); read per call: SDRHIP_IQBB_TPW (tiles per work unit), SDRHIP_IQBB_WGPCU (workgroups
+ * per CU of the persistent grid). None changes results. */
 int sdrhip_iqbb_i16_kernel_names(sdrhip_iqbb_i16 *h, char *buf, size_t len);
 /* outputs the next call of n_in samples will produce (does not advance the state) */
 int sdrhip_iqbb_i16_out_count(sdrhip_iqbb_i16 *h, size_t n_in, size_t *n_out);
@@ -319,7 +322,10 @@ int sdrhip_fbb_f32_destroy(sdrhip_fbb_f32 *h);
  * time) and one gather of the demodulated output per step. `devices[r]` is the HIP device of rank r. Collectives
  * are RCCL over xGMI (librccl is opened with dlopen at the first create that needs it) when the ranks sit on
  * distinct devices; ranks that all share one device (single-GPU boxes: tests) use device-to-device copies on that
- * device instead — RCCL refuses two ranks on one device. Every call is asynchronous on the ranks' streams. */
+ * device instead — RCCL refuses two ranks on one device. Every call is asynchronous on the ranks' streams and ordered
+ * on them in both directions under either transport: work enqueued afterwards on any rank's stream (the next step
+ * overwriting a send buffer, the root reusing its broadcast buffer) runs after the transfer has read what it needs —
+ * no sdrhip_comm_synchronize is required between steps (tests/cpp/test_gpu_nodes.cc: three pipelined gathers). */
 typedef struct sdrhip_comm sdrhip_comm;
 int sdrhip_comm_create(const int *devices, int nranks, sdrhip_comm **out);
 int sdrhip_comm_size(sdrhip_comm *c, int *nranks);

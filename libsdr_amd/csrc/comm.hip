@@ -37,17 +37,19 @@ struct RcclApi {
 
 RcclApi &rccl() {
   static RcclApi api;
-  if (api.lib) return api;
+  if (api.lib) return api;   // (set last: only once every symbol below has been found)
+  RcclApi a;
   const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  for (const char *n : names) { api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (api.lib) break; }
-  SDRHIP_REQUIRE(api.lib, SDRHIP_E_UNSUPPORTED, "RCCL (librccl.so.1) can not be loaded: %s", dlerror());
+  for (const char *n : names) { a.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (a.lib) break; }
+  SDRHIP_REQUIRE(a.lib, SDRHIP_E_UNSUPPORTED, "RCCL (librccl.so.1) can not be loaded: %s", dlerror());
 #define SDRHIP_SYM(field, sym)                                                                  \
-  api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.lib, #sym));                       \
-  SDRHIP_REQUIRE(api.field, SDRHIP_E_UNSUPPORTED, "librccl lacks %s", #sym)
+  a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.lib, #sym));                             \
+  if (!a.field) { dlclose(a.lib); SDRHIP_FAIL(SDRHIP_E_UNSUPPORTED, "librccl lacks %s", #sym); }
   SDRHIP_SYM(CommInitAll, ncclCommInitAll); SDRHIP_SYM(CommDestroy, ncclCommDestroy); SDRHIP_SYM(Broadcast, ncclBroadcast);
   SDRHIP_SYM(Send, ncclSend); SDRHIP_SYM(Recv, ncclRecv); SDRHIP_SYM(GroupStart, ncclGroupStart);
   SDRHIP_SYM(GroupEnd, ncclGroupEnd); SDRHIP_SYM(GetErrorString, ncclGetErrorString);
 #undef SDRHIP_SYM
+  api = a;
   return api;
 }
 
@@ -63,7 +65,8 @@ struct sdrhip_comm {
   std::vector<int> devices;
   std::vector<sdrhip_ctx *> ctx;        // one per rank (its own stream on its device)
   std::vector<ncclComm_t> nccl;         // empty when the ranks share devices
-  std::vector<hipEvent_t> ev;           // same-device transport: one event per rank
+  std::vector<hipEvent_t> ev;           // same-device transport: one event per rank (its stream has produced / consumed a buffer)
+  std::vector<hipEvent_t> ev2;          // ... and one more per rank for the opposite direction of the same call
   bool use_rccl = false;
 };
 
@@ -94,8 +97,12 @@ int sdrhip_comm_create(const int *devices, int nranks, sdrhip_comm **out) {
       } else {
         SDRHIP_REQUIRE(distinct.size() == 1, SDRHIP_E_UNSUPPORTED,
                        "ranks must sit on distinct devices (RCCL) or all on one device (same-device copies)");
-        c->ev.resize(nranks);
-        for (int r = 0; r < nranks; r++) { c->ctx[r]->use(); SDRHIP_CHECK_HIP(hipEventCreateWithFlags(&c->ev[r], hipEventDisableTiming)); }
+        c->ev.resize(nranks); c->ev2.resize(nranks);
+        for (int r = 0; r < nranks; r++) {
+          c->ctx[r]->use();
+          SDRHIP_CHECK_HIP(hipEventCreateWithFlags(&c->ev[r], hipEventDisableTiming));
+          SDRHIP_CHECK_HIP(hipEventCreateWithFlags(&c->ev2[r], hipEventDisableTiming));
+        }
       }
     } catch (...) {
       for (sdrhip_ctx *x : c->ctx) (void)sdrhip_ctx_destroy(x);
@@ -140,13 +147,17 @@ int sdrhip_comm_broadcast(sdrhip_comm *c, void *const *bufs_dev, size_t bytes, i
       for (int r = 0; r < n; r++)
         SDRHIP_CHECK_NCCL(rccl().Broadcast(bufs_dev[root], bufs_dev[r], bytes, ncclUint8, root, c->nccl[r], c->ctx[r]->stream));
       SDRHIP_CHECK_NCCL(rccl().GroupEnd());
-    } else {   // every rank copies from the root's buffer once the root's stream has produced it
+    } else {   // every rank copies from the root's buffer once the root's stream has produced it ...
       c->ctx[root]->use();
       SDRHIP_CHECK_HIP(hipEventRecord(c->ev[root], c->ctx[root]->stream));
       for (int r = 0; r < n; r++) {
         if (r == root || bufs_dev[r] == bufs_dev[root]) continue;
         SDRHIP_CHECK_HIP(hipStreamWaitEvent(c->ctx[r]->stream, c->ev[root], 0));
         SDRHIP_CHECK_HIP(hipMemcpyAsync(bufs_dev[r], bufs_dev[root], bytes, hipMemcpyDeviceToDevice, c->ctx[r]->stream));
+        // ... and the root's stream may not overwrite its buffer before every copy has read it (the call is
+        // asynchronous like the RCCL transport's: whatever the caller enqueues next on any rank's stream is ordered)
+        SDRHIP_CHECK_HIP(hipEventRecord(c->ev2[r], c->ctx[r]->stream));
+        SDRHIP_CHECK_HIP(hipStreamWaitEvent(c->ctx[root]->stream, c->ev2[r], 0));
       }
     }
   });
@@ -160,15 +171,21 @@ int sdrhip_comm_gather(sdrhip_comm *c, const void *const *send_dev, const size_t
     std::vector<size_t> off(n + 1, 0);
     for (int r = 0; r < n; r++) { SDRHIP_REQUIRE(!bytes[r] || send_dev[r], SDRHIP_E_INVALID, "rank %d: NULL buffer", r); off[r + 1] = off[r] + bytes[r]; }
     char *dst = static_cast<char *>(recv_dev);
-    if (c->use_rccl) {   // grouped point-to-point: every rank sends its block, the root posts one receive per rank
-      SDRHIP_CHECK_NCCL(rccl().GroupStart());
-      for (int r = 0; r < n; r++) {
-        if (!bytes[r]) continue;
-        SDRHIP_CHECK_NCCL(rccl().Send(send_dev[r], bytes[r], ncclUint8, root, c->nccl[r], c->ctx[r]->stream));
-        SDRHIP_CHECK_NCCL(rccl().Recv(dst + off[r], bytes[r], ncclUint8, r, c->nccl[root], c->ctx[root]->stream));
+    if (c->use_rccl) {   // grouped point-to-point: every other rank sends its block, the root posts one receive per rank
+      c->ctx[root]->use();   // (the root's own block is a copy on its stream: no self send/recv inside the group)
+      if (bytes[root]) SDRHIP_CHECK_HIP(hipMemcpyAsync(dst + off[root], send_dev[root], bytes[root], hipMemcpyDeviceToDevice, c->ctx[root]->stream));
+      bool any = false;
+      for (int r = 0; r < n; r++) any = any || (r != root && bytes[r]);
+      if (any) {
+        SDRHIP_CHECK_NCCL(rccl().GroupStart());
+        for (int r = 0; r < n; r++) {
+          if (r == root || !bytes[r]) continue;
+          SDRHIP_CHECK_NCCL(rccl().Send(send_dev[r], bytes[r], ncclUint8, root, c->nccl[r], c->ctx[r]->stream));
+          SDRHIP_CHECK_NCCL(rccl().Recv(dst + off[r], bytes[r], ncclUint8, r, c->nccl[root], c->ctx[root]->stream));
+        }
+        SDRHIP_CHECK_NCCL(rccl().GroupEnd());
       }
-      SDRHIP_CHECK_NCCL(rccl().GroupEnd());
-    } else {   // the root's stream copies each block once the owning rank's stream has produced it
+    } else {   // the root's stream copies each block once the owning rank's stream has produced it ...
       for (int r = 0; r < n; r++) {
         if (!bytes[r]) continue;
         c->ctx[r]->use();
@@ -178,6 +195,13 @@ int sdrhip_comm_gather(sdrhip_comm *c, const void *const *send_dev, const size_t
         }
         SDRHIP_CHECK_HIP(hipMemcpyAsync(dst + off[r], send_dev[r], bytes[r], hipMemcpyDeviceToDevice, c->ctx[root]->stream));
       }
+      // ... and no rank's stream may overwrite its send buffer before the root has copied it: with RCCL the send sits on
+      // the owning rank's stream; here every rank's stream waits for the root's copies (a caller that enqueues step
+      // k + 1 without sdrhip_comm_synchronize would otherwise race the copy of step k)
+      c->ctx[root]->use();
+      SDRHIP_CHECK_HIP(hipEventRecord(c->ev2[root], c->ctx[root]->stream));
+      for (int r = 0; r < n; r++)
+        if (r != root && bytes[r]) SDRHIP_CHECK_HIP(hipStreamWaitEvent(c->ctx[r]->stream, c->ev2[root], 0));
     }
   });
 }
@@ -194,7 +218,7 @@ int sdrhip_comm_destroy(sdrhip_comm *c) {
     if (!c) return;
     for (sdrhip_ctx *x : c->ctx) { x->use(); (void)hipStreamSynchronize(x->stream); }
     if (c->use_rccl) for (ncclComm_t k : c->nccl) if (k) (void)rccl().CommDestroy(k);
-    for (size_t r = 0; r < c->ev.size(); r++) { c->ctx[r]->use(); (void)hipEventDestroy(c->ev[r]); }
+    for (size_t r = 0; r < c->ev.size(); r++) { c->ctx[r]->use(); (void)hipEventDestroy(c->ev[r]); (void)hipEventDestroy(c->ev2[r]); }
     for (sdrhip_ctx *x : c->ctx) (void)sdrhip_ctx_destroy(x);
     delete c;
   });

@@ -250,6 +250,53 @@ static void testCommCalls() {
   }
 }
 
+// Pipelined use without sdrhip_comm_synchronize between the steps (sdrhip.h documents the comm calls as asynchronous):
+// step k + 1 overwrites every rank's send buffer right after gather k was enqueued, twice over; each gather must still
+// deliver the values of ITS step. Same-device transport (2 ranks on device 0) and, where the box has two devices, RCCL
+// between device 0 and device 1 — the first time ncclSend/ncclRecv move bytes between two GPUs from this side.
+static void testCommPipelinedAndTwoDevices() {
+  int ndev = 0; sdrhip_device_count(&ndev);
+  for (int two = 0; two < 2; two++) {
+    if (two && ndev < 2) { std::printf("  (one device: the two-device RCCL case is skipped)\n"); continue; }
+    int devs[2] = {0, two ? 1 : 0};
+    sdrhip_comm *cm = 0;
+    CHECK(sdrhip_comm_create(devs, 2, &cm) == SDRHIP_OK);
+    if (!cm) { std::printf("  comm_create: %s\n", sdrhip_last_error()); continue; }
+    const char *tr = ""; sdrhip_comm_transport(cm, &tr);
+    CHECK(std::string(tr) == (two ? "rccl" : "same-device copies"));
+    const size_t n = 1 << 20;   // 4 MiB per rank and step: long enough for a copy to still run when the next step starts
+    sdrhip_ctx *ctx[2]; void *snd[2], *all[3], *des[2];
+    for (int r = 0; r < 2; r++) { sdrhip_comm_ctx(cm, r, &ctx[r]); sdrhip_malloc(ctx[r], n * 4, &snd[r]); sdrhip_malloc(ctx[r], 4096, &des[r]); }
+    for (int k = 0; k < 3; k++) sdrhip_malloc(ctx[0], 2 * n * 4, &all[k]);
+    std::vector<uint32_t> design(1024); for (size_t i = 0; i < design.size(); i++) design[i] = uint32_t(i * 40503u + 7u);
+    sdrhip_memcpy_h2d(ctx[0], des[0], design.data(), 4096); sdrhip_memset(ctx[1], des[1], 0, 4096);
+    void *dd[2] = {des[0], des[1]};
+    CHECK(sdrhip_comm_broadcast(cm, dd, 4096, 0) == SDRHIP_OK);
+    sdrhip_memset(ctx[0], des[0], 0x55, 4096);   // the root reuses its buffer at once: the broadcast must have read it first
+    const size_t bytes[2] = {n * 4, n * 4};
+    const void *send[2] = {snd[0], snd[1]};
+    for (int k = 0; k < 3; k++) {   // step k: every rank fills its buffer with the byte 0x10 * (k + 1) + rank, then the gather
+      for (int r = 0; r < 2; r++) sdrhip_memset(ctx[r], snd[r], 0x10 * (k + 1) + r, n * 4);
+      CHECK(sdrhip_comm_gather(cm, send, bytes, all[k], 0) == SDRHIP_OK);
+    }
+    CHECK(sdrhip_comm_synchronize(cm) == SDRHIP_OK);
+    std::vector<uint32_t> got(1024);
+    sdrhip_memcpy_d2h(ctx[1], got.data(), des[1], 4096);
+    CHECK(got == design);
+    std::vector<uint8_t> g(2 * n * 4);
+    for (int k = 0; k < 3; k++) {
+      sdrhip_memcpy_d2h(ctx[0], g.data(), all[k], g.size());
+      bool ok = true;
+      for (int r = 0; r < 2; r++) for (size_t i = 0; i < n * 4; i += 4093) ok = ok && g[r * n * 4 + i] == uint8_t(0x10 * (k + 1) + r);
+      ok = ok && g[n * 4 - 1] == uint8_t(0x10 * (k + 1)) && g[2 * n * 4 - 1] == uint8_t(0x10 * (k + 1) + 1);
+      CHECK(ok);
+    }
+    for (int r = 0; r < 2; r++) { sdrhip_free(ctx[r], snd[r]); sdrhip_free(ctx[r], des[r]); }
+    for (int k = 0; k < 3; k++) sdrhip_free(ctx[0], all[k]);
+    CHECK(sdrhip_comm_destroy(cm) == SDRHIP_OK);
+  }
+}
+
 // float nodes: FIRLowPass<cf32> -> SubSample<cf32>(8) and the FFT filter bank vs direct convolution
 static void testFloatNodes() {
   const size_t N = 4096;
@@ -443,6 +490,7 @@ int main(int argc, char **argv) {
     testChannelBankDropsWhileOutputInUse();
     testChannelBankMultiRank();
     testCommCalls();
+    testCommPipelinedAndTwoDevices();
     testFloatNodes();
     testSdrFmChainCu8();
     testRealBaseBand();
