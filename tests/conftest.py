@@ -17,6 +17,7 @@ _DT = {"u8": np.uint8, "i8": np.int8, "i16": np.int16, "cs16": np.int16, "i32": 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "hostptr_only: keep this GPU test out of the red-zoned arena (it exercises the host-pointer path itself)")
 
 
 class Golden:
@@ -48,3 +49,29 @@ def orc():
     from oracle import pyoracle
     pyoracle.lib()
     return pyoracle
+
+
+@pytest.fixture(autouse=True)
+def redzone(request):
+    """GPU parity and fuzz tests run every node call inside a red-zoned device arena (libsdr_amd.nodes.RedZone: guard
+    bands before / between / after the rows of the input and output buffers, checked after every call). The parity
+    module runs twice: through the arena (device-pointer entry points, strided rows) and through the host-pointer entry
+    points (the library's own staging) — mark a test `hostptr_only` to keep it out of the arena."""
+    mod = request.node.module.__name__ if request.node.module else ""
+    gpu = request.node.get_closest_marker("gpu") is not None
+    if not gpu or not any(k in mod for k in ("test_gpu_parity", "test_gpu_fuzz")):
+        yield None
+        return
+    mode = getattr(request, "param", "redzone")
+    from libsdr_amd import nodes
+    nodes.RedZone.active = mode == "redzone" and request.node.get_closest_marker("hostptr_only") is None
+    try:
+        yield mode
+    finally:
+        nodes.RedZone.active = False
+
+
+def pytest_generate_tests(metafunc):
+    # the parity module: every test in both modes (the fuzz module: arena only)
+    if "redzone" in metafunc.fixturenames and metafunc.module.__name__.endswith("test_gpu_parity"):
+        metafunc.parametrize("redzone", ["redzone", "hostptr"], indirect=True)

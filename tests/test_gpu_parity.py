@@ -1105,3 +1105,26 @@ def test_fm_angle_every_int16_pair(ctx):
         got = y[1::2].to(torch.int64)
         bad = (got != -phi).nonzero()
         assert bad.numel() == 0, (a0, int(a[bad[0, 0]]), int(b[bad[0, 0]]), int(got[bad[0, 0]]), int(-phi[bad[0, 0]]))
+
+
+# ---- the red-zoned arena itself (tests/conftest.py `redzone`, libsdr_amd.nodes.RedZone) ------------------------------
+
+def test_redzone_arena_is_live_and_catches_stray_writes(ctx, golden, redzone):
+    from libsdr_amd.nodes import RedZone
+    m, node = iqbb_from_case(ctx, golden, "g3_iqbb127d8", "_out", sa.EPI_NONE)
+    before = RedZone.calls
+    node.process(golden.load("g1_iq_cs16")[:4096])
+    assert RedZone.active == (redzone == "redzone") and RedZone.calls == before + (1 if redzone == "redzone" else 0)
+    x, out = np.zeros((2, 64, 2), np.int16), np.zeros((2, 8), np.int16)
+    eb = 2
+    # one element past the end of row 0, one before row 0, one past the last row, and a write into the input arena
+    for where in ("after_row0", "before_row0", "after_last", "input"):
+        def stray(i, si, o, so, where=where):
+            if where == "input":
+                ctx.memset(i + 3 * 4, 0x11, 4)
+            else:
+                off = {"after_row0": 8 * eb, "before_row0": -eb, "after_last": (so + 8) * eb}[where]
+                ctx.memset(o + off, 0x11, eb)
+        with pytest.raises(AssertionError, match="red zone"):
+            RedZone.run(ctx, x, out, stray)
+    RedZone.run(ctx, x, out, lambda i, si, o, so: ctx.memset(o, 0, 8 * eb))   # writing the rows themselves is fine
