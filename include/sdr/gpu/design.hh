@@ -3,7 +3,7 @@
 // The kernels never design anything on the device: a 1-ulp libm difference may flip a truncation
 // (SURVEY §7 "Tap / LUT / kernel provenance"), so the numbers are produced here, on the host, with
 // the same operation order as the reference designers, and pinned against golden vectors
-// (tests/test_design.py).  Reference formulas restated (file:line):
+// (tests/test_abi.py; tests/cpp/test_gpu_nodes.cc --host-only).  Reference formulas restated (file:line):
 //   IQBaseBand::_update_filter_kernel   src/baseband.hh:239-262  (Ff, Fs, width held as int32: :266-272)
 //   BaseBand::_update_filter_kernel     src/baseband.hh:464-491  (real-input node, Q16)
 //   FreqShiftBase ctor / _update_lut_incr   src/freqshift.hh:26-36, :78-87

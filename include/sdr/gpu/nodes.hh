@@ -195,7 +195,12 @@ protected:
       }
     }
     if (!reuse) {
-      if (_plan) { sdrhip_iqbb_i16_destroy(_plan); _plan = 0; }
+      if (_plan) {   // (the reference keeps its ring through any _reconfigure; a new device plan starts from zeros: INTEGRATION.md)
+        LogMessage warn(LOG_WARNING);
+        warn << "gpu::IQBaseBand: order / decimation / buffer size / demodulator changed: new device plan, filter history is reset";
+        Logger::get().log(warn);
+        sdrhip_iqbb_i16_destroy(_plan); _plan = 0;
+      }
       if (kInt8) configCheck(sdrhip_iqbb_i8_create(Device::get(_device), taps.data(), int(_order), lut.data(), inc, 0 > _shift,
                                                    int(D), 1, _sourceBs, _epilogue, &_plan), "IQBaseBand");
       else configCheck(sdrhip_iqbb_i16_create(Device::get(_device), taps.data(), int(_order), lut.data(), inc, 0 > _shift,
@@ -274,6 +279,103 @@ public:
     : detail::IQBB16<uint8_t>(Fc, width, order, sub_sample, oFs, device) {}
   IQBaseBand(double Fc, double Ff, double width, size_t order, size_t sub_sample, double oFs = 0.0, int device = 0)
     : detail::IQBB16<uint8_t>(Fc, Ff, width, order, sub_sample, oFs, device) {}
+};
+
+/** IQBaseBand<float> — BASELINE config 2's node. The reference has NO working float baseband (IQBaseBand<float> does not
+ * compile: its compute type is hard-wired to int32, src/baseband.hh:28-31,205; FreqShift<float> truncates every sample to
+ * int16), so this node is BUILD-DEFINED behind the reference's constructor signatures
+ * (src/baseband.hh:33-37) and its config / ownership / drop rules (:115-151):
+ *     y = SubSample_D( FIRLowPass_cf32( x[n] * exp(-2*pi*i*Fc*n/Fs) ) ),   low-pass cut-off = width / 2
+ * — the band of `width` Hz around Fc moved to 0 Hz, filtered with FIRLowPassCoeffs (src/firfilter.hh:16-32: the
+ * reference's own cf32 arithmetic, pinned) and box-averaged like SubSample<complex<float>> (src/subsample.hh:92-101:
+ * pinned); the phasor is the float64 closed form of the absolute sample index (parity unpinned by necessity, checked
+ * against that closed form, <= 1e-5). A filter frequency other than Fc would need complex taps this definition does not
+ * have: it is refused with a ConfigError rather than silently filtered around the wrong centre. D = Fs / oFs when an
+ * output rate is given, as the reference node (:159-162). Never in place (the output is D times shorter and the node
+ * owns it); the input is dropped while the output buffer is still referenced downstream (:141-150). */
+template <>
+class IQBaseBand<float> : public Sink<cf32>, public Source {
+public:
+  IQBaseBand(double Fc, double width, size_t order, size_t sub_sample, double oFs = 0.0, int device = 0)
+    : _Fc(Fc), _Ff(Fc), _width(width), _Fs(0), _order(std::max(size_t(1), order)), _sub_sample(std::max(size_t(1), sub_sample)),
+      _oFs(oFs), _sourceBs(0), _device(device), _plan(0) {}
+  IQBaseBand(double Fc, double Ff, double width, size_t order, size_t sub_sample, double oFs = 0.0, int device = 0)
+    : _Fc(Fc), _Ff(Ff), _width(width), _Fs(0), _order(std::max(size_t(1), order)), _sub_sample(std::max(size_t(1), sub_sample)),
+      _oFs(oFs), _sourceBs(0), _device(device), _plan(0) {}
+  virtual ~IQBaseBand() {
+    if (_plan) sdrhip_fbb_f32_destroy(_plan);
+    _buffer.unref();
+  }
+  inline size_t order() const { return _order; }
+  void setOrder(size_t o) { _order = std::max(size_t(1), o); if (_Fs) _reconfigure(); }
+  inline double centerFrequency() const { return _Fc; }
+  /** (a new plan: the phasor, the filter history and the decimator restart — the float node keeps no LUT phase to carry) */
+  void setCenterFrequency(double Fc) { _Fc = Fc; _Ff = Fc; if (_Fs) _reconfigure(); }
+  inline double filterFrequency() const { return _Ff; }
+  void setFilterFrequency(double Ff) { _Ff = Ff; if (_Fs) _reconfigure(); }
+  inline double filterWidth() const { return _width; }
+  void setFilterWidth(double width) { _width = width; if (_Fs) _reconfigure(); }
+  size_t subSample() const { return _sub_sample; }
+  void setSubsample(size_t sub_sample) { _sub_sample = std::max(size_t(1), sub_sample); if (_Fs) _reconfigure(); }
+  void setOutputSampleRate(double Fs) { _oFs = Fs; if (_Fs) _reconfigure(); }
+
+  virtual void config(const Config &src_cfg) {
+    if (!src_cfg.hasType() || !src_cfg.hasSampleRate() || !src_cfg.hasBufferSize()) return;
+    if (Config::typeId<cf32>() != src_cfg.type()) {
+      ConfigError err;
+      err << "Can not configure IQBaseBand: Invalid type " << src_cfg.type() << ", expected " << Config::typeId<cf32>();
+      throw err;
+    }
+    _Fs = src_cfg.sampleRate();
+    _sourceBs = src_cfg.bufferSize();
+    _reconfigure();
+  }
+
+  virtual void process(const Buffer<cf32> &buffer, bool allow_overwrite) {
+    (void)allow_overwrite;
+    if (!_plan) return;
+    if (!_buffer.isUnused()) return;   // output still in use downstream: the input is dropped (src/baseband.hh:141-150)
+    size_t n = 0;
+    if (!detail::processOk(sdrhip_fbb_f32_process(_plan, reinterpret_cast<const float *>(buffer.data()), buffer.size(), 0,
+                                                  reinterpret_cast<float *>(_buffer.data()), _buffer.size(), &n), "gpu::IQBaseBand<float>"))
+      return;
+    this->send(_buffer.head(n), true);
+  }
+
+protected:
+  void _reconfigure() {
+    if (_Ff != _Fc) {
+      ConfigError err;
+      err << "Can not configure IQBaseBand<float>: filter frequency " << _Ff << "Hz differs from the center frequency " << _Fc
+          << "Hz (the build-defined float baseband low-pass filters the shifted band: sdr/gpu/nodes.hh)";
+      throw err;
+    }
+    const size_t D = design::iqbbDecimation(_Fs, _sub_sample, _oFs);
+    _sub_sample = D;
+    std::vector<double> alpha(_order);
+    design::firLowPass(_order, _width / 2, _Fs, alpha.data());
+    if (_plan) { sdrhip_fbb_f32_destroy(_plan); _plan = 0; }
+    detail::configCheck(sdrhip_fbb_f32_create(Device::get(_device), _Fc, _Fs, alpha.data(), int(_order), int(D), 1, _sourceBs, &_plan),
+                        "IQBaseBand<float>");
+    size_t buffer_size = _sourceBs / D + 1;   // (a call may emit one output more than Bs / D: the decimator's phase carries over)
+    _buffer.unref();
+    _buffer = Buffer<cf32>(buffer_size);
+    LogMessage msg(LOG_DEBUG);
+    msg << "Configured gpu::IQBaseBand<float> node:" << std::endl << " sample-rate " << _Fs << "Hz" << std::endl
+        << " center freq " << _Fc << "Hz" << std::endl << " width " << _width << "Hz" << std::endl
+        << " in buffer size " << _sourceBs << std::endl << " sub-sample by " << D << std::endl
+        << " out buffer size " << buffer_size;
+    Logger::get().log(msg);
+    this->setConfig(Config(Config::typeId<cf32>(), _Fs / double(D), buffer_size, 1));
+  }
+
+  double _Fc, _Ff, _width, _Fs;
+  size_t _order, _sub_sample;
+  double _oFs;
+  size_t _sourceBs;
+  int _device;
+  sdrhip_fbb_f32 *_plan;
+  Buffer<cf32> _buffer;
 };
 
 // =================================================================================================

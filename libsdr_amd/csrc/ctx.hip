@@ -1,6 +1,9 @@
 // ctx.hip — context, memory helpers, timers and error reporting of libsdrhip.so.
 #include "sdrhip_internal.hpp"
 
+#include <dlfcn.h>
+#include <cstdlib>
+
 namespace sdrhip {
 
 static thread_local char g_err[512] = "";
@@ -26,6 +29,39 @@ void copy_d2h_rows(const sdrhip_ctx *ctx, void *dst_host, size_t dst_pitch_b, co
                                     hipMemcpyDeviceToHost, ctx->stream));
   SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
 }
+
+namespace {
+struct Roctx {
+  int (*push)(const char *) = nullptr;
+  int (*pop)() = nullptr;
+  bool tried = false;
+};
+Roctx &roctx() {
+  static Roctx r;
+  if (!r.tried) {
+    r.tried = true;
+    const char *e = getenv("SDRHIP_ROCTX");
+    if (e && e[0] == '1') {
+      const char *names[] = {"librocprofiler-sdk-roctx.so.1", "libroctx64.so.4", "libroctx64.so"};
+      for (const char *n : names) {
+        void *lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (!lib) continue;
+        r.push = reinterpret_cast<int (*)(const char *)>(dlsym(lib, "roctxRangePushA"));
+        r.pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+        if (r.push && r.pop) break;
+        r.push = nullptr; r.pop = nullptr;
+      }
+    }
+  }
+  return r;
+}
+}  // namespace
+
+Range::Range(const char *name) : on(false) {
+  Roctx &r = roctx();
+  if (r.push) { r.push(name); on = true; }
+}
+Range::~Range() { if (on) roctx().pop(); }
 
 }  // namespace sdrhip
 

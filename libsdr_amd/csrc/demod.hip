@@ -385,6 +385,7 @@ int sdrhip_demod_create(sdrhip_ctx *ctx, int kind, int dtype, int channels, size
 int sdrhip_demod_process_dev(sdrhip_demod *h, const void *in_dev, size_t n, size_t in_stride, void *out_dev,
                              size_t out_stride) {
   return guarded([&] {
+    Range roctx_range("sdrhip_demod_process_dev");
     SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
     SDRHIP_REQUIRE(n <= h->max_in, SDRHIP_E_SIZE, "n %zu > max_in %zu", n, h->max_in);
     if (n == 0) return;
@@ -400,6 +401,7 @@ int sdrhip_demod_process_dev(sdrhip_demod *h, const void *in_dev, size_t n, size
 int sdrhip_demod_process(sdrhip_demod *h, const void *in_host, size_t n, size_t in_stride, void *out_host,
                          size_t out_stride) {
   return guarded([&] {
+    Range roctx_range("sdrhip_demod_process");
     SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
     SDRHIP_REQUIRE(n <= h->max_in, SDRHIP_E_SIZE, "n %zu > max_in %zu", n, h->max_in);
     if (n == 0) return;
@@ -457,6 +459,7 @@ int sdrhip_deemph_i16_create(sdrhip_ctx *ctx, int alpha, int channels, size_t ma
 int sdrhip_deemph_i16_process_dev(sdrhip_deemph *h, const int16_t *in_dev, size_t n, size_t in_stride, int16_t *out_dev,
                                   size_t out_stride) {
   return guarded([&] {
+    Range roctx_range("sdrhip_deemph_i16_process_dev");
     SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
     SDRHIP_REQUIRE(n <= h->max_in, SDRHIP_E_SIZE, "n %zu > max_in %zu", n, h->max_in);
     if (n == 0) return;
@@ -472,6 +475,7 @@ int sdrhip_deemph_i16_process_dev(sdrhip_deemph *h, const int16_t *in_dev, size_
 int sdrhip_deemph_i16_process(sdrhip_deemph *h, const int16_t *in_host, size_t n, size_t in_stride, int16_t *out_host,
                               size_t out_stride) {
   return guarded([&] {
+    Range roctx_range("sdrhip_deemph_i16_process");
     SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
     SDRHIP_REQUIRE(n <= h->max_in, SDRHIP_E_SIZE, "n %zu > max_in %zu", n, h->max_in);
     if (n == 0) return;
@@ -534,6 +538,7 @@ int sdrhip_subsample_out_count(sdrhip_subsample *h, size_t n_in, size_t *n_out) 
 int sdrhip_subsample_process_dev(sdrhip_subsample *h, const void *in_dev, size_t n_in, size_t in_stride,
                                  void *out_dev, size_t out_stride, size_t *n_out) {
   return guarded([&] {
+    Range roctx_range("sdrhip_subsample_process_dev");
     SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
     SDRHIP_REQUIRE(n_in <= h->max_in, SDRHIP_E_SIZE, "n_in %zu > max_in %zu", n_in, h->max_in);
     if (n_in == 0) { if (n_out) *n_out = 0; return; }
@@ -549,6 +554,7 @@ int sdrhip_subsample_process_dev(sdrhip_subsample *h, const void *in_dev, size_t
 int sdrhip_subsample_process(sdrhip_subsample *h, const void *in_host, size_t n_in, size_t in_stride,
                              void *out_host, size_t out_stride, size_t *n_out) {
   return guarded([&] {
+    Range roctx_range("sdrhip_subsample_process");
     SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
     SDRHIP_REQUIRE(n_in <= h->max_in, SDRHIP_E_SIZE, "n_in %zu > max_in %zu", n_in, h->max_in);
     if (n_in == 0) { if (n_out) *n_out = 0; return; }

@@ -52,6 +52,7 @@ int sdrhip_fbb_f32_out_count(sdrhip_fbb_f32 *h, size_t n_in, size_t *n_out) {
 int sdrhip_fbb_f32_process_dev(sdrhip_fbb_f32 *h, const float *in_dev, size_t n_in, size_t in_stride, float *out_dev,
                                size_t out_stride, size_t *n_out) {
   return guarded([&] {
+    Range roctx_range("sdrhip_fbb_f32_process_dev");
     SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
     SDRHIP_REQUIRE(n_in <= h->max_in, SDRHIP_E_SIZE, "n_in %zu > max_in %zu", n_in, h->max_in);
     if (n_in == 0) { if (n_out) *n_out = 0; return; }
@@ -67,6 +68,7 @@ int sdrhip_fbb_f32_process_dev(sdrhip_fbb_f32 *h, const float *in_dev, size_t n_
 int sdrhip_fbb_f32_process(sdrhip_fbb_f32 *h, const float *in_host, size_t n_in, size_t in_stride, float *out_host,
                            size_t out_stride, size_t *n_out) {
   return guarded([&] {
+    Range roctx_range("sdrhip_fbb_f32_process");
     SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
     SDRHIP_REQUIRE(n_in <= h->max_in, SDRHIP_E_SIZE, "n_in %zu > max_in %zu", n_in, h->max_in);
     if (n_in == 0) { if (n_out) *n_out = 0; return; }

@@ -854,6 +854,7 @@ int sdrhip_fftconv_set_kernel(sdrhip_fftconv *h, int band, const float *kernel) 
 int sdrhip_fftconv_process_dev(sdrhip_fftconv *h, const float *in_dev, size_t n_in, size_t in_stride,
                                float *out_dev, size_t out_stride) {
   return guarded([&] {
+    Range roctx_range("sdrhip_fftconv_process_dev");
     SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
     SDRHIP_REQUIRE(n_in <= h->max_in, SDRHIP_E_SIZE, "n_in %zu > max_in %zu", n_in, h->max_in);
     if (n_in == 0) return;
@@ -870,6 +871,7 @@ int sdrhip_fftconv_process_dev(sdrhip_fftconv *h, const float *in_dev, size_t n_
 int sdrhip_fftconv_process(sdrhip_fftconv *h, const float *in_host, size_t n_in, size_t in_stride, float *out_host,
                            size_t out_stride) {
   return guarded([&] {
+    Range roctx_range("sdrhip_fftconv_process");
     SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
     SDRHIP_REQUIRE(n_in <= h->max_in, SDRHIP_E_SIZE, "n_in %zu > max_in %zu", n_in, h->max_in);
     if (n_in == 0) return;

@@ -640,6 +640,7 @@ int sdrhip_fir_out_count(sdrhip_fir *h, size_t n_in, size_t *n_out) {
 int sdrhip_fir_process_dev(sdrhip_fir *h, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev,
                            size_t out_stride, size_t *n_out) {
   return guarded([&] {
+    Range roctx_range("sdrhip_fir_process_dev");
     SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
     SDRHIP_REQUIRE(n_in <= h->max_in, SDRHIP_E_SIZE, "n_in %zu > max_in %zu", n_in, h->max_in);
     if (n_in == 0) { if (n_out) *n_out = 0; return; }
@@ -659,6 +660,7 @@ int sdrhip_fir_process_dev(sdrhip_fir *h, const void *in_dev, size_t n_in, size_
 int sdrhip_fir_process(sdrhip_fir *h, const void *in_host, size_t n_in, size_t in_stride, void *out_host,
                        size_t out_stride, size_t *n_out) {
   return guarded([&] {
+    Range roctx_range("sdrhip_fir_process");
     SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
     SDRHIP_REQUIRE(n_in <= h->max_in, SDRHIP_E_SIZE, "n_in %zu > max_in %zu", n_in, h->max_in);
     if (n_in == 0) { if (n_out) *n_out = 0; return; }

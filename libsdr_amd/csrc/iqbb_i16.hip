@@ -1405,6 +1405,7 @@ int sdrhip_iqbb_i16_out_count(sdrhip_iqbb_i16 *h, size_t n_in, size_t *n_out) {
 int sdrhip_iqbb_i16_process_dev(sdrhip_iqbb_i16 *h, const int16_t *in_dev, size_t n_in, size_t in_stride,
                                 void *out_dev, size_t out_stride, size_t *n_out) {
   return guarded([&] {
+    Range roctx_range("sdrhip_iqbb_i16_process_dev");
     SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
     SDRHIP_REQUIRE(n_in <= h->max_in, SDRHIP_E_SIZE, "n_in %zu > max_in %zu", n_in, h->max_in);
     if (n_in == 0) { if (n_out) *n_out = 0; return; }
@@ -1421,6 +1422,7 @@ int sdrhip_iqbb_i16_process_dev(sdrhip_iqbb_i16 *h, const int16_t *in_dev, size_
 int sdrhip_iqbb_i16_process(sdrhip_iqbb_i16 *h, const int16_t *in_host, size_t n_in, size_t in_stride,
                             void *out_host, size_t out_stride, size_t *n_out) {
   return guarded([&] {
+    Range roctx_range("sdrhip_iqbb_i16_process");
     SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
     SDRHIP_REQUIRE(n_in <= h->max_in, SDRHIP_E_SIZE, "n_in %zu > max_in %zu", n_in, h->max_in);
     if (n_in == 0) { if (n_out) *n_out = 0; return; }

@@ -113,6 +113,16 @@ void copy_d2h_rows(const sdrhip_ctx *ctx, void *dst_host, size_t dst_pitch_b, co
 
 static inline size_t ceil_div(size_t a, size_t b) { return (a + b - 1) / b; }
 
+// roctx range around one process() call (SURVEY §5 tracing): with SDRHIP_ROCTX=1 in the environment every *_process /
+// *_process_dev entry point is bracketed by roctxRangePush / roctxRangePop, so that a `rocprofv3 --marker-trace` run
+// shows the node calls beside their kernels. libroctx64 is opened with dlopen the first time a range is asked for;
+// without the variable (or the library) a range costs one branch.
+struct Range {
+  explicit Range(const char *name);
+  ~Range();
+  bool on;
+};
+
 // *_process_dev contract (sdrhip.h): the kernels are tile-parallel (a workgroup reads neighbouring tiles' inputs and
 // the last one rolls the history from the input), so an output range that overlaps the input range would race
 // silently. rows x row_elems elements of elem bytes at a row stride of `stride` elements.

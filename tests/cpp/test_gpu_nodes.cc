@@ -445,6 +445,43 @@ static void testInt8Chain() {
 }
 
 // FFT::exec / FFTPlan<float|double> on host buffers against a direct O(n^2) DFT in long double
+// BASELINE config 2 through the node API: gpu::IQBaseBand<float> (build-defined: shift -> FIRLowPass<cf32>(order, width/2)
+// -> /D) against the oracle chain freqshift (float64 closed form) -> FIR cf32 -> SubSample, <= 1e-5; config / drop rules.
+static void testFloatBaseBandNode() {
+  const size_t N = 4096, NB = 3;
+  IQSigGen<float> gen(FS, N); gen.addSine(100e3, 0.5, 0.0); gen.addSine(-300e3, 0.3, 0.3);
+  gpu::IQBaseBand<float> bb(100e3, 100e3, 200e3, 127, 8);
+  Recorder<cf32> raw, out;
+  gen.connect(&raw, true); gen.connect(&bb, true); bb.connect(&out, true);
+  CHECK(bb.Source::sampleRate() == FS / 8 && bb.type() == Config::Type_cf32);
+  for (size_t b = 0; b < NB; b++) gen.next();
+  CHECK(out.data.size() == NB * N / 8);
+  std::vector<double> a(127); orc_fir_lowpass_design(127, 100e3, FS, a.data());
+  void *f = orc_fir_create(a.data(), 127); void *s = orc_subsample_create(8);
+  std::vector<float> sh(2 * NB * N), y(2 * NB * N), d(2 * NB * N / 8);
+  orc_freqshift_cf32((const float *)raw.data.data(), NB * N, 0, 100e3, FS, sh.data());
+  orc_fir_cf32_process(f, sh.data(), NB * N, y.data());
+  const size_t nd = orc_subsample_cf32_process(s, y.data(), NB * N, d.data());
+  orc_fir_destroy(f); orc_subsample_destroy(s);
+  CHECK(nd == out.data.size());
+  double err = 0, mx = 0;
+  for (size_t i = 0; i < std::min(nd, out.data.size()); i++) {
+    err = std::max(err, (double)std::abs(out.data[i] - cf32(d[2 * i], d[2 * i + 1]))); mx = std::max(mx, (double)std::abs(cf32(d[2 * i], d[2 * i + 1])));
+  }
+  CHECK(mx > 0.05 && err <= 1e-5 * mx);
+  // a filter that is not centred on the shift frequency is refused, a wrong input type too
+  bool threw = false;
+  try { gpu::IQBaseBand<float> off(100e3, 90e3, 50e3, 127, 8); off.config(Config(Config::Type_cf32, FS, N, 1)); } catch (ConfigError &) { threw = true; }
+  CHECK(threw);
+  threw = false;
+  try { gpu::IQBaseBand<float> t(100e3, 50e3, 127, 8); t.config(Config(Config::Type_cs16, FS, N, 1)); } catch (ConfigError &) { threw = true; }
+  CHECK(threw);
+  // output rate given instead of the decimation (src/baseband.hh:159-162): 2.4 MS/s -> 300 kS/s = /8
+  gpu::IQBaseBand<float> byrate(100e3, 200e3, 127, 1, 300e3);
+  byrate.config(Config(Config::Type_cf32, FS, N, 1));
+  CHECK(byrate.subSample() == 8 && byrate.Source::sampleRate() == 300e3);
+}
+
 template <class Scalar>
 static void testFftPlanOf(size_t n, double tol) {
   typedef std::complex<Scalar> CS;
@@ -479,7 +516,59 @@ static void testFftPlan() {
   CHECK(threw);   // sizes differ (the reference's check)
 }
 
+// The HOST half of the nodes (no device needed; tests/test_cpp.py builds this file with -fsanitize=address,undefined
+// and runs `--host-only` in the build container): the designers in design.hh against the golden taps / LUT / low-pass,
+// and the config() rules every node follows before it ever touches the device (reference src/baseband.hh:115-132,
+// src/firfilter.hh:172-207, src/demod.hh:195-226): silent return while the upstream Config is incomplete, ConfigError on
+// a type mismatch; with a complete Config either the plan is made (a GPU is present) or a ConfigError says that there
+// is no device and no CPU fallback — never a crash, and every node destructs cleanly either way.
+template <class Node> static void hostConfigRules(Node &n, Config::Type good, Config::Type bad, const char *what) {
+  n.config(Config());                                  // nothing known yet: silent
+  n.config(Config(good, 0, 0, 1));                     // type only: still silent
+  bool threw = false;
+  try { n.config(Config(bad, FS, 4096, 1)); } catch (ConfigError &) { threw = true; }
+  if (!threw) std::printf("  %s accepted a wrong input type\n", what);
+  CHECK(threw);
+  try { n.config(Config(good, FS, 4096, 1)); } catch (ConfigError &e) { (void)e; }   // no device here: a ConfigError, not a crash
+}
+static void testHostOnly() {
+  std::vector<int32_t> taps(254), lut(256);
+  gpu::design::iqbbTaps(100e3, 50e3, FS, 127, taps.data());
+  gpu::design::freqShiftLutI16(lut.data());
+  CHECK(taps == slurp<int32_t>("g3_iqbb127d8_taps.bin") && lut == slurp<int32_t>("g3_iqbb127d8_lut.bin"));
+  CHECK(gpu::design::freqShiftIncrement(100e3, FS) == 1365u && gpu::design::iqbbDecimation(FS, 8, 0.0) == 8);
+  CHECK(gpu::design::iqbbDecimation(2.4e6, 1, 8000.0) == 300);
+  for (int order : {127, 255, 4097}) {
+    std::vector<double> a(order);
+    gpu::design::firLowPass(order, 100e3, FS, a.data());
+    CHECK(a == slurp<double>("g2_firlp_alpha" + std::to_string(order) + ".bin"));
+  }
+  { gpu::IQBaseBand<int16_t> n(100e3, 100e3, 50e3, 127, 8); hostConfigRules(n, Config::Type_cs16, Config::Type_cf32, "IQBaseBand<int16_t>"); }
+  { gpu::IQBaseBand<float> n(100e3, 200e3, 127, 8); hostConfigRules(n, Config::Type_cf32, Config::Type_cs16, "IQBaseBand<float>"); }
+  { gpu::IQBaseBand<uint8_t> n(100e3, 100e3, 50e3, 21, 8); hostConfigRules(n, Config::Type_cu8, Config::Type_cs16, "IQBaseBand<uint8_t>"); }
+  { gpu::BaseBand<int16_t> n(100e3, 100e3, 50e3, 64, 8); hostConfigRules(n, Config::Type_s16, Config::Type_cs16, "BaseBand<int16_t>"); }
+  { gpu::FIRLowPass<cs16> n(127, 100e3); hostConfigRules(n, Config::Type_cs16, Config::Type_s16, "FIRLowPass<cs16>"); }
+  { gpu::FIRLowPass<cf32> n(127, 100e3); hostConfigRules(n, Config::Type_cf32, Config::Type_cs16, "FIRLowPass<cf32>"); }
+  { gpu::FMDemod<int16_t> n; hostConfigRules(n, Config::Type_cs16, Config::Type_cf32, "FMDemod<int16_t>"); }
+  { gpu::AMDemod<int16_t> n; hostConfigRules(n, Config::Type_cs16, Config::Type_cf32, "AMDemod<int16_t>"); }
+  { gpu::USBDemod<float> n; hostConfigRules(n, Config::Type_cf32, Config::Type_cs16, "USBDemod<float>"); }
+  { gpu::SubSample<cs16> n(size_t(8)); hostConfigRules(n, Config::Type_cs16, Config::Type_cf32, "SubSample<cs16>"); }
+  { gpu::FMDeemph<int16_t> n; hostConfigRules(n, Config::Type_s16, Config::Type_cs16, "FMDeemph<int16_t>"); }
+  {   // buffers and views as the nodes hand them on (ownership rules of src/buffer.hh:54-104)
+    Buffer<cs16> b(64); CHECK(b.isUnused());
+    Buffer<cs16> v = b.head(10); b.ref(); CHECK(!b.isUnused() && v.size() == 10); b.unref(); CHECK(b.isUnused());
+    b.unref();
+  }
+}
+
 int main(int argc, char **argv) {
+  if (argc > 1 && std::string(argv[1]) == "--host-only") {
+    if (argc > 2) g_golden = argv[2];
+    Logger::get().addHandler(new StreamLogHandler(std::cerr, LOG_WARNING));
+    try { testHostOnly(); } catch (std::exception &e) { std::printf("FAIL: exception: %s\n", e.what()); return 2; }
+    std::printf("%s (%d failures)\n", failures ? "FAILED" : "OK", failures);
+    return failures ? 1 : 0;
+  }
   if (argc > 1) g_golden = argv[1];
   Logger::get().addHandler(new StreamLogHandler(std::cerr, LOG_WARNING));
   try {
@@ -491,7 +580,9 @@ int main(int argc, char **argv) {
     testChannelBankMultiRank();
     testCommCalls();
     testCommPipelinedAndTwoDevices();
+    testHostOnly();
     testFloatNodes();
+    testFloatBaseBandNode();
     testSdrFmChainCu8();
     testRealBaseBand();
     testRetuneMidStream();

@@ -90,3 +90,13 @@ def test_no_oracle_in_product_path():
                     assert "pyoracle" not in txt and "liboracle" not in txt and "sdr_oracle" not in txt, f
     needed = subprocess.run(["ldd", abi.SO_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in needed
+
+
+@pytest.mark.gpu
+def test_roctx_ranges_around_process_calls():
+    """SDRHIP_ROCTX=1 brackets every *_process call with roctxRangePush / Pop (SURVEY §5 tracing): the smoke chain must run
+    unchanged with the ranges on (libroctx is opened with dlopen; without a profiler attached the calls are no-ops)."""
+    import subprocess, sys
+    env = dict(os.environ, SDRHIP_ROCTX="1")
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=abi.ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

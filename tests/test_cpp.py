@@ -41,6 +41,35 @@ def test_wav_nodes_cpu(tmp_path):
     assert r.returncode == 0 and "OK (0 failures)" in r.stdout, r.stdout + r.stderr
 
 
+SAN = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"]
+
+
+def _run_sanitized(exe, args, timeout=300):
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0 and "OK (0 failures)" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+
+
+def test_core_and_wav_under_sanitizers(tmp_path):
+    """the host side under -fsanitize=address,undefined in the build container — the API-compatible core
+    (Buffer refcounts, Queue thread, config propagation) and the WAV nodes."""
+    _run_sanitized(_build("test_core.cc", "test_core_san", SAN), [os.path.join(ROOT, "tests", "golden")])
+    _run_sanitized(_build("test_wav.cc", "test_wav_san", SAN), [os.path.join(ROOT, "tests", "golden"), str(tmp_path)])
+
+
+def test_gpu_node_headers_host_half_under_sanitizers():
+    """The host half of include/sdr/gpu/nodes.hh + design.hh (designers against golden vectors, config() rules, buffer
+    views, destructors) under -fsanitize=address,undefined; no device needed: a complete Config without a GPU must end in
+    a ConfigError ("no CPU fallback"), never in a crash. (Leak checking off for this one: the HIP runtime libsdrhip.so
+    brings in is not ours to sanitize.)"""
+    exe = _build("test_gpu_nodes.cc", "test_gpu_nodes_san", SAN + _gpu_link_flags())
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([exe, "--host-only", os.path.join(ROOT, "tests", "golden")], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "OK (0 failures)" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+
+
 def test_gpu_nodes_compile_and_link():
     """The node headers build against our core and link against the C-ABI library (no device needed)."""
     _build("test_gpu_nodes.cc", "test_gpu_nodes", _gpu_link_flags())
