@@ -96,6 +96,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   constexpr int LASTL = NPIECE - 64 * (NDMA - 1);              // lanes of the last one
   static_assert(NDMA <= 3, "immediate offsets 0 / 1024 / 2048");
   constexpr bool WIDE = hot_wide(S, NH, CU8, NW);
+  constexpr int NBUF = 2;   // window buffers per wave
   static_assert(hot_lds_bytes(S, NH, CU8, NW, WIDE) <= hot_lds_cap(NW), "LDS budget for 4 waves per SIMD");
   constexpr int TBLW = WIDE ? 1024 : 256;   // dwords
   constexpr int TPBH = 64 * NW;
@@ -111,7 +112,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   const int wv = w & 3;                                                   // slice of a tile this wave computes
   const int bx = (int)blockIdx.x * (NW / 4) + (w >> 2), gx = (int)gridDim.x * (NW / 4);   // virtual workgroup, virtual grid
   // tap fragments in LDS: the S low-plane fragments, then only the NH high-plane fragments of steps [S0, S0 + NH)
-  char *wbase = reinterpret_cast<char *>(smem + TBLW + (S + NH) * 64 * 4) + w * (2 * BUFB);
+  char *wbase = reinterpret_cast<char *>(smem + TBLW + (S + NH) * 64 * 4) + w * (NBUF * BUFB);
   for (int i = tid; i < S * 64; i += TPBH) taps_s[i] = a.tapfrag[(2 * (i >> 6) + 1) * 64 + (i & 63)];
   for (int i = tid; i < NH * 64; i += TPBH) taps_s[S * 64 + i] = a.tapfrag[(2 * (S0 + (i >> 6))) * 64 + (i & 63)];
   if (tid < 256) {
@@ -223,110 +224,71 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   unsigned prio_it = 0;
   const unsigned prio_slot = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 3u;   // HW_REG_HW_ID[3:0]: the wave's slot in its SIMD
 
-  // one slice out of window buffer PAR (compile-time: the buffer's offset folds into the LDS instructions' immediates)
-  auto slice = [&](auto par_) __attribute__((always_inline)) {
-    constexpr int PAR = decltype(par_)::value;
-    char *cb = wbase + PAR * BUFB, *nb = wbase + (1 - PAR) * BUFB;
-    // the step after this one: next tile of the unit, or the first hot tile of the workgroup's next unit
-    int nu = u, nc = c, ng = g, ntile = tile + 1, ntend = tend;
-    const char *nsrcb = srcb;
-    char *noutb = outb;
-    if (ntile >= tend) {
-      next_unit(nu, nc, ng, ntile, ntend);
-      nsrcb = chan_src(nc); noutb = chan_out(nc);
-    }
-    const bool more = nu < a.U;
-    // Fairness: the SIMD arbitrates its waves by priority, then AGE, and in a persistent grid the ages never change —
-    // the oldest wave of a SIMD ran at full speed and was done after 64 us, the youngest starved and finished alone
-    // at 120 us (s_memrealtime stamps). The priority rotates over the SIMD's four wave slots, one step per slice.
-    if (K1_PRIO_ROT == 1) {   // (s_setprio takes an immediate: a two-level branch tree, 5-6 scalar instructions executed)
-      const unsigned pv = prio_it++ + prio_slot;
-      asm volatile("s_bitcmp1_b32 %0, 1\n\ts_cbranch_scc1 2f\n\ts_bitcmp1_b32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n\ts_branch 4f\n"
-                   "1:\n\ts_setprio 1\n\ts_branch 4f\n"
-                   "2:\n\ts_bitcmp1_b32 %0, 0\n\ts_cbranch_scc1 3f\n\ts_setprio 2\n\ts_branch 4f\n"
-                   "3:\n\ts_setprio 3\n"
-                   "4:" :: "s"(pv) : "scc");
-    }
-    // ---- the next slice's window starts its journey into the other buffer (its planes were last read in the previous
-    // slice's K loop); then wait for this slice's own window: everything older than those NDMA instructions ----
-    K1_STAMP(0);
-    if (__builtin_expect(more, 1)) {
-      dma_issue(nsrcb + (long)ntile * tile_in_bytes + lane_byte, nb);
-      if (NDMA == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      else if (NDMA == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    K1_STAMP(1);
-    // ---- raw window -> byte planes, in place: every read of the wave is issued before its first write, and the LDS
-    // executes one wave's instructions in order ----
-    {
-      uint4 x[NDMA];
+  // ---- the four stages of a slice -----------------------------------------------------------------------------------
+  // P: raw window -> byte planes, in place: every read of the wave is issued before its first write, and the LDS
+  // executes one wave's instructions in order
+  auto stageP = [&](char *cb) __attribute__((always_inline)) {
+    uint4 x[NDMA];
 #pragma unroll
-      for (int k = 0; k < NDMA; k++)
-        if (k < NDMA - 1 || l < LASTL) x[k] = *reinterpret_cast<const uint4 *>(cb + 16 * (l + 64 * k));
-      asm volatile("" ::: "memory");
+    for (int k = 0; k < NDMA; k++)
+      if (k < NDMA - 1 || l < LASTL) x[k] = *reinterpret_cast<const uint4 *>(cb + 16 * (l + 64 * k));
+    asm volatile("" ::: "memory");
 #ifndef K1_ABL_NOCONV
 #pragma unroll
-      for (int k = 0; k < NDMA; k++) {
-        if (k < NDMA - 1 || l < LASTL) {
-          if (CU8) {   // AutoCast: high byte (b + 129) mod 256, low byte 0 (no low plane at all)
-            *reinterpret_cast<uint4 *>(cb + dofs[k]) = make_uint4(add129_bytes(x[k].x), add129_bytes(x[k].y), add129_bytes(x[k].z), add129_bytes(x[k].w));
-          } else {
-            uint2 l2, h2;
-            l2.x = __builtin_amdgcn_perm(x[k].y, x[k].x, 0x06040200u) ^ 0x80808080u;
-            l2.y = __builtin_amdgcn_perm(x[k].w, x[k].z, 0x06040200u) ^ 0x80808080u;
-            h2.x = __builtin_amdgcn_perm(x[k].y, x[k].x, 0x07050301u);
-            h2.y = __builtin_amdgcn_perm(x[k].w, x[k].z, 0x07050301u);
-            *reinterpret_cast<uint2 *>(cb + dofs[k]) = l2;
-            *reinterpret_cast<uint2 *>(cb + PLB + dofs[k]) = h2;
-          }
+    for (int k = 0; k < NDMA; k++) {
+      if (k < NDMA - 1 || l < LASTL) {
+        if (CU8) {   // AutoCast: high byte (b + 129) mod 256, low byte 0 (no low plane at all)
+          *reinterpret_cast<uint4 *>(cb + dofs[k]) = make_uint4(add129_bytes(x[k].x), add129_bytes(x[k].y), add129_bytes(x[k].z), add129_bytes(x[k].w));
+        } else {
+          uint2 l2, h2;
+          l2.x = __builtin_amdgcn_perm(x[k].y, x[k].x, 0x06040200u) ^ 0x80808080u;
+          l2.y = __builtin_amdgcn_perm(x[k].w, x[k].z, 0x06040200u) ^ 0x80808080u;
+          h2.x = __builtin_amdgcn_perm(x[k].y, x[k].x, 0x07050301u);
+          h2.y = __builtin_amdgcn_perm(x[k].w, x[k].z, 0x07050301u);
+          *reinterpret_cast<uint2 *>(cb + dofs[k]) = l2;
+          *reinterpret_cast<uint2 *>(cb + PLB + dofs[k]) = h2;
         }
       }
-#endif
     }
-    // (the plane reads below see these writes: same wave, in order. The empty asm statements keep the COMPILER from
-    // moving LDS accesses across: no barrier or fence instruction separates them.)
-    K1_STAMP(2);
-    asm volatile("" ::: "memory");
-
-    // ---- K loop: operands of step s+1 in flight while the MFMAs of step s issue ----
-    v16i acc_hh = {0}, acc_mid = {0}, acc_ll = {0};
-    if (!CU8) acc_ll = cinit;
+#endif
+  };
+  // K: the K loop out of the planes in `cb`: operands of step s+1 in flight while the MFMAs of step s issue
+  struct KOps { v4i uh, ul, Al, Ah; };
+  auto stageK_begin = [&](const char *cb, KOps &o) __attribute__((always_inline)) {
     const char *pl = cb + coff, *ph = cb + (CU8 ? 0 : PLB) + coff;
-    v4i uh = *reinterpret_cast<const v4i *>(ph), ul = uh;
-    if (!CU8) ul = *reinterpret_cast<const v4i *>(pl);
-    v4i Al = taps_s[l], Ah = Al;
-    if (S0 == 0) Ah = taps_s[S * 64 + l];
+    o.uh = *reinterpret_cast<const v4i *>(ph); o.ul = o.uh;
+    if (!CU8) o.ul = *reinterpret_cast<const v4i *>(pl);
+    o.Al = taps_s[l]; o.Ah = o.Al;
+    if (S0 == 0) o.Ah = taps_s[S * 64 + l];
+  };
+  auto stageK = [&](const char *cb, KOps &o, v16i &acc_hh, v16i &acc_mid, v16i &acc_ll) __attribute__((always_inline)) {
+    constexpr int SA = 0, SB = S;
+    const char *pl = cb + coff, *ph = cb + (CU8 ? 0 : PLB) + coff;
 #ifdef K1_ABL_NOKLOOP
-    acc_mid[0] = uh.x ^ ul.x ^ Al.x ^ Ah.x;
+    if (SA == 0) acc_mid[0] = o.uh.x ^ o.ul.x ^ o.Al.x ^ o.Ah.x;
 #else
 #pragma unroll
-    for (int s = 0; s < S; s++) {
-      v4i uh_n = uh, ul_n = ul, Al_n = Al, Ah_n = Ah;
+    for (int s = SA; s < SB; s++) {
+      KOps nx = o;
       if (s + 1 < S) {
-        uh_n = *reinterpret_cast<const v4i *>(ph + 16 * (s + 1));
-        if (!CU8) ul_n = *reinterpret_cast<const v4i *>(pl + 16 * (s + 1));
-        Al_n = taps_s[(s + 1) * 64 + l];
-        if (s + 1 >= S0 && s + 1 < S0 + NH) Ah_n = taps_s[(S + s + 1 - S0) * 64 + l];
+        nx.uh = *reinterpret_cast<const v4i *>(ph + 16 * (s + 1));
+        if (!CU8) nx.ul = *reinterpret_cast<const v4i *>(pl + 16 * (s + 1));
+        nx.Al = taps_s[(s + 1) * 64 + l];
+        if (s + 1 >= S0 && s + 1 < S0 + NH) nx.Ah = taps_s[(S + s + 1 - S0) * 64 + l];
       }
-      acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, uh, acc_mid, 0, 0, 0);
-      if (!CU8) acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, ul, acc_ll, 0, 0, 0);
+      acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.Al, o.uh, acc_mid, 0, 0, 0);
+      if (!CU8) acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.Al, o.ul, acc_ll, 0, 0, 0);
       if (s >= S0 && s < S0 + NH) {
-        acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, uh, acc_hh, 0, 0, 0);
-        if (!CU8) acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, ul, acc_mid, 0, 0, 0);
+        acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.Ah, o.uh, acc_hh, 0, 0, 0);
+        if (!CU8) acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.Ah, o.ul, acc_mid, 0, 0, 0);
       }
-      uh = uh_n; ul = ul_n; Al = Al_n; Ah = Ah_n;
+      o = nx;
     }
 #endif
-#ifdef K1_STAMPS
-    asm volatile("s_nop 0" : "+v"(acc_hh), "+v"(acc_mid), "+v"(acc_ll));   // the accumulators are complete before the stamp
-#endif
-    K1_STAMP(3);
-
-    // ---- epilogue: lane (n, h) owns group 2n + h of the wave ----
-    const uint32_t wave_cnt = cnt0 + (uint32_t)tile * tile_cnt;   // scalar unit
+  };
+  // E: lane (n, h) owns group 2n + h of the wave: recombine the byte-plane accumulators, >>14, rotate by LUT[idx(n)],
+  // window sum of the products' high halves. wave_cnt: LUT phase counter of the wave's first sample (scalar)
+  auto stageE = [&](const v16i &acc_hh, const v16i &acc_mid, const v16i &acc_ll, uint32_t wave_cnt) __attribute__((always_inline)) {
     int L[8][3];
 #ifdef K1_ABL_NOEPI
     if (false) {
@@ -379,36 +341,106 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       }
     }
 #endif
-#ifdef K1_STAMPS
-    asm volatile("" : "+v"(sum.x), "+v"(sum.y));
-#endif
-    K1_STAMP(4);
+    return sum;
+  };
+  // F: truncating division by 8, demodulator, store. orow: (scalar) the wave's first group of this slice; lanes below
+  // glw_lo store nothing (FM: group 0 only supplies the previous angle)
+  auto stageF = [&](int2 sum, char *orow, int glw_lo) __attribute__((always_inline)) {
     const int glw = 2 * n + h;
-    char *orow = outb + (long)tile * tile_out_bytes;   // (scalar) the wave's first group of this slice
     // libstdc++'s (s*8)/(8*8) (src/baseband.hh:214): |s| <= 9 * 2^17 (a window of 16-bit rotated values, or of 18-bit FIR
     // values when there is no shift), so nothing wraps and it is trunc(s / 8) + the int16 wrap of the assignment
     const int yr = div8_i16(sum.x), yi = div8_i16(sum.y);
     if (EPI == SDRHIP_EPI_NONE) {
-      reinterpret_cast<uint32_t *>(orow)[glw] = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
+      if (glw >= glw_lo) reinterpret_cast<uint32_t *>(orow)[glw] = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
     } else if (EPI == SDRHIP_EPI_AM) {
-      reinterpret_cast<short *>(orow)[glw] = am_i16(yr, yi);
+      const short o = am_i16(yr, yi);
+      if (glw >= glw_lo) reinterpret_cast<short *>(orow)[glw] = o;
     } else if (EPI == SDRHIP_EPI_USB) {
-      reinterpret_cast<short *>(orow)[glw] = usb_i16(yr, yi);
+      const short o = usb_i16(yr, yi);
+      if (glw >= glw_lo) reinterpret_cast<short *>(orow)[glw] = o;
     } else {
       const int phi = fm_phi(yr, yi);
       const int prev = prev_group_value(phi, h);
-      if (glw >= 1) reinterpret_cast<short *>(orow)[glw] = (short)(prev - phi);   // group 0 only supplies the previous angle
+      if (glw >= glw_lo) reinterpret_cast<short *>(orow)[glw] = (short)(prev - phi);
     }
-    K1_STAMP(5);
-#ifdef K1_STAMPS
-    st_tiles++;
-#endif
-    u = nu; c = nc; g = ng; tile = ntile; tend = ntend; srcb = nsrcb; outb = noutb;
   };
-  while (u < a.U) {
-    slice(std::integral_constant<int, 0>{});
-    if (!(u < a.U)) break;
-    slice(std::integral_constant<int, 1>{});
+  constexpr int GLW0 = EPI == SDRHIP_EPI_FM ? 1 : 0;
+  // Fairness: the SIMD arbitrates its waves by priority, then AGE, and in a persistent grid the ages never change —
+  // the oldest wave of a SIMD ran at full speed and was done after 64 us, the youngest starved and finished alone
+  // at 120 us (s_memrealtime stamps). The priority rotates over the SIMD's four wave slots, one step per slice.
+  auto rotate_priority = [&]() __attribute__((always_inline)) {
+    if (K1_PRIO_ROT == 1) {   // (s_setprio takes an immediate: a two-level branch tree, 5-6 scalar instructions executed)
+      const unsigned pv = prio_it++ + prio_slot;
+      asm volatile("s_bitcmp1_b32 %0, 1\n\ts_cbranch_scc1 2f\n\ts_bitcmp1_b32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n\ts_branch 4f\n"
+                   "1:\n\ts_setprio 1\n\ts_branch 4f\n"
+                   "2:\n\ts_bitcmp1_b32 %0, 0\n\ts_cbranch_scc1 3f\n\ts_setprio 2\n\ts_branch 4f\n"
+                   "3:\n\ts_setprio 3\n"
+                   "4:" :: "s"(pv) : "scc");
+    }
+  };
+  auto wait_dma = [&](bool newer_in_flight) __attribute__((always_inline)) {   // all VMEM older than the NDMA youngest instructions (or everything)
+    if (__builtin_expect(newer_in_flight, 1)) {
+      if (NDMA == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else if (NDMA == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  };
+
+  {
+    // ---- one slice after the other; 4 waves per SIMD overlap one wave's matrix phase with the others' vector phases ----
+    // (window buffer PAR is compile-time: the buffer's offset folds into the LDS instructions' immediates)
+    auto slice = [&](auto par_) __attribute__((always_inline)) {
+      constexpr int PAR = decltype(par_)::value;
+      char *cb = wbase + PAR * BUFB, *nb = wbase + (1 - PAR) * BUFB;
+      // the step after this one: next tile of the unit, or the first hot tile of the workgroup's next unit
+      int nu = u, nc = c, ng = g, ntile = tile + 1, ntend = tend;
+      const char *nsrcb = srcb;
+      char *noutb = outb;
+      if (ntile >= tend) {
+        next_unit(nu, nc, ng, ntile, ntend);
+        nsrcb = chan_src(nc); noutb = chan_out(nc);
+      }
+      const bool more = nu < a.U;
+      rotate_priority();
+      // the next slice's window starts its journey into the other buffer (its planes were last read in the previous
+      // slice's K loop); then wait for this slice's own window: everything older than those NDMA instructions
+      K1_STAMP(0);
+      if (__builtin_expect(more, 1)) dma_issue(nsrcb + (long)ntile * tile_in_bytes + lane_byte, nb);
+      wait_dma(more);
+      K1_STAMP(1);
+      stageP(cb);
+      // (the plane reads below see these writes: same wave, in order. The empty asm statements keep the COMPILER from
+      // moving LDS accesses across: no barrier or fence instruction separates them.)
+      K1_STAMP(2);
+      asm volatile("" ::: "memory");
+      v16i acc_hh = {0}, acc_mid = {0}, acc_ll = {0};
+      if (!CU8) acc_ll = cinit;
+      KOps ops;
+      stageK_begin(cb, ops);
+      stageK(cb, ops, acc_hh, acc_mid, acc_ll);
+#ifdef K1_STAMPS
+      asm volatile("s_nop 0" : "+v"(acc_hh), "+v"(acc_mid), "+v"(acc_ll));   // the accumulators are complete before the stamp
+#endif
+      K1_STAMP(3);
+      int2 sum = stageE(acc_hh, acc_mid, acc_ll, cnt0 + (uint32_t)tile * tile_cnt);
+#ifdef K1_STAMPS
+      asm volatile("" : "+v"(sum.x), "+v"(sum.y));
+#endif
+      K1_STAMP(4);
+      stageF(sum, outb + (long)tile * tile_out_bytes, GLW0);
+      K1_STAMP(5);
+#ifdef K1_STAMPS
+      st_tiles++;
+#endif
+      u = nu; c = nc; g = ng; tile = ntile; tend = ntend; srcb = nsrcb; outb = noutb;
+    };
+    while (u < a.U) {
+      slice(std::integral_constant<int, 0>{});
+      if (!(u < a.U)) break;
+      slice(std::integral_constant<int, 1>{});
+    }
   }
 
   // ---- the call's COLD slices --------------------------------------------------------------------------------
@@ -416,7 +448,11 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   // groups, the end of the input — are a few per channel (2 of 130 on the headline workload).
   {
     char *cb = wbase;
+#ifdef K1_ABL_NOCOLD   // tuning ablation (results wrong): no cold phase
+    for (int cc = a.C; cc < a.C; cc += gx) {
+#else
     for (int cc = bx; cc < a.C; cc += gx) {
+#endif
       for (int t = 0; t < b.tiles; t = (t == 0 ? max(b.bt_hi, 1) : t + 1)) {
         const int q0 = t * a.OG - a.ovl, groups_here = min(b.CG, b.n_groups - q0);
         if (slice_is_hot(HALO, a.base0_rel, a.OG, a.ovl, a.N, a.n_out, t, wv) || gw + a.ovl >= groups_here) continue;
@@ -530,10 +566,11 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
 }
 
 // One launch per call: the hot grid, then each virtual workgroup's share of the cold slices.
-template <int S, int S0, int NH, bool ROT, int EPI, bool CU8, int NW>
 #ifndef K1_MINWAVES
 #define K1_MINWAVES 4
 #endif
+// One launch per call: the hot grid, then each virtual workgroup's share of the cold slices.
+template <int S, int S0, int NH, bool ROT, int EPI, bool CU8, int NW>
 __global__ __launch_bounds__(64 * NW, K1_MINWAVES) void iqbb_hot_kernel(const HotArgs a, const IqbbArgs b) {
   iqbb_hot_body<S, S0, NH, ROT, EPI, CU8, NW>(a, b);
 }

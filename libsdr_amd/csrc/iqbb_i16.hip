@@ -1107,7 +1107,7 @@ struct sdrhip_iqbb_i16 {
 #endif
     // persistent grid of 4 virtual (4-wave) workgroups per CU = 4 waves per SIMD; a real workgroup is NW / 4 of them.
     // Units of at most 4 tiles so that the static split leaves a short tail.
-    int wgpcu = 4;
+    int wgpcu = 4;   // virtual (4-wave) workgroups per CU = waves per SIMD
     { const char *e = getenv("SDRHIP_IQBB_WGPCU"); if (e) wgpcu = std::max(1, atoi(e)); }   // tuning hook (builds with -DK1_MINWAVES=5)
     const int nvwg = wgpcu * ctx->prop.multiProcessorCount;
     int htpw = 4; while (htpw > 1 && (size_t)ceil_div((size_t)tiles, (size_t)htpw) * C < 4 * (size_t)nvwg) htpw >>= 1;
