@@ -48,9 +48,10 @@ __device__ __forceinline__ short usb_i16(int re, int im) { return (short)((re + 
 // =============================================================================================
 // K2: exact complex<int16> FIR
 // =============================================================================================
-constexpr int R2 = 4;              // consecutive outputs per lane
-constexpr int T2 = TPB * R2;       // outputs computed per tile
-constexpr int U2 = 4;              // taps per unrolled chunk (order zero-padded at the front)
+// R2 consecutive outputs per lane: 8 for batches that fill the chip (the circular window's conversions amortise over twice
+// the taps: +3 % over R2 = 4), 4 for small ones (twice the workgroups, half the serial work per lane: latency)
+constexpr int R2MAX = 8;
+constexpr int U2 = 4;              // taps per unrolled chunk (the order is zero-padded at the front to whole window periods R2 + U2)
 
 struct Fir16Args {
   const uint32_t *in; long in_stride;
@@ -75,8 +76,9 @@ __device__ __forceinline__ double tap_step(double acc, double alpha, double x) {
   return t;
 }
 
-template <bool WRAP>
+template <bool WRAP, int R2>
 __global__ __launch_bounds__(TPB) void fir_cs16_exact_kernel(const Fir16Args a) {
+  constexpr int T2 = TPB * R2;       // outputs computed per tile
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int XS = T2 + a.OP + 8;
   uint32_t *xs = smem;            // xs[i] = x[tb-(OP-1)+i]
@@ -97,8 +99,13 @@ __global__ __launch_bounds__(TPB) void fir_cs16_exact_kernel(const Fir16Args a) 
     double are[R2], aim[R2];
 #pragma unroll
     for (int r = 0; r < R2; r++) { are[r] = 0.0; aim[r] = 0.0; }
-    // window of converted samples: wre/wim[k] = x[R2*tid + i0 + k], k = 0 .. R2+U2-2
-    double wre[R2 + U2], wim[R2 + U2];
+    // CIRCULAR window of converted samples: slot (m mod W) holds x[R2*tid + m]; a chunk of U2 taps starting at tap i0
+    // needs m = i0 .. i0 + R2 + U2 - 2 and loads m = i0 + R2 .. i0 + R2 + U2 - 1 while the slots of m < i0 are dead.
+    // With W = R2 + U2 and the tap loop unrolled over W / U2 chunks every slot index is a compile-time constant: no
+    // register moves (the sliding window's 2 * R2 moves per chunk were a sixth of the loop's vector instructions).
+    constexpr int W = R2 + U2;
+    static_assert(W % U2 == 0 && R2 % U2 == 0, "the circular window's period is a whole number of chunks");
+    double wre[W], wim[W];
     const uint32_t *px = xs + R2 * tid;
 #pragma unroll
     for (int k = 0; k < R2; k++) {
@@ -106,23 +113,25 @@ __global__ __launch_bounds__(TPB) void fir_cs16_exact_kernel(const Fir16Args a) 
       wre[k] = (double)(short)(v & 0xffffu); wim[k] = (double)(short)(v >> 16);
     }
     const double *__restrict__ al = a.alpha;
-    for (int i0 = 0; i0 < a.OP; i0 += U2) {
+    for (int i0 = 0; i0 < a.OP; i0 += W) {   // (OP is a multiple of W: the order is zero-padded at the front)
 #pragma unroll
-      for (int k = 0; k < U2; k++) {
-        const uint32_t v = px[i0 + R2 + k];
-        wre[R2 + k] = (double)(short)(v & 0xffffu); wim[R2 + k] = (double)(short)(v >> 16);
-      }
+      for (int ch = 0; ch < W / U2; ch++) {   // chunk ch of this period: taps i0 + ch * U2 ..
+        const int ib = i0 + ch * U2;
 #pragma unroll
-      for (int u = 0; u < U2; u++) {
-        const double al_j = al[i0 + u];     // wave-uniform -> scalar load
+        for (int k = 0; k < U2; k++) {
+          const uint32_t v = px[ib + R2 + k];
+          wre[(ch * U2 + R2 + k) % W] = (double)(short)(v & 0xffffu); wim[(ch * U2 + R2 + k) % W] = (double)(short)(v >> 16);
+        }
 #pragma unroll
-        for (int r = 0; r < R2; r++) {
-          are[r] = tap_step<WRAP>(are[r], al_j, wre[u + r]);
-          aim[r] = tap_step<WRAP>(aim[r], al_j, wim[u + r]);
+        for (int u = 0; u < U2; u++) {
+          const double al_j = al[ib + u];     // wave-uniform -> scalar load
+#pragma unroll
+          for (int r = 0; r < R2; r++) {
+            are[r] = tap_step<WRAP>(are[r], al_j, wre[(ch * U2 + u + r) % W]);
+            aim[r] = tap_step<WRAP>(aim[r], al_j, wim[(ch * U2 + u + r) % W]);
+          }
         }
       }
-#pragma unroll
-      for (int k = 0; k < R2; k++) { wre[k] = wre[k + U2]; wim[k] = wim[k + U2]; }
     }
 #pragma unroll
     for (int r = 0; r < R2; r++) {
@@ -437,7 +446,7 @@ struct sdrhip_fir {
   uint64_t n0 = 0;
   int par = 0, par_fm = 0;
   // K2
-  int OP = 0, HH = 0, ovl = 0;
+  int OP = 0, HH = 0, ovl = 0, R2 = 4;   // R2: outputs per lane of the exact kernel (chosen at create)
   bool wrap = false;
   DevBuf<double> alpha;
   DevBuf<uint32_t> hist16[2];
@@ -471,13 +480,19 @@ struct sdrhip_fir {
       a.in = (const uint32_t *)in_dev; a.in_stride = (long)in_stride;
       a.hist_old = hist16[par].p; a.hist_new = hist16[par ^ 1].p; a.HH = HH;
       a.fm_old = fm[par_fm].p; a.fm_new = fm[par_fm ^ 1].p;
+      const int T2 = TPB * R2;
       a.alpha = alpha.p; a.OP = OP; a.N = (int)N; a.ovl = ovl; a.OT = T2 - ovl;
       a.out = out_dev; a.out_stride = (long)out_stride; a.epilogue = epi;
       const int tiles = (int)ceil_div(N, (size_t)a.OT);
       const size_t lds = ((size_t)T2 + OP + 8 + T2) * 4;
       dim3 grid(tiles, C), block(TPB);
-      if (wrap) hipLaunchKernelGGL(fir_cs16_exact_kernel<true>, grid, block, lds, ctx->stream, a);
-      else hipLaunchKernelGGL(fir_cs16_exact_kernel<false>, grid, block, lds, ctx->stream, a);
+      if (R2 == 8) {
+        if (wrap) hipLaunchKernelGGL((fir_cs16_exact_kernel<true, 8>), grid, block, lds, ctx->stream, a);
+        else hipLaunchKernelGGL((fir_cs16_exact_kernel<false, 8>), grid, block, lds, ctx->stream, a);
+      } else {
+        if (wrap) hipLaunchKernelGGL((fir_cs16_exact_kernel<true, 4>), grid, block, lds, ctx->stream, a);
+        else hipLaunchKernelGGL((fir_cs16_exact_kernel<false, 4>), grid, block, lds, ctx->stream, a);
+      }
       SDRHIP_CHECK_HIP(hipGetLastError());
       if (epi == SDRHIP_EPI_FM && N >= 2) par_fm ^= 1;
     } else {
@@ -571,10 +586,12 @@ int sdrhip_fir_create(sdrhip_ctx *ctx, int kind, const double *alpha, int order,
       h->ctx = ctx; h->kind = kind; h->order = order; h->D = decim; h->C = channels; h->epi = epilogue;
       h->max_in = max_in; h->max_out = max_in / decim + 1;
       if (kind == SDRHIP_FIR_CS16_EXACT) {
-        h->OP = (int)ceil_div((size_t)order, (size_t)U2) * U2;
+        // outputs per lane: 8 when full-size calls still leave >= 8 workgroups per CU, else 4
+        h->R2 = (ceil_div(max_in, (size_t)(TPB * 8)) * (size_t)channels >= 8 * (size_t)ctx->prop.multiProcessorCount) ? 8 : 4;
+        h->OP = (int)ceil_div((size_t)order, (size_t)(h->R2 + U2)) * (h->R2 + U2);   // whole periods of the kernel's circular window
         h->HH = h->OP - 1;
         h->ovl = epilogue == SDRHIP_EPI_FM ? 1 : 0;
-        SDRHIP_REQUIRE(((size_t)T2 + h->OP + 8 + T2) * 4 <= 64 * 1024, SDRHIP_E_UNSUPPORTED, "order %d exceeds the LDS tile", order);
+        SDRHIP_REQUIRE(((size_t)TPB * R2MAX + h->OP + 8 + TPB * R2MAX) * 4 <= 64 * 1024, SDRHIP_E_UNSUPPORTED, "order %d exceeds the LDS tile", order);
         std::vector<double> ap(h->OP, 0.0);
         double P = 0, Q = 0;   // sum of the positive / |negative| taps
         for (int i = 0; i < order; i++) {

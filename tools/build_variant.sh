@@ -1,13 +1,14 @@
 #!/bin/bash
-# Builds libsdr_amd/libsdrhip_<name>.so = the library with the K1 sources (iqbb_i16.hip, iqbb_hot_s*.hip) compiled under
-# extra flags (tuning A/B: tools/abk1.py times several such builds against each other in one process on one box).
+# Builds libsdr_amd/libsdrhip_<name>.so = the library with the K1 sources (iqbb_i16.hip, iqbb_hot_s*.hip; or the sources
+# named on the command line) compiled under extra flags (tuning A/B: tools/abk1.py times several such builds against each other in one process on one box).
 # usage: tools/build_variant.sh <name> "<flags>" [only-these-sources...]   e.g.  tools/build_variant.sh noepi "-DK1_ABL_NOEPI"
 set -e
 cd $(dirname $0)/../libsdr_amd/csrc
 NAME=$1; FLAGS=$2; shift 2
 make -s -j8 > /dev/null
-ALL=$(ls iqbb_i16.hip iqbb_hot_s*.hip | tr '\n' ' ')
-SRCS=" ${*:-$ALL} "
+K1=$(ls iqbb_i16.hip iqbb_hot_s*.hip | tr '\n' ' ')
+ALL=$(ls *.hip | tr '\n' ' ')
+SRCS=" ${*:-$K1} "   # default: the K1 sources; name any other source (fir.hip, fftconv.hip ...) to rebuild it under the flags
 mkdir -p _obj_$NAME
 : > _obj_$NAME/Makefile.v
 T=""
@@ -22,7 +23,6 @@ for f in $ALL; do
 done
 echo "all:$T" >> _obj_$NAME/Makefile.v
 make -s -j8 -f _obj_$NAME/Makefile.v all
-OBJS=$(ls _obj/*.o | grep -v "/iqbb_")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsdrhip_$NAME.so $OBJS _obj_$NAME/*.o -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsdrhip_$NAME.so _obj_$NAME/*.o -ldl
 rm -rf _obj_$NAME
 echo built libsdr_amd/libsdrhip_$NAME.so
