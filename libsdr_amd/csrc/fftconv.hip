@@ -321,12 +321,24 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
   auto radix_at = [&](int q) { return LG ? plan_radix(LG, q) : p.radix[q]; };
   // (one workgroup per (channel, block). A persistent grid — the resident workgroups walking the units in a loop —
   // measured 4.5 % SLOWER: a 16384-point block fills the CU's LDS, so either way one workgroup runs per CU, but the
-  // dispatcher starts the next workgroup's waves while the last one's stores drain, and the loop's closing barrier does not)
+  // dispatcher starts the next workgroup's waves while the last one's stores drain, and the loop's closing barrier does not.
+  // Round 3 tried it again WITH a register prefetch of the next block's input issued before the last inverse pass: 512
+  // lanes (registers to spare) 0.535 ms, 1024 lanes (prefetch once the twiddles are dead, 114 registers) 0.524 ms, against
+  // 0.508 ms for this kernel on the same box)
   const int tid0 = threadIdx.x, c = blockIdx.y, blk = blockIdx.x;
   // (every phase starts from an opaque copy of the lane index: the lane's LDS and table addresses of all passes are
   // otherwise computed up front and, kept live across the phases, spill — 49 to 93 registers in the run-time-plan kernels)
   // (the compile-time 16384-point plan fits without: there the hoisted addresses are worth 5 %)
   auto lane = [&]() { int t = tid0; if (LG == 0) asm volatile("" : "+v"(t)); return t; };
+  // After the first radix-16 pass the transform splits into 16 independent segments of L/16 points, and with one
+  // butterfly per lane (NT = L/16) the butterflies of a segment belong to consecutive lanes: for L = 16384 a segment is
+  // exactly one WAVE's 64 lanes x 16 points. The passes between the first forward and the last inverse pass then touch
+  // only data the same wave wrote — LDS operations of one wave execute in order, so they need no workgroup barrier: 2
+  // barriers per block instead of 7 (r08's counters: 44 % of the wave cycles parked at them, all 16 waves in lock step).
+  constexpr bool WAVE_LOCAL = !BANK && LG == 14 && NT == 1024;
+  auto pass_sync = [&]() { if (WAVE_LOCAL) asm volatile("" ::: "memory"); else __syncthreads(); };
+  // radix-4 butterfly q (0..3) of this lane: with WAVE_LOCAL the 256 butterflies of the wave's own segment
+  auto bfly4_index = [&](int tid, int q) { return WAVE_LOCAL ? ((tid >> 6) * 256 + (tid & 63) + 64 * q) : (tid + q * FT); };
   const int first = blk * a.hop - a.HH;   // call-relative index of element 0
   // ---- forward pass 0 (radix 16, stride L/16): global -> registers -> LDS ----
   {
@@ -383,7 +395,7 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
         for (int k = 0; k < 16; k++) xl[PAD(base + k * s)] = v[k];
       }
     } else {   // radix 4 (a radix-2 pass can only be the last one)
-      for (int b = tid; b < L / 4; b += FT) {
+      for (int b = tid; b < L / 4; b += FT) {   // (not reached by the 16384-point plan: its radix-4 pass is the last one)
         const int j = b & (s - 1), base = (b / s) * n + j;
         const float2 a0 = xl[PAD(base)], a1 = xl[PAD(base + s)], a2 = xl[PAD(base + 2 * s)], a3 = xl[PAD(base + 3 * s)];
         float2 X0, X1, X2, X3;
@@ -394,7 +406,7 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
         xl[PAD(base + 3 * s)] = cmul(X3, p.W[3 * j * tw]);
       }
     }
-    __syncthreads();
+    pass_sync();
     n = s;
   }
   // ---- filter bank (BANK): one forward transform per input block for all bands, as FilterSink feeds every FilterSource
@@ -476,7 +488,8 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
         for (int k = 0; k < 16; k++) xw[PAD(16 * b + k)] = v[k];
       }
     } else if (r == 4) {
-      for (int b = tid; b < L / 4; b += FT) {
+      for (int q = 0; q * FT + (WAVE_LOCAL ? 0 : tid) < L / 4; q++) {   // (small plans: fewer butterflies than lanes)
+        const int b = bfly4_index(tid, q);
         const float2 a0 = xs[PAD(4 * b)], a1 = xs[PAD(4 * b + 1)], a2 = xs[PAD(4 * b + 2)], a3 = xs[PAD(4 * b + 3)];
         float2 X0, X1, X2, X3, Z0, Z1, Z2, Z3;
         bfly4<-1>(a0, a1, a2, a3, X0, X1, X2, X3);
@@ -490,7 +503,7 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
         xw[PAD(2 * b)] = cadd(y0, y1); xw[PAD(2 * b + 1)] = csub(y0, y1);
       }
     }
-    __syncthreads();
+    pass_sync();
   }
   // ---- inverse passes np-2 .. 1 in LDS ----
   n = radix_at(np - 1);
@@ -524,7 +537,7 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
         xw[PAD(base)] = X0; xw[PAD(base + s)] = X1; xw[PAD(base + 2 * s)] = X2; xw[PAD(base + 3 * s)] = X3;
       }
     }
-    __syncthreads();
+    if (pass > 1) pass_sync(); else __syncthreads();   // (the last inverse pass crosses the segments again)
   }
   // ---- last inverse pass (radix 16, stride L/16): LDS -> registers -> global (only the hop kept samples) ----
   {
@@ -739,7 +752,6 @@ struct sdrhip_fftconv {
     SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   }
 
-  // bands a launch can serve from one forward transform: the forward image and one work image must fit the CU's LDS
   // bands a launch can serve from one forward transform: the bank kernel keeps the spectrum in registers, 16 values per
   // lane of an L/16-lane workgroup (L = 1024 .. 8192; 16384 points sit at the register cap of a 1024-lane workgroup)
   int bands_per_launch() const { return (plan.L >= 1024 && plan.L <= 8192) ? B : 1; }

@@ -326,8 +326,8 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       unsigned tre = ((unsigned)acc_hh[2 * j] << 8) + (unsigned)acc_mid[2 * j];   // (compiler code: it pads the MFMA -> VALU hazard)
       unsigned tim = ((unsigned)acc_hh[2 * j + 1] << 8) + (unsigned)acc_mid[2 * j + 1];
       int rr, ri;
-      if (CU8) {   // S = t << 8 exactly
-        rr = (int)(tre << 8) >> 14; ri = (int)(tim << 8) >> 14;
+      if (CU8) {   // S = t << 8 exactly (mod 2^32): S >> 14 = bits 6 .. 23 of t, sign-extended — one bit-field extract
+        rr = __builtin_amdgcn_sbfe((int)tre, 6, 18); ri = __builtin_amdgcn_sbfe((int)tim, 6, 18);
       } else {
         asm("" : "+v"(tre)); asm("" : "+v"(tim));   // no re-association into 2 shifts + add3
         rr = (int)((tre << 8) + (unsigned)acc_ll[2 * j]) >> 14; ri = (int)((tim << 8) + (unsigned)acc_ll[2 * j + 1]) >> 14;
