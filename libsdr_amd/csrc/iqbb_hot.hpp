@@ -46,14 +46,14 @@ constexpr bool hot_wide(int S, int NH, bool cu8, int NW) { return hot_lds_bytes(
 struct HotRange { int S0, NH, NW; };
 // per S: centred high-plane ranges, narrowest first; the last one covers every step
 constexpr HotRange hot_ranges_2[] = {{0, 2, 4}};
-constexpr HotRange hot_ranges_3[] = {{0, 3, 4}};
+constexpr HotRange hot_ranges_3[] = {{1, 2, 4}, {0, 3, 4}};
 constexpr HotRange hot_ranges_5[] = {{1, 3, 4}, {0, 5, 4}};
 constexpr HotRange hot_ranges_9[] = {{3, 3, 4}, {2, 5, 4}, {1, 7, 4}, {0, 9, 4}};
 constexpr HotRange hot_ranges_17[] = {{6, 5, 8}, {4, 9, 8}, {0, 17, 16}};
 inline const HotRange *hot_ranges(int S, int *count) {
   switch (S) {
     case 2: *count = 1; return hot_ranges_2;
-    case 3: *count = 1; return hot_ranges_3;
+    case 3: *count = 2; return hot_ranges_3;
     case 5: *count = 2; return hot_ranges_5;
     case 9: *count = 4; return hot_ranges_9;
     case 17: *count = 3; return hot_ranges_17;

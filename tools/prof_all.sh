@@ -1,0 +1,25 @@
+#!/bin/bash
+# One profiling round over every bench workload (run on the GPU box through gpurun): per workload tools/prof.sh
+# (kernel trace + the PMC passes of the same bench.py command line) under gpurun_out/prof_<round>_<name>/, and the
+# un-profiled bench.py lines in gpurun_out/<round>_bench.json (headline) and <round>_bench_other_workloads.jsonl.
+# usage: tools/prof_all.sh r09 [name ...]      then, here:  cp gpurun_out/summ/* gpurun_out/r09_bench* profiles/
+R=${1:-r09}; shift
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+declare -A W=( [fm127]="" [fm16]="--order 16" [fm21]="--order 21" [fm64]="--order 64" [fm255]="--order 255" [usb127]="--workload iqbb_usb"
+               [cu8]="--workload iqbb_fm_cu8" [real]="--workload bb_real_fm" [fir255]="--workload fir255_fm" [fbb]="--workload fbb_f32"
+               [fftconv]="--workload fftconv --fft-whole-blocks" [fftbank]="--workload fftbank" [fmdemod]="--workload fm_demod" [sub8]="--workload subsample8" )
+NAMES=${@:-fm127 fm16 fm21 fm64 fm255 usb127 cu8 real fir255 fbb fftconv fftbank fmdemod sub8}
+mkdir -p gpurun_out
+: > gpurun_out/${R}_bench_other_workloads.jsonl
+for n in $NAMES; do
+  if [ "$n" = fm127 ]; then python bench.py > gpurun_out/${R}_bench.json 2> gpurun_out/${R}_bench.err
+  else python bench.py ${W[$n]} --cpu-seconds 3 2>/dev/null | grep '^{' >> gpurun_out/${R}_bench_other_workloads.jsonl; fi
+done
+python bench.py --workload fbb_f32 --channels 1 --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | grep '^{' >> gpurun_out/${R}_bench_other_workloads.jsonl
+for n in $NAMES; do
+  tools/prof.sh ${R}_$n ${W[$n]} > gpurun_out/prof_${R}_$n.log 2>&1
+  # (the raw rocprofv3 trees are hundreds of MB: condense here, keep the summaries — they come back under gpurun_out/summ/)
+  python tools/summarize_prof.py ${R}_$n gpurun_out/summ > gpurun_out/summ_${R}_$n.log 2>&1
+  rm -rf gpurun_out/prof_${R}_$n
+done
+du -sh gpurun_out | tail -1

@@ -12,9 +12,10 @@ import os
 import sys
 
 tag = sys.argv[1]
+dst = sys.argv[2] if len(sys.argv) > 2 else "profiles"   # (on the GPU box: a directory under gpurun_out/, copied into profiles/ afterwards)
 src = os.path.join("gpurun_out", "prof_" + tag)
-os.makedirs("profiles", exist_ok=True)
-ours = ("iqbb", "fir_", "fftconv", "demod_", "subsample", "freqshift", "hist_roll", "fft_c2c")
+os.makedirs(dst, exist_ok=True)
+ours = ("iqbb", "bb_real", "fir_", "fftconv", "demod_", "subsample", "freqshift", "hist_roll", "fft_c2c")
 
 stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
 rows = []
@@ -22,7 +23,7 @@ if stats:
     with open(stats[0]) as f:
         rd = list(csv.reader(f))
     rows = [rd[0]] + [r for r in rd[1:] if any(k in r[0] for k in ours)]
-    with open(os.path.join("profiles", tag + "_kernel_stats.csv"), "w", newline="") as f:
+    with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w", newline="") as f:
         csv.writer(f).writerows(rows)
 
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -54,7 +55,7 @@ try:
 except Exception as e:
     meta = {"error": str(e)[:100]}
 out["_meta"] = meta
-json.dump(out, open(os.path.join("profiles", tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
+json.dump(out, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
 for r in rows[:6]:
     print(r[:4])
 print(json.dumps({k: v.get("derived") for k, v in out.items() if k != "_meta"}, indent=1), meta)
