@@ -65,6 +65,8 @@ def parse():
     p.add_argument("--fft-whole-blocks", action="store_true",
                    help="fftconv: round --samples up to whole overlap-save hops (12288) so that no ragged last block is transformed")
     p.add_argument("--dump-output", default="", help="rank 0 saves the last step's (gathered) output rows as .npy (tests)")
+    p.add_argument("--force-dist", action="store_true",
+                   help="tests: initialise the process group even with one rank, so that the RCCL gather path (side stream, async_op) runs on a one-GPU box")
     return p.parse_args()
 
 
@@ -408,15 +410,20 @@ def main():
                          % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:   # (--force-dist: a one-rank group)
+            import socket
+            s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); os.environ.setdefault("MASTER_PORT", str(s_.getsockname()[1])); s_.close()
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
         else:
             dist.init_process_group(a.backend)
     # one GPU: the north-star chain (FM, no collective); several: BASELINE config 5 (USB, output gathered on the root)
     wl = a.workload or ("iqbb_usb" if world > 1 else "iqbb_fm")
-    gather = (a.gather or (world > 1 and not a.workload)) and not a.no_gather and world > 1
+    gather = (a.gather or (world > 1 and not a.workload)) and not a.no_gather and use_dist
     C, W, K = a.channels, a.warmup, a.steps
 
     stream = torch.cuda.Stream(device=dev)
@@ -427,10 +434,14 @@ def main():
         w = build_workload(a, wl, sa, torch, shard, ctx, dev, rank, 2)
         N = w.N
         gathered, gl, g_ok = None, None, gather and a.backend == "nccl"
+        send = None
         if gather and w.outs[0].dim() == 2:
+            # (RCCL has no int16 type: the rows travel as bytes — uint8 views of the same memory)
+            send = [o.view(torch.uint8) for o in w.outs]
             if rank == 0:   # the root's landing zone: every rank's rows, in global channel order — no concatenation later
                 gathered = torch.zeros((world * C, w.outs[0].shape[1]), dtype=w.outs[0].dtype, device=dev)
-                gl = [gathered[r * C:(r + 1) * C] for r in range(world)]
+                g8 = gathered.view(torch.uint8)
+                gl = [g8[r * C:(r + 1) * C] for r in range(world)]
         elif gather:
             raise SystemExit("--gather needs a workload with one output row per channel")
         pending = [None, None]   # the gather that still reads outs[o]
@@ -447,7 +458,7 @@ def main():
                     ev[o].record(stream)
                     with torch.cuda.stream(side):
                         side.wait_event(ev[o])
-                        pending[o] = dist.gather(w.outs[o], gl if rank == 0 else None, dst=0, async_op=True)
+                        pending[o] = dist.gather(send[o], gl if rank == 0 else None, dst=0, async_op=True)
                 else:      # gloo dry runs / tests: host-staged, blocking
                     shard.gather_output(w.outs[o], C * world, dst=0, out=gathered)
 
@@ -459,7 +470,7 @@ def main():
 
         def barrier():
             drain()
-            if world > 1:
+            if use_dist:
                 dist.barrier()
             torch.cuda.synchronize()
 
@@ -537,9 +548,9 @@ def main():
             sustained = {"ms_per_launch": tot_ms / launches, "launches": launches, "last_chunk_ms_per_launch": last_ms}
             barrier()
 
-    host_coll = world > 1 and a.backend != "nccl"
+    host_coll = use_dist and a.backend != "nccl"
     red = torch.tensor([wall, no_gather["wall"] if no_gather else 0.0], dtype=torch.float64, device="cpu" if host_coll else dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(red, op=dist.ReduceOp.MAX)
     wall, wall_ng = float(red[0].item()), float(red[1].item())
 
@@ -564,7 +575,7 @@ def main():
                          "algorithmic_bytes_per_sample": alg_bytes, "avg_launch_ms": round(per_launch_s * 1e3, 4),
                          "hbm_read_frac": round(C * N * in_bytes / per_launch_s / 1e9 / HBM_PEAK_GBS, 5),
                          "per_gpu_msamples_s": round(C * N / per_launch_s / 1e6, 2),
-                         "ranks_seen": dist.get_world_size() if world > 1 else 1},
+                         "ranks_seen": dist.get_world_size() if use_dist else 1},
         }
         if verified is not None:
             res["verified"] = verified["ok"]
@@ -609,7 +620,7 @@ def main():
             if cb:
                 res["cpu_baseline"] = cb
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

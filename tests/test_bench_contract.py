@@ -123,3 +123,21 @@ def test_traffic_is_keyed_by_workload(tmp_path, monkeypatch):
     assert bench.measured_traffic("iqbb_fm/order127/d8/C1024/N65536", ["iqbb_hot_kernel"])["bytes"] == 3.0e8
     assert bench.measured_traffic("iqbb_fm_cu8/order127/d8/C1024/N65536", ["iqbb_hot_kernel"]) is None
     assert bench.measured_traffic("iqbb_fm/order127/d8/C1024/N65536", ["iqbb_hot_kernel", "other_kernel"]) is None
+
+
+@pytest.mark.gpu
+def test_rccl_gather_path_runs_on_one_rank(tmp_path):
+    """BASELINE config 5's collective as the multi-GPU line issues it — RCCL, side stream, `async_op=True`, byte views of the
+    int16 rows landing in one preallocated tensor — on a ONE-rank RCCL group (a one-GPU box cannot hold two RCCL ranks): the
+    gathered rows must equal the plain single-process run, and the line must carry both rates."""
+    import numpy as np
+    common = ["--workload", "iqbb_usb", "--channels", "16", "--samples", "32768", "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
+              "--sustain-seconds", "0", "--verify-channels", "4"]
+    one, two = str(tmp_path / "plain.npy"), str(tmp_path / "rccl.npy")
+    d1 = _bench(common + ["--dump-output", one])
+    d2 = _bench(common + ["--force-dist", "--gather", "--dump-output", two])
+    assert d2["verified"] is True and d2["roofline"]["ranks_seen"] == 1
+    assert d2["roofline"]["with_gather_msamples_s"] > 0 and d2["roofline"]["without_gather_msamples_s"] > 0
+    assert "gathered" in d2["config"]["parallelism"]
+    a, b = np.load(one), np.load(two)
+    assert a.shape == b.shape and np.array_equal(a, b) and np.count_nonzero(a) > a.size // 2
