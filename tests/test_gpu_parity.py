@@ -2,6 +2,8 @@
 compiled reference and (b) the CPU oracle on seeded inputs. Bit-exact for every int16 path;
 max|y - y_ref| / max|y_ref| <= 1e-5 for float / FFT paths (BASELINE.json north_star).
 Run with `pytest -m gpu` on an MI355X."""
+import os
+
 import numpy as np
 import pytest
 
@@ -508,6 +510,39 @@ def test_iqbb_full_size_properties(ctx, orc, k1path):
     whole = n1.process(x)
     parts = np.concatenate([n2.process(x[:, :30001]), n2.process(x[:, 30001:])], axis=1)
     assert np.array_equal(whole, parts)
+
+
+@pytest.mark.parametrize("order,cu8", [(127, False), (16, False), (127, True)])
+def test_timed_workload_every_channel_vs_oracle(ctx, orc, order, cu8):
+    """bench.py's own workload — 1024 DISTINCT channels (its on-device generator, two tones + hashed noise per channel),
+    65536 samples, two calls — with EVERY channel of both calls against the oracle (threads: the oracle library releases
+    the GIL), for the headline plan, the reference's 16-tap plan and complex<uint8> input: what the timed kernel computes
+    on the timed data is the reference's arithmetic, channel for channel (bench.py itself samples 32 channels per run)."""
+    import concurrent.futures
+    import bench
+    C, N, D = 1024, 65536, 8
+    dev = torch.device("cuda", 0)
+    x = np.stack([bench.synth_cs16(torch, C, N, dev, 1234 + b).cpu().numpy() for b in range(2)])   # [call, C, N, 2]
+    if cu8:
+        x = (((x.astype(np.int32) >> 6) + 127).clip(0, 255)).astype(np.uint8)
+    taps = sa.design_iqbb_taps(100e3, 50e3, FS, order)
+    lut, inc = sa.design_freqshift_lut_i16(), sa.design_freqshift_inc(100e3, FS)
+    node = sa.IQBaseBandI16(ctx, taps, lut, inc, False, D, channels=C, max_in=N, epilogue=sa.EPI_FM)
+    if cu8:
+        node.set_input_format(sa.abi.IN_CU8)
+    assert node.kernel_names == ["iqbb_hot_kernel"]
+    y = [node.process(x[0]), node.process(x[1])]
+
+    def check(c):
+        bb, fm = orc.IQBaseBandI16(taps, lut, inc, False, D), orc.FMDemodI16()
+        for k in range(2):
+            r = fm.process(bb.process(orc.autocast_cu8_cs16(x[k, c]) if cu8 else x[k, c]))
+            if not np.array_equal(y[k][c], r):
+                return c
+        return -1
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4)) as ex:
+        bad = [c for c in ex.map(check, range(C)) if c >= 0]
+    assert not bad, bad[:10]
 
 
 @pytest.mark.parametrize("epi,n_out", [(sa.EPI_FM, 630), (sa.EPI_FM, 693), (sa.EPI_NONE, 576), (sa.EPI_USB, 640), (sa.EPI_FM, 631)])
