@@ -16,7 +16,7 @@ __global__ __launch_bounds__(NT) void k(int iters, double *out, unsigned long lo
         if (MODE == 0) a[i] = __dmul_rn(a[i], al);
         else if (MODE == 1) a[i] = __dadd_rn(a[i], x);
         else if (MODE == 2) { double t; asm volatile("v_trunc_f64 %0, %1" : "=v"(t) : "v"(a[i])); a[i] = t; }
-        else a[i] = __builtin_trunc(__dadd_rn(a[i], __dmul_rn(al, x)));
+        else a[i] = __builtin_trunc(__dadd_rn(a[i], __dmul_rn(al, a[(i + 3) & 7])));   // (the product is not loop invariant)
       }
     }
   }

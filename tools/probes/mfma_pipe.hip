@@ -15,13 +15,14 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 #define VALU6(P, r) do { x0 = x0 * 3 + P##0[r]; x1 = (x1 << 1) ^ P##1[r]; x2 = x2 + (P##2[r] >> 3); x3 = x3 ^ (x4 >> 1); x4 = x4 + x5; x5 = x5 ^ x0; } while (0)
 
 template <int NT, int NM, int NVG, int MODE>   // NVG groups of 6 vector instructions; MODE 0 = alternate phases, 1 = interleave
-__global__ __launch_bounds__(NT) void k(int iters, const v4i *src, int *out) {
+__global__ __launch_bounds__(NT) void k(int iters, const v4i *src, int *out, unsigned long long *clk) {
   __shared__ v4i buf[2048];
   for (int i = threadIdx.x; i < 2048; i += NT) buf[i] = src[i];
   __syncthreads();
   v16i c0 = {0}, c1 = {0}, c2 = {0}, p0 = {0}, p1 = {0}, p2 = {0};
   int x0 = threadIdx.x, x1 = 3, x2 = 5, x3 = 7, x4 = 11, x5 = 13;
   const int l = threadIdx.x & 63;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   auto body = [&](auto par_, int i) __attribute__((always_inline)) {
     asm volatile("" ::: "memory");
     constexpr int PAR = decltype(par_)::value;
@@ -81,25 +82,30 @@ __global__ __launch_bounds__(NT) void k(int iters, const v4i *src, int *out) {
     body(std::integral_constant<int, 0>{}, i);
     body(std::integral_constant<int, 1>{}, i + 1);
   }
+  if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = __builtin_amdgcn_s_memtime() - t0; clk[1] = __builtin_amdgcn_s_memrealtime() - r0; }
   out[blockIdx.x * NT + threadIdx.x] = c0[0] + c1[1] + c2[2] + p0[3] + p1[4] + p2[5] + x0 + x1 + x2 + x3 + x4 + x5;
 }
 
+static unsigned long long *g_clk; static double g_ghz;
 template <int NT, int NM, int NVG, int MODE> float run(int iters, const v4i *src, int *d) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  for (int w = 0; w < 3; w++) hipLaunchKernelGGL((k<NT, NM, NVG, MODE>), dim3(256), dim3(NT), 0, 0, iters, src, d);   // warm up: the clock settles
+  for (int w = 0; w < 3; w++) hipLaunchKernelGGL((k<NT, NM, NVG, MODE>), dim3(256), dim3(NT), 0, 0, iters, src, d, g_clk);   // warm up: the clock settles
   (void)hipEventRecord(e0);
-  hipLaunchKernelGGL((k<NT, NM, NVG, MODE>), dim3(256), dim3(NT), 0, 0, iters, src, d);
+  hipLaunchKernelGGL((k<NT, NM, NVG, MODE>), dim3(256), dim3(NT), 0, 0, iters, src, d, g_clk);
   (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+  unsigned long long h[2]; (void)hipMemcpy(h, g_clk, 16, hipMemcpyDeviceToHost);
+  g_ghz = (double)h[0] / (double)h[1] / 10.0;   // shader cycles per 100 MHz tick: the clock this kernel held
   float ms; (void)hipEventElapsedTime(&ms, e0, e1); return ms;
 }
 
 int main() {
   int *d; (void)hipMalloc(&d, 256 * 1024 * 4);
-  v4i *src; (void)hipMalloc(&src, 2048 * 16);
+  v4i *src; (void)hipMalloc(&src, 2048 * 16); (void)hipMalloc(&g_clk, 16);
   { int h[2048 * 4]; srand(7); for (int i = 0; i < 2048 * 4; i++) h[i] = rand() ^ (rand() << 16); (void)hipMemcpy(src, h, sizeof(h), hipMemcpyHostToDevice); }
   const int it = 20000;
-#define ROW(NM, NVG, MODE) printf("  %-12s 1 wave/SIMD %5.0f   2 waves %5.0f   3 waves %5.0f   4 waves %5.0f\n", MODE ? "interleaved" : "alternating", \
-    run<256, NM, NVG, MODE>(it, src, d) * 1e6 / it, run<512, NM, NVG, MODE>(it, src, d) * 1e6 / it / 2, run<768, NM, NVG, MODE>(it, src, d) * 1e6 / it / 3, run<1024, NM, NVG, MODE>(it, src, d) * 1e6 / it / 4)
+#define ROW(NM, NVG, MODE) do { const double a1 = run<256, NM, NVG, MODE>(it, src, d) * 1e6 / it, g1 = g_ghz, a2 = run<512, NM, NVG, MODE>(it, src, d) * 1e6 / it / 2, g2 = g_ghz, \
+    a3 = run<768, NM, NVG, MODE>(it, src, d) * 1e6 / it / 3, g3 = g_ghz; \
+    printf("  %-12s 1 wave/SIMD %5.0f ns (%.2f GHz)   2 waves %5.0f (%.2f)   3 waves %5.0f (%.2f)\n", MODE ? "interleaved" : "alternating", a1, g1, a2, g2, a3, g3); } while (0)
   printf("ns per wave-iteration per SIMD; 28 MFMA (32 LDS operand reads) + 168 vector instructions (K1 at 127 taps):\n");
   ROW(28, 28, 0); ROW(28, 28, 1);
   printf("8 MFMA + 168 vector instructions (K1 at 16 taps):\n");
