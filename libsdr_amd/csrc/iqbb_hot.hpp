@@ -33,15 +33,20 @@
 namespace sdrhip {
 
 // ---- geometry shared by host and device ----------------------------------------------------------------------
-constexpr int hot_win(int S) { return 512 + 16 * (S - 1); }                    // samples in a wave window
-constexpr int hot_plb(int S) { return 2 * hot_win(S) + 32; }                   // bytes per byte plane (+ one chunk pair: both parity halves 16-byte aligned)
-constexpr int hot_bufb(int S, bool cu8) { return cu8 ? hot_plb(S) : 2 * hot_plb(S); }   // one window buffer
-constexpr int hot_lds_bytes(int S, int NH, bool cu8, int NW, bool wide) {
-  return (wide ? 4096 : 1024) + (S + NH) * 1024 + NW * 2 * hot_bufb(S, cu8);
+// input kinds: complex<int16> (one dword per sample), complex<uint8> (AutoCast fused), real int16 (BaseBand<int16_t>: the
+// element stream is the sample stream itself — a block advances by 16 elements instead of 32, a tap row by 1 instead of 2)
+enum { HOT_CS16 = 0, HOT_CU8 = 1, HOT_REAL = 2 };
+constexpr int hot_halo(int S, int in) { return in == HOT_REAL ? 32 * S - 16 : 16 * (S - 1); }   // samples before the slice's first one
+constexpr int hot_win(int S, int in) { return 512 + hot_halo(S, in) + (in == HOT_REAL ? 16 : 0); }   // samples in a wave window (real: whole 16-byte pieces)
+// bytes per byte plane: complex kinds 2 per sample (+ one chunk pair: both parity halves 16-byte aligned), real 1 per sample
+constexpr int hot_plb(int S, int in) { return in == HOT_REAL ? hot_win(S, in) : 2 * hot_win(S, in) + 32; }
+constexpr int hot_bufb(int S, int in) { return in == HOT_CU8 ? hot_plb(S, in) : 2 * hot_plb(S, in); }   // one window buffer
+constexpr int hot_lds_bytes(int S, int NH, int in, int NW, bool wide) {
+  return (wide ? 4096 : 1024) + (S + NH) * 1024 + NW * 2 * hot_bufb(S, in);
 }
 constexpr int hot_lds_cap(int NW) { return NW == 4 ? 40960 : NW == 8 ? 81920 : 163840; }   // 4 waves per SIMD: 160 KB / workgroups per CU
 // 4 KB rotation table ({Lx, Ly, -Ly, 0} x 256: one SDWA shift makes the address, no subtraction) while it fits
-constexpr bool hot_wide(int S, int NH, bool cu8, int NW) { return hot_lds_bytes(S, NH, cu8, NW, true) <= hot_lds_cap(NW); }
+constexpr bool hot_wide(int S, int NH, int in, int NW) { return hot_lds_bytes(S, NH, in, NW, true) <= hot_lds_cap(NW); }
 
 struct HotRange { int S0, NH, NW; };
 // per S: centred high-plane ranges, narrowest first; the last one covers every step
@@ -63,13 +68,14 @@ inline const HotRange *hot_ranges(int S, int *count) {
 
 struct HotLaunch { unsigned grid; hipStream_t stream; };
 // one function per translation unit (iqbb_hot_s*.hip): `range` indexes hot_ranges(S)
-void hot_launch_s2(bool cu8, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
-void hot_launch_s3(bool cu8, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
-void hot_launch_s5(bool cu8, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
+void hot_launch_s2(int in, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
+void hot_launch_s3(int in, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
+void hot_launch_s5(int in, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
 void hot_launch_s9_cs16(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
 void hot_launch_s9_cu8(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
 void hot_launch_s17_cs16(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
 void hot_launch_s17_cu8(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
+void hot_launch_real(int S, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);   // S = 5 or 9
 
 }  // namespace sdrhip
 
@@ -80,24 +86,28 @@ namespace {
 // (carry, the D+1 first window, FM's out[0] / out[1] rules) nor its last emitted one (that group hands the demodulator's
 // angle and the window carry to the next call — state only the cold phase's epilogue writes; found by
 // test_one_launch_kernel_random_long_calls), and all of them complete and are emitted.
-__host__ __device__ __forceinline__ bool slice_is_hot(int halo, int base0_rel, int OG, int ovl, int N, int n_out, int tile, int w) {
+__host__ __device__ __forceinline__ bool slice_is_hot(int halo, int win, int base0_rel, int OG, int ovl, int N, int n_out, int tile, int w) {
   const int qf = tile * OG - ovl + w * (64 - ovl);   // the slice's first group (output index within the call)
   const int ws = base0_rel + qf * 8 - halo;          // its window's first sample (N < 2^30: no overflow)
-  return ws >= 0 && ws + 512 + halo <= N && qf >= 1 && qf + 63 < n_out - 1;
+  return ws >= 0 && ws + win <= N && qf >= 1 && qf + 63 < n_out - 1;
 }
 
-template <int S, int S0, int NH, bool ROT, int EPI, bool CU8, int NW>
+template <int S, int S0, int NH, bool ROT, int EPI, int IN, int NW>
 __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &b) {
+  constexpr bool CU8 = IN == HOT_CU8, REAL = IN == HOT_REAL;
   static_assert(S >= 2 && S0 >= 0 && NH >= 1 && S0 + NH <= S, "high-plane range inside the K loop");
+  static_assert(!REAL || NW == 4, "real input: 4-wave workgroups");
   static_assert(NW == 4 || NW == 8 || NW == 16, "4-wave virtual workgroups");
-  constexpr int HALO = 16 * (S - 1), WIN = hot_win(S), PLB = hot_plb(S), HALF = PLB / 2, BUFB = hot_bufb(S, CU8);
-  constexpr int NPIECE = (CU8 ? 2 * WIN : 4 * WIN) / 16;        // 16-byte pieces of the raw window (cs16: 4 samples, cu8: 8)
+  constexpr int HALO = hot_halo(S, IN), WIN = hot_win(S, IN), PLB = hot_plb(S, IN), HALF = PLB / 2, BUFB = hot_bufb(S, IN);
+  constexpr int NPIECE = (IN == HOT_CS16 ? 4 * WIN : 2 * WIN) / 16;   // 16-byte pieces of the raw window (cs16: 4 samples, cu8 / real: 8)
+  constexpr int KSB = REAL ? 32 : 16;   // plane bytes a K step advances by (real: a block's window moves 16 elements per column, 32 per step)
+  constexpr int FSH = REAL ? 16 : 14;   // the FIR's right shift (Traits<int16_t>::shift for the real node, the literal 14 of IQBaseBand)
   constexpr int NDMA = (NPIECE + 63) / 64;                     // DMA wave-instructions per window
   constexpr int LASTL = NPIECE - 64 * (NDMA - 1);              // lanes of the last one
   static_assert(NDMA <= 3, "immediate offsets 0 / 1024 / 2048");
-  constexpr bool WIDE = hot_wide(S, NH, CU8, NW);
+  constexpr bool WIDE = hot_wide(S, NH, IN, NW);
   constexpr int NBUF = 2;   // window buffers per wave
-  static_assert(hot_lds_bytes(S, NH, CU8, NW, WIDE) <= hot_lds_cap(NW), "LDS budget for 4 waves per SIMD");
+  static_assert(hot_lds_bytes(S, NH, IN, NW, WIDE) <= hot_lds_cap(NW), "LDS budget for 4 waves per SIMD");
   constexpr int TBLW = WIDE ? 1024 : 256;   // dwords
   constexpr int TPBH = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -130,8 +140,8 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   // monotone in the tile — the same for every channel: found once per wave, so that the loop below tests tile numbers
   // instead of evaluating the conditions per slice.
   int hl = a.t_lo, hh = a.t_hi;
-  while (hl < hh && !slice_is_hot(HALO, a.base0_rel, a.OG, a.ovl, a.N, a.n_out, hl, wv)) hl++;
-  while (hh > hl && !slice_is_hot(HALO, a.base0_rel, a.OG, a.ovl, a.N, a.n_out, hh - 1, wv)) hh--;
+  while (hl < hh && !slice_is_hot(HALO, WIN, a.base0_rel, a.OG, a.ovl, a.N, a.n_out, hl, wv)) hl++;
+  while (hh > hl && !slice_is_hot(HALO, WIN, a.base0_rel, a.OG, a.ovl, a.N, a.n_out, hh - 1, wv)) hh--;
   int u = bx;
   int c = u / a.G, g = u - c * a.G;   // (one division per wave, at start; afterwards (c, g) advance by (dq, dr))
   int tile = max(a.t_lo + g * a.tpw, hl), tend = min(a.t_lo + g * a.tpw + a.tpw, hh);
@@ -150,7 +160,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   // global pointer: scalar base + the lane's 32-bit byte offset, ONE 64-bit vector add per slice; the DMA pieces differ
   // by the instruction's immediate offset, which applies to the global AND the LDS address alike.
   const uint32_t lane_byte = 16u * (uint32_t)l;
-  constexpr int SB = CU8 ? 2 : 4;                              // bytes per input sample
+  constexpr int SB = IN == HOT_CS16 ? 4 : 2;                   // bytes per input sample
   constexpr int OB = EPI == SDRHIP_EPI_NONE ? 4 : 2;           // bytes per output element
   const int tile_in_bytes = a.OG * 8 * SB, tile_out_bytes = a.OG * OB;
   const uint32_t tile_cnt = (uint32_t)(a.OG * 8) * a.inc;      // LUT phase counter advance per tile
@@ -193,10 +203,11 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
 #pragma unroll
   for (int k = 0; k < NDMA; k++) {
     const int p = l + 64 * k;
-    if (CU8) dofs[k] = (p & 1) * HALF + (p >> 1) * 16;
+    if (REAL) dofs[k] = 8 * p;   // linear planes: consecutive lanes read consecutive 16-byte chunks as it is
+    else if (CU8) dofs[k] = (p & 1) * HALF + (p >> 1) * 16;
     else { const int j = p >> 1; dofs[k] = (j & 1) * HALF + (j >> 1) * 16 + (p & 1) * 8; }
   }
-  const int coff = h * HALF + 16 * n;   // chunk 2(n + s) + h of the wave's window
+  const int coff = REAL ? 16 * (n + h) : h * HALF + 16 * n;   // chunk 2(n + s) + h of the wave's window (real: chunk n + 2s + h)
   // phase counters of the lane's samples 0 and 1 relative to the wave's first sample, as a 16-bit pair (only bits 8..14
   // of a counter pick the table entry); the wave's part is scalar and joins per slice in one v_pk_add_u16 per sample pair
   const uint32_t lane_cnt = (uint32_t)(MF_BLK * n + 8 * h) * a.inc;
@@ -271,8 +282,8 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
     for (int s = SA; s < SB; s++) {
       KOps nx = o;
       if (s + 1 < S) {
-        nx.uh = *reinterpret_cast<const v4i *>(ph + 16 * (s + 1));
-        if (!CU8) nx.ul = *reinterpret_cast<const v4i *>(pl + 16 * (s + 1));
+        nx.uh = *reinterpret_cast<const v4i *>(ph + KSB * (s + 1));
+        if (!CU8) nx.ul = *reinterpret_cast<const v4i *>(pl + KSB * (s + 1));
         nx.Al = taps_s[(s + 1) * 64 + l];
         if (s + 1 >= S0 && s + 1 < S0 + NH) nx.Ah = taps_s[(S + s + 1 - S0) * 64 + l];
       }
@@ -330,7 +341,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
         rr = __builtin_amdgcn_sbfe((int)tre, 6, 18); ri = __builtin_amdgcn_sbfe((int)tim, 6, 18);
       } else {
         asm("" : "+v"(tre)); asm("" : "+v"(tim));   // no re-association into 2 shifts + add3
-        rr = (int)((tre << 8) + (unsigned)acc_ll[2 * j]) >> 14; ri = (int)((tim << 8) + (unsigned)acc_ll[2 * j + 1]) >> 14;
+        rr = (int)((tre << 8) + (unsigned)acc_ll[2 * j]) >> FSH; ri = (int)((tim << 8) + (unsigned)acc_ll[2 * j + 1]) >> FSH;
       }
       if (ROT) {
         const int x = WIDE ? mad24a(L[j][0], rr, mul24a(L[j][2], ri)) : sub32(mul24a(L[j][0], rr), mul24a(L[j][1], ri));
@@ -455,12 +466,44 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
 #endif
       for (int t = 0; t < b.tiles; t = (t == 0 ? max(b.bt_hi, 1) : t + 1)) {
         const int q0 = t * a.OG - a.ovl, groups_here = min(b.CG, b.n_groups - q0);
-        if (slice_is_hot(HALO, a.base0_rel, a.OG, a.ovl, a.N, a.n_out, t, wv) || gw + a.ovl >= groups_here) continue;
+        if (slice_is_hot(HALO, WIN, a.base0_rel, a.OG, a.ovl, a.N, a.n_out, t, wv) || gw + a.ovl >= groups_here) continue;
         // the wave's window by ordinary loads: history / input / zeros per sample, every load issued from a clamped
         // address and masked afterwards (all in flight together)
         const int first = a.base0_rel + (q0 + gw) * 8 - HALO;
         const uint32_t *hrow = b.hist_old + (long)cc * b.HH;
-        if (CU8) {
+        if (REAL) {   // 8 real samples per piece: input int16, or the low half of a history dword
+          const uint16_t *row = reinterpret_cast<const uint16_t *>(a.in) + (long)cc * a.in_stride;
+          uint32_t v[NDMA][8];
+#pragma unroll
+          for (int k = 0; k < NDMA; k++) {
+            const int pp = min(l + 64 * k, NPIECE - 1);
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[k][j] = row[max(min(first + 8 * pp + j, a.N - 1), 0)];
+          }
+#pragma unroll
+          for (int k = 0; k < NDMA; k++) {
+            const int pp = min(l + 64 * k, NPIECE - 1);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+              const int rel = first + 8 * pp + j;
+              if (rel >= a.N) v[k][j] = 0u;
+              if (first < 0) {   // (wave-uniform: only the call's first slices reach into the history)
+                const uint32_t xh = hrow[max(b.HH + rel, 0)];
+                if (rel < 0) v[k][j] = (b.HH + rel >= 0) ? (xh & 0xffffu) : 0u;
+              }
+            }
+            if (k < NDMA - 1 || l < LASTL) {
+              const uint32_t x0 = v[k][0] | (v[k][1] << 16), x1 = v[k][2] | (v[k][3] << 16), x2 = v[k][4] | (v[k][5] << 16), x3 = v[k][6] | (v[k][7] << 16);
+              uint2 l2, h2;
+              l2.x = __builtin_amdgcn_perm(x1, x0, 0x06040200u) ^ 0x80808080u;
+              l2.y = __builtin_amdgcn_perm(x3, x2, 0x06040200u) ^ 0x80808080u;
+              h2.x = __builtin_amdgcn_perm(x1, x0, 0x07050301u);
+              h2.y = __builtin_amdgcn_perm(x3, x2, 0x07050301u);
+              *reinterpret_cast<uint2 *>(cb + dofs[k]) = l2;
+              *reinterpret_cast<uint2 *>(cb + PLB + dofs[k]) = h2;
+            }
+          }
+        } else if (CU8) {
           const uint16_t *row = reinterpret_cast<const uint16_t *>(a.in) + (long)cc * a.in_stride;
           uint32_t v[NDMA][8];
 #pragma unroll
@@ -529,11 +572,11 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
         const char *pl = cb + coff, *ph = cb + (CU8 ? 0 : PLB) + coff;
 #pragma unroll
         for (int s_ = 0; s_ < S; s_++) {
-          const v4i uh = *reinterpret_cast<const v4i *>(ph + 16 * s_);
+          const v4i uh = *reinterpret_cast<const v4i *>(ph + KSB * s_);
           const v4i Al = taps_s[s_ * 64 + l];
           acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, uh, acc_mid, 0, 0, 0);
           if (!CU8) {
-            const v4i ul = *reinterpret_cast<const v4i *>(pl + 16 * s_);
+            const v4i ul = *reinterpret_cast<const v4i *>(pl + KSB * s_);
             acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, ul, acc_ll, 0, 0, 0);
             if (s_ >= S0 && s_ < S0 + NH) {
               const v4i Ah = taps_s[(S + s_ - S0) * 64 + l];
@@ -545,7 +588,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
           }
         }
         const int tb = a.base0_rel + q0 * 8, rel0 = tb + 8 * gw + MF_BLK * n + 8 * h;
-        const int2 sum = group_sum<ROT, CU8, true, WIDE ? 2 : 1>(b, acc_hh, acc_mid, acc_ll, rel0);
+        const int2 sum = group_sum<ROT, CU8, true, WIDE ? 2 : 1, FSH>(b, acc_hh, acc_mid, acc_ll, rel0);
         group_finish(b, b.lut, cc, n, h, gw, q0, groups_here, sum);   // (its one table user, the stream's first sample, reads global memory)
         asm volatile("" ::: "memory");
       }
@@ -570,16 +613,16 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
 #define K1_MINWAVES 4
 #endif
 // One launch per call: the hot grid, then each virtual workgroup's share of the cold slices.
-template <int S, int S0, int NH, bool ROT, int EPI, bool CU8, int NW>
+template <int S, int S0, int NH, bool ROT, int EPI, int IN, int NW>
 __global__ __launch_bounds__(64 * NW, K1_MINWAVES) void iqbb_hot_kernel(const HotArgs a, const IqbbArgs b) {
-  iqbb_hot_body<S, S0, NH, ROT, EPI, CU8, NW>(a, b);
+  iqbb_hot_body<S, S0, NH, ROT, EPI, IN, NW>(a, b);
 }
 
-template <int S, int S0, int NH, bool CU8, int NW>
+template <int S, int S0, int NH, int IN, int NW>
 void hot_launch_one(bool rot, int epi, const HotLaunch &hl, const HotArgs &ha, const IqbbArgs &b) {
-  const size_t lds = (size_t)hot_lds_bytes(S, NH, CU8, NW, hot_wide(S, NH, CU8, NW));
+  const size_t lds = (size_t)hot_lds_bytes(S, NH, IN, NW, hot_wide(S, NH, IN, NW));
   const dim3 grid(hl.grid, 1), block(64 * NW);
-#define SDRHIP_HOT(R_, E_) hipLaunchKernelGGL((iqbb_hot_kernel<S, S0, NH, R_, E_, CU8, NW>), grid, block, lds, hl.stream, ha, b)
+#define SDRHIP_HOT(R_, E_) hipLaunchKernelGGL((iqbb_hot_kernel<S, S0, NH, R_, E_, IN, NW>), grid, block, lds, hl.stream, ha, b)
 #define SDRHIP_HOT_E(R_) do { switch (epi) { \
     case SDRHIP_EPI_FM: SDRHIP_HOT(R_, SDRHIP_EPI_FM); break; \
     case SDRHIP_EPI_AM: SDRHIP_HOT(R_, SDRHIP_EPI_AM); break; \

@@ -5,9 +5,9 @@
 namespace sdrhip {
 void hot_launch_s17_cs16(int range, bool rot, int epi, const HotLaunch &hl, const HotArgs &ha, const IqbbArgs &b) {
   switch (range) {
-    case 0: hot_launch_one<17, 6, 5, false, 8>(rot, epi, hl, ha, b); break;
-    case 1: hot_launch_one<17, 4, 9, false, 8>(rot, epi, hl, ha, b); break;
-    default: hot_launch_one<17, 0, 17, false, 16>(rot, epi, hl, ha, b); break;
+    case 0: hot_launch_one<17, 6, 5, HOT_CS16, 8>(rot, epi, hl, ha, b); break;
+    case 1: hot_launch_one<17, 4, 9, HOT_CS16, 8>(rot, epi, hl, ha, b); break;
+    default: hot_launch_one<17, 0, 17, HOT_CS16, 16>(rot, epi, hl, ha, b); break;
   }
 }
 }  // namespace sdrhip

@@ -3,9 +3,10 @@
 #include "iqbb_hot.hpp"
 
 namespace sdrhip {
-void hot_launch_s2(bool cu8, int range, bool rot, int epi, const HotLaunch &hl, const HotArgs &ha, const IqbbArgs &b) {
+void hot_launch_s2(int in, int range, bool rot, int epi, const HotLaunch &hl, const HotArgs &ha, const IqbbArgs &b) {
+  const bool cu8 = in == HOT_CU8;
   switch (range) {
-    default: if (cu8) hot_launch_one<2, 0, 2, true, 4>(rot, epi, hl, ha, b); else hot_launch_one<2, 0, 2, false, 4>(rot, epi, hl, ha, b); break;
+    default: if (cu8) hot_launch_one<2, 0, 2, HOT_CU8, 4>(rot, epi, hl, ha, b); else hot_launch_one<2, 0, 2, HOT_CS16, 4>(rot, epi, hl, ha, b); break;
   }
 }
 }  // namespace sdrhip

@@ -3,10 +3,11 @@
 #include "iqbb_hot.hpp"
 
 namespace sdrhip {
-void hot_launch_s5(bool cu8, int range, bool rot, int epi, const HotLaunch &hl, const HotArgs &ha, const IqbbArgs &b) {
+void hot_launch_s5(int in, int range, bool rot, int epi, const HotLaunch &hl, const HotArgs &ha, const IqbbArgs &b) {
+  const bool cu8 = in == HOT_CU8;
   switch (range) {
-    case 0: if (cu8) hot_launch_one<5, 1, 3, true, 4>(rot, epi, hl, ha, b); else hot_launch_one<5, 1, 3, false, 4>(rot, epi, hl, ha, b); break;
-    default: if (cu8) hot_launch_one<5, 0, 5, true, 4>(rot, epi, hl, ha, b); else hot_launch_one<5, 0, 5, false, 4>(rot, epi, hl, ha, b); break;
+    case 0: if (cu8) hot_launch_one<5, 1, 3, HOT_CU8, 4>(rot, epi, hl, ha, b); else hot_launch_one<5, 1, 3, HOT_CS16, 4>(rot, epi, hl, ha, b); break;
+    default: if (cu8) hot_launch_one<5, 0, 5, HOT_CU8, 4>(rot, epi, hl, ha, b); else hot_launch_one<5, 0, 5, HOT_CS16, 4>(rot, epi, hl, ha, b); break;
   }
 }
 }  // namespace sdrhip

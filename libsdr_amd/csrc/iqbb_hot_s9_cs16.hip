@@ -5,10 +5,10 @@
 namespace sdrhip {
 void hot_launch_s9_cs16(int range, bool rot, int epi, const HotLaunch &hl, const HotArgs &ha, const IqbbArgs &b) {
   switch (range) {
-    case 0: hot_launch_one<9, 3, 3, false, 4>(rot, epi, hl, ha, b); break;
-    case 1: hot_launch_one<9, 2, 5, false, 4>(rot, epi, hl, ha, b); break;
-    case 2: hot_launch_one<9, 1, 7, false, 4>(rot, epi, hl, ha, b); break;
-    default: hot_launch_one<9, 0, 9, false, 4>(rot, epi, hl, ha, b); break;
+    case 0: hot_launch_one<9, 3, 3, HOT_CS16, 4>(rot, epi, hl, ha, b); break;
+    case 1: hot_launch_one<9, 2, 5, HOT_CS16, 4>(rot, epi, hl, ha, b); break;
+    case 2: hot_launch_one<9, 1, 7, HOT_CS16, 4>(rot, epi, hl, ha, b); break;
+    default: hot_launch_one<9, 0, 9, HOT_CS16, 4>(rot, epi, hl, ha, b); break;
   }
 }
 }  // namespace sdrhip

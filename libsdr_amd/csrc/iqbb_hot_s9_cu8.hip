@@ -5,10 +5,10 @@
 namespace sdrhip {
 void hot_launch_s9_cu8(int range, bool rot, int epi, const HotLaunch &hl, const HotArgs &ha, const IqbbArgs &b) {
   switch (range) {
-    case 0: hot_launch_one<9, 3, 3, true, 4>(rot, epi, hl, ha, b); break;
-    case 1: hot_launch_one<9, 2, 5, true, 4>(rot, epi, hl, ha, b); break;
-    case 2: hot_launch_one<9, 1, 7, true, 4>(rot, epi, hl, ha, b); break;
-    default: hot_launch_one<9, 0, 9, true, 4>(rot, epi, hl, ha, b); break;
+    case 0: hot_launch_one<9, 3, 3, HOT_CU8, 4>(rot, epi, hl, ha, b); break;
+    case 1: hot_launch_one<9, 2, 5, HOT_CU8, 4>(rot, epi, hl, ha, b); break;
+    case 2: hot_launch_one<9, 1, 7, HOT_CU8, 4>(rot, epi, hl, ha, b); break;
+    default: hot_launch_one<9, 0, 9, HOT_CU8, 4>(rot, epi, hl, ha, b); break;
   }
 }
 }  // namespace sdrhip

@@ -941,11 +941,13 @@ __global__ __launch_bounds__(TPB, 3) void iqbb_i16_mfma16_kernel(const IqbbArgs 
 
 namespace {
 // the hot kernels live in one translation unit per filter-length class (iqbb_hot_s*.hip)
-void launch_hot(int S, bool cu8, int range, bool rot, int epi, const HotLaunch &hl, const HotArgs &ha, const IqbbArgs &b) {
+void launch_hot(int S, int in, int range, bool rot, int epi, const HotLaunch &hl, const HotArgs &ha, const IqbbArgs &b) {
+  if (in == HOT_REAL) { hot_launch_real(S, range, rot, epi, hl, ha, b); return; }
+  const bool cu8 = in == HOT_CU8;
   switch (S) {
-    case 2: hot_launch_s2(cu8, range, rot, epi, hl, ha, b); break;
-    case 3: hot_launch_s3(cu8, range, rot, epi, hl, ha, b); break;
-    case 5: hot_launch_s5(cu8, range, rot, epi, hl, ha, b); break;
+    case 2: hot_launch_s2(in, range, rot, epi, hl, ha, b); break;
+    case 3: hot_launch_s3(in, range, rot, epi, hl, ha, b); break;
+    case 5: hot_launch_s5(in, range, rot, epi, hl, ha, b); break;
     case 9: if (cu8) hot_launch_s9_cu8(range, rot, epi, hl, ha, b); else hot_launch_s9_cs16(range, rot, epi, hl, ha, b); break;
     default: if (cu8) hot_launch_s17_cu8(range, rot, epi, hl, ha, b); else hot_launch_s17_cs16(range, rot, epi, hl, ha, b); break;
   }
@@ -1017,6 +1019,12 @@ struct sdrhip_iqbb_i16 {
             if (ah != 0) ah_mask |= 1u << st;
             frag[(((size_t)(2 * st + 1) * 64 + l) * 16) + j] = (int8_t)al;
           }
+      {   // the hot kernel's compile-time high-plane range, as for path 1
+        int nr = 0;
+        const HotRange *rg = hot_ranges(S, &nr);
+        for (int r = 0; r < nr && hot_range < 0; r++)
+          if ((ah_mask & ~(((1u << rg[r].NH) - 1u) << rg[r].S0)) == 0) hot_range = r;
+      }
       if (!tapfrag.p) tapfrag.alloc((size_t)S * 2 * 64);
       tapfrag.upload(reinterpret_cast<const v4i *>(frag.data()), (size_t)S * 2 * 64, ctx->stream);
     } else if (path >= 1) {   // (a path 3 plan that fell back to the VALU kernel above has path 0 by now)
@@ -1088,8 +1096,8 @@ struct sdrhip_iqbb_i16 {
   // false: the call is too short to have a tile of hot slices; the general kernel runs it.
   bool launch_hot_call(IqbbArgs &a, const Geometry &g, const uint32_t *in_dev, size_t N, size_t in_stride, void *out_dev,
                        size_t out_stride, int tiles) {
-    const int halo = 16 * (S - 1);
-    auto host_hot = [&](int t, int w) { return slice_is_hot(halo, g.base0_rel, OG, ovl, (int)N, g.n_out, t, w); };
+    const int kind = real ? HOT_REAL : in_cu8 ? HOT_CU8 : HOT_CS16, halo = hot_halo(S, kind), win = hot_win(S, kind);
+    auto host_hot = [&](int t, int w) { return slice_is_hot(halo, win, g.base0_rel, OG, ovl, (int)N, g.n_out, t, w); };
     long t = tiles - 1;   // the last tile always holds cold slices (history roll, state)
     while (t >= 2 && !(host_hot((int)t - 1, 0) && host_hot((int)t - 1, 1) && host_hot((int)t - 1, 2) && host_hot((int)t - 1, 3))) t--;
     if (t < 2) return false;
@@ -1120,7 +1128,7 @@ struct sdrhip_iqbb_i16 {
     ha.dq = gx / ha.G; ha.dr = gx % ha.G;
     a.bt_hi = (int)t; a.tpw = 1;
     HotLaunch hl{(unsigned)grid, ctx->stream};
-    launch_hot(S, in_cu8 != 0, hot_range, inc != 0, epi, hl, ha, a);
+    launch_hot(S, kind, hot_range, inc != 0, epi, hl, ha, a);
     return true;
   }
 
@@ -1153,18 +1161,14 @@ struct sdrhip_iqbb_i16 {
     a.tiles = tiles; a.tpw = tpw; a.bt_hi = 0;
     a.lpg = 1; while (a.lpg < 64 && a.lpg * 8 < D) a.lpg <<= 1;
     dim3 grid((unsigned)ceil_div((size_t)tiles, (size_t)tpw), C), block(TPB);
-    if (path == 4) {
+    if (path == 4 && use_hot && hot_range >= 0 && tiles >= 3 && launch_hot_call(a, g, in_dev, N, in_stride, out_dev, out_stride, tiles)) {
+      // (real int16 input: the hot kernel took the whole call)
+    } else if (path == 4) {
 #define SDRHIP_MFR(S_) do { if (inc != 0) hipLaunchKernelGGL((bb_real_mfma_kernel<S_, true>), grid, block, lds_bytes, ctx->stream, a); \
                              else hipLaunchKernelGGL((bb_real_mfma_kernel<S_, false>), grid, block, lds_bytes, ctx->stream, a); } while (0)
       switch (S) {
-        case 1: SDRHIP_MFR(1); break;
-        case 2: SDRHIP_MFR(2); break;
         case 3: SDRHIP_MFR(3); break;
-        case 4: SDRHIP_MFR(4); break;
         case 5: SDRHIP_MFR(5); break;
-        case 6: SDRHIP_MFR(6); break;
-        case 7: SDRHIP_MFR(7); break;
-        case 8: SDRHIP_MFR(8); break;
         default: SDRHIP_MFR(9); break;
       }
 #undef SDRHIP_MFR
@@ -1302,7 +1306,7 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
         if (fits) h->path = 4;
       }
       if (h->path == 4) {
-        h->S = (order + 15 + 31) / 32;
+        h->S = order <= 81 ? 3 : order <= 145 ? 5 : 9;   // the hot kernel's filter-length classes (K steps of 32 real samples)
         h->OP = 32 * h->S - 15;
       } else if (h->path == 2) {
         h->S = (2 * order + 14 + 63) / 64;
@@ -1385,7 +1389,8 @@ int sdrhip_iqbb_i16_kernel_names(sdrhip_iqbb_i16 *h, char *buf, size_t len) {
   return guarded([&] {
     SDRHIP_REQUIRE(h && buf && len, SDRHIP_E_INVALID, "NULL argument");
     const char *nm = "iqbb_i16_kernel";
-    if (h->path == 4) nm = "bb_real_mfma_kernel";
+    if (h->path == 4 && h->use_hot && h->hot_range >= 0) nm = "iqbb_hot_kernel";   // (calls of < 3 tiles: the general kernel)
+    else if (h->path == 4) nm = "bb_real_mfma_kernel";
     else if (h->path == 3) nm = "iqbb_i16_mfmag_kernel";
     else if (h->path == 2) nm = "iqbb_i16_mfma16_kernel";
     else if (h->path == 1 && h->use_dma && h->use_hot && h->hot_range >= 0) nm = "iqbb_hot_kernel";   // (calls of < 3 tiles: the general kernel)

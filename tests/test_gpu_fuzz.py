@@ -279,9 +279,12 @@ def test_hot_kernel_every_length_class_random_long_calls(ctx, orc, seed, cu8):
     _hot_fuzz(ctx, orc, rng, int(rng.choice([3, 16, 17, 21, 33, 34, 64, 65, 66, 100, 127, 130, 200, 255, 257])), cu8)
 
 
+@pytest.mark.parametrize("hot", [True, False])
 @pytest.mark.parametrize("seed", range(16 + EXTRA))
-def test_bb_real_mfma_random_long_calls(ctx, orc, seed):
-    """The real-input BaseBand<int16> at decimation 8 on the matrix cores (1 .. 9 K steps by order), long ragged calls."""
+def test_bb_real_mfma_random_long_calls(ctx, orc, seed, hot, monkeypatch):
+    """The real-input BaseBand<int16> at decimation 8 on the matrix cores (3, 5 or 9 K steps by order), long ragged calls:
+    the hot kernel's real-input instantiation, and the general kernel alone."""
+    monkeypatch.setenv("SDRHIP_IQBB_HOT", "1" if hot else "0")
     rng = np.random.default_rng(9000 + seed)
     order = int(rng.choice([5, 17, 21, 33, 64, 100, 127, 128, 160, 200, 255, 273]))
     Fc = float(rng.choice([100e3, -100e3, 0.0, 41e3]))
@@ -293,6 +296,7 @@ def test_bb_real_mfma_random_long_calls(ctx, orc, seed):
     lens = [int(rng.integers(2000, 40000)) for _ in range(3)] + [int(rng.choice([0, 1, 7, 2015, 2016, 2017, 2048]))]
     rng.shuffle(lens)
     bb = sa.BaseBandI16(ctx, taps, lut, inc, Fc < 0, 8, channels=C, max_in=max(max(lens), 1), epilogue=epi)
+    assert bb.kernel_names == (["iqbb_hot_kernel"] if hot else ["bb_real_mfma_kernel"])
     refs = [orc.BaseBandI16(taps, lut, inc, Fc < 0, 8) for _ in range(C)]
     fms = [orc.FMDemodI16() for _ in range(C)]
     for n in lens:

@@ -304,15 +304,21 @@ BB_REAL_CASES = [("g10_bb21d8", "g10_real_in"), ("g10_bb127d8_neg_ragged", "g10_
                  ("g10_bb16d1_noshift", "g10_real_in"), ("g10_bb1d3", "g10_real_in"), ("g10_bb127d8_loud", "g10_real_loud_in")]
 
 
-@pytest.fixture(params=["auto", "valu"])
+@pytest.fixture(params=["auto", "general", "valu"])
 def bbpath(request, monkeypatch):
-    """The real-input node has two bit-exact kernels: the int8-MFMA formulation (path 4: decimation 8, taps within two byte
-    planes, up to 273 taps) and the VALU kernel (everything else, and on request)."""
+    """The real-input node has three bit-exact kernels: the int8-MFMA formulation (path 4: decimation 8, taps within two
+    byte planes, up to 273 taps) as the hot kernel's real-input instantiation (calls of >= 3 tiles) and as the general
+    kernel (short calls, and alone with SDRHIP_IQBB_HOT=0), and the VALU kernel (everything else, and on request)."""
+    monkeypatch.delenv("SDRHIP_IQBB_PATH", raising=False)
+    monkeypatch.delenv("SDRHIP_IQBB_HOT", raising=False)
     if request.param == "valu":
         monkeypatch.setenv("SDRHIP_IQBB_PATH", "valu")
-    else:
-        monkeypatch.delenv("SDRHIP_IQBB_PATH", raising=False)
+    elif request.param == "general":
+        monkeypatch.setenv("SDRHIP_IQBB_HOT", "0")
     return request.param
+
+
+BB_REAL_KERNEL = {"auto": ["iqbb_hot_kernel"], "general": ["bb_real_mfma_kernel"], "valu": ["iqbb_i16_kernel"]}
 
 
 @pytest.mark.parametrize("case,inp", BB_REAL_CASES)
@@ -321,8 +327,8 @@ def test_bb_real_golden(ctx, golden, case, inp, bbpath):
     assert np.array_equal(sa.design_bb_taps(m["Ff"], m["width"], m["Fs"], m["order"]), golden.load(case + "_taps").reshape(-1, 2))
     bb = sa.BaseBandI16(ctx, golden.load(case + "_taps"), sa.design_freqshift_lut_i16(), m["lut_inc"], m["negative"], m["decim"],
                         max_in=4096)
-    if bbpath == "auto" and m["decim"] == 8:
-        assert bb.kernel_names == ["bb_real_mfma_kernel"]
+    if m["decim"] == 8:
+        assert bb.kernel_names == BB_REAL_KERNEL[bbpath]
     x = golden.load(inp)
     outs, off = [], 0
     for n in m["in_lens"]:
@@ -378,8 +384,7 @@ def test_bb_real_long_calls_vs_oracle(ctx, orc, epi, order, Fc, bbpath):
     rng = np.random.default_rng(order + 17)
     taps, lut, inc = orc.bb_design(abs(Fc) if Fc else 120e3, 60e3, Fs, order), orc.freqshift_lut_i16(), orc.freqshift_inc(Fc, Fs)
     bb = sa.BaseBandI16(ctx, taps, lut, inc, Fc < 0, 8, channels=C, max_in=max(chunks), epilogue=epi)
-    if bbpath == "auto":
-        assert bb.kernel_names == ["bb_real_mfma_kernel"]
+    assert bb.kernel_names == BB_REAL_KERNEL[bbpath]
     refs = [orc.BaseBandI16(taps, lut, inc, Fc < 0, 8) for _ in range(C)]
     fms = [orc.FMDemodI16() for _ in range(C)]
     for n in chunks:
@@ -414,7 +419,7 @@ def test_bb_real_full_size_properties(ctx, orc):
     base = np.ascontiguousarray(synth_channels(orc, 8, N)[..., 0])
     x = np.ascontiguousarray(base[np.arange(C) % 8])
     node = sa.BaseBandI16(ctx, taps, lut, inc, False, D, channels=C, max_in=N, epilogue=sa.EPI_FM)
-    assert node.kernel_names == ["bb_real_mfma_kernel"]
+    assert node.kernel_names == ["iqbb_hot_kernel"]
     y1, y2 = node.process(x), node.process(x)
     for k in range(8):
         assert (y1[k::8] == y1[k]).all() and (y2[k::8] == y2[k]).all()

@@ -3,7 +3,7 @@
 settings) gets its own plan over the SAME resident input batches; timing rounds are interleaved (variant A, B, C, A, B,
 C, ...) so that clock drift and box-to-box differences cancel. Reports median / min ms per launch per variant.
 
-usage: tools/abk1.py [--order 127] [--epi fm|usb|am|none] [--cu8] [--channels 1024] [--samples 65536] [--rounds 7]
+usage: tools/abk1.py [--order 127] [--epi fm|usb|am|none] [--cu8|--real] [--channels 1024] [--samples 65536] [--rounds 7]
                      [--launches 200] name=libsdr_amd/libsdrhip_x.so[@ENV=VAL[,ENV=VAL]] ...
 """
 import argparse
@@ -26,6 +26,7 @@ def load(path):
     i32p = C.POINTER(C.c_int32)
     L.sdrhip_ctx_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
     L.sdrhip_iqbb_i16_create.argtypes = [vp, i32p, C.c_int, i32p, C.c_uint32, C.c_int, C.c_int, C.c_int, sz, C.c_int, C.POINTER(vp)]
+    L.sdrhip_bb_i16_create.argtypes = L.sdrhip_iqbb_i16_create.argtypes
     L.sdrhip_iqbb_i16_set_input_format.argtypes = [vp, C.c_int]
     L.sdrhip_iqbb_i16_process_dev.argtypes = [vp, vp, sz, sz, vp, sz, C.POINTER(sz)]
     L.sdrhip_iqbb_i16_kernel_names.argtypes = [vp, C.c_char_p, sz]
@@ -38,6 +39,7 @@ def main():
     p.add_argument("--order", type=int, default=127)
     p.add_argument("--epi", default="fm")
     p.add_argument("--cu8", action="store_true")
+    p.add_argument("--real", action="store_true", help="the real-input BaseBand<int16> (sdrhip_bb_i16_create)")
     p.add_argument("--channels", type=int, default=1024)
     p.add_argument("--samples", type=int, default=65536)
     p.add_argument("--rounds", type=int, default=7)
@@ -48,12 +50,14 @@ def main():
     Cn, N = a.channels, a.samples
     dev = torch.device("cuda", 0)
     stream = torch.cuda.Stream(device=dev)
-    taps = sa.design_iqbb_taps(100e3, 50e3, FS, a.order)
+    taps = sa.design_bb_taps(100e3, 50e3, FS, a.order) if a.real else sa.design_iqbb_taps(100e3, 50e3, FS, a.order)
     lut = sa.design_freqshift_lut_i16()
     inc = sa.design_freqshift_inc(100e3, FS)
     epi = {"none": 0, "fm": 1, "am": 2, "usb": 3}[a.epi]
     with torch.cuda.stream(stream):
-        if a.cu8:
+        if a.real:
+            xs = [torch.randint(-8000, 8000, (Cn, N), dtype=torch.int16, device=dev) for _ in range(3)]
+        elif a.cu8:
             xs = [torch.randint(0, 256, (Cn, N, 2), dtype=torch.uint8, device=dev) for _ in range(3)]
         else:
             xs = [torch.randint(-8000, 8000, (Cn, N, 2), dtype=torch.int16, device=dev) for _ in range(3)]
@@ -67,7 +71,7 @@ def main():
             L = load(path)
             ctx, h = C.c_void_p(), C.c_void_p()
             assert L.sdrhip_ctx_create(0, C.c_void_p(stream.cuda_stream), C.byref(ctx)) == 0
-            rc = L.sdrhip_iqbb_i16_create(ctx, taps.ctypes.data_as(C.POINTER(C.c_int32)), a.order, lut.ctypes.data_as(C.POINTER(C.c_int32)), inc, 0, 8,
+            rc = (L.sdrhip_bb_i16_create if a.real else L.sdrhip_iqbb_i16_create)(ctx, taps.ctypes.data_as(C.POINTER(C.c_int32)), a.order, lut.ctypes.data_as(C.POINTER(C.c_int32)), inc, 0, 8,
                                           Cn, N, epi, C.byref(h))
             assert rc == 0, L.sdrhip_last_error()
             if a.cu8:
