@@ -170,8 +170,9 @@ int sdrhip_iqbb_i16_set_input_format(sdrhip_iqbb_i16 *h, int format);
  * Traits<int16_t>::shift = 16; decimation windows are the D samples {gD .. gD+D-1} from the first sample on
  * (no D+1 first window). Output: cs16 (or the demodulated int16 with an epilogue).
  * Kernels: for decim == 8, order <= 273 and taps within two byte planes (|component| < 2^15 - 128: every filter but
- * very short ones) the int8-MFMA formulation over the real sample stream (bb_real_mfma_kernel), else the VALU kernel;
- * both bit-exact, sdrhip_iqbb_i16_kernel_names says which one a plan runs. */
+ * very short ones) the int8-MFMA formulation over the real sample stream (iqbb_hot_kernel's real-input instantiation;
+ * calls shorter than 3 tiles: bb_real_mfma_kernel), else the VALU kernel; all bit-exact,
+ * sdrhip_iqbb_i16_kernel_names says which one a plan runs. */
 int sdrhip_bb_i16_create(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32_t *lut,
                          uint32_t lut_inc, int negative, int decim, int channels, size_t max_in,
                          int epilogue, sdrhip_iqbb_i16 **out);
