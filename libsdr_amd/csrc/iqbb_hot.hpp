@@ -123,8 +123,13 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   const int bx = (int)blockIdx.x * (NW / 4) + (w >> 2), gx = (int)gridDim.x * (NW / 4);   // virtual workgroup, virtual grid
   // tap fragments in LDS: the S low-plane fragments, then only the NH high-plane fragments of steps [S0, S0 + NH)
   char *wbase = reinterpret_cast<char *>(smem + TBLW + (S + NH) * 64 * 4) + w * (NBUF * BUFB);
+#ifdef K1_ABL_ASAME   // (tuning ablation, results wrong: every step reads the SAME fragment values — K1_ABL_AREG's operand data with the reads kept)
+  for (int i = tid; i < S * 64; i += TPBH) taps_s[i] = a.tapfrag[64 + (i & 63)];
+  for (int i = tid; i < NH * 64; i += TPBH) taps_s[S * 64 + i] = a.tapfrag[(2 * S0) * 64 + (i & 63)];
+#else
   for (int i = tid; i < S * 64; i += TPBH) taps_s[i] = a.tapfrag[(2 * (i >> 6) + 1) * 64 + (i & 63)];
   for (int i = tid; i < NH * 64; i += TPBH) taps_s[S * 64 + i] = a.tapfrag[(2 * (S0 + (i >> 6))) * 64 + (i & 63)];
+#endif
   if (tid < 256) {
     const int2 e = a.lut[(tid & 127) ^ (a.negative ? 127 : 0)];
     if (WIDE) reinterpret_cast<v4i *>(smem)[tid] = v4i{e.x, e.y, -e.y, 0};
@@ -264,13 +269,28 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
 #endif
   };
   // K: the K loop out of the planes in `cb`: operands of step s+1 in flight while the MFMAs of step s issue
+#ifndef K1_AREG
+#define K1_AREG 0
+#endif
+  // (tuning variant K1_AREG=1: the tap fragments live in 4(S + NH) registers — build with -DK1_MINWAVES=3, run with
+  // SDRHIP_IQBB_WGPCU=3)
+  v4i AlR[K1_AREG ? S : 1], AhR[K1_AREG ? NH : 1];
+  if (K1_AREG) {
+#pragma unroll
+    for (int s = 0; s < S; s++) AlR[s] = taps_s[s * 64 + l];
+#pragma unroll
+    for (int s = 0; s < NH; s++) AhR[s] = taps_s[(S + s) * 64 + l];
+  }
   struct KOps { v4i uh, ul, Al, Ah; };
   auto stageK_begin = [&](const char *cb, KOps &o) __attribute__((always_inline)) {
     const char *pl = cb + coff, *ph = cb + (CU8 ? 0 : PLB) + coff;
     o.uh = *reinterpret_cast<const v4i *>(ph); o.ul = o.uh;
     if (!CU8) o.ul = *reinterpret_cast<const v4i *>(pl);
-    o.Al = taps_s[l]; o.Ah = o.Al;
-    if (S0 == 0) o.Ah = taps_s[S * 64 + l];
+    if (K1_AREG) { o.Al = AlR[0]; o.Ah = AhR[0]; }
+    else {
+      o.Al = taps_s[l]; o.Ah = o.Al;
+      if (S0 == 0) o.Ah = taps_s[S * 64 + l];
+    }
   };
   auto stageK = [&](const char *cb, KOps &o, v16i &acc_hh, v16i &acc_mid, v16i &acc_ll) __attribute__((always_inline)) {
     constexpr int SA = 0, SB = S;
@@ -284,8 +304,15 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       if (s + 1 < S) {
         nx.uh = *reinterpret_cast<const v4i *>(ph + KSB * (s + 1));
         if (!CU8) nx.ul = *reinterpret_cast<const v4i *>(pl + KSB * (s + 1));
-        nx.Al = taps_s[(s + 1) * 64 + l];
-        if (s + 1 >= S0 && s + 1 < S0 + NH) nx.Ah = taps_s[(S + s + 1 - S0) * 64 + l];
+#ifndef K1_ABL_AREG   // (tuning ablation, results wrong: the tap fragments of step 0 serve every step — what resident fragments would save)
+        if (K1_AREG) {
+          nx.Al = AlR[s + 1];
+          if (s + 1 >= S0 && s + 1 < S0 + NH) nx.Ah = AhR[s + 1 - S0];
+        } else {
+          nx.Al = taps_s[(s + 1) * 64 + l];
+          if (s + 1 >= S0 && s + 1 < S0 + NH) nx.Ah = taps_s[(S + s + 1 - S0) * 64 + l];
+        }
+#endif
       }
       acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.Al, o.uh, acc_mid, 0, 0, 0);
       if (!CU8) acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.Al, o.ul, acc_ll, 0, 0, 0);
@@ -429,8 +456,12 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       v16i acc_hh = {0}, acc_mid = {0}, acc_ll = {0};
       if (!CU8) acc_ll = cinit;
       KOps ops;
+      if (K1_PRIO_ROT == 2) asm volatile("s_setprio 3");   // (tuning variants: the matrix phase first / last)
+      if (K1_PRIO_ROT == 3) asm volatile("s_setprio 0");
       stageK_begin(cb, ops);
       stageK(cb, ops, acc_hh, acc_mid, acc_ll);
+      if (K1_PRIO_ROT == 2) asm volatile("s_setprio 0");
+      if (K1_PRIO_ROT == 3) asm volatile("s_setprio 3");
 #ifdef K1_STAMPS
       asm volatile("s_nop 0" : "+v"(acc_hh), "+v"(acc_mid), "+v"(acc_ll));   // the accumulators are complete before the stamp
 #endif
