@@ -293,7 +293,7 @@ def build_workload(a, wl, sa, torch, shard, ctx, dev, rank, nbuf_out):
         w.outs = [torch.zeros((C, n_out, 2), dtype=torch.float32, device=dev) for _ in range(nbuf_out)]
         w.ins = [torch.randn((C, N, 2), dtype=torch.float32, device=dev) * 0.3 for b in range(a.batches)]
         w.run = lambda b, o: node.process_dev(w.ins[b].data_ptr(), N, N, w.outs[o].data_ptr(), n_out)
-        w.dtype, w.kernels = "f32", ["fir_cf32_rt_kernel"]
+        w.dtype, w.kernels = "f32", node.kernel_names(N)
         w.desc = "float baseband: shift 100 kHz -> FIRLowPass<cf32>(127) -> /8"
         w.key = wl
 

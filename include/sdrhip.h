@@ -214,6 +214,10 @@ enum {
 int sdrhip_fir_create(sdrhip_ctx *ctx, int kind, const double *alpha, int order, int decim, int channels,
                       size_t max_in, int epilogue, sdrhip_fir **out);
 int sdrhip_fir_out_count(sdrhip_fir *h, size_t n_in, size_t *n_out);
+/* The kernel a call of n_in samples per channel runs (0: the plan's max_in), for profiles and tests:
+ * "fir_cs16_exact_kernel"; complex<float>: "fir_cf32_pipe_kernel" (decimation 8 and enough tiles to give every
+ * workgroup several: consecutive tiles software-pipelined in one workgroup) or "fir_cf32_rt_kernel". */
+int sdrhip_fir_kernel_names(sdrhip_fir *h, size_t n_in, char *buf, size_t len);
 int sdrhip_fir_process(sdrhip_fir *h, const void *in_host, size_t n_in, size_t in_stride, void *out_host,
                        size_t out_stride, size_t *n_out);
 int sdrhip_fir_process_dev(sdrhip_fir *h, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev,
@@ -309,6 +313,7 @@ int sdrhip_fft_exec(sdrhip_ctx *ctx, int dtype, int n, int sign, const void *in_
 int sdrhip_fbb_f32_create(sdrhip_ctx *ctx, double Fc, double Fs, const double *alpha, int order, int decim,
                           int channels, size_t max_in, sdrhip_fbb_f32 **out);
 int sdrhip_fbb_f32_out_count(sdrhip_fbb_f32 *h, size_t n_in, size_t *n_out);
+int sdrhip_fbb_f32_kernel_names(sdrhip_fbb_f32 *h, size_t n_in, char *buf, size_t len);   /* as sdrhip_fir_kernel_names */
 int sdrhip_fbb_f32_process(sdrhip_fbb_f32 *h, const float *in_host, size_t n_in, size_t in_stride,
                            float *out_host, size_t out_stride, size_t *n_out);
 int sdrhip_fbb_f32_process_dev(sdrhip_fbb_f32 *h, const float *in_dev, size_t n_in, size_t in_stride,

@@ -94,6 +94,7 @@ def lib():
             "sdrhip_iqbb_i16_destroy": (C.c_int, [vp]),
             "sdrhip_fir_create": (C.c_int, [vp, C.c_int, f64p, C.c_int, C.c_int, C.c_int, sz, C.c_int, pvp]),
             "sdrhip_fir_out_count": (C.c_int, [vp, sz, psz]),
+            "sdrhip_fir_kernel_names": (C.c_int, [vp, sz, C.c_char_p, sz]),
             "sdrhip_fir_process": (C.c_int, [vp, vp, sz, sz, vp, sz, psz]),
             "sdrhip_fir_process_dev": (C.c_int, [vp, vp, sz, sz, vp, sz, psz]),
             "sdrhip_fir_reset": (C.c_int, [vp]),
@@ -126,6 +127,7 @@ def lib():
             "sdrhip_fft_exec": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
             "sdrhip_fbb_f32_create": (C.c_int, [vp, C.c_double, C.c_double, f64p, C.c_int, C.c_int, C.c_int, sz, pvp]),
             "sdrhip_fbb_f32_out_count": (C.c_int, [vp, sz, psz]),
+            "sdrhip_fbb_f32_kernel_names": (C.c_int, [vp, sz, C.c_char_p, sz]),
             "sdrhip_fbb_f32_process": (C.c_int, [vp, vp, sz, sz, vp, sz, psz]),
             "sdrhip_fbb_f32_process_dev": (C.c_int, [vp, vp, sz, sz, vp, sz, psz]),
             "sdrhip_fbb_f32_reset": (C.c_int, [vp]),

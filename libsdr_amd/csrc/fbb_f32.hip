@@ -49,6 +49,11 @@ int sdrhip_fbb_f32_out_count(sdrhip_fbb_f32 *h, size_t n_in, size_t *n_out) {
   return sdrhip_fir_out_count(h->fir, n_in, n_out);
 }
 
+int sdrhip_fbb_f32_kernel_names(sdrhip_fbb_f32 *h, size_t n_in, char *buf, size_t len) {
+  if (!h) { set_error("handle is NULL"); return SDRHIP_E_INVALID; }
+  return sdrhip_fir_kernel_names(h->fir, n_in, buf, len);
+}
+
 int sdrhip_fbb_f32_process_dev(sdrhip_fbb_f32 *h, const float *in_dev, size_t n_in, size_t in_stride, float *out_dev,
                                size_t out_stride, size_t *n_out) {
   return guarded([&] {

@@ -202,6 +202,7 @@ struct Fir32Args {
   const float2 *etab2;              // E2[t] = the phasor of sample 2t (staging two samples per lane and load)
   float2 parg[32]; int p_in_args;   // calls of up to 32 tiles carry their tile factors in the arguments (host float64): no table kernel
   int roll;                         // the call's last tile also rolls the FIR history forward (hist_new <- concat(hist_old, in))
+  int tiles, tpw;                   // pipelined kernel: tiles of the call, consecutive tiles per workgroup
 };
 
 __device__ __forceinline__ float2 load_x32(const Fir32Args &a, int c, int rel) {
@@ -271,13 +272,17 @@ __global__ __launch_bounds__(TPB) void fir_cf32_rt_kernel(const Fir32Args a) {
   const float2 *src = a.in + (long)c * a.in_stride + w0;
   float2 E = make_float2(1.f, 0.f);
   if (a.shift_on) E = a.etab[tid];
+  // (lane-uniform row phasors through the constant address space: scalar loads, see the pipelined kernel)
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const __attribute__((address_space(4))) v2f *wtab_c = reinterpret_cast<const __attribute__((address_space(4))) v2f *>((uintptr_t)a.wtab);
   // staging by rows of TPB consecutive samples. The first FR rows are complete in every full tile whatever M is, so an
   // interior full tile (no history, no end of call) issues FR unconditional coalesced loads before its first wait;
   // the remaining rows (and every row of a border tile) go four at a time through clamped, branch-free loads that
   // are masked afterwards — per-element bounds branches would make every load its own round trip.
   auto put = [&](float2 v, int row, int i) {
     if (a.shift_on) {
-      const float2 W = a.wtab[row];   // lane-uniform
+      const v2f W_ = wtab_c[row];   // lane-uniform
+      const float2 W = make_float2(W_.x, W_.y);
       const float zr = E.x * W.x - E.y * W.y, zi = E.x * W.y + E.y * W.x;
       v = make_float2(v.x * zr - v.y * zi, v.x * zi + v.y * zr);
     }
@@ -299,7 +304,8 @@ __global__ __launch_bounds__(TPB) void fir_cf32_rt_kernel(const Fir32Args a) {
     for (int kk = 0; kk < FR / 2; kk++) {
       float4 o = v[kk];
       if (a.shift_on) {
-        const float2 W = a.wtab[2 * kk];   // lane-uniform
+        const v2f W_ = wtab_c[2 * kk];   // lane-uniform
+        const float2 W = make_float2(W_.x, W_.y);
         const float z0r = E2.x * W.x - E2.y * W.y, z0i = E2.x * W.y + E2.y * W.x;
         const float z1r = z0r * w1.x - z0i * w1.y, z1i = z0r * w1.y + z0i * w1.x;
         o = make_float4(v[kk].x * z0r - v[kk].y * z0i, v[kk].x * z0i + v[kk].y * z0r, v[kk].z * z1r - v[kk].w * z1i, v[kk].z * z1i + v[kk].w * z1r);
@@ -417,6 +423,175 @@ __global__ __launch_bounds__(TPB) void fir_cf32_rt_kernel(const Fir32Args a) {
   }
 }
 
+// The same register-tiled kernel as a SOFTWARE PIPELINE over `tpw` consecutive tiles of a channel (compile-time
+// decimation): the samples of tile t+1 are fetched into registers before tile t is computed out of LDS, and written to
+// LDS (shift applied) after it — one workgroup overlaps its own memory phase with its own arithmetic instead of
+// relying on the other workgroups of the CU being in the other phase (a tile is 34 KB: only 4 fit). Border tiles
+// (history, end of the call, unaligned rows) are staged by the clamped loads of the plain kernel, without prefetch.
+template <int R, int DC>
+__global__ __launch_bounds__(TPB, 4) void fir_cf32_pipe_kernel(const Fir32Args a) {
+  extern __shared__ __attribute__((aligned(16))) float2 smemf[];
+  float2 *xs = smemf;
+  const int c = blockIdx.y, tid = threadIdx.x;
+  constexpr int D = DC, RD = R * D, PD = 2;
+  constexpr int FR = ((TPB * R - 1) * D + 1) / TPB, NV4 = FR / 2, NX = 4;   // rows fetched as float4 pairs / as single rows
+  const int t_begin = blockIdx.x * a.tpw, t_end = min(t_begin + a.tpw, a.tiles);
+  const float2 *irow = a.in + (long)c * a.in_stride, *hrow = a.hist_old + (long)c * a.HH;
+  // The lane-uniform tables (taps, row and tile phasors) are read through the CONSTANT address space: scalar loads. Left
+  // as global pointers they become vector loads as soon as the loop holds a store (the scalar cache is not coherent with
+  // vector stores and nothing tells the compiler that `out` does not alias them) — and the wait for the first tap load
+  // would wait for the whole prefetch in front of it (vector memory returns in order).
+  typedef const __attribute__((address_space(4))) float *cfp;
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  typedef const __attribute__((address_space(4))) v2f *cf2p;
+  const cfp betap_c = reinterpret_cast<cfp>((uintptr_t)a.betap);
+  const cf2p wtab_c = reinterpret_cast<cf2p>((uintptr_t)a.wtab), ptab_c = reinterpret_cast<cf2p>((uintptr_t)a.ptab);
+  float2 E = make_float2(1.f, 0.f), E2 = make_float2(1.f, 0.f), w1 = make_float2(1.f, 0.f);
+  if (a.shift_on) { E = a.etab[tid]; E2 = a.etab2[tid]; w1 = a.etab[1]; }
+  auto put = [&](float2 v, int row, int i) {
+    if (a.shift_on) {
+      const v2f W_ = wtab_c[row];   // lane-uniform
+      const float2 W = make_float2(W_.x, W_.y);
+      const float zr = E.x * W.x - E.y * W.y, zi = E.x * W.y + E.y * W.x;
+      v = make_float2(v.x * zr - v.y * zi, v.x * zi + v.y * zr);
+    }
+    xs[i + PD * (i / RD)] = v;
+  };
+  auto w0_of = [&](int t) { return a.first_rel + t * (TPB * R) * D - (a.M - 1); };   // call-relative index of xs[0]
+  auto outs_of = [&](int t) { return min(TPB * R, a.n_out - t * (TPB * R)); };
+  auto fast = [&](int t) {   // a full interior tile with 16-byte aligned rows, short enough for the prefetch registers
+    const int w0 = w0_of(t), need = (TPB * R - 1) * D + a.M;
+    return outs_of(t) == TPB * R && w0 >= 0 && w0 + need <= a.N && need <= (2 * NV4 + NX) * TPB &&
+           ((reinterpret_cast<uintptr_t>(irow + w0) & 15) == 0);
+  };
+  float4 v4[NV4];
+  float2 vx[NX];
+  auto fetch = [&](int t) {
+    const float2 *src = irow + w0_of(t);
+    const int need = (TPB * R - 1) * D + a.M;
+#pragma unroll
+    for (int kk = 0; kk < NV4; kk++) v4[kk] = *reinterpret_cast<const float4 *>(src + 2 * tid + 2 * TPB * kk);
+#pragma unroll
+    for (int k = 0; k < NX; k++) vx[k] = src[min(tid + (2 * NV4 + k) * TPB, need - 1)];
+  };
+  auto zero_tail = [&](int need) {   // what a lane reads behind the staged samples must be finite (see the plain kernel)
+    for (int i = need + tid; i < need + (R - 1) * D + 16; i += TPB) xs[i + PD * (i / RD)] = make_float2(0.f, 0.f);
+  };
+  auto commit = [&](int t) {
+    const int need = (TPB * R - 1) * D + a.M;
+#pragma unroll
+    for (int kk = 0; kk < NV4; kk++) {
+      float4 o = v4[kk];
+      if (a.shift_on) {
+        const v2f W_ = wtab_c[2 * kk];   // lane-uniform
+        const float2 W = make_float2(W_.x, W_.y);
+        const float z0r = E2.x * W.x - E2.y * W.y, z0i = E2.x * W.y + E2.y * W.x;
+        const float z1r = z0r * w1.x - z0i * w1.y, z1i = z0r * w1.y + z0i * w1.x;
+        o = make_float4(v4[kk].x * z0r - v4[kk].y * z0i, v4[kk].x * z0i + v4[kk].y * z0r, v4[kk].z * z1r - v4[kk].w * z1i, v4[kk].z * z1i + v4[kk].w * z1r);
+      }
+      const int i = 2 * tid + 2 * TPB * kk;
+      *reinterpret_cast<float4 *>(xs + i + PD * (i / RD)) = o;
+    }
+#pragma unroll
+    for (int k = 0; k < NX; k++) {
+      const int i = tid + (2 * NV4 + k) * TPB;
+      if (i < need) put(vx[k], 2 * NV4 + k, i);
+    }
+    zero_tail(need);
+  };
+  auto stage_plain = [&](int t) {
+    const int w0 = w0_of(t), outs_here = outs_of(t), need = (outs_here - 1) * D + a.M;
+    for (int row = 0; row * TPB < need; row += 4) {
+      float2 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int rel = w0 + tid + (row + k) * TPB, hh = a.HH + rel;
+        const float2 *p = rel >= 0 ? irow + min(rel, a.N - 1) : hrow + max(hh, 0);
+        v[k] = *p;
+        if (rel >= a.N || hh < 0) v[k] = make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int i = tid + (row + k) * TPB;
+        if (i < need) put(v[k], row + k, i);
+      }
+    }
+    zero_tail(need);
+  };
+  auto compute = [&](int t) {
+    const int j0 = t * (TPB * R), outs_here = outs_of(t);
+    if (R * tid >= outs_here) return;
+    float sr[R], si[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) { sr[r] = 0.f; si[r] = 0.f; }
+    const cfp bp = betap_c + (R - 1) * D;
+    const int steps = a.M + (R - 1) * D;
+    constexpr int U = 16, PADZ = (R - 1) * D, WN = U + PADZ;
+    const float2 *pu = xs + tid * (RD + PD);
+    for (int u0 = 0; u0 < steps; u0 += U) {
+      float tw[WN];
+#pragma unroll
+      for (int k = 0; k < WN; k++) tw[k] = bp[u0 - PADZ + k];
+      float2 x[U];
+#pragma unroll
+      for (int uu = 0; uu < U; uu += 2) {
+        const float4 v = *reinterpret_cast<const float4 *>(pu + uu);
+        x[uu] = make_float2(v.x, v.y); x[uu + 1] = make_float2(v.z, v.w);
+      }
+#pragma unroll
+      for (int uu = 0; uu < U; uu++) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          const float b = tw[uu - r * D + PADZ];
+          sr[r] = __builtin_fmaf(b, x[uu].x, sr[r]); si[r] = __builtin_fmaf(b, x[uu].y, si[r]);
+        }
+      }
+      pu += U;
+      if (((u0 + U) % RD) == 0) pu += PD;
+    }
+    if (a.shift_on) {
+      float2 P = a.parg[t & 31];
+      if (!a.p_in_args) { const v2f P_ = ptab_c[t]; P = make_float2(P_.x, P_.y); }
+#pragma unroll
+      for (int r = 0; r < R; r++) { const float yr = sr[r] * P.x - si[r] * P.y, yi = sr[r] * P.y + si[r] * P.x; sr[r] = yr; si[r] = yi; }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const int j = j0 + R * tid + r;
+      if (j < a.n_out) {
+        if (a.epilogue == SDRHIP_EPI_NONE) reinterpret_cast<float2 *>(a.out)[(long)c * a.out_stride + j] = make_float2(sr[r], si[r]);
+        else if (a.epilogue == SDRHIP_EPI_AM) reinterpret_cast<float *>(a.out)[(long)c * a.out_stride + j] = sqrtf(sr[r] * sr[r] + si[r] * si[r]);
+        else reinterpret_cast<float *>(a.out)[(long)c * a.out_stride + j] = (sr[r] + si[r]) / 2;
+      }
+    }
+  };
+
+  if (t_begin < t_end) {
+    if (fast(t_begin)) { fetch(t_begin); commit(t_begin); } else stage_plain(t_begin);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    __syncthreads();
+    for (int t = t_begin; t < t_end; t++) {
+      const bool more = t + 1 < t_end, nf = more && fast(t + 1);
+      if (nf) fetch(t + 1);   // in flight while this tile is computed
+      compute(t);
+      if (more) {
+        __syncthreads();   // every lane is done with tile t's samples
+        if (nf) commit(t + 1); else stage_plain(t + 1);
+        // nothing of this iteration stays in flight across the back edge: the compiler's wait-count model merges the
+        // border path's loads into the loop head otherwise and waits for the prefetch right after issuing it
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+        __syncthreads();
+      }
+    }
+  }
+  if (a.roll && t_end == a.tiles) {   // (hist_old is only read, by this launch's border tiles; hist_new only written here)
+    for (int k = tid; k < a.HH; k += TPB) {
+      const long qq = (long)a.N + k;
+      a.hist_new[(long)c * a.HH + k] = qq < a.HH ? a.hist_old[(long)c * a.HH + qq] : a.in[(long)c * a.in_stride + (qq - a.HH)];
+    }
+  }
+}
+
 // per-tile phase factors of the fused frequency shift: P[t] = exp(-2 pi i frac(fc (n_first + t * step) / fs)), float64
 __global__ void tile_phasor_kernel(float2 *ptab, int tiles, long long n_first, long long step, double fc, double fs) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -453,6 +628,7 @@ struct sdrhip_fir {
   DevBuf<short> fm[2];
   // K3
   int M = 0, R = 1;
+  bool pipe = true;   // D = 8: several tiles per workgroup, software-pipelined (SDRHIP_FIR_PIPE=0: one tile per workgroup, tuning/tests)
   DevBuf<float> beta, betap;
   size_t lds3 = 0;
   // fused frequency shift (set by the float baseband)
@@ -469,6 +645,21 @@ struct sdrhip_fir {
   }
   // SubSample emits after every D-th input counted from the last reset (src/subsample.hh:94-99)
   size_t out_count(size_t N) const { return (size_t)((n0 + N) / (uint64_t)D - n0 / (uint64_t)D); }
+
+  // K3 at D = 8: consecutive tiles per workgroup of the pipelined kernel (1: the plain kernel, one tile per workgroup) —
+  // as many as leave >= 8 workgroups per CU
+  int pipe_tpw(int tiles) const {
+    if (!(D == 8 && (R == 2 || R == 4) && pipe)) return 1;
+    int tpw = 16;
+    while (tpw > 1 && ceil_div((size_t)tiles, (size_t)tpw) * (size_t)C < 8 * (size_t)ctx->prop.multiProcessorCount) tpw >>= 1;
+    if (const char *e = getenv("SDRHIP_FIR_TPW")) tpw = std::max(1, atoi(e));   // tuning hook
+    return tpw;
+  }
+  const char *kernel_name(size_t N) const {
+    if (kind == SDRHIP_FIR_CS16_EXACT) return "fir_cs16_exact_kernel";
+    const int tiles = (int)ceil_div(out_count(N), (size_t)TPB * R);
+    return pipe_tpw(tiles) > 1 ? "fir_cf32_pipe_kernel" : "fir_cf32_rt_kernel";
+  }
 
   void launch(const void *in_dev, size_t N, size_t in_stride, void *out_dev, size_t out_stride, size_t *n_out) {
     ctx->use();
@@ -526,7 +717,13 @@ struct sdrhip_fir {
           }
         }
         dim3 grid(tiles, C), block(TPB);
-        if (R == 4 && D == 8) hipLaunchKernelGGL((fir_cf32_rt_kernel<4, 8>), grid, block, lds3, ctx->stream, a);
+        // D = 8: the pipelined form, `tpw` consecutive tiles per workgroup while that leaves >= 8 workgroups per CU
+        const int tpw = pipe_tpw(tiles);
+        a.tiles = tiles; a.tpw = tpw;
+        dim3 gridp((unsigned)ceil_div((size_t)tiles, (size_t)tpw), C);
+        if (R == 4 && D == 8 && tpw > 1) hipLaunchKernelGGL((fir_cf32_pipe_kernel<4, 8>), gridp, block, lds3, ctx->stream, a);
+        else if (R == 2 && D == 8 && tpw > 1) hipLaunchKernelGGL((fir_cf32_pipe_kernel<2, 8>), gridp, block, lds3, ctx->stream, a);
+        else if (R == 4 && D == 8) hipLaunchKernelGGL((fir_cf32_rt_kernel<4, 8>), grid, block, lds3, ctx->stream, a);
         else if (R == 2 && D == 8) hipLaunchKernelGGL((fir_cf32_rt_kernel<2, 8>), grid, block, lds3, ctx->stream, a);
         else if (R == 4) hipLaunchKernelGGL((fir_cf32_rt_kernel<4, 0>), grid, block, lds3, ctx->stream, a);
         else if (R == 2) hipLaunchKernelGGL((fir_cf32_rt_kernel<2, 0>), grid, block, lds3, ctx->stream, a);
@@ -615,6 +812,7 @@ int sdrhip_fir_create(sdrhip_ctx *ctx, int kind, const double *alpha, int order,
         auto tile_bytes = [&](int R_) { const size_t need = ((size_t)TPB * R_ - 1) * decim + h->M; return (need + (size_t)(R_ - 1) * decim + 16 + (decim == 8 ? 2 : 1) * ((need + (size_t)(R_ - 1) * decim + 16) / ((size_t)R_ * decim) + 2)) * 8; };
         h->R = 4;
         if (const char *e = getenv("SDRHIP_FIR_R")) h->R = std::max(1, std::min(4, atoi(e)));   // tuning hook
+        if (const char *e = getenv("SDRHIP_FIR_PIPE")) h->pipe = e[0] != '0';
         // as many outputs per lane as keep the tile under 40 KB (4 workgroups = 16 waves per CU): more waves in
         // flight beat more reuse per LDS read — D = 8: R = 2 measured 25 % faster than R = 4 (2 workgroups per CU)
         // (R*D stays >= 2: the pad-per-R*D-samples layout needs an even lane stride)
@@ -622,9 +820,10 @@ int sdrhip_fir_create(sdrhip_ctx *ctx, int kind, const double *alpha, int order,
         SDRHIP_REQUIRE(tile_bytes(h->R) <= 144 * 1024, SDRHIP_E_UNSUPPORTED, "order %d with decim %d exceeds the LDS tile", order, decim);
         h->lds3 = tile_bytes(h->R);
         if (h->lds3 > 64 * 1024) {
-          const void *fns[5] = {(const void *)fir_cf32_rt_kernel<4, 8>, (const void *)fir_cf32_rt_kernel<4, 0>, (const void *)fir_cf32_rt_kernel<2, 8>,
-                                (const void *)fir_cf32_rt_kernel<2, 0>, (const void *)fir_cf32_rt_kernel<1, 0>};
-          for (int k = 0; k < 5; k++) SDRHIP_CHECK_HIP(hipFuncSetAttribute(fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds3));
+          const void *fns[7] = {(const void *)fir_cf32_rt_kernel<4, 8>, (const void *)fir_cf32_rt_kernel<4, 0>, (const void *)fir_cf32_rt_kernel<2, 8>,
+                                (const void *)fir_cf32_rt_kernel<2, 0>, (const void *)fir_cf32_rt_kernel<1, 0>,
+                                (const void *)fir_cf32_pipe_kernel<4, 8>, (const void *)fir_cf32_pipe_kernel<2, 8>};
+          for (int k = 0; k < 7; k++) SDRHIP_CHECK_HIP(hipFuncSetAttribute(fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds3));
         }
         std::vector<float> b(h->M);
         for (int m = 0; m < h->M; m++) {
@@ -644,6 +843,13 @@ int sdrhip_fir_create(sdrhip_ctx *ctx, int kind, const double *alpha, int order,
       SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     } catch (...) { delete h; throw; }
     *out = h;
+  });
+}
+
+int sdrhip_fir_kernel_names(sdrhip_fir *h, size_t n_in, char *buf, size_t len) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h && buf && len, SDRHIP_E_INVALID, "NULL argument");
+    snprintf(buf, len, "%s", h->kernel_name(n_in ? n_in : h->max_in));
   });
 }
 

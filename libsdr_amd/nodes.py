@@ -403,6 +403,12 @@ class FIR(_Node):
         check(abi.lib().sdrhip_fir_create(ctx.handle, kind, alpha.ctypes.data_as(C.POINTER(C.c_double)), alpha.shape[0],
                                           decim, channels, max_in, epilogue, C.byref(self._h)))
 
+    def kernel_names(self, n_in=0):
+        """The kernel a call of n_in samples per channel runs (0: max_in) — what to look for in a rocprofv3 kernel trace."""
+        b = C.create_string_buffer(256)
+        check(abi.lib().sdrhip_fir_kernel_names(self._h, n_in, b, 256))
+        return b.value.decode().split(",")
+
     def out_count(self, n_in):
         n = C.c_size_t(0)
         check(abi.lib().sdrhip_fir_out_count(self._h, n_in, C.byref(n)))
@@ -574,6 +580,12 @@ class FloatBaseBand(_Node):
         self.ctx, self.channels, self.decim = ctx, channels, decim
         check(abi.lib().sdrhip_fbb_f32_create(ctx.handle, Fc, Fs, alpha.ctypes.data_as(C.POINTER(C.c_double)),
                                               alpha.shape[0], decim, channels, max_in, C.byref(self._h)))
+
+    def kernel_names(self, n_in=0):
+        """The kernel a call of n_in samples per channel runs (0: max_in)."""
+        b = C.create_string_buffer(256)
+        check(abi.lib().sdrhip_fbb_f32_kernel_names(self._h, n_in, b, 256))
+        return b.value.decode().split(",")
 
     def out_count(self, n_in):
         n = C.c_size_t(0)

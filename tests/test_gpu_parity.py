@@ -930,6 +930,39 @@ def test_float_baseband_full_buffers_vs_oracle(ctx, golden, orc, D):
         n0 += n
 
 
+@pytest.mark.parametrize("tpw", [2, 3, 16])
+@pytest.mark.parametrize("shift", [True, False])
+def test_fir_cf32_pipelined_kernel_small_batches(ctx, golden, orc, tpw, shift, monkeypatch):
+    """The software-pipelined form of the decimation-8 float kernel (several consecutive tiles per workgroup, the next
+    tile prefetched into registers) is chosen for batches that fill the chip; SDRHIP_FIR_TPW forces it on 3 channels:
+    ragged calls (first tile with history, unaligned rows after an odd call, partial last tile, calls shorter than a
+    tile) against the oracle, and bit for bit against the one-tile-per-workgroup kernel."""
+    alpha = golden.load("g2_firlp_alpha127")
+    rng = np.random.default_rng(100 + tpw)
+    C, lens = 3, [40000, 1, 33333, 16389, 65536, 4096, 20000]
+    mk = (lambda: sa.FloatBaseBand(ctx, 100e3, FS, alpha, 8, channels=C, max_in=65536)) if shift else \
+         (lambda: sa.FIR(ctx, sa.FIR_CF32, alpha, decim=8, channels=C, max_in=65536))
+    monkeypatch.setenv("SDRHIP_FIR_PIPE", "0")
+    plain = mk()
+    monkeypatch.setenv("SDRHIP_FIR_PIPE", "1")
+    monkeypatch.setenv("SDRHIP_FIR_TPW", str(tpw))
+    node = mk()
+    assert node.kernel_names(65536) == ["fir_cf32_pipe_kernel"] and plain.kernel_names(65536) == ["fir_cf32_rt_kernel"]
+    firs, subs = [orc.FIR(alpha) for _ in range(C)], [orc.SubSample(8) for _ in range(C)]
+    n0 = 0
+    for n in lens:
+        x = (rng.standard_normal((C, n, 2)) * 0.3).astype(np.float32)
+        y, yp = node.process(x), plain.process(x)
+        for c in range(C):
+            xs = orc.freqshift_cf32(x[c], n0, 100e3, FS) if shift else x[c]
+            ref = subs[c].process_cf32(firs[c].process_cf32(xs))
+            assert y[c].shape == ref.shape
+            assert np.array_equal(y[c], yp[c]), (n, c)
+            if ref.size:
+                assert rel_err(y[c], ref) <= RTOL, (n, c)
+        n0 += n
+
+
 def test_fftconv_config4_many_channels(ctx, golden, orc):
     """BASELINE config 4 (ii) at C = 64, N = 65536: the fused overlap-save kernel against the time-domain oracle FIR
     on three of the channels, and against itself run one channel at a time."""
