@@ -325,17 +325,13 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
   // Round 3 tried it again WITH a register prefetch of the next block's input issued before the last inverse pass: 512
   // lanes (registers to spare) 0.535 ms, 1024 lanes (prefetch once the twiddles are dead, 114 registers) 0.524 ms, against
   // 0.508 ms for this kernel on the same box)
-  // XCD-aware (channel, block) assignment: workgroups are dealt round-robin over the 8 XCDs by linear id, and each XCD
-  // has its own L2. Consecutive blocks of a channel overlap by the filter's history (a quarter of a 16384-point block
-  // with 4097 taps, half of a filter-bank block): dealt in launch order they land on different XCDs and the overlap is
-  // fetched from HBM twice. Instead XCD x walks the channels x, x + 8, ... block by block, so that neighbouring blocks
-  // run on the same XCD at the same time and the second reader hits in L2 (speed only — any placement is correct).
-  int c = blockIdx.y, blk = blockIdx.x;
-#ifndef FFTCONV_NO_XCD   // (tuning: launch-order assignment)
-  if ((gridDim.y & 7) == 0) {
-    const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y, x = lin & 7u, k = lin >> 3;
-    c = (int)(x + 8u * (k / gridDim.x)); blk = (int)(k % gridDim.x);
-  }
+  // XCD-aware (channel, block) assignment (xcd_unit_order): consecutive blocks of a channel overlap by the filter's
+  // history — a quarter of a 16384-point block with 4097 taps, half of a filter-bank block
+  int c, blk;
+#ifdef FFTCONV_NO_XCD   // (tuning: launch-order assignment)
+  c = blockIdx.y; blk = blockIdx.x;
+#else
+  xcd_unit_order(blk, c);
 #endif
   const int tid0 = threadIdx.x;
   // (every phase starts from an opaque copy of the lane index: the lane's LDS and table addresses of all passes are

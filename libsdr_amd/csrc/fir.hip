@@ -84,7 +84,9 @@ __global__ __launch_bounds__(TPB) void fir_cs16_exact_kernel(const Fir16Args a) 
   uint32_t *xs = smem;            // xs[i] = x[tb-(OP-1)+i]
   uint32_t *ybuf = smem + XS;     // T2 packed cs16 results
 
-  const int c = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+  int c, tile;
+  xcd_unit_order(tile, c);   // (neighbouring tiles of a channel share OP - 1 input samples: same XCD, same L2)
+  const int tid = threadIdx.x;
   const int tb = tile * a.OT - a.ovl;            // index of the tile's first computed output
   const int outs_here = min(T2, a.N - tb);
 
@@ -255,7 +257,9 @@ template <int R, int DC>
 __global__ __launch_bounds__(TPB) void fir_cf32_rt_kernel(const Fir32Args a) {
   extern __shared__ __attribute__((aligned(16))) float2 smemf[];
   float2 *xs = smemf;
-  const int c = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+  int c, tile;
+  xcd_unit_order(tile, c);   // (neighbouring tiles of a channel share M - 1 input samples: same XCD, same L2)
+  const int tid = threadIdx.x;
   const int D = DC > 0 ? DC : a.D;
   const int RD = R * D;
   // pad elements per R*D samples: 1 keeps the lanes' stride an odd number of 8-byte bank pairs; the compile-time-D path takes

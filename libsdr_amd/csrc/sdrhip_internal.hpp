@@ -140,4 +140,19 @@ static inline void require_disjoint(const void *in, size_t in_stride, size_t in_
 // fir.hip: turn on the frequency shift fused into the cf32 FIR's staging (used by the float baseband, fbb_f32.hip)
 void fir_set_shift(sdrhip_fir *h, double fc, double fs);
 
+#ifdef __HIPCC__
+// XCD-aware unit order for grids of (units-per-channel, channels) whose neighbouring units of a channel re-read each
+// other's input (FIR history, overlap-save). Workgroups are dealt round-robin over the 8 XCDs by linear id and each XCD
+// has its own L2: in launch order (unit fastest) the two readers of an overlap sit on different XCDs and it is fetched
+// from HBM twice. With this map XCD x walks channels x, x + 8, ... unit by unit, so neighbours run on one XCD at the same
+// time and the second reader hits in L2. Speed only: any placement is correct (MI355X_MICROARCH.md, workgroup dispatch).
+__device__ __forceinline__ void xcd_unit_order(int &unit, int &chan) {
+  unit = (int)blockIdx.x; chan = (int)blockIdx.y;
+  if ((gridDim.y & 7u) == 0) {
+    const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y, x = lin & 7u, k = lin >> 3;
+    chan = (int)(x + 8u * (k / gridDim.x)); unit = (int)(k % gridDim.x);
+  }
+}
+#endif
+
 }  // namespace sdrhip
