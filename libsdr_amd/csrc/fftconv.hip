@@ -793,8 +793,22 @@ struct sdrhip_fftconv {
       case 256: fused(fftconv_fused_kernel<0, BANK_, 256>, 256); break; \
       case 128: fused(fftconv_fused_kernel<0, BANK_, 128>, 128); break; \
       default: fused(fftconv_fused_kernel<0, BANK_, 64>, 64); break; } } while (0)
+    // compile-time plans (strides, pad offsets and butterfly maps fold into immediates and shifts; the run-time-plan
+    // kernel divides by the pass stride per butterfly): 16384 points, and 2048 / 4096 / 8192 with L / 16 lanes
+    auto plan_is = [&](int lg) {
+      if (plan.L != (1 << lg) || plan.dev.npass != plan_npass(lg)) return false;
+      for (int q = 0; q < plan.dev.npass; q++) if (plan.dev.radix[q] != plan_radix(lg, q)) return false;
+      return true;
+    };
+    const bool ct = getenv("SDRHIP_K7_RUNTIME_PLAN") == nullptr;   // (tuning / tests: the run-time-plan kernel for every size)
     if (plan.L == 16384) {   // (never a bank: two images of 16384 points do not fit the LDS)
       fused(fftconv_fused_kernel<14, false, 1024>, 1024);   // (512 / 256 lanes measured 0.78x / 0.59x)
+    } else if (ct && fusable && nt == 128 && plan_is(11)) {
+      if (a.nb > 1) fused(fftconv_fused_kernel<11, true, 128>, 128); else fused(fftconv_fused_kernel<11, false, 128>, 128);
+    } else if (ct && fusable && nt == 256 && plan_is(12)) {
+      if (a.nb > 1) fused(fftconv_fused_kernel<12, true, 256>, 256); else fused(fftconv_fused_kernel<12, false, 256>, 256);
+    } else if (ct && fusable && nt == 512 && plan_is(13)) {
+      if (a.nb > 1) fused(fftconv_fused_kernel<13, true, 512>, 512); else fused(fftconv_fused_kernel<13, false, 512>, 512);
     } else if (fusable && a.nb > 1) {
       SDRHIP_FUSED(true);
     } else if (fusable) {
