@@ -634,7 +634,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
     unsigned long long *o = a.stamps + (size_t)((((unsigned)bx * 4 + wv) & 32767u) * 16);
     for (int i = 0; i < 6; i++) o[i] = st_acc[i];
     o[8] = st_tiles; o[9] = __builtin_amdgcn_s_getreg((15 << 11) | 4);
-    o[10] = st_r0; o[11] = __builtin_amdgcn_s_memrealtime();
+    o[10] = st_r0; o[11] = __builtin_amdgcn_s_memrealtime(); o[12] = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // XCC_ID[3:0]
   }
 #endif
 }

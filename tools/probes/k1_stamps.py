@@ -55,5 +55,9 @@ print("launch %.1f us; waves %d, wave-slices %.0f; cycles per wave %.0f, per wav
 for n_, c_ in zip(names, v):
     print("  %-24s %6.1f %%   %8.0f cycles per wave-slice" % (n_, 100.0 * c_ / tot, c_ / tiles))
 slot, simd = hwid & 15, (hwid >> 4) & 3
-for name, key in (("slot", slot), ("simd", simd)):
+xcc, cu, se = a[:, 12].astype(np.int64) & 15, (hwid >> 8) & 15, (hwid >> 13) & 7
+print("life quantiles (us): " + " ".join("%d%%:%.1f" % (q, np.percentile(life, q)) for q in (0, 5, 25, 50, 75, 95, 100)))
+print("end-time quantiles (us after the first start): " + " ".join("%d%%:%.1f" % (q, np.percentile((t1 - t0.min()) / 100.0, q)) for q in (0, 5, 25, 50, 75, 95, 100)))
+print("start-time quantiles (us): " + " ".join("%d%%:%.1f" % (q, np.percentile((t0 - t0.min()) / 100.0, q)) for q in (0, 50, 95, 100)))
+for name, key in (("slot", slot), ("simd", simd), ("xcc", xcc), ("se", se), ("cu", cu)):
     print("life by %-4s:" % name, " ".join("%d:%.0f" % (v_, life[key == v_].mean()) for v_ in np.unique(key)))
