@@ -313,11 +313,17 @@ def test_bb_real_mfma_random_long_calls(ctx, orc, seed, hot, monkeypatch):
             assert y[c].shape == r.shape and np.array_equal(y[c], r), (seed, order, Fc, epi, C, n, bb.kernel_names)
 
 
+@pytest.mark.parametrize("tpw", [0, 3])
 @pytest.mark.parametrize("seed", range(10 + EXTRA // 2))
-def test_float_baseband_random_calls(ctx, orc, seed):
+def test_float_baseband_random_calls(ctx, orc, seed, tpw, monkeypatch):
     """The float baseband (shift fused into the register-tiled FIR's staging, decimation folded): random shift, decimation,
     channel count and ragged call lengths — odd lengths move the rows over every alignment of the 16-byte staging loads and
-    the phase tables over every tile offset. <= 1e-5 against the float64-phasor oracle chain."""
+    the phase tables over every tile offset. <= 1e-5 against the float64-phasor oracle chain. tpw = 3: the decimation-8
+    plans run the software-pipelined kernel (3 tiles per workgroup; small batches would take the plain one)."""
+    if tpw:
+        monkeypatch.setenv("SDRHIP_FIR_TPW", str(tpw))
+    else:
+        monkeypatch.delenv("SDRHIP_FIR_TPW", raising=False)
     rng = np.random.default_rng(11000 + seed)
     Fc = float(rng.choice([100e3, -100e3, 37e3, 1.1e6, 0.0]))
     D = int(rng.choice([8, 8, 8, 5, 1, 16]))
