@@ -6,28 +6,35 @@
 //   with pi/4 = 4096, integer (truncating) division; a < 0 negates; (0, 0) gives 0; the demodulator halves (trunc).
 //
 // Both branches divide by den = |a| + |b| and their numerators are +-(|b| - |a|) * 4096, so there is ONE unsigned division
-// q = floor(4096 * ||b| - |a|| / den), q <= 4096, whose sign is sign(|b| - |a|) for b >= 0 and the opposite for b < 0.
-// The division: a float estimate biased DOWN by 2^-20 (v_rcp_f32 is good to 1 ulp, the two multiplies to half an ulp each,
-// the conversions of |d| <= 2^16 and den <= 2^17 are exact: the estimate lies in (x - 0.005, x], so its floor is q or q - 1)
-// and one exact remainder test. 32 vector instructions; the generic form (signed numerator, two-sided correction, separate
-// selects per branch) took 44.
+// q = floor(4096 * ||b| - |a|| / den), q <= 4096, and angle = (b >= 0 ? 4096 : 12288) - sigma * q with
+// sigma = sign(|b| - |a|) * sign(b) (sign(0) = +1 for b).
+//
+// Round 3: the whole evaluation runs on FLOAT registers holding exact integers (everything stays below 2^24, the one
+// larger product sits inside an fma whose exact result is small): |.| and negation are operand modifiers, the sign
+// transfers are one v_bfi each, the remainder of the division is one fma. 28 issue slots per angle (the integer form:
+// 37; the generic two-branch form of round 1: 44).
+//   division: a float estimate biased DOWN by 2^-20 (v_rcp_f32 is good to 1 ulp, the two multiplies to half an ulp each:
+//   the estimate lies in (x - 0.005, x], so its floor is q or q - 1), then the exact remainder r = 4096 d - q' den by fma
+//   (r is an integer in [0, 2 den), den < 2^17: representable, so the single rounding returns it exactly) and one test.
 #pragma once
 #include <hip/hip_runtime.h>
 
-__device__ __forceinline__ int fm_phi(int a, int b) {
-  const unsigned aabs = (unsigned)max(a, -a), babs = (unsigned)max(b, -b);
-  const unsigned den = aabs + babs, den1 = max(den, 1u);
-  unsigned dabs;   // ||b| - |a||
-  asm("v_sad_u32 %0, %1, %2, 0" : "=v"(dabs) : "v"(babs), "v"(aabs));
-  const float est = ((float)dabs * __builtin_amdgcn_rcpf((float)den1)) * 4095.99609375f;   // 4096 (1 - 2^-20)
-  unsigned q = (unsigned)est;
-  const unsigned r = (dabs << 12) - __umul24(q, den1);   // in [0, 2 den)
-  q += (r >= den1);
-  // sign of the quotient term: (|b| < |a|) xor (b < 0)
-  const int sx = ((int)(babs - aabs) ^ b) >> 31;           // -1: the term is negative
-  const int nterm = sx - ((int)q ^ sx);                    // -(+-q)
-  int angle = nterm + ((b >> 31) & 8192) + 4096;           // base 4096 (b >= 0) or 12288, minus the term
-  if (den == 0) angle = 0;
-  const int sa = a >> 31;
-  return ((angle >> 1) ^ sa) - sa;                         // a < 0 negates; angle >= 0, so trunc(-angle / 2) = -(angle >> 1)
+// the angle as a float holding an exact integer in [-8192, 8192]
+__device__ __forceinline__ float fm_phi_f(int a, int b) {
+  const float af = (float)a, bf = (float)b;                 // exact (|.| <= 2^15)
+  const float den = __builtin_fabsf(af) + __builtin_fabsf(bf);   // <= 2^16, exact
+  const float d = __builtin_fabsf(bf) - __builtin_fabsf(af);     // exact
+  const float den1 = __builtin_fmaxf(den, 1.0f);
+  const float est = (__builtin_fabsf(d) * __builtin_amdgcn_rcpf(den1)) * 4095.99609375f;   // 4096 (1 - 2^-20)
+  float q = __builtin_floorf(est);
+  const float r = __builtin_fmaf(-q, den1, __builtin_fabsf(d) * 4096.0f);   // exact, in [0, 2 den)
+  q += (r >= den1) ? 1.0f : 0.0f;
+  // angle = 8192 - copysign(4096, b) - copysign(q, d xor b): base 4096 (b >= 0) or 12288, term's sign sign(d) * sign(b)
+  const float sq = __builtin_copysignf(q, __builtin_bit_cast(float, __builtin_bit_cast(unsigned, d) ^ __builtin_bit_cast(unsigned, bf)));
+  float angle = 8192.0f - (__builtin_copysignf(4096.0f, bf) + sq);
+  if (den == 0.0f) angle = 0.0f;
+  const float h = __builtin_floorf(angle * 0.5f);           // angle >= 0: trunc(angle / 2); a < 0 negates: trunc(-angle / 2) = -h
+  return __builtin_copysignf(h, af);
 }
+
+__device__ __forceinline__ int fm_phi(int a, int b) { return (int)fm_phi_f(a, b); }
