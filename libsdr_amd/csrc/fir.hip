@@ -433,7 +433,7 @@ __global__ __launch_bounds__(TPB) void fir_cf32_rt_kernel(const Fir32Args a) {
 // relying on the other workgroups of the CU being in the other phase (a tile is 34 KB: only 4 fit). Border tiles
 // (history, end of the call, unaligned rows) are staged by the clamped loads of the plain kernel, without prefetch.
 template <int R, int DC>
-__global__ __launch_bounds__(TPB, 4) void fir_cf32_pipe_kernel(const Fir32Args a) {
+__global__ __launch_bounds__(TPB, R == 4 ? 2 : 4) void fir_cf32_pipe_kernel(const Fir32Args a) {
   extern __shared__ __attribute__((aligned(16))) float2 smemf[];
   float2 *xs = smemf;
   const int c = blockIdx.y, tid = threadIdx.x;
@@ -820,7 +820,7 @@ int sdrhip_fir_create(sdrhip_ctx *ctx, int kind, const double *alpha, int order,
         // as many outputs per lane as keep the tile under 40 KB (4 workgroups = 16 waves per CU): more waves in
         // flight beat more reuse per LDS read — D = 8: R = 2 measured 25 % faster than R = 4 (2 workgroups per CU)
         // (R*D stays >= 2: the pad-per-R*D-samples layout needs an even lane stride)
-        while (h->R > 1 && tile_bytes(h->R) > 40 * 1024 && (h->R / 2) * decim >= 2) h->R >>= 1;
+        while (h->R > 1 && tile_bytes(h->R) > 40 * 1024 && (h->R / 2) * decim >= 2 && !getenv("SDRHIP_FIR_RFORCE")) h->R >>= 1;   // (RFORCE: tuning, keep SDRHIP_FIR_R)
         SDRHIP_REQUIRE(tile_bytes(h->R) <= 144 * 1024, SDRHIP_E_UNSUPPORTED, "order %d with decim %d exceeds the LDS tile", order, decim);
         h->lds3 = tile_bytes(h->R);
         if (h->lds3 > 64 * 1024) {
