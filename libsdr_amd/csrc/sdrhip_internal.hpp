@@ -149,8 +149,8 @@ void fir_set_shift(sdrhip_fir *h, double fc, double fs);
 __device__ __forceinline__ void xcd_unit_order(int &unit, int &chan) {
   unit = (int)blockIdx.x; chan = (int)blockIdx.y;
   if ((gridDim.y & 7u) == 0) {
-    const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y, x = lin & 7u, k = lin >> 3;
-    chan = (int)(x + 8u * (k / gridDim.x)); unit = (int)(k % gridDim.x);
+    const unsigned long long lin = blockIdx.x + (unsigned long long)gridDim.x * blockIdx.y, k = lin >> 3;
+    chan = (int)((unsigned)(lin & 7u) + 8u * (unsigned)(k / gridDim.x)); unit = (int)(k % gridDim.x);
   }
 }
 #endif
