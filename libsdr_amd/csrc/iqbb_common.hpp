@@ -46,6 +46,7 @@ struct IqbbArgs {
   int lpg;          // path 3: lanes that share one box window
   int tiles, tpw;   // tiles per channel in this call; consecutive tiles walked by one workgroup (MFMA paths)
   int bt_hi;        // hot kernel's cold phase: beside tile 0, the tiles bt_hi .. tiles-1 hold cold slices
+  int bt_lo;        // any-D kernel in border mode (bt_hi > 0): only the tiles [0, bt_lo) and [bt_hi, tiles) — the hot kernel's any-D form ran the rest
 };
 
 // Arguments of the hot kernels (iqbb_hot.hpp): the persistent grid's work split; everything the cold phase needs
@@ -61,6 +62,7 @@ struct HotArgs {
   int N, n_out;                         // samples per channel in this call, groups emitted (slice_is_hot)
   int C;                                // channels (cold phase)
   int cre, cim;
+  int D, GS, lpg_sh; float inv_d;       // any-D form: decimation, whole groups per slice (512 / D), log2 of the lanes per group team, (1 / D)(1 - 2^-20)
   unsigned long long *stamps;           // diagnostic builds (-DK1_STAMPS) only
 };
 

@@ -76,6 +76,7 @@ void hot_launch_s9_cu8(int range, bool rot, int epi, const HotLaunch &, const Ho
 void hot_launch_s17_cs16(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
 void hot_launch_s17_cu8(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
 void hot_launch_real(int S, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);   // S = 5 or 9
+void hot_launch_anyd(int S, int in, int range, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);   // S = 2 or 3, cs16 / cu8, shifted plans
 
 }  // namespace sdrhip
 
@@ -86,15 +87,25 @@ namespace {
 // (carry, the D+1 first window, FM's out[0] / out[1] rules) nor its last emitted one (that group hands the demodulator's
 // angle and the window carry to the next call — state only the cold phase's epilogue writes; found by
 // test_one_launch_kernel_random_long_calls), and all of them complete and are emitted.
-__host__ __device__ __forceinline__ bool slice_is_hot(int halo, int win, int base0_rel, int OG, int ovl, int N, int n_out, int tile, int w) {
-  const int qf = tile * OG - ovl + w * (64 - ovl);   // the slice's first group (output index within the call)
-  const int ws = base0_rel + qf * 8 - halo;          // its window's first sample (N < 2^30: no overflow)
-  return ws >= 0 && ws + win <= N && qf >= 1 && qf + 63 < n_out - 1;
+// D: decimation, GS: whole groups in a slice's 512 samples (8 and 64 for the lane-owned-group kernels).
+__host__ __device__ __forceinline__ bool slice_is_hot(int halo, int win, int base0_rel, int OG, int ovl, int N, int n_out, int tile, int w,
+                                                      int D = 8, int GS = 64) {
+  const int qf = tile * OG - ovl + w * (GS - ovl);   // the slice's first group (output index within the call)
+  const int ws = base0_rel + qf * D - halo;          // its window's first sample (N < 2^30: no overflow)
+  return ws >= 0 && ws + win <= N && qf >= 1 && qf + GS - 1 < n_out - 1;
 }
 
-template <int S, int S0, int NH, bool ROT, int EPI, int IN, int NW>
+// DG: ANY decimation 9 <= D <= 180 (the reference's own receivers decimate by 62 and 125, examples/sdr_rec.cc:68,
+// examples/sdr_fm.cc:40). The matrix part, the windows and the grid are the same; a slice's 512 samples hold GS = 512 / D
+// whole groups (the slices of a wave advance by (GS - ovl) * D samples, so every slice starts on a group), the rotated
+// samples go through a 2 KB per-wave LDS array and lane teams sum the groups from there. The tap fragments are path 3's
+// (rows in natural order: the border tiles of the call run the general any-D kernel on the same plan), and there is no
+// cold phase: the host launches that kernel for the tiles this one leaves out.
+template <int S, int S0, int NH, bool ROT, int EPI, int IN, int NW, bool DG = false>
 __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &b) {
   constexpr bool CU8 = IN == HOT_CU8, REAL = IN == HOT_REAL;
+  static_assert(!DG || (ROT && !REAL && NW == 4), "any-D form: shifted complex plans, 4-wave workgroups");
+  const int DD = DG ? a.D : 8, GS = DG ? a.GS : 64;   // decimation, whole groups per slice
   static_assert(S >= 2 && S0 >= 0 && NH >= 1 && S0 + NH <= S, "high-plane range inside the K loop");
   static_assert(!REAL || NW == 4, "real input: 4-wave workgroups");
   static_assert(NW == 4 || NW == 8 || NW == 16, "4-wave virtual workgroups");
@@ -123,6 +134,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   const int bx = (int)blockIdx.x * (NW / 4) + (w >> 2), gx = (int)gridDim.x * (NW / 4);   // virtual workgroup, virtual grid
   // tap fragments in LDS: the S low-plane fragments, then only the NH high-plane fragments of steps [S0, S0 + NH)
   char *wbase = reinterpret_cast<char *>(smem + TBLW + (S + NH) * 64 * 4) + w * (NBUF * BUFB);
+  char *gscb = reinterpret_cast<char *>(smem + TBLW + (S + NH) * 64 * 4) + NW * (NBUF * BUFB) + w * 2048;   // (DG) the wave's rotated samples
 #ifdef K1_ABL_ASAME   // (tuning ablation, results wrong: every step reads the SAME fragment values — K1_ABL_AREG's operand data with the reads kept)
   for (int i = tid; i < S * 64; i += TPBH) taps_s[i] = a.tapfrag[64 + (i & 63)];
   for (int i = tid; i < NH * 64; i += TPBH) taps_s[S * 64 + i] = a.tapfrag[(2 * S0) * 64 + (i & 63)];
@@ -136,7 +148,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
     else if (tid < 128) lut_s[tid] = e;
   }
 
-  const int OGw = 64 - a.ovl, gw = wv * OGw;
+  const int OGw = GS - a.ovl, gw = wv * OGw;
   // PERSISTENT grid: gx virtual workgroups (4 per CU) stay resident and walk the work units u = bx, bx + gx, ...;
   // unit u = (channel u / G, tile group u % G of `tpw` consecutive tiles). All units are the same length, so the static
   // assignment balances (one workgroup per unit left ~3 of 4 workgroups per CU resident: the unsynchronised waves of a
@@ -145,8 +157,8 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   // monotone in the tile — the same for every channel: found once per wave, so that the loop below tests tile numbers
   // instead of evaluating the conditions per slice.
   int hl = a.t_lo, hh = a.t_hi;
-  while (hl < hh && !slice_is_hot(HALO, WIN, a.base0_rel, a.OG, a.ovl, a.N, a.n_out, hl, wv)) hl++;
-  while (hh > hl && !slice_is_hot(HALO, WIN, a.base0_rel, a.OG, a.ovl, a.N, a.n_out, hh - 1, wv)) hh--;
+  while (hl < hh && !slice_is_hot(HALO, WIN, a.base0_rel, a.OG, a.ovl, a.N, a.n_out, hl, wv, DD, GS)) hl++;
+  while (hh > hl && !slice_is_hot(HALO, WIN, a.base0_rel, a.OG, a.ovl, a.N, a.n_out, hh - 1, wv, DD, GS)) hh--;
   int u = bx;
   int c = u / a.G, g = u - c * a.G;   // (one division per wave, at start; afterwards (c, g) advance by (dq, dr))
   int tile = max(a.t_lo + g * a.tpw, hl), tend = min(a.t_lo + g * a.tpw + a.tpw, hh);
@@ -167,10 +179,10 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   const uint32_t lane_byte = 16u * (uint32_t)l;
   constexpr int SB = IN == HOT_CS16 ? 4 : 2;                   // bytes per input sample
   constexpr int OB = EPI == SDRHIP_EPI_NONE ? 4 : 2;           // bytes per output element
-  const int tile_in_bytes = a.OG * 8 * SB, tile_out_bytes = a.OG * OB;
-  const uint32_t tile_cnt = (uint32_t)(a.OG * 8) * a.inc;      // LUT phase counter advance per tile
-  const uint32_t cnt0 = (a.n0_lo + (uint32_t)(a.base0_rel + (gw - a.ovl) * 8)) * a.inc;   // ... of the wave's first sample in tile 0
-  auto chan_src = [&](int c_) { return reinterpret_cast<const char *>(a.in) + ((long)c_ * a.in_stride + (a.base0_rel + (gw - a.ovl) * 8 - HALO)) * SB; };
+  const int tile_in_bytes = a.OG * DD * SB, tile_out_bytes = a.OG * OB;
+  const uint32_t tile_cnt = (uint32_t)(a.OG * DD) * a.inc;      // LUT phase counter advance per tile
+  const uint32_t cnt0 = (a.n0_lo + (uint32_t)(a.base0_rel + (gw - a.ovl) * DD)) * a.inc;   // ... of the wave's first sample in tile 0
+  auto chan_src = [&](int c_) { return reinterpret_cast<const char *>(a.in) + ((long)c_ * a.in_stride + (a.base0_rel + (gw - a.ovl) * DD - HALO)) * SB; };
   auto chan_out = [&](int c_) { return reinterpret_cast<char *>(a.out) + ((long)c_ * a.out_stride + (gw - a.ovl)) * OB; };
   const char *srcb = chan_src(c);
   char *outb = chan_out(c);
@@ -215,7 +227,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   const int coff = REAL ? 16 * (n + h) : h * HALF + 16 * n;   // chunk 2(n + s) + h of the wave's window (real: chunk n + 2s + h)
   // phase counters of the lane's samples 0 and 1 relative to the wave's first sample, as a 16-bit pair (only bits 8..14
   // of a counter pick the table entry); the wave's part is scalar and joins per slice in one v_pk_add_u16 per sample pair
-  const uint32_t lane_cnt = (uint32_t)(MF_BLK * n + 8 * h) * a.inc;
+  const uint32_t lane_cnt = (uint32_t)(MF_BLK * n + (DG ? 2 : 8) * h) * a.inc;   // (DG: natural row order — the lane's sample pairs sit at 16n + 2h + 4jj)
   const uint32_t lane_pair = (lane_cnt & 0xffffu) | ((lane_cnt + a.inc) << 16);
 
   // + 128*sum(a) rides into the low-plane accumulator as the first MFMA's C operand: a 16-register block that must
@@ -336,7 +348,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       typedef int v2i __attribute__((ext_vector_type(2)));
 #pragma unroll
       for (int jj = 0; jj < 4; jj++) {
-        const uint32_t wc = (wave_cnt + 2u * jj * a.inc) & 0xffffu, wpair = wc | (wc << 16);
+        const uint32_t wc = (wave_cnt + (DG ? 4u : 2u) * jj * a.inc) & 0xffffu, wpair = wc | (wc << 16);
         uint32_t pr, o0, o1;
         asm("v_pk_add_u16 %0, %1, %2" : "=v"(pr) : "v"(lane_pair), "s"(wpair));
         if (WIDE) {
@@ -355,6 +367,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       }
     }
     int2 sum = make_int2(0, 0);
+    unsigned pk[8];   // (DG) the lane's rotated samples
 #ifdef K1_ABL_NOEPI
 #pragma unroll
     for (int r = 0; r < 16; r += 2) { sum.x += acc_hh[r] ^ acc_mid[r] ^ acc_ll[r]; sum.y += acc_hh[r + 1] ^ acc_mid[r + 1] ^ acc_ll[r + 1]; }
@@ -373,13 +386,69 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       if (ROT) {
         const int x = WIDE ? mad24a(L[j][0], rr, mul24a(L[j][2], ri)) : sub32(mul24a(L[j][0], rr), mul24a(L[j][1], ri));
         const int y = mad24a(L[j][0], ri, mul24a(L[j][1], rr));
-        sum.x = add_hi16(x, sum.x); sum.y = add_hi16(y, sum.y);
+        if (DG) pk[j] = __builtin_amdgcn_perm((unsigned)y, (unsigned)x, 0x07060302u);   // {x >> 16, y >> 16} as two int16
+        else { sum.x = add_hi16(x, sum.x); sum.y = add_hi16(y, sum.y); }
       } else {
         sum.x = (int)((unsigned)sum.x + (unsigned)rr); sum.y = (int)((unsigned)sum.y + (unsigned)ri);
       }
     }
 #endif
+    if (DG) {
+      // the wave's 512 rotated samples in stream order (lane (n, h) holds the pairs 16n + 2h + 4jj + {0, 1}), then teams of
+      // `lpg` lanes (a power of two <= 16, about 64 / GS) sum one group each: strided partial sums, then a shift tree
+      // inside the team (one wave's LDS operations execute in order; the asm keeps the compiler from reordering them)
+      unsigned *gsc = reinterpret_cast<unsigned *>(gscb);
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++)
+        *reinterpret_cast<uint2 *>(gsc + 16 * n + 2 * h + 4 * jj) = make_uint2(pk[2 * jj], pk[2 * jj + 1]);
+      asm volatile("" ::: "memory");
+      const int lsh = a.lpg_sh, k = l >> lsh, t = l & ((1 << lsh) - 1);
+      int sx = 0, sy = 0;
+      if (k < GS) {
+        const unsigned *gp = gsc + k * DD;
+        for (int e = t; e < DD; e += 1 << lsh) {
+          const unsigned v = gp[e];
+          asm("v_add_u32_sdwa %0, sext(%1), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "+v"(sx) : "v"(v));
+          asm("v_add_u32_sdwa %0, sext(%1), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(sy) : "v"(v));
+        }
+      }
+      asm volatile("" ::: "memory");
+      // lane t of a team += lane t + s (row_shl: s, zero beyond the 16-lane row) for s = 1, 2, 4, 8 below the team size
+      if (lsh > 0) { sx += __builtin_amdgcn_update_dpp(0, sx, 0x101, 0xf, 0xf, true); sy += __builtin_amdgcn_update_dpp(0, sy, 0x101, 0xf, 0xf, true); }
+      if (lsh > 1) { sx += __builtin_amdgcn_update_dpp(0, sx, 0x102, 0xf, 0xf, true); sy += __builtin_amdgcn_update_dpp(0, sy, 0x102, 0xf, 0xf, true); }
+      if (lsh > 2) { sx += __builtin_amdgcn_update_dpp(0, sx, 0x104, 0xf, 0xf, true); sy += __builtin_amdgcn_update_dpp(0, sy, 0x104, 0xf, 0xf, true); }
+      if (lsh > 3) { sx += __builtin_amdgcn_update_dpp(0, sx, 0x108, 0xf, 0xf, true); sy += __builtin_amdgcn_update_dpp(0, sy, 0x108, 0xf, 0xf, true); }
+      sum = make_int2(sx, sy);   // (whole in the team's first lane)
+    }
     return sum;
+  };
+  // F (DG): the team's first lane owns group k = l >> lpg_sh of the slice: truncating division by D (|sum| <= D * 2^15 and
+  // D <= 180: libstdc++'s (s * D) / (D * D) of src/baseband.hh:214 cannot wrap, it is trunc(s / D): a float estimate
+  // biased down + one exact remainder step), demodulator, store; FM: the previous group's angle from the team before
+  auto div_d = [&](int v) __attribute__((always_inline)) {
+    const unsigned m = (unsigned)max(v, -v);
+    unsigned q = (unsigned)((float)m * a.inv_d);          // inv_d = (1 / D)(1 - 2^-20): q or q - 1 (m < 2^23: the product is good to 2^-7)
+    const unsigned r = m - q * (unsigned)DD;
+    q += (r >= (unsigned)DD) ? 1u : 0u;
+    return (int)(short)(v < 0 ? -(int)q : (int)q);        // (the int16 wrap of the assignment)
+  };
+  auto stageF_gen = [&](int2 sum, char *orow, int k_lo) __attribute__((always_inline)) {
+    const int lsh = a.lpg_sh, k = l >> lsh;
+    const bool lead = (l & ((1 << lsh) - 1)) == 0 && k < GS;
+    const int yr = div_d(sum.x), yi = div_d(sum.y);
+    if (EPI == SDRHIP_EPI_NONE) {
+      if (lead && k >= k_lo) reinterpret_cast<uint32_t *>(orow)[k] = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
+    } else if (EPI == SDRHIP_EPI_AM) {
+      const short o = am_i16(yr, yi);
+      if (lead && k >= k_lo) reinterpret_cast<short *>(orow)[k] = o;
+    } else if (EPI == SDRHIP_EPI_USB) {
+      const short o = usb_i16(yr, yi);
+      if (lead && k >= k_lo) reinterpret_cast<short *>(orow)[k] = o;
+    } else {
+      const int phi = fm_phi(yr, yi);
+      const int prev = __builtin_amdgcn_ds_bpermute(4 * (((k - 1) << lsh) & 63), phi);   // the leader of team k - 1
+      if (lead && k >= k_lo) reinterpret_cast<short *>(orow)[k] = (short)(prev - phi);
+    }
   };
   // F: truncating division by 8, demodulator, store. orow: (scalar) the wave's first group of this slice; lanes below
   // glw_lo store nothing (FM: group 0 only supplies the previous angle)
@@ -471,7 +540,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       asm volatile("" : "+v"(sum.x), "+v"(sum.y));
 #endif
       K1_STAMP(4);
-      stageF(sum, outb + (long)tile * tile_out_bytes, GLW0);
+      if (DG) stageF_gen(sum, outb + (long)tile * tile_out_bytes, GLW0); else stageF(sum, outb + (long)tile * tile_out_bytes, GLW0);
       K1_STAMP(5);
 #ifdef K1_STAMPS
       st_tiles++;
@@ -493,7 +562,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
 #ifdef K1_ABL_NOCOLD   // tuning ablation (results wrong): no cold phase
     for (int cc = a.C; cc < a.C; cc += gx) {
 #else
-    for (int cc = bx; cc < a.C; cc += gx) {
+    for (int cc = DG ? a.C : bx; cc < a.C; cc += gx) {   // (DG: the border tiles run the general any-D kernel, a launch of its own)
 #endif
       for (int t = 0; t < b.tiles; t = (t == 0 ? max(b.bt_hi, 1) : t + 1)) {
         const int q0 = t * a.OG - a.ovl, groups_here = min(b.CG, b.n_groups - q0);
@@ -648,6 +717,10 @@ template <int S, int S0, int NH, bool ROT, int EPI, int IN, int NW>
 __global__ __launch_bounds__(64 * NW, K1_MINWAVES) void iqbb_hot_kernel(const HotArgs a, const IqbbArgs b) {
   iqbb_hot_body<S, S0, NH, ROT, EPI, IN, NW>(a, b);
 }
+template <int S, int S0, int NH, int EPI, int IN>
+__global__ __launch_bounds__(256, K1_MINWAVES) void iqbb_hot_anyd_kernel(const HotArgs a, const IqbbArgs b) {
+  iqbb_hot_body<S, S0, NH, true, EPI, IN, 4, true>(a, b);
+}
 
 template <int S, int S0, int NH, int IN, int NW>
 void hot_launch_one(bool rot, int epi, const HotLaunch &hl, const HotArgs &ha, const IqbbArgs &b) {
@@ -662,6 +735,18 @@ void hot_launch_one(bool rot, int epi, const HotLaunch &hl, const HotArgs &ha, c
   if (rot) SDRHIP_HOT_E(true); else SDRHIP_HOT_E(false);
 #undef SDRHIP_HOT_E
 #undef SDRHIP_HOT
+}
+
+template <int S, int S0, int NH, int IN>
+void hot_launch_anyd_one(int epi, const HotLaunch &hl, const HotArgs &ha, const IqbbArgs &b) {
+  const size_t lds = (size_t)hot_lds_bytes(S, NH, IN, 4, hot_wide(S, NH, IN, 4)) + 4 * 2048;
+  const dim3 grid(hl.grid, 1), block(256);
+  switch (epi) {
+    case SDRHIP_EPI_FM: hipLaunchKernelGGL((iqbb_hot_anyd_kernel<S, S0, NH, SDRHIP_EPI_FM, IN>), grid, block, lds, hl.stream, ha, b); break;
+    case SDRHIP_EPI_AM: hipLaunchKernelGGL((iqbb_hot_anyd_kernel<S, S0, NH, SDRHIP_EPI_AM, IN>), grid, block, lds, hl.stream, ha, b); break;
+    case SDRHIP_EPI_USB: hipLaunchKernelGGL((iqbb_hot_anyd_kernel<S, S0, NH, SDRHIP_EPI_USB, IN>), grid, block, lds, hl.stream, ha, b); break;
+    default: hipLaunchKernelGGL((iqbb_hot_anyd_kernel<S, S0, NH, SDRHIP_EPI_NONE, IN>), grid, block, lds, hl.stream, ha, b); break;
+  }
 }
 
 }  // namespace

@@ -594,8 +594,12 @@ __global__ __launch_bounds__(TPB, 3) void iqbb_i16_mfmag_kernel(const IqbbArgs a
       }
     }
   };
-  const int tile_end = min((int)(blockIdx.x + 1) * a.tpw, a.tiles);
+  int tile_end = min((int)(blockIdx.x + 1) * a.tpw, a.tiles);
   int tile = blockIdx.x * a.tpw;
+  if (a.bt_hi > 0) {   // border mode: one tile per workgroup, the call's first bt_lo tiles and the tiles from bt_hi on
+    tile = (int)blockIdx.x < a.bt_lo ? (int)blockIdx.x : (int)blockIdx.x - a.bt_lo + a.bt_hi;
+    tile_end = tile + 1;
+  }
   if (tile < tile_end) fetch(tile);
   for (; tile < tile_end; tile++) {
   const int q0 = tile * a.OG - a.ovl;    // first group (relative to the call's first group) of this tile
@@ -1060,7 +1064,7 @@ struct sdrhip_iqbb_i16 {
             if (ah != 0) ah_mask |= 1u << st;
             frag[(((size_t)(2 * st + 1) * 64 + l) * 16) + j] = (int8_t)al;
           }
-      if (path == 1) {   // smallest centred range [S0, S0+NH) of the hot kernel that covers the mask
+      if (path == 1 || path == 3) {   // smallest centred range [S0, S0+NH) of the hot kernel that covers the mask (path 3: its any-D form)
         int nr = 0;
         const HotRange *rg = hot_ranges(S, &nr);
         for (int r = 0; r < nr && hot_range < 0; r++)
@@ -1109,6 +1113,7 @@ struct sdrhip_iqbb_i16 {
     ha.tapfrag = tapfrag.p; ha.lut = lut.p; ha.inc = inc; ha.n0_lo = (uint32_t)(n0 - phase0); ha.negative = negative;
     ha.base0_rel = g.base0_rel; ha.OG = OG; ha.ovl = ovl; ha.t_lo = 0; ha.t_hi = tiles; ha.cre = cre; ha.cim = cim;
     ha.N = (int)N; ha.n_out = g.n_out; ha.C = C; ha.stamps = nullptr;
+    ha.D = 8; ha.GS = 64; ha.lpg_sh = 0; ha.inv_d = 0.125f;   // (the any-D form's fields)
 #ifdef K1_STAMPS
     if (!k1_stamps.p) { k1_stamps.alloc(32768 * 16); k1_stamps.zero(ctx->stream); }
     ha.stamps = k1_stamps.p;
@@ -1129,6 +1134,62 @@ struct sdrhip_iqbb_i16 {
     a.bt_hi = (int)t; a.tpw = 1;
     HotLaunch hl{(unsigned)grid, ctx->stream};
     launch_hot(S, kind, hot_range, inc != 0, epi, hl, ha, a);
+    return true;
+  }
+
+  // Path 3's long calls: the hot kernel's any-D form (iqbb_hot.hpp, DG) for the tiles whose four slices are all hot, the
+  // general any-D kernel in border mode for the rest (first and last tiles: history, carries, the stream's first sample,
+  // state for the next call). Both write the groups of the seam tiles they share — the same values.
+  // false: not this plan / call (the general kernel runs it whole).
+  bool anyd_plan() const {
+    return path == 3 && use_hot && hot_range >= 0 && inc != 0 && (S == 2 || S == 3) && !i8 && !real && D >= 9 && D <= 180 && 512 / D - ovl >= 1;
+  }
+  bool launch_anyd_call(IqbbArgs &a, const Geometry &g, const uint32_t *in_dev, size_t N, size_t in_stride, void *out_dev,
+                        size_t out_stride, int tiles_m, size_t lds_m) {
+    const int kind = in_cu8 ? HOT_CU8 : HOT_CS16, halo = hot_halo(S, kind), win = hot_win(S, kind);
+    const int GS = 512 / D, OGw = GS - ovl, OGh = 4 * OGw;
+    const int tiles_h = (int)ceil_div((size_t)g.n_groups, (size_t)OGh);
+    auto tile_hot = [&](int t) {
+      for (int w = 0; w < 4; w++) if (!slice_is_hot(halo, win, g.base0_rel, OGh, ovl, (int)N, g.n_out, t, w, D, GS)) return false;
+      return true;
+    };
+    int t_lo = 0, t_hi = tiles_h;
+    while (t_lo < t_hi && !tile_hot(t_lo)) t_lo++;
+    while (t_hi > t_lo && !tile_hot(t_hi - 1)) t_hi--;
+    if (t_hi - t_lo < 4) return false;
+    // border tiles of the general kernel: its tiles emit OG groups each
+    const long ga = (long)t_lo * OGh, gb = (long)t_hi * OGh;
+    int bt_lo = (int)ceil_div((size_t)ga, (size_t)OG), bt_hi = (int)(gb / OG);
+    bt_hi = std::min(bt_hi, tiles_m - 1);   // (the last tile always: it rolls the history and hands the state on)
+    if (bt_lo >= bt_hi) return false;
+    HotArgs ha;
+    ha.in = in_dev; ha.in_stride = (long)in_stride; ha.out = out_dev; ha.out_stride = (long)out_stride;
+    ha.tapfrag = tapfrag.p; ha.lut = lut.p; ha.inc = inc; ha.n0_lo = (uint32_t)(n0 - phase0); ha.negative = negative;
+    ha.base0_rel = g.base0_rel; ha.OG = OGh; ha.ovl = ovl; ha.t_lo = t_lo; ha.t_hi = t_hi; ha.cre = cre; ha.cim = cim;
+    ha.N = (int)N; ha.n_out = g.n_out; ha.C = C; ha.stamps = nullptr;
+    ha.D = D; ha.GS = GS;
+    { int lpg = 1; while (2 * lpg <= 16 && 2 * lpg * GS <= 64) lpg *= 2; int sh = 0; while ((1 << sh) < lpg) sh++; ha.lpg_sh = sh; }
+    ha.inv_d = (float)((1.0 / D) * (1.0 - 1.0 / 1048576.0));
+#ifdef K1_STAMPS
+    if (!k1_stamps.p) { k1_stamps.alloc(32768 * 16); k1_stamps.zero(ctx->stream); }
+    ha.stamps = k1_stamps.p;
+#endif
+    const int nvwg = 4 * ctx->prop.multiProcessorCount;
+    int htpw = 4; while (htpw > 1 && (size_t)ceil_div((size_t)tiles_h, (size_t)htpw) * C < 4 * (size_t)nvwg) htpw >>= 1;
+    { const char *e = getenv("SDRHIP_IQBB_TPW"); if (e) htpw = std::max(1, atoi(e)); }   // tuning hook
+    ha.tpw = htpw;
+    ha.G = (int)ceil_div((size_t)tiles_h, (size_t)htpw); ha.U = ha.G * C;
+    const int grid = std::max(1, std::min(nvwg, ha.U));
+    ha.dq = grid / ha.G; ha.dr = grid % ha.G;
+    HotLaunch hl{(unsigned)grid, ctx->stream};
+    hot_launch_anyd(S, kind, hot_range, epi, hl, ha, a);
+    // the border tiles (a.* is the general kernel's own geometry)
+    a.bt_lo = bt_lo; a.bt_hi = bt_hi; a.tpw = 1;
+    const dim3 gridb((unsigned)(bt_lo + tiles_m - bt_hi), C), block(TPB);
+#define SDRHIP_MFGB(S_) do { if (in_cu8) hipLaunchKernelGGL((iqbb_i16_mfmag_kernel<S_, true, true>), gridb, block, lds_m, ctx->stream, a); \
+                             else hipLaunchKernelGGL((iqbb_i16_mfmag_kernel<S_, true, false>), gridb, block, lds_m, ctx->stream, a); } while (0)
+    if (S == 2) SDRHIP_MFGB(2); else SDRHIP_MFGB(3);
+#undef SDRHIP_MFGB
     return true;
   }
 
@@ -1158,7 +1219,7 @@ struct sdrhip_iqbb_i16 {
     int tpw = 1;
     if (path == 1 || path == 2 || path == 4) { tpw = 8; while (tpw > 1 && (size_t)ceil_div((size_t)tiles, (size_t)tpw) * C < 2048) tpw >>= 1; }
     { const char *t = getenv("SDRHIP_IQBB_TPW"); if (t && (path == 1 || path == 2 || path == 4)) tpw = std::max(1, atoi(t)); }   // tuning hook
-    a.tiles = tiles; a.tpw = tpw; a.bt_hi = 0;
+    a.tiles = tiles; a.tpw = tpw; a.bt_hi = 0; a.bt_lo = 0;
     a.lpg = 1; while (a.lpg < 64 && a.lpg * 8 < D) a.lpg <<= 1;
     dim3 grid((unsigned)ceil_div((size_t)tiles, (size_t)tpw), C), block(TPB);
     if (path == 4 && use_hot && hot_range >= 0 && tiles >= 3 && launch_hot_call(a, g, in_dev, N, in_stride, out_dev, out_stride, tiles)) {
@@ -1172,7 +1233,10 @@ struct sdrhip_iqbb_i16 {
         default: SDRHIP_MFR(9); break;
       }
 #undef SDRHIP_MFR
+    } else if (path == 3 && anyd_plan() && launch_anyd_call(a, g, in_dev, N, in_stride, out_dev, out_stride, tiles, lds_bytes)) {
+      // (the hot kernel's any-D form took the interior tiles, the general kernel the border ones)
     } else if (path == 3) {
+      a.bt_hi = 0; a.bt_lo = 0; a.tpw = tpw;
       int tpw3 = 8; while (tpw3 > 1 && (size_t)ceil_div((size_t)tiles, (size_t)tpw3) * C < 2048) tpw3 >>= 1;
       { const char *t = getenv("SDRHIP_IQBB_TPW"); if (t) tpw3 = std::max(1, atoi(t)); }   // tuning hook
       a.tpw = tpw3;
@@ -1391,6 +1455,7 @@ int sdrhip_iqbb_i16_kernel_names(sdrhip_iqbb_i16 *h, char *buf, size_t len) {
     const char *nm = "iqbb_i16_kernel";
     if (h->path == 4 && h->use_hot && h->hot_range >= 0) nm = "iqbb_hot_kernel";   // (calls of < 3 tiles: the general kernel)
     else if (h->path == 4) nm = "bb_real_mfma_kernel";
+    else if (h->path == 3 && h->anyd_plan()) nm = "iqbb_hot_anyd_kernel,iqbb_i16_mfmag_kernel";   // (calls of a few tiles: the general kernel alone)
     else if (h->path == 3) nm = "iqbb_i16_mfmag_kernel";
     else if (h->path == 2) nm = "iqbb_i16_mfma16_kernel";
     else if (h->path == 1 && h->use_dma && h->use_hot && h->hot_range >= 0) nm = "iqbb_hot_kernel";   // (calls of < 3 tiles: the general kernel)

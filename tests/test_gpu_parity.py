@@ -145,6 +145,67 @@ def test_iqbb_batched_vs_oracle(ctx, orc, epi, order, decim, Fc, k1path):
         off += n
 
 
+ANYD_CASES = [(21, 125, 100e3, True), (16, 62, 100e3, False), (21, 9, -60e3, False), (33, 180, 41e3, False), (16, 12, 100e3, False),
+              (17, 31, -250e3, True), (3, 100, 100e3, False), (33, 10, 70e3, True)]
+
+
+@pytest.mark.parametrize("hot", [True, False])
+@pytest.mark.parametrize("epi", [sa.EPI_NONE, sa.EPI_FM, sa.EPI_AM, sa.EPI_USB])
+@pytest.mark.parametrize("order,decim,Fc,cu8", ANYD_CASES)
+def test_iqbb_any_decimation_long_calls_vs_oracle(ctx, orc, order, decim, Fc, cu8, epi, hot, monkeypatch):
+    """The reference's own receivers decimate by 62 (examples/sdr_rec.cc:68, 16 taps) and 125 (examples/sdr_fm.cc:40, 21
+    taps on complex<uint8> input): plans of up to 33 taps with a shift and 9 <= D <= 180 run the hot kernel's any-D form
+    on the interior tiles of a long call and the general any-D kernel on the border tiles (two launches, seam tiles
+    written by both). Ragged long and short calls, state carried across them, against the oracle; `hot` = False: the
+    general kernel alone (SDRHIP_IQBB_HOT=0)."""
+    monkeypatch.setenv("SDRHIP_IQBB_HOT", "1" if hot else "0")
+    monkeypatch.delenv("SDRHIP_IQBB_PATH", raising=False)
+    FSr, C = 1e6, 3
+    rng = np.random.default_rng(order * 1000 + decim)
+    taps, lut, inc = orc.iqbb_design(abs(Fc), 12.5e3, FSr, order), orc.freqshift_lut_i16(), orc.freqshift_inc(Fc, FSr)
+    node = sa.IQBaseBandI16(ctx, taps, lut, inc, Fc < 0, decim, channels=C, max_in=70000, epilogue=epi)
+    if cu8:
+        node.set_input_format(sa.abi.IN_CU8)
+    assert node.path == 3
+    assert node.kernel_names == (["iqbb_hot_anyd_kernel", "iqbb_i16_mfmag_kernel"] if hot else ["iqbb_i16_mfmag_kernel"])
+    refs = [orc.IQBaseBandI16(taps, lut, inc, Fc < 0, decim) for _ in range(C)]
+    fms = [orc.FMDemodI16() for _ in range(C)]
+    for n in (65536, 70000, 12345, 1, 40001, 2 * decim + 1, 65536):
+        x = rng.integers(0, 256, (C, n, 2), dtype=np.uint8) if cu8 else rng.integers(-32768, 32768, (C, n, 2), dtype=np.int16)
+        y = node.process(x)
+        for c in range(C):
+            r = refs[c].process(orc.autocast_cu8_cs16(x[c]) if cu8 else x[c])
+            if epi == sa.EPI_FM:
+                r = fms[c].process(r) if len(r) else np.zeros(0, np.int16)
+            elif epi == sa.EPI_AM:
+                r = orc.am_i16(r)
+            elif epi == sa.EPI_USB:
+                r = orc.usb_i16(r)
+            assert y[c].shape == r.shape and np.array_equal(y[c], r), (n, c)
+
+
+def test_iqbb_any_decimation_full_size(ctx, orc):
+    """The sdr_fm plan (21 taps, decimation 125, complex<uint8> input, FM) at the BASELINE batch: 1024 channels x 65536
+    samples, two calls: batching invariance over all channels, 8 patterns against the oracle."""
+    C, N, D = 1024, 65536, 125
+    FSr = 1e6
+    taps, lut, inc = orc.iqbb_design(100e3, 12.5e3, FSr, 21), orc.freqshift_lut_i16(), orc.freqshift_inc(100e3, FSr)
+    rng = np.random.default_rng(77)
+    base = rng.integers(0, 256, (8, 2 * N, 2), dtype=np.uint8)
+    x = np.ascontiguousarray(base[np.arange(C) % 8])
+    node = sa.IQBaseBandI16(ctx, taps, lut, inc, False, D, channels=C, max_in=N, epilogue=sa.EPI_FM)
+    node.set_input_format(sa.abi.IN_CU8)
+    assert node.kernel_names[0] == "iqbb_hot_anyd_kernel"
+    ys = [node.process(x[:, :N]), node.process(x[:, N:])]
+    for y in ys:
+        for k in range(8):
+            assert (y[k::8] == y[k]).all()
+    for k in range(8):
+        bb, fm = orc.IQBaseBandI16(taps, lut, inc, False, D), orc.FMDemodI16()
+        for i, y in enumerate(ys):
+            assert np.array_equal(y[k], fm.process(bb.process(orc.autocast_cu8_cs16(base[k, i * N:(i + 1) * N])))), (k, i)
+
+
 def test_iqbb_random_fullscale_vs_oracle(ctx, orc, k1path):
     """Full-range random int16 input (worst case for the int32 accumulators and the >>14/>>16 steps)."""
     rng = np.random.default_rng(7)
