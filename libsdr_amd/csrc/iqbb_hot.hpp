@@ -432,7 +432,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
     q += (r >= (unsigned)DD) ? 1u : 0u;
     return (int)(short)(v < 0 ? -(int)q : (int)q);        // (the int16 wrap of the assignment)
   };
-  auto stageF_gen = [&](int2 sum, char *orow, int k_lo) __attribute__((always_inline)) {
+  auto stageF_gen = [&](int2 sum, char *orow, int k_lo, short *plast) __attribute__((always_inline)) {
     const int lsh = a.lpg_sh, k = l >> lsh;
     const bool lead = (l & ((1 << lsh) - 1)) == 0 && k < GS;
     const int yr = div_d(sum.x), yi = div_d(sum.y);
@@ -445,9 +445,12 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       const short o = usb_i16(yr, yi);
       if (lead && k >= k_lo) reinterpret_cast<short *>(orow)[k] = o;
     } else {
+      // every group of the slice is emitted; the first one as -phi: the border launch adds the previous slice's last
+      // angle, which this slice's last team leaves in philast (IqbbArgs::fix_*)
       const int phi = fm_phi(yr, yi);
       const int prev = __builtin_amdgcn_ds_bpermute(4 * (((k - 1) << lsh) & 63), phi);   // the leader of team k - 1
-      if (lead && k >= k_lo) reinterpret_cast<short *>(orow)[k] = (short)(prev - phi);
+      if (lead) reinterpret_cast<short *>(orow)[k] = (short)((k > 0 ? prev : 0) - phi);
+      if (lead && k == GS - 1) *plast = (short)phi;
     }
   };
   // F: truncating division by 8, demodulator, store. orow: (scalar) the wave's first group of this slice; lanes below
@@ -540,7 +543,8 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       asm volatile("" : "+v"(sum.x), "+v"(sum.y));
 #endif
       K1_STAMP(4);
-      if (DG) stageF_gen(sum, outb + (long)tile * tile_out_bytes, GLW0); else stageF(sum, outb + (long)tile * tile_out_bytes, GLW0);
+      if (DG) stageF_gen(sum, outb + (long)tile * tile_out_bytes, 0, a.philast + (long)c * a.philast_stride + 4 * tile + wv);
+      else stageF(sum, outb + (long)tile * tile_out_bytes, GLW0);
       K1_STAMP(5);
 #ifdef K1_STAMPS
       st_tiles++;

@@ -716,6 +716,11 @@ __global__ __launch_bounds__(TPB, 3) void iqbb_i16_mfmag_kernel(const IqbbArgs a
   __syncthreads();
   epilogue_and_roll(a, c, tile, tid, q0, groups_here, ybuf);
   }   // (the next tile's planes / vbuf / ybuf writes are each separated from this tile's reads by one of its barriers)
+  if (a.bt_hi > 0 && a.fix_hi > a.fix_lo && blockIdx.x == 0) {   // border mode with FM: the hot slices' first groups (IqbbArgs::fix_*)
+    short *row = reinterpret_cast<short *>(a.out) + (long)c * a.out_stride;
+    const short *pl = a.philast + (long)c * a.philast_stride;
+    for (int sl = a.fix_lo + tid; sl < a.fix_hi; sl += TPB) row[sl * a.fix_gs] = (short)(row[sl * a.fix_gs] + pl[sl - 1]);
+  }
 }
 
 // =================================================================================================
@@ -987,6 +992,7 @@ struct sdrhip_iqbb_i16 {
 #ifdef K1_STAMPS
   DevBuf<unsigned long long> k1_stamps;   // diagnostic builds: per-wave phase totals of the hot kernel
 #endif
+  DevBuf<short> philast;   // any-D hot form with FM: the last angle of every slice (HotArgs::philast)
 
 
   // (re)loads the tap-dependent device data: packed taps (VALU kernel, the slow first-sample evaluation), the
@@ -1113,7 +1119,7 @@ struct sdrhip_iqbb_i16 {
     ha.tapfrag = tapfrag.p; ha.lut = lut.p; ha.inc = inc; ha.n0_lo = (uint32_t)(n0 - phase0); ha.negative = negative;
     ha.base0_rel = g.base0_rel; ha.OG = OG; ha.ovl = ovl; ha.t_lo = 0; ha.t_hi = tiles; ha.cre = cre; ha.cim = cim;
     ha.N = (int)N; ha.n_out = g.n_out; ha.C = C; ha.stamps = nullptr;
-    ha.D = 8; ha.GS = 64; ha.lpg_sh = 0; ha.inv_d = 0.125f;   // (the any-D form's fields)
+    ha.D = 8; ha.GS = 64; ha.lpg_sh = 0; ha.inv_d = 0.125f; ha.philast = nullptr; ha.philast_stride = 0;   // (the any-D form's fields)
 #ifdef K1_STAMPS
     if (!k1_stamps.p) { k1_stamps.alloc(32768 * 16); k1_stamps.zero(ctx->stream); }
     ha.stamps = k1_stamps.p;
@@ -1147,10 +1153,11 @@ struct sdrhip_iqbb_i16 {
   bool launch_anyd_call(IqbbArgs &a, const Geometry &g, const uint32_t *in_dev, size_t N, size_t in_stride, void *out_dev,
                         size_t out_stride, int tiles_m, size_t lds_m) {
     const int kind = in_cu8 ? HOT_CU8 : HOT_CS16, halo = hot_halo(S, kind), win = hot_win(S, kind);
-    const int GS = 512 / D, OGw = GS - ovl, OGh = 4 * OGw;
+    const int ovh = 0;   // (the any-D form never recomputes an overlap group: FM's first angles come through philast)
+    const int GS = 512 / D, OGw = GS - ovh, OGh = 4 * OGw;
     const int tiles_h = (int)ceil_div((size_t)g.n_groups, (size_t)OGh);
     auto tile_hot = [&](int t) {
-      for (int w = 0; w < 4; w++) if (!slice_is_hot(halo, win, g.base0_rel, OGh, ovl, (int)N, g.n_out, t, w, D, GS)) return false;
+      for (int w = 0; w < 4; w++) if (!slice_is_hot(halo, win, g.base0_rel, OGh, ovh, (int)N, g.n_out, t, w, D, GS)) return false;
       return true;
     };
     int t_lo = 0, t_hi = tiles_h;
@@ -1159,17 +1166,28 @@ struct sdrhip_iqbb_i16 {
     if (t_hi - t_lo < 4) return false;
     // border tiles of the general kernel: its tiles emit OG groups each
     const long ga = (long)t_lo * OGh, gb = (long)t_hi * OGh;
-    int bt_lo = (int)ceil_div((size_t)ga, (size_t)OG), bt_hi = (int)(gb / OG);
+    // (FM: the first hot slice's first group has no philast entry before it — the border tiles own it too)
+    int bt_lo = (int)ceil_div((size_t)(ga + (epi == SDRHIP_EPI_FM ? 1 : 0)), (size_t)OG), bt_hi = (int)(gb / OG);
     bt_hi = std::min(bt_hi, tiles_m - 1);   // (the last tile always: it rolls the history and hands the state on)
     if (bt_lo >= bt_hi) return false;
     HotArgs ha;
     ha.in = in_dev; ha.in_stride = (long)in_stride; ha.out = out_dev; ha.out_stride = (long)out_stride;
     ha.tapfrag = tapfrag.p; ha.lut = lut.p; ha.inc = inc; ha.n0_lo = (uint32_t)(n0 - phase0); ha.negative = negative;
-    ha.base0_rel = g.base0_rel; ha.OG = OGh; ha.ovl = ovl; ha.t_lo = t_lo; ha.t_hi = t_hi; ha.cre = cre; ha.cim = cim;
+    ha.base0_rel = g.base0_rel; ha.OG = OGh; ha.ovl = ovh; ha.t_lo = t_lo; ha.t_hi = t_hi; ha.cre = cre; ha.cim = cim;
     ha.N = (int)N; ha.n_out = g.n_out; ha.C = C; ha.stamps = nullptr;
     ha.D = D; ha.GS = GS;
     { int lpg = 1; while (2 * lpg <= 16 && 2 * lpg * GS <= 64) lpg *= 2; int sh = 0; while ((1 << sh) < lpg) sh++; ha.lpg_sh = sh; }
     ha.inv_d = (float)((1.0 / D) * (1.0 - 1.0 / 1048576.0));
+    ha.philast = nullptr; ha.philast_stride = 4 * tiles_h;
+    a.philast = nullptr; a.philast_stride = 0; a.fix_lo = a.fix_hi = 0; a.fix_gs = GS;
+    if (epi == SDRHIP_EPI_FM) {
+      const size_t need = (size_t)C * 4 * tiles_h;
+      if (philast.n < need) philast.alloc(need + 1024);
+      ha.philast = philast.p; a.philast = philast.p; a.philast_stride = 4 * tiles_h;
+      // slices whose first group lies in [bt_lo * OG, bt_hi * OG): neither border range writes it
+      a.fix_lo = std::max(4 * t_lo + 1, (int)ceil_div((size_t)bt_lo * OG, (size_t)GS));
+      a.fix_hi = std::min(4 * t_hi, (int)ceil_div((size_t)bt_hi * OG, (size_t)GS));
+    }
 #ifdef K1_STAMPS
     if (!k1_stamps.p) { k1_stamps.alloc(32768 * 16); k1_stamps.zero(ctx->stream); }
     ha.stamps = k1_stamps.p;
@@ -1219,7 +1237,7 @@ struct sdrhip_iqbb_i16 {
     int tpw = 1;
     if (path == 1 || path == 2 || path == 4) { tpw = 8; while (tpw > 1 && (size_t)ceil_div((size_t)tiles, (size_t)tpw) * C < 2048) tpw >>= 1; }
     { const char *t = getenv("SDRHIP_IQBB_TPW"); if (t && (path == 1 || path == 2 || path == 4)) tpw = std::max(1, atoi(t)); }   // tuning hook
-    a.tiles = tiles; a.tpw = tpw; a.bt_hi = 0; a.bt_lo = 0;
+    a.tiles = tiles; a.tpw = tpw; a.bt_hi = 0; a.bt_lo = 0; a.philast = nullptr; a.philast_stride = 0; a.fix_lo = a.fix_hi = 0; a.fix_gs = 1;
     a.lpg = 1; while (a.lpg < 64 && a.lpg * 8 < D) a.lpg <<= 1;
     dim3 grid((unsigned)ceil_div((size_t)tiles, (size_t)tpw), C), block(TPB);
     if (path == 4 && use_hot && hot_range >= 0 && tiles >= 3 && launch_hot_call(a, g, in_dev, N, in_stride, out_dev, out_stride, tiles)) {
