@@ -231,13 +231,32 @@ def build_workload(a, wl, sa, torch, shard, ctx, dev, rank, nbuf_out):
         w.key = "%s/order%d/d%d" % (wl, order, D)
         w.n_valid = node.out_count(N)   # (every call after the first emits N / D outputs)
 
-        def verify(prev, last, out, orc):
+        w.verify_needs_n0 = w.verify_needs_pre = True
+
+        def verify(prev, last, out, orc, n0=0, pre=None):
             # the state a call starts from (FIR history, open window, FM angle) depends on the previous buffer only;
             # LUT and decimator phases repeat every 32768 / D samples, so they are those of a stream's second call
-            if N % 32768 or N % D or order > N:
-                return None
             bb, fm = orc.IQBaseBandI16(taps_h, lut_h, inc, False, D), orc.FMDemodI16()
             cast = (lambda x: orc.autocast_cu8_cs16(x)) if cu8 else (lambda x: x)
+            if N % 32768 or N % D:
+                # any other decimation: the oracle is put at the last emission in front of the previous buffer (absolute
+                # index s0 = g*D + 1 <= n0 - N: decimator and LUT phase by seek(), the FIR ring primed with the `order`
+                # samples before s0 — both from the tail of the buffer before the previous one) and runs from there
+                n_prev = n0 - N
+                s0 = ((n_prev - 1) // D) * D + 1
+                if pre is None or D < 2 or s0 < D + 1 or n_prev - s0 + order > N or order > N:
+                    return None
+                tail = cast(pre[N - (n_prev - s0) - order:])
+                bb.process(tail[:order])
+                bb.seek(s0)
+                r0 = np.concatenate([bb.process(tail[order:]), bb.process(cast(prev))])
+                if epi == sa.EPI_FM:
+                    fm.process(r0)
+                r = bb.process(cast(last))
+                r = fm.process(r) if epi == sa.EPI_FM else orc.usb_i16(r)
+                return bool(np.array_equal(out[:len(r)], r)) and len(r) == (n0 + N - 1) // D - (n0 - 1) // D
+            if order > N:
+                return None
             r0 = bb.process(cast(prev))
             if epi == sa.EPI_FM:
                 fm.process(r0)
@@ -505,6 +524,8 @@ def main():
                     prev, last = w.ins[bp][c].cpu().numpy(), w.ins[bl][c].cpu().numpy()
                     out = (xo[:, c] if getattr(w, "out_rows_axis", 0) == 1 else xo[c]).cpu().numpy()
                     kw = {"n0": (calls - 1) * N} if getattr(w, "verify_needs_n0", False) else {}
+                    if getattr(w, "verify_needs_pre", False) and calls >= 3:   # (the buffer before the previous one)
+                        kw["pre"] = w.ins[(last_i - 2) % a.batches][c].cpu().numpy()
                     oks.append(w.verify(prev, last, out, orc, **kw))
                 if all(o is None for o in oks):
                     verified = {"ok": None, "why": "this sample count / decimation is outside what the last-step check covers"}

@@ -45,6 +45,7 @@ def lib():
             "orc_iqbb_i16_create": (vp, [i32p, C.c_int, i32p, C.c_uint32, C.c_int, C.c_int]),
             "orc_iqbb_i16_process": (C.c_size_t, [vp, i16p, C.c_size_t, i16p]),
             "orc_iqbb_i16_reset": (None, [vp]),
+            "orc_iqbb_i16_seek": (C.c_int, [vp, C.c_uint64]),
             "orc_freqshift_lut_i8": (None, [C.POINTER(C.c_int32)]),
             "orc_iqbb_i8_create": (vp, [C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32), C.c_uint32, C.c_int, C.c_int]),
             "orc_iqbb_i8_process": (C.c_size_t, [vp, C.POINTER(C.c_int8), C.c_size_t, C.POINTER(C.c_int8)]),
@@ -177,6 +178,12 @@ class IQBaseBandI16:
 
     def reset(self):
         lib().orc_iqbb_i16_reset(self._h)
+
+    def seek(self, abs_index):
+        """Test-bench helper: decimator and LUT phase as they stand in front of absolute sample `abs_index` = g*D + 1 (right
+        behind an emission); the ring is kept — prime it with the `order` samples before that index first."""
+        if lib().orc_iqbb_i16_seek(self._h, int(abs_index)) != 0:
+            raise ValueError("seek: %d is not right behind an emission (g*D + 1, g >= 1)" % abs_index)
 
     def set_taps(self, taps):
         taps = np.ascontiguousarray(taps, np.int32).reshape(self.order, 2)

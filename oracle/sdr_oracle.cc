@@ -346,6 +346,20 @@ void orc_iqbb_i16_reset(void *h) {   // _reconfigure (:175-177) + setSampleRate 
   IQBB *s = (IQBB *)h; s->off = 0; s->count = 0; s->lut_count = 0; s->last = C32{0, 0};
 }
 
+// Test-bench helper (no counterpart in the reference): put the decimator and the LUT phase where they stand when the NEXT
+// sample is absolute index `abs_index` of a stream, for an index right behind an emission (abs_index = g*D + 1, g >= 1:
+// after the D+1 first window every window is D samples, emitted at indices D, 2D, ... — _process :200-214). The ring is
+// left as it is: prime it with the `order` samples in front of abs_index first. Returns 0, or -1 for an index that is
+// not such a boundary.
+int orc_iqbb_i16_seek(void *h, uint64_t abs_index) {
+  IQBB *s = (IQBB *)h;
+  const uint64_t D = (uint64_t)s->decim;
+  if (D < 2 || abs_index < D + 1 || (abs_index - 1) % D != 0) return -1;
+  s->count = 1; s->last = C32{0, 0};
+  s->lut_count = (size_t)((abs_index % 32768u) * (uint64_t)(s->inc % 32768u) % 32768u);   // lut_count = abs_index * inc mod 128 * 256
+  return 0;
+}
+
 size_t orc_iqbb_i16_process(void *h, const int16_t *in, size_t n, int16_t *out) {
   IQBB *s = (IQBB *)h;
   const size_t order = (size_t)s->order, D = (size_t)s->decim;
