@@ -594,14 +594,17 @@ __global__ __launch_bounds__(TPB, 3) void iqbb_i16_mfmag_kernel(const IqbbArgs a
       }
     }
   };
-  int tile_end = min((int)(blockIdx.x + 1) * a.tpw, a.tiles);
-  int tile = blockIdx.x * a.tpw;
-  if (a.bt_hi > 0) {   // border mode: one tile per workgroup, the call's first bt_lo tiles and the tiles from bt_hi on
-    tile = (int)blockIdx.x < a.bt_lo ? (int)blockIdx.x : (int)blockIdx.x - a.bt_lo + a.bt_hi;
-    tile_end = tile + 1;
-  }
-  if (tile < tile_end) fetch(tile);
-  for (; tile < tile_end; tile++) {
+  // the workgroup's tiles: positions [it, it_end) of the launch's tile list — every tile of the call, or (border mode,
+  // bt_hi > 0) the call's first bt_lo tiles followed by the tiles from bt_hi on, all of one channel in ONE workgroup:
+  // the next tile's samples are in flight while this one is computed, and the tap fragments are fetched once
+  const bool border = a.bt_hi > 0;
+  auto tile_at = [&](int i) { return (border && i >= a.bt_lo) ? i - a.bt_lo + a.bt_hi : i; };
+  const int n_list = border ? a.bt_lo + a.tiles - a.bt_hi : a.tiles;
+  const int it_end = min((int)(blockIdx.x + 1) * a.tpw, n_list);
+  int it = blockIdx.x * a.tpw;
+  if (it < it_end) fetch(tile_at(it));
+  for (; it < it_end; it++) {
+  const int tile = tile_at(it);
   const int q0 = tile * a.OG - a.ovl;    // first group (relative to the call's first group) of this tile
   const int tb = a.base0_rel + q0 * a.D; // call-relative index of the tile's first sample
   const int groups_here = min(a.CG, a.n_groups - q0);
@@ -628,7 +631,7 @@ __global__ __launch_bounds__(TPB, 3) void iqbb_i16_mfmag_kernel(const IqbbArgs a
     }
   }
   __syncthreads();
-  if (tile + 1 < tile_end) fetch(tile + 1);   // in flight during the matrix work and the window sums below
+  if (it + 1 < it_end) fetch(tile_at(it + 1));   // in flight during the matrix work and the window sums below
 
   // ---- the FIR at this wave's 512 samples (blocks 32w .. 32w+31 of the tile) ----
   {
@@ -1156,16 +1159,16 @@ struct sdrhip_iqbb_i16 {
     const int ovh = 0;   // (the any-D form never recomputes an overlap group: FM's first angles come through philast)
     const int GS = 512 / D, OGw = GS - ovh, OGh = 4 * OGw;
     const int tiles_h = (int)ceil_div((size_t)g.n_groups, (size_t)OGh);
-    auto tile_hot = [&](int t) {
-      for (int w = 0; w < 4; w++) if (!slice_is_hot(halo, win, g.base0_rel, OGh, ovh, (int)N, g.n_out, t, w, D, GS)) return false;
-      return true;
-    };
-    int t_lo = 0, t_hi = tiles_h;
-    while (t_lo < t_hi && !tile_hot(t_lo)) t_lo++;
-    while (t_hi > t_lo && !tile_hot(t_hi - 1)) t_hi--;
-    if (t_hi - t_lo < 4) return false;
+    // the hot slices of a channel are ONE range of slice numbers s = 4 * tile + w (slice_is_hot is monotone in s): every
+    // wave finds its own tile range inside [t_lo, t_hi) in the kernel; the border tiles start / end at slice granularity
+    auto slice_hot = [&](int sl) { return slice_is_hot(halo, win, g.base0_rel, OGh, ovh, (int)N, g.n_out, sl >> 2, sl & 3, D, GS); };
+    int s_lo = 0, s_hi = 4 * tiles_h;
+    while (s_lo < s_hi && !slice_hot(s_lo)) s_lo++;
+    while (s_hi > s_lo && !slice_hot(s_hi - 1)) s_hi--;
+    if (s_hi - s_lo < 16) return false;
+    const int t_lo = s_lo >> 2, t_hi = (s_hi + 3) >> 2;
     // border tiles of the general kernel: its tiles emit OG groups each
-    const long ga = (long)t_lo * OGh, gb = (long)t_hi * OGh;
+    const long ga = (long)s_lo * GS, gb = (long)s_hi * GS;
     // (FM: the first hot slice's first group has no philast entry before it — the border tiles own it too)
     int bt_lo = (int)ceil_div((size_t)(ga + (epi == SDRHIP_EPI_FM ? 1 : 0)), (size_t)OG), bt_hi = (int)(gb / OG);
     bt_hi = std::min(bt_hi, tiles_m - 1);   // (the last tile always: it rolls the history and hands the state on)
@@ -1185,8 +1188,8 @@ struct sdrhip_iqbb_i16 {
       if (philast.n < need) philast.alloc(need + 1024);
       ha.philast = philast.p; a.philast = philast.p; a.philast_stride = 4 * tiles_h;
       // slices whose first group lies in [bt_lo * OG, bt_hi * OG): neither border range writes it
-      a.fix_lo = std::max(4 * t_lo + 1, (int)ceil_div((size_t)bt_lo * OG, (size_t)GS));
-      a.fix_hi = std::min(4 * t_hi, (int)ceil_div((size_t)bt_hi * OG, (size_t)GS));
+      a.fix_lo = std::max(s_lo + 1, (int)ceil_div((size_t)bt_lo * OG, (size_t)GS));
+      a.fix_hi = std::min(s_hi, (int)ceil_div((size_t)bt_hi * OG, (size_t)GS));
     }
 #ifdef K1_STAMPS
     if (!k1_stamps.p) { k1_stamps.alloc(32768 * 16); k1_stamps.zero(ctx->stream); }
@@ -1202,8 +1205,8 @@ struct sdrhip_iqbb_i16 {
     HotLaunch hl{(unsigned)grid, ctx->stream};
     hot_launch_anyd(S, kind, hot_range, epi, hl, ha, a);
     // the border tiles (a.* is the general kernel's own geometry)
-    a.bt_lo = bt_lo; a.bt_hi = bt_hi; a.tpw = 1;
-    const dim3 gridb((unsigned)(bt_lo + tiles_m - bt_hi), C), block(TPB);
+    a.bt_lo = bt_lo; a.bt_hi = bt_hi; a.tpw = bt_lo + tiles_m - bt_hi;   // (one workgroup per channel walks the border tiles)
+    const dim3 gridb(1, C), block(TPB);
 #define SDRHIP_MFGB(S_) do { if (in_cu8) hipLaunchKernelGGL((iqbb_i16_mfmag_kernel<S_, true, true>), gridb, block, lds_m, ctx->stream, a); \
                              else hipLaunchKernelGGL((iqbb_i16_mfmag_kernel<S_, true, false>), gridb, block, lds_m, ctx->stream, a); } while (0)
     if (S == 2) SDRHIP_MFGB(2); else SDRHIP_MFGB(3);
