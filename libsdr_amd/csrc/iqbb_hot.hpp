@@ -76,7 +76,8 @@ void hot_launch_s9_cu8(int range, bool rot, int epi, const HotLaunch &, const Ho
 void hot_launch_s17_cs16(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
 void hot_launch_s17_cu8(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
 void hot_launch_real(int S, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);   // S = 5 or 9
-void hot_launch_anyd(int S, int in, int range, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);   // S = 2 or 3, cs16 / cu8, shifted plans
+void hot_launch_anyd(int S, int in, int range, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);   // S = 2, 3, 5 or 9, cs16 / cu8, shifted plans
+void hot_launch_anyd9(int in, int range, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
 
 }  // namespace sdrhip
 
@@ -338,7 +339,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   };
   // E: lane (n, h) owns group 2n + h of the wave: recombine the byte-plane accumulators, >>14, rotate by LUT[idx(n)],
   // window sum of the products' high halves. wave_cnt: LUT phase counter of the wave's first sample (scalar)
-  auto stageE = [&](const v16i &acc_hh, const v16i &acc_mid, const v16i &acc_ll, uint32_t wave_cnt) __attribute__((always_inline)) {
+  auto stageE = [&](const v16i &acc_hh, const v16i &acc_mid, const v16i &acc_ll, uint32_t wave_cnt, char *escr) __attribute__((always_inline)) {
     int L[8][3];
 #ifdef K1_ABL_NOEPI
     if (false) {
@@ -397,7 +398,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       // the wave's 512 rotated samples in stream order (lane (n, h) holds the pairs 16n + 2h + 4jj + {0, 1}), then teams of
       // `lpg` lanes (a power of two <= 16, about 64 / GS) sum one group each: strided partial sums, then a shift tree
       // inside the team (one wave's LDS operations execute in order; the asm keeps the compiler from reordering them)
-      unsigned *gsc = reinterpret_cast<unsigned *>(gscb);
+      unsigned *gsc = reinterpret_cast<unsigned *>(BUFB >= 2048 ? escr : gscb);   // (the slice's own window buffer is done with: 2 KB of it, or the wave's extra array)
 #pragma unroll
       for (int jj = 0; jj < 4; jj++)
         *reinterpret_cast<uint2 *>(gsc + 16 * n + 2 * h + 4 * jj) = make_uint2(pk[2 * jj], pk[2 * jj + 1]);
@@ -538,7 +539,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       asm volatile("s_nop 0" : "+v"(acc_hh), "+v"(acc_mid), "+v"(acc_ll));   // the accumulators are complete before the stamp
 #endif
       K1_STAMP(3);
-      int2 sum = stageE(acc_hh, acc_mid, acc_ll, cnt0 + (uint32_t)tile * tile_cnt);
+      int2 sum = stageE(acc_hh, acc_mid, acc_ll, cnt0 + (uint32_t)tile * tile_cnt, cb);
 #ifdef K1_STAMPS
       asm volatile("" : "+v"(sum.x), "+v"(sum.y));
 #endif
@@ -743,7 +744,7 @@ void hot_launch_one(bool rot, int epi, const HotLaunch &hl, const HotArgs &ha, c
 
 template <int S, int S0, int NH, int IN>
 void hot_launch_anyd_one(int epi, const HotLaunch &hl, const HotArgs &ha, const IqbbArgs &b) {
-  const size_t lds = (size_t)hot_lds_bytes(S, NH, IN, 4, hot_wide(S, NH, IN, 4)) + 4 * 2048;
+  const size_t lds = (size_t)hot_lds_bytes(S, NH, IN, 4, hot_wide(S, NH, IN, 4)) + (hot_bufb(S, IN) >= 2048 ? 0 : 4 * 2048);
   const dim3 grid(hl.grid, 1), block(256);
   switch (epi) {
     case SDRHIP_EPI_FM: hipLaunchKernelGGL((iqbb_hot_anyd_kernel<S, S0, NH, SDRHIP_EPI_FM, IN>), grid, block, lds, hl.stream, ha, b); break;

@@ -1151,7 +1151,7 @@ struct sdrhip_iqbb_i16 {
   // state for the next call). Both write the groups of the seam tiles they share — the same values.
   // false: not this plan / call (the general kernel runs it whole).
   bool anyd_plan() const {
-    return path == 3 && use_hot && hot_range >= 0 && inc != 0 && (S == 2 || S == 3) && !i8 && !real && D >= 9 && D <= 180 && 512 / D - ovl >= 1;
+    return path == 3 && use_hot && hot_range >= 0 && inc != 0 && S <= 9 && !i8 && !real && D >= 9 && D <= 180;
   }
   bool launch_anyd_call(IqbbArgs &a, const Geometry &g, const uint32_t *in_dev, size_t N, size_t in_stride, void *out_dev,
                         size_t out_stride, int tiles_m, size_t lds_m) {
@@ -1209,7 +1209,7 @@ struct sdrhip_iqbb_i16 {
     const dim3 gridb(1, C), block(TPB);
 #define SDRHIP_MFGB(S_) do { if (in_cu8) hipLaunchKernelGGL((iqbb_i16_mfmag_kernel<S_, true, true>), gridb, block, lds_m, ctx->stream, a); \
                              else hipLaunchKernelGGL((iqbb_i16_mfmag_kernel<S_, true, false>), gridb, block, lds_m, ctx->stream, a); } while (0)
-    if (S == 2) SDRHIP_MFGB(2); else SDRHIP_MFGB(3);
+    switch (S) { case 2: SDRHIP_MFGB(2); break; case 3: SDRHIP_MFGB(3); break; case 5: SDRHIP_MFGB(5); break; default: SDRHIP_MFGB(9); break; }
 #undef SDRHIP_MFGB
     return true;
   }
