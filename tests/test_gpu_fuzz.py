@@ -212,7 +212,7 @@ def test_subsample_and_demods_random(ctx, orc, seed):
                 assert np.array_equal(z[c], fms[c].process(x[c]))
 
 
-def _hot_fuzz(ctx, orc, rng, order, cu8):
+def _hot_fuzz(ctx, orc, rng, order, cu8, decim=8):
     Fc = float(rng.choice([100e3, -100e3, 0.0, 333e3]))
     epi = int(rng.choice([sa.EPI_NONE, sa.EPI_FM, sa.EPI_FM, sa.EPI_AM, sa.EPI_USB]))
     width = float(rng.choice([12.5e3, 50e3, 200e3, 600e3]))
@@ -221,11 +221,14 @@ def _hot_fuzz(ctx, orc, rng, order, cu8):
     lut, inc = sa.design_freqshift_lut_i16(), sa.design_freqshift_inc(Fc, FS)
     lens = [int(rng.integers(4000, 70000)) for _ in range(3)] + [int(rng.choice([1, 500, 2047, 4031, 4032, 4033, 65536]))] + [int(rng.integers(4000, 30000))]
     rng.shuffle(lens)
-    node = sa.IQBaseBandI16(ctx, taps, lut, inc, Fc < 0, 8, channels=C, max_in=max(lens), epilogue=epi)
+    node = sa.IQBaseBandI16(ctx, taps, lut, inc, Fc < 0, decim, channels=C, max_in=max(lens), epilogue=epi)
     if cu8:
         node.set_input_format(sa.abi.IN_CU8)
-    assert node.kernel_names == ["iqbb_hot_kernel"]
-    refs = [orc.IQBaseBandI16(taps, lut, inc, Fc < 0, 8) for _ in range(C)]
+    if decim == 8:
+        assert node.kernel_names == ["iqbb_hot_kernel"]
+    else:   # (an unshifted plan runs the general any-D kernel alone; retuning between buffers moves a plan from one to the other)
+        assert node.path == 3 and node.kernel_names in (["iqbb_hot_anyd_kernel", "iqbb_i16_mfmag_kernel"], ["iqbb_i16_mfmag_kernel"])
+    refs = [orc.IQBaseBandI16(taps, lut, inc, Fc < 0, decim) for _ in range(C)]
     fms = [orc.FMDemodI16() for _ in range(C)]
     for n in lens:
         ev = int(rng.integers(0, 4))   # between buffers: retune the shift, swap the filter, both, or nothing (src/baseband.hh:82-112)
@@ -277,6 +280,18 @@ def test_hot_kernel_every_length_class_random_long_calls(ctx, orc, seed, cu8):
     complex<uint8> with AutoCast fused, src/autocast.hh:187-194)."""
     rng = np.random.default_rng(17000 + 2 * seed + int(cu8))
     _hot_fuzz(ctx, orc, rng, int(rng.choice([3, 16, 17, 21, 33, 34, 64, 65, 66, 100, 127, 130, 200, 255, 257])), cu8)
+
+
+@pytest.mark.parametrize("cu8", [False, True])
+@pytest.mark.parametrize("seed", range(16 + EXTRA))
+def test_hot_kernel_any_decimation_random_long_calls(ctx, orc, seed, cu8):
+    """The hot kernel's any-decimation form (9 <= D <= 180, up to 129 taps, shifted plans; the border tiles by the general
+    any-D kernel): random plans incl. the reference receivers' (16 taps / 62, 21 taps / 125), ragged long and short calls,
+    retuning (also to and from no shift at all), filter swaps and _reconfigure between buffers."""
+    rng = np.random.default_rng(23000 + 2 * seed + int(cu8))
+    order = int(rng.choice([3, 16, 17, 21, 33, 34, 64, 65, 100, 127, 129]))
+    decim = int(rng.choice([9, 10, 12, 31, 50, 62, 100, 125, 180]))
+    _hot_fuzz(ctx, orc, rng, order, cu8, decim)
 
 
 @pytest.mark.parametrize("hot", [True, False])
