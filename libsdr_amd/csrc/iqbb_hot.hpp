@@ -399,9 +399,21 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       // `lpg` lanes (a power of two <= 16, about 64 / GS) sum one group each: strided partial sums, then a shift tree
       // inside the team (one wave's LDS operations execute in order; the asm keeps the compiler from reordering them)
       unsigned *gsc = reinterpret_cast<unsigned *>(BUFB >= 2048 ? escr : gscb);   // (the slice's own window buffer is done with: 2 KB of it, or the wave's extra array)
+      // lanes (n, 0) and (n, 1) trade halves (v_permlane32_swap: lanes 32..63 of the first operand <-> lanes 0..31 of the
+      // second) so that each holds 8 CONSECUTIVE samples — (n, h): 16n + 8h + {0..7} — and the wave writes its 2 KB as 64
+      // contiguous 32-byte pieces (written pair by pair at the lanes' own 64-byte stride the stores ran into 8-way bank
+      // conflicts: half of the kernel's LDS cycles)
+      unsigned q8[8];
 #pragma unroll
-      for (int jj = 0; jj < 4; jj++)
-        *reinterpret_cast<uint2 *>(gsc + 16 * n + 2 * h + 4 * jj) = make_uint2(pk[2 * jj], pk[2 * jj + 1]);
+      for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+        for (int tt = 0; tt < 2; tt++) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(pk[2 * jj + tt], pk[2 * (jj + 2) + tt], false, false);
+          // h = 0: own pair jj (positions 4jj + tt) and (n, 1)'s pair jj (2 + 4jj + tt); h = 1: (n, 0)'s pair jj + 2 and the own one
+          q8[4 * jj + tt] = sw[0]; q8[4 * jj + 2 + tt] = sw[1];
+        }
+      *reinterpret_cast<uint4 *>(gsc + 8 * (2 * n + h)) = make_uint4(q8[0], q8[1], q8[2], q8[3]);
+      *reinterpret_cast<uint4 *>(gsc + 8 * (2 * n + h) + 4) = make_uint4(q8[4], q8[5], q8[6], q8[7]);
       asm volatile("" ::: "memory");
       const int lsh = a.lpg_sh, k = l >> lsh, t = l & ((1 << lsh) - 1);
       int sx = 0, sy = 0;
