@@ -417,10 +417,20 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       asm volatile("" ::: "memory");
       const int lsh = a.lpg_sh, k = l >> lsh, t = l & ((1 << lsh) - 1);
       int sx = 0, sy = 0;
-      if (k < GS) {
-        const unsigned *gp = gsc + k * DD;
-        for (int e = t; e < DD; e += 1 << lsh) {
-          const unsigned v = gp[e];
+      {
+        // D / lpg rounds in which every lane of a team has an element (a scalar loop: no per-lane bounds), then one round
+        // for the D % lpg lanes that have one more; the lanes beyond the GS-th team read the wave's last dword and drop it
+        const int kk = min(k, GS - 1);
+        const unsigned *gp = gsc + kk * DD + t;
+        const int nfull = DD >> lsh;
+        for (int i = 0; i < nfull; i++) {
+          const unsigned v = gp[i << lsh];
+          asm("v_add_u32_sdwa %0, sext(%1), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "+v"(sx) : "v"(v));
+          asm("v_add_u32_sdwa %0, sext(%1), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(sy) : "v"(v));
+        }
+        if ((nfull << lsh) < DD) {   // (scalar)
+          unsigned v = gp[min(nfull << lsh, DD - 1 - t)];
+          if (t + (nfull << lsh) >= DD) v = 0u;
           asm("v_add_u32_sdwa %0, sext(%1), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "+v"(sx) : "v"(v));
           asm("v_add_u32_sdwa %0, sext(%1), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(sy) : "v"(v));
         }
