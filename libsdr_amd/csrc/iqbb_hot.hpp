@@ -46,7 +46,9 @@ constexpr int hot_lds_bytes(int S, int NH, int in, int NW, bool wide) {
 }
 constexpr int hot_lds_cap(int NW) { return NW == 4 ? 40960 : NW == 8 ? 81920 : 163840; }   // 4 waves per SIMD: 160 KB / workgroups per CU
 // 4 KB rotation table ({Lx, Ly, -Ly, 0} x 256: one SDWA shift makes the address, no subtraction) while it fits
-constexpr bool hot_wide(int S, int NH, int in, int NW) { return hot_lds_bytes(S, NH, in, NW, true) <= hot_lds_cap(NW); }
+constexpr bool hot_wide(int S, int NH, int in, int NW, int extra = 0) { return hot_lds_bytes(S, NH, in, NW, true) + extra <= hot_lds_cap(NW); }
+// the any-D form's additions to a workgroup's LDS: parked group sums, and the rotated samples where the window buffer is too small
+constexpr int hot_anyd_extra(int S, int in) { return 4 * 512 + (hot_bufb(S, in) >= 2048 ? 0 : 4 * 2048); }
 
 struct HotRange { int S0, NH, NW; };
 // per S: centred high-plane ranges, narrowest first; the last one covers every step
@@ -117,7 +119,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   constexpr int NDMA = (NPIECE + 63) / 64;                     // DMA wave-instructions per window
   constexpr int LASTL = NPIECE - 64 * (NDMA - 1);              // lanes of the last one
   static_assert(NDMA <= 3, "immediate offsets 0 / 1024 / 2048");
-  constexpr bool WIDE = hot_wide(S, NH, IN, NW);
+  constexpr bool WIDE = hot_wide(S, NH, IN, NW, DG ? hot_anyd_extra(S, IN) : 0);
   constexpr int NBUF = 2;   // window buffers per wave
   static_assert(hot_lds_bytes(S, NH, IN, NW, WIDE) <= hot_lds_cap(NW), "LDS budget for 4 waves per SIMD");
   constexpr int TBLW = WIDE ? 1024 : 256;   // dwords
@@ -135,7 +137,8 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   const int bx = (int)blockIdx.x * (NW / 4) + (w >> 2), gx = (int)gridDim.x * (NW / 4);   // virtual workgroup, virtual grid
   // tap fragments in LDS: the S low-plane fragments, then only the NH high-plane fragments of steps [S0, S0 + NH)
   char *wbase = reinterpret_cast<char *>(smem + TBLW + (S + NH) * 64 * 4) + w * (NBUF * BUFB);
-  char *gscb = reinterpret_cast<char *>(smem + TBLW + (S + NH) * 64 * 4) + NW * (NBUF * BUFB) + w * 2048;   // (DG) the wave's rotated samples
+  char *pendb = reinterpret_cast<char *>(smem + TBLW + (S + NH) * 64 * 4) + NW * (NBUF * BUFB) + w * 512;    // (DG) the wave's parked group sums (64 x int2)
+  char *gscb = reinterpret_cast<char *>(smem + TBLW + (S + NH) * 64 * 4) + NW * (NBUF * BUFB) + NW * 512 + w * 2048;   // (DG) the wave's rotated samples (when its window buffer is too small)
 #ifdef K1_ABL_ASAME   // (tuning ablation, results wrong: every step reads the SAME fragment values — K1_ABL_AREG's operand data with the reads kept)
   for (int i = tid; i < S * 64; i += TPBH) taps_s[i] = a.tapfrag[64 + (i & 63)];
   for (int i = tid; i < NH * 64; i += TPBH) taps_s[S * 64 + i] = a.tapfrag[(2 * S0) * 64 + (i & 63)];
@@ -455,26 +458,44 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
     q += (r >= (unsigned)DD) ? 1u : 0u;
     return (int)(short)(v < 0 ? -(int)q : (int)q);        // (the int16 wrap of the assignment)
   };
-  auto stageF_gen = [&](int2 sum, char *orow, int k_lo, short *plast) __attribute__((always_inline)) {
+  // A slice yields only GS group sums (4 at decimation 125) in its team leaders, and finishing them — two divisions, the
+  // demodulator (28 slots for FM alone) — would cost every slice a fifth of its vector instructions for a handful of
+  // lanes. The leaders PARK their sums in a 64-entry per-wave LDS array instead, slice after slice of the unit (a unit's
+  // tiles are consecutive), and one pass finishes up to 64 groups, one per lane, when the unit ends or the array is full.
+  int2 *pend = reinterpret_cast<int2 *>(pendb);
+  int npend = 0, ptile0 = 0;          // (scalar) groups parked, tile of the first parked slice
+  // the lane's place in a flush: parked entry l is group k_f of the j_f-th parked slice
+  const int j_f = l / GS, k_f = l - j_f * GS;
+  auto park = [&](int2 sum) __attribute__((always_inline)) {
     const int lsh = a.lpg_sh, k = l >> lsh;
-    const bool lead = (l & ((1 << lsh) - 1)) == 0 && k < GS;
+    if ((l & ((1 << lsh) - 1)) == 0 && k < GS) pend[npend + k] = sum;
+    npend += GS;
+    asm volatile("" ::: "memory");
+  };
+  auto flush = [&](int c_) __attribute__((always_inline)) {
+    const int2 sum = pend[min(l, 63)];
+    asm volatile("" ::: "memory");
+    const bool live = l < npend;
     const int yr = div_d(sum.x), yi = div_d(sum.y);
+    // group k_f of tile ptile0 + j_f: output index (ptile0 + j_f) * OG + gw + k_f of the channel's row (outb points at gw)
+    char *orow = outb + ((long)(ptile0 + j_f) * a.OG + k_f) * OB;
     if (EPI == SDRHIP_EPI_NONE) {
-      if (lead && k >= k_lo) reinterpret_cast<uint32_t *>(orow)[k] = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
+      if (live) *reinterpret_cast<uint32_t *>(orow) = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
     } else if (EPI == SDRHIP_EPI_AM) {
       const short o = am_i16(yr, yi);
-      if (lead && k >= k_lo) reinterpret_cast<short *>(orow)[k] = o;
+      if (live) *reinterpret_cast<short *>(orow) = o;
     } else if (EPI == SDRHIP_EPI_USB) {
       const short o = usb_i16(yr, yi);
-      if (lead && k >= k_lo) reinterpret_cast<short *>(orow)[k] = o;
+      if (live) *reinterpret_cast<short *>(orow) = o;
     } else {
-      // every group of the slice is emitted; the first one as -phi: the border launch adds the previous slice's last
-      // angle, which this slice's last team leaves in philast (IqbbArgs::fix_*)
+      // every group of a slice is emitted; its first one as -phi: the border launch adds the previous slice's last angle,
+      // which this slice's last group leaves in philast (IqbbArgs::fix_*)
       const int phi = fm_phi(yr, yi);
-      const int prev = __builtin_amdgcn_ds_bpermute(4 * (((k - 1) << lsh) & 63), phi);   // the leader of team k - 1
-      if (lead) reinterpret_cast<short *>(orow)[k] = (short)((k > 0 ? prev : 0) - phi);
-      if (lead && k == GS - 1) *plast = (short)phi;
+      const int prev = __builtin_amdgcn_update_dpp(0, phi, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);   // entry l - 1: the group before, within a slice
+      if (live) *reinterpret_cast<short *>(orow) = (short)((k_f > 0 ? prev : 0) - phi);
+      if (live && k_f == GS - 1) a.philast[(long)c_ * a.philast_stride + 4 * (ptile0 + j_f) + wv] = (short)phi;
     }
+    npend = 0;
   };
   // F: truncating division by 8, demodulator, store. orow: (scalar) the wave's first group of this slice; lanes below
   // glw_lo store nothing (FM: group 0 only supplies the previous angle)
@@ -566,8 +587,13 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       asm volatile("" : "+v"(sum.x), "+v"(sum.y));
 #endif
       K1_STAMP(4);
-      if (DG) stageF_gen(sum, outb + (long)tile * tile_out_bytes, 0, a.philast + (long)c * a.philast_stride + 4 * tile + wv);
-      else stageF(sum, outb + (long)tile * tile_out_bytes, GLW0);
+      if (DG) {
+        if (npend == 0) ptile0 = tile;
+        park(sum);
+        if (tile + 1 >= tend || npend + GS > 64) flush(c);   // the unit ends here (its tiles were consecutive), or the array is full
+      } else {
+        stageF(sum, outb + (long)tile * tile_out_bytes, GLW0);
+      }
       K1_STAMP(5);
 #ifdef K1_STAMPS
       st_tiles++;
@@ -766,7 +792,7 @@ void hot_launch_one(bool rot, int epi, const HotLaunch &hl, const HotArgs &ha, c
 
 template <int S, int S0, int NH, int IN>
 void hot_launch_anyd_one(int epi, const HotLaunch &hl, const HotArgs &ha, const IqbbArgs &b) {
-  const size_t lds = (size_t)hot_lds_bytes(S, NH, IN, 4, hot_wide(S, NH, IN, 4)) + (hot_bufb(S, IN) >= 2048 ? 0 : 4 * 2048);
+  const size_t lds = (size_t)hot_lds_bytes(S, NH, IN, 4, hot_wide(S, NH, IN, 4, hot_anyd_extra(S, IN))) + hot_anyd_extra(S, IN);
   const dim3 grid(hl.grid, 1), block(256);
   switch (epi) {
     case SDRHIP_EPI_FM: hipLaunchKernelGGL((iqbb_hot_anyd_kernel<S, S0, NH, SDRHIP_EPI_FM, IN>), grid, block, lds, hl.stream, ha, b); break;
