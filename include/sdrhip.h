@@ -146,9 +146,9 @@ int sdrhip_iqbb_i16_path(sdrhip_iqbb_i16 *h, int *path);
  * whose workgroups finish with the call's first and last slices, the state and the history roll (calls of fewer than
  * 3 tiles, about 6000 samples, run the general kernel "iqbb_i16_mfma_dma_kernel" / "iqbb_i16_mfma_kernel" instead).
  * Path 3 plans with a shift, up to 129 taps and 9 <= decim <= 180 (the reference's receivers: 16 taps / 62, 21 taps / 125,
- * examples/sdr_rec.cc:68, examples/sdr_fm.cc:40) run TWO launches per long call, "iqbb_hot_anyd_kernel" (the same
- * persistent structure over the interior tiles) then "iqbb_i16_mfmag_kernel" on the call's first and last tiles; other
- * path 3 plans and short calls the latter alone.
+ * examples/sdr_rec.cc:68, examples/sdr_fm.cc:40) run "iqbb_hot_anyd_kernel" on long calls — the same persistent
+ * structure, cold slices included (with FM a second, tiny launch completes the slices' first outputs); other path 3
+ * plans and short calls the general kernel "iqbb_i16_mfmag_kernel".
  * Tuning / test variables read at create time: SDRHIP_IQBB_HOT=0 (general kernels only), SDRHIP_IQBB_DMA=0 (round 1's
  * register-staged general kernel); read per call: SDRHIP_IQBB_TPW (tiles per work unit), SDRHIP_IQBB_WGPCU (workgroups
  * per CU of the persistent grid). None changes results. */

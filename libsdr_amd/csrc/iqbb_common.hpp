@@ -46,11 +46,6 @@ struct IqbbArgs {
   int lpg;          // path 3: lanes that share one box window
   int tiles, tpw;   // tiles per channel in this call; consecutive tiles walked by one workgroup (MFMA paths)
   int bt_hi;        // hot kernel's cold phase: beside tile 0, the tiles bt_hi .. tiles-1 hold cold slices
-  int bt_lo;        // any-D kernel in border mode (bt_hi > 0): only the tiles [0, bt_lo) and [bt_hi, tiles) — the hot kernel's any-D form ran the rest
-  // ... with FM: the hot kernel's slices emit ALL their groups (no recomputed overlap group: at decimation 125 that would
-  // be a quarter of a slice); the first group of slice s is stored as -phi and this launch's workgroup 0 of the channel
-  // adds the previous slice's last angle, philast[s - 1], for the slices fix_lo <= s < fix_hi (first group fix_gs * s)
-  const short *philast; int philast_stride, fix_lo, fix_hi, fix_gs;
 };
 
 // Arguments of the hot kernels (iqbb_hot.hpp): the persistent grid's work split; everything the cold phase needs
@@ -68,6 +63,7 @@ struct HotArgs {
   int cre, cim;
   int D, GS, lpg_sh; float inv_d;       // any-D form: decimation, whole groups per slice (512 / D), log2 of the lanes per group team, (1 / D)(1 - 2^-20)
   short *philast; int philast_stride;   // any-D form with FM: slice (tile, w) leaves the angle of its last group in philast[c * stride + 4 * tile + w]
+  int tiles_h;                          // any-D form: tiles of the call (4 slices of GS groups each)
   unsigned long long *stamps;           // diagnostic builds (-DK1_STAMPS) only
 };
 

@@ -100,10 +100,10 @@ __host__ __device__ __forceinline__ bool slice_is_hot(int halo, int win, int bas
 
 // DG: ANY decimation 9 <= D <= 180 (the reference's own receivers decimate by 62 and 125, examples/sdr_rec.cc:68,
 // examples/sdr_fm.cc:40). The matrix part, the windows and the grid are the same; a slice's 512 samples hold GS = 512 / D
-// whole groups (the slices of a wave advance by (GS - ovl) * D samples, so every slice starts on a group), the rotated
-// samples go through a 2 KB per-wave LDS array and lane teams sum the groups from there. The tap fragments are path 3's
-// (rows in natural order: the border tiles of the call run the general any-D kernel on the same plan), and there is no
-// cold phase: the host launches that kernel for the tiles this one leaves out.
+// whole groups (the slices of a wave advance by GS * D samples, so every slice starts on a group), the rotated samples go
+// through a 2 KB per-wave LDS array and lane teams sum the groups from there. The tap fragments are path 3's (rows in
+// natural order: short calls run the general any-D kernel on the same plan). The cold phase is the same code with the
+// samples outside the call masked and the team leaders applying the border rules themselves (cold_finish_gen).
 template <int S, int S0, int NH, bool ROT, int EPI, int IN, int NW, bool DG = false>
 __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &b) {
   constexpr bool CU8 = IN == HOT_CU8, REAL = IN == HOT_REAL;
@@ -342,7 +342,9 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   };
   // E: lane (n, h) owns group 2n + h of the wave: recombine the byte-plane accumulators, >>14, rotate by LUT[idx(n)],
   // window sum of the products' high halves. wave_cnt: LUT phase counter of the wave's first sample (scalar)
-  auto stageE = [&](const v16i &acc_hh, const v16i &acc_mid, const v16i &acc_ll, uint32_t wave_cnt, char *escr) __attribute__((always_inline)) {
+  // (edge_: the cold slices of the any-D form — samples outside the call contribute nothing; erel0: call-relative index of the lane's first sample)
+  auto stageE = [&](auto edge_, const v16i &acc_hh, const v16i &acc_mid, const v16i &acc_ll, uint32_t wave_cnt, char *escr, int erel0) __attribute__((always_inline)) {
+    constexpr bool EDGE = decltype(edge_)::value;
     int L[8][3];
 #ifdef K1_ABL_NOEPI
     if (false) {
@@ -386,6 +388,10 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       } else {
         asm("" : "+v"(tre)); asm("" : "+v"(tim));   // no re-association into 2 shifts + add3
         rr = (int)((tre << 8) + (unsigned)acc_ll[2 * j]) >> FSH; ri = (int)((tim << 8) + (unsigned)acc_ll[2 * j + 1]) >> FSH;
+      }
+      if (EDGE) {   // (natural row order: register pair j is sample 4 (j >> 1) + (j & 1) of the lane's run)
+        const int rel = erel0 + 4 * (j >> 1) + (j & 1);
+        if (rel < 0 || rel >= a.N) { rr = 0; ri = 0; }
       }
       if (ROT) {
         const int x = WIDE ? mad24a(L[j][0], rr, mul24a(L[j][2], ri)) : sub32(mul24a(L[j][0], rr), mul24a(L[j][1], ri));
@@ -488,8 +494,8 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       const short o = usb_i16(yr, yi);
       if (live) *reinterpret_cast<short *>(orow) = o;
     } else {
-      // every group of a slice is emitted; its first one as -phi: the border launch adds the previous slice's last angle,
-      // which this slice's last group leaves in philast (IqbbArgs::fix_*)
+      // every group of a slice is emitted; its first one as -phi: a tiny launch behind this one (iqbb_fm_fixup_kernel) adds
+      // the previous slice's last angle, which that slice's last group leaves in philast
       const int phi = fm_phi(yr, yi);
       const int prev = __builtin_amdgcn_update_dpp(0, phi, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);   // entry l - 1: the group before, within a slice
       if (live) *reinterpret_cast<short *>(orow) = (short)((k_f > 0 ? prev : 0) - phi);
@@ -582,7 +588,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       asm volatile("s_nop 0" : "+v"(acc_hh), "+v"(acc_mid), "+v"(acc_ll));   // the accumulators are complete before the stamp
 #endif
       K1_STAMP(3);
-      int2 sum = stageE(acc_hh, acc_mid, acc_ll, cnt0 + (uint32_t)tile * tile_cnt, cb);
+      int2 sum = stageE(std::false_type{}, acc_hh, acc_mid, acc_ll, cnt0 + (uint32_t)tile * tile_cnt, cb, 0);
 #ifdef K1_STAMPS
       asm volatile("" : "+v"(sum.x), "+v"(sum.y));
 #endif
@@ -607,6 +613,52 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
     }
   }
 
+  // (DG) a cold slice's groups, finished by the team leaders themselves: the carry into the call's first group and the
+  // stream's D+1 first window, the open last group and the demodulator's angle for the next call, FMDemod's first two
+  // outputs of a buffer (group_finish is the decimation-8 form of the same rules). sid: the slice's number 4 * tile + wv.
+  auto cold_finish_gen = [&](int2 sum, int cc, int sid) __attribute__((always_inline)) {
+    const int lsh = a.lpg_sh, k = l >> lsh, q = sid * GS + k;   // q: the group's output index within the call
+    const bool lead = (l & ((1 << lsh) - 1)) == 0 && k < GS && q < b.n_groups;
+    if (lead && q == 0) {
+      const int2 carry = b.acc_old[cc];
+      sum.x = (int)((unsigned)sum.x + (unsigned)carry.x);
+      sum.y = (int)((unsigned)sum.y + (unsigned)carry.y);
+      if (b.extra0) {   // absolute sample 0: one slow FIR evaluation per channel and stream start
+        int er = 0, ei = 0;
+        for (int i = 0; i < b.OP; i++) {
+          const uint32_t x = load_x(b, cc, -(b.OP - 1) + i);
+          const uint2 kk = b.taps[i];
+          er = dot2(x, kk.x, er); ei = dot2(x, kk.y, ei);
+        }
+        const int2 v = rotate(b, b.lut, make_int2(er >> 14, ei >> 14), b.n0_lo);
+        sum.x = (int)((unsigned)sum.x + (unsigned)v.x);
+        sum.y = (int)((unsigned)sum.y + (unsigned)v.y);
+      }
+    }
+    const bool emits = lead && q < b.n_out;
+    if (lead && q == b.n_groups - 1) b.acc_new[cc] = emits ? make_int2(0, 0) : sum;
+    const int yr = div_d(sum.x), yi = div_d(sum.y);
+    if (EPI == SDRHIP_EPI_NONE) {
+      if (emits) reinterpret_cast<uint32_t *>(a.out)[(long)cc * a.out_stride + q] = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
+    } else if (EPI == SDRHIP_EPI_AM) {
+      const short o = am_i16(yr, yi);
+      if (emits) reinterpret_cast<short *>(a.out)[(long)cc * a.out_stride + q] = o;
+    } else if (EPI == SDRHIP_EPI_USB) {
+      const short o = usb_i16(yr, yi);
+      if (emits) reinterpret_cast<short *>(a.out)[(long)cc * a.out_stride + q] = o;
+    } else {
+      const int phi = fm_phi(yr, yi);
+      const int prev = __builtin_amdgcn_ds_bpermute(4 * (((k - 1) << lsh) & 63), phi);   // the leader of team k - 1
+      short o;
+      if (q == 0) o = (short)yr;                                   // index 0 is never written by FMDemod (in place)
+      else if (q == 1) o = (short)((int)b.fm_old[cc] - phi);       // y[0] is never looked at: the previous call's last angle
+      else o = (short)((k > 0 ? prev : 0) - phi);                  // (a slice's first group: the fix-up launch adds philast)
+      if (emits) reinterpret_cast<short *>(a.out)[(long)cc * a.out_stride + q] = o;
+      if (emits && k == GS - 1) a.philast[(long)cc * a.philast_stride + sid] = (short)phi;
+      if (emits && q == b.n_out - 1 && b.n_out >= 2) b.fm_new[cc] = (short)phi;
+    }
+  };
+
   // ---- the call's COLD slices --------------------------------------------------------------------------------
   // The slices slice_is_hot() rejects — history in the window, the call's first group, incomplete or unemitted
   // groups, the end of the input — are a few per channel (2 of 130 on the headline workload).
@@ -615,14 +667,16 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
 #ifdef K1_ABL_NOCOLD   // tuning ablation (results wrong): no cold phase
     for (int cc = a.C; cc < a.C; cc += gx) {
 #else
-    for (int cc = DG ? a.C : bx; cc < a.C; cc += gx) {   // (DG: the border tiles run the general any-D kernel, a launch of its own)
+    for (int cc = bx; cc < a.C; cc += gx) {
 #endif
-      for (int t = 0; t < b.tiles; t = (t == 0 ? max(b.bt_hi, 1) : t + 1)) {
-        const int q0 = t * a.OG - a.ovl, groups_here = min(b.CG, b.n_groups - q0);
-        if (slice_is_hot(HALO, WIN, a.base0_rel, a.OG, a.ovl, a.N, a.n_out, t, wv) || gw + a.ovl >= groups_here) continue;
+      // (DG: every tile of the call in turn; the wave's own hot tiles [hl, hh) and the slices behind the call's last group are skipped)
+      for (int t = 0; t < (DG ? a.tiles_h : b.tiles); t = DG ? t + 1 : (t == 0 ? max(b.bt_hi, 1) : t + 1)) {
+        const int q0 = t * a.OG - a.ovl, groups_here = DG ? 0 : min(b.CG, b.n_groups - q0);
+        if (DG) { if ((t >= hl && t < hh) || (q0 + gw) >= b.n_groups) continue; }
+        else if (slice_is_hot(HALO, WIN, a.base0_rel, a.OG, a.ovl, a.N, a.n_out, t, wv) || gw + a.ovl >= groups_here) continue;
         // the wave's window by ordinary loads: history / input / zeros per sample, every load issued from a clamped
         // address and masked afterwards (all in flight together)
-        const int first = a.base0_rel + (q0 + gw) * 8 - HALO;
+        const int first = a.base0_rel + (q0 + gw) * DD - HALO;
         const uint32_t *hrow = b.hist_old + (long)cc * b.HH;
         if (REAL) {   // 8 real samples per piece: input int16, or the low half of a history dword
           const uint16_t *row = reinterpret_cast<const uint16_t *>(a.in) + (long)cc * a.in_stride;
@@ -740,9 +794,15 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
             acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(taps_s[(S + s_ - S0) * 64 + l], uh, acc_hh, 0, 0, 0);
           }
         }
-        const int tb = a.base0_rel + q0 * 8, rel0 = tb + 8 * gw + MF_BLK * n + 8 * h;
-        const int2 sum = group_sum<ROT, CU8, true, WIDE ? 2 : 1, FSH>(b, acc_hh, acc_mid, acc_ll, rel0);
-        group_finish(b, b.lut, cc, n, h, gw, q0, groups_here, sum);   // (its one table user, the stream's first sample, reads global memory)
+        if (DG) {
+          const int s0 = a.base0_rel + (q0 + gw) * DD;   // the slice's first sample, call-relative
+          const int2 sum = stageE(std::true_type{}, acc_hh, acc_mid, acc_ll, (a.n0_lo + (uint32_t)s0) * a.inc, cb, s0 + MF_BLK * n + 2 * h);
+          cold_finish_gen(sum, cc, 4 * t + wv);
+        } else {
+          const int tb = a.base0_rel + q0 * 8, rel0 = tb + 8 * gw + MF_BLK * n + 8 * h;
+          const int2 sum = group_sum<ROT, CU8, true, WIDE ? 2 : 1, FSH>(b, acc_hh, acc_mid, acc_ll, rel0);
+          group_finish(b, b.lut, cc, n, h, gw, q0, groups_here, sum);   // (its one table user, the stream's first sample, reads global memory)
+        }
         asm volatile("" ::: "memory");
       }
       for (int k = tid & 255; k < b.HH; k += 256) {   // the FIR history for the next call (this virtual workgroup's channel)

@@ -594,17 +594,10 @@ __global__ __launch_bounds__(TPB, 3) void iqbb_i16_mfmag_kernel(const IqbbArgs a
       }
     }
   };
-  // the workgroup's tiles: positions [it, it_end) of the launch's tile list — every tile of the call, or (border mode,
-  // bt_hi > 0) the call's first bt_lo tiles followed by the tiles from bt_hi on, all of one channel in ONE workgroup:
-  // the next tile's samples are in flight while this one is computed, and the tap fragments are fetched once
-  const bool border = a.bt_hi > 0;
-  auto tile_at = [&](int i) { return (border && i >= a.bt_lo) ? i - a.bt_lo + a.bt_hi : i; };
-  const int n_list = border ? a.bt_lo + a.tiles - a.bt_hi : a.tiles;
-  const int it_end = min((int)(blockIdx.x + 1) * a.tpw, n_list);
-  int it = blockIdx.x * a.tpw;
-  if (it < it_end) fetch(tile_at(it));
-  for (; it < it_end; it++) {
-  const int tile = tile_at(it);
+  const int tile_end = min((int)(blockIdx.x + 1) * a.tpw, a.tiles);
+  int tile = blockIdx.x * a.tpw;
+  if (tile < tile_end) fetch(tile);
+  for (; tile < tile_end; tile++) {
   const int q0 = tile * a.OG - a.ovl;    // first group (relative to the call's first group) of this tile
   const int tb = a.base0_rel + q0 * a.D; // call-relative index of the tile's first sample
   const int groups_here = min(a.CG, a.n_groups - q0);
@@ -631,7 +624,7 @@ __global__ __launch_bounds__(TPB, 3) void iqbb_i16_mfmag_kernel(const IqbbArgs a
     }
   }
   __syncthreads();
-  if (it + 1 < it_end) fetch(tile_at(it + 1));   // in flight during the matrix work and the window sums below
+  if (tile + 1 < tile_end) fetch(tile + 1);   // in flight during the matrix work and the window sums below
 
   // ---- the FIR at this wave's 512 samples (blocks 32w .. 32w+31 of the tile) ----
   {
@@ -719,11 +712,16 @@ __global__ __launch_bounds__(TPB, 3) void iqbb_i16_mfmag_kernel(const IqbbArgs a
   __syncthreads();
   epilogue_and_roll(a, c, tile, tid, q0, groups_here, ybuf);
   }   // (the next tile's planes / vbuf / ybuf writes are each separated from this tile's reads by one of its barriers)
-  if (a.bt_hi > 0 && a.fix_hi > a.fix_lo && blockIdx.x == 0) {   // border mode with FM: the hot slices' first groups (IqbbArgs::fix_*)
-    short *row = reinterpret_cast<short *>(a.out) + (long)c * a.out_stride;
-    const short *pl = a.philast + (long)c * a.philast_stride;
-    for (int sl = a.fix_lo + tid; sl < a.fix_hi; sl += TPB) row[sl * a.fix_gs] = (short)(row[sl * a.fix_gs] + pl[sl - 1]);
-  }
+}
+
+// The any-D hot form with FM stores the first output of slice s as -phi and leaves the last angle of every slice in
+// philast; this adds philast[s - 1] for the slices fix_lo <= s < fix_hi (first output fix_gs * s). After the hot kernel.
+__global__ void iqbb_fm_fixup_kernel(short *out, long out_stride, const short *philast, int philast_stride, int fix_lo, int fix_hi, int fix_gs) {
+  const int c = blockIdx.y;
+  short *row = out + (long)c * out_stride;
+  const short *pl = philast + (long)c * philast_stride;
+  for (int sl = fix_lo + blockIdx.x * blockDim.x + threadIdx.x; sl < fix_hi; sl += gridDim.x * blockDim.x)
+    row[sl * fix_gs] = (short)(row[sl * fix_gs] + pl[sl - 1]);
 }
 
 // =================================================================================================
@@ -1146,50 +1144,39 @@ struct sdrhip_iqbb_i16 {
     return true;
   }
 
-  // Path 3's long calls: the hot kernel's any-D form (iqbb_hot.hpp, DG) for the tiles whose four slices are all hot, the
-  // general any-D kernel in border mode for the rest (first and last tiles: history, carries, the stream's first sample,
-  // state for the next call). Both write the groups of the seam tiles they share — the same values.
-  // false: not this plan / call (the general kernel runs it whole).
+  // Path 3's long calls: the hot kernel's any-D form (iqbb_hot.hpp, DG) — hot slices and, at the end of each workgroup,
+  // the call's cold slices (history, carries, the stream's first sample, state for the next call); with FM a second,
+  // tiny launch adds the previous slice's last angle to every slice's first output.
+  // false: not this plan / call (the general kernel runs it).
   bool anyd_plan() const {
     return path == 3 && use_hot && hot_range >= 0 && inc != 0 && S <= 9 && !i8 && !real && D >= 9 && D <= 180;
   }
   bool launch_anyd_call(IqbbArgs &a, const Geometry &g, const uint32_t *in_dev, size_t N, size_t in_stride, void *out_dev,
-                        size_t out_stride, int tiles_m, size_t lds_m) {
+                        size_t out_stride) {
     const int kind = in_cu8 ? HOT_CU8 : HOT_CS16, halo = hot_halo(S, kind), win = hot_win(S, kind);
-    const int ovh = 0;   // (the any-D form never recomputes an overlap group: FM's first angles come through philast)
-    const int GS = 512 / D, OGw = GS - ovh, OGh = 4 * OGw;
+    const int GS = 512 / D, OGh = 4 * GS;   // (no recomputed overlap group: FM's first angles come through philast)
     const int tiles_h = (int)ceil_div((size_t)g.n_groups, (size_t)OGh);
     // the hot slices of a channel are ONE range of slice numbers s = 4 * tile + w (slice_is_hot is monotone in s): every
-    // wave finds its own tile range inside [t_lo, t_hi) in the kernel; the border tiles start / end at slice granularity
-    auto slice_hot = [&](int sl) { return slice_is_hot(halo, win, g.base0_rel, OGh, ovh, (int)N, g.n_out, sl >> 2, sl & 3, D, GS); };
+    // wave finds its own tile range inside [t_lo, t_hi) in the kernel
+    auto slice_hot = [&](int sl) { return slice_is_hot(halo, win, g.base0_rel, OGh, 0, (int)N, g.n_out, sl >> 2, sl & 3, D, GS); };
     int s_lo = 0, s_hi = 4 * tiles_h;
     while (s_lo < s_hi && !slice_hot(s_lo)) s_lo++;
     while (s_hi > s_lo && !slice_hot(s_hi - 1)) s_hi--;
     if (s_hi - s_lo < 16) return false;
     const int t_lo = s_lo >> 2, t_hi = (s_hi + 3) >> 2;
-    // border tiles of the general kernel: its tiles emit OG groups each
-    const long ga = (long)s_lo * GS, gb = (long)s_hi * GS;
-    // (FM: the first hot slice's first group has no philast entry before it — the border tiles own it too)
-    int bt_lo = (int)ceil_div((size_t)(ga + (epi == SDRHIP_EPI_FM ? 1 : 0)), (size_t)OG), bt_hi = (int)(gb / OG);
-    bt_hi = std::min(bt_hi, tiles_m - 1);   // (the last tile always: it rolls the history and hands the state on)
-    if (bt_lo >= bt_hi) return false;
     HotArgs ha;
     ha.in = in_dev; ha.in_stride = (long)in_stride; ha.out = out_dev; ha.out_stride = (long)out_stride;
     ha.tapfrag = tapfrag.p; ha.lut = lut.p; ha.inc = inc; ha.n0_lo = (uint32_t)(n0 - phase0); ha.negative = negative;
-    ha.base0_rel = g.base0_rel; ha.OG = OGh; ha.ovl = ovh; ha.t_lo = t_lo; ha.t_hi = t_hi; ha.cre = cre; ha.cim = cim;
+    ha.base0_rel = g.base0_rel; ha.OG = OGh; ha.ovl = 0; ha.t_lo = t_lo; ha.t_hi = t_hi; ha.cre = cre; ha.cim = cim;
     ha.N = (int)N; ha.n_out = g.n_out; ha.C = C; ha.stamps = nullptr;
-    ha.D = D; ha.GS = GS;
+    ha.D = D; ha.GS = GS; ha.tiles_h = tiles_h;
     { int lpg = 1; while (2 * lpg <= 16 && 2 * lpg * GS <= 64) lpg *= 2; int sh = 0; while ((1 << sh) < lpg) sh++; ha.lpg_sh = sh; }
     ha.inv_d = (float)((1.0 / D) * (1.0 - 1.0 / 1048576.0));
     ha.philast = nullptr; ha.philast_stride = 4 * tiles_h;
-    a.philast = nullptr; a.philast_stride = 0; a.fix_lo = a.fix_hi = 0; a.fix_gs = GS;
     if (epi == SDRHIP_EPI_FM) {
       const size_t need = (size_t)C * 4 * tiles_h;
       if (philast.n < need) philast.alloc(need + 1024);
-      ha.philast = philast.p; a.philast = philast.p; a.philast_stride = 4 * tiles_h;
-      // slices whose first group lies in [bt_lo * OG, bt_hi * OG): neither border range writes it
-      a.fix_lo = std::max(s_lo + 1, (int)ceil_div((size_t)bt_lo * OG, (size_t)GS));
-      a.fix_hi = std::min(s_hi, (int)ceil_div((size_t)bt_hi * OG, (size_t)GS));
+      ha.philast = philast.p;
     }
 #ifdef K1_STAMPS
     if (!k1_stamps.p) { k1_stamps.alloc(32768 * 16); k1_stamps.zero(ctx->stream); }
@@ -1200,17 +1187,16 @@ struct sdrhip_iqbb_i16 {
     { const char *e = getenv("SDRHIP_IQBB_TPW"); if (e) htpw = std::max(1, atoi(e)); }   // tuning hook
     ha.tpw = htpw;
     ha.G = (int)ceil_div((size_t)tiles_h, (size_t)htpw); ha.U = ha.G * C;
-    const int grid = std::max(1, std::min(nvwg, ha.U));
+    const int grid = std::max(1, std::min(nvwg, std::max(ha.U, C)));   // (every channel's cold slices need a taker too)
     ha.dq = grid / ha.G; ha.dr = grid % ha.G;
     HotLaunch hl{(unsigned)grid, ctx->stream};
     hot_launch_anyd(S, kind, hot_range, epi, hl, ha, a);
-    // the border tiles (a.* is the general kernel's own geometry)
-    a.bt_lo = bt_lo; a.bt_hi = bt_hi; a.tpw = bt_lo + tiles_m - bt_hi;   // (one workgroup per channel walks the border tiles)
-    const dim3 gridb(1, C), block(TPB);
-#define SDRHIP_MFGB(S_) do { if (in_cu8) hipLaunchKernelGGL((iqbb_i16_mfmag_kernel<S_, true, true>), gridb, block, lds_m, ctx->stream, a); \
-                             else hipLaunchKernelGGL((iqbb_i16_mfmag_kernel<S_, true, false>), gridb, block, lds_m, ctx->stream, a); } while (0)
-    switch (S) { case 2: SDRHIP_MFGB(2); break; case 3: SDRHIP_MFGB(3); break; case 5: SDRHIP_MFGB(5); break; default: SDRHIP_MFGB(9); break; }
-#undef SDRHIP_MFGB
+    if (epi == SDRHIP_EPI_FM) {   // slices 1 .. whose first group is emitted
+      const int fix_hi = (int)ceil_div((size_t)g.n_out, (size_t)GS);
+      if (fix_hi > 1)
+        hipLaunchKernelGGL(iqbb_fm_fixup_kernel, dim3((unsigned)ceil_div((size_t)(fix_hi - 1), (size_t)256), C), dim3(256), 0, ctx->stream,
+                           reinterpret_cast<short *>(out_dev), (long)out_stride, philast.p, 4 * tiles_h, 1, fix_hi, GS);
+    }
     return true;
   }
 
@@ -1240,7 +1226,7 @@ struct sdrhip_iqbb_i16 {
     int tpw = 1;
     if (path == 1 || path == 2 || path == 4) { tpw = 8; while (tpw > 1 && (size_t)ceil_div((size_t)tiles, (size_t)tpw) * C < 2048) tpw >>= 1; }
     { const char *t = getenv("SDRHIP_IQBB_TPW"); if (t && (path == 1 || path == 2 || path == 4)) tpw = std::max(1, atoi(t)); }   // tuning hook
-    a.tiles = tiles; a.tpw = tpw; a.bt_hi = 0; a.bt_lo = 0; a.philast = nullptr; a.philast_stride = 0; a.fix_lo = a.fix_hi = 0; a.fix_gs = 1;
+    a.tiles = tiles; a.tpw = tpw; a.bt_hi = 0;
     a.lpg = 1; while (a.lpg < 64 && a.lpg * 8 < D) a.lpg <<= 1;
     dim3 grid((unsigned)ceil_div((size_t)tiles, (size_t)tpw), C), block(TPB);
     if (path == 4 && use_hot && hot_range >= 0 && tiles >= 3 && launch_hot_call(a, g, in_dev, N, in_stride, out_dev, out_stride, tiles)) {
@@ -1254,10 +1240,9 @@ struct sdrhip_iqbb_i16 {
         default: SDRHIP_MFR(9); break;
       }
 #undef SDRHIP_MFR
-    } else if (path == 3 && anyd_plan() && launch_anyd_call(a, g, in_dev, N, in_stride, out_dev, out_stride, tiles, lds_bytes)) {
-      // (the hot kernel's any-D form took the interior tiles, the general kernel the border ones)
+    } else if (path == 3 && anyd_plan() && launch_anyd_call(a, g, in_dev, N, in_stride, out_dev, out_stride)) {
+      // (the hot kernel's any-D form took the whole call)
     } else if (path == 3) {
-      a.bt_hi = 0; a.bt_lo = 0; a.tpw = tpw;
       int tpw3 = 8; while (tpw3 > 1 && (size_t)ceil_div((size_t)tiles, (size_t)tpw3) * C < 2048) tpw3 >>= 1;
       { const char *t = getenv("SDRHIP_IQBB_TPW"); if (t) tpw3 = std::max(1, atoi(t)); }   // tuning hook
       a.tpw = tpw3;
@@ -1476,7 +1461,7 @@ int sdrhip_iqbb_i16_kernel_names(sdrhip_iqbb_i16 *h, char *buf, size_t len) {
     const char *nm = "iqbb_i16_kernel";
     if (h->path == 4 && h->use_hot && h->hot_range >= 0) nm = "iqbb_hot_kernel";   // (calls of < 3 tiles: the general kernel)
     else if (h->path == 4) nm = "bb_real_mfma_kernel";
-    else if (h->path == 3 && h->anyd_plan()) nm = "iqbb_hot_anyd_kernel,iqbb_i16_mfmag_kernel";   // (calls of a few tiles: the general kernel alone)
+    else if (h->path == 3 && h->anyd_plan()) nm = "iqbb_hot_anyd_kernel";   // (calls of a few tiles: the general kernel "iqbb_i16_mfmag_kernel")
     else if (h->path == 3) nm = "iqbb_i16_mfmag_kernel";
     else if (h->path == 2) nm = "iqbb_i16_mfma16_kernel";
     else if (h->path == 1 && h->use_dma && h->use_hot && h->hot_range >= 0) nm = "iqbb_hot_kernel";   // (calls of < 3 tiles: the general kernel)

@@ -227,7 +227,7 @@ def _hot_fuzz(ctx, orc, rng, order, cu8, decim=8):
     if decim == 8:
         assert node.kernel_names == ["iqbb_hot_kernel"]
     else:   # (an unshifted plan runs the general any-D kernel alone; retuning between buffers moves a plan from one to the other)
-        assert node.path == 3 and node.kernel_names in (["iqbb_hot_anyd_kernel", "iqbb_i16_mfmag_kernel"], ["iqbb_i16_mfmag_kernel"])
+        assert node.path == 3 and node.kernel_names in (["iqbb_hot_anyd_kernel"], ["iqbb_i16_mfmag_kernel"])
     refs = [orc.IQBaseBandI16(taps, lut, inc, Fc < 0, decim) for _ in range(C)]
     fms = [orc.FMDemodI16() for _ in range(C)]
     for n in lens:
