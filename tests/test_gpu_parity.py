@@ -207,6 +207,31 @@ def test_iqbb_any_decimation_full_size(ctx, orc):
             assert np.array_equal(y[k], fm.process(bb.process(orc.autocast_cu8_cs16(base[k, i * N:(i + 1) * N])))), (k, i)
 
 
+@pytest.mark.parametrize("epi", [sa.EPI_FM, sa.EPI_NONE])
+def test_iqbb_any_decimation_more_channels_than_workgroups(ctx, orc, epi):
+    """More channels (1100) than the persistent grid has workgroups (1024): the hot units and the cold slices of the any-D
+    form wrap around. 16 taps at decimation 62 on complex<int16>, two calls (the second starts inside a group)."""
+    C, N, D = 1100, 40001, 62
+    FSr = 1e6
+    taps, lut, inc = orc.iqbb_design(100e3, 12.5e3, FSr, 16), orc.freqshift_lut_i16(), orc.freqshift_inc(-100e3, FSr)
+    rng = np.random.default_rng(78)
+    base = rng.integers(-32768, 32768, (8, 2 * N, 2), dtype=np.int16)
+    x = np.ascontiguousarray(base[np.arange(C) % 8])
+    node = sa.IQBaseBandI16(ctx, taps, lut, inc, True, D, channels=C, max_in=N, epilogue=epi)
+    assert node.kernel_names == ["iqbb_hot_anyd_kernel"]
+    ys = [node.process(x[:, :N]), node.process(x[:, N:])]
+    for y in ys:
+        for k in range(8):
+            assert (y[k::8] == y[k]).all()
+    for k in range(8):
+        bb, fm = orc.IQBaseBandI16(taps, lut, inc, True, D), orc.FMDemodI16()
+        for i, y in enumerate(ys):
+            r = bb.process(base[k, i * N:(i + 1) * N])
+            if epi == sa.EPI_FM:
+                r = fm.process(r)
+            assert np.array_equal(y[k], r), (k, i)
+
+
 def test_iqbb_random_fullscale_vs_oracle(ctx, orc, k1path):
     """Full-range random int16 input (worst case for the int32 accumulators and the >>14/>>16 steps)."""
     rng = np.random.default_rng(7)
