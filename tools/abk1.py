@@ -3,7 +3,7 @@
 settings) gets its own plan over the SAME resident input batches; timing rounds are interleaved (variant A, B, C, A, B,
 C, ...) so that clock drift and box-to-box differences cancel. Reports median / min ms per launch per variant.
 
-usage: tools/abk1.py [--order 127] [--epi fm|usb|am|none] [--cu8|--real] [--channels 1024] [--samples 65536] [--rounds 7]
+usage: tools/abk1.py [--order 127] [--epi fm|usb|am|none] [--cu8|--real] [--decim 8] [--channels 1024] [--samples 65536] [--rounds 7]
                      [--launches 200] name=libsdr_amd/libsdrhip_x.so[@ENV=VAL[,ENV=VAL]] ...
 """
 import argparse
@@ -39,6 +39,7 @@ def main():
     p.add_argument("--order", type=int, default=127)
     p.add_argument("--epi", default="fm")
     p.add_argument("--cu8", action="store_true")
+    p.add_argument("--decim", type=int, default=8)
     p.add_argument("--real", action="store_true", help="the real-input BaseBand<int16> (sdrhip_bb_i16_create)")
     p.add_argument("--channels", type=int, default=1024)
     p.add_argument("--samples", type=int, default=65536)
@@ -71,7 +72,7 @@ def main():
             L = load(path)
             ctx, h = C.c_void_p(), C.c_void_p()
             assert L.sdrhip_ctx_create(0, C.c_void_p(stream.cuda_stream), C.byref(ctx)) == 0
-            rc = (L.sdrhip_bb_i16_create if a.real else L.sdrhip_iqbb_i16_create)(ctx, taps.ctypes.data_as(C.POINTER(C.c_int32)), a.order, lut.ctypes.data_as(C.POINTER(C.c_int32)), inc, 0, 8,
+            rc = (L.sdrhip_bb_i16_create if a.real else L.sdrhip_iqbb_i16_create)(ctx, taps.ctypes.data_as(C.POINTER(C.c_int32)), a.order, lut.ctypes.data_as(C.POINTER(C.c_int32)), inc, 0, a.decim,
                                           Cn, N, epi, C.byref(h))
             assert rc == 0, L.sdrhip_last_error()
             if a.cu8:
