@@ -6,7 +6,7 @@ set -e
 cd $(dirname $0)/../libsdr_amd/csrc
 NAME=$1; FLAGS=$2; shift 2
 make -s -j8 > /dev/null
-K1=$(ls iqbb_i16.hip iqbb_hot_s*.hip | tr '\n' ' ')
+K1=$(ls iqbb_i16.hip iqbb_hot_*.hip | tr '\n' ' ')
 ALL=$(ls *.hip | tr '\n' ' ')
 SRCS=" ${*:-$K1} "   # default: the K1 sources; name any other source (fir.hip, fftconv.hip ...) to rebuild it under the flags
 mkdir -p _obj_$NAME
