@@ -98,7 +98,7 @@ __host__ __device__ __forceinline__ bool slice_is_hot(int halo, int win, int bas
   return ws >= 0 && ws + win <= N && qf >= 1 && qf + GS - 1 < n_out - 1;
 }
 
-// DG: ANY decimation 9 <= D <= 180 (the reference's own receivers decimate by 62 and 125, examples/sdr_rec.cc:68,
+// DG: ANY decimation 9 <= D <= 256 (the reference's own receivers decimate by 62 and 125, examples/sdr_rec.cc:68,
 // examples/sdr_fm.cc:40). The matrix part, the windows and the grid are the same; a slice's 512 samples hold GS = 512 / D
 // whole groups (the slices of a wave advance by GS * D samples, so every slice starts on a group), the rotated samples go
 // through a 2 KB per-wave LDS array and lane teams sum the groups from there. The tap fragments are path 3's (rows in
@@ -450,14 +450,18 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       if (lsh > 1) { sx += __builtin_amdgcn_update_dpp(0, sx, 0x102, 0xf, 0xf, true); sy += __builtin_amdgcn_update_dpp(0, sy, 0x102, 0xf, 0xf, true); }
       if (lsh > 2) { sx += __builtin_amdgcn_update_dpp(0, sx, 0x104, 0xf, 0xf, true); sy += __builtin_amdgcn_update_dpp(0, sy, 0x104, 0xf, 0xf, true); }
       if (lsh > 3) { sx += __builtin_amdgcn_update_dpp(0, sx, 0x108, 0xf, 0xf, true); sy += __builtin_amdgcn_update_dpp(0, sy, 0x108, 0xf, 0xf, true); }
+      if (lsh > 4) {   // teams of 32 lanes (GS = 2): the second 16-lane row's sum comes over by ds_bpermute
+        sx += __builtin_amdgcn_ds_bpermute(4 * ((l + 16) & 63), sx); sy += __builtin_amdgcn_ds_bpermute(4 * ((l + 16) & 63), sy);
+      }
       sum = make_int2(sx, sy);   // (whole in the team's first lane)
     }
     return sum;
   };
-  // F (DG): the team's first lane owns group k = l >> lpg_sh of the slice: truncating division by D (|sum| <= D * 2^15 and
-  // D <= 180: libstdc++'s (s * D) / (D * D) of src/baseband.hh:214 cannot wrap, it is trunc(s / D): a float estimate
+  // F (DG): the team's first lane owns group k = l >> lpg_sh of the slice: truncating division by D (|sum| <= D * 2^15; up to
+  // D = 180 libstdc++'s (s * D) / (D * D) of src/baseband.hh:214 cannot wrap, it is trunc(s / D): a float estimate
   // biased down + one exact remainder step), demodulator, store; FM: the previous group's angle from the team before
   auto div_d = [&](int v) __attribute__((always_inline)) {
+    if (DD > 180) return (int)(short)box_div(v, DD);      // (s * D can wrap from D = 182 on: the reference's wrapping arithmetic, generic division — once per group)
     const unsigned m = (unsigned)max(v, -v);
     unsigned q = (unsigned)((float)m * a.inv_d);          // inv_d = (1 / D)(1 - 2^-20): q or q - 1 (m < 2^23: the product is good to 2^-7)
     const unsigned r = m - q * (unsigned)DD;
