@@ -95,10 +95,11 @@ __host__ __device__ __forceinline__ bool slice_is_hot(int halo, int win, int bas
                                                       int D = 8, int GS = 64) {
   const int qf = tile * OG - ovl + w * (GS - ovl);   // the slice's first group (output index within the call)
   const int ws = base0_rel + qf * D - halo;          // its window's first sample (N < 2^30: no overflow)
-  return ws >= 0 && ws + win <= N && qf >= 1 && qf + GS - 1 < n_out - 1;
+  // (the call's groups 0 and 1 are cold: carry and D+1 window; FMDemod's out[1] takes the previous CALL's last angle)
+  return ws >= 0 && ws + win <= N && qf >= (GS == 1 ? 2 : 1) && qf + GS - 1 < n_out - 1;
 }
 
-// DG: ANY decimation 9 <= D <= 256 (the reference's own receivers decimate by 62 and 125, examples/sdr_rec.cc:68,
+// DG: ANY decimation 9 <= D <= 512 (the reference's own receivers decimate by 62 and 125, examples/sdr_rec.cc:68,
 // examples/sdr_fm.cc:40). The matrix part, the windows and the grid are the same; a slice's 512 samples hold GS = 512 / D
 // whole groups (the slices of a wave advance by GS * D samples, so every slice starts on a group), the rotated samples go
 // through a 2 KB per-wave LDS array and lane teams sum the groups from there. The tap fragments are path 3's (rows in
@@ -452,6 +453,9 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       if (lsh > 3) { sx += __builtin_amdgcn_update_dpp(0, sx, 0x108, 0xf, 0xf, true); sy += __builtin_amdgcn_update_dpp(0, sy, 0x108, 0xf, 0xf, true); }
       if (lsh > 4) {   // teams of 32 lanes (GS = 2): the second 16-lane row's sum comes over by ds_bpermute
         sx += __builtin_amdgcn_ds_bpermute(4 * ((l + 16) & 63), sx); sy += __builtin_amdgcn_ds_bpermute(4 * ((l + 16) & 63), sy);
+      }
+      if (lsh > 5) {   // ... and of the whole wave (GS = 1: decimations 257 .. 512 — only D of a slice's 512 samples are used)
+        sx += __builtin_amdgcn_ds_bpermute(4 * ((l + 32) & 63), sx); sy += __builtin_amdgcn_ds_bpermute(4 * ((l + 32) & 63), sy);
       }
       sum = make_int2(sx, sy);   // (whole in the team's first lane)
     }

@@ -1150,7 +1150,7 @@ struct sdrhip_iqbb_i16 {
   // tiny launch adds the previous slice's last angle to every slice's first output.
   // false: not this plan / call (the general kernel runs it).
   bool anyd_plan() const {
-    return path == 3 && use_hot && hot_range >= 0 && inc != 0 && S <= 9 && !i8 && !real && D >= 9 && D <= 256;
+    return path == 3 && use_hot && hot_range >= 0 && inc != 0 && S <= 9 && !i8 && !real && D >= 9 && D <= 512;
   }
   bool launch_anyd_call(IqbbArgs &a, const Geometry &g, const uint32_t *in_dev, size_t N, size_t in_stride, void *out_dev,
                         size_t out_stride) {
@@ -1171,7 +1171,7 @@ struct sdrhip_iqbb_i16 {
     ha.base0_rel = g.base0_rel; ha.OG = OGh; ha.ovl = 0; ha.t_lo = t_lo; ha.t_hi = t_hi; ha.cre = cre; ha.cim = cim;
     ha.N = (int)N; ha.n_out = g.n_out; ha.C = C; ha.stamps = nullptr;
     ha.D = D; ha.GS = GS; ha.tiles_h = tiles_h;
-    { int lpg = 1; while (2 * lpg <= 32 && 2 * lpg * GS <= 64) lpg *= 2; int sh = 0; while ((1 << sh) < lpg) sh++; ha.lpg_sh = sh; }
+    { int lpg = 1; while (2 * lpg <= 64 && 2 * lpg * GS <= 64) lpg *= 2; int sh = 0; while ((1 << sh) < lpg) sh++; ha.lpg_sh = sh; }
     ha.inv_d = (float)((1.0 / D) * (1.0 - 1.0 / 1048576.0));
     ha.philast = nullptr; ha.philast_stride = 4 * tiles_h;
     if (epi == SDRHIP_EPI_FM) {
@@ -1192,11 +1192,11 @@ struct sdrhip_iqbb_i16 {
     ha.dq = grid / ha.G; ha.dr = grid % ha.G;
     HotLaunch hl{(unsigned)grid, ctx->stream};
     hot_launch_anyd(S, kind, hot_range, epi, hl, ha, a);
-    if (epi == SDRHIP_EPI_FM) {   // slices 1 .. whose first group is emitted
-      const int fix_hi = (int)ceil_div((size_t)g.n_out, (size_t)GS);
-      if (fix_hi > 1)
+    if (epi == SDRHIP_EPI_FM) {   // the slices whose first output is neither out[0] nor out[1] (their own rules) and is emitted
+      const int fix_lo = GS == 1 ? 2 : 1, fix_hi = (int)ceil_div((size_t)g.n_out, (size_t)GS);
+      if (fix_hi > fix_lo)
         hipLaunchKernelGGL(iqbb_fm_fixup_kernel, dim3((unsigned)ceil_div((size_t)C, (size_t)4)), dim3(256), 0, ctx->stream,
-                           reinterpret_cast<short *>(out_dev), (long)out_stride, philast.p, 4 * tiles_h, 1, fix_hi, GS, C);
+                           reinterpret_cast<short *>(out_dev), (long)out_stride, philast.p, 4 * tiles_h, fix_lo, fix_hi, GS, C);
     }
     return true;
   }

@@ -148,7 +148,8 @@ def test_iqbb_batched_vs_oracle(ctx, orc, epi, order, decim, Fc, k1path):
 ANYD_CASES = [(21, 125, 100e3, True), (16, 62, 100e3, False), (21, 9, -60e3, False), (33, 180, 41e3, False), (16, 12, 100e3, False),
               (17, 31, -250e3, True), (3, 100, 100e3, False), (33, 10, 70e3, True),
               (64, 20, 100e3, False), (65, 125, -100e3, True), (127, 125, 100e3, False), (129, 9, 30e3, True), (100, 50, 100e3, False),
-              (21, 200, 100e3, True), (16, 256, -100e3, False), (64, 181, 41e3, False)]
+              (21, 200, 100e3, True), (16, 256, -100e3, False), (64, 181, 41e3, False), (21, 300, 100e3, True), (16, 512, 100e3, False),
+              (33, 257, -60e3, False)]
 
 
 @pytest.mark.parametrize("hot", [True, False])
@@ -156,7 +157,7 @@ ANYD_CASES = [(21, 125, 100e3, True), (16, 62, 100e3, False), (21, 9, -60e3, Fal
 @pytest.mark.parametrize("order,decim,Fc,cu8", ANYD_CASES)
 def test_iqbb_any_decimation_long_calls_vs_oracle(ctx, orc, order, decim, Fc, cu8, epi, hot, monkeypatch):
     """The reference's own receivers decimate by 62 (examples/sdr_rec.cc:68, 16 taps) and 125 (examples/sdr_fm.cc:40, 21
-    taps on complex<uint8> input): plans of up to 129 taps with a shift and 9 <= D <= 256 run the hot kernel's any-D form
+    taps on complex<uint8> input): plans of up to 129 taps with a shift and 9 <= D <= 512 run the hot kernel's any-D form
     on the interior tiles of a long call and the general any-D kernel on the border tiles (two launches, seam tiles
     written by both). Ragged long and short calls, state carried across them, against the oracle; `hot` = False: the
     general kernel alone (SDRHIP_IQBB_HOT=0)."""
