@@ -50,6 +50,7 @@ def parse():
     p.add_argument("--samples", type=int, default=65536, help="samples per channel per step")
     p.add_argument("--workload", default="", help="default: iqbb_fm on one GPU, iqbb_usb with the gather (BASELINE config 5) on several")
     p.add_argument("--decim", type=int, default=8, help="iqbb_* workloads: decimation D (8 = the BASELINE configs)")
+    p.add_argument("--fc", type=float, default=100e3, help="iqbb_* workloads: centre and filter frequency in Hz (0: no frequency shift, as examples/sdr_rec.cc tunes)")
     p.add_argument("--order", type=int, default=127, help="iqbb_* workloads: FIR order (127 = the BASELINE configs)")
     p.add_argument("--batches", type=int, default=3, help="distinct input batches rotated through (defeats the 256 MiB L3)")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -208,10 +209,10 @@ def build_workload(a, wl, sa, torch, shard, ctx, dev, rank, nbuf_out):
     order, D = a.order, a.decim
     cs16 = lambda: [synth_cs16(torch, C, N, dev, 1234 + b, chan0=rank * C) for b in range(a.batches)]
     if wl in ("iqbb_fm", "iqbb_usb", "iqbb_fm_cu8"):
-        taps = torch.from_numpy(sa.design_iqbb_taps(100e3, 50e3, FS, order)).to(dev)
+        taps = torch.from_numpy(sa.design_iqbb_taps(a.fc, 50e3, FS, order)).to(dev)
         lut = torch.from_numpy(sa.design_freqshift_lut_i16()).to(dev)
         shard.broadcast_design([taps, lut], src=0)
-        taps_h, lut_h, inc = taps.cpu().numpy(), lut.cpu().numpy(), sa.design_freqshift_inc(100e3, FS)
+        taps_h, lut_h, inc = taps.cpu().numpy(), lut.cpu().numpy(), sa.design_freqshift_inc(a.fc, FS)
         epi = sa.EPI_USB if wl == "iqbb_usb" else sa.EPI_FM
         node = sa.IQBaseBandI16(ctx, taps_h, lut_h, inc, False, D, channels=C, max_in=N, epilogue=epi)
         w.in_bytes, w.alg_bytes = 4.0, 4.0 + 2.0 / D
@@ -225,10 +226,11 @@ def build_workload(a, wl, sa, torch, shard, ctx, dev, rank, nbuf_out):
             w.in_bytes, w.alg_bytes = 2.0, 2.0 + 2.0 / D
         w.run = lambda b, o: node.process_dev(w.ins[b].data_ptr(), N, N, w.outs[o].data_ptr(), n_out)
         w.dtype, w.kernels = "i16", node.kernel_names
-        w.desc = "IQBaseBand<int16>(%d-tap Q14 FIR, LUT shift 100 kHz, /%d) -> %s" % (order, D, "USBDemod" if wl == "iqbb_usb" else "FMDemod")
+        w.desc = "IQBaseBand<int16>(%d-tap Q14 FIR, %s, /%d) -> %s" % (order, "LUT shift %g kHz" % (a.fc / 1e3) if inc else "no shift", D,
+                                                                      "USBDemod" if wl == "iqbb_usb" else "FMDemod")
         if cu8:
             w.desc = "complex<uint8> -> AutoCast + " + w.desc
-        w.key = "%s/order%d/d%d" % (wl, order, D)
+        w.key = "%s/order%d/d%d" % (wl, order, D) + ("" if a.fc == 100e3 else "/fc%g" % a.fc)
         w.n_valid = node.out_count(N)   # (every call after the first emits N / D outputs)
 
         w.verify_needs_n0 = w.verify_needs_pre = True

@@ -48,7 +48,8 @@ constexpr int hot_lds_cap(int NW) { return NW == 4 ? 40960 : NW == 8 ? 81920 : 1
 // 4 KB rotation table ({Lx, Ly, -Ly, 0} x 256: one SDWA shift makes the address, no subtraction) while it fits
 constexpr bool hot_wide(int S, int NH, int in, int NW, int extra = 0) { return hot_lds_bytes(S, NH, in, NW, true) + extra <= hot_lds_cap(NW); }
 // the any-D form's additions to a workgroup's LDS: parked group sums, and the rotated samples where the window buffer is too small
-constexpr int hot_anyd_extra(int S, int in) { return 4 * 512 + (hot_bufb(S, in) >= 2048 ? 0 : 4 * 2048); }
+// (rot = false, plans without a shift: the unrotated values have 18 bits — two arrays of dwords instead of one of int16 pairs)
+constexpr int hot_anyd_extra(int S, int in, bool rot = true) { return 4 * 512 + (hot_bufb(S, in) >= 2048 ? 0 : 4 * 2048) + (rot ? 0 : 4 * 2048); }
 
 struct HotRange { int S0, NH, NW; };
 // per S: centred high-plane ranges, narrowest first; the last one covers every step
@@ -78,8 +79,8 @@ void hot_launch_s9_cu8(int range, bool rot, int epi, const HotLaunch &, const Ho
 void hot_launch_s17_cs16(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
 void hot_launch_s17_cu8(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
 void hot_launch_real(int S, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);   // S = 5 or 9
-void hot_launch_anyd(int S, int in, int range, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);   // S = 2, 3, 5 or 9, cs16 / cu8, shifted plans
-void hot_launch_anyd9(int in, int range, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
+void hot_launch_anyd(int S, int in, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);   // S = 2, 3, 5 or 9, cs16 / cu8
+void hot_launch_anyd9(int in, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
 
 }  // namespace sdrhip
 
@@ -108,7 +109,7 @@ __host__ __device__ __forceinline__ bool slice_is_hot(int halo, int win, int bas
 template <int S, int S0, int NH, bool ROT, int EPI, int IN, int NW, bool DG = false>
 __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &b) {
   constexpr bool CU8 = IN == HOT_CU8, REAL = IN == HOT_REAL;
-  static_assert(!DG || (ROT && !REAL && NW == 4), "any-D form: shifted complex plans, 4-wave workgroups");
+  static_assert(!DG || (!REAL && NW == 4), "any-D form: complex plans, 4-wave workgroups");
   const int DD = DG ? a.D : 8, GS = DG ? a.GS : 64;   // decimation, whole groups per slice
   static_assert(S >= 2 && S0 >= 0 && NH >= 1 && S0 + NH <= S, "high-plane range inside the K loop");
   static_assert(!REAL || NW == 4, "real input: 4-wave workgroups");
@@ -120,7 +121,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   constexpr int NDMA = (NPIECE + 63) / 64;                     // DMA wave-instructions per window
   constexpr int LASTL = NPIECE - 64 * (NDMA - 1);              // lanes of the last one
   static_assert(NDMA <= 3, "immediate offsets 0 / 1024 / 2048");
-  constexpr bool WIDE = hot_wide(S, NH, IN, NW, DG ? hot_anyd_extra(S, IN) : 0);
+  constexpr bool WIDE = hot_wide(S, NH, IN, NW, DG ? hot_anyd_extra(S, IN, ROT) : 0);
   constexpr int NBUF = 2;   // window buffers per wave
   static_assert(hot_lds_bytes(S, NH, IN, NW, WIDE) <= hot_lds_cap(NW), "LDS budget for 4 waves per SIMD");
   constexpr int TBLW = WIDE ? 1024 : 256;   // dwords
@@ -140,6 +141,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   char *wbase = reinterpret_cast<char *>(smem + TBLW + (S + NH) * 64 * 4) + w * (NBUF * BUFB);
   char *pendb = reinterpret_cast<char *>(smem + TBLW + (S + NH) * 64 * 4) + NW * (NBUF * BUFB) + w * 512;    // (DG) the wave's parked group sums (64 x int2)
   char *gscb = reinterpret_cast<char *>(smem + TBLW + (S + NH) * 64 * 4) + NW * (NBUF * BUFB) + NW * 512 + w * 2048;   // (DG) the wave's rotated samples (when its window buffer is too small)
+  char *gscb2 = gscb + NW * 2048;   // (DG, no shift, small window buffers) the second array
 #ifdef K1_ABL_ASAME   // (tuning ablation, results wrong: every step reads the SAME fragment values — K1_ABL_AREG's operand data with the reads kept)
   for (int i = tid; i < S * 64; i += TPBH) taps_s[i] = a.tapfrag[64 + (i & 63)];
   for (int i = tid; i < NH * 64; i += TPBH) taps_s[S * 64 + i] = a.tapfrag[(2 * S0) * 64 + (i & 63)];
@@ -374,7 +376,8 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       }
     }
     int2 sum = make_int2(0, 0);
-    unsigned pk[8];   // (DG) the lane's rotated samples
+    unsigned pk[8];   // (DG) the lane's rotated samples, or (no shift) their real parts
+    unsigned pky[8];  // (DG, no shift) the imaginary parts
 #ifdef K1_ABL_NOEPI
 #pragma unroll
     for (int r = 0; r < 16; r += 2) { sum.x += acc_hh[r] ^ acc_mid[r] ^ acc_ll[r]; sum.y += acc_hh[r + 1] ^ acc_mid[r + 1] ^ acc_ll[r + 1]; }
@@ -399,6 +402,8 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
         const int y = mad24a(L[j][0], ri, mul24a(L[j][1], rr));
         if (DG) pk[j] = __builtin_amdgcn_perm((unsigned)y, (unsigned)x, 0x07060302u);   // {x >> 16, y >> 16} as two int16
         else { sum.x = add_hi16(x, sum.x); sum.y = add_hi16(y, sum.y); }
+      } else if (DG) {
+        pk[j] = (unsigned)rr; pky[j] = (unsigned)ri;
       } else {
         sum.x = (int)((unsigned)sum.x + (unsigned)rr); sum.y = (int)((unsigned)sum.y + (unsigned)ri);
       }
@@ -424,6 +429,18 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
         }
       *reinterpret_cast<uint4 *>(gsc + 8 * (2 * n + h)) = make_uint4(q8[0], q8[1], q8[2], q8[3]);
       *reinterpret_cast<uint4 *>(gsc + 8 * (2 * n + h) + 4) = make_uint4(q8[4], q8[5], q8[6], q8[7]);
+      unsigned *gsy = reinterpret_cast<unsigned *>(BUFB >= 2048 ? gscb : gscb2);   // (no shift) the imaginary parts' array
+      if (!ROT) {
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+          for (int tt = 0; tt < 2; tt++) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(pky[2 * jj + tt], pky[2 * (jj + 2) + tt], false, false);
+            q8[4 * jj + tt] = sw[0]; q8[4 * jj + 2 + tt] = sw[1];
+          }
+        *reinterpret_cast<uint4 *>(gsy + 8 * (2 * n + h)) = make_uint4(q8[0], q8[1], q8[2], q8[3]);
+        *reinterpret_cast<uint4 *>(gsy + 8 * (2 * n + h) + 4) = make_uint4(q8[4], q8[5], q8[6], q8[7]);
+      }
       asm volatile("" ::: "memory");
       const int lsh = a.lpg_sh, k = l >> lsh, t = l & ((1 << lsh) - 1);
       int sx = 0, sy = 0;
@@ -433,16 +450,26 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
         const int kk = min(k, GS - 1);
         const unsigned *gp = gsc + kk * DD + t;
         const int nfull = DD >> lsh;
+        const unsigned *gpy = gsy + kk * DD + t;
         for (int i = 0; i < nfull; i++) {
           const unsigned v = gp[i << lsh];
-          asm("v_add_u32_sdwa %0, sext(%1), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "+v"(sx) : "v"(v));
-          asm("v_add_u32_sdwa %0, sext(%1), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(sy) : "v"(v));
+          if (ROT) {
+            asm("v_add_u32_sdwa %0, sext(%1), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "+v"(sx) : "v"(v));
+            asm("v_add_u32_sdwa %0, sext(%1), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(sy) : "v"(v));
+          } else {
+            sx = (int)((unsigned)sx + v); sy = (int)((unsigned)sy + gpy[i << lsh]);
+          }
         }
         if ((nfull << lsh) < DD) {   // (scalar)
-          unsigned v = gp[min(nfull << lsh, DD - 1 - t)];
-          if (t + (nfull << lsh) >= DD) v = 0u;
-          asm("v_add_u32_sdwa %0, sext(%1), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "+v"(sx) : "v"(v));
-          asm("v_add_u32_sdwa %0, sext(%1), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(sy) : "v"(v));
+          const int ei = min(nfull << lsh, DD - 1 - t);
+          unsigned v = gp[ei], vy = ROT ? 0u : gpy[ei];
+          if (t + (nfull << lsh) >= DD) { v = 0u; vy = 0u; }
+          if (ROT) {
+            asm("v_add_u32_sdwa %0, sext(%1), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "+v"(sx) : "v"(v));
+            asm("v_add_u32_sdwa %0, sext(%1), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(sy) : "v"(v));
+          } else {
+            sx = (int)((unsigned)sx + v); sy = (int)((unsigned)sy + vy);
+          }
         }
       }
       asm volatile("" ::: "memory");
@@ -465,7 +492,9 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   // D = 180 libstdc++'s (s * D) / (D * D) of src/baseband.hh:214 cannot wrap, it is trunc(s / D): a float estimate
   // biased down + one exact remainder step), demodulator, store; FM: the previous group's angle from the team before
   auto div_d = [&](int v) __attribute__((always_inline)) {
-    if (DD > 180) return (int)(short)box_div(v, DD);      // (s * D can wrap from D = 182 on: the reference's wrapping arithmetic, generic division — once per group)
+    // (s * D can wrap from D = 182 on — unrotated 18-bit values: from 128 on, and past 2^24 the float estimate is no longer
+    // exact enough: the reference's wrapping arithmetic then, a generic division, once per group)
+    if (DD > (ROT ? 180 : 90)) return (int)(short)box_div(v, DD);
     const unsigned m = (unsigned)max(v, -v);
     unsigned q = (unsigned)((float)m * a.inv_d);          // inv_d = (1 / D)(1 - 2^-20): q or q - 1 (m < 2^23: the product is good to 2^-7)
     const unsigned r = m - q * (unsigned)DD;
@@ -838,9 +867,9 @@ template <int S, int S0, int NH, bool ROT, int EPI, int IN, int NW>
 __global__ __launch_bounds__(64 * NW, K1_MINWAVES) void iqbb_hot_kernel(const HotArgs a, const IqbbArgs b) {
   iqbb_hot_body<S, S0, NH, ROT, EPI, IN, NW>(a, b);
 }
-template <int S, int S0, int NH, int EPI, int IN>
+template <int S, int S0, int NH, bool ROT, int EPI, int IN>
 __global__ __launch_bounds__(256, K1_MINWAVES) void iqbb_hot_anyd_kernel(const HotArgs a, const IqbbArgs b) {
-  iqbb_hot_body<S, S0, NH, true, EPI, IN, 4, true>(a, b);
+  iqbb_hot_body<S, S0, NH, ROT, EPI, IN, 4, true>(a, b);
 }
 
 template <int S, int S0, int NH, int IN, int NW>
@@ -859,15 +888,19 @@ void hot_launch_one(bool rot, int epi, const HotLaunch &hl, const HotArgs &ha, c
 }
 
 template <int S, int S0, int NH, int IN>
-void hot_launch_anyd_one(int epi, const HotLaunch &hl, const HotArgs &ha, const IqbbArgs &b) {
-  const size_t lds = (size_t)hot_lds_bytes(S, NH, IN, 4, hot_wide(S, NH, IN, 4, hot_anyd_extra(S, IN))) + hot_anyd_extra(S, IN);
+void hot_launch_anyd_one(bool rot, int epi, const HotLaunch &hl, const HotArgs &ha, const IqbbArgs &b) {
+  const int extra = hot_anyd_extra(S, IN, rot);
+  const size_t lds = (size_t)hot_lds_bytes(S, NH, IN, 4, hot_wide(S, NH, IN, 4, extra)) + extra;
   const dim3 grid(hl.grid, 1), block(256);
-  switch (epi) {
-    case SDRHIP_EPI_FM: hipLaunchKernelGGL((iqbb_hot_anyd_kernel<S, S0, NH, SDRHIP_EPI_FM, IN>), grid, block, lds, hl.stream, ha, b); break;
-    case SDRHIP_EPI_AM: hipLaunchKernelGGL((iqbb_hot_anyd_kernel<S, S0, NH, SDRHIP_EPI_AM, IN>), grid, block, lds, hl.stream, ha, b); break;
-    case SDRHIP_EPI_USB: hipLaunchKernelGGL((iqbb_hot_anyd_kernel<S, S0, NH, SDRHIP_EPI_USB, IN>), grid, block, lds, hl.stream, ha, b); break;
-    default: hipLaunchKernelGGL((iqbb_hot_anyd_kernel<S, S0, NH, SDRHIP_EPI_NONE, IN>), grid, block, lds, hl.stream, ha, b); break;
-  }
+#define SDRHIP_ANYD(R_, E_) hipLaunchKernelGGL((iqbb_hot_anyd_kernel<S, S0, NH, R_, E_, IN>), grid, block, lds, hl.stream, ha, b)
+#define SDRHIP_ANYD_E(R_) do { switch (epi) { \
+    case SDRHIP_EPI_FM: SDRHIP_ANYD(R_, SDRHIP_EPI_FM); break; \
+    case SDRHIP_EPI_AM: SDRHIP_ANYD(R_, SDRHIP_EPI_AM); break; \
+    case SDRHIP_EPI_USB: SDRHIP_ANYD(R_, SDRHIP_EPI_USB); break; \
+    default: SDRHIP_ANYD(R_, SDRHIP_EPI_NONE); break; } } while (0)
+  if (rot) SDRHIP_ANYD_E(true); else SDRHIP_ANYD_E(false);
+#undef SDRHIP_ANYD_E
+#undef SDRHIP_ANYD
 }
 
 }  // namespace

@@ -1150,7 +1150,7 @@ struct sdrhip_iqbb_i16 {
   // tiny launch adds the previous slice's last angle to every slice's first output.
   // false: not this plan / call (the general kernel runs it).
   bool anyd_plan() const {
-    return path == 3 && use_hot && hot_range >= 0 && inc != 0 && S <= 9 && !i8 && !real && D >= 9 && D <= 512;
+    return path == 3 && use_hot && hot_range >= 0 && S <= 9 && !i8 && !real && D >= 9 && D <= 512;
   }
   bool launch_anyd_call(IqbbArgs &a, const Geometry &g, const uint32_t *in_dev, size_t N, size_t in_stride, void *out_dev,
                         size_t out_stride) {
@@ -1191,7 +1191,7 @@ struct sdrhip_iqbb_i16 {
     const int grid = std::max(1, std::min(nvwg, std::max(ha.U, C)));   // (every channel's cold slices need a taker too)
     ha.dq = grid / ha.G; ha.dr = grid % ha.G;
     HotLaunch hl{(unsigned)grid, ctx->stream};
-    hot_launch_anyd(S, kind, hot_range, epi, hl, ha, a);
+    hot_launch_anyd(S, kind, hot_range, inc != 0, epi, hl, ha, a);
     if (epi == SDRHIP_EPI_FM) {   // the slices whose first output is neither out[0] nor out[1] (their own rules) and is emitted
       const int fix_lo = GS == 1 ? 2 : 1, fix_hi = (int)ceil_div((size_t)g.n_out, (size_t)GS);
       if (fix_hi > fix_lo)

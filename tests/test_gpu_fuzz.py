@@ -226,8 +226,8 @@ def _hot_fuzz(ctx, orc, rng, order, cu8, decim=8):
         node.set_input_format(sa.abi.IN_CU8)
     if decim == 8:
         assert node.kernel_names == ["iqbb_hot_kernel"]
-    else:   # (an unshifted plan runs the general any-D kernel alone; retuning between buffers moves a plan from one to the other)
-        assert node.path == 3 and node.kernel_names in (["iqbb_hot_anyd_kernel"], ["iqbb_i16_mfmag_kernel"])
+    else:
+        assert node.path == 3 and node.kernel_names == ["iqbb_hot_anyd_kernel"]
     refs = [orc.IQBaseBandI16(taps, lut, inc, Fc < 0, decim) for _ in range(C)]
     fms = [orc.FMDemodI16() for _ in range(C)]
     for n in lens:
@@ -285,7 +285,7 @@ def test_hot_kernel_every_length_class_random_long_calls(ctx, orc, seed, cu8):
 @pytest.mark.parametrize("cu8", [False, True])
 @pytest.mark.parametrize("seed", range(16 + EXTRA))
 def test_hot_kernel_any_decimation_random_long_calls(ctx, orc, seed, cu8):
-    """The hot kernel's any-decimation form (9 <= D <= 512, up to 129 taps, shifted plans): random plans incl. the reference receivers' (16 taps / 62, 21 taps / 125), ragged long and short calls,
+    """The hot kernel's any-decimation form (9 <= D <= 512, up to 129 taps, shifted or not): random plans incl. the reference receivers' (16 taps / 62, 21 taps / 125), ragged long and short calls,
     retuning (also to and from no shift at all), filter swaps and _reconfigure between buffers."""
     rng = np.random.default_rng(23000 + 2 * seed + int(cu8))
     order = int(rng.choice([3, 16, 17, 21, 33, 34, 64, 65, 100, 127, 129]))

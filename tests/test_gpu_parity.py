@@ -149,7 +149,8 @@ ANYD_CASES = [(21, 125, 100e3, True), (16, 62, 100e3, False), (21, 9, -60e3, Fal
               (17, 31, -250e3, True), (3, 100, 100e3, False), (33, 10, 70e3, True),
               (64, 20, 100e3, False), (65, 125, -100e3, True), (127, 125, 100e3, False), (129, 9, 30e3, True), (100, 50, 100e3, False),
               (21, 200, 100e3, True), (16, 256, -100e3, False), (64, 181, 41e3, False), (21, 300, 100e3, True), (16, 512, 100e3, False),
-              (33, 257, -60e3, False)]
+              (33, 257, -60e3, False),
+              (16, 20, 0.0, True), (16, 83, 0.0, True), (21, 125, 0.0, False), (64, 100, 0.0, False), (127, 300, 0.0, True), (16, 9, 0.0, False)]   # (no shift: examples/sdr_rec.cc:42-58 tunes every mode to the centre)
 
 
 @pytest.mark.parametrize("hot", [True, False])
@@ -157,7 +158,7 @@ ANYD_CASES = [(21, 125, 100e3, True), (16, 62, 100e3, False), (21, 9, -60e3, Fal
 @pytest.mark.parametrize("order,decim,Fc,cu8", ANYD_CASES)
 def test_iqbb_any_decimation_long_calls_vs_oracle(ctx, orc, order, decim, Fc, cu8, epi, hot, monkeypatch):
     """The reference's own receivers decimate by 62 (examples/sdr_rec.cc:68, 16 taps) and 125 (examples/sdr_fm.cc:40, 21
-    taps on complex<uint8> input): plans of up to 129 taps with a shift and 9 <= D <= 512 run the hot kernel's any-D form
+    taps on complex<uint8> input): plans of up to 129 taps, shifted or not, with 9 <= D <= 512 run the hot kernel's any-D form
     on the interior tiles of a long call and the general any-D kernel on the border tiles (two launches, seam tiles
     written by both). Ragged long and short calls, state carried across them, against the oracle; `hot` = False: the
     general kernel alone (SDRHIP_IQBB_HOT=0)."""
@@ -166,6 +167,7 @@ def test_iqbb_any_decimation_long_calls_vs_oracle(ctx, orc, order, decim, Fc, cu
     FSr, C = 1e6, 3
     rng = np.random.default_rng(order * 1000 + decim)
     taps, lut, inc = orc.iqbb_design(abs(Fc), 12.5e3, FSr, order), orc.freqshift_lut_i16(), orc.freqshift_inc(Fc, FSr)
+    assert (inc == 0) == (Fc == 0.0)
     node = sa.IQBaseBandI16(ctx, taps, lut, inc, Fc < 0, decim, channels=C, max_in=70000, epilogue=epi)
     if cu8:
         node.set_input_format(sa.abi.IN_CU8)
