@@ -145,8 +145,8 @@ int sdrhip_iqbb_i16_path(sdrhip_iqbb_i16 *h, int *path);
  * ONE launch per call, "iqbb_hot_kernel": a persistent grid over the wave slices that touch no border of the call,
  * whose workgroups finish with the call's first and last slices, the state and the history roll (calls of fewer than
  * 3 tiles, about 6000 samples, run the general kernel "iqbb_i16_mfma_dma_kernel" / "iqbb_i16_mfma_kernel" instead).
- * Path 3 plans with a shift, up to 129 taps and 9 <= decim <= 512 (the reference's receivers: 16 taps / 62, 21 taps / 125,
- * examples/sdr_rec.cc:68, examples/sdr_fm.cc:40) run "iqbb_hot_anyd_kernel" on long calls — the same persistent
+ * Path 3 plans of up to 129 taps and 9 <= decim <= 512, shifted or not (the reference's receivers: 16 taps / 83 or / 20
+ * without a shift, 21 taps / 125 with one; examples/sdr_rec.cc:42-68, examples/sdr_fm.cc:40) run "iqbb_hot_anyd_kernel" on long calls — the same persistent
  * structure, cold slices included (with FM a second, tiny launch completes the slices' first outputs); other path 3
  * plans and short calls the general kernel "iqbb_i16_mfmag_kernel".
  * Tuning / test variables read at create time: SDRHIP_IQBB_HOT=0 (general kernels only), SDRHIP_IQBB_DMA=0 (round 1's
