@@ -237,7 +237,98 @@ struct DeemphArgs {
   const short *in; long in_stride; short *out; long out_stride;
   int N, C, alpha;
   short *avg;   // one per channel, updated in place (each channel has exactly one lane)
+  unsigned magic;   // floor(2^32 / alpha) + 1: trunc(m / alpha) = umulhi(m, magic) for m < 2^16 (alpha < 2^15)
 };
+
+// The recursion as a latency chain, nothing else: one lane walks one channel's row in registers — 16-byte loads, DE_PF chunks
+// of 8 samples in flight ahead of the arithmetic (a lane's loads are its own row: uncoalesced, but a buffer of demodulated
+// audio is a megabyte), the division by the node's constant alpha as one multiply-high, 16-byte stores. The LDS-tiled
+// kernel below (coalesced, but 2-byte loads by the 64 lanes that also do the arithmetic, an LDS round trip and a float
+// reciprocal per step) took 172 us for 1024 channels x 524 samples — twice the baseband kernel in front of it in the
+// reference's sdr_fm chain — where this one takes the chain's latency.
+constexpr int DE_PF = 8;
+// (branch-free, and without compare + select pairs: on gfx950 a v_cmp's SGPR result costs wait states before the select that
+// reads it, twice per step of a chain that is nothing but latency)
+__device__ __forceinline__ int deemph_step(int x, int &avg, int half, unsigned magic) {
+  const int d = (int)(short)(x - avg);                 // the int16 wrap of the difference
+  const int s = (d - 1) >> 31;                         // -1 for d <= 0 (the reference subtracts alpha / 2 then), else 0
+  const int n = d + half + (s & (-2 * half));          // d > 0 ? d + half : d - half
+  const int sn = n >> 31;
+  const unsigned m = (unsigned)((n ^ sn) - sn);        // |n| < 2^16
+  const int q = (int)__umulhi(m, magic);
+  avg = (int)(short)(avg + ((q ^ sn) - sn));           // trunc(n / alpha); ... and the int16 wrap of the average
+  return avg;
+}
+__global__ __launch_bounds__(64) void deemph_i16_seq_kernel(const DeemphArgs a) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= a.C) return;
+  const short *in = a.in + (long)c * a.in_stride;
+  short *out = a.out + (long)c * a.out_stride;
+  int avg = (int)a.avg[c];
+  const int half = a.alpha / 2;
+  const unsigned magic = a.magic;
+  // the row's samples before its first 16-byte boundary (0 .. 7, a lane's own count), one by one
+  const int head = min(a.N, (int)(((16u - (unsigned)(reinterpret_cast<uintptr_t>(in) & 15u)) & 15u) >> 1));
+  {
+    short hd[7];
+#pragma unroll
+    for (int j = 0; j < 7; j++) hd[j] = in[min(j, max(head - 1, 0))];   // (all loads first: one latency)
+#pragma unroll
+    for (int j = 0; j < 7; j++) if (j < head) out[j] = (short)deemph_step((int)hd[j], avg, half, magic);
+  }
+  const int nch = (a.N - head) >> 3;   // whole 16-byte chunks of 8 samples
+  const uint4 *in4 = reinterpret_cast<const uint4 *>(in + head);
+  short *o8 = out + head;
+  const bool out16 = (reinterpret_cast<uintptr_t>(o8) & 15u) == 0;   // (else eight 2-byte stores per chunk)
+  uint4 cur[DE_PF];
+  if (nch > 0) {
+#pragma unroll
+    for (int k = 0; k < DE_PF; k++) cur[k] = in4[min(k, nch - 1)];   // (clamped: a short row repeats its last chunk, unused)
+  }
+  for (int g = 0; g < nch; g += DE_PF) {
+    uint4 nxt[DE_PF];
+#pragma unroll
+    for (int k = 0; k < DE_PF; k++) nxt[k] = in4[min(g + DE_PF + k, nch - 1)];   // the next group, in flight during this one's arithmetic
+#pragma unroll
+    for (int k = 0; k < DE_PF; k++) {
+      if (g + k < nch) {
+        uint32_t w[4] = {cur[k].x, cur[k].y, cur[k].z, cur[k].w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int y0 = deemph_step((int)(short)(w[j] & 0xffffu), avg, half, magic);
+          const int y1 = deemph_step((int)(short)(w[j] >> 16), avg, half, magic);
+          w[j] = ((uint32_t)(uint16_t)y0) | ((uint32_t)(uint16_t)y1 << 16);
+        }
+        if (out16) reinterpret_cast<uint4 *>(o8)[g + k] = make_uint4(w[0], w[1], w[2], w[3]);
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; j++) { o8[8 * (g + k) + 2 * j] = (short)(w[j] & 0xffffu); o8[8 * (g + k) + 2 * j + 1] = (short)(w[j] >> 16); }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < DE_PF; k++) cur[k] = nxt[k];
+  }
+  const int done = head + 8 * nch, rem = a.N - done;   // the last samples (< 8): all loads first, then the chain
+  if (rem > 0) {
+    short tl[7];
+#pragma unroll
+    for (int j = 0; j < 7; j++) tl[j] = in[done + min(j, rem - 1)];
+#pragma unroll
+    for (int j = 0; j < 7; j++) if (j < rem) out[done + j] = (short)deemph_step((int)tl[j], avg, half, magic);
+  }
+  a.avg[c] = (short)avg;
+}
+
+// alpha = 1 (sample rates below about 11 kS/s: src/demod.hh:305-306 rounds 1 / (1 - exp(-1 / (Fs 75 us))) to 1): the
+// update is avg = x exactly — a copy, and the last sample as the state
+__global__ __launch_bounds__(256) void deemph_i16_copy_kernel(const DeemphArgs a) {
+  const int c = blockIdx.y;
+  const short *in = a.in + (long)c * a.in_stride;
+  short *out = a.out + (long)c * a.out_stride;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < a.N; i += gridDim.x * 256) out[i] = in[i];
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.avg[c] = in[a.N - 1];
+}
 
 __global__ __launch_bounds__(DE_CH) void deemph_i16_kernel(const DeemphArgs a) {
   __shared__ short tile[DE_CH * DE_LD];
@@ -351,7 +442,14 @@ struct sdrhip_deemph {
     DeemphArgs a;
     a.in = in_dev; a.in_stride = (long)in_stride; a.out = out_dev; a.out_stride = (long)out_stride;
     a.N = (int)N; a.C = C; a.alpha = alpha; a.avg = avg.p;
-    hipLaunchKernelGGL(deemph_i16_kernel, dim3((unsigned)ceil_div((size_t)C, (size_t)DE_CH)), dim3(DE_CH), 0, ctx->stream, a);
+    a.magic = (unsigned)((1ull << 32) / (unsigned)alpha) + 1u;   // (alpha = 1 never divides)
+    const bool tiled = getenv("SDRHIP_DEEMPH_TILED") != nullptr;   // (tests: the LDS-tiled kernel of rounds 1-2)
+    if (alpha == 1 && !tiled)
+      hipLaunchKernelGGL(deemph_i16_copy_kernel, dim3((unsigned)std::min<size_t>(ceil_div(N, (size_t)256), 64), C), dim3(256), 0, ctx->stream, a);
+    else if (!tiled)
+      hipLaunchKernelGGL(deemph_i16_seq_kernel, dim3((unsigned)ceil_div((size_t)C, (size_t)64)), dim3(64), 0, ctx->stream, a);
+    else
+      hipLaunchKernelGGL(deemph_i16_kernel, dim3((unsigned)ceil_div((size_t)C, (size_t)DE_CH)), dim3(DE_CH), 0, ctx->stream, a);
     SDRHIP_CHECK_HIP(hipGetLastError());
   }
 };

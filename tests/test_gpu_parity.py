@@ -4,6 +4,7 @@ max|y - y_ref| / max|y_ref| <= 1e-5 for float / FFT paths (BASELINE.json north_s
 Run with `pytest -m gpu` on an MI355X."""
 import os
 
+import ctypes
 import numpy as np
 import pytest
 
@@ -578,6 +579,54 @@ def test_fmdeemph_golden_and_batched(ctx, golden, orc, rate):
         got = de.process(z[:, lo:hi])
         for c in range(C):
             assert np.array_equal(got[c], refs[c].process(z[c, lo:hi]))
+
+
+@pytest.mark.parametrize("alpha", [1, 2, 4, 7, 100, 32767])
+def test_fmdeemph_every_kernel_vs_oracle(ctx, orc, alpha, monkeypatch):
+    """FMDeemph<int16_t>'s three kernels — the register-walking one, the copy (alpha = 1: the update is avg = x,
+    src/demod.hh:342-351 with the alpha of a sample rate below about 11 kS/s) and the LDS-tiled one of rounds 1-2
+    (SDRHIP_DEEMPH_TILED=1) — on device rows of every length and alignment class (odd row stride: every lane's row starts
+    at its own offset from a 16-byte boundary, input and output rows at different ones), state carried from call to call,
+    against the oracle's recursion with the same alpha."""
+    dev = torch.device("cuda:0")
+    C, ld = 70, 3289
+    rng = np.random.default_rng(alpha)
+
+    def ref_rows(x, avgs):
+        out = np.zeros_like(x)
+        for c in range(x.shape[0]):
+            o = np.zeros(x.shape[1], np.int16)
+            if x.shape[1]:
+                orc.lib().orc_fmdeemph_i16(orc._p(np.ascontiguousarray(x[c]), ctypes.c_int16), x.shape[1], alpha, orc._p(avgs[c], ctypes.c_int16), orc._p(o, ctypes.c_int16))
+            out[c] = o
+        return out
+
+    for tiled in (False, True):
+        if tiled:
+            monkeypatch.setenv("SDRHIP_DEEMPH_TILED", "1")
+        else:
+            monkeypatch.delenv("SDRHIP_DEEMPH_TILED", raising=False)
+        node = sa.FMDeemphI16(ctx, alpha, channels=C, max_in=ld)
+        avgs = [np.zeros(1, np.int16) for _ in range(C)]
+        xin = torch.zeros((C, ld), dtype=torch.int16, device=dev)
+        xout_flat = torch.zeros(C * (ld + 3) + 8, dtype=torch.int16, device=dev)
+        xout = xout_flat[5:5 + C * (ld + 3)].view(C, ld + 3)   # (another stride and base offset than the input's)
+        for n in (3276, 1, 7, 8, 524, 65, 0, 1000, 9, 16):
+            x = rng.integers(-32768, 32768, (C, n), dtype=np.int16)
+            xin[:, :n] = torch.from_numpy(x).to(dev)
+            torch.cuda.synchronize()
+            node.process_dev(xin.data_ptr(), n, ld, xout.data_ptr(), ld + 3)
+            ctx.synchronize()
+            assert np.array_equal(xout[:, :n].cpu().numpy(), ref_rows(x, avgs)), (alpha, tiled, n)
+        xal = torch.zeros((C, 3280), dtype=torch.int16, device=dev)   # 16-byte aligned rows on both sides: 16-byte stores
+        yal = torch.zeros((C, 3280), dtype=torch.int16, device=dev)
+        for n in (3276, 3):
+            x = rng.integers(-32768, 32768, (C, n), dtype=np.int16)
+            xal[:, :n] = torch.from_numpy(x).to(dev)
+            torch.cuda.synchronize()
+            node.process_dev(xal.data_ptr(), n, 3280, yal.data_ptr(), 3280)
+            ctx.synchronize()
+            assert np.array_equal(yal[:, :n].cpu().numpy(), ref_rows(x, avgs)), (alpha, tiled, n, "aligned")
 
 
 # ---- K1 at the BASELINE size: properties + sampled oracle comparison ------------------------------------
