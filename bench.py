@@ -51,6 +51,7 @@ def parse():
     p.add_argument("--workload", default="", help="default: iqbb_fm on one GPU, iqbb_usb with the gather (BASELINE config 5) on several")
     p.add_argument("--decim", type=int, default=8, help="iqbb_* workloads: decimation D (8 = the BASELINE configs)")
     p.add_argument("--fc", type=float, default=100e3, help="iqbb_* workloads: centre and filter frequency in Hz (0: no frequency shift, as examples/sdr_rec.cc tunes)")
+    p.add_argument("--deemph", action="store_true", help="iqbb_fm* workloads: FMDeemph<int16> behind the demodulator (examples/sdr_fm.cc:44-53), alpha from the output rate")
     p.add_argument("--order", type=int, default=127, help="iqbb_* workloads: FIR order (127 = the BASELINE configs)")
     p.add_argument("--batches", type=int, default=3, help="distinct input batches rotated through (defeats the 256 MiB L3)")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -232,10 +233,43 @@ def build_workload(a, wl, sa, torch, shard, ctx, dev, rank, nbuf_out):
             w.desc = "complex<uint8> -> AutoCast + " + w.desc
         w.key = "%s/order%d/d%d" % (wl, order, D) + ("" if a.fc == 100e3 else "/fc%g" % a.fc)
         w.n_valid = node.out_count(N)   # (every call after the first emits N / D outputs)
+        de_alpha = 0
+        if a.deemph and epi == sa.EPI_FM:
+            # the rest of the reference's FM receiver chain: the demodulated rows go through FMDeemph (a second launch; the
+            # recurrence is sequential per channel). The call's output count is known on the host (out_count).
+            de_alpha = sa.design_fmdeemph_alpha(FS / D)
+            de = sa.FMDeemphI16(ctx, de_alpha, channels=C, max_in=n_out)
+            w.mids = w.outs
+            w.outs = [torch.zeros((C, n_out), dtype=torch.int16, device=dev) for _ in range(nbuf_out)]
+
+            def run_chain(b, o):
+                k = node.process_dev(w.ins[b].data_ptr(), N, N, w.mids[o].data_ptr(), n_out)
+                de.process_dev(w.mids[o].data_ptr(), k, n_out, w.outs[o].data_ptr(), n_out)
+            w.run = run_chain
+            w.kernels = w.kernels + ["deemph_i16_copy_kernel" if de_alpha == 1 else "deemph_i16_seq_kernel"]
+            w.desc += " -> FMDeemph(alpha %d)" % de_alpha
+            w.key += "/deemph"
+            w.verify_needs_chan = True
 
         w.verify_needs_n0 = w.verify_needs_pre = True
 
-        def verify(prev, last, out, orc, n0=0, pre=None):
+        def check(out, r, orc, n_expect, chan, last_i):
+            if len(r) != n_expect:
+                return False
+            if not de_alpha:
+                return bool(np.array_equal(out[:len(r)], r))
+            # with FMDeemph: the demodulator's rows are the intermediate buffer; the filter's state before the last call is
+            # the last value it wrote in the call before (its output IS its running average, src/demod.hh FMDeemph)
+            if not np.array_equal(w.mids[last_i & 1][chan].cpu().numpy()[:len(r)], r):
+                return False
+            n_prev = (n0_of[0] - 1) // D - (n0_of[0] - N - 1) // D
+            d = orc.FMDeemphI16.__new__(orc.FMDeemphI16)
+            d.alpha, d.avg = de_alpha, w.outs[(last_i - 1) & 1][chan].cpu().numpy()[n_prev - 1:n_prev].copy()
+            return bool(np.array_equal(out[:len(r)], d.process(r)))
+        n0_of = [0]
+
+        def verify(prev, last, out, orc, n0=0, pre=None, chan=0, last_i=0):
+            n0_of[0] = n0
             # the state a call starts from (FIR history, open window, FM angle) depends on the previous buffer only;
             # LUT and decimator phases repeat every 32768 / D samples, so they are those of a stream's second call
             bb, fm = orc.IQBaseBandI16(taps_h, lut_h, inc, False, D), orc.FMDemodI16()
@@ -256,7 +290,7 @@ def build_workload(a, wl, sa, torch, shard, ctx, dev, rank, nbuf_out):
                     fm.process(r0)
                 r = bb.process(cast(last))
                 r = fm.process(r) if epi == sa.EPI_FM else orc.usb_i16(r)
-                return bool(np.array_equal(out[:len(r)], r)) and len(r) == (n0 + N - 1) // D - (n0 - 1) // D
+                return check(out, r, orc, (n0 + N - 1) // D - (n0 - 1) // D, chan, last_i)
             if order > N:
                 return None
             r0 = bb.process(cast(prev))
@@ -264,7 +298,7 @@ def build_workload(a, wl, sa, torch, shard, ctx, dev, rank, nbuf_out):
                 fm.process(r0)
             r = bb.process(cast(last))
             r = fm.process(r) if epi == sa.EPI_FM else orc.usb_i16(r)
-            return bool(np.array_equal(out[:len(r)], r)) and len(r) == N // D
+            return check(out, r, orc, N // D, chan, last_i)
         w.verify = verify
     elif wl == "bb_real_fm":   # the real-input BaseBand<int16_t> (2 bytes per sample in)
         taps_h = sa.design_bb_taps(100e3, 50e3, FS, order)
@@ -528,6 +562,8 @@ def main():
                     kw = {"n0": (calls - 1) * N} if getattr(w, "verify_needs_n0", False) else {}
                     if getattr(w, "verify_needs_pre", False) and calls >= 3:   # (the buffer before the previous one)
                         kw["pre"] = w.ins[(last_i - 2) % a.batches][c].cpu().numpy()
+                    if getattr(w, "verify_needs_chan", False):
+                        kw.update(chan=c, last_i=last_i)
                     oks.append(w.verify(prev, last, out, orc, **kw))
                 if all(o is None for o in oks):
                     verified = {"ok": None, "why": "this sample count / decimation is outside what the last-step check covers"}

@@ -320,6 +320,194 @@ __global__ __launch_bounds__(64) void deemph_i16_seq_kernel(const DeemphArgs a) 
   a.avg[c] = (short)avg;
 }
 
+// The same chain, cut in time. The recursion cannot be split exactly ahead of time — but it forgets: two runs over the same
+// samples from different averages never cross and close in (the update is monotone in the average, |difference| never
+// grows), and once they agree they agree for good. So P lanes share a channel: lane p owns the p-th segment of the row and
+// first runs over the `wc` chunks in front of it from a guessed average (the sample there), which leaves it — almost
+// always — with the exact state at its segment's start. "Almost" is then removed: after the pass, every lane compares the
+// state it started from with the final state of the lane before it (lane 0 started from the node's true state); a lane that
+// guessed wrong runs its segment again from the right state, until its average meets the value it had stored at the same
+// index (from there on the stored row is right) or the segment ends (then its final state changes and the lane after it
+// checks again). The result is the sequential recursion's, bit for bit, whatever the data; what the data decides is the
+// time: (n / P + 8 wc) steps when the guesses hold, at worst (constant rows sit inside the rounding dead zone and never
+// meet) one sequential pass on top.
+struct DeemphSpecArgs { DeemphArgs d; int lgP, Lc, wc; };
+__device__ __forceinline__ void deemph_chunk(uint32_t (&w)[4], int &avg, int half, unsigned magic) {
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int y0 = deemph_step((int)(short)(w[j] & 0xffffu), avg, half, magic);
+    const int y1 = deemph_step((int)(short)(w[j] >> 16), avg, half, magic);
+    w[j] = ((uint32_t)(uint16_t)y0) | ((uint32_t)(uint16_t)y1 << 16);
+  }
+}
+__device__ __forceinline__ void deemph_store(short *o8, bool out16, int id, const uint32_t (&w)[4]) {
+  if (out16) reinterpret_cast<uint4 *>(o8)[id] = make_uint4(w[0], w[1], w[2], w[3]);
+  else {
+#pragma unroll
+    for (int j = 0; j < 4; j++) { o8[8 * id + 2 * j] = (short)(w[j] & 0xffffu); o8[8 * id + 2 * j + 1] = (short)(w[j] >> 16); }
+  }
+}
+__global__ __launch_bounds__(256) void deemph_i16_spec_kernel(const DeemphSpecArgs sa) {
+  __shared__ int redo_from[128], redo_state[128];   // per channel of the workgroup (at most 128: P >= 2): where a given-up row resumes
+  const DeemphArgs &a = sa.d;
+  const int P = 1 << sa.lgP, Lc = sa.Lc;
+  const int lin = blockIdx.x * 256 + threadIdx.x;
+  const bool live = (lin >> sa.lgP) < a.C;
+  const int c = min(lin >> sa.lgP, a.C - 1), p = lin & (P - 1);   // (lanes beyond the last channel shadow it, without stores)
+  const short *in = a.in + (long)c * a.in_stride;
+  short *out = a.out + (long)c * a.out_stride;
+  const int half = a.alpha / 2;
+  const unsigned magic = a.magic;
+  const int head = min(a.N, (int)(((16u - (unsigned)(reinterpret_cast<uintptr_t>(in) & 15u)) & 15u) >> 1));
+  const int nch = (a.N - head) >> 3;
+  const uint4 *in4 = reinterpret_cast<const uint4 *>(in + head);
+  short *o8 = out + head;
+  const bool out16 = (reinterpret_cast<uintptr_t>(o8) & 15u) == 0;
+  const int c0 = p * Lc;                          // the lane's first chunk; its segment: [c0, min(c0 + Lc, nch))
+  int avg;
+  if (p == 0) {                                   // the channel's first lane: the true state, and the samples before the first chunk
+    avg = (int)a.avg[c];
+    short hd[7];
+#pragma unroll
+    for (int j = 0; j < 7; j++) hd[j] = in[min(j, max(head - 1, 0))];
+#pragma unroll
+    for (int j = 0; j < 7; j++) if (j < head) { const int y = deemph_step((int)hd[j], avg, half, magic); if (live) out[j] = (short)y; }
+  } else avg = (int)(in + head)[8 * min(max(c0 - sa.wc, 0), max(nch - 1, 0))];   // the guess: the sample the run-in starts at
+  int s = avg, f;
+  uint4 cur[DE_PF];
+#pragma unroll
+  for (int k = 0; k < DE_PF; k++) cur[k] = in4[min(max(c0 - sa.wc + k, 0), max(nch - 1, 0))];
+  for (int g = -sa.wc; g < Lc; g += DE_PF) {      // (wc is a multiple of DE_PF: the segment starts at a group boundary)
+    if (g == 0) s = avg;
+    uint4 nxt[DE_PF];
+#pragma unroll
+    for (int k = 0; k < DE_PF; k++) nxt[k] = in4[min(max(c0 + g + DE_PF + k, 0), max(nch - 1, 0))];
+#pragma unroll
+    for (int k = 0; k < DE_PF; k++) {
+      const int id = c0 + g + k;
+      if (id >= 0 && id < nch && g + k < Lc && (p > 0 || g >= 0)) {
+        uint32_t w[4] = {cur[k].x, cur[k].y, cur[k].z, cur[k].w};
+        deemph_chunk(w, avg, half, magic);
+        if (g >= 0 && live) deemph_store(o8, out16, id, w);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < DE_PF; k++) cur[k] = nxt[k];
+  }
+  f = avg;
+  // the check: P - 1 rounds at most (a wrong state can travel one lane per round)
+  bool given_up = false;
+  for (int it = 1; it < P; it++) {
+    const int pf = __shfl_up(f, 1, 64);
+    const bool need = !given_up && p > 0 && pf != s;
+    if (!__any(need)) break;
+    bool unmet = false;
+    if (need) {
+      s = pf;
+      int av = pf;
+      bool met = false;
+      const int hi = min(c0 + Lc, nch);
+      // (loads a group ahead, as in the pass above: a row that never meets — a constant one — costs the sequential chain, not
+      // the chain plus a load latency per chunk)
+      uint4 cu[DE_PF];
+      short ol[DE_PF];
+#pragma unroll
+      for (int k = 0; k < DE_PF; k++) { const int id = min(c0 + k, nch - 1); cu[k] = in4[id]; ol[k] = o8[8 * id + 7]; }
+      for (int g = c0; g < hi && !met; g += DE_PF) {
+        uint4 nx[DE_PF];
+        short no[DE_PF];
+#pragma unroll
+        for (int k = 0; k < DE_PF; k++) { const int id = min(g + DE_PF + k, nch - 1); nx[k] = in4[id]; no[k] = o8[8 * id + 7]; }
+#pragma unroll
+        for (int k = 0; k < DE_PF; k++) {
+          if (g + k < hi && !met) {
+            uint32_t w[4] = {cu[k].x, cu[k].y, cu[k].z, cu[k].w};
+            deemph_chunk(w, av, half, magic);
+            if (live) deemph_store(o8, out16, g + k, w);
+            met = av == (int)ol[k];   // the value stored here by the run from the wrong state: from now on the two are one
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < DE_PF; k++) { cu[k] = nx[k]; ol[k] = no[k]; }
+      }
+      if (!met) { f = av; unmet = true; }
+    }
+    // a lane that ran to its segment's end without meeting (a run-in AND a segment of 16 alpha samples each were not enough):
+    // this row does not forget — a constant stretch: every run stops inside the rounding dead zone, each on its own value —
+    // and the rounds would hand the right state on one lane at a time, each with its load latencies. After round `it` the
+    // lanes 0 .. it are exact (each was compared with an exact predecessor): the row is walked from lane it's end, alone.
+    const unsigned long long um = __ballot(unmet) >> (threadIdx.x & 63 & ~(P - 1));
+    if (!given_up && (um & ((P == 64) ? ~0ull : ((1ull << P) - 1ull))) != 0) {
+      given_up = true;
+      if (p == it) { redo_from[threadIdx.x >> sa.lgP] = (it + 1) * Lc; redo_state[threadIdx.x >> sa.lgP] = f; }
+    }
+  }
+  if (p == P - 1 && !given_up) {                  // the last samples (< 8) and the state
+    redo_from[threadIdx.x >> sa.lgP] = -1;
+    avg = f;
+    const int done = head + 8 * nch, rem = a.N - done;
+    if (rem > 0) {
+      short tl[7];
+#pragma unroll
+      for (int j = 0; j < 7; j++) tl[j] = in[done + min(j, rem - 1)];
+#pragma unroll
+      for (int j = 0; j < 7; j++) if (j < rem) { const int y = deemph_step((int)tl[j], avg, half, magic); if (live) out[done + j] = (short)y; }
+    }
+    if (live) a.avg[c] = (short)avg;
+  }
+  // The rows that were given up, one per LANE of the workgroup's first wave: a wave's chain keeps its SIMD's issue port busy
+  // whatever the number of active lanes (about 14 instructions of 4 cycles per step), so the walkers are packed — left in
+  // their own waves (one or two active lanes each, several waves to a SIMD) a constant batch took twice the one-lane kernel's
+  // time; like this it takes that time plus the first pass.
+  const int teams = 256 >> sa.lgP;
+  __syncthreads();
+  bool any_redo = false;
+  for (int t = 0; t < teams; t++) any_redo |= redo_from[t] >= 0;
+  if (any_redo) {   // (workgroup-uniform) every lane's stores to the rows are done before a row is written again — by another wave
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    __syncthreads();
+  }
+  if (threadIdx.x < teams && redo_from[threadIdx.x] >= 0 && blockIdx.x * teams + threadIdx.x < a.C) {
+    const int cw = blockIdx.x * teams + threadIdx.x;
+    const short *inw = a.in + (long)cw * a.in_stride;
+    short *outw = a.out + (long)cw * a.out_stride;
+    const int hw = min(a.N, (int)(((16u - (unsigned)(reinterpret_cast<uintptr_t>(inw) & 15u)) & 15u) >> 1));
+    const int nw = (a.N - hw) >> 3;
+    const uint4 *i4 = reinterpret_cast<const uint4 *>(inw + hw);
+    short *ow = outw + hw;
+    const bool o16 = (reinterpret_cast<uintptr_t>(ow) & 15u) == 0;
+    int av = redo_state[threadIdx.x];
+    const int from = redo_from[threadIdx.x];
+    uint4 cu[DE_PF];
+#pragma unroll
+    for (int k = 0; k < DE_PF; k++) cu[k] = i4[min(from + k, nw - 1)];
+    for (int g = from; g < nw; g += DE_PF) {
+      uint4 nx[DE_PF];
+#pragma unroll
+      for (int k = 0; k < DE_PF; k++) nx[k] = i4[min(g + DE_PF + k, nw - 1)];
+#pragma unroll
+      for (int k = 0; k < DE_PF; k++) {
+        if (g + k < nw) {
+          uint32_t w[4] = {cu[k].x, cu[k].y, cu[k].z, cu[k].w};
+          deemph_chunk(w, av, half, magic);
+          deemph_store(ow, o16, g + k, w);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < DE_PF; k++) cu[k] = nx[k];
+    }
+    const int done = hw + 8 * nw, rem = a.N - done;
+    if (rem > 0) {
+      short tl[7];
+#pragma unroll
+      for (int j = 0; j < 7; j++) tl[j] = inw[done + min(j, rem - 1)];
+#pragma unroll
+      for (int j = 0; j < 7; j++) if (j < rem) outw[done + j] = (short)deemph_step((int)tl[j], av, half, magic);
+    }
+    a.avg[cw] = (short)av;
+  }
+}
+
 // alpha = 1 (sample rates below about 11 kS/s: src/demod.hh:305-306 rounds 1 / (1 - exp(-1 / (Fs 75 us))) to 1): the
 // update is avg = x exactly — a copy, and the last sample as the state
 __global__ __launch_bounds__(256) void deemph_i16_copy_kernel(const DeemphArgs a) {
@@ -446,9 +634,24 @@ struct sdrhip_deemph {
     const bool tiled = getenv("SDRHIP_DEEMPH_TILED") != nullptr;   // (tests: the LDS-tiled kernel of rounds 1-2)
     if (alpha == 1 && !tiled)
       hipLaunchKernelGGL(deemph_i16_copy_kernel, dim3((unsigned)std::min<size_t>(ceil_div(N, (size_t)256), 64), C), dim3(256), 0, ctx->stream, a);
-    else if (!tiled)
-      hipLaunchKernelGGL(deemph_i16_seq_kernel, dim3((unsigned)ceil_div((size_t)C, (size_t)64)), dim3(64), 0, ctx->stream, a);
-    else
+    else if (!tiled) {
+      // long rows of a filter that forgets fast: P lanes per channel (deemph_i16_spec_kernel). The run-in is 16 alpha
+      // samples (measured on noise-like rows: two runs meet within about 12 alpha), in whole groups of 64; P is the largest
+      // of 32 … 4 whose segments are at least as long as the run-in
+      const char *ev = getenv("SDRHIP_DEEMPH_SPEC");   // (tests / timing: 0 = the one-lane kernel, else P)
+      int lgP = 0;
+      const char *ew = getenv("SDRHIP_DEEMPH_WC");     // (tests: the run-in in groups of 64 samples; 0: every guess is checked cold)
+      const int wc = (ew ? atoi(ew) : (int)ceil_div((size_t)16 * alpha, (size_t)64)) * DE_PF, n8 = (int)(N / 8);
+      if (alpha <= 16 && !(ev && atoi(ev) == 0))
+        for (int l = 5; l >= 2 && !lgP; l--) if ((n8 + (1 << l) - 1) >> l >= wc) lgP = l;
+      if (ev && atoi(ev) > 1 && n8 >= atoi(ev)) { lgP = 0; while ((2 << lgP) <= atoi(ev) && lgP < 6) lgP++; }
+      if (lgP) {
+        DeemphSpecArgs sa;
+        sa.d = a; sa.lgP = lgP; sa.Lc = (n8 + (1 << lgP) - 1) >> lgP; sa.wc = wc;
+        hipLaunchKernelGGL(deemph_i16_spec_kernel, dim3((unsigned)ceil_div((size_t)C << lgP, (size_t)256)), dim3(256), 0, ctx->stream, sa);
+      } else
+        hipLaunchKernelGGL(deemph_i16_seq_kernel, dim3((unsigned)ceil_div((size_t)C, (size_t)64)), dim3(64), 0, ctx->stream, a);
+    } else
       hipLaunchKernelGGL(deemph_i16_kernel, dim3((unsigned)ceil_div((size_t)C, (size_t)DE_CH)), dim3(DE_CH), 0, ctx->stream, a);
     SDRHIP_CHECK_HIP(hipGetLastError());
   }

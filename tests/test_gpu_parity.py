@@ -151,7 +151,8 @@ ANYD_CASES = [(21, 125, 100e3, True), (16, 62, 100e3, False), (21, 9, -60e3, Fal
               (64, 20, 100e3, False), (65, 125, -100e3, True), (127, 125, 100e3, False), (129, 9, 30e3, True), (100, 50, 100e3, False),
               (21, 200, 100e3, True), (16, 256, -100e3, False), (64, 181, 41e3, False), (21, 300, 100e3, True), (16, 512, 100e3, False),
               (33, 257, -60e3, False),
-              (16, 20, 0.0, True), (16, 83, 0.0, True), (21, 125, 0.0, False), (64, 100, 0.0, False), (127, 300, 0.0, True), (16, 9, 0.0, False)]   # (no shift: examples/sdr_rec.cc:42-58 tunes every mode to the centre)
+              (16, 20, 0.0, True), (16, 83, 0.0, True), (21, 125, 0.0, False), (64, 100, 0.0, False), (127, 300, 0.0, True), (16, 9, 0.0, False),
+              (21, 45, 0.0, True)]   # (no shift: examples/sdr_rec.cc:42-58 tunes every mode to the centre; 21 taps / 45: examples/sdr_pocsag.cc:117 and sdr_ax25.cc:117 behind a 1 MS/s RTL source)
 
 
 @pytest.mark.parametrize("hot", [True, False])
@@ -579,6 +580,60 @@ def test_fmdeemph_golden_and_batched(ctx, golden, orc, rate):
         got = de.process(z[:, lo:hi])
         for c in range(C):
             assert np.array_equal(got[c], refs[c].process(z[c, lo:hi]))
+
+
+@pytest.mark.parametrize("data", ["noise", "fullscale", "constant", "steps", "quiet"])
+@pytest.mark.parametrize("alpha,P,wc", [(2, None, None), (4, None, None), (10, None, None), (16, None, None), (4, 32, 0), (10, 8, 0), (10, 32, 1),
+                                        (100, 16, 0), (100, 4, 2), (3, 2, 0), (32767, 8, 1), (2, 64, 0), (5, 64, 1)])
+def test_fmdeemph_segmented_kernel_vs_oracle(ctx, orc, alpha, P, wc, data, monkeypatch):
+    """FMDeemph<int16_t> with P lanes per channel (deemph_i16_spec_kernel): every lane but a channel's first starts its
+    segment from a state it GUESSED by running over the samples in front of it; the kernel then checks every guess against
+    the final state of the lane before and repeats what was wrong. Whatever the guesses are worth, the rows must be the
+    sequential recursion's (src/demod.hh:342-351), bit for bit: rows that forget fast (noise), rows whose runs meet late
+    (full-scale data wraps the int16 difference), rows that NEVER meet (constant rows and long steps sit inside the rounding
+    dead zone: every lane repeats its whole segment, and its successor after it), with the default run-in, with none at all
+    (SDRHIP_DEEMPH_WC=0: the guess is the segment's first sample) and with forced lane counts; unaligned rows, ragged call
+    lengths, state carried across calls (short calls between the long ones run the one-lane kernel on the same state)."""
+    dev = torch.device("cuda:0")
+    C, ld = 37, 9001
+    rng = np.random.default_rng(alpha * 7 + (P or 0))
+    for k, v in (("SDRHIP_DEEMPH_SPEC", P), ("SDRHIP_DEEMPH_WC", wc)):
+        if v is None:
+            monkeypatch.delenv(k, raising=False)
+        else:
+            monkeypatch.setenv(k, str(v))
+    monkeypatch.delenv("SDRHIP_DEEMPH_TILED", raising=False)
+
+    def make(n):
+        if data == "noise":
+            return (3000 * np.sin(np.arange(n) * 0.01)[None, :] + rng.normal(0, 200, (C, n))).astype(np.int16)
+        if data == "fullscale":
+            return rng.integers(-32768, 32768, (C, n), dtype=np.int16)
+        if data == "constant":
+            return np.repeat(rng.integers(-32768, 32768, (C, 1), dtype=np.int16), n, axis=1)
+        if data == "quiet":
+            return rng.integers(-2, 3, (C, n)).astype(np.int16)
+        x = np.repeat(rng.integers(-20000, 20000, (C, n // 700 + 1)), 700, axis=1)[:, :n]   # long plateaus, sudden steps
+        return x.astype(np.int16)
+
+    node = sa.FMDeemphI16(ctx, alpha, channels=C, max_in=ld)
+    avgs = [np.zeros(1, np.int16) for _ in range(C)]
+    xin = torch.zeros((C, ld), dtype=torch.int16, device=dev)
+    xout_flat = torch.zeros(C * (ld + 5) + 8, dtype=torch.int16, device=dev)
+    xout = xout_flat[3:3 + C * (ld + 5)].view(C, ld + 5)
+    for n in (9001, 3276, 40, 8192, 1, 2100, 524, 9000):
+        x = make(n)
+        xin[:, :n] = torch.from_numpy(x).to(dev)
+        torch.cuda.synchronize()
+        node.process_dev(xin.data_ptr(), n, ld, xout.data_ptr(), ld + 5)
+        ctx.synchronize()
+        want = np.zeros_like(x)
+        for c in range(C):
+            o = np.zeros(n, np.int16)
+            orc.lib().orc_fmdeemph_i16(orc._p(np.ascontiguousarray(x[c]), ctypes.c_int16), n, alpha, orc._p(avgs[c], ctypes.c_int16), orc._p(o, ctypes.c_int16))
+            want[c] = o
+        got = xout[:, :n].cpu().numpy()
+        assert np.array_equal(got, want), (alpha, P, wc, data, n, np.argwhere(got != want)[:4])
 
 
 @pytest.mark.parametrize("alpha", [1, 2, 4, 7, 100, 32767])
