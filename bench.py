@@ -246,7 +246,7 @@ def build_workload(a, wl, sa, torch, shard, ctx, dev, rank, nbuf_out):
                 k = node.process_dev(w.ins[b].data_ptr(), N, N, w.mids[o].data_ptr(), n_out)
                 de.process_dev(w.mids[o].data_ptr(), k, n_out, w.outs[o].data_ptr(), n_out)
             w.run = run_chain
-            w.kernels = w.kernels + ["deemph_i16_copy_kernel" if de_alpha == 1 else "deemph_i16_seq_kernel"]
+            w.kernels = w.kernels + de.kernel_names(node.out_count(N))
             w.desc += " -> FMDeemph(alpha %d)" % de_alpha
             w.key += "/deemph"
             w.verify_needs_chan = True

@@ -108,6 +108,7 @@ def lib():
             "sdrhip_deemph_i16_create": (C.c_int, [vp, C.c_int, C.c_int, sz, pvp]),
             "sdrhip_deemph_i16_process": (C.c_int, [vp, vp, sz, sz, vp, sz]),
             "sdrhip_deemph_i16_process_dev": (C.c_int, [vp, vp, sz, sz, vp, sz]),
+            "sdrhip_deemph_i16_kernel_names": (C.c_int, [vp, sz, C.c_char_p, sz]),
             "sdrhip_deemph_i16_reset": (C.c_int, [vp]),
             "sdrhip_deemph_i16_destroy": (C.c_int, [vp]),
             "sdrhip_iqbb_i16_set_input_format": (C.c_int, [vp, C.c_int]),

@@ -624,6 +624,24 @@ struct sdrhip_deemph {
   size_t max_in = 0;
   DevBuf<short> avg;
   DevBuf<short> stage_in, stage_out;
+  // which kernel a call of N samples per channel runs: 0 copy (alpha = 1), 1 one lane per channel, 2 P = 2^lgP lanes per
+  // channel (long rows of a filter that forgets fast: the run-in is 16 alpha samples — measured on noise-like rows, two
+  // runs meet within about 12 alpha — in whole groups of 64; P is the largest of 32 … 4 whose segments are at least as
+  // long as the run-in), 3 the LDS-tiled kernel of rounds 1-2 (SDRHIP_DEEMPH_TILED, tests)
+  int plan(size_t N, int *lgP_out, int *wc_out) const {
+    if (getenv("SDRHIP_DEEMPH_TILED")) return 3;
+    if (alpha == 1) return 0;
+    const char *ev = getenv("SDRHIP_DEEMPH_SPEC");   // (tests / timing: 0 = the one-lane kernel, else P)
+    const char *ew = getenv("SDRHIP_DEEMPH_WC");     // (tests: the run-in in groups of 64 samples; 0: every guess is checked cold)
+    int lgP = 0;
+    const int wc = (ew ? atoi(ew) : (int)ceil_div((size_t)16 * alpha, (size_t)64)) * DE_PF, n8 = (int)(N / 8);
+    if (alpha <= 16 && !(ev && atoi(ev) == 0))
+      for (int l = 5; l >= 2 && !lgP; l--) if ((n8 + (1 << l) - 1) >> l >= wc) lgP = l;
+    if (ev && atoi(ev) > 1 && n8 >= atoi(ev)) { lgP = 0; while ((2 << lgP) <= atoi(ev) && lgP < 6) lgP++; }
+    if (lgP_out) *lgP_out = lgP;
+    if (wc_out) *wc_out = wc;
+    return lgP ? 2 : 1;
+  }
   void launch(const short *in_dev, size_t N, size_t in_stride, short *out_dev, size_t out_stride) {
     ctx->use();
     if (N == 0) return;
@@ -631,27 +649,17 @@ struct sdrhip_deemph {
     a.in = in_dev; a.in_stride = (long)in_stride; a.out = out_dev; a.out_stride = (long)out_stride;
     a.N = (int)N; a.C = C; a.alpha = alpha; a.avg = avg.p;
     a.magic = (unsigned)((1ull << 32) / (unsigned)alpha) + 1u;   // (alpha = 1 never divides)
-    const bool tiled = getenv("SDRHIP_DEEMPH_TILED") != nullptr;   // (tests: the LDS-tiled kernel of rounds 1-2)
-    if (alpha == 1 && !tiled)
+    int lgP = 0, wc = 0;
+    const int k = plan(N, &lgP, &wc);
+    if (k == 0)
       hipLaunchKernelGGL(deemph_i16_copy_kernel, dim3((unsigned)std::min<size_t>(ceil_div(N, (size_t)256), 64), C), dim3(256), 0, ctx->stream, a);
-    else if (!tiled) {
-      // long rows of a filter that forgets fast: P lanes per channel (deemph_i16_spec_kernel). The run-in is 16 alpha
-      // samples (measured on noise-like rows: two runs meet within about 12 alpha), in whole groups of 64; P is the largest
-      // of 32 … 4 whose segments are at least as long as the run-in
-      const char *ev = getenv("SDRHIP_DEEMPH_SPEC");   // (tests / timing: 0 = the one-lane kernel, else P)
-      int lgP = 0;
-      const char *ew = getenv("SDRHIP_DEEMPH_WC");     // (tests: the run-in in groups of 64 samples; 0: every guess is checked cold)
-      const int wc = (ew ? atoi(ew) : (int)ceil_div((size_t)16 * alpha, (size_t)64)) * DE_PF, n8 = (int)(N / 8);
-      if (alpha <= 16 && !(ev && atoi(ev) == 0))
-        for (int l = 5; l >= 2 && !lgP; l--) if ((n8 + (1 << l) - 1) >> l >= wc) lgP = l;
-      if (ev && atoi(ev) > 1 && n8 >= atoi(ev)) { lgP = 0; while ((2 << lgP) <= atoi(ev) && lgP < 6) lgP++; }
-      if (lgP) {
-        DeemphSpecArgs sa;
-        sa.d = a; sa.lgP = lgP; sa.Lc = (n8 + (1 << lgP) - 1) >> lgP; sa.wc = wc;
-        hipLaunchKernelGGL(deemph_i16_spec_kernel, dim3((unsigned)ceil_div((size_t)C << lgP, (size_t)256)), dim3(256), 0, ctx->stream, sa);
-      } else
-        hipLaunchKernelGGL(deemph_i16_seq_kernel, dim3((unsigned)ceil_div((size_t)C, (size_t)64)), dim3(64), 0, ctx->stream, a);
-    } else
+    else if (k == 2) {
+      DeemphSpecArgs sa;
+      sa.d = a; sa.lgP = lgP; sa.Lc = ((int)(N / 8) + (1 << lgP) - 1) >> lgP; sa.wc = wc;
+      hipLaunchKernelGGL(deemph_i16_spec_kernel, dim3((unsigned)ceil_div((size_t)C << lgP, (size_t)256)), dim3(256), 0, ctx->stream, sa);
+    } else if (k == 1)
+      hipLaunchKernelGGL(deemph_i16_seq_kernel, dim3((unsigned)ceil_div((size_t)C, (size_t)64)), dim3(64), 0, ctx->stream, a);
+    else
       hipLaunchKernelGGL(deemph_i16_kernel, dim3((unsigned)ceil_div((size_t)C, (size_t)DE_CH)), dim3(DE_CH), 0, ctx->stream, a);
     SDRHIP_CHECK_HIP(hipGetLastError());
   }
@@ -790,6 +798,14 @@ int sdrhip_deemph_i16_process(sdrhip_deemph *h, const int16_t *in_host, size_t n
     h->launch(h->stage_in.p, n, n, h->stage_out.p, n);
     copy_d2h_rows(h->ctx, out_host, out_stride * 2, h->stage_out.p, n * 2, n * 2, h->C);
     SDRHIP_CHECK_HIP(hipStreamSynchronize(h->ctx->stream));
+  });
+}
+
+int sdrhip_deemph_i16_kernel_names(sdrhip_deemph *h, size_t n, char *buf, size_t len) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h && buf && len, SDRHIP_E_INVALID, "NULL argument");
+    static const char *const nm[4] = {"deemph_i16_copy_kernel", "deemph_i16_seq_kernel", "deemph_i16_spec_kernel", "deemph_i16_kernel"};
+    snprintf(buf, len, "%s", nm[h->plan(n ? n : h->max_in, nullptr, nullptr)]);
   });
 }
 

@@ -486,6 +486,12 @@ class FMDeemphI16(_Node):
         check(abi.lib().sdrhip_deemph_i16_process(self._h, _ptr(x), n, n, _ptr(out), n))
         return out
 
+    def kernel_names(self, n=0):
+        """The kernel a call of n samples per channel runs (0: max_in)."""
+        b = C.create_string_buffer(256)
+        check(abi.lib().sdrhip_deemph_i16_kernel_names(self._h, n, b, 256))
+        return b.value.decode().split(",")
+
     def process_dev(self, in_ptr, n, in_stride, out_ptr, out_stride):
         check(abi.lib().sdrhip_deemph_i16_process_dev(self._h, C.c_void_p(in_ptr), n, in_stride, C.c_void_p(out_ptr), out_stride))
 

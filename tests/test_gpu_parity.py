@@ -617,6 +617,8 @@ def test_fmdeemph_segmented_kernel_vs_oracle(ctx, orc, alpha, P, wc, data, monke
         return x.astype(np.int16)
 
     node = sa.FMDeemphI16(ctx, alpha, channels=C, max_in=ld)
+    if P is None:
+        assert node.kernel_names() == node.kernel_names(9001) == ["deemph_i16_spec_kernel"] and node.kernel_names(40) == ["deemph_i16_seq_kernel"]
     avgs = [np.zeros(1, np.int16) for _ in range(C)]
     xin = torch.zeros((C, ld), dtype=torch.int16, device=dev)
     xout_flat = torch.zeros(C * (ld + 5) + 8, dtype=torch.int16, device=dev)

@@ -15,7 +15,7 @@ tag = sys.argv[1]
 dst = sys.argv[2] if len(sys.argv) > 2 else "profiles"   # (on the GPU box: a directory under gpurun_out/, copied into profiles/ afterwards)
 src = os.path.join("gpurun_out", "prof_" + tag)
 os.makedirs(dst, exist_ok=True)
-ours = ("iqbb", "bb_real", "fir_", "fftconv", "demod_", "subsample", "freqshift", "hist_roll", "fft_c2c")
+ours = ("iqbb", "bb_real", "fir_", "fftconv", "demod_", "deemph_", "subsample", "freqshift", "hist_roll", "fft_c2c")
 
 stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
 rows = []
