@@ -638,6 +638,25 @@ def test_fmdeemph_segmented_kernel_vs_oracle(ctx, orc, alpha, P, wc, data, monke
         assert np.array_equal(got, want), (alpha, P, wc, data, n, np.argwhere(got != want)[:4])
 
 
+@pytest.mark.parametrize("C", [1, 2, 300])
+@pytest.mark.parametrize("data", ["noise", "constant"])
+def test_fmdeemph_segmented_kernel_channel_counts(ctx, orc, C, data):
+    """... one channel (the drop-in node's case: one workgroup, most of its lanes shadowing the last channel without
+    stores), two, and more channels than one workgroup's 8 … 64; through the HOST entry point (staging buffers), rows of a
+    call length that leaves a ragged last segment and a tail."""
+    alpha, rng = 4, np.random.default_rng(C)
+    node = sa.FMDeemphI16(ctx, alpha, channels=C, max_in=5003)
+    assert node.kernel_names(5003) == ["deemph_i16_spec_kernel"]
+    avgs = [np.zeros(1, np.int16) for _ in range(C)]
+    for n in (5003, 4096, 700, 5000):
+        x = (rng.normal(0, 500, (C, n)) if data == "noise" else np.repeat(rng.integers(-3000, 3000, (C, 1)), n, axis=1)).astype(np.int16)
+        got = node.process(x)
+        for c in range(C):
+            o = np.zeros(n, np.int16)
+            orc.lib().orc_fmdeemph_i16(orc._p(np.ascontiguousarray(x[c]), ctypes.c_int16), n, alpha, orc._p(avgs[c], ctypes.c_int16), orc._p(o, ctypes.c_int16))
+            assert np.array_equal(got[c], o), (C, data, n, c)
+
+
 @pytest.mark.parametrize("alpha", [1, 2, 4, 7, 100, 32767])
 def test_fmdeemph_every_kernel_vs_oracle(ctx, orc, alpha, monkeypatch):
     """FMDeemph<int16_t>'s three kernels — the register-walking one, the copy (alpha = 1: the update is avg = x,
