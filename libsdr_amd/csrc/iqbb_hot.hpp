@@ -448,9 +448,15 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
         // D / lpg rounds in which every lane of a team has an element (a scalar loop: no per-lane bounds), then one round
         // for the D % lpg lanes that have one more; the lanes beyond the GS-th team read the wave's last dword and drop it
         const int kk = min(k, GS - 1);
+#ifdef K1_ABL_ODDSTRIDE   // (timing only: the teams' bank conflicts gone, wrong results)
+        const unsigned *gp = gsc + min(kk * (DD | 1), 512 - DD) + t;
+        const int nfull = DD >> lsh;
+        const unsigned *gpy = gsy + min(kk * (DD | 1), 512 - DD) + t;
+#else
         const unsigned *gp = gsc + kk * DD + t;
         const int nfull = DD >> lsh;
         const unsigned *gpy = gsy + kk * DD + t;
+#endif
         for (int i = 0; i < nfull; i++) {
           const unsigned v = gp[i << lsh];
           if (ROT) {

@@ -3,7 +3,7 @@
 settings) gets its own plan over the SAME resident input batches; timing rounds are interleaved (variant A, B, C, A, B,
 C, ...) so that clock drift and box-to-box differences cancel. Reports median / min ms per launch per variant.
 
-usage: tools/abk1.py [--order 127] [--epi fm|usb|am|none] [--cu8|--real] [--decim 8] [--channels 1024] [--samples 65536] [--rounds 7]
+usage: tools/abk1.py [--order 127] [--epi fm|usb|am|none] [--cu8|--real] [--decim 8] [--fc 100e3] [--channels 1024] [--samples 65536] [--rounds 7]
                      [--launches 200] name=libsdr_amd/libsdrhip_x.so[@ENV=VAL[,ENV=VAL]] ...
 """
 import argparse
@@ -40,6 +40,7 @@ def main():
     p.add_argument("--epi", default="fm")
     p.add_argument("--cu8", action="store_true")
     p.add_argument("--decim", type=int, default=8)
+    p.add_argument("--fc", type=float, default=100e3, help="centre frequency (0: no shift)")
     p.add_argument("--real", action="store_true", help="the real-input BaseBand<int16> (sdrhip_bb_i16_create)")
     p.add_argument("--channels", type=int, default=1024)
     p.add_argument("--samples", type=int, default=65536)
@@ -51,9 +52,9 @@ def main():
     Cn, N = a.channels, a.samples
     dev = torch.device("cuda", 0)
     stream = torch.cuda.Stream(device=dev)
-    taps = sa.design_bb_taps(100e3, 50e3, FS, a.order) if a.real else sa.design_iqbb_taps(100e3, 50e3, FS, a.order)
+    taps = sa.design_bb_taps(100e3, 50e3, FS, a.order) if a.real else sa.design_iqbb_taps(a.fc, 50e3, FS, a.order)
     lut = sa.design_freqshift_lut_i16()
-    inc = sa.design_freqshift_inc(100e3, FS)
+    inc = sa.design_freqshift_inc(a.fc, FS)
     epi = {"none": 0, "fm": 1, "am": 2, "usb": 3}[a.epi]
     with torch.cuda.stream(stream):
         if a.real:
