@@ -409,6 +409,9 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       }
     }
 #endif
+#ifdef K1_ABL_NOTEAM   // (timing only: no LDS round trip, no team sums)
+    if (DG) { for (int j = 0; j < 8; j++) { sum.x ^= (int)pk[j]; if (!ROT) sum.y ^= (int)pky[j]; } } else
+#endif
     if (DG) {
       // the wave's 512 rotated samples in stream order (lane (n, h) holds the pairs 16n + 2h + 4jj + {0, 1}), then teams of
       // `lpg` lanes (a power of two <= 16, about 64 / GS) sum one group each: strided partial sums, then a shift tree
