@@ -49,7 +49,11 @@ constexpr int hot_lds_cap(int NW) { return NW == 4 ? 40960 : NW == 8 ? 81920 : 1
 constexpr bool hot_wide(int S, int NH, int in, int NW, int extra = 0) { return hot_lds_bytes(S, NH, in, NW, true) + extra <= hot_lds_cap(NW); }
 // the any-D form's additions to a workgroup's LDS: parked group sums, and the rotated samples where the window buffer is too small
 // (rot = false, plans without a shift: the unrotated values have 18 bits — two arrays of dwords instead of one of int16 pairs)
+#ifdef K1_TEAM_LDS
 constexpr int hot_anyd_extra(int S, int in, bool rot = true) { return 4 * 512 + (hot_bufb(S, in) >= 2048 ? 0 : 4 * 2048) + (rot ? 0 : 4 * 2048); }
+#else   // (the team sums stay in registers: only the parked group sums)
+constexpr int hot_anyd_extra(int, int, bool = true) { return 4 * 512; }
+#endif
 
 struct HotRange { int S0, NH, NW; };
 // per S: centred high-plane ranges, narrowest first; the last one covers every step
@@ -346,6 +350,23 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   // E: lane (n, h) owns group 2n + h of the wave: recombine the byte-plane accumulators, >>14, rotate by LUT[idx(n)],
   // window sum of the products' high halves. wave_cnt: LUT phase counter of the wave's first sample (scalar)
   // (edge_: the cold slices of the any-D form — samples outside the call contribute nothing; erel0: call-relative index of the lane's first sample)
+  // (DG) the team sums without an LDS round trip: after the half swap lane (n, h) holds the 8 consecutive samples of block
+  // Lb = 2n + h; D >= 9 puts at most ONE group boundary inside a block, at tm_sp (8: none) — a constant of the lane, like the
+  // lanes a team leader fetches its group's two prefix sums from (tm_a0 / tm_a1: ds_bpermute addresses; tm_end: the group
+  // ends with the slice's 512 samples)
+  int tm_sp = 8, tm_a0 = 0, tm_a1 = 0;
+  bool tm_end = false;
+  if (DG) {
+    const int Lb = 2 * n + h;
+    const int g = (8 * Lb + DD - 1) / DD, pos = g * DD;
+    tm_sp = (g <= GS && pos < 8 * Lb + 8) ? pos - 8 * Lb : 8;
+    const int kk = min(l >> a.lpg_sh, GS - 1);
+    const int b0 = (kk * DD) >> 3, b1 = ((kk + 1) * DD) >> 3, b1c = min(b1, 63);
+    tm_a0 = 4 * ((b0 >> 1) + 32 * (b0 & 1));
+    tm_a1 = 4 * ((b1c >> 1) + 32 * (b1c & 1));
+    tm_end = b1 >= 64;
+  }
+  (void)tm_sp; (void)tm_a0; (void)tm_a1; (void)tm_end;
   auto stageE = [&](auto edge_, const v16i &acc_hh, const v16i &acc_mid, const v16i &acc_ll, uint32_t wave_cnt, char *escr, int erel0) __attribute__((always_inline)) {
     constexpr bool EDGE = decltype(edge_)::value;
     int L[8][3];
@@ -412,7 +433,69 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
 #ifdef K1_ABL_NOTEAM   // (timing only: no LDS round trip, no team sums)
     if (DG) { for (int j = 0; j < 8; j++) { sum.x ^= (int)pk[j]; if (!ROT) sum.y ^= (int)pky[j]; } } else
 #endif
+#ifndef K1_TEAM_LDS
     if (DG) {
+      // Group sums as differences of PREFIX sums over the wave's 512 samples, all in registers: the lanes trade halves
+      // (v_permlane32_swap) so that block Lb = 2n + h holds 8 consecutive samples; running sums inside the block; the
+      // totals of a lane pair's 16 samples are scanned over n (the same scan in both halves of the wave: four row shifts
+      // and lane 15's value for the second row); a lane with a group boundary inside its block publishes the prefix sum AT the
+      // boundary, and the team leader of group k fetches the two that bound its group (ds_bpermute: the LDS crossbar, no LDS
+      // memory). The first form went through LDS — 2 KB (4 KB without a shift) written, D / lpg strided reads and adds per
+      // lane in a scalar loop, a shift tree inside the team — and was 28 % (sdr_fm's plan) to 41 % (sdr_rec's WFM plan) of the
+      // kernel's time (-DK1_TEAM_LDS keeps it for A/B).
+      int rx[8], ry[8];
+      {
+        unsigned q8[8], q8y[8];
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+          for (int tt = 0; tt < 2; tt++) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(pk[2 * jj + tt], pk[2 * (jj + 2) + tt], false, false);
+            q8[4 * jj + tt] = sw[0]; q8[4 * jj + 2 + tt] = sw[1];
+            if (!ROT) {
+              const auto swy = __builtin_amdgcn_permlane32_swap(pky[2 * jj + tt], pky[2 * (jj + 2) + tt], false, false);
+              q8y[4 * jj + tt] = swy[0]; q8y[4 * jj + 2 + tt] = swy[1];
+            }
+          }
+        if (ROT) {
+          rx[0] = (int)(short)(q8[0] & 0xffffu); ry[0] = (int)q8[0] >> 16;
+#pragma unroll
+          for (int j = 1; j < 8; j++) {
+            rx[j] = rx[j - 1]; ry[j] = ry[j - 1];
+            asm("v_add_u32_sdwa %0, sext(%1), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "+v"(rx[j]) : "v"(q8[j]));
+            asm("v_add_u32_sdwa %0, sext(%1), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(ry[j]) : "v"(q8[j]));
+          }
+        } else {
+          rx[0] = (int)q8[0]; ry[0] = (int)q8y[0];
+#pragma unroll
+          for (int j = 1; j < 8; j++) { rx[j] = (int)((unsigned)rx[j - 1] + q8[j]); ry[j] = (int)((unsigned)ry[j - 1] + q8y[j]); }
+        }
+      }
+      int ax = 0, ay = 0;   // the block's samples in front of its boundary
+#pragma unroll
+      for (int j = 0; j < 7; j++) { ax = tm_sp == j + 1 ? rx[j] : ax; ay = tm_sp == j + 1 ? ry[j] : ay; }
+      const auto tx = __builtin_amdgcn_permlane32_swap((unsigned)rx[7], (unsigned)rx[7], false, false);   // {block (n, 0)'s total, block (n, 1)'s} in both halves
+      const auto ty = __builtin_amdgcn_permlane32_swap((unsigned)ry[7], (unsigned)ry[7], false, false);
+      const int cx = (int)(tx[0] + tx[1]), cy = (int)(ty[0] + ty[1]);
+      int ix = cx, iy = cy;   // inclusive scan over n, 16-lane rows first (row_shr: s, zero beyond the row)
+      ix += __builtin_amdgcn_update_dpp(0, ix, 0x111, 0xf, 0xf, true); iy += __builtin_amdgcn_update_dpp(0, iy, 0x111, 0xf, 0xf, true);
+      ix += __builtin_amdgcn_update_dpp(0, ix, 0x112, 0xf, 0xf, true); iy += __builtin_amdgcn_update_dpp(0, iy, 0x112, 0xf, 0xf, true);
+      ix += __builtin_amdgcn_update_dpp(0, ix, 0x114, 0xf, 0xf, true); iy += __builtin_amdgcn_update_dpp(0, iy, 0x114, 0xf, 0xf, true);
+      ix += __builtin_amdgcn_update_dpp(0, ix, 0x118, 0xf, 0xf, true); iy += __builtin_amdgcn_update_dpp(0, iy, 0x118, 0xf, 0xf, true);
+      const int r0x = __builtin_amdgcn_readlane(ix, 15), r0y = __builtin_amdgcn_readlane(iy, 15);
+      if (l & 16) { ix += r0x; iy += r0y; }
+      const int totx = __builtin_amdgcn_readlane(ix, 31), toty = __builtin_amdgcn_readlane(iy, 31);
+      // the prefix sum in front of the block, plus the samples in front of its boundary
+      const int sbx = ix - (h ? (int)tx[1] : cx) + ax, sby = iy - (h ? (int)ty[1] : cy) + ay;
+      const int s0x = __builtin_amdgcn_ds_bpermute(tm_a0, sbx), s0y = __builtin_amdgcn_ds_bpermute(tm_a0, sby);
+      int s1x = __builtin_amdgcn_ds_bpermute(tm_a1, sbx), s1y = __builtin_amdgcn_ds_bpermute(tm_a1, sby);
+      if (tm_end) { s1x = totx; s1y = toty; }
+      sum = make_int2(s1x - s0x, s1y - s0y);   // (whole in the team's first lane)
+    }
+    if (false) {
+#else
+    if (DG) {
+#endif
       // the wave's 512 rotated samples in stream order (lane (n, h) holds the pairs 16n + 2h + 4jj + {0, 1}), then teams of
       // `lpg` lanes (a power of two <= 16, about 64 / GS) sum one group each: strided partial sums, then a shift tree
       // inside the team (one wave's LDS operations execute in order; the asm keeps the compiler from reordering them)
