@@ -716,13 +716,13 @@ __global__ __launch_bounds__(TPB, 3) void iqbb_i16_mfmag_kernel(const IqbbArgs a
 
 // The any-D hot form with FM stores the first output of slice s as -phi and leaves the last angle of every slice in
 // philast; this adds philast[s - 1] for the slices fix_lo <= s < fix_hi (first output fix_gs * s). After the hot kernel.
-// (one wave per channel: a few hundred elements at most)
-__global__ void iqbb_fm_fixup_kernel(short *out, long out_stride, const short *philast, int philast_stride, int fix_lo, int fix_hi, int fix_gs, int C) {
-  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (c >= C) return;
+// (one slice per lane, blockIdx.y = channel)
+__global__ void iqbb_fm_fixup_kernel(short *__restrict__ out, long out_stride, const short *__restrict__ philast, int philast_stride, int fix_lo, int fix_hi, int fix_gs, int C) {
+  // one slice per lane (a wave per channel walking its 512 slices in 8 dependent trips took 5 us for half a megabyte)
+  const int c = blockIdx.y, sl = fix_lo + blockIdx.x * blockDim.x + threadIdx.x;
+  if (sl >= fix_hi) return;
   short *row = out + (long)c * out_stride;
-  const short *pl = philast + (long)c * philast_stride;
-  for (int sl = fix_lo + (threadIdx.x & 63); sl < fix_hi; sl += 64) row[sl * fix_gs] = (short)(row[sl * fix_gs] + pl[sl - 1]);
+  row[sl * fix_gs] = (short)(row[sl * fix_gs] + philast[(long)c * philast_stride + sl - 1]);
 }
 
 // =================================================================================================
@@ -1195,7 +1195,7 @@ struct sdrhip_iqbb_i16 {
     if (epi == SDRHIP_EPI_FM) {   // the slices whose first output is neither out[0] nor out[1] (their own rules) and is emitted
       const int fix_lo = GS == 1 ? 2 : 1, fix_hi = (int)ceil_div((size_t)g.n_out, (size_t)GS);
       if (fix_hi > fix_lo)
-        hipLaunchKernelGGL(iqbb_fm_fixup_kernel, dim3((unsigned)ceil_div((size_t)C, (size_t)4)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(iqbb_fm_fixup_kernel, dim3((unsigned)ceil_div((size_t)(fix_hi - fix_lo), (size_t)256), (unsigned)C), dim3(256), 0, ctx->stream,
                            reinterpret_cast<short *>(out_dev), (long)out_stride, philast.p, 4 * tiles_h, fix_lo, fix_hi, GS, C);
     }
     return true;
