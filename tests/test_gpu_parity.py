@@ -191,6 +191,37 @@ def test_iqbb_any_decimation_long_calls_vs_oracle(ctx, orc, order, decim, Fc, cu
             assert y[c].shape == r.shape and np.array_equal(y[c], r), (n, c)
 
 
+@pytest.mark.parametrize("hot", [True, False])
+@pytest.mark.parametrize("mode,Ff,width,epi", [("USB", 1500.0, 3e3, sa.EPI_USB), ("LSB", -1500.0, 3e3, sa.EPI_USB), ("AM", 0.0, 15e3, sa.EPI_AM),
+                                               ("USB-shifted", 1500.0, 3e3, sa.EPI_USB)])
+@pytest.mark.parametrize("cu8", [True, False])
+def test_iqbb_sdr_rec_ssb_am_modes_vs_oracle(ctx, orc, mode, Ff, width, epi, cu8, hot, monkeypatch):
+    """examples/sdr_rec.cc:50-58 in its AM / USB / LSB modes: f_center = 0 (NO frequency shift) but the 16-tap filter centred
+    on f_filter = +-1500 Hz — complex taps without a rotation, the unshifted any-decimation form with 18-bit values in both
+    components — at 1 MS/s to 12 kS/s (decimation 83), demodulated by USBDemod / AMDemod; "USB-shifted": the same filter
+    with a 100 kHz shift in front (filter centre and shift differ). Ragged calls, state carried, both inputs."""
+    monkeypatch.setenv("SDRHIP_IQBB_HOT", "1" if hot else "0")
+    monkeypatch.delenv("SDRHIP_IQBB_PATH", raising=False)
+    FSr, C, D = 1e6, 3, 83
+    Fc = 100e3 if mode == "USB-shifted" else 0.0
+    rng = np.random.default_rng(len(mode) + int(cu8))
+    taps, lut, inc = orc.iqbb_design(Ff, width, FSr, 16), orc.freqshift_lut_i16(), orc.freqshift_inc(Fc, FSr)
+    if Ff:
+        assert np.any(taps[:, 1] != 0)
+    node = sa.IQBaseBandI16(ctx, taps, lut, inc, False, D, channels=C, max_in=70000, epilogue=epi)
+    if cu8:
+        node.set_input_format(sa.abi.IN_CU8)
+    assert node.kernel_names == (["iqbb_hot_anyd_kernel"] if hot else ["iqbb_i16_mfmag_kernel"])
+    refs = [orc.IQBaseBandI16(taps, lut, inc, False, D) for _ in range(C)]
+    for n in (65536, 70000, 777, 40001, 65536):
+        x = rng.integers(0, 256, (C, n, 2), dtype=np.uint8) if cu8 else rng.integers(-32768, 32768, (C, n, 2), dtype=np.int16)
+        y = node.process(x)
+        for c in range(C):
+            r = refs[c].process(orc.autocast_cu8_cs16(x[c]) if cu8 else x[c])
+            r = orc.am_i16(r) if epi == sa.EPI_AM else orc.usb_i16(r)
+            assert y[c].shape == r.shape and np.array_equal(y[c], r), (mode, n, c)
+
+
 def test_iqbb_any_decimation_full_size(ctx, orc):
     """The sdr_fm plan (21 taps, decimation 125, complex<uint8> input, FM) at the BASELINE batch: 1024 channels x 65536
     samples, two calls: batching invariance over all channels, 8 patterns against the oracle."""
