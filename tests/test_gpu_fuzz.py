@@ -361,3 +361,51 @@ def test_float_baseband_random_calls(ctx, orc, seed, tpw, monkeypatch):
                 err = np.abs(y[c].astype(np.float64) - ref).max() / max(np.abs(ref).max(), 0.05)
                 assert err <= 1e-5, (seed, Fc, D, C, order, n, err)
         n0 += n
+
+
+@pytest.mark.parametrize("seed", range(24 + EXTRA))
+def test_fmdeemph_random_rows(ctx, orc, seed, monkeypatch):
+    """FMDeemph<int16_t>: alpha, channel count, call lengths, the number of lanes per channel (the plan's own choice or forced),
+    the run-in (default / none / one / two groups of 64) and the rows' character — noise, full scale, constant, plateaus,
+    a few spikes on silence, mixed per channel — drawn at random; the segmented kernel's guesses, checks and repairs must
+    leave the sequential recursion's rows (src/demod.hh:342-351), whatever they were worth."""
+    import ctypes
+    rng = np.random.default_rng(7000 + seed)
+    alpha = int(rng.choice([2, 3, 4, 5, 8, 10, 13, 16, 17, 40, 1000]))
+    C = int(rng.choice([1, 2, 7, 33, 130]))
+    P = rng.choice([None, None, 4, 8, 16, 32, 64])
+    wc = rng.choice([None, None, 0, 1, 2])
+    for k, v in (("SDRHIP_DEEMPH_SPEC", P), ("SDRHIP_DEEMPH_WC", wc)):
+        if v is None:
+            monkeypatch.delenv(k, raising=False)
+        else:
+            monkeypatch.setenv(k, str(int(v)))
+    monkeypatch.delenv("SDRHIP_DEEMPH_TILED", raising=False)
+    max_in = 12000
+    node = sa.FMDeemphI16(ctx, alpha, channels=C, max_in=max_in)
+    avgs = [np.zeros(1, np.int16) for _ in range(C)]
+
+    def row(n):
+        kind = rng.integers(0, 6)
+        if kind == 0:
+            return (rng.normal(0, float(rng.choice([3, 300, 5000])), n) + 2000 * np.sin(np.arange(n) * rng.uniform(0.001, 0.3))).clip(-32768, 32767)
+        if kind == 1:
+            return rng.integers(-32768, 32768, n)
+        if kind == 2:
+            return np.full(n, rng.integers(-32768, 32768))
+        if kind == 3:
+            w = int(rng.integers(20, 3000))
+            return np.repeat(rng.integers(-30000, 30000, n // w + 1), w)[:n]
+        if kind == 4:
+            x = np.zeros(n)
+            x[rng.integers(0, n, max(1, n // 500))] = rng.integers(-32768, 32768, max(1, n // 500))
+            return x
+        return np.concatenate([rng.integers(-100, 100, n // 2), np.full(n - n // 2, rng.integers(-5, 5))])
+
+    for n in [int(v) for v in rng.choice([12000, 8192, 3276, 2049, 1000, 524, 65, 7, 1], size=5)]:
+        x = np.stack([row(n) for _ in range(C)]).astype(np.int16)
+        got = node.process(x)
+        for c in range(C):
+            o = np.zeros(n, np.int16)
+            orc.lib().orc_fmdeemph_i16(orc._p(np.ascontiguousarray(x[c]), ctypes.c_int16), n, alpha, orc._p(avgs[c], ctypes.c_int16), orc._p(o, ctypes.c_int16))
+            assert np.array_equal(got[c], o), (seed, alpha, C, P, wc, n, c, np.argwhere(got[c] != o)[:3].tolist())
