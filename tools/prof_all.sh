@@ -9,9 +9,11 @@ declare -A W=( [fm127]="" [fm16]="--order 16" [fm21]="--order 21" [fm64]="--orde
                [cu8]="--workload iqbb_fm_cu8" [real]="--workload bb_real_fm" [fir255]="--workload fir255_fm" [fbb]="--workload fbb_f32"
                [fftconv]="--workload fftconv --fft-whole-blocks" [fftbank]="--workload fftbank" [fmdemod]="--workload fm_demod" [sub8]="--workload subsample8"
                [sdrfm]="--workload iqbb_fm_cu8 --order 21 --decim 125" [sdrrec]="--workload iqbb_fm_cu8 --order 16 --decim 83 --fc 0"
-               [sdrfmchain]="--workload iqbb_fm_cu8 --order 21 --decim 125 --deemph" [wfmchain]="--workload iqbb_fm_cu8 --order 16 --decim 20 --fc 0 --deemph" )   # ... and the whole chains: + FMDeemph (sdr_fm.cc:44-53; sdr_rec.cc WFM: 16 taps, no shift, 1 MS/s to 50 kS/s)
+               [sdrfmchain]="--workload iqbb_fm_cu8 --order 21 --decim 125 --deemph" [wfmchain]="--workload iqbb_fm_cu8 --order 16 --decim 20 --fc 0 --deemph"
+               [pocsag]="--workload iqbb_fm_cu8 --order 21 --decim 45 --fc 0" [ssb]="--workload iqbb_usb --order 16 --decim 83 --fc 0" )   # examples/sdr_pocsag.cc:117 / sdr_ax25.cc:117 (21 taps, 1 MS/s to 22.05 kS/s); sdr_rec's USB mode on complex<int16>
+#   # ... and the whole chains: + FMDeemph (sdr_fm.cc:44-53; sdr_rec.cc WFM: 16 taps, no shift, 1 MS/s to 50 kS/s)
 #    # the plans of examples/sdr_fm.cc:40 and examples/sdr_rec.cc:42-68 (narrow FM: no shift, 1 MS/s to 12 kS/s)
-NAMES=${@:-fm127 fm16 fm21 fm64 fm255 usb127 cu8 real fir255 fbb fftconv fftbank fmdemod sub8 sdrfm sdrrec}
+NAMES=${@:-fm127 fm16 fm21 fm64 fm255 usb127 cu8 real fir255 fbb fftconv fftbank fmdemod sub8 sdrfm sdrrec sdrfmchain wfmchain pocsag ssb}
 mkdir -p gpurun_out
 : > gpurun_out/${R}_bench_other_workloads.jsonl
 for n in $NAMES; do
