@@ -255,7 +255,7 @@ int sdrhip_deemph_i16_process(sdrhip_deemph *h, const int16_t *in_host, size_t n
 int sdrhip_deemph_i16_process_dev(sdrhip_deemph *h, const int16_t *in_dev, size_t n, size_t in_stride, int16_t *out_dev,
                                   size_t out_stride);
 /* The kernel a call of n samples per channel runs (0: the plan's max_in): "deemph_i16_copy_kernel" (alpha = 1: the update is
- * avg = x), "deemph_i16_seq_kernel" (one lane walks one channel), "deemph_i16_spec_kernel" (alpha <= 16 and rows of at least
+ * avg = x), "deemph_i16_seq_kernel" (one lane walks one channel), "deemph_i16_spec_kernel" (alpha <= 32 and rows of at least
  * 64 alpha samples: 4 … 32 lanes per channel start their segments from guessed states that the kernel checks and repairs —
  * the same bits as the sequential recursion, whatever the data). */
 int sdrhip_deemph_i16_kernel_names(sdrhip_deemph *h, size_t n, char *buf, size_t len);

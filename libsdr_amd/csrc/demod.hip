@@ -652,7 +652,7 @@ struct sdrhip_deemph {
     const char *ew = getenv("SDRHIP_DEEMPH_WC");     // (tests: the run-in in groups of 64 samples; 0: every guess is checked cold)
     int lgP = 0;
     const int wc = (ew ? atoi(ew) : (int)ceil_div((size_t)16 * alpha, (size_t)64)) * DE_PF, n8 = (int)(N / 8);
-    if (alpha <= 16 && !(ev && atoi(ev) == 0))
+    if (alpha <= 32 && !(ev && atoi(ev) == 0))
       for (int l = 5; l >= 2 && !lgP; l--) if ((n8 + (1 << l) - 1) >> l >= wc) lgP = l;
     if (ev && atoi(ev) > 1 && n8 >= atoi(ev)) { lgP = 0; while ((2 << lgP) <= atoi(ev) && lgP < 6) lgP++; }
     if (lgP_out) *lgP_out = lgP;
