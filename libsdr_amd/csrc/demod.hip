@@ -227,9 +227,12 @@ __global__ __launch_bounds__(TPB) void subsample_cf32_kernel(const SubArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 // FMDeemph<int16_t> (src/demod.hh:342-351): avg += (x - avg +/- alpha/2) / alpha, all in int with an int16
-// wrap of the difference and of the average. The recursion is nonlinear, so time cannot be split: one lane
-// walks one channel; a 64-lane workgroup moves 64 channels x 128 samples at a time through LDS so that
-// global loads and stores stay coalesced along the channel rows.
+// wrap of the difference and of the average — a nonlinear recursion, sequential per channel. Four kernels:
+//   deemph_i16_copy_kernel   alpha = 1: the update is avg = x
+//   deemph_i16_seq_kernel    one lane walks one channel's row in registers
+//   deemph_i16_spec_kernel   long rows, alpha <= 32: P lanes per channel from guessed segment states, checked and repaired
+//   deemph_i16_kernel        rounds 1-2 (kept as a parity form, SDRHIP_DEEMPH_TILED): a 64-lane workgroup moves 64 channels x 128
+//                            samples at a time through LDS so that global loads and stores stay coalesced along the channel rows
 // ---------------------------------------------------------------------------------------------
 constexpr int DE_CH = 64, DE_N = 128, DE_LD = DE_N + 2;
 
@@ -247,8 +250,7 @@ struct DeemphArgs {
 // reciprocal per step) took 172 us for 1024 channels x 524 samples — twice the baseband kernel in front of it in the
 // reference's sdr_fm chain — where this one takes the chain's latency.
 constexpr int DE_PF = 8;
-// (branch-free, and without compare + select pairs: on gfx950 a v_cmp's SGPR result costs wait states before the select that
-// reads it, twice per step of a chain that is nothing but latency)
+// One step in plain C++ (the rows' first and last samples, off the 16-byte chunks; the chunks run deemph_chunk below)
 __device__ __forceinline__ int deemph_step(int x, int &avg, int half, unsigned magic) {
   const int d = (int)(short)(x - avg);                 // the int16 wrap of the difference
   const int s = (d - 1) >> 31;                         // -1 for d <= 0 (the reference subtracts alpha / 2 then), else 0
