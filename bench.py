@@ -47,6 +47,9 @@ def parse():
     p.add_argument("--steps", type=int, default=400)    # ~50 ms timed at the headline workload (a few-ms burst shows a clock the chip does not hold)
     p.add_argument("--warmup", type=int, default=100)
     p.add_argument("--channels", type=int, default=1024, help="channels per GPU")
+    p.add_argument("--global-channels", type=int, default=0,
+                   help="STRONG scaling: this many channels in all, a contiguous block of G / N per GPU (BASELINE config 5: 8192); "
+                        "overrides --channels and the line says \"scaling\": \"strong\"")
     p.add_argument("--samples", type=int, default=65536, help="samples per channel per step")
     p.add_argument("--workload", default="", help="default: iqbb_fm on one GPU, iqbb_usb with the gather (BASELINE config 5) on several")
     p.add_argument("--decim", type=int, default=8, help="iqbb_* workloads: decimation D (8 = the BASELINE configs)")
@@ -195,6 +198,100 @@ def measured_traffic(workload_key, kernels):
         except Exception:
             pass
     return None
+
+
+class Telemetry:
+    """Shader clock and socket power of one device while a phase runs, read from amdgpu's sysfs files by a side THREAD of
+    this process (plain file reads: no HIP call, no child process, nothing re-executed): hwmon freq1_input (sclk, Hz) or
+    the starred line of pp_dpm_sclk, and hwmon power1_average / power1_input (microwatts). Whatever the box does not
+    expose stays None; `source` says what was read."""
+
+    def __init__(self, pci_bus_id, period_s=0.02):
+        import glob
+        self.period, self.sclk, self.power, self.files = period_s, [], [], {}
+        devs = []
+        for d in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+            try:
+                real = os.path.realpath(d)
+            except OSError:
+                continue
+            if pci_bus_id and os.path.basename(real).lower() != pci_bus_id.lower():
+                continue
+            devs.append(d)
+        if not devs and not pci_bus_id:
+            devs = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))[:1]
+        for d in devs[:1]:
+            for h in sorted(glob.glob(os.path.join(d, "hwmon", "hwmon*"))):
+                for key, names in (("sclk_hz", ["freq1_input"]), ("power_uw", ["power1_average", "power1_input"])):
+                    for nm in names:
+                        f = os.path.join(h, nm)
+                        if key not in self.files and os.access(f, os.R_OK):
+                            self.files[key] = f
+            f = os.path.join(d, "pp_dpm_sclk")
+            if "sclk_hz" not in self.files and os.access(f, os.R_OK):
+                self.files["sclk_dpm"] = f
+        self._stop, self._thr = None, None
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return f.read()
+        except OSError:
+            return None
+
+    def _sample(self):
+        if "sclk_hz" in self.files:
+            t = self._read(self.files["sclk_hz"])
+            if t and t.strip().isdigit():
+                self.sclk.append(int(t) / 1e6)
+        elif "sclk_dpm" in self.files:
+            for line in (self._read(self.files["sclk_dpm"]) or "").splitlines():
+                if line.rstrip().endswith("*"):
+                    try:
+                        self.sclk.append(float(line.split(":")[1].strip().lower().split("mhz")[0]))
+                    except (IndexError, ValueError):
+                        pass
+        if "power_uw" in self.files:
+            t = self._read(self.files["power_uw"])
+            if t and t.strip().isdigit():
+                self.power.append(int(t) / 1e6)
+
+    def start(self):
+        import threading
+        if not self.files:
+            return
+        self.sclk, self.power = [], []
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                self._sample()
+                self._stop.wait(self.period)
+        self._thr = threading.Thread(target=loop, daemon=True)
+        self._thr.start()
+
+    def stop(self):
+        if self._thr is not None:
+            self._stop.set()
+            self._thr.join(timeout=2.0)
+            self._thr = None
+        avg = lambda v: round(sum(v) / len(v), 1) if v else None
+        return {"sclk_mhz": avg(self.sclk), "sclk_mhz_min": round(min(self.sclk), 1) if self.sclk else None,
+                "power_w": avg(self.power), "samples": max(len(self.sclk), len(self.power)),
+                "source": {k: v for k, v in self.files.items()} or None}
+
+
+def error_line(a, text, world=None):
+    """The one JSON line of a run that could not measure: same keys, value null, an `error` text (the caller exits non-zero)."""
+    return json.dumps({"metric": "Msamples/s through baseband->FIR->demod chain", "value": None, "unit": "Msamples/s",
+                       "n_gpus": world if world is not None else a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": None,
+                       "higher_is_better": True, "scaling": "strong" if a.global_channels else "weak", "vs_baseline": None,
+                       "data": "synthetic", "error": str(text)[:600]})
+
+
+class BenchError(RuntimeError):
+    pass
 
 
 class Workload:
@@ -435,16 +532,48 @@ def build_workload(a, wl, sa, torch, shard, ctx, dev, rank, nbuf_out):
                 return bool(np.array_equal(out[:len(r)], r))
         w.verify, w.dtype, w.key = verify, "i16", wl
     else:
-        raise SystemExit("unknown workload " + wl)
+        raise BenchError("unknown workload " + wl)
     w.node = node
     w.key += "/C%d/N%d" % (C, w.N)
     return w
 
 
 def main():
+    """Runs the bench; whatever goes wrong (fewer devices than ranks, RCCL that does not come up, a failed launch) still
+    ends in ONE JSON line on rank 0 — with an `error` key and value null — and a non-zero exit code."""
     a = parse()
+    rank = int(os.environ.get("RANK", "0"))
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # (counting devices does not initialise the GPU on this image, so the child processes start from a clean parent)
+        try:
+            import torch
+            seen = torch.cuda.device_count()
+        except Exception as e:   # no torch / no driver: let the ranks report
+            seen = None
+            sys.stderr.write("bench.py: could not count devices (%s)\n" % e)
+        if seen is not None and seen < a.gpus and a.force_device < 0:
+            print(error_line(a, "--gpus %d but only %d HIP device(s) visible on this node" % (a.gpus, seen)), flush=True)
+            raise SystemExit(2)
         raise SystemExit(spawn_ranks(a))
+    try:
+        run(a)
+    except BenchError as e:
+        if rank == 0:
+            print(error_line(a, e, world=int(os.environ.get("WORLD_SIZE", "1"))), flush=True)
+        else:
+            sys.stderr.write("bench.py rank %d: %s\n" % (rank, e))
+        raise SystemExit(2)
+    except SystemExit:
+        raise
+    except BaseException as e:   # (a HIP / RCCL error surfaces as RuntimeError or SdrHipError)
+        import traceback
+        traceback.print_exc()
+        if rank == 0:
+            print(error_line(a, "%s: %s" % (type(e).__name__, e), world=int(os.environ.get("WORLD_SIZE", "1"))), flush=True)
+        raise SystemExit(3)
+
+
+def run(a):
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -455,14 +584,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+        raise BenchError("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     if a.force_device >= 0:
         local = a.force_device
     if world != a.gpus and rank == 0:
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d; reporting the ranks that run\n" % (a.gpus, world))
     if local >= torch.cuda.device_count():
-        raise SystemExit("bench.py: rank %d wants device %d but only %d visible (dry runs: --backend gloo --force-device 0)"
+        raise BenchError("rank %d wants device %d but only %d visible (dry runs: --backend gloo --force-device 0)"
                          % (rank, local, torch.cuda.device_count()))
+    if a.global_channels:   # strong scaling: a fixed job, contiguous blocks of G / N channels per GPU
+        if a.global_channels % world:
+            raise BenchError("--global-channels %d is not a multiple of the %d ranks" % (a.global_channels, world))
+        a.channels = a.global_channels // world
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or a.force_dist
@@ -498,7 +631,7 @@ def main():
                 g8 = gathered.view(torch.uint8)
                 gl = [g8[r * C:(r + 1) * C] for r in range(world)]
         elif gather:
-            raise SystemExit("--gather needs a workload with one output row per channel")
+            raise BenchError("--gather needs a workload with one output row per channel")
         pending = [None, None]   # the gather that still reads outs[o]
         ev = [torch.cuda.Event(), torch.cuda.Event()]
 
@@ -592,9 +725,20 @@ def main():
         # ---- sustained figure: >= --sustain-seconds of back-to-back launches on the same stream, so that the
         # clock the chip HOLDS under this load (DVFS) is what is measured, not a few-ms burst (every rank runs it;
         # rank 0 reports its own) ----
-        sustained = None
+        sustained, telemetry = None, None
         if a.sustain_seconds > 0:
             chunk = max(K, 20)
+            tele = None
+            if rank == 0:
+                try:   # the device's sysfs directory by its PCI address (domain:bus:device.function)
+                    pr = torch.cuda.get_device_properties(local)
+                    tele = Telemetry("%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id))
+                    if not tele.files:
+                        tele = Telemetry("")   # (containers that remap PCI addresses: the first card)
+                except Exception:
+                    tele = None
+            if tele is not None:
+                tele.start()
             tot_ms, launches, t1 = 0.0, 0, time.perf_counter()
             while time.perf_counter() - t1 < a.sustain_seconds:
                 timer.start()
@@ -605,6 +749,8 @@ def main():
                 launches += chunk
             last_ms = timer.elapsed_ms() / chunk
             sustained = {"ms_per_launch": tot_ms / launches, "launches": launches, "last_chunk_ms_per_launch": last_ms}
+            if tele is not None:
+                telemetry = tele.stop()
             barrier()
 
     host_coll = use_dist and a.backend != "nccl"
@@ -622,7 +768,7 @@ def main():
         res = {
             "metric": "Msamples/s through baseband->FIR->demod chain",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": round(wall / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(wall / K * 1e3, 4), "higher_is_better": True, "scaling": "strong" if a.global_channels else "weak",
             "vs_baseline": None, "dtype": w.dtype, "data": "synthetic",
             "config": {"workload": w.desc, "workload_key": w.key, "channels_per_gpu": C, "samples_per_channel_per_step": N,
                        "global_channels": C * world,
@@ -674,14 +820,21 @@ def main():
         if wl == "fbb_f32" and C == 1:   # BASELINE config 2: one channel — what a buffer costs, and against real time
             res["roofline"]["per_buffer_us"] = round(per_launch_s * 1e6, 2)
             res["roofline"]["real_time_factor"] = round((N / FS) / per_launch_s, 1)
-        if world == 1 and not a.no_cpu_baseline:
+        if telemetry:   # the clock and power the chip HELD over the sustained phase (rank 0's device)
+            rf = res["roofline"]
+            rf["sclk_mhz"], rf["sclk_mhz_min"], rf["power_w"] = telemetry["sclk_mhz"], telemetry["sclk_mhz_min"], telemetry["power_w"]
+            rf["telemetry"] = {"samples": telemetry["samples"], "phase": "sustained", "source": telemetry["source"]}
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        # the CPU baseline runs once the GPU work is over and the process group is gone (the other ranks have left: the
+        # host cores are idle), on rank 0, for every N
+        if not a.no_cpu_baseline:
             cb = cpu_baseline(wl, a.cpu_seconds)
             if cb:
                 res["cpu_baseline"] = cb
         print(json.dumps(res), flush=True)
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -120,7 +120,13 @@ public:
   void setDemod(int epilogue) { _epilogue = epilogue; if (_Fs) _reconfigure(); }
 
   inline size_t order() const { return _order; }
-  void setOrder(size_t o) { _order = std::max(size_t(1), o); if (_Fs) _reconfigure(); }
+  /** As the reference (src/baseband.hh:69-79): a new kernel and a NEW ring; the decimator window, the sample counter, the
+   * LUT phase and the Config go on untouched. (The reference's new ring is uninitialised memory until `order` samples
+   * have passed; here it is zeros.) */
+  void setOrder(size_t o) {
+    _order = std::max(size_t(1), o);
+    if (_plan) _newPlan(SDRHIP_KEEP_FM | SDRHIP_KEEP_COUNTERS);
+  }
   inline double centerFrequency() const { return _Fc; }
   /** As the reference (src/baseband.hh:84-86 -> src/freqshift.hh:52-54,78-87): new LUT increment and sign, the LUT
    * phase restarts; filter history, decimator state and the kernel go on unchanged. */
@@ -163,53 +169,63 @@ protected:
     std::vector<int32_t> taps(2 * _order);
     design::iqbbTaps(_Ff, _width, _Fs, _order, taps.data());
     const int rc = sdrhip_iqbb_i16_set_taps(_plan, taps.data());
-    if (rc == SDRHIP_E_UNSUPPORTED) {   // the new kernel does not fit the plan's formulation: a fresh plan (state is lost)
-      LogMessage msg(LOG_WARNING);
-      msg << "gpu::IQBaseBand: new filter kernel needs a new device plan; filter history is reset";
-      Logger::get().log(msg);
-      _planOrder = 0; _reconfigure();
-    } else configCheck(rc, "IQBaseBand");
+    // the new kernel does not fit the plan's formulation (tap bytes): a new plan that takes the whole stream state over
+    if (rc == SDRHIP_E_UNSUPPORTED) _newPlan(SDRHIP_KEEP_RING | SDRHIP_KEEP_FM | SDRHIP_KEEP_COUNTERS);
+    else configCheck(rc, "IQBaseBand");
   }
 
-  /** IQBaseBand::_reconfigure (src/baseband.hh:156-194): kernel and LUT increment recomputed, counters and phases reset,
-   * the FIR ring's CONTENTS kept where they lie (sdrhip_iqbb_i16_reset(keep_history = 1) reproduces the rotated ring);
-   * a new device plan (zeroed history) only when the geometry changes (order, decimation, buffer size, demodulator). */
-  void _reconfigure() {
-    const size_t D = design::iqbbDecimation(_Fs, _sub_sample, _oFs);
-    _sub_sample = D;
+  /** A device plan for the node's present parameters; `carry` (SDRHIP_KEEP_*) names the streaming state it takes over
+   * from the plan it replaces (sdrhip_iqbb_i16_adopt_state), so that a new plan is not an event of its own. */
+  void _newPlan(int carry) {
+    const size_t D = std::max(size_t(1), _sub_sample);
     std::vector<int32_t> taps(2 * _order), lut(2 * design::kLutSize);
     design::iqbbTaps(_Ff, _width, _Fs, _order, taps.data());
     if (kInt8) design::freqShiftLutI8(lut.data()); else design::freqShiftLutI16(lut.data());
     const uint32_t inc = design::freqShiftIncrement(_shift, double(_Fs));
+    sdrhip_iqbb_i16 *neu = 0;
+    if (kInt8) configCheck(sdrhip_iqbb_i8_create(Device::get(_device), taps.data(), int(_order), lut.data(), inc, 0 > _shift,
+                                                 int(D), 1, _sourceBs, _epilogue, &neu), "IQBaseBand");
+    else configCheck(sdrhip_iqbb_i16_create(Device::get(_device), taps.data(), int(_order), lut.data(), inc, 0 > _shift,
+                                            int(D), 1, _sourceBs, _epilogue, &neu), "IQBaseBand");
+    int rc = kCu8 ? sdrhip_iqbb_i16_set_input_format(neu, SDRHIP_IN_CU8) : SDRHIP_OK;
+    if (rc == SDRHIP_OK && _plan) {
+      if (_planOrder != _order) carry &= ~SDRHIP_KEEP_RING;   // (a new order is a new ring, src/baseband.hh:75-76)
+      if (_planEpi != SDRHIP_EPI_FM || _epilogue != SDRHIP_EPI_FM) carry &= ~SDRHIP_KEEP_FM;
+      rc = sdrhip_iqbb_i16_adopt_state(neu, _plan, carry);
+    }
+    if (rc != SDRHIP_OK) { sdrhip_iqbb_i16_destroy(neu); configCheck(rc, "IQBaseBand"); }
+    if (_plan) sdrhip_iqbb_i16_destroy(_plan);
+    _plan = neu;
+    _planOrder = _order; _planD = D; _planBs = _sourceBs; _planEpi = _epilogue;
+  }
+
+  /** IQBaseBand::_reconfigure (src/baseband.hh:156-194): kernel and LUT increment recomputed, counters and phases reset,
+   * the FIR ring's CONTENTS kept where they lie (read rotated afterwards) — on the plan in place
+   * (sdrhip_iqbb_i16_reset(keep_history = 1)) or, when the geometry changed (decimation, buffer size, demodulator),
+   * carried into the new device plan. */
+  void _reconfigure() {
+    const size_t D = design::iqbbDecimation(_Fs, _sub_sample, _oFs);
+    _sub_sample = D;
+    size_t buffer_size = _sourceBs / D;
+    if (_sourceBs % D) buffer_size += 1;
+    const double oRate = double(size_t(_Fs) / D);   // the reference divides int32 by size_t (src/baseband.hh:192-193)
+    const Config out_cfg(_epilogue == SDRHIP_EPI_NONE ? Config::typeId<COut>() : Config::typeId<int16_t>(), oRate, buffer_size, 1);
+    // (a fused demodulator is reconfigured — FM's last angle zeroed — only if the Config we propagate changes,
+    // src/node.cc:98-105, src/demod.hh:210)
+    const bool same_cfg = (out_cfg == this->_config);
     bool reuse = _plan && _planOrder == _order && _planD == D && _planBs == _sourceBs && _planEpi == _epilogue;
     if (reuse) {
+      std::vector<int32_t> taps(2 * _order);
+      design::iqbbTaps(_Ff, _width, _Fs, _order, taps.data());
       const int rc = sdrhip_iqbb_i16_set_taps(_plan, taps.data());
       if (rc == SDRHIP_E_UNSUPPORTED) reuse = false;
       else {
         configCheck(rc, "IQBaseBand");
-        configCheck(sdrhip_iqbb_i16_set_shift(_plan, inc, 0 > _shift), "IQBaseBand");
-        // (a fused demodulator is reconfigured — FM's last angle zeroed — only if the Config we propagate changes)
-        const double oRateNow = double(size_t(_Fs) / D);
-        const bool same_cfg = this->_config.hasSampleRate() && this->_config.sampleRate() == oRateNow;
+        configCheck(sdrhip_iqbb_i16_set_shift(_plan, design::freqShiftIncrement(_shift, double(_Fs)), 0 > _shift), "IQBaseBand");
         configCheck(sdrhip_iqbb_i16_reset(_plan, same_cfg ? 3 : 1), "IQBaseBand");
       }
     }
-    if (!reuse) {
-      if (_plan) {   // (the reference keeps its ring through any _reconfigure; a new device plan starts from zeros: INTEGRATION.md)
-        LogMessage warn(LOG_WARNING);
-        warn << "gpu::IQBaseBand: order / decimation / buffer size / demodulator changed: new device plan, filter history is reset";
-        Logger::get().log(warn);
-        sdrhip_iqbb_i16_destroy(_plan); _plan = 0;
-      }
-      if (kInt8) configCheck(sdrhip_iqbb_i8_create(Device::get(_device), taps.data(), int(_order), lut.data(), inc, 0 > _shift,
-                                                   int(D), 1, _sourceBs, _epilogue, &_plan), "IQBaseBand");
-      else configCheck(sdrhip_iqbb_i16_create(Device::get(_device), taps.data(), int(_order), lut.data(), inc, 0 > _shift,
-                                              int(D), 1, _sourceBs, _epilogue, &_plan), "IQBaseBand");
-      if (kCu8) configCheck(sdrhip_iqbb_i16_set_input_format(_plan, SDRHIP_IN_CU8), "IQBaseBand");
-      _planOrder = _order; _planD = D; _planBs = _sourceBs; _planEpi = _epilogue;
-    }
-    size_t buffer_size = _sourceBs / D;
-    if (_sourceBs % D) buffer_size += 1;
+    if (!reuse) _newPlan(SDRHIP_KEEP_RING | (same_cfg ? SDRHIP_KEEP_FM : 0));
     _buffer.unref();
     _buffer = Buffer<COut>(buffer_size);
 
@@ -220,9 +236,7 @@ protected:
         << " out buffer size " << buffer_size;
     Logger::get().log(msg);
 
-    const double oRate = double(size_t(_Fs) / D);   // the reference divides int32 by size_t (src/baseband.hh:192-193)
-    if (_epilogue == SDRHIP_EPI_NONE) this->setConfig(Config(Config::typeId<COut>(), oRate, buffer_size, 1));
-    else this->setConfig(Config(Config::typeId<int16_t>(), oRate, buffer_size, 1));
+    this->setConfig(out_cfg);
   }
 
   void _process(const Buffer<CIn> &in, const Buffer<COut> &out) {
@@ -402,7 +416,24 @@ public:
   void setDemod(int epilogue) { _epilogue = epilogue; if (_Fs) _reconfigure(); }
   inline double sampleRate() const { return _Fs; }
   inline double frequencyShift() const { return _shift; }
-  void setFrequencyShift(double F) { _shift = F; if (_Fs) _reconfigure(); }
+  /** FreqShiftBase::setFrequencyShift (src/freqshift.hh:52-54,78-87): new increment and sign, the LUT phase restarts;
+   * ring, decimator and kernel go on. */
+  void setFrequencyShift(double F) {
+    _shift = F;
+    if (_plan) detail::configCheck(sdrhip_iqbb_i16_set_shift(_plan, design::freqShiftIncrement(_shift, _Fs), 0 > _shift), "BaseBand");
+  }
+  /** BaseBand::setSampleRate (src/baseband.hh:397-401): the LUT increment and the kernel are recomputed, nothing is
+   * propagated (the reference marks that as a bug of its own, :400). */
+  void setSampleRate(double Fs) {
+    _Fs = Fs;
+    if (!_plan) return;
+    detail::configCheck(sdrhip_iqbb_i16_set_shift(_plan, design::freqShiftIncrement(_shift, _Fs), 0 > _shift), "BaseBand");
+    std::vector<int32_t> taps(2 * _order);
+    design::bbTaps(_Ff, _width, _Fs, _order, taps.data());
+    const int rc = sdrhip_iqbb_i16_set_taps(_plan, taps.data());
+    if (rc == SDRHIP_E_UNSUPPORTED) _newPlan(SDRHIP_KEEP_RING | SDRHIP_KEEP_FM | SDRHIP_KEEP_COUNTERS);
+    else detail::configCheck(rc, "BaseBand");
+  }
 
   virtual void config(const Config &src_cfg) {
     if (!src_cfg.hasType() || !src_cfg.hasSampleRate() || !src_cfg.hasBufferSize()) return;
@@ -429,22 +460,49 @@ public:
   }
 
 protected:
-  void _reconfigure() {
+  void _newPlan(int carry) {
     std::vector<int32_t> taps(2 * _order), lut(2 * design::kLutSize);
     design::bbTaps(_Ff, _width, _Fs, _order, taps.data());
     design::freqShiftLutI16(lut.data());
-    const uint32_t inc = design::freqShiftIncrement(_shift, _Fs);
-    if (_plan) { sdrhip_iqbb_i16_destroy(_plan); _plan = 0; }
-    detail::configCheck(sdrhip_bb_i16_create(Device::get(_device), taps.data(), int(_order), lut.data(), inc, 0 > _shift,
-                                             int(_sub_sample), 1, _sourceBs, _epilogue, &_plan), "BaseBand");
-    size_t buffer_size = _sourceBs / _sub_sample;
-    if (_sourceBs % _sub_sample) buffer_size += 1;
-    _buffer.unref();
-    _buffer = Buffer<cs16>(buffer_size);
-    if (_epilogue == SDRHIP_EPI_NONE) this->setConfig(Config(Config::typeId<cs16>(), _Fs / _sub_sample, buffer_size, 1));
-    else this->setConfig(Config(Config::typeId<int16_t>(), _Fs / _sub_sample, buffer_size, 1));
+    sdrhip_iqbb_i16 *neu = 0;
+    detail::configCheck(sdrhip_bb_i16_create(Device::get(_device), taps.data(), int(_order), lut.data(), design::freqShiftIncrement(_shift, _Fs),
+                                             0 > _shift, int(_sub_sample), 1, _sourceBs, _epilogue, &neu), "BaseBand");
+    if (_plan) {
+      if (_planEpi != SDRHIP_EPI_FM || _epilogue != SDRHIP_EPI_FM) carry &= ~SDRHIP_KEEP_FM;
+      const int rc = sdrhip_iqbb_i16_adopt_state(neu, _plan, carry);
+      if (rc != SDRHIP_OK) { sdrhip_iqbb_i16_destroy(neu); detail::configCheck(rc, "BaseBand"); }
+      sdrhip_iqbb_i16_destroy(_plan);
+    }
+    _plan = neu; _planBs = _sourceBs; _planEpi = _epilogue;
   }
 
+  /** BaseBand::config (src/baseband.hh:357-395): sample rate (LUT increment, kernel), output buffer, counters reset —
+   * the ring's contents stay where they lie, as in IQBaseBand::_reconfigure. */
+  void _reconfigure() {
+    size_t buffer_size = _sourceBs / _sub_sample;
+    if (_sourceBs % _sub_sample) buffer_size += 1;
+    const Config out_cfg(_epilogue == SDRHIP_EPI_NONE ? Config::typeId<cs16>() : Config::typeId<int16_t>(), _Fs / _sub_sample, buffer_size, 1);
+    const bool same_cfg = (out_cfg == this->_config);
+    bool reuse = _plan && _planBs == _sourceBs && _planEpi == _epilogue;
+    if (reuse) {
+      std::vector<int32_t> taps(2 * _order);
+      design::bbTaps(_Ff, _width, _Fs, _order, taps.data());
+      const int rc = sdrhip_iqbb_i16_set_taps(_plan, taps.data());
+      if (rc == SDRHIP_E_UNSUPPORTED) reuse = false;
+      else {
+        detail::configCheck(rc, "BaseBand");
+        detail::configCheck(sdrhip_iqbb_i16_set_shift(_plan, design::freqShiftIncrement(_shift, _Fs), 0 > _shift), "BaseBand");
+        detail::configCheck(sdrhip_iqbb_i16_reset(_plan, same_cfg ? 3 : 1), "BaseBand");
+      }
+    }
+    if (!reuse) _newPlan(SDRHIP_KEEP_RING | (same_cfg ? SDRHIP_KEEP_FM : 0));
+    _buffer.unref();
+    _buffer = Buffer<cs16>(buffer_size);
+    this->setConfig(out_cfg);
+  }
+
+  size_t _planBs = 0;
+  int _planEpi = 0;
   double _shift, _Ff, _width, _Fs;
   size_t _order, _sub_sample, _sourceBs;
   int _epilogue, _device;

@@ -205,6 +205,21 @@ int sdrhip_iqbb_i16_set_shift(sdrhip_iqbb_i16 *h, uint32_t lut_inc, int negative
  * keeps the demodulator's last angle — the FMDemod node behind a reconfigured baseband is only reset when the Config
  * it receives changes (src/node.cc:98-105, src/demod.hh:210); 1 alone resets it (a changed output Config). */
 int sdrhip_iqbb_i16_reset(sdrhip_iqbb_i16 *h, int keep_history);
+/* Streaming state carried from one plan into a FRESH one (same channels, same sample kind, same device) — what the
+ * reference node keeps when a setter changes what a device plan is made for (decimation, buffer size, order, fused
+ * demodulator), so that a new plan is no visible event:
+ *   SDRHIP_KEEP_RING      the FIR ring (equal orders). Alone: as IQBaseBand::_reconfigure leaves it — setSubsample /
+ *                         setOutputSampleRate / config(), src/baseband.hh:106-112,115-132,156-194: counters reset, ring
+ *                         contents kept where they lie, i.e. read ROTATED afterwards (as reset(keep_history = 1)).
+ *   SDRHIP_KEEP_FM        the fused FMDemod's last angle (the node behind the baseband is reset only when the Config it
+ *                         receives changes, src/node.cc:98-105).
+ *   SDRHIP_KEEP_COUNTERS  the stream goes on (equal decimations): absolute sample index, open decimator window and its
+ *                         partial sum, LUT phase. With KEEP_RING the history is copied in time order (no rotation). This
+ *                         is IQBaseBand::setOrder (src/baseband.hh:69-79: new kernel, NEW ring, nothing else touched)
+ *                         without KEEP_RING — the reference's new ring is uninitialised memory, a fresh plan's is zeros.
+ * `from` is only read; destroy it afterwards. */
+enum { SDRHIP_KEEP_RING = 1, SDRHIP_KEEP_FM = 2, SDRHIP_KEEP_COUNTERS = 4 };
+int sdrhip_iqbb_i16_adopt_state(sdrhip_iqbb_i16 *h, sdrhip_iqbb_i16 *from, int what);
 int sdrhip_iqbb_i16_destroy(sdrhip_iqbb_i16 *h);
 
 /* ---- K2/K3: FIRFilter<complex<int16_t>> (exact) and FIRFilter<complex<float>> ------------- */

@@ -20,6 +20,7 @@ EPI_NONE, EPI_FM, EPI_AM, EPI_USB = 0, 1, 2, 3
 FIR_CS16_EXACT, FIR_CF32 = 0, 1
 T_CS16, T_CF32, T_CS8, T_CF64 = 0, 1, 2, 3
 IN_CS16, IN_CU8 = 0, 1
+KEEP_RING, KEEP_FM, KEEP_COUNTERS = 1, 2, 4
 FFTCONV_OLA, FFTCONV_OLS = 0, 1
 
 
@@ -91,6 +92,7 @@ def lib():
             "sdrhip_iqbb_i16_process": (C.c_int, [vp, vp, sz, sz, vp, sz, psz]),
             "sdrhip_iqbb_i16_process_dev": (C.c_int, [vp, vp, sz, sz, vp, sz, psz]),
             "sdrhip_iqbb_i16_reset": (C.c_int, [vp, C.c_int]),
+            "sdrhip_iqbb_i16_adopt_state": (C.c_int, [vp, vp, C.c_int]),
             "sdrhip_iqbb_i16_destroy": (C.c_int, [vp]),
             "sdrhip_fir_create": (C.c_int, [vp, C.c_int, f64p, C.c_int, C.c_int, C.c_int, sz, C.c_int, pvp]),
             "sdrhip_fir_out_count": (C.c_int, [vp, sz, psz]),

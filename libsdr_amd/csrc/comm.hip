@@ -17,6 +17,7 @@
 #include <rccl/rccl.h>   // types and prototypes only; every entry point is resolved through dlsym
 
 #include <cstdlib>
+#include <mutex>
 #include <set>
 
 using namespace sdrhip;
@@ -37,6 +38,8 @@ struct RcclApi {
 
 RcclApi &rccl() {
   static RcclApi api;
+  static std::mutex mtx;   // (a failed load throws and may be retried, so no once-flag: the table is filled under the lock)
+  std::lock_guard<std::mutex> lock(mtx);
   if (api.lib) return api;   // (set last: only once every symbol below has been found)
   RcclApi a;
   const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};

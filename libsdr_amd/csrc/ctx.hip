@@ -34,31 +34,32 @@ namespace {
 struct Roctx {
   int (*push)(const char *) = nullptr;
   int (*pop)() = nullptr;
-  bool tried = false;
 };
-Roctx &roctx() {
-  static Roctx r;
-  if (!r.tried) {
-    r.tried = true;
-    const char *e = getenv("SDRHIP_ROCTX");
-    if (e && e[0] == '1') {
-      const char *names[] = {"librocprofiler-sdk-roctx.so.1", "libroctx64.so.4", "libroctx64.so"};
-      for (const char *n : names) {
-        void *lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-        if (!lib) continue;
-        r.push = reinterpret_cast<int (*)(const char *)>(dlsym(lib, "roctxRangePushA"));
-        r.pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
-        if (r.push && r.pop) break;
-        r.push = nullptr; r.pop = nullptr;
-      }
-    }
+// resolved once, by whichever thread comes first (a function-local static's initialisation is thread-safe): the nodes may
+// be driven from a Queue worker beside the thread that configured them
+Roctx load_roctx() {
+  Roctx r;
+  const char *e = getenv("SDRHIP_ROCTX");
+  if (!(e && e[0] == '1')) return r;
+  const char *names[] = {"librocprofiler-sdk-roctx.so.1", "libroctx64.so.4", "libroctx64.so"};
+  for (const char *n : names) {
+    void *lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (!lib) continue;
+    r.push = reinterpret_cast<int (*)(const char *)>(dlsym(lib, "roctxRangePushA"));
+    r.pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+    if (r.push && r.pop) break;
+    r.push = nullptr; r.pop = nullptr;
   }
+  return r;
+}
+const Roctx &roctx() {
+  static const Roctx r = load_roctx();
   return r;
 }
 }  // namespace
 
 Range::Range(const char *name) : on(false) {
-  Roctx &r = roctx();
+  const Roctx &r = roctx();
   if (r.push) { r.push(name); on = true; }
 }
 Range::~Range() { if (on) roctx().pop(); }

@@ -449,7 +449,8 @@ __global__ __launch_bounds__(256) void deemph_i16_spec_kernel(const DeemphSpecAr
 #pragma unroll
         for (int k = 0; k < DE_PF; k++) { cu[k] = nx[k]; ol[k] = no[k]; }
       }
-      if (!met) { f = av; unmet = true; }
+      if (c0 >= nch) f = pf;   // an empty segment (P * Lc > nch): its end state IS its start state, exact now — nothing to repair
+      else if (!met) { f = av; unmet = true; }
     }
     // a lane that ran to its segment's end without meeting (a run-in AND a segment of 16 alpha samples each were not enough):
     // this row does not forget — a constant stretch: every run stops inside the rounding dead zone, each on its own value —
@@ -647,16 +648,23 @@ struct sdrhip_deemph {
   // channel (long rows of a filter that forgets fast: the run-in is 16 alpha samples — measured on noise-like rows, two
   // runs meet within about 12 alpha — in whole groups of 64; P is the largest of 32 … 4 whose segments are at least as
   // long as the run-in), 3 the LDS-tiled kernel of rounds 1-2 (SDRHIP_DEEMPH_TILED, tests)
+  // test / timing hooks, read once at create: SDRHIP_DEEMPH_TILED; SDRHIP_DEEMPH_SPEC (0 = the one-lane kernel, else P;
+  // -1: not set); SDRHIP_DEEMPH_WC (the run-in in groups of 64 samples; 0: every guess is checked cold; -1: not set)
+  bool env_tiled = false;
+  int env_spec = -1, env_wc = -1;
+  void read_env() {
+    env_tiled = getenv("SDRHIP_DEEMPH_TILED") != nullptr;
+    if (const char *e = getenv("SDRHIP_DEEMPH_SPEC")) env_spec = std::max(0, atoi(e));
+    if (const char *e = getenv("SDRHIP_DEEMPH_WC")) env_wc = std::max(0, atoi(e));
+  }
   int plan(size_t N, int *lgP_out, int *wc_out) const {
-    if (getenv("SDRHIP_DEEMPH_TILED")) return 3;
+    if (env_tiled) return 3;
     if (alpha == 1) return 0;
-    const char *ev = getenv("SDRHIP_DEEMPH_SPEC");   // (tests / timing: 0 = the one-lane kernel, else P)
-    const char *ew = getenv("SDRHIP_DEEMPH_WC");     // (tests: the run-in in groups of 64 samples; 0: every guess is checked cold)
     int lgP = 0;
-    const int wc = (ew ? atoi(ew) : (int)ceil_div((size_t)16 * alpha, (size_t)64)) * DE_PF, n8 = (int)(N / 8);
-    if (alpha <= 32 && !(ev && atoi(ev) == 0))
+    const int wc = (env_wc >= 0 ? env_wc : (int)ceil_div((size_t)16 * alpha, (size_t)64)) * DE_PF, n8 = (int)(N / 8);
+    if (alpha <= 32 && env_spec != 0)
       for (int l = 5; l >= 2 && !lgP; l--) if ((n8 + (1 << l) - 1) >> l >= wc) lgP = l;
-    if (ev && atoi(ev) > 1 && n8 >= atoi(ev)) { lgP = 0; while ((2 << lgP) <= atoi(ev) && lgP < 6) lgP++; }
+    if (env_spec > 1 && n8 >= env_spec) { lgP = 0; while ((2 << lgP) <= env_spec && lgP < 6) lgP++; }
     if (lgP_out) *lgP_out = lgP;
     if (wc_out) *wc_out = wc;
     return lgP ? 2 : 1;
@@ -776,7 +784,7 @@ int sdrhip_deemph_i16_create(sdrhip_ctx *ctx, int alpha, int channels, size_t ma
     ctx->use();
     sdrhip_deemph *h = new sdrhip_deemph;
     try {
-      h->ctx = ctx; h->alpha = alpha; h->C = channels; h->max_in = max_in;
+      h->ctx = ctx; h->alpha = alpha; h->C = channels; h->max_in = max_in; h->read_env();
       h->avg.alloc(channels); h->avg.zero(ctx->stream);
       SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     } catch (...) { delete h; throw; }

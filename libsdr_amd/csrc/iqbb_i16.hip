@@ -977,6 +977,7 @@ struct sdrhip_iqbb_i16 {
   bool fast8 = false;
   bool use_dma = true;   // path 1, cs16 input: LDS-DMA fed kernel (SDRHIP_IQBB_DMA=0: the register-staged one, tuning)
   bool use_hot = true;   // path 1, calls of >= 3 tiles: the hot kernel (SDRHIP_IQBB_HOT=0: the general kernels only, tuning/tests)
+  int env_tpw = 0, env_wgpcu = 0;   // tuning hooks SDRHIP_IQBB_TPW / SDRHIP_IQBB_WGPCU, read once at create (0: not set)
   int hot_range = -1;    // which compile-time high-plane K-step range of the hot kernel covers ah_mask (-1: none)
   int in_cu8 = 0, real = 0, i8 = 0;   // input kinds: complex<uint8> with AutoCast, real int16 (BaseBand), complex<int8> (IQBaseBand<int8_t>)
   int path = 0, S = 0, cre = 0, cim = 0;   // path 1 = int8-MFMA formulation with S K-steps
@@ -1129,10 +1130,10 @@ struct sdrhip_iqbb_i16 {
     // persistent grid of 4 virtual (4-wave) workgroups per CU = 4 waves per SIMD; a real workgroup is NW / 4 of them.
     // Units of at most 4 tiles so that the static split leaves a short tail.
     int wgpcu = 4;   // virtual (4-wave) workgroups per CU = waves per SIMD
-    { const char *e = getenv("SDRHIP_IQBB_WGPCU"); if (e) wgpcu = std::max(1, atoi(e)); }   // tuning hook (builds with -DK1_MINWAVES=5)
+    if (env_wgpcu) wgpcu = env_wgpcu;   // tuning hook (builds with -DK1_MINWAVES=5)
     const int nvwg = wgpcu * ctx->prop.multiProcessorCount;
     int htpw = 4; while (htpw > 1 && (size_t)ceil_div((size_t)tiles, (size_t)htpw) * C < 4 * (size_t)nvwg) htpw >>= 1;
-    { const char *e = getenv("SDRHIP_IQBB_TPW"); if (e) htpw = std::max(1, atoi(e)); }   // tuning hook
+    if (env_tpw) htpw = env_tpw;   // tuning hook
     ha.tpw = htpw;
     ha.G = (int)ceil_div((size_t)tiles, (size_t)htpw); ha.U = ha.G * C;
     const int vper = NW / 4;
@@ -1174,9 +1175,8 @@ struct sdrhip_iqbb_i16 {
     { int lpg = 1; while (2 * lpg <= 64 && 2 * lpg * GS <= 64) lpg *= 2; int sh = 0; while ((1 << sh) < lpg) sh++; ha.lpg_sh = sh; }
     ha.inv_d = (float)((1.0 / D) * (1.0 - 1.0 / 1048576.0));
     ha.philast = nullptr; ha.philast_stride = 4 * tiles_h;
-    if (epi == SDRHIP_EPI_FM) {
-      const size_t need = (size_t)C * 4 * tiles_h;
-      if (philast.n < need) philast.alloc(need + 1024);
+    if (epi == SDRHIP_EPI_FM) {   // (sized at create for max_in: no allocation, i.e. no device-wide synchronisation, on the call path)
+      SDRHIP_REQUIRE(philast.n >= (size_t)C * 4 * tiles_h, SDRHIP_E_SIZE, "philast holds %zu entries, the call needs %zu", philast.n, (size_t)C * 4 * tiles_h);
       ha.philast = philast.p;
     }
 #ifdef K1_STAMPS
@@ -1185,7 +1185,7 @@ struct sdrhip_iqbb_i16 {
 #endif
     const int nvwg = 4 * ctx->prop.multiProcessorCount;
     int htpw = 4; while (htpw > 1 && (size_t)ceil_div((size_t)tiles_h, (size_t)htpw) * C < 4 * (size_t)nvwg) htpw >>= 1;
-    { const char *e = getenv("SDRHIP_IQBB_TPW"); if (e) htpw = std::max(1, atoi(e)); }   // tuning hook
+    if (env_tpw) htpw = env_tpw;   // tuning hook
     ha.tpw = htpw;
     ha.G = (int)ceil_div((size_t)tiles_h, (size_t)htpw); ha.U = ha.G * C;
     const int grid = std::max(1, std::min(nvwg, std::max(ha.U, C)));   // (every channel's cold slices need a taker too)
@@ -1226,7 +1226,7 @@ struct sdrhip_iqbb_i16 {
     // keep >= ~8 workgroups per CU in flight for balance
     int tpw = 1;
     if (path == 1 || path == 2 || path == 4) { tpw = 8; while (tpw > 1 && (size_t)ceil_div((size_t)tiles, (size_t)tpw) * C < 2048) tpw >>= 1; }
-    { const char *t = getenv("SDRHIP_IQBB_TPW"); if (t && (path == 1 || path == 2 || path == 4)) tpw = std::max(1, atoi(t)); }   // tuning hook
+    if (env_tpw && (path == 1 || path == 2 || path == 4)) tpw = env_tpw;   // tuning hook
     a.tiles = tiles; a.tpw = tpw; a.bt_hi = 0;
     a.lpg = 1; while (a.lpg < 64 && a.lpg * 8 < D) a.lpg <<= 1;
     dim3 grid((unsigned)ceil_div((size_t)tiles, (size_t)tpw), C), block(TPB);
@@ -1245,7 +1245,7 @@ struct sdrhip_iqbb_i16 {
       // (the hot kernel's any-D form took the whole call)
     } else if (path == 3) {
       int tpw3 = 8; while (tpw3 > 1 && (size_t)ceil_div((size_t)tiles, (size_t)tpw3) * C < 2048) tpw3 >>= 1;
-      { const char *t = getenv("SDRHIP_IQBB_TPW"); if (t) tpw3 = std::max(1, atoi(t)); }   // tuning hook
+      if (env_tpw) tpw3 = env_tpw;   // tuning hook
       a.tpw = tpw3;
       dim3 grid3((unsigned)ceil_div((size_t)tiles, (size_t)tpw3), C);
 #define SDRHIP_MFG(S_) do { if (in_cu8 && inc != 0) hipLaunchKernelGGL((iqbb_i16_mfmag_kernel<S_, true, true>), grid3, block, lds_bytes, ctx->stream, a); \
@@ -1354,6 +1354,8 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
         if (high_byte(taps[i]) > 127 || high_byte(-taps[i]) > 127) mfma_ok = false;
       { const char *d = getenv("SDRHIP_IQBB_DMA"); if (d && d[0] == '0') h->use_dma = false; }
       { const char *d = getenv("SDRHIP_IQBB_HOT"); if (d && d[0] == '0') h->use_hot = false; }
+      { const char *e = getenv("SDRHIP_IQBB_TPW"); if (e) h->env_tpw = std::max(1, atoi(e)); }
+      { const char *e = getenv("SDRHIP_IQBB_WGPCU"); if (e) h->env_wgpcu = std::max(1, atoi(e)); }
       const char *force = getenv("SDRHIP_IQBB_PATH");   // "valu" / "mfma" / "mfma16": test hook
       if (force && !strcmp(force, "valu")) mfma_ok = false;
       bool mfma16_ok = !real && !i8 && (decim == R) && (order <= 153);
@@ -1421,6 +1423,10 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
         h->fm[p].alloc(channels); h->fm[p].zero(ctx->stream);
       }
       h->max_out = max_in / decim + 2;
+      if (epilogue == SDRHIP_EPI_FM && h->path == 3 && decim >= 9 && decim <= 512) {   // any-D hot form: one angle per slice of the longest call (launch_anyd_call)
+        const size_t GS = 512 / (size_t)decim, tiles_h = ceil_div(max_in / (size_t)decim + 2, 4 * GS);
+        h->philast.alloc((size_t)channels * 4 * tiles_h + 1024);
+      }
       SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     } catch (...) { delete h; throw; }
     *out = h;
@@ -1428,6 +1434,25 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
 }
 
 }  // namespace
+
+// What IQBaseBand::_reconfigure leaves of the FIR ring (src/baseband.hh:175-177: _ring_offset = 0, the ring's contents
+// stay where they lie), as the history rows (HH_dst entries per channel, oldest first, the newest at the end) of a plan
+// that starts counting at zero: with P = (samples so far) mod order the node afterwards reads the old ring ROTATED —
+// the apparent history, oldest first, is ring[1..order-1], ring[i] = t[order-P+i] (i < P) or t[i-P] (i >= P),
+// t = the last `order` samples in time order (the tail of the source plan's rows).
+static std::vector<uint32_t> reconfigured_ring(const sdrhip_iqbb_i16 *src, int HH_dst) {
+  const int order = src->order, HH = src->HH, P = (int)(src->n0 % (uint64_t)order);
+  hipStream_t st = src->ctx->stream;
+  std::vector<uint32_t> old((size_t)src->C * HH), neu((size_t)src->C * HH_dst, 0u);
+  SDRHIP_CHECK_HIP(hipMemcpyAsync(old.data(), src->hist[src->par].p, old.size() * 4, hipMemcpyDeviceToHost, st));
+  SDRHIP_CHECK_HIP(hipStreamSynchronize(st));
+  for (int c = 0; c < src->C; c++) {
+    const uint32_t *t = old.data() + (size_t)c * HH + (HH - order);
+    uint32_t *d = neu.data() + (size_t)c * HH_dst + (HH_dst - (order - 1));
+    for (int k = 0; k + 1 < order; k++) { const int i = k + 1; d[k] = i < P ? t[order - P + i] : t[i - P]; }
+  }
+  return neu;
+}
 
 extern "C" {
 
@@ -1539,7 +1564,7 @@ int sdrhip_iqbb_i16_reset(sdrhip_iqbb_i16 *h, int keep_history) {
     SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
     h->ctx->use();
     hipStream_t st = h->ctx->stream;
-    // bit 0 of keep_history: the FIR ring survives (rotated, below); bit 1: so does the fused FMDemod's last angle
+    // bit 0 of keep_history: the FIR ring survives (rotated, above); bit 1: so does the fused FMDemod's last angle
     // — IQBaseBand::_reconfigure does not touch the FMDemod node behind it, whose config() (and with it the reset of
     // _last_value, src/demod.hh:210) only runs when the Config the baseband propagates CHANGES (src/node.cc:98-105)
     const bool keep_fm = (keep_history & 2) != 0;
@@ -1548,23 +1573,44 @@ int sdrhip_iqbb_i16_reset(sdrhip_iqbb_i16 *h, int keep_history) {
     if (!keep_history) {
       for (int p = 0; p < 2; p++) h->hist[p].zero(st);
     } else if (h->n0 % (uint64_t)h->order != 0) {
-      // IQBaseBand::_reconfigure resets _ring_offset but leaves the ring contents where they are
-      // (src/baseband.hh:175-177), so the node afterwards reads the old ring ROTATED: with
-      // P = (samples so far) mod order the apparent history, oldest first, is ring[1..order-1],
-      // ring[i] = t[order-P+i] (i < P) or t[i-P] (i >= P), t = the last `order` samples in time order.
-      const int order = h->order, HH = h->HH, P = (int)(h->n0 % (uint64_t)order);
-      std::vector<uint32_t> old((size_t)h->C * HH), neu((size_t)h->C * HH, 0u);
-      SDRHIP_CHECK_HIP(hipMemcpyAsync(old.data(), h->hist[h->par].p, old.size() * 4, hipMemcpyDeviceToHost, st));
-      SDRHIP_CHECK_HIP(hipStreamSynchronize(st));
-      for (int c = 0; c < h->C; c++) {
-        const uint32_t *t = old.data() + (size_t)c * HH + (HH - order);
-        uint32_t *d = neu.data() + (size_t)c * HH + (HH - (order - 1));
-        for (int k = 0; k + 1 < order; k++) { const int i = k + 1; d[k] = i < P ? t[order - P + i] : t[i - P]; }
-      }
+      const std::vector<uint32_t> neu = reconfigured_ring(h, h->HH);
       SDRHIP_CHECK_HIP(hipMemcpyAsync(h->hist[h->par].p, neu.data(), neu.size() * 4, hipMemcpyHostToDevice, st));
       SDRHIP_CHECK_HIP(hipStreamSynchronize(st));
     }
     h->n0 = 0; h->phase0 = 0;
+  });
+}
+
+int sdrhip_iqbb_i16_adopt_state(sdrhip_iqbb_i16 *h, sdrhip_iqbb_i16 *from, int what) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h && from && h != from, SDRHIP_E_INVALID, "two distinct handles are needed");
+    SDRHIP_REQUIRE(h->n0 == 0, SDRHIP_E_INVALID, "the adopting plan must be fresh (no buffer processed since create / reset)");
+    SDRHIP_REQUIRE(h->C == from->C && h->real == from->real && h->i8 == from->i8 && h->in_cu8 == from->in_cu8, SDRHIP_E_INVALID,
+                   "plans differ in channels (%d / %d) or sample kind", h->C, from->C);
+    SDRHIP_REQUIRE(h->ctx->device == from->ctx->device, SDRHIP_E_INVALID, "plans live on different devices");
+    const bool ring = (what & SDRHIP_KEEP_RING) != 0, fmk = (what & SDRHIP_KEEP_FM) != 0, stream = (what & SDRHIP_KEEP_COUNTERS) != 0;
+    SDRHIP_REQUIRE(!ring || h->order == from->order, SDRHIP_E_INVALID, "SDRHIP_KEEP_RING needs equal orders (%d / %d)", h->order, from->order);
+    SDRHIP_REQUIRE(!stream || h->D == from->D, SDRHIP_E_INVALID, "SDRHIP_KEEP_COUNTERS needs equal decimations (%d / %d)", h->D, from->D);
+    h->ctx->use();
+    hipStream_t st = h->ctx->stream;
+    SDRHIP_CHECK_HIP(hipStreamSynchronize(from->ctx->stream));   // (the source plan's last launch wrote the state read here)
+    const size_t C = (size_t)h->C;
+    if (ring && stream) {
+      // the stream goes on: the last `order` samples in time order, as they lie at the end of the source's rows
+      const int order = h->order;
+      SDRHIP_CHECK_HIP(hipMemcpy2DAsync(h->hist[h->par].p + (h->HH - order), (size_t)h->HH * 4, from->hist[from->par].p + (from->HH - order),
+                                        (size_t)from->HH * 4, (size_t)order * 4, C, hipMemcpyDeviceToDevice, st));
+    } else if (ring) {
+      const std::vector<uint32_t> neu = reconfigured_ring(from, h->HH);
+      SDRHIP_CHECK_HIP(hipMemcpyAsync(h->hist[h->par].p, neu.data(), neu.size() * 4, hipMemcpyHostToDevice, st));
+      SDRHIP_CHECK_HIP(hipStreamSynchronize(st));
+    }
+    if (fmk) SDRHIP_CHECK_HIP(hipMemcpyAsync(h->fm[h->par_fm].p, from->fm[from->par_fm].p, C * sizeof(short), hipMemcpyDeviceToDevice, st));
+    if (stream) {   // decimator window (position and partial sum), sample counter and LUT phase go on
+      SDRHIP_CHECK_HIP(hipMemcpyAsync(h->acc[h->par].p, from->acc[from->par].p, C * sizeof(int2), hipMemcpyDeviceToDevice, st));
+      h->n0 = from->n0; h->phase0 = from->phase0;
+    }
+    SDRHIP_CHECK_HIP(hipStreamSynchronize(st));
   });
 }
 

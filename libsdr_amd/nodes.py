@@ -315,6 +315,11 @@ class IQBaseBandI16(_Node):
     def reset(self, keep_history=False, keep_fm=False):
         check(abi.lib().sdrhip_iqbb_i16_reset(self._h, int(bool(keep_history)) | (2 if keep_fm else 0)))
 
+    def adopt_state(self, other, what):
+        """Streaming state of `other` carried into this FRESH plan (abi.KEEP_RING | KEEP_FM | KEEP_COUNTERS): what the
+        reference node keeps when a setter changes the geometry a device plan is made for."""
+        check(abi.lib().sdrhip_iqbb_i16_adopt_state(self._h, other._h, int(what)))
+
     def set_taps(self, taps):
         """setFilterFrequency / setFilterWidth of the reference node: the kernel only."""
         taps = np.ascontiguousarray(taps, np.int32).reshape(-1, 2)

@@ -67,16 +67,44 @@ int main() {
     g1.next(); g2.next();
     cpu_bb.setSubsample(8); gpu_bb.setSubsample(8);            // _reconfigure, same geometry: ring kept
     g1.next(); g2.next();
-    cpu_bb.setSubsample(4); gpu_bb.setSubsample(4);            // _reconfigure with a new decimation: new output Config
+    cpu_bb.setSubsample(4); gpu_bb.setSubsample(4);            // _reconfigure with a new decimation: new output Config, new device plan
     g1.next(); g2.next();
-    CHECK(cpu_out.data.size() > 3000 && cpu_out.data.size() == gpu_out.data.size());
-    // (after the decimation change the reference reads its OLD ring rotated; a new device plan starts from zero
-    // history, so the first `order` input samples' worth of outputs of that last buffer may differ: compare up to there)
-    const size_t same = 511 + 512 + 512 + 511;   // (_reconfigure restarts the decimator: the D+1 first window again)
-    size_t bad = same;
-    for (size_t i = 0; i < same && i < cpu_out.data.size(); i++) if (cpu_out.data[i] != gpu_out.data[i]) { bad = i; break; }
-    if (bad != same) std::printf("first mismatch at output %zu: reference %d, gpu %d\n", bad, cpu_out.data[bad], gpu_out.data[bad]);
-    CHECK(cpu_out.data.size() >= same && bad == same);
+    cpu_bb.setOutputSampleRate(100e3); gpu_bb.setOutputSampleRate(100e3);   // ... and ÷24
+    g1.next(); g2.next();
+    cpu_bb.setCenterFrequency(80e3); gpu_bb.setCenterFrequency(80e3);
+    cpu_bb.setSubsample(8); gpu_bb.setSubsample(8);            // (the output rate set above still rules: ÷24 again, same Config)
+    g1.next(); g2.next();
+    // every output must match: the new device plans take the ring over as _reconfigure leaves it (rotated), the
+    // reference FMDemod behind either node is reset by the same Config changes
+    CHECK(cpu_out.data.size() > 3300 && cpu_out.data.size() == gpu_out.data.size());
+    size_t bad = cpu_out.data.size();
+    for (size_t i = 0; i < cpu_out.data.size() && i < gpu_out.data.size(); i++) if (cpu_out.data[i] != gpu_out.data[i]) { bad = i; break; }
+    if (bad != cpu_out.data.size()) std::printf("first mismatch at output %zu: reference %d, gpu %d\n", bad, cpu_out.data[bad], gpu_out.data[bad]);
+    CHECK(bad == cpu_out.data.size());
+    CHECK(gpu_bb.subSample() == cpu_bb.subSample() && gpu_bb.Source::sampleRate() == cpu_bb.Source::sampleRate());
+  }
+  {   // setOrder mid-stream (src/baseband.hh:69-79: new kernel, new ring — uninitialised in the reference —, nothing else):
+      // once `order` samples have passed the two nodes agree again, i.e. decimator, counters and LUT phase went on
+    const size_t N2 = 4096;
+    IQSigGen<int16_t> g1(Fs, N2), g2(Fs, N2);
+    g1.addSine(100e3, 8000, 0); g1.addSine(-300e3, 6000, 0.3); g2.addSine(100e3, 8000, 0); g2.addSine(-300e3, 6000, 0.3);
+    sdr::IQBaseBand<int16_t> cpu_bb(100e3, 100e3, 50e3, 127, 8); Rec<cs16> cpu_out;
+    sdr::gpu::IQBaseBand<int16_t> gpu_bb(100e3, 100e3, 50e3, 127, 8); Rec<cs16> gpu_out;
+    g1.connect(&cpu_bb, true); cpu_bb.connect(&cpu_out, true);
+    g2.connect(&gpu_bb, true); gpu_bb.connect(&gpu_out, true);
+    g1.next(); g2.next();
+    const size_t before = cpu_out.data.size();
+    cpu_bb.setOrder(161); gpu_bb.setOrder(161);
+    g1.next(); g2.next(); g1.next(); g2.next();
+    CHECK(cpu_out.data.size() == gpu_out.data.size() && cpu_out.data.size() == before + 1024);
+    const size_t skip = (161 + 8) / 8 + 1;   // windows that may still see the reference's uninitialised ring
+    size_t bad = cpu_out.data.size();
+    for (size_t i = 0; i < cpu_out.data.size() && i < gpu_out.data.size(); i++) {
+      if (i >= before && i < before + skip) continue;
+      if (cpu_out.data[i] != gpu_out.data[i]) { bad = i; break; }
+    }
+    if (bad != cpu_out.data.size()) std::printf("setOrder: first mismatch at output %zu\n", bad);
+    CHECK(bad == cpu_out.data.size());
   }
   std::printf("%s (%d failures)\n", failures ? "FAILED" : "OK", failures);
   return failures ? 1 : 0;

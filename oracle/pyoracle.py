@@ -52,6 +52,8 @@ def lib():
             "orc_iqbb_i8_destroy": (None, [vp]),
             "orc_fm_i8": (None, [C.POINTER(C.c_int8), C.c_size_t, C.POINTER(C.c_int16), C.POINTER(C.c_int16)]),
             "orc_iqbb_i16_set_taps": (None, [vp, C.POINTER(C.c_int32)]),
+            "orc_iqbb_i16_set_decim": (None, [vp, C.c_int]),
+            "orc_iqbb_i16_set_order": (None, [vp, C.POINTER(C.c_int32), C.c_int]),
             "orc_iqbb_i16_set_shift": (None, [vp, C.c_uint32, C.c_int]),
             "orc_iqbb_i16_destroy": (None, [vp]),
             "orc_bb_design": (None, [C.c_double, C.c_double, C.c_double, C.c_int, i32p]),
@@ -184,6 +186,17 @@ class IQBaseBandI16:
         behind an emission); the ring is kept — prime it with the `order` samples before that index first."""
         if lib().orc_iqbb_i16_seek(self._h, int(abs_index)) != 0:
             raise ValueError("seek: %d is not right behind an emission (g*D + 1, g >= 1)" % abs_index)
+
+    def set_decim(self, decim):
+        """setSubsample's new decimation; follow with reset() (= _reconfigure)."""
+        self.decim = int(decim)
+        lib().orc_iqbb_i16_set_decim(self._h, self.decim)
+
+    def set_order(self, taps):
+        """setOrder: new kernel and new (zeroed) ring; decimator, counters and LUT phase go on."""
+        taps = np.ascontiguousarray(taps, np.int32).reshape(-1, 2)
+        self.order = taps.shape[0]
+        lib().orc_iqbb_i16_set_order(self._h, _p(taps, C.c_int32), self.order)
 
     def set_taps(self, taps):
         taps = np.ascontiguousarray(taps, np.int32).reshape(self.order, 2)

@@ -597,6 +597,45 @@ static void golden_wav() {
     if (fm) dump("g12_retune_fm", "i16", capf.data, ev + ", " + lens_json("in_lens", used) + ", " + lens_json("out_lens", capf.lens));
     else dump("g12_retune_out", "cs16", flat16(cap.data), ev + ", " + lens_json("in_lens", used) + ", " + lens_json("out_lens", cap.lens));
   }
+
+  // G14 — the node's GEOMETRY changed mid-stream: setSubsample / setOutputSampleRate (src/baseband.hh:106-112) and a new
+  // source Config (another buffer size, :115-132) all run _reconfigure (:156-194: counters and LUT phase reset, the
+  // ring's contents kept where they lie); setOrder (:69-79) swaps kernel and ring and touches nothing else — its new
+  // ring is UNINITIALISED memory, so the outputs whose windows still see it are not defined: the first `undefined_head`
+  // outputs of the feed behind it are written as zeros here and skipped by the tests (the order only grows: a smaller
+  // one can leave _ring_offset beyond the new ring).
+  for (int fm = 0; fm < 2; fm++) {
+    Feeder<cs16> src; src.configure(Fs, 4096);
+    BBProbe bb(100e3, 100e3, 50e3, 127, 8);
+    src.connect(&bb, true);
+    Capture<cs16> cap; Capture<int16_t> capf; FMDemod<int16_t> dem;
+    if (fm) { bb.connect(&dem, true); dem.connect(&capf, true); } else bb.connect(&cap, true);
+    std::vector<size_t> used;
+    size_t off = 0;
+    auto feed = [&](size_t n) { src.feed(&x16[off], n); used.push_back(n); off += n; };
+    feed(4096); feed(3000);
+    bb.setSubsample(4);
+    feed(2000);
+    bb.setOutputSampleRate(100e3);            // D = trunc(2.4e6 / 100e3) = 24
+    feed(3192);
+    src.configure(Fs, 2048);                  // a new source Config: config() -> _reconfigure
+    feed(2048);
+    bb.setOrder(161);
+    const size_t before = fm ? capf.data.size() : cap.data.size();
+    feed(2048);
+    const size_t undefined_head = (161 + 24 + 23) / 24 + 2;   // windows that may still see the new ring's old contents (+1: FM looks one back)
+    std::ostringstream ev;
+    ev << "\"Fs\": 2400000, \"order\": 127, \"decim\": 8, \"undefined_head\": " << undefined_head << ", \"events\": [[\"feed\", 4096], [\"feed\", 3000], "
+          "[\"subsample\", 4], [\"feed\", 2000], [\"orate\", 100000], [\"feed\", 3192], [\"bufsize\", 2048], [\"feed\", 2048], "
+          "[\"order\", 161], [\"feed\", 2048]]";
+    if (fm) {
+      for (size_t i = before; i < before + undefined_head && i < capf.data.size(); i++) capf.data[i] = 0;
+      dump("g14_regeom_fm", "i16", capf.data, ev.str() + ", " + lens_json("in_lens", used) + ", " + lens_json("out_lens", capf.lens));
+    } else {
+      for (size_t i = before; i < before + undefined_head && i < cap.data.size(); i++) cap.data[i] = cs16(0, 0);
+      dump("g14_regeom_out", "cs16", flat16(cap.data), ev.str() + ", " + lens_json("in_lens", used) + ", " + lens_json("out_lens", cap.lens));
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -345,6 +345,19 @@ void orc_iqbb_i16_set_shift(void *h, uint32_t inc, int negative) {
 void orc_iqbb_i16_reset(void *h) {   // _reconfigure (:175-177) + setSampleRate -> _update_lut_incr
   IQBB *s = (IQBB *)h; s->off = 0; s->count = 0; s->lut_count = 0; s->last = C32{0, 0};
 }
+// setSubsample / setOutputSampleRate (src/baseband.hh:106-112): the new _sub_sample, then _reconfigure (call
+// orc_iqbb_i16_reset next); the ring is not touched
+void orc_iqbb_i16_set_decim(void *h, int decim) { ((IQBB *)h)->decim = decim; }
+// setOrder (src/baseband.hh:69-79): _kernel and _ring are REALLOCATED (the new ring is uninitialised memory in the
+// reference; zeros here — outputs are defined again once `order` samples have passed), _update_filter_kernel();
+// _ring_offset, _sample_count, _last and the LUT phase are not touched. (A ring offset beyond the new order is an
+// out-of-bounds write in the reference; here it wraps.)
+void orc_iqbb_i16_set_order(void *h, const int32_t *taps, int order) {
+  IQBB *s = (IQBB *)h;
+  s->order = order; s->k.resize(order); s->ring.assign(order, C32{0, 0});
+  for (int i = 0; i < order; i++) { s->k[i].re = taps[2 * i]; s->k[i].im = taps[2 * i + 1]; }
+  if (s->off >= (size_t)order) s->off = 0;
+}
 
 // Test-bench helper (no counterpart in the reference): put the decimator and the LUT phase where they stand when the NEXT
 // sample is absolute index `abs_index` of a stream, for an index right behind an emission (abs_index = g*D + 1, g >= 1:

@@ -55,6 +55,8 @@ size_t orc_iqbb_i8_process(void *h, const int8_t *in, size_t n, int8_t *out);
 void orc_iqbb_i8_destroy(void *h);
 void orc_fm_i8(const int8_t *in, size_t n, int16_t *out, int16_t *last);
 void orc_iqbb_i16_reset(void *h);   /* what _reconfigure does: counters, NOT the ring */
+void orc_iqbb_i16_set_decim(void *h, int decim);   /* setSubsample: the new decimation (follow with reset = _reconfigure) */
+void orc_iqbb_i16_set_order(void *h, const int32_t *taps, int order);   /* setOrder: new kernel + new (zeroed) ring, counters go on */
 void orc_iqbb_i16_set_taps(void *h, const int32_t *taps);               /* setFilterFrequency / setFilterWidth: kernel only */
 void orc_iqbb_i16_set_shift(void *h, uint32_t lut_inc, int negative);   /* setCenterFrequency: increment, sign, LUT phase = 0 */
 void orc_iqbb_i16_destroy(void *h);

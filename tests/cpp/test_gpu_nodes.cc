@@ -423,6 +423,51 @@ static void testRetuneMidStream() {
   }
 }
 
+// the node's GEOMETRY changed between buffers, against the golden vector cut from the reference node doing the same:
+// setSubsample(4), setOutputSampleRate(100e3) (÷24), a new source buffer size (all _reconfigure: ring kept) and
+// setOrder(161) (kernel and ring only). Every change needs a new device plan; nothing but the outputs the reference
+// itself leaves undefined behind setOrder (`undefined_head` = 10 of the last feed) may differ.
+static void testRegeometryMidStream() {
+  std::vector<int16_t> xin = slurp<int16_t>("g1_iq_cs16.bin"), ref = slurp<int16_t>("g14_regeom_out.bin"), reff = slurp<int16_t>("g14_regeom_fm.bin");
+  CHECK(xin.size() == 2 * 16384 && ref.size() == 2 * 1687 && reff.size() == 1687);
+  const size_t undef_lo = 1687 - 85, undef_hi = undef_lo + 10;
+  for (int fused = 0; fused < 3; fused++) {   // 0: complex out; 1: gpu::FMDemod behind the node; 2: FM fused into the launch
+    Feeder src; src.cfg(Config::Type_cs16, 4096);
+    gpu::IQBaseBand<int16_t> bb(100e3, 100e3, 50e3, 127, 8);
+    gpu::FMDemod<int16_t> fm; Recorder<cs16> out; Recorder<int16_t> outf;
+    if (fused == 2) bb.setDemod(SDRHIP_EPI_FM);
+    src.connect(&bb, true);
+    if (fused == 0) bb.connect(&out, true);
+    else if (fused == 1) { bb.connect(&fm, true); fm.connect(&outf, true); }
+    else bb.connect(&outf, true);
+    cs16 *x = reinterpret_cast<cs16 *>(xin.data());
+    size_t off = 0;
+    src.feed(x + off, 4096); off += 4096; src.feed(x + off, 3000); off += 3000;
+    bb.setSubsample(4);
+    CHECK(bb.Source::sampleRate() == 600000.0);
+    src.feed(x + off, 2000); off += 2000;
+    bb.setOutputSampleRate(100e3);
+    CHECK(bb.subSample() == 24 && bb.Source::sampleRate() == 100000.0);
+    src.feed(x + off, 3192); off += 3192;
+    src.cfg(Config::Type_cs16, 2048);
+    src.feed(x + off, 2048); off += 2048;
+    bb.setOrder(161);
+    CHECK(bb.order() == 161);
+    src.feed(x + off, 2048);
+    bool same = true;
+    if (fused == 0) {
+      CHECK(out.data.size() * 2 == ref.size());
+      for (size_t i = 0; i < out.data.size() && same; i++)
+        if ((i < undef_lo || i >= undef_hi) && (out.data[i].real() != ref[2 * i] || out.data[i].imag() != ref[2 * i + 1])) { same = false; std::printf("regeometry: output %zu differs\n", i); }
+    } else {
+      CHECK(outf.data.size() == reff.size());
+      for (size_t i = 0; i < outf.data.size() && i < reff.size() && same; i++)
+        if ((i < undef_lo || i >= undef_hi) && outf.data[i] != reff[i]) { same = false; std::printf("regeometry (fm %d): output %zu differs\n", fused, i); }
+    }
+    CHECK(same);
+  }
+}
+
 // the documentation example's chain (reference src/sdr.hh:225-240) on the GPU nodes: IQBaseBand<int8_t>(0, 100e3, 16, 0, 100e3)
 // -> FMDemod<int8_t,int16_t>, against the golden vector cut from the reference chain
 static void testInt8Chain() {
@@ -586,6 +631,7 @@ int main(int argc, char **argv) {
     testSdrFmChainCu8();
     testRealBaseBand();
     testRetuneMidStream();
+    testRegeometryMidStream();
     testInt8Chain();
     testFftPlan();
   } catch (std::exception &e) {

@@ -355,7 +355,7 @@ def test_iqbb_i8_batched_random_vs_oracle(ctx, orc):
 
 class _GpuRetune:
     def __init__(self, ctx, Ff, width, Fc, epi, order=127, D=8):
-        self.order = order
+        self.order, self.ctx, self.epi, self.D, self.max_in = order, ctx, epi, D, 4096
         self.node = sa.IQBaseBandI16(ctx, sa.design_iqbb_taps(Ff, width, FS, order), sa.design_freqshift_lut_i16(),
                                      sa.design_freqshift_inc(Fc, FS), Fc < 0, D, max_in=4096, epilogue=epi)
 
@@ -371,6 +371,23 @@ class _GpuRetune:
     def reconfigure(self):
         self.node.reset(keep_history=True, keep_fm=True)   # (the FMDemod behind the baseband sees no Config change)
 
+    def _replan(self, Ff, width, Fc, D, max_in, what):
+        """A new device plan for another geometry that takes the old one's streaming state over."""
+        neu = sa.IQBaseBandI16(self.ctx, sa.design_iqbb_taps(Ff, width, FS, self.order), sa.design_freqshift_lut_i16(),
+                               sa.design_freqshift_inc(Fc, FS), Fc < 0, D, max_in=max_in, epilogue=self.epi)
+        neu.adopt_state(self.node, what)
+        self.node, self.D, self.max_in = neu, D, max_in
+
+    def regeometry(self, D, bufsize, Ff, width, Fc):
+        # _reconfigure (src/baseband.hh:156-194): counters reset, ring kept where it lies; the FMDemod behind the node is
+        # reset (every g14 event of this kind changes the Config it receives)
+        self._replan(Ff, width, Fc, D, bufsize, sa.abi.KEEP_RING)
+
+    def set_order(self, order, Ff, width, Fc):
+        # setOrder (src/baseband.hh:69-79): kernel and ring only
+        self.order = order
+        self._replan(Ff, width, Fc, self.D, self.max_in, sa.abi.KEEP_FM | sa.abi.KEEP_COUNTERS)
+
 
 @pytest.mark.parametrize("which,epi", [("g12_retune_out", sa.EPI_NONE), ("g12_retune_fm", sa.EPI_FM)])
 def test_iqbb_retune_midstream_golden(ctx, golden, which, epi, k1path):
@@ -381,6 +398,68 @@ def test_iqbb_retune_midstream_golden(ctx, golden, which, epi, k1path):
     outs = replay_retune(m, golden.load("g1_iq_cs16"), lambda Ff, w, Fc: _GpuRetune(ctx, Ff, w, Fc, epi))
     assert [len(o) for o in outs] == m["out_lens"]
     assert np.array_equal(np.concatenate(outs), golden.load(which))
+
+
+@pytest.mark.parametrize("which,epi", [("g14_regeom_out", sa.EPI_NONE), ("g14_regeom_fm", sa.EPI_FM)])
+def test_iqbb_regeometry_midstream_golden(ctx, golden, which, epi, k1path):
+    """The reference node's GEOMETRY changed between buffers — setSubsample(4), setOutputSampleRate (÷24), a new source
+    buffer size (all _reconfigure: the ring survives, rotated) and setOrder(161) (kernel and ring only; decimator, counters
+    and LUT phase go on): every change needs a new device plan, which adopts the old plan's state
+    (sdrhip_iqbb_i16_adopt_state). Every output the reference defines must match."""
+    from test_oracle_golden import replay_retune, defined_mask
+    m = golden.meta(which)
+    ok = defined_mask(m)
+    outs = replay_retune(m, golden.load("g1_iq_cs16"), lambda Ff, w, Fc: _GpuRetune(ctx, Ff, w, Fc, epi))
+    assert [len(o) for o in outs] == m["out_lens"]
+    want = golden.load(which)
+    if epi == sa.EPI_NONE:
+        want = want.reshape(-1, 2)
+    assert np.array_equal(np.concatenate(outs)[ok], want[ok])
+
+
+def test_iqbb_adopt_state_vs_oracle(ctx, orc, k1path):
+    """adopt_state over many channels and plan pairs (÷8 hot form -> any-D form -> general form -> long filter), ragged
+    calls, against the oracle: _reconfigure's rotated ring for every ring position, setOrder's continuing decimator."""
+    rng = np.random.default_rng(77)
+    C, lut = 5, sa.design_freqshift_lut_i16()
+    x = rng.integers(-20000, 20000, (C, 40000, 2)).astype(np.int16)
+    inc = sa.design_freqshift_inc(-150e3, FS)
+    for epi in (sa.EPI_NONE, sa.EPI_FM, sa.EPI_USB):
+        order, D = 127, 8
+        taps = sa.design_iqbb_taps(-150e3, 60e3, FS, order)
+        node = sa.IQBaseBandI16(ctx, taps, lut, inc, True, D, channels=C, max_in=8192, epilogue=epi)
+        refs = [orc.IQBaseBandI16(taps, lut, inc, True, D) for _ in range(C)]
+        fms = [orc.FMDemodI16() for _ in range(C)]
+        off = 0
+        steps = [("feed", 5000), ("geom", 12), ("feed", 6001), ("geom", 3), ("feed", 777), ("order", 200), ("feed", 8000),
+                 ("geom", 8), ("feed", 4100), ("order", 300), ("feed", 5003), ("geom", 125), ("feed", 8192)]
+        for kind, v in steps:
+            if kind == "feed":
+                y = node.process(x[:, off:off + v])
+                for c in range(C):
+                    r = refs[c].process(x[c, off:off + v])
+                    if epi == sa.EPI_FM:
+                        r = fms[c].process(r)
+                    elif epi == sa.EPI_USB:
+                        r = orc.usb_i16(r)
+                    assert np.array_equal(y[c], r), (epi, kind, v, off, c)
+                off += v
+            elif kind == "geom":
+                D = v
+                neu = sa.IQBaseBandI16(ctx, taps, lut, inc, True, D, channels=C, max_in=8192, epilogue=epi)
+                neu.adopt_state(node, sa.abi.KEEP_RING)
+                node = neu
+                for c in range(C):
+                    refs[c].set_decim(D); refs[c].set_taps(taps); refs[c].set_shift(inc, True); refs[c].reset()
+                fms = [orc.FMDemodI16() for _ in range(C)]
+            else:
+                order = v
+                taps = sa.design_iqbb_taps(-150e3, 60e3, FS, order)
+                neu = sa.IQBaseBandI16(ctx, taps, lut, inc, True, D, channels=C, max_in=8192, epilogue=epi)
+                neu.adopt_state(node, sa.abi.KEEP_FM | sa.abi.KEEP_COUNTERS)
+                node = neu
+                for c in range(C):
+                    refs[c].set_order(taps)
 
 
 # ---- "next" rows (SURVEY §8f): cu8 input with AutoCast fused into the K1 load, FMDeemph behind the demodulator ----

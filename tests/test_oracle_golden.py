@@ -320,10 +320,14 @@ def test_bb_real_i16(golden, orc, case, inp):
 
 # ---- mid-stream retuning (src/baseband.hh:82-112): the reference node's setters between buffers -------------------
 
-def replay_retune(m, x, make_node, demod=None):
-    """Replays the manifest's event list ("feed n" / "center Fc" / "filter Ff width" / "reconfigure") on a node made by
-    make_node(taps, lut_inc, negative) with set_taps / set_shift / reset; returns the outputs per feed."""
-    Fs, order, Fc, Ff, width = float(m["Fs"]), m["order"], 100e3, 100e3, 50e3
+def replay_retune(m, x, make_node, demod=None, demod_reset=None):
+    """Replays the manifest's event list on a node made by make_node(Ff, width, Fc): "feed n" / "center Fc" /
+    "filter Ff width" / "reconfigure" (set_taps / set_shift / reset) and, g14, the events that change what a device plan
+    is made for: "subsample D" / "orate Fs_out" / "bufsize n" (each runs _reconfigure: node.regeometry(D, bufsize), and
+    the FMDemod behind the node is reset because the Config it receives changes) and "order n" (node.set_order(n):
+    kernel and ring only). Returns the outputs per feed."""
+    Fs, Fc, Ff, width = float(m["Fs"]), 100e3, 100e3, 50e3
+    D, bufsize = m["decim"], 4096
     node, outs, off = None, [], 0
     for ev in m["events"]:
         if ev[0] == "feed":
@@ -340,7 +344,33 @@ def replay_retune(m, x, make_node, demod=None):
             node.set_filter(Ff, width)
         elif ev[0] == "reconfigure":
             node.set_filter(Ff, width); node.set_shift_hz(Fc); node.reconfigure()
+        elif ev[0] in ("subsample", "orate", "bufsize"):
+            if ev[0] == "subsample":
+                D = int(ev[1])
+            elif ev[0] == "orate":
+                D = max(1, int(int(Fs) / float(ev[1])))   # src/baseband.hh:159-162
+            else:
+                bufsize = int(ev[1])
+            node.regeometry(D, bufsize, Ff, width, Fc)
+            if demod_reset:
+                demod_reset()
+        elif ev[0] == "order":
+            node.set_order(int(ev[1]), Ff, width, Fc)
     return outs
+
+
+def defined_mask(m):
+    """True for every output of a g14 fixture that the reference defines (setOrder's new ring is uninitialised memory:
+    the first `undefined_head` outputs of the feed behind it are not)."""
+    lens, ok = m["out_lens"], np.ones(sum(m["out_lens"]), bool)
+    feed = -1
+    for ev in m["events"]:
+        if ev[0] == "feed":
+            feed += 1
+        elif ev[0] == "order":
+            a = sum(lens[:feed + 1])
+            ok[a:a + m["undefined_head"]] = False
+    return ok
 
 
 class _OrcRetune:
@@ -359,6 +389,31 @@ class _OrcRetune:
 
     def reconfigure(self):
         self.bb.reset()
+
+    def regeometry(self, D, bufsize, Ff, width, Fc):   # _reconfigure: kernel, LUT increment, counters; the ring stays
+        self.bb.set_decim(D)
+        self.set_filter(Ff, width); self.set_shift_hz(Fc); self.bb.reset()
+
+    def set_order(self, order, Ff, width, Fc):
+        self.order = order
+        self.bb.set_order(self.orc.iqbb_design(Ff, width, FS, order))
+
+
+def test_iqbb_regeometry_midstream(golden, orc):
+    """g14: setSubsample / setOutputSampleRate / a new source Config (all _reconfigure, ring kept) and setOrder."""
+    x = golden.load("g1_iq_cs16")
+    m = golden.meta("g14_regeom_out")
+    ok = defined_mask(m)
+    assert ok.sum() == len(ok) - m["undefined_head"]
+    outs = replay_retune(m, x, lambda Ff, w, Fc: _OrcRetune(orc, Ff, w, Fc))
+    assert [len(o) for o in outs] == m["out_lens"]
+    assert np.array_equal(np.concatenate(outs)[ok], golden.load("g14_regeom_out").reshape(-1, 2)[ok])
+    fm = [orc.FMDemodI16()]
+    def fm_reset():
+        fm[0] = orc.FMDemodI16()
+    m = golden.meta("g14_regeom_fm")
+    outs = replay_retune(m, x, lambda Ff, w, Fc: _OrcRetune(orc, Ff, w, Fc), demod=lambda y: fm[0].process(y), demod_reset=fm_reset)
+    assert np.array_equal(np.concatenate(outs)[ok], golden.load("g14_regeom_fm")[ok])
 
 
 def test_iqbb_retune_midstream(golden, orc):
