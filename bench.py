@@ -222,7 +222,7 @@ class Telemetry:
             devs = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))[:1]
         for d in devs[:1]:
             for h in sorted(glob.glob(os.path.join(d, "hwmon", "hwmon*"))):
-                for key, names in (("sclk_hz", ["freq1_input"]), ("power_uw", ["power1_average", "power1_input"])):
+                for key, names in (("sclk_hz", ["freq1_input"]), ("power_uw", ["power1_average", "power1_input"]), ("power_cap_uw", ["power1_cap"])):
                     for nm in names:
                         f = os.path.join(h, nm)
                         if key not in self.files and os.access(f, os.R_OK):
@@ -277,8 +277,10 @@ class Telemetry:
             self._thr.join(timeout=2.0)
             self._thr = None
         avg = lambda v: round(sum(v) / len(v), 1) if v else None
+        cap = self._read(self.files["power_cap_uw"]) if "power_cap_uw" in self.files else None
         return {"sclk_mhz": avg(self.sclk), "sclk_mhz_min": round(min(self.sclk), 1) if self.sclk else None,
-                "power_w": avg(self.power), "samples": max(len(self.sclk), len(self.power)),
+                "power_w": avg(self.power), "power_cap_w": round(int(cap) / 1e6, 1) if cap and cap.strip().isdigit() else None,
+                "samples": max(len(self.sclk), len(self.power)),
                 "source": {k: v for k, v in self.files.items()} or None}
 
 
@@ -823,6 +825,7 @@ def run(a):
         if telemetry:   # the clock and power the chip HELD over the sustained phase (rank 0's device)
             rf = res["roofline"]
             rf["sclk_mhz"], rf["sclk_mhz_min"], rf["power_w"] = telemetry["sclk_mhz"], telemetry["sclk_mhz_min"], telemetry["power_w"]
+            rf["power_cap_w"] = telemetry["power_cap_w"]   # (the socket's limit: a kernel at it runs at the clock the limit allows)
             rf["telemetry"] = {"samples": telemetry["samples"], "phase": "sustained", "source": telemetry["source"]}
     if use_dist:
         dist.barrier()

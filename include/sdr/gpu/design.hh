@@ -127,59 +127,67 @@ inline int fmDeemphAlpha(double sampleRate) {
   return int(round(1.0 / ((1.0 - exp(-1.0 / (sampleRate * 75e-6))))));
 }
 
-/** Time-domain kernel of the FFT filter, N complex floats. The modulation phase is rounded to
- * float before the exponential, as in the reference (a double phase is 3e-5 off). */
-inline void fftFilterKernel(int N, double fmin, double fmax, double sampleRate, float *h) {
+/** Time-domain kernel of the FFT filter, N complex Scalars: sinc_flt_kernel<Scalar> + FilterSource::_updateFilter's band
+ * clamp (reference src/filternode.hh:18-28,186-196). The value is a complex<Scalar> from the first assignment on, so for
+ * float the modulation phase is rounded to float before the exponential (a double phase is 3e-5 off). */
+template <class Scalar>
+inline void fftFilterKernel(int N, double fmin, double fmax, double sampleRate, Scalar *h) {
   const double lo = std::max(fmin, -sampleRate / 2), hi = std::min(fmax, sampleRate / 2);
   const double bw = hi - lo, fc = lo + bw / 2;
   const int c = N / 2;
   for (int i = 0; i < N; i++) {
-    std::complex<float> v;
+    std::complex<Scalar> v;
     if (c == i) v = M_PI * (bw / sampleRate);
     else v = std::sin(M_PI * (bw / sampleRate) * (i - c)) / (i - c);
-    v *= std::exp(std::complex<float>(0.0, (2 * M_PI * fc * i) / sampleRate));
+    v *= std::exp(std::complex<Scalar>(0.0, (2 * M_PI * fc * i) / sampleRate));
     v *= (0.42 - 0.5 * cos((2 * M_PI * i) / N) + 0.08 * cos((4 * M_PI * i) / N));
     h[2 * i] = v.real();
     h[2 * i + 1] = v.imag();
   }
 }
 
-/** In-place iterative radix-2 DFT in double (host only; n a power of two; sign -1 = forward). */
+/** DFT in double of any length (host only; sign -1 = forward): Cooley-Tukey over the smallest prime factor, the factor's
+ * own small DFTs written out as sums; a prime length is a plain sum. */
 inline void dft(std::vector< std::complex<double> > &a, int sign) {
   const size_t n = a.size();
-  for (size_t i = 1, j = 0; i < n; i++) {
-    size_t bit = n >> 1;
-    for (; j & bit; bit >>= 1) j ^= bit;
-    j ^= bit;
-    if (i < j) std::swap(a[i], a[j]);
-  }
-  for (size_t len = 2; len <= n; len <<= 1) {
-    for (size_t k = 0; k < len / 2; k++) {
-      const double ang = sign * 2.0 * M_PI * double(k) / double(len);
-      const std::complex<double> w(std::cos(ang), std::sin(ang));
-      for (size_t s = 0; s < n; s += len) {
-        const std::complex<double> u = a[s + k], t = w * a[s + k + len / 2];
-        a[s + k] = u + t;
-        a[s + k + len / 2] = u - t;
-      }
+  if (n < 2) return;
+  size_t p = n;
+  for (size_t q = 2; q * q <= n; q++) if (n % q == 0) { p = q; break; }
+  const size_t m = n / p;
+  std::vector< std::vector< std::complex<double> > > part(p);
+  if (m > 1)
+    for (size_t r = 0; r < p; r++) {
+      part[r].resize(m);
+      for (size_t i = 0; i < m; i++) part[r][i] = a[i * p + r];
+      dft(part[r], sign);
     }
+  std::vector< std::complex<double> > out(n);
+  for (size_t k = 0; k < n; k++) {
+    std::complex<double> acc(0, 0);
+    for (size_t r = 0; r < p; r++) {
+      const double ang = sign * 2.0 * M_PI * double((r * k) % n) / double(n);
+      acc += (m > 1 ? part[r][k % m] : a[r]) * std::complex<double>(std::cos(ang), std::sin(ang));
+    }
+    out[k] = acc;
   }
+  a.swap(out);
 }
 
-/** Spectrum the FilterSource multiplies with: K = DFT_2N([h, 0]) / ||K||_2, 2N complex floats.
- * The reference computes this DFT with FFTW3f (un-vendored): any correct DFT is within float
- * rounding of it. */
-inline void fftFilterSpectrum(int N, const float *h, float *K) {
+/** Spectrum the FilterSource multiplies with: K = DFT_2N([h, 0]) / ||K||_2, 2N complex Scalars
+ * (src/filternode.hh:197-202; the norm accumulates real(conj(k) k) in double, src/buffer.hh:182-188).
+ * The reference computes this DFT with FFTW3 (un-vendored): any correct DFT is within rounding of it. */
+template <class Scalar>
+inline void fftFilterSpectrum(int N, const Scalar *h, Scalar *K) {
   std::vector< std::complex<double> > a(2 * size_t(N));
   for (int i = 0; i < N; i++) a[i] = std::complex<double>(h[2 * i], h[2 * i + 1]);
   dft(a, -1);
   double e = 0;
   for (size_t i = 0; i < a.size(); i++) {
-    K[2 * i] = float(a[i].real());
-    K[2 * i + 1] = float(a[i].imag());
+    K[2 * i] = Scalar(a[i].real());
+    K[2 * i + 1] = Scalar(a[i].imag());
     e += K[2 * i] * K[2 * i] + K[2 * i + 1] * K[2 * i + 1];
   }
-  const float d = float(std::sqrt(e));
+  const Scalar d = Scalar(std::sqrt(e));
   for (size_t i = 0; i < 2 * a.size(); i++) K[i] /= d;
 }
 

@@ -7,7 +7,7 @@
 //   sdr::gpu::FIRLowPass<complex<int16|float>>  <->  sdr::FIRLowPass<...>            src/firfilter.hh:117-289
 //   sdr::gpu::FMDemod<int16_t>, AMDemod<S>, USBDemod<S>  <->  same names             src/demod.hh:18-264
 //   sdr::gpu::SubSample<complex<...>>       <->  sdr::SubSample<...>                 src/subsample.hh:16-116
-//   sdr::gpu::FilterNode<float>             <->  sdr::FilterNode<float>              src/filternode.hh:232-284
+//   sdr::gpu::FilterNode<float|double>      <->  sdr::FilterNode<Scalar>             src/filternode.hh:230-284
 //   sdr::gpu::FFT, FFTPlan<float|double>    <->  sdr::FFT, sdr::FFTPlan<...>        src/fftplan.hh, src/fftplan_fftw3.hh
 //   sdr::gpu::ChannelBank<int16_t>          many IQBaseBand(+demod) channels in ONE batched kernel launch;
 //                                           sink(c)/source(c) per channel like Combine::sink(i) (src/combine.hh:66-150)
@@ -734,13 +734,31 @@ protected:
 };
 
 // =================================================================================================
-// FilterNode<float>: FFT filter bank (one forward transform's worth of input, several band filters)
+// FilterNode<float|double>: FFT filter bank (one forward transform's worth of input, several band filters)
 // =================================================================================================
-template <class Scalar> class FilterNode;
+namespace detail {
+/** The complex<float> / complex<double> entry points of the FFT filter behind one set of names. */
+template <class Scalar> struct FftConvApi;
+template <> struct FftConvApi<float> {
+  static int create(sdrhip_ctx *c, int fft, const float *K, int bands, size_t max_in, sdrhip_fftconv **out) {
+    return sdrhip_fftconv_create_bank(c, SDRHIP_FFTCONV_OLA, fft, K, 0, bands, 1, max_in, out); }
+  static int setKernel(sdrhip_fftconv *h, int band, const float *K) { return sdrhip_fftconv_set_kernel(h, band, K); }
+  static int process(sdrhip_fftconv *h, const float *in, size_t n, float *out) { return sdrhip_fftconv_process(h, in, n, 0, out, 0); }
+};
+template <> struct FftConvApi<double> {
+  static int create(sdrhip_ctx *c, int fft, const double *K, int bands, size_t max_in, sdrhip_fftconv **out) {
+    return sdrhip_fftconv_f64_create_bank(c, SDRHIP_FFTCONV_OLA, fft, K, 0, bands, 1, max_in, out); }
+  static int setKernel(sdrhip_fftconv *h, int band, const double *K) { return sdrhip_fftconv_f64_set_kernel(h, band, K); }
+  static int process(sdrhip_fftconv *h, const double *in, size_t n, double *out) { return sdrhip_fftconv_f64_process(h, in, n, 0, out, 0); }
+};
+}  // namespace detail
 
-template <>
-class FilterNode<float> {
+/** Drop-in for sdr::FilterNode<Scalar>, Scalar = float or double (reference src/filternode.hh:230-284), any block size
+ * whose FFT (2 x block_size points) has no prime factor above 13 (:235: `FilterNode(size_t block_size=1024)`). */
+template <class Scalar>
+class FilterNode {
 public:
+  typedef std::complex<Scalar> CScalar;
   /** One band of the bank: a Source of complex<float> buffers (role of FilterSource, src/filternode.hh:105-227). */
   class Band : public Source {
   public:
@@ -760,7 +778,7 @@ public:
     FilterNode *_p;
     size_t _index;
     double _fmin, _fmax;
-    Buffer<cf32> _buffer;
+    Buffer<CScalar> _buffer;
   };
 
   explicit FilterNode(size_t block_size = 1024, int device = 0) : _block(block_size), _device(device), _plan(0), _sink(this) {}
@@ -770,7 +788,7 @@ public:
   }
 
   /** The input of the bank. Unlike the reference (whose BufferNode crashes: SURVEY fact 7) any buffer size is accepted. */
-  Sink<cf32> *sink() { return &_sink; }
+  Sink<CScalar> *sink() { return &_sink; }
   /** Adds a band [fmin, fmax]; the returned Source emits the filtered stream. Adding a band to a configured bank makes
    * a new device plan (the bands' overlap history restarts). */
   Band *addFilter(double fmin, double fmax) {
@@ -781,8 +799,8 @@ public:
   }
 
 protected:
-  void _kernelOf(const Band *b, float *K) const {   // sinc_flt_kernel + FilterSource::_updateFilter (:18-28,186-203)
-    std::vector<float> h(2 * _block);
+  void _kernelOf(const Band *b, Scalar *K) const {   // sinc_flt_kernel + FilterSource::_updateFilter (:18-28,186-203)
+    std::vector<Scalar> h(2 * _block);
     design::fftFilterKernel(int(_block), b->_fmin, b->_fmax, _cfg.sampleRate(), h.data());
     design::fftFilterSpectrum(int(_block), h.data(), K);
   }
@@ -792,50 +810,50 @@ protected:
     _cfg = cfg;
     if (_plan) { sdrhip_fftconv_destroy(_plan); _plan = 0; }
     if (_bands.empty()) return;
-    std::vector<float> K(4 * _block * _bands.size());
+    std::vector<Scalar> K(4 * _block * _bands.size());
     for (size_t b = 0; b < _bands.size(); b++) _kernelOf(_bands[b], K.data() + b * 4 * _block);
-    detail::configCheck(sdrhip_fftconv_create_bank(Device::get(_device), SDRHIP_FFTCONV_OLA, int(2 * _block), K.data(), 0,
-                                                   int(_bands.size()), 1, cfg.bufferSize(), &_plan), "FFT filter");
+    detail::configCheck(detail::FftConvApi<Scalar>::create(Device::get(_device), int(2 * _block), K.data(), int(_bands.size()),
+                                                           cfg.bufferSize(), &_plan), "FFT filter");
     _stage.resize(2 * cfg.bufferSize() * _bands.size());
     for (size_t b = 0; b < _bands.size(); b++) {
       _bands[b]->_buffer.unref();
-      _bands[b]->_buffer = Buffer<cf32>(cfg.bufferSize());
-      _bands[b]->setConfig(Config(Config::typeId<cf32>(), cfg.sampleRate(), cfg.bufferSize(), 1));
+      _bands[b]->_buffer = Buffer<CScalar>(cfg.bufferSize());
+      _bands[b]->setConfig(Config(Config::typeId<CScalar>(), cfg.sampleRate(), cfg.bufferSize(), 1));
     }
   }
   void _bandChanged(size_t index) {
     if (!_plan) return;
-    std::vector<float> K(4 * _block);
+    std::vector<Scalar> K(4 * _block);
     _kernelOf(_bands[index], K.data());
-    detail::configCheck(sdrhip_fftconv_set_kernel(_plan, int(index), K.data()), "FFT filter");
+    detail::configCheck(detail::FftConvApi<Scalar>::setKernel(_plan, int(index), K.data()), "FFT filter");
   }
-  void _run(const Buffer<cf32> &in) {
+  void _run(const Buffer<CScalar> &in) {
     if (!_plan || in.size() * 2 * _bands.size() > _stage.size()) return;
     // a band whose output buffer is still referenced downstream drops this block (src/baseband.hh:141-150 rule); the
     // bank still runs, so that every band's overlap history stays aligned with the input
-    if (!detail::processOk(sdrhip_fftconv_process(_plan, reinterpret_cast<const float *>(in.data()), in.size(), 0, _stage.data(), 0),
+    if (!detail::processOk(detail::FftConvApi<Scalar>::process(_plan, reinterpret_cast<const Scalar *>(in.data()), in.size(), _stage.data()),
                            "gpu::FilterNode")) return;
     for (size_t b = 0; b < _bands.size(); b++) {
       Band *bd = _bands[b];
       if (!bd->_buffer.isUnused()) continue;
-      memcpy(bd->_buffer.data(), _stage.data() + b * 2 * in.size(), in.size() * sizeof(cf32));
+      memcpy(bd->_buffer.data(), _stage.data() + b * 2 * in.size(), in.size() * sizeof(CScalar));
       bd->send(bd->_buffer.head(in.size()), false);
     }
   }
 
-  class In : public Sink<cf32> {
+  class In : public Sink<CScalar> {
   public:
     explicit In(FilterNode *p) : _p(p) {}
     virtual void config(const Config &src_cfg) {
       if (Config::Type_UNDEFINED == src_cfg.type() || 0 == src_cfg.sampleRate() || 0 == src_cfg.bufferSize()) return;
-      if (Config::typeId<cf32>() != src_cfg.type()) {
+      if (Config::typeId<CScalar>() != src_cfg.type()) {
         ConfigError err;
-        err << "Can not configure filter-sink: Invalid type " << src_cfg.type() << ", expected " << Config::typeId<cf32>();
+        err << "Can not configure filter-sink: Invalid type " << src_cfg.type() << ", expected " << Config::typeId<CScalar>();
         throw err;
       }
       _p->_configure(src_cfg);
     }
-    virtual void process(const Buffer<cf32> &buffer, bool) { _p->_run(buffer); }
+    virtual void process(const Buffer<CScalar> &buffer, bool) { _p->_run(buffer); }
     FilterNode *_p;
   };
   friend class Band;
@@ -845,7 +863,7 @@ protected:
   sdrhip_fftconv *_plan;
   In _sink;
   std::vector<Band *> _bands;
-  std::vector<float> _stage;
+  std::vector<Scalar> _stage;
 };
 
 // =================================================================================================
@@ -1091,10 +1109,14 @@ public:
 protected:
   static int _dtype() { return sizeof(Scalar) == 8 ? SDRHIP_T_CF64 : SDRHIP_T_CF32; }
   void _check() const {
+    // any size the device plans: one transform in one workgroup's LDS, prime factors 2 ... 13 (csrc/fftgen.hpp)
     const size_t n = _in.size(), nmax = sizeof(Scalar) == 8 ? 8192 : 16384;
-    if (n < 4 || n > nmax || (n & (n - 1))) {
+    size_t rest = n;
+    const size_t primes[] = {2, 3, 5, 7, 11, 13};
+    for (size_t q = 0; q < 6 && rest > 1; q++) while (rest % primes[q] == 0) rest /= primes[q];
+    if (n < 1 || n > nmax || rest != 1) {
       ConfigError err;
-      err << "Can not construct FFT plan: the device plan needs a power of two in [4, " << nmax << "], got " << n;
+      err << "Can not construct FFT plan: the device plans sizes up to " << nmax << " whose prime factors are 2, 3, 5, 7, 11 or 13, got " << n;
       throw err;
     }
   }

@@ -118,6 +118,9 @@ int sdrhip_design_fir_lowpass(int order, double upper_freq, double sample_rate, 
 int sdrhip_design_fftfilt_kernel(int n, double fmin, double fmax, double sample_rate, float *h);
 /* FilterSource::_updateFilter (src/filternode.hh:197-202): 2N x (re,im) float spectrum */
 int sdrhip_design_fftfilt_spectrum(int n, const float *h, float *spectrum);
+/* the same for FilterSource<double> (the filter classes are templates over Scalar, src/filternode.hh:16-17,104-105) */
+int sdrhip_design_fftfilt_kernel_f64(int n, double fmin, double fmax, double sample_rate, double *h);
+int sdrhip_design_fftfilt_spectrum_f64(int n, const double *h, double *spectrum);
 
 /* ---- K1: IQBaseBand<int16_t> (+ fused demodulator) ---------------------------------------- */
 /* Replaces IQBaseBand<int16_t>::_process/_filter_ring (reference src/baseband.hh:198-236) and
@@ -321,10 +324,27 @@ int sdrhip_fftconv_process_dev(sdrhip_fftconv *h, const float *in_dev, size_t n_
                                float *out_dev, size_t out_stride);
 int sdrhip_fftconv_reset(sdrhip_fftconv *h);
 int sdrhip_fftconv_destroy(sdrhip_fftconv *h);
-/* plain batched DFT of the library's own FFT (tests): sign -1 forward / +1 backward, unnormalised */
+/* FFT sizes: the reference plans ANY size (FilterNode(size_t block_size = 1024), src/filternode.hh:235-245;
+ * fftw_plan_dft_1d(in.size(), ...), src/fftplan_fftw3.hh:34-36). Powers of two from 4 to 16384 run the tuned complex<float>
+ * kernels (every BASELINE configuration); any other fft_size whose prime factors are 2, 3, 5, 7, 11 or 13 — and every size in
+ * complex<double> — runs the general in-LDS mixed-radix plan (csrc/fftgen.hpp; one transform must fit one workgroup's LDS:
+ * up to 16384 points in float, 8192 in double). A size with a larger prime factor is SDRHIP_E_UNSUPPORTED.
+ *
+ * FilterNode<double> (the filter classes are templates over Scalar, src/filternode.hh:30-32,102-104,230-232): the same
+ * plan on complex<double> buffers; kernels / spectra are doubles (sdrhip_design_fftfilt_*_f64). bands / reset / destroy
+ * are the calls above; a handle made here refuses the complex<float> entry points and vice versa. */
+int sdrhip_fftconv_f64_create_bank(sdrhip_ctx *ctx, int mode, int fft_size, const double *kernels, int n_taps, int n_bands,
+                                   int channels, size_t max_in, sdrhip_fftconv **out);
+int sdrhip_fftconv_f64_set_kernel(sdrhip_fftconv *h, int band, const double *kernel);
+int sdrhip_fftconv_f64_process(sdrhip_fftconv *h, const double *in_host, size_t n_in, size_t in_stride,
+                               double *out_host, size_t out_stride);
+int sdrhip_fftconv_f64_process_dev(sdrhip_fftconv *h, const double *in_dev, size_t n_in, size_t in_stride,
+                                   double *out_dev, size_t out_stride);
+/* plain batched DFT of the library's own FFT (FFTPlan<float>): sign -1 forward / +1 backward, unnormalised; any n of the
+ * factors 2 ... 13 up to 16384 */
 int sdrhip_fft_c2c(sdrhip_ctx *ctx, int n, int sign, int batch, const float *in_dev, float *out_dev);
-/* FFTPlan<double> (reference src/fftplan_fftw3.hh:12-76): the same on complex<double>, n a power of two in [2, 8192]
- * (in-LDS radix-2, double arithmetic, twiddles from a host table made in long double). */
+/* FFTPlan<double> (reference src/fftplan_fftw3.hh:12-76): the same on complex<double>, any n of the factors 2 ... 13 up
+ * to 8192 (in LDS, double arithmetic, roots from a host table made in long double). */
 int sdrhip_fft_c2c_f64(sdrhip_ctx *ctx, int n, int sign, int batch, const double *in_dev, double *out_dev);
 /* FFT::exec / FFTPlan<Scalar>::operator() on HOST buffers (reference src/fftplan.hh:22-36): one transform of n points,
  * dtype SDRHIP_T_CF32 or SDRHIP_T_CF64, sign -1 = FFT::FORWARD, +1 = FFT::BACKWARD, unnormalised like FFTW. in == out

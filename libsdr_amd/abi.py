@@ -138,6 +138,12 @@ def lib():
             "sdrhip_fftconv_create_bank": (C.c_int, [vp, C.c_int, C.c_int, f32p, C.c_int, C.c_int, C.c_int, sz, pvp]),
             "sdrhip_fftconv_bands": (C.c_int, [vp, C.POINTER(C.c_int)]),
             "sdrhip_fftconv_set_kernel": (C.c_int, [vp, C.c_int, f32p]),
+            "sdrhip_design_fftfilt_kernel_f64": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_double, f64p]),
+            "sdrhip_design_fftfilt_spectrum_f64": (C.c_int, [C.c_int, f64p, f64p]),
+            "sdrhip_fftconv_f64_create_bank": (C.c_int, [vp, C.c_int, C.c_int, f64p, C.c_int, C.c_int, C.c_int, sz, pvp]),
+            "sdrhip_fftconv_f64_set_kernel": (C.c_int, [vp, C.c_int, f64p]),
+            "sdrhip_fftconv_f64_process": (C.c_int, [vp, vp, sz, sz, vp, sz]),
+            "sdrhip_fftconv_f64_process_dev": (C.c_int, [vp, vp, sz, sz, vp, sz]),
             "sdrhip_comm_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, pvp]),
             "sdrhip_comm_size": (C.c_int, [vp, C.POINTER(C.c_int)]),
             "sdrhip_comm_ctx": (C.c_int, [vp, C.c_int, pvp]),

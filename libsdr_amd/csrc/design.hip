@@ -73,7 +73,21 @@ int sdrhip_design_fftfilt_kernel(int n, double fmin, double fmax, double sample_
 
 int sdrhip_design_fftfilt_spectrum(int n, const float *h, float *spectrum) {
   return guarded([&] {
-    SDRHIP_REQUIRE(h && spectrum && n >= 2 && (n & (n - 1)) == 0, SDRHIP_E_INVALID, "n must be a power of two");
+    SDRHIP_REQUIRE(h && spectrum && n >= 1, SDRHIP_E_INVALID, "bad argument");
+    dz::fftFilterSpectrum(n, h, spectrum);
+  });
+}
+
+int sdrhip_design_fftfilt_kernel_f64(int n, double fmin, double fmax, double sample_rate, double *h) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h && n >= 2 && sample_rate != 0, SDRHIP_E_INVALID, "bad argument");
+    dz::fftFilterKernel(n, fmin, fmax, sample_rate, h);
+  });
+}
+
+int sdrhip_design_fftfilt_spectrum_f64(int n, const double *h, double *spectrum) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h && spectrum && n >= 1, SDRHIP_E_INVALID, "bad argument");
     dz::fftFilterSpectrum(n, h, spectrum);
   });
 }

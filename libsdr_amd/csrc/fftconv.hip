@@ -18,6 +18,9 @@
 
 #include <cmath>
 #include <complex>
+#include <memory>
+
+#include "fftgen.hpp"
 
 using namespace sdrhip;
 
@@ -704,16 +707,108 @@ struct FftPlan {
   size_t lds_bytes() const { return (size_t)(L + (L >> 6) * 4) * sizeof(float2); }
 };
 
+inline bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
 template <class K>
 void allow_big_lds(K kernel, size_t bytes) {
   if (bytes > 64 * 1024)
     SDRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
 }
 
+// The general plan (fftgen.hpp) behind the same handle: any FFT size made of the factors 2 ... 13 in complex<float>, and
+// every size in complex<double> (FilterNode<double>, FFTPlan<double>). Same overlap-save evaluation, same state rules.
+template <class T2>
+struct GenConv {
+  typedef typename fftgen::Real<T2>::type R;
+  sdrhip_ctx *ctx = nullptr;
+  int mode = 0, C = 1, B = 1, hop = 0, HH = 0, par = 0, n_taps = 0;
+  size_t max_in = 0;
+  fftgen::GenPlan<T2> plan;
+  DevBuf<T2> Kp, hist[2], stage_in, stage_out;
+  static constexpr size_t kMaxLds = 160 * 1024;
+
+  void create(sdrhip_ctx *ctx_, int mode_, int L, const R *kernels, int n_taps_, int n_bands, int channels, size_t max_in_) {
+    ctx = ctx_; mode = mode_; C = channels; B = n_bands; max_in = max_in_;
+    plan.build(ctx, L, (int)(128 * 1024 / sizeof(T2)));
+    if (mode == SDRHIP_FFTCONV_OLA) {
+      SDRHIP_REQUIRE(L % 2 == 0, SDRHIP_E_INVALID, "overlap-add mode: fft_size %d must be 2N", L);
+      hop = L / 2; n_taps = L / 2;
+    } else {
+      SDRHIP_REQUIRE(n_taps_ >= 1 && n_taps_ <= L, SDRHIP_E_INVALID, "n_taps %d outside [1,%d]", n_taps_, L);
+      hop = L - n_taps_ + 1; n_taps = n_taps_;
+    }
+    HH = L - hop;
+    Kp.alloc((size_t)L * B);
+    const size_t per_band = mode == SDRHIP_FFTCONV_OLA ? (size_t)2 * L : (size_t)2 * n_taps;   // reals per band in `kernels`
+    for (int b = 0; b < B; b++) load_kernel(b, kernels + (size_t)b * per_band);
+    for (int p = 0; p < 2; p++) { hist[p].alloc((size_t)C * std::max(1, HH)); hist[p].zero(ctx->stream); }
+    SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  void load_kernel(int band, const R *kernel) {
+    const int L = plan.L;
+    std::vector< std::complex<double> > spec(L, std::complex<double>(0, 0));
+    if (mode == SDRHIP_FFTCONV_OLA) {
+      for (int i = 0; i < L; i++) spec[i] = std::complex<double>(kernel[2 * i], kernel[2 * i + 1]);
+    } else {
+      for (int i = 0; i < n_taps; i++) spec[i] = std::complex<double>(kernel[2 * i], kernel[2 * i + 1]);
+      fftgen::host_dft(spec, -1);
+    }
+    std::vector<T2> kp(L);
+    for (int pos = 0; pos < L; pos++) {
+      const std::complex<double> v = spec[plan.perm[pos]] / (double)L;
+      kp[pos].x = (R)v.real(); kp[pos].y = (R)v.imag();
+    }
+    SDRHIP_CHECK_HIP(hipMemcpyAsync(Kp.p + (size_t)band * L, kp.data(), (size_t)L * sizeof(T2), hipMemcpyHostToDevice, ctx->stream));
+    SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  void launch(const T2 *in_dev, size_t N, size_t in_stride, T2 *out_dev, size_t out_stride, size_t out_band) {
+    ctx->use();
+    if (N == 0) return;
+    fftgen::GenConvArgs<T2> a;
+    a.fft = plan.dev; a.in = in_dev; a.in_stride = (long)in_stride; a.hist = hist[par].p; a.HH = HH;
+    a.hist_new = HH > 0 ? hist[par ^ 1].p : nullptr;
+    a.Kp = Kp.p; a.out = out_dev; a.out_stride = (long)out_stride; a.N = (int)N; a.hop = hop; a.nb = B; a.out_band = (long)out_band;
+    a.two = (B > 1 && 2 * plan.lds_bytes() <= kMaxLds) ? 1 : 0;
+    const size_t lds = plan.lds_bytes() * (a.two ? 2 : 1);
+    allow_big_lds(fftgen::conv_kernel<T2>, lds);
+    hipLaunchKernelGGL(fftgen::conv_kernel<T2>, dim3((unsigned)ceil_div(N, (size_t)hop), C), dim3(fftgen::GT), lds, ctx->stream, a);
+    SDRHIP_CHECK_HIP(hipGetLastError());
+    if (HH > 0) par ^= 1;
+  }
+  void process_dev(const R *in_dev, size_t n_in, size_t in_stride, R *out_dev, size_t out_stride) {
+    SDRHIP_REQUIRE(n_in <= max_in, SDRHIP_E_SIZE, "n_in %zu > max_in %zu", n_in, max_in);
+    if (n_in == 0) return;
+    SDRHIP_REQUIRE(in_dev && out_dev, SDRHIP_E_INVALID, "NULL buffer");
+    if (in_stride == 0) in_stride = n_in;
+    if (out_stride == 0) out_stride = n_in;
+    SDRHIP_REQUIRE(in_stride >= n_in && out_stride >= n_in, SDRHIP_E_SIZE, "stride smaller than n_in");
+    require_disjoint(in_dev, in_stride, n_in, sizeof(T2), out_dev, out_stride, n_in, sizeof(T2), (size_t)C, (size_t)C * B);
+    launch(reinterpret_cast<const T2 *>(in_dev), n_in, in_stride, reinterpret_cast<T2 *>(out_dev), out_stride, (size_t)C * out_stride);
+  }
+  void process(const R *in_host, size_t n_in, size_t in_stride, R *out_host, size_t out_stride) {
+    SDRHIP_REQUIRE(n_in <= max_in, SDRHIP_E_SIZE, "n_in %zu > max_in %zu", n_in, max_in);
+    if (n_in == 0) return;
+    SDRHIP_REQUIRE(in_host && out_host, SDRHIP_E_INVALID, "NULL buffer");
+    ctx->use();
+    if (in_stride == 0) in_stride = n_in;
+    if (out_stride == 0) out_stride = n_in;
+    SDRHIP_REQUIRE(in_stride >= n_in && out_stride >= n_in, SDRHIP_E_SIZE, "stride smaller than n_in");
+    if (!stage_in.p) { stage_in.alloc((size_t)C * max_in); stage_out.alloc((size_t)B * C * max_in); }
+    const size_t eb = sizeof(T2);
+    copy_h2d_rows(ctx, stage_in.p, n_in * eb, in_host, in_stride * eb, n_in * eb, C);
+    launch(stage_in.p, n_in, n_in, stage_out.p, n_in, (size_t)C * n_in);
+    copy_d2h_rows(ctx, out_host, out_stride * eb, stage_out.p, n_in * eb, n_in * eb, (size_t)B * C);
+    SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  void reset() { ctx->use(); for (int p = 0; p < 2; p++) hist[p].zero(ctx->stream); }
+};
+
 }  // namespace
 
 struct sdrhip_fftconv {
   sdrhip_ctx *ctx = nullptr;
+  std::unique_ptr< GenConv<float2> > g32;    // the general plan in complex<float> (FFT sizes that are not powers of two)
+  std::unique_ptr< GenConv<double2> > g64;   // complex<double> (every size)
   int mode = 0, C = 1, hop = 0, HH = 0, par = 0;
   int B = 1;            // bands of the bank (spectra sharing one forward transform)
   int n_taps = 0;
@@ -830,6 +925,19 @@ struct sdrhip_fftconv {
   }
 };
 
+namespace {
+template <class T2>
+void gen_c2c(sdrhip_ctx *ctx, int n, int sign, int batch, const void *in_dev, void *out_dev) {
+  fftgen::GenPlan<T2> plan;
+  plan.build(ctx, n, (int)(128 * 1024 / sizeof(T2)));
+  allow_big_lds(fftgen::c2c_kernel<T2>, plan.lds_bytes());
+  hipLaunchKernelGGL(fftgen::c2c_kernel<T2>, dim3(batch), dim3(fftgen::GT), plan.lds_bytes(), ctx->stream, plan.dev, plan.perm_d.p, sign,
+                     reinterpret_cast<const T2 *>(in_dev), reinterpret_cast<T2 *>(out_dev));
+  SDRHIP_CHECK_HIP(hipGetLastError());
+  SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));   // the plan's tables die with this scope
+}
+}  // namespace
+
 extern "C" {
 
 int sdrhip_fftconv_create_bank(sdrhip_ctx *ctx, int mode, int fft_size, const float *kernels, int n_taps, int n_bands,
@@ -845,6 +953,12 @@ int sdrhip_fftconv_create_bank(sdrhip_ctx *ctx, int mode, int fft_size, const fl
     sdrhip_fftconv *h = new sdrhip_fftconv;
     try {
       h->ctx = ctx; h->mode = mode; h->C = channels; h->max_in = max_in; h->B = n_bands;
+      if (!is_pow2(fft_size) || fft_size < 4) {   // (FilterNode(size_t block_size) takes any block size: src/filternode.hh:235-245)
+        h->g32.reset(new GenConv<float2>());
+        h->g32->create(ctx, mode, fft_size, kernels, n_taps, n_bands, channels, max_in);
+        *out = h;
+        return;
+      }
       h->plan.build(ctx, fft_size);
       const int L = fft_size;
       if (mode == SDRHIP_FFTCONV_OLA) { h->hop = L / 2; h->n_taps = L / 2; }
@@ -879,8 +993,10 @@ int sdrhip_fftconv_set_kernel(sdrhip_fftconv *h, int band, const float *kernel) 
   return guarded([&] {
     SDRHIP_REQUIRE(h && kernel, SDRHIP_E_INVALID, "NULL argument");
     SDRHIP_REQUIRE(band >= 0 && band < h->B, SDRHIP_E_INVALID, "band %d outside [0,%d)", band, h->B);
+    SDRHIP_REQUIRE(!h->g64, SDRHIP_E_INVALID, "a complex<double> plan: use sdrhip_fftconv_f64_set_kernel");
     h->ctx->use();
     SDRHIP_CHECK_HIP(hipStreamSynchronize(h->ctx->stream));   // launches in flight still read the old spectrum
+    if (h->g32) { h->g32->load_kernel(band, kernel); return; }
     h->load_kernel(band, kernel);
   });
 }
@@ -890,6 +1006,8 @@ int sdrhip_fftconv_process_dev(sdrhip_fftconv *h, const float *in_dev, size_t n_
   return guarded([&] {
     Range roctx_range("sdrhip_fftconv_process_dev");
     SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
+    SDRHIP_REQUIRE(!h->g64, SDRHIP_E_INVALID, "a complex<double> plan: use sdrhip_fftconv_f64_process_dev");
+    if (h->g32) { h->g32->process_dev(in_dev, n_in, in_stride, out_dev, out_stride); return; }
     SDRHIP_REQUIRE(n_in <= h->max_in, SDRHIP_E_SIZE, "n_in %zu > max_in %zu", n_in, h->max_in);
     if (n_in == 0) return;
     SDRHIP_REQUIRE(in_dev && out_dev, SDRHIP_E_INVALID, "NULL buffer");
@@ -907,6 +1025,8 @@ int sdrhip_fftconv_process(sdrhip_fftconv *h, const float *in_host, size_t n_in,
   return guarded([&] {
     Range roctx_range("sdrhip_fftconv_process");
     SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
+    SDRHIP_REQUIRE(!h->g64, SDRHIP_E_INVALID, "a complex<double> plan: use sdrhip_fftconv_f64_process");
+    if (h->g32) { h->g32->process(in_host, n_in, in_stride, out_host, out_stride); return; }
     SDRHIP_REQUIRE(n_in <= h->max_in, SDRHIP_E_SIZE, "n_in %zu > max_in %zu", n_in, h->max_in);
     if (n_in == 0) return;
     SDRHIP_REQUIRE(in_host && out_host, SDRHIP_E_INVALID, "NULL buffer");
@@ -926,6 +1046,8 @@ int sdrhip_fftconv_reset(sdrhip_fftconv *h) {
   return guarded([&] {
     SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
     h->ctx->use();
+    if (h->g32) { h->g32->reset(); return; }
+    if (h->g64) { h->g64->reset(); return; }
     for (int p = 0; p < 2; p++) h->hist[p].zero(h->ctx->stream);
   });
 }
@@ -939,11 +1061,60 @@ int sdrhip_fftconv_destroy(sdrhip_fftconv *h) {
   });
 }
 
+// ---- FilterNode<double> (reference src/filternode.hh:230-232: the filter classes are templates over Scalar) ----
+int sdrhip_fftconv_f64_create_bank(sdrhip_ctx *ctx, int mode, int fft_size, const double *kernels, int n_taps, int n_bands,
+                                   int channels, size_t max_in, sdrhip_fftconv **out) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(ctx && kernels && out, SDRHIP_E_INVALID, "NULL argument");
+    *out = nullptr;
+    SDRHIP_REQUIRE(mode == SDRHIP_FFTCONV_OLA || mode == SDRHIP_FFTCONV_OLS, SDRHIP_E_INVALID, "bad mode %d", mode);
+    SDRHIP_REQUIRE(channels >= 1 && channels <= 65535, SDRHIP_E_INVALID, "channels %d outside [1,65535]", channels);
+    SDRHIP_REQUIRE(n_bands >= 1 && n_bands <= 256, SDRHIP_E_INVALID, "n_bands %d outside [1,256]", n_bands);
+    SDRHIP_REQUIRE(max_in >= 1 && max_in < (size_t(1) << 30), SDRHIP_E_SIZE, "max_in %zu outside [1,2^30)", max_in);
+    ctx->use();
+    sdrhip_fftconv *h = new sdrhip_fftconv;
+    try {
+      h->ctx = ctx; h->mode = mode; h->C = channels; h->max_in = max_in; h->B = n_bands;
+      h->g64.reset(new GenConv<double2>());
+      h->g64->create(ctx, mode, fft_size, kernels, n_taps, n_bands, channels, max_in);
+    } catch (...) { delete h; throw; }
+    *out = h;
+  });
+}
+
+int sdrhip_fftconv_f64_set_kernel(sdrhip_fftconv *h, int band, const double *kernel) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h && kernel && h->g64, SDRHIP_E_INVALID, "not a complex<double> plan");
+    SDRHIP_REQUIRE(band >= 0 && band < h->B, SDRHIP_E_INVALID, "band %d outside [0,%d)", band, h->B);
+    h->ctx->use();
+    SDRHIP_CHECK_HIP(hipStreamSynchronize(h->ctx->stream));
+    h->g64->load_kernel(band, kernel);
+  });
+}
+
+int sdrhip_fftconv_f64_process(sdrhip_fftconv *h, const double *in_host, size_t n_in, size_t in_stride, double *out_host, size_t out_stride) {
+  return guarded([&] {
+    Range roctx_range("sdrhip_fftconv_f64_process");
+    SDRHIP_REQUIRE(h && h->g64, SDRHIP_E_INVALID, "not a complex<double> plan");
+    h->g64->process(in_host, n_in, in_stride, out_host, out_stride);
+  });
+}
+
+int sdrhip_fftconv_f64_process_dev(sdrhip_fftconv *h, const double *in_dev, size_t n_in, size_t in_stride, double *out_dev, size_t out_stride) {
+  return guarded([&] {
+    Range roctx_range("sdrhip_fftconv_f64_process_dev");
+    SDRHIP_REQUIRE(h && h->g64, SDRHIP_E_INVALID, "not a complex<double> plan");
+    h->g64->process_dev(in_dev, n_in, in_stride, out_dev, out_stride);
+  });
+}
+
+
 int sdrhip_fft_c2c_f64(sdrhip_ctx *ctx, int n, int sign, int batch, const double *in_dev, double *out_dev) {
   return guarded([&] {
     SDRHIP_REQUIRE(ctx && in_dev && out_dev && batch >= 1 && (sign == 1 || sign == -1), SDRHIP_E_INVALID, "bad argument");
-    SDRHIP_REQUIRE(n >= 2 && n <= 8192 && (n & (n - 1)) == 0, SDRHIP_E_UNSUPPORTED, "double FFT size %d: need a power of two in [2,8192]", n);
     ctx->use();
+    if (!is_pow2(n) || n < 2) { gen_c2c<double2>(ctx, n, sign, batch, in_dev, out_dev); return; }   // any size of factors 2 ... 13
+    SDRHIP_REQUIRE(n <= 8192, SDRHIP_E_UNSUPPORTED, "double FFT size %d outside [1,8192] (one transform lives in one workgroup's LDS)", n);
     int lg = 0; while ((1 << lg) < n) lg++;
     std::vector<double2> w(n / 2);
     for (int k = 0; k < n / 2; k++) {
@@ -983,6 +1154,7 @@ int sdrhip_fft_c2c(sdrhip_ctx *ctx, int n, int sign, int batch, const float *in_
   return guarded([&] {
     SDRHIP_REQUIRE(ctx && in_dev && out_dev && batch >= 1 && (sign == 1 || sign == -1), SDRHIP_E_INVALID, "bad argument");
     ctx->use();
+    if (!is_pow2(n) || n < 4) { gen_c2c<float2>(ctx, n, sign, batch, in_dev, out_dev); return; }   // any size of factors 2 ... 13
     FftPlan plan;
     plan.build(ctx, n);
     allow_big_lds(fft_c2c_kernel, plan.lds_bytes());

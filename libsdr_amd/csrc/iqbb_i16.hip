@@ -972,6 +972,11 @@ struct sdrhip_iqbb_i16 {
   size_t max_in = 0;
   uint64_t n0 = 0;
   uint64_t phase0 = 0;   // absolute sample index at which the LUT phase counter was last restarted (set_shift)
+  // the reference's _ring_offset at sample n0 is (ring_off0 + n0 - ring_n0) mod order: n0 mod order unless setOrder changed
+  // the ring's length mid-stream (adopt_state with SDRHIP_KEEP_COUNTERS); what a later _reconfigure rotates the ring by
+  uint64_t ring_n0 = 0;
+  int ring_off0 = 0;
+  int ring_offset() const { return (int)(((uint64_t)ring_off0 + (n0 - ring_n0)) % (uint64_t)order); }
   int par = 0, par_fm = 0;
   int CG = 0, OG = 0, ovl = 0;
   bool fast8 = false;
@@ -1441,7 +1446,7 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
 // the apparent history, oldest first, is ring[1..order-1], ring[i] = t[order-P+i] (i < P) or t[i-P] (i >= P),
 // t = the last `order` samples in time order (the tail of the source plan's rows).
 static std::vector<uint32_t> reconfigured_ring(const sdrhip_iqbb_i16 *src, int HH_dst) {
-  const int order = src->order, HH = src->HH, P = (int)(src->n0 % (uint64_t)order);
+  const int order = src->order, HH = src->HH, P = src->ring_offset();
   hipStream_t st = src->ctx->stream;
   std::vector<uint32_t> old((size_t)src->C * HH), neu((size_t)src->C * HH_dst, 0u);
   SDRHIP_CHECK_HIP(hipMemcpyAsync(old.data(), src->hist[src->par].p, old.size() * 4, hipMemcpyDeviceToHost, st));
@@ -1572,12 +1577,12 @@ int sdrhip_iqbb_i16_reset(sdrhip_iqbb_i16 *h, int keep_history) {
     for (int p = 0; p < 2; p++) { h->acc[p].zero(st); if (!keep_fm) h->fm[p].zero(st); }
     if (!keep_history) {
       for (int p = 0; p < 2; p++) h->hist[p].zero(st);
-    } else if (h->n0 % (uint64_t)h->order != 0) {
+    } else if (h->ring_offset() != 0) {
       const std::vector<uint32_t> neu = reconfigured_ring(h, h->HH);
       SDRHIP_CHECK_HIP(hipMemcpyAsync(h->hist[h->par].p, neu.data(), neu.size() * 4, hipMemcpyHostToDevice, st));
       SDRHIP_CHECK_HIP(hipStreamSynchronize(st));
     }
-    h->n0 = 0; h->phase0 = 0;
+    h->n0 = 0; h->phase0 = 0; h->ring_n0 = 0; h->ring_off0 = 0;
   });
 }
 
@@ -1609,6 +1614,9 @@ int sdrhip_iqbb_i16_adopt_state(sdrhip_iqbb_i16 *h, sdrhip_iqbb_i16 *from, int w
     if (stream) {   // decimator window (position and partial sum), sample counter and LUT phase go on
       SDRHIP_CHECK_HIP(hipMemcpyAsync(h->acc[h->par].p, from->acc[from->par].p, C * sizeof(int2), hipMemcpyDeviceToDevice, st));
       h->n0 = from->n0; h->phase0 = from->phase0;
+      // _ring_offset goes on from where it stands (a position beyond a shorter new ring is an out-of-bounds write in the
+      // reference; it wraps here, as in the oracle)
+      h->ring_n0 = h->n0; h->ring_off0 = from->ring_offset() < h->order ? from->ring_offset() : 0;
     }
     SDRHIP_CHECK_HIP(hipStreamSynchronize(st));
   });

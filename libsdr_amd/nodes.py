@@ -64,17 +64,27 @@ def design_fmdeemph_alpha(Fs):
     return v.value
 
 
-def design_fftfilt_kernel(N, fmin, fmax, Fs):
-    h = np.zeros((N, 2), np.float32)
-    check(abi.lib().sdrhip_design_fftfilt_kernel(N, fmin, fmax, Fs, h.ctypes.data_as(C.POINTER(C.c_float))))
+def design_fftfilt_kernel(N, fmin, fmax, Fs, dtype=np.float32):
+    """sinc_flt_kernel<float> (default) or <double> (dtype=np.float64): N x (re, im)."""
+    h = np.zeros((N, 2), dtype)
+    if np.dtype(dtype) == np.float64:
+        check(abi.lib().sdrhip_design_fftfilt_kernel_f64(N, fmin, fmax, Fs, h.ctypes.data_as(C.POINTER(C.c_double))))
+    else:
+        check(abi.lib().sdrhip_design_fftfilt_kernel(N, fmin, fmax, Fs, h.ctypes.data_as(C.POINTER(C.c_float))))
     return h
 
 
 def design_fftfilt_spectrum(h):
-    h = np.ascontiguousarray(h, np.float32).reshape(-1, 2)
-    K = np.zeros((2 * h.shape[0], 2), np.float32)
-    check(abi.lib().sdrhip_design_fftfilt_spectrum(h.shape[0], h.ctypes.data_as(C.POINTER(C.c_float)),
-                                                   K.ctypes.data_as(C.POINTER(C.c_float))))
+    """FilterSource::_updateFilter: K = DFT_2N([h, 0]) / ||K||; the dtype follows h (float32 unless h is float64)."""
+    f64 = np.asarray(h).dtype == np.float64
+    h = np.ascontiguousarray(h, np.float64 if f64 else np.float32).reshape(-1, 2)
+    K = np.zeros((2 * h.shape[0], 2), h.dtype)
+    if f64:
+        check(abi.lib().sdrhip_design_fftfilt_spectrum_f64(h.shape[0], h.ctypes.data_as(C.POINTER(C.c_double)),
+                                                           K.ctypes.data_as(C.POINTER(C.c_double))))
+    else:
+        check(abi.lib().sdrhip_design_fftfilt_spectrum(h.shape[0], h.ctypes.data_as(C.POINTER(C.c_float)),
+                                                       K.ctypes.data_as(C.POINTER(C.c_float))))
     return K
 
 
@@ -546,36 +556,44 @@ class SubSample(_Node):
 class FFTConv(_Node):
     """K7 — FilterSink+FilterSource (mode OLA, kernel = 2N spectrum) or overlap-save with taps (mode OLS).
     `kernels` may be a list of equally sized kernels: a filter bank behind one forward transform per block
-    (FilterNode); process() then returns [bands, channels, n, 2]."""
+    (FilterNode); process() then returns [bands, channels, n, 2]. dtype=np.float64: FilterNode<double>'s plan
+    (sdrhip_fftconv_f64_*)."""
     _destroy = "sdrhip_fftconv_destroy"
 
-    def __init__(self, ctx, mode, fft_size, kernel, channels=1, max_in=65536):
+    def __init__(self, ctx, mode, fft_size, kernel, channels=1, max_in=65536, dtype=np.float32):
         super().__init__()
         bank = isinstance(kernel, (list, tuple))
-        ks = [np.ascontiguousarray(k, np.float32).reshape(-1, 2) for k in (kernel if bank else [kernel])]
+        self.dtype = np.dtype(dtype)
+        self.f64 = self.dtype == np.float64
+        self._ct = C.c_double if self.f64 else C.c_float
+        ks = [np.ascontiguousarray(k, self.dtype).reshape(-1, 2) for k in (kernel if bank else [kernel])]
         assert all(k.shape == ks[0].shape for k in ks)
         self.ctx, self.mode, self.fft_size, self.channels, self.bands, self._bank = ctx, mode, fft_size, channels, len(ks), bank
         allk = np.ascontiguousarray(np.stack(ks))
-        check(abi.lib().sdrhip_fftconv_create_bank(ctx.handle, mode, fft_size, allk.ctypes.data_as(C.POINTER(C.c_float)),
-                                                   ks[0].shape[0], len(ks), channels, max_in, C.byref(self._h)))
+        create = abi.lib().sdrhip_fftconv_f64_create_bank if self.f64 else abi.lib().sdrhip_fftconv_create_bank
+        check(create(ctx.handle, mode, fft_size, allk.ctypes.data_as(C.POINTER(self._ct)), ks[0].shape[0], len(ks), channels, max_in,
+                     C.byref(self._h)))
 
     def process(self, x):
-        x = _as3(x, np.float32)
+        x = _as3(x, self.dtype)
         n = x.shape[1]
-        out = np.zeros((self.bands,) + x.shape, np.float32)
+        out = np.zeros((self.bands,) + x.shape, self.dtype)
         if RedZone.active and n:
             flat = out.reshape((self.bands * x.shape[0],) + x.shape[1:])   # band-major rows, as the C ABI lays them out
             RedZone.run(self.ctx, x, flat, lambda i, si, o, so: self.process_dev(i, n, si, o, so))
             return out if self._bank else out[0]
-        check(abi.lib().sdrhip_fftconv_process(self._h, _ptr(x), n, n, _ptr(out), n))
+        fn = abi.lib().sdrhip_fftconv_f64_process if self.f64 else abi.lib().sdrhip_fftconv_process
+        check(fn(self._h, _ptr(x), n, n, _ptr(out), n))
         return out if self._bank else out[0]
 
     def set_kernel(self, band, kernel):
-        kernel = np.ascontiguousarray(kernel, np.float32).reshape(-1, 2)
-        check(abi.lib().sdrhip_fftconv_set_kernel(self._h, band, kernel.ctypes.data_as(C.POINTER(C.c_float))))
+        kernel = np.ascontiguousarray(kernel, self.dtype).reshape(-1, 2)
+        fn = abi.lib().sdrhip_fftconv_f64_set_kernel if self.f64 else abi.lib().sdrhip_fftconv_set_kernel
+        check(fn(self._h, band, kernel.ctypes.data_as(C.POINTER(self._ct))))
 
     def process_dev(self, in_ptr, n, in_stride, out_ptr, out_stride):
-        check(abi.lib().sdrhip_fftconv_process_dev(self._h, C.c_void_p(in_ptr), n, in_stride, C.c_void_p(out_ptr), out_stride))
+        fn = abi.lib().sdrhip_fftconv_f64_process_dev if self.f64 else abi.lib().sdrhip_fftconv_process_dev
+        check(fn(self._h, C.c_void_p(in_ptr), n, in_stride, C.c_void_p(out_ptr), out_stride))
 
     def reset(self):
         check(abi.lib().sdrhip_fftconv_reset(self._h))

@@ -77,6 +77,9 @@ def lib():
             "orc_subsample_cf32_process": (C.c_size_t, [vp, f32p, C.c_size_t, f32p]),
             "orc_subsample_destroy": (None, [vp]),
             "orc_fftfilt_create": (vp, [C.c_int, f32p]),
+            "orc_fftfilt_design_h_f64": (None, [C.c_int, C.c_double, C.c_double, C.c_double, f64p]),
+            "orc_fftfilt_design_K_f64": (None, [C.c_int, f64p, f64p]),
+            "orc_fftfilt_process_f64": (None, [C.c_int, f64p, f64p, f64p, f64p]),
             "orc_fftfilt_process": (None, [vp, f32p, f32p]),
             "orc_fftfilt_destroy": (None, [vp]),
             "orc_dft_f64": (None, [C.c_int, C.c_int, f64p, f64p]),
@@ -130,6 +133,35 @@ def fftfilt_design_h(N, fmin, fmax, Fs):
     h = np.zeros(2 * N, np.float32)
     lib().orc_fftfilt_design_h(N, fmin, fmax, Fs, _p(h, C.c_float))
     return h.reshape(N, 2)
+
+
+def fftfilt_design_h_f64(N, fmin, fmax, Fs):
+    """sinc_flt_kernel<double>."""
+    h = np.zeros(2 * N, np.float64)
+    lib().orc_fftfilt_design_h_f64(N, fmin, fmax, Fs, _p(h, C.c_double))
+    return h.reshape(N, 2)
+
+
+def fftfilt_design_K_f64(h):
+    h = np.ascontiguousarray(h, np.float64).reshape(-1, 2)
+    K = np.zeros(4 * h.shape[0], np.float64)
+    lib().orc_fftfilt_design_K_f64(h.shape[0], _p(h, C.c_double), _p(K, C.c_double))
+    return K.reshape(2 * h.shape[0], 2)
+
+
+class FFTFilterF64:
+    """FilterSink<double> + FilterSource<double> (overlap-add, FFT size 2N). PARITY UNPINNED (FFTW)."""
+
+    def __init__(self, K):
+        self.K = np.ascontiguousarray(K, np.float64).reshape(-1, 2)
+        self.N = self.K.shape[0] // 2
+        self.last = np.zeros((self.N, 2), np.float64)
+
+    def process(self, x):
+        x = np.ascontiguousarray(x, np.float64).reshape(self.N, 2)
+        o = np.zeros_like(x)
+        lib().orc_fftfilt_process_f64(self.N, _p(self.K, C.c_double), _p(self.last, C.c_double), _p(x, C.c_double), _p(o, C.c_double))
+        return o
 
 
 def fftfilt_design_K(h):

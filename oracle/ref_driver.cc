@@ -636,6 +636,21 @@ static void golden_wav() {
       dump("g14_regeom_out", "cs16", flat16(cap.data), ev.str() + ", " + lens_json("in_lens", used) + ", " + lens_json("out_lens", cap.lens));
     }
   }
+
+  // G15 — the FFT filter's kernel designer for a block size that is not a power of two and for Scalar = double
+  // (sinc_flt_kernel<Scalar>, src/filternode.hh:16-28: FilterNode(size_t block_size), template <class Scalar>)
+  { const double fmin = -350e3, fmax = -250e3, bw = fmax - fmin, Fc = fmin + bw / 2;
+    std::vector<cf32> h;
+    for (int i = 0; i < 1000; i++) h.push_back(sinc_flt_kernel<float>(i, 1000, Fc, bw, Fs));
+    dump("g15_fftfilt_h1000", "cf32", flatf(h), "\"Fs\": 2400000, \"fmin\": -350000, \"fmax\": -250000");
+    const int Ns[2] = {1000, 1024};
+    for (int k = 0; k < 2; k++) {
+      std::vector<double> hd;
+      for (int i = 0; i < Ns[k]; i++) { const std::complex<double> v = sinc_flt_kernel<double>(i, Ns[k], Fc, bw, Fs); hd.push_back(v.real()); hd.push_back(v.imag()); }
+      std::ostringstream nm; nm << "g15_fftfilt_h" << Ns[k] << "_f64";
+      dump(nm.str(), "f64", hd, "\"Fs\": 2400000, \"fmin\": -350000, \"fmax\": -250000");
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

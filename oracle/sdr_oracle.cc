@@ -139,26 +139,80 @@ void orc_fftfilt_design_h(int N, double fmin_, double fmax_, double Fs, float *h
   }
 }
 
-// radix-2 decimation-in-time DFT in double; n must be a power of two.
+// DFT in double of any length n (the reference hands every size to FFTW): decimation in frequency over the prime
+// factors of n, smallest first, each stage's butterflies evaluated as the small DFTs they are; the digit-reversed result
+// is sorted out at the end. Powers of two run the same code (factor 2 throughout).
 void orc_dft_f64(int n, int sign, const double *in, double *out) {
-  std::vector< std::complex<double> > a(n);
-  int lg = 0; while ((1 << lg) < n) lg++;
-  for (int i = 0; i < n; i++) {
-    int r = 0; for (int b = 0; b < lg; b++) if (i & (1 << b)) r |= 1 << (lg - 1 - b);
-    a[r] = std::complex<double>(in[2 * i], in[2 * i + 1]);
-  }
-  for (int len = 2; len <= n; len <<= 1) {
-    const int half = len / 2;
-    for (int k = 0; k < half; k++) {
-      const double ang = sign * 2.0 * M_PI * k / len;
-      const std::complex<double> w(std::cos(ang), std::sin(ang));
-      for (int s = 0; s < n; s += len) {
-        std::complex<double> u = a[s + k], t = w * a[s + k + half];
-        a[s + k] = u + t; a[s + k + half] = u - t;
+  typedef std::complex<double> cd;
+  std::vector<cd> a(n), t(n);
+  for (int i = 0; i < n; i++) a[i] = cd(in[2 * i], in[2 * i + 1]);
+  std::vector<int> fac;
+  for (int m = n, q = 2; m > 1;) { if (m % q == 0) { fac.push_back(q); m /= q; } else q++; }
+  int len = n;                                   // current sub-transform length
+  for (size_t f = 0; f < fac.size(); f++) {
+    const int r = fac[f], s = len / r;
+    std::vector<cd> wr(r);
+    for (int q = 0; q < r; q++) { const double ang = sign * 2.0 * M_PI * q / r; wr[q] = cd(std::cos(ang), std::sin(ang)); }
+    for (int base = 0; base < n; base += len)
+      for (int j = 0; j < s; j++) {
+        for (int m = 0; m < r; m++) {
+          cd acc(0, 0);
+          for (int k = 0; k < r; k++) acc += a[base + j + k * s] * wr[(k * m) % r];
+          const double ang = sign * 2.0 * M_PI * (double)((long)j * m) / (double)len;
+          t[base + j + m * s] = acc * cd(std::cos(ang), std::sin(ang));
+        }
       }
-    }
+    a.swap(t);
+    len = s;
   }
-  for (int i = 0; i < n; i++) { out[2 * i] = a[i].real(); out[2 * i + 1] = a[i].imag(); }
+  // position -> frequency: position = sum_f d_f * (len after stage f), frequency = sum_f d_f * (product of the radices before f)
+  for (int pos = 0; pos < n; pos++) {
+    int rem = pos, l = n, k = 0, mult = 1;
+    for (size_t f = 0; f < fac.size(); f++) { const int s = l / fac[f], d = rem / s; rem -= d * s; k += d * mult; mult *= fac[f]; l = s; }
+    out[2 * k] = a[pos].real(); out[2 * k + 1] = a[pos].imag();
+  }
+}
+
+// sinc_flt_kernel<double> (src/filternode.hh:16-28) with FilterSource<double>::_updateFilter's band clamp (:186-196)
+void orc_fftfilt_design_h_f64(int N, double fmin_, double fmax_, double Fs, double *h) {
+  const double fmin = std::max(fmin_, -Fs / 2);
+  const double fmax = std::min(fmax_, Fs / 2);
+  const double bw = fmax - fmin;
+  const double Fc = fmin + bw / 2;
+  for (int i = 0; i < N; i++) {
+    std::complex<double> v;
+    if ((N / 2) == i) v = M_PI * (bw / Fs);
+    else v = std::sin(M_PI * (bw / Fs) * (i - N / 2)) / (i - N / 2);
+    v *= std::exp(std::complex<double>(0.0, (2 * M_PI * Fc * i) / Fs));
+    v *= (0.42 - 0.5 * cos((2 * M_PI * i) / N) + 0.08 * cos((4 * M_PI * i) / N));
+    h[2 * i] = v.real();
+    h[2 * i + 1] = v.imag();
+  }
+}
+
+// FilterSource<double>::_updateFilter (:197-202) and ::process (:164-181) in double: K = DFT_2N([h, 0]) / ||K||_2;
+// one block: out = last + IDFT(DFT([x, 0]) K) / 2N, last = second half. `last` holds N complex doubles of state.
+void orc_fftfilt_design_K_f64(int N, const double *h, double *K) {
+  const int L = 2 * N;
+  std::vector<double> in(2 * L, 0.0);
+  for (int i = 0; i < 2 * N; i++) in[i] = h[i];
+  orc_dft_f64(L, -1, in.data(), K);
+  double nrm2 = 0;
+  for (int i = 0; i < L; i++) nrm2 += K[2 * i] * K[2 * i] + K[2 * i + 1] * K[2 * i + 1];
+  const double d = std::sqrt(nrm2);
+  for (int i = 0; i < 2 * L; i++) K[i] = K[i] / d;
+}
+void orc_fftfilt_process_f64(int N, const double *K, double *last, const double *in, double *out) {
+  const int L = 2 * N;
+  std::vector<double> a(2 * L, 0.0), b(2 * L);
+  for (int i = 0; i < 2 * N; i++) a[i] = in[i];
+  orc_dft_f64(L, -1, a.data(), b.data());
+  for (int i = 0; i < L; i++) {
+    const double re = b[2 * i] * K[2 * i] - b[2 * i + 1] * K[2 * i + 1], im = b[2 * i] * K[2 * i + 1] + b[2 * i + 1] * K[2 * i];
+    a[2 * i] = re; a[2 * i + 1] = im;
+  }
+  orc_dft_f64(L, +1, a.data(), b.data());
+  for (int i = 0; i < 2 * N; i++) { out[i] = last[i] + b[i] / (double)L; last[i] = b[2 * N + i] / (double)L; }
 }
 
 // src/filternode.hh:197-202: K = DFT_2N([h, 0]) stored as float, then K /= norm2(K) where

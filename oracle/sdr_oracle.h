@@ -91,7 +91,11 @@ void *orc_fftfilt_create(int N, const float *K);
 void orc_fftfilt_process(void *h, const float *in /*N*/, float *out /*N*/);
 void orc_fftfilt_destroy(void *h);
 /* plain double-precision DFT helper (sign = -1 forward, +1 backward, unnormalised), n = 2^k */
-void orc_dft_f64(int n, int sign, const double *in, double *out);
+void orc_dft_f64(int n, int sign, const double *in, double *out);   /* any n */
+/* FilterSource<double> (the filter classes are templates over Scalar): designer, spectrum, one overlap-add block */
+void orc_fftfilt_design_h_f64(int N, double fmin, double fmax, double Fs, double *h);
+void orc_fftfilt_design_K_f64(int N, const double *h, double *K);
+void orc_fftfilt_process_f64(int N, const double *K, double *last /*N cf64 state*/, const double *in /*N*/, double *out /*N*/);
 
 /* ---- build-defined float baseband (NO reference node exists) ----------------- */
 /* y = x[n] * exp(-2*pi*i*Fc*n/Fs), phasor in float64 closed form per absolute index, result

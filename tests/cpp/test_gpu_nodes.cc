@@ -553,12 +553,58 @@ static void testFftPlanOf(size_t n, double tol) {
 static void testFftPlan() {
   testFftPlanOf<float>(64, 2e-6); testFftPlanOf<float>(4096, 2e-6);
   testFftPlanOf<double>(64, 1e-13); testFftPlanOf<double>(8192, 1e-13);
+  // any size, as the reference plans whatever in.size() is (src/fftplan_fftw3.hh:34-36): FilterNode(1000)'s 2000 points,
+  // 3000, 5000, and factors up to 13
+  testFftPlanOf<float>(2000, 3e-6); testFftPlanOf<float>(3000, 3e-6); testFftPlanOf<float>(5000, 3e-6); testFftPlanOf<float>(1001, 3e-6);
+  testFftPlanOf<double>(1000, 1e-13); testFftPlanOf<double>(6006, 1e-13);
   bool threw = false;
-  try { Buffer< std::complex<double> > a(1000), b(1000); gpu::FFTPlan<double> p(a, b, gpu::FFT::FORWARD); } catch (ConfigError &) { threw = true; }
-  CHECK(threw);   // not a power of two: ConfigError at construction
+  try { Buffer< std::complex<double> > a(1003), b(1003); gpu::FFTPlan<double> p(a, b, gpu::FFT::FORWARD); } catch (ConfigError &) { threw = true; }
+  CHECK(threw);   // 1003 = 17 x 59: a prime factor the device does not plan — ConfigError at construction
   threw = false;
   try { Buffer< std::complex<float> > a(64), b(128); gpu::FFTPlan<float> p(a, b, gpu::FFT::FORWARD); } catch (ConfigError &) { threw = true; }
   CHECK(threw);   // sizes differ (the reference's check)
+}
+
+// FilterNode for a block size that is not a power of two and for Scalar = double (src/filternode.hh:230-245), against the
+// closed form of the reference's overlap-add filter: y = h (*) x / (sqrt(2N) ||h||_2)
+template <class Scalar>
+static void testFilterNodeOf(size_t N, double tol) {
+  typedef std::complex<Scalar> CS;
+  const size_t nblk = 4;
+  IQSigGen<Scalar> gen(FS, N); gen.addSine(100e3, 0.5, 0.0); gen.addSine(-300e3, 0.3, 0.3);
+  Recorder<CS> raw, band, band2;
+  gpu::FilterNode<Scalar> bank(N);
+  gen.connect(&raw, true); gen.connect(bank.sink(), true);
+  bank.addFilter(50e3, 150e3)->connect(&band, true);
+  typename gpu::FilterNode<Scalar>::Band *b2 = bank.addFilter(-350e3, -250e3);
+  b2->connect(&band2, true);
+  for (size_t b = 0; b < nblk; b++) gen.next();
+  CHECK(band.data.size() == nblk * N && band2.data.size() == nblk * N && b2->Source::sampleRate() == FS);
+  const double lo[2] = {50e3, -350e3}, hi[2] = {150e3, -250e3};
+  for (int k = 0; k < 2; k++) {
+    std::vector<Scalar> h(2 * N);
+    gpu::design::fftFilterKernel(int(N), lo[k], hi[k], FS, h.data());
+    long double e = 0;
+    for (size_t i = 0; i < 2 * N; i++) e += (long double)h[i] * h[i];
+    const long double sc = 1.0L / (sqrtl((long double)(2 * N)) * sqrtl(e));
+    const std::vector<CS> &y = k ? band2.data : band.data;
+    double err = 0, mx = 0;
+    for (size_t n = 0; n < y.size() && n < raw.data.size(); n += 7) {   // sampled outputs
+      std::complex<long double> acc(0, 0);
+      for (size_t t = 0; t < N && t <= n; t++)
+        acc += std::complex<long double>(h[2 * t], h[2 * t + 1]) * std::complex<long double>(raw.data[n - t].real(), raw.data[n - t].imag());
+      acc *= sc;
+      err = std::max(err, (double)std::abs(acc - std::complex<long double>(y[n].real(), y[n].imag())));
+      mx = std::max(mx, (double)std::abs(acc));
+    }
+    if (!(err <= tol * mx)) std::printf("  FilterNode<%s>(%zu) band %d: error %.3g of %.3g\n", sizeof(Scalar) == 8 ? "double" : "float", N, k, err, mx);
+    CHECK(err <= tol * mx);
+  }
+}
+static void testFilterNodeAnySizeAndDouble() {
+  testFilterNodeOf<float>(1000, 1e-5);
+  testFilterNodeOf<double>(1024, 1e-12);
+  testFilterNodeOf<double>(1000, 1e-12);
 }
 
 // The HOST half of the nodes (no device needed; tests/test_cpp.py builds this file with -fsanitize=address,undefined
@@ -634,6 +680,7 @@ int main(int argc, char **argv) {
     testRegeometryMidStream();
     testInt8Chain();
     testFftPlan();
+    testFilterNodeAnySizeAndDouble();
   } catch (std::exception &e) {
     std::printf("FAIL: exception: %s\n", e.what());
     return 2;

@@ -63,6 +63,20 @@ def test_product_designers_fftfilt(golden, orc, N):
     assert np.abs(K - Ko).max() <= 1e-6 * np.abs(Ko).max()
 
 
+def test_product_designers_fftfilt_any_block_size_and_double(golden, orc):
+    """g15: the product's sinc_flt_kernel<float> at N = 1000 and sinc_flt_kernel<double> (bit-exact to the reference's),
+    and the spectra behind them (any DFT length) against the oracle's."""
+    h = nodes.design_fftfilt_kernel(1000, -350e3, -250e3, 2.4e6)
+    assert np.array_equal(h, golden.load("g15_fftfilt_h1000"))
+    K, Ko = nodes.design_fftfilt_spectrum(h), orc.fftfilt_design_K(h)
+    assert K.shape == (2000, 2) and np.abs(K - Ko).max() <= 1e-6 * np.abs(Ko).max()
+    for N in (1000, 1024):
+        hd = nodes.design_fftfilt_kernel(N, -350e3, -250e3, 2.4e6, dtype=np.float64)
+        assert hd.dtype == np.float64 and np.array_equal(hd.ravel(), golden.load("g15_fftfilt_h%d_f64" % N))
+        K, Ko = nodes.design_fftfilt_spectrum(hd), orc.fftfilt_design_K_f64(hd)
+        assert K.dtype == np.float64 and np.abs(K - Ko).max() <= 1e-13 * np.abs(Ko).max()
+
+
 @pytest.mark.parametrize("case", ["g10_bb21d8", "g10_bb127d8_neg_ragged", "g10_bb64d5", "g10_bb16d1_noshift", "g10_bb1d3",
                                   "g10_bb127d8_loud"])
 def test_product_designers_real_baseband(golden, case):

@@ -1103,8 +1103,98 @@ def test_fft_exec_host_buffers(ctx, dt, tol):
     assert np.abs(X - np.fft.fft(x.astype(np.complex128))).max() / np.abs(X).max() < tol
     back = sa.fft_exec(ctx, X, +1)
     assert np.abs(back / 4096 - x).max() < tol * 10
-    with pytest.raises(sa.abi.SdrHipError):
-        sa.fft_exec(ctx, x[:1000], -1)
+    with pytest.raises(sa.abi.SdrHipError) as e:   # 1003 = 17 x 59: a prime factor the device does not plan
+        sa.fft_exec(ctx, x[:1003], -1)
+    assert e.value.code == sa.abi.E_UNSUPPORTED and "17" in str(e.value)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 6, 12, 100, 1000, 1001, 2000, 3000, 5000, 6006, 15000, 16380])
+def test_fft_any_size_vs_numpy(ctx, n):
+    """FFTPlan<float> / FFT::exec plan ANY size in the reference (fftw_plan_dft_1d(in.size(), ...), src/fftplan_fftw3.hh:34-36):
+    sizes that are not powers of two run the general mixed-radix plan (factors 2 ... 13; csrc/fftgen.hpp) — held to numpy's
+    double FFT like the power-of-two plans (FFTW is not in /root/reference)."""
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((3, n, 2)).astype(np.float32)
+    xc = x[..., 0].astype(np.float64) + 1j * x[..., 1]
+    for sign, ref in ((-1, np.fft.fft(xc, axis=1)), (+1, np.fft.ifft(xc, axis=1) * n)):
+        y = sa.fft_c2c(ctx, x, sign)
+        yc = y[..., 0].astype(np.float64) + 1j * y[..., 1]
+        assert np.abs(yc - ref).max() / np.abs(ref).max() < 3e-6, (n, sign)
+
+
+@pytest.mark.parametrize("n", [1, 3, 5, 7, 30, 1000, 2000, 2002, 3000, 5000, 6006, 8190])
+def test_fft_double_any_size_vs_numpy(ctx, n):
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((3, n, 2))
+    xc = x[..., 0] + 1j * x[..., 1]
+    for sign, ref in ((-1, np.fft.fft(xc, axis=1)), (+1, np.fft.ifft(xc, axis=1) * n)):
+        y = sa.fft_c2c_f64(ctx, x, sign)
+        assert np.abs(y[..., 0] + 1j * y[..., 1] - ref).max() / np.abs(ref).max() < 1e-13, (n, sign)
+
+
+def test_fft_sizes_the_device_does_not_plan(ctx):
+    """a prime factor above 13, or a transform that does not fit one workgroup's LDS: E_UNSUPPORTED with the reason"""
+    for fn, n, dt in ((sa.fft_c2c, 34, np.float32), (sa.fft_c2c, 16384 * 3, np.float32), (sa.fft_c2c_f64, 2 * 19, np.float64),
+                      (sa.fft_c2c_f64, 10000, np.float64)):
+        with pytest.raises(sa.abi.SdrHipError) as e:
+            fn(ctx, np.zeros((1, n, 2), dt), -1)
+        assert e.value.code == sa.abi.E_UNSUPPORTED, (n, str(e.value))
+
+
+@pytest.mark.parametrize("N,dtype,tol", [(1000, np.float32, RTOL), (1500, np.float32, RTOL), (1000, np.float64, 1e-12), (1024, np.float64, 1e-12),
+                                         (7, np.float32, RTOL)])
+def test_fftconv_any_block_size_and_double(ctx, golden, orc, N, dtype, tol):
+    """FilterNode(size_t block_size) for block sizes that are not powers of two, and FilterNode<double>
+    (src/filternode.hh:230-245): a 3-band bank behind one plan, two calls (history carried), ragged call lengths —
+    against the oracle's FilterSink / FilterSource blocks AND the closed form y = h (*) x / (sqrt(2N) ||h||_2)."""
+    f64 = np.dtype(dtype) == np.float64
+    bands = [(-350e3, -250e3), (50e3, 150e3), (-20e3, 20e3)]
+    hs = [sa.design_fftfilt_kernel(N, lo, hi, FS, dtype=dtype) for lo, hi in bands]
+    if N == 1000:
+        assert np.array_equal(hs[0].ravel(), golden.load("g15_fftfilt_h1000_f64") if f64 else golden.load("g15_fftfilt_h1000").ravel())
+    Ks = [sa.design_fftfilt_spectrum(h) for h in hs]
+    nblk = 5
+    rng = np.random.default_rng(N)
+    x = (rng.standard_normal((2, nblk * N, 2)) * 0.3).astype(dtype)
+    bank = sa.FFTConv(ctx, sa.FFTCONV_OLA, 2 * N, Ks, channels=2, max_in=nblk * N, dtype=dtype)
+    cut = 2 * N + N // 3   # (not a multiple of the block: the overlap-save evaluation takes any call length)
+    y = np.concatenate([bank.process(x[:, :cut]), bank.process(x[:, cut:])], axis=2)
+    assert y.shape == (3, 2, nblk * N, 2) and y.dtype == np.dtype(dtype)
+    for b, (h, K) in enumerate(zip(hs, Ks)):
+        flt = orc.FFTFilterF64(orc.fftfilt_design_K_f64(h)) if f64 else orc.FFTFilter(orc.fftfilt_design_K(h))
+        for c in range(2):
+            ref = np.concatenate([flt.process(x[c, i * N:(i + 1) * N]) for i in range(nblk)]) if c == 1 else None
+            yc = y[b, c, :, 0].astype(np.float64) + 1j * y[b, c, :, 1]
+            if ref is not None:
+                assert rel_err(y[b, c], ref) <= tol, (N, b, c)
+            hc = h[:, 0].astype(np.float64) + 1j * h[:, 1]
+            xc = x[c, :, 0].astype(np.float64) + 1j * x[c, :, 1]
+            closed = np.convolve(xc, hc)[:len(xc)] / (np.sqrt(2 * N) * np.sqrt((np.abs(hc) ** 2).sum()))
+            assert np.abs(yc - closed).max() / np.abs(closed).max() <= tol, (N, b, c)
+    # one band retuned between calls (FilterSource::setFreq): equals a plan made with the new kernel from the second call on
+    K2 = sa.design_fftfilt_spectrum(sa.design_fftfilt_kernel(N, 100e3, 300e3, FS, dtype=dtype))
+    b2 = sa.FFTConv(ctx, sa.FFTCONV_OLA, 2 * N, Ks, channels=2, max_in=nblk * N, dtype=dtype)
+    b2.process(x[:, :2 * N]); b2.set_kernel(1, K2)
+    fresh = sa.FFTConv(ctx, sa.FFTCONV_OLA, 2 * N, [Ks[0], K2, Ks[2]], channels=2, max_in=nblk * N, dtype=dtype)
+    fresh.process(x[:, :2 * N])
+    assert np.array_equal(b2.process(x[:, 2 * N:]), fresh.process(x[:, 2 * N:]))
+
+
+def test_fftconv_ols_taps_any_fft_size(ctx, orc):
+    """overlap-save with time-domain taps on FFT sizes that are not powers of two (float: 3000 points / 701 taps; double:
+    2000 / 301) against a direct convolution"""
+    rng = np.random.default_rng(5)
+    for L, M, dtype, tol in ((3000, 701, np.float32, RTOL), (2000, 301, np.float64, 1e-12)):
+        taps = (rng.standard_normal((M, 2)) / M).astype(dtype)
+        x = rng.standard_normal((2, 7000, 2)).astype(dtype)
+        node = sa.FFTConv(ctx, sa.FFTCONV_OLS, L, taps, channels=2, max_in=4000, dtype=dtype)
+        y = np.concatenate([node.process(x[:, :3111]), node.process(x[:, 3111:])], axis=1)
+        tc = taps[:, 0].astype(np.float64) + 1j * taps[:, 1]
+        for c in range(2):
+            xc = x[c, :, 0].astype(np.float64) + 1j * x[c, :, 1]
+            ref = np.convolve(xc, tc)[:7000]
+            yc = y[c, :, 0].astype(np.float64) + 1j * y[c, :, 1]
+            assert np.abs(yc - ref).max() / np.abs(ref).max() <= tol, (L, c)
 
 
 @pytest.mark.parametrize("N", [1024, 8192])

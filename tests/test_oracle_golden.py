@@ -85,6 +85,13 @@ def test_fftfilt_kernel_h(golden, orc, N):
     assert np.array_equal(h, golden.load("g7_fftfilt_h%d" % N))
 
 
+def test_fftfilt_kernel_h_any_block_size_and_double(golden, orc):
+    """g15: sinc_flt_kernel<float> at N = 1000 (FilterNode takes any block size) and sinc_flt_kernel<double>."""
+    assert np.array_equal(orc.fftfilt_design_h(1000, -350e3, -250e3, FS), golden.load("g15_fftfilt_h1000"))
+    for N in (1000, 1024):
+        assert np.array_equal(orc.fftfilt_design_h_f64(N, -350e3, -250e3, FS).ravel(), golden.load("g15_fftfilt_h%d_f64" % N))
+
+
 # ---- IQBaseBand<int16_t> ------------------------------------------------------------------------
 
 def run_iqbb(golden, orc, case, inp, suffix):
@@ -247,15 +254,38 @@ def test_fftfilt_closed_form(golden, orc, N):
     assert np.abs(yc - ref).max() / np.abs(ref).max() < 1e-5
 
 
-def test_dft_helper(orc):
+@pytest.mark.parametrize("n", [1, 2, 3, 256, 1000, 2000, 2002, 97, 3000])
+def test_dft_helper(orc, n):
+    """the oracle's own DFT (any length: the reference hands every size to FFTW) against numpy, both directions"""
     import ctypes as C
-    rng = np.random.default_rng(1)
-    n = 256
+    rng = np.random.default_rng(n)
     x = rng.standard_normal(2 * n)
     o = np.zeros(2 * n)
-    orc.lib().orc_dft_f64(n, -1, x.ctypes.data_as(C.POINTER(C.c_double)), o.ctypes.data_as(C.POINTER(C.c_double)))
-    ref = np.fft.fft(x[0::2] + 1j * x[1::2])
-    assert np.abs((o[0::2] + 1j * o[1::2]) - ref).max() < 1e-10
+    for sign, ref in ((-1, np.fft.fft(x[0::2] + 1j * x[1::2])), (+1, np.fft.ifft(x[0::2] + 1j * x[1::2]) * n)):
+        orc.lib().orc_dft_f64(n, sign, x.ctypes.data_as(C.POINTER(C.c_double)), o.ctypes.data_as(C.POINTER(C.c_double)))
+        assert np.abs((o[0::2] + 1j * o[1::2]) - ref).max() < 1e-10 * max(1.0, np.abs(ref).max())
+
+
+def test_fftfilt_closed_form_block_1000_and_double(golden, orc):
+    """FilterNode(1000) and FilterNode<double>: the overlap-add filter equals y = h (*) x / (sqrt(2N) ||h||_2) for a block
+    size that is not a power of two (float) and in double (1e-12)."""
+    N = 1000
+    h = golden.load("g15_fftfilt_h1000")
+    flt = orc.FFTFilter(orc.fftfilt_design_K(h))
+    x = golden.load("g1_iq_cf32")[:4 * N]
+    y = np.concatenate([flt.process(x[i * N:(i + 1) * N]) for i in range(4)])
+    hc = h[:, 0].astype(np.float64) + 1j * h[:, 1]
+    xc = x[:, 0].astype(np.float64) + 1j * x[:, 1]
+    ref = np.convolve(xc, hc)[:4 * N] / (np.sqrt(2 * N) * np.sqrt((np.abs(hc) ** 2).sum()))
+    assert np.abs(y[:, 0].astype(np.float64) + 1j * y[:, 1] - ref).max() / np.abs(ref).max() < 1e-5
+    for N in (1000, 1024):
+        hd = golden.load("g15_fftfilt_h%d_f64" % N).reshape(-1, 2)
+        fl = orc.FFTFilterF64(orc.fftfilt_design_K_f64(hd))
+        xd = x[:3 * N].astype(np.float64)
+        y = np.concatenate([fl.process(xd[i * N:(i + 1) * N]) for i in range(3)])
+        hc, xc = hd[:, 0] + 1j * hd[:, 1], xd[:, 0] + 1j * xd[:, 1]
+        ref = np.convolve(xc, hc)[:3 * N] / (np.sqrt(2 * N) * np.sqrt((np.abs(hc) ** 2).sum()))
+        assert np.abs(y[:, 0] + 1j * y[:, 1] - ref).max() / np.abs(ref).max() < 1e-12
 
 
 # ---- "next" rows (SURVEY §8f): AutoCast cu8 -> cs16 in front, FMDeemph behind ---------------------------
