@@ -41,18 +41,21 @@ public:
     return o._type == _type && o._sampleRate == _sampleRate && o._bufferSize == _bufferSize && o._numBuffers == _numBuffers;
   }
 
-  inline bool hasType() const { return Type_UNDEFINED != _type; }
-  inline Type type() const { return _type; }
-  inline void setType(Type type) { _type = type; }
-  inline bool hasSampleRate() const { return 0 != _sampleRate; }
-  inline double sampleRate() const { return _sampleRate; }
-  inline void setSampleRate(double rate) { _sampleRate = rate; }
-  inline bool hasBufferSize() const { return 0 != _bufferSize; }
-  inline size_t bufferSize() const { return _bufferSize; }
-  inline void setBufferSize(size_t size) { _bufferSize = size; }
-  inline bool hasNumBuffers() const { return 0 != _numBuffers; }
-  inline size_t numBuffers() const { return _numBuffers; }
-  inline void setNumBuffers(size_t N) { _numBuffers = N; }
+  // a field still at its zero value has not been decided upstream yet (nodes wait for the fields they need)
+  bool hasType() const { return _type != Type_UNDEFINED; }
+  bool hasSampleRate() const { return _sampleRate != 0.0; }
+  bool hasBufferSize() const { return _bufferSize > 0; }
+  bool hasNumBuffers() const { return _numBuffers > 0; }
+
+  Type type() const { return _type; }
+  double sampleRate() const { return _sampleRate; }
+  size_t bufferSize() const { return _bufferSize; }
+  size_t numBuffers() const { return _numBuffers; }
+
+  void setType(Type t) { _type = t; }
+  void setSampleRate(double hz) { _sampleRate = hz; }
+  void setBufferSize(size_t samples) { _bufferSize = samples; }
+  void setNumBuffers(size_t count) { _numBuffers = count; }
 
   template <typename T> static inline Type typeId();
 

@@ -53,19 +53,19 @@ void deliver(SinkBase *sink, const RawBuffer &buffer, bool allow_overwrite);
 
 class Queue {
 public:
+  /** One queued delivery: what goes where, and whether the receiver may write into it. */
   class Message {
   public:
-    Message(const RawBuffer &buffer, SinkBase *sink, bool allow_overwrite)
-      : _buffer(buffer), _sink(sink), _allow_overwrite(allow_overwrite) {}
-    inline const RawBuffer &buffer() const { return _buffer; }
-    inline RawBuffer &buffer() { return _buffer; }
-    inline SinkBase *sink() const { return _sink; }
-    inline bool allowOverwrite() const { return _allow_overwrite; }
+    Message(const RawBuffer &what, SinkBase *to, bool writable) : _what(what), _to(to), _writable(writable) {}
+    RawBuffer &buffer() { return _what; }
+    const RawBuffer &buffer() const { return _what; }
+    SinkBase *sink() const { return _to; }
+    bool allowOverwrite() const { return _writable; }
 
-  protected:
-    RawBuffer _buffer;
-    SinkBase *_sink;
-    bool _allow_overwrite;
+  private:
+    RawBuffer _what;
+    SinkBase *_to;
+    bool _writable;
   };
 
 protected:

@@ -138,10 +138,10 @@ int sdrhip_iqbb_i16_create(sdrhip_ctx *ctx, const int32_t *taps, int order, cons
                            uint32_t lut_inc, int negative, int decim, int channels, size_t max_in,
                            int epilogue, sdrhip_iqbb_i16 **out);
 /* which kernel formulation the plan selected: 0 = VALU v_dot2c_i32_i16 (any decim/order), 1 = int8-MFMA
- * block-Toeplitz GEMM on 32x32x32 tiles (decim 8, order <= 257; LDS-DMA fed, see kernel_names), 2 = the same on 16x16x64 tiles with an
- * in-wave MFMA/VALU pipeline (decim 8, order <= 153), 3 = the 32x32x32 matrix part for any other decimation with
- * the box windows summed through LDS (order <= 257); all bit-exact. Environment variable
- * SDRHIP_IQBB_PATH=valu|mfma|mfma16|mfmag states a preference at create time (tests, tuning). */
+ * block-Toeplitz GEMM on 32x32x32 tiles (decim 8, order <= 257; LDS-DMA fed, see kernel_names), 3 = the same matrix
+ * part for any other decimation (order <= 257), 4 = the real-input node on the matrix cores; all bit-exact.
+ * (2 was round 1's 16x16x64 shape, removed in round 4.) SDRHIP_IQBB_PATH=valu at create time selects the VALU kernel
+ * for every plan (tests). */
 int sdrhip_iqbb_i16_path(sdrhip_iqbb_i16 *h, int *path);
 /* Names of the kernels a call of this plan launches, dominant one first, comma separated (measurement aid: what to
  * look for in a rocprofv3 kernel trace). Path 1 (decim 8, order <= 257, complex<int16> or complex<uint8> input) runs
@@ -152,9 +152,8 @@ int sdrhip_iqbb_i16_path(sdrhip_iqbb_i16 *h, int *path);
  * without a shift, 21 taps / 125 with one; examples/sdr_rec.cc:42-68, examples/sdr_fm.cc:40) run "iqbb_hot_anyd_kernel" on long calls — the same persistent
  * structure, cold slices included (with FM a second, tiny launch completes the slices' first outputs); other path 3
  * plans and short calls the general kernel "iqbb_i16_mfmag_kernel".
- * Tuning / test variables read at create time: SDRHIP_IQBB_HOT=0 (general kernels only), SDRHIP_IQBB_DMA=0 (round 1's
- * register-staged general kernel); read per call: SDRHIP_IQBB_TPW (tiles per work unit), SDRHIP_IQBB_WGPCU (workgroups
- * per CU of the persistent grid). None changes results. */
+ * Tuning / test variables, all read at create time: SDRHIP_IQBB_HOT=0 (general kernels only), SDRHIP_IQBB_TPW (tiles per
+ * work unit), SDRHIP_IQBB_WGPCU (workgroups per CU of the persistent grid). None changes results. */
 int sdrhip_iqbb_i16_kernel_names(sdrhip_iqbb_i16 *h, char *buf, size_t len);
 /* outputs the next call of n_in samples will produce (does not advance the state) */
 int sdrhip_iqbb_i16_out_count(sdrhip_iqbb_i16 *h, size_t n_in, size_t *n_out);

@@ -127,6 +127,30 @@ __device__ __forceinline__ void dft16(float2 *v) {
   for (int m = 0; m < 16; m++) v[m] = o[m];
 }
 
+// The last two passes of a plan that ends in radix 4 (stride 2) and radix 2 (stride 1) — 2048 = 16 x 16 x 4 x 2 — work
+// inside groups of 8 CONSECUTIVE elements: one lane runs both on a group held in registers (same butterflies, same
+// twiddles W8^(j m), same element order as the two LDS passes they replace, so the spectrum layout is unchanged).
+// forward (decimation in frequency): radix 4 over (e[j], e[j+2], e[j+4], e[j+6]), j = 0, 1, then radix 2 over the pairs
+__device__ __forceinline__ void dif8_fwd(float2 *e) {
+  constexpr float H = 0.70710678118654752f;
+  float2 a0, a1, a2, a3, b0, b1, b2, b3;
+  bfly4<-1>(e[0], e[2], e[4], e[6], a0, a1, a2, a3);
+  bfly4<-1>(e[1], e[3], e[5], e[7], b0, b1, b2, b3);
+  b1 = cmul_k<true>(b1, H, H);      // W8^1 = (H, -H)
+  b2 = mul_mi(b2);                  // W8^2 = -i
+  b3 = cmul_k<true>(b3, -H, H);     // W8^3 = (-H, -H)
+  e[0] = cadd(a0, b0); e[1] = csub(a0, b0); e[2] = cadd(a1, b1); e[3] = csub(a1, b1);
+  e[4] = cadd(a2, b2); e[5] = csub(a2, b2); e[6] = cadd(a3, b3); e[7] = csub(a3, b3);
+}
+// backward (decimation in time): radix 2 over the pairs, then radix 4 with the conjugate twiddles
+__device__ __forceinline__ void dit8_inv(float2 *e) {
+  constexpr float H = 0.70710678118654752f;
+  const float2 a0 = cadd(e[0], e[1]), b0 = csub(e[0], e[1]), a1 = cadd(e[2], e[3]), b1 = csub(e[2], e[3]);
+  const float2 a2 = cadd(e[4], e[5]), b2 = csub(e[4], e[5]), a3 = cadd(e[6], e[7]), b3 = csub(e[6], e[7]);
+  bfly4<1>(a0, a1, a2, a3, e[0], e[2], e[4], e[6]);
+  bfly4<1>(b0, cmul_k<false>(b1, H, H), mul_pi(b2), cmul_k<false>(b3, -H, H), e[1], e[3], e[5], e[7]);
+}
+
 // twiddles W^(j tw k), k = 1..15, of radix-16 pass q for butterfly column j: straight from the pass's own table
 // (lanes walk consecutive j: 15 coalesced loads that hit L1/L2). Deriving them from 4 table entries with 11 complex
 // products cost a quarter of the kernel (ablation: 0.80 -> 0.61 ms).
@@ -320,7 +344,21 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
   constexpr int FT = NT;   // (shadows the file-wide workgroup size)
   extern __shared__ __attribute__((aligned(16))) float2 xl[];
   const FftDev &p = a.fft;
+  // TAIL8 (the 2048-point plan 16 x 16 x 4 x 2, the filter-bank node's default block): the radix-4 (stride 2) and radix-2
+  // (stride 1) passes run in REGISTERS on groups of 8 consecutive elements (dif8_fwd / dit8_inv), two groups per lane — one
+  // LDS round trip and one barrier less per transform, and the two passes whose 16-byte-strided accesses were 4-way bank
+  // conflicts (r12's counters: 55 % of this kernel's LDS cycles) are gone. The image is padded 2 elements per 32 instead
+  // of 4 per 64: a lane's 64-byte group then starts 16 (t >> 2) + 64 t bytes in, so the 16 lanes of one ds_read_b128 /
+  // ds_write_b128 cover all 16 slots of a bank row, and the radix-16 stride-8 pass (8 lanes per 64 contiguous bytes,
+  // neighbouring octets 1088 bytes apart) stays conflict-free as before.
+#ifdef K7_NO_TAIL8   // (A/B: the four-pass LDS form)
+  constexpr bool TAIL8 = false;
+#else
+  constexpr bool TAIL8 = LG == 11 && NT == 128;
+#endif
+  auto P = [](int i) { return TAIL8 ? i + ((i >> 5) << 1) : PAD(i); };
   const int L = LG ? (1 << LG) : p.L, np = LG ? plan_npass(LG) : p.npass;
+  const int np_lds = TAIL8 ? np - 1 : np;   // passes that go through LDS (TAIL8: the last two are one register step)
   auto radix_at = [&](int q) { return LG ? plan_radix(LG, q) : p.radix[q]; };
   // (one workgroup per (channel, block). A persistent grid — the resident workgroups walking the units in a loop —
   // measured 4.5 % SLOWER: a 16384-point block fills the CU's LDS, so either way one workgroup runs per CU, but the
@@ -383,13 +421,13 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
 #pragma unroll
       for (int k = 1; k < 16; k++) v[k] = cmul(v[k], w[k]);
 #pragma unroll
-      for (int k = 0; k < 16; k++) xl[PAD(j + k * s)] = v[k];
+      for (int k = 0; k < 16; k++) xl[P(j + k * s)] = v[k];
     }
     __syncthreads();
   }
   // ---- forward passes 1 .. np-2 in LDS ----
   int n = L / 16;
-  for (int pass = 1; pass + 1 < np; pass++) {
+  for (int pass = 1; pass + 1 < np_lds; pass++) {
     const int tid = lane();
     const int r = radix_at(pass), s = n / r, tw = L / n;
     if (r == 16) {
@@ -397,24 +435,24 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
         const int j = b & (s - 1), base = (b / s) * n + j;
         float2 v[16], w[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) v[k] = xl[PAD(base + k * s)];
+        for (int k = 0; k < 16; k++) v[k] = xl[P(base + k * s)];
         dft16<-1>(v);
         twiddles16(p, pass, s, j, w);
 #pragma unroll
         for (int k = 1; k < 16; k++) v[k] = cmul(v[k], w[k]);
 #pragma unroll
-        for (int k = 0; k < 16; k++) xl[PAD(base + k * s)] = v[k];
+        for (int k = 0; k < 16; k++) xl[P(base + k * s)] = v[k];
       }
     } else {   // radix 4 (a radix-2 pass can only be the last one)
       for (int b = tid; b < L / 4; b += FT) {   // (not reached by the 16384-point plan: its radix-4 pass is the last one)
         const int j = b & (s - 1), base = (b / s) * n + j;
-        const float2 a0 = xl[PAD(base)], a1 = xl[PAD(base + s)], a2 = xl[PAD(base + 2 * s)], a3 = xl[PAD(base + 3 * s)];
+        const float2 a0 = xl[P(base)], a1 = xl[P(base + s)], a2 = xl[P(base + 2 * s)], a3 = xl[P(base + 3 * s)];
         float2 X0, X1, X2, X3;
         bfly4<-1>(a0, a1, a2, a3, X0, X1, X2, X3);
-        xl[PAD(base)] = X0;
-        xl[PAD(base + s)] = cmul(X1, p.W[j * tw]);
-        xl[PAD(base + 2 * s)] = cmul(X2, p.W[2 * j * tw]);
-        xl[PAD(base + 3 * s)] = cmul(X3, p.W[3 * j * tw]);
+        xl[P(base)] = X0;
+        xl[P(base + s)] = cmul(X1, p.W[j * tw]);
+        xl[P(base + 2 * s)] = cmul(X2, p.W[2 * j * tw]);
+        xl[P(base + 3 * s)] = cmul(X3, p.W[3 * j * tw]);
       }
     }
     pass_sync();
@@ -428,24 +466,51 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
   float2 *xw = xl;
   const int nb = BANK ? a.nb : 1;
   float2 fwd[16];
-  if (BANK) {
+  // (TAIL8) the lane's two groups of 8 consecutive elements: group g at elements 8 g .. 8 g + 7, four 16-byte pieces
+  auto load8 = [&](const float2 *img, int g, float2 *e) {
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      const float4 q = *reinterpret_cast<const float4 *>(img + P(8 * g + 2 * m));
+      e[2 * m] = make_float2(q.x, q.y); e[2 * m + 1] = make_float2(q.z, q.w);
+    }
+  };
+  auto store8 = [&](float2 *img, int g, const float2 *e) {
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+      *reinterpret_cast<float4 *>(img + P(8 * g + 2 * m)) = make_float4(e[2 * m].x, e[2 * m].y, e[2 * m + 1].x, e[2 * m + 1].y);
+  };
+  // which group a lane owns: lane bits (0, 1, 2, 3) -> group bits (0, 2, 3, 1). With the groups in lane order the eight
+  // lanes of a ds_write_b128 group land on 4 of the 8 slots of a 128-byte row, two by two (every remaining conflict cycle of
+  // the first TAIL8 cut: counter = model = 256 per wave and block); permuted, a group's stores cover all 8 slots, the four
+  // reads per transform pay one extra cycle each instead (model: 512 -> 64 extra cycles per block of a 4-band bank).
+#ifdef K7_NO_GROUP_PERM   // (A/B: groups in lane order)
+  auto group_of = [](int t) { return t; };
+#else
+  auto group_of = [](int t) { return (t & ~0xE) | (((t >> 1) & 1) << 2) | (((t >> 2) & 1) << 3) | (((t >> 3) & 1) << 1); };
+#endif
+  if (BANK && TAIL8) {
+    const int tid = group_of(lane());
+    load8(xl, tid, fwd); load8(xl, tid + FT, fwd + 8);
+    dif8_fwd(fwd); dif8_fwd(fwd + 8);
+    __syncthreads();   // every lane holds its part of the spectrum: the image is free
+  } else if (BANK) {
     const int tid = lane();
     const int r = radix_at(np - 1);
     if (r == 16) {
 #pragma unroll
-      for (int k = 0; k < 16; k++) fwd[k] = xl[PAD(16 * tid + k)];
+      for (int k = 0; k < 16; k++) fwd[k] = xl[P(16 * tid + k)];
       dft16<-1>(fwd);
     } else if (r == 4) {
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const int b = tid + q * FT;
-        bfly4<-1>(xl[PAD(4 * b)], xl[PAD(4 * b + 1)], xl[PAD(4 * b + 2)], xl[PAD(4 * b + 3)], fwd[4 * q], fwd[4 * q + 1], fwd[4 * q + 2], fwd[4 * q + 3]);
+        bfly4<-1>(xl[P(4 * b)], xl[P(4 * b + 1)], xl[P(4 * b + 2)], xl[P(4 * b + 3)], fwd[4 * q], fwd[4 * q + 1], fwd[4 * q + 2], fwd[4 * q + 3]);
       }
     } else {
 #pragma unroll
       for (int q = 0; q < 8; q++) {
         const int b = tid + q * FT;
-        const float2 a0 = xl[PAD(2 * b)], a1 = xl[PAD(2 * b + 1)];
+        const float2 a0 = xl[P(2 * b)], a1 = xl[P(2 * b + 1)];
         fwd[2 * q] = cadd(a0, a1); fwd[2 * q + 1] = csub(a0, a1);
       }
     }
@@ -455,7 +520,30 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
   const float2 *kp = BANK ? a.Kp + (long)band * L : a.Kp;
   float2 *outb = BANK ? a.out + (long)band * a.out_band : a.out;
   // ---- last forward pass (stride 1, no twiddles) x spectrum x first inverse pass ----
-  if (BANK) {
+  if (TAIL8) {
+    const int tid = group_of(lane());
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int g = tid + h * FT;
+      float2 v[8];
+      if (BANK) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = fwd[8 * h + k];
+      } else {
+        load8(xl, g, v);
+        dif8_fwd(v);
+      }
+      const float4 *kq = reinterpret_cast<const float4 *>(kp + 8 * g);   // (the spectrum rows are 16-byte aligned: hipMalloc + 8 L bytes per band)
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        const float4 q = kq[m];
+        v[2 * m] = cmul(v[2 * m], make_float2(q.x, q.y)); v[2 * m + 1] = cmul(v[2 * m + 1], make_float2(q.z, q.w));
+      }
+      dit8_inv(v);
+      store8(xw, g, v);   // (in place: the group is this lane's own)
+    }
+    __syncthreads();
+  } else if (BANK) {
     const int tid = lane();
     const int r = radix_at(np - 1);
     if (r == 16) {
@@ -464,21 +552,21 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
       for (int k = 0; k < 16; k++) v[k] = cmul(fwd[k], kp[16 * tid + k]);
       dft16<1>(v);
 #pragma unroll
-      for (int k = 0; k < 16; k++) xw[PAD(16 * tid + k)] = v[k];
+      for (int k = 0; k < 16; k++) xw[P(16 * tid + k)] = v[k];
     } else if (r == 4) {
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const int b = tid + q * FT;
         float2 Z0, Z1, Z2, Z3;
         bfly4<1>(cmul(fwd[4 * q], kp[4 * b]), cmul(fwd[4 * q + 1], kp[4 * b + 1]), cmul(fwd[4 * q + 2], kp[4 * b + 2]), cmul(fwd[4 * q + 3], kp[4 * b + 3]), Z0, Z1, Z2, Z3);
-        xw[PAD(4 * b)] = Z0; xw[PAD(4 * b + 1)] = Z1; xw[PAD(4 * b + 2)] = Z2; xw[PAD(4 * b + 3)] = Z3;
+        xw[P(4 * b)] = Z0; xw[P(4 * b + 1)] = Z1; xw[P(4 * b + 2)] = Z2; xw[P(4 * b + 3)] = Z3;
       }
     } else {
 #pragma unroll
       for (int q = 0; q < 8; q++) {
         const int b = tid + q * FT;
         const float2 y0 = cmul(fwd[2 * q], kp[2 * b]), y1 = cmul(fwd[2 * q + 1], kp[2 * b + 1]);
-        xw[PAD(2 * b)] = cadd(y0, y1); xw[PAD(2 * b + 1)] = csub(y0, y1);
+        xw[P(2 * b)] = cadd(y0, y1); xw[P(2 * b + 1)] = csub(y0, y1);
       }
     }
     __syncthreads();
@@ -490,35 +578,35 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
       for (int b = tid; b < L / 16; b += FT) {
         float2 v[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) v[k] = xs[PAD(16 * b + k)];
+        for (int k = 0; k < 16; k++) v[k] = xs[P(16 * b + k)];
         dft16<-1>(v);
 #pragma unroll
         for (int k = 0; k < 16; k++) v[k] = cmul(v[k], kp[16 * b + k]);
         dft16<1>(v);
 #pragma unroll
-        for (int k = 0; k < 16; k++) xw[PAD(16 * b + k)] = v[k];
+        for (int k = 0; k < 16; k++) xw[P(16 * b + k)] = v[k];
       }
     } else if (r == 4) {
       for (int q = 0; q * FT + (WAVE_LOCAL ? 0 : tid) < L / 4; q++) {   // (small plans: fewer butterflies than lanes)
         const int b = bfly4_index(tid, q);
-        const float2 a0 = xs[PAD(4 * b)], a1 = xs[PAD(4 * b + 1)], a2 = xs[PAD(4 * b + 2)], a3 = xs[PAD(4 * b + 3)];
+        const float2 a0 = xs[P(4 * b)], a1 = xs[P(4 * b + 1)], a2 = xs[P(4 * b + 2)], a3 = xs[P(4 * b + 3)];
         float2 X0, X1, X2, X3, Z0, Z1, Z2, Z3;
         bfly4<-1>(a0, a1, a2, a3, X0, X1, X2, X3);
         bfly4<1>(cmul(X0, kp[4 * b]), cmul(X1, kp[4 * b + 1]), cmul(X2, kp[4 * b + 2]), cmul(X3, kp[4 * b + 3]), Z0, Z1, Z2, Z3);
-        xw[PAD(4 * b)] = Z0; xw[PAD(4 * b + 1)] = Z1; xw[PAD(4 * b + 2)] = Z2; xw[PAD(4 * b + 3)] = Z3;
+        xw[P(4 * b)] = Z0; xw[P(4 * b + 1)] = Z1; xw[P(4 * b + 2)] = Z2; xw[P(4 * b + 3)] = Z3;
       }
     } else {
       for (int b = tid; b < L / 2; b += FT) {
-        const float2 a0 = xs[PAD(2 * b)], a1 = xs[PAD(2 * b + 1)];
+        const float2 a0 = xs[P(2 * b)], a1 = xs[P(2 * b + 1)];
         const float2 y0 = cmul(cadd(a0, a1), kp[2 * b]), y1 = cmul(csub(a0, a1), kp[2 * b + 1]);
-        xw[PAD(2 * b)] = cadd(y0, y1); xw[PAD(2 * b + 1)] = csub(y0, y1);
+        xw[P(2 * b)] = cadd(y0, y1); xw[P(2 * b + 1)] = csub(y0, y1);
       }
     }
     pass_sync();
   }
   // ---- inverse passes np-2 .. 1 in LDS ----
-  n = radix_at(np - 1);
-  for (int pass = np - 2; pass >= 1; pass--) {
+  n = TAIL8 ? 8 : radix_at(np - 1);
+  for (int pass = np_lds - 2; pass >= 1; pass--) {
     const int tid = lane();
     const int r = radix_at(pass), s = n;
     n *= r;
@@ -528,24 +616,24 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
         const int j = b & (s - 1), base = (b / s) * n + j;
         float2 v[16], w[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) v[k] = xw[PAD(base + k * s)];
+        for (int k = 0; k < 16; k++) v[k] = xw[P(base + k * s)];
         twiddles16(p, pass, s, j, w);
 #pragma unroll
         for (int k = 1; k < 16; k++) v[k] = cmulc(v[k], w[k]);
         dft16<1>(v);
 #pragma unroll
-        for (int k = 0; k < 16; k++) xw[PAD(base + k * s)] = v[k];
+        for (int k = 0; k < 16; k++) xw[P(base + k * s)] = v[k];
       }
     } else {
       for (int b = tid; b < L / 4; b += FT) {
         const int j = b & (s - 1), base = (b / s) * n + j;
-        const float2 a0 = xw[PAD(base)];
-        const float2 a1 = cmulc(xw[PAD(base + s)], p.W[j * tw]);
-        const float2 a2 = cmulc(xw[PAD(base + 2 * s)], p.W[2 * j * tw]);
-        const float2 a3 = cmulc(xw[PAD(base + 3 * s)], p.W[3 * j * tw]);
+        const float2 a0 = xw[P(base)];
+        const float2 a1 = cmulc(xw[P(base + s)], p.W[j * tw]);
+        const float2 a2 = cmulc(xw[P(base + 2 * s)], p.W[2 * j * tw]);
+        const float2 a3 = cmulc(xw[P(base + 3 * s)], p.W[3 * j * tw]);
         float2 X0, X1, X2, X3;
         bfly4<1>(a0, a1, a2, a3, X0, X1, X2, X3);
-        xw[PAD(base)] = X0; xw[PAD(base + s)] = X1; xw[PAD(base + 2 * s)] = X2; xw[PAD(base + 3 * s)] = X3;
+        xw[P(base)] = X0; xw[P(base + s)] = X1; xw[P(base + 2 * s)] = X2; xw[P(base + 3 * s)] = X3;
       }
     }
     if (pass > 1) pass_sync(); else __syncthreads();   // (the last inverse pass crosses the segments again)
@@ -557,7 +645,7 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
     for (int j = tid; j < s; j += FT) {
       float2 v[16], w[16];
 #pragma unroll
-      for (int k = 0; k < 16; k++) v[k] = xw[PAD(j + k * s)];
+      for (int k = 0; k < 16; k++) v[k] = xw[P(j + k * s)];
       twiddles16(p, 0, s, j, w);
 #pragma unroll
       for (int k = 1; k < 16; k++) v[k] = cmulc(v[k], w[k]);

@@ -725,229 +725,6 @@ __global__ void iqbb_fm_fixup_kernel(short *__restrict__ out, long out_stride, c
   row[sl * fix_gs] = (short)(row[sl * fix_gs] + philast[(long)c * philast_stride + sl - 1]);
 }
 
-// =================================================================================================
-// MFMA formulation, 16x16x64 tiles with an in-wave software pipeline (path 2; D == 8, order <= 153).
-//
-// Same byte-plane algebra as above, but a block is ONE decimation group (8 samples), a sub-tile is 16
-// blocks (Dmat[m = (t,comp): 16][n = block: 16], K = 64 per instruction) and a wave walks the 4 sub-tiles
-// of its 64 groups. A sub-tile needs only 3 x 4 accumulator registers, so two sets fit and the MFMA chain
-// of sub-tile j+1 is issued interleaved with the vector epilogue of sub-tile j by the SAME wave: the
-// matrix pipe and the VALU overlap without relying on other waves being in a different phase. Tap
-// fragments stay in registers (8 VGPRs per K step); the plain plane layout is already conflict-free for
-// this shape (lane (n,g) reads chunk b0+n+4s+g: 16 consecutive chunks per lane group).
-// Result layout (16x16 C/D map): lane (n = l&15, g = l>>4), register r -> comp = r&1, t = 2g + (r>>1).
-// =================================================================================================
-template <int S, bool ROT>
-__global__ __launch_bounds__(TPB, 3) void iqbb_i16_mfma16_kernel(const IqbbArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  const int PLW = (2 * (TI + a.OP) + 64 + 15) / 16 * 4;    // dwords per byte plane (plain layout)
-  int2 *lut_s = reinterpret_cast<int2 *>(smem + 4 * PLW);   // after two double-buffered plane pairs
-
-  const int c = blockIdx.y, tid = threadIdx.x;
-  const int w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
-  v4i Ah[S], Al[S];   // Toeplitz tap fragments, wave-invariant: lane (m = l&15, g) byte j <-> k = 64s+16g+j
-#pragma unroll
-  for (int s = 0; s < S; s++) { Ah[s] = a.tapfrag[(2 * s) * 64 + l]; Al[s] = a.tapfrag[(2 * s + 1) * 64 + l]; }
-  if (tid < 128) lut_s[tid] = a.lut[tid];
-
-  constexpr int NQ = (TI + 153 + 2 + 4 * TPB - 1) / (4 * TPB);   // sample quads per lane and tile (OP <= 153)
-  struct __attribute__((packed, aligned(4))) Quad { uint32_t v[4]; };
-  Quad px[NQ];
-  auto fetch = [&](int tile_) {
-    const int q0_ = tile_ * a.OG - a.ovl;
-    const int first = a.base0_rel + q0_ * 8 - (a.OP - 1);
-    const int quads = (min(a.CG, a.n_groups - q0_) * 8 + a.OP + 4) / 4;
-    if (!a.in_cu8 && first >= 0 && first + 4 * quads <= a.N) {
-      const uint32_t *src = a.in + (long)c * a.in_stride + first;
-#pragma unroll
-      for (int k = 0; k < NQ; k++) {
-        const int p = tid + k * TPB;
-        if (p < quads) px[k] = *reinterpret_cast<const Quad *>(src + 4 * p);
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < NQ; k++) {
-        const int p = tid + k * TPB;
-        if (p < quads) {
-#pragma unroll
-          for (int j = 0; j < 4; j++) px[k].v[j] = load_x(a, c, first + 4 * p + j);
-        }
-      }
-    }
-  };
-
-  const int OGw = 64 - a.ovl, gw = w * OGw;   // groups a wave emits / its first group (= block) within a tile
-  const int tile_end = min((int)(blockIdx.x + 1) * a.tpw, a.tiles);
-  int tile = blockIdx.x * a.tpw;
-  if (tile < tile_end) fetch(tile);
-  for (int it = 0; tile < tile_end; tile++, it++) {
-    const int q0 = tile * a.OG - a.ovl;
-    const int tb = a.base0_rel + q0 * 8;
-    const int groups_here = min(a.CG, a.n_groups - q0);
-    uint32_t *lo = smem + (it & 1) * 2 * PLW, *hi = lo + PLW;
-    {
-      const int quads = (groups_here * 8 + a.OP + 4) / 4;
-#pragma unroll
-      for (int k = 0; k < NQ; k++) {
-        const int p = tid + k * TPB;
-        if (p < quads) {
-          uint2 l2, h2;
-          l2.x = __builtin_amdgcn_perm(px[k].v[1], px[k].v[0], 0x06040200u) ^ 0x80808080u;
-          l2.y = __builtin_amdgcn_perm(px[k].v[3], px[k].v[2], 0x06040200u) ^ 0x80808080u;
-          h2.x = __builtin_amdgcn_perm(px[k].v[1], px[k].v[0], 0x07050301u);
-          h2.y = __builtin_amdgcn_perm(px[k].v[3], px[k].v[2], 0x07050301u);
-          *reinterpret_cast<uint2 *>(lo + 2 * p) = l2;
-          *reinterpret_cast<uint2 *>(hi + 2 * p) = h2;
-        }
-      }
-    }
-    __syncthreads();   // the only barrier per tile (planes are double-buffered)
-    if (tile + 1 < tile_end) fetch(tile + 1);
-
-    if (gw + a.ovl < groups_here) {   // wave-uniform: the wave has at least one group of its own
-      const char *pl = reinterpret_cast<const char *>(lo) + 16 * (gw + n + g);   // chunk gw + 16j + n + 4s + g
-      const char *ph = reinterpret_cast<const char *>(hi) + 16 * (gw + n + g);
-      const int rel_base = tb + 8 * (gw + n) + 2 * g;   // sample (j, k) of this lane sits at rel_base + 128 j + k
-      const bool edge = (tb < 0) || (tb + groups_here * 8 > a.N);
-      uint32_t cntb = 0;
-      if (ROT) cntb = (a.n0_lo + (uint32_t)rel_base) * a.inc;
-      const uint32_t negx = a.negative ? 127u : 0u;
-      v4i hh[2], mid[2], ll[2];
-      int2 part[4];
-
-      // K step s of sub-tile j into accumulator set b
-      auto mstep = [&](int j, int s, int b) {
-        const v4i ul = *reinterpret_cast<const v4i *>(pl + 256 * j + 64 * s);
-        const v4i uh = *reinterpret_cast<const v4i *>(ph + 256 * j + 64 * s);
-        if (s == 0) {
-          const v4i z = {0, 0, 0, 0};
-          const v4i cc = {a.cre, a.cim, a.cre, a.cim};   // + 128*sum(a) rides in as C
-          mid[b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ah[s], ul, z, 0, 0, 0);
-          hh[b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ah[s], uh, z, 0, 0, 0);
-          mid[b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Al[s], uh, mid[b], 0, 0, 0);
-          ll[b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Al[s], ul, cc, 0, 0, 0);
-        } else {
-          mid[b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ah[s], ul, mid[b], 0, 0, 0);
-          hh[b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ah[s], uh, hh[b], 0, 0, 0);
-          mid[b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Al[s], uh, mid[b], 0, 0, 0);
-          ll[b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Al[s], ul, ll[b], 0, 0, 0);
-        }
-      };
-      // vector epilogue of sub-tile j (accumulator set b), in 5 chunks that ride in the shadow of the MFMAs
-      int2 r0, r1, L0, L1;
-      auto echunk = [&](int j, int ch, int b) {
-        if (ch == 0) {   // recombine the byte planes, >>14
-          const unsigned s0 = ((((unsigned)hh[b][0] << 8) + (unsigned)mid[b][0]) << 8) + (unsigned)ll[b][0];
-          const unsigned s1 = ((((unsigned)hh[b][1] << 8) + (unsigned)mid[b][1]) << 8) + (unsigned)ll[b][1];
-          const unsigned s2 = ((((unsigned)hh[b][2] << 8) + (unsigned)mid[b][2]) << 8) + (unsigned)ll[b][2];
-          const unsigned s3 = ((((unsigned)hh[b][3] << 8) + (unsigned)mid[b][3]) << 8) + (unsigned)ll[b][3];
-          r0 = make_int2((int)s0 >> 14, (int)s1 >> 14);
-          r1 = make_int2((int)s2 >> 14, (int)s3 >> 14);
-        } else if (ch == 1) {   // LUT reads of the two samples
-          if (ROT) {
-            const uint32_t i0 = (((cntb + (uint32_t)(128 * j) * a.inc) & 32767u) >> 8) ^ negx;
-            const uint32_t i1 = (((cntb + (uint32_t)(128 * j + 1) * a.inc) & 32767u) >> 8) ^ negx;
-            L0 = lut_s[i0]; L1 = lut_s[i1];
-          }
-        } else if (ch == 2) {
-          if (ROT) {
-            const int2 r = r0;
-            r0.x = (int)((unsigned)__mul24(L0.x, r.x) - (unsigned)__mul24(L0.y, r.y)) >> 16;
-            r0.y = (int)((unsigned)__mul24(L0.x, r.y) + (unsigned)__mul24(L0.y, r.x)) >> 16;
-          }
-        } else if (ch == 3) {
-          if (ROT) {
-            const int2 r = r1;
-            r1.x = (int)((unsigned)__mul24(L1.x, r.x) - (unsigned)__mul24(L1.y, r.y)) >> 16;
-            r1.y = (int)((unsigned)__mul24(L1.x, r.y) + (unsigned)__mul24(L1.y, r.x)) >> 16;
-          }
-        } else {
-          if (edge) {
-            const int rel = rel_base + 128 * j;
-            if (rel < 0 || rel >= a.N) r0 = make_int2(0, 0);
-            if (rel + 1 < 0 || rel + 1 >= a.N) r1 = make_int2(0, 0);
-          }
-          part[j] = make_int2((int)((unsigned)r0.x + (unsigned)r1.x), (int)((unsigned)r0.y + (unsigned)r1.y));
-        }
-      };
-      // source order is the schedule: K step s of sub-tile j+1, then the epilogue chunk(s) of sub-tile j
-#pragma unroll
-      for (int s = 0; s < S; s++) mstep(0, s, 0);
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-#pragma unroll
-        for (int s = 0; s < S; s++) {
-          if (j + 1 < 4) mstep(j + 1, s, (j + 1) & 1);
-#pragma unroll
-          for (int ch = 0; ch < 5; ch++)
-            if ((ch * S) / 5 == s) echunk(j, ch, j & 1);
-        }
-      }
-      // transposing reduction over the four lanes (g = 0..3) that share a block: lane (n, g) ends up with the
-      // complete sum of block n of sub-tile j = g, i.e. group glw = 16 g + n = l of the wave
-      int2 sum;
-      {
-        const bool odd = g & 1;   // (selects, not runtime-indexed arrays: those go to scratch)
-        int2 keepA = odd ? part[1] : part[0], keepB = odd ? part[3] : part[2];             // j with the same low bit as g
-        const int2 giveA = odd ? part[0] : part[1], giveB = odd ? part[2] : part[3];
-        keepA.x = (int)((unsigned)keepA.x + (unsigned)__shfl_xor(giveA.x, 16));
-        keepA.y = (int)((unsigned)keepA.y + (unsigned)__shfl_xor(giveA.y, 16));
-        keepB.x = (int)((unsigned)keepB.x + (unsigned)__shfl_xor(giveB.x, 16));
-        keepB.y = (int)((unsigned)keepB.y + (unsigned)__shfl_xor(giveB.y, 16));
-        const int2 mine = (g & 2) ? keepB : keepA, give = (g & 2) ? keepA : keepB;
-        sum.x = (int)((unsigned)mine.x + (unsigned)__shfl_xor(give.x, 32));
-        sum.y = (int)((unsigned)mine.y + (unsigned)__shfl_xor(give.y, 32));
-      }
-      // ---- wave-local group epilogue: lane l owns group l of the wave ----------------------------------
-      const int glw = l;
-      const int ql = gw + glw, q = q0 + ql;
-      const bool live = (ql < groups_here) && (q >= 0);
-      if (live && q == 0) {
-        const int2 carry = a.acc_old[c];
-        sum.x = (int)((unsigned)sum.x + (unsigned)carry.x);
-        sum.y = (int)((unsigned)sum.y + (unsigned)carry.y);
-        if (a.extra0) {
-          int er = 0, ei = 0;
-          for (int i = 0; i < a.OP; i++) {
-            const uint32_t x = load_x(a, c, -(a.OP - 1) + i);
-            const uint2 k = a.taps[i];
-            er = dot2(x, k.x, er); ei = dot2(x, k.y, ei);
-          }
-          const int2 v = rotate(a, lut_s, make_int2(er >> 14, ei >> 14), a.n0_lo);
-          sum.x = (int)((unsigned)sum.x + (unsigned)v.x);
-          sum.y = (int)((unsigned)sum.y + (unsigned)v.y);
-        }
-      }
-      const bool own = live && (glw >= a.ovl);
-      const bool emits = live && (q < a.n_out);
-      const int yr = (short)box_div(sum.x, 8), yi = (short)box_div(sum.y, 8);
-      if (own && q == a.n_groups - 1) a.acc_new[c] = emits ? make_int2(0, 0) : sum;
-      if (a.epilogue == SDRHIP_EPI_NONE) {
-        if (own && emits) reinterpret_cast<uint32_t *>(a.out)[(long)c * a.out_stride + q] = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
-      } else {
-        short o;
-        if (a.epilogue == SDRHIP_EPI_AM) o = am_i16(yr, yi);
-        else if (a.epilogue == SDRHIP_EPI_USB) o = usb_i16(yr, yi);
-        else {
-          const int phi = fm_phi(yr, yi);
-          const int prev = __shfl_up(phi, 1);   // previous group's angle sits in the previous lane
-          if (q == 0) o = (short)yr;
-          else o = (short)((q == 1 ? (int)a.fm_old[c] : prev) - phi);
-          if (own && emits && q == a.n_out - 1 && a.n_out >= 2) a.fm_new[c] = (short)phi;
-        }
-        if (own && emits) reinterpret_cast<short *>(a.out)[(long)c * a.out_stride + q] = o;
-      }
-    }
-    if (tile == a.tiles - 1) {
-      for (int k = tid; k < a.HH; k += TPB) {
-        const long qq = (long)a.N + k;
-        a.hist_new[(long)c * a.HH + k] =
-            qq < a.HH ? a.hist_old[(long)c * a.HH + qq] : raw_x(a, c, qq - a.HH);
-      }
-    }
-  }
-}
-
 }  // namespace
 
 namespace {
@@ -980,7 +757,6 @@ struct sdrhip_iqbb_i16 {
   int par = 0, par_fm = 0;
   int CG = 0, OG = 0, ovl = 0;
   bool fast8 = false;
-  bool use_dma = true;   // path 1, cs16 input: LDS-DMA fed kernel (SDRHIP_IQBB_DMA=0: the register-staged one, tuning)
   bool use_hot = true;   // path 1, calls of >= 3 tiles: the hot kernel (SDRHIP_IQBB_HOT=0: the general kernels only, tuning/tests)
   int env_tpw = 0, env_wgpcu = 0;   // tuning hooks SDRHIP_IQBB_TPW / SDRHIP_IQBB_WGPCU, read once at create (0: not set)
   int hot_range = -1;    // which compile-time high-plane K-step range of the hot kernel covers ah_mask (-1: none)
@@ -1048,7 +824,6 @@ struct sdrhip_iqbb_i16 {
     } else if (path >= 1) {   // (a path 3 plan that fell back to the VALU kernel above has path 0 by now)
       // interleaved tap vectors a_comp[2i+c] and their Toeplitz fragments, TapT[m][k] = a_comp[k-2t], m = 2t+comp:
       // 32x32x32: lane (m = l&31, hh = l>>5), byte j of K-step s <-> k = 32s+16hh+j
-      // 16x16x64: lane (m = l&15, g  = l>>4), byte j of K-step s <-> k = 64s+16g+j
       const int OPm = OP;
       std::vector<int> are(2 * OPm, 0), aim(2 * OPm, 0);
       for (int i = 0; i < order; i++) {
@@ -1063,7 +838,7 @@ struct sdrhip_iqbb_i16 {
       for (int st = 0; st < S; st++)
         for (int l = 0; l < 64; l++)
           for (int j = 0; j < 16; j++) {
-            const int m = path == 2 ? (l & 15) : (l & 31), hh = path == 2 ? (l >> 4) : (l >> 5);
+            const int m = l & 31, hh = l >> 5;
             int t = m >> 1, comp = m & 1;
             if (path == 1) {   // row permutation: the 32x32 C/D map gives lane half hC = (m>>2)&1 the rows m with register
                                   // r = (m&3) + 4*(m>>3); row m carries sample t = 8*hC + (r>>1), component r&1, so that
@@ -1071,7 +846,7 @@ struct sdrhip_iqbb_i16 {
               const int hC = (m >> 2) & 1, r = (m & 3) + 4 * (m >> 3);
               t = 8 * hC + (r >> 1); comp = r & 1;
             }
-            const int idx = (path == 2 ? 64 : 32) * st + 16 * hh + j - 2 * t;
+            const int idx = 32 * st + 16 * hh + j - 2 * t;
             const int v = (idx >= 0 && idx < 2 * OPm) ? (comp ? aim[idx] : are[idx]) : 0;
             const int al = ((v + 128) & 255) - 128, ah = (v - al) >> 8;
             frag[(((size_t)(2 * st) * 64 + l) * 16) + j] = (int8_t)ah;
@@ -1230,8 +1005,8 @@ struct sdrhip_iqbb_i16 {
     // MFMA path: one workgroup walks `tpw` consecutive tiles so that the tap fragments are fetched once;
     // keep >= ~8 workgroups per CU in flight for balance
     int tpw = 1;
-    if (path == 1 || path == 2 || path == 4) { tpw = 8; while (tpw > 1 && (size_t)ceil_div((size_t)tiles, (size_t)tpw) * C < 2048) tpw >>= 1; }
-    if (env_tpw && (path == 1 || path == 2 || path == 4)) tpw = env_tpw;   // tuning hook
+    if (path == 1 || path == 4) { tpw = 8; while (tpw > 1 && (size_t)ceil_div((size_t)tiles, (size_t)tpw) * C < 2048) tpw >>= 1; }
+    if (env_tpw && (path == 1 || path == 4)) tpw = env_tpw;   // tuning hook
     a.tiles = tiles; a.tpw = tpw; a.bt_hi = 0;
     a.lpg = 1; while (a.lpg < 64 && a.lpg * 8 < D) a.lpg <<= 1;
     dim3 grid((unsigned)ceil_div((size_t)tiles, (size_t)tpw), C), block(TPB);
@@ -1265,20 +1040,9 @@ struct sdrhip_iqbb_i16 {
         default: SDRHIP_MFG(17); break;
       }
 #undef SDRHIP_MFG
-    } else if (path == 2) {
-#define SDRHIP_MF16(S_) do { if (inc != 0) hipLaunchKernelGGL((iqbb_i16_mfma16_kernel<S_, true>), grid, block, lds_bytes, ctx->stream, a); \
-                              else hipLaunchKernelGGL((iqbb_i16_mfma16_kernel<S_, false>), grid, block, lds_bytes, ctx->stream, a); } while (0)
-      switch (S) {
-        case 1: SDRHIP_MF16(1); break;
-        case 2: SDRHIP_MF16(2); break;
-        case 3: SDRHIP_MF16(3); break;
-        case 4: SDRHIP_MF16(4); break;
-        default: SDRHIP_MF16(5); break;
-      }
-#undef SDRHIP_MF16
-    } else if (path == 1 && use_dma && use_hot && hot_range >= 0 && tiles >= 3 && launch_hot_call(a, g, in_dev, N, in_stride, out_dev, out_stride, tiles)) {
+    } else if (path == 1 && use_hot && hot_range >= 0 && tiles >= 3 && launch_hot_call(a, g, in_dev, N, in_stride, out_dev, out_stride, tiles)) {
       // (complex<int16> or complex<uint8> input, any filter length of path 1: the hot kernel took the whole call)
-    } else if (path == 1 && !in_cu8 && use_dma) {
+    } else if (path == 1 && !in_cu8) {
       // complex<int16> input, calls too short for the hot kernel (or SDRHIP_IQBB_HOT=0): the general kernel, raw tiles
       // by LDS-DMA (LDS: table | one plane pair | raw tile | tap fragments)
       const size_t PLWd = (2 * (size_t)(TI + OP) + 64 + 31) / 32 * 8, quads = (TI + OP + 4) / 4;
@@ -1294,12 +1058,11 @@ struct sdrhip_iqbb_i16 {
       }
 #undef SDRHIP_MFD
     } else if (path == 1) {
-      // complex<uint8> input: the one-plane instantiation (its LDS: two single planes instead of two pairs)
-      const size_t lds1 = in_cu8 ? lds_bytes - 2 * (((2 * (size_t)(TI + OP) + 64 + 31) / 32 * 8) * 4) : lds_bytes;
-#define SDRHIP_MF(S_) do { if (in_cu8 && inc != 0) hipLaunchKernelGGL((iqbb_i16_mfma_kernel<S_, true, true>), grid, block, lds1, ctx->stream, a); \
-                            else if (in_cu8) hipLaunchKernelGGL((iqbb_i16_mfma_kernel<S_, false, true>), grid, block, lds1, ctx->stream, a); \
-                            else if (inc != 0) hipLaunchKernelGGL((iqbb_i16_mfma_kernel<S_, true, false>), grid, block, lds1, ctx->stream, a); \
-                            else hipLaunchKernelGGL((iqbb_i16_mfma_kernel<S_, false, false>), grid, block, lds1, ctx->stream, a); } while (0)
+      // complex<uint8> input, calls too short for the hot kernel: the one-plane general kernel (its LDS: two single planes
+      // instead of two pairs)
+      const size_t lds1 = lds_bytes - 2 * (((2 * (size_t)(TI + OP) + 64 + 31) / 32 * 8) * 4);
+#define SDRHIP_MF(S_) do { if (inc != 0) hipLaunchKernelGGL((iqbb_i16_mfma_kernel<S_, true, true>), grid, block, lds1, ctx->stream, a); \
+                            else hipLaunchKernelGGL((iqbb_i16_mfma_kernel<S_, false, true>), grid, block, lds1, ctx->stream, a); } while (0)
       switch (S) {
         case 2: SDRHIP_MF(2); break;
         case 3: SDRHIP_MF(3); break;
@@ -1357,26 +1120,18 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
       auto high_byte = [](int v) { const int al = ((v + 128) & 255) - 128; return (v - al) >> 8; };
       for (int i = 0; i < 2 * order && mfma_ok; i++)   // both v and -v are packed (Kr, -Ki / Ki, Kr)
         if (high_byte(taps[i]) > 127 || high_byte(-taps[i]) > 127) mfma_ok = false;
-      { const char *d = getenv("SDRHIP_IQBB_DMA"); if (d && d[0] == '0') h->use_dma = false; }
       { const char *d = getenv("SDRHIP_IQBB_HOT"); if (d && d[0] == '0') h->use_hot = false; }
       { const char *e = getenv("SDRHIP_IQBB_TPW"); if (e) h->env_tpw = std::max(1, atoi(e)); }
       { const char *e = getenv("SDRHIP_IQBB_WGPCU"); if (e) h->env_wgpcu = std::max(1, atoi(e)); }
-      const char *force = getenv("SDRHIP_IQBB_PATH");   // "valu" / "mfma" / "mfma16": test hook
+      const char *force = getenv("SDRHIP_IQBB_PATH");   // "valu": test hook (the VALU kernel for every plan)
       if (force && !strcmp(force, "valu")) mfma_ok = false;
-      bool mfma16_ok = !real && !i8 && (decim == R) && (order <= 153);
-      for (int i = 0; i < 2 * order && mfma16_ok; i++)
-        if (high_byte(taps[i]) > 127 || high_byte(-taps[i]) > 127) mfma16_ok = false;
-      if (force && !strcmp(force, "valu")) mfma16_ok = false;
-      h->path = mfma_ok ? 1 : (mfma16_ok ? 2 : 0);   // 32x32x32 measured 4 % faster than 16x16x64 at 127 taps
-      // path 3: the same matrix part for any decimation, windows summed through LDS (measured ahead of the VALU
-      // kernel at every order tried, 9 ... 257 taps)
+      h->path = mfma_ok ? 1 : 0;
+      // path 3: the same matrix part for any decimation (measured ahead of the VALU kernel at every order tried, 9 ... 257 taps)
       bool mfmag_ok = !real && !i8 && decim != R && order <= 257 && TI / decim - ovl >= 1;
       for (int i = 0; i < 2 * order && mfmag_ok; i++)
         if (high_byte(taps[i]) > 127 || high_byte(-taps[i]) > 127) mfmag_ok = false;
       if (force && !strcmp(force, "valu")) mfmag_ok = false;
       if (h->path == 0 && mfmag_ok) h->path = 3;
-      // a forced formulation is a preference: plans it cannot serve fall back to the default choice
-      if (force && !strcmp(force, "mfma16") && mfma16_ok) h->path = 2;
       // path 4: real input on the matrix cores — D == 8, at most 9 K steps, taps that fit two byte planes
       if (real && !i8 && decim == R && order <= 273 && !(force && !strcmp(force, "valu"))) {
         bool fits = true;
@@ -1386,9 +1141,6 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
       if (h->path == 4) {
         h->S = order <= 81 ? 3 : order <= 145 ? 5 : 9;   // the hot kernel's filter-length classes (K steps of 32 real samples)
         h->OP = 32 * h->S - 15;
-      } else if (h->path == 2) {
-        h->S = (2 * order + 14 + 63) / 64;
-        h->OP = 32 * h->S - 7;
       } else if (h->path == 1 || h->path == 3) {
         h->S = order <= 17 ? 2 : order <= 33 ? 3 : order <= 65 ? 5 : order <= 129 ? 9 : 17;
         h->OP = 16 * (h->S - 1) + 1;
@@ -1397,13 +1149,10 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
       }
       h->HH = h->OP;   // one more than the FIR needs: reset(keep_history) must see the whole ring
       h->CG = CG; h->ovl = ovl; h->OG = CG - ovl;
-      if (h->path == 1 || h->path == 2 || h->path == 4) { h->OG = 4 * (64 - ovl); h->CG = h->OG + ovl; }   // every wave recomputes its own FM overlap group
+      if (h->path == 1 || h->path == 4) { h->OG = 4 * (64 - ovl); h->CG = h->OG + ovl; }   // every wave recomputes its own FM overlap group
       h->fast8 = (decim == R);
       if (h->path == 4) {
         h->lds_bytes = 1024 + (size_t)h->S * 2 * 64 * 16 + 4 * 2 * (size_t)(512 + 32 * h->S);
-      } else if (h->path == 2) {
-        const size_t PLW = (2 * (size_t)(TI + h->OP) + 64 + 15) / 16 * 4;
-        h->lds_bytes = (4 * PLW + 256) * 4;
       } else if (h->path == 3) {
         const size_t PLW = (2 * (size_t)(TI + h->OP) + 64 + 31) / 32 * 8;
         h->lds_bytes = (2 * PLW + 256) * 4 + (size_t)h->S * 2 * 64 * 16 + (size_t)(TI + TI / 16 + 2) * 8 + 2 * (size_t)((CG + 3) & ~3) * 4;
@@ -1494,9 +1243,8 @@ int sdrhip_iqbb_i16_kernel_names(sdrhip_iqbb_i16 *h, char *buf, size_t len) {
     else if (h->path == 4) nm = "bb_real_mfma_kernel";
     else if (h->path == 3 && h->anyd_plan()) nm = "iqbb_hot_anyd_kernel";   // (calls of a few tiles: the general kernel "iqbb_i16_mfmag_kernel")
     else if (h->path == 3) nm = "iqbb_i16_mfmag_kernel";
-    else if (h->path == 2) nm = "iqbb_i16_mfma16_kernel";
-    else if (h->path == 1 && h->use_dma && h->use_hot && h->hot_range >= 0) nm = "iqbb_hot_kernel";   // (calls of < 3 tiles: the general kernel)
-    else if (h->path == 1 && (h->in_cu8 || !h->use_dma)) nm = "iqbb_i16_mfma_kernel";
+    else if (h->path == 1 && h->use_hot && h->hot_range >= 0) nm = "iqbb_hot_kernel";   // (calls of < 3 tiles: the general kernel)
+    else if (h->path == 1 && h->in_cu8) nm = "iqbb_i16_mfma_kernel";
     else if (h->path == 1) nm = "iqbb_i16_mfma_dma_kernel";
     snprintf(buf, len, "%s", nm);
   });

@@ -135,8 +135,8 @@ class Context:
 
     def close(self):
         if self._h:
-            for key in [k for k in RedZone._cache if k[0] == self._h.value]:   # (test aid: the arena's cached buffers)
-                abi.lib().sdrhip_free(self._h, C.c_void_p(RedZone._cache.pop(key)[0]))
+            for hook in close_hooks:   # (buffers a device_router holds on this context)
+                hook(self)
             abi.lib().sdrhip_ctx_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -197,72 +197,13 @@ def _as3(x, dtype, comps=2):
     return x
 
 
-class RedZone:
-    """Test aid (guard-band canaries around device buffers). While `RedZone.active` is set, every node's
-    process(x) runs through the DEVICE-pointer entry point (`*_process_dev`) on buffers cut from a red-zoned arena:
-    a pattern-filled guard band before the first row, between any two rows (the row stride is the row length plus the
-    band) and after the last one, for the input and for the output. After the call both arenas are read back whole:
-    every guard byte must still hold the pattern and the input rows must be untouched — an out-of-bounds WRITE that
-    lands in a neighbour row's not-yet-compared region, which an equality test of the outputs cannot see, fails here.
-    The odd band width also walks the rows over every alignment the 16-byte loads and LDS-DMA windows can meet."""
-    active = False
-    band = 37            # samples (elements of the row type)
-    calls = 0            # guarded calls made (tests assert that the fixture was live)
-    IN_PAT, OUT_PAT = 0xA5, 0x5A
-
-    _cache = {}          # (context handle, which) -> (device pointer, bytes): grow-only, one pair per context
-
-    @staticmethod
-    def _buf(ctx, which, nbytes):
-        key = (ctx.handle.value, which)
-        p, cap = RedZone._cache.get(key, (0, 0))
-        if cap < nbytes:
-            if p:
-                ctx.free(p)
-            cap = max(nbytes, 2 * cap, 1 << 16)
-            p = ctx.malloc(cap)
-            RedZone._cache[key] = (p, cap)
-        return p
-
-    @staticmethod
-    def run(ctx, x, out, call):
-        """x: [rows_in, n_in, ...] host array, out: [rows_out, n_out, ...] host array to fill;
-        call(in_ptr, in_stride, out_ptr, out_stride) -> launches on device pointers, strides in row elements."""
-        g = RedZone.band
-
-        def arena(a, pat):
-            rows, n = a.shape[0], a.shape[1]
-            eb = a.dtype.itemsize * int(np.prod(a.shape[2:], dtype=np.int64))   # bytes per row element
-            h = np.full(((rows * (n + g) + g) * eb,), pat, np.uint8)
-            return h, rows, n, eb
-
-        hin, ri, ni, ebi = arena(x, RedZone.IN_PAT)
-        rows_in = hin[g * ebi:].reshape(-1)[: ri * (ni + g) * ebi].reshape(ri, (ni + g) * ebi)
-        rows_in[:, : ni * ebi] = np.ascontiguousarray(x).view(np.uint8).reshape(ri, ni * ebi)
-        hout, ro, no, ebo = arena(out, RedZone.OUT_PAT)
-        # (the output rows start out as the caller's array does: a node that leaves an element alone — FMDemod never
-        # writes index 0 — leaves the caller's value there)
-        hout[g * ebo:].reshape(-1)[: ro * (no + g) * ebo].reshape(ro, (no + g) * ebo)[:, : no * ebo] = np.ascontiguousarray(out).view(np.uint8).reshape(ro, no * ebo)
-        din, dout = RedZone._buf(ctx, 0, hin.nbytes), RedZone._buf(ctx, 1, hout.nbytes)
-        ctx.h2d(din, hin)
-        ctx.h2d(dout, hout)
-        call(din + g * ebi, ni + g, dout + g * ebo, no + g)
-        ctx.synchronize()
-        bin_, bout = np.empty_like(hin), np.empty_like(hout)
-        ctx.d2h(bin_, din)
-        ctx.d2h(bout, dout)
-        RedZone.calls += 1
-        if not np.array_equal(bin_, hin):
-            bad = np.flatnonzero(bin_ != hin)
-            raise AssertionError("red zone: the call wrote into its INPUT arena (%d bytes, first at byte %d of %d)" % (bad.size, bad[0], hin.size))
-        rows_out = bout[g * ebo:].reshape(-1)[: ro * (no + g) * ebo].reshape(ro, (no + g) * ebo)
-        guard = np.concatenate([bout[: g * ebo], rows_out[:, no * ebo:].reshape(-1)])
-        if np.any(guard != RedZone.OUT_PAT):
-            bad = np.flatnonzero(guard != RedZone.OUT_PAT)
-            raise AssertionError("red zone: %d guard bytes of the OUTPUT arena were overwritten (rows of %d elements, band %d; first at guard byte %d)"
-                                 % (bad.size, no, g, bad[0]))
-        out.view(np.uint8).reshape(ro, no * ebo)[...] = rows_out[:, : no * ebo]
-        return out
+# Seam for callers that bring their own device buffers to process(): when `device_router` is set, process(x) hands
+# (ctx, x, out, call) to it instead of using the library's host-pointer entry point; the router stages x / out in device
+# memory of its choosing and runs `call(in_ptr, in_stride, out_ptr, out_stride)` (the node's *_process_dev entry point,
+# strides in row elements). None: the host-pointer path. `close_hooks` run before a context is destroyed.
+# (tests/redzone.py installs a red-zoned arena here: guard bands around every row, checked after every call.)
+device_router = None
+close_hooks = []
 
 
 class IQBaseBandI16(_Node):
@@ -306,8 +247,8 @@ class IQBaseBandI16(_Node):
             out = np.zeros((self.channels, no, 2), np.int16)
         else:
             out = np.zeros((self.channels, no), np.int16)
-        if RedZone.active and n_in and no:
-            return RedZone.run(self.ctx, x, out, lambda i, si, o, so: self._dev_checked(i, n_in, si, o, so, no))
+        if device_router is not None and n_in and no:
+            return device_router(self.ctx, x, out, lambda i, si, o, so: self._dev_checked(i, n_in, si, o, so, no))
         got = C.c_size_t(0)
         check(abi.lib().sdrhip_iqbb_i16_process(self._h, _ptr(x), n_in, n_in, _ptr(out), no, C.byref(got)))
         assert got.value == no
@@ -366,8 +307,8 @@ class BaseBandI16(IQBaseBandI16):
         n_in = x.shape[1]
         no = self.out_count(n_in)
         out = np.zeros((self.channels, no, 2) if self.epilogue == EPI_NONE else (self.channels, no), np.int16)
-        if RedZone.active and n_in and no:
-            return RedZone.run(self.ctx, x, out, lambda i, si, o, so: self._dev_checked(i, n_in, si, o, so, no))
+        if device_router is not None and n_in and no:
+            return device_router(self.ctx, x, out, lambda i, si, o, so: self._dev_checked(i, n_in, si, o, so, no))
         got = C.c_size_t(0)
         check(abi.lib().sdrhip_iqbb_i16_process(self._h, _ptr(x), n_in, n_in, _ptr(out), no, C.byref(got)))
         assert got.value == no
@@ -399,8 +340,8 @@ class IQBaseBandI8(IQBaseBandI16):
         n_in = x.shape[1]
         no = self.out_count(n_in)
         out = np.zeros((self.channels, no, 2), np.int8) if self.epilogue == EPI_NONE else np.zeros((self.channels, no), np.int16)
-        if RedZone.active and n_in and no:
-            return RedZone.run(self.ctx, x, out, lambda i, si, o, so: self._dev_checked(i, n_in, si, o, so, no))
+        if device_router is not None and n_in and no:
+            return device_router(self.ctx, x, out, lambda i, si, o, so: self._dev_checked(i, n_in, si, o, so, no))
         got = C.c_size_t(0)
         check(abi.lib().sdrhip_iqbb_i16_process(self._h, _ptr(x), n_in, n_in, _ptr(out), no, C.byref(got)))
         assert got.value == no
@@ -435,10 +376,10 @@ class FIR(_Node):
         n_in = x.shape[1]
         no = self.out_count(n_in)
         out = np.zeros((self.channels, no, 2) if self.epilogue == EPI_NONE else (self.channels, no), it)
-        if RedZone.active and n_in and no:
+        if device_router is not None and n_in and no:
             def call(i, si, o, so):
                 assert self.process_dev(i, n_in, si, o, so) == no
-            return RedZone.run(self.ctx, x, out, call)
+            return device_router(self.ctx, x, out, call)
         got = C.c_size_t(0)
         check(abi.lib().sdrhip_fir_process(self._h, _ptr(x), n_in, n_in, _ptr(out), no, C.byref(got)))
         assert got.value == no
@@ -469,8 +410,8 @@ class Demod(_Node):
         n = x.shape[1]
         if out is None:
             out = np.zeros((self.channels, n), np.float32 if self.dtype == T_CF32 else np.int16)
-            if RedZone.active and n:
-                return RedZone.run(self.ctx, x, out, lambda i, si, o, so: self.process_dev(i, n, si, o, so))
+            if device_router is not None and n:
+                return device_router(self.ctx, x, out, lambda i, si, o, so: self.process_dev(i, n, si, o, so))
         check(abi.lib().sdrhip_demod_process(self._h, _ptr(x), n, n, _ptr(out), n))
         return out
 
@@ -496,8 +437,8 @@ class FMDeemphI16(_Node):
             x = x[None]
         n = x.shape[1]
         out = np.zeros_like(x)
-        if RedZone.active and n:
-            return RedZone.run(self.ctx, x, out, lambda i, si, o, so: self.process_dev(i, n, si, o, so))
+        if device_router is not None and n:
+            return device_router(self.ctx, x, out, lambda i, si, o, so: self.process_dev(i, n, si, o, so))
         check(abi.lib().sdrhip_deemph_i16_process(self._h, _ptr(x), n, n, _ptr(out), n))
         return out
 
@@ -534,10 +475,10 @@ class SubSample(_Node):
         n_in = x.shape[1]
         no = self.out_count(n_in)
         out = np.zeros((self.channels, no, 2), it)
-        if RedZone.active and n_in and no:
+        if device_router is not None and n_in and no:
             def call(i, si, o, so):
                 assert self.process_dev(i, n_in, si, o, so) == no
-            return RedZone.run(self.ctx, x, out, call)
+            return device_router(self.ctx, x, out, call)
         got = C.c_size_t(0)
         check(abi.lib().sdrhip_subsample_process(self._h, _ptr(x), n_in, n_in, _ptr(out), no, C.byref(got)))
         assert got.value == no
@@ -578,9 +519,9 @@ class FFTConv(_Node):
         x = _as3(x, self.dtype)
         n = x.shape[1]
         out = np.zeros((self.bands,) + x.shape, self.dtype)
-        if RedZone.active and n:
+        if device_router is not None and n:
             flat = out.reshape((self.bands * x.shape[0],) + x.shape[1:])   # band-major rows, as the C ABI lays them out
-            RedZone.run(self.ctx, x, flat, lambda i, si, o, so: self.process_dev(i, n, si, o, so))
+            device_router(self.ctx, x, flat, lambda i, si, o, so: self.process_dev(i, n, si, o, so))
             return out if self._bank else out[0]
         fn = abi.lib().sdrhip_fftconv_f64_process if self.f64 else abi.lib().sdrhip_fftconv_process
         check(fn(self._h, _ptr(x), n, n, _ptr(out), n))
@@ -626,10 +567,10 @@ class FloatBaseBand(_Node):
         n_in = x.shape[1]
         no = self.out_count(n_in)
         out = np.zeros((self.channels, no, 2), np.float32)
-        if RedZone.active and n_in and no:
+        if device_router is not None and n_in and no:
             def call(i, si, o, so):
                 assert self.process_dev(i, n_in, si, o, so) == no
-            return RedZone.run(self.ctx, x, out, call)
+            return device_router(self.ctx, x, out, call)
         got = C.c_size_t(0)
         check(abi.lib().sdrhip_fbb_f32_process(self._h, _ptr(x), n_in, n_in, _ptr(out), no, C.byref(got)))
         assert got.value == no

@@ -8,6 +8,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+if os.path.join(ROOT, "tests") not in sys.path:
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
@@ -53,7 +55,7 @@ def orc():
 
 @pytest.fixture(autouse=True)
 def redzone(request):
-    """GPU parity and fuzz tests run every node call inside a red-zoned device arena (libsdr_amd.nodes.RedZone: guard
+    """GPU parity and fuzz tests run every node call inside a red-zoned device arena (tests/redzone.py: guard
     bands before / between / after the rows of the input and output buffers, checked after every call). The parity
     module runs twice: through the arena (device-pointer entry points, strided rows) and through the host-pointer entry
     points (the library's own staging) — mark a test `hostptr_only` to keep it out of the arena."""
@@ -63,12 +65,12 @@ def redzone(request):
         yield None
         return
     mode = getattr(request, "param", "redzone")
-    from libsdr_amd import nodes
-    nodes.RedZone.active = mode == "redzone" and request.node.get_closest_marker("hostptr_only") is None
+    from redzone import RedZone
+    RedZone.install(mode == "redzone" and request.node.get_closest_marker("hostptr_only") is None)
     try:
         yield mode
     finally:
-        nodes.RedZone.active = False
+        RedZone.install(False)
 
 
 def pytest_generate_tests(metafunc):

@@ -43,29 +43,20 @@ def ctx():
     c.close()
 
 
-@pytest.fixture(params=["auto", "valu", "mfma16", "mfmag", "general", "regstaged"])
+@pytest.fixture(params=["auto", "valu", "general"])
 def k1path(request, monkeypatch):
-    """K1 has four bit-exact formulations: int8-MFMA on 32x32x32 tiles for decimation 8 (path 1, picked automatically up to
-    257 taps) and for any other decimation (path 3), the 16x16x64 shape (path 2, on request) and the VALU dot2 kernel
-    (path 0: the int8 chain, taps that do not fit, longer filters); every K1 test runs under each selection. Path 1 itself
-    has three kernels: the hot kernel (one launch: persistent grid over the call's interior wave slices + cold phase; the
-    default for calls of >= 3 tiles, every filter length, complex<int16> and complex<uint8> input), the general LDS-DMA
-    kernel ("general": SDRHIP_IQBB_HOT=0, and what short calls run) and round 1's register-staged kernel ("regstaged":
-    SDRHIP_IQBB_DMA=0, also the general kernel of complex<uint8> input)."""
+    """K1's bit-exact formulations: the int8-MFMA block-Toeplitz GEMM on 32x32x32 tiles — decimation 8 (path 1), any other
+    decimation (path 3), real input (path 4), each with a hot kernel (one launch: persistent grid over the call's interior
+    wave slices + cold phase; long calls) and a general kernel (short calls; "general": SDRHIP_IQBB_HOT=0 runs it for every
+    call) — and the VALU dot2 kernel (path 0: the int8 chain, taps that do not fit two byte planes, longer filters;
+    "valu": SDRHIP_IQBB_PATH=valu runs it for every plan). Every K1 test runs under each selection. (Rounds 1-3 also
+    carried a 16x16x64 MFMA shape and a register-staged general kernel; neither served a plan by default: removed.)"""
     monkeypatch.delenv("SDRHIP_IQBB_HOT", raising=False)
-    monkeypatch.delenv("SDRHIP_IQBB_DMA", raising=False)
-    if request.param == "regstaged":
-        monkeypatch.delenv("SDRHIP_IQBB_PATH", raising=False)
-        monkeypatch.setenv("SDRHIP_IQBB_DMA", "0")
-    elif request.param == "general":
-        monkeypatch.delenv("SDRHIP_IQBB_PATH", raising=False)
+    monkeypatch.delenv("SDRHIP_IQBB_PATH", raising=False)
+    if request.param == "general":
         monkeypatch.setenv("SDRHIP_IQBB_HOT", "0")
     elif request.param == "valu":
         monkeypatch.setenv("SDRHIP_IQBB_PATH", "valu")
-    elif request.param in ("mfma16", "mfmag"):   # preferences: plans they cannot serve fall back to the default choice
-        monkeypatch.setenv("SDRHIP_IQBB_PATH", request.param)
-    else:
-        monkeypatch.delenv("SDRHIP_IQBB_PATH", raising=False)
     return request.param
 
 
@@ -294,12 +285,7 @@ def test_iqbb_path_selection(ctx, golden, monkeypatch):
     assert sa.IQBaseBandI16(ctx, big, lut, 1365, 0, 8).path == 0
     monkeypatch.setenv("SDRHIP_IQBB_PATH", "valu")
     assert sa.IQBaseBandI16(ctx, taps, lut, 1365, 0, 8).path == 0
-    monkeypatch.setenv("SDRHIP_IQBB_PATH", "mfma16")
-    assert sa.IQBaseBandI16(ctx, taps, lut, 1365, 0, 8).path == 2
-    assert sa.IQBaseBandI16(ctx, taps, lut, 1365, 0, 5).path == 3          # a preference, not a requirement
-    monkeypatch.setenv("SDRHIP_IQBB_PATH", "mfmag")
-    assert sa.IQBaseBandI16(ctx, golden.load("g8_o21_d3_taps"), lut, 1365, 0, 3).path == 3
-    assert sa.IQBaseBandI16(ctx, taps, lut, 1365, 0, 8).path == 1
+    assert sa.IQBaseBandI16(ctx, taps, lut, 1365, 0, 5).path == 0
 
 
 def test_iqbb_reset_semantics(ctx, orc, golden, k1path):
@@ -1596,10 +1582,10 @@ def test_fm_angle_every_int16_pair(ctx):
         assert bad.numel() == 0, (a0, int(a[bad[0, 0]]), int(b[bad[0, 0]]), int(got[bad[0, 0]]), int(-phi[bad[0, 0]]))
 
 
-# ---- the red-zoned arena itself (tests/conftest.py `redzone`, libsdr_amd.nodes.RedZone) ------------------------------
+# ---- the red-zoned arena itself (tests/conftest.py `redzone`, tests/redzone.py) ------------------------------
 
 def test_redzone_arena_is_live_and_catches_stray_writes(ctx, golden, redzone):
-    from libsdr_amd.nodes import RedZone
+    from redzone import RedZone
     m, node = iqbb_from_case(ctx, golden, "g3_iqbb127d8", "_out", sa.EPI_NONE)
     before = RedZone.calls
     node.process(golden.load("g1_iq_cs16")[:4096])
