@@ -323,10 +323,23 @@ public:
   inline size_t order() const { return _order; }
   void setOrder(size_t o) { _order = std::max(size_t(1), o); if (_Fs) _reconfigure(); }
   inline double centerFrequency() const { return _Fc; }
-  /** (a new plan: the phasor, the filter history and the decimator restart — the float node keeps no LUT phase to carry) */
+  /** (a new plan: the phasor, the filter history and the decimator restart — the float node keeps no LUT phase to carry).
+   * The build-defined float baseband filters AROUND its centre frequency (class comment): the centre takes the filter
+   * frequency with it, so that a retune is one call and never passes through an unsupported (Fc, Ff) pair. */
   void setCenterFrequency(double Fc) { _Fc = Fc; _Ff = Fc; if (_Fs) _reconfigure(); }
   inline double filterFrequency() const { return _Ff; }
-  void setFilterFrequency(double Ff) { _Ff = Ff; if (_Fs) _reconfigure(); }
+  /** Checked BEFORE anything changes: on a configured node a filter frequency other than the centre frequency throws
+   * ConfigError and leaves the node as it was (same values, same plan). */
+  void setFilterFrequency(double Ff) {
+    if (_Fs && Ff != _Fc) {
+      ConfigError err;
+      err << "Can not set filter frequency " << Ff << "Hz on IQBaseBand<float>: it differs from the center frequency " << _Fc
+          << "Hz (the build-defined float baseband low-pass filters the shifted band: sdr/gpu/nodes.hh); the node is unchanged";
+      throw err;
+    }
+    _Ff = Ff;
+    if (_Fs) _reconfigure();
+  }
   inline double filterWidth() const { return _width; }
   void setFilterWidth(double width) { _width = width; if (_Fs) _reconfigure(); }
   size_t subSample() const { return _sub_sample; }

@@ -479,14 +479,16 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
     for (int m = 0; m < 4; m++)
       *reinterpret_cast<float4 *>(img + P(8 * g + 2 * m)) = make_float4(e[2 * m].x, e[2 * m].y, e[2 * m + 1].x, e[2 * m + 1].y);
   };
-  // which group a lane owns: lane bits (0, 1, 2, 3) -> group bits (0, 2, 3, 1). With the groups in lane order the eight
-  // lanes of a ds_write_b128 group land on 4 of the 8 slots of a 128-byte row, two by two (every remaining conflict cycle of
-  // the first TAIL8 cut: counter = model = 256 per wave and block); permuted, a group's stores cover all 8 slots, the four
-  // reads per transform pay one extra cycle each instead (model: 512 -> 64 extra cycles per block of a 4-band bank).
-#ifdef K7_NO_GROUP_PERM   // (A/B: groups in lane order)
-  auto group_of = [](int t) { return t; };
-#else
+  // which group a lane owns: lane order. (-DK7_GROUP_PERM: lane bits (0, 1, 2, 3) -> group bits (0, 2, 3, 1), which makes
+  // the ds_write_b128 groups of 8 lanes conflict-free — in lane order they land on 4 of the 8 slots of a 128-byte row, two
+  // by two: every conflict cycle the TAIL8 kernel has left, counter = model = 256 per wave and block — at the price of one
+  // extra cycle on each ds_read_b128. Counters: SQ_LDS_BANK_CONFLICT 33.5 M -> 4.2 M of 180 M / 151 M LDS cycles; time,
+  // three interleaved runs on one box: 1.040 -> 1.115 ms. The reads sit on the dependent path, the stores do not (a
+  // ds_write_b128 costs its 13-cycle register transfer either way): the layout with FEWER conflicts is 7 % slower. Off.)
+#ifdef K7_GROUP_PERM
   auto group_of = [](int t) { return (t & ~0xE) | (((t >> 1) & 1) << 2) | (((t >> 2) & 1) << 3) | (((t >> 3) & 1) << 1); };
+#else
+  auto group_of = [](int t) { return t; };
 #endif
   if (BANK && TAIL8) {
     const int tid = group_of(lane());

@@ -521,6 +521,16 @@ static void testFloatBaseBandNode() {
   threw = false;
   try { gpu::IQBaseBand<float> t(100e3, 50e3, 127, 8); t.config(Config(Config::Type_cs16, FS, N, 1)); } catch (ConfigError &) { threw = true; }
   CHECK(threw);
+  {   // a setter that would leave an unsupported (Fc, Ff) pair throws BEFORE it changes anything; a retune is one call
+    gpu::IQBaseBand<float> t(100e3, 50e3, 127, 8);
+    t.config(Config(Config::Type_cf32, FS, N, 1));
+    threw = false;
+    try { t.setFilterFrequency(80e3); } catch (ConfigError &) { threw = true; }
+    CHECK(threw && t.filterFrequency() == 100e3 && t.centerFrequency() == 100e3);
+    t.setCenterFrequency(80e3);
+    CHECK(t.filterFrequency() == 80e3 && t.centerFrequency() == 80e3);
+    t.setFilterFrequency(80e3);   // (equal to the centre: fine)
+  }
   // output rate given instead of the decimation (src/baseband.hh:159-162): 2.4 MS/s -> 300 kS/s = /8
   gpu::IQBaseBand<float> byrate(100e3, 200e3, 127, 1, 300e3);
   byrate.config(Config(Config::Type_cf32, FS, N, 1));
