@@ -41,12 +41,20 @@ constexpr int hot_win(int S, int in) { return 512 + hot_halo(S, in) + (in == HOT
 // bytes per byte plane: complex kinds 2 per sample (+ one chunk pair: both parity halves 16-byte aligned), real 1 per sample
 constexpr int hot_plb(int S, int in) { return in == HOT_REAL ? hot_win(S, in) : 2 * hot_win(S, in) + 32; }
 constexpr int hot_bufb(int S, int in) { return in == HOT_CU8 ? hot_plb(S, in) : 2 * hot_plb(S, in); }   // one window buffer
-constexpr int hot_lds_bytes(int S, int NH, int in, int NW, bool wide) {
-  return (wide ? 4096 : 1024) + (S + NH) * 1024 + NW * 2 * hot_bufb(S, in);
+// -DK1_PAIR (tuning variant, D = 8, complex<int16>, 4-wave workgroups; build with -DK1_MINWAVES=2, run with
+// SDRHIP_IQBB_WGPCU=2): a wave works on TWO slices at a time — consecutive tiles of its unit — so that one read of a tap
+// fragment feeds the MFMAs of both (6 accumulators, 4 window buffers per wave, 2 waves per SIMD)
+#ifdef K1_PAIR
+constexpr bool hot_pair(int in, int NW, bool dg) { return !dg && in == HOT_CS16 && NW == 4; }
+#else
+constexpr bool hot_pair(int, int, bool) { return false; }
+#endif
+constexpr int hot_lds_bytes(int S, int NH, int in, int NW, bool wide, bool pair = false) {
+  return (wide ? 4096 : 1024) + (S + NH) * 1024 + NW * (pair ? 4 : 2) * hot_bufb(S, in);
 }
-constexpr int hot_lds_cap(int NW) { return NW == 4 ? 40960 : NW == 8 ? 81920 : 163840; }   // 4 waves per SIMD: 160 KB / workgroups per CU
+constexpr int hot_lds_cap(int NW, bool pair = false) { return NW == 4 ? (pair ? 81920 : 40960) : NW == 8 ? 81920 : 163840; }   // 4 waves per SIMD: 160 KB / workgroups per CU
 // 4 KB rotation table ({Lx, Ly, -Ly, 0} x 256: one SDWA shift makes the address, no subtraction) while it fits
-constexpr bool hot_wide(int S, int NH, int in, int NW, int extra = 0) { return hot_lds_bytes(S, NH, in, NW, true) + extra <= hot_lds_cap(NW); }
+constexpr bool hot_wide(int S, int NH, int in, int NW, int extra = 0, bool pair = false) { return hot_lds_bytes(S, NH, in, NW, true, pair) + extra <= hot_lds_cap(NW, pair); }
 // the any-D form's additions to a workgroup's LDS: parked group sums, and the rotated samples where the window buffer is too small
 // (rot = false, plans without a shift: the unrotated values have 18 bits — two arrays of dwords instead of one of int16 pairs)
 #ifdef K1_TEAM_LDS
@@ -54,6 +62,11 @@ constexpr int hot_anyd_extra(int S, int in, bool rot = true) { return 4 * 512 + 
 #else   // (the team sums stay in registers: only the parked group sums)
 constexpr int hot_anyd_extra(int, int, bool = true) { return 4 * 512; }
 #endif
+
+// the small-decimation form (2 <= D <= 7, SD): the wave's 512 rotated samples go through a 2 KB per-wave LDS array (the
+// slice's own window buffer when that is large enough; two arrays without a shift: the unrotated values have 18 bits)
+constexpr int hot_sd_extra(int S, int in, bool rot) { return (hot_bufb(S, in) >= 2048 ? 0 : 4 * 2048) + (rot ? 0 : 4 * 2048); }
+constexpr bool hot_sd_fits(int S, int NH, int in, bool rot) { return hot_lds_bytes(S, NH, in, 4, false) + hot_sd_extra(S, in, rot) <= hot_lds_cap(4); }
 
 struct HotRange { int S0, NH, NW; };
 // per S: centred high-plane ranges, narrowest first; the last one covers every step
@@ -85,6 +98,9 @@ void hot_launch_s17_cu8(int range, bool rot, int epi, const HotLaunch &, const H
 void hot_launch_real(int S, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);   // S = 5 or 9
 void hot_launch_anyd(int S, int in, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);   // S = 2, 3, 5 or 9, cs16 / cu8
 void hot_launch_anyd9(int in, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
+// decimations 2 ... 7 (S = 2, 3, 5 or 9, cs16 / cu8); false: this plan's LDS does not fit (the general kernel runs it)
+bool hot_launch_sd(int S, int in, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &, bool dry_run);
+bool hot_launch_sd9(int in, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &, bool dry_run);
 
 }  // namespace sdrhip
 
@@ -110,9 +126,14 @@ __host__ __device__ __forceinline__ bool slice_is_hot(int halo, int win, int bas
 // through a 2 KB per-wave LDS array and lane teams sum the groups from there. The tap fragments are path 3's (rows in
 // natural order: short calls run the general any-D kernel on the same plan). The cold phase is the same code with the
 // samples outside the call masked and the team leaders applying the border rules themselves (cold_finish_gen).
-template <int S, int S0, int NH, bool ROT, int EPI, int IN, int NW, bool DG = false>
+// SD (with DG): decimations 2 ... 7 — the windows, the grid and the natural row order are the any-D form's; a slice holds
+// GS = 512 / D groups (73 ... 256: more than lanes), so the wave's rotated samples go through a 2 KB LDS array in stream
+// order and lane l sums and FINISHES the groups l, l + 64, l + 128, l + 192 per slice (consecutive lanes, consecutive
+// outputs: coalesced stores), the /8 kernel's per-slice finish instead of the parked one.
+template <int S, int S0, int NH, bool ROT, int EPI, int IN, int NW, bool DG = false, bool SD = false>
 __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &b) {
   constexpr bool CU8 = IN == HOT_CU8, REAL = IN == HOT_REAL;
+  static_assert(!SD || DG, "the small-decimation form is a variant of the any-D form");
   static_assert(!DG || (!REAL && NW == 4), "any-D form: complex plans, 4-wave workgroups");
   const int DD = DG ? a.D : 8, GS = DG ? a.GS : 64;   // decimation, whole groups per slice
   static_assert(S >= 2 && S0 >= 0 && NH >= 1 && S0 + NH <= S, "high-plane range inside the K loop");
@@ -125,9 +146,11 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   constexpr int NDMA = (NPIECE + 63) / 64;                     // DMA wave-instructions per window
   constexpr int LASTL = NPIECE - 64 * (NDMA - 1);              // lanes of the last one
   static_assert(NDMA <= 3, "immediate offsets 0 / 1024 / 2048");
-  constexpr bool WIDE = hot_wide(S, NH, IN, NW, DG ? hot_anyd_extra(S, IN, ROT) : 0);
-  constexpr int NBUF = 2;   // window buffers per wave
-  static_assert(hot_lds_bytes(S, NH, IN, NW, WIDE) <= hot_lds_cap(NW), "LDS budget for 4 waves per SIMD");
+  constexpr bool PAIR = hot_pair(IN, NW, DG);
+  constexpr bool WIDE = SD ? false : hot_wide(S, NH, IN, NW, DG ? hot_anyd_extra(S, IN, ROT) : 0, PAIR);   // (SD: the narrow table, the LDS goes to the sample arrays)
+  static_assert(!SD || hot_sd_fits(S, NH, IN, ROT), "small-decimation form: LDS budget");
+  constexpr int NBUF = PAIR ? 4 : 2;   // window buffers per wave
+  static_assert(hot_lds_bytes(S, NH, IN, NW, WIDE, PAIR) <= hot_lds_cap(NW, PAIR), "LDS budget for 4 waves per SIMD");
   constexpr int TBLW = WIDE ? 1024 : 256;   // dwords
   constexpr int TPBH = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -144,7 +167,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   // tap fragments in LDS: the S low-plane fragments, then only the NH high-plane fragments of steps [S0, S0 + NH)
   char *wbase = reinterpret_cast<char *>(smem + TBLW + (S + NH) * 64 * 4) + w * (NBUF * BUFB);
   char *pendb = reinterpret_cast<char *>(smem + TBLW + (S + NH) * 64 * 4) + NW * (NBUF * BUFB) + w * 512;    // (DG) the wave's parked group sums (64 x int2)
-  char *gscb = reinterpret_cast<char *>(smem + TBLW + (S + NH) * 64 * 4) + NW * (NBUF * BUFB) + NW * 512 + w * 2048;   // (DG) the wave's rotated samples (when its window buffer is too small)
+  char *gscb = reinterpret_cast<char *>(smem + TBLW + (S + NH) * 64 * 4) + NW * (NBUF * BUFB) + (SD ? 0 : NW * 512) + w * 2048;   // (DG) the wave's rotated samples (when its window buffer is too small; SD: no parked sums in front)
   char *gscb2 = gscb + NW * 2048;   // (DG, no shift, small window buffers) the second array
 #ifdef K1_ABL_ASAME   // (tuning ablation, results wrong: every step reads the SAME fragment values — K1_ABL_AREG's operand data with the reads kept)
   for (int i = tid; i < S * 64; i += TPBH) taps_s[i] = a.tapfrag[64 + (i & 63)];
@@ -220,7 +243,10 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
 #pragma clang diagnostic pop
 #endif
   };
-  if (u < a.U) dma_issue(srcb + (long)tile * tile_in_bytes + lane_byte, wbase);
+  if (u < a.U) {
+    dma_issue(srcb + (long)tile * tile_in_bytes + lane_byte, wbase);
+    if (PAIR && tile + 1 < tend) dma_issue(srcb + (long)(tile + 1) * tile_in_bytes + lane_byte, wbase + BUFB);
+  }
   __syncthreads();   // tap fragments and table in place (the only workgroup barrier)
 
   // plane byte offsets of this lane's pieces. cs16: piece p = 4 samples = half of chunk j = p >> 1 (a chunk = 8 samples =
@@ -347,6 +373,37 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
     }
 #endif
   };
+  // (PAIR) the K loop over TWO windows: the tap fragments of a step are read once and feed the MFMAs of both slices
+  struct KOps2 { v4i uhA, ulA, uhB, ulB, Al, Ah; };
+  auto stageK2 = [&](const char *cbA, const char *cbB, v16i &hhA, v16i &midA, v16i &llA, v16i &hhB, v16i &midB, v16i &llB) __attribute__((always_inline)) {
+    const char *plA = cbA + coff, *phA = cbA + PLB + coff, *plB = cbB + coff, *phB = cbB + PLB + coff;
+    KOps2 o;
+    o.uhA = *reinterpret_cast<const v4i *>(phA); o.ulA = *reinterpret_cast<const v4i *>(plA);
+    o.uhB = *reinterpret_cast<const v4i *>(phB); o.ulB = *reinterpret_cast<const v4i *>(plB);
+    o.Al = taps_s[l]; o.Ah = o.Al;
+    if (S0 == 0) o.Ah = taps_s[S * 64 + l];
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+      KOps2 nx = o;
+      if (s + 1 < S) {
+        nx.uhA = *reinterpret_cast<const v4i *>(phA + KSB * (s + 1)); nx.ulA = *reinterpret_cast<const v4i *>(plA + KSB * (s + 1));
+        nx.uhB = *reinterpret_cast<const v4i *>(phB + KSB * (s + 1)); nx.ulB = *reinterpret_cast<const v4i *>(plB + KSB * (s + 1));
+        nx.Al = taps_s[(s + 1) * 64 + l];
+        if (s + 1 >= S0 && s + 1 < S0 + NH) nx.Ah = taps_s[(S + s + 1 - S0) * 64 + l];
+      }
+      midA = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.Al, o.uhA, midA, 0, 0, 0);
+      midB = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.Al, o.uhB, midB, 0, 0, 0);
+      llA = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.Al, o.ulA, llA, 0, 0, 0);
+      llB = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.Al, o.ulB, llB, 0, 0, 0);
+      if (s >= S0 && s < S0 + NH) {
+        hhA = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.Ah, o.uhA, hhA, 0, 0, 0);
+        hhB = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.Ah, o.uhB, hhB, 0, 0, 0);
+        midA = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.Ah, o.ulA, midA, 0, 0, 0);
+        midB = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.Ah, o.ulB, midB, 0, 0, 0);
+      }
+      o = nx;
+    }
+  };
   // E: lane (n, h) owns group 2n + h of the wave: recombine the byte-plane accumulators, >>14, rotate by LUT[idx(n)],
   // window sum of the products' high halves. wave_cnt: LUT phase counter of the wave's first sample (scalar)
   // (edge_: the cold slices of the any-D form — samples outside the call contribute nothing; erel0: call-relative index of the lane's first sample)
@@ -430,6 +487,35 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       }
     }
 #endif
+    if (SD) {
+      // the wave's 512 rotated samples in stream order: lanes (n, 0) and (n, 1) trade halves (v_permlane32_swap) so that
+      // each holds 8 CONSECUTIVE samples — (n, h): 16n + 8h + {0..7} — and the wave writes 64 contiguous 32-byte pieces
+      unsigned *gsc = reinterpret_cast<unsigned *>(BUFB >= 2048 ? escr : gscb);
+      unsigned *gsy = reinterpret_cast<unsigned *>(BUFB >= 2048 ? gscb : gscb2);   // (no shift) the imaginary parts' array
+      unsigned q8[8];
+#pragma unroll
+      for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+        for (int tt = 0; tt < 2; tt++) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(pk[2 * jj + tt], pk[2 * (jj + 2) + tt], false, false);
+          q8[4 * jj + tt] = sw[0]; q8[4 * jj + 2 + tt] = sw[1];
+        }
+      *reinterpret_cast<uint4 *>(gsc + 8 * (2 * n + h)) = make_uint4(q8[0], q8[1], q8[2], q8[3]);
+      *reinterpret_cast<uint4 *>(gsc + 8 * (2 * n + h) + 4) = make_uint4(q8[4], q8[5], q8[6], q8[7]);
+      if (!ROT) {
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+          for (int tt = 0; tt < 2; tt++) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(pky[2 * jj + tt], pky[2 * (jj + 2) + tt], false, false);
+            q8[4 * jj + tt] = sw[0]; q8[4 * jj + 2 + tt] = sw[1];
+          }
+        *reinterpret_cast<uint4 *>(gsy + 8 * (2 * n + h)) = make_uint4(q8[0], q8[1], q8[2], q8[3]);
+        *reinterpret_cast<uint4 *>(gsy + 8 * (2 * n + h) + 4) = make_uint4(q8[4], q8[5], q8[6], q8[7]);
+      }
+      asm volatile("" ::: "memory");   // (the group sums below read them: same wave, in order)
+      return sum;
+    }
 #ifdef K1_ABL_NOTEAM   // (timing only: no LDS round trip, no team sums)
     if (DG) { for (int j = 0; j < 8; j++) { sum.x ^= (int)pk[j]; if (!ROT) sum.y ^= (int)pky[j]; } } else
 #endif
@@ -632,6 +718,99 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
     }
     npend = 0;
   };
+  // (SD) group k = l + 64 i of the slice: the sum of its D consecutive samples out of the LDS arrays stageE left
+  auto sd_group_sum = [&](const char *escr, int k) __attribute__((always_inline)) {
+    const unsigned *gsc = reinterpret_cast<const unsigned *>(BUFB >= 2048 ? escr : gscb);
+    const unsigned *gsy = reinterpret_cast<const unsigned *>(BUFB >= 2048 ? gscb : gscb2);
+    const int kk = min(k, GS - 1);   // (lanes beyond the slice's last group read its samples and drop the result)
+    int sx = 0, sy = 0;
+    for (int t = 0; t < DD; t++) {   // (scalar trip count)
+      const unsigned v = gsc[kk * DD + t];
+      if (ROT) {
+        asm("v_add_u32_sdwa %0, sext(%1), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "+v"(sx) : "v"(v));
+        asm("v_add_u32_sdwa %0, sext(%1), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(sy) : "v"(v));
+      } else {
+        sx = (int)((unsigned)sx + v); sy = (int)((unsigned)sy + gsy[kk * DD + t]);
+      }
+    }
+    return make_int2(sx, sy);
+  };
+  // (SD) a HOT slice finished: every group whole, emitted, none of them the call's first or last. FM: the slice's first
+  // group goes out as -phi (iqbb_fm_fixup_kernel adds the previous slice's last angle), its last one leaves phi in philast.
+  auto sd_finish_hot = [&](const char *escr, char *orow, int c_, int tile_) __attribute__((always_inline)) {
+    int carry_phi = 0;   // (scalar) the angle of group 64 i - 1
+    for (int i = 0; 64 * i < GS; i++) {   // (scalar trip count: 2 ... 4)
+      const int k = l + 64 * i;
+      const bool live = k < GS;
+      const int2 sum = sd_group_sum(escr, k);
+      const int yr = div_d(sum.x), yi = div_d(sum.y);
+      if (EPI == SDRHIP_EPI_NONE) {
+        if (live) reinterpret_cast<uint32_t *>(orow)[k] = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
+      } else if (EPI == SDRHIP_EPI_AM) {
+        const short o = am_i16(yr, yi);
+        if (live) reinterpret_cast<short *>(orow)[k] = o;
+      } else if (EPI == SDRHIP_EPI_USB) {
+        const short o = usb_i16(yr, yi);
+        if (live) reinterpret_cast<short *>(orow)[k] = o;
+      } else {
+        const int phi = fm_phi(yr, yi);
+        int prev = __builtin_amdgcn_update_dpp(0, phi, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);   // lane l - 1: group k - 1
+        if (l == 0) prev = carry_phi;   // (i = 0: the slice's first group, -phi for now)
+        if (live) reinterpret_cast<short *>(orow)[k] = (short)(prev - phi);
+        if (live && k == GS - 1) a.philast[(long)c_ * a.philast_stride + 4 * tile_ + wv] = (short)phi;
+        carry_phi = __builtin_amdgcn_readlane(phi, 63);
+      }
+    }
+  };
+  // (SD) a COLD slice finished: the border rules of cold_finish_gen, per group. sid: the slice's number 4 * tile + wv.
+  auto sd_finish_cold = [&](const char *escr, int cc, int sid) __attribute__((always_inline)) {
+    int carry_phi = 0;
+    for (int i = 0; 64 * i < GS; i++) {
+      const int k = l + 64 * i, q = sid * GS + k;   // q: the group's output index within the call
+      const bool lead = k < GS && q < b.n_groups;
+      int2 sum = sd_group_sum(escr, k);
+      if (lead && q == 0) {
+        const int2 carry = b.acc_old[cc];
+        sum.x = (int)((unsigned)sum.x + (unsigned)carry.x);
+        sum.y = (int)((unsigned)sum.y + (unsigned)carry.y);
+        if (b.extra0) {   // absolute sample 0: one slow FIR evaluation per channel and stream start
+          int er = 0, ei = 0;
+          for (int ii = 0; ii < b.OP; ii++) {
+            const uint32_t x = load_x(b, cc, -(b.OP - 1) + ii);
+            const uint2 kk = b.taps[ii];
+            er = dot2(x, kk.x, er); ei = dot2(x, kk.y, ei);
+          }
+          const int2 v = rotate(b, b.lut, make_int2(er >> 14, ei >> 14), b.n0_lo);
+          sum.x = (int)((unsigned)sum.x + (unsigned)v.x);
+          sum.y = (int)((unsigned)sum.y + (unsigned)v.y);
+        }
+      }
+      const bool emits = lead && q < b.n_out;
+      if (lead && q == b.n_groups - 1) b.acc_new[cc] = emits ? make_int2(0, 0) : sum;
+      const int yr = div_d(sum.x), yi = div_d(sum.y);
+      if (EPI == SDRHIP_EPI_NONE) {
+        if (emits) reinterpret_cast<uint32_t *>(a.out)[(long)cc * a.out_stride + q] = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
+      } else if (EPI == SDRHIP_EPI_AM) {
+        const short o = am_i16(yr, yi);
+        if (emits) reinterpret_cast<short *>(a.out)[(long)cc * a.out_stride + q] = o;
+      } else if (EPI == SDRHIP_EPI_USB) {
+        const short o = usb_i16(yr, yi);
+        if (emits) reinterpret_cast<short *>(a.out)[(long)cc * a.out_stride + q] = o;
+      } else {
+        const int phi = fm_phi(yr, yi);
+        int prev = __builtin_amdgcn_update_dpp(0, phi, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        if (l == 0) prev = carry_phi;
+        short o;
+        if (q == 0) o = (short)yr;                                   // index 0 is never written by FMDemod (in place)
+        else if (q == 1) o = (short)((int)b.fm_old[cc] - phi);       // y[0] is never looked at: the previous call's last angle
+        else o = (short)(prev - phi);                                // (a slice's first group: prev = 0, the fix-up launch adds philast)
+        if (emits) reinterpret_cast<short *>(a.out)[(long)cc * a.out_stride + q] = o;
+        if (emits && k == GS - 1) a.philast[(long)cc * a.philast_stride + sid] = (short)phi;
+        if (emits && q == b.n_out - 1 && b.n_out >= 2) b.fm_new[cc] = (short)phi;
+        carry_phi = __builtin_amdgcn_readlane(phi, 63);
+      }
+    }
+  };
   // F: truncating division by 8, demodulator, store. orow: (scalar) the wave's first group of this slice; lanes below
   // glw_lo store nothing (FM: group 0 only supplies the previous angle)
   auto stageF = [&](int2 sum, char *orow, int glw_lo) __attribute__((always_inline)) {
@@ -722,7 +901,9 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       asm volatile("" : "+v"(sum.x), "+v"(sum.y));
 #endif
       K1_STAMP(4);
-      if (DG) {
+      if (SD) {
+        sd_finish_hot(cb, outb + (long)tile * tile_out_bytes, c, tile);
+      } else if (DG) {
         if (npend == 0) ptile0 = tile;
         park(sum);
         if (tile + 1 >= tend || npend + GS > 64) flush(c);   // the unit ends here (its tiles were consecutive), or the array is full
@@ -735,10 +916,58 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
 #endif
       u = nu; c = nc; g = ng; tile = ntile; tend = ntend; srcb = nsrcb; outb = noutb;
     };
-    while (u < a.U) {
-      slice(std::integral_constant<int, 0>{});
-      if (!(u < a.U)) break;
-      slice(std::integral_constant<int, 1>{});
+    // (PAIR) one step = the unit's next TWO tiles (the last step of a unit with an odd tile count: one; its second window
+    // then holds stale samples and its results are dropped). Buffers 2 PAR, 2 PAR + 1 hold this step's windows, the other
+    // two receive the next step's.
+    auto slice2 = [&](auto par_) __attribute__((always_inline)) {
+      constexpr int PAR = decltype(par_)::value;
+      char *cbA = wbase + (2 * PAR) * BUFB, *cbB = cbA + BUFB, *nbA = wbase + (2 * (1 - PAR)) * BUFB, *nbB = nbA + BUFB;
+      const bool hasB = tile + 1 < tend;
+      int nu = u, nc = c, ng = g, ntile = tile + (hasB ? 2 : 1), ntend = tend;
+      const char *nsrcb = srcb;
+      char *noutb = outb;
+      if (ntile >= tend) {
+        next_unit(nu, nc, ng, ntile, ntend);
+        nsrcb = chan_src(nc); noutb = chan_out(nc);
+      }
+      const bool more = nu < a.U, nhasB = more && ntile + 1 < ntend;
+      rotate_priority();
+      if (__builtin_expect(more, 1)) {
+        dma_issue(nsrcb + (long)ntile * tile_in_bytes + lane_byte, nbA);
+        if (nhasB) dma_issue(nsrcb + (long)(ntile + 1) * tile_in_bytes + lane_byte, nbB);
+      }
+      // everything older than the DMA instructions just issued (VMEM retires in order)
+      static_assert(!PAIR || NDMA == 3, "pair variant: three DMA instructions per window");
+      if (nhasB) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (more) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stageP(cbA);
+      if (hasB) stageP(cbB);
+      asm volatile("" ::: "memory");
+      v16i hhA = {0}, midA = {0}, llA = cinit, hhB = {0}, midB = {0}, llB = cinit;
+      stageK2(cbA, cbB, hhA, midA, llA, hhB, midB, llB);
+      {
+        const int2 sum = stageE(std::false_type{}, hhA, midA, llA, cnt0 + (uint32_t)tile * tile_cnt, cbA, 0);
+        stageF(sum, outb + (long)tile * tile_out_bytes, GLW0);
+      }
+      if (hasB) {
+        const int2 sum = stageE(std::false_type{}, hhB, midB, llB, cnt0 + (uint32_t)(tile + 1) * tile_cnt, cbB, 0);
+        stageF(sum, outb + (long)(tile + 1) * tile_out_bytes, GLW0);
+      }
+      u = nu; c = nc; g = ng; tile = ntile; tend = ntend; srcb = nsrcb; outb = noutb;
+    };
+    if (PAIR) {
+      while (u < a.U) {
+        slice2(std::integral_constant<int, 0>{});
+        if (!(u < a.U)) break;
+        slice2(std::integral_constant<int, 1>{});
+      }
+    } else {
+      while (u < a.U) {
+        slice(std::integral_constant<int, 0>{});
+        if (!(u < a.U)) break;
+        slice(std::integral_constant<int, 1>{});
+      }
     }
   }
 
@@ -926,7 +1155,8 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
         if (DG) {
           const int s0 = a.base0_rel + (q0 + gw) * DD;   // the slice's first sample, call-relative
           const int2 sum = stageE(std::true_type{}, acc_hh, acc_mid, acc_ll, (a.n0_lo + (uint32_t)s0) * a.inc, cb, s0 + MF_BLK * n + 2 * h);
-          cold_finish_gen(sum, cc, 4 * t + wv);
+          if (SD) sd_finish_cold(cb, cc, 4 * t + wv);
+          else cold_finish_gen(sum, cc, 4 * t + wv);
         } else {
           const int tb = a.base0_rel + q0 * 8, rel0 = tb + 8 * gw + MF_BLK * n + 8 * h;
           const int2 sum = group_sum<ROT, CU8, true, WIDE ? 2 : 1, FSH>(b, acc_hh, acc_mid, acc_ll, rel0);
@@ -964,9 +1194,40 @@ __global__ __launch_bounds__(256, K1_MINWAVES) void iqbb_hot_anyd_kernel(const H
   iqbb_hot_body<S, S0, NH, ROT, EPI, IN, 4, true>(a, b);
 }
 
+template <int S, int S0, int NH, bool ROT, int EPI, int IN>
+__global__ __launch_bounds__(256, K1_MINWAVES) void iqbb_hot_sd_kernel(const HotArgs a, const IqbbArgs b) {
+  iqbb_hot_body<S, S0, NH, ROT, EPI, IN, 4, true, true>(a, b);
+}
+
+// false: the plan's LDS does not fit four workgroups per CU (nothing launched); dry_run: only answer
+template <int S, int S0, int NH, int IN>
+bool hot_launch_sd_one(bool rot, int epi, const HotLaunch &hl, const HotArgs &ha, const IqbbArgs &b, bool dry_run) {
+  const dim3 grid(hl.grid, 1), block(256);
+#define SDRHIP_SD(R_, E_) hipLaunchKernelGGL((iqbb_hot_sd_kernel<S, S0, NH, R_, E_, IN>), grid, block, lds, hl.stream, ha, b)
+#define SDRHIP_SD_E(R_) do { if (dry_run) return true; \
+    const size_t lds = (size_t)hot_lds_bytes(S, NH, IN, 4, false) + hot_sd_extra(S, IN, R_); \
+    switch (epi) { \
+    case SDRHIP_EPI_FM: SDRHIP_SD(R_, SDRHIP_EPI_FM); break; \
+    case SDRHIP_EPI_AM: SDRHIP_SD(R_, SDRHIP_EPI_AM); break; \
+    case SDRHIP_EPI_USB: SDRHIP_SD(R_, SDRHIP_EPI_USB); break; \
+    default: SDRHIP_SD(R_, SDRHIP_EPI_NONE); break; } return true; } while (0)
+  if (rot) { if constexpr (hot_sd_fits(S, NH, IN, true)) SDRHIP_SD_E(true); }
+  else { if constexpr (hot_sd_fits(S, NH, IN, false)) SDRHIP_SD_E(false); }
+#undef SDRHIP_SD_E
+#undef SDRHIP_SD
+  return false;
+}
+
 template <int S, int S0, int NH, int IN, int NW>
 void hot_launch_one(bool rot, int epi, const HotLaunch &hl, const HotArgs &ha, const IqbbArgs &b) {
-  const size_t lds = (size_t)hot_lds_bytes(S, NH, IN, NW, hot_wide(S, NH, IN, NW));
+  constexpr bool PAIR = hot_pair(IN, NW, false);
+  const size_t lds = (size_t)hot_lds_bytes(S, NH, IN, NW, hot_wide(S, NH, IN, NW, 0, PAIR), PAIR);
+  if (lds > 64 * 1024) {   // (the pair variant's four window buffers per wave)
+#define SDRHIP_HOT_ATTR(R_, E_) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&iqbb_hot_kernel<S, S0, NH, R_, E_, IN, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+    SDRHIP_HOT_ATTR(true, SDRHIP_EPI_FM); SDRHIP_HOT_ATTR(true, SDRHIP_EPI_AM); SDRHIP_HOT_ATTR(true, SDRHIP_EPI_USB); SDRHIP_HOT_ATTR(true, SDRHIP_EPI_NONE);
+    SDRHIP_HOT_ATTR(false, SDRHIP_EPI_FM); SDRHIP_HOT_ATTR(false, SDRHIP_EPI_AM); SDRHIP_HOT_ATTR(false, SDRHIP_EPI_USB); SDRHIP_HOT_ATTR(false, SDRHIP_EPI_NONE);
+#undef SDRHIP_HOT_ATTR
+  }
   const dim3 grid(hl.grid, 1), block(64 * NW);
 #define SDRHIP_HOT(R_, E_) hipLaunchKernelGGL((iqbb_hot_kernel<S, S0, NH, R_, E_, IN, NW>), grid, block, lds, hl.stream, ha, b)
 #define SDRHIP_HOT_E(R_) do { switch (epi) { \

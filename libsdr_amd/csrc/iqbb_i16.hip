@@ -931,7 +931,10 @@ struct sdrhip_iqbb_i16 {
   // tiny launch adds the previous slice's last angle to every slice's first output.
   // false: not this plan / call (the general kernel runs it).
   bool anyd_plan() const {
-    return path == 3 && use_hot && hot_range >= 0 && S <= 9 && !i8 && !real && D >= 9 && D <= 512;
+    if (!(path == 3 && use_hot && hot_range >= 0 && S <= 9 && !i8 && !real)) return false;
+    if (D >= 9 && D <= 512) return true;
+    // decimations 2 ... 7: the small-decimation form, where its sample arrays fit the workgroup's LDS (iqbb_hot.hpp, SD)
+    return D >= 2 && D <= 7 && hot_launch_sd(S, in_cu8 ? HOT_CU8 : HOT_CS16, hot_range, inc != 0, epi, HotLaunch{0, nullptr}, HotArgs{}, IqbbArgs{}, true);
   }
   bool launch_anyd_call(IqbbArgs &a, const Geometry &g, const uint32_t *in_dev, size_t N, size_t in_stride, void *out_dev,
                         size_t out_stride) {
@@ -971,7 +974,8 @@ struct sdrhip_iqbb_i16 {
     const int grid = std::max(1, std::min(nvwg, std::max(ha.U, C)));   // (every channel's cold slices need a taker too)
     ha.dq = grid / ha.G; ha.dr = grid % ha.G;
     HotLaunch hl{(unsigned)grid, ctx->stream};
-    hot_launch_anyd(S, kind, hot_range, inc != 0, epi, hl, ha, a);
+    if (D < 8) (void)hot_launch_sd(S, kind, hot_range, inc != 0, epi, hl, ha, a, false);
+    else hot_launch_anyd(S, kind, hot_range, inc != 0, epi, hl, ha, a);
     if (epi == SDRHIP_EPI_FM) {   // the slices whose first output is neither out[0] nor out[1] (their own rules) and is emitted
       const int fix_lo = GS == 1 ? 2 : 1, fix_hi = (int)ceil_div((size_t)g.n_out, (size_t)GS);
       if (fix_hi > fix_lo)
@@ -1177,7 +1181,7 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
         h->fm[p].alloc(channels); h->fm[p].zero(ctx->stream);
       }
       h->max_out = max_in / decim + 2;
-      if (epilogue == SDRHIP_EPI_FM && h->path == 3 && decim >= 9 && decim <= 512) {   // any-D hot form: one angle per slice of the longest call (launch_anyd_call)
+      if (epilogue == SDRHIP_EPI_FM && h->path == 3 && decim >= 2 && decim <= 512) {   // any-D hot forms: one angle per slice of the longest call (launch_anyd_call)
         const size_t GS = 512 / (size_t)decim, tiles_h = ceil_div(max_in / (size_t)decim + 2, 4 * GS);
         h->philast.alloc((size_t)channels * 4 * tiles_h + 1024);
       }
@@ -1241,7 +1245,7 @@ int sdrhip_iqbb_i16_kernel_names(sdrhip_iqbb_i16 *h, char *buf, size_t len) {
     const char *nm = "iqbb_i16_kernel";
     if (h->path == 4 && h->use_hot && h->hot_range >= 0) nm = "iqbb_hot_kernel";   // (calls of < 3 tiles: the general kernel)
     else if (h->path == 4) nm = "bb_real_mfma_kernel";
-    else if (h->path == 3 && h->anyd_plan()) nm = "iqbb_hot_anyd_kernel";   // (calls of a few tiles: the general kernel "iqbb_i16_mfmag_kernel")
+    else if (h->path == 3 && h->anyd_plan()) nm = h->D < 8 ? "iqbb_hot_sd_kernel" : "iqbb_hot_anyd_kernel";   // (calls of a few tiles: the general kernel "iqbb_i16_mfmag_kernel")
     else if (h->path == 3) nm = "iqbb_i16_mfmag_kernel";
     else if (h->path == 1 && h->use_hot && h->hot_range >= 0) nm = "iqbb_hot_kernel";   // (calls of < 3 tiles: the general kernel)
     else if (h->path == 1 && h->in_cu8) nm = "iqbb_i16_mfma_kernel";

@@ -226,6 +226,9 @@ def _hot_fuzz(ctx, orc, rng, order, cu8, decim=8):
         node.set_input_format(sa.abi.IN_CU8)
     if decim == 8:
         assert node.kernel_names == ["iqbb_hot_kernel"]
+    elif decim < 8:   # (9 K steps without a shift do not fit the small-decimation form's LDS: the general kernel)
+        assert node.path == 3 and node.kernel_names[0] in ("iqbb_hot_sd_kernel", "iqbb_i16_mfmag_kernel")
+        assert node.kernel_names == ["iqbb_hot_sd_kernel"] or (order > 65 and inc == 0)
     else:
         assert node.path == 3 and node.kernel_names == ["iqbb_hot_anyd_kernel"]
     refs = [orc.IQBaseBandI16(taps, lut, inc, Fc < 0, decim) for _ in range(C)]
@@ -290,6 +293,18 @@ def test_hot_kernel_any_decimation_random_long_calls(ctx, orc, seed, cu8):
     rng = np.random.default_rng(23000 + 2 * seed + int(cu8))
     order = int(rng.choice([3, 16, 17, 21, 33, 34, 64, 65, 100, 127, 129]))
     decim = int(rng.choice([9, 10, 12, 31, 50, 62, 100, 125, 180, 200, 256, 300, 512]))
+    _hot_fuzz(ctx, orc, rng, order, cu8, decim)
+
+
+@pytest.mark.parametrize("cu8", [False, True])
+@pytest.mark.parametrize("seed", range(16 + EXTRA))
+def test_hot_kernel_small_decimation_random_long_calls(ctx, orc, seed, cu8):
+    """The hot kernel's small-decimation form (2 <= D <= 7, up to 129 taps, shifted or not; the reference accepts any
+    sub_sample, src/baseband.hh:159-162): random plans, ragged long and short calls, retuning (also to and from no shift
+    at all: the two forms differ in their LDS arrays), filter swaps and _reconfigure between buffers."""
+    rng = np.random.default_rng(29000 + 2 * seed + int(cu8))
+    order = int(rng.choice([3, 16, 17, 21, 33, 34, 64, 65, 100, 127, 129]))
+    decim = int(rng.choice([2, 3, 4, 5, 6, 7]))
     _hot_fuzz(ctx, orc, rng, order, cu8, decim)
 
 

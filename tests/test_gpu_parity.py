@@ -143,7 +143,11 @@ ANYD_CASES = [(21, 125, 100e3, True), (16, 62, 100e3, False), (21, 9, -60e3, Fal
               (21, 200, 100e3, True), (16, 256, -100e3, False), (64, 181, 41e3, False), (21, 300, 100e3, True), (16, 512, 100e3, False),
               (33, 257, -60e3, False),
               (16, 20, 0.0, True), (16, 83, 0.0, True), (21, 125, 0.0, False), (64, 100, 0.0, False), (127, 300, 0.0, True), (16, 9, 0.0, False),
-              (21, 45, 0.0, True)]   # (no shift: examples/sdr_rec.cc:42-58 tunes every mode to the centre; 21 taps / 45: examples/sdr_pocsag.cc:117 and sdr_ax25.cc:117 behind a 1 MS/s RTL source)
+              (21, 45, 0.0, True),
+              # decimations 2 ... 7: the hot kernel's small-decimation form (a slice holds 73 ... 256 groups: lane l finishes
+              # the groups l, l + 64, ... of every slice)
+              (21, 2, 100e3, False), (16, 3, -100e3, True), (33, 4, 70e3, False), (64, 5, 100e3, True), (127, 6, -60e3, False), (21, 7, 100e3, True),
+              (129, 2, 30e3, True), (16, 4, 0.0, False), (21, 7, 0.0, True), (65, 3, 0.0, False), (127, 5, 0.0, True)]   # (no shift: examples/sdr_rec.cc:42-58 tunes every mode to the centre; 21 taps / 45: examples/sdr_pocsag.cc:117 and sdr_ax25.cc:117 behind a 1 MS/s RTL source)
 
 
 @pytest.mark.parametrize("hot", [True, False])
@@ -165,7 +169,13 @@ def test_iqbb_any_decimation_long_calls_vs_oracle(ctx, orc, order, decim, Fc, cu
     if cu8:
         node.set_input_format(sa.abi.IN_CU8)
     assert node.path == 3
-    assert node.kernel_names == (["iqbb_hot_anyd_kernel"] if hot else ["iqbb_i16_mfmag_kernel"])
+    hot_name = "iqbb_hot_sd_kernel" if decim < 8 else "iqbb_hot_anyd_kernel"
+    if hot and decim < 8 and node.kernel_names == ["iqbb_i16_mfmag_kernel"]:
+        # (the small-decimation form's sample arrays must fit the workgroup's LDS beside the tap fragments: 9 K steps
+        # WITHOUT a shift — two arrays of 18-bit values — do not, and run the general kernel)
+        assert order > 65 and Fc == 0.0
+    else:
+        assert node.kernel_names == ([hot_name] if hot else ["iqbb_i16_mfmag_kernel"])
     refs = [orc.IQBaseBandI16(taps, lut, inc, Fc < 0, decim) for _ in range(C)]
     fms = [orc.FMDemodI16() for _ in range(C)]
     for n in (65536, 70000, 12345, 1, 40001, 2 * decim + 1, 65536):
@@ -1219,9 +1229,15 @@ def test_fftconv_filter_bank(ctx, golden, orc, N):
     for b, K in enumerate(Ks):
         one = sa.FFTConv(ctx, sa.FFTCONV_OLA, 2 * N, K, channels=2, max_in=nblk * N)
         assert np.array_equal(np.concatenate([one.process(x[:, :N]), one.process(x[:, N:])], axis=1), y[b])
-        flt = orc.FFTFilter(K)
-        ref = np.concatenate([flt.process(x[1, i * N:(i + 1) * N]) for i in range(nblk)])
-        assert rel_err(y[b, 1], ref) <= RTOL
+        for c in range(2):   # every band and channel against the oracle's FilterSink / FilterSource blocks and the closed form
+            flt = orc.FFTFilter(K)
+            ref = np.concatenate([flt.process(x[c, i * N:(i + 1) * N]) for i in range(nblk)])
+            assert rel_err(y[b, c], ref) <= RTOL, (b, c)
+        h = sa.design_fftfilt_kernel(N, bands[b][0], bands[b][1], FS)
+        hc = h[:, 0].astype(np.float64) + 1j * h[:, 1]
+        xc = x[0, :, 0].astype(np.float64) + 1j * x[0, :, 1]
+        closed = np.convolve(xc, hc)[:len(xc)] / (np.sqrt(2 * N) * np.sqrt((np.abs(hc) ** 2).sum()))
+        assert np.abs(y[b, 0, :, 0].astype(np.float64) + 1j * y[b, 0, :, 1] - closed).max() / np.abs(closed).max() <= RTOL, b
     # a band retuned between calls: from the second block on it equals a plan made with the new kernel from the start
     # (overlap-save: history is INPUT, so one block of transient — see sdrhip.h)
     K2 = sa.design_fftfilt_spectrum(sa.design_fftfilt_kernel(N, 100e3, 300e3, FS))
