@@ -150,8 +150,9 @@ int sdrhip_iqbb_i16_path(sdrhip_iqbb_i16 *h, int *path);
  * 3 tiles, about 6000 samples, run the general kernel "iqbb_i16_mfma_dma_kernel" / "iqbb_i16_mfma_kernel" instead).
  * Path 3 plans of up to 129 taps and 9 <= decim <= 512, shifted or not (the reference's receivers: 16 taps / 83 or / 20
  * without a shift, 21 taps / 125 with one; examples/sdr_rec.cc:42-68, examples/sdr_fm.cc:40) run "iqbb_hot_anyd_kernel" on long calls — the same persistent
- * structure, cold slices included (with FM a second, tiny launch completes the slices' first outputs); other path 3
- * plans and short calls the general kernel "iqbb_i16_mfmag_kernel".
+ * structure, cold slices included (with FM a second, tiny launch completes the slices' first outputs); decimations 2 ... 7
+ * run "iqbb_hot_sd_kernel" (the small-decimation form: a slice's 73 ... 256 groups summed out of an LDS array; plans of 9 K
+ * steps without a shift do not fit its LDS); other path 3 plans and short calls the general kernel "iqbb_i16_mfmag_kernel".
  * Tuning / test variables, all read at create time: SDRHIP_IQBB_HOT=0 (general kernels only), SDRHIP_IQBB_TPW (tiles per
  * work unit), SDRHIP_IQBB_WGPCU (workgroups per CU of the persistent grid). None changes results. */
 int sdrhip_iqbb_i16_kernel_names(sdrhip_iqbb_i16 *h, char *buf, size_t len);
