@@ -60,6 +60,7 @@ def lib():
             "orc_bb_i16_create": (vp, [i32p, C.c_int, i32p, C.c_uint32, C.c_int, C.c_int]),
             "orc_bb_i16_process": (C.c_size_t, [vp, i16p, C.c_size_t, i16p]),
             "orc_bb_i16_reset": (None, [vp]),
+            "orc_bb_i16_set_shift": (None, [vp, C.c_uint32, C.c_int]),
             "orc_bb_i16_destroy": (None, [vp]),
             "orc_fir_create": (vp, [f64p, C.c_int]),
             "orc_fir_cs16_process": (None, [vp, i16p, C.c_size_t, i16p]),
@@ -308,6 +309,9 @@ class BaseBandI16:
 
     def reset(self):
         lib().orc_bb_i16_reset(self._h)
+
+    def set_shift(self, lut_inc, negative):
+        lib().orc_bb_i16_set_shift(self._h, lut_inc, int(negative))
 
     def __del__(self):
         if self._h:

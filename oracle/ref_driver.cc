@@ -479,6 +479,26 @@ static void golden_real() {
   case_bb_real("g10_bb16d1_noshift", x, Fs, 0, 230e3, 50e3, 16, 1, c1);
   case_bb_real("g10_bb1d3", x, Fs, 230e3, 230e3, 50e3, 1, 3, ragged);       // order 1: the single tap is 65536 (17 bits)
   case_bb_real("g10_bb127d8_loud", loud, Fs, 100e3, 100e3, 300e3, 127, 8, c4096);
+
+  // G16 — the real-input node retuned and reconfigured MID-STREAM: setFrequencyShift (FreqShiftBase, src/freqshift.hh:52-54,
+  // 78-87: new increment and sign, LUT phase restarts, nothing else) and a new source Config with another buffer size
+  // (BaseBand::config, src/baseband.hh:357-395: setSampleRate -> LUT increment + kernel; _last, _sample_count and _ring_offset
+  // reset; the ring's contents kept where they lie)
+  { Feeder<int16_t> src; src.configure(Fs, 4096);
+    RBProbe bb(100e3, 100e3, 50e3, 127, 8);
+    src.connect(&bb, true);
+    Capture<cs16> cap; bb.connect(&cap, true);
+    std::vector<size_t> used;
+    size_t off = 0;
+    auto feed = [&](size_t n) { src.feed(&x[off], n); used.push_back(n); off += n; };
+    feed(4096); feed(1000);
+    bb.setFrequencyShift(-150e3);
+    feed(3000);
+    src.configure(Fs, 2048);
+    feed(2048); feed(2048);
+    const std::string ev = "\"Fs\": 1000000, \"Fc\": 100000, \"Ff\": 100000, \"width\": 50000, \"order\": 127, \"decim\": 8, \"events\": [[\"feed\", 4096], [\"feed\", 1000], "
+        "[\"shift\", -150000], [\"feed\", 3000], [\"bufsize\", 2048], [\"feed\", 2048], [\"feed\", 2048]]";
+    dump("g16_bb_real_retune_out", "cs16", flat16(cap.data), ev + ", " + lens_json("in_lens", used) + ", " + lens_json("out_lens", cap.lens)); }
 }
 
 

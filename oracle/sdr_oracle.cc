@@ -709,6 +709,11 @@ void orc_bb_i16_destroy(void *h) { delete (RBB *)h; }
 void orc_bb_i16_reset(void *h) {   // config() :391-393 + setSampleRate -> _update_lut_incr; the ring keeps its content
   RBB *s = (RBB *)h; s->off = 0; s->count = 0; s->lut_count = 0; s->last = C32{0, 0};
 }
+// FreqShiftBase::setFrequencyShift (src/freqshift.hh:52-54 -> _update_lut_incr :78-87): new increment and sign, the LUT
+// phase counter restarts at 0; ring, decimator and kernel go on
+void orc_bb_i16_set_shift(void *h, uint32_t inc, int negative) {
+  RBB *s = (RBB *)h; s->inc = inc; s->negative = negative; s->lut_count = 0;
+}
 
 size_t orc_bb_i16_process(void *h, const int16_t *in, size_t n, int16_t *out) {
   RBB *s = (RBB *)h;

@@ -395,6 +395,26 @@ static void testRealBaseBand() {
   CHECK(thrown);
 }
 
+// the real-input node retuned and reconfigured between buffers (golden g16: setFrequencyShift, then a new source buffer size)
+static void testRealBaseBandRetune() {
+  std::vector<int16_t> x = slurp<int16_t>("g10_real_in.bin"), ref = slurp<int16_t>("g16_bb_real_retune_out.bin");
+  CHECK(x.size() == 3 * 4096 && ref.size() == 2 * 1524);
+  struct S16Feeder : public Source { void cfg(size_t bs) { setConfig(Config(Config::Type_s16, 1e6, bs, 1)); }
+                                     void feed(int16_t *p, size_t n) { Buffer<int16_t> b(p, n); send(b, false); } } src;
+  src.cfg(4096);
+  gpu::BaseBand<int16_t> bb(100e3, 100e3, 50e3, 127, 8);
+  Recorder<cs16> out;
+  src.connect(&bb, true); bb.connect(&out, true);
+  size_t off = 0;
+  src.feed(&x[off], 4096); off += 4096; src.feed(&x[off], 1000); off += 1000;
+  bb.setFrequencyShift(-150e3);
+  CHECK(bb.frequencyShift() == -150e3);
+  src.feed(&x[off], 3000); off += 3000;
+  src.cfg(2048);
+  src.feed(&x[off], 2048); off += 2048; src.feed(&x[off], 2048);
+  CHECK(out.data.size() * 2 == ref.size() && 0 == memcmp(out.data.data(), ref.data(), ref.size() * 2));
+}
+
 // the node retuned between buffers, against the golden vector cut from the reference node doing the same
 // (setCenterFrequency: LUT phase restarts only; setFilterFrequency / setFilterWidth: kernel only; setSubsample: _reconfigure)
 static void testRetuneMidStream() {
@@ -686,6 +706,7 @@ int main(int argc, char **argv) {
     testFloatBaseBandNode();
     testSdrFmChainCu8();
     testRealBaseBand();
+    testRealBaseBandRetune();
     testRetuneMidStream();
     testRegeometryMidStream();
     testInt8Chain();

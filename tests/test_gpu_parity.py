@@ -520,6 +520,35 @@ def bbpath(request, monkeypatch):
 BB_REAL_KERNEL = {"auto": ["iqbb_hot_kernel"], "general": ["bb_real_mfma_kernel"], "valu": ["iqbb_i16_kernel"]}
 
 
+def test_bb_real_retune_midstream_golden(ctx, golden, bbpath):
+    """g16: the reference's real-input node through setFrequencyShift (LUT increment, sign and phase; nothing else) and a
+    new source Config with another buffer size (BaseBand::config: counters and LUT phase restart, the ring's contents stay
+    where they lie — a new device plan that adopts the old plan's ring), between buffers."""
+    from test_oracle_golden import replay_bb_real_retune
+    m = golden.meta("g16_bb_real_retune_out")
+    Fs = float(m["Fs"])
+    taps, lut = sa.design_bb_taps(m["Ff"], m["width"], Fs, m["order"]), sa.design_freqshift_lut_i16()
+
+    class Node:
+        def __init__(self, F, bufsize=4096, old=None):
+            self.node = sa.BaseBandI16(ctx, taps, lut, sa.design_freqshift_inc(F, Fs), F < 0, m["decim"], max_in=bufsize)
+            if old is not None:
+                self.node.adopt_state(old.node, sa.abi.KEEP_RING)
+
+        def process(self, x):
+            return self.node.process(x)[0]
+
+        def set_shift_hz(self, F):
+            self.node.set_shift(sa.design_freqshift_inc(F, Fs), F < 0)
+
+        def reconfigured(self, bufsize, F):
+            return Node(F, bufsize, self)
+
+    outs = replay_bb_real_retune(m, golden.load("g10_real_in"), Node)
+    assert [len(o) for o in outs] == m["out_lens"]
+    assert np.array_equal(np.concatenate(outs), golden.load("g16_bb_real_retune_out"))
+
+
 @pytest.mark.parametrize("case,inp", BB_REAL_CASES)
 def test_bb_real_golden(ctx, golden, case, inp, bbpath):
     m = golden.meta(case + "_out")

@@ -348,6 +348,49 @@ def test_bb_real_i16(golden, orc, case, inp):
     assert np.array_equal(np.concatenate(outs), golden.load(case + "_out"))
 
 
+def replay_bb_real_retune(m, x, make_node):
+    """g16's event list on a real-input node made by make_node(lut_inc, negative, bufsize): "feed n", "shift F"
+    (setFrequencyShift: node.set_shift), "bufsize n" (a new source Config: node = node.reconfigured(bufsize))."""
+    Fs, F = float(m["Fs"]), float(m["Fc"])
+    node, outs, off = None, [], 0
+    for ev in m["events"]:
+        if ev[0] == "feed":
+            if node is None:
+                node = make_node(F)
+            outs.append(node.process(x[off:off + ev[1]])); off += ev[1]
+        elif ev[0] == "shift":
+            F = float(ev[1])
+            node.set_shift_hz(F)
+        elif ev[0] == "bufsize":
+            node = node.reconfigured(int(ev[1]), F)
+    return outs
+
+
+def test_bb_real_retune_midstream(golden, orc):
+    """g16: BaseBand<int16_t> through setFrequencyShift and a new source Config between buffers."""
+    m = golden.meta("g16_bb_real_retune_out")
+    Fs = float(m["Fs"])
+    taps, lut = orc.bb_design(m["Ff"], m["width"], Fs, m["order"]), orc.freqshift_lut_i16()
+
+    class Node:
+        def __init__(self, F):
+            self.bb = orc.BaseBandI16(taps, lut, orc.freqshift_inc(F, Fs), F < 0, m["decim"])
+
+        def process(self, x):
+            return self.bb.process(x)
+
+        def set_shift_hz(self, F):
+            self.bb.set_shift(orc.freqshift_inc(F, Fs), F < 0)
+
+        def reconfigured(self, bufsize, F):   # config(): LUT phase and counters restart, the ring stays
+            self.bb.set_shift(orc.freqshift_inc(F, Fs), F < 0); self.bb.reset()
+            return self
+
+    outs = replay_bb_real_retune(m, golden.load("g10_real_in"), Node)
+    assert [len(o) for o in outs] == m["out_lens"]
+    assert np.array_equal(np.concatenate(outs), golden.load("g16_bb_real_retune_out"))
+
+
 # ---- mid-stream retuning (src/baseband.hh:82-112): the reference node's setters between buffers -------------------
 
 def replay_retune(m, x, make_node, demod=None, demod_reset=None):
