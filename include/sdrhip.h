@@ -328,7 +328,9 @@ int sdrhip_fftconv_destroy(sdrhip_fftconv *h);
  * fftw_plan_dft_1d(in.size(), ...), src/fftplan_fftw3.hh:34-36). Powers of two from 4 to 16384 run the tuned complex<float>
  * kernels (every BASELINE configuration); any other fft_size whose prime factors are 2, 3, 5, 7, 11 or 13 — and every size in
  * complex<double> — runs the general in-LDS mixed-radix plan (csrc/fftgen.hpp; one transform must fit one workgroup's LDS:
- * up to 16384 points in float, 8192 in double). A size with a larger prime factor is SDRHIP_E_UNSUPPORTED.
+ * up to 16384 points in float, 8192 in double). sdrhip_fft_c2c / _f64 / sdrhip_fft_exec also take sizes with LARGER prime
+ * factors (Bluestein's chirp transform over the next power of two >= 2n - 1: n up to 8192 in float, 4096 in double); the
+ * filter (sdrhip_fftconv_*) answers SDRHIP_E_UNSUPPORTED for such an fft_size.
  *
  * FilterNode<double> (the filter classes are templates over Scalar, src/filternode.hh:30-32,102-104,230-232): the same
  * plan on complex<double> buffers; kernels / spectra are doubles (sdrhip_design_fftfilt_*_f64). bands / reset / destroy
@@ -340,11 +342,11 @@ int sdrhip_fftconv_f64_process(sdrhip_fftconv *h, const double *in_host, size_t 
                                double *out_host, size_t out_stride);
 int sdrhip_fftconv_f64_process_dev(sdrhip_fftconv *h, const double *in_dev, size_t n_in, size_t in_stride,
                                    double *out_dev, size_t out_stride);
-/* plain batched DFT of the library's own FFT (FFTPlan<float>): sign -1 forward / +1 backward, unnormalised; any n of the
- * factors 2 ... 13 up to 16384 */
+/* plain batched DFT of the library's own FFT (FFTPlan<float>): sign -1 forward / +1 backward, unnormalised; any n (see
+ * above) */
 int sdrhip_fft_c2c(sdrhip_ctx *ctx, int n, int sign, int batch, const float *in_dev, float *out_dev);
-/* FFTPlan<double> (reference src/fftplan_fftw3.hh:12-76): the same on complex<double>, any n of the factors 2 ... 13 up
- * to 8192 (in LDS, double arithmetic, roots from a host table made in long double). */
+/* FFTPlan<double> (reference src/fftplan_fftw3.hh:12-76): the same on complex<double> (in LDS, double arithmetic, roots
+ * from a host table made in long double). */
 int sdrhip_fft_c2c_f64(sdrhip_ctx *ctx, int n, int sign, int batch, const double *in_dev, double *out_dev);
 /* FFT::exec / FFTPlan<Scalar>::operator() on HOST buffers (reference src/fftplan.hh:22-36): one transform of n points,
  * dtype SDRHIP_T_CF32 or SDRHIP_T_CF64, sign -1 = FFT::FORWARD, +1 = FFT::BACKWARD, unnormalised like FFTW. in == out

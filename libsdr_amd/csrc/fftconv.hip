@@ -1016,8 +1016,46 @@ struct sdrhip_fftconv {
 };
 
 namespace {
+// a length with a prime factor above 13: Bluestein's chirp transform over a power-of-two plan of M >= 2n - 1 points
+template <class T2>
+void bluestein_c2c(sdrhip_ctx *ctx, int n, int sign, int batch, const void *in_dev, void *out_dev) {
+  typedef typename fftgen::Real<T2>::type R;
+  const int maxM = (int)(128 * 1024 / sizeof(T2));
+  int M = 1; while (M < 2 * n - 1) M <<= 1;
+  SDRHIP_REQUIRE(M <= maxM, SDRHIP_E_UNSUPPORTED,
+                 "FFT size %d has a prime factor above 13 and needs a chirp transform of %d points: more than one workgroup's LDS holds (%d)", n, M, maxM);
+  fftgen::GenPlan<T2> plan;
+  plan.build(ctx, M, maxM);
+  const long double PI = 3.14159265358979323846264338327950288L;
+  std::vector<T2> w(n);
+  std::vector< std::complex<double> > b(M, std::complex<double>(0, 0));
+  for (int j = 0; j < n; j++) {
+    const long double ang = (long double)sign * PI * (long double)(((long long)j * j) % (2LL * n)) / (long double)n;   // (j^2 mod 2n: the phase stays exact)
+    w[j].x = (R)cosl(ang); w[j].y = (R)sinl(ang);
+    const std::complex<double> cw((double)cosl(ang), -(double)sinl(ang));   // conj(w[j])
+    b[j] = cw;
+    if (j) b[M - j] = cw;
+  }
+  fftgen::host_dft(b, -1);
+  std::vector<T2> bs(M);
+  for (int pos = 0; pos < M; pos++) { const std::complex<double> v = b[plan.perm[pos]] / (double)M; bs[pos].x = (R)v.real(); bs[pos].y = (R)v.imag(); }
+  DevBuf<T2> wd, bd;
+  wd.alloc(n); wd.upload(w.data(), n, ctx->stream);
+  bd.alloc(M); bd.upload(bs.data(), M, ctx->stream);
+  allow_big_lds(fftgen::bluestein_kernel<T2>, plan.lds_bytes());
+  hipLaunchKernelGGL(fftgen::bluestein_kernel<T2>, dim3(batch), dim3(fftgen::GT), plan.lds_bytes(), ctx->stream, plan.dev, n, wd.p, bd.p,
+                     reinterpret_cast<const T2 *>(in_dev), reinterpret_cast<T2 *>(out_dev));
+  SDRHIP_CHECK_HIP(hipGetLastError());
+  SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));   // the tables die with this scope
+}
+
 template <class T2>
 void gen_c2c(sdrhip_ctx *ctx, int n, int sign, int batch, const void *in_dev, void *out_dev) {
+  {
+    std::vector<int> rx;
+    SDRHIP_REQUIRE(n >= 1, SDRHIP_E_INVALID, "FFT size %d", n);
+    if (!fftgen::GenPlan<T2>::factor(n, rx, nullptr)) { bluestein_c2c<T2>(ctx, n, sign, batch, in_dev, out_dev); return; }
+  }
   fftgen::GenPlan<T2> plan;
   plan.build(ctx, n, (int)(128 * 1024 / sizeof(T2)));
   allow_big_lds(fftgen::c2c_kernel<T2>, plan.lds_bytes());

@@ -151,6 +151,27 @@ __global__ __launch_bounds__(GT) void c2c_kernel(const GenDev<T2> p, const int *
   }
 }
 
+// Bluestein's chirp transform for lengths with a prime factor above 13 (the reference plans them like any other size):
+//   X[k] = w[k] * sum_j (x[j] w[j]) conj(w)[k - j],   w[j] = exp(sign * pi * i * j^2 / n)
+// i.e. one circular convolution of length M >= 2n - 1 (a power of two) between the chirped input and the conjugate chirp,
+// evaluated with the plan's own in-LDS FFT: forward DIF, product with the chirp's spectrum (made on the host, stored in the
+// forward transform's output order, pre-scaled by 1 / M), inverse DIT, and the output chirp. One workgroup per transform.
+template <class T2>
+__global__ __launch_bounds__(GT) void bluestein_kernel(const GenDev<T2> p, int n, const T2 *w, const T2 *bspec, const T2 *in, T2 *out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T2 *xl = reinterpret_cast<T2 *>(smem_raw);
+  const int tid = threadIdx.x, M = p.L;
+  const T2 *src = in + (long)blockIdx.x * n;
+  T2 *dst = out + (long)blockIdx.x * n;
+  for (int i = tid; i < M; i += GT) xl[i] = i < n ? gmul(src[i], w[i]) : mk<T2>(0, 0);
+  __syncthreads();
+  forward_dif(xl, p, tid);
+  for (int i = tid; i < M; i += GT) xl[i] = gmul(xl[i], bspec[i]);
+  __syncthreads();
+  inverse_dit(xl, p, tid);
+  for (int i = tid; i < n; i += GT) dst[i] = gmul(xl[i], w[i]);
+}
+
 // FFT convolution by overlap-save, as fftconv.hip's fftconv_kernel: block b transforms the L samples ending at its last
 // output and keeps the last `hop` results. Several bands share the forward transform when two LDS images fit (`two`);
 // otherwise the block is transformed once per band.

@@ -587,9 +587,10 @@ static void testFftPlan() {
   // 3000, 5000, and factors up to 13
   testFftPlanOf<float>(2000, 3e-6); testFftPlanOf<float>(3000, 3e-6); testFftPlanOf<float>(5000, 3e-6); testFftPlanOf<float>(1001, 3e-6);
   testFftPlanOf<double>(1000, 1e-13); testFftPlanOf<double>(6006, 1e-13);
+  testFftPlanOf<float>(1003, 1e-5); testFftPlanOf<double>(2053, 1e-12);   // a prime factor above 13: the chirp transform
   bool threw = false;
-  try { Buffer< std::complex<double> > a(1003), b(1003); gpu::FFTPlan<double> p(a, b, gpu::FFT::FORWARD); } catch (ConfigError &) { threw = true; }
-  CHECK(threw);   // 1003 = 17 x 59: a prime factor the device does not plan — ConfigError at construction
+  try { Buffer< std::complex<double> > a(4099), b(4099); gpu::FFTPlan<double> p(a, b, gpu::FFT::FORWARD); } catch (ConfigError &) { threw = true; }
+  CHECK(threw);   // 4099 is prime and its chirp transform (16384 points in double) does not fit the LDS: ConfigError at construction
   threw = false;
   try { Buffer< std::complex<float> > a(64), b(128); gpu::FFTPlan<float> p(a, b, gpu::FFT::FORWARD); } catch (ConfigError &) { threw = true; }
   CHECK(threw);   // sizes differ (the reference's check)

@@ -1128,9 +1128,9 @@ def test_fft_exec_host_buffers(ctx, dt, tol):
     assert np.abs(X - np.fft.fft(x.astype(np.complex128))).max() / np.abs(X).max() < tol
     back = sa.fft_exec(ctx, X, +1)
     assert np.abs(back / 4096 - x).max() < tol * 10
-    with pytest.raises(sa.abi.SdrHipError) as e:   # 1003 = 17 x 59: a prime factor the device does not plan
-        sa.fft_exec(ctx, x[:1003], -1)
-    assert e.value.code == sa.abi.E_UNSUPPORTED and "17" in str(e.value)
+    y = sa.fft_exec(ctx, x[:1003], -1)   # 1003 = 17 x 59: a prime factor above 13 — the chirp transform
+    ref = np.fft.fft(x[:1003].astype(np.complex128))
+    assert np.abs(y - ref).max() / np.abs(ref).max() < tol * 5
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 6, 12, 100, 1000, 1001, 2000, 3000, 5000, 6006, 15000, 16380])
@@ -1157,13 +1157,33 @@ def test_fft_double_any_size_vs_numpy(ctx, n):
         assert np.abs(y[..., 0] + 1j * y[..., 1] - ref).max() / np.abs(ref).max() < 1e-13, (n, sign)
 
 
+@pytest.mark.parametrize("n,dtype,tol", [(17, np.float32, 3e-6), (34, np.float32, 3e-6), (97, np.float32, 3e-6), (1003, np.float32, 5e-6),
+                                         (4099, np.float32, 1e-5), (8191, np.float32, 1e-5), (19, np.float64, 1e-13), (2053, np.float64, 1e-12),
+                                         (4093, np.float64, 1e-12)])
+def test_fft_prime_sizes_vs_numpy(ctx, n, dtype, tol):
+    """Sizes with a prime factor above 13 (FFTW plans them like any other): Bluestein's chirp transform over the next power
+    of two >= 2n - 1, evaluated with the general in-LDS plan — both directions against numpy's double FFT."""
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((2, n, 2)).astype(dtype)
+    xc = x[..., 0].astype(np.float64) + 1j * x[..., 1]
+    fn = sa.fft_c2c_f64 if np.dtype(dtype) == np.float64 else sa.fft_c2c
+    for sign, ref in ((-1, np.fft.fft(xc, axis=1)), (+1, np.fft.ifft(xc, axis=1) * n)):
+        y = fn(ctx, x, sign)
+        yc = y[..., 0].astype(np.float64) + 1j * y[..., 1]
+        assert np.abs(yc - ref).max() / np.abs(ref).max() < tol, (n, sign)
+
+
 def test_fft_sizes_the_device_does_not_plan(ctx):
-    """a prime factor above 13, or a transform that does not fit one workgroup's LDS: E_UNSUPPORTED with the reason"""
-    for fn, n, dt in ((sa.fft_c2c, 34, np.float32), (sa.fft_c2c, 16384 * 3, np.float32), (sa.fft_c2c_f64, 2 * 19, np.float64),
-                      (sa.fft_c2c_f64, 10000, np.float64)):
+    """a transform (or the chirp transform a size with a prime factor above 13 needs) that does not fit one workgroup's LDS,
+    and such a size as the filter's FFT: E_UNSUPPORTED with the reason"""
+    for fn, n, dt in ((sa.fft_c2c, 16384 * 3, np.float32), (sa.fft_c2c, 8209, np.float32), (sa.fft_c2c_f64, 10000, np.float64),
+                      (sa.fft_c2c_f64, 4099, np.float64)):
         with pytest.raises(sa.abi.SdrHipError) as e:
             fn(ctx, np.zeros((1, n, 2), dt), -1)
         assert e.value.code == sa.abi.E_UNSUPPORTED, (n, str(e.value))
+    with pytest.raises(sa.abi.SdrHipError) as e:   # FilterNode(17): a 34-point transform
+        sa.FFTConv(ctx, sa.FFTCONV_OLA, 34, np.zeros((34, 2), np.float32))
+    assert e.value.code == sa.abi.E_UNSUPPORTED and "17" in str(e.value)
 
 
 @pytest.mark.parametrize("N,dtype,tol", [(1000, np.float32, RTOL), (1500, np.float32, RTOL), (1000, np.float64, 1e-12), (1024, np.float64, 1e-12),
