@@ -349,10 +349,48 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
 #else
 #pragma unroll
     for (int s = SA; s < SB; s++) {
+#ifdef K1_BSHIFT
+      // (the two-lane reads below are invisible to the compiler's wait counts: this step's operands — issued a whole step
+      // of MFMAs ago — are waited for here, BEFORE the next step's reads are issued)
+      if (!REAL && s > SA) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o.uh), "+v"(o.ul) :: "memory");
+#endif
       KOps nx = o;
       if (s + 1 < S) {
+#ifdef K1_BSHIFT
+        // (-DK1_BSHIFT) The sample-plane operand of step s + 1 IS the operand of step s one lane to the left inside each
+        // half of the wave (lane (n, h) reads piece n + s of half h): the next operand comes by four DPP moves per plane
+        // (wave_shl:1) and only the lanes (31, h) read their fresh piece from LDS — 32 bytes per plane and step instead of
+        // 1 KB. An LDS read costs energy by the byte (tools/probes/mfma_energy.hip: one wave-wide ds_read_b128 is half an
+        // MFMA's worth), and the kernel runs at the power limit.
+        if (!REAL) {
+          auto shl1 = [](v4i x) __attribute__((always_inline)) {
+            v4i r;
+#pragma unroll
+            for (int q = 0; q < 4; q++) r[q] = __builtin_amdgcn_update_dpp(x[q], x[q], 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+            return r;
+          };
+          nx.uh = shl1(o.uh);
+          if (!CU8) nx.ul = shl1(o.ul);
+          if (n == 31) {   // (lanes 31 and 63; asm: the compiler must not turn the branch into a wave-wide read and a select)
+            const unsigned ah_ = (unsigned)(uintptr_t)(ph + KSB * (s + 1));
+            asm volatile("ds_read_b128 %0, %1" : "+v"(nx.uh) : "v"(ah_) : "memory");
+            if (!CU8) {
+              const unsigned al_ = (unsigned)(uintptr_t)(pl + KSB * (s + 1));
+              asm volatile("ds_read_b128 %0, %1" : "+v"(nx.ul) : "v"(al_) : "memory");
+            }
+          }
+        } else
+#endif
+        {
+#if defined(K1_ABL_BSAME_NOREAD)   // (tuning ablation, results wrong: step 0's sample planes serve every step, no reads)
+#elif defined(K1_ABL_BSAME_READ)   // (... the same operand values with the reads KEPT: their difference prices the reads alone)
+        { const v4i t0 = *reinterpret_cast<const v4i *>(ph + KSB * (s + 1)), t1 = *reinterpret_cast<const v4i *>(pl + KSB * (s + 1));
+          asm volatile("" :: "v"(t0), "v"(t1)); }
+#else
         nx.uh = *reinterpret_cast<const v4i *>(ph + KSB * (s + 1));
         if (!CU8) nx.ul = *reinterpret_cast<const v4i *>(pl + KSB * (s + 1));
+#endif
+        }
 #ifndef K1_ABL_AREG   // (tuning ablation, results wrong: the tap fragments of step 0 serve every step — what resident fragments would save)
         if (K1_AREG) {
           nx.Al = AlR[s + 1];
