@@ -413,17 +413,29 @@ def test_iqbb_regeometry_midstream_golden(ctx, golden, which, epi, k1path):
     assert np.array_equal(np.concatenate(outs)[ok], want[ok])
 
 
-def test_iqbb_adopt_state_vs_oracle(ctx, orc, k1path):
-    """adopt_state over many channels and plan pairs (÷8 hot form -> any-D form -> general form -> long filter), ragged
-    calls, against the oracle: _reconfigure's rotated ring for every ring position, setOrder's continuing decimator."""
+@pytest.mark.parametrize("cu8", [False, True])
+def test_iqbb_adopt_state_vs_oracle(ctx, orc, k1path, cu8):
+    """adopt_state over many channels and plan pairs (÷8 hot form -> any-D form -> small-decimation form -> long filter),
+    ragged calls, against the oracle: _reconfigure's rotated ring for every ring position, setOrder's continuing decimator;
+    complex<int16> and complex<uint8> (AutoCast fused: what sdr::gpu::IQBaseBand<uint8_t>'s setters go through)."""
     rng = np.random.default_rng(77)
     C, lut = 5, sa.design_freqshift_lut_i16()
-    x = rng.integers(-20000, 20000, (C, 40000, 2)).astype(np.int16)
+    if cu8:
+        xu = rng.integers(0, 256, (C, 40000, 2), dtype=np.uint8)
+        x = np.stack([orc.autocast_cu8_cs16(xu[c]) for c in range(C)])
+    else:
+        x = rng.integers(-20000, 20000, (C, 40000, 2)).astype(np.int16)
     inc = sa.design_freqshift_inc(-150e3, FS)
+
+    def make(taps_, D_, epi_):
+        nd = sa.IQBaseBandI16(ctx, taps_, lut, inc, True, D_, channels=C, max_in=8192, epilogue=epi_)
+        if cu8:
+            nd.set_input_format(sa.abi.IN_CU8)
+        return nd
     for epi in (sa.EPI_NONE, sa.EPI_FM, sa.EPI_USB):
         order, D = 127, 8
         taps = sa.design_iqbb_taps(-150e3, 60e3, FS, order)
-        node = sa.IQBaseBandI16(ctx, taps, lut, inc, True, D, channels=C, max_in=8192, epilogue=epi)
+        node = make(taps, D, epi)
         refs = [orc.IQBaseBandI16(taps, lut, inc, True, D) for _ in range(C)]
         fms = [orc.FMDemodI16() for _ in range(C)]
         off = 0
@@ -431,7 +443,7 @@ def test_iqbb_adopt_state_vs_oracle(ctx, orc, k1path):
                  ("geom", 8), ("feed", 4100), ("order", 300), ("feed", 5003), ("geom", 125), ("feed", 8192)]
         for kind, v in steps:
             if kind == "feed":
-                y = node.process(x[:, off:off + v])
+                y = node.process(xu[:, off:off + v] if cu8 else x[:, off:off + v])
                 for c in range(C):
                     r = refs[c].process(x[c, off:off + v])
                     if epi == sa.EPI_FM:
@@ -442,7 +454,7 @@ def test_iqbb_adopt_state_vs_oracle(ctx, orc, k1path):
                 off += v
             elif kind == "geom":
                 D = v
-                neu = sa.IQBaseBandI16(ctx, taps, lut, inc, True, D, channels=C, max_in=8192, epilogue=epi)
+                neu = make(taps, D, epi)
                 neu.adopt_state(node, sa.abi.KEEP_RING)
                 node = neu
                 for c in range(C):
@@ -451,7 +463,7 @@ def test_iqbb_adopt_state_vs_oracle(ctx, orc, k1path):
             else:
                 order = v
                 taps = sa.design_iqbb_taps(-150e3, 60e3, FS, order)
-                neu = sa.IQBaseBandI16(ctx, taps, lut, inc, True, D, channels=C, max_in=8192, epilogue=epi)
+                neu = make(taps, D, epi)
                 neu.adopt_state(node, sa.abi.KEEP_FM | sa.abi.KEEP_COUNTERS)
                 node = neu
                 for c in range(C):
