@@ -607,10 +607,12 @@ def run(a):
             import socket
             s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); os.environ.setdefault("MASTER_PORT", str(s_.getsockname()[1])); s_.close()
             os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        import datetime
+        tmo = datetime.timedelta(seconds=300)   # (a collective that never completes becomes an error line, not a hung run)
         if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)   # "nccl" is RCCL on ROCm
         else:
-            dist.init_process_group(a.backend)
+            dist.init_process_group(a.backend, timeout=tmo)
     # one GPU: the north-star chain (FM, no collective); several: BASELINE config 5 (USB, output gathered on the root)
     wl = a.workload or ("iqbb_usb" if world > 1 else "iqbb_fm")
     gather = (a.gather or (world > 1 and not a.workload)) and not a.no_gather and use_dist
