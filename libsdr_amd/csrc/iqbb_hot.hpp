@@ -54,7 +54,11 @@ constexpr int hot_lds_bytes(int S, int NH, int in, int NW, bool wide, bool pair 
 }
 constexpr int hot_lds_cap(int NW, bool pair = false) { return NW == 4 ? (pair ? 81920 : 40960) : NW == 8 ? 81920 : 163840; }   // 4 waves per SIMD: 160 KB / workgroups per CU
 // 4 KB rotation table ({Lx, Ly, -Ly, 0} x 256: one SDWA shift makes the address, no subtraction) while it fits
+#ifdef K1_NARROW_LUT   // (tuning: the 1 KB {Lx, Ly} table everywhere — half the rotation's LDS bytes, one subtraction more per sample)
+constexpr bool hot_wide(int, int, int, int, int = 0, bool = false) { return false; }
+#else
 constexpr bool hot_wide(int S, int NH, int in, int NW, int extra = 0, bool pair = false) { return hot_lds_bytes(S, NH, in, NW, true, pair) + extra <= hot_lds_cap(NW, pair); }
+#endif
 // the any-D form's additions to a workgroup's LDS: parked group sums, and the rotated samples where the window buffer is too small
 // (rot = false, plans without a shift: the unrotated values have 18 bits — two arrays of dwords instead of one of int16 pairs)
 #ifdef K1_TEAM_LDS
