@@ -766,14 +766,31 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
     const unsigned *gsy = reinterpret_cast<const unsigned *>(BUFB >= 2048 ? gscb : gscb2);
     const int kk = min(k, GS - 1);   // (lanes beyond the slice's last group read its samples and drop the result)
     int sx = 0, sy = 0;
-    for (int t = 0; t < DD; t++) {   // (scalar trip count)
-      const unsigned v = gsc[kk * DD + t];
+    auto add1 = [&](unsigned v, unsigned vy) __attribute__((always_inline)) {
       if (ROT) {
         asm("v_add_u32_sdwa %0, sext(%1), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "+v"(sx) : "v"(v));
         asm("v_add_u32_sdwa %0, sext(%1), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(sy) : "v"(v));
       } else {
-        sx = (int)((unsigned)sx + v); sy = (int)((unsigned)sy + gsy[kk * DD + t]);
+        sx = (int)((unsigned)sx + v); sy = (int)((unsigned)sy + vy);
       }
+    };
+    // (wave-uniform branches) an even D reads its group in 16- or 8-byte pieces — consecutive lanes, contiguous or
+    // 24-byte-strided addresses: conflict-free, where dword reads at a stride of 2, 4 or 6 dwords are 2- to 4-way bank
+    // conflicts (r13b's counters: half of the ÷4 kernel's LDS cycles); an odd stride is conflict-free as it is
+    if (DD == 4) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(gsc + 4 * kk);
+      uint4 vy = make_uint4(0, 0, 0, 0);
+      if (!ROT) vy = *reinterpret_cast<const uint4 *>(gsy + 4 * kk);
+      add1(v.x, vy.x); add1(v.y, vy.y); add1(v.z, vy.z); add1(v.w, vy.w);
+    } else if ((DD & 1) == 0) {
+      for (int t = 0; t < DD; t += 2) {   // (scalar trip count)
+        const uint2 v = *reinterpret_cast<const uint2 *>(gsc + kk * DD + t);
+        uint2 vy = make_uint2(0, 0);
+        if (!ROT) vy = *reinterpret_cast<const uint2 *>(gsy + kk * DD + t);
+        add1(v.x, vy.x); add1(v.y, vy.y);
+      }
+    } else {
+      for (int t = 0; t < DD; t++) add1(gsc[kk * DD + t], ROT ? 0u : gsy[kk * DD + t]);   // (scalar trip count)
     }
     return make_int2(sx, sy);
   };
