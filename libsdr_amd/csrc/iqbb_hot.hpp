@@ -135,7 +135,16 @@ __host__ __device__ __forceinline__ bool slice_is_hot(int halo, int win, int bas
 // order and lane l sums and FINISHES the groups l, l + 64, l + 128, l + 192 per slice (consecutive lanes, consecutive
 // outputs: coalesced stores), the /8 kernel's per-slice finish instead of the parked one.
 template <int S, int S0, int NH, bool ROT, int EPI, int IN, int NW, bool DG = false, bool SD = false>
-__device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &b) {
+__device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &b_kernarg) {
+  // `b` serves the cold phase only. Left to itself the compiler loads the whole block at kernel entry and keeps it in
+  // scalar registers ACROSS the hot loop — in the any-D forms that pushed the loop's own scalars into spill lanes (27 to
+  // 49 v_readlane per slice in kernels that are bound by vector issue). It is copied out of the kernarg segment behind
+  // the hot loop instead, through a pointer the compiler cannot see through (K1_LATE_B=0: the old behaviour, A/B).
+#ifndef K1_LATE_B
+#define K1_LATE_B 1
+#endif
+  IqbbArgs b_late;
+  const IqbbArgs &b = K1_LATE_B ? b_late : b_kernarg;
   constexpr bool CU8 = IN == HOT_CU8, REAL = IN == HOT_REAL;
   static_assert(!SD || DG, "the small-decimation form is a variant of the any-D form");
   static_assert(!DG || (!REAL && NW == 4), "any-D form: complex plans, 4-wave workgroups");
@@ -508,7 +517,10 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       unsigned tim = ((unsigned)acc_hh[2 * j + 1] << 8) + (unsigned)acc_mid[2 * j + 1];
       int rr, ri;
       if (CU8) {   // S = t << 8 exactly (mod 2^32): S >> 14 = bits 6 .. 23 of t, sign-extended — one bit-field extract
-        rr = __builtin_amdgcn_sbfe((int)tre, 6, 18); ri = __builtin_amdgcn_sbfe((int)tim, 6, 18);
+        // (as an instruction: the builtin came out as a shift pair — 16 vector instructions more per slice in kernels
+        // that are bound by vector issue)
+        asm("v_bfe_i32 %0, %1, 6, 18" : "=v"(rr) : "v"(tre));
+        asm("v_bfe_i32 %0, %1, 6, 18" : "=v"(ri) : "v"(tim));
       } else {
         asm("" : "+v"(tre)); asm("" : "+v"(tim));   // no re-association into 2 shifts + add3
         rr = (int)((tre << 8) + (unsigned)acc_ll[2 * j]) >> FSH; ri = (int)((tim << 8) + (unsigned)acc_ll[2 * j + 1]) >> FSH;
@@ -1076,6 +1088,20 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
     }
   };
 
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (K1_LATE_B) {
+    // the block's place in the kernarg segment: the second explicit argument of every kernel that calls this body
+    // (`(const HotArgs a, const IqbbArgs b)`), arguments laid out in declaration order at their natural alignment
+    typedef const uint32_t __attribute__((address_space(4))) *KernargP;   // (the kernarg segment is constant memory: scalar loads)
+    constexpr size_t B_OFF = (sizeof(HotArgs) + alignof(IqbbArgs) - 1) / alignof(IqbbArgs) * alignof(IqbbArgs);
+    KernargP bp = (KernargP)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + B_OFF);
+    asm volatile("" : "+s"(bp) :: "memory");
+    static_assert(sizeof(IqbbArgs) % 4 == 0, "copied by dwords");
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&b_late);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(IqbbArgs) / 4); i++) dst[i] = bp[i];
+  }
+#endif
   // ---- the call's COLD slices --------------------------------------------------------------------------------
   // The slices slice_is_hot() rejects — history in the window, the call's first group, incomplete or unemitted
   // groups, the end of the input — are a few per channel (2 of 130 on the headline workload).
