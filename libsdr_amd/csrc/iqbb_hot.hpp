@@ -145,6 +145,8 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
 #endif
   IqbbArgs b_late;
   const IqbbArgs &b = K1_LATE_B ? b_late : b_kernarg;
+  HotArgs a_late;                                        // (likewise the cold phase's copy of `a`: what only it needs — the
+  const HotArgs &ac = K1_LATE_B ? a_late : a;            //  channel count, the call's geometry — does not live across the hot loop)
   constexpr bool CU8 = IN == HOT_CU8, REAL = IN == HOT_REAL;
   static_assert(!SD || DG, "the small-decimation form is a variant of the any-D form");
   static_assert(!DG || (!REAL && NW == 4), "any-D form: complex plans, 4-wave workgroups");
@@ -611,9 +613,16 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
           for (int j = 1; j < 8; j++) { rx[j] = (int)((unsigned)rx[j - 1] + q8[j]); ry[j] = (int)((unsigned)ry[j - 1] + q8y[j]); }
         }
       }
-      int ax = 0, ay = 0;   // the block's samples in front of its boundary
-#pragma unroll
-      for (int j = 0; j < 7; j++) { ax = tm_sp == j + 1 ? rx[j] : ax; ay = tm_sp == j + 1 ? ry[j] : ay; }
+      // the block's samples in front of its boundary: rx[tm_sp - 1] for tm_sp = 1 ... 7, else 0 — a three-level select tree
+      // on the bits of the lane-constant index (7 selects per component; a chain over the 7 candidates was 14 + compares)
+      const int ti = tm_sp - 1;
+      const bool tb0 = (ti & 1) != 0, tb1 = (ti & 2) != 0, tb2 = (ti & 4) != 0, tok = ti >= 0 && ti <= 6;
+      auto pick7 = [&](const int *v) __attribute__((always_inline)) {
+        const int t0 = tb0 ? v[1] : v[0], t1 = tb0 ? v[3] : v[2], t2 = tb0 ? v[5] : v[4], t3 = v[6];
+        const int u0 = tb1 ? t1 : t0, u1 = tb1 ? t3 : t2;
+        return tok ? (tb2 ? u1 : u0) : 0;
+      };
+      const int ax = pick7(rx), ay = pick7(ry);
       const auto tx = __builtin_amdgcn_permlane32_swap((unsigned)rx[7], (unsigned)rx[7], false, false);   // {block (n, 0)'s total, block (n, 1)'s} in both halves
       const auto ty = __builtin_amdgcn_permlane32_swap((unsigned)ry[7], (unsigned)ry[7], false, false);
       const int cx = (int)(tx[0] + tx[1]), cy = (int)(ty[0] + ty[1]);
@@ -860,13 +869,13 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       if (lead && q == b.n_groups - 1) b.acc_new[cc] = emits ? make_int2(0, 0) : sum;
       const int yr = div_d(sum.x), yi = div_d(sum.y);
       if (EPI == SDRHIP_EPI_NONE) {
-        if (emits) reinterpret_cast<uint32_t *>(a.out)[(long)cc * a.out_stride + q] = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
+        if (emits) reinterpret_cast<uint32_t *>(ac.out)[(long)cc * ac.out_stride + q] = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
       } else if (EPI == SDRHIP_EPI_AM) {
         const short o = am_i16(yr, yi);
-        if (emits) reinterpret_cast<short *>(a.out)[(long)cc * a.out_stride + q] = o;
+        if (emits) reinterpret_cast<short *>(ac.out)[(long)cc * ac.out_stride + q] = o;
       } else if (EPI == SDRHIP_EPI_USB) {
         const short o = usb_i16(yr, yi);
-        if (emits) reinterpret_cast<short *>(a.out)[(long)cc * a.out_stride + q] = o;
+        if (emits) reinterpret_cast<short *>(ac.out)[(long)cc * ac.out_stride + q] = o;
       } else {
         const int phi = fm_phi(yr, yi);
         int prev = __builtin_amdgcn_update_dpp(0, phi, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
@@ -875,8 +884,8 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
         if (q == 0) o = (short)yr;                                   // index 0 is never written by FMDemod (in place)
         else if (q == 1) o = (short)((int)b.fm_old[cc] - phi);       // y[0] is never looked at: the previous call's last angle
         else o = (short)(prev - phi);                                // (a slice's first group: prev = 0, the fix-up launch adds philast)
-        if (emits) reinterpret_cast<short *>(a.out)[(long)cc * a.out_stride + q] = o;
-        if (emits && k == GS - 1) a.philast[(long)cc * a.philast_stride + sid] = (short)phi;
+        if (emits) reinterpret_cast<short *>(ac.out)[(long)cc * ac.out_stride + q] = o;
+        if (emits && k == GS - 1) ac.philast[(long)cc * ac.philast_stride + sid] = (short)phi;
         if (emits && q == b.n_out - 1 && b.n_out >= 2) b.fm_new[cc] = (short)phi;
         carry_phi = __builtin_amdgcn_readlane(phi, 63);
       }
@@ -1046,7 +1055,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   // stream's D+1 first window, the open last group and the demodulator's angle for the next call, FMDemod's first two
   // outputs of a buffer (group_finish is the decimation-8 form of the same rules). sid: the slice's number 4 * tile + wv.
   auto cold_finish_gen = [&](int2 sum, int cc, int sid) __attribute__((always_inline)) {
-    const int lsh = a.lpg_sh, k = l >> lsh, q = sid * GS + k;   // q: the group's output index within the call
+    const int lsh = ac.lpg_sh, k = l >> lsh, q = sid * GS + k;   // q: the group's output index within the call
     const bool lead = (l & ((1 << lsh) - 1)) == 0 && k < GS && q < b.n_groups;
     if (lead && q == 0) {
       const int2 carry = b.acc_old[cc];
@@ -1068,13 +1077,13 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
     if (lead && q == b.n_groups - 1) b.acc_new[cc] = emits ? make_int2(0, 0) : sum;
     const int yr = div_d(sum.x), yi = div_d(sum.y);
     if (EPI == SDRHIP_EPI_NONE) {
-      if (emits) reinterpret_cast<uint32_t *>(a.out)[(long)cc * a.out_stride + q] = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
+      if (emits) reinterpret_cast<uint32_t *>(ac.out)[(long)cc * ac.out_stride + q] = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
     } else if (EPI == SDRHIP_EPI_AM) {
       const short o = am_i16(yr, yi);
-      if (emits) reinterpret_cast<short *>(a.out)[(long)cc * a.out_stride + q] = o;
+      if (emits) reinterpret_cast<short *>(ac.out)[(long)cc * ac.out_stride + q] = o;
     } else if (EPI == SDRHIP_EPI_USB) {
       const short o = usb_i16(yr, yi);
-      if (emits) reinterpret_cast<short *>(a.out)[(long)cc * a.out_stride + q] = o;
+      if (emits) reinterpret_cast<short *>(ac.out)[(long)cc * ac.out_stride + q] = o;
     } else {
       const int phi = fm_phi(yr, yi);
       const int prev = __builtin_amdgcn_ds_bpermute(4 * (((k - 1) << lsh) & 63), phi);   // the leader of team k - 1
@@ -1082,24 +1091,27 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       if (q == 0) o = (short)yr;                                   // index 0 is never written by FMDemod (in place)
       else if (q == 1) o = (short)((int)b.fm_old[cc] - phi);       // y[0] is never looked at: the previous call's last angle
       else o = (short)((k > 0 ? prev : 0) - phi);                  // (a slice's first group: the fix-up launch adds philast)
-      if (emits) reinterpret_cast<short *>(a.out)[(long)cc * a.out_stride + q] = o;
-      if (emits && k == GS - 1) a.philast[(long)cc * a.philast_stride + sid] = (short)phi;
+      if (emits) reinterpret_cast<short *>(ac.out)[(long)cc * ac.out_stride + q] = o;
+      if (emits && k == GS - 1) ac.philast[(long)cc * ac.philast_stride + sid] = (short)phi;
       if (emits && q == b.n_out - 1 && b.n_out >= 2) b.fm_new[cc] = (short)phi;
     }
   };
 
 #if defined(__HIP_DEVICE_COMPILE__)
   if (K1_LATE_B) {
-    // the block's place in the kernarg segment: the second explicit argument of every kernel that calls this body
-    // (`(const HotArgs a, const IqbbArgs b)`), arguments laid out in declaration order at their natural alignment
+    // the blocks' places in the kernarg segment: the explicit arguments of every kernel that calls this body
+    // (`(const HotArgs a, const IqbbArgs b)`), laid out in declaration order at their natural alignment
     typedef const uint32_t __attribute__((address_space(4))) *KernargP;   // (the kernarg segment is constant memory: scalar loads)
     constexpr size_t B_OFF = (sizeof(HotArgs) + alignof(IqbbArgs) - 1) / alignof(IqbbArgs) * alignof(IqbbArgs);
-    KernargP bp = (KernargP)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + B_OFF);
-    asm volatile("" : "+s"(bp) :: "memory");
-    static_assert(sizeof(IqbbArgs) % 4 == 0, "copied by dwords");
+    const char __attribute__((address_space(4))) *kp = (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp) :: "memory");
+    static_assert(sizeof(IqbbArgs) % 4 == 0 && sizeof(HotArgs) % 4 == 0, "copied by dwords");
     uint32_t *dst = reinterpret_cast<uint32_t *>(&b_late);
 #pragma unroll
-    for (int i = 0; i < (int)(sizeof(IqbbArgs) / 4); i++) dst[i] = bp[i];
+    for (int i = 0; i < (int)(sizeof(IqbbArgs) / 4); i++) dst[i] = ((KernargP)(kp + B_OFF))[i];
+    uint32_t *dsta = reinterpret_cast<uint32_t *>(&a_late);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(HotArgs) / 4); i++) dsta[i] = ((KernargP)kp)[i];
   }
 #endif
   // ---- the call's COLD slices --------------------------------------------------------------------------------
@@ -1108,27 +1120,27 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   {
     char *cb = wbase;
 #ifdef K1_ABL_NOCOLD   // tuning ablation (results wrong): no cold phase
-    for (int cc = a.C; cc < a.C; cc += gx) {
+    for (int cc = ac.C; cc < ac.C; cc += gx) {
 #else
-    for (int cc = bx; cc < a.C; cc += gx) {
+    for (int cc = bx; cc < ac.C; cc += gx) {
 #endif
       // (DG: every tile of the call in turn; the wave's own hot tiles [hl, hh) and the slices behind the call's last group are skipped)
-      for (int t = 0; t < (DG ? a.tiles_h : b.tiles); t = DG ? t + 1 : (t == 0 ? max(b.bt_hi, 1) : t + 1)) {
-        const int q0 = t * a.OG - a.ovl, groups_here = DG ? 0 : min(b.CG, b.n_groups - q0);
+      for (int t = 0; t < (DG ? ac.tiles_h : b.tiles); t = DG ? t + 1 : (t == 0 ? max(b.bt_hi, 1) : t + 1)) {
+        const int q0 = t * ac.OG - ac.ovl, groups_here = DG ? 0 : min(b.CG, b.n_groups - q0);
         if (DG) { if ((t >= hl && t < hh) || (q0 + gw) >= b.n_groups) continue; }
-        else if (slice_is_hot(HALO, WIN, a.base0_rel, a.OG, a.ovl, a.N, a.n_out, t, wv) || gw + a.ovl >= groups_here) continue;
+        else if (slice_is_hot(HALO, WIN, ac.base0_rel, ac.OG, ac.ovl, ac.N, ac.n_out, t, wv) || gw + ac.ovl >= groups_here) continue;
         // the wave's window by ordinary loads: history / input / zeros per sample, every load issued from a clamped
         // address and masked afterwards (all in flight together)
-        const int first = a.base0_rel + (q0 + gw) * DD - HALO;
+        const int first = ac.base0_rel + (q0 + gw) * DD - HALO;
         const uint32_t *hrow = b.hist_old + (long)cc * b.HH;
         if (REAL) {   // 8 real samples per piece: input int16, or the low half of a history dword
-          const uint16_t *row = reinterpret_cast<const uint16_t *>(a.in) + (long)cc * a.in_stride;
+          const uint16_t *row = reinterpret_cast<const uint16_t *>(ac.in) + (long)cc * ac.in_stride;
           uint32_t v[NDMA][8];
 #pragma unroll
           for (int k = 0; k < NDMA; k++) {
             const int pp = min(l + 64 * k, NPIECE - 1);
 #pragma unroll
-            for (int j = 0; j < 8; j++) v[k][j] = row[max(min(first + 8 * pp + j, a.N - 1), 0)];
+            for (int j = 0; j < 8; j++) v[k][j] = row[max(min(first + 8 * pp + j, ac.N - 1), 0)];
           }
 #pragma unroll
           for (int k = 0; k < NDMA; k++) {
@@ -1136,7 +1148,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
 #pragma unroll
             for (int j = 0; j < 8; j++) {
               const int rel = first + 8 * pp + j;
-              if (rel >= a.N) v[k][j] = 0u;
+              if (rel >= ac.N) v[k][j] = 0u;
               if (first < 0) {   // (wave-uniform: only the call's first slices reach into the history)
                 const uint32_t xh = hrow[max(b.HH + rel, 0)];
                 if (rel < 0) v[k][j] = (b.HH + rel >= 0) ? (xh & 0xffffu) : 0u;
@@ -1154,13 +1166,13 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
             }
           }
         } else if (CU8) {
-          const uint16_t *row = reinterpret_cast<const uint16_t *>(a.in) + (long)cc * a.in_stride;
+          const uint16_t *row = reinterpret_cast<const uint16_t *>(ac.in) + (long)cc * ac.in_stride;
           uint32_t v[NDMA][8];
 #pragma unroll
           for (int k = 0; k < NDMA; k++) {
             const int pp = min(l + 64 * k, NPIECE - 1);
 #pragma unroll
-            for (int j = 0; j < 8; j++) v[k][j] = row[max(min(first + 8 * pp + j, a.N - 1), 0)];
+            for (int j = 0; j < 8; j++) v[k][j] = row[max(min(first + 8 * pp + j, ac.N - 1), 0)];
           }
 #pragma unroll
           for (int k = 0; k < NDMA; k++) {
@@ -1170,7 +1182,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
               const int rel = first + 8 * pp + j;
               // the sample's two high-plane bytes: AutoCast of the input bytes, or bytes 1 and 3 of a history dword
               uint32_t hb = ((v[k][j] + 0x81u) & 0xffu) | ((v[k][j] + 0x8100u) & 0xff00u);
-              if (rel >= a.N) hb = 0u;
+              if (rel >= ac.N) hb = 0u;
               if (first < 0) {   // (wave-uniform: only the call's first slices reach into the history)
                 const uint32_t xh = hrow[max(b.HH + rel, 0)];
                 if (rel < 0) hb = (b.HH + rel >= 0) ? (((xh >> 8) & 0xffu) | ((xh >> 16) & 0xff00u)) : 0u;
@@ -1182,7 +1194,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
                                                                     v[k][4] | (v[k][5] << 16), v[k][6] | (v[k][7] << 16));
           }
         } else {
-          const uint32_t *row = reinterpret_cast<const uint32_t *>(a.in) + (long)cc * a.in_stride;
+          const uint32_t *row = reinterpret_cast<const uint32_t *>(ac.in) + (long)cc * ac.in_stride;
           uint32_t v[NDMA][4];
 #pragma unroll
           for (int k = 0; k < NDMA; k++) {
@@ -1190,7 +1202,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
 #pragma unroll
             for (int j = 0; j < 4; j++) {
               const int rel = first + 4 * pp + j, hh = b.HH + rel;
-              const uint32_t *src = rel >= 0 ? row + min(rel, a.N - 1) : hrow + max(hh, 0);
+              const uint32_t *src = rel >= 0 ? row + min(rel, ac.N - 1) : hrow + max(hh, 0);
               v[k][j] = *src;
             }
           }
@@ -1200,7 +1212,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
 #pragma unroll
             for (int j = 0; j < 4; j++) {
               const int rel = first + 4 * pp + j;
-              if (rel >= a.N || b.HH + rel < 0) v[k][j] = 0u;
+              if (rel >= ac.N || b.HH + rel < 0) v[k][j] = 0u;
             }
             if (k < NDMA - 1 || l < LASTL) {
               uint2 l2, h2;
@@ -1217,7 +1229,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
         v16i acc_hh = {0}, acc_mid = {0}, acc_ll = {0};
         if (!CU8) {
 #pragma unroll
-          for (int r = 0; r < 16; r++) acc_ll[r] = (r & 1) ? a.cim : a.cre;
+          for (int r = 0; r < 16; r++) acc_ll[r] = (r & 1) ? ac.cim : ac.cre;
         }
         const char *pl = cb + coff, *ph = cb + (CU8 ? 0 : PLB) + coff;
 #pragma unroll
@@ -1238,19 +1250,19 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
           }
         }
         if (DG) {
-          const int s0 = a.base0_rel + (q0 + gw) * DD;   // the slice's first sample, call-relative
-          const int2 sum = stageE(std::true_type{}, acc_hh, acc_mid, acc_ll, (a.n0_lo + (uint32_t)s0) * a.inc, cb, s0 + MF_BLK * n + 2 * h);
+          const int s0 = ac.base0_rel + (q0 + gw) * DD;   // the slice's first sample, call-relative
+          const int2 sum = stageE(std::true_type{}, acc_hh, acc_mid, acc_ll, (ac.n0_lo + (uint32_t)s0) * ac.inc, cb, s0 + MF_BLK * n + 2 * h);
           if (SD) sd_finish_cold(cb, cc, 4 * t + wv);
           else cold_finish_gen(sum, cc, 4 * t + wv);
         } else {
-          const int tb = a.base0_rel + q0 * 8, rel0 = tb + 8 * gw + MF_BLK * n + 8 * h;
+          const int tb = ac.base0_rel + q0 * 8, rel0 = tb + 8 * gw + MF_BLK * n + 8 * h;
           const int2 sum = group_sum<ROT, CU8, true, WIDE ? 2 : 1, FSH>(b, acc_hh, acc_mid, acc_ll, rel0);
           group_finish(b, b.lut, cc, n, h, gw, q0, groups_here, sum);   // (its one table user, the stream's first sample, reads global memory)
         }
         asm volatile("" ::: "memory");
       }
       for (int k = tid & 255; k < b.HH; k += 256) {   // the FIR history for the next call (this virtual workgroup's channel)
-        const long qq = (long)a.N + k;   // index into concat(hist_old, in)
+        const long qq = (long)ac.N + k;   // index into concat(hist_old, in)
         b.hist_new[(long)cc * b.HH + k] = qq < b.HH ? b.hist_old[(long)cc * b.HH + qq] : raw_x(b, cc, qq - b.HH);
       }
     }
