@@ -1122,19 +1122,19 @@ public:
 protected:
   static int _dtype() { return sizeof(Scalar) == 8 ? SDRHIP_T_CF64 : SDRHIP_T_CF32; }
   void _check() const {
-    // any size the device plans: one transform in one workgroup's LDS — sizes made of the prime factors 2 ... 13 up to
-    // nmax points, any other size (Bluestein's chirp transform over the next power of two >= 2n - 1) up to nmax / 2
-    // (csrc/fftgen.hpp)
+    // any size the device plans (csrc/fftgen.hpp): sizes made of the prime factors 2 ... 13 of any length (one workgroup's
+    // LDS up to nmax points, the four-step plan n1 x n2 beyond), and sizes with a larger prime factor up to nmax / 2
+    // (Bluestein's chirp transform over the next power of two >= 2n - 1)
     const size_t n = _in.size(), nmax = sizeof(Scalar) == 8 ? 8192 : 16384;
     size_t rest = n;
     const size_t primes[] = {2, 3, 5, 7, 11, 13};
     for (size_t q = 0; q < 6 && rest > 1; q++) while (rest % primes[q] == 0) rest /= primes[q];
     size_t chirp = 1;
     while (chirp < 2 * n - 1) chirp <<= 1;
-    if (n < 1 || (rest == 1 ? n > nmax : chirp > nmax)) {
+    if (n < 1 || (rest == 1 ? n > nmax * nmax : chirp > nmax)) {
       ConfigError err;
-      err << "Can not construct FFT plan: the device plans sizes up to " << nmax << " points (" << nmax / 2
-          << " where a prime factor above 13 needs the chirp transform), got " << n;
+      err << "Can not construct FFT plan: the device plans sizes made of the prime factors 2 ... 13, and sizes with a larger prime factor up to "
+          << nmax / 2 << " points, got " << n;
       throw err;
     }
   }

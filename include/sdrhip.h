@@ -328,7 +328,8 @@ int sdrhip_fftconv_destroy(sdrhip_fftconv *h);
  * fftw_plan_dft_1d(in.size(), ...), src/fftplan_fftw3.hh:34-36). Powers of two from 4 to 16384 run the tuned complex<float>
  * kernels (every BASELINE configuration); any other fft_size whose prime factors are 2, 3, 5, 7, 11 or 13 — and every size in
  * complex<double> — runs the general in-LDS mixed-radix plan (csrc/fftgen.hpp; one transform must fit one workgroup's LDS:
- * up to 16384 points in float, 8192 in double). sdrhip_fft_c2c / _f64 / sdrhip_fft_exec also take sizes with LARGER prime
+ * up to 16384 points in float, 8192 in double). sdrhip_fft_c2c / _f64 / sdrhip_fft_exec also take LONGER transforms of such
+ * factors (the four-step plan n = n1 x n2 through a temporary in device memory) and sizes with LARGER prime
  * factors (Bluestein's chirp transform over the next power of two >= 2n - 1: n up to 8192 in float, 4096 in double); the
  * filter (sdrhip_fftconv_*) answers SDRHIP_E_UNSUPPORTED for such an fft_size.
  *

@@ -1016,6 +1016,47 @@ struct sdrhip_fftconv {
 };
 
 namespace {
+// a transform longer than one workgroup's LDS holds, n = n1 * n2 with both factors plannable in LDS: the four-step plan
+// (fftgen::strided_c2c_kernel twice, a temporary of n elements between them). false: n has no such factorisation.
+template <class T2>
+bool four_step_c2c(sdrhip_ctx *ctx, long n, int sign, int batch, const void *in_dev, void *out_dev) {
+  typedef typename fftgen::Real<T2>::type R;
+  const long maxL = (long)(128 * 1024 / sizeof(T2));
+  long n1 = 0;
+  for (long d = maxL; d >= 2 && !n1; d--) {   // the largest plannable divisor whose cofactor is plannable too
+    if (n % d || n / d > maxL) continue;
+    std::vector<int> rx;
+    if (fftgen::GenPlan<T2>::factor((int)d, rx, nullptr) && fftgen::GenPlan<T2>::factor((int)(n / d), rx, nullptr)) n1 = d;
+  }
+  if (!n1) return false;
+  const long n2 = n / n1;
+  fftgen::GenPlan<T2> p1, p2;
+  p1.build(ctx, (int)n1, (int)maxL); p2.build(ctx, (int)n2, (int)maxL);
+  const long double PI2 = 2.0L * 3.14159265358979323846264338327950288L;
+  std::vector<T2> wa(n1), wb(n2);   // W_n^(a n2) = W_n1^a and W_n^b (forward sign; the kernel conjugates for the backward transform)
+  for (long a = 0; a < n1; a++) { const long double ang = -PI2 * (long double)a / (long double)n1; wa[a].x = (R)cosl(ang); wa[a].y = (R)sinl(ang); }
+  for (long b = 0; b < n2; b++) { const long double ang = -PI2 * (long double)b / (long double)n; wb[b].x = (R)cosl(ang); wb[b].y = (R)sinl(ang); }
+  DevBuf<T2> wad, wbd, tmp;
+  wad.alloc(n1); wad.upload(wa.data(), n1, ctx->stream);
+  wbd.alloc(n2); wbd.upload(wb.data(), n2, ctx->stream);
+  tmp.alloc((size_t)n);
+  allow_big_lds(fftgen::strided_c2c_kernel<T2, true>, p1.lds_bytes());
+  allow_big_lds(fftgen::strided_c2c_kernel<T2, false>, p2.lds_bytes());
+  for (int bt = 0; bt < batch; bt++) {
+    const T2 *src = reinterpret_cast<const T2 *>(in_dev) + (size_t)bt * n;
+    T2 *dst = reinterpret_cast<T2 *>(out_dev) + (size_t)bt * n;
+    // pass 1: column j2 (stride n2) -> A[k1][j2] = tmp[k1 n2 + j2], twiddled
+    hipLaunchKernelGGL((fftgen::strided_c2c_kernel<T2, true>), dim3((unsigned)n2), dim3(fftgen::GT), p1.lds_bytes(), ctx->stream, p1.dev, p1.perm_d.p,
+                       sign, src, n2, 1L, tmp.p, n2, 1L, wad.p, wbd.p, (int)n2);
+    // pass 2: row k1 of A -> X[k1 + n1 k2]
+    hipLaunchKernelGGL((fftgen::strided_c2c_kernel<T2, false>), dim3((unsigned)n1), dim3(fftgen::GT), p2.lds_bytes(), ctx->stream, p2.dev, p2.perm_d.p,
+                       sign, tmp.p, 1L, n2, dst, n1, 1L, wad.p, wbd.p, (int)n2);
+  }
+  SDRHIP_CHECK_HIP(hipGetLastError());
+  SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));   // the plans' tables and the temporary die with this scope
+  return true;
+}
+
 // a length with a prime factor above 13: Bluestein's chirp transform over a power-of-two plan of M >= 2n - 1 points
 template <class T2>
 void bluestein_c2c(sdrhip_ctx *ctx, int n, int sign, int batch, const void *in_dev, void *out_dev) {
@@ -1054,6 +1095,8 @@ void gen_c2c(sdrhip_ctx *ctx, int n, int sign, int batch, const void *in_dev, vo
   {
     std::vector<int> rx;
     SDRHIP_REQUIRE(n >= 1, SDRHIP_E_INVALID, "FFT size %d", n);
+    const int maxL = (int)(128 * 1024 / sizeof(T2));
+    if (n > maxL && four_step_c2c<T2>(ctx, n, sign, batch, in_dev, out_dev)) return;   // longer than the LDS holds: n = n1 * n2
     if (!fftgen::GenPlan<T2>::factor(n, rx, nullptr)) { bluestein_c2c<T2>(ctx, n, sign, batch, in_dev, out_dev); return; }
   }
   fftgen::GenPlan<T2> plan;
@@ -1241,8 +1284,7 @@ int sdrhip_fft_c2c_f64(sdrhip_ctx *ctx, int n, int sign, int batch, const double
   return guarded([&] {
     SDRHIP_REQUIRE(ctx && in_dev && out_dev && batch >= 1 && (sign == 1 || sign == -1), SDRHIP_E_INVALID, "bad argument");
     ctx->use();
-    if (!is_pow2(n) || n < 2) { gen_c2c<double2>(ctx, n, sign, batch, in_dev, out_dev); return; }   // any size of factors 2 ... 13
-    SDRHIP_REQUIRE(n <= 8192, SDRHIP_E_UNSUPPORTED, "double FFT size %d outside [1,8192] (one transform lives in one workgroup's LDS)", n);
+    if (!is_pow2(n) || n < 2 || n > 8192) { gen_c2c<double2>(ctx, n, sign, batch, in_dev, out_dev); return; }   // the general plans: any size
     int lg = 0; while ((1 << lg) < n) lg++;
     std::vector<double2> w(n / 2);
     for (int k = 0; k < n / 2; k++) {
@@ -1282,7 +1324,7 @@ int sdrhip_fft_c2c(sdrhip_ctx *ctx, int n, int sign, int batch, const float *in_
   return guarded([&] {
     SDRHIP_REQUIRE(ctx && in_dev && out_dev && batch >= 1 && (sign == 1 || sign == -1), SDRHIP_E_INVALID, "bad argument");
     ctx->use();
-    if (!is_pow2(n) || n < 4) { gen_c2c<float2>(ctx, n, sign, batch, in_dev, out_dev); return; }   // any size of factors 2 ... 13
+    if (!is_pow2(n) || n < 4 || n > 16384) { gen_c2c<float2>(ctx, n, sign, batch, in_dev, out_dev); return; }   // the general plans: any size
     FftPlan plan;
     plan.build(ctx, n);
     allow_big_lds(fft_c2c_kernel, plan.lds_bytes());

@@ -151,6 +151,43 @@ __global__ __launch_bounds__(GT) void c2c_kernel(const GenDev<T2> p, const int *
   }
 }
 
+// One pass of the FOUR-STEP plan for transforms longer than one workgroup's LDS holds, n = n1 * n2:
+//   X[k1 + n1 k2] = sum_j2 W_n^(j2 k1) ( sum_j1 x[j1 n2 + j2] W_n1^(j1 k1) ) W_n2^(j2 k2)
+// pass 1: n2 transforms of n1 points over the stride-n2 columns, times the twiddle W_n^(j2 k1) = Wa[a] Wb[b] with
+// j2 k1 = a n2 + b (two small tables instead of n roots), written transposed as A[k1][j2]; pass 2: n1 transforms of n2
+// points over A's rows, written with stride n1. This kernel is either pass: transform t reads in[t ibs + i is], writes
+// out[t obs + k os]; TW: multiply output k of transform t by the twiddle (t k) first. (No BASELINE figure: generality.)
+template <class T2, bool TW>
+__global__ __launch_bounds__(GT) void strided_c2c_kernel(const GenDev<T2> p, const int *perm, int sign, const T2 *in, long is, long ibs,
+                                                          T2 *out, long os, long obs, const T2 *wa, const T2 *wb, int n2) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T2 *xl = reinterpret_cast<T2 *>(smem_raw);
+  const int tid = threadIdx.x, L = p.L;
+  const long t = blockIdx.x;
+  const T2 *src = in + t * ibs;
+  T2 *dst = out + t * obs;
+  auto put = [&](int k, T2 v) {
+    if (TW) {   // W_n^(sign t k): t k = a n2 + b, a < n1 (k < n1, t < n2), b < n2
+      const long m = t * (long)k, a_ = m / n2, b_ = m - a_ * n2;
+      T2 w = gmul(wa[a_], wb[b_]);
+      if (sign > 0) w.y = -w.y;
+      v = gmul(v, w);
+    }
+    dst[(long)k * os] = v;
+  };
+  if (sign < 0) {
+    for (int i = tid; i < L; i += GT) xl[i] = src[(long)i * is];
+    __syncthreads();
+    forward_dif(xl, p, tid);
+    for (int i = tid; i < L; i += GT) put(perm[i], xl[i]);   // position i holds frequency perm[i]
+  } else {
+    for (int i = tid; i < L; i += GT) xl[i] = src[(long)perm[i] * is];
+    __syncthreads();
+    inverse_dit(xl, p, tid);
+    for (int i = tid; i < L; i += GT) put(i, xl[i]);
+  }
+}
+
 // Bluestein's chirp transform for lengths with a prime factor above 13 (the reference plans them like any other size):
 //   X[k] = w[k] * sum_j (x[j] w[j]) conj(w)[k - j],   w[j] = exp(sign * pi * i * j^2 / n)
 // i.e. one circular convolution of length M >= 2n - 1 (a power of two) between the chirped input and the conjugate chirp,

@@ -564,7 +564,7 @@ static void testFftPlanOf(size_t n, double tol) {
   for (size_t i = 0; i < n; i++) in[i] = CS(Scalar(std::sin(0.37 * i) + 0.25 * std::cos(1.9 * i)), Scalar(std::cos(0.11 * i * i)));
   gpu::FFT::exec<Scalar>(in, out, gpu::FFT::FORWARD);
   double worst = 0, scale = 0;
-  for (size_t k = 0; k < n; k += (n > 256 ? 37 : 1)) {   // sampled bins for the larger sizes
+  for (size_t k = 0; k < n; k += (n > 8192 ? n / 61 : n > 256 ? 37 : 1)) {   // sampled bins for the larger sizes
     std::complex<long double> acc(0, 0);
     for (size_t i = 0; i < n; i++) {
       const long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)((i * k) % n) / (long double)n;
@@ -588,6 +588,7 @@ static void testFftPlan() {
   testFftPlanOf<float>(2000, 3e-6); testFftPlanOf<float>(3000, 3e-6); testFftPlanOf<float>(5000, 3e-6); testFftPlanOf<float>(1001, 3e-6);
   testFftPlanOf<double>(1000, 1e-13); testFftPlanOf<double>(6006, 1e-13);
   testFftPlanOf<float>(1003, 1e-5); testFftPlanOf<double>(2053, 1e-12);   // a prime factor above 13: the chirp transform
+  testFftPlanOf<float>(65536, 3e-6); testFftPlanOf<double>(30000, 1e-12);   // longer than the LDS holds: the four-step plan
   bool threw = false;
   try { Buffer< std::complex<double> > a(4099), b(4099); gpu::FFTPlan<double> p(a, b, gpu::FFT::FORWARD); } catch (ConfigError &) { threw = true; }
   CHECK(threw);   // 4099 is prime and its chirp transform (16384 points in double) does not fit the LDS: ConfigError at construction

@@ -1185,11 +1185,27 @@ def test_fft_prime_sizes_vs_numpy(ctx, n, dtype, tol):
         assert np.abs(yc - ref).max() / np.abs(ref).max() < tol, (n, sign)
 
 
+@pytest.mark.parametrize("n,dtype,tol", [(32768, np.float32, 3e-6), (65536, np.float32, 3e-6), (100000, np.float32, 5e-6), (3 * 16384, np.float32, 3e-6),
+                                         (1 << 20, np.float32, 5e-6), (16384, np.float64, 1e-13), (10000, np.float64, 1e-13), (200000, np.float64, 1e-12)])
+def test_fft_long_sizes_vs_numpy(ctx, n, dtype, tol):
+    """Transforms longer than one workgroup's LDS holds (FFTW has no such limit): the four-step plan n = n1 x n2 — n2
+    column transforms with the twiddle, n1 row transforms, both through the general in-LDS passes — against numpy, both
+    directions."""
+    rng = np.random.default_rng(n % 1000)
+    x = rng.standard_normal((2, n, 2)).astype(dtype)
+    xc = x[..., 0].astype(np.float64) + 1j * x[..., 1]
+    fn = sa.fft_c2c_f64 if np.dtype(dtype) == np.float64 else sa.fft_c2c
+    for sign, ref in ((-1, np.fft.fft(xc, axis=1)), (+1, np.fft.ifft(xc, axis=1) * n)):
+        y = fn(ctx, x, sign)
+        yc = y[..., 0].astype(np.float64) + 1j * y[..., 1]
+        assert np.abs(yc - ref).max() / np.abs(ref).max() < tol, (n, sign)
+
+
 def test_fft_sizes_the_device_does_not_plan(ctx):
     """a transform (or the chirp transform a size with a prime factor above 13 needs) that does not fit one workgroup's LDS,
     and such a size as the filter's FFT: E_UNSUPPORTED with the reason"""
-    for fn, n, dt in ((sa.fft_c2c, 16384 * 3, np.float32), (sa.fft_c2c, 8209, np.float32), (sa.fft_c2c_f64, 10000, np.float64),
-                      (sa.fft_c2c_f64, 4099, np.float64)):
+    for fn, n, dt in ((sa.fft_c2c, 2 * 16411, np.float32), (sa.fft_c2c, 8209, np.float32), (sa.fft_c2c_f64, 2 * 8209, np.float64),
+                      (sa.fft_c2c_f64, 4099, np.float64)):   # (long sizes with a large prime factor; primes whose chirp transform does not fit)
         with pytest.raises(sa.abi.SdrHipError) as e:
             fn(ctx, np.zeros((1, n, 2), dt), -1)
         assert e.value.code == sa.abi.E_UNSUPPORTED, (n, str(e.value))
