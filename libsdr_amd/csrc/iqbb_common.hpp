@@ -46,6 +46,8 @@ struct IqbbArgs {
   int lpg;          // path 3: lanes that share one box window
   int tiles, tpw;   // tiles per channel in this call; consecutive tiles walked by one workgroup (MFMA paths)
   int bt_hi;        // hot kernel's cold phase: beside tile 0, the tiles bt_hi .. tiles-1 hold cold slices
+  int fix_lo, fix_hi;   // any-D forms with FM, channel-resident units: the slices [fix_lo, fix_hi) get their first angle difference
+                        // completed at the END of the hot kernel (iqbb_hot.hpp); empty: by iqbb_fm_fixup_kernel behind it
 };
 
 // Arguments of the hot kernels (iqbb_hot.hpp): the persistent grid's work split; everything the cold phase needs

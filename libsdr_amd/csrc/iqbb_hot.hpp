@@ -143,10 +143,17 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
 #ifndef K1_LATE_B
 #define K1_LATE_B 1
 #endif
+#ifndef K1_LATE_A
+#define K1_LATE_A 0
+#endif
+  // Only the any-D forms do this: in the /8 kernels nothing was spilled to begin with, and there the late copies cost
+  // vector registers instead (16 of them spilled to scratch in the USB and no-demodulator kernels of the 9-step class:
+  // +11 % time, +28 % HBM traffic on the 127-tap USB workload when it was tried for all kernels).
+  constexpr bool LATE_B = K1_LATE_B && DG, LATE_A = K1_LATE_A && DG;
   IqbbArgs b_late;
-  const IqbbArgs &b = K1_LATE_B ? b_late : b_kernarg;
-  HotArgs a_late;                                        // (likewise the cold phase's copy of `a`: what only it needs — the
-  const HotArgs &ac = K1_LATE_B ? a_late : a;            //  channel count, the call's geometry — does not live across the hot loop)
+  const IqbbArgs &b = LATE_B ? b_late : b_kernarg;
+  HotArgs a_late;                                        // (K1_LATE_A: likewise the cold phase's copy of `a`; off — it left 8 to
+  const HotArgs &ac = LATE_A ? a_late : a;               //  24 bytes of scratch in a dozen any-D kernels for -0.8 % in the others)
   constexpr bool CU8 = IN == HOT_CU8, REAL = IN == HOT_REAL;
   static_assert(!SD || DG, "the small-decimation form is a variant of the any-D form");
   static_assert(!DG || (!REAL && NW == 4), "any-D form: complex plans, 4-wave workgroups");
@@ -1098,7 +1105,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   };
 
 #if defined(__HIP_DEVICE_COMPILE__)
-  if (K1_LATE_B) {
+  if (LATE_B || LATE_A) {
     // the blocks' places in the kernarg segment: the explicit arguments of every kernel that calls this body
     // (`(const HotArgs a, const IqbbArgs b)`), laid out in declaration order at their natural alignment
     typedef const uint32_t __attribute__((address_space(4))) *KernargP;   // (the kernarg segment is constant memory: scalar loads)
@@ -1108,10 +1115,10 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
     static_assert(sizeof(IqbbArgs) % 4 == 0 && sizeof(HotArgs) % 4 == 0, "copied by dwords");
     uint32_t *dst = reinterpret_cast<uint32_t *>(&b_late);
 #pragma unroll
-    for (int i = 0; i < (int)(sizeof(IqbbArgs) / 4); i++) dst[i] = ((KernargP)(kp + B_OFF))[i];
+    for (int i = 0; i < (LATE_B ? (int)(sizeof(IqbbArgs) / 4) : 0); i++) dst[i] = ((KernargP)(kp + B_OFF))[i];
     uint32_t *dsta = reinterpret_cast<uint32_t *>(&a_late);
 #pragma unroll
-    for (int i = 0; i < (int)(sizeof(HotArgs) / 4); i++) dsta[i] = ((KernargP)kp)[i];
+    for (int i = 0; i < (LATE_A ? (int)(sizeof(HotArgs) / 4) : 0); i++) dsta[i] = ((KernargP)kp)[i];
   }
 #endif
   // ---- the call's COLD slices --------------------------------------------------------------------------------
@@ -1267,6 +1274,27 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       }
     }
   }
+  // FM in the any-D forms: a slice's first output went out as -phi (the slice before it, another wave's, holds the angle it
+  // is a difference with, and leaves it in philast). When the units are whole channels (G = 1: the host chooses that where
+  // the channels fill the grid evenly) every slice of the channels this workgroup walked — hot or cold — was finished by
+  // one of ITS four waves: the missing angles are all in place behind one workgroup barrier, and the fix-up is the
+  // workgroup's last step instead of a second launch (5 us: a launch's floor) behind this one.
+  if (DG && EPI == SDRHIP_EPI_FM) {
+    if (b.fix_hi > b.fix_lo) {   // (kernel-uniform)
+      __threadfence();           // this wave's outputs and philast entries, device-wide (the waves of a workgroup share no cache line here, but a CU's L1 is not where stores land)
+      __syncthreads();
+      for (int cc = bx; cc < ac.C; cc += gx) {
+        short *row = reinterpret_cast<short *>(ac.out) + (long)cc * ac.out_stride;
+        short *pl = ac.philast + (long)cc * ac.philast_stride;
+        for (int sl = b.fix_lo + (tid & 255); sl < b.fix_hi; sl += 256) {
+          short *o = row + (long)sl * GS;
+          const short v = __hip_atomic_load(o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (past the L1: written by another wave)
+          const short p = __hip_atomic_load(pl + sl - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          *o = (short)(v + p);
+        }
+      }
+    }
+  }
 #ifdef K1_STAMPS
   if (l == 0 && a.stamps) {   // 16 words per wave: 6 phase totals, -, -, slices, HW_ID, first and last realtime stamp
     unsigned long long *o = a.stamps + (size_t)((((unsigned)bx * 4 + wv) & 32767u) * 16);
@@ -1277,7 +1305,6 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
 #endif
 }
 
-// One launch per call: the hot grid, then each virtual workgroup's share of the cold slices.
 #ifndef K1_MINWAVES
 #define K1_MINWAVES 4
 #endif

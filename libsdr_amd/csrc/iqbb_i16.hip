@@ -759,6 +759,7 @@ struct sdrhip_iqbb_i16 {
   bool fast8 = false;
   bool use_hot = true;   // path 1, calls of >= 3 tiles: the hot kernel (SDRHIP_IQBB_HOT=0: the general kernels only, tuning/tests)
   int env_tpw = 0, env_wgpcu = 0;   // tuning hooks SDRHIP_IQBB_TPW / SDRHIP_IQBB_WGPCU, read once at create (0: not set)
+  int env_fm_resident = -1;         // SDRHIP_IQBB_FM_RESIDENT=0|1: never / always complete the any-D forms' FM outputs inside the hot kernel (-1: by the channel count)
   int hot_range = -1;    // which compile-time high-plane K-step range of the hot kernel covers ah_mask (-1: none)
   int in_cu8 = 0, real = 0, i8 = 0;   // input kinds: complex<uint8> with AutoCast, real int16 (BaseBand), complex<int8> (IQBaseBand<int8_t>)
   int path = 0, S = 0, cre = 0, cim = 0;   // path 1 = int8-MFMA formulation with S K-steps
@@ -930,6 +931,12 @@ struct sdrhip_iqbb_i16 {
   // the call's cold slices (history, carries, the stream's first sample, state for the next call); with FM a second,
   // tiny launch adds the previous slice's last angle to every slice's first output.
   // false: not this plan / call (the general kernel runs it).
+  // (any-D forms, FM) whole channels as the persistent grid's units: where they deal evenly over the grid
+  bool fm_resident_units() const {
+    if (env_fm_resident >= 0) return env_fm_resident != 0;   // tuning / test hook (SDRHIP_IQBB_FM_RESIDENT=0|1)
+    const size_t nvwg = 4 * (size_t)ctx->prop.multiProcessorCount, rounds = ceil_div((size_t)C, nvwg);
+    return (size_t)C * 100 >= rounds * nvwg * 97;
+  }
   bool anyd_plan() const {
     if (!(path == 3 && use_hot && hot_range >= 0 && S <= 9 && !i8 && !real)) return false;
     if (D >= 9 && D <= 512) return true;
@@ -968,7 +975,15 @@ struct sdrhip_iqbb_i16 {
 #endif
     const int nvwg = 4 * ctx->prop.multiProcessorCount;
     int htpw = 4; while (htpw > 1 && (size_t)ceil_div((size_t)tiles_h, (size_t)htpw) * C < 4 * (size_t)nvwg) htpw >>= 1;
-    if (env_tpw) htpw = env_tpw;   // tuning hook
+    // FM: the slices whose first output is neither out[0] nor out[1] (their own rules) and is emitted lack the angle of the
+    // slice before them. Where whole channels deal evenly over the persistent grid (within 3 %: 1024 or 8192 channels on 1024
+    // workgroups) a unit is a channel — one workgroup then finishes every slice of a channel and completes those outputs
+    // itself, behind a barrier at its end; otherwise (few channels: units of 4 tiles keep the grid full) a second launch does.
+    const int fix_lo = GS == 1 ? 2 : 1, fix_hi = epi == SDRHIP_EPI_FM ? (int)ceil_div((size_t)g.n_out, (size_t)GS) : 0;
+    const bool resident = fix_hi > fix_lo && fm_resident_units();
+    if (resident) htpw = tiles_h;
+    else if (env_tpw) htpw = env_tpw;   // tuning hook
+    a.fix_lo = resident ? fix_lo : 0; a.fix_hi = resident ? fix_hi : 0;
     ha.tpw = htpw;
     ha.G = (int)ceil_div((size_t)tiles_h, (size_t)htpw); ha.U = ha.G * C;
     const int grid = std::max(1, std::min(nvwg, std::max(ha.U, C)));   // (every channel's cold slices need a taker too)
@@ -976,12 +991,9 @@ struct sdrhip_iqbb_i16 {
     HotLaunch hl{(unsigned)grid, ctx->stream};
     if (D < 8) (void)hot_launch_sd(S, kind, hot_range, inc != 0, epi, hl, ha, a, false);
     else hot_launch_anyd(S, kind, hot_range, inc != 0, epi, hl, ha, a);
-    if (epi == SDRHIP_EPI_FM) {   // the slices whose first output is neither out[0] nor out[1] (their own rules) and is emitted
-      const int fix_lo = GS == 1 ? 2 : 1, fix_hi = (int)ceil_div((size_t)g.n_out, (size_t)GS);
-      if (fix_hi > fix_lo)
-        hipLaunchKernelGGL(iqbb_fm_fixup_kernel, dim3((unsigned)ceil_div((size_t)(fix_hi - fix_lo), (size_t)256), (unsigned)C), dim3(256), 0, ctx->stream,
-                           reinterpret_cast<short *>(out_dev), (long)out_stride, philast.p, 4 * tiles_h, fix_lo, fix_hi, GS, C);
-    }
+    if (!resident && fix_hi > fix_lo)
+      hipLaunchKernelGGL(iqbb_fm_fixup_kernel, dim3((unsigned)ceil_div((size_t)(fix_hi - fix_lo), (size_t)256), (unsigned)C), dim3(256), 0, ctx->stream,
+                         reinterpret_cast<short *>(out_dev), (long)out_stride, philast.p, 4 * tiles_h, fix_lo, fix_hi, GS, C);
     return true;
   }
 
@@ -1011,7 +1023,7 @@ struct sdrhip_iqbb_i16 {
     int tpw = 1;
     if (path == 1 || path == 4) { tpw = 8; while (tpw > 1 && (size_t)ceil_div((size_t)tiles, (size_t)tpw) * C < 2048) tpw >>= 1; }
     if (env_tpw && (path == 1 || path == 4)) tpw = env_tpw;   // tuning hook
-    a.tiles = tiles; a.tpw = tpw; a.bt_hi = 0;
+    a.tiles = tiles; a.tpw = tpw; a.bt_hi = 0; a.fix_lo = a.fix_hi = 0;
     a.lpg = 1; while (a.lpg < 64 && a.lpg * 8 < D) a.lpg <<= 1;
     dim3 grid((unsigned)ceil_div((size_t)tiles, (size_t)tpw), C), block(TPB);
     if (path == 4 && use_hot && hot_range >= 0 && tiles >= 3 && launch_hot_call(a, g, in_dev, N, in_stride, out_dev, out_stride, tiles)) {
@@ -1127,6 +1139,7 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
       { const char *d = getenv("SDRHIP_IQBB_HOT"); if (d && d[0] == '0') h->use_hot = false; }
       { const char *e = getenv("SDRHIP_IQBB_TPW"); if (e) h->env_tpw = std::max(1, atoi(e)); }
       { const char *e = getenv("SDRHIP_IQBB_WGPCU"); if (e) h->env_wgpcu = std::max(1, atoi(e)); }
+      { const char *e = getenv("SDRHIP_IQBB_FM_RESIDENT"); if (e) h->env_fm_resident = atoi(e) != 0; }
       const char *force = getenv("SDRHIP_IQBB_PATH");   // "valu": test hook (the VALU kernel for every plan)
       if (force && !strcmp(force, "valu")) mfma_ok = false;
       h->path = mfma_ok ? 1 : 0;
@@ -1245,7 +1258,10 @@ int sdrhip_iqbb_i16_kernel_names(sdrhip_iqbb_i16 *h, char *buf, size_t len) {
     const char *nm = "iqbb_i16_kernel";
     if (h->path == 4 && h->use_hot && h->hot_range >= 0) nm = "iqbb_hot_kernel";   // (calls of < 3 tiles: the general kernel)
     else if (h->path == 4) nm = "bb_real_mfma_kernel";
-    else if (h->path == 3 && h->anyd_plan()) nm = h->D < 8 ? "iqbb_hot_sd_kernel" : "iqbb_hot_anyd_kernel";   // (calls of a few tiles: the general kernel "iqbb_i16_mfmag_kernel")
+    else if (h->path == 3 && h->anyd_plan()) {   // (calls of a few tiles: the general kernel "iqbb_i16_mfmag_kernel")
+      nm = h->D < 8 ? "iqbb_hot_sd_kernel" : "iqbb_hot_anyd_kernel";
+      if (h->epi == SDRHIP_EPI_FM && !h->fm_resident_units()) nm = h->D < 8 ? "iqbb_hot_sd_kernel,iqbb_fm_fixup_kernel" : "iqbb_hot_anyd_kernel,iqbb_fm_fixup_kernel";
+    }
     else if (h->path == 3) nm = "iqbb_i16_mfmag_kernel";
     else if (h->path == 1 && h->use_hot && h->hot_range >= 0) nm = "iqbb_hot_kernel";   // (calls of < 3 tiles: the general kernel)
     else if (h->path == 1 && h->in_cu8) nm = "iqbb_i16_mfma_kernel";

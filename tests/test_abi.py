@@ -30,6 +30,29 @@ def test_library_is_hip_code_for_gfx950():
         assert k in blob
 
 
+def test_hot_kernels_keep_out_of_scratch(tmp_path):
+    """No K1 hot kernel may spill vector registers: scratch is HBM traffic behind the kernel's back (a change that left 68
+    bytes of it in the /8 USB kernels cost 11 % time and 28 % traffic before it was seen in a profile). Read from the
+    code objects' own metadata; the one allowance is a cold-phase spill of three dwords in one any-D kernel."""
+    import re
+    import shutil
+    so = shutil.copy(abi.SO_PATH, tmp_path / "lib.so")
+    subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", str(so)], capture_output=True, text=True, check=True, cwd=tmp_path)
+    objs = sorted(tmp_path.glob("lib.so.*gfx950"))
+    assert len(objs) >= 15, objs
+    seen, bad = 0, []
+    for o in objs:
+        notes = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", str(o)], capture_output=True, text=True).stdout
+        for name, scratch in re.findall(r"\.name:\s+(\S+)[\s\S]*?\.private_segment_fixed_size:\s+(\d+)", notes):
+            if "iqbb_hot" not in name:
+                continue
+            seen += 1
+            if int(scratch):
+                bad.append((name, int(scratch)))
+    assert seen >= 400, seen
+    assert len(bad) <= 1 and all("anyd" in n and b <= 12 for n, b in bad), bad
+
+
 def test_strerror_and_errors_without_device():
     L = abi.lib()
     assert L.sdrhip_strerror(0) == b"ok" and b"device" in L.sdrhip_strerror(abi.E_NODEVICE)

@@ -221,16 +221,23 @@ def _hot_fuzz(ctx, orc, rng, order, cu8, decim=8):
     lut, inc = sa.design_freqshift_lut_i16(), sa.design_freqshift_inc(Fc, FS)
     lens = [int(rng.integers(4000, 70000)) for _ in range(3)] + [int(rng.choice([1, 500, 2047, 4031, 4032, 4033, 65536]))] + [int(rng.integers(4000, 30000))]
     rng.shuffle(lens)
-    node = sa.IQBaseBandI16(ctx, taps, lut, inc, Fc < 0, decim, channels=C, max_in=max(lens), epilogue=epi)
+    # (any-D forms, FM: the slices' first angle differences by the fix-up launch or inside the hot kernel — read at create)
+    resident = int(rng.integers(0, 2))
+    os.environ["SDRHIP_IQBB_FM_RESIDENT"] = str(resident)
+    try:
+        node = sa.IQBaseBandI16(ctx, taps, lut, inc, Fc < 0, decim, channels=C, max_in=max(lens), epilogue=epi)
+    finally:
+        del os.environ["SDRHIP_IQBB_FM_RESIDENT"]
+    fix = ["iqbb_fm_fixup_kernel"] if epi == sa.EPI_FM and not resident else []
     if cu8:
         node.set_input_format(sa.abi.IN_CU8)
     if decim == 8:
         assert node.kernel_names == ["iqbb_hot_kernel"]
     elif decim < 8:   # (9 K steps without a shift do not fit the small-decimation form's LDS: the general kernel)
         assert node.path == 3 and node.kernel_names[0] in ("iqbb_hot_sd_kernel", "iqbb_i16_mfmag_kernel")
-        assert node.kernel_names == ["iqbb_hot_sd_kernel"] or (order > 65 and inc == 0)
+        assert node.kernel_names == ["iqbb_hot_sd_kernel"] + fix or (order > 65 and inc == 0)
     else:
-        assert node.path == 3 and node.kernel_names == ["iqbb_hot_anyd_kernel"]
+        assert node.path == 3 and node.kernel_names == ["iqbb_hot_anyd_kernel"] + fix
     refs = [orc.IQBaseBandI16(taps, lut, inc, Fc < 0, decim) for _ in range(C)]
     fms = [orc.FMDemodI16() for _ in range(C)]
     for n in lens:

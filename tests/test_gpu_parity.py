@@ -150,7 +150,7 @@ ANYD_CASES = [(21, 125, 100e3, True), (16, 62, 100e3, False), (21, 9, -60e3, Fal
               (129, 2, 30e3, True), (16, 4, 0.0, False), (21, 7, 0.0, True), (65, 3, 0.0, False), (127, 5, 0.0, True)]   # (no shift: examples/sdr_rec.cc:42-58 tunes every mode to the centre; 21 taps / 45: examples/sdr_pocsag.cc:117 and sdr_ax25.cc:117 behind a 1 MS/s RTL source)
 
 
-@pytest.mark.parametrize("hot", [True, False])
+@pytest.mark.parametrize("hot", [True, "resident", False])
 @pytest.mark.parametrize("epi", [sa.EPI_NONE, sa.EPI_FM, sa.EPI_AM, sa.EPI_USB])
 @pytest.mark.parametrize("order,decim,Fc,cu8", ANYD_CASES)
 def test_iqbb_any_decimation_long_calls_vs_oracle(ctx, orc, order, decim, Fc, cu8, epi, hot, monkeypatch):
@@ -158,8 +158,13 @@ def test_iqbb_any_decimation_long_calls_vs_oracle(ctx, orc, order, decim, Fc, cu
     taps on complex<uint8> input): plans of up to 129 taps, shifted or not, with 9 <= D <= 512 run the hot kernel's any-D form
     on the interior tiles of a long call and the general any-D kernel on the border tiles (two launches, seam tiles
     written by both). Ragged long and short calls, state carried across them, against the oracle; `hot` = False: the
-    general kernel alone (SDRHIP_IQBB_HOT=0)."""
+    general kernel alone (SDRHIP_IQBB_HOT=0); "resident" (FM only): whole channels as the hot kernel's units, which then
+    completes the slices' first angle differences itself instead of leaving them to iqbb_fm_fixup_kernel (what 1024 or 8192
+    channels get by themselves: SDRHIP_IQBB_FM_RESIDENT forces it on these 3)."""
+    if hot == "resident" and epi != sa.EPI_FM:
+        pytest.skip("the unit choice only matters to FM")
     monkeypatch.setenv("SDRHIP_IQBB_HOT", "1" if hot else "0")
+    monkeypatch.setenv("SDRHIP_IQBB_FM_RESIDENT", "1" if hot == "resident" else "0")
     monkeypatch.delenv("SDRHIP_IQBB_PATH", raising=False)
     FSr, C = 1e6, 3
     rng = np.random.default_rng(order * 1000 + decim)
@@ -175,7 +180,8 @@ def test_iqbb_any_decimation_long_calls_vs_oracle(ctx, orc, order, decim, Fc, cu
         # WITHOUT a shift — two arrays of 18-bit values — do not, and run the general kernel)
         assert order > 65 and Fc == 0.0
     else:
-        assert node.kernel_names == ([hot_name] if hot else ["iqbb_i16_mfmag_kernel"])
+        launches = [hot_name] + (["iqbb_fm_fixup_kernel"] if epi == sa.EPI_FM and hot is True else [])
+        assert node.kernel_names == (launches if hot else ["iqbb_i16_mfmag_kernel"])
     refs = [orc.IQBaseBandI16(taps, lut, inc, Fc < 0, decim) for _ in range(C)]
     fms = [orc.FMDemodI16() for _ in range(C)]
     for n in (65536, 70000, 12345, 1, 40001, 2 * decim + 1, 65536):
@@ -234,7 +240,12 @@ def test_iqbb_any_decimation_full_size(ctx, orc):
     x = np.ascontiguousarray(base[np.arange(C) % 8])
     node = sa.IQBaseBandI16(ctx, taps, lut, inc, False, D, channels=C, max_in=N, epilogue=sa.EPI_FM)
     node.set_input_format(sa.abi.IN_CU8)
+    # (1024 channels deal evenly over the 4 x 256 workgroups of the persistent grid: a unit is a channel, and the hot kernel
+    # completes the slices' first angle differences itself — one launch; a part with another CU count may add the fix-up)
     assert node.kernel_names[0] == "iqbb_hot_anyd_kernel"
+    import torch
+    if torch.cuda.get_device_properties(0).multi_processor_count == 256:
+        assert node.kernel_names == ["iqbb_hot_anyd_kernel"]
     ys = [node.process(x[:, :N]), node.process(x[:, N:])]
     for y in ys:
         for k in range(8):
@@ -245,10 +256,13 @@ def test_iqbb_any_decimation_full_size(ctx, orc):
             assert np.array_equal(y[k], fm.process(bb.process(orc.autocast_cu8_cs16(base[k, i * N:(i + 1) * N])))), (k, i)
 
 
-@pytest.mark.parametrize("epi", [sa.EPI_FM, sa.EPI_NONE])
-def test_iqbb_any_decimation_more_channels_than_workgroups(ctx, orc, epi):
+@pytest.mark.parametrize("epi,resident", [(sa.EPI_FM, False), (sa.EPI_FM, True), (sa.EPI_NONE, False)])
+def test_iqbb_any_decimation_more_channels_than_workgroups(ctx, orc, epi, resident, monkeypatch):
     """More channels (1100) than the persistent grid has workgroups (1024): the hot units and the cold slices of the any-D
-    form wrap around. 16 taps at decimation 62 on complex<int16>, two calls (the second starts inside a group)."""
+    form wrap around. 16 taps at decimation 62 on complex<int16>, two calls (the second starts inside a group). FM with
+    units of 4 tiles + the fix-up launch (what 1100 channels get), and with whole channels as units (forced: some workgroups
+    then walk two channels and complete both themselves)."""
+    monkeypatch.setenv("SDRHIP_IQBB_FM_RESIDENT", "1" if resident else "0")
     C, N, D = 1100, 40001, 62
     FSr = 1e6
     taps, lut, inc = orc.iqbb_design(100e3, 12.5e3, FSr, 16), orc.freqshift_lut_i16(), orc.freqshift_inc(-100e3, FSr)
@@ -256,7 +270,7 @@ def test_iqbb_any_decimation_more_channels_than_workgroups(ctx, orc, epi):
     base = rng.integers(-32768, 32768, (8, 2 * N, 2), dtype=np.int16)
     x = np.ascontiguousarray(base[np.arange(C) % 8])
     node = sa.IQBaseBandI16(ctx, taps, lut, inc, True, D, channels=C, max_in=N, epilogue=epi)
-    assert node.kernel_names == ["iqbb_hot_anyd_kernel"]
+    assert node.kernel_names == ["iqbb_hot_anyd_kernel"] + (["iqbb_fm_fixup_kernel"] if epi == sa.EPI_FM and not resident else [])
     ys = [node.process(x[:, :N]), node.process(x[:, N:])]
     for y in ys:
         for k in range(8):
