@@ -154,7 +154,9 @@ int sdrhip_iqbb_i16_path(sdrhip_iqbb_i16 *h, int *path);
  * run "iqbb_hot_sd_kernel" (the small-decimation form: a slice's 73 ... 256 groups summed out of an LDS array; plans of 9 K
  * steps without a shift do not fit its LDS); other path 3 plans and short calls the general kernel "iqbb_i16_mfmag_kernel".
  * Tuning / test variables, all read at create time: SDRHIP_IQBB_HOT=0 (general kernels only), SDRHIP_IQBB_TPW (tiles per
- * work unit), SDRHIP_IQBB_WGPCU (workgroups per CU of the persistent grid). None changes results. */
+ * work unit), SDRHIP_IQBB_WGPCU (workgroups per CU of the persistent grid), SDRHIP_IQBB_FM_RESIDENT=0|1 (FM at a
+ * decimation other than 8: never / always whole channels as work units, i.e. the slices' first angle differences by a
+ * second launch / inside the hot kernel; unset: by whether the channels deal evenly over the grid). None changes results. */
 int sdrhip_iqbb_i16_kernel_names(sdrhip_iqbb_i16 *h, char *buf, size_t len);
 /* outputs the next call of n_in samples will produce (does not advance the state) */
 int sdrhip_iqbb_i16_out_count(sdrhip_iqbb_i16 *h, size_t n_in, size_t *n_out);
