@@ -150,8 +150,7 @@ ANYD_CASES = [(21, 125, 100e3, True), (16, 62, 100e3, False), (21, 9, -60e3, Fal
               (129, 2, 30e3, True), (16, 4, 0.0, False), (21, 7, 0.0, True), (65, 3, 0.0, False), (127, 5, 0.0, True)]   # (no shift: examples/sdr_rec.cc:42-58 tunes every mode to the centre; 21 taps / 45: examples/sdr_pocsag.cc:117 and sdr_ax25.cc:117 behind a 1 MS/s RTL source)
 
 
-@pytest.mark.parametrize("hot", [True, "resident", False])
-@pytest.mark.parametrize("epi", [sa.EPI_NONE, sa.EPI_FM, sa.EPI_AM, sa.EPI_USB])
+@pytest.mark.parametrize("epi,hot", [(e, h) for e in (sa.EPI_NONE, sa.EPI_FM, sa.EPI_AM, sa.EPI_USB) for h in (True, False)] + [(sa.EPI_FM, "resident")])
 @pytest.mark.parametrize("order,decim,Fc,cu8", ANYD_CASES)
 def test_iqbb_any_decimation_long_calls_vs_oracle(ctx, orc, order, decim, Fc, cu8, epi, hot, monkeypatch):
     """The reference's own receivers decimate by 62 (examples/sdr_rec.cc:68, 16 taps) and 125 (examples/sdr_fm.cc:40, 21
@@ -161,8 +160,6 @@ def test_iqbb_any_decimation_long_calls_vs_oracle(ctx, orc, order, decim, Fc, cu
     general kernel alone (SDRHIP_IQBB_HOT=0); "resident" (FM only): whole channels as the hot kernel's units, which then
     completes the slices' first angle differences itself instead of leaving them to iqbb_fm_fixup_kernel (what 1024 or 8192
     channels get by themselves: SDRHIP_IQBB_FM_RESIDENT forces it on these 3)."""
-    if hot == "resident" and epi != sa.EPI_FM:
-        pytest.skip("the unit choice only matters to FM")
     monkeypatch.setenv("SDRHIP_IQBB_HOT", "1" if hot else "0")
     monkeypatch.setenv("SDRHIP_IQBB_FM_RESIDENT", "1" if hot == "resident" else "0")
     monkeypatch.delenv("SDRHIP_IQBB_PATH", raising=False)
