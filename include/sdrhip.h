@@ -148,11 +148,12 @@ int sdrhip_iqbb_i16_path(sdrhip_iqbb_i16 *h, int *path);
  * ONE launch per call, "iqbb_hot_kernel": a persistent grid over the wave slices that touch no border of the call,
  * whose workgroups finish with the call's first and last slices, the state and the history roll (calls of fewer than
  * 3 tiles, about 6000 samples, run the general kernel "iqbb_i16_mfma_dma_kernel" / "iqbb_i16_mfma_kernel" instead).
- * Path 3 plans of up to 129 taps and 9 <= decim <= 512, shifted or not (the reference's receivers: 16 taps / 83 or / 20
+ * Path 3 plans of up to 257 taps and 9 <= decim <= 512, shifted or not (the reference's receivers: 16 taps / 83 or / 20
  * without a shift, 21 taps / 125 with one; examples/sdr_rec.cc:42-68, examples/sdr_fm.cc:40) run "iqbb_hot_anyd_kernel" on long calls — the same persistent
- * structure, cold slices included (with FM a second, tiny launch completes the slices' first outputs); decimations 2 ... 7
- * run "iqbb_hot_sd_kernel" (the small-decimation form: a slice's 73 ... 256 groups summed out of an LDS array; plans of 9 K
- * steps without a shift do not fit its LDS); other path 3 plans and short calls the general kernel "iqbb_i16_mfmag_kernel".
+ * structure, cold slices included (with FM the slices' first outputs are completed at the end of that kernel where the
+ * channels deal evenly over its grid, else by a second, tiny launch "iqbb_fm_fixup_kernel"); decimations 2 ... 7 run
+ * "iqbb_hot_sd_kernel" (the small-decimation form: a slice's 73 ... 256 groups summed out of an LDS array; up to 129 taps,
+ * and plans of 9 K steps without a shift do not fit its LDS); other path 3 plans and short calls the general kernel "iqbb_i16_mfmag_kernel".
  * Tuning / test variables, all read at create time: SDRHIP_IQBB_HOT=0 (general kernels only), SDRHIP_IQBB_TPW (tiles per
  * work unit), SDRHIP_IQBB_WGPCU (workgroups per CU of the persistent grid), SDRHIP_IQBB_FM_RESIDENT=0|1 (FM at a
  * decimation other than 8: never / always whole channels as work units, i.e. the slices' first angle differences by a

@@ -62,9 +62,9 @@ constexpr bool hot_wide(int S, int NH, int in, int NW, int extra = 0, bool pair 
 // the any-D form's additions to a workgroup's LDS: parked group sums, and the rotated samples where the window buffer is too small
 // (rot = false, plans without a shift: the unrotated values have 18 bits — two arrays of dwords instead of one of int16 pairs)
 #ifdef K1_TEAM_LDS
-constexpr int hot_anyd_extra(int S, int in, bool rot = true) { return 4 * 512 + (hot_bufb(S, in) >= 2048 ? 0 : 4 * 2048) + (rot ? 0 : 4 * 2048); }
-#else   // (the team sums stay in registers: only the parked group sums)
-constexpr int hot_anyd_extra(int, int, bool = true) { return 4 * 512; }
+constexpr int hot_anyd_extra(int S, int in, bool rot = true, int NW = 4) { return NW * 512 + (hot_bufb(S, in) >= 2048 ? 0 : NW * 2048) + (rot ? 0 : NW * 2048); }
+#else   // (the team sums stay in registers: only the parked group sums, 512 bytes per wave)
+constexpr int hot_anyd_extra(int, int, bool = true, int NW = 4) { return NW * 512; }
 #endif
 
 // the small-decimation form (2 <= D <= 7, SD): the wave's 512 rotated samples go through a 2 KB per-wave LDS array (the
@@ -100,8 +100,10 @@ void hot_launch_s9_cu8(int range, bool rot, int epi, const HotLaunch &, const Ho
 void hot_launch_s17_cs16(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
 void hot_launch_s17_cu8(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
 void hot_launch_real(int S, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);   // S = 5 or 9
-void hot_launch_anyd(int S, int in, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);   // S = 2, 3, 5 or 9, cs16 / cu8
+void hot_launch_anyd(int S, int in, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);   // S = 2, 3, 5, 9 or 17, cs16 / cu8
 void hot_launch_anyd9(int in, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
+void hot_launch_anyd17_cs16(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);   // (orders 130 ... 257: 8- and 16-wave workgroups, as the /8 kernel's)
+void hot_launch_anyd17_cu8(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
 // decimations 2 ... 7 (S = 2, 3, 5 or 9, cs16 / cu8); false: this plan's LDS does not fit (the general kernel runs it)
 bool hot_launch_sd(int S, int in, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &, bool dry_run);
 bool hot_launch_sd9(int in, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &, bool dry_run);
@@ -156,7 +158,8 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   const HotArgs &ac = LATE_A ? a_late : a;               //  24 bytes of scratch in a dozen any-D kernels for -0.8 % in the others)
   constexpr bool CU8 = IN == HOT_CU8, REAL = IN == HOT_REAL;
   static_assert(!SD || DG, "the small-decimation form is a variant of the any-D form");
-  static_assert(!DG || (!REAL && NW == 4), "any-D form: complex plans, 4-wave workgroups");
+  static_assert(!DG || !REAL, "any-D form: complex plans");
+  static_assert(!SD || NW == 4, "small-decimation form: 4-wave workgroups");
   const int DD = DG ? a.D : 8, GS = DG ? a.GS : 64;   // decimation, whole groups per slice
   static_assert(S >= 2 && S0 >= 0 && NH >= 1 && S0 + NH <= S, "high-plane range inside the K loop");
   static_assert(!REAL || NW == 4, "real input: 4-wave workgroups");
@@ -169,7 +172,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   constexpr int LASTL = NPIECE - 64 * (NDMA - 1);              // lanes of the last one
   static_assert(NDMA <= 3, "immediate offsets 0 / 1024 / 2048");
   constexpr bool PAIR = hot_pair(IN, NW, DG);
-  constexpr bool WIDE = SD ? false : hot_wide(S, NH, IN, NW, DG ? hot_anyd_extra(S, IN, ROT) : 0, PAIR);   // (SD: the narrow table, the LDS goes to the sample arrays)
+  constexpr bool WIDE = SD ? false : hot_wide(S, NH, IN, NW, DG ? hot_anyd_extra(S, IN, ROT, NW) : 0, PAIR);   // (SD: the narrow table, the LDS goes to the sample arrays)
   static_assert(!SD || hot_sd_fits(S, NH, IN, ROT), "small-decimation form: LDS budget");
   constexpr int NBUF = PAIR ? 4 : 2;   // window buffers per wave
   static_assert(hot_lds_bytes(S, NH, IN, NW, WIDE, PAIR) <= hot_lds_cap(NW, PAIR), "LDS budget for 4 waves per SIMD");
@@ -1313,9 +1316,9 @@ template <int S, int S0, int NH, bool ROT, int EPI, int IN, int NW>
 __global__ __launch_bounds__(64 * NW, K1_MINWAVES) void iqbb_hot_kernel(const HotArgs a, const IqbbArgs b) {
   iqbb_hot_body<S, S0, NH, ROT, EPI, IN, NW>(a, b);
 }
-template <int S, int S0, int NH, bool ROT, int EPI, int IN>
-__global__ __launch_bounds__(256, K1_MINWAVES) void iqbb_hot_anyd_kernel(const HotArgs a, const IqbbArgs b) {
-  iqbb_hot_body<S, S0, NH, ROT, EPI, IN, 4, true>(a, b);
+template <int S, int S0, int NH, bool ROT, int EPI, int IN, int NW = 4>
+__global__ __launch_bounds__(64 * NW, K1_MINWAVES) void iqbb_hot_anyd_kernel(const HotArgs a, const IqbbArgs b) {
+  iqbb_hot_body<S, S0, NH, ROT, EPI, IN, NW, true>(a, b);
 }
 
 template <int S, int S0, int NH, bool ROT, int EPI, int IN>
@@ -1364,12 +1367,23 @@ void hot_launch_one(bool rot, int epi, const HotLaunch &hl, const HotArgs &ha, c
 #undef SDRHIP_HOT
 }
 
-template <int S, int S0, int NH, int IN>
+template <int S, int S0, int NH, int IN, int NW = 4>
 void hot_launch_anyd_one(bool rot, int epi, const HotLaunch &hl, const HotArgs &ha, const IqbbArgs &b) {
-  const int extra = hot_anyd_extra(S, IN, rot);
-  const size_t lds = (size_t)hot_lds_bytes(S, NH, IN, 4, hot_wide(S, NH, IN, 4, extra)) + extra;
-  const dim3 grid(hl.grid, 1), block(256);
-#define SDRHIP_ANYD(R_, E_) hipLaunchKernelGGL((iqbb_hot_anyd_kernel<S, S0, NH, R_, E_, IN>), grid, block, lds, hl.stream, ha, b)
+  const int extra = hot_anyd_extra(S, IN, rot, NW);
+  const size_t lds = (size_t)hot_lds_bytes(S, NH, IN, NW, hot_wide(S, NH, IN, NW, extra)) + extra;
+  static_assert(hot_lds_bytes(S, NH, IN, NW, false) + hot_anyd_extra(S, IN, false, NW) <= 163840, "any-D form: a workgroup's LDS");
+  if (NW > 4) {   // (beyond 64 KB of dynamic LDS: once per process and kernel)
+    static bool attr_set = false;
+    if (!attr_set) {
+#define SDRHIP_ANYD_ATTR(R_, E_) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&iqbb_hot_anyd_kernel<S, S0, NH, R_, E_, IN, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, hot_lds_cap(NW) + hot_anyd_extra(S, IN, false, NW) > 163840 ? 163840 : hot_lds_cap(NW) + hot_anyd_extra(S, IN, false, NW))
+      SDRHIP_ANYD_ATTR(true, SDRHIP_EPI_NONE); SDRHIP_ANYD_ATTR(true, SDRHIP_EPI_FM); SDRHIP_ANYD_ATTR(true, SDRHIP_EPI_AM); SDRHIP_ANYD_ATTR(true, SDRHIP_EPI_USB);
+      SDRHIP_ANYD_ATTR(false, SDRHIP_EPI_NONE); SDRHIP_ANYD_ATTR(false, SDRHIP_EPI_FM); SDRHIP_ANYD_ATTR(false, SDRHIP_EPI_AM); SDRHIP_ANYD_ATTR(false, SDRHIP_EPI_USB);
+#undef SDRHIP_ANYD_ATTR
+      attr_set = true;
+    }
+  }
+  const dim3 grid(hl.grid, 1), block(64 * NW);
+#define SDRHIP_ANYD(R_, E_) hipLaunchKernelGGL((iqbb_hot_anyd_kernel<S, S0, NH, R_, E_, IN, NW>), grid, block, lds, hl.stream, ha, b)
 #define SDRHIP_ANYD_E(R_) do { switch (epi) { \
     case SDRHIP_EPI_FM: SDRHIP_ANYD(R_, SDRHIP_EPI_FM); break; \
     case SDRHIP_EPI_AM: SDRHIP_ANYD(R_, SDRHIP_EPI_AM); break; \

@@ -1,6 +1,6 @@
 // iqbb_hot_anyd.hip — explicit instantiations of the hot kernel's any-decimation form (iqbb_hot.hpp, DG) for S = 2, 3 and 5
 // K steps (orders up to 65; the reference's receivers use 16 and 21 taps at decimation 62 and 125), complex<int16> and
-// complex<uint8> input. S = 9: iqbb_hot_anyd9.hip.
+// complex<uint8> input. S = 9: iqbb_hot_anyd9.hip; S = 17: iqbb_hot_anyd17_*.hip.
 #include "iqbb_hot.hpp"
 
 namespace sdrhip {
@@ -14,8 +14,10 @@ void hot_launch_anyd(int S, int in, int range, bool rot, int epi, const HotLaunc
   } else if (S == 5) {
     if (range == 0) { if (cu8) hot_launch_anyd_one<5, 1, 3, HOT_CU8>(rot, epi, hl, ha, b); else hot_launch_anyd_one<5, 1, 3, HOT_CS16>(rot, epi, hl, ha, b); }
     else { if (cu8) hot_launch_anyd_one<5, 0, 5, HOT_CU8>(rot, epi, hl, ha, b); else hot_launch_anyd_one<5, 0, 5, HOT_CS16>(rot, epi, hl, ha, b); }
-  } else {
+  } else if (S == 9) {
     hot_launch_anyd9(in, range, rot, epi, hl, ha, b);
+  } else {
+    if (cu8) hot_launch_anyd17_cu8(range, rot, epi, hl, ha, b); else hot_launch_anyd17_cs16(range, rot, epi, hl, ha, b);
   }
 }
 }  // namespace sdrhip

@@ -938,8 +938,9 @@ struct sdrhip_iqbb_i16 {
     return (size_t)C * 100 >= rounds * nvwg * 97;
   }
   bool anyd_plan() const {
-    if (!(path == 3 && use_hot && hot_range >= 0 && S <= 9 && !i8 && !real)) return false;
+    if (!(path == 3 && use_hot && hot_range >= 0 && S <= 17 && !i8 && !real)) return false;
     if (D >= 9 && D <= 512) return true;
+    if (S > 9) return false;   // (the small-decimation form: 4-wave workgroups, orders up to 129)
     // decimations 2 ... 7: the small-decimation form, where its sample arrays fit the workgroup's LDS (iqbb_hot.hpp, SD)
     return D >= 2 && D <= 7 && hot_launch_sd(S, in_cu8 ? HOT_CU8 : HOT_CS16, hot_range, inc != 0, epi, HotLaunch{0, nullptr}, HotArgs{}, IqbbArgs{}, true);
   }
@@ -973,6 +974,10 @@ struct sdrhip_iqbb_i16 {
     if (!k1_stamps.p) { k1_stamps.alloc(32768 * 16); k1_stamps.zero(ctx->stream); }
     ha.stamps = k1_stamps.p;
 #endif
+    // (17 K steps: 8- or 16-wave workgroups = 2 or 4 virtual ones sharing the tap fragments, as the /8 kernel of that class)
+    int cnt = 0;
+    const HotRange *ranges = hot_ranges(S, &cnt);
+    const int NW = ranges[std::min(hot_range, cnt - 1)].NW, vper = NW / 4;
     const int nvwg = 4 * ctx->prop.multiProcessorCount;
     int htpw = 4; while (htpw > 1 && (size_t)ceil_div((size_t)tiles_h, (size_t)htpw) * C < 4 * (size_t)nvwg) htpw >>= 1;
     // FM: the slices whose first output is neither out[0] nor out[1] (their own rules) and is emitted lack the angle of the
@@ -986,8 +991,9 @@ struct sdrhip_iqbb_i16 {
     a.fix_lo = resident ? fix_lo : 0; a.fix_hi = resident ? fix_hi : 0;
     ha.tpw = htpw;
     ha.G = (int)ceil_div((size_t)tiles_h, (size_t)htpw); ha.U = ha.G * C;
-    const int grid = std::max(1, std::min(nvwg, std::max(ha.U, C)));   // (every channel's cold slices need a taker too)
-    ha.dq = grid / ha.G; ha.dr = grid % ha.G;
+    const int grid = (int)ceil_div((size_t)std::max(1, std::min(nvwg, std::max(ha.U, C))), (size_t)vper);   // (every channel's cold slices need a taker too)
+    const int gx = grid * vper;   // virtual workgroups
+    ha.dq = gx / ha.G; ha.dr = gx % ha.G;
     HotLaunch hl{(unsigned)grid, ctx->stream};
     if (D < 8) (void)hot_launch_sd(S, kind, hot_range, inc != 0, epi, hl, ha, a, false);
     else hot_launch_anyd(S, kind, hot_range, inc != 0, epi, hl, ha, a);

@@ -144,6 +144,8 @@ ANYD_CASES = [(21, 125, 100e3, True), (16, 62, 100e3, False), (21, 9, -60e3, Fal
               (33, 257, -60e3, False),
               (16, 20, 0.0, True), (16, 83, 0.0, True), (21, 125, 0.0, False), (64, 100, 0.0, False), (127, 300, 0.0, True), (16, 9, 0.0, False),
               (21, 45, 0.0, True),
+              # orders 130 ... 257 (17 K steps): the any-D form in the 8- and 16-wave workgroups of the /8 kernel's long-filter class
+              (255, 125, 100e3, True), (200, 20, -60e3, False), (257, 9, 0.0, False), (130, 62, 100e3, False), (161, 300, 0.0, True),
               # decimations 2 ... 7: the hot kernel's small-decimation form (a slice holds 73 ... 256 groups: lane l finishes
               # the groups l, l + 64, ... of every slice)
               (21, 2, 100e3, False), (16, 3, -100e3, True), (33, 4, 70e3, False), (64, 5, 100e3, True), (127, 6, -60e3, False), (21, 7, 100e3, True),
@@ -154,7 +156,7 @@ ANYD_CASES = [(21, 125, 100e3, True), (16, 62, 100e3, False), (21, 9, -60e3, Fal
 @pytest.mark.parametrize("order,decim,Fc,cu8", ANYD_CASES)
 def test_iqbb_any_decimation_long_calls_vs_oracle(ctx, orc, order, decim, Fc, cu8, epi, hot, monkeypatch):
     """The reference's own receivers decimate by 62 (examples/sdr_rec.cc:68, 16 taps) and 125 (examples/sdr_fm.cc:40, 21
-    taps on complex<uint8> input): plans of up to 129 taps, shifted or not, with 9 <= D <= 512 run the hot kernel's any-D form
+    taps on complex<uint8> input): plans of up to 257 taps, shifted or not, with 9 <= D <= 512 run the hot kernel's any-D form
     on the interior tiles of a long call and the general any-D kernel on the border tiles (two launches, seam tiles
     written by both). Ragged long and short calls, state carried across them, against the oracle; `hot` = False: the
     general kernel alone (SDRHIP_IQBB_HOT=0); "resident" (FM only): whole channels as the hot kernel's units, which then
