@@ -295,11 +295,22 @@ def test_hot_kernel_every_length_class_random_long_calls(ctx, orc, seed, cu8):
 @pytest.mark.parametrize("cu8", [False, True])
 @pytest.mark.parametrize("seed", range(16 + EXTRA))
 def test_hot_kernel_any_decimation_random_long_calls(ctx, orc, seed, cu8):
-    """The hot kernel's any-decimation form (9 <= D <= 512, up to 129 taps, shifted or not): random plans incl. the reference receivers' (16 taps / 62, 21 taps / 125), ragged long and short calls,
+    """The hot kernel's any-decimation form (9 <= D <= 512, here up to 129 taps, shifted or not): random plans incl. the reference receivers' (16 taps / 62, 21 taps / 125), ragged long and short calls,
     retuning (also to and from no shift at all), filter swaps and _reconfigure between buffers."""
     rng = np.random.default_rng(23000 + 2 * seed + int(cu8))
     order = int(rng.choice([3, 16, 17, 21, 33, 34, 64, 65, 100, 127, 129]))
     decim = int(rng.choice([9, 10, 12, 31, 50, 62, 100, 125, 180, 200, 256, 300, 512]))
+    _hot_fuzz(ctx, orc, rng, order, cu8, decim)
+
+
+@pytest.mark.parametrize("cu8", [False, True])
+@pytest.mark.parametrize("seed", range(8 + EXTRA))
+def test_hot_kernel_any_decimation_long_filters_random_long_calls(ctx, orc, seed, cu8):
+    """The any-decimation form's 17-K-step class (orders 130 ... 257: 8- or 16-wave workgroups by the taps' high-plane
+    range — a filter swap between buffers moves a plan from one to the other)."""
+    rng = np.random.default_rng(31000 + 2 * seed + int(cu8))
+    order = int(rng.choice([130, 161, 200, 255, 257]))
+    decim = int(rng.choice([9, 12, 31, 62, 125, 200, 300, 512]))
     _hot_fuzz(ctx, orc, rng, order, cu8, decim)
 
 
