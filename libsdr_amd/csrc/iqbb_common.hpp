@@ -52,6 +52,10 @@ struct IqbbArgs {
 
 // Arguments of the hot kernels (iqbb_hot.hpp): the persistent grid's work split; everything the cold phase needs
 // beyond them comes from the IqbbArgs block passed beside it.
+// the hot kernel's fifth "epilogue" (internal; sdrhip.h's are 0 ... 3): no division, no demodulator — partial box sums for
+// iqbb_bigd_finish_kernel (decimations above 512: a group spans slices)
+constexpr int HOT_EPI_PARTIAL = 4;
+
 struct HotArgs {
   const void *in; long in_stride;       // cs16: one dword per sample; cu8: one ushort (stride in samples)
   void *out; long out_stride;
@@ -66,6 +70,10 @@ struct HotArgs {
   int D, GS, lpg_sh; float inv_d;       // any-D form: decimation, whole groups per slice (512 / D), log2 of the lanes per group team, (1 / D)(1 - 2^-20)
   short *philast; int philast_stride;   // any-D form with FM: slice (tile, w) leaves the angle of its last group in philast[c * stride + 4 * tile + w]
   int tiles_h;                          // any-D form: tiles of the call (4 slices of GS groups each)
+  // large-decimation form (HOT_EPI_PARTIAL): slices of 512 samples from the call's first sample on, whatever the groups; slice
+  // sid of channel c leaves the sums of its (at most three) stretches between group boundaries in part[c * part_stride + 3 sid + k]
+  int2 *part; int part_stride;
+  int Dreal, base_real;                 // the plan's decimation, and the call-relative index its groups are counted from (boundaries: base_real + j Dreal, j >= 1)
   unsigned long long *stamps;           // diagnostic builds (-DK1_STAMPS) only
 };
 

@@ -157,6 +157,16 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   HotArgs a_late;                                        // (K1_LATE_A: likewise the cold phase's copy of `a`; off — it left 8 to
   const HotArgs &ac = LATE_A ? a_late : a;               //  24 bytes of scratch in a dozen any-D kernels for -0.8 % in the others)
   constexpr bool CU8 = IN == HOT_CU8, REAL = IN == HOT_REAL;
+  // PART (with DG): decimations above 512 — a group no longer fits a slice. The kernel runs the any-D form's geometry of
+  // "decimation 512" from the call's first sample on (one pseudo-group per slice, cold slices where the window leaves the
+  // call) and a slice, instead of finishing groups, leaves the sums of its stretches between the REAL group boundaries
+  // (at most two inside 512 samples) in global memory; iqbb_bigd_finish_kernel adds each group's stretches, the carry and
+  // the border rules, divides and demodulates.
+  constexpr bool PART = EPI == HOT_EPI_PARTIAL;
+  static_assert(!PART || (DG && !SD), "partial sums: a variant of the any-D form");
+#ifdef K1_TEAM_LDS
+  static_assert(!PART, "partial sums come out of the register prefix sums");
+#endif
   static_assert(!SD || DG, "the small-decimation form is a variant of the any-D form");
   static_assert(!DG || !REAL, "any-D form: complex plans");
   static_assert(!SD || NW == 4, "small-decimation form: 4-wave workgroups");
@@ -487,7 +497,8 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
     tm_end = b1 >= 64;
   }
   (void)tm_sp; (void)tm_a0; (void)tm_a1; (void)tm_end;
-  auto stageE = [&](auto edge_, const v16i &acc_hh, const v16i &acc_mid, const v16i &acc_ll, uint32_t wave_cnt, char *escr, int erel0) __attribute__((always_inline)) {
+  auto stageE = [&](auto edge_, const v16i &acc_hh, const v16i &acc_mid, const v16i &acc_ll, uint32_t wave_cnt, char *escr, int erel0,
+                    int2 *pdst = nullptr, int ob0 = 0) __attribute__((always_inline)) {   // (PART: where the slice's partial sums go, its first group boundary)
     constexpr bool EDGE = decltype(edge_)::value;
     int L[8][3];
 #ifdef K1_ABL_NOEPI
@@ -644,6 +655,28 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       const int r0x = __builtin_amdgcn_readlane(ix, 15), r0y = __builtin_amdgcn_readlane(iy, 15);
       if (l & 16) { ix += r0x; iy += r0y; }
       const int totx = __builtin_amdgcn_readlane(ix, 31), toty = __builtin_amdgcn_readlane(iy, 31);
+      if (PART) {
+        // the sums in front of the (wave-uniform) boundaries ob0 and ob0 + Dreal, where they fall inside the slice: the
+        // prefix in front of the boundary's block + the block's samples in front of it, read from the lane that owns it
+        const int bpx = ix - (h ? (int)tx[1] : cx), bpy = iy - (h ? (int)ty[1] : cy);
+        auto prefix_at = [&](int p, int &px, int &py) __attribute__((always_inline)) {   // 0 < p < 512 (scalar)
+          const int j = p & 7, lb = p >> 3, ln = (lb >> 1) + 32 * (lb & 1);
+          int vx = bpx, vy = bpy;
+#pragma unroll
+          for (int t = 1; t < 8; t++) if (j == t) { vx += rx[t - 1]; vy += ry[t - 1]; }   // (scalar conditions)
+          px = __builtin_amdgcn_readlane(vx, ln); py = __builtin_amdgcn_readlane(vy, ln);
+        };
+        int p0x = totx, p0y = toty, p1x = totx, p1y = toty;
+        if (ob0 < 512) prefix_at(ob0, p0x, p0y);
+        if (ob0 + a.Dreal < 512) prefix_at(ob0 + a.Dreal, p1x, p1y); else { p1x = totx; p1y = toty; }
+        if (ob0 >= 512) { p1x = totx; p1y = toty; }
+        if (l == 0) {
+          pdst[0] = make_int2(p0x, p0y);
+          pdst[1] = make_int2(p1x - p0x, p1y - p0y);
+          pdst[2] = make_int2(totx - p1x, toty - p1y);
+        }
+        return sum;
+      }
       // the prefix sum in front of the block, plus the samples in front of its boundary
       const int sbx = ix - (h ? (int)tx[1] : cx) + ax, sby = iy - (h ? (int)ty[1] : cy) + ay;
       const int s0x = __builtin_amdgcn_ds_bpermute(tm_a0, sbx), s0y = __builtin_amdgcn_ds_bpermute(tm_a0, sby);
@@ -986,13 +1019,22 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       asm volatile("s_nop 0" : "+v"(acc_hh), "+v"(acc_mid), "+v"(acc_ll));   // the accumulators are complete before the stamp
 #endif
       K1_STAMP(3);
-      int2 sum = stageE(std::false_type{}, acc_hh, acc_mid, acc_ll, cnt0 + (uint32_t)tile * tile_cnt, cb, 0);
+      int2 *pdst = nullptr;
+      int ob0 = 0;
+      if (PART) {   // (scalar) the slice's number, its first sample, its first group boundary
+        const int sid = 4 * tile + wv, t0 = a.base0_rel + sid * 512 - a.base_real;
+        ob0 = t0 < 0 ? a.Dreal - t0 : a.Dreal - (int)((unsigned)t0 % (unsigned)a.Dreal);
+        pdst = a.part + (long)c * a.part_stride + 3 * sid;
+      }
+      int2 sum = stageE(std::false_type{}, acc_hh, acc_mid, acc_ll, cnt0 + (uint32_t)tile * tile_cnt, cb, 0, pdst, ob0);
 #ifdef K1_STAMPS
       asm volatile("" : "+v"(sum.x), "+v"(sum.y));
 #endif
       K1_STAMP(4);
       if (SD) {
         sd_finish_hot(cb, outb + (long)tile * tile_out_bytes, c, tile);
+      } else if (PART) {
+        // (the slice's partial sums are out: stageE)
       } else if (DG) {
         if (npend == 0) ptile0 = tile;
         park(sum);
@@ -1261,9 +1303,16 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
         }
         if (DG) {
           const int s0 = ac.base0_rel + (q0 + gw) * DD;   // the slice's first sample, call-relative
-          const int2 sum = stageE(std::true_type{}, acc_hh, acc_mid, acc_ll, (ac.n0_lo + (uint32_t)s0) * ac.inc, cb, s0 + MF_BLK * n + 2 * h);
+          int2 *pdst = nullptr;
+          int ob0 = 0;
+          if (PART) {
+            const int t0 = s0 - ac.base_real;
+            ob0 = t0 < 0 ? ac.Dreal - t0 : ac.Dreal - (int)((unsigned)t0 % (unsigned)ac.Dreal);
+            pdst = ac.part + (long)cc * ac.part_stride + 3 * (4 * t + wv);
+          }
+          const int2 sum = stageE(std::true_type{}, acc_hh, acc_mid, acc_ll, (ac.n0_lo + (uint32_t)s0) * ac.inc, cb, s0 + MF_BLK * n + 2 * h, pdst, ob0);
           if (SD) sd_finish_cold(cb, cc, 4 * t + wv);
-          else cold_finish_gen(sum, cc, 4 * t + wv);
+          else if (!PART) cold_finish_gen(sum, cc, 4 * t + wv);
         } else {
           const int tb = ac.base0_rel + q0 * 8, rel0 = tb + 8 * gw + MF_BLK * n + 8 * h;
           const int2 sum = group_sum<ROT, CU8, true, WIDE ? 2 : 1, FSH>(b, acc_hh, acc_mid, acc_ll, rel0);
@@ -1378,6 +1427,7 @@ void hot_launch_anyd_one(bool rot, int epi, const HotLaunch &hl, const HotArgs &
 #define SDRHIP_ANYD_ATTR(R_, E_) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&iqbb_hot_anyd_kernel<S, S0, NH, R_, E_, IN, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, hot_lds_cap(NW) + hot_anyd_extra(S, IN, false, NW) > 163840 ? 163840 : hot_lds_cap(NW) + hot_anyd_extra(S, IN, false, NW))
       SDRHIP_ANYD_ATTR(true, SDRHIP_EPI_NONE); SDRHIP_ANYD_ATTR(true, SDRHIP_EPI_FM); SDRHIP_ANYD_ATTR(true, SDRHIP_EPI_AM); SDRHIP_ANYD_ATTR(true, SDRHIP_EPI_USB);
       SDRHIP_ANYD_ATTR(false, SDRHIP_EPI_NONE); SDRHIP_ANYD_ATTR(false, SDRHIP_EPI_FM); SDRHIP_ANYD_ATTR(false, SDRHIP_EPI_AM); SDRHIP_ANYD_ATTR(false, SDRHIP_EPI_USB);
+      SDRHIP_ANYD_ATTR(true, HOT_EPI_PARTIAL); SDRHIP_ANYD_ATTR(false, HOT_EPI_PARTIAL);
 #undef SDRHIP_ANYD_ATTR
       attr_set = true;
     }
@@ -1388,6 +1438,7 @@ void hot_launch_anyd_one(bool rot, int epi, const HotLaunch &hl, const HotArgs &
     case SDRHIP_EPI_FM: SDRHIP_ANYD(R_, SDRHIP_EPI_FM); break; \
     case SDRHIP_EPI_AM: SDRHIP_ANYD(R_, SDRHIP_EPI_AM); break; \
     case SDRHIP_EPI_USB: SDRHIP_ANYD(R_, SDRHIP_EPI_USB); break; \
+    case HOT_EPI_PARTIAL: SDRHIP_ANYD(R_, HOT_EPI_PARTIAL); break; \
     default: SDRHIP_ANYD(R_, SDRHIP_EPI_NONE); break; } } while (0)
   if (rot) SDRHIP_ANYD_E(true); else SDRHIP_ANYD_E(false);
 #undef SDRHIP_ANYD_E

@@ -725,6 +725,60 @@ __global__ void iqbb_fm_fixup_kernel(short *__restrict__ out, long out_stride, c
   row[sl * fix_gs] = (short)(row[sl * fix_gs] + philast[(long)c * philast_stride + sl - 1]);
 }
 
+// Decimations above 512 on the hot structure (iqbb_hot.hpp, PART): the hot kernel left, per slice of 512 samples, the sums
+// of its stretches between group boundaries; one lane per group adds the stretches that are its own (a group spans
+// D / 512 slices), the carry of the open group (src/baseband.hh:212-217: the window sum lives across buffers), divides
+// (libstdc++'s wrapping complex division by (D, 0): box_div) and demodulates, with the call-border rules of the other
+// kernels: the stream's sample 0 belongs to group 0, FMDemod's outputs 0 and 1 of a buffer, the states for the next call.
+struct BigdArgs {
+  const int2 *part; int part_stride;
+  int D, base0_rel, N, n_groups, n_out, epi, C;
+  const int2 *acc_old; int2 *acc_new;
+  const short *fm_old; short *fm_new;
+  void *out; long out_stride;
+};
+__global__ __launch_bounds__(256) void iqbb_bigd_finish_kernel(const BigdArgs a) {
+  const int c = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= a.n_groups) return;
+  const int2 *pc = a.part + (long)c * a.part_stride;
+  auto group_sum = [&](int g) {
+    // the group's samples inside the call: [lo, hi) — group 0 takes everything in front of its first boundary
+    const long lo = g == 0 ? 0 : (long)a.base0_rel + (long)g * a.D, hi = min((long)a.base0_rel + (long)(g + 1) * a.D, (long)a.N);
+    int2 s = make_int2(0, 0);
+    if (g == 0) s = a.acc_old[c];
+    for (long sl = lo >> 9; sl <= (hi - 1) >> 9; sl++) {
+      const long x0 = sl << 9;   // the slice's first sample: in group gf, the slice's stretch 0
+      const int gf = x0 < a.base0_rel ? 0 : (int)((x0 - a.base0_rel) / a.D);
+      const int2 v = pc[3 * sl + (g - gf)];
+      s.x = (int)((unsigned)s.x + (unsigned)v.x); s.y = (int)((unsigned)s.y + (unsigned)v.y);
+    }
+    return s;
+  };
+  const int2 s = group_sum(q);
+  const bool emits = q < a.n_out;
+  if (q == a.n_groups - 1) a.acc_new[c] = emits ? make_int2(0, 0) : s;
+  if (!emits) return;
+  const int yr = (short)box_div(s.x, a.D), yi = (short)box_div(s.y, a.D);
+  if (a.epi == SDRHIP_EPI_NONE) {
+    reinterpret_cast<uint32_t *>(a.out)[(long)c * a.out_stride + q] = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
+  } else if (a.epi == SDRHIP_EPI_AM) {
+    reinterpret_cast<short *>(a.out)[(long)c * a.out_stride + q] = am_i16(yr, yi);
+  } else if (a.epi == SDRHIP_EPI_USB) {
+    reinterpret_cast<short *>(a.out)[(long)c * a.out_stride + q] = usb_i16(yr, yi);
+  } else {
+    const int phi = fm_phi(yr, yi);
+    short o;
+    if (q == 0) o = (short)yr;                              // index 0 is never written by FMDemod (in place)
+    else if (q == 1) o = (short)((int)a.fm_old[c] - phi);   // y[0] is never looked at: the previous call's last angle
+    else {                                                  // (the group before: summed again — a group is a handful of loads)
+      const int2 sp = group_sum(q - 1);
+      o = (short)(fm_phi((short)box_div(sp.x, a.D), (short)box_div(sp.y, a.D)) - phi);
+    }
+    reinterpret_cast<short *>(a.out)[(long)c * a.out_stride + q] = o;
+    if (q == a.n_out - 1 && a.n_out >= 2) a.fm_new[c] = (short)phi;
+  }
+}
+
 }  // namespace
 
 namespace {
@@ -778,6 +832,12 @@ struct sdrhip_iqbb_i16 {
   DevBuf<unsigned long long> k1_stamps;   // diagnostic builds: per-wave phase totals of the hot kernel
 #endif
   DevBuf<short> philast;   // any-D hot form with FM: the last angle of every slice (HotArgs::philast)
+  DevBuf<int2> part;       // decimations above 512: three partial box sums per slice of the longest call (HotArgs::part)
+  // Decimations 257 ... 512 run either form: the any-D form's one group per slice uses D of a slice's 512 samples (÷257: half
+  // of the matrix work is thrown away), the large-decimation form all of them plus a 5 us launch — measured crossover at
+  // D = 470 (21 taps, complex<uint8>, FM: ÷257 0.120 -> 0.080 ms per step, ÷300 0.105 -> 0.078, ÷400 0.085 -> 0.077, ÷480 0.075 / 0.076,
+  // ÷512 0.072 / 0.075). SDRHIP_IQBB_BIGD_MIN=n (tests, A/B): exactly the decimations >= n take the large-decimation form.
+  int bigd_min = 257, bigd_skip_lo = 465;   // (default: 257 ... 464 and 513 ...)
 
 
   // (re)loads the tap-dependent device data: packed taps (VALU kernel, the slow first-sample evaluation), the
@@ -931,6 +991,51 @@ struct sdrhip_iqbb_i16 {
   // the call's cold slices (history, carries, the stream's first sample, state for the next call); with FM a second,
   // tiny launch adds the previous slice's last angle to every slice's first output.
   // false: not this plan / call (the general kernel runs it).
+  // Decimations above 512 (bigd_min): the hot kernel's large-decimation form + iqbb_bigd_finish_kernel (iqbb_hot.hpp, PART)
+  bool bigd_plan() const {
+    return path == 3 && use_hot && hot_range >= 0 && S <= 17 && !i8 && !real && D >= bigd_min && D >= 257 && !(D >= bigd_skip_lo && D <= 512) && part.p != nullptr;
+  }
+  bool launch_bigd_call(const IqbbArgs &a0, const Geometry &g, const uint32_t *in_dev, size_t N, size_t in_stride, void *out_dev, size_t out_stride) {
+    const int kind = in_cu8 ? HOT_CU8 : HOT_CS16, halo = hot_halo(S, kind), win = hot_win(S, kind);
+    // the kernel's geometry: slices of 512 samples from the call's first sample on = "decimation 512", one pseudo-group per slice
+    const int nsl = (int)ceil_div(N, (size_t)512), tiles_h = (int)ceil_div((size_t)nsl, (size_t)4);
+    auto slice_hot = [&](int sl) { return slice_is_hot(halo, win, 0, 4, 0, (int)N, nsl, sl >> 2, sl & 3, 512, 1); };
+    int s_lo = 0, s_hi = 4 * tiles_h;
+    while (s_lo < s_hi && !slice_hot(s_lo)) s_lo++;
+    while (s_hi > s_lo && !slice_hot(s_hi - 1)) s_hi--;
+    if (s_hi - s_lo < 16) return false;
+    SDRHIP_REQUIRE(part.n >= (size_t)C * 12 * tiles_h, SDRHIP_E_SIZE, "part holds %zu entries, the call needs %zu", part.n, (size_t)C * 12 * tiles_h);
+    IqbbArgs a = a0;   // (the cold phase walks the PSEUDO groups; the real geometry goes to the finishing kernel)
+    a.base0_rel = 0; a.n_groups = nsl; a.n_out = nsl; a.extra0 = 0; a.D = 512; a.fix_lo = a.fix_hi = 0;
+    HotArgs ha;
+    ha.in = in_dev; ha.in_stride = (long)in_stride; ha.out = out_dev; ha.out_stride = (long)out_stride;
+    ha.tapfrag = tapfrag.p; ha.lut = lut.p; ha.inc = inc; ha.n0_lo = (uint32_t)(n0 - phase0); ha.negative = negative;
+    ha.base0_rel = 0; ha.OG = 4; ha.ovl = 0; ha.t_lo = s_lo >> 2; ha.t_hi = (s_hi + 3) >> 2; ha.cre = cre; ha.cim = cim;
+    ha.N = (int)N; ha.n_out = nsl; ha.C = C; ha.stamps = nullptr;
+    ha.D = 512; ha.GS = 1; ha.tiles_h = tiles_h; ha.lpg_sh = 6; ha.inv_d = 0.f;
+    ha.philast = nullptr; ha.philast_stride = 0;
+    ha.part = part.p; ha.part_stride = 12 * tiles_h; ha.Dreal = D; ha.base_real = g.base0_rel;
+    int cnt = 0;
+    const HotRange *ranges = hot_ranges(S, &cnt);
+    const int NW = ranges[std::min(hot_range, cnt - 1)].NW, vper = NW / 4;
+    const int nvwg = 4 * ctx->prop.multiProcessorCount;
+    int htpw = 4; while (htpw > 1 && (size_t)ceil_div((size_t)tiles_h, (size_t)htpw) * C < 4 * (size_t)nvwg) htpw >>= 1;
+    if (env_tpw) htpw = env_tpw;   // tuning hook
+    ha.tpw = htpw;
+    ha.G = (int)ceil_div((size_t)tiles_h, (size_t)htpw); ha.U = ha.G * C;
+    const int grid = (int)ceil_div((size_t)std::max(1, std::min(nvwg, std::max(ha.U, C))), (size_t)vper);
+    const int gx = grid * vper;
+    ha.dq = gx / ha.G; ha.dr = gx % ha.G;
+    HotLaunch hl{(unsigned)grid, ctx->stream};
+    hot_launch_anyd(S, kind, hot_range, inc != 0, HOT_EPI_PARTIAL, hl, ha, a);
+    BigdArgs f;
+    f.part = part.p; f.part_stride = 12 * tiles_h;
+    f.D = D; f.base0_rel = g.base0_rel; f.N = (int)N; f.n_groups = g.n_groups; f.n_out = g.n_out; f.epi = epi; f.C = C;
+    f.acc_old = a0.acc_old; f.acc_new = a0.acc_new; f.fm_old = a0.fm_old; f.fm_new = a0.fm_new;
+    f.out = out_dev; f.out_stride = (long)out_stride;
+    hipLaunchKernelGGL(iqbb_bigd_finish_kernel, dim3((unsigned)ceil_div((size_t)g.n_groups, (size_t)256), (unsigned)C), dim3(256), 0, ctx->stream, f);
+    return true;
+  }
   // (any-D forms, FM) whole channels as the persistent grid's units: where they deal evenly over the grid
   bool fm_resident_units() const {
     if (env_fm_resident >= 0) return env_fm_resident != 0;   // tuning / test hook (SDRHIP_IQBB_FM_RESIDENT=0|1)
@@ -1043,6 +1148,8 @@ struct sdrhip_iqbb_i16 {
         default: SDRHIP_MFR(9); break;
       }
 #undef SDRHIP_MFR
+    } else if (path == 3 && bigd_plan() && launch_bigd_call(a, g, in_dev, N, in_stride, out_dev, out_stride)) {
+      // (decimations above 512: partial sums by the hot kernel, groups finished by a second, small launch)
     } else if (path == 3 && anyd_plan() && launch_anyd_call(a, g, in_dev, N, in_stride, out_dev, out_stride)) {
       // (the hot kernel's any-D form took the whole call)
     } else if (path == 3) {
@@ -1204,6 +1311,9 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
         const size_t GS = 512 / (size_t)decim, tiles_h = ceil_div(max_in / (size_t)decim + 2, 4 * GS);
         h->philast.alloc((size_t)channels * 4 * tiles_h + 1024);
       }
+      { const char *e = getenv("SDRHIP_IQBB_BIGD_MIN"); if (e) { h->bigd_min = std::max(257, atoi(e)); h->bigd_skip_lo = 513; } }   // tuning / test hook
+      if (h->path == 3 && decim >= 257 && decim >= h->bigd_min)   // (launch_bigd_call: 3 sums per slice of 512 samples)
+        h->part.alloc((size_t)channels * 12 * ceil_div(ceil_div(max_in, (size_t)512), (size_t)4) + 64);
       SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     } catch (...) { delete h; throw; }
     *out = h;
@@ -1264,6 +1374,7 @@ int sdrhip_iqbb_i16_kernel_names(sdrhip_iqbb_i16 *h, char *buf, size_t len) {
     const char *nm = "iqbb_i16_kernel";
     if (h->path == 4 && h->use_hot && h->hot_range >= 0) nm = "iqbb_hot_kernel";   // (calls of < 3 tiles: the general kernel)
     else if (h->path == 4) nm = "bb_real_mfma_kernel";
+    else if (h->path == 3 && h->bigd_plan()) nm = "iqbb_hot_anyd_kernel,iqbb_bigd_finish_kernel";   // (calls of a few tiles: the general kernel)
     else if (h->path == 3 && h->anyd_plan()) {   // (calls of a few tiles: the general kernel "iqbb_i16_mfmag_kernel")
       nm = h->D < 8 ? "iqbb_hot_sd_kernel" : "iqbb_hot_anyd_kernel";
       if (h->epi == SDRHIP_EPI_FM && !h->fm_resident_units()) nm = h->D < 8 ? "iqbb_hot_sd_kernel,iqbb_fm_fixup_kernel" : "iqbb_hot_anyd_kernel,iqbb_fm_fixup_kernel";

@@ -229,6 +229,8 @@ def _hot_fuzz(ctx, orc, rng, order, cu8, decim=8):
     finally:
         del os.environ["SDRHIP_IQBB_FM_RESIDENT"]
     fix = ["iqbb_fm_fixup_kernel"] if epi == sa.EPI_FM and not resident else []
+    if 257 <= decim <= 464 or decim > 512:   # (the large-decimation form: partial box sums + a finishing launch, whatever the demodulator)
+        fix = ["iqbb_bigd_finish_kernel"]
     if cu8:
         node.set_input_format(sa.abi.IN_CU8)
     if decim == 8:
@@ -299,7 +301,7 @@ def test_hot_kernel_any_decimation_random_long_calls(ctx, orc, seed, cu8):
     retuning (also to and from no shift at all), filter swaps and _reconfigure between buffers."""
     rng = np.random.default_rng(23000 + 2 * seed + int(cu8))
     order = int(rng.choice([3, 16, 17, 21, 33, 34, 64, 65, 100, 127, 129]))
-    decim = int(rng.choice([9, 10, 12, 31, 50, 62, 100, 125, 180, 200, 256, 300, 512]))
+    decim = int(rng.choice([9, 10, 12, 31, 50, 62, 100, 125, 180, 200, 256, 300, 512, 257, 464, 465, 513, 700, 1024]))
     _hot_fuzz(ctx, orc, rng, order, cu8, decim)
 
 
@@ -310,7 +312,7 @@ def test_hot_kernel_any_decimation_long_filters_random_long_calls(ctx, orc, seed
     range — a filter swap between buffers moves a plan from one to the other)."""
     rng = np.random.default_rng(31000 + 2 * seed + int(cu8))
     order = int(rng.choice([130, 161, 200, 255, 257]))
-    decim = int(rng.choice([9, 12, 31, 62, 125, 200, 300, 512]))
+    decim = int(rng.choice([9, 12, 31, 62, 125, 200, 300, 512, 640, 1000]))
     _hot_fuzz(ctx, orc, rng, order, cu8, decim)
 
 

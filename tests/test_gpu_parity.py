@@ -146,6 +146,10 @@ ANYD_CASES = [(21, 125, 100e3, True), (16, 62, 100e3, False), (21, 9, -60e3, Fal
               (21, 45, 0.0, True),
               # orders 130 ... 257 (17 K steps): the any-D form in the 8- and 16-wave workgroups of the /8 kernel's long-filter class
               (255, 125, 100e3, True), (200, 20, -60e3, False), (257, 9, 0.0, False), (130, 62, 100e3, False), (161, 300, 0.0, True),
+              # decimations above 512: a group spans slices — the hot kernel leaves partial box sums, iqbb_bigd_finish_kernel finishes the groups
+              # (the library takes decimations up to 1024)
+              (21, 600, 100e3, True), (16, 1000, 0.0, False), (64, 513, -60e3, False), (127, 900, 100e3, True), (21, 1023, 0.0, False),
+              (200, 700, 100e3, False), (33, 777, 41e3, True), (21, 1024, 100e3, False),
               # decimations 2 ... 7: the hot kernel's small-decimation form (a slice holds 73 ... 256 groups: lane l finishes
               # the groups l, l + 64, ... of every slice)
               (21, 2, 100e3, False), (16, 3, -100e3, True), (33, 4, 70e3, False), (64, 5, 100e3, True), (127, 6, -60e3, False), (21, 7, 100e3, True),
@@ -165,6 +169,16 @@ def test_iqbb_any_decimation_long_calls_vs_oracle(ctx, orc, order, decim, Fc, cu
     monkeypatch.setenv("SDRHIP_IQBB_HOT", "1" if hot else "0")
     monkeypatch.setenv("SDRHIP_IQBB_FM_RESIDENT", "1" if hot == "resident" else "0")
     monkeypatch.delenv("SDRHIP_IQBB_PATH", raising=False)
+    monkeypatch.delenv("SDRHIP_IQBB_BIGD_MIN", raising=False)
+    # decimations 257 ... 512 run either of two hot forms (by default the faster one: the large-decimation form below 465):
+    # both are tested — SDRHIP_IQBB_BIGD_MIN=n sends exactly the decimations >= n to the large-decimation form
+    for bigd_min in ([513, 257] if 257 <= decim <= 512 and hot else [None]):
+        if bigd_min is not None:
+            monkeypatch.setenv("SDRHIP_IQBB_BIGD_MIN", str(bigd_min))
+        _any_decimation_case(ctx, orc, order, decim, Fc, cu8, epi, hot, decim > 512 or bigd_min == 257)
+
+
+def _any_decimation_case(ctx, orc, order, decim, Fc, cu8, epi, hot, bigd):
     FSr, C = 1e6, 3
     rng = np.random.default_rng(order * 1000 + decim)
     taps, lut, inc = orc.iqbb_design(abs(Fc), 12.5e3, FSr, order), orc.freqshift_lut_i16(), orc.freqshift_inc(Fc, FSr)
@@ -180,6 +194,8 @@ def test_iqbb_any_decimation_long_calls_vs_oracle(ctx, orc, order, decim, Fc, cu
         assert order > 65 and Fc == 0.0
     else:
         launches = [hot_name] + (["iqbb_fm_fixup_kernel"] if epi == sa.EPI_FM and hot is True else [])
+        if bigd:
+            launches = [hot_name, "iqbb_bigd_finish_kernel"]
         assert node.kernel_names == (launches if hot else ["iqbb_i16_mfmag_kernel"])
     refs = [orc.IQBaseBandI16(taps, lut, inc, Fc < 0, decim) for _ in range(C)]
     fms = [orc.FMDemodI16() for _ in range(C)]
