@@ -11,7 +11,9 @@ declare -A W=( [fm127]="" [fm16]="--order 16" [fm21]="--order 21" [fm64]="--orde
                [sdrfm]="--workload iqbb_fm_cu8 --order 21 --decim 125" [sdrrec]="--workload iqbb_fm_cu8 --order 16 --decim 83 --fc 0"
                [sdrfmchain]="--workload iqbb_fm_cu8 --order 21 --decim 125 --deemph" [wfmchain]="--workload iqbb_fm_cu8 --order 16 --decim 20 --fc 0 --deemph"
                [pocsag]="--workload iqbb_fm_cu8 --order 21 --decim 45 --fc 0" [ssb]="--workload iqbb_usb --order 16 --decim 83 --fc 0"
-               [sd4]="--workload iqbb_fm_cu8 --order 21 --decim 4" [sd7usb]="--workload iqbb_usb --order 21 --decim 7" )   # round 4: the small-decimation form (not in the default list)   # examples/sdr_pocsag.cc:117 / sdr_ax25.cc:117 (21 taps, 1 MS/s to 22.05 kS/s); sdr_rec's USB mode on complex<int16>
+               [sd4]="--workload iqbb_fm_cu8 --order 21 --decim 4" [sd7usb]="--workload iqbb_usb --order 21 --decim 7"
+               [d300]="--workload iqbb_fm_cu8 --order 21 --decim 300" [d1000]="--workload iqbb_fm_cu8 --order 21 --decim 1000"
+               [o255d125]="--workload iqbb_fm_cu8 --order 255 --decim 125" )   # (d300 / d1000: the large-decimation form; o255d125: the any-D form's long-filter class)   # round 4: the small-decimation form (not in the default list)   # examples/sdr_pocsag.cc:117 / sdr_ax25.cc:117 (21 taps, 1 MS/s to 22.05 kS/s); sdr_rec's USB mode on complex<int16>
 #   # ... and the whole chains: + FMDeemph (sdr_fm.cc:44-53; sdr_rec.cc WFM: 16 taps, no shift, 1 MS/s to 50 kS/s)
 #    # the plans of examples/sdr_fm.cc:40 and examples/sdr_rec.cc:42-68 (narrow FM: no shift, 1 MS/s to 12 kS/s)
 NAMES=${@:-fm127 fm16 fm21 fm64 fm255 usb127 cu8 real fir255 fbb fftconv fftbank fmdemod sub8 sdrfm sdrrec sdrfmchain wfmchain pocsag ssb}
