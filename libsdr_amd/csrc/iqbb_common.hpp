@@ -74,6 +74,7 @@ struct HotArgs {
   // sid of channel c leaves the sums of its (at most three) stretches between group boundaries in part[c * part_stride + 3 sid + k]
   int2 *part; int part_stride;
   int Dreal, base_real;                 // the plan's decimation, and the call-relative index its groups are counted from (boundaries: base_real + j Dreal, j >= 1)
+  int fin_groups, fin_out, fin_epi;     // ... whole channels as units: the groups (touched / completed in this call) the workgroup finishes itself as its last step, the plan's demodulator; fin_groups = 0: iqbb_bigd_finish_kernel does
   unsigned long long *stamps;           // diagnostic builds (-DK1_STAMPS) only
 };
 
@@ -163,6 +164,58 @@ __device__ __forceinline__ short am_i16(int re, int im) {
 }
 
 __device__ __forceinline__ short usb_i16(int re, int im) { return (short)((re + im) / 2); }
+
+// Decimations above 256 on the hot structure (iqbb_hot.hpp, PART): the hot kernel left, per slice of 512 samples, the sums
+// of its stretches between group boundaries; one lane per group adds the stretches that are its own (a group spans
+// D / 512 slices), the carry of the open group (src/baseband.hh:212-217: the window sum lives across buffers), divides
+// (libstdc++'s wrapping complex division by (D, 0): box_div) and demodulates, with the call-border rules of the other
+// kernels: the stream's sample 0 belongs to group 0, FMDemod's outputs 0 and 1 of a buffer, the states for the next call.
+struct BigdArgs {
+  const int2 *part; int part_stride;
+  int D, base0_rel, N, n_groups, n_out, epi, C;
+  const int2 *acc_old; int2 *acc_new;
+  const short *fm_old; short *fm_new;
+  void *out; long out_stride;
+};
+__device__ __forceinline__ void bigd_finish_group(const BigdArgs &a, int c, int q) {
+  const int2 *pc = a.part + (long)c * a.part_stride;
+  auto group_sum = [&](int g) {
+    // the group's samples inside the call: [lo, hi) — group 0 takes everything in front of its first boundary
+    const long lo = g == 0 ? 0 : (long)a.base0_rel + (long)g * a.D, hi = min((long)a.base0_rel + (long)(g + 1) * a.D, (long)a.N);
+    int2 s = make_int2(0, 0);
+    if (g == 0) s = a.acc_old[c];
+    for (long sl = lo >> 9; sl <= (hi - 1) >> 9; sl++) {
+      const long x0 = sl << 9;   // the slice's first sample: in group gf, the slice's stretch 0
+      const int gf = x0 < a.base0_rel ? 0 : (int)((x0 - a.base0_rel) / a.D);
+      const int2 v = pc[3 * sl + (g - gf)];
+      s.x = (int)((unsigned)s.x + (unsigned)v.x); s.y = (int)((unsigned)s.y + (unsigned)v.y);
+    }
+    return s;
+  };
+  const int2 s = group_sum(q);
+  const bool emits = q < a.n_out;
+  if (q == a.n_groups - 1) a.acc_new[c] = emits ? make_int2(0, 0) : s;
+  if (!emits) return;
+  const int yr = (short)box_div(s.x, a.D), yi = (short)box_div(s.y, a.D);
+  if (a.epi == SDRHIP_EPI_NONE) {
+    reinterpret_cast<uint32_t *>(a.out)[(long)c * a.out_stride + q] = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
+  } else if (a.epi == SDRHIP_EPI_AM) {
+    reinterpret_cast<short *>(a.out)[(long)c * a.out_stride + q] = am_i16(yr, yi);
+  } else if (a.epi == SDRHIP_EPI_USB) {
+    reinterpret_cast<short *>(a.out)[(long)c * a.out_stride + q] = usb_i16(yr, yi);
+  } else {
+    const int phi = fm_phi(yr, yi);
+    short o;
+    if (q == 0) o = (short)yr;                              // index 0 is never written by FMDemod (in place)
+    else if (q == 1) o = (short)((int)a.fm_old[c] - phi);   // y[0] is never looked at: the previous call's last angle
+    else {                                                  // (the group before: summed again — a group is a handful of loads)
+      const int2 sp = group_sum(q - 1);
+      o = (short)(fm_phi((short)box_div(sp.x, a.D), (short)box_div(sp.y, a.D)) - phi);
+    }
+    reinterpret_cast<short *>(a.out)[(long)c * a.out_stride + q] = o;
+    if (q == a.n_out - 1 && a.n_out >= 2) a.fm_new[c] = (short)phi;
+  }
+}
 
 // one decimation group is complete (or left open at the end of the call): carry, first-sample quirk,
 // truncating division, state

@@ -1347,6 +1347,20 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       }
     }
   }
+  // (PART, whole channels as units) likewise the groups of the large-decimation form: every slice's partial sums of this
+  // workgroup's channels are its own waves' — the finishing launch's work, one lane per group, behind the same barrier
+  if (PART) {
+    if (ac.fin_groups > 0) {   // (kernel-uniform)
+      __syncthreads();
+      BigdArgs f;
+      f.part = ac.part; f.part_stride = ac.part_stride;
+      f.D = ac.Dreal; f.base0_rel = ac.base_real; f.N = ac.N; f.n_groups = ac.fin_groups; f.n_out = ac.fin_out; f.epi = ac.fin_epi; f.C = ac.C;
+      f.acc_old = b.acc_old; f.acc_new = b.acc_new; f.fm_old = b.fm_old; f.fm_new = b.fm_new;
+      f.out = ac.out; f.out_stride = ac.out_stride;
+      for (int cc = bx; cc < ac.C; cc += gx)
+        for (int q = tid & 255; q < f.n_groups; q += 256) bigd_finish_group(f, cc, q);
+    }
+  }
 #ifdef K1_STAMPS
   if (l == 0 && a.stamps) {   // 16 words per wave: 6 phase totals, -, -, slices, HW_ID, first and last realtime stamp
     unsigned long long *o = a.stamps + (size_t)((((unsigned)bx * 4 + wv) & 32767u) * 16);

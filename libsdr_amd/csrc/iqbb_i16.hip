@@ -725,58 +725,12 @@ __global__ void iqbb_fm_fixup_kernel(short *__restrict__ out, long out_stride, c
   row[sl * fix_gs] = (short)(row[sl * fix_gs] + philast[(long)c * philast_stride + sl - 1]);
 }
 
-// Decimations above 512 on the hot structure (iqbb_hot.hpp, PART): the hot kernel left, per slice of 512 samples, the sums
-// of its stretches between group boundaries; one lane per group adds the stretches that are its own (a group spans
-// D / 512 slices), the carry of the open group (src/baseband.hh:212-217: the window sum lives across buffers), divides
-// (libstdc++'s wrapping complex division by (D, 0): box_div) and demodulates, with the call-border rules of the other
-// kernels: the stream's sample 0 belongs to group 0, FMDemod's outputs 0 and 1 of a buffer, the states for the next call.
-struct BigdArgs {
-  const int2 *part; int part_stride;
-  int D, base0_rel, N, n_groups, n_out, epi, C;
-  const int2 *acc_old; int2 *acc_new;
-  const short *fm_old; short *fm_new;
-  void *out; long out_stride;
-};
+// Decimations above 256 on the hot structure (iqbb_hot.hpp, PART), the stand-alone finishing launch: one lane per group
+// (bigd_finish_group, iqbb_common.hpp). Where whole channels are the hot kernel's units it runs the same function as its
+// workgroups' last step instead.
 __global__ __launch_bounds__(256) void iqbb_bigd_finish_kernel(const BigdArgs a) {
-  const int c = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
-  if (q >= a.n_groups) return;
-  const int2 *pc = a.part + (long)c * a.part_stride;
-  auto group_sum = [&](int g) {
-    // the group's samples inside the call: [lo, hi) — group 0 takes everything in front of its first boundary
-    const long lo = g == 0 ? 0 : (long)a.base0_rel + (long)g * a.D, hi = min((long)a.base0_rel + (long)(g + 1) * a.D, (long)a.N);
-    int2 s = make_int2(0, 0);
-    if (g == 0) s = a.acc_old[c];
-    for (long sl = lo >> 9; sl <= (hi - 1) >> 9; sl++) {
-      const long x0 = sl << 9;   // the slice's first sample: in group gf, the slice's stretch 0
-      const int gf = x0 < a.base0_rel ? 0 : (int)((x0 - a.base0_rel) / a.D);
-      const int2 v = pc[3 * sl + (g - gf)];
-      s.x = (int)((unsigned)s.x + (unsigned)v.x); s.y = (int)((unsigned)s.y + (unsigned)v.y);
-    }
-    return s;
-  };
-  const int2 s = group_sum(q);
-  const bool emits = q < a.n_out;
-  if (q == a.n_groups - 1) a.acc_new[c] = emits ? make_int2(0, 0) : s;
-  if (!emits) return;
-  const int yr = (short)box_div(s.x, a.D), yi = (short)box_div(s.y, a.D);
-  if (a.epi == SDRHIP_EPI_NONE) {
-    reinterpret_cast<uint32_t *>(a.out)[(long)c * a.out_stride + q] = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
-  } else if (a.epi == SDRHIP_EPI_AM) {
-    reinterpret_cast<short *>(a.out)[(long)c * a.out_stride + q] = am_i16(yr, yi);
-  } else if (a.epi == SDRHIP_EPI_USB) {
-    reinterpret_cast<short *>(a.out)[(long)c * a.out_stride + q] = usb_i16(yr, yi);
-  } else {
-    const int phi = fm_phi(yr, yi);
-    short o;
-    if (q == 0) o = (short)yr;                              // index 0 is never written by FMDemod (in place)
-    else if (q == 1) o = (short)((int)a.fm_old[c] - phi);   // y[0] is never looked at: the previous call's last angle
-    else {                                                  // (the group before: summed again — a group is a handful of loads)
-      const int2 sp = group_sum(q - 1);
-      o = (short)(fm_phi((short)box_div(sp.x, a.D), (short)box_div(sp.y, a.D)) - phi);
-    }
-    reinterpret_cast<short *>(a.out)[(long)c * a.out_stride + q] = o;
-    if (q == a.n_out - 1 && a.n_out >= 2) a.fm_new[c] = (short)phi;
-  }
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q < a.n_groups) bigd_finish_group(a, (int)blockIdx.y, q);
 }
 
 }  // namespace
@@ -963,7 +917,7 @@ struct sdrhip_iqbb_i16 {
     ha.tapfrag = tapfrag.p; ha.lut = lut.p; ha.inc = inc; ha.n0_lo = (uint32_t)(n0 - phase0); ha.negative = negative;
     ha.base0_rel = g.base0_rel; ha.OG = OG; ha.ovl = ovl; ha.t_lo = 0; ha.t_hi = tiles; ha.cre = cre; ha.cim = cim;
     ha.N = (int)N; ha.n_out = g.n_out; ha.C = C; ha.stamps = nullptr;
-    ha.D = 8; ha.GS = 64; ha.lpg_sh = 0; ha.inv_d = 0.125f; ha.philast = nullptr; ha.philast_stride = 0;   // (the any-D form's fields)
+    ha.D = 8; ha.GS = 64; ha.lpg_sh = 0; ha.inv_d = 0.125f; ha.philast = nullptr; ha.philast_stride = 0; ha.part = nullptr; ha.fin_groups = 0;   // (the any-D form's fields)
 #ifdef K1_STAMPS
     if (!k1_stamps.p) { k1_stamps.alloc(32768 * 16); k1_stamps.zero(ctx->stream); }
     ha.stamps = k1_stamps.p;
@@ -1020,7 +974,12 @@ struct sdrhip_iqbb_i16 {
     const int NW = ranges[std::min(hot_range, cnt - 1)].NW, vper = NW / 4;
     const int nvwg = 4 * ctx->prop.multiProcessorCount;
     int htpw = 4; while (htpw > 1 && (size_t)ceil_div((size_t)tiles_h, (size_t)htpw) * C < 4 * (size_t)nvwg) htpw >>= 1;
-    if (env_tpw) htpw = env_tpw;   // tuning hook
+    // whole channels as units where they deal evenly over the grid (as the FM fix-up of the any-D form): a workgroup then
+    // finishes the groups of its channels itself and the second launch is not needed
+    const bool resident = fm_resident_units();
+    if (resident) htpw = tiles_h;
+    else if (env_tpw) htpw = env_tpw;   // tuning hook
+    ha.fin_groups = resident ? g.n_groups : 0; ha.fin_out = g.n_out; ha.fin_epi = epi;
     ha.tpw = htpw;
     ha.G = (int)ceil_div((size_t)tiles_h, (size_t)htpw); ha.U = ha.G * C;
     const int grid = (int)ceil_div((size_t)std::max(1, std::min(nvwg, std::max(ha.U, C))), (size_t)vper);
@@ -1028,6 +987,7 @@ struct sdrhip_iqbb_i16 {
     ha.dq = gx / ha.G; ha.dr = gx % ha.G;
     HotLaunch hl{(unsigned)grid, ctx->stream};
     hot_launch_anyd(S, kind, hot_range, inc != 0, HOT_EPI_PARTIAL, hl, ha, a);
+    if (resident) return true;
     BigdArgs f;
     f.part = part.p; f.part_stride = 12 * tiles_h;
     f.D = D; f.base0_rel = g.base0_rel; f.N = (int)N; f.n_groups = g.n_groups; f.n_out = g.n_out; f.epi = epi; f.C = C;
@@ -1070,7 +1030,7 @@ struct sdrhip_iqbb_i16 {
     ha.D = D; ha.GS = GS; ha.tiles_h = tiles_h;
     { int lpg = 1; while (2 * lpg <= 64 && 2 * lpg * GS <= 64) lpg *= 2; int sh = 0; while ((1 << sh) < lpg) sh++; ha.lpg_sh = sh; }
     ha.inv_d = (float)((1.0 / D) * (1.0 - 1.0 / 1048576.0));
-    ha.philast = nullptr; ha.philast_stride = 4 * tiles_h;
+    ha.philast = nullptr; ha.philast_stride = 4 * tiles_h; ha.part = nullptr; ha.fin_groups = 0;
     if (epi == SDRHIP_EPI_FM) {   // (sized at create for max_in: no allocation, i.e. no device-wide synchronisation, on the call path)
       SDRHIP_REQUIRE(philast.n >= (size_t)C * 4 * tiles_h, SDRHIP_E_SIZE, "philast holds %zu entries, the call needs %zu", philast.n, (size_t)C * 4 * tiles_h);
       ha.philast = philast.p;
@@ -1374,7 +1334,7 @@ int sdrhip_iqbb_i16_kernel_names(sdrhip_iqbb_i16 *h, char *buf, size_t len) {
     const char *nm = "iqbb_i16_kernel";
     if (h->path == 4 && h->use_hot && h->hot_range >= 0) nm = "iqbb_hot_kernel";   // (calls of < 3 tiles: the general kernel)
     else if (h->path == 4) nm = "bb_real_mfma_kernel";
-    else if (h->path == 3 && h->bigd_plan()) nm = "iqbb_hot_anyd_kernel,iqbb_bigd_finish_kernel";   // (calls of a few tiles: the general kernel)
+    else if (h->path == 3 && h->bigd_plan()) nm = h->fm_resident_units() ? "iqbb_hot_anyd_kernel" : "iqbb_hot_anyd_kernel,iqbb_bigd_finish_kernel";   // (calls of a few tiles: the general kernel)
     else if (h->path == 3 && h->anyd_plan()) {   // (calls of a few tiles: the general kernel "iqbb_i16_mfmag_kernel")
       nm = h->D < 8 ? "iqbb_hot_sd_kernel" : "iqbb_hot_anyd_kernel";
       if (h->epi == SDRHIP_EPI_FM && !h->fm_resident_units()) nm = h->D < 8 ? "iqbb_hot_sd_kernel,iqbb_fm_fixup_kernel" : "iqbb_hot_anyd_kernel,iqbb_fm_fixup_kernel";

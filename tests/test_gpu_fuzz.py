@@ -230,7 +230,7 @@ def _hot_fuzz(ctx, orc, rng, order, cu8, decim=8):
         del os.environ["SDRHIP_IQBB_FM_RESIDENT"]
     fix = ["iqbb_fm_fixup_kernel"] if epi == sa.EPI_FM and not resident else []
     if 257 <= decim <= 464 or decim > 512:   # (the large-decimation form: partial box sums + a finishing launch, whatever the demodulator)
-        fix = ["iqbb_bigd_finish_kernel"]
+        fix = [] if resident else ["iqbb_bigd_finish_kernel"]
     if cu8:
         node.set_input_format(sa.abi.IN_CU8)
     if decim == 8:

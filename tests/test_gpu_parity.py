@@ -175,10 +175,15 @@ def test_iqbb_any_decimation_long_calls_vs_oracle(ctx, orc, order, decim, Fc, cu
     for bigd_min in ([513, 257] if 257 <= decim <= 512 and hot else [None]):
         if bigd_min is not None:
             monkeypatch.setenv("SDRHIP_IQBB_BIGD_MIN", str(bigd_min))
-        _any_decimation_case(ctx, orc, order, decim, Fc, cu8, epi, hot, decim > 512 or bigd_min == 257)
+        bigd = decim > 512 or bigd_min == 257
+        # (whole channels as units: the large-decimation form then finishes its groups inside the hot kernel, whatever the
+        # demodulator — both ways for every epilogue)
+        for resident in ([False, True] if bigd and hot is True else [hot == "resident"]):
+            monkeypatch.setenv("SDRHIP_IQBB_FM_RESIDENT", "1" if resident else "0")
+            _any_decimation_case(ctx, orc, order, decim, Fc, cu8, epi, hot, bigd, resident)
 
 
-def _any_decimation_case(ctx, orc, order, decim, Fc, cu8, epi, hot, bigd):
+def _any_decimation_case(ctx, orc, order, decim, Fc, cu8, epi, hot, bigd, resident):
     FSr, C = 1e6, 3
     rng = np.random.default_rng(order * 1000 + decim)
     taps, lut, inc = orc.iqbb_design(abs(Fc), 12.5e3, FSr, order), orc.freqshift_lut_i16(), orc.freqshift_inc(Fc, FSr)
@@ -193,9 +198,9 @@ def _any_decimation_case(ctx, orc, order, decim, Fc, cu8, epi, hot, bigd):
         # WITHOUT a shift — two arrays of 18-bit values — do not, and run the general kernel)
         assert order > 65 and Fc == 0.0
     else:
-        launches = [hot_name] + (["iqbb_fm_fixup_kernel"] if epi == sa.EPI_FM and hot is True else [])
+        launches = [hot_name] + (["iqbb_fm_fixup_kernel"] if epi == sa.EPI_FM and not resident else [])
         if bigd:
-            launches = [hot_name, "iqbb_bigd_finish_kernel"]
+            launches = [hot_name] + ([] if resident else ["iqbb_bigd_finish_kernel"])
         assert node.kernel_names == (launches if hot else ["iqbb_i16_mfmag_kernel"])
     refs = [orc.IQBaseBandI16(taps, lut, inc, Fc < 0, decim) for _ in range(C)]
     fms = [orc.FMDemodI16() for _ in range(C)]
