@@ -792,6 +792,7 @@ struct sdrhip_iqbb_i16 {
   // D = 470 (21 taps, complex<uint8>, FM: ÷257 0.120 -> 0.080 ms per step, ÷300 0.105 -> 0.078, ÷400 0.085 -> 0.077, ÷480 0.075 / 0.076,
   // ÷512 0.072 / 0.075). SDRHIP_IQBB_BIGD_MIN=n (tests, A/B): exactly the decimations >= n take the large-decimation form.
   int bigd_min = 257, bigd_skip_lo = 465;   // (default: 257 ... 464 and 513 ...)
+  bool bigd_always = false;                 // every call, however short, through the large-decimation form (its cold path serves any slice)
 
 
   // (re)loads the tap-dependent device data: packed taps (VALU kernel, the slow first-sample evaluation), the
@@ -957,7 +958,7 @@ struct sdrhip_iqbb_i16 {
     int s_lo = 0, s_hi = 4 * tiles_h;
     while (s_lo < s_hi && !slice_hot(s_lo)) s_lo++;
     while (s_hi > s_lo && !slice_hot(s_hi - 1)) s_hi--;
-    if (s_hi - s_lo < 16) return false;
+    if (s_hi - s_lo < 16 && !bigd_always) return false;   // (short calls: the general kernel, where the plan has one)
     SDRHIP_REQUIRE(part.n >= (size_t)C * 12 * tiles_h, SDRHIP_E_SIZE, "part holds %zu entries, the call needs %zu", part.n, (size_t)C * 12 * tiles_h);
     IqbbArgs a = a0;   // (the cold phase walks the PSEUDO groups; the real geometry goes to the finishing kernel)
     a.base0_rel = 0; a.n_groups = nsl; a.n_out = nsl; a.extra0 = 0; a.D = 512; a.fix_lo = a.fix_hi = 0;
@@ -1187,8 +1188,13 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
     SDRHIP_REQUIRE(max_in >= 1 && max_in < (size_t(1) << 30), SDRHIP_E_SIZE, "max_in %zu outside [1,2^30)", max_in);
     SDRHIP_REQUIRE(epilogue >= SDRHIP_EPI_NONE && epilogue <= SDRHIP_EPI_USB, SDRHIP_E_INVALID, "bad epilogue %d", epilogue);
     const int ovl = epilogue == SDRHIP_EPI_FM ? 1 : 0;
-    const int CG = TI / decim;
-    SDRHIP_REQUIRE(CG - ovl >= 1, SDRHIP_E_UNSUPPORTED, "decim %d too large (max %d)", decim, TI / (1 + ovl));
+    // Decimations beyond the general kernels' tile (TI / (1 + ovl): 2048, with FM 1024) exist as the hot kernel's large-
+    // decimation form only, which then takes every call, however short (its cold path serves any slice): complex<int16> /
+    // complex<uint8> input, up to 257 taps whose high bytes fit int8, up to 32768 (D * D must not wrap: box_div).
+    const bool beyond = TI / decim - ovl < 1;
+    const int CG = beyond ? 1 + ovl : TI / decim;   // (beyond: a placeholder — no general kernel ever runs such a plan)
+    SDRHIP_REQUIRE(!beyond || (!real && !i8 && order <= 257 && decim <= 32768), SDRHIP_E_UNSUPPORTED,
+                   "decim %d too large (max %d; complex<int16> / complex<uint8> plans of up to 257 taps: 32768)", decim, TI / (1 + ovl));
     for (int i = 0; i < 2 * order; i++) {
       if (real) SDRHIP_REQUIRE(taps[i] > -(1 << 23) && taps[i] < (1 << 23), SDRHIP_E_UNSUPPORTED,
                                "tap %d = %d exceeds 24 bits", i / 2, taps[i]);
@@ -1217,11 +1223,15 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
       if (force && !strcmp(force, "valu")) mfma_ok = false;
       h->path = mfma_ok ? 1 : 0;
       // path 3: the same matrix part for any decimation (measured ahead of the VALU kernel at every order tried, 9 ... 257 taps)
-      bool mfmag_ok = !real && !i8 && decim != R && order <= 257 && TI / decim - ovl >= 1;
+      bool mfmag_ok = !real && !i8 && decim != R && order <= 257;
       for (int i = 0; i < 2 * order && mfmag_ok; i++)
         if (high_byte(taps[i]) > 127 || high_byte(-taps[i]) > 127) mfmag_ok = false;
       if (force && !strcmp(force, "valu")) mfmag_ok = false;
       if (h->path == 0 && mfmag_ok) h->path = 3;
+      SDRHIP_REQUIRE(!beyond || (h->path == 3 && h->use_hot), SDRHIP_E_UNSUPPORTED,
+                     "decim %d too large (max %d) for this plan: beyond it only the hot kernel's large-decimation form exists (tap high bytes within int8, SDRHIP_IQBB_HOT / SDRHIP_IQBB_PATH unset)",
+                     decim, TI / (1 + ovl));
+      h->bigd_always = beyond;
       // path 4: real input on the matrix cores — D == 8, at most 9 K steps, taps that fit two byte planes
       if (real && !i8 && decim == R && order <= 273 && !(force && !strcmp(force, "valu"))) {
         bool fits = true;
@@ -1272,6 +1282,7 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
         h->philast.alloc((size_t)channels * 4 * tiles_h + 1024);
       }
       { const char *e = getenv("SDRHIP_IQBB_BIGD_MIN"); if (e) { h->bigd_min = std::max(257, atoi(e)); h->bigd_skip_lo = 513; } }   // tuning / test hook
+      { const char *e = getenv("SDRHIP_IQBB_BIGD_ALWAYS"); if (e && atoi(e) != 0 && decim >= 257) { h->bigd_always = true; h->bigd_skip_lo = 513; } }   // test hook: short calls too
       if (h->path == 3 && decim >= 257 && decim >= h->bigd_min)   // (launch_bigd_call: 3 sums per slice of 512 samples)
         h->part.alloc((size_t)channels * 12 * ceil_div(ceil_div(max_in, (size_t)512), (size_t)4) + 64);
       SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));

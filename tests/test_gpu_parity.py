@@ -147,7 +147,9 @@ ANYD_CASES = [(21, 125, 100e3, True), (16, 62, 100e3, False), (21, 9, -60e3, Fal
               # orders 130 ... 257 (17 K steps): the any-D form in the 8- and 16-wave workgroups of the /8 kernel's long-filter class
               (255, 125, 100e3, True), (200, 20, -60e3, False), (257, 9, 0.0, False), (130, 62, 100e3, False), (161, 300, 0.0, True),
               # decimations above 512: a group spans slices — the hot kernel leaves partial box sums, iqbb_bigd_finish_kernel finishes the groups
-              # (the library takes decimations up to 1024)
+              # (up to 2048, with FM 1024, a plan has a general kernel for its short calls; beyond — up to 32768 — the large-
+              # decimation form serves every call, and a plan without the hot kernel does not exist)
+              (21, 2048, 100e3, True), (16, 5000, 0.0, False), (64, 30000, -60e3, False), (200, 1025, 41e3, True),
               (21, 600, 100e3, True), (16, 1000, 0.0, False), (64, 513, -60e3, False), (127, 900, 100e3, True), (21, 1023, 0.0, False),
               (200, 700, 100e3, False), (33, 777, 41e3, True), (21, 1024, 100e3, False),
               # decimations 2 ... 7: the hot kernel's small-decimation form (a slice holds 73 ... 256 groups: lane l finishes
@@ -188,6 +190,11 @@ def _any_decimation_case(ctx, orc, order, decim, Fc, cu8, epi, hot, bigd, reside
     rng = np.random.default_rng(order * 1000 + decim)
     taps, lut, inc = orc.iqbb_design(abs(Fc), 12.5e3, FSr, order), orc.freqshift_lut_i16(), orc.freqshift_inc(Fc, FSr)
     assert (inc == 0) == (Fc == 0.0)
+    if not hot and decim > (1024 if epi == sa.EPI_FM else 2048):   # (no general kernel for such a plan: the hot kernel or nothing)
+        with pytest.raises(sa.abi.SdrHipError) as e:
+            sa.IQBaseBandI16(ctx, taps, lut, inc, Fc < 0, decim, channels=C, max_in=70000, epilogue=epi)
+        assert e.value.code == sa.abi.E_UNSUPPORTED and "too large" in str(e.value)
+        return
     node = sa.IQBaseBandI16(ctx, taps, lut, inc, Fc < 0, decim, channels=C, max_in=70000, epilogue=epi)
     if cu8:
         node.set_input_format(sa.abi.IN_CU8)
