@@ -1667,7 +1667,7 @@ def test_error_codes(ctx, golden):
         sa.IQBaseBandI16(ctx, taps, lut, 1365, 0, 0)
     assert e.value.code == sa.abi.E_INVALID
     with pytest.raises(sa.SdrHipError) as e:
-        sa.IQBaseBandI16(ctx, taps, lut, 1365, 0, 5000)
+        sa.IQBaseBandI16(ctx, taps, lut, 1365, 0, 40000)   # (beyond 32768: D * D wraps in the box average's division)
     assert e.value.code == sa.abi.E_UNSUPPORTED
     node = sa.IQBaseBandI16(ctx, taps, lut, 1365, 0, 8, max_in=128)
     with pytest.raises(sa.SdrHipError) as e:
