@@ -152,8 +152,8 @@ int sdrhip_iqbb_i16_path(sdrhip_iqbb_i16 *h, int *path);
  * without a shift, 21 taps / 125 with one; examples/sdr_rec.cc:42-68, examples/sdr_fm.cc:40) run "iqbb_hot_anyd_kernel" on long calls — the same persistent
  * structure, cold slices included (with FM the slices' first outputs are completed at the end of that kernel where the
  * channels deal evenly over its grid, else by a second, tiny launch "iqbb_fm_fixup_kernel"); decimations 2 ... 7 run
- * "iqbb_hot_sd_kernel" (the small-decimation form: a slice's 73 ... 256 groups summed out of an LDS array; up to 129 taps,
- * and plans of 9 K steps without a shift do not fit its LDS); decimations 257 ... 464 and 513 ... 32768 run the same hot
+ * "iqbb_hot_sd_kernel" (the small-decimation form: a slice's 73 ... 256 groups summed out of an LDS array; in workgroups
+ * of 4, 8 or 16 waves by what fits beside the tap fragments); decimations 257 ... 464 and 513 ... 32768 run the same hot
  * kernel emitting partial box sums per 512-sample slice + "iqbb_bigd_finish_kernel" (a group spans slices; beyond 2048,
  * with FM 1024, there is no general kernel: every call takes that form, and plans the hot kernel cannot serve — real or
  * int8 input, SDRHIP_IQBB_HOT=0 — are SDRHIP_E_UNSUPPORTED); other path 3 plans and short calls the general kernel "iqbb_i16_mfmag_kernel".

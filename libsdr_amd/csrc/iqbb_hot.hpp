@@ -69,8 +69,15 @@ constexpr int hot_anyd_extra(int, int, bool = true, int NW = 4) { return NW * 51
 
 // the small-decimation form (2 <= D <= 7, SD): the wave's 512 rotated samples go through a 2 KB per-wave LDS array (the
 // slice's own window buffer when that is large enough; two arrays without a shift: the unrotated values have 18 bits)
-constexpr int hot_sd_extra(int S, int in, bool rot) { return (hot_bufb(S, in) >= 2048 ? 0 : 4 * 2048) + (rot ? 0 : 4 * 2048); }
-constexpr bool hot_sd_fits(int S, int NH, int in, bool rot) { return hot_lds_bytes(S, NH, in, 4, false) + hot_sd_extra(S, in, rot) <= hot_lds_cap(4); }
+constexpr int hot_sd_extra(int S, int in, bool rot, int NW = 4) { return (hot_bufb(S, in) >= 2048 ? 0 : NW * 2048) + (rot ? 0 : NW * 2048); }
+constexpr bool hot_sd_fits(int S, int NH, int in, bool rot, int NW = 4) { return hot_lds_bytes(S, NH, in, NW, false) + hot_sd_extra(S, in, rot, NW) <= hot_lds_cap(NW); }
+// ... and the workgroup it runs in: the class's own size (HotRange::NW) or, where the arrays do not fit beside the tap
+// fragments (9 K steps without a shift; 17 K steps without one), the next one that shares a copy of the fragments among
+// twice the waves — 0: none fits
+constexpr int hot_sd_nw(int S, int NH, int in, bool rot, int nw0) {
+  for (int nw = nw0; nw <= 16; nw *= 2) if (hot_sd_fits(S, NH, in, rot, nw)) return nw;
+  return 0;
+}
 
 struct HotRange { int S0, NH, NW; };
 // per S: centred high-plane ranges, narrowest first; the last one covers every step
@@ -105,8 +112,10 @@ void hot_launch_anyd9(int in, int range, bool rot, int epi, const HotLaunch &, c
 void hot_launch_anyd17_cs16(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);   // (orders 130 ... 257: 8- and 16-wave workgroups, as the /8 kernel's)
 void hot_launch_anyd17_cu8(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
 // decimations 2 ... 7 (S = 2, 3, 5 or 9, cs16 / cu8); false: this plan's LDS does not fit (the general kernel runs it)
-bool hot_launch_sd(int S, int in, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &, bool dry_run);
-bool hot_launch_sd9(int in, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &, bool dry_run);
+int hot_launch_sd(int S, int in, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &, bool dry_run);   // (returns the waves per workgroup, 0: no form fits)
+int hot_launch_sd9(int in, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &, bool dry_run);
+int hot_launch_sd17_cs16(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &, bool dry_run);
+int hot_launch_sd17_cu8(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &, bool dry_run);
 
 }  // namespace sdrhip
 
@@ -169,7 +178,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
 #endif
   static_assert(!SD || DG, "the small-decimation form is a variant of the any-D form");
   static_assert(!DG || !REAL, "any-D form: complex plans");
-  static_assert(!SD || NW == 4, "small-decimation form: 4-wave workgroups");
+
   const int DD = DG ? a.D : 8, GS = DG ? a.GS : 64;   // decimation, whole groups per slice
   static_assert(S >= 2 && S0 >= 0 && NH >= 1 && S0 + NH <= S, "high-plane range inside the K loop");
   static_assert(!REAL || NW == 4, "real input: 4-wave workgroups");
@@ -183,7 +192,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   static_assert(NDMA <= 3, "immediate offsets 0 / 1024 / 2048");
   constexpr bool PAIR = hot_pair(IN, NW, DG);
   constexpr bool WIDE = SD ? false : hot_wide(S, NH, IN, NW, DG ? hot_anyd_extra(S, IN, ROT, NW) : 0, PAIR);   // (SD: the narrow table, the LDS goes to the sample arrays)
-  static_assert(!SD || hot_sd_fits(S, NH, IN, ROT), "small-decimation form: LDS budget");
+  static_assert(!SD || hot_sd_fits(S, NH, IN, ROT, NW), "small-decimation form: LDS budget");
   constexpr int NBUF = PAIR ? 4 : 2;   // window buffers per wave
   static_assert(hot_lds_bytes(S, NH, IN, NW, WIDE, PAIR) <= hot_lds_cap(NW, PAIR), "LDS budget for 4 waves per SIMD");
   constexpr int TBLW = WIDE ? 1024 : 256;   // dwords
@@ -1384,28 +1393,32 @@ __global__ __launch_bounds__(64 * NW, K1_MINWAVES) void iqbb_hot_anyd_kernel(con
   iqbb_hot_body<S, S0, NH, ROT, EPI, IN, NW, true>(a, b);
 }
 
-template <int S, int S0, int NH, bool ROT, int EPI, int IN>
-__global__ __launch_bounds__(256, K1_MINWAVES) void iqbb_hot_sd_kernel(const HotArgs a, const IqbbArgs b) {
-  iqbb_hot_body<S, S0, NH, ROT, EPI, IN, 4, true, true>(a, b);
+template <int S, int S0, int NH, bool ROT, int EPI, int IN, int NW = 4>
+__global__ __launch_bounds__(64 * NW, K1_MINWAVES) void iqbb_hot_sd_kernel(const HotArgs a, const IqbbArgs b) {
+  iqbb_hot_body<S, S0, NH, ROT, EPI, IN, NW, true, true>(a, b);
 }
 
-// false: the plan's LDS does not fit four workgroups per CU (nothing launched); dry_run: only answer
-template <int S, int S0, int NH, int IN>
-bool hot_launch_sd_one(bool rot, int epi, const HotLaunch &hl, const HotArgs &ha, const IqbbArgs &b, bool dry_run) {
-  const dim3 grid(hl.grid, 1), block(256);
-#define SDRHIP_SD(R_, E_) hipLaunchKernelGGL((iqbb_hot_sd_kernel<S, S0, NH, R_, E_, IN>), grid, block, lds, hl.stream, ha, b)
-#define SDRHIP_SD_E(R_) do { if (dry_run) return true; \
-    const size_t lds = (size_t)hot_lds_bytes(S, NH, IN, 4, false) + hot_sd_extra(S, IN, R_); \
+// returns the waves per workgroup the plan runs in (hot_sd_nw; the host sizes the grid by it) — 0: its LDS fits none (nothing
+// launched); dry_run: only answer
+template <int S, int S0, int NH, int IN, int NW0 = 4>
+int hot_launch_sd_one(bool rot, int epi, const HotLaunch &hl, const HotArgs &ha, const IqbbArgs &b, bool dry_run) {
+  const dim3 grid(hl.grid, 1);
+#define SDRHIP_SD(R_, E_) hipLaunchKernelGGL((iqbb_hot_sd_kernel<S, S0, NH, R_, E_, IN, NWX>), grid, dim3(64 * NWX), lds, hl.stream, ha, b)
+#define SDRHIP_SD_ATTR(R_, E_) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&iqbb_hot_sd_kernel<S, S0, NH, R_, E_, IN, NWX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+#define SDRHIP_SD_E(R_) do { if (dry_run) return NWX; \
+    const size_t lds = (size_t)hot_lds_bytes(S, NH, IN, NWX, false) + hot_sd_extra(S, IN, R_, NWX); \
+    if (lds > 64 * 1024) { static bool attr_set = false; if (!attr_set) { SDRHIP_SD_ATTR(R_, SDRHIP_EPI_FM); SDRHIP_SD_ATTR(R_, SDRHIP_EPI_AM); SDRHIP_SD_ATTR(R_, SDRHIP_EPI_USB); SDRHIP_SD_ATTR(R_, SDRHIP_EPI_NONE); attr_set = true; } } \
     switch (epi) { \
     case SDRHIP_EPI_FM: SDRHIP_SD(R_, SDRHIP_EPI_FM); break; \
     case SDRHIP_EPI_AM: SDRHIP_SD(R_, SDRHIP_EPI_AM); break; \
     case SDRHIP_EPI_USB: SDRHIP_SD(R_, SDRHIP_EPI_USB); break; \
-    default: SDRHIP_SD(R_, SDRHIP_EPI_NONE); break; } return true; } while (0)
-  if (rot) { if constexpr (hot_sd_fits(S, NH, IN, true)) SDRHIP_SD_E(true); }
-  else { if constexpr (hot_sd_fits(S, NH, IN, false)) SDRHIP_SD_E(false); }
+    default: SDRHIP_SD(R_, SDRHIP_EPI_NONE); break; } return NWX; } while (0)
+  if (rot) { constexpr int NWX = hot_sd_nw(S, NH, IN, true, NW0); if constexpr (NWX > 0) SDRHIP_SD_E(true); }
+  else { constexpr int NWX = hot_sd_nw(S, NH, IN, false, NW0); if constexpr (NWX > 0) SDRHIP_SD_E(false); }
 #undef SDRHIP_SD_E
+#undef SDRHIP_SD_ATTR
 #undef SDRHIP_SD
-  return false;
+  return 0;
 }
 
 template <int S, int S0, int NH, int IN, int NW>

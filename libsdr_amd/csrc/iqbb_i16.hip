@@ -1006,9 +1006,8 @@ struct sdrhip_iqbb_i16 {
   bool anyd_plan() const {
     if (!(path == 3 && use_hot && hot_range >= 0 && S <= 17 && !i8 && !real)) return false;
     if (D >= 9 && D <= 512) return true;
-    if (S > 9) return false;   // (the small-decimation form: 4-wave workgroups, orders up to 129)
-    // decimations 2 ... 7: the small-decimation form, where its sample arrays fit the workgroup's LDS (iqbb_hot.hpp, SD)
-    return D >= 2 && D <= 7 && hot_launch_sd(S, in_cu8 ? HOT_CU8 : HOT_CS16, hot_range, inc != 0, epi, HotLaunch{0, nullptr}, HotArgs{}, IqbbArgs{}, true);
+    // decimations 2 ... 7: the small-decimation form, where its sample arrays fit a workgroup's LDS (iqbb_hot.hpp, SD, hot_sd_nw)
+    return D >= 2 && D <= 7 && hot_launch_sd(S, in_cu8 ? HOT_CU8 : HOT_CS16, hot_range, inc != 0, epi, HotLaunch{0, nullptr}, HotArgs{}, IqbbArgs{}, true) != 0;
   }
   bool launch_anyd_call(IqbbArgs &a, const Geometry &g, const uint32_t *in_dev, size_t N, size_t in_stride, void *out_dev,
                         size_t out_stride) {
@@ -1043,7 +1042,9 @@ struct sdrhip_iqbb_i16 {
     // (17 K steps: 8- or 16-wave workgroups = 2 or 4 virtual ones sharing the tap fragments, as the /8 kernel of that class)
     int cnt = 0;
     const HotRange *ranges = hot_ranges(S, &cnt);
-    const int NW = ranges[std::min(hot_range, cnt - 1)].NW, vper = NW / 4;
+    int NW = ranges[std::min(hot_range, cnt - 1)].NW;
+    if (D < 8) NW = hot_launch_sd(S, kind, hot_range, inc != 0, epi, HotLaunch{0, nullptr}, HotArgs{}, IqbbArgs{}, true);   // (the small-decimation form picks its own: hot_sd_nw)
+    const int vper = NW / 4;
     const int nvwg = 4 * ctx->prop.multiProcessorCount;
     int htpw = 4; while (htpw > 1 && (size_t)ceil_div((size_t)tiles_h, (size_t)htpw) * C < 4 * (size_t)nvwg) htpw >>= 1;
     // FM: the slices whose first output is neither out[0] nor out[1] (their own rules) and is emitted lack the angle of the

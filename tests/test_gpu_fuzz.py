@@ -235,9 +235,8 @@ def _hot_fuzz(ctx, orc, rng, order, cu8, decim=8):
         node.set_input_format(sa.abi.IN_CU8)
     if decim == 8:
         assert node.kernel_names == ["iqbb_hot_kernel"]
-    elif decim < 8:   # (9 K steps without a shift do not fit the small-decimation form's LDS: the general kernel)
-        assert node.path == 3 and node.kernel_names[0] in ("iqbb_hot_sd_kernel", "iqbb_i16_mfmag_kernel")
-        assert node.kernel_names == ["iqbb_hot_sd_kernel"] + fix or (order > 65 and inc == 0)
+    elif decim < 8:   # (17 K steps whose taps need every high plane, WITHOUT a shift: two sample arrays beside 34 KB of tap fragments fit no workgroup — the general kernel)
+        assert node.path == 3 and (node.kernel_names == ["iqbb_hot_sd_kernel"] + fix or (order > 129 and inc == 0 and node.kernel_names == ["iqbb_i16_mfmag_kernel"]))
     else:
         assert node.path == 3 and node.kernel_names == ["iqbb_hot_anyd_kernel"] + fix
     refs = [orc.IQBaseBandI16(taps, lut, inc, Fc < 0, decim) for _ in range(C)]
@@ -323,8 +322,8 @@ def test_hot_kernel_small_decimation_random_long_calls(ctx, orc, seed, cu8):
     sub_sample, src/baseband.hh:159-162): random plans, ragged long and short calls, retuning (also to and from no shift
     at all: the two forms differ in their LDS arrays), filter swaps and _reconfigure between buffers."""
     rng = np.random.default_rng(29000 + 2 * seed + int(cu8))
-    order = int(rng.choice([3, 16, 17, 21, 33, 34, 64, 65, 100, 127, 129]))
-    decim = int(rng.choice([2, 3, 4, 5, 6, 7]))
+    order = int(rng.choice([3, 16, 17, 21, 33, 34, 64, 65, 100, 127, 129, 130, 200, 257]))
+    decim = int(rng.choice([2, 3, 4, 5, 6, 7] if order <= 129 else [6, 7]))   # (17 K steps below 6: no matrix plan, the vector kernel)
     _hot_fuzz(ctx, orc, rng, order, cu8, decim)
 
 

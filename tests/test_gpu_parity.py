@@ -155,7 +155,11 @@ ANYD_CASES = [(21, 125, 100e3, True), (16, 62, 100e3, False), (21, 9, -60e3, Fal
               # decimations 2 ... 7: the hot kernel's small-decimation form (a slice holds 73 ... 256 groups: lane l finishes
               # the groups l, l + 64, ... of every slice)
               (21, 2, 100e3, False), (16, 3, -100e3, True), (33, 4, 70e3, False), (64, 5, 100e3, True), (127, 6, -60e3, False), (21, 7, 100e3, True),
-              (129, 2, 30e3, True), (16, 4, 0.0, False), (21, 7, 0.0, True), (65, 3, 0.0, False), (127, 5, 0.0, True)]   # (no shift: examples/sdr_rec.cc:42-58 tunes every mode to the centre; 21 taps / 45: examples/sdr_pocsag.cc:117 and sdr_ax25.cc:117 behind a 1 MS/s RTL source)
+              (129, 2, 30e3, True), (16, 4, 0.0, False), (21, 7, 0.0, True), (65, 3, 0.0, False), (127, 5, 0.0, True),
+              # ... in 8- and 16-wave workgroups: 17 K steps (orders 130 ... 257), and 9 K steps without a shift (127 / 5 above)
+              # (17 K steps at decimations 2 ... 5 have no matrix plan at all — the general kernel's tile does not fit the LDS
+              # with them — and stay on the vector kernel)
+              (255, 6, 100e3, True), (200, 7, 0.0, False), (130, 7, -60e3, False), (257, 6, 0.0, True), (100, 6, 0.0, False), (129, 2, 0.0, True)]   # (no shift: examples/sdr_rec.cc:42-58 tunes every mode to the centre; 21 taps / 45: examples/sdr_pocsag.cc:117 and sdr_ax25.cc:117 behind a 1 MS/s RTL source)
 
 
 @pytest.mark.parametrize("epi,hot", [(e, h) for e in (sa.EPI_NONE, sa.EPI_FM, sa.EPI_AM, sa.EPI_USB) for h in (True, False)] + [(sa.EPI_FM, "resident")])
@@ -200,15 +204,13 @@ def _any_decimation_case(ctx, orc, order, decim, Fc, cu8, epi, hot, bigd, reside
         node.set_input_format(sa.abi.IN_CU8)
     assert node.path == 3
     hot_name = "iqbb_hot_sd_kernel" if decim < 8 else "iqbb_hot_anyd_kernel"
-    if hot and decim < 8 and node.kernel_names == ["iqbb_i16_mfmag_kernel"]:
-        # (the small-decimation form's sample arrays must fit the workgroup's LDS beside the tap fragments: 9 K steps
-        # WITHOUT a shift — two arrays of 18-bit values — do not, and run the general kernel)
-        assert order > 65 and Fc == 0.0
-    else:
-        launches = [hot_name] + (["iqbb_fm_fixup_kernel"] if epi == sa.EPI_FM and not resident else [])
-        if bigd:
-            launches = [hot_name] + ([] if resident else ["iqbb_bigd_finish_kernel"])
-        assert node.kernel_names == (launches if hot else ["iqbb_i16_mfmag_kernel"])
+    # (the small-decimation form's sample arrays must fit a workgroup's LDS beside the tap fragments: where they do not
+    # in the class's own workgroup — 9 or 17 K steps WITHOUT a shift: two arrays of 18-bit values — the plan runs in one of
+    # twice the waves sharing the fragments; every plan of up to 257 taps has a hot form)
+    launches = [hot_name] + (["iqbb_fm_fixup_kernel"] if epi == sa.EPI_FM and not resident else [])
+    if bigd:
+        launches = [hot_name] + ([] if resident else ["iqbb_bigd_finish_kernel"])
+    assert node.kernel_names == (launches if hot else ["iqbb_i16_mfmag_kernel"])
     refs = [orc.IQBaseBandI16(taps, lut, inc, Fc < 0, decim) for _ in range(C)]
     fms = [orc.FMDemodI16() for _ in range(C)]
     for n in (65536, 70000, 12345, 1, 40001, 2 * decim + 1, 65536):
