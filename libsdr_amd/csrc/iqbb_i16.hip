@@ -792,6 +792,7 @@ struct sdrhip_iqbb_i16 {
   // D = 470 (21 taps, complex<uint8>, FM: ÷257 0.120 -> 0.080 ms per step, ÷300 0.105 -> 0.078, ÷400 0.085 -> 0.077, ÷480 0.075 / 0.076,
   // ÷512 0.072 / 0.075). SDRHIP_IQBB_BIGD_MIN=n (tests, A/B): exactly the decimations >= n take the large-decimation form.
   int bigd_min = 257, bigd_skip_lo = 465;   // (default: 257 ... 464 and 513 ...)
+  bool mfmag_attr_set = false;              // the general any-D kernel's dynamic-LDS limit raised (plans beyond 64 KB)
   bool bigd_always = false;                 // every call, however short, through the large-decimation form (its cold path serves any slice)
 
 
@@ -1123,6 +1124,12 @@ struct sdrhip_iqbb_i16 {
                              else if (in_cu8) hipLaunchKernelGGL((iqbb_i16_mfmag_kernel<S_, false, true>), grid3, block, lds_bytes, ctx->stream, a); \
                              else if (inc != 0) hipLaunchKernelGGL((iqbb_i16_mfmag_kernel<S_, true, false>), grid3, block, lds_bytes, ctx->stream, a); \
                              else hipLaunchKernelGGL((iqbb_i16_mfmag_kernel<S_, false, false>), grid3, block, lds_bytes, ctx->stream, a); } while (0)
+      if (lds_bytes > 64 * 1024 && !mfmag_attr_set) {   // (17 K steps, small decimations: once per plan)
+#define SDRHIP_MFG_ATTR(R_, C_) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&iqbb_i16_mfmag_kernel<17, R_, C_>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)
+        SDRHIP_MFG_ATTR(true, true); SDRHIP_MFG_ATTR(false, true); SDRHIP_MFG_ATTR(true, false); SDRHIP_MFG_ATTR(false, false);
+#undef SDRHIP_MFG_ATTR
+        mfmag_attr_set = true;
+      }
       switch (S) {
         case 2: SDRHIP_MFG(2); break;
         case 3: SDRHIP_MFG(3); break;
@@ -1257,7 +1264,9 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
       } else if (h->path == 3) {
         const size_t PLW = (2 * (size_t)(TI + h->OP) + 64 + 31) / 32 * 8;
         h->lds_bytes = (2 * PLW + 256) * 4 + (size_t)h->S * 2 * 64 * 16 + (size_t)(TI + TI / 16 + 2) * 8 + 2 * (size_t)((CG + 3) & ~3) * 4;
-        if (h->lds_bytes > 64 * 1024) {   // (decimation 1 with 17 K steps): back to the VALU kernel
+        // (17 K steps at decimations up to 5 need 65 ... 79 KB: two workgroups per CU of gfx950's 160 KB — the launch raises the
+        // kernel's dynamic-LDS limit; beyond that: back to the VALU kernel)
+        if (h->lds_bytes > 80 * 1024) {
           h->path = 0; h->OP = (int)ceil_div((size_t)order, (size_t)TAPC) * TAPC; h->HH = h->OP;
           const size_t XS = TI + h->OP + 8;
           h->lds_bytes = (XS + 256 + 2 * ((CG + 3) & ~3)) * 4 + (h->fast8 ? 0 : (size_t)TI * 8);
@@ -1269,7 +1278,7 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
         const size_t XS = TI + h->OP + 8;
         h->lds_bytes = (XS + 256 + 2 * ((CG + 3) & ~3)) * 4 + (h->fast8 ? 0 : (size_t)TI * 8);
       }
-      SDRHIP_REQUIRE(h->lds_bytes <= 64 * 1024, SDRHIP_E_UNSUPPORTED, "LDS budget exceeded (%zu B)", h->lds_bytes);
+      SDRHIP_REQUIRE(h->lds_bytes <= (h->path == 3 ? 80 : 64) * 1024, SDRHIP_E_UNSUPPORTED, "LDS budget exceeded (%zu B)", h->lds_bytes);
       h->load_taps(taps);
       h->lut.alloc(128); h->lut.upload(reinterpret_cast<const int2 *>(lut), 128, ctx->stream);
       for (int p = 0; p < 2; p++) {
