@@ -978,7 +978,7 @@ struct sdrhip_iqbb_i16 {
     int htpw = 4; while (htpw > 1 && (size_t)ceil_div((size_t)tiles_h, (size_t)htpw) * C < 4 * (size_t)nvwg) htpw >>= 1;
     // whole channels as units where they deal evenly over the grid (as the FM fix-up of the any-D form): a workgroup then
     // finishes the groups of its channels itself and the second launch is not needed
-    const bool resident = fm_resident_units();
+    const bool resident = channel_units();
     if (resident) htpw = tiles_h;
     else if (env_tpw) htpw = env_tpw;   // tuning hook
     ha.fin_groups = resident ? g.n_groups : 0; ha.fin_out = g.n_out; ha.fin_epi = epi;
@@ -998,8 +998,9 @@ struct sdrhip_iqbb_i16 {
     hipLaunchKernelGGL(iqbb_bigd_finish_kernel, dim3((unsigned)ceil_div((size_t)g.n_groups, (size_t)256), (unsigned)C), dim3(256), 0, ctx->stream, f);
     return true;
   }
-  // (any-D forms, FM) whole channels as the persistent grid's units: where they deal evenly over the grid
-  bool fm_resident_units() const {
+  // whole channels as the persistent grid's units (any-D forms with FM: the slices' first angle differences, large-decimation
+  // form: the groups, finished inside the hot kernel instead of by a second launch): where they deal evenly over the grid
+  bool channel_units() const {
     if (env_fm_resident >= 0) return env_fm_resident != 0;   // tuning / test hook (SDRHIP_IQBB_FM_RESIDENT=0|1)
     const size_t nvwg = 4 * (size_t)ctx->prop.multiProcessorCount, rounds = ceil_div((size_t)C, nvwg);
     return (size_t)C * 100 >= rounds * nvwg * 97;
@@ -1053,7 +1054,7 @@ struct sdrhip_iqbb_i16 {
     // workgroups) a unit is a channel — one workgroup then finishes every slice of a channel and completes those outputs
     // itself, behind a barrier at its end; otherwise (few channels: units of 4 tiles keep the grid full) a second launch does.
     const int fix_lo = GS == 1 ? 2 : 1, fix_hi = epi == SDRHIP_EPI_FM ? (int)ceil_div((size_t)g.n_out, (size_t)GS) : 0;
-    const bool resident = fix_hi > fix_lo && fm_resident_units();
+    const bool resident = fix_hi > fix_lo && channel_units();
     if (resident) htpw = tiles_h;
     else if (env_tpw) htpw = env_tpw;   // tuning hook
     a.fix_lo = resident ? fix_lo : 0; a.fix_hi = resident ? fix_hi : 0;
@@ -1355,10 +1356,10 @@ int sdrhip_iqbb_i16_kernel_names(sdrhip_iqbb_i16 *h, char *buf, size_t len) {
     const char *nm = "iqbb_i16_kernel";
     if (h->path == 4 && h->use_hot && h->hot_range >= 0) nm = "iqbb_hot_kernel";   // (calls of < 3 tiles: the general kernel)
     else if (h->path == 4) nm = "bb_real_mfma_kernel";
-    else if (h->path == 3 && h->bigd_plan()) nm = h->fm_resident_units() ? "iqbb_hot_anyd_kernel" : "iqbb_hot_anyd_kernel,iqbb_bigd_finish_kernel";   // (calls of a few tiles: the general kernel)
+    else if (h->path == 3 && h->bigd_plan()) nm = h->channel_units() ? "iqbb_hot_anyd_kernel" : "iqbb_hot_anyd_kernel,iqbb_bigd_finish_kernel";   // (calls of a few tiles: the general kernel)
     else if (h->path == 3 && h->anyd_plan()) {   // (calls of a few tiles: the general kernel "iqbb_i16_mfmag_kernel")
       nm = h->D < 8 ? "iqbb_hot_sd_kernel" : "iqbb_hot_anyd_kernel";
-      if (h->epi == SDRHIP_EPI_FM && !h->fm_resident_units()) nm = h->D < 8 ? "iqbb_hot_sd_kernel,iqbb_fm_fixup_kernel" : "iqbb_hot_anyd_kernel,iqbb_fm_fixup_kernel";
+      if (h->epi == SDRHIP_EPI_FM && !h->channel_units()) nm = h->D < 8 ? "iqbb_hot_sd_kernel,iqbb_fm_fixup_kernel" : "iqbb_hot_anyd_kernel,iqbb_fm_fixup_kernel";
     }
     else if (h->path == 3) nm = "iqbb_i16_mfmag_kernel";
     else if (h->path == 1 && h->use_hot && h->hot_range >= 0) nm = "iqbb_hot_kernel";   // (calls of < 3 tiles: the general kernel)
