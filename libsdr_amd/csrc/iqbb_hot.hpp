@@ -25,6 +25,15 @@
 //     wave w computes slice w of tile 0 and of the tiles from bt_hi on where that slice is cold — window by clamped
 //     ordinary loads (history / input / zeros), the same LDS-resident tap fragments and table, the general epilogue
 //     (group_sum<EDGE> + group_finish: edge masks, carry, first-sample quirk, state) — and rolls the FIR history.
+//
+// Forms of the same body (template flags; windows, K loop, grid and cold phase are shared):
+//   D = 8             iqbb_hot_kernel       lane (n, h) owns one group of a slice; FM recomputes one overlap group per slice
+//   D = 9 ... 512     iqbb_hot_anyd_kernel  DG: a slice holds 512 / D whole groups, summed out of in-register prefix sums and
+//                                           parked; FM's first angle difference of a slice completed afterwards (in the
+//                                           kernel's last step where whole channels are its units, else by a tiny launch)
+//   D = 2 ... 7       iqbb_hot_sd_kernel    SD: 73 ... 256 groups per slice out of an LDS array, finished per slice
+//   D = 257 ... 32768 iqbb_hot_anyd_kernel  PART: slices of 512 samples whatever the groups; a slice leaves the sums of its
+//                                           stretches between group boundaries, one lane per group finishes (same choice)
 #pragma once
 #include "iqbb_common.hpp"
 
@@ -111,7 +120,7 @@ void hot_launch_anyd(int S, int in, int range, bool rot, int epi, const HotLaunc
 void hot_launch_anyd9(int in, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
 void hot_launch_anyd17_cs16(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);   // (orders 130 ... 257: 8- and 16-wave workgroups, as the /8 kernel's)
 void hot_launch_anyd17_cu8(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
-// decimations 2 ... 7 (S = 2, 3, 5 or 9, cs16 / cu8); false: this plan's LDS does not fit (the general kernel runs it)
+// decimations 2 ... 7 (S = 2, 3, 5, 9 or 17, cs16 / cu8): returns the waves per workgroup the plan runs in — 0: its LDS fits none (the general kernel runs it)
 int hot_launch_sd(int S, int in, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &, bool dry_run);   // (returns the waves per workgroup, 0: no form fits)
 int hot_launch_sd9(int in, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &, bool dry_run);
 int hot_launch_sd17_cs16(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &, bool dry_run);
