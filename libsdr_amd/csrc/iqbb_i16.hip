@@ -786,7 +786,7 @@ struct sdrhip_iqbb_i16 {
   DevBuf<unsigned long long> k1_stamps;   // diagnostic builds: per-wave phase totals of the hot kernel
 #endif
   DevBuf<short> philast;   // any-D hot form with FM: the last angle of every slice (HotArgs::philast)
-  DevBuf<int2> part;       // decimations above 512: three partial box sums per slice of the longest call (HotArgs::part)
+  DevBuf<int2> part;       // decimations above 256: three partial box sums per slice of the longest call (HotArgs::part)
   // Decimations 257 ... 512 run either form: the any-D form's one group per slice uses D of a slice's 512 samples (÷257: half
   // of the matrix work is thrown away), the large-decimation form all of them plus a 5 us launch — measured crossover at
   // D = 470 (21 taps, complex<uint8>, FM: ÷257 0.120 -> 0.080 ms per step, ÷300 0.105 -> 0.078, ÷400 0.085 -> 0.077, ÷480 0.075 / 0.076,
@@ -947,7 +947,7 @@ struct sdrhip_iqbb_i16 {
   // the call's cold slices (history, carries, the stream's first sample, state for the next call); with FM a second,
   // tiny launch adds the previous slice's last angle to every slice's first output.
   // false: not this plan / call (the general kernel runs it).
-  // Decimations above 512 (bigd_min): the hot kernel's large-decimation form + iqbb_bigd_finish_kernel (iqbb_hot.hpp, PART)
+  // Decimations from 257 on (bigd_min, bigd_skip_lo): the hot kernel's large-decimation form + iqbb_bigd_finish_kernel (iqbb_hot.hpp, PART)
   bool bigd_plan() const {
     return path == 3 && use_hot && hot_range >= 0 && S <= 17 && !i8 && !real && D >= bigd_min && D >= 257 && !(D >= bigd_skip_lo && D <= 512) && part.p != nullptr;
   }
@@ -1113,7 +1113,7 @@ struct sdrhip_iqbb_i16 {
       }
 #undef SDRHIP_MFR
     } else if (path == 3 && bigd_plan() && launch_bigd_call(a, g, in_dev, N, in_stride, out_dev, out_stride)) {
-      // (decimations above 512: partial sums by the hot kernel, groups finished by a second, small launch)
+      // (decimations above 256: partial sums by the hot kernel, groups finished in its last step or by a second, small launch)
     } else if (path == 3 && anyd_plan() && launch_anyd_call(a, g, in_dev, N, in_stride, out_dev, out_stride)) {
       // (the hot kernel's any-D form took the whole call)
     } else if (path == 3) {
@@ -1294,6 +1294,7 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
       }
       { const char *e = getenv("SDRHIP_IQBB_BIGD_MIN"); if (e) { h->bigd_min = std::max(257, atoi(e)); h->bigd_skip_lo = 513; } }   // tuning / test hook
       { const char *e = getenv("SDRHIP_IQBB_BIGD_ALWAYS"); if (e && atoi(e) != 0 && decim >= 257) { h->bigd_always = true; h->bigd_skip_lo = 513; } }   // test hook: short calls too
+      if (beyond) { h->bigd_min = 257; h->bigd_skip_lo = 513; }   // (such a plan has no other kernel, whatever the hooks say)
       if (h->path == 3 && decim >= 257 && decim >= h->bigd_min)   // (launch_bigd_call: 3 sums per slice of 512 samples)
         h->part.alloc((size_t)channels * 12 * ceil_div(ceil_div(max_in, (size_t)512), (size_t)4) + 64);
       SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
