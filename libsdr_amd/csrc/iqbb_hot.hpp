@@ -1416,7 +1416,7 @@ int hot_launch_sd_one(bool rot, int epi, const HotLaunch &hl, const HotArgs &ha,
 #define SDRHIP_SD_ATTR(R_, E_) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&iqbb_hot_sd_kernel<S, S0, NH, R_, E_, IN, NWX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
 #define SDRHIP_SD_E(R_) do { if (dry_run) return NWX; \
     const size_t lds = (size_t)hot_lds_bytes(S, NH, IN, NWX, false) + hot_sd_extra(S, IN, R_, NWX); \
-    if (lds > 64 * 1024) { static bool attr_set = false; if (!attr_set) { SDRHIP_SD_ATTR(R_, SDRHIP_EPI_FM); SDRHIP_SD_ATTR(R_, SDRHIP_EPI_AM); SDRHIP_SD_ATTR(R_, SDRHIP_EPI_USB); SDRHIP_SD_ATTR(R_, SDRHIP_EPI_NONE); attr_set = true; } } \
+    if (lds > 64 * 1024) { static const bool attr_set = [&] { SDRHIP_SD_ATTR(R_, SDRHIP_EPI_FM); SDRHIP_SD_ATTR(R_, SDRHIP_EPI_AM); SDRHIP_SD_ATTR(R_, SDRHIP_EPI_USB); SDRHIP_SD_ATTR(R_, SDRHIP_EPI_NONE); return true; }(); (void)attr_set; } \
     switch (epi) { \
     case SDRHIP_EPI_FM: SDRHIP_SD(R_, SDRHIP_EPI_FM); break; \
     case SDRHIP_EPI_AM: SDRHIP_SD(R_, SDRHIP_EPI_AM); break; \
@@ -1457,16 +1457,16 @@ void hot_launch_anyd_one(bool rot, int epi, const HotLaunch &hl, const HotArgs &
   const int extra = hot_anyd_extra(S, IN, rot, NW);
   const size_t lds = (size_t)hot_lds_bytes(S, NH, IN, NW, hot_wide(S, NH, IN, NW, extra)) + extra;
   static_assert(hot_lds_bytes(S, NH, IN, NW, false) + hot_anyd_extra(S, IN, false, NW) <= 163840, "any-D form: a workgroup's LDS");
-  if (NW > 4) {   // (beyond 64 KB of dynamic LDS: once per process and kernel)
-    static bool attr_set = false;
-    if (!attr_set) {
+  if (NW > 4) {   // (beyond 64 KB of dynamic LDS: once per process and kernel — a function-local static's initialiser is thread-safe)
+    static const bool attr_set = [] {
 #define SDRHIP_ANYD_ATTR(R_, E_) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&iqbb_hot_anyd_kernel<S, S0, NH, R_, E_, IN, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, hot_lds_cap(NW) + hot_anyd_extra(S, IN, false, NW) > 163840 ? 163840 : hot_lds_cap(NW) + hot_anyd_extra(S, IN, false, NW))
       SDRHIP_ANYD_ATTR(true, SDRHIP_EPI_NONE); SDRHIP_ANYD_ATTR(true, SDRHIP_EPI_FM); SDRHIP_ANYD_ATTR(true, SDRHIP_EPI_AM); SDRHIP_ANYD_ATTR(true, SDRHIP_EPI_USB);
       SDRHIP_ANYD_ATTR(false, SDRHIP_EPI_NONE); SDRHIP_ANYD_ATTR(false, SDRHIP_EPI_FM); SDRHIP_ANYD_ATTR(false, SDRHIP_EPI_AM); SDRHIP_ANYD_ATTR(false, SDRHIP_EPI_USB);
       SDRHIP_ANYD_ATTR(true, HOT_EPI_PARTIAL); SDRHIP_ANYD_ATTR(false, HOT_EPI_PARTIAL);
 #undef SDRHIP_ANYD_ATTR
-      attr_set = true;
-    }
+      return true;
+    }();
+    (void)attr_set;
   }
   const dim3 grid(hl.grid, 1), block(64 * NW);
 #define SDRHIP_ANYD(R_, E_) hipLaunchKernelGGL((iqbb_hot_anyd_kernel<S, S0, NH, R_, E_, IN, NW>), grid, block, lds, hl.stream, ha, b)
