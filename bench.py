@@ -56,6 +56,8 @@ def parse():
     p.add_argument("--fc", type=float, default=100e3, help="iqbb_* workloads: centre and filter frequency in Hz (0: no frequency shift, as examples/sdr_rec.cc tunes)")
     p.add_argument("--deemph", action="store_true", help="iqbb_fm* workloads: FMDeemph<int16> behind the demodulator (examples/sdr_fm.cc:44-53), alpha from the output rate")
     p.add_argument("--order", type=int, default=127, help="iqbb_* workloads: FIR order (127 = the BASELINE configs)")
+    p.add_argument("--fs", type=float, default=FS, help="iqbb_* workloads: input sample rate the filter is designed for")
+    p.add_argument("--width", type=float, default=50e3, help="iqbb_* workloads: filter width in Hz")
     p.add_argument("--batches", type=int, default=3, help="distinct input batches rotated through (defeats the 256 MiB L3)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for single-GPU dry runs)")
@@ -64,7 +66,16 @@ def parse():
     p.add_argument("--no-gather", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     p.add_argument("--sustain-seconds", type=float, default=2.0,
-                   help="after the timed steps: this many seconds of back-to-back launches for the sustained-clock figure (0 = skip)")
+                   help="BEFORE the warm-up and the timed steps: this many seconds of back-to-back launches, so that the timed region "
+                        "starts at the clock the chip holds under this load; also the sustained figure (0 = skip)")
+    p.add_argument("--no-configs", action="store_true",
+                   help="default one-GPU run: do not append the other BASELINE configs (2, 3, 4 i/ii, 5 at G=1, the sdr_fm plan) as \"configs\"")
+    p.add_argument("--configs-max-channels", type=int, default=0, help="tests: cap the channel count of every entry of \"configs\"")
+    p.add_argument("--config-sustain-seconds", type=float, default=0.4, help="pre-conditioning per entry of \"configs\"")
+    p.add_argument("--config-cpu-seconds", type=float, default=2.5, help="CPU-baseline sample per entry of \"configs\"")
+    p.add_argument("--comm", default="torch", choices=["torch", "sdrhip"],
+                   help="sdrhip: ONE process drives --gpus N rank contexts through the C ABI's sdrhip_comm_* (RCCL opened by the library; "
+                        "ranks that share a device use its same-device transport)")
     p.add_argument("--no-verify", action="store_true", help="skip the oracle check of the last timed step's output")
     p.add_argument("--verify-channels", type=int, default=32)
     p.add_argument("--fft-whole-blocks", action="store_true",
@@ -75,10 +86,35 @@ def parse():
     return p.parse_args()
 
 
+def count_gpus_sysfs():
+    """HIP devices of this node WITHOUT touching HIP or torch: KFD topology nodes that have SIMDs (CPUs have none).
+    None if the topology is not readable (the ranks then report a shortage themselves)."""
+    import glob
+    n, seen = 0, False
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            for line in open(f):
+                if line.startswith("simd_count"):
+                    seen = True
+                    n += int(line.split()[1]) > 0
+        except (OSError, ValueError):
+            pass
+    if seen:
+        return n
+    try:   # no readable topology: ask a short-lived child (this parent still never loads torch or HIP)
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
+        return int(r.stdout.strip().splitlines()[-1])
+    except Exception as e:
+        sys.stderr.write("bench.py: could not count devices (%s)\n" % e)
+        return None
+
+
 def spawn_ranks(a):
     """`python bench.py --gpus N` outside torchrun: start the N ranks as a CHILD `torch.distributed.run`
-    (one process per GPU, rendezvous on 127.0.0.1) and hand back its exit code. This runs before torch or
-    HIP is touched in this process, and it is a child process, never an exec."""
+    (one process per GPU, rendezvous on 127.0.0.1) and hand back its exit code. Neither torch nor HIP is touched in this
+    process, and it is a child process, never an exec. The child's stdout is passed through line by line; if it ends
+    with a non-zero code and no JSON line was seen (a rank other than 0 died first, or the RCCL watchdog aborted the
+    ranks), this parent prints the one error line the contract asks for."""
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -88,7 +124,16 @@ def spawn_ranks(a):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    return subprocess.call(cmd, env=env, cwd=ROOT)
+    child = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True, bufsize=1)
+    saw_json = False
+    for line in child.stdout:
+        saw_json = saw_json or line.lstrip().startswith("{")
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    rc = child.wait()
+    if rc != 0 and not saw_json:
+        print(error_line(a, "the %d ranks exited with code %d before rank 0 printed its line (see stderr)" % (a.gpus, rc)), flush=True)
+    return rc
 
 
 def synth_cs16(torch, C, N, dev, seed, chan0=0):
@@ -128,45 +173,112 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(workload, target_s):
+def cpu_limits():
+    """What the box lets this process use: CPUs in the affinity mask, and the cgroup CPU quota if there is one
+    (cgroup v2 cpu.max "quota period", or v1 cfs_quota_us / cfs_period_us) as a number of cores."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = os.cpu_count() or 1
+    quota, src = None, None
+    try:
+        t = open("/sys/fs/cgroup/cpu.max").read().split()
+        src = "cgroup v2 cpu.max = %s" % " ".join(t)
+        if t and t[0] != "max":
+            quota = float(t[0]) / float(t[1])
+    except (OSError, ValueError, IndexError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            pr = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            src = "cgroup v1 cfs_quota_us / cfs_period_us = %d / %d" % (q, pr)
+            if q > 0:
+                quota = q / float(pr)
+        except (OSError, ValueError):
+            pass
+    return {"cpus_online": os.cpu_count(), "cpus_in_affinity_mask": aff, "cgroup_quota_cores": quota, "cgroup_source": src}
+
+
+def _throttled():
+    try:
+        for line in open("/sys/fs/cgroup/cpu.stat"):
+            if line.startswith("nr_throttled"):
+                return int(line.split()[1])
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+CPU_CHAINS = {"iqbb_fm": "iqbb_fm", "iqbb_usb": "iqbb_usb", "fir255_fm": "fir255_fm", "fir127_fm": "fir127_fm",
+              "fbb_f32": "fir_cf32_sub8", "fftconv": "fir_cf32_4097", "iqbb_fm_cu8/sdr_fm": "sdr_fm_cu8"}
+CPU_CHAIN_NOTE = {"fir_cf32_sub8": "FIRLowPass<cf32>(127) -> SubSample(8): the reference has no float frequency-shift node (SURVEY fact 6)",
+                  "fir_cf32_4097": "FIRLowPass<cf32>(4097 taps), the time-domain filter config 4 (ii) is set against (the reference's FFT filter needs FFTW3, absent here)",
+                  "sdr_fm_cu8": "examples/sdr_fm.cc's plan: cu8 -> AutoCast -> IQBaseBand<int16>(21 taps, 1 MS/s -> 8 kS/s) -> FMDemod"}
+
+
+def cpu_baseline(workload, target_s, all_cores=True, chain=None):
     """Reference CPU path on this box: the compiled, unmodified reference if oracle/_ref travelled here,
     else the oracle port. One thread = the reference's real execution model (one Queue worker)."""
-    chain = {"iqbb_fm": "iqbb_fm", "iqbb_usb": "iqbb_usb", "fir255_fm": "fir255_fm", "fir127_fm": "fir127_fm",
-             "fbb_f32": "fir_cf32_sub8"}.get(workload)
+    chain = chain or CPU_CHAINS.get(workload)
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
     cores_avail = os.cpu_count()
+    nsamp = 16384 if chain == "fir_cf32_4097" else 65536   # (4097 fp64 taps per sample: a 65536 buffer alone is seconds)
     if chain and os.path.exists(ref):
         try:
-            probe = json.loads(subprocess.run([ref, "bench", chain, "8"], capture_output=True, text=True, timeout=120).stdout)
-            nbuf = max(8, int(target_s * probe["msps"] * 1e6 / 65536))
-            r = json.loads(subprocess.run([ref, "bench", chain, str(nbuf)], capture_output=True, text=True, timeout=600).stdout)
+            probe = json.loads(subprocess.run([ref, "bench", chain, "1" if nsamp < 65536 else "8", str(nsamp)], capture_output=True, text=True, timeout=120).stdout)
+            nbuf = max(1 if nsamp < 65536 else 8, int(target_s * probe["msps"] * 1e6 / nsamp))
+            r = json.loads(subprocess.run([ref, "bench", chain, str(nbuf), str(nsamp)], capture_output=True, text=True, timeout=600).stdout)
             res = {"value": round(r["msps"], 4), "unit": "Msamples/s", "cores": 1, "kind": "reference",
-                   "sample": "%d buffers x 65536 cs16 samples, 1 channel, chain %s (reference nodes compiled -O3, "
-                             "%.1f s)" % (nbuf, chain, r["seconds"]), "host_cores_available": cores_avail, "cpu_model": cpu_model()}
-            # SURVEY §8d (ii): one channel (= one reference graph) per host core, all cores at once, ~5 s
+                   "sample": "%d buffers x %d samples, 1 channel, chain %s (reference nodes compiled -O3, "
+                             "%.1f s)" % (nbuf, nsamp, chain, r["seconds"]), "host_cores_available": cores_avail, "cpu_model": cpu_model()}
+            if chain in CPU_CHAIN_NOTE:
+                res["chain"] = CPU_CHAIN_NOTE[chain]
+            if not all_cores:
+                return res
+            # SURVEY §8d (ii): one channel (= one reference graph) per host core the box lets us use, all at once, ~3 s
             try:
-                try:
-                    ncore = len(os.sched_getaffinity(0))
-                except AttributeError:
-                    ncore = cores_avail or 1
-                ncore = max(1, min(ncore, 32))   # (the GPU boxes expose 256 CPUs under a much smaller CPU quota)
-                nb = max(8, int(3.0 * probe["msps"] * 1e6 / 65536))
+                lim = cpu_limits()
+                ncore = lim["cpus_in_affinity_mask"]
+                if lim["cgroup_quota_cores"]:
+                    ncore = min(ncore, max(1, int(lim["cgroup_quota_cores"] + 0.5)))
+                ncore = max(1, min(ncore, 256))
+                nb = max(8, int(3.0 * probe["msps"] * 1e6 / nsamp))
+                th0 = _throttled()
                 t0 = time.perf_counter()
-                procs = [subprocess.Popen([ref, "bench", chain, str(nb)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+                procs = [subprocess.Popen([ref, "bench", chain, str(nb), str(nsamp)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
                          for _ in range(ncore)]
                 outs = [pr.communicate(timeout=600)[0] for pr in procs]
                 wall = time.perf_counter() - t0
-                done = sum(json.loads(o)["samples"] for o in outs if o.strip())
+                rows = [json.loads(o) for o in outs if o.strip()]
+                done = sum(x["samples"] for x in rows)
+                th1 = _throttled()
                 res["all_cores"] = {"value": round(done / wall / 1e6, 2), "unit": "Msamples/s", "cores": ncore,
-                                    "sample": "%d independent reference graphs (processes) x %d buffers, wall %.1f s" % (ncore, nb, wall)}
+                                    "per_process_msps": round(sum(x["msps"] for x in rows) / max(1, len(rows)), 3),
+                                    "sample": "%d independent reference graphs (processes) x %d buffers, wall %.1f s" % (ncore, nb, wall),
+                                    "limits": lim, "cgroup_throttled_periods": (th1 - th0) if th0 is not None and th1 is not None else None}
             except Exception as e:
                 res["all_cores"] = {"error": str(e)[:80]}
             return res
         except Exception as e:   # fall through to the port
             sys.stderr.write("cpu_baseline: reference binary failed (%s), using the port\n" % e)
+    from oracle import pyoracle as orc   # bench.py's cpu_baseline leg may use the oracle
+    if workload == "fftconv_ola":
+        # the reference's FilterSink/FilterSource need FFTW3 (not in /root/reference, not installed): the oracle's restatement
+        # of the same overlap-add blocks (its own double-precision radix-2 transform) is what can be timed here
+        import numpy as np
+        f = orc.FFTFilter(orc.fftfilt_design_K(orc.fftfilt_design_h(8192, 50e3, 150e3, FS)))
+        x = (np.random.default_rng(1).standard_normal((8192, 2)) * 0.3).astype(np.float32)
+        f.process(x)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < target_s:
+            f.process(x)
+            n += 1
+        sec = time.perf_counter() - t0
+        return {"value": round(n * 8192 / sec / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "port",
+                "sample": "%d blocks x 8192 cf32 samples, 1 channel, the oracle's FilterSink -> FilterSource restatement (16384-point "
+                          "double-precision radix-2 transforms; the reference's own needs FFTW3), %.1f s" % (n, sec),
+                "host_cores_available": cores_avail, "cpu_model": cpu_model()}
     if workload not in ("iqbb_fm",):
         return None
-    from oracle import pyoracle as orc   # bench.py's cpu_baseline leg may use the oracle
     taps = orc.iqbb_design(100e3, 50e3, FS, 127)
     lut = orc.freqshift_lut_i16()
     x = orc.IQSigGen(FS, [(100e3, 8000, 0.0), (-300e3, 6000, 0.3)]).next_cs16(65536)
@@ -309,10 +421,10 @@ def build_workload(a, wl, sa, torch, shard, ctx, dev, rank, nbuf_out):
     order, D = a.order, a.decim
     cs16 = lambda: [synth_cs16(torch, C, N, dev, 1234 + b, chan0=rank * C) for b in range(a.batches)]
     if wl in ("iqbb_fm", "iqbb_usb", "iqbb_fm_cu8"):
-        taps = torch.from_numpy(sa.design_iqbb_taps(a.fc, 50e3, FS, order)).to(dev)
+        taps = torch.from_numpy(sa.design_iqbb_taps(a.fc, a.width, a.fs, order)).to(dev)
         lut = torch.from_numpy(sa.design_freqshift_lut_i16()).to(dev)
         shard.broadcast_design([taps, lut], src=0)
-        taps_h, lut_h, inc = taps.cpu().numpy(), lut.cpu().numpy(), sa.design_freqshift_inc(a.fc, FS)
+        taps_h, lut_h, inc = taps.cpu().numpy(), lut.cpu().numpy(), sa.design_freqshift_inc(a.fc, a.fs)
         epi = sa.EPI_USB if wl == "iqbb_usb" else sa.EPI_FM
         node = sa.IQBaseBandI16(ctx, taps_h, lut_h, inc, False, D, channels=C, max_in=N, epilogue=epi)
         w.in_bytes, w.alg_bytes = 4.0, 4.0 + 2.0 / D
@@ -330,7 +442,7 @@ def build_workload(a, wl, sa, torch, shard, ctx, dev, rank, nbuf_out):
                                                                       "USBDemod" if wl == "iqbb_usb" else "FMDemod")
         if cu8:
             w.desc = "complex<uint8> -> AutoCast + " + w.desc
-        w.key = "%s/order%d/d%d" % (wl, order, D) + ("" if a.fc == 100e3 else "/fc%g" % a.fc)
+        w.key = "%s/order%d/d%d" % (wl, order, D) + ("" if a.fc == 100e3 else "/fc%g" % a.fc) + ("" if a.fs == FS and a.width == 50e3 else "/fs%g/w%g" % (a.fs, a.width))
         w.n_valid = node.out_count(N)   # (every call after the first emits N / D outputs)
         de_alpha = 0
         if a.deemph and epi == sa.EPI_FM:
@@ -484,6 +596,27 @@ def build_workload(a, wl, sa, torch, shard, ctx, dev, rank, nbuf_out):
                 ok = ok and bool(np.abs(out[bi].astype(np.float64) - r).max() <= RTOL * max(np.abs(r).max(), 1e-30))
             return ok
         w.verify = verify
+    elif wl == "fftconv_ola":   # BASELINE config 4 (i): the reference's own mode — FilterSink -> FilterSource, block 8192, 16384-point
+        Nb = 8192
+        hk = sa.design_fftfilt_kernel(Nb, 50e3, 150e3, FS)
+        Kk = sa.design_fftfilt_spectrum(hk)
+        N = (N + Nb - 1) // Nb * Nb   # (the reference only accepts whole blocks: FilterSink::config throws otherwise)
+        w.N = N
+        node = sa.FFTConv(ctx, sa.FFTCONV_OLA, 2 * Nb, Kk, channels=C, max_in=N)
+        w.in_bytes, w.alg_bytes = 8.0, 16.0
+        w.outs = [torch.zeros((C, N, 2), dtype=torch.float32, device=dev) for _ in range(nbuf_out)]
+        w.ins = [torch.randn((C, N, 2), dtype=torch.float32, device=dev) * 0.3 for b in range(a.batches)]
+        w.run = lambda b, o: node.process_dev(w.ins[b].data_ptr(), N, N, w.outs[o].data_ptr(), N)
+        w.dtype, w.kernels = "f32", ["fftconv_fused_kernel"]
+        w.desc = "FFT filter, reference mode: overlap-add, blocks of 8192, 16384-point transforms, 8192-tap FilterSource kernel 50..150 kHz"
+        w.key = wl
+
+        def verify(prev, last, out, orc):
+            f = orc.FFTFilter(orc.fftfilt_design_K(hk))
+            f.process(prev[-Nb:])   # (the overlap-add tail reaches one block back)
+            r = np.concatenate([f.process(last[blk * Nb:(blk + 1) * Nb]) for blk in range(N // Nb)])
+            return bool(np.abs(out.astype(np.float64) - r).max() <= RTOL * max(np.abs(r).max(), 1e-30))
+        w.verify = verify
     elif wl == "fftconv":
         alpha_h = sa.design_fir_lowpass(4097, 100e3, FS)
         tapsf = np.stack([alpha_h[::-1], np.zeros_like(alpha_h)], 1).astype(np.float32)   # h[k] = alpha[order-1-k]
@@ -545,14 +678,22 @@ def main():
     ends in ONE JSON line on rank 0 — with an `error` key and value null — and a non-zero exit code."""
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
-    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # (counting devices does not initialise the GPU on this image, so the child processes start from a clean parent)
+    if a.comm == "sdrhip":   # one process whatever --gpus says: the library owns the ranks
         try:
-            import torch
-            seen = torch.cuda.device_count()
-        except Exception as e:   # no torch / no driver: let the ranks report
-            seen = None
-            sys.stderr.write("bench.py: could not count devices (%s)\n" % e)
+            run_sdrhip(a)
+        except BenchError as e:
+            print(error_line(a, e), flush=True)
+            raise SystemExit(2)
+        except SystemExit:
+            raise
+        except BaseException as e:
+            import traceback
+            traceback.print_exc()
+            print(error_line(a, "%s: %s" % (type(e).__name__, e)), flush=True)
+            raise SystemExit(3)
+        return
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        seen = count_gpus_sysfs()   # (KFD topology in sysfs: neither torch nor HIP is loaded in this parent)
         if seen is not None and seen < a.gpus and a.force_device < 0:
             print(error_line(a, "--gpus %d but only %d HIP device(s) visible on this node" % (a.gpus, seen)), flush=True)
             raise SystemExit(2)
@@ -573,6 +714,122 @@ def main():
         if rank == 0:
             print(error_line(a, "%s: %s" % (type(e).__name__, e), world=int(os.environ.get("WORLD_SIZE", "1"))), flush=True)
         raise SystemExit(3)
+
+
+def verify_last(a, w, calls, rank, np, torch):
+    """The LAST step's output of a few channels against the CPU oracle (outside every timed region). `calls` = steps run so
+    far on this plan (the step counter is global: step i read batch i % batches and wrote output buffer i & 1)."""
+    if a.no_verify or w.verify is None or calls < 2:
+        return None
+    C, N = w.outs[0].shape[1 if getattr(w, "out_rows_axis", 0) == 1 else 0], w.N
+    last_i = calls - 1
+    try:
+        from oracle import pyoracle as orc   # checker only: never on the measured path
+        rng = np.random.default_rng(12345 + rank)
+        chans = sorted(rng.choice(C, size=min(a.verify_channels, C), replace=False).tolist())
+        bl, bp = last_i % a.batches, (last_i - 1) % a.batches
+        xo = w.outs[last_i & 1]
+        oks = []
+        for c in chans:
+            prev, last = w.ins[bp][c].cpu().numpy(), w.ins[bl][c].cpu().numpy()
+            out = (xo[:, c] if getattr(w, "out_rows_axis", 0) == 1 else xo[c]).cpu().numpy()
+            kw = {"n0": (calls - 1) * N} if getattr(w, "verify_needs_n0", False) else {}
+            if getattr(w, "verify_needs_pre", False) and calls >= 3:   # (the buffer before the previous one)
+                kw["pre"] = w.ins[(last_i - 2) % a.batches][c].cpu().numpy()
+            if getattr(w, "verify_needs_chan", False):
+                kw.update(chan=c, last_i=last_i)
+            oks.append(w.verify(prev, last, out, orc, **kw))
+        if all(o is None for o in oks):
+            return {"ok": None, "why": "this sample count / decimation is outside what the last-step check covers"}
+        return {"ok": bool(all(oks)), "channels": len(chans), "mode": "last timed step vs CPU oracle",
+                "tolerance": "bit-exact" if w.dtype in ("i16", "f64") else "max|y-ref|/max|ref| <= 1e-5"}
+    except Exception as e:
+        return {"ok": None, "why": "oracle unavailable: %s" % str(e)[:120]}
+
+
+# The other BASELINE.json configs, measured in the same default one-GPU run behind the headline ("configs": [...]).
+# `args` override the command line's; steps / warmup are the run's own. SURVEY §8d gives each config's shape.
+CONFIG_SPECS = [
+    {"id": "config2_c1", "baseline_config": 2, "workload": "fbb_f32", "args": {"channels": 1},
+     "what": "single channel complex<float> baseband (shift -> 127-tap FIR -> /8), 65536 samples per buffer: launch-latency-bound"},
+    {"id": "config2_c1024", "baseline_config": 2, "workload": "fbb_f32", "args": {"channels": 1024},
+     "what": "the same float baseband on 1024 channels per launch"},
+    {"id": "config3", "baseline_config": 3, "workload": "fir255_fm", "args": {"channels": 1024},
+     "what": "1024 int16 IQ channels, FIRLowPass<cs16>(255 taps, exact per-tap truncation in fp64) -> FMDemod"},
+    {"id": "config4_i_ola8192", "baseline_config": 4, "workload": "fftconv_ola", "args": {"channels": 1024},
+     "what": "fftplan FFT filter in the reference's mode (overlap-add, 16384-point, 8192-tap kernel), 1024 channels"},
+    {"id": "config4_ii_ols4097", "baseline_config": 4, "workload": "fftconv", "args": {"channels": 1024, "fft_whole_blocks": True},
+     "what": "overlap-save 16384-point FFT convolution with the 4097 FIRLowPass taps (vs the time-domain FIRFilter), 1024 channels"},
+    {"id": "config5_g1", "baseline_config": 5, "workload": "iqbb_usb", "args": {"channels": 8192, "batches": 2},
+     "what": "8192 channels, IQBaseBand<int16>(127, /8) -> USBDemod, the whole job on ONE GPU (G = 1 point of the scaling curve)"},
+    {"id": "sdr_fm_plan", "baseline_config": None, "workload": "iqbb_fm_cu8", "cpu_chain": "sdr_fm_cu8",
+     "args": {"channels": 1024, "order": 21, "decim": 125, "fs": 1e6, "width": 12.5e3},
+     "what": "the reference's own FM receiver plan (examples/sdr_fm.cc:38-43): complex<uint8> -> AutoCast -> IQBaseBand<int16>(21 taps, /125) -> FMDemod"},
+]
+
+
+def measure_config(a, spec, sa, torch, shard, ctx, dev, np):
+    """One entry of "configs": its own plan and resident inputs; pre-condition, W warm-up steps, K timed steps (wall clock
+    around a synchronised region + HIP events on the kernel's stream), then the oracle check of the last step."""
+    aa = argparse.Namespace(**vars(a))
+    for k, v in spec["args"].items():
+        setattr(aa, k, v)
+    if a.configs_max_channels:
+        aa.channels = min(aa.channels, a.configs_max_channels)
+    t_setup = time.perf_counter()
+    w = build_workload(aa, spec["workload"], sa, torch, shard, ctx, dev, 0, 2)
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
+    C, N, K, W = aa.channels, w.N, a.steps, a.warmup
+    timer = sa.Timer(ctx)
+    it = [0]
+
+    def step():
+        w.run(it[0] % aa.batches, it[0] & 1)
+        it[0] += 1
+    pre_ms, pre_n, t1 = 0.0, 0, time.perf_counter()
+    chunk = max(K, 20)
+    while time.perf_counter() - t1 < a.config_sustain_seconds:
+        timer.start()
+        for _ in range(chunk):
+            step()
+        timer.stop()
+        pre_ms += timer.elapsed_ms()
+        pre_n += chunk
+    pre_s = time.perf_counter() - t1
+    for _ in range(W):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    timer.start()
+    for _ in range(K):
+        step()
+    timer.stop()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dev_ms = timer.elapsed_ms()
+    ver = verify_last(aa, w, it[0], 0, np, torch)
+    per_launch_s = dev_ms / 1e3 / K
+    e = {"id": spec["id"], "baseline_config": spec["baseline_config"], "what": spec["what"], "workload": w.desc, "workload_key": w.key,
+         "channels": C, "samples_per_channel_per_step": N, "steps": K, "warmup": W, "preconditioned_s": round(pre_s, 2),
+         "ms_per_step": round(wall / K * 1e3, 4), "value": round(float(C) * N * K / wall / 1e6, 2), "unit": "Msamples/s", "dtype": w.dtype,
+         "roofline": {"bound": "hbm", "frac": round(C * N * w.alg_bytes / per_launch_s / 1e9 / HBM_PEAK_GBS, 5),
+                      "achieved": round(C * N * w.alg_bytes / per_launch_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "kernel": w.kernels[0], "kernels_per_step": w.kernels, "algorithmic_bytes_per_sample": w.alg_bytes,
+                      "avg_launch_ms": round(per_launch_s * 1e3, 4),
+                      "sustained_ms_per_launch": round(pre_ms / pre_n, 4) if pre_n else None},
+         "verified": ver["ok"] if ver else None, "verify": ver, "setup_s": round(t_setup, 2)}
+    tr = measured_traffic(w.key, w.kernels)
+    if tr:
+        e["roofline"]["traffic"], e["roofline"]["traffic_source"] = tr["bytes"], "profiles/" + tr["source"]
+    if spec["workload"] == "fbb_f32" and C == 1:   # config 2 as SURVEY §8d states it: what a buffer costs, and against real time
+        e["roofline"]["per_buffer_us"] = round(per_launch_s * 1e6, 2)
+        e["roofline"]["real_time_factor"] = round((N / FS) / per_launch_s, 1)
+    del timer
+    w.node.close()
+    del w
+    torch.cuda.empty_cache()
+    return e
 
 
 def run(a):
@@ -617,6 +874,7 @@ def run(a):
     wl = a.workload or ("iqbb_usb" if world > 1 else "iqbb_fm")
     gather = (a.gather or (world > 1 and not a.workload)) and not a.no_gather and use_dist
     C, W, K = a.channels, a.warmup, a.steps
+    t_run0 = time.perf_counter()
 
     stream = torch.cuda.Stream(device=dev)
     side = torch.cuda.Stream(device=dev)   # the gather's stream
@@ -638,21 +896,28 @@ def run(a):
             raise BenchError("--gather needs a workload with one output row per channel")
         pending = [None, None]   # the gather that still reads outs[o]
         ev = [torch.cuda.Event(), torch.cuda.Event()]
+        it = [0]                 # steps run so far on this plan: step i reads batch i % batches and writes output buffer i & 1
 
-        def step(i, with_gather):
+        def issue_gather(o):
+            if g_ok:   # RCCL: on the side stream, behind this step's kernel; the next step starts meanwhile
+                ev[o].record(stream)
+                with torch.cuda.stream(side):
+                    side.wait_event(ev[o])
+                    pending[o] = dist.gather(send[o], gl if rank == 0 else None, dst=0, async_op=True)
+            else:      # gloo dry runs / tests: host-staged, blocking
+                shard.gather_output(w.outs[o], C * world, dst=0, out=gathered)
+
+        def step(with_gather, compute=True):
+            i = it[0]
             o = i & 1
             if pending[o] is not None:   # the compute stream waits (on the device) until the gather of step i-2 has read outs[o]
                 pending[o].wait()
                 pending[o] = None
-            w.run(i % a.batches, o)
+            if compute:
+                w.run(i % a.batches, o)
+                it[0] = i + 1
             if with_gather:
-                if g_ok:   # RCCL: on the side stream, behind this step's kernel; the next step starts meanwhile
-                    ev[o].record(stream)
-                    with torch.cuda.stream(side):
-                        side.wait_event(ev[o])
-                        pending[o] = dist.gather(send[o], gl if rank == 0 else None, dst=0, async_op=True)
-                else:      # gloo dry runs / tests: host-staged, blocking
-                    shard.gather_output(w.outs[o], C * world, dst=0, out=gathered)
+                issue_gather(o)
 
         def drain():
             for o in (0, 1):
@@ -666,73 +931,27 @@ def run(a):
                 dist.barrier()
             torch.cuda.synchronize()
 
-        calls = 0
-        for i in range(W):
-            step(i, gather)
-        calls += W
-        barrier()
         timer = sa.Timer(ctx)
-        t0 = time.perf_counter()
-        timer.start()
-        for i in range(K):
-            step(i, gather)
-        drain()
-        timer.stop()
-        barrier()
-        wall = time.perf_counter() - t0
-        dev_ms = timer.elapsed_ms()
-        calls += K
-        last_i = K - 1
-        # ---- verification (outside the timed region): the LAST timed step's output of a few channels vs the CPU oracle ----
-        verified = None
-        if not a.no_verify and w.verify is not None and K + W >= 2:
-            try:
-                from oracle import pyoracle as orc   # checker only: never on the measured path
-                rng = np.random.default_rng(12345 + rank)
-                chans = sorted(rng.choice(C, size=min(a.verify_channels, C), replace=False).tolist())
-                bl, bp = last_i % a.batches, (last_i - 1) % a.batches
-                xo = w.outs[last_i & 1]
-                oks = []
-                for c in chans:
-                    prev, last = w.ins[bp][c].cpu().numpy(), w.ins[bl][c].cpu().numpy()
-                    out = (xo[:, c] if getattr(w, "out_rows_axis", 0) == 1 else xo[c]).cpu().numpy()
-                    kw = {"n0": (calls - 1) * N} if getattr(w, "verify_needs_n0", False) else {}
-                    if getattr(w, "verify_needs_pre", False) and calls >= 3:   # (the buffer before the previous one)
-                        kw["pre"] = w.ins[(last_i - 2) % a.batches][c].cpu().numpy()
-                    if getattr(w, "verify_needs_chan", False):
-                        kw.update(chan=c, last_i=last_i)
-                    oks.append(w.verify(prev, last, out, orc, **kw))
-                if all(o is None for o in oks):
-                    verified = {"ok": None, "why": "this sample count / decimation is outside what the last-step check covers"}
-                else:
-                    verified = {"ok": bool(all(oks)), "channels": len(chans), "mode": "last timed step vs CPU oracle",
-                                "tolerance": "bit-exact" if w.dtype in ("i16", "f64") else "max|y-ref|/max|ref| <= 1e-5"}
-            except Exception as e:
-                verified = {"ok": None, "why": "oracle unavailable: %s" % str(e)[:120]}
-        if a.dump_output and rank == 0:
-            torch.cuda.synchronize()
-            np.save(a.dump_output, (gathered if gathered is not None else w.outs[last_i & 1]).cpu().numpy())
 
-        # the same K steps without the gather (the per-GPU kernel alone), reported beside the headline of a gathered run
-        no_gather = None
-        if gather:
+        def timed(n, with_gather, compute=True):
             barrier()
-            t1 = time.perf_counter()
+            t0 = time.perf_counter()
             timer.start()
-            for i in range(K):
-                step(i, False)
+            for _ in range(n):
+                step(with_gather, compute)
+            drain()
             timer.stop()
             barrier()
-            no_gather = {"wall": time.perf_counter() - t1, "dev_ms": timer.elapsed_ms()}
-            calls += K
+            return time.perf_counter() - t0, timer.elapsed_ms()
 
-        # ---- sustained figure: >= --sustain-seconds of back-to-back launches on the same stream, so that the
-        # clock the chip HOLDS under this load (DVFS) is what is measured, not a few-ms burst (every rank runs it;
-        # rank 0 reports its own) ----
-        sustained, telemetry = None, None
+        # ---- pre-conditioning = the sustained figure: >= --sustain-seconds of back-to-back launches on the same stream
+        # BEFORE the warm-up and the timed steps, so that the timed region runs at the clock the chip HOLDS under this load
+        # (DVFS), not on the ramp out of idle (every rank runs it; rank 0 reports its own) ----
+        sustained, telemetry, tele, pre_s = None, None, None, 0.0
+        for _ in range(2):   # (first launches: code objects load, LDS attributes are set)
+            step(False)
         if a.sustain_seconds > 0:
             chunk = max(K, 20)
-            tele = None
             if rank == 0:
                 try:   # the device's sysfs directory by its PCI address (domain:bus:device.function)
                     pr = torch.cuda.get_device_properties(local)
@@ -746,22 +965,61 @@ def run(a):
             tot_ms, launches, t1 = 0.0, 0, time.perf_counter()
             while time.perf_counter() - t1 < a.sustain_seconds:
                 timer.start()
-                for i in range(chunk):
-                    step(i, False)
+                for _ in range(chunk):
+                    step(False)
                 timer.stop()
                 tot_ms += timer.elapsed_ms()   # waits for the chunk; the next one follows within microseconds
                 launches += chunk
+            pre_s = time.perf_counter() - t1
             last_ms = timer.elapsed_ms() / chunk
             sustained = {"ms_per_launch": tot_ms / launches, "launches": launches, "last_chunk_ms_per_launch": last_ms}
-            if tele is not None:
-                telemetry = tele.stop()
-            barrier()
+        # ---- W warm-up steps, then EXACTLY K timed steps between barrier + synchronize on both sides ----
+        for _ in range(W):
+            step(gather)
+        wall, dev_ms = timed(K, gather)
+        if tele is not None:
+            telemetry = tele.stop()   # (stopped only now: nothing but launches between the pre-conditioning and the timed region)
+        # ---- verification (outside the timed region): the LAST timed step's output of a few channels vs the CPU oracle ----
+        verified = verify_last(a, w, it[0], rank, np, torch) if K + W >= 2 else None
+        if a.dump_output and rank == 0:
+            torch.cuda.synchronize()
+            np.save(a.dump_output, (gathered if gathered is not None else w.outs[(it[0] - 1) & 1]).cpu().numpy())
+
+        # the same K steps without the gather (the per-GPU kernel alone) and the gather alone (no kernel), reported
+        # beside the headline of a gathered run
+        no_gather, gather_only = None, None
+        if gather:
+            wl_, dm_ = timed(K, False)
+            no_gather = {"wall": wl_, "dev_ms": dm_}
+            wl_, dm_ = timed(K, True, compute=False)
+            gather_only = {"wall": wl_}
+
+        # ---- the other BASELINE configs, each to the same recipe (one GPU, default run only) ----
+        configs = None
+        if world == 1 and not use_dist and not a.workload and not a.no_configs and not a.global_channels:
+            w_key, w_desc, w_dtype, w_kernels, w_alg, w_in = w.key, w.desc, w.dtype, w.kernels, w.alg_bytes, w.in_bytes
+            w.node.close()
+            w.ins = w.outs = None
+            torch.cuda.empty_cache()
+            configs = []
+            for spec in CONFIG_SPECS:
+                try:
+                    configs.append(measure_config(a, spec, sa, torch, shard, ctx, dev, np))
+                except Exception as e:   # (one entry that fails says so; the headline and the other entries stand)
+                    configs.append({"id": spec["id"], "error": "%s: %s" % (type(e).__name__, str(e)[:200])})
+                    torch.cuda.empty_cache()
 
     host_coll = use_dist and a.backend != "nccl"
-    red = torch.tensor([wall, no_gather["wall"] if no_gather else 0.0], dtype=torch.float64, device="cpu" if host_coll else dev)
+    cdev = "cpu" if host_coll else dev
+    mine = dev_ms / K
+    red = torch.tensor([wall, no_gather["wall"] if no_gather else 0.0, gather_only["wall"] if gather_only else 0.0, mine, -mine],
+                       dtype=torch.float64, device=cdev)
+    ranks_seen = torch.ones(1, dtype=torch.float64, device=cdev)
     if use_dist:
         dist.all_reduce(red, op=dist.ReduceOp.MAX)
-    wall, wall_ng = float(red[0].item()), float(red[1].item())
+        dist.all_reduce(ranks_seen, op=dist.ReduceOp.SUM)   # (counted by the collective itself, not read from the launcher's env)
+    wall, wall_ng, wall_go = float(red[0].item()), float(red[1].item()), float(red[2].item())
+    launch_max, launch_min = float(red[3].item()), -float(red[4].item())
 
     if rank == 0:
         alg_bytes, in_bytes = w.alg_bytes, w.in_bytes
@@ -774,6 +1032,7 @@ def run(a):
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(wall / K * 1e3, 4), "higher_is_better": True, "scaling": "strong" if a.global_channels else "weak",
             "vs_baseline": None, "dtype": w.dtype, "data": "synthetic",
+            "preconditioned_s": round(pre_s, 2),
             "config": {"workload": w.desc, "workload_key": w.key, "channels_per_gpu": C, "samples_per_channel_per_step": N,
                        "global_channels": C * world,
                        "input": "int16 (real)" if wl == "bb_real_fm" else {2.0: "complex<uint8>", 4.0: "complex<int16>"}.get(in_bytes, "complex<float>"),
@@ -784,7 +1043,8 @@ def run(a):
                          "algorithmic_bytes_per_sample": alg_bytes, "avg_launch_ms": round(per_launch_s * 1e3, 4),
                          "hbm_read_frac": round(C * N * in_bytes / per_launch_s / 1e9 / HBM_PEAK_GBS, 5),
                          "per_gpu_msamples_s": round(C * N / per_launch_s / 1e6, 2),
-                         "ranks_seen": dist.get_world_size() if use_dist else 1},
+                         "ranks_seen": int(round(float(ranks_seen.item()))),
+                         "avg_launch_ms_min_rank": round(launch_min, 4), "avg_launch_ms_max_rank": round(launch_max, 4)},
         }
         if verified is not None:
             res["verified"] = verified["ok"]
@@ -795,6 +1055,15 @@ def run(a):
             rf["without_gather_msamples_s"] = round(total_samples / wall_ng / 1e6, 2)
             rf["without_gather_ms_per_step"] = round(wall_ng / K * 1e3, 4)
             rf["without_gather_avg_launch_ms"] = round(no_gather["dev_ms"] / K, 4)
+            # what the gather moves: every rank's rows land on the root each step; the remote part crosses xGMI
+            row_bytes = w.outs[0].shape[1] * w.outs[0].element_size()
+            gb, gb_remote = world * C * row_bytes, (world - 1) * C * row_bytes
+            rf["gather_bytes_per_step"], rf["gather_remote_bytes_per_step"] = gb, gb_remote
+            rf["gather_only_ms_per_step"] = round(wall_go / K * 1e3, 4)
+            rf["gather_gbs"] = round(gb / (wall_go / K) / 1e9, 2)                 # the gather alone, back to back (root ingress incl. its own copy)
+            rf["gather_remote_gbs"] = round(gb_remote / (wall_go / K) / 1e9, 2)   # ... the part that crosses links
+            rf["gather_gbs_in_step"] = round(gb / (wall / K) / 1e9, 2)            # what the gathered steps delivered
+            rf["claim"] = "without_gather_* = how the kernel scales; value / with_gather_* = what the root receives (root-ingress-bound at 8 GPUs, DESIGN.md §5)"
         if sustained:
             rf = res["roofline"]
             rf["sustained_ms_per_launch"] = round(sustained["ms_per_launch"], 4)
@@ -802,7 +1071,8 @@ def run(a):
             rf["sustained_launches"] = sustained["launches"]
             rf["sustained_last_chunk_ms_per_launch"] = round(sustained["last_chunk_ms_per_launch"], 4)
             rf["sustained_per_gpu_msamples_s"] = round(C * N / (sustained["ms_per_launch"] / 1e3) / 1e6, 2)
-            if wall * 1e3 < 20.0:   # a timed region this short is a burst at a clock the chip does not hold: the sustained value beside it
+            rf["sustained_phase"] = "pre-conditioning, in front of the warm-up and the timed steps"
+            if wall * 1e3 < 20.0:   # a timed region this short: the same metric over the pre-conditioning launches beside it
                 res["value_sustained"] = round(C * N * world / (sustained["ms_per_launch"] / 1e3) / 1e6, 2)
                 res["value_sustained_note"] = "timed region %.1f ms < 20 ms; this is the same metric over >= %.0f s of back-to-back steps (rank 0's kernel rate x ranks, no gather)" % (wall * 1e3, a.sustain_seconds)
         try:   # what this box's HBM delivers to a pure read of the same buffers, beside the nominal peak
@@ -824,22 +1094,193 @@ def run(a):
         if wl == "fbb_f32" and C == 1:   # BASELINE config 2: one channel — what a buffer costs, and against real time
             res["roofline"]["per_buffer_us"] = round(per_launch_s * 1e6, 2)
             res["roofline"]["real_time_factor"] = round((N / FS) / per_launch_s, 1)
-        if telemetry:   # the clock and power the chip HELD over the sustained phase (rank 0's device)
+        if telemetry:   # the clock and power the chip HELD over the pre-conditioning and the timed steps (rank 0's device)
             rf = res["roofline"]
             rf["sclk_mhz"], rf["sclk_mhz_min"], rf["power_w"] = telemetry["sclk_mhz"], telemetry["sclk_mhz_min"], telemetry["power_w"]
             rf["power_cap_w"] = telemetry["power_cap_w"]   # (the socket's limit: a kernel at it runs at the clock the limit allows)
-            rf["telemetry"] = {"samples": telemetry["samples"], "phase": "sustained", "source": telemetry["source"]}
+            rf["telemetry"] = {"samples": telemetry["samples"], "phase": "pre-conditioning + warm-up + timed steps", "source": telemetry["source"]}
+        if configs is not None:
+            res["configs"] = configs
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        # the CPU baseline runs once the GPU work is over and the process group is gone (the other ranks have left: the
+        # the CPU baselines run once the GPU work is over and the process group is gone (the other ranks have left: the
         # host cores are idle), on rank 0, for every N
         if not a.no_cpu_baseline:
             cb = cpu_baseline(wl, a.cpu_seconds)
             if cb:
                 res["cpu_baseline"] = cb
+            for spec, e in zip(CONFIG_SPECS, configs or []):
+                if "error" in e:
+                    continue
+                try:
+                    cb = cpu_baseline(spec["workload"], a.config_cpu_seconds, all_cores=False, chain=spec.get("cpu_chain"))
+                except Exception as ex:
+                    cb = {"error": str(ex)[:120]}
+                if cb:
+                    e["cpu_baseline"] = cb
+        res["run_s"] = round(time.perf_counter() - t_run0, 1)
         print(json.dumps(res), flush=True)
+
+
+class _CommDesign:
+    """build_workload's `shard` seam in --comm sdrhip mode: the design tensors a rank builds its plan from are the bytes
+    that travelled to that rank through sdrhip_comm_broadcast."""
+
+    def __init__(self, received):
+        self.received = received
+
+    def broadcast_design(self, tensors, src=0):
+        for t, b in zip(tensors, self.received):
+            t.copy_(b.view(t.dtype).reshape(t.shape))
+        return tensors
+
+
+def run_sdrhip(a):
+    """BASELINE config 5 through the C ABI's multi-GPU path: ONE process, --gpus N rank
+    contexts from sdrhip_comm_create (one per device; with --force-device D all on device D, where the library uses its
+    same-device transport), the design broadcast with sdrhip_comm_broadcast, every step = one *_process_dev per rank on
+    the rank's own stream + one sdrhip_comm_gather of the demodulated rows to rank 0. torch only allocates and fills the
+    device buffers."""
+    import numpy as np
+    import torch
+    import libsdr_amd as sa
+
+    if not torch.cuda.is_available():
+        raise BenchError("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    G = a.gpus
+    ndev = torch.cuda.device_count()
+    devices = [a.force_device] * G if a.force_device >= 0 else list(range(G))
+    if max(devices) >= ndev:
+        raise BenchError("--comm sdrhip --gpus %d but only %d HIP device(s) visible (one box: --force-device 0)" % (G, ndev))
+    wl = a.workload or "iqbb_usb"
+    if wl not in ("iqbb_usb", "iqbb_fm", "iqbb_fm_cu8"):
+        raise BenchError("--comm sdrhip runs the iqbb_* workloads (config 5's chain)")
+    if a.global_channels:
+        if a.global_channels % G:
+            raise BenchError("--global-channels %d is not a multiple of the %d ranks" % (a.global_channels, G))
+        a.channels = a.global_channels // G
+    C, W, K = a.channels, a.warmup, a.steps
+    t_run0 = time.perf_counter()
+    comm = sa.Comm(devices)
+    tdev = [torch.device("cuda", d) for d in devices]
+    # ---- config(): designed once (rank 0), broadcast to every rank's device through the library ----
+    taps0 = torch.from_numpy(sa.design_iqbb_taps(a.fc, a.width, a.fs, a.order)).to(tdev[0])
+    lut0 = torch.from_numpy(sa.design_freqshift_lut_i16()).to(tdev[0])
+    recv = []
+    for t0_ in (taps0, lut0):
+        bufs = [t0_ if r == 0 else torch.zeros_like(t0_, device=tdev[r]) for r in range(G)]
+        for d in set(devices):
+            torch.cuda.synchronize(d)
+        comm.broadcast([b.data_ptr() for b in bufs], t0_.numel() * t0_.element_size(), 0)
+        recv.append(bufs)
+    comm.synchronize()
+    ws, timers = [], []
+    for r in range(G):
+        torch.cuda.set_device(devices[r])
+        ws.append(build_workload(a, wl, sa, torch, _CommDesign([recv[0][r], recv[1][r]]), comm.ctx[r], tdev[r], r, 2))
+        timers.append(sa.Timer(comm.ctx[r]))
+    N, w0 = ws[0].N, ws[0]
+    row_elems = w0.outs[0].shape[1]
+    row_bytes = row_elems * w0.outs[0].element_size()
+    torch.cuda.set_device(devices[0])
+    gathered = torch.zeros((G * C, row_elems), dtype=w0.outs[0].dtype, device=tdev[0])
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    it = [0]
+
+    def step(with_gather, compute=True):
+        i = it[0]
+        o = i & 1
+        if compute:
+            for r in range(G):
+                ws[r].run(i % a.batches, o)
+            it[0] = i + 1
+        if with_gather:   # (ordered on the ranks' streams in both directions by the library: no host wait between steps)
+            comm.gather([ws[r].outs[o].data_ptr() for r in range(G)], [C * row_bytes] * G, gathered.data_ptr(), 0)
+
+    def timed(n, with_gather, compute=True):
+        comm.synchronize()
+        t0 = time.perf_counter()
+        for t in timers:
+            t.start()
+        for _ in range(n):
+            step(with_gather, compute)
+        for t in timers:
+            t.stop()
+        comm.synchronize()
+        return time.perf_counter() - t0, [t.elapsed_ms() for t in timers]
+
+    for _ in range(2):
+        step(False)
+    pre_s, sustained = 0.0, None
+    if a.sustain_seconds > 0:
+        chunk, tot, n, t1 = max(K, 20), 0.0, 0, time.perf_counter()
+        while time.perf_counter() - t1 < a.sustain_seconds:
+            _, ms = timed(chunk, False)
+            tot += ms[0]
+            n += chunk
+        pre_s, sustained = time.perf_counter() - t1, tot / n
+    for _ in range(W):
+        step(True)
+    wall, ms = timed(K, True)
+    verified = None
+    if K + W >= 2 and not a.no_verify:
+        oks = []
+        for r in range(G):
+            torch.cuda.set_device(devices[r])
+            v = verify_last(a, ws[r], it[0], r, np, torch)
+            oks.append(v["ok"] if v else None)
+        verified = {"ok": None if all(o is None for o in oks) else bool(all(o for o in oks if o is not None) and any(oks)),
+                    "ranks": G, "channels_per_rank": min(a.verify_channels, C), "mode": "last timed step of every rank vs CPU oracle", "tolerance": "bit-exact"}
+        o = (it[0] - 1) & 1   # ... and the root's landing zone holds exactly the ranks' rows, in global channel order
+        torch.cuda.set_device(devices[0])
+        same = all(bool(torch.equal(gathered[r * C:(r + 1) * C].cpu(), ws[r].outs[o].cpu())) for r in range(G))
+        verified["gathered_equals_rank_rows"] = same
+        if not same:
+            verified["ok"] = False
+    if a.dump_output:
+        np.save(a.dump_output, gathered.cpu().numpy())
+    wall_ng, ms_ng = timed(K, False)
+    wall_go, _ = timed(K, True, compute=False)
+    alg, inb = w0.alg_bytes, w0.in_bytes
+    per_launch_s = ms[0] / 1e3 / K
+    total = float(C) * N * K * G
+    gb, gb_remote = G * C * row_bytes, (G - 1) * C * row_bytes
+    res = {"metric": "Msamples/s through baseband->FIR->demod chain", "value": round(total / wall / 1e6, 2), "unit": "Msamples/s",
+           "n_gpus": len(set(devices)), "ranks": G, "steps": K, "warmup": W, "ms_per_step": round(wall / K * 1e3, 4), "higher_is_better": True,
+           "scaling": "strong" if a.global_channels else "weak", "vs_baseline": None, "dtype": w0.dtype, "data": "synthetic",
+           "preconditioned_s": round(pre_s, 2), "comm": "sdrhip",
+           "config": {"workload": w0.desc, "workload_key": w0.key, "channels_per_gpu": C, "samples_per_channel_per_step": N, "global_channels": C * G,
+                      "input": {2.0: "complex<uint8>", 4.0: "complex<int16>"}.get(inb),
+                      "parallelism": "ONE process, %d rank contexts on devices %s through sdrhip_comm_* (transport: %s); design broadcast, "
+                                     "output gathered on rank 0 every step" % (G, devices, comm.transport)},
+           "roofline": {"bound": "hbm", "achieved": round(C * N * alg / per_launch_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(C * N * alg / per_launch_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "kernel": w0.kernels[0],
+                        "kernels_per_step": w0.kernels, "algorithmic_bytes_per_sample": alg,
+                        "avg_launch_ms": round(ms[0] / K, 4), "avg_launch_ms_min_rank": round(min(ms) / K, 4), "avg_launch_ms_max_rank": round(max(ms) / K, 4),
+                        "avg_launch_note": "HIP events on each rank's stream around the K steps INCLUDING that stream's share of the gather",
+                        "ranks_seen": G,
+                        "with_gather_msamples_s": round(total / wall / 1e6, 2), "without_gather_msamples_s": round(total / wall_ng / 1e6, 2),
+                        "without_gather_ms_per_step": round(wall_ng / K * 1e3, 4), "without_gather_avg_launch_ms": round(ms_ng[0] / K, 4),
+                        "gather_bytes_per_step": gb, "gather_remote_bytes_per_step": gb_remote,
+                        "gather_only_ms_per_step": round(wall_go / K * 1e3, 4), "gather_gbs": round(gb / (wall_go / K) / 1e9, 2),
+                        "gather_remote_gbs": round(gb_remote / (wall_go / K) / 1e9, 2), "gather_gbs_in_step": round(gb / (wall / K) / 1e9, 2)}}
+    if sustained:
+        res["roofline"]["sustained_ms_per_launch"] = round(sustained, 4)
+    if verified is not None:
+        res["verified"], res["verify"] = verified["ok"], verified
+    for w in ws:
+        w.node.close()
+    del timers
+    comm.close()
+    if not a.no_cpu_baseline:
+        cb = cpu_baseline(wl, a.cpu_seconds)
+        if cb:
+            res["cpu_baseline"] = cb
+    res["run_s"] = round(time.perf_counter() - t_run0, 1)
+    print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":

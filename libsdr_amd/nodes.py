@@ -102,6 +102,13 @@ class Context:
         check(abi.lib().sdrhip_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h)))
         self.device = device
 
+    @classmethod
+    def borrowed(cls, handle, device):
+        """A context some other object owns (sdrhip_comm_ctx: rank r's context lives as long as the comm)."""
+        self = cls.__new__(cls)
+        self._h, self.device, self._borrowed = C.c_void_p(handle.value if isinstance(handle, C.c_void_p) else handle), device, True
+        return self
+
     @property
     def handle(self):
         return self._h
@@ -137,7 +144,8 @@ class Context:
         if self._h:
             for hook in close_hooks:   # (buffers a device_router holds on this context)
                 hook(self)
-            abi.lib().sdrhip_ctx_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                abi.lib().sdrhip_ctx_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -626,3 +634,50 @@ def fft_exec(ctx, x, sign):
     check(abi.lib().sdrhip_fft_exec(ctx.handle, abi.T_CF64 if x.dtype == np.complex128 else abi.T_CF32, x.shape[0], sign,
                                     _ptr(x), _ptr(out)))
     return out
+
+
+class Comm:
+    """sdrhip_comm_*: one process, one rank context per device (RCCL between distinct devices, same-device copies when
+    every rank sits on one device). Mirrors what sdr::gpu::ChannelBank(devices) does on the C++ side."""
+
+    def __init__(self, devices):
+        devs = (C.c_int * len(devices))(*devices)
+        self._h = C.c_void_p()
+        check(abi.lib().sdrhip_comm_create(devs, len(devices), C.byref(self._h)))
+        self.devices = list(devices)
+        self.ctx = []
+        for r, d in enumerate(devices):
+            h = C.c_void_p()
+            check(abi.lib().sdrhip_comm_ctx(self._h, r, C.byref(h)))
+            self.ctx.append(Context.borrowed(h, d))
+
+    @property
+    def transport(self):
+        s = C.c_char_p()
+        check(abi.lib().sdrhip_comm_transport(self._h, C.byref(s)))
+        return s.value.decode()
+
+    def broadcast(self, ptrs, nbytes, root=0):
+        arr = (C.c_void_p * len(ptrs))(*ptrs)
+        check(abi.lib().sdrhip_comm_broadcast(self._h, arr, nbytes, root))
+
+    def gather(self, send_ptrs, nbytes, recv_ptr, root=0):
+        sp = (C.c_void_p * len(send_ptrs))(*send_ptrs)
+        nb = (C.c_size_t * len(nbytes))(*nbytes)
+        check(abi.lib().sdrhip_comm_gather(self._h, sp, nb, C.c_void_p(recv_ptr), root))
+
+    def synchronize(self):
+        check(abi.lib().sdrhip_comm_synchronize(self._h))
+
+    def close(self):
+        if self._h:
+            for c in self.ctx:
+                c.close()
+            abi.lib().sdrhip_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -676,11 +676,11 @@ static void golden_wav() {
 // ---------------------------------------------------------------------------------------------
 // timing of the reference CPU path (bench.py cpu_baseline kind "reference")
 // ---------------------------------------------------------------------------------------------
-static int bench(const std::string &chain, size_t nbuf) {
-  const double Fs = 2.4e6; const size_t N = 65536;
+static int bench(const std::string &chain, size_t nbuf, size_t N) {
+  const double Fs = 2.4e6;
   std::vector<cs16> x = siggen<int16_t>(Fs, N, 1, two_tone_i16());
   std::vector<cf32> xf;
-  if (chain == "fir_cf32_sub8") xf = siggen<float>(Fs, N, 1, two_tone_f32());
+  if (chain == "fir_cf32_sub8" || chain == "fir_cf32_4097") xf = siggen<float>(Fs, N, 1, two_tone_f32());
   std::vector<cs16> work(N);
   size_t total_out = 0; long checksum = 0;
   std::chrono::steady_clock::time_point t0, t1;
@@ -714,6 +714,30 @@ static int bench(const std::string &chain, size_t nbuf) {
     t0 = std::chrono::steady_clock::now();
     for (size_t b = 0; b < nbuf; b++) src.feed(&xf[0], N);
     t1 = std::chrono::steady_clock::now(); total_out = cap.total;
+  } else if (chain == "fir_cf32_4097") {
+    // BASELINE config 4 (ii)'s time-domain side: FIRLowPass<complex<float>>(4097 taps) (src/firfilter.hh:231-247)
+    Feeder<cf32> src; src.configure(Fs, N);
+    FIRLowPass<cf32> fir(4097, 100e3);
+    src.connect(&fir, true);
+    Capture<cf32> cap; cap.keep = false; fir.connect(&cap, true);
+    src.feed(&xf[0], N);
+    t0 = std::chrono::steady_clock::now();
+    for (size_t b = 0; b < nbuf; b++) src.feed(&xf[0], N);
+    t1 = std::chrono::steady_clock::now(); total_out = cap.total;
+  } else if (chain == "sdr_fm_cu8") {
+    // the reference's own FM receiver plan (examples/sdr_fm.cc:38-53 without the audio device): complex<uint8> at 1 MS/s
+    // -> AutoCast<cs16> -> IQBaseBand<int16>(100 kHz, 12.5 kHz wide, 21 taps, to 8 kS/s = /125) -> FMDemod
+    typedef std::complex<uint8_t> cu8;
+    std::vector<cu8> xb(N);
+    for (size_t i = 0; i < N; i++) xb[i] = cu8((uint8_t)((x[i].real() >> 6) + 127), (uint8_t)((x[i].imag() >> 6) + 127));
+    Feeder<cu8> src; src.configure(1e6, N); AutoCast<cs16> cast;
+    IQBaseBand<int16_t> bb(100e3, 12.5e3, 21, 1, 8000.0); bb.setCenterFrequency(100e3); bb.setFilterFrequency(100e3);
+    FMDemod<int16_t> fm; Capture<int16_t> cap; cap.keep = false;
+    src.connect(&cast, true); cast.connect(&bb, true); bb.connect(&fm, true); fm.connect(&cap, true);
+    for (size_t b = 0; b < 2; b++) src.feed(&xb[0], N);
+    t0 = std::chrono::steady_clock::now();
+    for (size_t b = 0; b < nbuf; b++) src.feed(&xb[0], N);
+    t1 = std::chrono::steady_clock::now(); total_out = cap.total;
   } else {
     fprintf(stderr, "unknown chain %s\n", chain.c_str()); return 2;
   }
@@ -738,8 +762,8 @@ int main(int argc, char **argv) {
     return 0;
   }
   if (argc >= 4 && std::string(argv[1]) == "bench") {
-    return bench(argv[2], (size_t)atol(argv[3]));
+    return bench(argv[2], (size_t)atol(argv[3]), argc >= 5 ? (size_t)atol(argv[4]) : (size_t)65536);
   }
-  fprintf(stderr, "usage: ref_driver golden <outdir> | bench <chain> <nbuf>\n");
+  fprintf(stderr, "usage: ref_driver golden <outdir> | bench <chain> <nbuf> [samples per buffer]\n");
   return 1;
 }

@@ -192,3 +192,63 @@ def test_rccl_gather_path_runs_on_one_rank(tmp_path):
     assert "gathered" in d2["config"]["parallelism"]
     a, b = np.load(one), np.load(two)
     assert a.shape == b.shape and np.array_equal(a, b) and np.count_nonzero(a) > a.size // 2
+
+
+@pytest.mark.gpu
+def test_default_line_carries_every_baseline_config():
+    """The default one-GPU line (what the driver runs) appends BASELINE configs 2, 3, 4 (i)/(ii), 5 at G = 1 and the
+    reference's own sdr_fm plan as "configs": each entry timed to the same recipe, checked against the oracle on its last
+    step, with its roofline and the reference CPU chain beside it. (Channel counts capped here; the driver's run is full size.)"""
+    d = _bench(["--channels", "16", "--samples", "32768", "--steps", "3", "--warmup", "2", "--sustain-seconds", "0.2",
+                "--config-sustain-seconds", "0.05", "--cpu-seconds", "0.5", "--config-cpu-seconds", "0.3", "--configs-max-channels", "16",
+                "--verify-channels", "4"])
+    assert d["verified"] is True and d["preconditioned_s"] >= 0.2 and d["roofline"]["sustained_ms_per_launch"] > 0
+    ids = [e["id"] for e in d["configs"]]
+    assert ids == ["config2_c1", "config2_c1024", "config3", "config4_i_ola8192", "config4_ii_ols4097", "config5_g1", "sdr_fm_plan"]
+    for e in d["configs"]:
+        assert "error" not in e, e
+        assert e["verified"] is True, e
+        assert e["value"] > 0 and e["ms_per_step"] > 0 and e["workload_key"]
+        rf = e["roofline"]
+        assert rf["kernel"] and rf["algorithmic_bytes_per_sample"] > 0 and 0 < rf["frac"] < 1
+        assert e["cpu_baseline"]["value"] > 0 and e["cpu_baseline"]["kind"] in ("reference", "port")
+    assert d["configs"][0]["roofline"]["per_buffer_us"] > 0
+    lim = d["cpu_baseline"]["all_cores"]["limits"]
+    assert lim["cpus_in_affinity_mask"] >= 1 and "cgroup_quota_cores" in lim
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["iqbb_usb", "iqbb_fm"])
+def test_comm_sdrhip_ranks_on_one_device_match_single_rank(tmp_path, workload):
+    """BASELINE config 5 through the C ABI's multi-GPU path (`--comm sdrhip`): ONE process, 2 and 4 rank contexts from
+    sdrhip_comm_create — all on device 0 here, where the library uses its same-device transport — design broadcast with
+    sdrhip_comm_broadcast, sdrhip_comm_gather every step. The gathered rows equal the single-rank run over the same
+    global channels bit for bit."""
+    import numpy as np
+    common = ["--workload", workload, "--samples", "8192", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--sustain-seconds", "0"]
+    one = str(tmp_path / "one.npy")
+    d1 = _bench(["--gpus", "1", "--channels", "16", "--dump-output", one] + common)
+    b = np.load(one)
+    for G in (2, 4):
+        out = str(tmp_path / ("comm%d.npy" % G))
+        d = _bench(["--comm", "sdrhip", "--gpus", str(G), "--force-device", "0", "--channels", str(16 // G), "--dump-output", out] + common)
+        assert d["comm"] == "sdrhip" and d["ranks"] == G and d["config"]["global_channels"] == 16
+        assert "same-device" in d["config"]["parallelism"]
+        assert d["verified"] is True and d["verify"]["gathered_equals_rank_rows"] is True, d["verify"]
+        rf = d["roofline"]
+        assert rf["gather_bytes_per_step"] == b.size * 2 and rf["gather_gbs"] > 0 and rf["without_gather_msamples_s"] > 0
+        a = np.load(out)
+        assert a.shape == b.shape and a.dtype == np.int16 and np.array_equal(a, b)
+    assert np.count_nonzero(b) > b.size // 2
+
+
+@pytest.mark.gpu
+def test_dist_line_reports_the_gather_and_the_ranks_it_counted():
+    """The N > 1 line's extra keys, visible on a one-rank RCCL group: bytes and GB/s of the gather (alone and inside the
+    steps), per-rank launch time min / max, and `ranks_seen` counted by an all-reduce."""
+    d = _bench(["--workload", "iqbb_usb", "--channels", "16", "--samples", "32768", "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
+                "--sustain-seconds", "0", "--verify-channels", "4", "--force-dist", "--gather"])
+    rf = d["roofline"]
+    assert rf["ranks_seen"] == 1 and rf["gather_bytes_per_step"] > 0 and rf["gather_bytes_per_step"] % 32 == 0
+    assert rf["gather_gbs"] > 0 and rf["gather_gbs_in_step"] > 0 and rf["gather_only_ms_per_step"] > 0
+    assert 0 < rf["avg_launch_ms_min_rank"] <= rf["avg_launch_ms_max_rank"]
