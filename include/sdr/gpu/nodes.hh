@@ -321,12 +321,19 @@ public:
     _buffer.unref();
   }
   inline size_t order() const { return _order; }
-  void setOrder(size_t o) { _order = std::max(size_t(1), o); if (_Fs) _reconfigure(); }
+  /** A new order is a new plan (filter history, decimator and phasor restart: the reference's setOrder reallocates its ring
+   * too, src/baseband.hh:69-79); the same order changes nothing. */
+  void setOrder(size_t o) { o = std::max(size_t(1), o); if (o == _order) return; _order = o; if (_Fs) _reconfigure(); }
   inline double centerFrequency() const { return _Fc; }
-  /** (a new plan: the phasor, the filter history and the decimator restart — the float node keeps no LUT phase to carry).
+  /** The plan and its streaming state are KEPT (src/baseband.hh:82-86: setCenterFrequency only updates the LUT increment):
+   * the phasor restarts at the current sample with the new frequency, filter history and decimator go on.
    * The build-defined float baseband filters AROUND its centre frequency (class comment): the centre takes the filter
    * frequency with it, so that a retune is one call and never passes through an unsupported (Fc, Ff) pair. */
-  void setCenterFrequency(double Fc) { _Fc = Fc; _Ff = Fc; if (_Fs) _reconfigure(); }
+  void setCenterFrequency(double Fc) {
+    _Fc = Fc; _Ff = Fc;
+    if (_plan) detail::configCheck(sdrhip_fbb_f32_set_shift(_plan, _Fc), "IQBaseBand<float>");
+    else if (_Fs) _reconfigure();
+  }
   inline double filterFrequency() const { return _Ff; }
   /** Checked BEFORE anything changes: on a configured node a filter frequency other than the centre frequency throws
    * ConfigError and leaves the node as it was (same values, same plan). */
@@ -337,14 +344,33 @@ public:
           << "Hz (the build-defined float baseband low-pass filters the shifted band: sdr/gpu/nodes.hh); the node is unchanged";
       throw err;
     }
-    _Ff = Ff;
-    if (_Fs) _reconfigure();
+    _Ff = Ff;   // (equal to the centre frequency: nothing to update)
+    if (_Fs && !_plan) _reconfigure();
   }
   inline double filterWidth() const { return _width; }
-  void setFilterWidth(double width) { _width = width; if (_Fs) _reconfigure(); }
+  /** New coefficients on the SAME plan (src/baseband.hh:95-101: setFilterWidth only recomputes the kernel; the ring stays). */
+  void setFilterWidth(double width) {
+    _width = width;
+    if (_plan) {
+      std::vector<double> alpha(_order);
+      design::firLowPass(_order, _width / 2, _Fs, alpha.data());
+      detail::configCheck(sdrhip_fbb_f32_set_taps(_plan, alpha.data()), "IQBaseBand<float>");
+    } else if (_Fs) _reconfigure();
+  }
   size_t subSample() const { return _sub_sample; }
-  void setSubsample(size_t sub_sample) { _sub_sample = std::max(size_t(1), sub_sample); if (_Fs) _reconfigure(); }
-  void setOutputSampleRate(double Fs) { _oFs = Fs; if (_Fs) _reconfigure(); }
+  /** A decimation that does not change keeps plan and state; a new one is a new plan (the reference runs _reconfigure:
+   * counters reset, src/baseband.hh:106-112). */
+  void setSubsample(size_t sub_sample) {
+    sub_sample = std::max(size_t(1), sub_sample);
+    const bool same = _plan && _oFs <= 0 && sub_sample == _sub_sample;
+    _sub_sample = sub_sample;
+    if (_Fs && !same) _reconfigure();
+  }
+  void setOutputSampleRate(double Fs) {
+    const bool same = _plan && Fs > 0 && design::iqbbDecimation(_Fs, _sub_sample, Fs) == _sub_sample;
+    _oFs = Fs;
+    if (_Fs && !same) _reconfigure();
+  }
 
   virtual void config(const Config &src_cfg) {
     if (!src_cfg.hasType() || !src_cfg.hasSampleRate() || !src_cfg.hasBufferSize()) return;
@@ -540,7 +566,15 @@ public:
   inline size_t order() const { return _order; }
   virtual void setOrder(size_t order) { order = std::max(size_t(1), order); if (order == _order) return; _order = order; if (_Fs) _plan_(); }
   inline double freq() const { return _Fu; }
-  inline void setFreq(double freq) { _Fu = freq; if (_Fs) _plan_(); }
+  /** FIRFilter::setUpperFreq (src/firfilter.hh:165-170,287): only the coefficients change; the ring — the stream — goes on. */
+  inline void setFreq(double freq) {
+    _Fu = freq;
+    if (!_Fs) return;
+    if (!_plan) { _plan_(); return; }
+    std::vector<double> alpha(_order);
+    design::firLowPass(_order, _Fu, _Fs, alpha.data());
+    detail::configCheck(sdrhip_fir_set_taps(_plan, alpha.data()), "FIRLowPass");
+  }
 
   virtual void config(const Config &src_cfg) {
     if (!src_cfg.hasType() || !src_cfg.hasSampleRate() || !src_cfg.hasBufferSize()) return;
@@ -766,8 +800,10 @@ template <> struct FftConvApi<double> {
 };
 }  // namespace detail
 
-/** Drop-in for sdr::FilterNode<Scalar>, Scalar = float or double (reference src/filternode.hh:230-284), any block size
- * whose FFT (2 x block_size points) has no prime factor above 13 (:235: `FilterNode(size_t block_size=1024)`). */
+/** Drop-in for sdr::FilterNode<Scalar>, Scalar = float or double (reference src/filternode.hh:230-284), ANY block size
+ * (:235: `FilterNode(size_t block_size=1024)`; FFTW plans any 2 x block_size): one launch per buffer where the transform
+ * fits a workgroup's LDS and is made of the factors 2 ... 13, passes over device memory around a four-step / chirp
+ * plan otherwise (csrc/fftany.hpp). */
 template <class Scalar>
 class FilterNode {
 public:
@@ -1085,13 +1121,14 @@ public:
 };
 
 /** FFTPlan<float> and FFTPlan<double>: same constructors and error texts as the FFTW-backed reference classes; the
- * transform is the library's own (unnormalised either way, like FFTW). Sizes: a power of two, up to 16384 (float) /
- * 8192 (double) — FFTW takes any size; a size the device plan cannot serve is a ConfigError at construction. */
+ * transform is the library's own (unnormalised either way, like FFTW), for ANY size. As in the reference the plan is made
+ * ONCE, in the constructor (src/fftplan_fftw3.hh:34-36,52-54: fftw_plan_dft_1d) — a size the device cannot plan is a
+ * ConfigError there — and operator() only executes it (:59); the destructor frees it (:64). */
 template <class Scalar>
 class FFTPlan {
 public:
   FFTPlan(const Buffer< std::complex<Scalar> > &in, const Buffer< std::complex<Scalar> > &out, FFT::Direction dir, int device = 0)
-    : _in(in), _out(out), _sign(dir == FFT::BACKWARD ? 1 : -1), _device(device) {
+    : _in(in), _out(out), _sign(dir == FFT::BACKWARD ? 1 : -1), _device(device), _plan(0) {
     if (in.size() != out.size()) {
       ConfigError err;
       err << "Can not construct FFT plan: input & output buffers are of different size!";
@@ -1102,44 +1139,42 @@ public:
       err << "Can not construct FFT plan: input or output buffer is empty!";
       throw err;
     }
-    _check();
+    _make();
   }
   FFTPlan(const Buffer< std::complex<Scalar> > &inplace, FFT::Direction dir, int device = 0)
-    : _in(inplace), _out(inplace), _sign(dir == FFT::BACKWARD ? 1 : -1), _device(device) {
+    : _in(inplace), _out(inplace), _sign(dir == FFT::BACKWARD ? 1 : -1), _device(device), _plan(0) {
     if (inplace.isEmpty()) {
       ConfigError err;
       err << "Can not construct FFT plan: Buffer is empty!";
       throw err;
     }
-    _check();
+    _make();
   }
-  virtual ~FFTPlan() {}
+  virtual ~FFTPlan() { if (_plan) sdrhip_fft_plan_destroy(_plan); }
   /** Performs the transformation. */
   void operator() () {
-    detail::configCheck(sdrhip_fft_exec(Device::get(_device), _dtype(), int(_in.size()), _sign, _in.data(), _out.data()), "FFT plan");
+    detail::configCheck(sdrhip_fft_plan_exec(_plan, _sign, _in.data(), _out.data()), "FFT plan");
   }
+  /** Which device plan serves this size ("radix-16 lds", "lds", "four-step", "chirp", ...). */
+  const char *form() const { const char *s = ""; sdrhip_fft_plan_form(_plan, &s); return s; }
 
 protected:
   static int _dtype() { return sizeof(Scalar) == 8 ? SDRHIP_T_CF64 : SDRHIP_T_CF32; }
-  void _check() const {
-    // any size the device plans (csrc/fftgen.hpp): sizes made of the prime factors 2 ... 13 of any length (one workgroup's
-    // LDS up to nmax points, the four-step plan n1 x n2 beyond), and sizes with a larger prime factor up to nmax / 2
-    // (Bluestein's chirp transform over the next power of two >= 2n - 1)
-    const size_t n = _in.size(), nmax = sizeof(Scalar) == 8 ? 8192 : 16384;
-    size_t rest = n;
-    const size_t primes[] = {2, 3, 5, 7, 11, 13};
-    for (size_t q = 0; q < 6 && rest > 1; q++) while (rest % primes[q] == 0) rest /= primes[q];
-    size_t chirp = 1;
-    while (chirp < 2 * n - 1) chirp <<= 1;
-    if (n < 1 || (rest == 1 ? n > nmax * nmax : chirp > nmax)) {
+  void _make() {
+    if (_in.size() > (size_t(1) << 27)) {
       ConfigError err;
-      err << "Can not construct FFT plan: the device plans sizes made of the prime factors 2 ... 13, and sizes with a larger prime factor up to "
-          << nmax / 2 << " points, got " << n;
+      err << "Can not construct FFT plan: " << _in.size() << " points exceed the device plans (2^27)";
       throw err;
     }
+    detail::configCheck(sdrhip_fft_plan_create(Device::get(_device), _dtype(), int(_in.size()), &_plan), "FFT plan");
   }
   Buffer< std::complex<Scalar> > _in, _out;
   int _sign, _device;
+  sdrhip_fft_plan *_plan;
+
+private:
+  FFTPlan(const FFTPlan &);              // (owns a device plan)
+  FFTPlan &operator=(const FFTPlan &);
 };
 
 }  // namespace gpu

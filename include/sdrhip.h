@@ -251,6 +251,9 @@ int sdrhip_fir_process(sdrhip_fir *h, const void *in_host, size_t n_in, size_t i
                        size_t out_stride, size_t *n_out);
 int sdrhip_fir_process_dev(sdrhip_fir *h, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev,
                            size_t out_stride, size_t *n_out);
+/* New coefficients for the SAME order between calls: FIRFilter::setLowerFreq / setUpperFreq (FIRLowPass::setFreq) only
+ * recompute _alpha — the ring, and with it the stream, goes on (reference src/firfilter.hh:155-170,287). `alpha`: order doubles. */
+int sdrhip_fir_set_taps(sdrhip_fir *h, const double *alpha);
 int sdrhip_fir_reset(sdrhip_fir *h); /* ring zeroed, as FIRFilter::config does (:193-195) */
 int sdrhip_fir_destroy(sdrhip_fir *h);
 
@@ -332,13 +335,15 @@ int sdrhip_fftconv_process_dev(sdrhip_fftconv *h, const float *in_dev, size_t n_
 int sdrhip_fftconv_reset(sdrhip_fftconv *h);
 int sdrhip_fftconv_destroy(sdrhip_fftconv *h);
 /* FFT sizes: the reference plans ANY size (FilterNode(size_t block_size = 1024), src/filternode.hh:235-245;
- * fftw_plan_dft_1d(in.size(), ...), src/fftplan_fftw3.hh:34-36). Powers of two from 4 to 16384 run the tuned complex<float>
- * kernels (every BASELINE configuration); any other fft_size whose prime factors are 2, 3, 5, 7, 11 or 13 — and every size in
- * complex<double> — runs the general in-LDS mixed-radix plan (csrc/fftgen.hpp; one transform must fit one workgroup's LDS:
- * up to 16384 points in float, 8192 in double). sdrhip_fft_c2c / _f64 / sdrhip_fft_exec also take LONGER transforms of such
- * factors (the four-step plan n = n1 x n2 through a temporary in device memory) and sizes with LARGER prime
- * factors (Bluestein's chirp transform over the next power of two >= 2n - 1: n up to 8192 in float, 4096 in double); the
- * filter (sdrhip_fftconv_*) answers SDRHIP_E_UNSUPPORTED for such an fft_size.
+ * fftw_plan_dft_1d(in.size(), ...), src/fftplan_fftw3.hh:34-36), and so do these entry points, the filter included:
+ *   - powers of two from 4 to 16384 in complex<float>: the tuned radix-16 kernels (every BASELINE configuration);
+ *   - any other fft_size made of the prime factors 2 ... 13 that fits one workgroup's LDS (16384 points in float, 8192 in
+ *     double): the general in-LDS mixed-radix plan (csrc/fftgen.hpp), one launch per call;
+ *   - every other size (csrc/fftany.hpp): longer transforms by the four-step plan n = n1 x n2 through device memory, sizes
+ *     with a prime factor above 13 by Bluestein's chirp transform over the next power of two >= 2n - 1 (in LDS, or over a
+ *     four-step plan beyond it); the filter then runs as passes over device memory (gather blocks, forward transforms,
+ *     per band: spectrum product, backward transforms, scatter) — FilterNode<float>(16384), (12000), (1009),
+ *     FilterNode<double>(8192) ... Limit: 2^27 points (2^25 with a large prime factor).
  *
  * FilterNode<double> (the filter classes are templates over Scalar, src/filternode.hh:30-32,102-104,230-232): the same
  * plan on complex<double> buffers; kernels / spectra are doubles (sdrhip_design_fftfilt_*_f64). bands / reset / destroy
@@ -360,6 +365,19 @@ int sdrhip_fft_c2c_f64(sdrhip_ctx *ctx, int n, int sign, int batch, const double
  * dtype SDRHIP_T_CF32 or SDRHIP_T_CF64, sign -1 = FFT::FORWARD, +1 = FFT::BACKWARD, unnormalised like FFTW. in == out
  * (the in-place plan) is allowed. */
 int sdrhip_fft_exec(sdrhip_ctx *ctx, int dtype, int n, int sign, const void *in_host, void *out_host);
+/* FFTPlan<Scalar> as the reference builds it: PLANNED ONCE in the constructor (fftw_plan_dft_1d, src/fftplan_fftw3.hh:34-36,
+ * 52-54,102-104,120-122), executed by operator() (fftw_execute, :59,127), destroyed with the object (:64,132). The plan
+ * owns its tables (roots, permutation, chirp, twiddles) and scratch on the context's device. `form` names what was
+ * planned: "radix-16 lds", "radix-2 lds (double)", "lds", "four-step", "chirp", "chirp over four-step". exec_dev:
+ * `batch` contiguous transforms of n points in device memory, asynchronous on the context's stream, in == out allowed;
+ * exec: one transform on host buffers (FFTPlan::operator()), returns when out_host is written. The one-shot calls above
+ * keep such plans in the context, keyed by (dtype, n). */
+typedef struct sdrhip_fft_plan sdrhip_fft_plan;
+int sdrhip_fft_plan_create(sdrhip_ctx *ctx, int dtype, int n, sdrhip_fft_plan **out);
+int sdrhip_fft_plan_form(sdrhip_fft_plan *p, const char **name);
+int sdrhip_fft_plan_exec_dev(sdrhip_fft_plan *p, int sign, int batch, const void *in_dev, void *out_dev);
+int sdrhip_fft_plan_exec(sdrhip_fft_plan *p, int sign, const void *in_host, void *out_host);
+int sdrhip_fft_plan_destroy(sdrhip_fft_plan *p);
 
 /* ---- float baseband (BASELINE config 2; build-defined) ---------------------- */
 /* y = SubSample_D( FIR_cf32( x[n] * exp(-2*pi*i*Fc*n/Fs) ) ); the reference has no float
@@ -372,6 +390,13 @@ int sdrhip_fbb_f32_process(sdrhip_fbb_f32 *h, const float *in_host, size_t n_in,
                            float *out_host, size_t out_stride, size_t *n_out);
 int sdrhip_fbb_f32_process_dev(sdrhip_fbb_f32 *h, const float *in_dev, size_t n_in, size_t in_stride,
                                float *out_dev, size_t out_stride, size_t *n_out);
+/* Setters that keep the stream going (same order, decimation and buffer size: no new plan). set_taps: new low-pass
+ * coefficients (`order` doubles) — what IQBaseBand::setFilterWidth / setFilterFrequency do to the kernel, the ring kept
+ * (reference src/baseband.hh:88-101). set_shift: a new centre frequency; the phasor restarts at the current sample,
+ * exp(-2 pi i Fc (n - n_now) / Fs), as setCenterFrequency -> _update_lut_incr restarts the LUT counter (src/baseband.hh:82-86,
+ * src/freqshift.hh:78-87); FIR history (raw input samples), decimator phase and sample counter go on. */
+int sdrhip_fbb_f32_set_taps(sdrhip_fbb_f32 *h, const double *alpha);
+int sdrhip_fbb_f32_set_shift(sdrhip_fbb_f32 *h, double Fc);
 int sdrhip_fbb_f32_reset(sdrhip_fbb_f32 *h);
 int sdrhip_fbb_f32_destroy(sdrhip_fbb_f32 *h);
 

@@ -100,6 +100,7 @@ def lib():
             "sdrhip_fir_process": (C.c_int, [vp, vp, sz, sz, vp, sz, psz]),
             "sdrhip_fir_process_dev": (C.c_int, [vp, vp, sz, sz, vp, sz, psz]),
             "sdrhip_fir_reset": (C.c_int, [vp]),
+            "sdrhip_fir_set_taps": (C.c_int, [vp, f64p]),
             "sdrhip_fir_destroy": (C.c_int, [vp]),
             "sdrhip_demod_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, sz, C.c_int, pvp]),
             "sdrhip_demod_process": (C.c_int, [vp, vp, sz, sz, vp, sz]),
@@ -134,6 +135,8 @@ def lib():
             "sdrhip_fbb_f32_process": (C.c_int, [vp, vp, sz, sz, vp, sz, psz]),
             "sdrhip_fbb_f32_process_dev": (C.c_int, [vp, vp, sz, sz, vp, sz, psz]),
             "sdrhip_fbb_f32_reset": (C.c_int, [vp]),
+            "sdrhip_fbb_f32_set_taps": (C.c_int, [vp, f64p]),
+            "sdrhip_fbb_f32_set_shift": (C.c_int, [vp, C.c_double]),
             "sdrhip_fbb_f32_destroy": (C.c_int, [vp]),
             "sdrhip_fftconv_create_bank": (C.c_int, [vp, C.c_int, C.c_int, f32p, C.c_int, C.c_int, C.c_int, sz, pvp]),
             "sdrhip_fftconv_bands": (C.c_int, [vp, C.POINTER(C.c_int)]),
@@ -144,6 +147,11 @@ def lib():
             "sdrhip_fftconv_f64_set_kernel": (C.c_int, [vp, C.c_int, f64p]),
             "sdrhip_fftconv_f64_process": (C.c_int, [vp, vp, sz, sz, vp, sz]),
             "sdrhip_fftconv_f64_process_dev": (C.c_int, [vp, vp, sz, sz, vp, sz]),
+            "sdrhip_fft_plan_create": (C.c_int, [vp, C.c_int, C.c_int, pvp]),
+            "sdrhip_fft_plan_form": (C.c_int, [vp, C.POINTER(C.c_char_p)]),
+            "sdrhip_fft_plan_exec_dev": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
+            "sdrhip_fft_plan_exec": (C.c_int, [vp, C.c_int, vp, vp]),
+            "sdrhip_fft_plan_destroy": (C.c_int, [vp]),
             "sdrhip_comm_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, pvp]),
             "sdrhip_comm_size": (C.c_int, [vp, C.POINTER(C.c_int)]),
             "sdrhip_comm_ctx": (C.c_int, [vp, C.c_int, pvp]),

@@ -149,6 +149,7 @@ int sdrhip_ctx_destroy(sdrhip_ctx *ctx) {
     if (!ctx) return;
     ctx->use();
     (void)hipStreamSynchronize(ctx->stream);
+    ctx->cache.clear();
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
   });

@@ -97,6 +97,22 @@ int sdrhip_fbb_f32_process(sdrhip_fbb_f32 *h, const float *in_host, size_t n_in,
   });
 }
 
+int sdrhip_fbb_f32_set_taps(sdrhip_fbb_f32 *h, const double *alpha) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h && alpha, SDRHIP_E_INVALID, "NULL argument");
+    const int rc = sdrhip_fir_set_taps(h->fir, alpha);
+    if (rc != SDRHIP_OK) throw Failure{rc};
+  });
+}
+
+int sdrhip_fbb_f32_set_shift(sdrhip_fbb_f32 *h, double Fc) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
+    h->fc = Fc;
+    fir_set_shift(h->fir, Fc, h->fs);   // the phasor restarts at the current sample; history and decimator go on
+  });
+}
+
 int sdrhip_fbb_f32_reset(sdrhip_fbb_f32 *h) {
   return guarded([&] {
     SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");

@@ -21,6 +21,7 @@
 #include <memory>
 
 #include "fftgen.hpp"
+#include "fftany.hpp"
 
 using namespace sdrhip;
 
@@ -807,8 +808,19 @@ void allow_big_lds(K kernel, size_t bytes) {
 
 // The general plan (fftgen.hpp) behind the same handle: any FFT size made of the factors 2 ... 13 in complex<float>, and
 // every size in complex<double> (FilterNode<double>, FFTPlan<double>). Same overlap-save evaluation, same state rules.
+// what the handle holds for every plan other than the tuned power-of-two complex<float> one
+struct ConvAny {
+  bool f64 = false;
+  virtual ~ConvAny() {}
+  virtual void load_kernel(int band, const void *kernel) = 0;
+  virtual void process_dev(const void *in_dev, size_t n_in, size_t in_stride, void *out_dev, size_t out_stride) = 0;
+  virtual void process(const void *in_host, size_t n_in, size_t in_stride, void *out_host, size_t out_stride) = 0;
+  virtual void reset() = 0;
+  virtual const char *kernel_names() const = 0;
+};
+
 template <class T2>
-struct GenConv {
+struct GenConv : ConvAny {
   typedef typename fftgen::Real<T2>::type R;
   sdrhip_ctx *ctx = nullptr;
   int mode = 0, C = 1, B = 1, hop = 0, HH = 0, par = 0, n_taps = 0;
@@ -818,7 +830,7 @@ struct GenConv {
   static constexpr size_t kMaxLds = 160 * 1024;
 
   void create(sdrhip_ctx *ctx_, int mode_, int L, const R *kernels, int n_taps_, int n_bands, int channels, size_t max_in_) {
-    ctx = ctx_; mode = mode_; C = channels; B = n_bands; max_in = max_in_;
+    ctx = ctx_; mode = mode_; C = channels; B = n_bands; max_in = max_in_; f64 = sizeof(R) == 8;
     plan.build(ctx, L, (int)(128 * 1024 / sizeof(T2)));
     if (mode == SDRHIP_FFTCONV_OLA) {
       SDRHIP_REQUIRE(L % 2 == 0, SDRHIP_E_INVALID, "overlap-add mode: fft_size %d must be 2N", L);
@@ -890,15 +902,171 @@ struct GenConv {
     copy_d2h_rows(ctx, out_host, out_stride * eb, stage_out.p, n_in * eb, n_in * eb, (size_t)B * C);
     SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   }
-  void reset() { ctx->use(); for (int p = 0; p < 2; p++) hist[p].zero(ctx->stream); }
+  void reset() override { ctx->use(); for (int p = 0; p < 2; p++) hist[p].zero(ctx->stream); }
+  void load_kernel(int band, const void *kernel) override { load_kernel(band, static_cast<const R *>(kernel)); }
+  void process_dev(const void *in_dev, size_t n_in, size_t in_stride, void *out_dev, size_t out_stride) override {
+    process_dev(static_cast<const R *>(in_dev), n_in, in_stride, static_cast<R *>(out_dev), out_stride); }
+  void process(const void *in_host, size_t n_in, size_t in_stride, void *out_host, size_t out_stride) override {
+    process(static_cast<const R *>(in_host), n_in, in_stride, static_cast<R *>(out_host), out_stride); }
+  const char *kernel_names() const override { return "conv_kernel"; }
+};
+
+// ---- the FFT filter for transforms that do NOT fit one workgroup's LDS, or whose size has a prime factor above 13 ------
+// (FilterNode<float>(16384), (12000), (1009), FilterNode<double>(8192), ...: the reference plans any 2 x block_size,
+// src/filternode.hh:236-245, src/fftplan_fftw3.hh:34-36). Same overlap-save evaluation and state rules as above, as passes
+// over device memory around one AnyFft plan (fftany.hpp: four-step beyond the LDS, Bluestein's chirp transform for large
+// primes): gather the blocks (history | input, zero beyond the call) -> forward transforms -> per band: spectrum product,
+// backward transforms, scatter of each block's last `hop` results. Channels go through in groups that keep the two block
+// images under kScratchBytes. Generality, not a BASELINE figure: every pass streams through HBM.
+template <class T2>
+__global__ void big_gather_kernel(const T2 *in, long in_stride, const T2 *hist, int HH, int N, int hop, long L, int nblk, T2 *X) {
+  const long blk = blockIdx.y, c = blockIdx.z;
+  const long first = blk * hop - HH;   // call-relative index of the block's first sample
+  T2 *dst = X + (c * nblk + blk) * L;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (long)gridDim.x * blockDim.x) {
+    const long rel = first + i;
+    T2 v = fftgen::mk<T2>(0, 0);
+    if (rel >= 0) { if (rel < N) v = in[c * in_stride + rel]; }
+    else { const long h = HH + rel; if (h >= 0) v = hist[c * HH + h]; }
+    dst[i] = v;
+  }
+}
+template <class T2>
+__global__ void big_mul_kernel(long L, const T2 *spec, const T2 *X, T2 *Y) {   // Y[b][k] = X[b][k] spec[k] (natural order, spec pre-scaled by 1 / L)
+  const long b = blockIdx.y;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (long)gridDim.x * blockDim.x) Y[b * L + i] = fftgen::gmul(X[b * L + i], spec[i]);
+}
+template <class T2>
+__global__ void big_scatter_kernel(const T2 *Y, long L, int HH, int hop, int N, int nblk, T2 *out, long out_stride) {
+  const long blk = blockIdx.y, c = blockIdx.z;
+  const T2 *src = Y + (c * nblk + blk) * L + HH;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < hop; i += (long)gridDim.x * blockDim.x) {
+    const long o = blk * hop + i;
+    if (o < N) out[c * out_stride + o] = src[i];
+  }
+}
+template <class T2>
+__global__ void big_hist_kernel(const T2 *in, long in_stride, const T2 *hist, T2 *hist_new, int HH, int N) {
+  const long c = blockIdx.y;
+  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < HH; k += (long)gridDim.x * blockDim.x) {
+    const long qq = (long)N + k;
+    hist_new[c * HH + k] = qq < HH ? hist[c * HH + qq] : in[c * in_stride + (qq - HH)];
+  }
+}
+
+template <class T2>
+struct BigConv : ConvAny {
+  typedef typename fftgen::Real<T2>::type R;
+  sdrhip_ctx *ctx = nullptr;
+  int mode = 0, C = 1, B = 1, hop = 0, HH = 0, par = 0, n_taps = 0;
+  long L = 0;
+  size_t max_in = 0;
+  fftany::AnyFft<T2> fft;
+  DevBuf<T2> Kp, hist[2], X, Y, stage_in, stage_out;
+  int group = 1;   // channels per pass
+  static constexpr size_t kScratchBytes = (size_t)1 << 30;
+
+  void create(sdrhip_ctx *ctx_, int mode_, int L_, const R *kernels, int n_taps_, int n_bands, int channels, size_t max_in_) {
+    ctx = ctx_; mode = mode_; C = channels; B = n_bands; max_in = max_in_; L = L_; f64 = sizeof(R) == 8;
+    SDRHIP_REQUIRE(L >= 2, SDRHIP_E_INVALID, "fft_size %ld", L);
+    if (mode == SDRHIP_FFTCONV_OLA) {
+      SDRHIP_REQUIRE(L % 2 == 0, SDRHIP_E_INVALID, "overlap-add mode: fft_size %ld must be 2N", L);
+      hop = (int)(L / 2); n_taps = (int)(L / 2);
+    } else {
+      SDRHIP_REQUIRE(n_taps_ >= 1 && n_taps_ <= L, SDRHIP_E_INVALID, "n_taps %d outside [1,%ld]", n_taps_, L);
+      hop = (int)(L - n_taps_ + 1); n_taps = n_taps_;
+    }
+    HH = (int)(L - hop);
+    fft.build(ctx, L);
+    const size_t nblk = ceil_div(max_in, (size_t)hop);
+    group = (int)std::max<size_t>(1, std::min<size_t>((size_t)C, kScratchBytes / (2 * nblk * (size_t)L * sizeof(T2))));
+    group = std::min(group, 65535);
+    X.alloc((size_t)group * nblk * L); Y.alloc((size_t)group * nblk * L);
+    fft.reserve((long)((size_t)group * nblk));
+    Kp.alloc((size_t)L * B);
+    const size_t per_band = mode == SDRHIP_FFTCONV_OLA ? (size_t)2 * L : (size_t)2 * n_taps;
+    for (int b = 0; b < B; b++) load_kernel_t(b, kernels + (size_t)b * per_band);
+    for (int p = 0; p < 2; p++) { hist[p].alloc((size_t)C * std::max(1, HH)); hist[p].zero(ctx->stream); }
+    SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  void load_kernel_t(int band, const R *kernel) {
+    std::vector< std::complex<double> > spec((size_t)L, std::complex<double>(0, 0));
+    if (mode == SDRHIP_FFTCONV_OLA) {
+      for (long i = 0; i < L; i++) spec[i] = std::complex<double>(kernel[2 * i], kernel[2 * i + 1]);
+    } else {
+      for (int i = 0; i < n_taps; i++) spec[i] = std::complex<double>(kernel[2 * i], kernel[2 * i + 1]);
+      fftgen::host_dft(spec, -1);
+    }
+    std::vector<T2> kp((size_t)L);
+    for (long k = 0; k < L; k++) { const std::complex<double> v = spec[k] / (double)L; kp[k].x = (R)v.real(); kp[k].y = (R)v.imag(); }
+    SDRHIP_CHECK_HIP(hipMemcpyAsync(Kp.p + (size_t)band * L, kp.data(), (size_t)L * sizeof(T2), hipMemcpyHostToDevice, ctx->stream));
+    SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  void load_kernel(int band, const void *kernel) override { load_kernel_t(band, static_cast<const R *>(kernel)); }
+  void launch(const T2 *in_dev, size_t N, size_t in_stride, T2 *out_dev, size_t out_stride, size_t out_band) {
+    ctx->use();
+    if (N == 0) return;
+    hipStream_t st = ctx->stream;
+    const int nblk = (int)ceil_div(N, (size_t)hop);
+    const unsigned gx = (unsigned)std::min<long>((L + 255) / 256, 1024);
+    for (int c0 = 0; c0 < C; c0 += group) {
+      const int cg = std::min(group, C - c0);
+      const long batch = (long)cg * nblk;
+      hipLaunchKernelGGL(big_gather_kernel<T2>, dim3(gx, nblk, cg), dim3(256), 0, st, in_dev + (size_t)c0 * in_stride, (long)in_stride,
+                         hist[par].p + (size_t)c0 * HH, HH, (int)N, hop, L, nblk, X.p);
+      fft.exec(-1, batch, X.p, X.p);
+      for (int band = 0; band < B; band++) {
+        for (long z0 = 0; z0 < batch; z0 += 32768) {
+          const long zb = std::min<long>(32768, batch - z0);
+          hipLaunchKernelGGL(big_mul_kernel<T2>, dim3(gx, (unsigned)zb), dim3(256), 0, st, L, Kp.p + (size_t)band * L, X.p + z0 * L, Y.p + z0 * L);
+        }
+        fft.exec(+1, batch, Y.p, Y.p);
+        hipLaunchKernelGGL(big_scatter_kernel<T2>, dim3((unsigned)std::min<long>((hop + 255) / 256, 1024), nblk, cg), dim3(256), 0, st, Y.p, L, HH, hop, (int)N, nblk,
+                           out_dev + (size_t)band * out_band + (size_t)c0 * out_stride, (long)out_stride);
+      }
+    }
+    if (HH > 0) {
+      hipLaunchKernelGGL(big_hist_kernel<T2>, dim3((unsigned)std::min<long>((HH + 255) / 256, 1024), C), dim3(256), 0, st, in_dev, (long)in_stride,
+                         hist[par].p, hist[par ^ 1].p, HH, (int)N);
+      par ^= 1;
+    }
+    SDRHIP_CHECK_HIP(hipGetLastError());
+  }
+  void process_dev(const void *in_dev, size_t n_in, size_t in_stride, void *out_dev, size_t out_stride) override {
+    SDRHIP_REQUIRE(n_in <= max_in, SDRHIP_E_SIZE, "n_in %zu > max_in %zu", n_in, max_in);
+    if (n_in == 0) return;
+    SDRHIP_REQUIRE(in_dev && out_dev, SDRHIP_E_INVALID, "NULL buffer");
+    if (in_stride == 0) in_stride = n_in;
+    if (out_stride == 0) out_stride = n_in;
+    SDRHIP_REQUIRE(in_stride >= n_in && out_stride >= n_in, SDRHIP_E_SIZE, "stride smaller than n_in");
+    require_disjoint(in_dev, in_stride, n_in, sizeof(T2), out_dev, out_stride, n_in, sizeof(T2), (size_t)C, (size_t)C * B);
+    launch(static_cast<const T2 *>(in_dev), n_in, in_stride, static_cast<T2 *>(out_dev), out_stride, (size_t)C * out_stride);
+  }
+  void process(const void *in_host, size_t n_in, size_t in_stride, void *out_host, size_t out_stride) override {
+    SDRHIP_REQUIRE(n_in <= max_in, SDRHIP_E_SIZE, "n_in %zu > max_in %zu", n_in, max_in);
+    if (n_in == 0) return;
+    SDRHIP_REQUIRE(in_host && out_host, SDRHIP_E_INVALID, "NULL buffer");
+    ctx->use();
+    if (in_stride == 0) in_stride = n_in;
+    if (out_stride == 0) out_stride = n_in;
+    SDRHIP_REQUIRE(in_stride >= n_in && out_stride >= n_in, SDRHIP_E_SIZE, "stride smaller than n_in");
+    if (!stage_in.p) { stage_in.alloc((size_t)C * max_in); stage_out.alloc((size_t)B * C * max_in); }
+    const size_t eb = sizeof(T2);
+    copy_h2d_rows(ctx, stage_in.p, n_in * eb, in_host, in_stride * eb, n_in * eb, C);
+    launch(stage_in.p, n_in, n_in, stage_out.p, n_in, (size_t)C * n_in);
+    copy_d2h_rows(ctx, out_host, out_stride * eb, stage_out.p, n_in * eb, n_in * eb, (size_t)B * C);
+    SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  void reset() override { ctx->use(); for (int p = 0; p < 2; p++) hist[p].zero(ctx->stream); }
+  const char *kernel_names() const override { return "big_gather_kernel,fft passes,big_mul_kernel,big_scatter_kernel"; }
 };
 
 }  // namespace
 
 struct sdrhip_fftconv {
   sdrhip_ctx *ctx = nullptr;
-  std::unique_ptr< GenConv<float2> > g32;    // the general plan in complex<float> (FFT sizes that are not powers of two)
-  std::unique_ptr< GenConv<double2> > g64;   // complex<double> (every size)
+  std::unique_ptr<ConvAny> any;   // every plan but the tuned power-of-two complex<float> one: GenConv (one transform in one workgroup's
+                                  // LDS, factors 2 ... 13) or BigConv (any size: four-step / chirp passes), float or double
   int mode = 0, C = 1, hop = 0, HH = 0, par = 0;
   int B = 1;            // bands of the bank (spectra sharing one forward transform)
   int n_taps = 0;
@@ -1015,97 +1183,90 @@ struct sdrhip_fftconv {
   }
 };
 
-namespace {
-// a transform longer than one workgroup's LDS holds, n = n1 * n2 with both factors plannable in LDS: the four-step plan
-// (fftgen::strided_c2c_kernel twice, a temporary of n elements between them). false: n has no such factorisation.
-template <class T2>
-bool four_step_c2c(sdrhip_ctx *ctx, long n, int sign, int batch, const void *in_dev, void *out_dev) {
-  typedef typename fftgen::Real<T2>::type R;
-  const long maxL = (long)(128 * 1024 / sizeof(T2));
-  long n1 = 0;
-  for (long d = maxL; d >= 2 && !n1; d--) {   // the largest plannable divisor whose cofactor is plannable too
-    if (n % d || n / d > maxL) continue;
-    std::vector<int> rx;
-    if (fftgen::GenPlan<T2>::factor((int)d, rx, nullptr) && fftgen::GenPlan<T2>::factor((int)(n / d), rx, nullptr)) n1 = d;
+// ---- FFTPlan<float|double>: planned once, executed many times (reference src/fftplan_fftw3.hh:14-36,82-104: the
+// plan is made in the constructor, operator() only executes) -------------------------------------------------------
+struct sdrhip_fft_plan {
+  sdrhip_ctx *ctx = nullptr;
+  int dtype = SDRHIP_T_CF32, n = 0;
+  std::unique_ptr<FftPlan> p32;                            // complex<float>, a power of two in [4, 16384]: the tuned radix-16 kernel
+  DevBuf<double2> W64; int lg64 = 0;                       // complex<double>, a power of two in [2, 8192]
+  std::unique_ptr< fftany::AnyFft<float2> > a32;           // any other size (fftany.hpp)
+  std::unique_ptr< fftany::AnyFft<double2> > a64;
+  DevBuf<char> stage_in, stage_out;                        // exec() on host buffers
+  size_t elem() const { return dtype == SDRHIP_T_CF64 ? 16 : 8; }
+  const char *form() const {
+    return p32 ? "radix-16 lds" : W64.p ? "radix-2 lds (double)" : a32 ? a32->kind_name() : a64 ? a64->kind_name() : "?";
   }
-  if (!n1) return false;
-  const long n2 = n / n1;
-  fftgen::GenPlan<T2> p1, p2;
-  p1.build(ctx, (int)n1, (int)maxL); p2.build(ctx, (int)n2, (int)maxL);
-  const long double PI2 = 2.0L * 3.14159265358979323846264338327950288L;
-  std::vector<T2> wa(n1), wb(n2);   // W_n^(a n2) = W_n1^a and W_n^b (forward sign; the kernel conjugates for the backward transform)
-  for (long a = 0; a < n1; a++) { const long double ang = -PI2 * (long double)a / (long double)n1; wa[a].x = (R)cosl(ang); wa[a].y = (R)sinl(ang); }
-  for (long b = 0; b < n2; b++) { const long double ang = -PI2 * (long double)b / (long double)n; wb[b].x = (R)cosl(ang); wb[b].y = (R)sinl(ang); }
-  DevBuf<T2> wad, wbd, tmp;
-  wad.alloc(n1); wad.upload(wa.data(), n1, ctx->stream);
-  wbd.alloc(n2); wbd.upload(wb.data(), n2, ctx->stream);
-  tmp.alloc((size_t)n);
-  allow_big_lds(fftgen::strided_c2c_kernel<T2, true>, p1.lds_bytes());
-  allow_big_lds(fftgen::strided_c2c_kernel<T2, false>, p2.lds_bytes());
-  for (int bt = 0; bt < batch; bt++) {
-    const T2 *src = reinterpret_cast<const T2 *>(in_dev) + (size_t)bt * n;
-    T2 *dst = reinterpret_cast<T2 *>(out_dev) + (size_t)bt * n;
-    // pass 1: column j2 (stride n2) -> A[k1][j2] = tmp[k1 n2 + j2], twiddled
-    hipLaunchKernelGGL((fftgen::strided_c2c_kernel<T2, true>), dim3((unsigned)n2), dim3(fftgen::GT), p1.lds_bytes(), ctx->stream, p1.dev, p1.perm_d.p,
-                       sign, src, n2, 1L, tmp.p, n2, 1L, wad.p, wbd.p, (int)n2);
-    // pass 2: row k1 of A -> X[k1 + n1 k2]
-    hipLaunchKernelGGL((fftgen::strided_c2c_kernel<T2, false>), dim3((unsigned)n1), dim3(fftgen::GT), p2.lds_bytes(), ctx->stream, p2.dev, p2.perm_d.p,
-                       sign, tmp.p, 1L, n2, dst, n1, 1L, wad.p, wbd.p, (int)n2);
-  }
-  SDRHIP_CHECK_HIP(hipGetLastError());
-  SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));   // the plans' tables and the temporary die with this scope
-  return true;
-}
-
-// a length with a prime factor above 13: Bluestein's chirp transform over a power-of-two plan of M >= 2n - 1 points
-template <class T2>
-void bluestein_c2c(sdrhip_ctx *ctx, int n, int sign, int batch, const void *in_dev, void *out_dev) {
-  typedef typename fftgen::Real<T2>::type R;
-  const int maxM = (int)(128 * 1024 / sizeof(T2));
-  int M = 1; while (M < 2 * n - 1) M <<= 1;
-  SDRHIP_REQUIRE(M <= maxM, SDRHIP_E_UNSUPPORTED,
-                 "FFT size %d has a prime factor above 13 and needs a chirp transform of %d points: more than one workgroup's LDS holds (%d)", n, M, maxM);
-  fftgen::GenPlan<T2> plan;
-  plan.build(ctx, M, maxM);
-  const long double PI = 3.14159265358979323846264338327950288L;
-  std::vector<T2> w(n);
-  std::vector< std::complex<double> > b(M, std::complex<double>(0, 0));
-  for (int j = 0; j < n; j++) {
-    const long double ang = (long double)sign * PI * (long double)(((long long)j * j) % (2LL * n)) / (long double)n;   // (j^2 mod 2n: the phase stays exact)
-    w[j].x = (R)cosl(ang); w[j].y = (R)sinl(ang);
-    const std::complex<double> cw((double)cosl(ang), -(double)sinl(ang));   // conj(w[j])
-    b[j] = cw;
-    if (j) b[M - j] = cw;
-  }
-  fftgen::host_dft(b, -1);
-  std::vector<T2> bs(M);
-  for (int pos = 0; pos < M; pos++) { const std::complex<double> v = b[plan.perm[pos]] / (double)M; bs[pos].x = (R)v.real(); bs[pos].y = (R)v.imag(); }
-  DevBuf<T2> wd, bd;
-  wd.alloc(n); wd.upload(w.data(), n, ctx->stream);
-  bd.alloc(M); bd.upload(bs.data(), M, ctx->stream);
-  allow_big_lds(fftgen::bluestein_kernel<T2>, plan.lds_bytes());
-  hipLaunchKernelGGL(fftgen::bluestein_kernel<T2>, dim3(batch), dim3(fftgen::GT), plan.lds_bytes(), ctx->stream, plan.dev, n, wd.p, bd.p,
-                     reinterpret_cast<const T2 *>(in_dev), reinterpret_cast<T2 *>(out_dev));
-  SDRHIP_CHECK_HIP(hipGetLastError());
-  SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));   // the tables die with this scope
-}
-
-template <class T2>
-void gen_c2c(sdrhip_ctx *ctx, int n, int sign, int batch, const void *in_dev, void *out_dev) {
-  {
-    std::vector<int> rx;
+  void build(sdrhip_ctx *ctx_, int dtype_, int n_) {
+    ctx = ctx_; dtype = dtype_; n = n_;
     SDRHIP_REQUIRE(n >= 1, SDRHIP_E_INVALID, "FFT size %d", n);
-    const int maxL = (int)(128 * 1024 / sizeof(T2));
-    if (n > maxL && four_step_c2c<T2>(ctx, n, sign, batch, in_dev, out_dev)) return;   // longer than the LDS holds: n = n1 * n2
-    if (!fftgen::GenPlan<T2>::factor(n, rx, nullptr)) { bluestein_c2c<T2>(ctx, n, sign, batch, in_dev, out_dev); return; }
+    ctx->use();
+    if (dtype == SDRHIP_T_CF32) {
+      if (is_pow2(n) && n >= 4 && n <= 16384) {
+        p32.reset(new FftPlan()); p32->build(ctx, n);
+        allow_big_lds(fft_c2c_kernel, p32->lds_bytes());
+      } else { a32.reset(new fftany::AnyFft<float2>()); a32->build(ctx, n); }
+    } else {
+      if (is_pow2(n) && n >= 2 && n <= 8192) {
+        while ((1 << lg64) < n) lg64++;
+        std::vector<double2> w(n / 2);
+        for (int k = 0; k < n / 2; k++) {
+          const long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)n;
+          w[k] = make_double2((double)cosl(ang), (double)sinl(ang));
+        }
+        W64.alloc(n / 2); W64.upload(w.data(), n / 2, ctx->stream);
+        allow_big_lds(fft_c2c_f64_kernel, (size_t)n * sizeof(double2));
+      } else { a64.reset(new fftany::AnyFft<double2>()); a64->build(ctx, n); }
+    }
   }
-  fftgen::GenPlan<T2> plan;
-  plan.build(ctx, n, (int)(128 * 1024 / sizeof(T2)));
-  allow_big_lds(fftgen::c2c_kernel<T2>, plan.lds_bytes());
-  hipLaunchKernelGGL(fftgen::c2c_kernel<T2>, dim3(batch), dim3(fftgen::GT), plan.lds_bytes(), ctx->stream, plan.dev, plan.perm_d.p, sign,
-                     reinterpret_cast<const T2 *>(in_dev), reinterpret_cast<T2 *>(out_dev));
-  SDRHIP_CHECK_HIP(hipGetLastError());
-  SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));   // the plan's tables die with this scope
+  // asynchronous on the context's stream; in == out allowed
+  void exec_dev(int sign, int batch, const void *in_dev, void *out_dev) {
+    ctx->use();
+    if (p32) {
+      hipLaunchKernelGGL(fft_c2c_kernel, dim3(batch), dim3(FT), p32->lds_bytes(), ctx->stream, p32->dev, p32->perm_d.p, sign,
+                         reinterpret_cast<const float2 *>(in_dev), reinterpret_cast<float2 *>(out_dev));
+    } else if (W64.p) {
+      hipLaunchKernelGGL(fft_c2c_f64_kernel, dim3(batch), dim3(FT), (size_t)n * sizeof(double2), ctx->stream, n, lg64, W64.p, sign,
+                         reinterpret_cast<const double2 *>(in_dev), reinterpret_cast<double2 *>(out_dev));
+    } else if (a32) {
+      a32->exec(sign, batch, reinterpret_cast<const float2 *>(in_dev), reinterpret_cast<float2 *>(out_dev));
+    } else {
+      a64->exec(sign, batch, reinterpret_cast<const double2 *>(in_dev), reinterpret_cast<double2 *>(out_dev));
+    }
+    SDRHIP_CHECK_HIP(hipGetLastError());
+  }
+};
+
+namespace {
+// the one-shot entry points (sdrhip_fft_c2c / _f64 / sdrhip_fft_exec) keep their plans in the context: (dtype, n) -> plan,
+// freed with the context
+sdrhip_fft_plan *cached_plan(sdrhip_ctx *ctx, int dtype, int n) {
+  const long long key = ((long long)dtype << 40) | (long long)(unsigned)n;
+  auto it = ctx->cache.find(key);
+  if (it != ctx->cache.end()) return static_cast<sdrhip_fft_plan *>(it->second.get());
+  std::unique_ptr<sdrhip_fft_plan> p(new sdrhip_fft_plan());
+  p->build(ctx, dtype, n);
+  if (ctx->cache.size() >= 64) ctx->cache.clear();   // (a sweep over many sizes: start over rather than hoard tables)
+  sdrhip_fft_plan *raw = p.release();
+  ctx->cache[key] = std::shared_ptr<void>(raw, [](void *q) { delete static_cast<sdrhip_fft_plan *>(q); });
+  return raw;
+}
+}  // namespace
+
+namespace {
+// GenConv where one transform fits one workgroup's LDS and has no prime factor above 13, BigConv for every other size
+template <class T2, class R>
+ConvAny *make_any_conv(sdrhip_ctx *ctx, int mode, int fft_size, const R *kernels, int n_taps, int n_bands, int channels, size_t max_in) {
+  std::vector<int> rx;
+  const long maxL = (long)(128 * 1024 / sizeof(T2));
+  if (fft_size >= 1 && fft_size <= maxL && fftgen::GenPlan<T2>::factor(fft_size, rx, nullptr)) {
+    std::unique_ptr< GenConv<T2> > g(new GenConv<T2>());
+    g->create(ctx, mode, fft_size, kernels, n_taps, n_bands, channels, max_in);
+    return g.release();
+  }
+  std::unique_ptr< BigConv<T2> > b(new BigConv<T2>());
+  b->create(ctx, mode, fft_size, kernels, n_taps, n_bands, channels, max_in);
+  return b.release();
 }
 }  // namespace
 
@@ -1124,9 +1285,8 @@ int sdrhip_fftconv_create_bank(sdrhip_ctx *ctx, int mode, int fft_size, const fl
     sdrhip_fftconv *h = new sdrhip_fftconv;
     try {
       h->ctx = ctx; h->mode = mode; h->C = channels; h->max_in = max_in; h->B = n_bands;
-      if (!is_pow2(fft_size) || fft_size < 4) {   // (FilterNode(size_t block_size) takes any block size: src/filternode.hh:235-245)
-        h->g32.reset(new GenConv<float2>());
-        h->g32->create(ctx, mode, fft_size, kernels, n_taps, n_bands, channels, max_in);
+      if (!is_pow2(fft_size) || fft_size < 4 || fft_size > 16384) {   // (FilterNode(size_t block_size) takes any block size: src/filternode.hh:235-245)
+        h->any.reset(make_any_conv<float2, float>(ctx, mode, fft_size, kernels, n_taps, n_bands, channels, max_in));
         *out = h;
         return;
       }
@@ -1164,10 +1324,10 @@ int sdrhip_fftconv_set_kernel(sdrhip_fftconv *h, int band, const float *kernel) 
   return guarded([&] {
     SDRHIP_REQUIRE(h && kernel, SDRHIP_E_INVALID, "NULL argument");
     SDRHIP_REQUIRE(band >= 0 && band < h->B, SDRHIP_E_INVALID, "band %d outside [0,%d)", band, h->B);
-    SDRHIP_REQUIRE(!h->g64, SDRHIP_E_INVALID, "a complex<double> plan: use sdrhip_fftconv_f64_set_kernel");
+    SDRHIP_REQUIRE(!(h->any && h->any->f64), SDRHIP_E_INVALID, "a complex<double> plan: use sdrhip_fftconv_f64_set_kernel");
     h->ctx->use();
     SDRHIP_CHECK_HIP(hipStreamSynchronize(h->ctx->stream));   // launches in flight still read the old spectrum
-    if (h->g32) { h->g32->load_kernel(band, kernel); return; }
+    if (h->any) { h->any->load_kernel(band, kernel); return; }
     h->load_kernel(band, kernel);
   });
 }
@@ -1177,8 +1337,8 @@ int sdrhip_fftconv_process_dev(sdrhip_fftconv *h, const float *in_dev, size_t n_
   return guarded([&] {
     Range roctx_range("sdrhip_fftconv_process_dev");
     SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
-    SDRHIP_REQUIRE(!h->g64, SDRHIP_E_INVALID, "a complex<double> plan: use sdrhip_fftconv_f64_process_dev");
-    if (h->g32) { h->g32->process_dev(in_dev, n_in, in_stride, out_dev, out_stride); return; }
+    SDRHIP_REQUIRE(!(h->any && h->any->f64), SDRHIP_E_INVALID, "a complex<double> plan: use sdrhip_fftconv_f64_process_dev");
+    if (h->any) { h->any->process_dev(in_dev, n_in, in_stride, out_dev, out_stride); return; }
     SDRHIP_REQUIRE(n_in <= h->max_in, SDRHIP_E_SIZE, "n_in %zu > max_in %zu", n_in, h->max_in);
     if (n_in == 0) return;
     SDRHIP_REQUIRE(in_dev && out_dev, SDRHIP_E_INVALID, "NULL buffer");
@@ -1196,8 +1356,8 @@ int sdrhip_fftconv_process(sdrhip_fftconv *h, const float *in_host, size_t n_in,
   return guarded([&] {
     Range roctx_range("sdrhip_fftconv_process");
     SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
-    SDRHIP_REQUIRE(!h->g64, SDRHIP_E_INVALID, "a complex<double> plan: use sdrhip_fftconv_f64_process");
-    if (h->g32) { h->g32->process(in_host, n_in, in_stride, out_host, out_stride); return; }
+    SDRHIP_REQUIRE(!(h->any && h->any->f64), SDRHIP_E_INVALID, "a complex<double> plan: use sdrhip_fftconv_f64_process");
+    if (h->any) { h->any->process(in_host, n_in, in_stride, out_host, out_stride); return; }
     SDRHIP_REQUIRE(n_in <= h->max_in, SDRHIP_E_SIZE, "n_in %zu > max_in %zu", n_in, h->max_in);
     if (n_in == 0) return;
     SDRHIP_REQUIRE(in_host && out_host, SDRHIP_E_INVALID, "NULL buffer");
@@ -1217,8 +1377,7 @@ int sdrhip_fftconv_reset(sdrhip_fftconv *h) {
   return guarded([&] {
     SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
     h->ctx->use();
-    if (h->g32) { h->g32->reset(); return; }
-    if (h->g64) { h->g64->reset(); return; }
+    if (h->any) { h->any->reset(); return; }
     for (int p = 0; p < 2; p++) h->hist[p].zero(h->ctx->stream);
   });
 }
@@ -1246,8 +1405,7 @@ int sdrhip_fftconv_f64_create_bank(sdrhip_ctx *ctx, int mode, int fft_size, cons
     sdrhip_fftconv *h = new sdrhip_fftconv;
     try {
       h->ctx = ctx; h->mode = mode; h->C = channels; h->max_in = max_in; h->B = n_bands;
-      h->g64.reset(new GenConv<double2>());
-      h->g64->create(ctx, mode, fft_size, kernels, n_taps, n_bands, channels, max_in);
+      h->any.reset(make_any_conv<double2, double>(ctx, mode, fft_size, kernels, n_taps, n_bands, channels, max_in));
     } catch (...) { delete h; throw; }
     *out = h;
   });
@@ -1255,50 +1413,84 @@ int sdrhip_fftconv_f64_create_bank(sdrhip_ctx *ctx, int mode, int fft_size, cons
 
 int sdrhip_fftconv_f64_set_kernel(sdrhip_fftconv *h, int band, const double *kernel) {
   return guarded([&] {
-    SDRHIP_REQUIRE(h && kernel && h->g64, SDRHIP_E_INVALID, "not a complex<double> plan");
+    SDRHIP_REQUIRE(h && kernel && h->any && h->any->f64, SDRHIP_E_INVALID, "not a complex<double> plan");
     SDRHIP_REQUIRE(band >= 0 && band < h->B, SDRHIP_E_INVALID, "band %d outside [0,%d)", band, h->B);
     h->ctx->use();
     SDRHIP_CHECK_HIP(hipStreamSynchronize(h->ctx->stream));
-    h->g64->load_kernel(band, kernel);
+    h->any->load_kernel(band, kernel);
   });
 }
 
 int sdrhip_fftconv_f64_process(sdrhip_fftconv *h, const double *in_host, size_t n_in, size_t in_stride, double *out_host, size_t out_stride) {
   return guarded([&] {
     Range roctx_range("sdrhip_fftconv_f64_process");
-    SDRHIP_REQUIRE(h && h->g64, SDRHIP_E_INVALID, "not a complex<double> plan");
-    h->g64->process(in_host, n_in, in_stride, out_host, out_stride);
+    SDRHIP_REQUIRE(h && h->any && h->any->f64, SDRHIP_E_INVALID, "not a complex<double> plan");
+    h->any->process(in_host, n_in, in_stride, out_host, out_stride);
   });
 }
 
 int sdrhip_fftconv_f64_process_dev(sdrhip_fftconv *h, const double *in_dev, size_t n_in, size_t in_stride, double *out_dev, size_t out_stride) {
   return guarded([&] {
     Range roctx_range("sdrhip_fftconv_f64_process_dev");
-    SDRHIP_REQUIRE(h && h->g64, SDRHIP_E_INVALID, "not a complex<double> plan");
-    h->g64->process_dev(in_dev, n_in, in_stride, out_dev, out_stride);
+    SDRHIP_REQUIRE(h && h->any && h->any->f64, SDRHIP_E_INVALID, "not a complex<double> plan");
+    h->any->process_dev(in_dev, n_in, in_stride, out_dev, out_stride);
   });
 }
 
 
+int sdrhip_fft_plan_create(sdrhip_ctx *ctx, int dtype, int n, sdrhip_fft_plan **out) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(ctx && out, SDRHIP_E_INVALID, "NULL argument");
+    *out = nullptr;
+    SDRHIP_REQUIRE(dtype == SDRHIP_T_CF32 || dtype == SDRHIP_T_CF64, SDRHIP_E_INVALID, "FFT dtype %d: complex<float> or complex<double>", dtype);
+    SDRHIP_REQUIRE(n >= 1, SDRHIP_E_INVALID, "FFT size %d", n);
+    std::unique_ptr<sdrhip_fft_plan> p(new sdrhip_fft_plan());
+    p->build(ctx, dtype, n);
+    *out = p.release();
+  });
+}
+
+int sdrhip_fft_plan_form(sdrhip_fft_plan *p, const char **name) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(p && name, SDRHIP_E_INVALID, "NULL argument");
+    *name = p->form();
+  });
+}
+
+int sdrhip_fft_plan_exec_dev(sdrhip_fft_plan *p, int sign, int batch, const void *in_dev, void *out_dev) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(p && in_dev && out_dev && batch >= 1 && (sign == 1 || sign == -1), SDRHIP_E_INVALID, "bad argument");
+    p->exec_dev(sign, batch, in_dev, out_dev);
+  });
+}
+
+int sdrhip_fft_plan_exec(sdrhip_fft_plan *p, int sign, const void *in_host, void *out_host) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(p && in_host && out_host && (sign == 1 || sign == -1), SDRHIP_E_INVALID, "bad argument");
+    p->ctx->use();
+    const size_t bytes = (size_t)p->n * p->elem();
+    if (!p->stage_in.p) { p->stage_in.alloc(bytes); p->stage_out.alloc(bytes); }
+    SDRHIP_CHECK_HIP(hipMemcpyAsync(p->stage_in.p, in_host, bytes, hipMemcpyHostToDevice, p->ctx->stream));
+    p->exec_dev(sign, 1, p->stage_in.p, p->stage_out.p);
+    SDRHIP_CHECK_HIP(hipMemcpyAsync(out_host, p->stage_out.p, bytes, hipMemcpyDeviceToHost, p->ctx->stream));
+    SDRHIP_CHECK_HIP(hipStreamSynchronize(p->ctx->stream));
+  });
+}
+
+int sdrhip_fft_plan_destroy(sdrhip_fft_plan *p) {
+  return guarded([&] {
+    if (!p) return;
+    p->ctx->use();
+    (void)hipStreamSynchronize(p->ctx->stream);
+    delete p;
+  });
+}
+
 int sdrhip_fft_c2c_f64(sdrhip_ctx *ctx, int n, int sign, int batch, const double *in_dev, double *out_dev) {
   return guarded([&] {
-    SDRHIP_REQUIRE(ctx && in_dev && out_dev && batch >= 1 && (sign == 1 || sign == -1), SDRHIP_E_INVALID, "bad argument");
-    ctx->use();
-    if (!is_pow2(n) || n < 2 || n > 8192) { gen_c2c<double2>(ctx, n, sign, batch, in_dev, out_dev); return; }   // the general plans: any size
-    int lg = 0; while ((1 << lg) < n) lg++;
-    std::vector<double2> w(n / 2);
-    for (int k = 0; k < n / 2; k++) {
-      const long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)n;
-      w[k] = make_double2((double)cosl(ang), (double)sinl(ang));
-    }
-    DevBuf<double2> W;
-    W.alloc(n / 2); W.upload(w.data(), n / 2, ctx->stream);
-    const size_t lds = (size_t)n * sizeof(double2);
-    allow_big_lds(fft_c2c_f64_kernel, lds);
-    hipLaunchKernelGGL(fft_c2c_f64_kernel, dim3(batch), dim3(FT), lds, ctx->stream, n, lg, W.p, sign,
-                       reinterpret_cast<const double2 *>(in_dev), reinterpret_cast<double2 *>(out_dev));
-    SDRHIP_CHECK_HIP(hipGetLastError());
-    SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));   // the table dies with this scope
+    SDRHIP_REQUIRE(ctx && in_dev && out_dev && batch >= 1 && n >= 1 && (sign == 1 || sign == -1), SDRHIP_E_INVALID, "bad argument");
+    cached_plan(ctx, SDRHIP_T_CF64, n)->exec_dev(sign, batch, in_dev, out_dev);
+    SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   });
 }
 
@@ -1306,32 +1498,17 @@ int sdrhip_fft_exec(sdrhip_ctx *ctx, int dtype, int n, int sign, const void *in_
   return guarded([&] {
     SDRHIP_REQUIRE(ctx && in_host && out_host, SDRHIP_E_INVALID, "NULL argument");
     SDRHIP_REQUIRE(dtype == SDRHIP_T_CF32 || dtype == SDRHIP_T_CF64, SDRHIP_E_INVALID, "FFT dtype %d: complex<float> or complex<double>", dtype);
-    ctx->use();
-    const size_t bytes = (size_t)n * (dtype == SDRHIP_T_CF64 ? 16 : 8);
-    DevBuf<char> din, dout;
-    din.alloc(bytes); dout.alloc(bytes);
-    SDRHIP_CHECK_HIP(hipMemcpyAsync(din.p, in_host, bytes, hipMemcpyHostToDevice, ctx->stream));
-    int rc;
-    if (dtype == SDRHIP_T_CF64) rc = sdrhip_fft_c2c_f64(ctx, n, sign, 1, reinterpret_cast<const double *>(din.p), reinterpret_cast<double *>(dout.p));
-    else rc = sdrhip_fft_c2c(ctx, n, sign, 1, reinterpret_cast<const float *>(din.p), reinterpret_cast<float *>(dout.p));
+    SDRHIP_REQUIRE(n >= 1 && (sign == 1 || sign == -1), SDRHIP_E_INVALID, "FFT size %d, sign %d", n, sign);
+    const int rc = sdrhip_fft_plan_exec(cached_plan(ctx, dtype, n), sign, in_host, out_host);
     if (rc != SDRHIP_OK) throw Failure{rc};   // (the message is already set)
-    SDRHIP_CHECK_HIP(hipMemcpyAsync(out_host, dout.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   });
 }
 
 int sdrhip_fft_c2c(sdrhip_ctx *ctx, int n, int sign, int batch, const float *in_dev, float *out_dev) {
   return guarded([&] {
-    SDRHIP_REQUIRE(ctx && in_dev && out_dev && batch >= 1 && (sign == 1 || sign == -1), SDRHIP_E_INVALID, "bad argument");
-    ctx->use();
-    if (!is_pow2(n) || n < 4 || n > 16384) { gen_c2c<float2>(ctx, n, sign, batch, in_dev, out_dev); return; }   // the general plans: any size
-    FftPlan plan;
-    plan.build(ctx, n);
-    allow_big_lds(fft_c2c_kernel, plan.lds_bytes());
-    hipLaunchKernelGGL(fft_c2c_kernel, dim3(batch), dim3(FT), plan.lds_bytes(), ctx->stream, plan.dev, plan.perm_d.p, sign,
-                       reinterpret_cast<const float2 *>(in_dev), reinterpret_cast<float2 *>(out_dev));
-    SDRHIP_CHECK_HIP(hipGetLastError());
-    SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));   // the plan's tables die with this scope
+    SDRHIP_REQUIRE(ctx && in_dev && out_dev && batch >= 1 && n >= 1 && (sign == 1 || sign == -1), SDRHIP_E_INVALID, "bad argument");
+    cached_plan(ctx, SDRHIP_T_CF32, n)->exec_dev(sign, batch, in_dev, out_dev);
+    SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   });
 }
 

@@ -272,6 +272,11 @@ struct GenPlan {
   DevBuf<int> perm_d;
   std::vector<int> perm;   // position -> frequency index after the forward DIF
 
+  static bool factor_long(long n) {   // made of 2, 3, 5, 7, 11, 13 only?
+    const long primes[] = {2, 3, 5, 7, 11, 13};
+    for (long q : primes) while (n > 1 && n % q == 0) n /= q;
+    return n == 1;
+  }
   static bool factor(int L, std::vector<int> &radix, int *bad) {
     radix.clear();
     int n = L;

@@ -637,6 +637,7 @@ struct sdrhip_fir {
   size_t lds3 = 0;
   // fused frequency shift (set by the float baseband)
   bool shift_on = false; double fc = 0, fs = 1;
+  long long phase0 = 0;   // absolute sample index at which the fused shift's phasor was last (re)started (set_shift)
   DevBuf<float2> etab, etab2, wtab, ptab;   // phase tables of the fused shift (see Fir32Args)
   DevBuf<float2> hist32[2];
   // staging
@@ -706,7 +707,7 @@ struct sdrhip_fir {
         const int tiles = (int)ceil_div(no, (size_t)TPB * R);
         a.p_in_args = 0; a.roll = M > 1 ? 1 : 0;
         if (shift_on) {   // sample 0 of tile t is absolute index n0 + first_rel - (M-1) + t * TPB*R*D
-          const long long n_first = (long long)n0 + a.first_rel - (M - 1), step = (long long)TPB * R * D;
+          const long long n_first = (long long)n0 - phase0 + a.first_rel - (M - 1), step = (long long)TPB * R * D;
           if (tiles <= 32) {
             a.p_in_args = 1;
             for (int t = 0; t < tiles; t++) {
@@ -747,8 +748,45 @@ struct sdrhip_fir {
 };
 
 namespace sdrhip {
+// the coefficient tables of a plan from `order` doubles (create, and set_taps between calls: the uploads are ordered on the
+// context's stream behind the launches already enqueued; buffers are allocated by create)
+void fir_load_taps(sdrhip_fir *h, const double *alpha) {
+  const int order = h->order, decim = h->D;
+  if (h->kind == SDRHIP_FIR_CS16_EXACT) {
+    std::vector<double> ap(h->OP, 0.0);
+    double P = 0, Q = 0;   // sum of the positive / |negative| taps
+    for (int i = 0; i < order; i++) {
+      ap[h->OP - order + i] = alpha[i];
+      if (alpha[i] >= 0) P += alpha[i]; else Q -= alpha[i];
+    }
+    // Truncation toward zero never grows a partial sum, so |acc| <= sum |alpha_k x_k| with
+    // x in [-32768, 32767]. The int16 wrap of the reference can only trigger if a partial sum
+    // can reach +32768 or go below -32768; otherwise acc stays in range and the wrap is skipped.
+    const bool pos_ok = 32767.0 * P + 32768.0 * Q < 32768.0 - 1e-6;
+    const bool neg_ok = 32768.0 * P + 32767.0 * Q < 32769.0 - 1e-6;
+    h->wrap = !(pos_ok && neg_ok) || !(P == P && Q == Q);
+    h->alpha.upload(ap.data(), h->OP, h->ctx->stream);
+    return;
+  }
+  // beta[m] = (1/D) * sum_k alpha[m-k], k in [0,D): FIR followed by the D-sample box average
+  std::vector<float> b(h->M);
+  for (int m = 0; m < h->M; m++) {
+    double s = 0;
+    for (int k = 0; k < decim; k++) { const int i = m - k; if (i >= 0 && i < order) s += alpha[i]; }
+    b[m] = (float)(s / decim);
+  }
+  h->beta.upload(b.data(), h->M, h->ctx->stream);
+  const int padz = (h->R - 1) * decim;
+  std::vector<float> bpad((size_t)h->M + 2 * padz + 16, 0.f);
+  for (int m = 0; m < h->M; m++) bpad[padz + m] = b[m];
+  h->betap.upload(bpad.data(), bpad.size(), h->ctx->stream);
+}
+
+// (re)starts the fused shift's phasor at the CURRENT sample: exp(-2 pi i fc (n - n_now) / fs) from the next call on — what
+// FreqShiftBase::setFrequencyShift does to its LUT counter (src/freqshift.hh:78-87). FIR history (raw input samples),
+// decimator phase and sample counter go on.
 void fir_set_shift(sdrhip_fir *h, double fc, double fs) {
-  h->shift_on = true; h->fc = fc; h->fs = fs;
+  h->shift_on = true; h->fc = fc; h->fs = fs; h->phase0 = (long long)h->n0;
   h->ctx->use();
   auto ph = [&](double t) {   // exp(-2 pi i frac(fc t / fs)), the oracle's closed form, rounded to float once
     const double a = -2.0 * M_PI * std::fmod(fc * t / fs, 1.0);
@@ -757,9 +795,10 @@ void fir_set_shift(sdrhip_fir *h, double fc, double fs) {
   std::vector<float2> e(TPB), e2(TPB), w(256);
   for (int t = 0; t < TPB; t++) { e[t] = ph((double)t); e2[t] = ph((double)(2 * t)); }
   for (int k = 0; k < 256; k++) w[k] = ph((double)TPB * k);
-  h->etab.alloc(TPB); h->etab.upload(e.data(), TPB, h->ctx->stream);
-  h->etab2.alloc(TPB); h->etab2.upload(e2.data(), TPB, h->ctx->stream);
-  h->wtab.alloc(256); h->wtab.upload(w.data(), 256, h->ctx->stream);
+  if (!h->etab.p) { h->etab.alloc(TPB); h->etab2.alloc(TPB); h->wtab.alloc(256); }   // (a retune rewrites the tables in stream order)
+  h->etab.upload(e.data(), TPB, h->ctx->stream);
+  h->etab2.upload(e2.data(), TPB, h->ctx->stream);
+  h->wtab.upload(w.data(), 256, h->ctx->stream);
 }
 }  // namespace sdrhip
 
@@ -793,19 +832,8 @@ int sdrhip_fir_create(sdrhip_ctx *ctx, int kind, const double *alpha, int order,
         h->HH = h->OP - 1;
         h->ovl = epilogue == SDRHIP_EPI_FM ? 1 : 0;
         SDRHIP_REQUIRE(((size_t)TPB * R2MAX + h->OP + 8 + TPB * R2MAX) * 4 <= 64 * 1024, SDRHIP_E_UNSUPPORTED, "order %d exceeds the LDS tile", order);
-        std::vector<double> ap(h->OP, 0.0);
-        double P = 0, Q = 0;   // sum of the positive / |negative| taps
-        for (int i = 0; i < order; i++) {
-          ap[h->OP - order + i] = alpha[i];
-          if (alpha[i] >= 0) P += alpha[i]; else Q -= alpha[i];
-        }
-        // Truncation toward zero never grows a partial sum, so |acc| <= sum |alpha_k x_k| with
-        // x in [-32768, 32767]. The int16 wrap of the reference can only trigger if a partial sum
-        // can reach +32768 or go below -32768; otherwise acc stays in range and the wrap is skipped.
-        const bool pos_ok = 32767.0 * P + 32768.0 * Q < 32768.0 - 1e-6;
-        const bool neg_ok = 32768.0 * P + 32767.0 * Q < 32769.0 - 1e-6;
-        h->wrap = !(pos_ok && neg_ok) || !(P == P && Q == Q);
-        h->alpha.alloc(h->OP); h->alpha.upload(ap.data(), h->OP, ctx->stream);
+        h->alpha.alloc(h->OP);
+        fir_load_taps(h, alpha);
         for (int p = 0; p < 2; p++) {
           h->hist16[p].alloc((size_t)channels * h->HH); h->hist16[p].zero(ctx->stream);
           h->fm[p].alloc(channels); h->fm[p].zero(ctx->stream);
@@ -829,17 +857,9 @@ int sdrhip_fir_create(sdrhip_ctx *ctx, int kind, const double *alpha, int order,
                                 (const void *)fir_cf32_pipe_kernel<4, 8>, (const void *)fir_cf32_pipe_kernel<2, 8>};
           for (int k = 0; k < 7; k++) SDRHIP_CHECK_HIP(hipFuncSetAttribute(fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds3));
         }
-        std::vector<float> b(h->M);
-        for (int m = 0; m < h->M; m++) {
-          double s = 0;
-          for (int k = 0; k < decim; k++) { const int i = m - k; if (i >= 0 && i < order) s += alpha[i]; }
-          b[m] = (float)(s / decim);
-        }
-        h->beta.alloc(h->M); h->beta.upload(b.data(), h->M, ctx->stream);
-        { const int padz = (h->R - 1) * decim;
-          std::vector<float> bpad((size_t)h->M + 2 * padz + 16, 0.f);
-          for (int m = 0; m < h->M; m++) bpad[padz + m] = b[m];
-          h->betap.alloc(bpad.size()); h->betap.upload(bpad.data(), bpad.size(), ctx->stream); }
+        h->beta.alloc(h->M);
+        h->betap.alloc((size_t)h->M + 2 * (size_t)(h->R - 1) * decim + 16);
+        fir_load_taps(h, alpha);
         for (int p = 0; p < 2; p++) {
           h->hist32[p].alloc((size_t)channels * std::max(1, h->M - 1)); h->hist32[p].zero(ctx->stream);
         }
@@ -911,11 +931,19 @@ int sdrhip_fir_process(sdrhip_fir *h, const void *in_host, size_t n_in, size_t i
   });
 }
 
+int sdrhip_fir_set_taps(sdrhip_fir *h, const double *alpha) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h && alpha, SDRHIP_E_INVALID, "NULL argument");
+    h->ctx->use();
+    fir_load_taps(h, alpha);
+  });
+}
+
 int sdrhip_fir_reset(sdrhip_fir *h) {
   return guarded([&] {
     SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
     h->ctx->use();
-    h->n0 = 0;
+    h->n0 = 0; h->phase0 = 0;
     for (int p = 0; p < 2; p++) {
       h->hist16[p].zero(h->ctx->stream); h->hist32[p].zero(h->ctx->stream); h->fm[p].zero(h->ctx->stream);
     }

@@ -35,6 +35,7 @@
 //   D = 257 ... 32768 iqbb_hot_anyd_kernel  PART: slices of 512 samples whatever the groups; a slice leaves the sums of its
 //                                           stretches between group boundaries, one lane per group finishes (same choice)
 #pragma once
+#include <atomic>
 #include "iqbb_common.hpp"
 
 #include <type_traits>
@@ -1407,16 +1408,29 @@ __global__ __launch_bounds__(64 * NW, K1_MINWAVES) void iqbb_hot_sd_kernel(const
   iqbb_hot_body<S, S0, NH, ROT, EPI, IN, NW, true, true>(a, b);
 }
 
+// HIP function attributes are PER DEVICE, and one process may drive several (sdrhip_comm_create: one context per
+// device): a kernel's dynamic-LDS limit is raised once per device id (bit d of `mask`; the launch runs on the device the
+// context made current). The setter is idempotent, so two threads racing on one device only set it twice.
+template <class F>
+inline void once_per_device(std::atomic<uint64_t> &mask, F &&set_attributes) {
+  int d = 0;
+  SDRHIP_CHECK_HIP(hipGetDevice(&d));
+  const uint64_t bit = 1ull << (d & 63);
+  if (mask.load(std::memory_order_acquire) & bit) return;
+  set_attributes();
+  mask.fetch_or(bit, std::memory_order_release);
+}
+
 // returns the waves per workgroup the plan runs in (hot_sd_nw; the host sizes the grid by it) — 0: its LDS fits none (nothing
 // launched); dry_run: only answer
 template <int S, int S0, int NH, int IN, int NW0 = 4>
 int hot_launch_sd_one(bool rot, int epi, const HotLaunch &hl, const HotArgs &ha, const IqbbArgs &b, bool dry_run) {
   const dim3 grid(hl.grid, 1);
 #define SDRHIP_SD(R_, E_) hipLaunchKernelGGL((iqbb_hot_sd_kernel<S, S0, NH, R_, E_, IN, NWX>), grid, dim3(64 * NWX), lds, hl.stream, ha, b)
-#define SDRHIP_SD_ATTR(R_, E_) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&iqbb_hot_sd_kernel<S, S0, NH, R_, E_, IN, NWX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+#define SDRHIP_SD_ATTR(R_, E_) SDRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&iqbb_hot_sd_kernel<S, S0, NH, R_, E_, IN, NWX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
 #define SDRHIP_SD_E(R_) do { if (dry_run) return NWX; \
     const size_t lds = (size_t)hot_lds_bytes(S, NH, IN, NWX, false) + hot_sd_extra(S, IN, R_, NWX); \
-    if (lds > 64 * 1024) { static const bool attr_set = [&] { SDRHIP_SD_ATTR(R_, SDRHIP_EPI_FM); SDRHIP_SD_ATTR(R_, SDRHIP_EPI_AM); SDRHIP_SD_ATTR(R_, SDRHIP_EPI_USB); SDRHIP_SD_ATTR(R_, SDRHIP_EPI_NONE); return true; }(); (void)attr_set; } \
+    if (lds > 64 * 1024) { static std::atomic<uint64_t> attr_set{0}; once_per_device(attr_set, [&] { SDRHIP_SD_ATTR(R_, SDRHIP_EPI_FM); SDRHIP_SD_ATTR(R_, SDRHIP_EPI_AM); SDRHIP_SD_ATTR(R_, SDRHIP_EPI_USB); SDRHIP_SD_ATTR(R_, SDRHIP_EPI_NONE); }); } \
     switch (epi) { \
     case SDRHIP_EPI_FM: SDRHIP_SD(R_, SDRHIP_EPI_FM); break; \
     case SDRHIP_EPI_AM: SDRHIP_SD(R_, SDRHIP_EPI_AM); break; \
@@ -1435,10 +1449,13 @@ void hot_launch_one(bool rot, int epi, const HotLaunch &hl, const HotArgs &ha, c
   constexpr bool PAIR = hot_pair(IN, NW, false);
   const size_t lds = (size_t)hot_lds_bytes(S, NH, IN, NW, hot_wide(S, NH, IN, NW, 0, PAIR), PAIR);
   if (lds > 64 * 1024) {   // (the pair variant's four window buffers per wave)
-#define SDRHIP_HOT_ATTR(R_, E_) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&iqbb_hot_kernel<S, S0, NH, R_, E_, IN, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+    static std::atomic<uint64_t> attr_set{0};
+    once_per_device(attr_set, [&] {
+#define SDRHIP_HOT_ATTR(R_, E_) SDRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&iqbb_hot_kernel<S, S0, NH, R_, E_, IN, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
     SDRHIP_HOT_ATTR(true, SDRHIP_EPI_FM); SDRHIP_HOT_ATTR(true, SDRHIP_EPI_AM); SDRHIP_HOT_ATTR(true, SDRHIP_EPI_USB); SDRHIP_HOT_ATTR(true, SDRHIP_EPI_NONE);
     SDRHIP_HOT_ATTR(false, SDRHIP_EPI_FM); SDRHIP_HOT_ATTR(false, SDRHIP_EPI_AM); SDRHIP_HOT_ATTR(false, SDRHIP_EPI_USB); SDRHIP_HOT_ATTR(false, SDRHIP_EPI_NONE);
 #undef SDRHIP_HOT_ATTR
+    });
   }
   const dim3 grid(hl.grid, 1), block(64 * NW);
 #define SDRHIP_HOT(R_, E_) hipLaunchKernelGGL((iqbb_hot_kernel<S, S0, NH, R_, E_, IN, NW>), grid, block, lds, hl.stream, ha, b)
@@ -1457,16 +1474,15 @@ void hot_launch_anyd_one(bool rot, int epi, const HotLaunch &hl, const HotArgs &
   const int extra = hot_anyd_extra(S, IN, rot, NW);
   const size_t lds = (size_t)hot_lds_bytes(S, NH, IN, NW, hot_wide(S, NH, IN, NW, extra)) + extra;
   static_assert(hot_lds_bytes(S, NH, IN, NW, false) + hot_anyd_extra(S, IN, false, NW) <= 163840, "any-D form: a workgroup's LDS");
-  if (NW > 4) {   // (beyond 64 KB of dynamic LDS: once per process and kernel — a function-local static's initialiser is thread-safe)
-    static const bool attr_set = [] {
-#define SDRHIP_ANYD_ATTR(R_, E_) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&iqbb_hot_anyd_kernel<S, S0, NH, R_, E_, IN, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, hot_lds_cap(NW) + hot_anyd_extra(S, IN, false, NW) > 163840 ? 163840 : hot_lds_cap(NW) + hot_anyd_extra(S, IN, false, NW))
+  if (NW > 4) {   // (beyond 64 KB of dynamic LDS: once per DEVICE and kernel)
+    static std::atomic<uint64_t> attr_set{0};
+    once_per_device(attr_set, [] {
+#define SDRHIP_ANYD_ATTR(R_, E_) SDRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&iqbb_hot_anyd_kernel<S, S0, NH, R_, E_, IN, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, hot_lds_cap(NW) + hot_anyd_extra(S, IN, false, NW) > 163840 ? 163840 : hot_lds_cap(NW) + hot_anyd_extra(S, IN, false, NW)))
       SDRHIP_ANYD_ATTR(true, SDRHIP_EPI_NONE); SDRHIP_ANYD_ATTR(true, SDRHIP_EPI_FM); SDRHIP_ANYD_ATTR(true, SDRHIP_EPI_AM); SDRHIP_ANYD_ATTR(true, SDRHIP_EPI_USB);
       SDRHIP_ANYD_ATTR(false, SDRHIP_EPI_NONE); SDRHIP_ANYD_ATTR(false, SDRHIP_EPI_FM); SDRHIP_ANYD_ATTR(false, SDRHIP_EPI_AM); SDRHIP_ANYD_ATTR(false, SDRHIP_EPI_USB);
       SDRHIP_ANYD_ATTR(true, HOT_EPI_PARTIAL); SDRHIP_ANYD_ATTR(false, HOT_EPI_PARTIAL);
 #undef SDRHIP_ANYD_ATTR
-      return true;
-    }();
-    (void)attr_set;
+    });
   }
   const dim3 grid(hl.grid, 1), block(64 * NW);
 #define SDRHIP_ANYD(R_, E_) hipLaunchKernelGGL((iqbb_hot_anyd_kernel<S, S0, NH, R_, E_, IN, NW>), grid, block, lds, hl.stream, ha, b)

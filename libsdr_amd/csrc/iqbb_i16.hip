@@ -1126,7 +1126,7 @@ struct sdrhip_iqbb_i16 {
                              else if (inc != 0) hipLaunchKernelGGL((iqbb_i16_mfmag_kernel<S_, true, false>), grid3, block, lds_bytes, ctx->stream, a); \
                              else hipLaunchKernelGGL((iqbb_i16_mfmag_kernel<S_, false, false>), grid3, block, lds_bytes, ctx->stream, a); } while (0)
       if (lds_bytes > 64 * 1024 && !mfmag_attr_set) {   // (17 K steps, small decimations: once per plan)
-#define SDRHIP_MFG_ATTR(R_, C_) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&iqbb_i16_mfmag_kernel<17, R_, C_>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)
+#define SDRHIP_MFG_ATTR(R_, C_) SDRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&iqbb_i16_mfmag_kernel<17, R_, C_>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024))
         SDRHIP_MFG_ATTR(true, true); SDRHIP_MFG_ATTR(false, true); SDRHIP_MFG_ATTR(true, false); SDRHIP_MFG_ATTR(false, false);
 #undef SDRHIP_MFG_ATTR
         mfmag_attr_set = true;
@@ -1464,6 +1464,8 @@ int sdrhip_iqbb_i16_adopt_state(sdrhip_iqbb_i16 *h, sdrhip_iqbb_i16 *from, int w
     const bool ring = (what & SDRHIP_KEEP_RING) != 0, fmk = (what & SDRHIP_KEEP_FM) != 0, stream = (what & SDRHIP_KEEP_COUNTERS) != 0;
     SDRHIP_REQUIRE(!ring || h->order == from->order, SDRHIP_E_INVALID, "SDRHIP_KEEP_RING needs equal orders (%d / %d)", h->order, from->order);
     SDRHIP_REQUIRE(!stream || h->D == from->D, SDRHIP_E_INVALID, "SDRHIP_KEEP_COUNTERS needs equal decimations (%d / %d)", h->D, from->D);
+    SDRHIP_REQUIRE(!fmk || (h->epi == SDRHIP_EPI_FM && from->epi == SDRHIP_EPI_FM), SDRHIP_E_INVALID,
+                   "SDRHIP_KEEP_FM needs the FM epilogue on both plans (%d / %d)", h->epi, from->epi);
     h->ctx->use();
     hipStream_t st = h->ctx->stream;
     SDRHIP_CHECK_HIP(hipStreamSynchronize(from->ctx->stream));   // (the source plan's last launch wrote the state read here)
@@ -1482,8 +1484,8 @@ int sdrhip_iqbb_i16_adopt_state(sdrhip_iqbb_i16 *h, sdrhip_iqbb_i16 *from, int w
     if (stream) {   // decimator window (position and partial sum), sample counter and LUT phase go on
       SDRHIP_CHECK_HIP(hipMemcpyAsync(h->acc[h->par].p, from->acc[from->par].p, C * sizeof(int2), hipMemcpyDeviceToDevice, st));
       h->n0 = from->n0; h->phase0 = from->phase0;
-      // _ring_offset goes on from where it stands (a position beyond a shorter new ring is an out-of-bounds write in the
-      // reference; it wraps here, as in the oracle)
+      // _ring_offset goes on from where it stands; a position at or beyond a SHORTER new ring is an out-of-bounds write
+      // in the reference (undefined): here, as in the oracle's set_order, the offset restarts at 0
       h->ring_n0 = h->n0; h->ring_off0 = from->ring_offset() < h->order ? from->ring_offset() : 0;
     }
     SDRHIP_CHECK_HIP(hipStreamSynchronize(st));

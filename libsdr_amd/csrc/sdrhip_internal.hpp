@@ -6,6 +6,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <memory>
 #include <new>
 #include <string>
 #include <vector>
@@ -66,6 +68,9 @@ struct sdrhip_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipDeviceProp_t prop;
+  // plans the one-shot entry points keep between calls (sdrhip_fft_c2c / sdrhip_fft_exec: (dtype, n) -> plan), type-erased;
+  // released in sdrhip_ctx_destroy before the stream goes
+  std::map<long long, std::shared_ptr<void> > cache;
   void use() const;  // hipSetDevice
 };
 
@@ -139,6 +144,7 @@ static inline void require_disjoint(const void *in, size_t in_stride, size_t in_
 
 // fir.hip: turn on the frequency shift fused into the cf32 FIR's staging (used by the float baseband, fbb_f32.hip)
 void fir_set_shift(sdrhip_fir *h, double fc, double fs);
+void fir_load_taps(sdrhip_fir *h, const double *alpha);
 
 #ifdef __HIPCC__
 // XCD-aware unit order for grids of (units-per-channel, channels) whose neighbouring units of a channel re-read each

@@ -364,6 +364,7 @@ class FIR(_Node):
         super().__init__()
         alpha = np.ascontiguousarray(alpha, np.float64)
         self.ctx, self.kind, self.channels, self.decim, self.epilogue = ctx, kind, channels, decim, epilogue
+        self.order = alpha.shape[0]
         check(abi.lib().sdrhip_fir_create(ctx.handle, kind, alpha.ctypes.data_as(C.POINTER(C.c_double)), alpha.shape[0],
                                           decim, channels, max_in, epilogue, C.byref(self._h)))
 
@@ -401,6 +402,12 @@ class FIR(_Node):
 
     def reset(self):
         check(abi.lib().sdrhip_fir_reset(self._h))
+
+    def set_taps(self, alpha):
+        """New coefficients, same order: the ring (the stream) goes on (FIRFilter::setUpperFreq, src/firfilter.hh:165-170)."""
+        alpha = np.ascontiguousarray(alpha, np.float64)
+        assert alpha.shape == (self.order,)
+        check(abi.lib().sdrhip_fir_set_taps(self._h, alpha.ctypes.data_as(C.POINTER(C.c_double))))
 
 
 class Demod(_Node):
@@ -593,6 +600,13 @@ class FloatBaseBand(_Node):
     def reset(self):
         check(abi.lib().sdrhip_fbb_f32_reset(self._h))
 
+    def set_taps(self, alpha):
+        alpha = np.ascontiguousarray(alpha, np.float64)
+        check(abi.lib().sdrhip_fbb_f32_set_taps(self._h, alpha.ctypes.data_as(C.POINTER(C.c_double))))
+
+    def set_shift(self, Fc):
+        check(abi.lib().sdrhip_fbb_f32_set_shift(self._h, float(Fc)))
+
 
 def fft_c2c(ctx, x, sign):
     """Batched DFT with the library's own in-LDS FFT (test hook)."""
@@ -681,3 +695,43 @@ class Comm:
             self.close()
         except Exception:
             pass
+
+
+class FFTPlan(_Node):
+    """sdrhip_fft_plan_*: FFTPlan<float|double> planned once (any size), executed many times."""
+    _destroy = "sdrhip_fft_plan_destroy"
+
+    def __init__(self, ctx, n, dtype=np.complex64):
+        super().__init__()
+        self.ctx, self.n, self.dtype = ctx, int(n), np.dtype(dtype)
+        assert self.dtype in (np.dtype(np.complex64), np.dtype(np.complex128))
+        check(abi.lib().sdrhip_fft_plan_create(ctx.handle, abi.T_CF64 if self.dtype == np.complex128 else abi.T_CF32, self.n, C.byref(self._h)))
+
+    @property
+    def form(self):
+        s = C.c_char_p()
+        check(abi.lib().sdrhip_fft_plan_form(self._h, C.byref(s)))
+        return s.value.decode()
+
+    def exec(self, x, sign):
+        """One transform on host buffers (FFTPlan::operator())."""
+        x = np.ascontiguousarray(x, self.dtype)
+        assert x.shape == (self.n,)
+        out = np.empty_like(x)
+        check(abi.lib().sdrhip_fft_plan_exec(self._h, sign, _ptr(x), _ptr(out)))
+        return out
+
+    def exec_batch(self, x, sign):
+        """x: [batch, n] -> [batch, n] through device memory (exec_dev)."""
+        x = np.ascontiguousarray(x, self.dtype)
+        assert x.ndim == 2 and x.shape[1] == self.n
+        din, dout = self.ctx.malloc(x.nbytes), self.ctx.malloc(x.nbytes)
+        try:
+            self.ctx.h2d(din, x)
+            check(abi.lib().sdrhip_fft_plan_exec_dev(self._h, sign, x.shape[0], C.c_void_p(din), C.c_void_p(dout)))
+            out = np.empty_like(x)
+            self.ctx.d2h(out, dout)
+        finally:
+            self.ctx.free(din)
+            self.ctx.free(dout)
+        return out

@@ -673,6 +673,22 @@ static void golden_wav() {
   }
 }
 
+// G17 — FIRLowPass::setFreq between buffers (FIRFilter::setUpperFreq, src/firfilter.hh:165-170,287): only _alpha is
+// recomputed, the ring goes on. 4 buffers of G1's inputs, cut-off 100 kHz -> 40 kHz after the second buffer.
+static void golden_setters() {
+  const double Fs = 2.4e6; const size_t N = 4096;
+  std::vector<cs16> x16 = siggen<int16_t>(Fs, N, 4, two_tone_i16());
+  std::vector<cf32> xf = siggen<float>(Fs, N, 3, two_tone_f32());
+  { Feeder<cs16> src; src.configure(Fs, N); FIRLowPass<cs16> fir(127, 100e3); Capture<cs16> cap;
+    src.connect(&fir, true); fir.connect(&cap, true);
+    for (size_t b = 0; b < 4; b++) { if (b == 2) fir.setFreq(40e3); src.feed(&x16[b * N], N); }
+    dump("g17_fir127_setfreq_cs16", "cs16", flat16(cap.data), "\"Fs\": 2400000, \"order\": 127, \"freq\": [100000, 40000], \"switch_after_buffers\": 2, \"bufsize\": 4096"); }
+  { Feeder<cf32> src; src.configure(Fs, N); FIRLowPass<cf32> fir(127, 100e3); Capture<cf32> cap;
+    src.connect(&fir, true); fir.connect(&cap, true);
+    for (size_t b = 0; b < 3; b++) { if (b == 1) fir.setFreq(40e3); src.feed(&xf[b * N], N); }
+    dump("g17_fir127_setfreq_cf32", "cf32", flatf(cap.data), "\"Fs\": 2400000, \"order\": 127, \"freq\": [100000, 40000], \"switch_after_buffers\": 1, \"bufsize\": 4096"); }
+}
+
 // ---------------------------------------------------------------------------------------------
 // timing of the reference CPU path (bench.py cpu_baseline kind "reference")
 // ---------------------------------------------------------------------------------------------
@@ -756,6 +772,7 @@ int main(int argc, char **argv) {
     golden_next();
     golden_real();
     golden_wav();
+    golden_setters();
     g_manifest << "\n}\n";
     std::string mp = g_out + "/manifest.json";
     FILE *f = fopen(mp.c_str(), "w"); fputs(g_manifest.str().c_str(), f); fclose(f);

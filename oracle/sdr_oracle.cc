@@ -404,8 +404,8 @@ void orc_iqbb_i16_reset(void *h) {   // _reconfigure (:175-177) + setSampleRate 
 void orc_iqbb_i16_set_decim(void *h, int decim) { ((IQBB *)h)->decim = decim; }
 // setOrder (src/baseband.hh:69-79): _kernel and _ring are REALLOCATED (the new ring is uninitialised memory in the
 // reference; zeros here — outputs are defined again once `order` samples have passed), _update_filter_kernel();
-// _ring_offset, _sample_count, _last and the LUT phase are not touched. (A ring offset beyond the new order is an
-// out-of-bounds write in the reference; here it wraps.)
+// _ring_offset, _sample_count, _last and the LUT phase are not touched. (A ring offset at or beyond the new order is an
+// out-of-bounds write in the reference — undefined; here the offset restarts at 0.)
 void orc_iqbb_i16_set_order(void *h, const int32_t *taps, int order) {
   IQBB *s = (IQBB *)h;
   s->order = order; s->k.resize(order); s->ring.assign(order, C32{0, 0});

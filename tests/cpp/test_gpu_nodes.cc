@@ -92,6 +92,30 @@ static void testFirFmOnQueue() {
   CHECK(ref.size() == out.data.size() && 0 == memcmp(ref.data(), out.data.data(), ref.size() * 2));
 }
 
+// FIRLowPass::setFreq between buffers (FIRFilter::setUpperFreq, src/firfilter.hh:165-170,287): only the coefficients change,
+// the ring goes on. The oracle has no setter: a fresh filter with the new coefficients primed with the `order` samples in
+// front of the switch continues the reference's stream (pinned to the compiled reference: tests/golden g17).
+static void testFirSetFreqKeepsTheRing() {
+  const size_t N = 4096;
+  IQSigGen<int16_t> gen(FS, N); gen.addSine(100e3, 8000, 0.0); gen.addSine(-300e3, 6000, 0.3);
+  Recorder<cs16> raw, out; gpu::FIRLowPass<cs16> fir(127, 100e3);
+  gen.connect(&raw, true); gen.connect(&fir, true); fir.connect(&out, true);
+  gen.next(); gen.next();
+  fir.setFreq(40e3);
+  CHECK(fir.freq() == 40e3);
+  gen.next(); gen.next();
+  CHECK(out.data.size() == 4 * N);
+  std::vector<double> a(127), b(127);
+  orc_fir_lowpass_design(127, 100e3, FS, a.data()); orc_fir_lowpass_design(127, 40e3, FS, b.data());
+  void *f1 = orc_fir_create(a.data(), 127), *f2 = orc_fir_create(b.data(), 127);
+  std::vector<int16_t> y1(2 * 2 * N), y2(2 * 2 * N), scratch(2 * 127);
+  orc_fir_cs16_process(f1, (const int16_t *)&raw.data[0], 2 * N, y1.data());
+  orc_fir_cs16_process(f2, (const int16_t *)&raw.data[2 * N - 127], 127, scratch.data());
+  orc_fir_cs16_process(f2, (const int16_t *)&raw.data[2 * N], 2 * N, y2.data());
+  orc_fir_destroy(f1); orc_fir_destroy(f2);
+  CHECK(0 == memcmp(y1.data(), &out.data[0], 2 * N * 4) && 0 == memcmp(y2.data(), &out.data[2 * N], 2 * N * 4));
+}
+
 // ownership rules: in place when allowed, own buffer otherwise, drop while the own buffer is referenced
 static void testOwnership() {
   std::vector<cs16> x = tones(4096);
@@ -551,6 +575,20 @@ static void testFloatBaseBandNode() {
     CHECK(t.filterFrequency() == 80e3 && t.centerFrequency() == 80e3);
     t.setFilterFrequency(80e3);   // (equal to the centre: fine)
   }
+  {   // setters that change neither order, decimation nor buffer size keep the plan and its stream: the decimator's phase
+      // carries across them (5 samples in, then a retune / a new width, then 11 more: 16 samples = 2 outputs in all)
+    gpu::IQBaseBand<float> t(100e3, 50e3, 127, 8);
+    Feeder src; src.cfg(Config::Type_cf32, 64); Recorder<cf32> rec;
+    src.connect(&t, true); t.connect(&rec, true);
+    std::vector<cf32> x(64, cf32(0.25f, -0.5f));
+    src.feed(x.data(), 5);
+    t.setCenterFrequency(80e3); t.setFilterWidth(30e3); t.setSubsample(8); t.setOrder(127);
+    src.feed(x.data(), 11);
+    CHECK(rec.data.size() == 2);
+    t.setSubsample(4);   // a new decimation IS a new plan: counters restart
+    src.feed(x.data(), 5);
+    CHECK(rec.data.size() == 3 && t.Source::sampleRate() == FS / 4);
+  }
   // output rate given instead of the decimation (src/baseband.hh:159-162): 2.4 MS/s -> 300 kS/s = /8
   gpu::IQBaseBand<float> byrate(100e3, 200e3, 127, 1, 300e3);
   byrate.config(Config(Config::Type_cf32, FS, N, 1));
@@ -589,10 +627,14 @@ static void testFftPlan() {
   testFftPlanOf<double>(1000, 1e-13); testFftPlanOf<double>(6006, 1e-13);
   testFftPlanOf<float>(1003, 1e-5); testFftPlanOf<double>(2053, 1e-12);   // a prime factor above 13: the chirp transform
   testFftPlanOf<float>(65536, 3e-6); testFftPlanOf<double>(30000, 1e-12);   // longer than the LDS holds: the four-step plan
+  // a chirp transform beyond one workgroup's LDS runs over a four-step plan (round 4 refused these at construction)
+  testFftPlanOf<double>(4099, 1e-12); testFftPlanOf<float>(2 * 16411, 1e-5);
+  { Buffer< std::complex<float> > a(20014), b(20014); gpu::FFTPlan<float> p(a, b, gpu::FFT::FORWARD);
+    CHECK(std::string(p.form()) == "chirp over four-step");
+    for (size_t i = 0; i < a.size(); i++) a[i] = std::complex<float>(float(i % 7) - 3.f, float(i % 5) - 2.f);
+    p(); const std::complex<float> first = b[1]; p();   // planned once, executed twice
+    CHECK(b[1] == first); }
   bool threw = false;
-  try { Buffer< std::complex<double> > a(4099), b(4099); gpu::FFTPlan<double> p(a, b, gpu::FFT::FORWARD); } catch (ConfigError &) { threw = true; }
-  CHECK(threw);   // 4099 is prime and its chirp transform (16384 points in double) does not fit the LDS: ConfigError at construction
-  threw = false;
   try { Buffer< std::complex<float> > a(64), b(128); gpu::FFTPlan<float> p(a, b, gpu::FFT::FORWARD); } catch (ConfigError &) { threw = true; }
   CHECK(threw);   // sizes differ (the reference's check)
 }
@@ -621,7 +663,7 @@ static void testFilterNodeOf(size_t N, double tol) {
     const long double sc = 1.0L / (sqrtl((long double)(2 * N)) * sqrtl(e));
     const std::vector<CS> &y = k ? band2.data : band.data;
     double err = 0, mx = 0;
-    for (size_t n = 0; n < y.size() && n < raw.data.size(); n += 7) {   // sampled outputs
+    for (size_t n = 0; n < y.size() && n < raw.data.size(); n += (N > 4096 ? 397 : 7)) {   // sampled outputs
       std::complex<long double> acc(0, 0);
       for (size_t t = 0; t < N && t <= n; t++)
         acc += std::complex<long double>(h[2 * t], h[2 * t + 1]) * std::complex<long double>(raw.data[n - t].real(), raw.data[n - t].imag());
@@ -637,6 +679,12 @@ static void testFilterNodeAnySizeAndDouble() {
   testFilterNodeOf<float>(1000, 1e-5);
   testFilterNodeOf<double>(1024, 1e-12);
   testFilterNodeOf<double>(1000, 1e-12);
+  // block sizes whose 2N-point transform does not fit one workgroup's LDS (four-step) or has a prime factor above 13 (chirp
+  // transform): the reference takes any block_size (src/filternode.hh:236-245, FFTW plans any n)
+  testFilterNodeOf<float>(16384, 1e-5);
+  testFilterNodeOf<float>(12000, 1e-5);
+  testFilterNodeOf<float>(1009, 1e-5);
+  testFilterNodeOf<double>(8192, 1e-11);
 }
 
 // The HOST half of the nodes (no device needed; tests/test_cpp.py builds this file with -fsanitize=address,undefined
@@ -714,6 +762,7 @@ int main(int argc, char **argv) {
     testInt8Chain();
     testFftPlan();
     testFilterNodeAnySizeAndDouble();
+    testFirSetFreqKeepsTheRing();
   } catch (std::exception &e) {
     std::printf("FAIL: exception: %s\n", e.what());
     return 2;

@@ -1053,6 +1053,66 @@ def test_fir_cf32_golden(ctx, golden):
     assert rel_err(y, golden.load("g6_fir127_cf32_out")) <= RTOL
 
 
+def test_fir_setfreq_midstream_golden(ctx, golden):
+    """FIRLowPass::setFreq between buffers (FIRFilter::setUpperFreq, src/firfilter.hh:165-170,287): only the coefficients
+    change, the ring goes on — sdrhip_fir_set_taps on the SAME plan against the reference's own output (g17), bit-exact for
+    complex<int16>, <= 1e-5 for complex<float>."""
+    a100, a40 = sa.design_fir_lowpass(127, 100e3, FS), sa.design_fir_lowpass(127, 40e3, FS)
+    assert np.array_equal(a100, golden.load("g2_firlp_alpha127"))
+    x = golden.load("g1_iq_cs16")
+    node = sa.FIR(ctx, sa.FIR_CS16_EXACT, a100, max_in=4096)
+    outs = []
+    for b in range(4):
+        if b == golden.meta("g17_fir127_setfreq_cs16")["switch_after_buffers"]:
+            node.set_taps(a40)
+        outs.append(node.process(x[b * 4096:(b + 1) * 4096])[0])
+    assert np.array_equal(np.concatenate(outs), golden.load("g17_fir127_setfreq_cs16"))
+    xf = golden.load("g1_iq_cf32")
+    nodef = sa.FIR(ctx, sa.FIR_CF32, a100, max_in=4096)
+    outs = []
+    for b in range(3):
+        if b == golden.meta("g17_fir127_setfreq_cf32")["switch_after_buffers"]:
+            nodef.set_taps(a40)
+        outs.append(nodef.process(xf[b * 4096:(b + 1) * 4096])[0])
+    ref = golden.load("g17_fir127_setfreq_cf32")
+    assert rel_err(np.concatenate(outs), ref) <= RTOL
+    # right behind the switch (the old ring under the new taps), against the stream's scale
+    assert np.abs(np.concatenate(outs)[4096:4096 + 200].astype(np.float64) - ref[4096:4096 + 200]).max() <= RTOL * np.abs(ref).max()
+
+
+def test_float_baseband_setters_keep_the_stream(ctx):
+    """IQBaseBand<float> setters on the SAME plan (same order, decimation, buffer size): setFilterWidth = new low-pass
+    coefficients over the kept history; setCenterFrequency = the phasor restarts at the current sample, history and
+    decimator go on (src/baseband.hh:82-101 semantics) — against the float64 closed form of exactly that definition."""
+    D, order, N = 8, 127, 4096
+    rng = np.random.default_rng(77)
+    x = (rng.standard_normal((2, 4 * N, 2)) * 0.3).astype(np.float32)
+    a1, a2 = sa.design_fir_lowpass(order, 25e3, FS), sa.design_fir_lowpass(order, 60e3, FS)
+    node = sa.FloatBaseBand(ctx, 100e3, FS, a1, D, channels=2, max_in=N)
+    ys = []
+    for b in range(4):
+        if b == 1:
+            node.set_taps(a2)
+        if b == 2:
+            node.set_shift(-250e3)
+        ys.append(node.process(x[:, b * N:(b + 1) * N]))
+    y = np.concatenate(ys, axis=1)
+    n = np.arange(4 * N, dtype=np.float64)
+    for c in range(2):
+        xc = x[c, :, 0].astype(np.float64) + 1j * x[c, :, 1]
+        ref = []
+        # output j averages the FIR outputs at n = j*D .. j*D + D-1; a FIR output at n uses x[n - k] * phasor(n - k), k < order
+        for seg, (alpha, fc, n_sw) in enumerate([(a1, 100e3, 0), (a2, 100e3, 0), (a2, -250e3, 2 * N), (a2, -250e3, 2 * N)]):
+            sh = xc * np.exp(-2j * np.pi * np.fmod(fc * (n - n_sw) / FS, 1.0))
+            f = np.convolve(sh, alpha[::-1])[:4 * N]   # alpha[order-1] multiplies the newest sample (src/firfilter.hh:237-243)
+            box = f.reshape(-1, D).mean(axis=1)
+            ref.append(box[seg * N // D:(seg + 1) * N // D])
+        ref = np.concatenate(ref)
+        yc = y[c, :, 0].astype(np.float64) + 1j * y[c, :, 1]
+        assert yc.shape == ref.shape
+        assert np.abs(yc - ref).max() / np.abs(ref).max() <= RTOL, c
+
+
 @pytest.mark.parametrize("n", [8, 3])
 def test_fir_cf32_decimated_golden(ctx, golden, n):
     x = golden.load("g1_iq_cf32")
@@ -1244,17 +1304,104 @@ def test_fft_long_sizes_vs_numpy(ctx, n, dtype, tol):
         assert np.abs(yc - ref).max() / np.abs(ref).max() < tol, (n, sign)
 
 
-def test_fft_sizes_the_device_does_not_plan(ctx):
-    """a transform (or the chirp transform a size with a prime factor above 13 needs) that does not fit one workgroup's LDS,
-    and such a size as the filter's FFT: E_UNSUPPORTED with the reason"""
-    for fn, n, dt in ((sa.fft_c2c, 2 * 16411, np.float32), (sa.fft_c2c, 8209, np.float32), (sa.fft_c2c_f64, 2 * 8209, np.float64),
-                      (sa.fft_c2c_f64, 4099, np.float64)):   # (long sizes with a large prime factor; primes whose chirp transform does not fit)
+@pytest.mark.parametrize("n,dtype,tol,form", [(2 * 16411, np.float32, 1e-5, "chirp over four-step"), (8209, np.float32, 1e-5, "chirp over four-step"),
+                                              (2 * 8209, np.float64, 1e-12, "chirp over four-step"), (4099, np.float64, 1e-12, "chirp over four-step"),
+                                              (20014, np.float32, 1e-5, "chirp over four-step"), (2018, np.float32, 5e-6, "chirp"),
+                                              (24000, np.float32, 3e-6, "four-step"), (32768, np.float32, 3e-6, "four-step"),
+                                              (16384, np.float64, 1e-13, "four-step"), (16384, np.float32, 3e-6, "radix-16 lds"),
+                                              (6000, np.float32, 3e-6, "lds"), (4096, np.float64, 1e-13, "radix-2 lds (double)")])
+def test_fft_plan_any_size_planned_once(ctx, n, dtype, tol, form):
+    """FFTPlan<Scalar> as the reference builds it (src/fftplan_fftw3.hh:34-36,59,64): planned ONCE — for any size, including
+    those round 4 refused (a large prime factor in a long transform, a chirp transform beyond one workgroup's LDS) — then
+    executed several times, both directions, batched and on host buffers, against numpy's double FFT."""
+    cdt = np.complex128 if np.dtype(dtype) == np.float64 else np.complex64
+    plan = sa.FFTPlan(ctx, n, cdt)
+    assert plan.form == form, plan.form
+    rng = np.random.default_rng(n % 977)
+    for rep in range(2):   # (the same plan again: its tables and scratch are reused)
+        x = (rng.standard_normal((3, n)) + 1j * rng.standard_normal((3, n))).astype(cdt)
+        xd = x.astype(np.complex128)
+        for sign, ref in ((-1, np.fft.fft(xd, axis=1)), (+1, np.fft.ifft(xd, axis=1) * n)):
+            y = plan.exec_batch(x, sign)
+            assert np.abs(y - ref).max() / np.abs(ref).max() < tol, (n, sign, rep)
+        y1 = plan.exec(x[1], -1)
+        assert np.abs(y1 - np.fft.fft(xd[1])).max() / np.abs(np.fft.fft(xd[1])).max() < tol
+    # the one-shot entry point serves the same sizes from the context's plan cache
+    x2 = rng.standard_normal((2, n, 2)).astype(dtype)
+    fn = sa.fft_c2c_f64 if np.dtype(dtype) == np.float64 else sa.fft_c2c
+    y2 = fn(ctx, x2, -1)
+    ref2 = np.fft.fft(x2[..., 0].astype(np.float64) + 1j * x2[..., 1], axis=1)
+    assert np.abs(y2[..., 0].astype(np.float64) + 1j * y2[..., 1] - ref2).max() / np.abs(ref2).max() < tol
+    assert np.array_equal(fn(ctx, x2, -1), y2)   # (second call: the cached plan)
+
+
+def test_fft_bad_arguments(ctx):
+    """sizes below 1 are E_INVALID before anything is allocated (a negative n used to become a huge allocation)"""
+    for n in (0, -5):
         with pytest.raises(sa.abi.SdrHipError) as e:
-            fn(ctx, np.zeros((1, n, 2), dt), -1)
-        assert e.value.code == sa.abi.E_UNSUPPORTED, (n, str(e.value))
-    with pytest.raises(sa.abi.SdrHipError) as e:   # FilterNode(17): a 34-point transform
-        sa.FFTConv(ctx, sa.FFTCONV_OLA, 34, np.zeros((34, 2), np.float32))
-    assert e.value.code == sa.abi.E_UNSUPPORTED and "17" in str(e.value)
+            sa.abi.check(sa.abi.lib().sdrhip_fft_exec(ctx.handle, sa.abi.T_CF32, n, -1, np.zeros(4, np.float32).ctypes.data_as(ctypes.c_void_p),
+                                                      np.zeros(4, np.float32).ctypes.data_as(ctypes.c_void_p)))
+        assert e.value.code == sa.abi.E_INVALID
+    with pytest.raises(sa.abi.SdrHipError) as e:
+        sa.FFTPlan(ctx, 0)
+    assert e.value.code == sa.abi.E_INVALID
+
+
+@pytest.mark.parametrize("N,dtype,tol,nblk", [(16384, np.float32, RTOL, 3), (12000, np.float32, RTOL, 3), (1009, np.float32, RTOL, 5),
+                                              (8192, np.float64, 1e-11, 3), (10007, np.float32, RTOL, 2), (17, np.float32, RTOL, 9),
+                                              (6007, np.float64, 1e-11, 2)])
+def test_filternode_any_block_size_beyond_one_workgroup(ctx, orc, N, dtype, tol, nblk):
+    """FilterNode<float>(16384), (12000), (1009), FilterNode<double>(8192) ... (src/filternode.hh:236-245: any block size,
+    FFTW plans any 2N): transforms beyond one workgroup's LDS (four-step) and sizes with a prime factor above 13 (chirp
+    transform, in LDS or over a four-step plan) — a 2-band bank, 3 channels, two ragged calls, against the oracle's
+    FilterSink / FilterSource blocks AND the closed form y = h (*) x / (sqrt(2N) ||h||_2)."""
+    from scipy.signal import fftconvolve
+    f64 = np.dtype(dtype) == np.float64
+    bands = [(-350e3, -250e3), (50e3, 150e3)]
+    hs = [sa.design_fftfilt_kernel(N, lo, hi, FS, dtype=dtype) for lo, hi in bands]
+    Ks = [sa.design_fftfilt_spectrum(h) for h in hs]
+    rng = np.random.default_rng(N)
+    x = (rng.standard_normal((3, nblk * N, 2)) * 0.3).astype(dtype)
+    bank = sa.FFTConv(ctx, sa.FFTCONV_OLA, 2 * N, Ks, channels=3, max_in=nblk * N, dtype=dtype)
+    cut = N + N // 3   # (not a multiple of the block)
+    y = np.concatenate([bank.process(x[:, :cut]), bank.process(x[:, cut:])], axis=2)
+    assert y.shape == (2, 3, nblk * N, 2) and y.dtype == np.dtype(dtype)
+    for b, h in enumerate(hs):
+        hc = h[:, 0].astype(np.float64) + 1j * h[:, 1]
+        for c in range(3):
+            xc = x[c, :, 0].astype(np.float64) + 1j * x[c, :, 1]
+            closed = fftconvolve(xc, hc)[:len(xc)] / (np.sqrt(2 * N) * np.sqrt((np.abs(hc) ** 2).sum()))
+            yc = y[b, c, :, 0].astype(np.float64) + 1j * y[b, c, :, 1]
+            assert np.abs(yc - closed).max() / np.abs(closed).max() <= tol, (N, b, c)
+    flt = orc.FFTFilterF64(orc.fftfilt_design_K_f64(hs[1])) if f64 else orc.FFTFilter(orc.fftfilt_design_K(hs[1]))
+    ref = np.concatenate([flt.process(x[2, i * N:(i + 1) * N]) for i in range(nblk)])
+    assert rel_err(y[1, 2], ref) <= tol, N
+    # the device-pointer entry point, reset, and a kernel swap between calls
+    bank.reset()
+    assert np.array_equal(bank.process(x[:, :cut]), y[:, :, :cut])
+    K2 = sa.design_fftfilt_spectrum(sa.design_fftfilt_kernel(N, 100e3, 300e3, FS, dtype=dtype))
+    bank.set_kernel(0, K2)
+    fresh = sa.FFTConv(ctx, sa.FFTCONV_OLA, 2 * N, [K2, Ks[1]], channels=3, max_in=nblk * N, dtype=dtype)
+    fresh.process(x[:, :cut])
+    assert np.array_equal(bank.process(x[:, cut:]), fresh.process(x[:, cut:]))
+
+
+def test_fftconv_ols_long_transforms(ctx):
+    """overlap-save with time-domain taps on transforms beyond the LDS: 65536 points / 30001 taps (float, four-step) and
+    20014 points / 5000 taps (float, chirp over four-step) against a direct convolution in double"""
+    from scipy.signal import fftconvolve
+    rng = np.random.default_rng(11)
+    for L, M in ((65536, 30001), (20014, 5000)):
+        taps = (rng.standard_normal((M, 2)) / M).astype(np.float32)
+        x = rng.standard_normal((2, 90000, 2)).astype(np.float32)
+        node = sa.FFTConv(ctx, sa.FFTCONV_OLS, L, taps, channels=2, max_in=50000)
+        y = np.concatenate([node.process(x[:, :41111]), node.process(x[:, 41111:])], axis=1)
+        tc = taps[:, 0].astype(np.float64) + 1j * taps[:, 1]
+        for c in range(2):
+            xc = x[c, :, 0].astype(np.float64) + 1j * x[c, :, 1]
+            ref = fftconvolve(xc, tc)[:90000]
+            yc = y[c, :, 0].astype(np.float64) + 1j * y[c, :, 1]
+            assert np.abs(yc - ref).max() / np.abs(ref).max() <= RTOL, (L, c)
 
 
 @pytest.mark.parametrize("N,dtype,tol", [(1000, np.float32, RTOL), (1500, np.float32, RTOL), (1000, np.float64, 1e-12), (1024, np.float64, 1e-12),

@@ -519,3 +519,22 @@ def test_iqbb_i8_chain(golden, orc, case):
     bb, fm = mk(), orc.FMDemodI8()
     outs = [fm.process(bb.process(c)) for c in split(x, m["in_lens"])]
     assert np.array_equal(np.concatenate(outs), golden.load(case + "_fm"))
+
+
+def test_fir_setfreq_midstream(golden, orc):
+    """FIRLowPass::setFreq between buffers only recomputes the coefficients; the ring goes on (src/firfilter.hh:165-170).
+    The oracle has no setter: a fresh filter with the new coefficients, primed with the `order` samples in front of the
+    switch, continues the reference's stream (g17) bit for bit — the FIR's output depends on the last `order` samples only."""
+    a100, a40 = orc.fir_lowpass_design(127, 100e3, 2.4e6), orc.fir_lowpass_design(127, 40e3, 2.4e6)
+    x, ref = golden.load("g1_iq_cs16"), golden.load("g17_fir127_setfreq_cs16")
+    sw = golden.meta("g17_fir127_setfreq_cs16")["switch_after_buffers"] * 4096
+    f1, f2 = orc.FIR(a100), orc.FIR(a40)
+    y1 = f1.process_cs16(x[:sw])
+    f2.process_cs16(x[sw - 127:sw])
+    assert np.array_equal(np.concatenate([y1, f2.process_cs16(x[sw:])]), ref)
+    xf, reff = golden.load("g1_iq_cf32"), golden.load("g17_fir127_setfreq_cf32")
+    sw = golden.meta("g17_fir127_setfreq_cf32")["switch_after_buffers"] * 4096
+    f1, f2 = orc.FIR(a100), orc.FIR(a40)
+    y1 = f1.process_cf32(xf[:sw])
+    f2.process_cf32(xf[sw - 127:sw])
+    assert np.array_equal(np.concatenate([y1, f2.process_cf32(xf[sw:])]), reff)
