@@ -70,6 +70,11 @@ struct HotArgs {
   int D, GS, lpg_sh; float inv_d;       // any-D form: decimation, whole groups per slice (512 / D), log2 of the lanes per group team, (1 / D)(1 - 2^-20)
   short *philast; int philast_stride;   // any-D form with FM: slice (tile, w) leaves the angle of its last group in philast[c * stride + 4 * tile + w]
   int tiles_h;                          // any-D form: tiles of the call (4 slices of GS groups each)
+  // any-D forms with FM whose units are NOT whole channels (few channels): neighbouring slices complete the angle difference
+  // between them by a handshake through device memory instead of a second launch (iqbb_hot.hpp, hs_exchange). Entry
+  // {seq << 32 | phi}: hs[c * hs_stride + sid + 1] = the angle of slice sid's LAST group, hs[(C + c) * hs_stride + sid + 1] =
+  // the angle of its FIRST group; hs_seq: this call's number (an entry of another call never matches). nullptr: off.
+  long long *hs; int hs_stride, hs_seq;
   // large-decimation form (HOT_EPI_PARTIAL): slices of 512 samples from the call's first sample on, whatever the groups; slice
   // sid of channel c leaves the sums of its (at most three) stretches between group boundaries in part[c * part_stride + 3 sid + k]
   int2 *part; int part_stride;

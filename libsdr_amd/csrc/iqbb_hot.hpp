@@ -808,6 +808,29 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   // demodulator (28 slots for FM alone) — would cost every slice a fifth of its vector instructions for a handful of
   // lanes. The leaders PARK their sums in a 64-entry per-wave LDS array instead, slice after slice of the unit (a unit's
   // tiles are consecutive), and one pass finishes up to 64 groups, one per lane, when the unit ends or the array is full.
+  // (HS) FM in the any-D forms where the units are not whole channels: a slice's first output is the difference between the
+  // last angle of the slice BEFORE it — another wave's, possibly on another XCD — and its own first angle. Both owners post
+  // their angle in device memory (agent-scope stores: written through the XCD's L2), wait for the stores, then look for the
+  // other's entry (agent-scope loads): whoever finds it — at least one of the two does, both may — writes the output
+  // (again through the L2; the two values are the same). The entry carries the call's number, so nothing of an older call
+  // is mistaken for this one's. A lane passes first / last for the group it holds; sid: its slice, phi: its angle.
+  auto hs_exchange = [&](const HotArgs &A, bool first, bool last, int cc, int sid, int phi) __attribute__((always_inline)) {
+    long long *plast = A.hs + (long)cc * A.hs_stride + sid + 1;              // slice sid's last angle
+    long long *pfirst = A.hs + ((long)A.C + cc) * A.hs_stride + sid + 1;     // slice sid's first angle
+    const long long mine = ((long long)A.hs_seq << 32) | (long long)(unsigned)phi;
+    if (last) __hip_atomic_store(plast, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (first) __hip_atomic_store(pfirst, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the stores are acknowledged from beyond the L2 before the loads go out)
+    short *row = reinterpret_cast<short *>(A.out) + (long)cc * A.out_stride;
+    if (first) {
+      const long long v = __hip_atomic_load(plast - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((int)(v >> 32) == A.hs_seq) __hip_atomic_store(row + (long)sid * GS, (short)((int)(unsigned)v - phi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (last) {
+      const long long v = __hip_atomic_load(pfirst + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((int)(v >> 32) == A.hs_seq) __hip_atomic_store(row + (long)(sid + 1) * GS, (short)(phi - (int)(unsigned)v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
   int2 *pend = reinterpret_cast<int2 *>(pendb);
   int npend = 0, ptile0 = 0;          // (scalar) groups parked, tile of the first parked slice
   // the lane's place in a flush: parked entry l is group k_f of the j_f-th parked slice
@@ -838,8 +861,13 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       // the previous slice's last angle, which that slice's last group leaves in philast
       const int phi = fm_phi(yr, yi);
       const int prev = __builtin_amdgcn_update_dpp(0, phi, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);   // entry l - 1: the group before, within a slice
-      if (live) *reinterpret_cast<short *>(orow) = (short)((k_f > 0 ? prev : 0) - phi);
-      if (live && k_f == GS - 1) a.philast[(long)c_ * a.philast_stride + 4 * (ptile0 + j_f) + wv] = (short)phi;
+      if (a.hs != nullptr) {   // (kernel-uniform) few channels: the slices' first outputs by the neighbours' handshake
+        if (live && k_f > 0) *reinterpret_cast<short *>(orow) = (short)(prev - phi);
+        hs_exchange(a, live && k_f == 0, live && k_f == GS - 1, c_, 4 * (ptile0 + j_f) + wv, phi);
+      } else {
+        if (live) *reinterpret_cast<short *>(orow) = (short)((k_f > 0 ? prev : 0) - phi);
+        if (live && k_f == GS - 1) a.philast[(long)c_ * a.philast_stride + 4 * (ptile0 + j_f) + wv] = (short)phi;
+      }
     }
     npend = 0;
   };
@@ -898,8 +926,13 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
         const int phi = fm_phi(yr, yi);
         int prev = __builtin_amdgcn_update_dpp(0, phi, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);   // lane l - 1: group k - 1
         if (l == 0) prev = carry_phi;   // (i = 0: the slice's first group, -phi for now)
-        if (live) reinterpret_cast<short *>(orow)[k] = (short)(prev - phi);
-        if (live && k == GS - 1) a.philast[(long)c_ * a.philast_stride + 4 * tile_ + wv] = (short)phi;
+        if (a.hs != nullptr) {   // (kernel-uniform)
+          if (live && k > 0) reinterpret_cast<short *>(orow)[k] = (short)(prev - phi);
+          if (i == 0 || 64 * (i + 1) >= GS) hs_exchange(a, live && k == 0, live && k == GS - 1, c_, 4 * tile_ + wv, phi);   // (scalar: the chunks that hold the first / last group)
+        } else {
+          if (live) reinterpret_cast<short *>(orow)[k] = (short)(prev - phi);
+          if (live && k == GS - 1) a.philast[(long)c_ * a.philast_stride + 4 * tile_ + wv] = (short)phi;
+        }
         carry_phi = __builtin_amdgcn_readlane(phi, 63);
       }
     }
@@ -946,8 +979,14 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
         if (q == 0) o = (short)yr;                                   // index 0 is never written by FMDemod (in place)
         else if (q == 1) o = (short)((int)b.fm_old[cc] - phi);       // y[0] is never looked at: the previous call's last angle
         else o = (short)(prev - phi);                                // (a slice's first group: prev = 0, the fix-up launch adds philast)
-        if (emits) reinterpret_cast<short *>(ac.out)[(long)cc * ac.out_stride + q] = o;
-        if (emits && k == GS - 1) ac.philast[(long)cc * ac.philast_stride + sid] = (short)phi;
+        if (ac.hs != nullptr) {   // (kernel-uniform)
+          const bool hfirst = emits && k == 0 && q >= 2;   // (outputs 0 and 1 have their own rules above)
+          if (emits && !hfirst) reinterpret_cast<short *>(ac.out)[(long)cc * ac.out_stride + q] = o;
+          if (i == 0 || 64 * (i + 1) >= GS) hs_exchange(ac, hfirst, emits && k == GS - 1, cc, sid, phi);
+        } else {
+          if (emits) reinterpret_cast<short *>(ac.out)[(long)cc * ac.out_stride + q] = o;
+          if (emits && k == GS - 1) ac.philast[(long)cc * ac.philast_stride + sid] = (short)phi;
+        }
         if (emits && q == b.n_out - 1 && b.n_out >= 2) b.fm_new[cc] = (short)phi;
         carry_phi = __builtin_amdgcn_readlane(phi, 63);
       }
@@ -1162,8 +1201,14 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       if (q == 0) o = (short)yr;                                   // index 0 is never written by FMDemod (in place)
       else if (q == 1) o = (short)((int)b.fm_old[cc] - phi);       // y[0] is never looked at: the previous call's last angle
       else o = (short)((k > 0 ? prev : 0) - phi);                  // (a slice's first group: the fix-up launch adds philast)
-      if (emits) reinterpret_cast<short *>(ac.out)[(long)cc * ac.out_stride + q] = o;
-      if (emits && k == GS - 1) ac.philast[(long)cc * ac.philast_stride + sid] = (short)phi;
+      if (ac.hs != nullptr) {   // (kernel-uniform)
+        const bool hfirst = emits && k == 0 && q >= 2;   // (outputs 0 and 1 have their own rules above)
+        if (emits && !hfirst) reinterpret_cast<short *>(ac.out)[(long)cc * ac.out_stride + q] = o;
+        hs_exchange(ac, hfirst, emits && k == GS - 1, cc, sid, phi);
+      } else {
+        if (emits) reinterpret_cast<short *>(ac.out)[(long)cc * ac.out_stride + q] = o;
+        if (emits && k == GS - 1) ac.philast[(long)cc * ac.philast_stride + sid] = (short)phi;
+      }
       if (emits && q == b.n_out - 1 && b.n_out >= 2) b.fm_new[cc] = (short)phi;
     }
   };

@@ -786,6 +786,10 @@ struct sdrhip_iqbb_i16 {
   DevBuf<unsigned long long> k1_stamps;   // diagnostic builds: per-wave phase totals of the hot kernel
 #endif
   DevBuf<short> philast;   // any-D hot form with FM: the last angle of every slice (HotArgs::philast)
+  DevBuf<long long> hs;    // ... where the units are not whole channels: the neighbouring slices' handshake entries (HotArgs::hs)
+  int hs_stride = 0, hs_seq = 0;
+  int env_fm_handshake = -1;   // SDRHIP_IQBB_FM_HANDSHAKE=0|1: the fix-up launch / the in-kernel handshake for such calls (-1 = 0: the launch — measured
+                               // equal at 1 channel and faster from 16 channels on, profiles/r17_ab_fm_handshake.txt, r17_fm_latency.txt)
   DevBuf<int2> part;       // decimations above 256: three partial box sums per slice of the longest call (HotArgs::part)
   // Decimations 257 ... 512 run either form: the any-D form's one group per slice uses D of a slice's 512 samples (÷257: half
   // of the matrix work is thrown away), the large-decimation form all of them plus a 5 us launch — measured crossover at
@@ -914,7 +918,7 @@ struct sdrhip_iqbb_i16 {
     int nr = 0;
     const HotRange *rg = hot_ranges(S, &nr);
     const int NW = rg[hot_range].NW;
-    HotArgs ha;
+    HotArgs ha{};
     ha.in = in_dev; ha.in_stride = (long)in_stride; ha.out = out_dev; ha.out_stride = (long)out_stride;
     ha.tapfrag = tapfrag.p; ha.lut = lut.p; ha.inc = inc; ha.n0_lo = (uint32_t)(n0 - phase0); ha.negative = negative;
     ha.base0_rel = g.base0_rel; ha.OG = OG; ha.ovl = ovl; ha.t_lo = 0; ha.t_hi = tiles; ha.cre = cre; ha.cim = cim;
@@ -963,7 +967,7 @@ struct sdrhip_iqbb_i16 {
     SDRHIP_REQUIRE(part.n >= (size_t)C * 12 * tiles_h, SDRHIP_E_SIZE, "part holds %zu entries, the call needs %zu", part.n, (size_t)C * 12 * tiles_h);
     IqbbArgs a = a0;   // (the cold phase walks the PSEUDO groups; the real geometry goes to the finishing kernel)
     a.base0_rel = 0; a.n_groups = nsl; a.n_out = nsl; a.extra0 = 0; a.D = 512; a.fix_lo = a.fix_hi = 0;
-    HotArgs ha;
+    HotArgs ha{};
     ha.in = in_dev; ha.in_stride = (long)in_stride; ha.out = out_dev; ha.out_stride = (long)out_stride;
     ha.tapfrag = tapfrag.p; ha.lut = lut.p; ha.inc = inc; ha.n0_lo = (uint32_t)(n0 - phase0); ha.negative = negative;
     ha.base0_rel = 0; ha.OG = 4; ha.ovl = 0; ha.t_lo = s_lo >> 2; ha.t_hi = (s_hi + 3) >> 2; ha.cre = cre; ha.cim = cim;
@@ -1024,7 +1028,7 @@ struct sdrhip_iqbb_i16 {
     while (s_hi > s_lo && !slice_hot(s_hi - 1)) s_hi--;
     if (s_hi - s_lo < 16) return false;
     const int t_lo = s_lo >> 2, t_hi = (s_hi + 3) >> 2;
-    HotArgs ha;
+    HotArgs ha{};
     ha.in = in_dev; ha.in_stride = (long)in_stride; ha.out = out_dev; ha.out_stride = (long)out_stride;
     ha.tapfrag = tapfrag.p; ha.lut = lut.p; ha.inc = inc; ha.n0_lo = (uint32_t)(n0 - phase0); ha.negative = negative;
     ha.base0_rel = g.base0_rel; ha.OG = OGh; ha.ovl = 0; ha.t_lo = t_lo; ha.t_hi = t_hi; ha.cre = cre; ha.cim = cim;
@@ -1058,6 +1062,17 @@ struct sdrhip_iqbb_i16 {
     if (resident) htpw = tiles_h;
     else if (env_tpw) htpw = env_tpw;   // tuning hook
     a.fix_lo = resident ? fix_lo : 0; a.fix_hi = resident ? fix_hi : 0;
+    // ... and where they do not (few channels, or a count that leaves the grid uneven): the owners of neighbouring slices
+    // can complete the first output between them by a handshake through device memory (iqbb_hot.hpp, hs_exchange) — ONE
+    // launch, SDRHIP_IQBB_FM_HANDSHAKE=1. It is NOT the default: the write-through stores and the wait in front of the loads
+    // cost each wave two memory round trips per unit, and the second, tiny launch (iqbb_fm_fixup_kernel) it replaces costs
+    // nothing that can be measured — per buffer, host to host, on ONE channel: 42.2 us against 41.4 us (sdr_fm's plan),
+    // device-resident 11.7 against 11.2 us; at 128 channels 27 against 21 us (profiles/r17_*).
+    const bool handshake = fix_hi > fix_lo && !resident && env_fm_handshake == 1 && hs.p != nullptr && 4 * tiles_h + 2 <= hs_stride;
+    if (handshake) {
+      if (++hs_seq <= 0) hs_seq = 1;
+      ha.hs = hs.p; ha.hs_stride = hs_stride; ha.hs_seq = hs_seq;
+    }
     ha.tpw = htpw;
     ha.G = (int)ceil_div((size_t)tiles_h, (size_t)htpw); ha.U = ha.G * C;
     const int grid = (int)ceil_div((size_t)std::max(1, std::min(nvwg, std::max(ha.U, C))), (size_t)vper);   // (every channel's cold slices need a taker too)
@@ -1066,7 +1081,7 @@ struct sdrhip_iqbb_i16 {
     HotLaunch hl{(unsigned)grid, ctx->stream};
     if (D < 8) (void)hot_launch_sd(S, kind, hot_range, inc != 0, epi, hl, ha, a, false);
     else hot_launch_anyd(S, kind, hot_range, inc != 0, epi, hl, ha, a);
-    if (!resident && fix_hi > fix_lo)
+    if (!resident && !handshake && fix_hi > fix_lo)
       hipLaunchKernelGGL(iqbb_fm_fixup_kernel, dim3((unsigned)ceil_div((size_t)(fix_hi - fix_lo), (size_t)256), (unsigned)C), dim3(256), 0, ctx->stream,
                          reinterpret_cast<short *>(out_dev), (long)out_stride, philast.p, 4 * tiles_h, fix_lo, fix_hi, GS, C);
     return true;
@@ -1228,6 +1243,7 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
       { const char *e = getenv("SDRHIP_IQBB_TPW"); if (e) h->env_tpw = std::max(1, atoi(e)); }
       { const char *e = getenv("SDRHIP_IQBB_WGPCU"); if (e) h->env_wgpcu = std::max(1, atoi(e)); }
       { const char *e = getenv("SDRHIP_IQBB_FM_RESIDENT"); if (e) h->env_fm_resident = atoi(e) != 0; }
+      { const char *e = getenv("SDRHIP_IQBB_FM_HANDSHAKE"); if (e) h->env_fm_handshake = atoi(e) != 0; }
       const char *force = getenv("SDRHIP_IQBB_PATH");   // "valu": test hook (the VALU kernel for every plan)
       if (force && !strcmp(force, "valu")) mfma_ok = false;
       h->path = mfma_ok ? 1 : 0;
@@ -1291,6 +1307,8 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
       if (epilogue == SDRHIP_EPI_FM && h->path == 3 && decim >= 2 && decim <= 512) {   // any-D hot forms: one angle per slice of the longest call (launch_anyd_call)
         const size_t GS = 512 / (size_t)decim, tiles_h = ceil_div(max_in / (size_t)decim + 2, 4 * GS);
         h->philast.alloc((size_t)channels * 4 * tiles_h + 1024);
+        h->hs_stride = (int)(4 * tiles_h + 2);
+        h->hs.alloc((size_t)2 * channels * h->hs_stride); h->hs.zero(ctx->stream);   // (call numbers start at 1: a zeroed entry matches none)
       }
       { const char *e = getenv("SDRHIP_IQBB_BIGD_MIN"); if (e) { h->bigd_min = std::max(257, atoi(e)); h->bigd_skip_lo = 513; } }   // tuning / test hook
       { const char *e = getenv("SDRHIP_IQBB_BIGD_ALWAYS"); if (e && atoi(e) != 0 && decim >= 257) { h->bigd_always = true; h->bigd_skip_lo = 513; } }   // test hook: short calls too
@@ -1360,7 +1378,8 @@ int sdrhip_iqbb_i16_kernel_names(sdrhip_iqbb_i16 *h, char *buf, size_t len) {
     else if (h->path == 3 && h->bigd_plan()) nm = h->channel_units() ? "iqbb_hot_anyd_kernel" : "iqbb_hot_anyd_kernel,iqbb_bigd_finish_kernel";   // (calls of a few tiles: the general kernel)
     else if (h->path == 3 && h->anyd_plan()) {   // (calls of a few tiles: the general kernel "iqbb_i16_mfmag_kernel")
       nm = h->D < 8 ? "iqbb_hot_sd_kernel" : "iqbb_hot_anyd_kernel";
-      if (h->epi == SDRHIP_EPI_FM && !h->channel_units()) nm = h->D < 8 ? "iqbb_hot_sd_kernel,iqbb_fm_fixup_kernel" : "iqbb_hot_anyd_kernel,iqbb_fm_fixup_kernel";
+      if (h->epi == SDRHIP_EPI_FM && !h->channel_units() && (h->env_fm_handshake != 1 || !h->hs.p))
+        nm = h->D < 8 ? "iqbb_hot_sd_kernel,iqbb_fm_fixup_kernel" : "iqbb_hot_anyd_kernel,iqbb_fm_fixup_kernel";
     }
     else if (h->path == 3) nm = "iqbb_i16_mfmag_kernel";
     else if (h->path == 1 && h->use_hot && h->hot_range >= 0) nm = "iqbb_hot_kernel";   // (calls of < 3 tiles: the general kernel)

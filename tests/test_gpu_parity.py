@@ -162,7 +162,7 @@ ANYD_CASES = [(21, 125, 100e3, True), (16, 62, 100e3, False), (21, 9, -60e3, Fal
               (255, 4, 100e3, True), (130, 2, -60e3, False), (257, 5, 0.0, True), (200, 3, 100e3, False)]   # (no shift: examples/sdr_rec.cc:42-58 tunes every mode to the centre; 21 taps / 45: examples/sdr_pocsag.cc:117 and sdr_ax25.cc:117 behind a 1 MS/s RTL source)
 
 
-@pytest.mark.parametrize("epi,hot", [(e, h) for e in (sa.EPI_NONE, sa.EPI_FM, sa.EPI_AM, sa.EPI_USB) for h in (True, False)] + [(sa.EPI_FM, "resident")])
+@pytest.mark.parametrize("epi,hot", [(e, h) for e in (sa.EPI_NONE, sa.EPI_FM, sa.EPI_AM, sa.EPI_USB) for h in (True, False)] + [(sa.EPI_FM, "resident"), (sa.EPI_FM, "handshake")])
 @pytest.mark.parametrize("order,decim,Fc,cu8", ANYD_CASES)
 def test_iqbb_any_decimation_long_calls_vs_oracle(ctx, orc, order, decim, Fc, cu8, epi, hot, monkeypatch):
     """The reference's own receivers decimate by 62 (examples/sdr_rec.cc:68, 16 taps) and 125 (examples/sdr_fm.cc:40, 21
@@ -171,9 +171,12 @@ def test_iqbb_any_decimation_long_calls_vs_oracle(ctx, orc, order, decim, Fc, cu
     written by both). Ragged long and short calls, state carried across them, against the oracle; `hot` = False: the
     general kernel alone (SDRHIP_IQBB_HOT=0); "resident" (FM only): whole channels as the hot kernel's units, which then
     completes the slices' first angle differences itself instead of leaving them to iqbb_fm_fixup_kernel (what 1024 or 8192
-    channels get by themselves: SDRHIP_IQBB_FM_RESIDENT forces it on these 3)."""
+    channels get by themselves: SDRHIP_IQBB_FM_RESIDENT forces it on these 3). "handshake" (FM, units that are not whole
+    channels): ONE launch too — the owners of neighbouring slices complete the first output between them through device
+    memory (SDRHIP_IQBB_FM_HANDSHAKE=1; measured no faster than the fix-up launch, so not the default)."""
     monkeypatch.setenv("SDRHIP_IQBB_HOT", "1" if hot else "0")
     monkeypatch.setenv("SDRHIP_IQBB_FM_RESIDENT", "1" if hot == "resident" else "0")
+    monkeypatch.setenv("SDRHIP_IQBB_FM_HANDSHAKE", "1" if hot == "handshake" else "0")
     monkeypatch.delenv("SDRHIP_IQBB_PATH", raising=False)
     monkeypatch.delenv("SDRHIP_IQBB_BIGD_MIN", raising=False)
     # decimations 257 ... 512 run either of two hot forms (by default the faster one: the large-decimation form below 465):
@@ -186,10 +189,10 @@ def test_iqbb_any_decimation_long_calls_vs_oracle(ctx, orc, order, decim, Fc, cu
         # demodulator — both ways for every epilogue)
         for resident in ([False, True] if bigd and hot is True else [hot == "resident"]):
             monkeypatch.setenv("SDRHIP_IQBB_FM_RESIDENT", "1" if resident else "0")
-            _any_decimation_case(ctx, orc, order, decim, Fc, cu8, epi, hot, bigd, resident)
+            _any_decimation_case(ctx, orc, order, decim, Fc, cu8, epi, hot, bigd, resident, hot == "handshake")
 
 
-def _any_decimation_case(ctx, orc, order, decim, Fc, cu8, epi, hot, bigd, resident):
+def _any_decimation_case(ctx, orc, order, decim, Fc, cu8, epi, hot, bigd, resident, handshake=False):
     FSr, C = 1e6, 3
     rng = np.random.default_rng(order * 1000 + decim)
     taps, lut, inc = orc.iqbb_design(abs(Fc), 12.5e3, FSr, order), orc.freqshift_lut_i16(), orc.freqshift_inc(Fc, FSr)
@@ -207,7 +210,7 @@ def _any_decimation_case(ctx, orc, order, decim, Fc, cu8, epi, hot, bigd, reside
     # (the small-decimation form's sample arrays must fit a workgroup's LDS beside the tap fragments: where they do not
     # in the class's own workgroup — 9 or 17 K steps WITHOUT a shift: two arrays of 18-bit values — the plan runs in one of
     # twice the waves sharing the fragments; every plan of up to 257 taps has a hot form)
-    launches = [hot_name] + (["iqbb_fm_fixup_kernel"] if epi == sa.EPI_FM and not resident else [])
+    launches = [hot_name] + (["iqbb_fm_fixup_kernel"] if epi == sa.EPI_FM and not resident and not handshake else [])
     if bigd:
         launches = [hot_name] + ([] if resident else ["iqbb_bigd_finish_kernel"])
     assert node.kernel_names == (launches if hot else ["iqbb_i16_mfmag_kernel"])
@@ -285,13 +288,17 @@ def test_iqbb_any_decimation_full_size(ctx, orc):
             assert np.array_equal(y[k], fm.process(bb.process(orc.autocast_cu8_cs16(base[k, i * N:(i + 1) * N])))), (k, i)
 
 
-@pytest.mark.parametrize("epi,resident", [(sa.EPI_FM, False), (sa.EPI_FM, True), (sa.EPI_NONE, False)])
+@pytest.mark.parametrize("epi,resident", [(sa.EPI_FM, False), (sa.EPI_FM, "handshake"), (sa.EPI_FM, True), (sa.EPI_NONE, False)])
 def test_iqbb_any_decimation_more_channels_than_workgroups(ctx, orc, epi, resident, monkeypatch):
     """More channels (1100) than the persistent grid has workgroups (1024): the hot units and the cold slices of the any-D
     form wrap around. 16 taps at decimation 62 on complex<int16>, two calls (the second starts inside a group). FM with
     units of 4 tiles + the fix-up launch (what 1100 channels get), and with whole channels as units (forced: some workgroups
-    then walk two channels and complete both themselves)."""
+    then walk two channels and complete both themselves). "handshake": ONE launch with units of 4 tiles — the slices'
+    first outputs by the neighbours' handshake (SDRHIP_IQBB_FM_HANDSHAKE=1)."""
+    handshake = resident == "handshake"
+    resident = resident is True
     monkeypatch.setenv("SDRHIP_IQBB_FM_RESIDENT", "1" if resident else "0")
+    monkeypatch.setenv("SDRHIP_IQBB_FM_HANDSHAKE", "1" if handshake else "0")
     C, N, D = 1100, 40001, 62
     FSr = 1e6
     taps, lut, inc = orc.iqbb_design(100e3, 12.5e3, FSr, 16), orc.freqshift_lut_i16(), orc.freqshift_inc(-100e3, FSr)
@@ -299,7 +306,7 @@ def test_iqbb_any_decimation_more_channels_than_workgroups(ctx, orc, epi, reside
     base = rng.integers(-32768, 32768, (8, 2 * N, 2), dtype=np.int16)
     x = np.ascontiguousarray(base[np.arange(C) % 8])
     node = sa.IQBaseBandI16(ctx, taps, lut, inc, True, D, channels=C, max_in=N, epilogue=epi)
-    assert node.kernel_names == ["iqbb_hot_anyd_kernel"] + (["iqbb_fm_fixup_kernel"] if epi == sa.EPI_FM and not resident else [])
+    assert node.kernel_names == ["iqbb_hot_anyd_kernel"] + (["iqbb_fm_fixup_kernel"] if epi == sa.EPI_FM and not resident and not handshake else [])
     ys = [node.process(x[:, :N]), node.process(x[:, N:])]
     for y in ys:
         for k in range(8):
@@ -311,6 +318,38 @@ def test_iqbb_any_decimation_more_channels_than_workgroups(ctx, orc, epi, reside
             if epi == sa.EPI_FM:
                 r = fm.process(r)
             assert np.array_equal(y[k], r), (k, i)
+
+
+@pytest.mark.parametrize("C", [1, 16, 128, 1100])
+@pytest.mark.parametrize("order,decim,Fc,cu8", [(21, 125, 100e3, True), (16, 20, 0.0, True), (21, 4, 100e3, True), (127, 125, -100e3, False)])
+def test_iqbb_fm_one_launch_at_any_channel_count(ctx, orc, C, order, decim, Fc, cu8, monkeypatch):
+    """The reference's graphs are ONE channel (examples/sdr_fm.cc:40-43: 21 taps, /125; sdr_rec.cc:66-72): with
+    SDRHIP_IQBB_FM_HANDSHAKE=1 FM at a decimation other than 8 is ONE launch whatever the channel count — whole channels as
+    units where they fill the grid, the neighbouring slices' handshake otherwise — with ragged calls (a call that ends
+    inside a group, a one-sample call) and the state carried across them, bit-exact against the oracle on every channel.
+    (Measured no faster than the two-launch form at any channel count — profiles/r17_ab_fm_handshake.txt — so opt-in.)"""
+    for k in ("SDRHIP_IQBB_HOT", "SDRHIP_IQBB_FM_RESIDENT", "SDRHIP_IQBB_PATH"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("SDRHIP_IQBB_FM_HANDSHAKE", "1")
+    FSr = 1e6
+    taps, lut, inc = orc.iqbb_design(abs(Fc), 12.5e3, FSr, order), orc.freqshift_lut_i16(), orc.freqshift_inc(Fc, FSr)
+    node = sa.IQBaseBandI16(ctx, taps, lut, inc, Fc < 0, decim, channels=C, max_in=65536, epilogue=sa.EPI_FM)
+    if cu8:
+        node.set_input_format(sa.abi.IN_CU8)
+    assert node.kernel_names == ["iqbb_hot_sd_kernel" if decim < 8 else "iqbb_hot_anyd_kernel"]
+    rng = np.random.default_rng(C * 1000 + decim)
+    nb = min(C, 8)
+    refs = [(orc.IQBaseBandI16(taps, lut, inc, Fc < 0, decim), orc.FMDemodI16()) for _ in range(nb)]
+    for n in (65536, 40001, 1, 65536, 12345, 65536):
+        base = rng.integers(0, 256, (nb, n, 2), dtype=np.uint8) if cu8 else rng.integers(-32768, 32768, (nb, n, 2), dtype=np.int16)
+        x = np.ascontiguousarray(base[np.arange(C) % nb])
+        y = node.process(x)
+        for k in range(nb):
+            bb, fm = refs[k]
+            r = bb.process(orc.autocast_cu8_cs16(base[k]) if cu8 else base[k])
+            r = fm.process(r) if len(r) else np.zeros(0, np.int16)
+            assert y[k].shape == r.shape and np.array_equal(y[k], r), (n, k)
+            assert (y[k::nb] == y[k]).all(), (n, k)
 
 
 def test_iqbb_random_fullscale_vs_oracle(ctx, orc, k1path):
