@@ -455,12 +455,49 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
         }
 #endif
       }
+#ifndef K1_MFMA_ORDER
+#define K1_MFMA_ORDER 1
+#endif
+#if K1_MFMA_ORDER == 1
+      // A step's four MFMAs in an order in which ONE operand stays between neighbours — (Al,uh) (Ah,uh) (Ah,ul) (Al,ul): two
+      // changes of the tap operand and one of the sample plane inside a step, where (Al,uh) (Al,ul) (Ah,uh) (Ah,ul) changed
+      // the sample plane every time. The kernel runs at the socket's power limit and an int8 MFMA's energy follows what its
+      // multipliers' inputs switch: -1.4 % per launch, FM and USB alike (tools/abk1.py, 9 interleaved rounds, bands that
+      // do not overlap: profiles/r17_ab_mfma_order.txt; -DK1_MFMA_ORDER=0: the old order). The asm statements pin the order.
+      acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.Al, o.uh, acc_mid, 0, 0, 0);
+      asm volatile("" : "+v"(acc_mid));
+      if (s >= S0 && s < S0 + NH) {
+        acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.Ah, o.uh, acc_hh, 0, 0, 0);
+        asm volatile("" : "+v"(acc_hh));
+        if (!CU8) { acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.Ah, o.ul, acc_mid, 0, 0, 0); asm volatile("" : "+v"(acc_mid)); }
+      }
+      if (!CU8) { acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.Al, o.ul, acc_ll, 0, 0, 0); asm volatile("" : "+v"(acc_ll)); }
+#elif K1_MFMA_ORDER == 2
+      // (tuning variant: alternate the step's direction — even steps (Al,uh) (Ah,uh) (Ah,ul) (Al,ul), odd steps the reverse —
+      // so that the tap operand Al also carries over the step boundary's neighbours as little changed as the algebra allows)
+      if ((s & 1) == 0) {
+        acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.Al, o.uh, acc_mid, 0, 0, 0); asm volatile("" : "+v"(acc_mid));
+        if (s >= S0 && s < S0 + NH) {
+          acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.Ah, o.uh, acc_hh, 0, 0, 0); asm volatile("" : "+v"(acc_hh));
+          if (!CU8) { acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.Ah, o.ul, acc_mid, 0, 0, 0); asm volatile("" : "+v"(acc_mid)); }
+        }
+        if (!CU8) { acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.Al, o.ul, acc_ll, 0, 0, 0); asm volatile("" : "+v"(acc_ll)); }
+      } else {
+        if (!CU8) { acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.Al, o.ul, acc_ll, 0, 0, 0); asm volatile("" : "+v"(acc_ll)); }
+        if (s >= S0 && s < S0 + NH) {
+          if (!CU8) { acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.Ah, o.ul, acc_mid, 0, 0, 0); asm volatile("" : "+v"(acc_mid)); }
+          acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.Ah, o.uh, acc_hh, 0, 0, 0); asm volatile("" : "+v"(acc_hh));
+        }
+        acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.Al, o.uh, acc_mid, 0, 0, 0); asm volatile("" : "+v"(acc_mid));
+      }
+#else
       acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.Al, o.uh, acc_mid, 0, 0, 0);
       if (!CU8) acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.Al, o.ul, acc_ll, 0, 0, 0);
       if (s >= S0 && s < S0 + NH) {
         acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.Ah, o.uh, acc_hh, 0, 0, 0);
         if (!CU8) acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.Ah, o.ul, acc_mid, 0, 0, 0);
       }
+#endif
       o = nx;
     }
 #endif
