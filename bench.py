@@ -1193,12 +1193,13 @@ def run_sdrhip(a):
     def step(with_gather, compute=True):
         i = it[0]
         o = i & 1
+        comm.gather_wait(o)   # (enqueued on the ranks' streams: the gather of step i - 2 has read outs[o]; a slot never begun: nothing)
         if compute:
             for r in range(G):
                 ws[r].run(i % a.batches, o)
             it[0] = i + 1
-        if with_gather:   # (ordered on the ranks' streams in both directions by the library: no host wait between steps)
-            comm.gather([ws[r].outs[o].data_ptr() for r in range(G)], [C * row_bytes] * G, gathered.data_ptr(), 0)
+        if with_gather:   # on the comm's own streams, behind this step's kernels: the next step's kernels start meanwhile
+            comm.gather_begin(o, [ws[r].outs[o].data_ptr() for r in range(G)], [C * row_bytes] * G, gathered.data_ptr(), 0)
 
     def timed(n, with_gather, compute=True):
         comm.synchronize()
@@ -1207,6 +1208,8 @@ def run_sdrhip(a):
             t.start()
         for _ in range(n):
             step(with_gather, compute)
+        comm.gather_wait(0)
+        comm.gather_wait(1)
         for t in timers:
             t.stop()
         comm.synchronize()
@@ -1260,7 +1263,7 @@ def run_sdrhip(a):
                         "frac": round(C * N * alg / per_launch_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "kernel": w0.kernels[0],
                         "kernels_per_step": w0.kernels, "algorithmic_bytes_per_sample": alg,
                         "avg_launch_ms": round(ms[0] / K, 4), "avg_launch_ms_min_rank": round(min(ms) / K, 4), "avg_launch_ms_max_rank": round(max(ms) / K, 4),
-                        "avg_launch_note": "HIP events on each rank's stream around the K steps INCLUDING that stream's share of the gather",
+                        "avg_launch_note": "HIP events on each rank's stream around the K steps; the gather runs on the comm's own streams (sdrhip_comm_gather_begin / _wait), double-buffered",
                         "ranks_seen": G,
                         "with_gather_msamples_s": round(total / wall / 1e6, 2), "without_gather_msamples_s": round(total / wall_ng / 1e6, 2),
                         "without_gather_ms_per_step": round(wall_ng / K * 1e3, 4), "without_gather_avg_launch_ms": round(ms_ng[0] / K, 4),

@@ -421,7 +421,15 @@ int sdrhip_comm_transport(sdrhip_comm *c, const char **name); /* "rccl" or "same
 int sdrhip_comm_broadcast(sdrhip_comm *c, void *const *bufs_dev, size_t bytes, int root);
 /* rank r's bytes[r] bytes at send_dev[r] -> recv_dev (on the root's device), concatenated in rank order */
 int sdrhip_comm_gather(sdrhip_comm *c, const void *const *send_dev, const size_t *bytes, void *recv_dev, int root);
-int sdrhip_comm_synchronize(sdrhip_comm *c);
+/* The same gather OVERLAPPED with the ranks' next kernels (double-buffered outputs, as the reference's nodes keep sending
+ * while downstream still reads the previous buffer): the transfer runs on streams the comm owns, behind what the ranks'
+ * streams have enqueued so far, and nothing waits for it until sdrhip_comm_gather_wait(c, slot) enqueues — on every rank's
+ * stream — a wait for the transfer begun under `slot` (0 ... 3; a slot never begun is no wait). Between begin and wait the
+ * caller neither overwrites send_dev[r] nor reads recv_dev. Typical step k: wait(k & 1); launch the kernels writing output
+ * buffer k & 1; begin(k & 1, ...). */
+int sdrhip_comm_gather_begin(sdrhip_comm *c, int slot, const void *const *send_dev, const size_t *bytes, void *recv_dev, int root);
+int sdrhip_comm_gather_wait(sdrhip_comm *c, int slot);
+int sdrhip_comm_synchronize(sdrhip_comm *c);   /* every rank's stream, and the comm's own transfer streams */
 int sdrhip_comm_destroy(sdrhip_comm *c);
 
 /* ---- pinned host memory, asynchronous copies (staging of the many-channel nodes) --------------------------------- */

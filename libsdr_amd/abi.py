@@ -158,6 +158,8 @@ def lib():
             "sdrhip_comm_transport": (C.c_int, [vp, C.POINTER(C.c_char_p)]),
             "sdrhip_comm_broadcast": (C.c_int, [vp, pvp, sz, C.c_int]),
             "sdrhip_comm_gather": (C.c_int, [vp, pvp, psz, vp, C.c_int]),
+            "sdrhip_comm_gather_begin": (C.c_int, [vp, C.c_int, pvp, psz, vp, C.c_int]),
+            "sdrhip_comm_gather_wait": (C.c_int, [vp, C.c_int]),
             "sdrhip_comm_synchronize": (C.c_int, [vp]),
             "sdrhip_comm_destroy": (C.c_int, [vp]),
             "sdrhip_host_alloc": (C.c_int, [sz, pvp]),

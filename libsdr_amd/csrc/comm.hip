@@ -71,6 +71,25 @@ struct sdrhip_comm {
   std::vector<hipEvent_t> ev;           // same-device transport: one event per rank (its stream has produced / consumed a buffer)
   std::vector<hipEvent_t> ev2;          // ... and one more per rank for the opposite direction of the same call
   bool use_rccl = false;
+  // gather_begin / gather_wait: the transfers run on streams the comm owns (one per rank, made at the first begin), so that
+  // a rank's next kernels do not queue up behind them
+  static constexpr int kSlots = 4;
+  std::vector<hipStream_t> side;                 // per rank
+  std::vector<hipEvent_t> ready;                 // per rank: its stream has produced the send buffer
+  std::vector<hipEvent_t> done[kSlots];          // per slot and rank: the transfer issued under the slot has read / written that rank's memory
+  bool slot_used[kSlots] = {false, false, false, false};
+  void make_side() {
+    if (!side.empty()) return;
+    const size_t n = ctx.size();
+    side.resize(n); ready.resize(n);
+    for (int k = 0; k < kSlots; k++) done[k].resize(n);
+    for (size_t r = 0; r < n; r++) {
+      ctx[r]->use();
+      SDRHIP_CHECK_HIP(hipStreamCreateWithFlags(&side[r], hipStreamNonBlocking));
+      SDRHIP_CHECK_HIP(hipEventCreateWithFlags(&ready[r], hipEventDisableTiming));
+      for (int k = 0; k < kSlots; k++) SDRHIP_CHECK_HIP(hipEventCreateWithFlags(&done[k][r], hipEventDisableTiming));
+    }
+  }
 };
 
 extern "C" {
@@ -209,10 +228,69 @@ int sdrhip_comm_gather(sdrhip_comm *c, const void *const *send_dev, const size_t
   });
 }
 
+int sdrhip_comm_gather_begin(sdrhip_comm *c, int slot, const void *const *send_dev, const size_t *bytes, void *recv_dev, int root) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(c && send_dev && bytes && recv_dev, SDRHIP_E_INVALID, "NULL argument");
+    const int n = (int)c->ctx.size();
+    SDRHIP_REQUIRE(root >= 0 && root < n, SDRHIP_E_INVALID, "root %d outside [0,%d)", root, n);
+    SDRHIP_REQUIRE(slot >= 0 && slot < sdrhip_comm::kSlots, SDRHIP_E_INVALID, "slot %d outside [0,%d)", slot, sdrhip_comm::kSlots);
+    std::vector<size_t> off(n + 1, 0);
+    for (int r = 0; r < n; r++) { SDRHIP_REQUIRE(!bytes[r] || send_dev[r], SDRHIP_E_INVALID, "rank %d: NULL buffer", r); off[r + 1] = off[r] + bytes[r]; }
+    c->make_side();
+    char *dst = static_cast<char *>(recv_dev);
+    // every rank's side stream starts behind what the rank's own stream has enqueued so far (the kernel that fills send_dev[r])
+    for (int r = 0; r < n; r++) {
+      c->ctx[r]->use();
+      SDRHIP_CHECK_HIP(hipEventRecord(c->ready[r], c->ctx[r]->stream));
+      SDRHIP_CHECK_HIP(hipStreamWaitEvent(c->side[r], c->ready[r], 0));
+    }
+    if (c->use_rccl) {
+      c->ctx[root]->use();
+      if (bytes[root]) SDRHIP_CHECK_HIP(hipMemcpyAsync(dst + off[root], send_dev[root], bytes[root], hipMemcpyDeviceToDevice, c->side[root]));
+      bool any = false;
+      for (int r = 0; r < n; r++) any = any || (r != root && bytes[r]);
+      if (any) {
+        SDRHIP_CHECK_NCCL(rccl().GroupStart());
+        for (int r = 0; r < n; r++) {
+          if (r == root || !bytes[r]) continue;
+          SDRHIP_CHECK_NCCL(rccl().Send(send_dev[r], bytes[r], ncclUint8, root, c->nccl[r], c->side[r]));
+          SDRHIP_CHECK_NCCL(rccl().Recv(dst + off[r], bytes[r], ncclUint8, r, c->nccl[root], c->side[root]));
+        }
+        SDRHIP_CHECK_NCCL(rccl().GroupEnd());
+      }
+      for (int r = 0; r < n; r++) { c->ctx[r]->use(); SDRHIP_CHECK_HIP(hipEventRecord(c->done[slot][r], c->side[r])); }
+    } else {   // one device: the root's side stream copies every block once the owning rank's stream has produced it
+      c->ctx[root]->use();
+      for (int r = 0; r < n; r++) {
+        if (!bytes[r]) continue;
+        if (r != root) SDRHIP_CHECK_HIP(hipStreamWaitEvent(c->side[root], c->ready[r], 0));
+        SDRHIP_CHECK_HIP(hipMemcpyAsync(dst + off[r], send_dev[r], bytes[r], hipMemcpyDeviceToDevice, c->side[root]));
+      }
+      for (int r = 0; r < n; r++) SDRHIP_CHECK_HIP(hipEventRecord(c->done[slot][r], c->side[root]));
+    }
+    c->slot_used[slot] = true;
+  });
+}
+
+int sdrhip_comm_gather_wait(sdrhip_comm *c, int slot) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(c, SDRHIP_E_INVALID, "comm is NULL");
+    SDRHIP_REQUIRE(slot >= 0 && slot < sdrhip_comm::kSlots, SDRHIP_E_INVALID, "slot %d outside [0,%d)", slot, sdrhip_comm::kSlots);
+    if (!c->slot_used[slot]) return;
+    const int n = (int)c->ctx.size();
+    for (int r = 0; r < n; r++) { c->ctx[r]->use(); SDRHIP_CHECK_HIP(hipStreamWaitEvent(c->ctx[r]->stream, c->done[slot][r], 0)); }
+    c->slot_used[slot] = false;
+  });
+}
+
 int sdrhip_comm_synchronize(sdrhip_comm *c) {
   return guarded([&] {
     SDRHIP_REQUIRE(c, SDRHIP_E_INVALID, "comm is NULL");
-    for (sdrhip_ctx *x : c->ctx) { x->use(); SDRHIP_CHECK_HIP(hipStreamSynchronize(x->stream)); }
+    for (size_t r = 0; r < c->ctx.size(); r++) {
+      c->ctx[r]->use();
+      SDRHIP_CHECK_HIP(hipStreamSynchronize(c->ctx[r]->stream));
+      if (!c->side.empty()) SDRHIP_CHECK_HIP(hipStreamSynchronize(c->side[r]));
+    }
   });
 }
 
@@ -220,6 +298,11 @@ int sdrhip_comm_destroy(sdrhip_comm *c) {
   return guarded([&] {
     if (!c) return;
     for (sdrhip_ctx *x : c->ctx) { x->use(); (void)hipStreamSynchronize(x->stream); }
+    for (size_t r = 0; r < c->side.size(); r++) {
+      c->ctx[r]->use();
+      (void)hipStreamSynchronize(c->side[r]); (void)hipStreamDestroy(c->side[r]); (void)hipEventDestroy(c->ready[r]);
+      for (int k = 0; k < sdrhip_comm::kSlots; k++) (void)hipEventDestroy(c->done[k][r]);
+    }
     if (c->use_rccl) for (ncclComm_t k : c->nccl) if (k) (void)rccl().CommDestroy(k);
     for (size_t r = 0; r < c->ev.size(); r++) { c->ctx[r]->use(); (void)hipEventDestroy(c->ev[r]); (void)hipEventDestroy(c->ev2[r]); }
     for (sdrhip_ctx *x : c->ctx) (void)sdrhip_ctx_destroy(x);

@@ -680,6 +680,15 @@ class Comm:
         nb = (C.c_size_t * len(nbytes))(*nbytes)
         check(abi.lib().sdrhip_comm_gather(self._h, sp, nb, C.c_void_p(recv_ptr), root))
 
+    def gather_begin(self, slot, send_ptrs, nbytes, recv_ptr, root=0):
+        """The gather on the comm's own streams (overlaps the ranks' next kernels); gather_wait(slot) orders the ranks' streams behind it."""
+        sp = (C.c_void_p * len(send_ptrs))(*send_ptrs)
+        nb = (C.c_size_t * len(nbytes))(*nbytes)
+        check(abi.lib().sdrhip_comm_gather_begin(self._h, slot, sp, nb, C.c_void_p(recv_ptr), root))
+
+    def gather_wait(self, slot):
+        check(abi.lib().sdrhip_comm_gather_wait(self._h, slot))
+
     def synchronize(self):
         check(abi.lib().sdrhip_comm_synchronize(self._h))
 

@@ -315,6 +315,30 @@ static void testCommPipelinedAndTwoDevices() {
       ok = ok && g[n * 4 - 1] == uint8_t(0x10 * (k + 1)) && g[2 * n * 4 - 1] == uint8_t(0x10 * (k + 1) + 1);
       CHECK(ok);
     }
+    // the overlapped form (sdrhip_comm_gather_begin / _wait): double-buffered send buffers, step k waits for the gather of
+    // step k - 2 before it refills buffer k & 1; six steps, every landing zone checked, then the slots drained
+    { void *snd2[2][2], *land[6];
+      for (int r = 0; r < 2; r++) for (int o = 0; o < 2; o++) sdrhip_malloc(ctx[r], n * 4, &snd2[r][o]);
+      for (int k = 0; k < 6; k++) sdrhip_malloc(ctx[0], 2 * n * 4, &land[k]);
+      for (int k = 0; k < 6; k++) {
+        const int o = k & 1;
+        CHECK(sdrhip_comm_gather_wait(cm, o) == SDRHIP_OK);
+        for (int r = 0; r < 2; r++) sdrhip_memset(ctx[r], snd2[r][o], 0x20 + 8 * k + r, n * 4);
+        const void *sp[2] = {snd2[0][o], snd2[1][o]};
+        CHECK(sdrhip_comm_gather_begin(cm, o, sp, bytes, land[k], 0) == SDRHIP_OK);
+      }
+      CHECK(sdrhip_comm_gather_wait(cm, 0) == SDRHIP_OK && sdrhip_comm_gather_wait(cm, 1) == SDRHIP_OK);
+      CHECK(sdrhip_comm_gather_wait(cm, 3) == SDRHIP_OK);   // (a slot never begun: no wait)
+      CHECK(sdrhip_comm_gather_begin(cm, 9, send, bytes, land[0], 0) == SDRHIP_E_INVALID);
+      CHECK(sdrhip_comm_synchronize(cm) == SDRHIP_OK);
+      for (int k = 0; k < 6; k++) {
+        sdrhip_memcpy_d2h(ctx[0], g.data(), land[k], g.size());
+        bool ok = true;
+        for (int r = 0; r < 2; r++) for (size_t i = 0; i < n * 4; i += 4093) ok = ok && g[r * n * 4 + i] == uint8_t(0x20 + 8 * k + r);
+        CHECK(ok);
+      }
+      for (int r = 0; r < 2; r++) for (int o = 0; o < 2; o++) sdrhip_free(ctx[r], snd2[r][o]);
+      for (int k = 0; k < 6; k++) sdrhip_free(ctx[0], land[k]); }
     for (int r = 0; r < 2; r++) { sdrhip_free(ctx[r], snd[r]); sdrhip_free(ctx[r], des[r]); }
     for (int k = 0; k < 3; k++) sdrhip_free(ctx[0], all[k]);
     CHECK(sdrhip_comm_destroy(cm) == SDRHIP_OK);

@@ -352,6 +352,27 @@ def test_iqbb_fm_one_launch_at_any_channel_count(ctx, orc, C, order, decim, Fc, 
             assert (y[k::nb] == y[k]).all(), (n, k)
 
 
+def test_big_lds_plans_on_a_second_device(orc):
+    """HIP function attributes are per device: the plans that need more than 64 KB of dynamic LDS (255 taps at /125 — 17 K
+    steps in a 16-wave workgroup —, the small-decimation form, the large-decimation form) raise the limit once per DEVICE.
+    Runs them on device 1 of a process that has already run them on device 0 (needs two GPUs: skipped on the one-GPU boxes)."""
+    if sa.device_count() < 2:
+        pytest.skip("one HIP device")
+    FSr = 1e6
+    rng = np.random.default_rng(5)
+    for order, decim in ((255, 125), (255, 4), (21, 300)):
+        taps, lut, inc = orc.iqbb_design(100e3, 12.5e3, FSr, order), orc.freqshift_lut_i16(), orc.freqshift_inc(100e3, FSr)
+        x = rng.integers(-32768, 32768, (2, 65536, 2), dtype=np.int16)
+        ref = orc.FMDemodI16().process(orc.IQBaseBandI16(taps, lut, inc, False, decim).process(x[1]))
+        for dev in (0, 1):
+            c = sa.Context(dev)
+            node = sa.IQBaseBandI16(c, taps, lut, inc, False, decim, channels=2, max_in=65536, epilogue=sa.EPI_FM)
+            y = node.process(x)
+            assert np.array_equal(y[1], ref), (order, decim, dev)
+            node.close()
+            c.close()
+
+
 def test_iqbb_random_fullscale_vs_oracle(ctx, orc, k1path):
     """Full-range random int16 input (worst case for the int32 accumulators and the >>14/>>16 steps)."""
     rng = np.random.default_rng(7)
@@ -464,7 +485,8 @@ class _GpuRetune:
     def set_order(self, order, Ff, width, Fc):
         # setOrder (src/baseband.hh:69-79): kernel and ring only
         self.order = order
-        self._replan(Ff, width, Fc, self.D, self.max_in, sa.abi.KEEP_FM | sa.abi.KEEP_COUNTERS)
+        # (KEEP_FM only between plans that both fuse the FM demodulator: the ABI refuses it otherwise, as the C++ node masks it)
+        self._replan(Ff, width, Fc, self.D, self.max_in, (sa.abi.KEEP_FM if self.epi == sa.EPI_FM else 0) | sa.abi.KEEP_COUNTERS)
 
 
 @pytest.mark.parametrize("which,epi", [("g12_retune_out", sa.EPI_NONE), ("g12_retune_fm", sa.EPI_FM)])
@@ -546,7 +568,11 @@ def test_iqbb_adopt_state_vs_oracle(ctx, orc, k1path, cu8):
                 order = v
                 taps = sa.design_iqbb_taps(-150e3, 60e3, FS, order)
                 neu = make(taps, D, epi)
-                neu.adopt_state(node, sa.abi.KEEP_FM | sa.abi.KEEP_COUNTERS)
+                neu.adopt_state(node, (sa.abi.KEEP_FM if epi == sa.EPI_FM else 0) | sa.abi.KEEP_COUNTERS)
+                if epi != sa.EPI_FM:   # (the flag without the FM epilogue on both plans is an argument error)
+                    with pytest.raises(sa.SdrHipError) as e:
+                        make(taps, D, epi).adopt_state(node, sa.abi.KEEP_FM | sa.abi.KEEP_COUNTERS)
+                    assert e.value.code == sa.abi.E_INVALID
                 node = neu
                 for c in range(C):
                     refs[c].set_order(taps)
