@@ -7,7 +7,7 @@ R=${1:-r09}; shift
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 declare -A W=( [fm127]="" [fm16]="--order 16" [fm21]="--order 21" [fm64]="--order 64" [fm255]="--order 255" [usb127]="--workload iqbb_usb"
                [cu8]="--workload iqbb_fm_cu8" [real]="--workload bb_real_fm" [fir255]="--workload fir255_fm" [fbb]="--workload fbb_f32"
-               [fftconv]="--workload fftconv --fft-whole-blocks" [fftbank]="--workload fftbank" [fmdemod]="--workload fm_demod" [sub8]="--workload subsample8"
+               [fftconv]="--workload fftconv --fft-whole-blocks" [fftola]="--workload fftconv_ola" [fftbank]="--workload fftbank" [fmdemod]="--workload fm_demod" [sub8]="--workload subsample8"
                [sdrfm]="--workload iqbb_fm_cu8 --order 21 --decim 125" [sdrrec]="--workload iqbb_fm_cu8 --order 16 --decim 83 --fc 0"
                [sdrfmchain]="--workload iqbb_fm_cu8 --order 21 --decim 125 --deemph" [wfmchain]="--workload iqbb_fm_cu8 --order 16 --decim 20 --fc 0 --deemph"
                [pocsag]="--workload iqbb_fm_cu8 --order 21 --decim 45 --fc 0" [ssb]="--workload iqbb_usb --order 16 --decim 83 --fc 0"
@@ -16,11 +16,11 @@ declare -A W=( [fm127]="" [fm16]="--order 16" [fm21]="--order 21" [fm64]="--orde
                [o255d125]="--workload iqbb_fm_cu8 --order 255 --decim 125" )   # (d300 / d1000: the large-decimation form; o255d125: the any-D form's long-filter class)   # round 4: the small-decimation form (not in the default list)   # examples/sdr_pocsag.cc:117 / sdr_ax25.cc:117 (21 taps, 1 MS/s to 22.05 kS/s); sdr_rec's USB mode on complex<int16>
 #   # ... and the whole chains: + FMDeemph (sdr_fm.cc:44-53; sdr_rec.cc WFM: 16 taps, no shift, 1 MS/s to 50 kS/s)
 #    # the plans of examples/sdr_fm.cc:40 and examples/sdr_rec.cc:42-68 (narrow FM: no shift, 1 MS/s to 12 kS/s)
-NAMES=${@:-fm127 fm16 fm21 fm64 fm255 usb127 cu8 real fir255 fbb fftconv fftbank fmdemod sub8 sdrfm sdrrec sdrfmchain wfmchain pocsag ssb}
+NAMES=${@:-fm127 fm16 fm21 fm64 fm255 usb127 cu8 real fir255 fbb fftconv fftola fftbank fmdemod sub8 sdrfm sdrrec sdrfmchain wfmchain pocsag ssb sd4 sd7usb d300 d1000 o255d125}
 mkdir -p gpurun_out
 : > gpurun_out/${R}_bench_other_workloads.jsonl
 for n in $NAMES; do
-  if [ "$n" = fm127 ]; then python bench.py > gpurun_out/${R}_bench.json 2> gpurun_out/${R}_bench.err
+  if [ "$n" = fm127 ]; then python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${R}_bench.json 2> gpurun_out/${R}_bench.err   # (the driver's own command line: headline + "configs")
   else python bench.py ${W[$n]} --cpu-seconds 3 2>/dev/null | grep '^{' >> gpurun_out/${R}_bench_other_workloads.jsonl; fi
 done
 python bench.py --workload fbb_f32 --channels 1 --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | grep '^{' >> gpurun_out/${R}_bench_other_workloads.jsonl
