@@ -825,6 +825,8 @@ def measure_config(a, spec, sa, torch, shard, ctx, dev, np):
     if spec["workload"] == "fbb_f32" and C == 1:   # config 2 as SURVEY §8d states it: what a buffer costs, and against real time
         e["roofline"]["per_buffer_us"] = round(per_launch_s * 1e6, 2)
         e["roofline"]["real_time_factor"] = round((N / FS) / per_launch_s, 1)
+        if pre_n:   # (K = 20 launches of a few microseconds each mostly time the launch ramp: the back-to-back figure beside it)
+            e["roofline"]["per_buffer_us_sustained"] = round(pre_ms / pre_n * 1e3, 2)
     del timer
     w.node.close()
     del w

@@ -384,6 +384,16 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
 #pragma unroll
     for (int s = 0; s < NH; s++) AhR[s] = taps_s[(S + s) * 64 + l];
   }
+  // (K1_ARES = n: the HIGH-plane tap fragments of the first n high steps stay in registers for the whole kernel — the headline
+  // kernel uses 114 of the 128 registers four waves per SIMD leave it; a fragment read is 1 KB per wave and slice, and LDS
+  // reads are a fifth of the energy of a launch that runs at the power limit. Not for the AM epilogue: 126 registers.)
+#ifndef K1_ARES
+#define K1_ARES 0
+#endif
+  constexpr int NRES = (K1_AREG || CU8 || REAL || EPI == SDRHIP_EPI_AM || NW != 4) ? 0 : (K1_ARES < NH ? K1_ARES : NH);
+  v4i AhRes[NRES > 0 ? NRES : 1];
+#pragma unroll
+  for (int s = 0; s < NRES; s++) AhRes[s] = taps_s[(S + s) * 64 + l];
   struct KOps { v4i uh, ul, Al, Ah; };
   auto stageK_begin = [&](const char *cb, KOps &o) __attribute__((always_inline)) {
     const char *pl = cb + coff, *ph = cb + (CU8 ? 0 : PLB) + coff;
@@ -392,7 +402,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
     if (K1_AREG) { o.Al = AlR[0]; o.Ah = AhR[0]; }
     else {
       o.Al = taps_s[l]; o.Ah = o.Al;
-      if (S0 == 0) o.Ah = taps_s[S * 64 + l];
+      if (S0 == 0) o.Ah = NRES > 0 ? AhRes[0] : taps_s[S * 64 + l];
     }
   };
   auto stageK = [&](const char *cb, KOps &o, v16i &acc_hh, v16i &acc_mid, v16i &acc_ll) __attribute__((always_inline)) {
@@ -451,7 +461,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
           if (s + 1 >= S0 && s + 1 < S0 + NH) nx.Ah = AhR[s + 1 - S0];
         } else {
           nx.Al = taps_s[(s + 1) * 64 + l];
-          if (s + 1 >= S0 && s + 1 < S0 + NH) nx.Ah = taps_s[(S + s + 1 - S0) * 64 + l];
+          if (s + 1 >= S0 && s + 1 < S0 + NH) nx.Ah = (s + 1 - S0 < NRES) ? AhRes[s + 1 - S0 < NRES ? s + 1 - S0 : 0] : taps_s[(S + s + 1 - S0) * 64 + l];
         }
 #endif
       }
@@ -851,6 +861,14 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   // other's entry (agent-scope loads): whoever finds it — at least one of the two does, both may — writes the output
   // (again through the L2; the two values are the same). The entry carries the call's number, so nothing of an older call
   // is mistaken for this one's. A lane passes first / last for the group it holds; sid: its slice, phi: its angle.
+  // Compiled in only under -DK1_FM_HANDSHAKE (tools/build_variant.sh hs "-DK1_FM_HANDSHAKE"; run with SDRHIP_IQBB_FM_HANDSHAKE=1):
+  // it measured no faster than the fix-up launch at any channel count, and its mere presence — a kernel-uniform branch at
+  // the four emission sites — cost the any-D FM kernels 2-4 % (profiles/r17_ab_fm_handshake.txt, r17_ab_nohs.txt).
+#ifdef K1_FM_HANDSHAKE
+#define HS_ON(A_) ((A_).hs != nullptr)
+#else
+#define HS_ON(A_) false
+#endif
   auto hs_exchange = [&](const HotArgs &A, bool first, bool last, int cc, int sid, int phi) __attribute__((always_inline)) {
     long long *plast = A.hs + (long)cc * A.hs_stride + sid + 1;              // slice sid's last angle
     long long *pfirst = A.hs + ((long)A.C + cc) * A.hs_stride + sid + 1;     // slice sid's first angle
@@ -898,7 +916,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       // the previous slice's last angle, which that slice's last group leaves in philast
       const int phi = fm_phi(yr, yi);
       const int prev = __builtin_amdgcn_update_dpp(0, phi, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);   // entry l - 1: the group before, within a slice
-      if (a.hs != nullptr) {   // (kernel-uniform) few channels: the slices' first outputs by the neighbours' handshake
+      if (HS_ON(a)) {   // (kernel-uniform) few channels: the slices' first outputs by the neighbours' handshake
         if (live && k_f > 0) *reinterpret_cast<short *>(orow) = (short)(prev - phi);
         hs_exchange(a, live && k_f == 0, live && k_f == GS - 1, c_, 4 * (ptile0 + j_f) + wv, phi);
       } else {
@@ -963,7 +981,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
         const int phi = fm_phi(yr, yi);
         int prev = __builtin_amdgcn_update_dpp(0, phi, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);   // lane l - 1: group k - 1
         if (l == 0) prev = carry_phi;   // (i = 0: the slice's first group, -phi for now)
-        if (a.hs != nullptr) {   // (kernel-uniform)
+        if (HS_ON(a)) {   // (kernel-uniform)
           if (live && k > 0) reinterpret_cast<short *>(orow)[k] = (short)(prev - phi);
           if (i == 0 || 64 * (i + 1) >= GS) hs_exchange(a, live && k == 0, live && k == GS - 1, c_, 4 * tile_ + wv, phi);   // (scalar: the chunks that hold the first / last group)
         } else {
@@ -1016,7 +1034,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
         if (q == 0) o = (short)yr;                                   // index 0 is never written by FMDemod (in place)
         else if (q == 1) o = (short)((int)b.fm_old[cc] - phi);       // y[0] is never looked at: the previous call's last angle
         else o = (short)(prev - phi);                                // (a slice's first group: prev = 0, the fix-up launch adds philast)
-        if (ac.hs != nullptr) {   // (kernel-uniform)
+        if (HS_ON(ac)) {   // (kernel-uniform)
           const bool hfirst = emits && k == 0 && q >= 2;   // (outputs 0 and 1 have their own rules above)
           if (emits && !hfirst) reinterpret_cast<short *>(ac.out)[(long)cc * ac.out_stride + q] = o;
           if (i == 0 || 64 * (i + 1) >= GS) hs_exchange(ac, hfirst, emits && k == GS - 1, cc, sid, phi);
@@ -1238,7 +1256,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       if (q == 0) o = (short)yr;                                   // index 0 is never written by FMDemod (in place)
       else if (q == 1) o = (short)((int)b.fm_old[cc] - phi);       // y[0] is never looked at: the previous call's last angle
       else o = (short)((k > 0 ? prev : 0) - phi);                  // (a slice's first group: the fix-up launch adds philast)
-      if (ac.hs != nullptr) {   // (kernel-uniform)
+      if (HS_ON(ac)) {   // (kernel-uniform)
         const bool hfirst = emits && k == 0 && q >= 2;   // (outputs 0 and 1 have their own rules above)
         if (emits && !hfirst) reinterpret_cast<short *>(ac.out)[(long)cc * ac.out_stride + q] = o;
         hs_exchange(ac, hfirst, emits && k == GS - 1, cc, sid, phi);

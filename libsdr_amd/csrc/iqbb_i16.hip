@@ -1064,11 +1064,15 @@ struct sdrhip_iqbb_i16 {
     a.fix_lo = resident ? fix_lo : 0; a.fix_hi = resident ? fix_hi : 0;
     // ... and where they do not (few channels, or a count that leaves the grid uneven): the owners of neighbouring slices
     // can complete the first output between them by a handshake through device memory (iqbb_hot.hpp, hs_exchange) — ONE
-    // launch, SDRHIP_IQBB_FM_HANDSHAKE=1. It is NOT the default: the write-through stores and the wait in front of the loads
+    // launch, in builds with -DK1_FM_HANDSHAKE under SDRHIP_IQBB_FM_HANDSHAKE=1. NOT in the shipped build: the write-through stores and the wait in front of the loads
     // cost each wave two memory round trips per unit, and the second, tiny launch (iqbb_fm_fixup_kernel) it replaces costs
     // nothing that can be measured — per buffer, host to host, on ONE channel: 42.2 us against 41.4 us (sdr_fm's plan),
     // device-resident 11.7 against 11.2 us; at 128 channels 27 against 21 us (profiles/r17_*).
+#ifdef K1_FM_HANDSHAKE
     const bool handshake = fix_hi > fix_lo && !resident && env_fm_handshake == 1 && hs.p != nullptr && 4 * tiles_h + 2 <= hs_stride;
+#else
+    const bool handshake = false;   // (the kernels are built without it: see iqbb_hot.hpp, hs_exchange)
+#endif
     if (handshake) {
       if (++hs_seq <= 0) hs_seq = 1;
       ha.hs = hs.p; ha.hs_stride = hs_stride; ha.hs_seq = hs_seq;
@@ -1307,8 +1311,10 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
       if (epilogue == SDRHIP_EPI_FM && h->path == 3 && decim >= 2 && decim <= 512) {   // any-D hot forms: one angle per slice of the longest call (launch_anyd_call)
         const size_t GS = 512 / (size_t)decim, tiles_h = ceil_div(max_in / (size_t)decim + 2, 4 * GS);
         h->philast.alloc((size_t)channels * 4 * tiles_h + 1024);
+#ifdef K1_FM_HANDSHAKE
         h->hs_stride = (int)(4 * tiles_h + 2);
         h->hs.alloc((size_t)2 * channels * h->hs_stride); h->hs.zero(ctx->stream);   // (call numbers start at 1: a zeroed entry matches none)
+#endif
       }
       { const char *e = getenv("SDRHIP_IQBB_BIGD_MIN"); if (e) { h->bigd_min = std::max(257, atoi(e)); h->bigd_skip_lo = 513; } }   // tuning / test hook
       { const char *e = getenv("SDRHIP_IQBB_BIGD_ALWAYS"); if (e && atoi(e) != 0 && decim >= 257) { h->bigd_always = true; h->bigd_skip_lo = 513; } }   // test hook: short calls too

@@ -223,15 +223,12 @@ def _hot_fuzz(ctx, orc, rng, order, cu8, decim=8):
     rng.shuffle(lens)
     # (any-D forms, FM: the slices' first angle differences by the fix-up launch or inside the hot kernel — read at create)
     resident = int(rng.integers(0, 2))
-    handshake = int(rng.integers(0, 2))   # (units that are not whole channels: the neighbours' handshake, or the fix-up launch)
     os.environ["SDRHIP_IQBB_FM_RESIDENT"] = str(resident)
-    os.environ["SDRHIP_IQBB_FM_HANDSHAKE"] = str(handshake)
     try:
         node = sa.IQBaseBandI16(ctx, taps, lut, inc, Fc < 0, decim, channels=C, max_in=max(lens), epilogue=epi)
     finally:
         del os.environ["SDRHIP_IQBB_FM_RESIDENT"]
-        del os.environ["SDRHIP_IQBB_FM_HANDSHAKE"]
-    fix = ["iqbb_fm_fixup_kernel"] if epi == sa.EPI_FM and not resident and not handshake else []
+    fix = ["iqbb_fm_fixup_kernel"] if epi == sa.EPI_FM and not resident else []
     if 257 <= decim <= 464 or decim > 512:   # (the large-decimation form: partial box sums + a finishing launch, whatever the demodulator)
         fix = [] if resident else ["iqbb_bigd_finish_kernel"]
     if cu8:

@@ -162,7 +162,7 @@ ANYD_CASES = [(21, 125, 100e3, True), (16, 62, 100e3, False), (21, 9, -60e3, Fal
               (255, 4, 100e3, True), (130, 2, -60e3, False), (257, 5, 0.0, True), (200, 3, 100e3, False)]   # (no shift: examples/sdr_rec.cc:42-58 tunes every mode to the centre; 21 taps / 45: examples/sdr_pocsag.cc:117 and sdr_ax25.cc:117 behind a 1 MS/s RTL source)
 
 
-@pytest.mark.parametrize("epi,hot", [(e, h) for e in (sa.EPI_NONE, sa.EPI_FM, sa.EPI_AM, sa.EPI_USB) for h in (True, False)] + [(sa.EPI_FM, "resident"), (sa.EPI_FM, "handshake")])
+@pytest.mark.parametrize("epi,hot", [(e, h) for e in (sa.EPI_NONE, sa.EPI_FM, sa.EPI_AM, sa.EPI_USB) for h in (True, False)] + [(sa.EPI_FM, "resident")])
 @pytest.mark.parametrize("order,decim,Fc,cu8", ANYD_CASES)
 def test_iqbb_any_decimation_long_calls_vs_oracle(ctx, orc, order, decim, Fc, cu8, epi, hot, monkeypatch):
     """The reference's own receivers decimate by 62 (examples/sdr_rec.cc:68, 16 taps) and 125 (examples/sdr_fm.cc:40, 21
@@ -171,12 +171,10 @@ def test_iqbb_any_decimation_long_calls_vs_oracle(ctx, orc, order, decim, Fc, cu
     written by both). Ragged long and short calls, state carried across them, against the oracle; `hot` = False: the
     general kernel alone (SDRHIP_IQBB_HOT=0); "resident" (FM only): whole channels as the hot kernel's units, which then
     completes the slices' first angle differences itself instead of leaving them to iqbb_fm_fixup_kernel (what 1024 or 8192
-    channels get by themselves: SDRHIP_IQBB_FM_RESIDENT forces it on these 3). "handshake" (FM, units that are not whole
-    channels): ONE launch too — the owners of neighbouring slices complete the first output between them through device
-    memory (SDRHIP_IQBB_FM_HANDSHAKE=1; measured no faster than the fix-up launch, so not the default)."""
+    channels get by themselves: SDRHIP_IQBB_FM_RESIDENT forces it on these 3)."""
     monkeypatch.setenv("SDRHIP_IQBB_HOT", "1" if hot else "0")
     monkeypatch.setenv("SDRHIP_IQBB_FM_RESIDENT", "1" if hot == "resident" else "0")
-    monkeypatch.setenv("SDRHIP_IQBB_FM_HANDSHAKE", "1" if hot == "handshake" else "0")
+    monkeypatch.delenv("SDRHIP_IQBB_FM_HANDSHAKE", raising=False)
     monkeypatch.delenv("SDRHIP_IQBB_PATH", raising=False)
     monkeypatch.delenv("SDRHIP_IQBB_BIGD_MIN", raising=False)
     # decimations 257 ... 512 run either of two hot forms (by default the faster one: the large-decimation form below 465):
@@ -189,7 +187,7 @@ def test_iqbb_any_decimation_long_calls_vs_oracle(ctx, orc, order, decim, Fc, cu
         # demodulator — both ways for every epilogue)
         for resident in ([False, True] if bigd and hot is True else [hot == "resident"]):
             monkeypatch.setenv("SDRHIP_IQBB_FM_RESIDENT", "1" if resident else "0")
-            _any_decimation_case(ctx, orc, order, decim, Fc, cu8, epi, hot, bigd, resident, hot == "handshake")
+            _any_decimation_case(ctx, orc, order, decim, Fc, cu8, epi, hot, bigd, resident)
 
 
 def _any_decimation_case(ctx, orc, order, decim, Fc, cu8, epi, hot, bigd, resident, handshake=False):
@@ -288,17 +286,15 @@ def test_iqbb_any_decimation_full_size(ctx, orc):
             assert np.array_equal(y[k], fm.process(bb.process(orc.autocast_cu8_cs16(base[k, i * N:(i + 1) * N])))), (k, i)
 
 
-@pytest.mark.parametrize("epi,resident", [(sa.EPI_FM, False), (sa.EPI_FM, "handshake"), (sa.EPI_FM, True), (sa.EPI_NONE, False)])
+@pytest.mark.parametrize("epi,resident", [(sa.EPI_FM, False), (sa.EPI_FM, True), (sa.EPI_NONE, False)])
 def test_iqbb_any_decimation_more_channels_than_workgroups(ctx, orc, epi, resident, monkeypatch):
     """More channels (1100) than the persistent grid has workgroups (1024): the hot units and the cold slices of the any-D
     form wrap around. 16 taps at decimation 62 on complex<int16>, two calls (the second starts inside a group). FM with
     units of 4 tiles + the fix-up launch (what 1100 channels get), and with whole channels as units (forced: some workgroups
-    then walk two channels and complete both themselves). "handshake": ONE launch with units of 4 tiles — the slices'
-    first outputs by the neighbours' handshake (SDRHIP_IQBB_FM_HANDSHAKE=1)."""
-    handshake = resident == "handshake"
-    resident = resident is True
+    then walk two channels and complete both themselves)."""
+    handshake = False
     monkeypatch.setenv("SDRHIP_IQBB_FM_RESIDENT", "1" if resident else "0")
-    monkeypatch.setenv("SDRHIP_IQBB_FM_HANDSHAKE", "1" if handshake else "0")
+    monkeypatch.delenv("SDRHIP_IQBB_FM_HANDSHAKE", raising=False)
     C, N, D = 1100, 40001, 62
     FSr = 1e6
     taps, lut, inc = orc.iqbb_design(100e3, 12.5e3, FSr, 16), orc.freqshift_lut_i16(), orc.freqshift_inc(-100e3, FSr)
@@ -322,12 +318,12 @@ def test_iqbb_any_decimation_more_channels_than_workgroups(ctx, orc, epi, reside
 
 @pytest.mark.parametrize("C", [1, 16, 128, 1100])
 @pytest.mark.parametrize("order,decim,Fc,cu8", [(21, 125, 100e3, True), (16, 20, 0.0, True), (21, 4, 100e3, True), (127, 125, -100e3, False)])
-def test_iqbb_fm_one_launch_at_any_channel_count(ctx, orc, C, order, decim, Fc, cu8, monkeypatch):
-    """The reference's graphs are ONE channel (examples/sdr_fm.cc:40-43: 21 taps, /125; sdr_rec.cc:66-72): with
-    SDRHIP_IQBB_FM_HANDSHAKE=1 FM at a decimation other than 8 is ONE launch whatever the channel count — whole channels as
-    units where they fill the grid, the neighbouring slices' handshake otherwise — with ragged calls (a call that ends
-    inside a group, a one-sample call) and the state carried across them, bit-exact against the oracle on every channel.
-    (Measured no faster than the two-launch form at any channel count — profiles/r17_ab_fm_handshake.txt — so opt-in.)"""
+def test_iqbb_fm_at_any_channel_count(ctx, orc, C, order, decim, Fc, cu8, monkeypatch):
+    """The reference's graphs are ONE channel (examples/sdr_fm.cc:40-43: 21 taps, /125; sdr_rec.cc:66-72): FM at a decimation
+    other than 8 on 1, 16, 128 and 1100 channels — the hot kernel + the tiny fix-up launch (or, in a -DK1_FM_HANDSHAKE build under
+    SDRHIP_IQBB_FM_HANDSHAKE=1, ONE launch: the neighbouring slices' handshake) — with ragged calls (a call that ends inside
+    a group, a one-sample call) and the state carried across them, bit-exact against the oracle on every channel. (The
+    handshake measured no faster at any channel count — profiles/r17_ab_fm_handshake.txt — and is not in the shipped build.)"""
     for k in ("SDRHIP_IQBB_HOT", "SDRHIP_IQBB_FM_RESIDENT", "SDRHIP_IQBB_PATH"):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setenv("SDRHIP_IQBB_FM_HANDSHAKE", "1")
@@ -336,7 +332,8 @@ def test_iqbb_fm_one_launch_at_any_channel_count(ctx, orc, C, order, decim, Fc, 
     node = sa.IQBaseBandI16(ctx, taps, lut, inc, Fc < 0, decim, channels=C, max_in=65536, epilogue=sa.EPI_FM)
     if cu8:
         node.set_input_format(sa.abi.IN_CU8)
-    assert node.kernel_names == ["iqbb_hot_sd_kernel" if decim < 8 else "iqbb_hot_anyd_kernel"]
+    hot_name = "iqbb_hot_sd_kernel" if decim < 8 else "iqbb_hot_anyd_kernel"
+    assert node.kernel_names in ([hot_name], [hot_name, "iqbb_fm_fixup_kernel"])   # (one launch only in a handshake build)
     rng = np.random.default_rng(C * 1000 + decim)
     nb = min(C, 8)
     refs = [(orc.IQBaseBandI16(taps, lut, inc, Fc < 0, decim), orc.FMDemodI16()) for _ in range(nb)]
