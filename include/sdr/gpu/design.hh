@@ -153,6 +153,31 @@ inline void dft(std::vector< std::complex<double> > &a, int sign) {
   if (n < 2) return;
   size_t p = n;
   for (size_t q = 2; q * q <= n; q++) if (n % q == 0) { p = q; break; }
+  if (p == n && n > 64) {   // a large prime (FilterNode(1009): 2018 = 2 x 1009): the chirp transform over radix-2 transforms
+    size_t M = 1; while (M < 2 * n - 1) M <<= 1;
+    struct R2 { static void run(std::vector< std::complex<long double> > &v, int sg) {
+      const size_t L = v.size();
+      for (size_t i = 1, j = 0; i < L; i++) { size_t bit = L >> 1; for (; j & bit; bit >>= 1) j ^= bit; j ^= bit; if (i < j) std::swap(v[i], v[j]); }
+      for (size_t len = 2; len <= L; len <<= 1)
+        for (size_t k = 0; k < len / 2; k++) {
+          const long double ang = sg * 2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)len;
+          const std::complex<long double> wk(cosl(ang), sinl(ang));
+          for (size_t q = 0; q < L; q += len) { const std::complex<long double> u = v[q + k], t = wk * v[q + k + len / 2]; v[q + k] = u + t; v[q + k + len / 2] = u - t; }
+        } } };
+    std::vector< std::complex<long double> > w(n), A(M), B(M);
+    for (size_t j = 0; j < n; j++) {
+      const long double ang = sign * 3.14159265358979323846264338327950288L * (long double)((j * j) % (2 * n)) / (long double)n;
+      w[j] = std::complex<long double>(cosl(ang), sinl(ang));
+      A[j] = std::complex<long double>(a[j].real(), a[j].imag()) * w[j];
+      B[j] = std::conj(w[j]);
+      if (j) B[M - j] = std::conj(w[j]);
+    }
+    R2::run(A, -1); R2::run(B, -1);
+    for (size_t k = 0; k < M; k++) A[k] *= B[k];
+    R2::run(A, +1);
+    for (size_t k = 0; k < n; k++) { const std::complex<long double> v = A[k] / (long double)M * w[k]; a[k] = std::complex<double>((double)v.real(), (double)v.imag()); }
+    return;
+  }
   const size_t m = n / p;
   std::vector< std::vector< std::complex<double> > > part(p);
   if (m > 1)

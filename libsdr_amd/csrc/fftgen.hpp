@@ -325,7 +325,33 @@ inline void host_dft(std::vector< std::complex<double> > &a, int sign) {
   size_t r = 0;
   for (size_t q = 2; q * q <= n && !r; q++) if (n % q == 0) r = q;
   const long double PI2 = 2.0L * 3.14159265358979323846264338327950288L;
-  if (!r) {   // prime length: direct
+  if (!r && n > 64) {   // a large prime: Bluestein's chirp transform over radix-2 transforms of M >= 2n - 1 points, all in double
+    size_t M = 1; while (M < 2 * n - 1) M <<= 1;
+    auto fft2 = [](std::vector< std::complex<long double> > &v, int sg) {
+      const size_t L = v.size();
+      for (size_t i = 1, j = 0; i < L; i++) { size_t bit = L >> 1; for (; j & bit; bit >>= 1) j ^= bit; j ^= bit; if (i < j) std::swap(v[i], v[j]); }
+      for (size_t len = 2; len <= L; len <<= 1)
+        for (size_t k = 0; k < len / 2; k++) {
+          const long double ang = sg * 2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)len;
+          const std::complex<long double> wk(cosl(ang), sinl(ang));
+          for (size_t q = 0; q < L; q += len) { const std::complex<long double> u = v[q + k], t = wk * v[q + k + len / 2]; v[q + k] = u + t; v[q + k + len / 2] = u - t; }
+        }
+    };
+    std::vector< std::complex<long double> > w(n), A(M, std::complex<long double>(0, 0)), B(M, std::complex<long double>(0, 0));
+    for (size_t j = 0; j < n; j++) {
+      const long double ang = sign * 3.14159265358979323846264338327950288L * (long double)((j * j) % (2 * n)) / (long double)n;   // (j^2 mod 2n: exact phase)
+      w[j] = std::complex<long double>(cosl(ang), sinl(ang));
+      A[j] = std::complex<long double>(a[j].real(), a[j].imag()) * w[j];
+      B[j] = std::conj(w[j]);
+      if (j) B[M - j] = std::conj(w[j]);
+    }
+    fft2(A, -1); fft2(B, -1);
+    for (size_t k = 0; k < M; k++) A[k] *= B[k];
+    fft2(A, +1);
+    for (size_t k = 0; k < n; k++) { const std::complex<long double> v = A[k] / (long double)M * w[k]; a[k] = std::complex<double>((double)v.real(), (double)v.imag()); }
+    return;
+  }
+  if (!r) {   // a small prime: direct
     std::vector< std::complex<double> > o(n);
     for (size_t m = 0; m < n; m++) {
       std::complex<long double> acc(0, 0);

@@ -749,6 +749,28 @@ static void testHostOnly() {
   { gpu::USBDemod<float> n; hostConfigRules(n, Config::Type_cf32, Config::Type_cs16, "USBDemod<float>"); }
   { gpu::SubSample<cs16> n(size_t(8)); hostConfigRules(n, Config::Type_cs16, Config::Type_cf32, "SubSample<cs16>"); }
   { gpu::FMDeemph<int16_t> n; hostConfigRules(n, Config::Type_s16, Config::Type_cs16, "FMDeemph<int16_t>"); }
+  {   // the designers' own DFT (the spectrum of a FilterNode kernel, any 2N): composite, small-prime and large-prime lengths
+      // (a large prime runs the chirp transform) against the direct sum, both signs; the f64 golden spectrum of N = 1000
+    for (size_t n : {12u, 61u, 2018u, 20014u}) {
+      std::vector< std::complex<double> > a(n), b;
+      for (size_t i = 0; i < n; i++) a[i] = std::complex<double>(std::sin(0.37 * i) + 0.25, std::cos(0.011 * i * i));
+      for (int sign = -1; sign <= 1; sign += 2) {
+        b = a; gpu::design::dft(b, sign);
+        double worst = 0, scale = 0;
+        for (size_t k = 0; k < n; k += (n > 256 ? n / 7 : 1)) {
+          std::complex<long double> acc(0, 0);
+          for (size_t i = 0; i < n; i++) {
+            const long double ang = sign * 2.0L * 3.14159265358979323846264338327950288L * (long double)((i * k) % n) / (long double)n;
+            acc += std::complex<long double>(a[i].real(), a[i].imag()) * std::complex<long double>(cosl(ang), sinl(ang));
+          }
+          worst = std::max(worst, (double)std::abs(acc - std::complex<long double>(b[k].real(), b[k].imag())));
+          scale = std::max(scale, (double)std::abs(acc));
+        }
+        if (!(worst <= 1e-11 * scale)) std::printf("  design::dft(%zu, %d): error %.3g of %.3g\n", n, sign, worst, scale);
+        CHECK(worst <= 1e-11 * scale);
+      }
+    }
+  }
   {   // buffers and views as the nodes hand them on (ownership rules of src/buffer.hh:54-104)
     Buffer<cs16> b(64); CHECK(b.isUnused());
     Buffer<cs16> v = b.head(10); b.ref(); CHECK(!b.isUnused() && v.size() == 10); b.unref(); CHECK(b.isUnused());

@@ -137,6 +137,53 @@ def test_fftconv_bank_random_plans(ctx, seed):
             assert np.abs(got - ref).max() / np.abs(ref).max() <= 1e-5, (seed, L, n_taps, B, C, lens, b, c)
 
 
+@pytest.mark.parametrize("seed", range(16 + EXTRA // 2))
+def test_fft_plan_random_sizes(ctx, seed):
+    """FFTPlan at RANDOM sizes — whatever form the plan picks (in LDS, four-step, chirp in LDS, chirp over a four-step plan;
+    fftany.hpp) — float and double, both directions, a batch of 2, against numpy's double FFT."""
+    rng = np.random.default_rng(9100 + seed)
+    n = int(rng.choice([int(rng.integers(1, 300)), int(rng.integers(300, 20000)), int(rng.integers(20000, 70000))]))
+    f64 = bool(rng.integers(0, 2))
+    cdt, tol = (np.complex128, 2e-12) if f64 else (np.complex64, 1e-5)
+    plan = sa.FFTPlan(ctx, n, cdt)
+    x = (rng.standard_normal((2, n)) + 1j * rng.standard_normal((2, n))).astype(cdt)
+    xd = x.astype(np.complex128)
+    for sign, ref in ((-1, np.fft.fft(xd, axis=1)), (+1, np.fft.ifft(xd, axis=1) * n)):
+        y = plan.exec_batch(x, sign)
+        assert np.abs(y - ref).max() <= tol * max(np.abs(ref).max(), 1e-30), (seed, n, plan.form, sign)
+
+
+@pytest.mark.parametrize("seed", range(10 + EXTRA // 4))
+def test_fftconv_random_sizes_beyond_the_tuned_plans(ctx, seed):
+    """Overlap-save at RANDOM FFT sizes (any factorisation, in or beyond one workgroup's LDS: GenConv / BigConv), random tap
+    counts, 1-3 channels, 1-2 bands, ragged calls, float and double — against a direct convolution in double."""
+    from scipy.signal import fftconvolve
+    rng = np.random.default_rng(9300 + seed)
+    L = int(rng.choice([int(rng.integers(8, 3000)), int(rng.integers(3000, 20000)), int(rng.integers(20000, 40000))]))
+    n_taps = int(rng.integers(1, max(2, L // 2)))
+    C, B = int(rng.integers(1, 4)), int(rng.integers(1, 3))
+    f64 = bool(rng.integers(0, 2))
+    dt, tol = (np.float64, 1e-10) if f64 else (np.float32, 1e-5)
+    hs = [(rng.standard_normal((n_taps, 2)) / np.sqrt(n_taps)).astype(dt) for _ in range(B)]
+    max_in = 3 * L
+    node = sa.FFTConv(ctx, sa.FFTCONV_OLS, L, hs if B > 1 else hs[0], channels=C, max_in=max_in, dtype=dt)
+    lens = [int(v) for v in rng.choice([1, 7, L - n_taps + 1, L, 2 * L + 3, max_in], size=3)]
+    x = (rng.standard_normal((C, sum(lens), 2)) * 0.3).astype(dt)
+    ys, off = [], 0
+    for n in lens:
+        ys.append(node.process(x[:, off:off + n])); off += n
+    y = np.concatenate(ys, axis=-2)
+    if B == 1:
+        y = y[None]
+    for b in range(B):
+        hc = hs[b][:, 0].astype(np.float64) + 1j * hs[b][:, 1]
+        for c in range(C):
+            xc = x[c, :, 0].astype(np.float64) + 1j * x[c, :, 1]
+            ref = fftconvolve(xc, hc)[:x.shape[1]]
+            got = y[b, c, :, 0].astype(np.float64) + 1j * y[b, c, :, 1]
+            assert np.abs(got - ref).max() <= tol * np.abs(ref).max(), (seed, L, n_taps, C, B, f64, lens, b, c)
+
+
 @pytest.mark.parametrize("seed", range(10 + EXTRA))
 def test_fir_cs16_exact_random_plans(ctx, orc, seed):
     """Exact per-tap-truncating complex<int16> FIR (+ FM / AM / USB) at random orders and ragged calls: bit-exact, including
