@@ -42,31 +42,76 @@ __global__ __launch_bounds__(GT) void lds_c2c_kernel(const fftgen::GenDev<T2> p,
   for (int i = tid; i < L; i += GT) { T2 v = xl[i]; if (conj) v.y = -v.y; dst[perm[i]] = v; }   // position i holds frequency perm[i]
 }
 
-// one pass of the four-step plan (fftgen.hpp explains the algebra), batched: transform t of batch item z reads
-// in[z n + t ibs + i is] and writes out[z n + t obs + k os]; TW: times W_n^(t k) = wa[a] wb[b], t k = a n2 + b.
-template <class T2, bool TW>
-__global__ __launch_bounds__(GT) void fourstep_pass_kernel(const fftgen::GenDev<T2> p, const int *perm, int conj, long n, const T2 *in, long is, long ibs,
-                                                            T2 *out, long os, long obs, const T2 *wa, const T2 *wb, int n2) {
+// The general plan's passes for a TEAM of `nt` lanes (nt divides GT): a workgroup then runs GT / nt transforms side by side,
+// each in its own LDS array, all teams in step (the barriers are the workgroup's). Same algebra as fftgen::pass_dif.
+template <class T2, int R>
+__device__ __forceinline__ void team_pass_dif(T2 *x, const fftgen::GenDev<T2> &p, int n, int lt, int nt) {
+  const int s = n / R, tw = p.L / n;
+  for (int b = lt; b < p.L / R; b += nt) {
+    const int blk = b / s, j = b - blk * s, base = blk * n + j;
+    T2 v[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) v[k] = x[base + k * s];
+    fftgen::dft_small<T2, R, -1>(v, p);
+    x[base] = v[0];
+#pragma unroll
+    for (int m = 1; m < R; m++) x[base + m * s] = s > 1 ? gmul(v[m], p.W[j * tw * m]) : v[m];
+  }
+}
+template <class T2>
+__device__ void team_forward_dif(T2 *x, const fftgen::GenDev<T2> &p, int lt, int nt) {
+  int n = p.L;
+  for (int pass = 0; pass < p.npass; pass++) {
+    const int r = p.radix[pass];
+#define SDRHIP_GEN_CALL(R_) team_pass_dif<T2, R_>(x, p, n, lt, nt)
+    SDRHIP_GEN_RADIX_SWITCH(r, SDRHIP_GEN_CALL)
+#undef SDRHIP_GEN_CALL
+    __syncthreads();
+    n /= r;
+  }
+}
+
+// One pass of the four-step plan (fftgen.hpp explains the algebra), batched and TILED: a workgroup takes TC neighbouring
+// transforms — pass 1 (COLS): the columns j2 = t TC ... of the n1 x n2 image, each n1 points at stride n2, so that every row
+// of the tile is TC contiguous elements; results, twiddled by W_n^(j2 k1) = wa[a] wb[b] (j2 k1 = a n2 + b), go to
+// A[k1][j2] — again TC contiguous elements per k1. Pass 2 (!COLS): the rows k1 = t TC ... of A (n2 contiguous points each);
+// X[k1 + n1 k2] is TC contiguous elements per k2. `len` = points per transform, `cnt` = transforms per batch item.
+// Backward = conj(forward(conj x)): pass 1 conjugates what it reads, pass 2 what it writes.
+template <class T2, bool COLS>
+__global__ __launch_bounds__(GT) void fourstep_tile_kernel(const fftgen::GenDev<T2> p, const int *perm, int conj, long n, int len, int cnt, int TC,
+                                                            const T2 *in, T2 *out, const T2 *wa, const T2 *wb, int n1, int n2) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T2 *xl = reinterpret_cast<T2 *>(smem_raw);
-  const int tid = threadIdx.x, L = p.L;
-  const long t = blockIdx.x, z = blockIdx.y;
-  const T2 *src = in + z * n + t * ibs;
-  T2 *dst = out + z * n + t * obs;
-  // pass 1 (TW) conjugates what it reads, pass 2 what it writes: conj(F(conj x)) with the twiddles in between untouched
-  for (int i = tid; i < L; i += GT) { T2 v = src[(long)i * is]; if (conj && TW) v.y = -v.y; xl[i] = v; }
+  const int tid = threadIdx.x, nt = GT / TC, team = tid / nt, lt = tid - team * nt;
+  const long z = blockIdx.y;
+  const int t0 = blockIdx.x * TC;   // first transform of the tile
+  const T2 *src = in + z * n;
+  T2 *dst = out + z * n;
+  const int LP = len + 1;           // (one pad element per array: the tile's loads walk the arrays at the same index)
+  // load: element i of transform t0 + c sits at  COLS: i n2 + (t0 + c)   rows: (t0 + c) n2 + i
+  for (int e = tid; e < len * TC; e += GT) {
+    int i, c;
+    if (COLS) { i = e / TC; c = e - i * TC; } else { c = e / len; i = e - c * len; }
+    T2 v = mk<T2>(0, 0);
+    if (t0 + c < cnt) { v = COLS ? src[(long)i * n2 + (t0 + c)] : src[(long)(t0 + c) * n2 + i]; if (conj && COLS) v.y = -v.y; }
+    xl[c * LP + i] = v;
+  }
   __syncthreads();
-  fftgen::forward_dif(xl, p, tid);
-  for (int i = tid; i < L; i += GT) {
-    const int k = perm[i];
-    T2 v = xl[i];
-    if (TW) {
-      const long m = t * (long)k, a_ = m / n2, b_ = m - a_ * n2;
+  team_forward_dif(xl + team * LP, p, lt, nt);
+  // store: frequency k of transform t0 + c goes to  COLS: k n2 + (t0 + c) [twiddled]   rows: (t0 + c) + n1 k
+  for (int e = tid; e < len * TC; e += GT) {
+    const int pos = e / TC, c = e - pos * TC;
+    if (t0 + c >= cnt) continue;
+    const int k = perm[pos];
+    T2 v = xl[c * LP + pos];
+    if (COLS) {
+      const long m = (long)(t0 + c) * k, a_ = m / n2, b_ = m - a_ * n2;
       v = gmul(v, gmul(wa[a_], wb[b_]));
-    } else if (conj) {
-      v.y = -v.y;
+      dst[(long)k * n2 + (t0 + c)] = v;
+    } else {
+      if (conj) v.y = -v.y;
+      dst[(long)(t0 + c) + (long)n1 * k] = v;
     }
-    dst[(long)k * os] = v;
   }
 }
 
@@ -141,16 +186,24 @@ struct AnyFft {
   static long max_lds_points() { return (long)(128 * 1024 / sizeof(T2)); }
   const char *kind_name() const { return kind == LDS ? "lds" : kind == FOURSTEP ? "four-step" : kind == CHIRP ? "chirp" : "chirp over four-step"; }
 
-  // the largest plannable divisor of n whose cofactor is plannable too (0: none)
+  // n = n1 x n2 with both parts plannable in LDS, as BALANCED as the factors allow (two passes of sqrt(n)-point transforms:
+  // a lopsided split would run one pass as tens of thousands of 2-point transforms); 0: none
   static long split(long n) {
     const long maxL = max_lds_points();
     std::vector<int> rx;
     if (!fftgen::GenPlan<T2>::factor_long(n)) return 0;
-    for (long d = maxL; d >= 2; d--) {
+    long best = 0;
+    for (long d = 2; d * d <= n; d++) {   // d <= n / d: the larger part is n / d
       if (n % d || n / d > maxL) continue;
-      if (fftgen::GenPlan<T2>::factor((int)d, rx, nullptr) && fftgen::GenPlan<T2>::factor((int)(n / d), rx, nullptr)) return d;
+      if (fftgen::GenPlan<T2>::factor((int)d, rx, nullptr) && fftgen::GenPlan<T2>::factor((int)(n / d), rx, nullptr)) best = d;
     }
-    return 0;
+    return best ? n / best : 0;   // n1 = the larger part (columns of n1 points in pass 1), n2 = n / n1 <= n1
+  }
+  int tc1 = 1, tc2 = 1;   // transforms per workgroup in pass 1 / pass 2
+  static int tile_count(long len) {   // a power of two <= 16, <= GT / 16 lanes per team, arrays within 96 KB
+    int tc = 16;
+    while (tc > 1 && (size_t)tc * (len + 1) * sizeof(T2) > 96 * 1024) tc >>= 1;
+    return tc;
   }
 
   void build(sdrhip_ctx *ctx_, long n_) {
@@ -174,8 +227,9 @@ struct AnyFft {
       for (long b = 0; b < n2; b++) { const long double ang = -PI2 * (long double)b / (long double)n; hb[b].x = (R)cosl(ang); hb[b].y = (R)sinl(ang); }
       wa.alloc(n1); wa.upload(ha.data(), n1, ctx->stream);
       wb.alloc(n2); wb.upload(hb.data(), n2, ctx->stream);
-      allow_lds(fourstep_pass_kernel<T2, true>, p1.lds_bytes());
-      allow_lds(fourstep_pass_kernel<T2, false>, p2.lds_bytes());
+      tc1 = tile_count(n1); tc2 = tile_count(n2);
+      allow_lds((fourstep_tile_kernel<T2, true>), (size_t)tc1 * (n1 + 1) * sizeof(T2));
+      allow_lds((fourstep_tile_kernel<T2, false>), (size_t)tc2 * (n2 + 1) * sizeof(T2));
       return;
     }
     // a prime factor above 13 (or no split): Bluestein over M = 2^k >= 2n - 1
@@ -252,10 +306,10 @@ struct AnyFft {
         for (long z0 = 0; z0 < batch; z0 += 32768) {
           const long zb = std::min<long>(32768, batch - z0);
           // pass 1: column j2 (stride n2) -> A[k1][j2] = tmp[k1 n2 + j2], twiddled; pass 2: row k1 of A -> X[k1 + n1 k2]
-          hipLaunchKernelGGL((fourstep_pass_kernel<T2, true>), dim3((unsigned)n2, (unsigned)zb), dim3(GT), p1.lds_bytes(), st, p1.dev, p1.perm_d.p, conj, n,
-                             in + z0 * n, n2, 1L, tmp.p + z0 * n, n2, 1L, wa.p, wb.p, (int)n2);
-          hipLaunchKernelGGL((fourstep_pass_kernel<T2, false>), dim3((unsigned)n1, (unsigned)zb), dim3(GT), p2.lds_bytes(), st, p2.dev, p2.perm_d.p, conj, n,
-                             tmp.p + z0 * n, 1L, n2, out + z0 * n, n1, 1L, wa.p, wb.p, (int)n2);
+          hipLaunchKernelGGL((fourstep_tile_kernel<T2, true>), dim3((unsigned)((n2 + tc1 - 1) / tc1), (unsigned)zb), dim3(GT), (size_t)tc1 * (n1 + 1) * sizeof(T2), st,
+                             p1.dev, p1.perm_d.p, conj, n, (int)n1, (int)n2, tc1, in + z0 * n, tmp.p + z0 * n, wa.p, wb.p, (int)n1, (int)n2);
+          hipLaunchKernelGGL((fourstep_tile_kernel<T2, false>), dim3((unsigned)((n1 + tc2 - 1) / tc2), (unsigned)zb), dim3(GT), (size_t)tc2 * (n2 + 1) * sizeof(T2), st,
+                             p2.dev, p2.perm_d.p, conj, n, (int)n2, (int)n1, tc2, tmp.p + z0 * n, out + z0 * n, wa.p, wb.p, (int)n1, (int)n2);
         }
         break;
       case CHIRP:
