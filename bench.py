@@ -999,7 +999,6 @@ def run(a):
         # ---- the other BASELINE configs, each to the same recipe (one GPU, default run only) ----
         configs = None
         if world == 1 and not use_dist and not a.workload and not a.no_configs and not a.global_channels:
-            w_key, w_desc, w_dtype, w_kernels, w_alg, w_in = w.key, w.desc, w.dtype, w.kernels, w.alg_bytes, w.in_bytes
             w.node.close()
             w.ins = w.outs = None
             torch.cuda.empty_cache()
