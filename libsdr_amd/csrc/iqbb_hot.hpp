@@ -427,6 +427,26 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
         // 1 KB. An LDS read costs energy by the byte (tools/probes/mfma_energy.hip: one wave-wide ds_read_b128 is half an
         // MFMA's worth), and the kernel runs at the power limit.
         if (!REAL) {
+#if K1_BSHIFT == 2
+          // (round 5's second cut: the moves have no tied old operand — bound_ctrl zero-fills the lanes without a source, which
+          // the two-lane reads overwrite anyway — and the reads run under an exec mask set INSIDE the asm statement: no
+          // branch, no memory clobber that would pin the tap-fragment loads)
+          auto shl1 = [](v4i x) __attribute__((always_inline)) {
+            v4i r;
+#pragma unroll
+            for (int q = 0; q < 4; q++) r[q] = __builtin_amdgcn_mov_dpp(x[q], 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+            return r;
+          };
+          nx.uh = shl1(o.uh);
+          if (!CU8) nx.ul = shl1(o.ul);
+          const unsigned ah_ = (unsigned)(uintptr_t)(ph + KSB * (s + 1)), al_ = (unsigned)(uintptr_t)(pl + KSB * (s + 1));
+          const unsigned long long m2 = 0x8000000080000000ull;   // lanes 31 and 63
+          if (!CU8)
+            asm volatile("s_mov_b64 exec, %4\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_mov_b64 exec, -1"
+                         : "+v"(nx.uh), "+v"(nx.ul) : "v"(ah_), "v"(al_), "s"(m2));
+          else
+            asm volatile("s_mov_b64 exec, %2\n\tds_read_b128 %0, %1\n\ts_mov_b64 exec, -1" : "+v"(nx.uh) : "v"(ah_), "s"(m2));
+#else
           auto shl1 = [](v4i x) __attribute__((always_inline)) {
             v4i r;
 #pragma unroll
@@ -443,6 +463,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
               asm volatile("ds_read_b128 %0, %1" : "+v"(nx.ul) : "v"(al_) : "memory");
             }
           }
+#endif
         } else
 #endif
         {
