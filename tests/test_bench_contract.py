@@ -252,3 +252,19 @@ def test_dist_line_reports_the_gather_and_the_ranks_it_counted():
     assert rf["ranks_seen"] == 1 and rf["gather_bytes_per_step"] > 0 and rf["gather_bytes_per_step"] % 32 == 0
     assert rf["gather_gbs"] > 0 and rf["gather_gbs_in_step"] > 0 and rf["gather_only_ms_per_step"] > 0
     assert 0 < rf["avg_launch_ms_min_rank"] <= rf["avg_launch_ms_max_rank"]
+
+
+def test_host_side_helpers_touch_no_gpu(tmp_path, monkeypatch):
+    """cpu_limits(): affinity and cgroup quota as numbers; count_gpus_sysfs(): the KFD topology (nodes with SIMDs) or, where
+    that is not readable, a short-lived child — the bench's parent process itself never loads torch or HIP before it starts
+    the ranks (`spawn_ranks`)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    lim = bench.cpu_limits()
+    assert lim["cpus_in_affinity_mask"] >= 1 and lim["cpus_online"] >= lim["cpus_in_affinity_mask"]
+    assert lim["cgroup_quota_cores"] is None or lim["cgroup_quota_cores"] > 0
+    n = bench.count_gpus_sysfs()
+    assert n is None or n >= 0
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("def spawn_ranks(a):"):src.index("def synth_cs16(")]
+    assert "import torch" not in body and "libsdr_amd" not in body
