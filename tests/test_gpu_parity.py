@@ -1448,6 +1448,28 @@ def test_filternode_any_block_size_beyond_one_workgroup(ctx, orc, N, dtype, tol,
     assert np.array_equal(bank.process(x[:, cut:]), fresh.process(x[:, cut:]))
 
 
+def test_filternode_big_block_many_channels(ctx):
+    """FilterNode<float>(16384) on 600 channels: more than one pass of the scratch-bounded channel groups (512 channels per
+    pass at this size), rows of 8 distinct streams tiled over the channels — every copy equal, the distinct ones against the
+    closed form y = h (*) x / (sqrt(2N) ||h||_2)."""
+    from scipy.signal import fftconvolve
+    N, C, nblk = 16384, 600, 2
+    h = sa.design_fftfilt_kernel(N, 50e3, 150e3, FS)
+    K = sa.design_fftfilt_spectrum(h)
+    rng = np.random.default_rng(99)
+    base = (rng.standard_normal((8, nblk * N, 2)) * 0.3).astype(np.float32)
+    x = np.ascontiguousarray(base[np.arange(C) % 8])
+    node = sa.FFTConv(ctx, sa.FFTCONV_OLA, 2 * N, K, channels=C, max_in=nblk * N)
+    y = np.concatenate([node.process(x[:, :N + 5]), node.process(x[:, N + 5:])], axis=1)
+    hc = h[:, 0].astype(np.float64) + 1j * h[:, 1]
+    for k in range(8):
+        assert np.array_equal(y[k::8], np.broadcast_to(y[k], y[k::8].shape)), k
+        xc = base[k, :, 0].astype(np.float64) + 1j * base[k, :, 1]
+        closed = fftconvolve(xc, hc)[:len(xc)] / (np.sqrt(2 * N) * np.sqrt((np.abs(hc) ** 2).sum()))
+        yc = y[k, :, 0].astype(np.float64) + 1j * y[k, :, 1]
+        assert np.abs(yc - closed).max() / np.abs(closed).max() <= RTOL, k
+
+
 def test_fftconv_ols_long_transforms(ctx):
     """overlap-save with time-domain taps on transforms beyond the LDS: 65536 points / 30001 taps (float, four-step) and
     20014 points / 5000 taps (float, chirp over four-step) against a direct convolution in double"""
