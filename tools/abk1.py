@@ -63,7 +63,7 @@ def main():
             xs = [torch.randint(0, 256, (Cn, N, 2), dtype=torch.uint8, device=dev) for _ in range(3)]
         else:
             xs = [torch.randint(-8000, 8000, (Cn, N, 2), dtype=torch.int16, device=dev) for _ in range(3)]
-        out = torch.zeros((Cn, N // 8 + 2, 2), dtype=torch.int16, device=dev)
+        out = torch.zeros((Cn, N // min(a.decim, 8) + 2, 2), dtype=torch.int16, device=dev)
         plans = []
         for v in a.variants:
             name, rest = v.split("=", 1)
