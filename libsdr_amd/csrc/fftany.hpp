@@ -45,10 +45,12 @@ __global__ __launch_bounds__(GT) void lds_c2c_kernel(const fftgen::GenDev<T2> p,
 // The general plan's passes for a TEAM of `nt` lanes (nt divides GT): a workgroup then runs GT / nt transforms side by side,
 // each in its own LDS array, all teams in step (the barriers are the workgroup's). Same algebra as fftgen::pass_dif.
 template <class T2, int R>
-__device__ __forceinline__ void team_pass_dif(T2 *x, const fftgen::GenDev<T2> &p, int n, int lt, int nt) {
+__device__ __forceinline__ void team_pass_dif(T2 *x, const fftgen::GenDev<T2> &p0, const T2 *W, int n, int lt, int nt) {
+  fftgen::GenDev<T2> p = p0; p.W = W;   // (the roots from the workgroup's LDS copy)
   const int s = n / R, tw = p.L / n;
+  const float inv_s = 1.0f / (float)s;   // (b < 2^14: floor((b + 0.5) / s) in float is exact — an integer division costs 30 instructions)
   for (int b = lt; b < p.L / R; b += nt) {
-    const int blk = b / s, j = b - blk * s, base = blk * n + j;
+    const int blk = (int)(((float)b + 0.5f) * inv_s), j = b - blk * s, base = blk * n + j;
     T2 v[R];
 #pragma unroll
     for (int k = 0; k < R; k++) v[k] = x[base + k * s];
@@ -59,11 +61,11 @@ __device__ __forceinline__ void team_pass_dif(T2 *x, const fftgen::GenDev<T2> &p
   }
 }
 template <class T2>
-__device__ void team_forward_dif(T2 *x, const fftgen::GenDev<T2> &p, int lt, int nt) {
+__device__ void team_forward_dif(T2 *x, const fftgen::GenDev<T2> &p, const T2 *W, int lt, int nt) {
   int n = p.L;
   for (int pass = 0; pass < p.npass; pass++) {
     const int r = p.radix[pass];
-#define SDRHIP_GEN_CALL(R_) team_pass_dif<T2, R_>(x, p, n, lt, nt)
+#define SDRHIP_GEN_CALL(R_) team_pass_dif<T2, R_>(x, p, W, n, lt, nt)
     SDRHIP_GEN_RADIX_SWITCH(r, SDRHIP_GEN_CALL)
 #undef SDRHIP_GEN_CALL
     __syncthreads();
@@ -77,9 +79,21 @@ __device__ void team_forward_dif(T2 *x, const fftgen::GenDev<T2> &p, int lt, int
 // A[k1][j2] — again TC contiguous elements per k1. Pass 2 (!COLS): the rows k1 = t TC ... of A (n2 contiguous points each);
 // X[k1 + n1 k2] is TC contiguous elements per k2. `len` = points per transform, `cnt` = transforms per batch item.
 // Backward = conj(forward(conj x)): pass 1 conjugates what it reads, pass 2 what it writes.
-template <class T2, bool COLS>
+// What the overlap-save filter folds into the transform's passes (BigConv, fftconv.hip): the block GATHER (history | input, zero
+// beyond the call) into forward pass 1's loads, the spectrum PRODUCT (all bands) into forward pass 2's stores, and the SCATTER
+// of a block's last `hop` results into inverse pass 2's stores — 7.5 instead of 13.5 array passes per block.
+// Batch item z of the forward transform = block z % nblk of channel z / nblk; of the inverse: band z / (cg nblk) first.
+template <class T2>
+struct ConvFuse {
+  const T2 *in; long in_stride; const T2 *hist; int HH, N, hop, nblk;   // FUSE_GATHER
+  const T2 *Kp; int nb; long band_elems;                                // FUSE_MUL: Y[b * band_elems + z n + idx] = X[idx] Kp[b n + idx]
+  T2 *out; long out_stride, out_band; int cg;                           // FUSE_SCATTER
+};
+enum { FUSE_NONE = 0, FUSE_GATHER = 1, FUSE_MUL = 2, FUSE_SCATTER = 3 };
+
+template <class T2, bool COLS, int FUSE = FUSE_NONE>
 __global__ __launch_bounds__(GT) void fourstep_tile_kernel(const fftgen::GenDev<T2> p, const int *perm, int conj, long n, int len, int cnt, int TC,
-                                                            const T2 *in, T2 *out, const T2 *wa, const T2 *wb, int n1, int n2) {
+                                                            const T2 *in, T2 *out, const T2 *wa, const T2 *wb, int n1, int n2, const ConvFuse<T2> f, int wl_on) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T2 *xl = reinterpret_cast<T2 *>(smem_raw);
   const int tid = threadIdx.x, nt = GT / TC, team = tid / nt, lt = tid - team * nt;
@@ -88,29 +102,96 @@ __global__ __launch_bounds__(GT) void fourstep_tile_kernel(const fftgen::GenDev<
   const T2 *src = in + z * n;
   T2 *dst = out + z * n;
   const int LP = len + 1;           // (one pad element per array: the tile's loads walk the arrays at the same index)
+  T2 *wl = xl + (size_t)TC * LP;    // the plan's roots exp(-2 pi i t / len) and its output permutation, once per workgroup (where they fit beside the tile)
+  int *pl_ = reinterpret_cast<int *>(wl + len);
+  if (wl_on) for (int i = tid; i < len; i += GT) { wl[i] = p.W[i]; pl_[i] = perm[i]; }
+  const T2 *Wr = wl_on ? wl : p.W;
+  const int *permL = wl_on ? pl_ : perm;
   // load: element i of transform t0 + c sits at  COLS: i n2 + (t0 + c)   rows: (t0 + c) n2 + i
-  for (int e = tid; e < len * TC; e += GT) {
-    int i, c;
-    if (COLS) { i = e / TC; c = e - i * TC; } else { c = e / len; i = e - c * len; }
-    T2 v = mk<T2>(0, 0);
-    if (t0 + c < cnt) { v = COLS ? src[(long)i * n2 + (t0 + c)] : src[(long)(t0 + c) * n2 + i]; if (conj && COLS) v.y = -v.y; }
-    xl[c * LP + i] = v;
+  const long gc = FUSE == FUSE_GATHER ? z / f.nblk : 0, gfirst = FUSE == FUSE_GATHER ? (z - gc * f.nblk) * (long)f.hop - f.HH : 0;
+  const int tsh = 31 - __clz(TC);   // (TC is a power of two)
+  const float inv_len = 1.0f / (float)len;
+  // (U loads in flight per lane: written as "issue U loads, then U LDS stores" — a plain loop waits for every load before the
+  // next one is issued, and 16 dependent trips to memory per workgroup were most of this kernel's time)
+  constexpr int U = 8;
+  const int total = len * TC;
+  for (int e0 = tid; e0 < total; e0 += GT * U) {   // (e < 2^18: the float quotient below is exact)
+    T2 v[U];
+    int li[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int e = min(e0 + u * GT, total - 1);
+      int i, c;
+      if (COLS) { i = e >> tsh; c = e & (TC - 1); } else { c = (int)(((float)e + 0.5f) * inv_len); i = e - c * len; }
+      li[u] = c * LP + i;
+      const bool ok = t0 + c < cnt;
+      const int cc = ok ? c : 0;   // (clamped address, value dropped below)
+      if (FUSE == FUSE_GATHER) {   // (COLS) the block's sample (i n2 + col) straight from the call's input / the history
+        const long rel = gfirst + (long)i * n2 + (t0 + cc);
+        const long h = f.HH + rel;
+        const T2 *ptr = rel >= 0 ? f.in + gc * f.in_stride + (rel < f.N ? rel : (long)f.N - 1) : f.hist + gc * f.HH + (h >= 0 ? h : 0);
+        v[u] = *ptr;
+        if (!ok || rel >= f.N || h < 0) v[u] = mk<T2>(0, 0);
+      } else {
+        v[u] = COLS ? src[(long)i * n2 + (t0 + cc)] : src[(long)(t0 + cc) * n2 + i];
+        if (!ok) v[u] = mk<T2>(0, 0);
+      }
+      if (conj && COLS) v[u].y = -v[u].y;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) if (e0 + u * GT < total) xl[li[u]] = v[u];
   }
   __syncthreads();
-  team_forward_dif(xl + team * LP, p, lt, nt);
+  team_forward_dif(xl + team * LP, p, Wr, lt, nt);
   // store: frequency k of transform t0 + c goes to  COLS: k n2 + (t0 + c) [twiddled]   rows: (t0 + c) + n1 k
-  for (int e = tid; e < len * TC; e += GT) {
-    const int pos = e / TC, c = e - pos * TC;
-    if (t0 + c >= cnt) continue;
-    const int k = perm[pos];
-    T2 v = xl[c * LP + pos];
-    if (COLS) {
-      const long m = (long)(t0 + c) * k, a_ = m / n2, b_ = m - a_ * n2;
-      v = gmul(v, gmul(wa[a_], wb[b_]));
-      dst[(long)k * n2 + (t0 + c)] = v;
-    } else {
-      if (conj) v.y = -v.y;
-      dst[(long)(t0 + c) + (long)n1 * k] = v;
+  const float inv_n2 = 1.0f / (float)n2;
+  for (int e0 = tid; e0 < total; e0 += GT * U) {   // (likewise: the permutation and twiddle lookups of U elements first, then the stores)
+    T2 v[U], w1[U], w2[U];
+    int kk[U], cc_[U];
+    bool okk[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int e = min(e0 + u * GT, total - 1);
+      const int pos = e >> tsh, c = e & (TC - 1);
+      okk[u] = e0 + u * GT < total && t0 + c < cnt;
+      cc_[u] = c;
+      kk[u] = permL[pos];
+      v[u] = xl[c * LP + pos];
+      if (COLS) {
+        // m = a n2 + b (m < n <= 2^27): a float estimate of the quotient, off by at most two, then exact remainder steps
+        const unsigned m = okk[u] ? (unsigned)(t0 + c) * (unsigned)kk[u] : 0u;
+        unsigned a_ = (unsigned)((float)m * inv_n2);
+        int r_ = (int)(m - a_ * (unsigned)n2);
+        if (r_ < 0) { a_--; r_ += n2; }
+        if (r_ < 0) { a_--; r_ += n2; }
+        if (r_ >= n2) { a_++; r_ -= n2; }
+        if (r_ >= n2) { a_++; r_ -= n2; }
+        w1[u] = wa[a_]; w2[u] = wb[r_];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (!okk[u]) continue;
+      const int c = cc_[u], k = kk[u];
+      T2 val = v[u];
+      if (COLS) {
+        val = gmul(val, gmul(w1[u], w2[u]));
+        dst[(long)k * n2 + (t0 + c)] = val;
+      } else {
+        if (conj) val.y = -val.y;
+        const long idx = (long)(t0 + c) + (long)n1 * k;   // natural order
+        if (FUSE == FUSE_MUL) {
+          for (int b = 0; b < f.nb; b++) out[(long)b * f.band_elems + z * n + idx] = gmul(val, f.Kp[(long)b * n + idx]);
+        } else if (FUSE == FUSE_SCATTER) {
+          if (idx >= f.HH) {
+            const long per = (long)f.cg * f.nblk, band = z / per, r = z - band * per, ch = r / f.nblk, blk = r - ch * f.nblk;
+            const long o = blk * (long)f.hop + (idx - f.HH);
+            if (o < f.N) f.out[band * f.out_band + ch * f.out_stride + o] = val;
+          }
+        } else {
+          dst[idx] = val;
+        }
+      }
     }
   }
 }
@@ -200,9 +281,12 @@ struct AnyFft {
     return best ? n / best : 0;   // n1 = the larger part (columns of n1 points in pass 1), n2 = n / n1 <= n1
   }
   int tc1 = 1, tc2 = 1;   // transforms per workgroup in pass 1 / pass 2
+  // a pass's LDS: the tile's arrays, and the roots beside them where that still fits a workgroup
+  static bool roots_fit(int tc, long len) { return ((size_t)tc * (len + 1) + len) * sizeof(T2) + (size_t)len * 4 <= 150 * 1024; }
+  static size_t pass_lds(int tc, long len) { return ((size_t)tc * (len + 1) + (roots_fit(tc, len) ? len : 0)) * sizeof(T2) + (roots_fit(tc, len) ? (size_t)len * 4 : 0); }
   static int tile_count(long len) {   // a power of two <= 16, <= GT / 16 lanes per team, arrays within 96 KB
     int tc = 16;
-    while (tc > 1 && (size_t)tc * (len + 1) * sizeof(T2) > 96 * 1024) tc >>= 1;
+    while (tc > 1 && ((size_t)tc * (len + 1) + len) * sizeof(T2) > 96 * 1024) tc >>= 1;   // (tc = 1, len 16384: 128 KB, the roots stay in global memory)
     return tc;
   }
 
@@ -228,8 +312,11 @@ struct AnyFft {
       wa.alloc(n1); wa.upload(ha.data(), n1, ctx->stream);
       wb.alloc(n2); wb.upload(hb.data(), n2, ctx->stream);
       tc1 = tile_count(n1); tc2 = tile_count(n2);
-      allow_lds((fourstep_tile_kernel<T2, true>), (size_t)tc1 * (n1 + 1) * sizeof(T2));
-      allow_lds((fourstep_tile_kernel<T2, false>), (size_t)tc2 * (n2 + 1) * sizeof(T2));
+      allow_lds((fourstep_tile_kernel<T2, true>), pass_lds(tc1, n1));
+      allow_lds((fourstep_tile_kernel<T2, false>), pass_lds(tc2, n2));
+      allow_lds((fourstep_tile_kernel<T2, true, FUSE_GATHER>), pass_lds(tc1, n1));
+      allow_lds((fourstep_tile_kernel<T2, false, FUSE_MUL>), pass_lds(tc2, n2));
+      allow_lds((fourstep_tile_kernel<T2, false, FUSE_SCATTER>), pass_lds(tc2, n2));
       return;
     }
     // a prime factor above 13 (or no split): Bluestein over M = 2^k >= 2n - 1
@@ -290,6 +377,37 @@ struct AnyFft {
     tmp_batch = batch;
   }
 
+  // (FOURSTEP plans) the filter's two transforms with gather / product / scatter folded in (ConvFuse). conv_forward: `batch`
+  // blocks gathered from f.in / f.hist, transformed, times the f.nb spectra -> Y (f.nb x batch x n, band-major);
+  // conv_inverse: the f.nb x batch spectra in Y transformed back, each block's last hop results scattered to f.out.
+  // The plan's scratch must hold f.nb x batch transforms (reserve).
+  bool fuses() const { return kind == FOURSTEP; }
+  void conv_forward(const ConvFuse<T2> &f, long batch, T2 *Y) {
+    ctx->use();
+    reserve(batch);
+    hipStream_t st = ctx->stream;
+    for (long z0 = 0; z0 < batch; z0 += 32768) {   // (chunk starts are multiples of 32768 blocks; the gather needs z = absolute block number)
+      const long zb = std::min<long>(32768, batch - z0);
+      SDRHIP_REQUIRE(z0 == 0, SDRHIP_E_UNSUPPORTED, "more than 32768 blocks in one pass");
+      hipLaunchKernelGGL((fourstep_tile_kernel<T2, true, FUSE_GATHER>), dim3((unsigned)((n2 + tc1 - 1) / tc1), (unsigned)zb), dim3(GT), pass_lds(tc1, n1), st,
+                         p1.dev, p1.perm_d.p, 0, n, (int)n1, (int)n2, tc1, (const T2 *)nullptr, tmp.p, wa.p, wb.p, (int)n1, (int)n2, f, (int)roots_fit(tc1, n1));
+      hipLaunchKernelGGL((fourstep_tile_kernel<T2, false, FUSE_MUL>), dim3((unsigned)((n1 + tc2 - 1) / tc2), (unsigned)zb), dim3(GT), pass_lds(tc2, n2), st,
+                         p2.dev, p2.perm_d.p, 0, n, (int)n2, (int)n1, tc2, tmp.p, Y, wa.p, wb.p, (int)n1, (int)n2, f, (int)roots_fit(tc2, n2));
+    }
+    SDRHIP_CHECK_HIP(hipGetLastError());
+  }
+  void conv_inverse(const ConvFuse<T2> &f, long batch_all, T2 *Y) {
+    ctx->use();
+    reserve(batch_all);
+    hipStream_t st = ctx->stream;
+    SDRHIP_REQUIRE(batch_all <= 32768, SDRHIP_E_UNSUPPORTED, "more than 32768 blocks in one pass");
+    hipLaunchKernelGGL((fourstep_tile_kernel<T2, true>), dim3((unsigned)((n2 + tc1 - 1) / tc1), (unsigned)batch_all), dim3(GT), pass_lds(tc1, n1), st,
+                       p1.dev, p1.perm_d.p, 1, n, (int)n1, (int)n2, tc1, Y, tmp.p, wa.p, wb.p, (int)n1, (int)n2, ConvFuse<T2>{}, (int)roots_fit(tc1, n1));
+    hipLaunchKernelGGL((fourstep_tile_kernel<T2, false, FUSE_SCATTER>), dim3((unsigned)((n1 + tc2 - 1) / tc2), (unsigned)batch_all), dim3(GT), pass_lds(tc2, n2), st,
+                       p2.dev, p2.perm_d.p, 1, n, (int)n2, (int)n1, tc2, tmp.p, (T2 *)nullptr, wa.p, wb.p, (int)n1, (int)n2, f, (int)roots_fit(tc2, n2));
+    SDRHIP_CHECK_HIP(hipGetLastError());
+  }
+
   // batch transforms of n points, contiguous; sign -1 forward, +1 backward (unnormalised); in == out is allowed
   void exec(int sign, long batch, const T2 *in, T2 *out) {
     if (batch <= 0) return;
@@ -306,10 +424,10 @@ struct AnyFft {
         for (long z0 = 0; z0 < batch; z0 += 32768) {
           const long zb = std::min<long>(32768, batch - z0);
           // pass 1: column j2 (stride n2) -> A[k1][j2] = tmp[k1 n2 + j2], twiddled; pass 2: row k1 of A -> X[k1 + n1 k2]
-          hipLaunchKernelGGL((fourstep_tile_kernel<T2, true>), dim3((unsigned)((n2 + tc1 - 1) / tc1), (unsigned)zb), dim3(GT), (size_t)tc1 * (n1 + 1) * sizeof(T2), st,
-                             p1.dev, p1.perm_d.p, conj, n, (int)n1, (int)n2, tc1, in + z0 * n, tmp.p + z0 * n, wa.p, wb.p, (int)n1, (int)n2);
-          hipLaunchKernelGGL((fourstep_tile_kernel<T2, false>), dim3((unsigned)((n1 + tc2 - 1) / tc2), (unsigned)zb), dim3(GT), (size_t)tc2 * (n2 + 1) * sizeof(T2), st,
-                             p2.dev, p2.perm_d.p, conj, n, (int)n2, (int)n1, tc2, tmp.p + z0 * n, out + z0 * n, wa.p, wb.p, (int)n1, (int)n2);
+          hipLaunchKernelGGL((fourstep_tile_kernel<T2, true>), dim3((unsigned)((n2 + tc1 - 1) / tc1), (unsigned)zb), dim3(GT), pass_lds(tc1, n1), st,
+                             p1.dev, p1.perm_d.p, conj, n, (int)n1, (int)n2, tc1, in + z0 * n, tmp.p + z0 * n, wa.p, wb.p, (int)n1, (int)n2, ConvFuse<T2>{}, (int)roots_fit(tc1, n1));
+          hipLaunchKernelGGL((fourstep_tile_kernel<T2, false>), dim3((unsigned)((n1 + tc2 - 1) / tc2), (unsigned)zb), dim3(GT), pass_lds(tc2, n2), st,
+                             p2.dev, p2.perm_d.p, conj, n, (int)n2, (int)n1, tc2, tmp.p + z0 * n, out + z0 * n, wa.p, wb.p, (int)n1, (int)n2, ConvFuse<T2>{}, (int)roots_fit(tc2, n2));
         }
         break;
       case CHIRP:

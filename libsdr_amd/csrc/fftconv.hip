@@ -979,10 +979,20 @@ struct BigConv : ConvAny {
     HH = (int)(L - hop);
     fft.build(ctx, L);
     const size_t nblk = ceil_div(max_in, (size_t)hop);
-    group = (int)std::max<size_t>(1, std::min<size_t>((size_t)C, kScratchBytes / (2 * nblk * (size_t)L * sizeof(T2))));
-    group = std::min(group, 65535);
-    X.alloc((size_t)group * nblk * L); Y.alloc((size_t)group * nblk * L);
-    fft.reserve((long)((size_t)group * nblk));
+    if (fft.fuses()) {
+      // four-step plans: gather, spectrum product and scatter ride in the transform's own passes (fftany.hpp, ConvFuse) —
+      // the scratch is the bands' spectra (B x blocks) plus the plan's own temporary of the same size
+      group = (int)std::max<size_t>(1, std::min<size_t>((size_t)C, kScratchBytes / (2 * (size_t)B * nblk * (size_t)L * sizeof(T2))));
+      group = (int)std::min<size_t>((size_t)group, std::max<size_t>(1, 32768 / ((size_t)B * nblk)));   // (one launch's grid.y)
+      SDRHIP_REQUIRE((size_t)B * nblk <= 32768, SDRHIP_E_UNSUPPORTED, "%zu blocks x %d bands per call exceed one pass: lower max_in", nblk, B);
+      Y.alloc((size_t)B * group * nblk * L);
+      fft.reserve((long)((size_t)B * group * nblk));
+    } else {
+      group = (int)std::max<size_t>(1, std::min<size_t>((size_t)C, kScratchBytes / (2 * nblk * (size_t)L * sizeof(T2))));
+      group = std::min(group, 65535);
+      X.alloc((size_t)group * nblk * L); Y.alloc((size_t)group * nblk * L);
+      fft.reserve((long)((size_t)group * nblk));
+    }
     Kp.alloc((size_t)L * B);
     const size_t per_band = mode == SDRHIP_FFTCONV_OLA ? (size_t)2 * L : (size_t)2 * n_taps;
     for (int b = 0; b < B; b++) load_kernel_t(b, kernels + (size_t)b * per_band);
@@ -1012,6 +1022,15 @@ struct BigConv : ConvAny {
     for (int c0 = 0; c0 < C; c0 += group) {
       const int cg = std::min(group, C - c0);
       const long batch = (long)cg * nblk;
+      if (fft.fuses()) {
+        fftany::ConvFuse<T2> f{};
+        f.in = in_dev + (size_t)c0 * in_stride; f.in_stride = (long)in_stride; f.hist = hist[par].p + (size_t)c0 * HH; f.HH = HH; f.N = (int)N; f.hop = hop; f.nblk = nblk;
+        f.Kp = Kp.p; f.nb = B; f.band_elems = batch * L;
+        f.out = out_dev + (size_t)c0 * out_stride; f.out_stride = (long)out_stride; f.out_band = (long)out_band; f.cg = cg;
+        fft.conv_forward(f, batch, Y.p);
+        fft.conv_inverse(f, (long)B * batch, Y.p);
+        continue;
+      }
       hipLaunchKernelGGL(big_gather_kernel<T2>, dim3(gx, nblk, cg), dim3(256), 0, st, in_dev + (size_t)c0 * in_stride, (long)in_stride,
                          hist[par].p + (size_t)c0 * HH, HH, (int)N, hop, L, nblk, X.p);
       fft.exec(-1, batch, X.p, X.p);
@@ -1058,7 +1077,7 @@ struct BigConv : ConvAny {
     SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   }
   void reset() override { ctx->use(); for (int p = 0; p < 2; p++) hist[p].zero(ctx->stream); }
-  const char *kernel_names() const override { return "big_gather_kernel,fft passes,big_mul_kernel,big_scatter_kernel"; }
+  const char *kernel_names() const override { return fft.fuses() ? "fourstep_tile_kernel x4 (gather, product, scatter fused)" : "big_gather_kernel,fft passes,big_mul_kernel,big_scatter_kernel"; }
 };
 
 }  // namespace
