@@ -36,10 +36,23 @@ __global__ __launch_bounds__(GT) void lds_c2c_kernel(const fftgen::GenDev<T2> p,
   if (b >= batch) return;
   const T2 *src = in + b * L;
   T2 *dst = out + b * L;
-  for (int i = tid; i < L; i += GT) { T2 v = src[i]; if (conj) v.y = -v.y; xl[i] = v; }
+  constexpr int U = 8;   // (loads in flight per lane, see fourstep_tile_kernel)
+  for (int i0 = tid; i0 < L; i0 += GT * U) {
+    T2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = src[min(i0 + u * GT, L - 1)];
+#pragma unroll
+    for (int u = 0; u < U; u++) if (i0 + u * GT < L) { if (conj) v[u].y = -v[u].y; xl[i0 + u * GT] = v[u]; }
+  }
   __syncthreads();
   fftgen::forward_dif(xl, p, tid);
-  for (int i = tid; i < L; i += GT) { T2 v = xl[i]; if (conj) v.y = -v.y; dst[perm[i]] = v; }   // position i holds frequency perm[i]
+  for (int i0 = tid; i0 < L; i0 += GT * U) {   // position i holds frequency perm[i]
+    int pk[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) pk[u] = perm[min(i0 + u * GT, L - 1)];
+#pragma unroll
+    for (int u = 0; u < U; u++) if (i0 + u * GT < L) { T2 v = xl[i0 + u * GT]; if (conj) v.y = -v.y; dst[pk[u]] = v; }
+  }
 }
 
 // The general plan's passes for a TEAM of `nt` lanes (nt divides GT): a workgroup then runs GT / nt transforms side by side,
@@ -206,17 +219,35 @@ __global__ __launch_bounds__(GT) void chirp_lds_kernel(const fftgen::GenDev<T2> 
   if (b >= batch) return;
   const T2 *src = in + b * n;
   T2 *dst = out + b * n;
-  for (int i = tid; i < M; i += GT) {
-    T2 v = mk<T2>(0, 0);
-    if (i < n) { v = src[i]; if (conj) v.y = -v.y; v = gmul(v, w[i]); }
-    xl[i] = v;
+  constexpr int U = 8;   // (loads in flight per lane, see fourstep_tile_kernel)
+  for (int i0 = tid; i0 < M; i0 += GT * U) {
+    T2 v[U], wv[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { const int i = min(i0 + u * GT, n - 1); v[u] = src[i]; wv[u] = w[i]; }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = i0 + u * GT;
+      if (i < M) { T2 t = v[u]; if (conj) t.y = -t.y; xl[i] = i < n ? gmul(t, wv[u]) : mk<T2>(0, 0); }
+    }
   }
   __syncthreads();
   fftgen::forward_dif(xl, p, tid);
-  for (int i = tid; i < M; i += GT) xl[i] = gmul(xl[i], bspec[i]);   // (stored in the forward transform's output order, pre-scaled by 1 / M)
+  for (int i0 = tid; i0 < M; i0 += GT * U) {   // (the spectrum: stored in the forward transform's output order, pre-scaled by 1 / M)
+    T2 bq[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) bq[u] = bspec[min(i0 + u * GT, M - 1)];
+#pragma unroll
+    for (int u = 0; u < U; u++) if (i0 + u * GT < M) xl[i0 + u * GT] = gmul(xl[i0 + u * GT], bq[u]);
+  }
   __syncthreads();
   fftgen::inverse_dit(xl, p, tid);
-  for (int i = tid; i < n; i += GT) { T2 v = gmul(xl[i], w[i]); if (conj) v.y = -v.y; dst[i] = v; }
+  for (int i0 = tid; i0 < n; i0 += GT * U) {
+    T2 wv[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) wv[u] = w[min(i0 + u * GT, n - 1)];
+#pragma unroll
+    for (int u = 0; u < U; u++) if (i0 + u * GT < n) { T2 v = gmul(xl[i0 + u * GT], wv[u]); if (conj) v.y = -v.y; dst[i0 + u * GT] = v; }
+  }
 }
 
 // the global passes of the chirp transform around an inner plan of M points

@@ -230,13 +230,21 @@ __global__ __launch_bounds__(GT) void conv_kernel(const GenConvArgs<T2> a) {
   T2 *xl = reinterpret_cast<T2 *>(smem_raw);
   const int c = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x, L = a.fft.L;
   const int first = blk * a.hop - a.HH;   // call-relative index of xl[0]
+  // (U loads in flight per lane: a plain `for (i = tid; ...) xl[i] = load` waits for every load before the next is issued — a
+  // dozen dependent trips to memory per block; round 5 found that in the four-step passes and here)
+  constexpr int U = 8;
   auto load = [&]() {
-    for (int i = tid; i < L; i += GT) {
-      const int rel = first + i;
-      T2 v = mk<T2>(0, 0);
-      if (rel >= 0) { if (rel < a.N) v = a.in[(long)c * a.in_stride + rel]; }
-      else { const int h = a.HH + rel; if (h >= 0) v = a.hist[(long)c * a.HH + h]; }
-      xl[i] = v;
+    for (int i0 = tid; i0 < L; i0 += GT * U) {
+      T2 v[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int i = min(i0 + u * GT, L - 1), rel = first + i, h = a.HH + rel;
+        const T2 *ptr = rel >= 0 ? a.in + (long)c * a.in_stride + min(rel, a.N - 1) : a.hist + (long)c * a.HH + max(h, 0);
+        v[u] = *ptr;
+        if (rel >= a.N || h < 0) v[u] = mk<T2>(0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) if (i0 + u * GT < L) xl[i0 + u * GT] = v[u];
     }
     __syncthreads();
     forward_dif(xl, a.fft, tid);
@@ -245,7 +253,13 @@ __global__ __launch_bounds__(GT) void conv_kernel(const GenConvArgs<T2> a) {
   if (a.two) load();
   for (int band = 0; band < a.nb; band++) {
     if (!a.two) load();
-    for (int i = tid; i < L; i += GT) xw[i] = gmul(xl[i], a.Kp[(long)band * L + i]);
+    for (int i0 = tid; i0 < L; i0 += GT * U) {
+      T2 kq[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) kq[u] = a.Kp[(long)band * L + min(i0 + u * GT, L - 1)];
+#pragma unroll
+      for (int u = 0; u < U; u++) if (i0 + u * GT < L) xw[i0 + u * GT] = gmul(xl[i0 + u * GT], kq[u]);
+    }
     __syncthreads();
     inverse_dit(xw, a.fft, tid);
     const int o0 = blk * a.hop;
