@@ -344,6 +344,11 @@ int sdrhip_fftconv_destroy(sdrhip_fftconv *h);
  *     four-step plan beyond it); the filter then runs as passes over device memory (gather blocks, forward transforms,
  *     per band: spectrum product, backward transforms, scatter) — FilterNode<float>(16384), (12000), (1009),
  *     FilterNode<double>(8192) ... Limit: 2^27 points (2^25 with a large prime factor).
+ * An OLA plan whose fft_size = 2N is not one of the tuned powers of two does not have to transform 2N points at all: its
+ * result is the N-tap convolution whatever evaluates it, so it runs as overlap-save with the same N taps (the first N points
+ * of the spectrum's inverse DFT, taken on the host in double) on the power of two that costs least per output — provided N
+ * leaves such a block a quarter of its points (N <= 12288; 6144 in double). FilterNode<float>(1000), (1009), (12000) run the
+ * tuned kernels that way; SDRHIP_FFTCONV_LITERAL=1 in the environment keeps the 2N-point transform (tests).
  *
  * FilterNode<double> (the filter classes are templates over Scalar, src/filternode.hh:30-32,102-104,230-232): the same
  * plan on complex<double> buffers; kernels / spectra are doubles (sdrhip_design_fftfilt_*_f64). bands / reset / destroy

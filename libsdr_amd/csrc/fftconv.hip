@@ -1087,6 +1087,7 @@ struct sdrhip_fftconv {
   std::unique_ptr<ConvAny> any;   // every plan but the tuned power-of-two complex<float> one: GenConv (one transform in one workgroup's
                                   // LDS, factors 2 ... 13) or BigConv (any size: four-step / chirp passes), float or double
   int mode = 0, C = 1, hop = 0, HH = 0, par = 0;
+  int ola_L = 0;        // an overlap-add plan (2N-point spectra) that runs as overlap-save on another transform: the caller's 2N (set_kernel converts)
   int B = 1;            // bands of the bank (spectra sharing one forward transform)
   int n_taps = 0;
   size_t max_in = 0;
@@ -1273,6 +1274,34 @@ sdrhip_fft_plan *cached_plan(sdrhip_ctx *ctx, int dtype, int n) {
 }  // namespace
 
 namespace {
+// FilterNode's block size is the granularity of ITS buffers, not a property of the result: an overlap-add filter with a
+// 2N-point spectrum of support N is the N-tap convolution y[n] = sum_k h[k] x[n - k], whatever transform evaluates it. A block
+// size whose 2N-point transform is awkward (not a power of two: generic radix passes, four-step or chirp plans) is therefore run
+// as OVERLAP-SAVE with the same N taps on the power-of-two transform that costs least per output — the tuned kernels in
+// complex<float>. The taps are the first N points of the inverse DFT of the spectrum (host, double, one-off per kernel).
+template <class R>
+std::vector<R> ola_spectrum_to_taps(const R *K, int L) {
+  std::vector< std::complex<double> > spec(L);
+  for (int i = 0; i < L; i++) spec[i] = std::complex<double>(K[2 * i], K[2 * i + 1]);
+  fftgen::host_dft(spec, +1);
+  std::vector<R> taps((size_t)L);   // N = L / 2 complex taps
+  for (int i = 0; i < L / 2; i++) { taps[2 * i] = (R)(spec[i].real() / L); taps[2 * i + 1] = (R)(spec[i].imag() / L); }
+  return taps;
+}
+// the power of two (4 ... max_l) on which an N-tap overlap-save filter costs the fewest butterfly operations per output, provided
+// a block keeps at least a quarter of its points; 0: none (N too long for max_l)
+int overlap_save_fft_size(int N, int max_l) {
+  int best = 0;
+  double best_cost = 0;
+  for (int l = 4, lg = 2; l <= max_l; l <<= 1, lg++) {
+    const int hop = l - N + 1;
+    if (hop < 1 || 4 * hop < l) continue;
+    const double cost = (double)l * lg / hop;
+    if (!best || cost < best_cost) { best = l; best_cost = cost; }
+  }
+  return best;
+}
+
 // GenConv where one transform fits one workgroup's LDS and has no prime factor above 13, BigConv for every other size
 template <class T2, class R>
 ConvAny *make_any_conv(sdrhip_ctx *ctx, int mode, int fft_size, const R *kernels, int n_taps, int n_bands, int channels, size_t max_in) {
@@ -1304,6 +1333,20 @@ int sdrhip_fftconv_create_bank(sdrhip_ctx *ctx, int mode, int fft_size, const fl
     sdrhip_fftconv *h = new sdrhip_fftconv;
     try {
       h->ctx = ctx; h->mode = mode; h->C = channels; h->max_in = max_in; h->B = n_bands;
+      std::vector<float> taps_all;
+      if (mode == SDRHIP_FFTCONV_OLA && (!is_pow2(fft_size) || fft_size < 4 || fft_size > 16384) && fft_size % 2 == 0 && !getenv("SDRHIP_FFTCONV_LITERAL")) {
+        // an awkward 2N: the same N taps by overlap-save on the best power of two (ola_spectrum_to_taps); SDRHIP_FFTCONV_LITERAL=1
+        // keeps the 2N-point transform (tests of the general plans)
+        const int N = fft_size / 2, lp = overlap_save_fft_size(N, 16384);
+        if (lp) {
+          for (int b = 0; b < n_bands; b++) {
+            const std::vector<float> t = ola_spectrum_to_taps(kernels + (size_t)b * 2 * fft_size, fft_size);
+            taps_all.insert(taps_all.end(), t.begin(), t.begin() + 2 * N);
+          }
+          h->ola_L = fft_size;
+          mode = SDRHIP_FFTCONV_OLS; h->mode = mode; fft_size = lp; n_taps = N; kernels = taps_all.data();
+        }
+      }
       if (!is_pow2(fft_size) || fft_size < 4 || fft_size > 16384) {   // (FilterNode(size_t block_size) takes any block size: src/filternode.hh:235-245)
         h->any.reset(make_any_conv<float2, float>(ctx, mode, fft_size, kernels, n_taps, n_bands, channels, max_in));
         *out = h;
@@ -1346,6 +1389,8 @@ int sdrhip_fftconv_set_kernel(sdrhip_fftconv *h, int band, const float *kernel) 
     SDRHIP_REQUIRE(!(h->any && h->any->f64), SDRHIP_E_INVALID, "a complex<double> plan: use sdrhip_fftconv_f64_set_kernel");
     h->ctx->use();
     SDRHIP_CHECK_HIP(hipStreamSynchronize(h->ctx->stream));   // launches in flight still read the old spectrum
+    std::vector<float> taps;
+    if (h->ola_L) { taps = ola_spectrum_to_taps(kernel, h->ola_L); kernel = taps.data(); }   // (the plan runs as overlap-save: see create)
     if (h->any) { h->any->load_kernel(band, kernel); return; }
     h->load_kernel(band, kernel);
   });
@@ -1424,6 +1469,18 @@ int sdrhip_fftconv_f64_create_bank(sdrhip_ctx *ctx, int mode, int fft_size, cons
     sdrhip_fftconv *h = new sdrhip_fftconv;
     try {
       h->ctx = ctx; h->mode = mode; h->C = channels; h->max_in = max_in; h->B = n_bands;
+      std::vector<double> taps_all;
+      if (mode == SDRHIP_FFTCONV_OLA && !(is_pow2(fft_size) && fft_size <= 8192) && fft_size % 2 == 0 && fft_size >= 4 && !getenv("SDRHIP_FFTCONV_LITERAL")) {
+        const int N = fft_size / 2, lp = overlap_save_fft_size(N, 8192);   // (as the complex<float> plans: the general in-LDS plan's power-of-two passes)
+        if (lp) {
+          for (int b = 0; b < n_bands; b++) {
+            const std::vector<double> t = ola_spectrum_to_taps(kernels + (size_t)b * 2 * fft_size, fft_size);
+            taps_all.insert(taps_all.end(), t.begin(), t.begin() + 2 * N);
+          }
+          h->ola_L = fft_size;
+          mode = SDRHIP_FFTCONV_OLS; h->mode = mode; fft_size = lp; n_taps = N; kernels = taps_all.data();
+        }
+      }
       h->any.reset(make_any_conv<double2, double>(ctx, mode, fft_size, kernels, n_taps, n_bands, channels, max_in));
     } catch (...) { delete h; throw; }
     *out = h;
@@ -1436,6 +1493,8 @@ int sdrhip_fftconv_f64_set_kernel(sdrhip_fftconv *h, int band, const double *ker
     SDRHIP_REQUIRE(band >= 0 && band < h->B, SDRHIP_E_INVALID, "band %d outside [0,%d)", band, h->B);
     h->ctx->use();
     SDRHIP_CHECK_HIP(hipStreamSynchronize(h->ctx->stream));
+    std::vector<double> taps;
+    if (h->ola_L) { taps = ola_spectrum_to_taps(kernel, h->ola_L); kernel = taps.data(); }
     h->any->load_kernel(band, kernel);
   });
 }

@@ -1412,12 +1412,19 @@ def test_fft_bad_arguments(ctx):
 @pytest.mark.parametrize("N,dtype,tol,nblk", [(16384, np.float32, RTOL, 3), (12000, np.float32, RTOL, 3), (1009, np.float32, RTOL, 5),
                                               (8192, np.float64, 1e-11, 3), (10007, np.float32, RTOL, 2), (17, np.float32, RTOL, 9),
                                               (6007, np.float64, 1e-11, 2)])
-def test_filternode_any_block_size_beyond_one_workgroup(ctx, orc, N, dtype, tol, nblk):
+@pytest.mark.parametrize("literal", [False, True])
+def test_filternode_any_block_size_beyond_one_workgroup(ctx, orc, N, dtype, tol, nblk, literal, monkeypatch):
     """FilterNode<float>(16384), (12000), (1009), FilterNode<double>(8192) ... (src/filternode.hh:236-245: any block size,
     FFTW plans any 2N): transforms beyond one workgroup's LDS (four-step) and sizes with a prime factor above 13 (chirp
     transform, in LDS or over a four-step plan) — a 2-band bank, 3 channels, two ragged calls, against the oracle's
-    FilterSink / FilterSource blocks AND the closed form y = h (*) x / (sqrt(2N) ||h||_2)."""
+    FilterSink / FilterSource blocks AND the closed form y = h (*) x / (sqrt(2N) ||h||_2). `literal`: the 2N-point transform
+    itself (four-step / chirp plans); otherwise overlap-save on the best power of two where N leaves one a quarter of its points
+    (12000, 1009, 10007, 17 in float; 6007 in double), the 2N-point plans where it does not (16384; 8192 in double)."""
     from scipy.signal import fftconvolve
+    if literal:
+        monkeypatch.setenv("SDRHIP_FFTCONV_LITERAL", "1")
+    else:
+        monkeypatch.delenv("SDRHIP_FFTCONV_LITERAL", raising=False)
     f64 = np.dtype(dtype) == np.float64
     bands = [(-350e3, -250e3), (50e3, 150e3)]
     hs = [sa.design_fftfilt_kernel(N, lo, hi, FS, dtype=dtype) for lo, hi in bands]
@@ -1490,10 +1497,17 @@ def test_fftconv_ols_long_transforms(ctx):
 
 @pytest.mark.parametrize("N,dtype,tol", [(1000, np.float32, RTOL), (1500, np.float32, RTOL), (1000, np.float64, 1e-12), (1024, np.float64, 1e-12),
                                          (7, np.float32, RTOL)])
-def test_fftconv_any_block_size_and_double(ctx, golden, orc, N, dtype, tol):
+@pytest.mark.parametrize("literal", [False, True])
+def test_fftconv_any_block_size_and_double(ctx, golden, orc, N, dtype, tol, literal, monkeypatch):
     """FilterNode(size_t block_size) for block sizes that are not powers of two, and FilterNode<double>
     (src/filternode.hh:230-245): a 3-band bank behind one plan, two calls (history carried), ragged call lengths —
-    against the oracle's FilterSink / FilterSource blocks AND the closed form y = h (*) x / (sqrt(2N) ||h||_2)."""
+    against the oracle's FilterSink / FilterSource blocks AND the closed form y = h (*) x / (sqrt(2N) ||h||_2).
+    By default such a block size runs as overlap-save with the same N taps on the power-of-two transform that costs least
+    (the tuned kernels in float); `literal`: the 2N-point transform itself (SDRHIP_FFTCONV_LITERAL=1: the general plans)."""
+    if literal:
+        monkeypatch.setenv("SDRHIP_FFTCONV_LITERAL", "1")
+    else:
+        monkeypatch.delenv("SDRHIP_FFTCONV_LITERAL", raising=False)
     f64 = np.dtype(dtype) == np.float64
     bands = [(-350e3, -250e3), (50e3, 150e3), (-20e3, 20e3)]
     hs = [sa.design_fftfilt_kernel(N, lo, hi, FS, dtype=dtype) for lo, hi in bands]
