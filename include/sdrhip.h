@@ -348,7 +348,9 @@ int sdrhip_fftconv_destroy(sdrhip_fftconv *h);
  * result is the N-tap convolution whatever evaluates it, so it runs as overlap-save with the same N taps (the first N points
  * of the spectrum's inverse DFT, taken on the host in double) on the power of two that costs least per output — provided N
  * leaves such a block a quarter of its points (N <= 12288; 6144 in double). FilterNode<float>(1000), (1009), (12000) run the
- * tuned kernels that way; SDRHIP_FFTCONV_LITERAL=1 in the environment keeps the 2N-point transform (tests).
+ * tuned kernels that way — and so does a single band on a power of two other than 2048 (half of every 2N-point block is
+ * overlap, a longer block keeps up to 7/8 of its points); filter banks and the 2048-point plan keep their own transform.
+ * SDRHIP_FFTCONV_LITERAL=1 in the environment keeps the 2N-point transform everywhere (tests).
  *
  * FilterNode<double> (the filter classes are templates over Scalar, src/filternode.hh:30-32,102-104,230-232): the same
  * plan on complex<double> buffers; kernels / spectra are doubles (sdrhip_design_fftfilt_*_f64). bands / reset / destroy

@@ -1334,11 +1334,16 @@ int sdrhip_fftconv_create_bank(sdrhip_ctx *ctx, int mode, int fft_size, const fl
     try {
       h->ctx = ctx; h->mode = mode; h->C = channels; h->max_in = max_in; h->B = n_bands;
       std::vector<float> taps_all;
-      if (mode == SDRHIP_FFTCONV_OLA && (!is_pow2(fft_size) || fft_size < 4 || fft_size > 16384) && fft_size % 2 == 0 && !getenv("SDRHIP_FFTCONV_LITERAL")) {
-        // an awkward 2N: the same N taps by overlap-save on the best power of two (ola_spectrum_to_taps); SDRHIP_FFTCONV_LITERAL=1
+      // (a single band on a power of two as well: half of every 2N-point block is overlap, a longer block keeps up to 7/8 —
+      // N = 256: 13.9 -> 50.4 % of the roofline, 512: 28 -> 43 %, 2048: 29.5 -> 33 %, 4096: 21.6 -> 28 % at 256 channels. Not the
+      // 2048-point plan (its last passes run in registers: 35.6 % against 33.8 % remapped) and not the banks (one forward transform
+      // per block for all bands, tuned at these sizes: 32 % against 26 %). profiles/r17_bigconv_time.txt)
+      const bool awkward = !is_pow2(fft_size) || fft_size < 4 || fft_size > 16384;
+      if (mode == SDRHIP_FFTCONV_OLA && (awkward || (n_bands == 1 && fft_size != 2048)) && fft_size % 2 == 0 && !getenv("SDRHIP_FFTCONV_LITERAL")) {
+        // the same N taps by overlap-save on the best power of two (ola_spectrum_to_taps); SDRHIP_FFTCONV_LITERAL=1
         // keeps the 2N-point transform (tests of the general plans)
         const int N = fft_size / 2, lp = overlap_save_fft_size(N, 16384);
-        if (lp) {
+        if (lp && lp != fft_size) {
           for (int b = 0; b < n_bands; b++) {
             const std::vector<float> t = ola_spectrum_to_taps(kernels + (size_t)b * 2 * fft_size, fft_size);
             taps_all.insert(taps_all.end(), t.begin(), t.begin() + 2 * N);

@@ -16,7 +16,7 @@ stream = torch.cuda.Stream(device=dev)
 with torch.cuda.stream(stream):
     ctx = sa.Context(0, stream=stream.cuda_stream)
     print("SDRHIP_FFTCONV_LITERAL =", os.environ.get("SDRHIP_FFTCONV_LITERAL", "(unset: awkward block sizes run as overlap-save on the best power of two)"))
-    for Nb, C, dt in ((1024, 256, np.float32), (1000, 256, np.float32), (6000, 256, np.float32), (1000, 128, np.float64), (8192, 256, np.float32), (16384, 256, np.float32), (12000, 256, np.float32), (1009, 256, np.float32), (10007, 256, np.float32), (8192, 128, np.float64)):
+    for Nb, C, dt in ((256, 256, np.float32), (512, 256, np.float32), (1024, 256, np.float32), (2048, 256, np.float32), (4096, 256, np.float32), (1000, 256, np.float32), (6000, 256, np.float32), (1000, 128, np.float64), (8192, 256, np.float32), (16384, 256, np.float32), (12000, 256, np.float32), (1009, 256, np.float32), (10007, 256, np.float32), (8192, 128, np.float64)):
         N = (65536 // Nb + 1) * Nb if 65536 % Nb else 65536
         K = sa.design_fftfilt_spectrum(sa.design_fftfilt_kernel(Nb, 50e3, 150e3, FS, dtype=dt))
         node = sa.FFTConv(ctx, sa.FFTCONV_OLA, 2 * Nb, K, channels=C, max_in=N, dtype=dt)
