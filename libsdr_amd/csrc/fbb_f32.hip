@@ -35,7 +35,7 @@ int sdrhip_fbb_f32_create(sdrhip_ctx *ctx, double Fc, double Fs, const double *a
     sdrhip_fbb_f32 *h = new sdrhip_fbb_f32;
     try {
       h->ctx = ctx; h->fc = Fc; h->fs = Fs; h->C = channels; h->max_in = max_in;
-      int rc = sdrhip_fir_create(ctx, SDRHIP_FIR_CF32, alpha, order, decim, channels, max_in, SDRHIP_EPI_NONE, &h->fir);
+      int rc = fir_create_impl(ctx, SDRHIP_FIR_CF32, alpha, order, decim, channels, max_in, SDRHIP_EPI_NONE, false, &h->fir);   // (the shift rides in the time-domain kernel's staging)
       if (rc != SDRHIP_OK) throw Failure{rc};
       fir_set_shift(h->fir, Fc, Fs);   // the shift rides in the FIR's staging: one kernel, no intermediate buffer
       h->max_out = max_in / decim + 1;

@@ -636,6 +636,8 @@ struct sdrhip_fir {
   DevBuf<float> beta, betap;
   size_t lds3 = 0;
   // fused frequency shift (set by the float baseband)
+  // complex<float>, no decimation, no demodulator: the filter runs as overlap-save FFT convolution behind this handle (see create)
+  sdrhip_fftconv *fftc = nullptr;
   bool shift_on = false; double fc = 0, fs = 1;
   long long phase0 = 0;   // absolute sample index at which the fused shift's phasor was last (re)started (set_shift)
   DevBuf<float2> etab, etab2, wtab, ptab;   // phase tables of the fused shift (see Fir32Args)
@@ -782,6 +784,20 @@ void fir_load_taps(sdrhip_fir *h, const double *alpha) {
   h->betap.upload(bpad.data(), bpad.size(), h->ctx->stream);
 }
 
+// FIRFilter<complex<float>> is a tolerance path (<= 1e-5: the reference itself sits 4e-7 from the exact convolution,
+// src/firfilter.hh:231-247 with src/operators.hh:16-18), and without decimation the time-domain kernel pays `order` multiply-adds
+// per sample where an overlap-save FFT convolution pays a constant: 1024 channels x 65536 samples, ms per call, time domain /
+// FFT — 8 taps 0.35 / 0.25, 127 taps 1.50 / 0.24, 1023 taps 10.4 / 0.36, 4097 taps 60.2 / 0.46
+// (tools/probes/fir_cf32_vs_fft.py). So such a plan IS an overlap-save plan on the tuned FFT kernels (fftconv.hip): h[k] =
+// alpha[order - 1 - k], transform 2048 points up to 512 taps, 4096 up to 2048, 16384 beyond. SDRHIP_FIR_TIME_DOMAIN=1 keeps the
+// time-domain kernel (tests); decimating plans (the float baseband: the folded, shift-fused kernel) and fused demodulators keep it.
+static std::vector<float> fir_fft_taps(const double *alpha, int order) {
+  std::vector<float> t(2 * (size_t)order, 0.f);
+  for (int k = 0; k < order; k++) t[2 * k] = (float)alpha[order - 1 - k];
+  return t;
+}
+static int fir_fft_size(int order) { return order <= 512 ? 2048 : order <= 2048 ? 4096 : 16384; }
+
 // (re)starts the fused shift's phasor at the CURRENT sample: exp(-2 pi i fc (n - n_now) / fs) from the next call on — what
 // FreqShiftBase::setFrequencyShift does to its LUT counter (src/freqshift.hh:78-87). FIR history (raw input samples),
 // decimator phase and sample counter go on.
@@ -804,8 +820,12 @@ void fir_set_shift(sdrhip_fir *h, double fc, double fs) {
 
 extern "C" {
 
-int sdrhip_fir_create(sdrhip_ctx *ctx, int kind, const double *alpha, int order, int decim, int channels,
-                      size_t max_in, int epilogue, sdrhip_fir **out) {
+}  // extern "C"
+
+namespace sdrhip {
+// allow_fft = false: the time-domain kernel whatever the plan (the float baseband fuses its frequency shift into that kernel's staging)
+int fir_create_impl(sdrhip_ctx *ctx, int kind, const double *alpha, int order, int decim, int channels,
+                    size_t max_in, int epilogue, bool allow_fft, sdrhip_fir **out) {
   return guarded([&] {
     SDRHIP_REQUIRE(ctx && alpha && out, SDRHIP_E_INVALID, "NULL argument");
     *out = nullptr;
@@ -838,6 +858,10 @@ int sdrhip_fir_create(sdrhip_ctx *ctx, int kind, const double *alpha, int order,
           h->hist16[p].alloc((size_t)channels * h->HH); h->hist16[p].zero(ctx->stream);
           h->fm[p].alloc(channels); h->fm[p].zero(ctx->stream);
         }
+      } else if (allow_fft && decim == 1 && epilogue == SDRHIP_EPI_NONE && !(getenv("SDRHIP_FIR_TIME_DOMAIN") && getenv("SDRHIP_FIR_TIME_DOMAIN")[0] != '0')) {
+        const std::vector<float> t = fir_fft_taps(alpha, order);
+        const int rc = sdrhip_fftconv_create(ctx, SDRHIP_FFTCONV_OLS, fir_fft_size(order), t.data(), order, channels, max_in, &h->fftc);
+        if (rc != SDRHIP_OK) throw Failure{rc};
       } else {
         // beta[m] = (1/D) * sum_k alpha[m-k], k in [0,D): FIR followed by the D-sample box average
         h->M = order + decim - 1;
@@ -865,14 +889,23 @@ int sdrhip_fir_create(sdrhip_ctx *ctx, int kind, const double *alpha, int order,
         }
       }
       SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    } catch (...) { delete h; throw; }
+    } catch (...) { if (h->fftc) (void)sdrhip_fftconv_destroy(h->fftc); delete h; throw; }
     *out = h;
   });
+}
+}  // namespace sdrhip
+
+extern "C" {
+
+int sdrhip_fir_create(sdrhip_ctx *ctx, int kind, const double *alpha, int order, int decim, int channels,
+                      size_t max_in, int epilogue, sdrhip_fir **out) {
+  return fir_create_impl(ctx, kind, alpha, order, decim, channels, max_in, epilogue, true, out);
 }
 
 int sdrhip_fir_kernel_names(sdrhip_fir *h, size_t n_in, char *buf, size_t len) {
   return guarded([&] {
     SDRHIP_REQUIRE(h && buf && len, SDRHIP_E_INVALID, "NULL argument");
+    if (h->fftc) { snprintf(buf, len, "fftconv_fused_kernel"); return; }
     snprintf(buf, len, "%s", h->kernel_name(n_in ? n_in : h->max_in));
   });
 }
@@ -892,6 +925,13 @@ int sdrhip_fir_process_dev(sdrhip_fir *h, const void *in_dev, size_t n_in, size_
     SDRHIP_REQUIRE(n_in <= h->max_in, SDRHIP_E_SIZE, "n_in %zu > max_in %zu", n_in, h->max_in);
     if (n_in == 0) { if (n_out) *n_out = 0; return; }
     SDRHIP_REQUIRE(in_dev && out_dev, SDRHIP_E_INVALID, "NULL buffer");
+    if (h->fftc) {
+      const int rc = sdrhip_fftconv_process_dev(h->fftc, static_cast<const float *>(in_dev), n_in, in_stride, static_cast<float *>(out_dev), out_stride);
+      if (rc != SDRHIP_OK) throw Failure{rc};
+      h->n0 += n_in;
+      if (n_out) *n_out = n_in;
+      return;
+    }
     if (in_stride == 0) in_stride = n_in;
     SDRHIP_REQUIRE(in_stride >= n_in, SDRHIP_E_SIZE, "in_stride %zu < n_in %zu", in_stride, n_in);
     if (out_stride == 0) out_stride = h->out_count(n_in);
@@ -912,6 +952,13 @@ int sdrhip_fir_process(sdrhip_fir *h, const void *in_host, size_t n_in, size_t i
     SDRHIP_REQUIRE(n_in <= h->max_in, SDRHIP_E_SIZE, "n_in %zu > max_in %zu", n_in, h->max_in);
     if (n_in == 0) { if (n_out) *n_out = 0; return; }
     SDRHIP_REQUIRE(in_host && out_host, SDRHIP_E_INVALID, "NULL buffer");
+    if (h->fftc) {
+      const int rc = sdrhip_fftconv_process(h->fftc, static_cast<const float *>(in_host), n_in, in_stride, static_cast<float *>(out_host), out_stride);
+      if (rc != SDRHIP_OK) throw Failure{rc};
+      h->n0 += n_in;
+      if (n_out) *n_out = n_in;
+      return;
+    }
     h->ctx->use();
     if (in_stride == 0) in_stride = n_in;
     const size_t no = h->out_count(n_in);
@@ -935,6 +982,12 @@ int sdrhip_fir_set_taps(sdrhip_fir *h, const double *alpha) {
   return guarded([&] {
     SDRHIP_REQUIRE(h && alpha, SDRHIP_E_INVALID, "NULL argument");
     h->ctx->use();
+    if (h->fftc) {   // (the overlap-save history is input samples: the stream goes on under the new taps, as the ring does)
+      const std::vector<float> t = fir_fft_taps(alpha, h->order);
+      const int rc = sdrhip_fftconv_set_kernel(h->fftc, 0, t.data());
+      if (rc != SDRHIP_OK) throw Failure{rc};
+      return;
+    }
     fir_load_taps(h, alpha);
   });
 }
@@ -944,6 +997,7 @@ int sdrhip_fir_reset(sdrhip_fir *h) {
     SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
     h->ctx->use();
     h->n0 = 0; h->phase0 = 0;
+    if (h->fftc) { const int rc = sdrhip_fftconv_reset(h->fftc); if (rc != SDRHIP_OK) throw Failure{rc}; return; }
     for (int p = 0; p < 2; p++) {
       h->hist16[p].zero(h->ctx->stream); h->hist32[p].zero(h->ctx->stream); h->fm[p].zero(h->ctx->stream);
     }
@@ -955,6 +1009,7 @@ int sdrhip_fir_destroy(sdrhip_fir *h) {
     if (!h) return;
     h->ctx->use();
     (void)hipStreamSynchronize(h->ctx->stream);
+    if (h->fftc) (void)sdrhip_fftconv_destroy(h->fftc);
     delete h;
   });
 }

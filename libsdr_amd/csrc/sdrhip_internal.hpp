@@ -145,6 +145,8 @@ static inline void require_disjoint(const void *in, size_t in_stride, size_t in_
 // fir.hip: turn on the frequency shift fused into the cf32 FIR's staging (used by the float baseband, fbb_f32.hip)
 void fir_set_shift(sdrhip_fir *h, double fc, double fs);
 void fir_load_taps(sdrhip_fir *h, const double *alpha);
+int fir_create_impl(sdrhip_ctx *ctx, int kind, const double *alpha, int order, int decim, int channels, size_t max_in, int epilogue,
+                    bool allow_fft, sdrhip_fir **out);
 
 #ifdef __HIPCC__
 // XCD-aware unit order for grids of (units-per-channel, channels) whose neighbouring units of a channel re-read each
