@@ -1342,7 +1342,10 @@ int sdrhip_fftconv_create_bank(sdrhip_ctx *ctx, int mode, int fft_size, const fl
       if (mode == SDRHIP_FFTCONV_OLA && (awkward || (n_bands == 1 && fft_size != 2048)) && fft_size % 2 == 0 && !getenv("SDRHIP_FFTCONV_LITERAL")) {
         // the same N taps by overlap-save on the best power of two (ola_spectrum_to_taps); SDRHIP_FFTCONV_LITERAL=1
         // keeps the 2N-point transform (tests of the general plans)
-        const int N = fft_size / 2, lp = overlap_save_fft_size(N, 16384);
+        // (complex<float>: the tuned kernels' own ranking — 2048 points up to 512 taps, 4096 up to 2048, 16384 beyond — measured at
+        // 8 ... 4097 taps, tools/probes/fir_cf32_vs_fft.py; the operation count alone would pick 8192 points for 1000 taps: 0.41 ms
+        // against 0.35 ms on 4096)
+        const int N = fft_size / 2, lp = N <= 512 ? 2048 : N <= 2048 ? 4096 : N <= 12289 ? 16384 : 0;
         if (lp && lp != fft_size) {
           for (int b = 0; b < n_bands; b++) {
             const std::vector<float> t = ola_spectrum_to_taps(kernels + (size_t)b * 2 * fft_size, fft_size);
