@@ -1013,7 +1013,7 @@ struct sdrhip_iqbb_i16 {
     if (!(path == 3 && use_hot && hot_range >= 0 && S <= 17 && !i8 && !real)) return false;
     if (D >= 9 && D <= 512) return true;
     // decimations 2 ... 7: the small-decimation form, where its sample arrays fit a workgroup's LDS (iqbb_hot.hpp, SD, hot_sd_nw)
-    return D >= 2 && D <= 7 && hot_launch_sd(S, in_cu8 ? HOT_CU8 : HOT_CS16, hot_range, inc != 0, epi, HotLaunch{0, nullptr}, HotArgs{}, IqbbArgs{}, true) != 0;
+    return D >= 1 && D <= 7 && hot_launch_sd(S, in_cu8 ? HOT_CU8 : HOT_CS16, hot_range, inc != 0, epi, HotLaunch{0, nullptr}, HotArgs{}, IqbbArgs{}, true) != 0;
   }
   bool launch_anyd_call(IqbbArgs &a, const Geometry &g, const uint32_t *in_dev, size_t N, size_t in_stride, void *out_dev,
                         size_t out_stride) {
@@ -1308,7 +1308,7 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
         h->fm[p].alloc(channels); h->fm[p].zero(ctx->stream);
       }
       h->max_out = max_in / decim + 2;
-      if (epilogue == SDRHIP_EPI_FM && h->path == 3 && decim >= 2 && decim <= 512) {   // any-D hot forms: one angle per slice of the longest call (launch_anyd_call)
+      if (epilogue == SDRHIP_EPI_FM && h->path == 3 && decim >= 1 && decim <= 512) {   // any-D hot forms: one angle per slice of the longest call (launch_anyd_call)
         const size_t GS = 512 / (size_t)decim, tiles_h = ceil_div(max_in / (size_t)decim + 2, 4 * GS);
         h->philast.alloc((size_t)channels * 4 * tiles_h + 1024);
 #ifdef K1_FM_HANDSHAKE

@@ -154,7 +154,7 @@ ANYD_CASES = [(21, 125, 100e3, True), (16, 62, 100e3, False), (21, 9, -60e3, Fal
               (200, 700, 100e3, False), (33, 777, 41e3, True), (21, 1024, 100e3, False),
               # decimations 2 ... 7: the hot kernel's small-decimation form (a slice holds 73 ... 256 groups: lane l finishes
               # the groups l, l + 64, ... of every slice)
-              (21, 2, 100e3, False), (16, 3, -100e3, True), (33, 4, 70e3, False), (64, 5, 100e3, True), (127, 6, -60e3, False), (21, 7, 100e3, True),
+              (21, 1, 100e3, False), (16, 1, -100e3, True), (127, 1, 0.0, False), (21, 2, 100e3, False), (16, 3, -100e3, True), (33, 4, 70e3, False), (64, 5, 100e3, True), (127, 6, -60e3, False), (21, 7, 100e3, True),
               (129, 2, 30e3, True), (16, 4, 0.0, False), (21, 7, 0.0, True), (65, 3, 0.0, False), (127, 5, 0.0, True),
               # ... in 8- and 16-wave workgroups: 17 K steps (orders 130 ... 257), and 9 K steps without a shift (127 / 5 above)
               (255, 6, 100e3, True), (200, 7, 0.0, False), (130, 7, -60e3, False), (257, 6, 0.0, True), (100, 6, 0.0, False), (129, 2, 0.0, True),
