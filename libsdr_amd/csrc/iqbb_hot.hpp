@@ -71,11 +71,8 @@ constexpr bool hot_wide(int S, int NH, int in, int NW, int extra = 0, bool pair 
 #endif
 // the any-D form's additions to a workgroup's LDS: parked group sums, and the rotated samples where the window buffer is too small
 // (rot = false, plans without a shift: the unrotated values have 18 bits — two arrays of dwords instead of one of int16 pairs)
-#ifdef K1_TEAM_LDS
-constexpr int hot_anyd_extra(int S, int in, bool rot = true, int NW = 4) { return NW * 512 + (hot_bufb(S, in) >= 2048 ? 0 : NW * 2048) + (rot ? 0 : NW * 2048); }
-#else   // (the team sums stay in registers: only the parked group sums, 512 bytes per wave)
+// (the team sums stay in registers: only the parked group sums, 512 bytes per wave)
 constexpr int hot_anyd_extra(int, int, bool = true, int NW = 4) { return NW * 512; }
-#endif
 
 // the small-decimation form (2 <= D <= 7, SD): the wave's 512 rotated samples go through a 2 KB per-wave LDS array (the
 // slice's own window buffer when that is large enough; two arrays without a shift: the unrotated values have 18 bits)
@@ -147,11 +144,12 @@ __host__ __device__ __forceinline__ bool slice_is_hot(int halo, int win, int bas
 
 // DG: ANY decimation 9 <= D <= 512 (the reference's own receivers decimate by 62 and 125, examples/sdr_rec.cc:68,
 // examples/sdr_fm.cc:40). The matrix part, the windows and the grid are the same; a slice's 512 samples hold GS = 512 / D
-// whole groups (the slices of a wave advance by GS * D samples, so every slice starts on a group), the rotated samples go
-// through a 2 KB per-wave LDS array and lane teams sum the groups from there. The tap fragments are path 3's (rows in
-// natural order: short calls run the general any-D kernel on the same plan). The cold phase is the same code with the
-// samples outside the call masked and the team leaders applying the border rules themselves (cold_finish_gen).
-// SD (with DG): decimations 2 ... 7 — the windows, the grid and the natural row order are the any-D form's; a slice holds
+// whole groups (the slices of a wave advance by GS * D samples, so every slice starts on a group), the rotated samples are
+// combined in registers (stageE: prefix sums, one team of lanes per group). The tap fragments are a set of their own with
+// the /8 kernel's row permutation (a lane ends up with 8 consecutive samples; the plan's general kernel for short calls
+// keeps its natural-order set). The cold phase is the same code with the samples outside the call masked and the team
+// leaders applying the border rules themselves (cold_finish_gen).
+// SD (with DG): decimations 2 ... 7 — the windows, the grid and the tap fragments are the any-D form's; a slice holds
 // GS = 512 / D groups (73 ... 256: more than lanes), so the wave's rotated samples go through a 2 KB LDS array in stream
 // order and lane l sums and FINISHES the groups l, l + 64, l + 128, l + 192 per slice (consecutive lanes, consecutive
 // outputs: coalesced stores), the /8 kernel's per-slice finish instead of the parked one.
@@ -183,9 +181,6 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   // the border rules, divides and demodulates.
   constexpr bool PART = EPI == HOT_EPI_PARTIAL;
   static_assert(!PART || (DG && !SD), "partial sums: a variant of the any-D form");
-#ifdef K1_TEAM_LDS
-  static_assert(!PART, "partial sums come out of the register prefix sums");
-#endif
   static_assert(!SD || DG, "the small-decimation form is a variant of the any-D form");
   static_assert(!DG || !REAL, "any-D form: complex plans");
 
@@ -318,7 +313,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   const int coff = REAL ? 16 * (n + h) : h * HALF + 16 * n;   // chunk 2(n + s) + h of the wave's window (real: chunk n + 2s + h)
   // phase counters of the lane's samples 0 and 1 relative to the wave's first sample, as a 16-bit pair (only bits 8..14
   // of a counter pick the table entry); the wave's part is scalar and joins per slice in one v_pk_add_u16 per sample pair
-  const uint32_t lane_cnt = (uint32_t)(MF_BLK * n + (DG ? 2 : 8) * h) * a.inc;   // (DG: natural row order — the lane's sample pairs sit at 16n + 2h + 4jj)
+  const uint32_t lane_cnt = (uint32_t)(MF_BLK * n + 8 * h) * a.inc;   // (every form: the lane's 8 samples are 16n + 8h + {0 ... 7} of the slice)
   const uint32_t lane_pair = (lane_cnt & 0xffffu) | ((lane_cnt + a.inc) << 16);
 
   // + 128*sum(a) rides into the low-plane accumulator as the first MFMA's C operand: a 16-register block that must
@@ -564,14 +559,20 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       o = nx;
     }
   };
-  // E: lane (n, h) owns group 2n + h of the wave: recombine the byte-plane accumulators, >>14, rotate by LUT[idx(n)],
-  // window sum of the products' high halves. wave_cnt: LUT phase counter of the wave's first sample (scalar)
+  // E: lane (n, h) holds the 8 consecutive samples 16n + 8h + {0 ... 7} of the wave's slice — block Lb = 2n + h — in EVERY form
+  // (the tap fragments' rows are permuted for it on the host: complex and real input alike): recombine the byte-plane
+  // accumulators, >>14, rotate by LUT[idx(n)]. D = 8: the block IS the lane's group — window sum of the products' high halves.
+  // wave_cnt: LUT phase counter of the wave's first sample (scalar)
   // (edge_: the cold slices of the any-D form — samples outside the call contribute nothing; erel0: call-relative index of the lane's first sample)
-  // (DG) the team sums without an LDS round trip: after the half swap lane (n, h) holds the 8 consecutive samples of block
-  // Lb = 2n + h; D >= 9 puts at most ONE group boundary inside a block, at tm_sp (8: none) — a constant of the lane, like the
-  // lanes a team leader fetches its group's two prefix sums from (tm_a0 / tm_a1: ds_bpermute addresses; tm_end: the group
-  // ends with the slice's 512 samples)
+  // (DG) the group sums without an LDS round trip, out of PREFIX sums over the wave's 512 samples: D >= 9 puts at most ONE
+  // group boundary inside a block, tm_sp samples into it (8: none) — a constant of the lane, like the lanes a team leader
+  // fetches its group's two prefix sums from (tm_a0 / tm_a1: ds_bpermute addresses). With a frequency shift the rotated
+  // samples are 16-bit: packed in pairs, the block's total and the part in front of its boundary are four v_dot2_i32_i16
+  // each — against (1, 1), and against the lane's 0 / 1 masks tm_m (sample 2jj in the low half, 2jj + 1 in the high half).
+  // Where the slice's last group ends with the slice (GS * D = 512) block 63 has no boundary inside and publishes the
+  // wave's total instead: the last team's leader fetches it like any other prefix.
   int tm_sp = 8, tm_a0 = 0, tm_a1 = 0;
+  unsigned tm_m[4] = {0u, 0u, 0u, 0u};
   bool tm_end = false;
   if (DG) {
     const int Lb = 2 * n + h;
@@ -582,8 +583,11 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
     tm_a0 = 4 * ((b0 >> 1) + 32 * (b0 & 1));
     tm_a1 = 4 * ((b1c >> 1) + 32 * (b1c & 1));
     tm_end = b1 >= 64;
+    const int spm = tm_sp < 8 ? tm_sp : (Lb == 63 && GS * DD == 512) ? 8 : 0;   // samples of the block that count for the published prefix
+#pragma unroll
+    for (int jj = 0; jj < 4; jj++) tm_m[jj] = (2 * jj < spm ? 1u : 0u) | (2 * jj + 1 < spm ? 0x10000u : 0u);
   }
-  (void)tm_sp; (void)tm_a0; (void)tm_a1; (void)tm_end;
+  (void)tm_sp; (void)tm_a0; (void)tm_a1; (void)tm_end; (void)tm_m;
   auto stageE = [&](auto edge_, const v16i &acc_hh, const v16i &acc_mid, const v16i &acc_ll, uint32_t wave_cnt, char *escr, int erel0,
                     int2 *pdst = nullptr, int ob0 = 0) __attribute__((always_inline)) {   // (PART: where the slice's partial sums go, its first group boundary)
     constexpr bool EDGE = decltype(edge_)::value;
@@ -596,7 +600,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       typedef int v2i __attribute__((ext_vector_type(2)));
 #pragma unroll
       for (int jj = 0; jj < 4; jj++) {
-        const uint32_t wc = (wave_cnt + (DG ? 4u : 2u) * jj * a.inc) & 0xffffu, wpair = wc | (wc << 16);
+        const uint32_t wc = (wave_cnt + 2u * jj * a.inc) & 0xffffu, wpair = wc | (wc << 16);
         uint32_t pr, o0, o1;
         asm("v_pk_add_u16 %0, %1, %2" : "=v"(pr) : "v"(lane_pair), "s"(wpair));
         if (WIDE) {
@@ -615,11 +619,12 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       }
     }
     int2 sum = make_int2(0, 0);
-    unsigned pk[8];   // (DG) the lane's rotated samples, or (no shift) their real parts
-    unsigned pky[8];  // (DG, no shift) the imaginary parts
+    int vx[8], vy[8];   // (DG) the lane's samples after the rotation (32-bit products: the sample is the high half), or (no shift) the FIR values
 #ifdef K1_ABL_NOEPI
 #pragma unroll
     for (int r = 0; r < 16; r += 2) { sum.x += acc_hh[r] ^ acc_mid[r] ^ acc_ll[r]; sum.y += acc_hh[r + 1] ^ acc_mid[r + 1] ^ acc_ll[r + 1]; }
+#pragma unroll
+    for (int j = 0; j < 8; j++) { vx[j] = sum.x; vy[j] = sum.y; }
 #else
 #pragma unroll
     for (int j = 0; j < 8; j++) {
@@ -635,123 +640,121 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
         asm("" : "+v"(tre)); asm("" : "+v"(tim));   // no re-association into 2 shifts + add3
         rr = (int)((tre << 8) + (unsigned)acc_ll[2 * j]) >> FSH; ri = (int)((tim << 8) + (unsigned)acc_ll[2 * j + 1]) >> FSH;
       }
-      if (EDGE) {   // (natural row order: register pair j is sample 4 (j >> 1) + (j & 1) of the lane's run)
-        const int rel = erel0 + 4 * (j >> 1) + (j & 1);
+      if (EDGE) {   // (register pair j is sample j of the lane's run)
+        const int rel = erel0 + j;
         if (rel < 0 || rel >= a.N) { rr = 0; ri = 0; }
       }
       if (ROT) {
         const int x = WIDE ? mad24a(L[j][0], rr, mul24a(L[j][2], ri)) : sub32(mul24a(L[j][0], rr), mul24a(L[j][1], ri));
         const int y = mad24a(L[j][0], ri, mul24a(L[j][1], rr));
-        if (DG) pk[j] = __builtin_amdgcn_perm((unsigned)y, (unsigned)x, 0x07060302u);   // {x >> 16, y >> 16} as two int16
+        if (DG) { vx[j] = x; vy[j] = y; }
         else { sum.x = add_hi16(x, sum.x); sum.y = add_hi16(y, sum.y); }
       } else if (DG) {
-        pk[j] = (unsigned)rr; pky[j] = (unsigned)ri;
+        vx[j] = rr; vy[j] = ri;
       } else {
         sum.x = (int)((unsigned)sum.x + (unsigned)rr); sum.y = (int)((unsigned)sum.y + (unsigned)ri);
       }
     }
 #endif
     if (SD) {
-      // the wave's 512 rotated samples in stream order: lanes (n, 0) and (n, 1) trade halves (v_permlane32_swap) so that
-      // each holds 8 CONSECUTIVE samples — (n, h): 16n + 8h + {0..7} — and the wave writes 64 contiguous 32-byte pieces
+      // the wave's 512 rotated samples in stream order: lane (n, h) holds 16n + 8h + {0 ... 7}, the wave writes 64 contiguous
+      // 32-byte pieces ({x >> 16, y >> 16} as two int16 per sample; without a shift the 18-bit parts in two arrays)
       unsigned *gsc = reinterpret_cast<unsigned *>(BUFB >= 2048 ? escr : gscb);
       unsigned *gsy = reinterpret_cast<unsigned *>(BUFB >= 2048 ? gscb : gscb2);   // (no shift) the imaginary parts' array
       unsigned q8[8];
 #pragma unroll
-      for (int jj = 0; jj < 2; jj++)
-#pragma unroll
-        for (int tt = 0; tt < 2; tt++) {
-          const auto sw = __builtin_amdgcn_permlane32_swap(pk[2 * jj + tt], pk[2 * (jj + 2) + tt], false, false);
-          q8[4 * jj + tt] = sw[0]; q8[4 * jj + 2 + tt] = sw[1];
-        }
+      for (int j = 0; j < 8; j++) q8[j] = ROT ? __builtin_amdgcn_perm((unsigned)vy[j], (unsigned)vx[j], 0x07060302u) : (unsigned)vx[j];
       *reinterpret_cast<uint4 *>(gsc + 8 * (2 * n + h)) = make_uint4(q8[0], q8[1], q8[2], q8[3]);
       *reinterpret_cast<uint4 *>(gsc + 8 * (2 * n + h) + 4) = make_uint4(q8[4], q8[5], q8[6], q8[7]);
       if (!ROT) {
-#pragma unroll
-        for (int jj = 0; jj < 2; jj++)
-#pragma unroll
-          for (int tt = 0; tt < 2; tt++) {
-            const auto sw = __builtin_amdgcn_permlane32_swap(pky[2 * jj + tt], pky[2 * (jj + 2) + tt], false, false);
-            q8[4 * jj + tt] = sw[0]; q8[4 * jj + 2 + tt] = sw[1];
-          }
-        *reinterpret_cast<uint4 *>(gsy + 8 * (2 * n + h)) = make_uint4(q8[0], q8[1], q8[2], q8[3]);
-        *reinterpret_cast<uint4 *>(gsy + 8 * (2 * n + h) + 4) = make_uint4(q8[4], q8[5], q8[6], q8[7]);
+        *reinterpret_cast<uint4 *>(gsy + 8 * (2 * n + h)) = make_uint4((unsigned)vy[0], (unsigned)vy[1], (unsigned)vy[2], (unsigned)vy[3]);
+        *reinterpret_cast<uint4 *>(gsy + 8 * (2 * n + h) + 4) = make_uint4((unsigned)vy[4], (unsigned)vy[5], (unsigned)vy[6], (unsigned)vy[7]);
       }
       asm volatile("" ::: "memory");   // (the group sums below read them: same wave, in order)
       return sum;
     }
-#ifdef K1_ABL_NOTEAM   // (timing only: no LDS round trip, no team sums)
-    if (DG) { for (int j = 0; j < 8; j++) { sum.x ^= (int)pk[j]; if (!ROT) sum.y ^= (int)pky[j]; } } else
+#ifdef K1_ABL_NOTEAM   // (timing only: no team sums)
+    if (DG) { for (int j = 0; j < 8; j++) { sum.x ^= vx[j]; sum.y ^= vy[j]; } return sum; }
 #endif
-#ifndef K1_TEAM_LDS
     if (DG) {
-      // Group sums as differences of PREFIX sums over the wave's 512 samples, all in registers: the lanes trade halves
-      // (v_permlane32_swap) so that block Lb = 2n + h holds 8 consecutive samples; running sums inside the block; the
-      // totals of a lane pair's 16 samples are scanned over n (the same scan in both halves of the wave: four row shifts
-      // and lane 15's value for the second row); a lane with a group boundary inside its block publishes the prefix sum AT the
-      // boundary, and the team leader of group k fetches the two that bound its group (ds_bpermute: the LDS crossbar, no LDS
-      // memory). The first form went through LDS — 2 KB (4 KB without a shift) written, D / lpg strided reads and adds per
-      // lane in a scalar loop, a shift tree inside the team — and was 28 % (sdr_fm's plan) to 41 % (sdr_rec's WFM plan) of the
-      // kernel's time (-DK1_TEAM_LDS keeps it for A/B).
-      int rx[8], ry[8];
-      {
-        unsigned q8[8], q8y[8];
+      // Group sums as differences of PREFIX sums over the wave's 512 samples, all in registers. Per block: its total tX / tY
+      // and the part in front of its group boundary aX / aY (0 where it has none). The totals of a lane pair's 16 samples are
+      // scanned over n (the same scan in both halves of the wave: four row shifts and one row broadcast); a lane publishes the
+      // prefix sum AT its boundary, and the team leader of group k fetches the two that bound its group (ds_bpermute: the LDS
+      // crossbar, no LDS memory). History: through LDS with strided reads per team 28 - 41 % of the kernel's time (round 3);
+      // running sums + a select tree over them 70 vector instructions per slice (round 4); this form 30.
+      int tX, tY, aX, aY;
+      int px[4], py[4];   // (with a shift) the samples packed in pairs: {sample 2jj, sample 2jj + 1} as two int16
+      if (ROT) {
 #pragma unroll
-        for (int jj = 0; jj < 2; jj++)
+        for (int jj = 0; jj < 4; jj++) {
+          px[jj] = (int)__builtin_amdgcn_perm((unsigned)vx[2 * jj + 1], (unsigned)vx[2 * jj], 0x07060302u);
+          py[jj] = (int)__builtin_amdgcn_perm((unsigned)vy[2 * jj + 1], (unsigned)vy[2 * jj], 0x07060302u);
+        }
+        auto dsum = [&](const int *p4, unsigned m0, unsigned m1, unsigned m2, unsigned m3) __attribute__((always_inline)) {
+          int acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, p4[0]), __builtin_bit_cast(s16x2, m0), 0, false);
+          acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, p4[1]), __builtin_bit_cast(s16x2, m1), acc, false);
+          acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, p4[2]), __builtin_bit_cast(s16x2, m2), acc, false);
+          return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, p4[3]), __builtin_bit_cast(s16x2, m3), acc, false);
+        };
+        unsigned ones = 0x00010001u;
+        asm("" : "+s"(ones));   // (one scalar register: VOP3P takes no literal)
+        tX = dsum(px, ones, ones, ones, ones); tY = dsum(py, ones, ones, ones, ones);
+        if (!PART) { aX = dsum(px, tm_m[0], tm_m[1], tm_m[2], tm_m[3]); aY = dsum(py, tm_m[0], tm_m[1], tm_m[2], tm_m[3]); }
+        else { aX = 0; aY = 0; }
+      } else {
+        // (no shift: 18-bit values) running sums inside the block, the one in front of the boundary by a three-level select
+        // tree on the bits of the lane-constant index
+        int rx[8], ry[8];
+        rx[0] = vx[0]; ry[0] = vy[0];
 #pragma unroll
-          for (int tt = 0; tt < 2; tt++) {
-            const auto sw = __builtin_amdgcn_permlane32_swap(pk[2 * jj + tt], pk[2 * (jj + 2) + tt], false, false);
-            q8[4 * jj + tt] = sw[0]; q8[4 * jj + 2 + tt] = sw[1];
-            if (!ROT) {
-              const auto swy = __builtin_amdgcn_permlane32_swap(pky[2 * jj + tt], pky[2 * (jj + 2) + tt], false, false);
-              q8y[4 * jj + tt] = swy[0]; q8y[4 * jj + 2 + tt] = swy[1];
-            }
-          }
-        if (ROT) {
-          rx[0] = (int)(short)(q8[0] & 0xffffu); ry[0] = (int)q8[0] >> 16;
+        for (int j = 1; j < 8; j++) { rx[j] = (int)((unsigned)rx[j - 1] + (unsigned)vx[j]); ry[j] = (int)((unsigned)ry[j - 1] + (unsigned)vy[j]); }
+        const int ti = tm_sp - 1;
+        const bool tb0 = (ti & 1) != 0, tb1 = (ti & 2) != 0, tb2 = (ti & 4) != 0, tok = ti >= 0 && ti <= 6;
+        auto pick7 = [&](const int *v) __attribute__((always_inline)) {
+          const int t0 = tb0 ? v[1] : v[0], t1 = tb0 ? v[3] : v[2], t2 = tb0 ? v[5] : v[4], t3 = v[6];
+          const int u0 = tb1 ? t1 : t0, u1 = tb1 ? t3 : t2;
+          return tok ? (tb2 ? u1 : u0) : 0;
+        };
+        tX = rx[7]; tY = ry[7];
+        aX = pick7(rx); aY = pick7(ry);
+        if (PART) {   // (the boundaries are the wave's, not the lane's: the running sums stay for prefix_at)
 #pragma unroll
-          for (int j = 1; j < 8; j++) {
-            rx[j] = rx[j - 1]; ry[j] = ry[j - 1];
-            asm("v_add_u32_sdwa %0, sext(%1), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "+v"(rx[j]) : "v"(q8[j]));
-            asm("v_add_u32_sdwa %0, sext(%1), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(ry[j]) : "v"(q8[j]));
-          }
-        } else {
-          rx[0] = (int)q8[0]; ry[0] = (int)q8y[0];
-#pragma unroll
-          for (int j = 1; j < 8; j++) { rx[j] = (int)((unsigned)rx[j - 1] + q8[j]); ry[j] = (int)((unsigned)ry[j - 1] + q8y[j]); }
+          for (int j = 0; j < 8; j++) { vx[j] = rx[j]; vy[j] = ry[j]; }
         }
       }
-      // the block's samples in front of its boundary: rx[tm_sp - 1] for tm_sp = 1 ... 7, else 0 — a three-level select tree
-      // on the bits of the lane-constant index (7 selects per component; a chain over the 7 candidates was 14 + compares)
-      const int ti = tm_sp - 1;
-      const bool tb0 = (ti & 1) != 0, tb1 = (ti & 2) != 0, tb2 = (ti & 4) != 0, tok = ti >= 0 && ti <= 6;
-      auto pick7 = [&](const int *v) __attribute__((always_inline)) {
-        const int t0 = tb0 ? v[1] : v[0], t1 = tb0 ? v[3] : v[2], t2 = tb0 ? v[5] : v[4], t3 = v[6];
-        const int u0 = tb1 ? t1 : t0, u1 = tb1 ? t3 : t2;
-        return tok ? (tb2 ? u1 : u0) : 0;
-      };
-      const int ax = pick7(rx), ay = pick7(ry);
-      const auto tx = __builtin_amdgcn_permlane32_swap((unsigned)rx[7], (unsigned)rx[7], false, false);   // {block (n, 0)'s total, block (n, 1)'s} in both halves
-      const auto ty = __builtin_amdgcn_permlane32_swap((unsigned)ry[7], (unsigned)ry[7], false, false);
+      const auto tx = __builtin_amdgcn_permlane32_swap((unsigned)tX, (unsigned)tX, false, false);   // {block (n, 0)'s total, block (n, 1)'s} in both halves
+      const auto ty = __builtin_amdgcn_permlane32_swap((unsigned)tY, (unsigned)tY, false, false);
       const int cx = (int)(tx[0] + tx[1]), cy = (int)(ty[0] + ty[1]);
-      int ix = cx, iy = cy;   // inclusive scan over n, 16-lane rows first (row_shr: s, zero beyond the row)
+      int ix = cx, iy = cy;   // inclusive scan over n: inside the 16-lane rows (row_shr: s, zero beyond the row), then the row before (row_bcast: 15 into rows 1 and 3)
       ix += __builtin_amdgcn_update_dpp(0, ix, 0x111, 0xf, 0xf, true); iy += __builtin_amdgcn_update_dpp(0, iy, 0x111, 0xf, 0xf, true);
       ix += __builtin_amdgcn_update_dpp(0, ix, 0x112, 0xf, 0xf, true); iy += __builtin_amdgcn_update_dpp(0, iy, 0x112, 0xf, 0xf, true);
       ix += __builtin_amdgcn_update_dpp(0, ix, 0x114, 0xf, 0xf, true); iy += __builtin_amdgcn_update_dpp(0, iy, 0x114, 0xf, 0xf, true);
       ix += __builtin_amdgcn_update_dpp(0, ix, 0x118, 0xf, 0xf, true); iy += __builtin_amdgcn_update_dpp(0, iy, 0x118, 0xf, 0xf, true);
-      const int r0x = __builtin_amdgcn_readlane(ix, 15), r0y = __builtin_amdgcn_readlane(iy, 15);
-      if (l & 16) { ix += r0x; iy += r0y; }
-      const int totx = __builtin_amdgcn_readlane(ix, 31), toty = __builtin_amdgcn_readlane(iy, 31);
+      ix += __builtin_amdgcn_update_dpp(0, ix, 0x142 /* row_bcast:15 */, 0xa, 0xf, false); iy += __builtin_amdgcn_update_dpp(0, iy, 0x142, 0xa, 0xf, false);
+      // the prefix sum in front of the block
+      const int bpx = ix - (h ? (int)tx[1] : cx), bpy = iy - (h ? (int)ty[1] : cy);
       if (PART) {
         // the sums in front of the (wave-uniform) boundaries ob0 and ob0 + Dreal, where they fall inside the slice: the
         // prefix in front of the boundary's block + the block's samples in front of it, read from the lane that owns it
-        const int bpx = ix - (h ? (int)tx[1] : cx), bpy = iy - (h ? (int)ty[1] : cy);
-        auto prefix_at = [&](int p, int &px, int &py) __attribute__((always_inline)) {   // 0 < p < 512 (scalar)
+        const int totx = __builtin_amdgcn_readlane(ix, 31), toty = __builtin_amdgcn_readlane(iy, 31);
+        auto prefix_at = [&](int p, int &ox, int &oy) __attribute__((always_inline)) {   // 0 < p < 512 (scalar)
           const int j = p & 7, lb = p >> 3, ln = (lb >> 1) + 32 * (lb & 1);
-          int vx = bpx, vy = bpy;
+          int wx = bpx, wy = bpy;
+          if (ROT) {   // (scalar masks: samples 2jj, 2jj + 1 in front of position j)
+            unsigned m[4];
 #pragma unroll
-          for (int t = 1; t < 8; t++) if (j == t) { vx += rx[t - 1]; vy += ry[t - 1]; }   // (scalar conditions)
-          px = __builtin_amdgcn_readlane(vx, ln); py = __builtin_amdgcn_readlane(vy, ln);
+            for (int jj = 0; jj < 4; jj++) m[jj] = (2 * jj < j ? 1u : 0u) | (2 * jj + 1 < j ? 0x10000u : 0u);
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+              wx = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, px[jj]), __builtin_bit_cast(s16x2, m[jj]), wx, false);
+              wy = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, py[jj]), __builtin_bit_cast(s16x2, m[jj]), wy, false);
+            }
+          } else {
+#pragma unroll
+            for (int t = 1; t < 8; t++) if (j == t) { wx += vx[t - 1]; wy += vy[t - 1]; }   // (scalar conditions; vx / vy: the running sums)
+          }
+          ox = __builtin_amdgcn_readlane(wx, ln); oy = __builtin_amdgcn_readlane(wy, ln);
         };
         int p0x = totx, p0y = toty, p1x = totx, p1y = toty;
         if (ob0 < 512) prefix_at(ob0, p0x, p0y);
@@ -764,98 +767,14 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
         }
         return sum;
       }
-      // the prefix sum in front of the block, plus the samples in front of its boundary
-      const int sbx = ix - (h ? (int)tx[1] : cx) + ax, sby = iy - (h ? (int)ty[1] : cy) + ay;
+      const int sbx = bpx + aX, sby = bpy + aY;
       const int s0x = __builtin_amdgcn_ds_bpermute(tm_a0, sbx), s0y = __builtin_amdgcn_ds_bpermute(tm_a0, sby);
       int s1x = __builtin_amdgcn_ds_bpermute(tm_a1, sbx), s1y = __builtin_amdgcn_ds_bpermute(tm_a1, sby);
-      if (tm_end) { s1x = totx; s1y = toty; }
+      if (!ROT) {   // (the select tree has no entry for a whole block: the wave's total by a broadcast)
+        const int totx = __builtin_amdgcn_readlane(ix, 31), toty = __builtin_amdgcn_readlane(iy, 31);
+        if (tm_end) { s1x = totx; s1y = toty; }
+      }
       sum = make_int2(s1x - s0x, s1y - s0y);   // (whole in the team's first lane)
-    }
-    if (false) {
-#else
-    if (DG) {
-#endif
-      // the wave's 512 rotated samples in stream order (lane (n, h) holds the pairs 16n + 2h + 4jj + {0, 1}), then teams of
-      // `lpg` lanes (a power of two <= 16, about 64 / GS) sum one group each: strided partial sums, then a shift tree
-      // inside the team (one wave's LDS operations execute in order; the asm keeps the compiler from reordering them)
-      unsigned *gsc = reinterpret_cast<unsigned *>(BUFB >= 2048 ? escr : gscb);   // (the slice's own window buffer is done with: 2 KB of it, or the wave's extra array)
-      // lanes (n, 0) and (n, 1) trade halves (v_permlane32_swap: lanes 32..63 of the first operand <-> lanes 0..31 of the
-      // second) so that each holds 8 CONSECUTIVE samples — (n, h): 16n + 8h + {0..7} — and the wave writes its 2 KB as 64
-      // contiguous 32-byte pieces (written pair by pair at the lanes' own 64-byte stride the stores ran into 8-way bank
-      // conflicts: half of the kernel's LDS cycles)
-      unsigned q8[8];
-#pragma unroll
-      for (int jj = 0; jj < 2; jj++)
-#pragma unroll
-        for (int tt = 0; tt < 2; tt++) {
-          const auto sw = __builtin_amdgcn_permlane32_swap(pk[2 * jj + tt], pk[2 * (jj + 2) + tt], false, false);
-          // h = 0: own pair jj (positions 4jj + tt) and (n, 1)'s pair jj (2 + 4jj + tt); h = 1: (n, 0)'s pair jj + 2 and the own one
-          q8[4 * jj + tt] = sw[0]; q8[4 * jj + 2 + tt] = sw[1];
-        }
-      *reinterpret_cast<uint4 *>(gsc + 8 * (2 * n + h)) = make_uint4(q8[0], q8[1], q8[2], q8[3]);
-      *reinterpret_cast<uint4 *>(gsc + 8 * (2 * n + h) + 4) = make_uint4(q8[4], q8[5], q8[6], q8[7]);
-      unsigned *gsy = reinterpret_cast<unsigned *>(BUFB >= 2048 ? gscb : gscb2);   // (no shift) the imaginary parts' array
-      if (!ROT) {
-#pragma unroll
-        for (int jj = 0; jj < 2; jj++)
-#pragma unroll
-          for (int tt = 0; tt < 2; tt++) {
-            const auto sw = __builtin_amdgcn_permlane32_swap(pky[2 * jj + tt], pky[2 * (jj + 2) + tt], false, false);
-            q8[4 * jj + tt] = sw[0]; q8[4 * jj + 2 + tt] = sw[1];
-          }
-        *reinterpret_cast<uint4 *>(gsy + 8 * (2 * n + h)) = make_uint4(q8[0], q8[1], q8[2], q8[3]);
-        *reinterpret_cast<uint4 *>(gsy + 8 * (2 * n + h) + 4) = make_uint4(q8[4], q8[5], q8[6], q8[7]);
-      }
-      asm volatile("" ::: "memory");
-      const int lsh = a.lpg_sh, k = l >> lsh, t = l & ((1 << lsh) - 1);
-      int sx = 0, sy = 0;
-      {
-        // D / lpg rounds in which every lane of a team has an element (a scalar loop: no per-lane bounds), then one round
-        // for the D % lpg lanes that have one more; the lanes beyond the GS-th team read the wave's last dword and drop it
-        const int kk = min(k, GS - 1);
-#ifdef K1_ABL_ODDSTRIDE   // (timing only: the teams' bank conflicts gone, wrong results)
-        const unsigned *gp = gsc + min(kk * (DD | 1), 512 - DD) + t;
-        const int nfull = DD >> lsh;
-        const unsigned *gpy = gsy + min(kk * (DD | 1), 512 - DD) + t;
-#else
-        const unsigned *gp = gsc + kk * DD + t;
-        const int nfull = DD >> lsh;
-        const unsigned *gpy = gsy + kk * DD + t;
-#endif
-        for (int i = 0; i < nfull; i++) {
-          const unsigned v = gp[i << lsh];
-          if (ROT) {
-            asm("v_add_u32_sdwa %0, sext(%1), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "+v"(sx) : "v"(v));
-            asm("v_add_u32_sdwa %0, sext(%1), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(sy) : "v"(v));
-          } else {
-            sx = (int)((unsigned)sx + v); sy = (int)((unsigned)sy + gpy[i << lsh]);
-          }
-        }
-        if ((nfull << lsh) < DD) {   // (scalar)
-          const int ei = min(nfull << lsh, DD - 1 - t);
-          unsigned v = gp[ei], vy = ROT ? 0u : gpy[ei];
-          if (t + (nfull << lsh) >= DD) { v = 0u; vy = 0u; }
-          if (ROT) {
-            asm("v_add_u32_sdwa %0, sext(%1), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "+v"(sx) : "v"(v));
-            asm("v_add_u32_sdwa %0, sext(%1), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(sy) : "v"(v));
-          } else {
-            sx = (int)((unsigned)sx + v); sy = (int)((unsigned)sy + vy);
-          }
-        }
-      }
-      asm volatile("" ::: "memory");
-      // lane t of a team += lane t + s (row_shl: s, zero beyond the 16-lane row) for s = 1, 2, 4, 8 below the team size
-      if (lsh > 0) { sx += __builtin_amdgcn_update_dpp(0, sx, 0x101, 0xf, 0xf, true); sy += __builtin_amdgcn_update_dpp(0, sy, 0x101, 0xf, 0xf, true); }
-      if (lsh > 1) { sx += __builtin_amdgcn_update_dpp(0, sx, 0x102, 0xf, 0xf, true); sy += __builtin_amdgcn_update_dpp(0, sy, 0x102, 0xf, 0xf, true); }
-      if (lsh > 2) { sx += __builtin_amdgcn_update_dpp(0, sx, 0x104, 0xf, 0xf, true); sy += __builtin_amdgcn_update_dpp(0, sy, 0x104, 0xf, 0xf, true); }
-      if (lsh > 3) { sx += __builtin_amdgcn_update_dpp(0, sx, 0x108, 0xf, 0xf, true); sy += __builtin_amdgcn_update_dpp(0, sy, 0x108, 0xf, 0xf, true); }
-      if (lsh > 4) {   // teams of 32 lanes (GS = 2): the second 16-lane row's sum comes over by ds_bpermute
-        sx += __builtin_amdgcn_ds_bpermute(4 * ((l + 16) & 63), sx); sy += __builtin_amdgcn_ds_bpermute(4 * ((l + 16) & 63), sy);
-      }
-      if (lsh > 5) {   // ... and of the whole wave (GS = 1: decimations 257 .. 512 — only D of a slice's 512 samples are used)
-        sx += __builtin_amdgcn_ds_bpermute(4 * ((l + 32) & 63), sx); sy += __builtin_amdgcn_ds_bpermute(4 * ((l + 32) & 63), sy);
-      }
-      sum = make_int2(sx, sy);   // (whole in the team's first lane)
     }
     return sum;
   };
@@ -1450,7 +1369,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
             ob0 = t0 < 0 ? ac.Dreal - t0 : ac.Dreal - (int)((unsigned)t0 % (unsigned)ac.Dreal);
             pdst = ac.part + (long)cc * ac.part_stride + 3 * (4 * t + wv);
           }
-          const int2 sum = stageE(std::true_type{}, acc_hh, acc_mid, acc_ll, (ac.n0_lo + (uint32_t)s0) * ac.inc, cb, s0 + MF_BLK * n + 2 * h, pdst, ob0);
+          const int2 sum = stageE(std::true_type{}, acc_hh, acc_mid, acc_ll, (ac.n0_lo + (uint32_t)s0) * ac.inc, cb, s0 + MF_BLK * n + 8 * h, pdst, ob0);
           if (SD) sd_finish_cold(cb, cc, 4 * t + wv);
           else if (!PART) cold_finish_gen(sum, cc, 4 * t + wv);
         } else {

@@ -773,6 +773,7 @@ struct sdrhip_iqbb_i16 {
   int path = 0, S = 0, cre = 0, cim = 0;   // path 1 = int8-MFMA formulation with S K-steps
   unsigned ah_mask = 0;
   DevBuf<v4i> tapfrag;
+  DevBuf<v4i> tapfrag_hot;   // path 3: the any-D hot forms' fragments (rows permuted as path 1's)
   size_t lds_bytes = 0;
   DevBuf<uint2> taps;
   DevBuf<int2> lut;
@@ -856,24 +857,33 @@ struct sdrhip_iqbb_i16 {
       for (int k = 0; k < 2 * OPm; k++) { sre += (unsigned)are[k]; sim += (unsigned)aim[k]; }
       cre = (int)(128u * sre); cim = (int)(128u * sim);
       std::vector<int8_t> frag((size_t)S * 2 * 64 * 16, 0);
-      for (int st = 0; st < S; st++)
-        for (int l = 0; l < 64; l++)
-          for (int j = 0; j < 16; j++) {
-            const int m = l & 31, hh = l >> 5;
-            int t = m >> 1, comp = m & 1;
-            if (path == 1) {   // row permutation: the 32x32 C/D map gives lane half hC = (m>>2)&1 the rows m with register
-                                  // r = (m&3) + 4*(m>>3); row m carries sample t = 8*hC + (r>>1), component r&1, so that
-                                  // a lane ends up with one whole decimation group (8 consecutive samples)
-              const int hC = (m >> 2) & 1, r = (m & 3) + 4 * (m >> 3);
-              t = 8 * hC + (r >> 1); comp = r & 1;
+      auto build = [&](bool permuted) {
+        for (int st = 0; st < S; st++)
+          for (int l = 0; l < 64; l++)
+            for (int j = 0; j < 16; j++) {
+              const int m = l & 31, hh = l >> 5;
+              int t = m >> 1, comp = m & 1;
+              if (permuted) {   // row permutation: the 32x32 C/D map gives lane half hC = (m>>2)&1 the rows m with register
+                                // r = (m&3) + 4*(m>>3); row m carries sample t = 8*hC + (r>>1), component r&1, so that
+                                // a lane ends up with 8 consecutive samples (decimation 8: one whole group)
+                const int hC = (m >> 2) & 1, r = (m & 3) + 4 * (m >> 3);
+                t = 8 * hC + (r >> 1); comp = r & 1;
+              }
+              const int idx = 32 * st + 16 * hh + j - 2 * t;
+              const int v = (idx >= 0 && idx < 2 * OPm) ? (comp ? aim[idx] : are[idx]) : 0;
+              const int al = ((v + 128) & 255) - 128, ah = (v - al) >> 8;
+              frag[(((size_t)(2 * st) * 64 + l) * 16) + j] = (int8_t)ah;
+              if (ah != 0) ah_mask |= 1u << st;
+              frag[(((size_t)(2 * st + 1) * 64 + l) * 16) + j] = (int8_t)al;
             }
-            const int idx = 32 * st + 16 * hh + j - 2 * t;
-            const int v = (idx >= 0 && idx < 2 * OPm) ? (comp ? aim[idx] : are[idx]) : 0;
-            const int al = ((v + 128) & 255) - 128, ah = (v - al) >> 8;
-            frag[(((size_t)(2 * st) * 64 + l) * 16) + j] = (int8_t)ah;
-            if (ah != 0) ah_mask |= 1u << st;
-            frag[(((size_t)(2 * st + 1) * 64 + l) * 16) + j] = (int8_t)al;
-          }
+      };
+      if (path == 3) {   // the hot kernel's any-D forms read a permuted set of their own (iqbb_hot.hpp); the general kernel of
+                         // the plan (short calls) keeps the natural row order
+        build(true);
+        if (!tapfrag_hot.p) tapfrag_hot.alloc((size_t)S * 2 * 64);
+        tapfrag_hot.upload(reinterpret_cast<const v4i *>(frag.data()), (size_t)S * 2 * 64, ctx->stream);
+      }
+      build(path == 1);
       if (path == 1 || path == 3) {   // smallest centred range [S0, S0+NH) of the hot kernel that covers the mask (path 3: its any-D form)
         int nr = 0;
         const HotRange *rg = hot_ranges(S, &nr);
@@ -969,7 +979,7 @@ struct sdrhip_iqbb_i16 {
     a.base0_rel = 0; a.n_groups = nsl; a.n_out = nsl; a.extra0 = 0; a.D = 512; a.fix_lo = a.fix_hi = 0;
     HotArgs ha{};
     ha.in = in_dev; ha.in_stride = (long)in_stride; ha.out = out_dev; ha.out_stride = (long)out_stride;
-    ha.tapfrag = tapfrag.p; ha.lut = lut.p; ha.inc = inc; ha.n0_lo = (uint32_t)(n0 - phase0); ha.negative = negative;
+    ha.tapfrag = tapfrag_hot.p; ha.lut = lut.p; ha.inc = inc; ha.n0_lo = (uint32_t)(n0 - phase0); ha.negative = negative;
     ha.base0_rel = 0; ha.OG = 4; ha.ovl = 0; ha.t_lo = s_lo >> 2; ha.t_hi = (s_hi + 3) >> 2; ha.cre = cre; ha.cim = cim;
     ha.N = (int)N; ha.n_out = nsl; ha.C = C; ha.stamps = nullptr;
     ha.D = 512; ha.GS = 1; ha.tiles_h = tiles_h; ha.lpg_sh = 6; ha.inv_d = 0.f;
@@ -1030,7 +1040,7 @@ struct sdrhip_iqbb_i16 {
     const int t_lo = s_lo >> 2, t_hi = (s_hi + 3) >> 2;
     HotArgs ha{};
     ha.in = in_dev; ha.in_stride = (long)in_stride; ha.out = out_dev; ha.out_stride = (long)out_stride;
-    ha.tapfrag = tapfrag.p; ha.lut = lut.p; ha.inc = inc; ha.n0_lo = (uint32_t)(n0 - phase0); ha.negative = negative;
+    ha.tapfrag = tapfrag_hot.p; ha.lut = lut.p; ha.inc = inc; ha.n0_lo = (uint32_t)(n0 - phase0); ha.negative = negative;
     ha.base0_rel = g.base0_rel; ha.OG = OGh; ha.ovl = 0; ha.t_lo = t_lo; ha.t_hi = t_hi; ha.cre = cre; ha.cim = cim;
     ha.N = (int)N; ha.n_out = g.n_out; ha.C = C; ha.stamps = nullptr;
     ha.D = D; ha.GS = GS; ha.tiles_h = tiles_h;
