@@ -113,7 +113,12 @@ void hot_launch_s9_cs16(int range, bool rot, int epi, const HotLaunch &, const H
 void hot_launch_s9_cu8(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
 void hot_launch_s17_cs16(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
 void hot_launch_s17_cu8(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
-void hot_launch_real(int S, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);   // S = 5 or 9
+void hot_launch_real(int S, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);   // S = 3, 5 or 9
+// real input at any other decimation: the any-D form (9 ... 512) and the small-decimation form (1 ... 7; 0: its LDS does not fit)
+void hot_launch_real_anyd(int S, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
+void hot_launch_real_anyd9(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
+int hot_launch_real_sd(int S, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &, bool dry_run);
+int hot_launch_real_sd9(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &, bool dry_run);
 void hot_launch_anyd(int S, int in, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);   // S = 2, 3, 5, 9 or 17, cs16 / cu8
 void hot_launch_anyd9(int in, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
 void hot_launch_anyd17_cs16(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);   // (orders 130 ... 257: 8- and 16-wave workgroups, as the /8 kernel's)
@@ -182,7 +187,6 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   constexpr bool PART = EPI == HOT_EPI_PARTIAL;
   static_assert(!PART || (DG && !SD), "partial sums: a variant of the any-D form");
   static_assert(!SD || DG, "the small-decimation form is a variant of the any-D form");
-  static_assert(!DG || !REAL, "any-D form: complex plans");
 
   const int DD = DG ? a.D : 8, GS = DG ? a.GS : 64;   // decimation, whole groups per slice
   static_assert(S >= 2 && S0 >= 0 && NH >= 1 && S0 + NH <= S, "high-plane range inside the K loop");
@@ -1476,8 +1480,9 @@ int hot_launch_sd_one(bool rot, int epi, const HotLaunch &hl, const HotArgs &ha,
     case SDRHIP_EPI_AM: SDRHIP_SD(R_, SDRHIP_EPI_AM); break; \
     case SDRHIP_EPI_USB: SDRHIP_SD(R_, SDRHIP_EPI_USB); break; \
     default: SDRHIP_SD(R_, SDRHIP_EPI_NONE); break; } return NWX; } while (0)
-  if (rot) { constexpr int NWX = hot_sd_nw(S, NH, IN, true, NW0); if constexpr (NWX > 0) SDRHIP_SD_E(true); }
-  else { constexpr int NWX = hot_sd_nw(S, NH, IN, false, NW0); if constexpr (NWX > 0) SDRHIP_SD_E(false); }
+  // (real input: 4-wave workgroups only — a plan whose arrays need a larger one runs the VALU kernel)
+  if (rot) { constexpr int NWX = hot_sd_nw(S, NH, IN, true, NW0); if constexpr (NWX > 0 && (IN != HOT_REAL || NWX == 4)) SDRHIP_SD_E(true); }
+  else { constexpr int NWX = hot_sd_nw(S, NH, IN, false, NW0); if constexpr (NWX > 0 && (IN != HOT_REAL || NWX == 4)) SDRHIP_SD_E(false); }
 #undef SDRHIP_SD_E
 #undef SDRHIP_SD_ATTR
 #undef SDRHIP_SD
@@ -1530,7 +1535,7 @@ void hot_launch_anyd_one(bool rot, int epi, const HotLaunch &hl, const HotArgs &
     case SDRHIP_EPI_FM: SDRHIP_ANYD(R_, SDRHIP_EPI_FM); break; \
     case SDRHIP_EPI_AM: SDRHIP_ANYD(R_, SDRHIP_EPI_AM); break; \
     case SDRHIP_EPI_USB: SDRHIP_ANYD(R_, SDRHIP_EPI_USB); break; \
-    case HOT_EPI_PARTIAL: SDRHIP_ANYD(R_, HOT_EPI_PARTIAL); break; \
+    case HOT_EPI_PARTIAL: if constexpr (IN != HOT_REAL) SDRHIP_ANYD(R_, HOT_EPI_PARTIAL); break; \
     default: SDRHIP_ANYD(R_, SDRHIP_EPI_NONE); break; } } while (0)
   if (rot) SDRHIP_ANYD_E(true); else SDRHIP_ANYD_E(false);
 #undef SDRHIP_ANYD_E

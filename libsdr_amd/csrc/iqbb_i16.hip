@@ -817,9 +817,11 @@ struct sdrhip_iqbb_i16 {
     if (path == 4) {
       // real input: TapT[m = (t, comp)][k] = K_comp[k - t] over the real sample stream (window of a block = OP - 1 + 16
       // elements, OP = 32S - 15), rows permuted as for path 1; lane (m = l&31, hh = l>>5), byte j of K step s <-> k = 32s+16hh+j
-      std::vector<int> kre(OP, 0), kim(OP, 0);
+      // (OPm: the window the matrix part covers; the plan's OP is the same at decimation 8 and the VALU kernel's at the others)
+      const int OPm = 32 * S - 15, padm = OPm - order;
+      std::vector<int> kre(OPm, 0), kim(OPm, 0);
       unsigned sre = 0, sim = 0;
-      for (int i = 0; i < order; i++) { kre[pad + i] = taps[2 * i]; kim[pad + i] = taps[2 * i + 1]; sre += (unsigned)taps[2 * i]; sim += (unsigned)taps[2 * i + 1]; }
+      for (int i = 0; i < order; i++) { kre[padm + i] = taps[2 * i]; kim[padm + i] = taps[2 * i + 1]; sre += (unsigned)taps[2 * i]; sim += (unsigned)taps[2 * i + 1]; }
       cre = (int)(128u * sre); cim = (int)(128u * sim);
       std::vector<int8_t> frag((size_t)S * 2 * 64 * 16, 0);
       for (int st = 0; st < S; st++)
@@ -829,7 +831,7 @@ struct sdrhip_iqbb_i16 {
             const int hC = (m >> 2) & 1, r = (m & 3) + 4 * (m >> 3);
             const int t = 8 * hC + (r >> 1), comp = r & 1;
             const int idx = 32 * st + 16 * hh + j - t;
-            const int v = (idx >= 0 && idx < OP) ? (comp ? kim[idx] : kre[idx]) : 0;
+            const int v = (idx >= 0 && idx < OPm) ? (comp ? kim[idx] : kre[idx]) : 0;
             const int al = ((v + 128) & 255) - 128, ah = (v - al) >> 8;
             frag[(((size_t)(2 * st) * 64 + l) * 16) + j] = (int8_t)ah;
             if (ah != 0) ah_mask |= 1u << st;
@@ -1019,15 +1021,17 @@ struct sdrhip_iqbb_i16 {
     const size_t nvwg = 4 * (size_t)ctx->prop.multiProcessorCount, rounds = ceil_div((size_t)C, nvwg);
     return (size_t)C * 100 >= rounds * nvwg * 97;
   }
+  bool real_anyd() const { return path == 4 && D != R; }   // real input at a decimation other than 8: the any-D forms of the hot kernel
+  int hot_kind() const { return real ? HOT_REAL : in_cu8 ? HOT_CU8 : HOT_CS16; }
   bool anyd_plan() const {
-    if (!(path == 3 && use_hot && hot_range >= 0 && S <= 17 && !i8 && !real)) return false;
+    if (!(((path == 3 && !i8 && !real) || real_anyd()) && use_hot && hot_range >= 0 && S <= 17)) return false;
     if (D >= 9 && D <= 512) return true;
-    // decimations 2 ... 7: the small-decimation form, where its sample arrays fit a workgroup's LDS (iqbb_hot.hpp, SD, hot_sd_nw)
-    return D >= 1 && D <= 7 && hot_launch_sd(S, in_cu8 ? HOT_CU8 : HOT_CS16, hot_range, inc != 0, epi, HotLaunch{0, nullptr}, HotArgs{}, IqbbArgs{}, true) != 0;
+    // decimations 1 ... 7: the small-decimation form, where its sample arrays fit a workgroup's LDS (iqbb_hot.hpp, SD, hot_sd_nw)
+    return D >= 1 && D <= 7 && hot_launch_sd(S, hot_kind(), hot_range, inc != 0, epi, HotLaunch{0, nullptr}, HotArgs{}, IqbbArgs{}, true) != 0;
   }
   bool launch_anyd_call(IqbbArgs &a, const Geometry &g, const uint32_t *in_dev, size_t N, size_t in_stride, void *out_dev,
                         size_t out_stride) {
-    const int kind = in_cu8 ? HOT_CU8 : HOT_CS16, halo = hot_halo(S, kind), win = hot_win(S, kind);
+    const int kind = hot_kind(), halo = hot_halo(S, kind), win = hot_win(S, kind);
     const int GS = 512 / D, OGh = 4 * GS;   // (no recomputed overlap group: FM's first angles come through philast)
     const int tiles_h = (int)ceil_div((size_t)g.n_groups, (size_t)OGh);
     // the hot slices of a channel are ONE range of slice numbers s = 4 * tile + w (slice_is_hot is monotone in s): every
@@ -1040,7 +1044,8 @@ struct sdrhip_iqbb_i16 {
     const int t_lo = s_lo >> 2, t_hi = (s_hi + 3) >> 2;
     HotArgs ha{};
     ha.in = in_dev; ha.in_stride = (long)in_stride; ha.out = out_dev; ha.out_stride = (long)out_stride;
-    ha.tapfrag = tapfrag_hot.p; ha.lut = lut.p; ha.inc = inc; ha.n0_lo = (uint32_t)(n0 - phase0); ha.negative = negative;
+    ha.tapfrag = real ? tapfrag.p : tapfrag_hot.p;   // (path 4's only set is the permuted one)
+    ha.lut = lut.p; ha.inc = inc; ha.n0_lo = (uint32_t)(n0 - phase0); ha.negative = negative;
     ha.base0_rel = g.base0_rel; ha.OG = OGh; ha.ovl = 0; ha.t_lo = t_lo; ha.t_hi = t_hi; ha.cre = cre; ha.cim = cim;
     ha.N = (int)N; ha.n_out = g.n_out; ha.C = C; ha.stamps = nullptr;
     ha.D = D; ha.GS = GS; ha.tiles_h = tiles_h;
@@ -1125,13 +1130,18 @@ struct sdrhip_iqbb_i16 {
     // MFMA path: one workgroup walks `tpw` consecutive tiles so that the tap fragments are fetched once;
     // keep >= ~8 workgroups per CU in flight for balance
     int tpw = 1;
-    if (path == 1 || path == 4) { tpw = 8; while (tpw > 1 && (size_t)ceil_div((size_t)tiles, (size_t)tpw) * C < 2048) tpw >>= 1; }
-    if (env_tpw && (path == 1 || path == 4)) tpw = env_tpw;   // tuning hook
+    const bool mf8 = path == 1 || (path == 4 && D == R);   // the lane-owned-group kernels (decimation 8)
+    if (mf8) { tpw = 8; while (tpw > 1 && (size_t)ceil_div((size_t)tiles, (size_t)tpw) * C < 2048) tpw >>= 1; }
+    if (env_tpw && mf8) tpw = env_tpw;   // tuning hook
     a.tiles = tiles; a.tpw = tpw; a.bt_hi = 0; a.fix_lo = a.fix_hi = 0;
     a.lpg = 1; while (a.lpg < 64 && a.lpg * 8 < D) a.lpg <<= 1;
     dim3 grid((unsigned)ceil_div((size_t)tiles, (size_t)tpw), C), block(TPB);
-    if (path == 4 && use_hot && hot_range >= 0 && tiles >= 3 && launch_hot_call(a, g, in_dev, N, in_stride, out_dev, out_stride, tiles)) {
+    if (path == 4 && D == R && use_hot && hot_range >= 0 && tiles >= 3 && launch_hot_call(a, g, in_dev, N, in_stride, out_dev, out_stride, tiles)) {
       // (real int16 input: the hot kernel took the whole call)
+    } else if (real_anyd() && anyd_plan() && launch_anyd_call(a, g, in_dev, N, in_stride, out_dev, out_stride)) {
+      // (real int16 input at any other decimation: the hot kernel's any-D / small-decimation form took the whole call)
+    } else if (real_anyd()) {   // ... its short calls: the VALU kernel
+      hipLaunchKernelGGL((iqbb_i16_kernel<false, true>), grid, block, lds_bytes, ctx->stream, a);
     } else if (path == 4) {
 #define SDRHIP_MFR(S_) do { if (inc != 0) hipLaunchKernelGGL((bb_real_mfma_kernel<S_, true>), grid, block, lds_bytes, ctx->stream, a); \
                              else hipLaunchKernelGGL((bb_real_mfma_kernel<S_, false>), grid, block, lds_bytes, ctx->stream, a); } while (0)
@@ -1272,14 +1282,16 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
                      decim, TI / (1 + ovl));
       h->bigd_always = beyond;
       // path 4: real input on the matrix cores — D == 8, at most 9 K steps, taps that fit two byte planes
-      if (real && !i8 && decim == R && order <= 273 && !(force && !strcmp(force, "valu"))) {
+      // ... at decimation 8 the lane-owned-group kernel; at any other up to 512 the hot kernel's any-D forms for the long calls
+      // and the VALU kernel for the short ones (src/baseband.hh:305-529: any sub_sample)
+      if (real && !i8 && (decim == R || (decim <= 512 && h->use_hot)) && order <= 273 && !(force && !strcmp(force, "valu"))) {
         bool fits = true;
         for (int i = 0; i < 2 * order && fits; i++) if (high_byte(taps[i]) > 127 || high_byte(-taps[i]) > 127) fits = false;   // (the rule set_taps applies)
         if (fits) h->path = 4;
       }
       if (h->path == 4) {
         h->S = order <= 81 ? 3 : order <= 145 ? 5 : 9;   // the hot kernel's filter-length classes (K steps of 32 real samples)
-        h->OP = 32 * h->S - 15;
+        h->OP = decim == R ? 32 * h->S - 15 : (int)ceil_div((size_t)order, (size_t)TAPC) * TAPC;   // (other decimations: the VALU kernel's tap chunks)
       } else if (h->path == 1 || h->path == 3) {
         h->S = order <= 17 ? 2 : order <= 33 ? 3 : order <= 65 ? 5 : order <= 129 ? 9 : 17;
         h->OP = 16 * (h->S - 1) + 1;
@@ -1287,10 +1299,14 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
         h->OP = (int)ceil_div((size_t)order, (size_t)TAPC) * TAPC;
       }
       h->HH = h->OP;   // one more than the FIR needs: reset(keep_history) must see the whole ring
+      if (h->path == 4) h->HH = std::max(h->OP, 32 * h->S - 15);   // (the hot kernel's window reaches 32 S - 16 samples back)
       h->CG = CG; h->ovl = ovl; h->OG = CG - ovl;
-      if (h->path == 1 || h->path == 4) { h->OG = 4 * (64 - ovl); h->CG = h->OG + ovl; }   // every wave recomputes its own FM overlap group
+      if (h->path == 1 || (h->path == 4 && decim == R)) { h->OG = 4 * (64 - ovl); h->CG = h->OG + ovl; }   // every wave recomputes its own FM overlap group
       h->fast8 = (decim == R);
-      if (h->path == 4) {
+      if (h->path == 4 && decim != R) {   // (the VALU kernel's: it runs this plan's short calls)
+        const size_t XS = TI + h->OP + 8;
+        h->lds_bytes = (XS + 256 + 2 * ((CG + 3) & ~3)) * 4 + (size_t)TI * 8;
+      } else if (h->path == 4) {
         h->lds_bytes = 1024 + (size_t)h->S * 2 * 64 * 16 + 4 * 2 * (size_t)(512 + 32 * h->S);
       } else if (h->path == 3) {
         const size_t PLW = (2 * (size_t)(TI + h->OP) + 64 + 31) / 32 * 8;
@@ -1318,7 +1334,7 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
         h->fm[p].alloc(channels); h->fm[p].zero(ctx->stream);
       }
       h->max_out = max_in / decim + 2;
-      if (epilogue == SDRHIP_EPI_FM && h->path == 3 && decim >= 1 && decim <= 512) {   // any-D hot forms: one angle per slice of the longest call (launch_anyd_call)
+      if (epilogue == SDRHIP_EPI_FM && (h->path == 3 || h->real_anyd()) && decim >= 1 && decim <= 512) {   // any-D hot forms: one angle per slice of the longest call (launch_anyd_call)
         const size_t GS = 512 / (size_t)decim, tiles_h = ceil_div(max_in / (size_t)decim + 2, 4 * GS);
         h->philast.alloc((size_t)channels * 4 * tiles_h + 1024);
 #ifdef K1_FM_HANDSHAKE
@@ -1389,7 +1405,12 @@ int sdrhip_iqbb_i16_kernel_names(sdrhip_iqbb_i16 *h, char *buf, size_t len) {
   return guarded([&] {
     SDRHIP_REQUIRE(h && buf && len, SDRHIP_E_INVALID, "NULL argument");
     const char *nm = "iqbb_i16_kernel";
-    if (h->path == 4 && h->use_hot && h->hot_range >= 0) nm = "iqbb_hot_kernel";   // (calls of < 3 tiles: the general kernel)
+    if (h->real_anyd() && !h->anyd_plan()) nm = "iqbb_i16_kernel";
+    else if (h->real_anyd()) {   // (calls of a few tiles: the VALU kernel)
+      nm = h->D < 8 ? "iqbb_hot_sd_kernel" : "iqbb_hot_anyd_kernel";
+      if (h->epi == SDRHIP_EPI_FM && !h->channel_units()) nm = h->D < 8 ? "iqbb_hot_sd_kernel,iqbb_fm_fixup_kernel" : "iqbb_hot_anyd_kernel,iqbb_fm_fixup_kernel";
+    }
+    else if (h->path == 4 && h->use_hot && h->hot_range >= 0) nm = "iqbb_hot_kernel";   // (calls of < 3 tiles: the general kernel)
     else if (h->path == 4) nm = "bb_real_mfma_kernel";
     else if (h->path == 3 && h->bigd_plan()) nm = h->channel_units() ? "iqbb_hot_anyd_kernel" : "iqbb_hot_anyd_kernel,iqbb_bigd_finish_kernel";   // (calls of a few tiles: the general kernel)
     else if (h->path == 3 && h->anyd_plan()) {   // (calls of a few tiles: the general kernel "iqbb_i16_mfmag_kernel")

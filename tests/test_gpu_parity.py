@@ -745,6 +745,48 @@ def test_bb_real_long_calls_vs_oracle(ctx, orc, epi, order, Fc, bbpath):
                 assert np.array_equal(y[c], r)
 
 
+BB_REAL_ANYD_CASES = [(127, 5, 100e3), (127, 20, 100e3), (127, 125, 100e3), (21, 125, -100e3), (33, 9, 41e3), (64, 62, 0.0), (81, 83, 100e3),
+                      (145, 300, -60e3), (146, 12, 100e3), (273, 45, 0.0), (200, 512, 100e3), (16, 257, 0.0), (100, 180, 70e3), (9, 181, 100e3),
+                      # decimations 1 ... 7: the small-decimation form (9 K steps WITHOUT a shift: its two sample arrays do not fit
+                      # the real-input kernel's 4-wave workgroup — the VALU kernel keeps that plan)
+                      (21, 1, 100e3), (127, 2, -60e3), (64, 3, 0.0), (81, 4, 100e3), (145, 6, 0.0), (200, 7, 100e3), (16, 5, 0.0), (273, 3, 0.0)]
+
+
+@pytest.mark.parametrize("epi,resident", [(sa.EPI_NONE, False), (sa.EPI_FM, False), (sa.EPI_FM, True), (sa.EPI_AM, False), (sa.EPI_USB, False)])
+@pytest.mark.parametrize("order,decim,Fc", BB_REAL_ANYD_CASES)
+def test_bb_real_any_decimation_long_calls_vs_oracle(ctx, orc, order, decim, Fc, epi, resident, monkeypatch):
+    """BaseBand<int16_t> takes any sub_sample (src/baseband.hh:305-529): up to 273 taps within two byte planes and decimations
+    up to 512 run the hot kernel's any-D / small-decimation forms on the matrix cores (the real-input tile hands every lane 8
+    consecutive samples, as the permuted complex tile does: one epilogue for both), the VALU kernel only the calls too
+    short to hold a hot tile. Ragged long and short calls, odd lengths (2-byte aligned windows), state carried."""
+    monkeypatch.delenv("SDRHIP_IQBB_HOT", raising=False)
+    monkeypatch.delenv("SDRHIP_IQBB_PATH", raising=False)
+    monkeypatch.setenv("SDRHIP_IQBB_FM_RESIDENT", "1" if resident else "0")
+    FSr, C = 1e6, 3
+    rng = np.random.default_rng(order * 1000 + decim + 7)
+    taps, lut, inc = orc.bb_design(abs(Fc) if Fc else 120e3, 60e3, FSr, order), orc.freqshift_lut_i16(), orc.freqshift_inc(Fc, FSr)
+    node = sa.BaseBandI16(ctx, taps, lut, inc, Fc < 0, decim, channels=C, max_in=70000, epilogue=epi)
+    assert node.path == 4
+    no_form = decim < 8 and order > 145 and Fc == 0.0
+    hot_name = "iqbb_hot_sd_kernel" if decim < 8 else "iqbb_hot_anyd_kernel"
+    expect = ["iqbb_i16_kernel"] if no_form else [hot_name] + (["iqbb_fm_fixup_kernel"] if epi == sa.EPI_FM and not resident else [])
+    assert node.kernel_names == expect
+    refs = [orc.BaseBandI16(taps, lut, inc, Fc < 0, decim) for _ in range(C)]
+    fms = [orc.FMDemodI16() for _ in range(C)]
+    for n in (65536, 70000, 12345, 1, 40001, 2 * decim + 1, 65535, 0, 33333):
+        x = rng.integers(-32768, 32768, (C, n), dtype=np.int16)
+        y = node.process(x)
+        for c in range(C):
+            r = refs[c].process(x[c])
+            if epi == sa.EPI_FM:
+                r = fms[c].process(r) if len(r) else np.zeros(0, np.int16)
+            elif epi == sa.EPI_AM:
+                r = orc.am_i16(r)
+            elif epi == sa.EPI_USB:
+                r = orc.usb_i16(r)
+            assert y[c].shape == r.shape and np.array_equal(y[c], r), (n, c)
+
+
 def test_bb_real_wide_taps_fall_back(ctx, orc):
     """Q16 taps beyond two byte planes (only very short filters reach 2^15) keep the VALU kernel — and stay bit-exact."""
     Fs = 1e6
