@@ -163,6 +163,12 @@ int sdrhip_iqbb_i16_path(sdrhip_iqbb_i16 *h, int *path);
  * second launch / inside the hot kernel; unset: by whether the channels deal evenly over the grid), SDRHIP_IQBB_BIGD_MIN=n
  * (exactly the decimations >= n, n >= 257, take the large-decimation form). None changes results. */
 int sdrhip_iqbb_i16_kernel_names(sdrhip_iqbb_i16 *h, char *buf, size_t len);
+/* The plan the handle runs, for measurement tools (bench.py prices the matrix work with it): info[0] = path (0 VALU kernel,
+ * 1 int8-MFMA at decimation 8, 3 int8-MFMA at any decimation, 4 real input on the matrix cores), info[1] = K steps S of 32
+ * plane bytes per 512-sample slice, info[2], info[3] = first step and number of steps that also multiply the taps' high byte
+ * plane, info[4] = waves per workgroup, info[5] = input kind (0 complex<int16>, 1 complex<uint8>, 2 real int16), info[6] =
+ * padded filter length, info[7] = history samples kept per channel. n >= 8. */
+int sdrhip_iqbb_i16_plan_info(sdrhip_iqbb_i16 *h, int *info, int n);
 /* outputs the next call of n_in samples will produce (does not advance the state) */
 int sdrhip_iqbb_i16_out_count(sdrhip_iqbb_i16 *h, size_t n_in, size_t *n_out);
 /* in: channels x n_in cs16 (row stride in_stride samples); out: channels rows of out_stride
@@ -171,6 +177,15 @@ int sdrhip_iqbb_i16_process(sdrhip_iqbb_i16 *h, const int16_t *in_host, size_t n
                             void *out_host, size_t out_stride, size_t *n_out);
 int sdrhip_iqbb_i16_process_dev(sdrhip_iqbb_i16 *h, const int16_t *in_dev, size_t n_in, size_t in_stride,
                                 void *out_dev, size_t out_stride, size_t *n_out);
+/* n_buffers consecutive reference-sized buffers of n_per_buffer samples per channel (row c of `in` holds them back to back,
+ * n_buffers * n_per_buffer <= max_in) in ONE launch, with the buffer boundaries kept: the outputs are exactly those of
+ * n_buffers successive sdrhip_iqbb_i16_process_dev calls written one behind the other into row c of `out` — the baseband's
+ * state runs on across buffers anyway (src/baseband.hh:198-219); the fused FMDemod starts every buffer anew (index 0 of a
+ * buffer's output is the in-place value, index 1 takes the previous buffer's last angle: src/demod.hh:242-254, SURVEY §7
+ * "the batched API must carry buffer boundaries"). One launch amortises the grid's ramp, the call's border slices and the
+ * state hand-over over n_buffers buffers. n_out_per_buffer (n_buffers entries) and n_out_total may be NULL. */
+int sdrhip_iqbb_i16_process_dev_multi(sdrhip_iqbb_i16 *h, const int16_t *in_dev, size_t n_buffers, size_t n_per_buffer, size_t in_stride,
+                                      void *out_dev, size_t out_stride, size_t *n_out_per_buffer, size_t *n_out_total);
 /* Input sample format ("next" row). SDRHIP_IN_CU8: the buffers hold complex<uint8_t> (2 B per
  * sample, e.g. RTL-SDR) and AutoCast< complex<int16_t> > (reference src/autocast.hh:62,187-194: each byte read
  * as int8, (int16(b)-127)<<8) is applied while loading, as examples/sdr_fm.cc:49-50 chains the two nodes.

@@ -91,6 +91,8 @@ def lib():
             "sdrhip_iqbb_i16_out_count": (C.c_int, [vp, sz, psz]),
             "sdrhip_iqbb_i16_process": (C.c_int, [vp, vp, sz, sz, vp, sz, psz]),
             "sdrhip_iqbb_i16_process_dev": (C.c_int, [vp, vp, sz, sz, vp, sz, psz]),
+            "sdrhip_iqbb_i16_plan_info": (C.c_int, [vp, C.POINTER(C.c_int), C.c_int]),
+            "sdrhip_iqbb_i16_process_dev_multi": (C.c_int, [vp, vp, sz, sz, sz, vp, sz, psz, psz]),
             "sdrhip_iqbb_i16_reset": (C.c_int, [vp, C.c_int]),
             "sdrhip_iqbb_i16_adopt_state": (C.c_int, [vp, vp, C.c_int]),
             "sdrhip_iqbb_i16_destroy": (C.c_int, [vp]),

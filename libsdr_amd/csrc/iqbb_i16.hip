@@ -725,6 +725,55 @@ __global__ void iqbb_fm_fixup_kernel(short *__restrict__ out, long out_stride, c
   row[sl * fix_gs] = (short)(row[sl * fix_gs] + philast[(long)c * philast_stride + sl - 1]);
 }
 
+// sdrhip_iqbb_i16_process_dev_multi with the FM epilogue: B reference-sized buffers went through ONE launch as one long call,
+// whose FM outputs are the differences of consecutive angles throughout. FMDemod (src/demod.hh:242-254) starts every buffer
+// anew: index 0 of a buffer's output is never written (in place it keeps the real part of the baseband's first value) and
+// index 1 is the PREVIOUS BUFFER's last angle minus the angle of element 1 — element 0's angle is never looked at. With
+// q = the long call's output index of a buffer's first element and L the long call's outputs (mod 2^16):
+//   out[q + 1] = phi(q - 1) - phi(q + 1) = L[q] + L[q + 1],     out[q] = Re(baseband output q),
+// the latter recomputed from the input the way the reference does: FIR at the group's D samples, >>14 (real input: >>16),
+// LUT rotation, box sum, truncating division. One workgroup per (boundary, channel): TL lanes share a sample's taps.
+struct MultiFix { int nb; int q[63]; };
+__global__ __launch_bounds__(256) void iqbb_fm_multi_fixup_kernel(const IqbbArgs a, const MultiFix f) {
+  __shared__ int2 part[256];
+  const int c = blockIdx.y, q = f.q[blockIdx.x], tid = threadIdx.x, D = a.D;
+  int TL = 1;   // (bounded: left open-ended the compiler derived a zero stride for the final sum and dropped the block behind it)
+  while (TL < 256 && 2 * TL * min(D, 256) <= 256) TL *= 2;
+  const int SB = 256 / TL, il = tid / TL, ts = tid - il * TL;   // samples per pass, this thread's sample and tap slice
+  const int first = a.base0_rel + q * D;                       // the group's first sample, call-relative (q >= 2: no carry, not the stream's first window)
+  int2 vsum = make_int2(0, 0);
+  for (int p0 = 0; p0 < D; p0 += SB) {
+    const int i = p0 + il, rel = first + i;
+    int er = 0, ei = 0;
+    if (i < D)
+      for (int k = ts; k < a.OP; k += TL) {
+        const uint32_t x = load_x(a, c, rel - (a.OP - 1) + k);
+        const uint2 kk = a.taps[k];
+        if (a.in_real) { er = (int)((unsigned)er + (unsigned)mulw((int)kk.x, (int)x)); ei = (int)((unsigned)ei + (unsigned)mulw((int)kk.y, (int)x)); }
+        else { er = dot2(x, kk.x, er); ei = dot2(x, kk.y, ei); }
+      }
+    part[tid] = make_int2(er, ei);
+    __syncthreads();
+    if (ts == 0 && i < D) {
+      for (int t = 1; t < TL; t++) { er = (int)((unsigned)er + (unsigned)part[tid + t].x); ei = (int)((unsigned)ei + (unsigned)part[tid + t].y); }
+      const int sh = a.in_real ? 16 : 14;
+      const int2 v = rotate(a, a.lut, make_int2(er >> sh, ei >> sh), a.n0_lo + (uint32_t)rel);
+      vsum.x = (int)((unsigned)vsum.x + (unsigned)v.x); vsum.y = (int)((unsigned)vsum.y + (unsigned)v.y);
+    }
+    __syncthreads();
+  }
+  part[tid] = vsum;
+  __syncthreads();
+  if (tid == 0) {
+    int sx = 0;
+    for (int t = 0; t < 256; t += TL) sx = (int)((unsigned)sx + (unsigned)part[t].x);
+    short *row = reinterpret_cast<short *>(a.out) + (long)c * a.out_stride;
+    const short l0 = row[q], l1 = row[q + 1];
+    row[q + 1] = (short)(l0 + l1);
+    row[q] = (short)box_div(sx, D);
+  }
+}
+
 // Decimations above 256 on the hot structure (iqbb_hot.hpp, PART), the stand-alone finishing launch: one lane per group
 // (bigd_finish_group, iqbb_common.hpp). Where whole channels are the hot kernel's units it runs the same function as its
 // workgroups' last step instead.
@@ -1018,7 +1067,7 @@ struct sdrhip_iqbb_i16 {
   // form: the groups, finished inside the hot kernel instead of by a second launch): where they deal evenly over the grid
   bool channel_units() const {
     if (env_fm_resident >= 0) return env_fm_resident != 0;   // tuning / test hook (SDRHIP_IQBB_FM_RESIDENT=0|1)
-    const size_t nvwg = 4 * (size_t)ctx->prop.multiProcessorCount, rounds = ceil_div((size_t)C, nvwg);
+    const size_t nvwg = (size_t)(env_wgpcu ? env_wgpcu : 4) * (size_t)ctx->prop.multiProcessorCount, rounds = ceil_div((size_t)C, nvwg);
     return (size_t)C * 100 >= rounds * nvwg * 97;
   }
   bool real_anyd() const { return path == 4 && D != R; }   // real input at a decimation other than 8: the any-D forms of the hot kernel
@@ -1066,7 +1115,7 @@ struct sdrhip_iqbb_i16 {
     int NW = ranges[std::min(hot_range, cnt - 1)].NW;
     if (D < 8) NW = hot_launch_sd(S, kind, hot_range, inc != 0, epi, HotLaunch{0, nullptr}, HotArgs{}, IqbbArgs{}, true);   // (the small-decimation form picks its own: hot_sd_nw)
     const int vper = NW / 4;
-    const int nvwg = 4 * ctx->prop.multiProcessorCount;
+    const int nvwg = (env_wgpcu ? env_wgpcu : 4) * ctx->prop.multiProcessorCount;   // (SDRHIP_IQBB_WGPCU: tuning hook — waves per SIMD)
     int htpw = 4; while (htpw > 1 && (size_t)ceil_div((size_t)tiles_h, (size_t)htpw) * C < 4 * (size_t)nvwg) htpw >>= 1;
     // FM: the slices whose first output is neither out[0] nor out[1] (their own rules) and is emitted lack the angle of the
     // slice before them. Where whole channels deal evenly over the persistent grid (within 3 %: 1024 or 8192 channels on 1024
@@ -1219,6 +1268,35 @@ struct sdrhip_iqbb_i16 {
     if (fm_flip) par_fm ^= 1;
     n0 += N;
     if (n_out) *n_out = (size_t)g.n_out;
+    last_args = a;
+  }
+  IqbbArgs last_args{};   // the argument block of the last launch (launch_multi's fix-up reads the same call)
+
+  // B consecutive buffers of nb samples per channel in one launch (sdrhip_iqbb_i16_process_dev_multi). IQBaseBand's own
+  // state runs on across buffers, so the baseband part IS one long call; the buffer boundaries are only visible to the FM
+  // demodulator (iqbb_fm_multi_fixup_kernel). Where a buffer would emit fewer than two values (FMDemod then leaves its
+  // angle untouched), with the int8 chain, or beyond 64 buffers: one launch per buffer, same results.
+  void launch_multi(const uint32_t *in_dev, size_t B, size_t nb, size_t in_stride, void *out_dev, size_t out_stride, size_t *counts, size_t *total) {
+    std::vector<size_t> qs(B + 1, 0);   // outputs in front of buffer j
+    for (size_t j = 1; j <= B; j++) qs[j] = (size_t)geometry(j * nb).n_out;
+    for (size_t j = 0; j < B && counts; j++) counts[j] = qs[j + 1] - qs[j];
+    if (total) *total = qs[B];
+    bool one_launch = B >= 2 && !i8 && B <= 64;
+    if (epi == SDRHIP_EPI_FM) for (size_t j = 0; j < B; j++) if (qs[j + 1] - qs[j] < 2) one_launch = false;
+    if (!one_launch) {
+      const size_t ib = in_elem_bytes(), ob = out_elem_bytes();
+      for (size_t j = 0; j < B; j++)
+        launch(reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(in_dev) + j * nb * ib), nb, in_stride,
+               reinterpret_cast<char *>(out_dev) + qs[j] * ob, out_stride, nullptr);
+      return;
+    }
+    launch(in_dev, B * nb, in_stride, out_dev, out_stride, nullptr);
+    if (epi != SDRHIP_EPI_FM) return;
+    MultiFix f{};
+    f.nb = (int)B - 1;
+    for (size_t j = 1; j < B; j++) f.q[j - 1] = (int)qs[j];
+    hipLaunchKernelGGL(iqbb_fm_multi_fixup_kernel, dim3((unsigned)(B - 1), (unsigned)C), dim3(256), 0, ctx->stream, last_args, f);
+    SDRHIP_CHECK_HIP(hipGetLastError());
   }
 };
 
@@ -1401,6 +1479,17 @@ int sdrhip_iqbb_i16_path(sdrhip_iqbb_i16 *h, int *path) {
   });
 }
 
+int sdrhip_iqbb_i16_plan_info(sdrhip_iqbb_i16 *h, int *info, int n) {
+  return guarded([&] {
+    SDRHIP_REQUIRE(h && info && n >= 8, SDRHIP_E_INVALID, "info must hold 8 ints");
+    int cnt = 0;
+    const HotRange *rg = hot_ranges(h->S, &cnt);
+    const bool hot = h->hot_range >= 0 && h->hot_range < cnt;
+    info[0] = h->path; info[1] = h->S; info[2] = hot ? rg[h->hot_range].S0 : 0; info[3] = hot ? rg[h->hot_range].NH : 0;
+    info[4] = hot ? rg[h->hot_range].NW : 4; info[5] = h->hot_kind(); info[6] = h->OP; info[7] = h->HH;
+  });
+}
+
 int sdrhip_iqbb_i16_kernel_names(sdrhip_iqbb_i16 *h, char *buf, size_t len) {
   return guarded([&] {
     SDRHIP_REQUIRE(h && buf && len, SDRHIP_E_INVALID, "NULL argument");
@@ -1447,6 +1536,31 @@ int sdrhip_iqbb_i16_process_dev(sdrhip_iqbb_i16 *h, const int16_t *in_dev, size_
     require_disjoint(in_dev, in_stride, n_in, h->in_elem_bytes(), out_dev, out_stride, (size_t)h->geometry(n_in).n_out,
                      h->out_elem_bytes(), (size_t)h->C);
     h->launch(reinterpret_cast<const uint32_t *>(in_dev), n_in, in_stride, out_dev, out_stride, n_out);
+  });
+}
+
+int sdrhip_iqbb_i16_process_dev_multi(sdrhip_iqbb_i16 *h, const int16_t *in_dev, size_t n_buffers, size_t n_per_buffer, size_t in_stride,
+                                      void *out_dev, size_t out_stride, size_t *n_out_per_buffer, size_t *n_out_total) {
+  return guarded([&] {
+    Range roctx_range("sdrhip_iqbb_i16_process_dev_multi");
+    SDRHIP_REQUIRE(h, SDRHIP_E_INVALID, "handle is NULL");
+    const size_t n_in = n_buffers * n_per_buffer;
+    SDRHIP_REQUIRE(n_buffers == 0 || n_in / n_buffers == n_per_buffer, SDRHIP_E_SIZE, "n_buffers * n_per_buffer overflows");
+    SDRHIP_REQUIRE(n_in <= h->max_in, SDRHIP_E_SIZE, "n_buffers * n_per_buffer = %zu > max_in %zu", n_in, h->max_in);
+    if (n_in == 0) {
+      for (size_t j = 0; j < n_buffers && n_out_per_buffer; j++) n_out_per_buffer[j] = 0;
+      if (n_out_total) *n_out_total = 0;
+      return;
+    }
+    SDRHIP_REQUIRE(in_dev && out_dev, SDRHIP_E_INVALID, "NULL buffer");
+    if (in_stride == 0) in_stride = n_in;
+    SDRHIP_REQUIRE(in_stride >= n_in, SDRHIP_E_SIZE, "in_stride %zu < n_buffers * n_per_buffer %zu", in_stride, n_in);
+    const size_t no = (size_t)h->geometry(n_in).n_out;
+    if (out_stride == 0) out_stride = no;
+    SDRHIP_REQUIRE(out_stride >= no, SDRHIP_E_SIZE, "out_stride %zu < outputs %zu", out_stride, no);
+    require_disjoint(in_dev, in_stride, n_in, h->in_elem_bytes(), out_dev, out_stride, no, h->out_elem_bytes(), (size_t)h->C);
+    h->ctx->use();
+    h->launch_multi(reinterpret_cast<const uint32_t *>(in_dev), n_buffers, n_per_buffer, in_stride, out_dev, out_stride, n_out_per_buffer, n_out_total);
   });
 }
 

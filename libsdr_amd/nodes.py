@@ -241,6 +241,13 @@ class IQBaseBandI16(_Node):
         check(abi.lib().sdrhip_iqbb_i16_kernel_names(self._h, b, 256))
         return b.value.decode().split(",")
 
+    @property
+    def plan_info(self):
+        """{path, S, S0, NH, NW, kind, OP, HH} of the plan (sdrhip.h: sdrhip_iqbb_i16_plan_info)."""
+        v = (C.c_int * 8)()
+        check(abi.lib().sdrhip_iqbb_i16_plan_info(self._h, v, 8))
+        return dict(zip(("path", "S", "S0", "NH", "NW", "kind", "OP", "HH"), list(v)))
+
     def out_count(self, n_in):
         n = C.c_size_t(0)
         check(abi.lib().sdrhip_iqbb_i16_out_count(self._h, n_in, C.byref(n)))
@@ -270,6 +277,40 @@ class IQBaseBandI16(_Node):
         check(abi.lib().sdrhip_iqbb_i16_process_dev(self._h, C.c_void_p(in_ptr), n_in, in_stride, C.c_void_p(out_ptr),
                                                     out_stride, C.byref(got)))
         return got.value
+
+    def process_dev_multi(self, in_ptr, n_buffers, n_per_buffer, in_stride, out_ptr, out_stride):
+        """n_buffers consecutive buffers per channel in ONE launch, buffer boundaries kept (sdrhip.h); returns the output
+        counts per buffer (their outputs follow one another in each channel's row)."""
+        counts = (C.c_size_t * max(1, n_buffers))()
+        total = C.c_size_t(0)
+        check(abi.lib().sdrhip_iqbb_i16_process_dev_multi(self._h, C.c_void_p(in_ptr), n_buffers, n_per_buffer, in_stride, C.c_void_p(out_ptr),
+                                                          out_stride, counts, C.byref(total)))
+        assert sum(counts[:n_buffers]) == total.value
+        return list(counts[:n_buffers])
+
+    def process_multi(self, x, n_buffers):
+        """Host arrays through process_dev_multi: x = [channels, n_buffers * n_per_buffer(, 2)]; returns (rows, counts) — the
+        concatenated outputs of the buffers per channel and the output count of each buffer."""
+        real = x.ndim == 2 and not getattr(self, "_cu8", False) and isinstance(self, BaseBandI16)
+        x = np.ascontiguousarray(x, np.int16) if real else _as3(x, np.uint8 if getattr(self, "_cu8", False) else np.int16)
+        assert x.shape[0] == self.channels and x.shape[1] % n_buffers == 0
+        n_in, nb = x.shape[1], x.shape[1] // n_buffers
+        no = self.out_count(n_in)
+        out = np.zeros((self.channels, no, 2) if self.epilogue == EPI_NONE else (self.channels, no), np.int16)
+        counts = []
+        run = lambda i, si, o, so: counts.extend(self.process_dev_multi(i, n_buffers, nb, si, o, so))
+        if device_router is not None:
+            device_router(self.ctx, x, out, run)
+        else:
+            din, dout = self.ctx.malloc(max(x.nbytes, 16)), self.ctx.malloc(max(out.nbytes, 16))
+            try:
+                self.ctx.h2d(din, x); self.ctx.h2d(dout, out)
+                run(din, n_in, dout, no)
+                self.ctx.synchronize()
+                self.ctx.d2h(out, dout)
+            finally:
+                self.ctx.free(din); self.ctx.free(dout)
+        return out, counts
 
     def reset(self, keep_history=False, keep_fm=False):
         check(abi.lib().sdrhip_iqbb_i16_reset(self._h, int(bool(keep_history)) | (2 if keep_fm else 0)))

@@ -46,6 +46,7 @@ def lib():
             "orc_iqbb_i16_process": (C.c_size_t, [vp, i16p, C.c_size_t, i16p]),
             "orc_iqbb_i16_reset": (None, [vp]),
             "orc_iqbb_i16_seek": (C.c_int, [vp, C.c_uint64]),
+            "orc_bb_i16_seek": (C.c_int, [vp, C.c_uint64]),
             "orc_freqshift_lut_i8": (None, [C.POINTER(C.c_int32)]),
             "orc_iqbb_i8_create": (vp, [C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32), C.c_uint32, C.c_int, C.c_int]),
             "orc_iqbb_i8_process": (C.c_size_t, [vp, C.POINTER(C.c_int8), C.c_size_t, C.POINTER(C.c_int8)]),
@@ -309,6 +310,12 @@ class BaseBandI16:
 
     def reset(self):
         lib().orc_bb_i16_reset(self._h)
+
+    def seek(self, abs_index):
+        """Test-bench helper: decimator and LUT phase as they stand in front of absolute sample `abs_index` = g*D; the ring
+        is kept — prime it with the `order` samples before that index first."""
+        if lib().orc_bb_i16_seek(self._h, int(abs_index)) != 0:
+            raise ValueError("seek: %d is not a group boundary (g*D)" % abs_index)
 
     def set_shift(self, lut_inc, negative):
         lib().orc_bb_i16_set_shift(self._h, lut_inc, int(negative))

@@ -718,6 +718,20 @@ static int bench(const std::string &chain, size_t nbuf, size_t N) {
   } else if (chain == "fir127_fm") {
     FIRLowPass<cs16> fir(127, 100e3); FMDemod<int16_t> fm; fir.connect(&fm, true);
     RUN_I16(fir, fm, int16_t)
+  } else if (chain == "fir127_fm_queue") {
+    // BASELINE config 1 as written: the reference's IQSigGen driven by the Queue's idle signal, its buffers travelling through the
+    // Queue (a queued edge) into FIRLowPass<cs16>(127) -> FMDemod (direct edges) — examples/sdr_fm.cc:49-53's plumbing with the
+    // signal generator in the RTL source's place (src/queue.cc:83-125, src/siggen.hh:116-133). The generator's own synthesis
+    // (two complex exponentials per sample in double) is part of what the Queue thread does, as in the reference's examples.
+    IQSigGen<int16_t> gen(Fs, N, double(nbuf * N) / Fs - 0.5 / Fs);
+    gen.addSine(100e3, 0.5, 0.0); gen.addSine(-300e3, 0.4, 0.3);
+    FIRLowPass<cs16> fir(127, 100e3); FMDemod<int16_t> fm; Capture<int16_t> cap; cap.keep = false;
+    gen.connect(&fir); fir.connect(&fm, true); fm.connect(&cap, true);
+    Queue::get().addIdle(&gen, &IQSigGen<int16_t>::next);
+    t0 = std::chrono::steady_clock::now();
+    Queue::get().start(); Queue::get().wait();
+    t1 = std::chrono::steady_clock::now(); total_out = cap.total;
+    nbuf = total_out / N;
   } else if (chain == "fir255_fm") {
     FIRLowPass<cs16> fir(255, 100e3); FMDemod<int16_t> fm; fir.connect(&fm, true);
     RUN_I16(fir, fm, int16_t)

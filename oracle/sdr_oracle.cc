@@ -715,6 +715,17 @@ void orc_bb_i16_set_shift(void *h, uint32_t inc, int negative) {
   RBB *s = (RBB *)h; s->inc = inc; s->negative = negative; s->lut_count = 0;
 }
 
+// test-bench helper (as orc_iqbb_i16_seek): decimator and LUT phase as they stand in front of absolute sample abs_index = g*D
+// (right behind an emission: the real node closes its first window after D samples); the ring is kept
+int orc_bb_i16_seek(void *h, uint64_t abs_index) {
+  RBB *s = (RBB *)h;
+  const uint64_t D = (uint64_t)s->decim;
+  if (D < 1 || abs_index % D != 0) return -1;
+  s->count = 0; s->last = C32{0, 0};
+  s->lut_count = (size_t)((abs_index % 32768u) * (uint64_t)(s->inc % 32768u) % 32768u);
+  return 0;
+}
+
 size_t orc_bb_i16_process(void *h, const int16_t *in, size_t n, int16_t *out) {
   RBB *s = (RBB *)h;
   const size_t order = (size_t)s->order, D = (size_t)s->decim;

@@ -111,6 +111,7 @@ void orc_bb_design(double Ff, double width, double Fs, int order, int32_t *taps)
 void *orc_bb_i16_create(const int32_t *taps, int order, const int32_t *lut, uint32_t lut_inc, int negative, int decim);
 size_t orc_bb_i16_process(void *h, const int16_t *in /* n real */, size_t n, int16_t *out /* cs16 */);
 void orc_bb_i16_reset(void *h);
+int orc_bb_i16_seek(void *h, uint64_t abs_index);   /* test bench: decimator / LUT phase in front of sample g*D; ring kept */
 void orc_bb_i16_set_shift(void *h, uint32_t lut_inc, int negative);   /* setFrequencyShift: increment, sign, LUT phase = 0 */
 void orc_bb_i16_destroy(void *h);
 

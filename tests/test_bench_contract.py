@@ -24,8 +24,11 @@ def test_bench_json_contract():
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "i16" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     rf = d["roofline"]
-    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    # `bound` names what limits the kernel (the headline's 127-tap plan: the socket's power limit at the matrix pipe); achieved / peak /
+    # frac stay the HBM figures the contract asks for, and `compute` prices the limiting pipe against its own peak
+    assert rf["bound"] == "power/mfma" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and rf["achieved"] > 0
+    assert rf["compute"]["unit"] == "TOPS int8 MFMA" and 0 < rf["compute"]["frac"] < 1 and rf["compute"]["mfma_per_slice"] == 28
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
 
@@ -204,15 +207,25 @@ def test_default_line_carries_every_baseline_config():
                 "--verify-channels", "4"])
     assert d["verified"] is True and d["preconditioned_s"] >= 0.2 and d["roofline"]["sustained_ms_per_launch"] > 0
     ids = [e["id"] for e in d["configs"]]
-    assert ids == ["config2_c1", "config2_c1024", "config3", "config4_i_ola8192", "config4_ii_ols4097", "config5_g1", "sdr_fm_plan"]
+    assert ids == ["config1", "config2_c1", "config2_c1024", "config3", "config4_i_ola8192", "config4_ii_ols4097", "config5_g1", "sdr_fm_plan",
+                   "bb_real_d20", "multi_buffer"]
+    bounds = {"config1": "fp64-issue", "config2_c1": "hbm", "config2_c1024": "hbm", "config3": "fp64-issue", "config4_i_ola8192": "lds/issue",
+              "config4_ii_ols4097": "lds/issue", "config5_g1": "power/mfma", "sdr_fm_plan": "valu-issue", "bb_real_d20": "valu-issue",
+              "multi_buffer": "power/mfma"}
     for e in d["configs"]:
         assert "error" not in e, e
         assert e["verified"] is True, e
-        assert e["value"] > 0 and e["ms_per_step"] > 0 and e["workload_key"]
+        assert e["value"] > 0 and e["ms_per_step"] > 0 and e["key"]
         rf = e["roofline"]
-        assert rf["kernel"] and rf["algorithmic_bytes_per_sample"] > 0 and 0 < rf["frac"] < 1
-        assert e["cpu_baseline"]["value"] > 0 and e["cpu_baseline"]["kind"] in ("reference", "port")
-    assert d["configs"][0]["roofline"]["per_buffer_us"] > 0
+        assert rf["kernel"] and 0 < rf["frac"] < 1 and rf["bound"] == bounds[e["id"]]
+        if e["id"] != "bb_real_d20":   # (no reference chain is compiled for that plan)
+            assert e["cpu"]["value"] > 0 and e["cpu"]["kind"] in ("reference", "port")
+    by = {e["id"]: e for e in d["configs"]}
+    assert by["config2_c1"]["roofline"]["per_buffer_us"] > 0
+    assert by["config5_g1"]["with_h2d_ms_per_step"] > by["config5_g1"]["ms_per_step"] and by["config5_g1"]["with_h2d_pcie_gbs"] > 0
+    assert by["multi_buffer"]["key"].endswith("/B4/C16/N131072") and by["multi_buffer"]["roofline"]["kernels_per_step"][-1] == "iqbb_fm_multi_fixup_kernel"
+    assert by["config3"]["roofline"]["compute"]["unit"].startswith("T fp64")
+    assert len(json.dumps(d)) < 7700   # (the driver keeps the last 8 KB of stdout: the whole line must fit)
     lim = d["cpu_baseline"]["all_cores"]["limits"]
     assert lim["cpus_in_affinity_mask"] >= 1 and "cgroup_quota_cores" in lim
 

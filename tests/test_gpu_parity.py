@@ -745,6 +745,80 @@ def test_bb_real_long_calls_vs_oracle(ctx, orc, epi, order, Fc, bbpath):
                 assert np.array_equal(y[c], r)
 
 
+MULTI_CASES = [("cs16", 127, 8, 100e3), ("cs16", 21, 8, -100e3), ("cu8", 21, 125, 100e3), ("cs16", 16, 83, 0.0), ("cs16", 33, 5, 70e3),
+               ("cu8", 64, 600, 41e3), ("cs16", 255, 20, 100e3), ("real", 127, 8, 100e3), ("real", 127, 20, -60e3), ("real", 33, 5, 0.0),
+               ("cs16", 16, 1, 50e3), ("cs16", 300, 8, 100e3)]
+
+
+@pytest.mark.parametrize("epi", [sa.EPI_NONE, sa.EPI_FM, sa.EPI_AM, sa.EPI_USB])
+@pytest.mark.parametrize("kind,order,decim,Fc", MULTI_CASES)
+def test_iqbb_multi_buffer_call_equals_separate_calls(ctx, orc, kind, order, decim, Fc, epi):
+    """sdrhip_iqbb_i16_process_dev_multi: B reference-sized buffers per channel in ONE launch, buffer boundaries kept — the
+    outputs are those of B successive calls (FMDemod starts every buffer anew: index 0 in place, index 1 from the previous
+    buffer's last angle, src/demod.hh:242-254), against the ORACLE fed buffer by buffer; then the stream goes on with
+    ordinary calls (state handed over), and with multi calls whose buffers are too short for one launch (fallback)."""
+    FSr, C = 1e6, 3
+    rng = np.random.default_rng(order * 31 + decim)
+    real, cu8 = kind == "real", kind == "cu8"
+    lut, inc = orc.freqshift_lut_i16(), orc.freqshift_inc(Fc, FSr)
+    if real:
+        taps = orc.bb_design(abs(Fc) if Fc else 120e3, 60e3, FSr, order)
+        node = sa.BaseBandI16(ctx, taps, lut, inc, Fc < 0, decim, channels=C, max_in=70000, epilogue=epi)
+        refs = [orc.BaseBandI16(taps, lut, inc, Fc < 0, decim) for _ in range(C)]
+    else:
+        taps = orc.iqbb_design(abs(Fc) if Fc else 100e3, 12.5e3, FSr, order)
+        node = sa.IQBaseBandI16(ctx, taps, lut, inc, Fc < 0, decim, channels=C, max_in=70000, epilogue=epi)
+        if cu8:
+            node.set_input_format(sa.abi.IN_CU8)
+        refs = [orc.IQBaseBandI16(taps, lut, inc, Fc < 0, decim) for _ in range(C)]
+    fms = [orc.FMDemodI16() for _ in range(C)]
+
+    def gen(n):
+        if real:
+            return rng.integers(-32768, 32768, (C, n), dtype=np.int16)
+        return rng.integers(0, 256, (C, n, 2), dtype=np.uint8) if cu8 else rng.integers(-32768, 32768, (C, n, 2), dtype=np.int16)
+
+    def ref_buffer(c, xb):
+        r = refs[c].process(orc.autocast_cu8_cs16(xb) if cu8 else xb)
+        if epi == sa.EPI_FM:
+            return fms[c].process(r) if len(r) else np.zeros(0, np.int16)
+        return orc.am_i16(r) if epi == sa.EPI_AM else orc.usb_i16(r) if epi == sa.EPI_USB else r
+
+    # (B, n_per_buffer): four reference-sized buffers; odd sizes (groups straddle the boundaries); an ordinary call in between;
+    # buffers too short for FM's two-output rule (one launch per buffer inside the library); one buffer
+    for B, nb in ((4, 16384), (3, 23333), (0, 5000), (5, 2 * decim + 3), (7, max(1, decim // 2)), (1, 30000), (2, 35000)):
+        if B == 0:
+            x = gen(nb)
+            y = node.process(x)
+            for c in range(C):
+                r = ref_buffer(c, x[c])
+                assert y[c].shape == r.shape and np.array_equal(y[c], r)
+            continue
+        x = gen(B * nb)
+        y, counts = node.process_multi(x, B)
+        for c in range(C):
+            rs = [ref_buffer(c, x[c, j * nb:(j + 1) * nb]) for j in range(B)]
+            assert counts == [len(r) for r in rs], (B, nb, counts)
+            r = np.concatenate(rs) if rs else np.zeros(0, np.int16)
+            assert y[c].shape == r.shape, (B, nb, c)
+            if not np.array_equal(y[c], r):
+                bad = np.flatnonzero((y[c] != r).reshape(len(r), -1).any(axis=1))
+                raise AssertionError("multi call B=%d nb=%d channel %d: %d outputs differ, first at %d (buffer starts %s)"
+                                     % (B, nb, c, bad.size, bad[0], np.cumsum([0] + counts).tolist()))
+
+
+@pytest.mark.parametrize("demod", ["fm", "am", "usb"])
+def test_iqbb_multi_buffer_golden(ctx, golden, demod):
+    """g4: the reference's own IQBaseBand<int16>(127, /8) -> FMDemod / AMDemod / USBDemod output of four 4096-sample buffers,
+    through ONE multi-buffer call."""
+    epi = {"fm": sa.EPI_FM, "am": sa.EPI_AM, "usb": sa.EPI_USB}[demod]
+    m, node = iqbb_from_case(ctx, golden, "g4_iqbb127d8", "_" + demod, epi, max_in=16384)
+    assert m["in_lens"] == [4096] * 4
+    y, counts = node.process_multi(golden.load("g1_iq_cs16")[:16384][None], 4)
+    assert counts == m["out_lens"]
+    assert np.array_equal(y[0], golden.load("g4_iqbb127d8_" + demod))
+
+
 BB_REAL_ANYD_CASES = [(127, 5, 100e3), (127, 20, 100e3), (127, 125, 100e3), (21, 125, -100e3), (33, 9, 41e3), (64, 62, 0.0), (81, 83, 100e3),
                       (145, 300, -60e3), (146, 12, 100e3), (273, 45, 0.0), (200, 512, 100e3), (16, 257, 0.0), (100, 180, 70e3), (9, 181, 100e3),
                       # decimations 1 ... 7: the small-decimation form (9 K steps WITHOUT a shift: its two sample arrays do not fit
