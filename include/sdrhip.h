@@ -268,7 +268,10 @@ int sdrhip_fir_process_dev(sdrhip_fir *h, const void *in_dev, size_t n_in, size_
                            size_t out_stride, size_t *n_out);
 /* A complex<float> plan with decim = 1 and no epilogue (FIRLowPass<complex<float>>) runs as overlap-save FFT convolution on the
  * tuned FFT kernels behind this handle — a tolerance path either way (<= 1e-5), 6x faster at 127 taps and 130x at 4097 than
- * `order` multiply-adds per sample; SDRHIP_FIR_TIME_DOMAIN=1 in the environment keeps the time-domain kernel (tests).
+ * `order` multiply-adds per sample; SDRHIP_FIR_TIME_DOMAIN=1 in the environment keeps the time-domain kernel (tests). Below the
+ * measured crossover — up to 32 taps on plans of at most 2^18 samples per call (channels x max_in) — the time-domain kernel stays
+ * (a block transform costs a call 7 us however little it filters). On an FFT-backed plan sdrhip_fir_set_taps SYNCHRONISES the
+ * context's stream (the new kernel spectrum is transformed and swapped in before it returns); on the others it is stream-ordered.
  * New coefficients for the SAME order between calls: FIRFilter::setLowerFreq / setUpperFreq (FIRLowPass::setFreq) only
  * recompute _alpha — the ring, and with it the stream, goes on (reference src/firfilter.hh:155-170,287). `alpha`: order doubles. */
 int sdrhip_fir_set_taps(sdrhip_fir *h, const double *alpha);
@@ -365,7 +368,7 @@ int sdrhip_fftconv_destroy(sdrhip_fftconv *h);
  * An OLA plan whose fft_size = 2N is not one of the tuned powers of two does not have to transform 2N points at all: its
  * result is the N-tap convolution whatever evaluates it, so it runs as overlap-save with the same N taps (the first N points
  * of the spectrum's inverse DFT, taken on the host in double) on the power of two that costs least per output — provided N
- * leaves such a block a quarter of its points (N <= 12288; 6144 in double). FilterNode<float>(1000), (1009), (12000) run the
+ * leaves such a block a quarter of its points (N <= 12289; 6144 in double). FilterNode<float>(1000), (1009), (12000) run the
  * tuned kernels that way — and so does a single band on a power of two other than 2048 (half of every 2N-point block is
  * overlap, a longer block keeps up to 7/8 of its points); filter banks and the 2048-point plan keep their own transform.
  * SDRHIP_FFTCONV_LITERAL=1 in the environment keeps the 2N-point transform everywhere (tests).

@@ -80,15 +80,29 @@ struct sdrhip_comm {
   bool slot_used[kSlots] = {false, false, false, false};
   void make_side() {
     if (!side.empty()) return;
+    // built aside and swapped in only when every stream and event exists: a creation that throws half-way must not leave
+    // `side` non-empty with null handles (the next gather_begin would skip this and issue on the null stream)
     const size_t n = ctx.size();
-    side.resize(n); ready.resize(n);
-    for (int k = 0; k < kSlots; k++) done[k].resize(n);
-    for (size_t r = 0; r < n; r++) {
-      ctx[r]->use();
-      SDRHIP_CHECK_HIP(hipStreamCreateWithFlags(&side[r], hipStreamNonBlocking));
-      SDRHIP_CHECK_HIP(hipEventCreateWithFlags(&ready[r], hipEventDisableTiming));
-      for (int k = 0; k < kSlots; k++) SDRHIP_CHECK_HIP(hipEventCreateWithFlags(&done[k][r], hipEventDisableTiming));
+    std::vector<hipStream_t> s(n, nullptr);
+    std::vector<hipEvent_t> rd(n, nullptr), dn[kSlots];
+    for (int k = 0; k < kSlots; k++) dn[k].assign(n, nullptr);
+    try {
+      for (size_t r = 0; r < n; r++) {
+        ctx[r]->use();
+        SDRHIP_CHECK_HIP(hipStreamCreateWithFlags(&s[r], hipStreamNonBlocking));
+        SDRHIP_CHECK_HIP(hipEventCreateWithFlags(&rd[r], hipEventDisableTiming));
+        for (int k = 0; k < kSlots; k++) SDRHIP_CHECK_HIP(hipEventCreateWithFlags(&dn[k][r], hipEventDisableTiming));
+      }
+    } catch (...) {
+      for (size_t r = 0; r < n; r++) {
+        if (s[r]) (void)hipStreamDestroy(s[r]);
+        if (rd[r]) (void)hipEventDestroy(rd[r]);
+        for (int k = 0; k < kSlots; k++) if (dn[k][r]) (void)hipEventDestroy(dn[k][r]);
+      }
+      throw;
     }
+    side.swap(s); ready.swap(rd);
+    for (int k = 0; k < kSlots; k++) done[k].swap(dn[k]);
   }
 };
 

@@ -275,11 +275,9 @@ __global__ void chirp_out_kernel(int n, long M, int conj, const T2 *w, const T2 
   }
 }
 
+// (a kernel's dynamic-LDS limit: allow_lds_max, sdrhip_internal.hpp — once per kernel and device, to the hardware's maximum)
 template <class K>
-inline void allow_lds(K kernel, size_t bytes) {
-  if (bytes > 64 * 1024)
-    SDRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-}
+inline void allow_lds(K kernel, size_t bytes) { allow_lds_max(kernel, bytes); }
 
 template <class T2>
 struct AnyFft {

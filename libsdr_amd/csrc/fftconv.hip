@@ -801,10 +801,7 @@ struct FftPlan {
 inline bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
 template <class K>
-void allow_big_lds(K kernel, size_t bytes) {
-  if (bytes > 64 * 1024)
-    SDRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-}
+void allow_big_lds(K kernel, size_t bytes) { allow_lds_max(kernel, bytes); }   // (once per kernel and device, to the hardware's maximum)
 
 // The general plan (fftgen.hpp) behind the same handle: any FFT size made of the factors 2 ... 13 in complex<float>, and
 // every size in complex<double> (FilterNode<double>, FFTPlan<double>). Same overlap-save evaluation, same state rules.
@@ -988,6 +985,8 @@ struct BigConv : ConvAny {
       Y.alloc((size_t)B * group * nblk * L);
       fft.reserve((long)((size_t)B * group * nblk));
     } else {
+      // (the gather / scatter kernels take one block per grid.y entry: a small awkward size with a long max_in must not run past it)
+      SDRHIP_REQUIRE(nblk <= 65535, SDRHIP_E_UNSUPPORTED, "%zu blocks per call exceed one launch's grid: lower max_in", nblk);
       group = (int)std::max<size_t>(1, std::min<size_t>((size_t)C, kScratchBytes / (2 * nblk * (size_t)L * sizeof(T2))));
       group = std::min(group, 65535);
       X.alloc((size_t)group * nblk * L); Y.alloc((size_t)group * nblk * L);

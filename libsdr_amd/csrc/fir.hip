@@ -858,7 +858,11 @@ int fir_create_impl(sdrhip_ctx *ctx, int kind, const double *alpha, int order, i
           h->hist16[p].alloc((size_t)channels * h->HH); h->hist16[p].zero(ctx->stream);
           h->fm[p].alloc(channels); h->fm[p].zero(ctx->stream);
         }
-      } else if (allow_fft && decim == 1 && epilogue == SDRHIP_EPI_NONE && !(getenv("SDRHIP_FIR_TIME_DOMAIN") && getenv("SDRHIP_FIR_TIME_DOMAIN")[0] != '0')) {
+      } else if (allow_fft && decim == 1 && epilogue == SDRHIP_EPI_NONE && !(getenv("SDRHIP_FIR_TIME_DOMAIN") && getenv("SDRHIP_FIR_TIME_DOMAIN")[0] != '0') &&
+                 // measured crossover (tools/probes/fir_cf32_small.py, profiles/r18_fir_cf32_small.txt): a block transform costs a call
+                 // 7 us however little it filters — up to 32 taps on plans of at most 2^18 samples per call the time-domain kernel
+                 // is the faster one (4.6 - 6.8 us); everywhere else the FFT plan wins (127 taps: 7 against 14 us on ONE channel)
+                 (order > 32 || (size_t)channels * max_in > ((size_t)1 << 18) || getenv("SDRHIP_FIR_FFT_ALWAYS"))) {
         const std::vector<float> t = fir_fft_taps(alpha, order);
         const int rc = sdrhip_fftconv_create(ctx, SDRHIP_FFTCONV_OLS, fir_fft_size(order), t.data(), order, channels, max_in, &h->fftc);
         if (rc != SDRHIP_OK) throw Failure{rc};
@@ -879,7 +883,7 @@ int fir_create_impl(sdrhip_ctx *ctx, int kind, const double *alpha, int order, i
           const void *fns[7] = {(const void *)fir_cf32_rt_kernel<4, 8>, (const void *)fir_cf32_rt_kernel<4, 0>, (const void *)fir_cf32_rt_kernel<2, 8>,
                                 (const void *)fir_cf32_rt_kernel<2, 0>, (const void *)fir_cf32_rt_kernel<1, 0>,
                                 (const void *)fir_cf32_pipe_kernel<4, 8>, (const void *)fir_cf32_pipe_kernel<2, 8>};
-          for (int k = 0; k < 7; k++) SDRHIP_CHECK_HIP(hipFuncSetAttribute(fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds3));
+          for (int k = 0; k < 7; k++) allow_lds_max(fns[k], h->lds3);   // (once per kernel and device, to the hardware's maximum)
         }
         h->beta.alloc(h->M);
         h->betap.alloc((size_t)h->M + 2 * (size_t)(h->R - 1) * decim + 16);

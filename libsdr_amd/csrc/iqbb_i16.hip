@@ -846,7 +846,6 @@ struct sdrhip_iqbb_i16 {
   // D = 470 (21 taps, complex<uint8>, FM: ÷257 0.120 -> 0.080 ms per step, ÷300 0.105 -> 0.078, ÷400 0.085 -> 0.077, ÷480 0.075 / 0.076,
   // ÷512 0.072 / 0.075). SDRHIP_IQBB_BIGD_MIN=n (tests, A/B): exactly the decimations >= n take the large-decimation form.
   int bigd_min = 257, bigd_skip_lo = 465;   // (default: 257 ... 464 and 513 ...)
-  bool mfmag_attr_set = false;              // the general any-D kernel's dynamic-LDS limit raised (plans beyond 64 KB)
   bool bigd_always = false;                 // every call, however short, through the large-decimation form (its cold path serves any slice)
 
 
@@ -1213,11 +1212,9 @@ struct sdrhip_iqbb_i16 {
                              else if (in_cu8) hipLaunchKernelGGL((iqbb_i16_mfmag_kernel<S_, false, true>), grid3, block, lds_bytes, ctx->stream, a); \
                              else if (inc != 0) hipLaunchKernelGGL((iqbb_i16_mfmag_kernel<S_, true, false>), grid3, block, lds_bytes, ctx->stream, a); \
                              else hipLaunchKernelGGL((iqbb_i16_mfmag_kernel<S_, false, false>), grid3, block, lds_bytes, ctx->stream, a); } while (0)
-      if (lds_bytes > 64 * 1024 && !mfmag_attr_set) {   // (17 K steps, small decimations: once per plan)
-#define SDRHIP_MFG_ATTR(R_, C_) SDRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&iqbb_i16_mfmag_kernel<17, R_, C_>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024))
-        SDRHIP_MFG_ATTR(true, true); SDRHIP_MFG_ATTR(false, true); SDRHIP_MFG_ATTR(true, false); SDRHIP_MFG_ATTR(false, false);
-#undef SDRHIP_MFG_ATTR
-        mfmag_attr_set = true;
+      if (lds_bytes > 64 * 1024) {   // (17 K steps, small decimations; once per kernel and device: allow_lds_max)
+        allow_lds_max(&iqbb_i16_mfmag_kernel<17, true, true>, lds_bytes); allow_lds_max(&iqbb_i16_mfmag_kernel<17, false, true>, lds_bytes);
+        allow_lds_max(&iqbb_i16_mfmag_kernel<17, true, false>, lds_bytes); allow_lds_max(&iqbb_i16_mfmag_kernel<17, false, false>, lds_bytes);
       }
       switch (S) {
         case 2: SDRHIP_MFG(2); break;

@@ -8,6 +8,9 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
+#include <set>
+#include <utility>
 #include <new>
 #include <string>
 #include <vector>
@@ -117,6 +120,28 @@ void copy_d2h_rows(const sdrhip_ctx *ctx, void *dst_host, size_t dst_pitch_b, co
                    size_t src_pitch_b, size_t row_bytes, size_t rows);
 
 static inline size_t ceil_div(size_t a, size_t b) { return (a + b - 1) / b; }
+
+// A kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) belongs to the (kernel, device) pair, and one
+// template instance serves every plan of its type — cached and persistent plans included. It is therefore raised ONCE per
+// kernel and device to all the hardware has (160 KB less the kernel's static LDS), never to one plan's own need: a later
+// plan that needs less would otherwise lower the cap under a live plan that launches with more.
+template <class K>
+inline void allow_lds_max(K kernel, size_t need_bytes) {
+  if (need_bytes <= 64 * 1024) return;
+  constexpr size_t LDS_PER_CU = 160 * 1024;
+  SDRHIP_REQUIRE(need_bytes <= LDS_PER_CU, SDRHIP_E_UNSUPPORTED, "%zu bytes of LDS per workgroup exceed the CU's 160 KB", need_bytes);
+  static std::mutex mu;
+  static std::set<std::pair<const void *, int>> done;
+  int dev = 0;
+  SDRHIP_CHECK_HIP(hipGetDevice(&dev));
+  const void *fn = reinterpret_cast<const void *>(kernel);
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count({fn, dev})) return;
+  hipFuncAttributes fa{};
+  SDRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, fn));
+  SDRHIP_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_PER_CU - fa.sharedSizeBytes)));
+  done.insert({fn, dev});
+}
 
 // roctx range around one process() call (SURVEY §5 tracing): with SDRHIP_ROCTX=1 in the environment every *_process /
 // *_process_dev entry point is bracketed by roctxRangePush / roctxRangePop, so that a `rocprofv3 --marker-trace` run

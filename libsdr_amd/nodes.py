@@ -603,7 +603,7 @@ class FloatBaseBand(_Node):
     def __init__(self, ctx, Fc, Fs, alpha, decim, channels=1, max_in=65536):
         super().__init__()
         alpha = np.ascontiguousarray(alpha, np.float64)
-        self.ctx, self.channels, self.decim = ctx, channels, decim
+        self.ctx, self.channels, self.decim, self.order = ctx, channels, decim, alpha.shape[0]
         check(abi.lib().sdrhip_fbb_f32_create(ctx.handle, Fc, Fs, alpha.ctypes.data_as(C.POINTER(C.c_double)),
                                               alpha.shape[0], decim, channels, max_in, C.byref(self._h)))
 
@@ -643,6 +643,7 @@ class FloatBaseBand(_Node):
 
     def set_taps(self, alpha):
         alpha = np.ascontiguousarray(alpha, np.float64)
+        assert alpha.shape == (self.order,)   # (the C side reads `order` doubles)
         check(abi.lib().sdrhip_fbb_f32_set_taps(self._h, alpha.ctypes.data_as(C.POINTER(C.c_double))))
 
     def set_shift(self, Fc):

@@ -1536,6 +1536,32 @@ def test_fft_plan_any_size_planned_once(ctx, n, dtype, tol, form):
     assert np.array_equal(fn(ctx, x2, -1), y2)   # (second call: the cached plan)
 
 
+@pytest.mark.parametrize("big,small,dtype,tol", [(15360, 10240, np.float32, 3e-6), (12288, 9216, np.float32, 3e-6), (7680, 5120, np.float64, 1e-13),
+                                                  (2048 * 24, 1024 * 24, np.float32, 3e-6)])
+def test_fft_plans_of_one_kernel_keep_their_lds(ctx, big, small, dtype, tol):
+    """Two live plans on ONE kernel instance whose LDS needs differ and both exceed 64 KB (in-LDS transforms of 15360 / 10240
+    points = 120 / 80 KB; four-step passes of 2048 / 1024 columns): the kernel's dynamic-LDS limit belongs to the (kernel,
+    device) pair, so building the smaller plan must not lower it under the larger one — the larger plan
+    executes again AFTER the smaller one was built and run, and once more from the context's plan cache."""
+    cdt = np.complex128 if np.dtype(dtype) == np.float64 else np.complex64
+    rng = np.random.default_rng(big)
+
+    def check(plan, n):
+        x = (rng.standard_normal((2, n)) + 1j * rng.standard_normal((2, n))).astype(cdt)
+        ref = np.fft.fft(x.astype(np.complex128), axis=1)
+        assert np.abs(plan.exec_batch(x, -1) - ref).max() / np.abs(ref).max() < tol, n
+
+    pb = sa.FFTPlan(ctx, big, cdt)
+    check(pb, big)
+    ps = sa.FFTPlan(ctx, small, cdt)
+    check(ps, small)
+    check(pb, big)
+    for n in (big, small, big):   # the one-shot entry point: plans out of the context's cache, in the order that used to lower the cap
+        x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(cdt)
+        y, ref = sa.fft_exec(ctx, x, -1), np.fft.fft(x.astype(np.complex128))
+        assert np.abs(y - ref).max() / np.abs(ref).max() < tol, n
+
+
 def test_fft_bad_arguments(ctx):
     """sizes below 1 are E_INVALID before anything is allocated (a negative n used to become a huge allocation)"""
     for n in (0, -5):
