@@ -1028,6 +1028,8 @@ protected:
     }
     if (R > 1) detail::configCheck(sdrhip_malloc(_ranks[0].ctx, _C * _outStride * sizeof(cs16), &_gather), "ChannelBank");
     std::fill(_pending.begin(), _pending.end(), false);
+    _chunkHave.assign((_C + kChunk - 1) / kChunk, 0);
+    _copyOk = true;
     _have = 0;
     const double oRate = double(size_t(Fs) / _D);
     for (size_t c = 0; c < _C; c++)
@@ -1038,7 +1040,7 @@ protected:
    * numerical contract), then launches once per device for the whole bank. */
   void _deliver(size_t c, const Buffer<cs16> &b) {
     if (!_comm || b.size() > _bs) return;
-    if (_have == 0) _len = b.size();
+    if (_have == 0) { _len = b.size(); _copyOk = true; }
     if (_pending[c] || b.size() != _len) {
       LogMessage msg(LOG_WARNING);
       msg << "gpu::ChannelBank: channel " << c << " delivered out of step; buffer dropped";
@@ -1047,9 +1049,16 @@ protected:
     }
     memcpy(_stageIn.data() + c * _bs * sizeof(cs16), b.data(), b.size() * sizeof(cs16));
     _pending[c] = true;
+    // The round's input travels while the round is still being delivered: the channels come one buffer at a time from the
+    // caller's thread (a 256 KB memcpy each into the pinned staging area: 10 ms for 1024 channels on one core), so every
+    // completed chunk of kChunk channels starts its H2D copy at once and the copies hide behind the memcpys of the chunks
+    // that follow (measured through examples/bench_graph.cc: profiles/r18_host_path.txt)
+    const size_t k = c / kChunk;
+    if (++_chunkHave[k] == std::min(kChunk, _C - k * kChunk)) _copyChunk(k);
     if (++_have < _C) return;
     _have = 0;
     std::fill(_pending.begin(), _pending.end(), false);
+    std::fill(_chunkHave.begin(), _chunkHave.end(), 0);
     // the per-channel outputs are views of _stageOut: while a consumer (e.g. a queued edge) still holds one of the
     // last round, this round is dropped, as every node drops its input while its output buffer is in use
     // (src/baseband.hh:141-150)
@@ -1062,13 +1071,11 @@ protected:
     size_t n = 0;
     const size_t per = _epilogue == SDRHIP_EPI_NONE ? 1 : 2;   // int16 elements fit twice into a cs16 row
     const size_t R = _ranks.size(), rowB = _outStride * sizeof(cs16);
-    bool ok = true;
     std::vector<const void *> send(R); std::vector<size_t> bytes(R);
-    for (size_t r = 0; r < R && ok; r++) {   // every rank: H2D of its block and its batched launch, all asynchronous
+    bool ok = _copyOk;
+    for (size_t r = 0; r < R && ok; r++) {   // every rank: its batched launch behind its chunks' H2D copies (same stream), all asynchronous
       Rank &k = _ranks[r];
-      ok = detail::processOk(sdrhip_memcpy_h2d_async(k.ctx, k.din, _stageIn.data() + k.c0 * _bs * sizeof(cs16),
-                                                     (k.c1 - k.c0) * _bs * sizeof(cs16)), "gpu::ChannelBank") &&
-           detail::processOk(sdrhip_iqbb_i16_process_dev(k.plan, reinterpret_cast<const int16_t *>(k.din), _len, _bs, k.dout,
+      ok = detail::processOk(sdrhip_iqbb_i16_process_dev(k.plan, reinterpret_cast<const int16_t *>(k.din), _len, _bs, k.dout,
                                                          _outStride * per, &n), "gpu::ChannelBank");
       send[r] = k.dout; bytes[r] = (k.c1 - k.c0) * rowB;
     }
@@ -1085,6 +1092,22 @@ protected:
     }
   }
 
+  /** H2D copy of the channels [k * kChunk, (k + 1) * kChunk) of the round being collected: each rank's part on that rank's stream. */
+  void _copyChunk(size_t k) {
+    const size_t a = k * kChunk, b = std::min(_C, a + kChunk);
+    for (size_t r = 0; r < _ranks.size(); r++) {
+      Rank &rk = _ranks[r];
+      const size_t lo = std::max(a, rk.c0), hi = std::min(b, rk.c1);
+      if (lo >= hi) continue;
+      if (!detail::processOk(sdrhip_memcpy_h2d_async(rk.ctx, static_cast<char *>(rk.din) + (lo - rk.c0) * _bs * sizeof(cs16),
+                                                     _stageIn.data() + lo * _bs * sizeof(cs16), (hi - lo) * _bs * sizeof(cs16)), "gpu::ChannelBank"))
+        _copyOk = false;
+    }
+  }
+
+  static const size_t kChunk = 32;
+  std::vector<size_t> _chunkHave;
+  bool _copyOk = true;
   size_t _C;
   double _Fc, _Ff, _width;
   size_t _order, _D;

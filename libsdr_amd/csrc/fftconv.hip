@@ -276,7 +276,9 @@ __device__ void fft_inverse_dit(float2 *x, const FftDev &p, int tid) {
 struct ConvArgs {
   FftDev fft;
   const float2 *in; long in_stride;
-  const float2 *hist; int HH;        // HH = L - hop samples preceding the call
+  const float2 *hist; int HH;        // HH = L - hop: the samples of a block in front of the ones it keeps
+  int HL, delay;                     // history rows hold the HL samples preceding the call (HH + delay); the block's window starts `delay`
+                                     // samples earlier in the stream (partitioned convolution: the later tap partitions, fftconv_fused_kernel ACC)
   float2 *hist_new;                  // fused kernel: the channel's last block also writes the history of the next call (NULL: not this launch)
   const float2 *Kp;                  // spectra (band b at Kp + b*L), digit-reversed order, pre-scaled by 1/L
   float2 *out; long out_stride;
@@ -289,12 +291,12 @@ __global__ __launch_bounds__(FT) void fftconv_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float2 xl[];
   const int c = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
   const int L = a.fft.L;
-  const int first = blk * a.hop - a.HH;   // call-relative index of xl[0]
+  const int first = blk * a.hop - a.HH - a.delay;   // call-relative index of xl[0]
   for (int i = tid; i < L; i += FT) {
     const int rel = first + i;
     float2 v = make_float2(0.f, 0.f);
     if (rel >= 0) { if (rel < a.N) v = a.in[(long)c * a.in_stride + rel]; }
-    else { const int h = a.HH + rel; if (h >= 0) v = a.hist[(long)c * a.HH + h]; }
+    else { const int h = a.HL + rel; if (h >= 0) v = a.hist[(long)c * a.HL + h]; }
     xl[PAD(i)] = v;
   }
   __syncthreads();
@@ -325,8 +327,8 @@ __device__ __forceinline__ float lane_xor1(float x) {
 // (same element groups: stride 1) are one LDS round trip. 6 LDS reads + 6 writes of the block instead of 11 + 11.
 __device__ __forceinline__ float2 conv_fetch(const ConvArgs &a, int c, int rel) {
   if (rel >= 0) return rel < a.N ? a.in[(long)c * a.in_stride + rel] : make_float2(0.f, 0.f);
-  const int h = a.HH + rel;
-  return h >= 0 ? a.hist[(long)c * a.HH + h] : make_float2(0.f, 0.f);
+  const int h = a.HL + rel;
+  return h >= 0 ? a.hist[(long)c * a.HL + h] : make_float2(0.f, 0.f);
 }
 
 // LG > 0: the plan (L = 2^LG: radix-16 passes, then 4 and/or 2) is a compile-time constant — strides, pad offsets and
@@ -340,7 +342,10 @@ constexpr int plan_radix(int lg, int pass) { return pass < lg / 4 ? 16 : ((lg % 
 // NT: lanes per workgroup — L / 16 (one radix-16 butterfly per lane and pass), at least one wave, at most 1024: a 2048-point
 // filter-bank block on 1024 lanes kept 7 of 8 lanes idle in the radix-16 passes and, one workgroup at a time per CU pair of
 // images, nothing overlapped its latencies
-template <int LG, bool BANK, int NT>
+// ACC: the block's kept samples are ADDED to what the output rows hold (partitioned convolution: a filter of more taps than one
+// 16384-point block can carry runs as two passes over the same input — tap partition 0, then partition 1 on the window 8192
+// samples earlier, accumulated: y = h0 (*) x + z^-8192 (h1 (*) x))
+template <int LG, bool BANK, int NT, bool ACC = false>
 __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
   constexpr int FT = NT;   // (shadows the file-wide workgroup size)
   extern __shared__ __attribute__((aligned(16))) float2 xl[];
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
   auto pass_sync = [&]() { if (WAVE_LOCAL) asm volatile("" ::: "memory"); else __syncthreads(); };
   // radix-4 butterfly q (0..3) of this lane: with WAVE_LOCAL the 256 butterflies of the wave's own segment
   auto bfly4_index = [&](int tid, int q) { return WAVE_LOCAL ? ((tid >> 6) * 256 + (tid & 63) + 64 * q) : (tid + q * FT); };
-  const int first = blk * a.hop - a.HH;   // call-relative index of element 0
+  const int first = blk * a.hop - a.HH - a.delay;   // call-relative index of element 0
   // ---- forward pass 0 (radix 16, stride L/16): global -> registers -> LDS ----
   {
     const int tid = lane();
@@ -665,13 +670,20 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
           const float rx = lane_xor1(give.x), ry = lane_xor1(give.y);
           const float4 q = odd ? make_float4(rx, ry, v[2 * m + 1].x, v[2 * m + 1].y) : make_float4(v[2 * m].x, v[2 * m].y, rx, ry);
           const int i = je + (2 * m + odd) * s;
-          if (i >= a.HH) *reinterpret_cast<float4 *>(dst + i) = q;
+          if (i >= a.HH) {
+            if (ACC) { const float4 t = *reinterpret_cast<const float4 *>(dst + i); *reinterpret_cast<float4 *>(dst + i) = make_float4(q.x + t.x, q.y + t.y, q.z + t.z, q.w + t.w); }
+            else *reinterpret_cast<float4 *>(dst + i) = q;
+          }
         }
       } else {
 #pragma unroll
         for (int k = 0; k < 16; k++) {
           const int i = j + k * s - a.HH, o = o0 + i;
-          if (i >= 0 && o < a.N) outb[(long)c * a.out_stride + o] = v[k];
+          if (i >= 0 && o < a.N) {
+            float2 *po = outb + (long)c * a.out_stride + o;
+            if (ACC) { const float2 t = *po; *po = make_float2(v[k].x + t.x, v[k].y + t.y); }
+            else *po = v[k];
+          }
         }
       }
     }
@@ -681,9 +693,9 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
   // the channel's last block rolls the overlap history forward (hist_new <- the last HH samples of concat(hist, in); `hist`
   // is only read, by this launch's first blocks): no separate launch
   if (a.hist_new != nullptr && blk == (int)gridDim.x - 1) {
-    for (int k = tid0; k < a.HH; k += FT) {
+    for (int k = tid0; k < a.HL; k += FT) {
       const long qq = (long)a.N + k;
-      a.hist_new[(long)c * a.HH + k] = qq < a.HH ? a.hist[(long)c * a.HH + qq] : a.in[(long)c * a.in_stride + (qq - a.HH)];
+      a.hist_new[(long)c * a.HL + k] = qq < a.HL ? a.hist[(long)c * a.HL + qq] : a.in[(long)c * a.in_stride + (qq - a.HL)];
     }
   }
 }
@@ -1089,6 +1101,11 @@ struct sdrhip_fftconv {
   int ola_L = 0;        // an overlap-add plan (2N-point spectra) that runs as overlap-save on another transform: the caller's 2N (set_kernel converts)
   int B = 1;            // bands of the bank (spectra sharing one forward transform)
   int n_taps = 0;
+  // Partitioned overlap-save (12290 ... 16384 taps: FilterNode<float>(N) with 12289 < N <= 16384 — no single 16384-point block can
+  // carry them and a 32768-point block does not fit a workgroup's LDS): the taps in `parts` partitions of `part_taps`, every block
+  // convolved with each partition on the tuned 16384-point kernel — partition p on the window p * part_taps samples earlier,
+  // accumulated into the output. The history rows hold HL = HH + (parts - 1) * part_taps samples.
+  int parts = 1, part_taps = 0, HL = 0;
   size_t max_in = 0;
   FftPlan plan;
   DevBuf<float2> Kp;
@@ -1097,15 +1114,19 @@ struct sdrhip_fftconv {
 
   // spectrum of one band -> the device layout (digit-reversed position order, pre-scaled by 1/L)
   void load_kernel(int band, const float *kernel) {
+    for (int part = 0; part < parts; part++) load_kernel_part(band, part, kernel);
+  }
+  void load_kernel_part(int band, int part, const float *kernel) {
     const int L = plan.L;
     std::vector< std::complex<double> > spec(L);
     if (mode == SDRHIP_FFTCONV_OLA) {
       // kernel = the FilterSource spectrum (2N points); its time-domain support is N taps
       for (int i = 0; i < L; i++) spec[i] = std::complex<double>(kernel[2 * i], kernel[2 * i + 1]);
     } else {
-      // host DFT in double of the zero-padded taps (one-off)
+      // host DFT in double of the zero-padded taps (one-off); partitioned plans: of partition `part`'s taps
       std::vector< std::complex<double> > a(L, std::complex<double>(0, 0));
-      for (int i = 0; i < n_taps; i++) a[i] = std::complex<double>(kernel[2 * i], kernel[2 * i + 1]);
+      const int t0 = parts > 1 ? part * part_taps : 0, t1 = parts > 1 ? std::min(n_taps, t0 + part_taps) : n_taps;
+      for (int i = t0; i < t1; i++) a[i - t0] = std::complex<double>(kernel[2 * i], kernel[2 * i + 1]);
       for (size_t i = 1, j = 0; i < (size_t)L; i++) {
         size_t bit = (size_t)L >> 1;
         for (; j & bit; bit >>= 1) j ^= bit;
@@ -1128,7 +1149,7 @@ struct sdrhip_fftconv {
       const std::complex<double> v = spec[plan.perm[pos]] / (double)L;
       kp[pos] = make_float2((float)v.real(), (float)v.imag());
     }
-    SDRHIP_CHECK_HIP(hipMemcpyAsync(Kp.p + (size_t)band * L, kp.data(), (size_t)L * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
+    SDRHIP_CHECK_HIP(hipMemcpyAsync(Kp.p + ((size_t)band * parts + part) * L, kp.data(), (size_t)L * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
     SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   }
 
@@ -1143,16 +1164,17 @@ struct sdrhip_fftconv {
     const int bpl = bands_per_launch();
     bool rolled = false;
     for (int b0 = 0; b0 < B; b0 += bpl) {   // (a plan too large for two LDS images transforms the input once per band)
+    for (int part = 0; part < parts; part++) {
     ConvArgs a;
     a.nb = std::min(bpl, B - b0); a.out_band = (long)out_band; a.lds_elems = (int)(plan.lds_bytes() / sizeof(float2));
     const size_t lds = plan.lds_bytes();
     a.fft = plan.dev; a.in = in_dev; a.in_stride = (long)in_stride;
-    a.hist = hist[par].p; a.HH = HH; a.Kp = Kp.p + (size_t)b0 * plan.L;
+    a.hist = hist[par].p; a.HH = HH; a.HL = HL; a.delay = part * part_taps; a.Kp = Kp.p + ((size_t)b0 * parts + part) * plan.L;
     a.hist_new = nullptr;
     a.out = out_dev + (size_t)b0 * out_band; a.out_stride = (long)out_stride; a.N = (int)N; a.hop = hop;
     const int blocks = (int)ceil_div(N, (size_t)hop);
     auto fused = [&](auto kernel, int nt) {
-      if (HH > 0 && b0 + bpl >= B) { a.hist_new = hist[par ^ 1].p; rolled = true; }   // the call's last launch
+      if (HL > 0 && b0 + bpl >= B && part + 1 == parts) { a.hist_new = hist[par ^ 1].p; rolled = true; }   // the call's last launch
       allow_big_lds(kernel, lds);
       hipLaunchKernelGGL(kernel, dim3(blocks, C), dim3(nt), lds, ctx->stream, a);
     };
@@ -1173,7 +1195,9 @@ struct sdrhip_fftconv {
       return true;
     };
     const bool ct = getenv("SDRHIP_K7_RUNTIME_PLAN") == nullptr;   // (tuning / tests: the run-time-plan kernel for every size)
-    if (plan.L == 16384) {   // (never a bank: two images of 16384 points do not fit the LDS)
+    if (plan.L == 16384 && part > 0) {
+      fused(fftconv_fused_kernel<14, false, 1024, true>, 1024);   // (a later tap partition: accumulated)
+    } else if (plan.L == 16384) {   // (never a bank: two images of 16384 points do not fit the LDS)
       fused(fftconv_fused_kernel<14, false, 1024>, 1024);   // (512 / 256 lanes measured 0.78x / 0.59x)
     } else if (ct && fusable && nt == 128 && plan_is(11)) {
       if (a.nb > 1) fused(fftconv_fused_kernel<11, true, 128>, 128); else fused(fftconv_fused_kernel<11, false, 128>, 128);
@@ -1191,11 +1215,12 @@ struct sdrhip_fftconv {
       hipLaunchKernelGGL(fftconv_kernel, dim3(blocks, C), dim3(FT), lds, ctx->stream, a);
     }
     }
+    }
     SDRHIP_CHECK_HIP(hipGetLastError());
-    if (HH > 0 && rolled) par ^= 1;
-    else if (HH > 0) {
-      hipLaunchKernelGGL(hist_roll_kernel, dim3((unsigned)ceil_div((size_t)HH, (size_t)256), C), dim3(256), 0, ctx->stream,
-                         in_dev, (long)in_stride, hist[par].p, hist[par ^ 1].p, HH, (int)N);
+    if (HL > 0 && rolled) par ^= 1;
+    else if (HL > 0) {
+      hipLaunchKernelGGL(hist_roll_kernel, dim3((unsigned)ceil_div((size_t)HL, (size_t)256), C), dim3(256), 0, ctx->stream,
+                         in_dev, (long)in_stride, hist[par].p, hist[par ^ 1].p, HL, (int)N);
       SDRHIP_CHECK_HIP(hipGetLastError());
       par ^= 1;
     }
@@ -1344,7 +1369,9 @@ int sdrhip_fftconv_create_bank(sdrhip_ctx *ctx, int mode, int fft_size, const fl
         // (complex<float>: the tuned kernels' own ranking — 2048 points up to 512 taps, 4096 up to 2048, 16384 beyond — measured at
         // 8 ... 4097 taps, tools/probes/fir_cf32_vs_fft.py; the operation count alone would pick 8192 points for 1000 taps: 0.41 ms
         // against 0.35 ms on 4096)
-        const int N = fft_size / 2, lp = N <= 512 ? 2048 : N <= 2048 ? 4096 : N <= 12289 ? 16384 : 0;
+        // (12290 ... 16384 taps, one band: the same 16384-point kernel in two tap partitions — sdrhip_fftconv::parts)
+        const int N = fft_size / 2, lp = N <= 512 ? 2048 : N <= 2048 ? 4096 : N <= 12289 ? 16384 : (N <= 16384 && n_bands == 1 && !getenv("SDRHIP_FFTCONV_NO_PARTS")) ? 16384 : 0;
+        if (lp && N > 12289) { h->parts = 2; h->part_taps = 8192; }
         if (lp && lp != fft_size) {
           for (int b = 0; b < n_bands; b++) {
             const std::vector<float> t = ola_spectrum_to_taps(kernels + (size_t)b * 2 * fft_size, fft_size);
@@ -1362,15 +1389,17 @@ int sdrhip_fftconv_create_bank(sdrhip_ctx *ctx, int mode, int fft_size, const fl
       h->plan.build(ctx, fft_size);
       const int L = fft_size;
       if (mode == SDRHIP_FFTCONV_OLA) { h->hop = L / 2; h->n_taps = L / 2; }
+      else if (h->parts > 1) { h->hop = L - h->part_taps; h->n_taps = n_taps; }   // (a partition's taps: part_taps <= L - hop + 1)
       else {
         SDRHIP_REQUIRE(n_taps >= 1 && n_taps <= L, SDRHIP_E_INVALID, "n_taps %d outside [1,%d]", n_taps, L);
         h->hop = L - n_taps + 1; h->n_taps = n_taps;
       }
       h->HH = L - h->hop;
-      h->Kp.alloc((size_t)L * n_bands);
+      h->HL = h->HH + (h->parts - 1) * h->part_taps;
+      h->Kp.alloc((size_t)L * n_bands * h->parts);
       const size_t per_band = mode == SDRHIP_FFTCONV_OLA ? (size_t)2 * L : (size_t)2 * n_taps;   // floats per band in `kernels`
       for (int b = 0; b < n_bands; b++) h->load_kernel(b, kernels + (size_t)b * per_band);
-      for (int p = 0; p < 2; p++) { h->hist[p].alloc((size_t)channels * std::max(1, h->HH)); h->hist[p].zero(ctx->stream); }
+      for (int p = 0; p < 2; p++) { h->hist[p].alloc((size_t)channels * std::max(1, h->HL)); h->hist[p].zero(ctx->stream); }
       SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     } catch (...) { delete h; throw; }
     *out = h;

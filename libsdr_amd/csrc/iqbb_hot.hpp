@@ -1,5 +1,5 @@
 // iqbb_hot.hpp — K1's HOT kernel: IQBaseBand<int16_t> (D = 8) as the int8-MFMA block-Toeplitz GEMM, one launch per
-// call, for EVERY filter length path 1 serves (S = 2, 3, 5, 9, 17 K steps: orders up to 17 / 33 / 65 / 129 / 257) and
+// call, for EVERY filter length path 1 serves (S = 2, 3, 5, 9, 17, 33 K steps: orders up to 17 / 33 / 65 / 129 / 257 / 513) and
 // for complex<int16> and complex<uint8> (AutoCast fused) input.
 //
 // Replaces (reference, file:line): IQBaseBand<int16_t>::_process / _filter_ring  src/baseband.hh:198-236,
@@ -62,12 +62,15 @@ constexpr bool hot_pair(int, int, bool) { return false; }
 constexpr int hot_lds_bytes(int S, int NH, int in, int NW, bool wide, bool pair = false) {
   return (wide ? 4096 : 1024) + (S + NH) * 1024 + NW * (pair ? 4 : 2) * hot_bufb(S, in);
 }
-constexpr int hot_lds_cap(int NW, bool pair = false) { return NW == 4 ? (pair ? 81920 : 40960) : NW == 8 ? 81920 : 163840; }   // 4 waves per SIMD: 160 KB / workgroups per CU
+// 4 waves per SIMD: 160 KB / workgroups per CU. (S = 33, orders 258 ... 513: 33 ... 66 KB of tap fragments and 1024-sample windows —
+// ONE 8-wave workgroup per CU, two waves per SIMD: its 70 ... 132 MFMAs per slice keep the matrix pipe busy behind one
+// wave's vector phase)
+constexpr int hot_lds_cap(int NW, bool pair = false, int S = 0) { return S >= 33 ? 163840 : NW == 4 ? (pair ? 81920 : 40960) : NW == 8 ? 81920 : 163840; }
 // 4 KB rotation table ({Lx, Ly, -Ly, 0} x 256: one SDWA shift makes the address, no subtraction) while it fits
 #ifdef K1_NARROW_LUT   // (tuning: the 1 KB {Lx, Ly} table everywhere — half the rotation's LDS bytes, one subtraction more per sample)
 constexpr bool hot_wide(int, int, int, int, int = 0, bool = false) { return false; }
 #else
-constexpr bool hot_wide(int S, int NH, int in, int NW, int extra = 0, bool pair = false) { return hot_lds_bytes(S, NH, in, NW, true, pair) + extra <= hot_lds_cap(NW, pair); }
+constexpr bool hot_wide(int S, int NH, int in, int NW, int extra = 0, bool pair = false) { return hot_lds_bytes(S, NH, in, NW, true, pair) + extra <= hot_lds_cap(NW, pair, S); }
 #endif
 // the any-D form's additions to a workgroup's LDS: parked group sums, and the rotated samples where the window buffer is too small
 // (rot = false, plans without a shift: the unrotated values have 18 bits — two arrays of dwords instead of one of int16 pairs)
@@ -93,6 +96,7 @@ constexpr HotRange hot_ranges_3[] = {{1, 2, 4}, {0, 3, 4}};
 constexpr HotRange hot_ranges_5[] = {{1, 3, 4}, {0, 5, 4}};
 constexpr HotRange hot_ranges_9[] = {{3, 3, 4}, {2, 5, 4}, {1, 7, 4}, {0, 9, 4}};
 constexpr HotRange hot_ranges_17[] = {{6, 5, 8}, {4, 9, 8}, {0, 17, 16}};
+constexpr HotRange hot_ranges_33[] = {{12, 9, 8}, {8, 17, 8}, {0, 33, 8}};
 inline const HotRange *hot_ranges(int S, int *count) {
   switch (S) {
     case 2: *count = 1; return hot_ranges_2;
@@ -100,6 +104,7 @@ inline const HotRange *hot_ranges(int S, int *count) {
     case 5: *count = 2; return hot_ranges_5;
     case 9: *count = 4; return hot_ranges_9;
     case 17: *count = 3; return hot_ranges_17;
+    case 33: *count = 3; return hot_ranges_33;
     default: *count = 0; return nullptr;
   }
 }
@@ -113,6 +118,10 @@ void hot_launch_s9_cs16(int range, bool rot, int epi, const HotLaunch &, const H
 void hot_launch_s9_cu8(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
 void hot_launch_s17_cs16(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
 void hot_launch_s17_cu8(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
+void hot_launch_s33_cs16(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);   // (orders 258 ... 513)
+void hot_launch_s33_cu8(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
+void hot_launch_anyd33_cs16(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
+void hot_launch_anyd33_cu8(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
 void hot_launch_real(int S, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);   // S = 3, 5 or 9
 // real input at any other decimation: the any-D form (9 ... 512) and the small-decimation form (1 ... 7; 0: its LDS does not fit)
 void hot_launch_real_anyd(int S, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
@@ -132,6 +141,23 @@ int hot_launch_sd17_cu8(int range, bool rot, int epi, const HotLaunch &, const H
 }  // namespace sdrhip
 
 namespace {
+
+// AutoCast's high byte (b + 129) mod 256 of the four bytes of a dword in THREE instructions: a packed 16-bit add of 0x8100
+// reaches the upper byte of each half and cannot carry into anything, the dword is rotated by one byte, the same add again
+// reaches the other two. The result holds the bytes (b1', b2', b3', b0'): rotated by one inside the dword — the sample plane's
+// K order inside every dword, which the complex<uint8> plans' tap fragments follow on the host (frag_rot, iqbb_i16.hip). The
+// carry-free SWAR form it replaces (add129_bytes) took five; the plane conversion was 40 of the any-D kernel's 250 vector
+// instructions per slice.
+__device__ __forceinline__ uint32_t ror8(uint32_t x) { return __builtin_amdgcn_alignbit(x, x, 8); }
+__device__ __forceinline__ uint32_t add129_rot(uint32_t x) {
+  unsigned k = 0x81008100u;
+  asm("" : "+s"(k));   // (VOP3P takes no literal: one scalar register)
+  uint32_t t;
+  asm("v_pk_add_u16 %0, %1, %2" : "=v"(t) : "v"(x), "s"(k));
+  t = ror8(t);
+  asm("v_pk_add_u16 %0, %1, %2" : "=v"(t) : "v"(t), "s"(k));
+  return t;
+}
 
 // A wave slice (tile t, wave w of the tile's 4 waves: 64 groups, the first of them FM's overlap slot) is "hot" when
 // nothing about it touches the call's borders: its window lies inside the input, none of its groups is the call's first
@@ -198,12 +224,12 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   constexpr int FSH = REAL ? 16 : 14;   // the FIR's right shift (Traits<int16_t>::shift for the real node, the literal 14 of IQBaseBand)
   constexpr int NDMA = (NPIECE + 63) / 64;                     // DMA wave-instructions per window
   constexpr int LASTL = NPIECE - 64 * (NDMA - 1);              // lanes of the last one
-  static_assert(NDMA <= 3, "immediate offsets 0 / 1024 / 2048");
+  static_assert(NDMA <= 4, "immediate offsets 0 / 1024 / 2048 / 3072");
   constexpr bool PAIR = hot_pair(IN, NW, DG);
   constexpr bool WIDE = SD ? false : hot_wide(S, NH, IN, NW, DG ? hot_anyd_extra(S, IN, ROT, NW) : 0, PAIR);   // (SD: the narrow table, the LDS goes to the sample arrays)
   static_assert(!SD || hot_sd_fits(S, NH, IN, ROT, NW), "small-decimation form: LDS budget");
   constexpr int NBUF = PAIR ? 4 : 2;   // window buffers per wave
-  static_assert(hot_lds_bytes(S, NH, IN, NW, WIDE, PAIR) <= hot_lds_cap(NW, PAIR), "LDS budget for 4 waves per SIMD");
+  static_assert(hot_lds_bytes(S, NH, IN, NW, WIDE, PAIR) <= hot_lds_cap(NW, PAIR, S), "LDS budget for 4 waves per SIMD");
   constexpr int TBLW = WIDE ? 1024 : 256;   // dwords
   constexpr int TPBH = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -289,9 +315,13 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
     } else if (NDMA == 2) {
       asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(ldsb) : "memory", "m0");
       if (l < LASTL) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:1024" :: "v"(src), "s"(ldsb) : "memory", "m0");
-    } else {
+    } else if (NDMA == 3) {
       asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024" :: "v"(src), "s"(ldsb) : "memory", "m0");
       if (l < LASTL) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:2048" :: "v"(src), "s"(ldsb) : "memory", "m0");
+    } else {
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024\n\tglobal_load_lds_dwordx4 %0, off offset:2048"
+                   :: "v"(src), "s"(ldsb) : "memory", "m0");
+      if (l < LASTL) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:3072" :: "v"(src), "s"(ldsb) : "memory", "m0");
     }
 #pragma clang diagnostic pop
 #endif
@@ -356,7 +386,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
     for (int k = 0; k < NDMA; k++) {
       if (k < NDMA - 1 || l < LASTL) {
         if (CU8) {   // AutoCast: high byte (b + 129) mod 256, low byte 0 (no low plane at all)
-          *reinterpret_cast<uint4 *>(cb + dofs[k]) = make_uint4(add129_bytes(x[k].x), add129_bytes(x[k].y), add129_bytes(x[k].z), add129_bytes(x[k].w));
+          *reinterpret_cast<uint4 *>(cb + dofs[k]) = make_uint4(add129_rot(x[k].x), add129_rot(x[k].y), add129_rot(x[k].z), add129_rot(x[k].w));
         } else {
           uint2 l2, h2;
           l2.x = __builtin_amdgcn_perm(x[k].y, x[k].x, 0x06040200u) ^ 0x80808080u;
@@ -1028,7 +1058,8 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   };
   auto wait_dma = [&](bool newer_in_flight) __attribute__((always_inline)) {   // all VMEM older than the NDMA youngest instructions (or everything)
     if (__builtin_expect(newer_in_flight, 1)) {
-      if (NDMA == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      if (NDMA == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (NDMA == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
       else if (NDMA == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     } else {
@@ -1304,9 +1335,9 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
               }
               v[k][j] = hb;
             }
-            if (k < NDMA - 1 || l < LASTL)
-              *reinterpret_cast<uint4 *>(cb + dofs[k]) = make_uint4(v[k][0] | (v[k][1] << 16), v[k][2] | (v[k][3] << 16),
-                                                                    v[k][4] | (v[k][5] << 16), v[k][6] | (v[k][7] << 16));
+            if (k < NDMA - 1 || l < LASTL)   // (the hot loop's byte order inside a dword: add129_rot)
+              *reinterpret_cast<uint4 *>(cb + dofs[k]) = make_uint4(ror8(v[k][0] | (v[k][1] << 16)), ror8(v[k][2] | (v[k][3] << 16)),
+                                                                    ror8(v[k][4] | (v[k][5] << 16)), ror8(v[k][6] | (v[k][7] << 16)));
           }
         } else {
           const uint32_t *row = reinterpret_cast<const uint32_t *>(ac.in) + (long)cc * ac.in_stride;
@@ -1522,7 +1553,7 @@ void hot_launch_anyd_one(bool rot, int epi, const HotLaunch &hl, const HotArgs &
   if (NW > 4) {   // (beyond 64 KB of dynamic LDS: once per DEVICE and kernel)
     static std::atomic<uint64_t> attr_set{0};
     once_per_device(attr_set, [] {
-#define SDRHIP_ANYD_ATTR(R_, E_) SDRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&iqbb_hot_anyd_kernel<S, S0, NH, R_, E_, IN, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, hot_lds_cap(NW) + hot_anyd_extra(S, IN, false, NW) > 163840 ? 163840 : hot_lds_cap(NW) + hot_anyd_extra(S, IN, false, NW)))
+#define SDRHIP_ANYD_ATTR(R_, E_) SDRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&iqbb_hot_anyd_kernel<S, S0, NH, R_, E_, IN, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, hot_lds_cap(NW, false, S) + hot_anyd_extra(S, IN, false, NW) > 163840 ? 163840 : hot_lds_cap(NW, false, S) + hot_anyd_extra(S, IN, false, NW)))
       SDRHIP_ANYD_ATTR(true, SDRHIP_EPI_NONE); SDRHIP_ANYD_ATTR(true, SDRHIP_EPI_FM); SDRHIP_ANYD_ATTR(true, SDRHIP_EPI_AM); SDRHIP_ANYD_ATTR(true, SDRHIP_EPI_USB);
       SDRHIP_ANYD_ATTR(false, SDRHIP_EPI_NONE); SDRHIP_ANYD_ATTR(false, SDRHIP_EPI_FM); SDRHIP_ANYD_ATTR(false, SDRHIP_EPI_AM); SDRHIP_ANYD_ATTR(false, SDRHIP_EPI_USB);
       SDRHIP_ANYD_ATTR(true, HOT_EPI_PARTIAL); SDRHIP_ANYD_ATTR(false, HOT_EPI_PARTIAL);

@@ -17,8 +17,10 @@ void hot_launch_anyd(int S, int in, int range, bool rot, int epi, const HotLaunc
     else { if (cu8) hot_launch_anyd_one<5, 0, 5, HOT_CU8>(rot, epi, hl, ha, b); else hot_launch_anyd_one<5, 0, 5, HOT_CS16>(rot, epi, hl, ha, b); }
   } else if (S == 9) {
     hot_launch_anyd9(in, range, rot, epi, hl, ha, b);
-  } else {
+  } else if (S == 17) {
     if (cu8) hot_launch_anyd17_cu8(range, rot, epi, hl, ha, b); else hot_launch_anyd17_cs16(range, rot, epi, hl, ha, b);
+  } else {
+    if (cu8) hot_launch_anyd33_cu8(range, rot, epi, hl, ha, b); else hot_launch_anyd33_cs16(range, rot, epi, hl, ha, b);
   }
 }
 }  // namespace sdrhip

@@ -1,0 +1,13 @@
+// iqbb_hot_s33_cs16.hip — explicit instantiations of the hot kernel (iqbb_hot.hpp) for S = 33 K steps (orders 258 ... 513),
+// complex<int16> input: one 8-wave workgroup per CU (33 ... 66 KB of tap fragments, 1024-sample windows).
+#include "iqbb_hot.hpp"
+
+namespace sdrhip {
+void hot_launch_s33_cs16(int range, bool rot, int epi, const HotLaunch &hl, const HotArgs &ha, const IqbbArgs &b) {
+  switch (range) {
+    case 0: hot_launch_one<33, 12, 9, HOT_CS16, 8>(rot, epi, hl, ha, b); break;
+    case 1: hot_launch_one<33, 8, 17, HOT_CS16, 8>(rot, epi, hl, ha, b); break;
+    default: hot_launch_one<33, 0, 33, HOT_CS16, 8>(rot, epi, hl, ha, b); break;
+  }
+}
+}  // namespace sdrhip

@@ -16,6 +16,7 @@ int hot_launch_sd(int S, int in, int range, bool rot, int epi, const HotLaunch &
     return cu8 ? hot_launch_sd_one<5, 0, 5, HOT_CU8>(rot, epi, hl, ha, b, dry) : hot_launch_sd_one<5, 0, 5, HOT_CS16>(rot, epi, hl, ha, b, dry);
   }
   if (S == 9) return hot_launch_sd9(in, range, rot, epi, hl, ha, b, dry);
+  if (S >= 33) return 0;   // (orders 258 ... 513 at decimations 1 ... 7: no hot form — the VALU kernel)
   return cu8 ? hot_launch_sd17_cu8(range, rot, epi, hl, ha, b, dry) : hot_launch_sd17_cs16(range, rot, epi, hl, ha, b, dry);
 }
 }  // namespace sdrhip

@@ -794,7 +794,8 @@ void launch_hot(int S, int in, int range, bool rot, int epi, const HotLaunch &hl
     case 3: hot_launch_s3(in, range, rot, epi, hl, ha, b); break;
     case 5: hot_launch_s5(in, range, rot, epi, hl, ha, b); break;
     case 9: if (cu8) hot_launch_s9_cu8(range, rot, epi, hl, ha, b); else hot_launch_s9_cs16(range, rot, epi, hl, ha, b); break;
-    default: if (cu8) hot_launch_s17_cu8(range, rot, epi, hl, ha, b); else hot_launch_s17_cs16(range, rot, epi, hl, ha, b); break;
+    case 17: if (cu8) hot_launch_s17_cu8(range, rot, epi, hl, ha, b); else hot_launch_s17_cs16(range, rot, epi, hl, ha, b); break;
+    default: if (cu8) hot_launch_s33_cu8(range, rot, epi, hl, ha, b); else hot_launch_s33_cs16(range, rot, epi, hl, ha, b); break;
   }
 }
 }  // namespace
@@ -820,9 +821,10 @@ struct sdrhip_iqbb_i16 {
   int hot_range = -1;    // which compile-time high-plane K-step range of the hot kernel covers ah_mask (-1: none)
   int in_cu8 = 0, real = 0, i8 = 0;   // input kinds: complex<uint8> with AutoCast, real int16 (BaseBand), complex<int8> (IQBaseBand<int8_t>)
   int path = 0, S = 0, cre = 0, cim = 0;   // path 1 = int8-MFMA formulation with S K-steps
-  unsigned ah_mask = 0;
+  uint64_t ah_mask = 0;   // bit s: the high-byte tap fragments of K step s are not all zero (up to 33 steps)
   DevBuf<v4i> tapfrag;
   DevBuf<v4i> tapfrag_hot;   // path 3: the any-D hot forms' fragments (rows permuted as path 1's)
+  DevBuf<v4i> tapfrag_rot;   // paths 1 and 3: the hot forms' fragments for complex<uint8> input (bytes rotated inside every dword)
   size_t lds_bytes = 0;
   DevBuf<uint2> taps;
   DevBuf<int2> lut;
@@ -882,26 +884,27 @@ struct sdrhip_iqbb_i16 {
             const int v = (idx >= 0 && idx < OPm) ? (comp ? kim[idx] : kre[idx]) : 0;
             const int al = ((v + 128) & 255) - 128, ah = (v - al) >> 8;
             frag[(((size_t)(2 * st) * 64 + l) * 16) + j] = (int8_t)ah;
-            if (ah != 0) ah_mask |= 1u << st;
+            if (ah != 0) ah_mask |= (uint64_t)1 << st;
             frag[(((size_t)(2 * st + 1) * 64 + l) * 16) + j] = (int8_t)al;
           }
       {   // the hot kernel's compile-time high-plane range, as for path 1
         int nr = 0;
         const HotRange *rg = hot_ranges(S, &nr);
         for (int r = 0; r < nr && hot_range < 0; r++)
-          if ((ah_mask & ~(((1u << rg[r].NH) - 1u) << rg[r].S0)) == 0) hot_range = r;
+          if ((ah_mask & ~((((uint64_t)1 << rg[r].NH) - 1u) << rg[r].S0)) == 0) hot_range = r;
       }
       if (!tapfrag.p) tapfrag.alloc((size_t)S * 2 * 64);
       tapfrag.upload(reinterpret_cast<const v4i *>(frag.data()), (size_t)S * 2 * 64, ctx->stream);
     } else if (path >= 1) {   // (a path 3 plan that fell back to the VALU kernel above has path 0 by now)
       // interleaved tap vectors a_comp[2i+c] and their Toeplitz fragments, TapT[m][k] = a_comp[k-2t], m = 2t+comp:
       // 32x32x32: lane (m = l&31, hh = l>>5), byte j of K-step s <-> k = 32s+16hh+j
-      const int OPm = OP;
+      // (OPm: the window the matrix part covers; the plan's OP is the same up to 257 taps, the VALU kernel's chunked length beyond)
+      const int OPm = 16 * (S - 1) + 1, padm = OPm - order;
       std::vector<int> are(2 * OPm, 0), aim(2 * OPm, 0);
       for (int i = 0; i < order; i++) {
         const int kr = taps[2 * i], ki = taps[2 * i + 1];
-        are[2 * (pad + i)] = kr; are[2 * (pad + i) + 1] = -ki;
-        aim[2 * (pad + i)] = ki; aim[2 * (pad + i) + 1] = kr;
+        are[2 * (padm + i)] = kr; are[2 * (padm + i) + 1] = -ki;
+        aim[2 * (padm + i)] = ki; aim[2 * (padm + i) + 1] = kr;
       }
       unsigned sre = 0, sim = 0;
       for (int k = 0; k < 2 * OPm; k++) { sre += (unsigned)are[k]; sim += (unsigned)aim[k]; }
@@ -923,22 +926,32 @@ struct sdrhip_iqbb_i16 {
               const int v = (idx >= 0 && idx < 2 * OPm) ? (comp ? aim[idx] : are[idx]) : 0;
               const int al = ((v + 128) & 255) - 128, ah = (v - al) >> 8;
               frag[(((size_t)(2 * st) * 64 + l) * 16) + j] = (int8_t)ah;
-              if (ah != 0) ah_mask |= 1u << st;
+              if (ah != 0) ah_mask |= (uint64_t)1 << st;
               frag[(((size_t)(2 * st + 1) * 64 + l) * 16) + j] = (int8_t)al;
             }
+      };
+      // complex<uint8> input: the hot kernels leave the sample plane's bytes rotated by one inside every dword (add129_rot,
+      // iqbb_hot.hpp) — their tap fragments follow (byte p of a dword = element (p + 1) mod 4 of that dword's four K elements)
+      auto upload_rot = [&]() {
+        std::vector<int8_t> r(frag.size());
+        for (size_t i = 0; i < frag.size(); i++) r[i] = frag[(i & ~(size_t)3) | ((i + 1) & 3)];
+        if (!tapfrag_rot.p) tapfrag_rot.alloc((size_t)S * 2 * 64);
+        tapfrag_rot.upload(reinterpret_cast<const v4i *>(r.data()), (size_t)S * 2 * 64, ctx->stream);
       };
       if (path == 3) {   // the hot kernel's any-D forms read a permuted set of their own (iqbb_hot.hpp); the general kernel of
                          // the plan (short calls) keeps the natural row order
         build(true);
         if (!tapfrag_hot.p) tapfrag_hot.alloc((size_t)S * 2 * 64);
         tapfrag_hot.upload(reinterpret_cast<const v4i *>(frag.data()), (size_t)S * 2 * 64, ctx->stream);
+        upload_rot();
       }
       build(path == 1);
+      if (path == 1) upload_rot();
       if (path == 1 || path == 3) {   // smallest centred range [S0, S0+NH) of the hot kernel that covers the mask (path 3: its any-D form)
         int nr = 0;
         const HotRange *rg = hot_ranges(S, &nr);
         for (int r = 0; r < nr && hot_range < 0; r++)
-          if ((ah_mask & ~(((1u << rg[r].NH) - 1u) << rg[r].S0)) == 0) hot_range = r;
+          if ((ah_mask & ~((((uint64_t)1 << rg[r].NH) - 1u) << rg[r].S0)) == 0) hot_range = r;
       }
       if (!tapfrag.p) tapfrag.alloc((size_t)S * 2 * 64);
       tapfrag.upload(reinterpret_cast<const v4i *>(frag.data()), (size_t)S * 2 * 64, ctx->stream);
@@ -980,7 +993,7 @@ struct sdrhip_iqbb_i16 {
     const int NW = rg[hot_range].NW;
     HotArgs ha{};
     ha.in = in_dev; ha.in_stride = (long)in_stride; ha.out = out_dev; ha.out_stride = (long)out_stride;
-    ha.tapfrag = tapfrag.p; ha.lut = lut.p; ha.inc = inc; ha.n0_lo = (uint32_t)(n0 - phase0); ha.negative = negative;
+    ha.tapfrag = in_cu8 ? tapfrag_rot.p : tapfrag.p; ha.lut = lut.p; ha.inc = inc; ha.n0_lo = (uint32_t)(n0 - phase0); ha.negative = negative;
     ha.base0_rel = g.base0_rel; ha.OG = OG; ha.ovl = ovl; ha.t_lo = 0; ha.t_hi = tiles; ha.cre = cre; ha.cim = cim;
     ha.N = (int)N; ha.n_out = g.n_out; ha.C = C; ha.stamps = nullptr;
     ha.D = 8; ha.GS = 64; ha.lpg_sh = 0; ha.inv_d = 0.125f; ha.philast = nullptr; ha.philast_stride = 0; ha.part = nullptr; ha.fin_groups = 0;   // (the any-D form's fields)
@@ -990,9 +1003,7 @@ struct sdrhip_iqbb_i16 {
 #endif
     // persistent grid of 4 virtual (4-wave) workgroups per CU = 4 waves per SIMD; a real workgroup is NW / 4 of them.
     // Units of at most 4 tiles so that the static split leaves a short tail.
-    int wgpcu = 4;   // virtual (4-wave) workgroups per CU = waves per SIMD
-    if (env_wgpcu) wgpcu = env_wgpcu;   // tuning hook (builds with -DK1_MINWAVES=5)
-    const int nvwg = wgpcu * ctx->prop.multiProcessorCount;
+    const int nvwg = wgpcu() * ctx->prop.multiProcessorCount;   // virtual (4-wave) workgroups = waves per SIMD (SDRHIP_IQBB_WGPCU: tuning hook, builds with -DK1_MINWAVES=5)
     int htpw = 4; while (htpw > 1 && (size_t)ceil_div((size_t)tiles, (size_t)htpw) * C < 4 * (size_t)nvwg) htpw >>= 1;
     if (env_tpw) htpw = env_tpw;   // tuning hook
     ha.tpw = htpw;
@@ -1013,7 +1024,7 @@ struct sdrhip_iqbb_i16 {
   // false: not this plan / call (the general kernel runs it).
   // Decimations from 257 on (bigd_min, bigd_skip_lo): the hot kernel's large-decimation form + iqbb_bigd_finish_kernel (iqbb_hot.hpp, PART)
   bool bigd_plan() const {
-    return path == 3 && use_hot && hot_range >= 0 && S <= 17 && !i8 && !real && D >= bigd_min && D >= 257 && !(D >= bigd_skip_lo && D <= 512) && part.p != nullptr;
+    return path == 3 && use_hot && hot_range >= 0 && S <= 33 && !i8 && !real && D >= bigd_min && D >= 257 && !(D >= bigd_skip_lo && D <= 512) && part.p != nullptr;
   }
   bool launch_bigd_call(const IqbbArgs &a0, const Geometry &g, const uint32_t *in_dev, size_t N, size_t in_stride, void *out_dev, size_t out_stride) {
     const int kind = in_cu8 ? HOT_CU8 : HOT_CS16, halo = hot_halo(S, kind), win = hot_win(S, kind);
@@ -1029,7 +1040,7 @@ struct sdrhip_iqbb_i16 {
     a.base0_rel = 0; a.n_groups = nsl; a.n_out = nsl; a.extra0 = 0; a.D = 512; a.fix_lo = a.fix_hi = 0;
     HotArgs ha{};
     ha.in = in_dev; ha.in_stride = (long)in_stride; ha.out = out_dev; ha.out_stride = (long)out_stride;
-    ha.tapfrag = tapfrag_hot.p; ha.lut = lut.p; ha.inc = inc; ha.n0_lo = (uint32_t)(n0 - phase0); ha.negative = negative;
+    ha.tapfrag = in_cu8 ? tapfrag_rot.p : tapfrag_hot.p; ha.lut = lut.p; ha.inc = inc; ha.n0_lo = (uint32_t)(n0 - phase0); ha.negative = negative;
     ha.base0_rel = 0; ha.OG = 4; ha.ovl = 0; ha.t_lo = s_lo >> 2; ha.t_hi = (s_hi + 3) >> 2; ha.cre = cre; ha.cim = cim;
     ha.N = (int)N; ha.n_out = nsl; ha.C = C; ha.stamps = nullptr;
     ha.D = 512; ha.GS = 1; ha.tiles_h = tiles_h; ha.lpg_sh = 6; ha.inv_d = 0.f;
@@ -1038,7 +1049,7 @@ struct sdrhip_iqbb_i16 {
     int cnt = 0;
     const HotRange *ranges = hot_ranges(S, &cnt);
     const int NW = ranges[std::min(hot_range, cnt - 1)].NW, vper = NW / 4;
-    const int nvwg = 4 * ctx->prop.multiProcessorCount;
+    const int nvwg = wgpcu() * ctx->prop.multiProcessorCount;
     int htpw = 4; while (htpw > 1 && (size_t)ceil_div((size_t)tiles_h, (size_t)htpw) * C < 4 * (size_t)nvwg) htpw >>= 1;
     // whole channels as units where they deal evenly over the grid (as the FM fix-up of the any-D form): a workgroup then
     // finishes the groups of its channels itself and the second launch is not needed
@@ -1064,15 +1075,19 @@ struct sdrhip_iqbb_i16 {
   }
   // whole channels as the persistent grid's units (any-D forms with FM: the slices' first angle differences, large-decimation
   // form: the groups, finished inside the hot kernel instead of by a second launch): where they deal evenly over the grid
+  // virtual (4-wave) workgroups per CU of the persistent grids: 4 = four waves per SIMD; the 33-step class (orders 258 ... 513) runs
+  // one 8-wave workgroup per CU (SDRHIP_IQBB_WGPCU: tuning hook)
+  int wgpcu() const { return env_wgpcu ? env_wgpcu : S >= 33 ? 2 : 4; }
+  bool long_filter() const { return (path == 1 || path == 3) && S >= 33; }   // no general MFMA kernel: short calls run the VALU kernel
   bool channel_units() const {
     if (env_fm_resident >= 0) return env_fm_resident != 0;   // tuning / test hook (SDRHIP_IQBB_FM_RESIDENT=0|1)
-    const size_t nvwg = (size_t)(env_wgpcu ? env_wgpcu : 4) * (size_t)ctx->prop.multiProcessorCount, rounds = ceil_div((size_t)C, nvwg);
+    const size_t nvwg = (size_t)wgpcu() * (size_t)ctx->prop.multiProcessorCount, rounds = ceil_div((size_t)C, nvwg);
     return (size_t)C * 100 >= rounds * nvwg * 97;
   }
   bool real_anyd() const { return path == 4 && D != R; }   // real input at a decimation other than 8: the any-D forms of the hot kernel
   int hot_kind() const { return real ? HOT_REAL : in_cu8 ? HOT_CU8 : HOT_CS16; }
   bool anyd_plan() const {
-    if (!(((path == 3 && !i8 && !real) || real_anyd()) && use_hot && hot_range >= 0 && S <= 17)) return false;
+    if (!(((path == 3 && !i8 && !real) || real_anyd()) && use_hot && hot_range >= 0 && S <= 33)) return false;
     if (D >= 9 && D <= 512) return true;
     // decimations 1 ... 7: the small-decimation form, where its sample arrays fit a workgroup's LDS (iqbb_hot.hpp, SD, hot_sd_nw)
     return D >= 1 && D <= 7 && hot_launch_sd(S, hot_kind(), hot_range, inc != 0, epi, HotLaunch{0, nullptr}, HotArgs{}, IqbbArgs{}, true) != 0;
@@ -1092,7 +1107,7 @@ struct sdrhip_iqbb_i16 {
     const int t_lo = s_lo >> 2, t_hi = (s_hi + 3) >> 2;
     HotArgs ha{};
     ha.in = in_dev; ha.in_stride = (long)in_stride; ha.out = out_dev; ha.out_stride = (long)out_stride;
-    ha.tapfrag = real ? tapfrag.p : tapfrag_hot.p;   // (path 4's only set is the permuted one)
+    ha.tapfrag = real ? tapfrag.p : in_cu8 ? tapfrag_rot.p : tapfrag_hot.p;   // (path 4's only set is the permuted one)
     ha.lut = lut.p; ha.inc = inc; ha.n0_lo = (uint32_t)(n0 - phase0); ha.negative = negative;
     ha.base0_rel = g.base0_rel; ha.OG = OGh; ha.ovl = 0; ha.t_lo = t_lo; ha.t_hi = t_hi; ha.cre = cre; ha.cim = cim;
     ha.N = (int)N; ha.n_out = g.n_out; ha.C = C; ha.stamps = nullptr;
@@ -1114,7 +1129,7 @@ struct sdrhip_iqbb_i16 {
     int NW = ranges[std::min(hot_range, cnt - 1)].NW;
     if (D < 8) NW = hot_launch_sd(S, kind, hot_range, inc != 0, epi, HotLaunch{0, nullptr}, HotArgs{}, IqbbArgs{}, true);   // (the small-decimation form picks its own: hot_sd_nw)
     const int vper = NW / 4;
-    const int nvwg = (env_wgpcu ? env_wgpcu : 4) * ctx->prop.multiProcessorCount;   // (SDRHIP_IQBB_WGPCU: tuning hook — waves per SIMD)
+    const int nvwg = wgpcu() * ctx->prop.multiProcessorCount;   // (SDRHIP_IQBB_WGPCU: tuning hook — waves per SIMD)
     int htpw = 4; while (htpw > 1 && (size_t)ceil_div((size_t)tiles_h, (size_t)htpw) * C < 4 * (size_t)nvwg) htpw >>= 1;
     // FM: the slices whose first output is neither out[0] nor out[1] (their own rules) and is emitted lack the angle of the
     // slice before them. Where whole channels deal evenly over the persistent grid (within 3 %: 1024 or 8192 channels on 1024
@@ -1170,7 +1185,7 @@ struct sdrhip_iqbb_i16 {
     a.base0_rel = g.base0_rel; a.n_groups = g.n_groups; a.n_out = g.n_out; a.extra0 = g.extra0;
     a.CG = CG; a.OG = OG; a.ovl = ovl; a.CGr = (CG + 3) & ~3;
     a.out = out_dev; a.out_stride = (long)out_stride; a.epilogue = epi;
-    a.tapfrag = tapfrag.p; a.cre = cre; a.cim = cim; a.ah_mask = ah_mask;
+    a.tapfrag = tapfrag.p; a.cre = cre; a.cim = cim; a.ah_mask = (unsigned)ah_mask;   // (the general kernels: at most 17 steps)
 #ifdef SDRHIP_AH_FULL
     a.ah_mask = ~0u;   // tuning: never skip
 #endif
@@ -1178,7 +1193,7 @@ struct sdrhip_iqbb_i16 {
     // MFMA path: one workgroup walks `tpw` consecutive tiles so that the tap fragments are fetched once;
     // keep >= ~8 workgroups per CU in flight for balance
     int tpw = 1;
-    const bool mf8 = path == 1 || (path == 4 && D == R);   // the lane-owned-group kernels (decimation 8)
+    const bool mf8 = (path == 1 && !long_filter()) || (path == 4 && D == R);   // the lane-owned-group kernels (decimation 8) with a general form
     if (mf8) { tpw = 8; while (tpw > 1 && (size_t)ceil_div((size_t)tiles, (size_t)tpw) * C < 2048) tpw >>= 1; }
     if (env_tpw && mf8) tpw = env_tpw;   // tuning hook
     a.tiles = tiles; a.tpw = tpw; a.bt_hi = 0; a.fix_lo = a.fix_hi = 0;
@@ -1199,6 +1214,13 @@ struct sdrhip_iqbb_i16 {
         default: SDRHIP_MFR(9); break;
       }
 #undef SDRHIP_MFR
+    } else if (long_filter() && path == 1 && use_hot && hot_range >= 0 && tiles >= 3 && launch_hot_call(a, g, in_dev, N, in_stride, out_dev, out_stride, tiles)) {
+      // (orders 258 ... 513 at decimation 8: the hot kernel's 33-step class took the whole call)
+    } else if (long_filter() && path == 3 && bigd_plan() && launch_bigd_call(a, g, in_dev, N, in_stride, out_dev, out_stride)) {
+    } else if (long_filter() && path == 3 && anyd_plan() && launch_anyd_call(a, g, in_dev, N, in_stride, out_dev, out_stride)) {
+    } else if (long_filter()) {   // ... their short calls: the VALU kernel (the class has no general matrix kernel)
+      if (fast8) hipLaunchKernelGGL((iqbb_i16_kernel<true, false>), grid, block, lds_bytes, ctx->stream, a);
+      else hipLaunchKernelGGL((iqbb_i16_kernel<false, false>), grid, block, lds_bytes, ctx->stream, a);
     } else if (path == 3 && bigd_plan() && launch_bigd_call(a, g, in_dev, N, in_stride, out_dev, out_stride)) {
       // (decimations above 256: partial sums by the hot kernel, groups finished in its last step or by a second, small launch)
     } else if (path == 3 && anyd_plan() && launch_anyd_call(a, g, in_dev, N, in_stride, out_dev, out_stride)) {
@@ -1334,11 +1356,13 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
       SDRHIP_REQUIRE(!i8 || epilogue == SDRHIP_EPI_NONE || epilogue == SDRHIP_EPI_FM, SDRHIP_E_UNSUPPORTED,
                      "the int8 chain is IQBaseBand<int8_t> (-> FMDemod<int8_t,int16_t>): epilogue NONE or FM");
       // path: the int8-MFMA formulations need D == 8, order <= 257 (32x32x32) / 153 (16x16x64) and tap high bytes that fit int8
-      bool mfma_ok = !real && !i8 && (decim == R) && (order <= 257);
+      { const char *d = getenv("SDRHIP_IQBB_HOT"); if (d && d[0] == '0') h->use_hot = false; }
+      // (orders 258 ... 513: the hot kernel's 33-step class only — no general matrix kernel; SDRHIP_IQBB_HOT=0 leaves them the VALU kernel)
+      const int mfma_max_order = h->use_hot ? 513 : 257;
+      bool mfma_ok = !real && !i8 && (decim == R) && (order <= mfma_max_order);
       auto high_byte = [](int v) { const int al = ((v + 128) & 255) - 128; return (v - al) >> 8; };
       for (int i = 0; i < 2 * order && mfma_ok; i++)   // both v and -v are packed (Kr, -Ki / Ki, Kr)
         if (high_byte(taps[i]) > 127 || high_byte(-taps[i]) > 127) mfma_ok = false;
-      { const char *d = getenv("SDRHIP_IQBB_HOT"); if (d && d[0] == '0') h->use_hot = false; }
       { const char *e = getenv("SDRHIP_IQBB_TPW"); if (e) h->env_tpw = std::max(1, atoi(e)); }
       { const char *e = getenv("SDRHIP_IQBB_WGPCU"); if (e) h->env_wgpcu = std::max(1, atoi(e)); }
       { const char *e = getenv("SDRHIP_IQBB_FM_RESIDENT"); if (e) h->env_fm_resident = atoi(e) != 0; }
@@ -1347,7 +1371,7 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
       if (force && !strcmp(force, "valu")) mfma_ok = false;
       h->path = mfma_ok ? 1 : 0;
       // path 3: the same matrix part for any decimation (measured ahead of the VALU kernel at every order tried, 9 ... 257 taps)
-      bool mfmag_ok = !real && !i8 && decim != R && order <= 257;
+      bool mfmag_ok = !real && !i8 && decim != R && order <= mfma_max_order && (order <= 257 || decim >= 9);   // (the 33-step class has no small-decimation form)
       for (int i = 0; i < 2 * order && mfmag_ok; i++)
         if (high_byte(taps[i]) > 127 || high_byte(-taps[i]) > 127) mfmag_ok = false;
       if (force && !strcmp(force, "valu")) mfmag_ok = false;
@@ -1368,19 +1392,20 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
         h->S = order <= 81 ? 3 : order <= 145 ? 5 : 9;   // the hot kernel's filter-length classes (K steps of 32 real samples)
         h->OP = decim == R ? 32 * h->S - 15 : (int)ceil_div((size_t)order, (size_t)TAPC) * TAPC;   // (other decimations: the VALU kernel's tap chunks)
       } else if (h->path == 1 || h->path == 3) {
-        h->S = order <= 17 ? 2 : order <= 33 ? 3 : order <= 65 ? 5 : order <= 129 ? 9 : 17;
-        h->OP = 16 * (h->S - 1) + 1;
+        h->S = order <= 17 ? 2 : order <= 33 ? 3 : order <= 65 ? 5 : order <= 129 ? 9 : order <= 257 ? 17 : 33;
+        h->OP = h->S >= 33 ? (int)ceil_div((size_t)order, (size_t)TAPC) * TAPC : 16 * (h->S - 1) + 1;   // (33 steps: the VALU kernel's tap chunks — it runs the short calls)
       } else {
         h->OP = (int)ceil_div((size_t)order, (size_t)TAPC) * TAPC;
       }
       h->HH = h->OP;   // one more than the FIR needs: reset(keep_history) must see the whole ring
       if (h->path == 4) h->HH = std::max(h->OP, 32 * h->S - 15);   // (the hot kernel's window reaches 32 S - 16 samples back)
+      if (h->long_filter()) h->HH = std::max(h->OP, 16 * (h->S - 1) + 1);   // (... 16 (S - 1) back)
       h->CG = CG; h->ovl = ovl; h->OG = CG - ovl;
       if (h->path == 1 || (h->path == 4 && decim == R)) { h->OG = 4 * (64 - ovl); h->CG = h->OG + ovl; }   // every wave recomputes its own FM overlap group
       h->fast8 = (decim == R);
-      if (h->path == 4 && decim != R) {   // (the VALU kernel's: it runs this plan's short calls)
+      if ((h->path == 4 && decim != R) || h->long_filter()) {   // (the VALU kernel's: it runs this plan's short calls)
         const size_t XS = TI + h->OP + 8;
-        h->lds_bytes = (XS + 256 + 2 * ((CG + 3) & ~3)) * 4 + (size_t)TI * 8;
+        h->lds_bytes = (XS + 256 + 2 * (((size_t)h->CG + 3) & ~(size_t)3)) * 4 + (h->fast8 ? 0 : (size_t)TI * 8);
       } else if (h->path == 4) {
         h->lds_bytes = 1024 + (size_t)h->S * 2 * 64 * 16 + 4 * 2 * (size_t)(512 + 32 * h->S);
       } else if (h->path == 3) {

@@ -139,6 +139,56 @@ def test_two_ranks_through_hip_nodes_match_single_process(tmp_path, workload):
 
 
 @pytest.mark.gpu
+def test_eight_ranks_preflight_through_the_real_launcher(tmp_path):
+    """Multi-GPU pre-flight at the REAL rank count on one device (the driver's scaling run is first contact with 8
+    devices): `bench.py --gpus 8 --global-channels 8192` through the same parent -> torch.distributed.run -> 8 ranks path the
+    driver's command takes (gloo rendezvous, every rank on device 0), BASELINE config 5's chain with the gather — all 8 ranks
+    counted by the all-reduce, per-rank launch times present, and the gathered 8192 rows equal the single-rank run bit for bit."""
+    import numpy as np
+    common = ["--samples", "16384", "--steps", "3", "--warmup", "1", "--batches", "2", "--no-cpu-baseline", "--sustain-seconds", "0", "--verify-channels", "2"]
+    eight, one = str(tmp_path / "eight.npy"), str(tmp_path / "one.npy")
+    d8 = _bench(["--gpus", "8", "--backend", "gloo", "--force-device", "0", "--global-channels", "8192", "--dump-output", eight] + common, timeout=1500)
+    assert d8["n_gpus"] == 8 and d8["scaling"] == "strong" and d8["config"]["global_channels"] == 8192 and d8["config"]["channels_per_gpu"] == 1024
+    rf = d8["roofline"]
+    assert rf["ranks_seen"] == 8 and 0 < rf["avg_launch_ms_min_rank"] <= rf["avg_launch_ms_max_rank"]
+    assert rf["without_gather_msamples_s"] > 0 and d8["verified"] is True
+    d1 = _bench(["--gpus", "1", "--workload", "iqbb_usb", "--channels", "8192", "--dump-output", one] + common)
+    a, b = np.load(eight), np.load(one)
+    assert a.shape == b.shape and a.shape[0] == 8192 and a.shape[1] >= 2048 and np.array_equal(a, b) and np.count_nonzero(a) > a.size // 2
+    assert rf["gather_bytes_per_step"] == a.size * 2
+
+
+@pytest.mark.gpu
+def test_eight_rank_contexts_through_the_c_abi(tmp_path):
+    """The same job through `--comm sdrhip`: ONE process, 8 rank contexts from sdrhip_comm_create (all on device 0: the
+    library's same-device transport), design broadcast, the overlapped sdrhip_comm_gather_begin / _wait every step."""
+    import numpy as np
+    common = ["--samples", "16384", "--steps", "3", "--warmup", "1", "--batches", "2", "--no-cpu-baseline", "--sustain-seconds", "0", "--verify-channels", "2"]
+    eight, one = str(tmp_path / "eight.npy"), str(tmp_path / "one.npy")
+    d8 = _bench(["--comm", "sdrhip", "--gpus", "8", "--force-device", "0", "--global-channels", "8192", "--dump-output", eight] + common, timeout=1500)
+    assert d8["ranks"] == 8 and d8["roofline"]["ranks_seen"] == 8 and d8["verified"] is True and d8["verify"]["gathered_equals_rank_rows"] is True
+    assert 0 < d8["roofline"]["avg_launch_ms_min_rank"] <= d8["roofline"]["avg_launch_ms_max_rank"]
+    d1 = _bench(["--gpus", "1", "--workload", "iqbb_usb", "--channels", "8192", "--dump-output", one] + common)
+    a, b = np.load(eight), np.load(one)
+    assert a.shape == b.shape and a.shape[0] == 8192 and np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_eight_gpus_asked_of_a_smaller_box_is_one_error_line():
+    """`bench.py --gpus 8` (no --force-device) where fewer devices exist — the driver's scaling command on the wrong box: one
+    JSON line with `error` and a null value, a non-zero exit, and no rank ever started (the parent counts devices from sysfs
+    without touching HIP: nothing that has initialised the GPU is ever re-executed)."""
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("eight devices are present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode != 0
+    d = _error_line(r)
+    assert d["n_gpus"] == 8 and "visible" in d["error"] and "rank" not in r.stderr.lower()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("workload", ["iqbb_fm", "iqbb_usb", "iqbb_fm_cu8", "bb_real_fm", "fir255_fm", "fbb_f32", "fftconv", "fftbank", "fm_demod", "subsample8"])
 def test_every_workload_emits_its_line_and_verifies(workload):
     """Every `--workload` (the BASELINE configurations and the stand-alone kernels) runs on a small batch, prints one JSON

@@ -117,3 +117,23 @@ def test_sdr_rec_wav_file_to_file(tmp_path, mode):
     assert r.returncode == 0, r.stdout + r.stderr
     want = open(os.path.join(ROOT, "tests", "golden", "g11_chain_%s_wav.bin" % mode.lower()), "rb").read()
     assert out.read_bytes() == want
+
+
+def test_bench_graph_builds():
+    _build("bench_graph.cc", "bench_graph", _gpu_link_flags(), srcdir=("examples",))
+
+
+@pytest.mark.gpu
+def test_bench_graph_host_path_floor():
+    """examples/bench_graph.cc: the drop-in layer's own throughput (sources -> gpu::ChannelBank -> sinks through the sdr:: core,
+    pinned staging, PCIe both ways), so that the node layer cannot regress silently: a loose floor of 3.5 GS/s at 1024 channels
+    (measured 4.4 GS/s with the round's H2D copy issued at its end, more with the copies pipelined behind the per-channel
+    memcpys — one host core copying 268 MB per round into the staging area is the bound, not PCIe) and 10 us ... 1 ms per
+    single-channel round (profiles/r18_host_path.txt holds a full run)."""
+    import json
+    exe = _build("bench_graph.cc", "bench_graph", _gpu_link_flags(), srcdir=("examples",))
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["bench_graph"]
+    assert d["c1024_msps"] >= 3500.0, d
+    assert 0.01 < d["c1_ms"] < 1.0 and d["c64_msps"] > d["c1_msps"], d

@@ -343,7 +343,7 @@ def test_hot_kernel_every_length_class_random_long_calls(ctx, orc, seed, cu8):
     are order 16, examples/sdr_rec.cc:68, and 21, examples/sdr_fm.cc:40) and both input kinds (complex<int16>;
     complex<uint8> with AutoCast fused, src/autocast.hh:187-194)."""
     rng = np.random.default_rng(17000 + 2 * seed + int(cu8))
-    _hot_fuzz(ctx, orc, rng, int(rng.choice([3, 16, 17, 21, 33, 34, 64, 65, 66, 100, 127, 130, 200, 255, 257])), cu8)
+    _hot_fuzz(ctx, orc, rng, int(rng.choice([3, 16, 17, 21, 33, 34, 64, 65, 66, 100, 127, 130, 200, 255, 257, 258, 300, 400, 513])), cu8)
 
 
 @pytest.mark.parametrize("cu8", [False, True])
@@ -363,7 +363,7 @@ def test_hot_kernel_any_decimation_long_filters_random_long_calls(ctx, orc, seed
     """The any-decimation form's 17-K-step class (orders 130 ... 257: 8- or 16-wave workgroups by the taps' high-plane
     range — a filter swap between buffers moves a plan from one to the other)."""
     rng = np.random.default_rng(31000 + 2 * seed + int(cu8))
-    order = int(rng.choice([130, 161, 200, 255, 257]))
+    order = int(rng.choice([130, 161, 200, 255, 257, 300, 513]))
     decim = int(rng.choice([9, 12, 31, 62, 125, 200, 300, 512, 640, 1000]))
     _hot_fuzz(ctx, orc, rng, order, cu8, decim)
 

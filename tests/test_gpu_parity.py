@@ -111,7 +111,7 @@ def synth_channels(orc, C, N, seed=0x5D2):
 
 @pytest.mark.parametrize("epi", [sa.EPI_NONE, sa.EPI_FM, sa.EPI_AM, sa.EPI_USB])
 @pytest.mark.parametrize("order,decim,Fc", [(127, 8, 100e3), (21, 8, -100e3), (33, 5, 100e3), (16, 1, 50e3),
-                                             (129, 8, 0.0), (64, 8, 30e3), (9, 8, -250e3), (1, 8, 100e3), (150, 8, 70e3), (257, 8, 100e3), (200, 8, -40e3), (129, 5, 100e3), (200, 3, -60e3), (64, 12, 30e3)])
+                                             (129, 8, 0.0), (64, 8, 30e3), (9, 8, -250e3), (1, 8, 100e3), (150, 8, 70e3), (257, 8, 100e3), (200, 8, -40e3), (300, 8, 100e3), (513, 8, -60e3), (258, 8, 0.0), (129, 5, 100e3), (200, 3, -60e3), (64, 12, 30e3)])
 def test_iqbb_batched_vs_oracle(ctx, orc, epi, order, decim, Fc, k1path):
     C, chunks = 5, [8192, 3000, 1, 7, 5000, 8192]
     taps = sa.design_iqbb_taps(Fc, 50e3, FS, order)
@@ -146,6 +146,8 @@ ANYD_CASES = [(21, 125, 100e3, True), (16, 62, 100e3, False), (21, 9, -60e3, Fal
               (21, 45, 0.0, True),
               # orders 130 ... 257 (17 K steps): the any-D form in the 8- and 16-wave workgroups of the /8 kernel's long-filter class
               (255, 125, 100e3, True), (200, 20, -60e3, False), (257, 9, 0.0, False), (130, 62, 100e3, False), (161, 300, 0.0, True),
+              # orders 258 ... 513 (33 K steps): one 8-wave workgroup per CU, 1024-sample windows; short calls run the VALU kernel
+              (300, 125, 100e3, True), (513, 20, -60e3, False), (400, 9, 0.0, False), (258, 300, 100e3, True), (350, 62, 41e3, False), (300, 1000, 100e3, True),
               # decimations above 512: a group spans slices — the hot kernel leaves partial box sums, iqbb_bigd_finish_kernel finishes the groups
               # (up to 2048, with FM 1024, a plan has a general kernel for its short calls; beyond — up to 32768 — the large-
               # decimation form serves every call, and a plan without the hot kernel does not exist)
@@ -203,7 +205,6 @@ def _any_decimation_case(ctx, orc, order, decim, Fc, cu8, epi, hot, bigd, reside
     node = sa.IQBaseBandI16(ctx, taps, lut, inc, Fc < 0, decim, channels=C, max_in=70000, epilogue=epi)
     if cu8:
         node.set_input_format(sa.abi.IN_CU8)
-    assert node.path == 3
     hot_name = "iqbb_hot_sd_kernel" if decim < 8 else "iqbb_hot_anyd_kernel"
     # (the small-decimation form's sample arrays must fit a workgroup's LDS beside the tap fragments: where they do not
     # in the class's own workgroup — 9 or 17 K steps WITHOUT a shift: two arrays of 18-bit values — the plan runs in one of
@@ -211,7 +212,11 @@ def _any_decimation_case(ctx, orc, order, decim, Fc, cu8, epi, hot, bigd, reside
     launches = [hot_name] + (["iqbb_fm_fixup_kernel"] if epi == sa.EPI_FM and not resident and not handshake else [])
     if bigd:
         launches = [hot_name] + ([] if resident else ["iqbb_bigd_finish_kernel"])
-    assert node.kernel_names == (launches if hot else ["iqbb_i16_mfmag_kernel"])
+    if order > 257 and not hot:   # (the 33-step class exists as hot forms only: SDRHIP_IQBB_HOT=0 leaves such a plan the VALU kernel)
+        assert node.path == 0 and node.kernel_names == ["iqbb_i16_kernel"]
+    else:
+        assert node.path == 3
+        assert node.kernel_names == (launches if hot else ["iqbb_i16_mfmag_kernel"])
     refs = [orc.IQBaseBandI16(taps, lut, inc, Fc < 0, decim) for _ in range(C)]
     fms = [orc.FMDemodI16() for _ in range(C)]
     for n in (65536, 70000, 12345, 1, 40001, 2 * decim + 1, 65536):

@@ -8,7 +8,11 @@ cd ${GRAFT_REPO_ROOT:-/root/repo}
 declare -A W=( [fm127]="" [fm16]="--order 16" [fm21]="--order 21" [fm64]="--order 64" [fm255]="--order 255" [usb127]="--workload iqbb_usb"
                [cu8]="--workload iqbb_fm_cu8" [real]="--workload bb_real_fm" [fir255]="--workload fir255_fm" [fbb]="--workload fbb_f32"
                [fftconv]="--workload fftconv --fft-whole-blocks" [fftola]="--workload fftconv_ola" [fftbank]="--workload fftbank" [fmdemod]="--workload fm_demod" [sub8]="--workload subsample8"
-               [sdrfm]="--workload iqbb_fm_cu8 --order 21 --decim 125" [sdrrec]="--workload iqbb_fm_cu8 --order 16 --decim 83 --fc 0"
+               [sdrfm]="--workload iqbb_fm_cu8 --order 21 --decim 125 --fs 1e6 --width 12.5e3" [cfg5g1]="--workload iqbb_usb --channels 8192 --batches 2"
+               [cfg2c1]="--workload fbb_f32 --channels 1" [cfg1]="--workload fir127_fm" [multi4]="--buffers 4 --batches 2"
+               [real5]="--workload bb_real_fm --decim 5" [real20]="--workload bb_real_fm --decim 20" [real125]="--workload bb_real_fm --decim 125"
+               [o300]="--order 300" [o513d20]="--workload iqbb_usb --order 513 --decim 20"
+               [sdrrec]="--workload iqbb_fm_cu8 --order 16 --decim 83 --fc 0"
                [sdrfmchain]="--workload iqbb_fm_cu8 --order 21 --decim 125 --deemph" [wfmchain]="--workload iqbb_fm_cu8 --order 16 --decim 20 --fc 0 --deemph"
                [pocsag]="--workload iqbb_fm_cu8 --order 21 --decim 45 --fc 0" [ssb]="--workload iqbb_usb --order 16 --decim 83 --fc 0"
                [sd4]="--workload iqbb_fm_cu8 --order 21 --decim 4" [sd7usb]="--workload iqbb_usb --order 21 --decim 7"
@@ -16,7 +20,8 @@ declare -A W=( [fm127]="" [fm16]="--order 16" [fm21]="--order 21" [fm64]="--orde
                [o255d125]="--workload iqbb_fm_cu8 --order 255 --decim 125" )   # (d300 / d1000: the large-decimation form; o255d125: the any-D form's long-filter class)   # round 4: the small-decimation form (not in the default list)   # examples/sdr_pocsag.cc:117 / sdr_ax25.cc:117 (21 taps, 1 MS/s to 22.05 kS/s); sdr_rec's USB mode on complex<int16>
 #   # ... and the whole chains: + FMDeemph (sdr_fm.cc:44-53; sdr_rec.cc WFM: 16 taps, no shift, 1 MS/s to 50 kS/s)
 #    # the plans of examples/sdr_fm.cc:40 and examples/sdr_rec.cc:42-68 (narrow FM: no shift, 1 MS/s to 12 kS/s)
-NAMES=${@:-fm127 fm16 fm21 fm64 fm255 usb127 cu8 real fir255 fbb fftconv fftola fftbank fmdemod sub8 sdrfm sdrrec sdrfmchain wfmchain pocsag ssb sd4 sd7usb d300 d1000 o255d125}
+# (sdrfm, cfg5g1, cfg2c1, cfg1, multi4, real20: the command lines of bench.py's "configs" entries — their workload keys must match for `traffic`)
+NAMES=${@:-fm127 fm16 fm21 fm64 fm255 usb127 cu8 real fir255 fbb fftconv fftola fftbank fmdemod sub8 sdrfm cfg5g1 cfg2c1 cfg1 multi4 real5 real20 real125 o300 o513d20 sdrrec sdrfmchain wfmchain pocsag ssb sd4 sd7usb d300 d1000 o255d125}
 mkdir -p gpurun_out
 : > gpurun_out/${R}_bench_other_workloads.jsonl
 for n in $NAMES; do
