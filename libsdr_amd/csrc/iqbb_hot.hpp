@@ -369,6 +369,9 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
 #ifndef K1_PRIO_ROT
 #define K1_PRIO_ROT 1
 #endif
+#ifndef K1_PRIO_SHIFT
+#define K1_PRIO_SHIFT 11
+#endif
   unsigned prio_it = 0;
   const unsigned prio_slot = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 3u;   // HW_REG_HW_ID[3:0]: the wave's slot in its SIMD
 
@@ -1046,9 +1049,14 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   // Fairness: the SIMD arbitrates its waves by priority, then AGE, and in a persistent grid the ages never change —
   // the oldest wave of a SIMD ran at full speed and was done after 64 us, the youngest starved and finished alone
   // at 120 us (s_memrealtime stamps). The priority rotates over the SIMD's four wave slots, one step per slice.
+  unsigned prio_time = 0;
   auto rotate_priority = [&]() __attribute__((always_inline)) {
-    if (K1_PRIO_ROT == 1) {   // (s_setprio takes an immediate: a two-level branch tree, 5-6 scalar instructions executed)
-      const unsigned pv = prio_it++ + prio_slot;
+    if (K1_PRIO_ROT == 1 || K1_PRIO_ROT == 4) {   // (s_setprio takes an immediate: a two-level branch tree, 5-6 scalar instructions executed)
+      // (K1_PRIO_ROT=4, tuning variant: the rotation follows the shader clock — one step per 2048 cycles, the same for every wave
+      // of a SIMD — instead of the wave's own slice count: waves that drift apart in slice count can meet at EQUAL priority, the
+      // tie goes to the older one and the drift feeds itself. The counter is read one slice ahead: its latency is hidden.)
+      unsigned pv = prio_it++ + prio_slot;
+      if (K1_PRIO_ROT == 4) { pv = prio_time + prio_slot; prio_time = (unsigned)(__builtin_amdgcn_s_memtime() >> K1_PRIO_SHIFT); }
       asm volatile("s_bitcmp1_b32 %0, 1\n\ts_cbranch_scc1 2f\n\ts_bitcmp1_b32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n\ts_branch 4f\n"
                    "1:\n\ts_setprio 1\n\ts_branch 4f\n"
                    "2:\n\ts_bitcmp1_b32 %0, 0\n\ts_cbranch_scc1 3f\n\ts_setprio 2\n\ts_branch 4f\n"

@@ -1,5 +1,5 @@
 """Diagnostic (tools/build_variant.sh stamps "-DK1_STAMPS"): per-phase shader-clock totals of the K1 hot kernel.
-usage: python tools/probes/k1_stamps.py [variant-name=stamps] [order=127] [cu8=0] [epi=1]"""
+usage: python tools/probes/k1_stamps.py [variant-name=stamps] [order=127] [cu8=0] [epi=1] [decim=8] [fs=2.4e6] [width=50e3]"""
 import ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -7,23 +7,25 @@ os.environ["SDRHIP_LIB"] = os.path.join(ROOT, "libsdr_amd", "libsdrhip_%s.so" % 
 order = int(sys.argv[2]) if len(sys.argv) > 2 else 127
 cu8 = bool(int(sys.argv[3])) if len(sys.argv) > 3 else False
 epi = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+decim = int(sys.argv[5]) if len(sys.argv) > 5 else 8
 import torch
 import numpy as np
 import libsdr_amd as sa
-FS = 2.4e6
+FS = float(sys.argv[6]) if len(sys.argv) > 6 else 2.4e6
+WIDTH = float(sys.argv[7]) if len(sys.argv) > 7 else 50e3
 C, N = 1024, 65536
 dev = torch.device("cuda", 0)
 stream = torch.cuda.Stream(device=dev)
 with torch.cuda.stream(stream):
     ctx = sa.Context(0, stream=stream.cuda_stream)
-    taps = sa.design_iqbb_taps(100e3, 50e3, FS, order); lut = sa.design_freqshift_lut_i16()
-    node = sa.IQBaseBandI16(ctx, taps, lut, sa.design_freqshift_inc(100e3, FS), False, 8, channels=C, max_in=N, epilogue=epi)
+    taps = sa.design_iqbb_taps(100e3, WIDTH, FS, order); lut = sa.design_freqshift_lut_i16()
+    node = sa.IQBaseBandI16(ctx, taps, lut, sa.design_freqshift_inc(100e3, FS), False, decim, channels=C, max_in=N, epilogue=epi)
     if cu8:
         node.set_input_format(sa.abi.IN_CU8)
         x = [torch.randint(0, 256, (C, N, 2), dtype=torch.uint8, device=dev) for _ in range(3)]
     else:
         x = [torch.randint(-8000, 8000, (C, N, 2), dtype=torch.int16, device=dev) for _ in range(3)]
-    out = torch.zeros((C, N // 8 + 2, 2), dtype=torch.int16, device=dev)
+    out = torch.zeros((C, N // decim + 2, 2), dtype=torch.int16, device=dev)
     L = sa.abi.lib()
     L.sdrhip_debug_k1_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
     W = 32768 * 16
