@@ -14,7 +14,7 @@ on rank 0 inside the timed region — from a double-buffered output, on a side s
 preallocated [N * channels, n_out] tensor (`roofline.without_gather_*` = the same steps without the gather).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload iqbb_fm|iqbb_usb|iqbb_fm_cu8|bb_real_fm|fir255_fm|
-                     fir127_fm|fbb_f32|fftconv|fftbank|fm_demod|subsample8] [--order 127] [--no-verify]
+                     fir127_fm|fbb_f32|fftconv|fftbank|fm_demod|subsample8|iqbb_fm_cs8] [--order 127] [--no-verify]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
@@ -600,6 +600,32 @@ def build_workload(a, wl, sa, torch, shard, ctx, dev, rank, nbuf_out):
             r = fm.process(r) if epi == sa.EPI_FM else orc.usb_i16(r)
             return check(out, r, orc, N // D, chan, last_i)
         w.verify = multi_verify(verify, B, N, D, False) if B > 1 else verify
+    elif wl == "iqbb_fm_cs8":   # the int8 chain IQBaseBand<int8_t> -> FMDemod<int8_t,int16_t> (src/sdr.hh:225-240), 2 bytes per sample in
+        if B > 1:
+            raise BenchError("--buffers: not for the int8 chain")
+        taps_h = sa.design_iqbb_taps(a.fc if a.fc else 100e3, a.width, a.fs, order)
+        lut_h, inc = sa.design_freqshift_lut_i8(), sa.design_freqshift_inc(a.fc, a.fs)
+        node = sa.IQBaseBandI8(ctx, taps_h, lut_h, inc, False, D, channels=C, max_in=N, epilogue=sa.EPI_FM)
+        w.in_bytes, w.alg_bytes = 2.0, 2.0 + 2.0 / D
+        n_out = node.out_count(N) + 1
+        w.outs = [torch.zeros((C, n_out), dtype=torch.int16, device=dev) for _ in range(nbuf_out)]
+        w.ins = [(x.to(torch.int32) >> 7).clamp_(-128, 127).to(torch.int8) for x in cs16()]   # (the same signal at 8 bits)
+        w.run = lambda b, o: node.process_dev(w.ins[b].data_ptr(), N, N, w.outs[o].data_ptr(), n_out)
+        w.dtype, w.kernels = "i8", node.kernel_names
+        w.desc = "IQBaseBand<int8>(%d-tap Q14 FIR, %s, /%d) -> FMDemod<int8,int16>" % (order, "LUT shift %g kHz" % (a.fc / 1e3) if inc else "no shift", D)
+        w.key = "%s/order%d/d%d" % (wl, order, D) + ("" if a.fc == 100e3 else "/fc%g" % a.fc)
+        w.plan = node.plan_info
+        w.bound = "valu-issue"
+        w.mfma = lambda sps: mfma_compute(w.plan, sps, D, 1 if D == 8 else 0, True)
+
+        def verify(prev, last, out, orc, n0=0, pre=None):
+            if N % 32768 or N % D or order > N:
+                return None
+            bb, fm = orc.IQBaseBandI8(taps_h, lut_h, inc, False, D), orc.FMDemodI8()
+            fm.process(bb.process(prev))
+            r = fm.process(bb.process(last))
+            return bool(np.array_equal(out[:len(r)], r)) and len(r) == N // D
+        w.verify = verify
     elif wl == "bb_real_fm":   # the real-input BaseBand<int16_t> (2 bytes per sample in)
         taps_h = sa.design_bb_taps(100e3, 50e3, FS, order)
         lut_h, inc = sa.design_freqshift_lut_i16(), sa.design_freqshift_inc(100e3, FS)
@@ -854,7 +880,7 @@ def verify_last(a, w, calls, rank, np, torch):
         if all(o is None for o in oks):
             return {"ok": None, "why": "this sample count / decimation is outside what the last-step check covers"}
         return {"ok": bool(all(oks)), "channels": len(chans), "mode": "last timed step vs CPU oracle",
-                "tolerance": "bit-exact" if w.dtype in ("i16", "f64") else "max|y-ref|/max|ref| <= 1e-5"}
+                "tolerance": "bit-exact" if w.dtype in ("i16", "i8", "f64") else "max|y-ref|/max|ref| <= 1e-5"}
     except Exception as e:
         return {"ok": None, "why": "oracle unavailable: %s" % str(e)[:120]}
 

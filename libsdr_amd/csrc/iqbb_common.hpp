@@ -440,7 +440,7 @@ __device__ __forceinline__ int prev_group_value(int v, int h) {
 // read's address is the byte offset itself.
 // TBL: the table's layout at LDS offset 0 — 0: 128 x {Lx, Ly} in table order (a negative shift reads entry 127 - i);
 // 1: the same stored reversed for a negative shift; 2: 16-byte entries {Lx, Ly, -Ly, 0}, stored reversed (hot kernel)
-template <bool ROT, bool CU8, bool EDGE, int TBL = 0, int FSH = 14>   // FSH: the FIR's right shift (16: real-input BaseBand)
+template <bool ROT, bool CU8, bool EDGE, int TBL = 0, int FSH = 14, bool I8 = false>   // FSH: the FIR's right shift (16: real-input BaseBand); I8: IQBaseBand<int8_t> on one byte plane
 __device__ __forceinline__ int2 group_sum(const IqbbArgs &a, const v16i &acc_hh, const v16i &acc_mid, const v16i &acc_ll, int rel0) {
   typedef int v2i __attribute__((ext_vector_type(2)));
   typedef __attribute__((address_space(3))) const v2i lds_v2i;
@@ -466,7 +466,9 @@ __device__ __forceinline__ int2 group_sum(const IqbbArgs &a, const v16i &acc_hh,
     unsigned tre = ((unsigned)acc_hh[2 * j] << 8) + (unsigned)acc_mid[2 * j];
     unsigned tim = ((unsigned)acc_hh[2 * j + 1] << 8) + (unsigned)acc_mid[2 * j + 1];
     int rr, ri;
-    if (CU8) {   // S = t << 8 exactly
+    if (I8) {    // S = t exactly; wrapped to int16 after the shift (src/baseband.hh:206)
+      rr = (short)((int)tre >> 14); ri = (short)((int)tim >> 14);
+    } else if (CU8) {   // S = t << 8 exactly
       rr = (int)(tre << 8) >> FSH; ri = (int)(tim << 8) >> FSH;
     } else {
       asm("" : "+v"(tre)); asm("" : "+v"(tim));
@@ -476,7 +478,8 @@ __device__ __forceinline__ int2 group_sum(const IqbbArgs &a, const v16i &acc_hh,
     if (ROT) {
       const int x = sub32(mul24a(L[j].x, rr), mul24a(L[j].y, ri));
       const int y = mad24a(L[j].x, ri, mul24a(L[j].y, rr));
-      sum.x = add_hi16(x, sum.x); sum.y = add_hi16(y, sum.y);   // += (x >> 16): one SDWA add each
+      if (I8) { sum.x += (int)(short)x >> 8; sum.y += (int)(short)y >> 8; }   // (the product wraps to int16, Traits<int8_t>::shift = 8)
+      else { sum.x = add_hi16(x, sum.x); sum.y = add_hi16(y, sum.y); }   // += (x >> 16): one SDWA add each
     } else {
       sum.x = (int)((unsigned)sum.x + (unsigned)rr); sum.y = (int)((unsigned)sum.y + (unsigned)ri);
     }
@@ -522,9 +525,12 @@ __device__ __forceinline__ void group_finish(const IqbbArgs &a, const int2 *lut_
   // libstdc++'s (s*8)/(8*8) (src/baseband.hh:214): |s| <= 9 * 2^17 here (a window of 16-bit rotated values, or of
   // 18-bit FIR values when there is no shift), so nothing wraps and it is trunc(s / 8): bias 7 for negative sums
   // (bits 31..29 of s), arithmetic shift, and the int16 wrap of the assignment in the same bit-field extract
-  const int yr = div8_i16(sum.x), yi = div8_i16(sum.y);
+  int yr = div8_i16(sum.x), yi = div8_i16(sum.y);
+  if (a.i8) { yr = (signed char)yr; yi = (signed char)yi; }   // (IQBaseBand<int8_t>: the node's output type)
   if (own && q == a.n_groups - 1) a.acc_new[c] = emits ? make_int2(0, 0) : sum;
-  if (a.epilogue == SDRHIP_EPI_NONE) {
+  if (a.epilogue == SDRHIP_EPI_NONE && a.i8) {
+    if (own && emits) reinterpret_cast<uint16_t *>(a.out)[(long)c * a.out_stride + q] = (uint16_t)((yr & 0xff) | ((yi & 0xff) << 8));
+  } else if (a.epilogue == SDRHIP_EPI_NONE) {
     if (own && emits) reinterpret_cast<uint32_t *>(a.out)[(long)c * a.out_stride + q] = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
   } else {
     short o;
@@ -535,7 +541,7 @@ __device__ __forceinline__ void group_finish(const IqbbArgs &a, const int2 *lut_
       // previous group's angle: lane (n,0) for h=1, lane (n-1,1) for h=0 — one v_permlane32_swap (both halves'
       // values in both halves) and one wave_shr:1 DPP move, no LDS round trip
       const int prev = prev_group_value(phi, h);
-      if (q == 0) o = (short)yr;             // index 0 is never written by FMDemod (in place)
+      if (q == 0) o = a.i8 ? (short)((yr & 0xff) | ((yi & 0xff) << 8)) : (short)yr;   // index 0 is never written by FMDemod (in place; int8 chain: the 2 bytes of in[0])
       else o = (short)((q == 1 ? (int)a.fm_old[c] : prev) - phi);   // y[0] is never looked at
       if (own && emits && q == a.n_out - 1 && a.n_out >= 2) a.fm_new[c] = (short)phi;
     }

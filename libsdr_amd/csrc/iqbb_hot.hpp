@@ -45,12 +45,14 @@ namespace sdrhip {
 // ---- geometry shared by host and device ----------------------------------------------------------------------
 // input kinds: complex<int16> (one dword per sample), complex<uint8> (AutoCast fused), real int16 (BaseBand<int16_t>: the
 // element stream is the sample stream itself — a block advances by 16 elements instead of 32, a tap row by 1 instead of 2)
-enum { HOT_CS16 = 0, HOT_CU8 = 1, HOT_REAL = 2 };
+// ... and complex<int8> (IQBaseBand<int8_t>, src/sdr.hh:225-240's chain: the sample IS one signed byte plane — no conversion at all)
+enum { HOT_CS16 = 0, HOT_CU8 = 1, HOT_REAL = 2, HOT_CS8 = 3 };
+constexpr bool hot_one_plane(int in) { return in == HOT_CU8 || in == HOT_CS8; }
 constexpr int hot_halo(int S, int in) { return in == HOT_REAL ? 32 * S - 16 : 16 * (S - 1); }   // samples before the slice's first one
 constexpr int hot_win(int S, int in) { return 512 + hot_halo(S, in) + (in == HOT_REAL ? 16 : 0); }   // samples in a wave window (real: whole 16-byte pieces)
 // bytes per byte plane: complex kinds 2 per sample (+ one chunk pair: both parity halves 16-byte aligned), real 1 per sample
 constexpr int hot_plb(int S, int in) { return in == HOT_REAL ? hot_win(S, in) : 2 * hot_win(S, in) + 32; }
-constexpr int hot_bufb(int S, int in) { return in == HOT_CU8 ? hot_plb(S, in) : 2 * hot_plb(S, in); }   // one window buffer
+constexpr int hot_bufb(int S, int in) { return hot_one_plane(in) ? hot_plb(S, in) : 2 * hot_plb(S, in); }   // one window buffer
 // -DK1_PAIR (tuning variant, D = 8, complex<int16>, 4-wave workgroups; build with -DK1_MINWAVES=2, run with
 // SDRHIP_IQBB_WGPCU=2): a wave works on TWO slices at a time — consecutive tiles of its unit — so that one read of a tap
 // fragment feeds the MFMAs of both (6 accumulators, 4 window buffers per wave, 2 waves per SIMD)
@@ -122,6 +124,8 @@ void hot_launch_s33_cs16(int range, bool rot, int epi, const HotLaunch &, const 
 void hot_launch_s33_cu8(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
 void hot_launch_anyd33_cs16(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
 void hot_launch_anyd33_cu8(int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
+void hot_launch_cs8(int S, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);        // complex<int8>: S = 2, 3, 5 or 9; no demodulator or FM
+void hot_launch_anyd_cs8(int S, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
 void hot_launch_real(int S, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);   // S = 3, 5 or 9
 // real input at any other decimation: the any-D form (9 ... 512) and the small-decimation form (1 ... 7; 0: its LDS does not fit)
 void hot_launch_real_anyd(int S, int range, bool rot, int epi, const HotLaunch &, const HotArgs &, const IqbbArgs &);
@@ -204,7 +208,12 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   const IqbbArgs &b = LATE_B ? b_late : b_kernarg;
   HotArgs a_late;                                        // (K1_LATE_A: likewise the cold phase's copy of `a`; off — it left 8 to
   const HotArgs &ac = LATE_A ? a_late : a;               //  24 bytes of scratch in a dozen any-D kernels for -0.8 % in the others)
-  constexpr bool CU8 = IN == HOT_CU8, REAL = IN == HOT_REAL;
+  // CU8: ONE byte plane per sample (complex<uint8> after AutoCast: the high plane; complex<int8>: the sample itself) — two MFMAs
+  // per K step, no low-plane accumulator. CS8 marks what differs for IQBaseBand<int8_t>: no plane conversion, the FIR value is
+  // (hh << 8) + mid wrapped to int16 after the shift (src/baseband.hh:206), the rotation wraps to int16 and shifts by 8
+  // (src/freqshift.hh:58-74, Traits<int8_t>::shift), outputs are int8.
+  constexpr bool CS8 = IN == HOT_CS8, CU8 = IN == HOT_CU8 || CS8, REAL = IN == HOT_REAL;
+  static_assert(!CS8 || (!SD && EPI != HOT_EPI_PARTIAL && (EPI == SDRHIP_EPI_NONE || EPI == SDRHIP_EPI_FM)), "int8 chain: /8 and any-D forms, no demodulator or FM");
   // PART (with DG): decimations above 512 — a group no longer fits a slice. The kernel runs the any-D form's geometry of
   // "decimation 512" from the call's first sample on (one pseudo-group per slice, cold slices where the window leaves the
   // call) and a slice, instead of finishing groups, leaves the sums of its stretches between the REAL group boundaries
@@ -291,7 +300,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   // by the instruction's immediate offset, which applies to the global AND the LDS address alike.
   const uint32_t lane_byte = 16u * (uint32_t)l;
   constexpr int SB = IN == HOT_CS16 ? 4 : 2;                   // bytes per input sample
-  constexpr int OB = EPI == SDRHIP_EPI_NONE ? 4 : 2;           // bytes per output element
+  constexpr int OB = (EPI == SDRHIP_EPI_NONE && !CS8) ? 4 : 2;   // bytes per output element (int8 chain: complex<int8>)
   const int tile_in_bytes = a.OG * DD * SB, tile_out_bytes = a.OG * OB;
   const uint32_t tile_cnt = (uint32_t)(a.OG * DD) * a.inc;      // LUT phase counter advance per tile
   const uint32_t cnt0 = (a.n0_lo + (uint32_t)(a.base0_rel + (gw - a.ovl) * DD)) * a.inc;   // ... of the wave's first sample in tile 0
@@ -388,7 +397,9 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
 #pragma unroll
     for (int k = 0; k < NDMA; k++) {
       if (k < NDMA - 1 || l < LASTL) {
-        if (CU8) {   // AutoCast: high byte (b + 129) mod 256, low byte 0 (no low plane at all)
+        if (CS8) {   // (the bytes are the plane: only their place changes)
+          *reinterpret_cast<uint4 *>(cb + dofs[k]) = x[k];
+        } else if (CU8) {   // AutoCast: high byte (b + 129) mod 256, low byte 0 (no low plane at all)
           *reinterpret_cast<uint4 *>(cb + dofs[k]) = make_uint4(add129_rot(x[k].x), add129_rot(x[k].y), add129_rot(x[k].z), add129_rot(x[k].w));
         } else {
           uint2 l2, h2;
@@ -668,7 +679,10 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       unsigned tre = ((unsigned)acc_hh[2 * j] << 8) + (unsigned)acc_mid[2 * j];   // (compiler code: it pads the MFMA -> VALU hazard)
       unsigned tim = ((unsigned)acc_hh[2 * j + 1] << 8) + (unsigned)acc_mid[2 * j + 1];
       int rr, ri;
-      if (CU8) {   // S = t << 8 exactly (mod 2^32): S >> 14 = bits 6 .. 23 of t, sign-extended — one bit-field extract
+      if (CS8) {   // S = t exactly; the int16 the reference's complex<int32> -> complex<int16> conversion leaves of S >> 14
+        asm("v_bfe_i32 %0, %1, 14, 16" : "=v"(rr) : "v"(tre));
+        asm("v_bfe_i32 %0, %1, 14, 16" : "=v"(ri) : "v"(tim));
+      } else if (CU8) {   // S = t << 8 exactly (mod 2^32): S >> 14 = bits 6 .. 23 of t, sign-extended — one bit-field extract
         // (as an instruction: the builtin came out as a shift pair — 16 vector instructions more per slice in kernels
         // that are bound by vector issue)
         asm("v_bfe_i32 %0, %1, 6, 18" : "=v"(rr) : "v"(tre));
@@ -682,9 +696,14 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
         if (rel < 0 || rel >= a.N) { rr = 0; ri = 0; }
       }
       if (ROT) {
-        const int x = WIDE ? mad24a(L[j][0], rr, mul24a(L[j][2], ri)) : sub32(mul24a(L[j][0], rr), mul24a(L[j][1], ri));
-        const int y = mad24a(L[j][0], ri, mul24a(L[j][1], rr));
+        int x = WIDE ? mad24a(L[j][0], rr, mul24a(L[j][2], ri)) : sub32(mul24a(L[j][0], rr), mul24a(L[j][1], ri));
+        int y = mad24a(L[j][0], ri, mul24a(L[j][1], rr));
+        if (CS8) {   // the product wraps to int16 and is shifted by Traits<int8_t>::shift = 8: bits 8 .. 15, sign-extended
+          asm("v_bfe_i32 %0, %1, 8, 8" : "=v"(x) : "v"(x));
+          asm("v_bfe_i32 %0, %1, 8, 8" : "=v"(y) : "v"(y));
+        }
         if (DG) { vx[j] = x; vy[j] = y; }
+        else if (CS8) { sum.x += x; sum.y += y; }
         else { sum.x = add_hi16(x, sum.x); sum.y = add_hi16(y, sum.y); }
       } else if (DG) {
         vx[j] = rr; vy[j] = ri;
@@ -725,8 +744,8 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       if (ROT) {
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) {
-          px[jj] = (int)__builtin_amdgcn_perm((unsigned)vx[2 * jj + 1], (unsigned)vx[2 * jj], 0x07060302u);
-          py[jj] = (int)__builtin_amdgcn_perm((unsigned)vy[2 * jj + 1], (unsigned)vy[2 * jj], 0x07060302u);
+          px[jj] = (int)__builtin_amdgcn_perm((unsigned)vx[2 * jj + 1], (unsigned)vx[2 * jj], CS8 ? 0x05040100u : 0x07060302u);   // (int8 chain: the values themselves)
+          py[jj] = (int)__builtin_amdgcn_perm((unsigned)vy[2 * jj + 1], (unsigned)vy[2 * jj], CS8 ? 0x05040100u : 0x07060302u);
         }
         auto dsum = [&](const int *p4, unsigned m0, unsigned m1, unsigned m2, unsigned m3) __attribute__((always_inline)) {
           int acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, p4[0]), __builtin_bit_cast(s16x2, m0), 0, false);
@@ -877,10 +896,13 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
     const int2 sum = pend[min(l, 63)];
     asm volatile("" ::: "memory");
     const bool live = l < npend;
-    const int yr = div_d(sum.x), yi = div_d(sum.y);
+    int yr = div_d(sum.x), yi = div_d(sum.y);
+    if (CS8) { yr = (signed char)yr; yi = (signed char)yi; }   // (the int8 node's output type)
     // group k_f of tile ptile0 + j_f: output index (ptile0 + j_f) * OG + gw + k_f of the channel's row (outb points at gw)
     char *orow = outb + ((long)(ptile0 + j_f) * a.OG + k_f) * OB;
-    if (EPI == SDRHIP_EPI_NONE) {
+    if (EPI == SDRHIP_EPI_NONE && CS8) {
+      if (live) *reinterpret_cast<uint16_t *>(orow) = (uint16_t)((yr & 0xff) | ((yi & 0xff) << 8));
+    } else if (EPI == SDRHIP_EPI_NONE) {
       if (live) *reinterpret_cast<uint32_t *>(orow) = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
     } else if (EPI == SDRHIP_EPI_AM) {
       const short o = am_i16(yr, yi);
@@ -1030,8 +1052,11 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
     const int glw = 2 * n + h;
     // libstdc++'s (s*8)/(8*8) (src/baseband.hh:214): |s| <= 9 * 2^17 (a window of 16-bit rotated values, or of 18-bit FIR
     // values when there is no shift), so nothing wraps and it is trunc(s / 8) + the int16 wrap of the assignment
-    const int yr = div8_i16(sum.x), yi = div8_i16(sum.y);
-    if (EPI == SDRHIP_EPI_NONE) {
+    int yr = div8_i16(sum.x), yi = div8_i16(sum.y);
+    if (CS8) { yr = (signed char)yr; yi = (signed char)yi; }   // (the int8 node's output type)
+    if (EPI == SDRHIP_EPI_NONE && CS8) {
+      if (glw >= glw_lo) reinterpret_cast<uint16_t *>(orow)[glw] = (uint16_t)((yr & 0xff) | ((yi & 0xff) << 8));
+    } else if (EPI == SDRHIP_EPI_NONE) {
       if (glw >= glw_lo) reinterpret_cast<uint32_t *>(orow)[glw] = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
     } else if (EPI == SDRHIP_EPI_AM) {
       const short o = am_i16(yr, yi);
@@ -1223,8 +1248,11 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
     }
     const bool emits = lead && q < b.n_out;
     if (lead && q == b.n_groups - 1) b.acc_new[cc] = emits ? make_int2(0, 0) : sum;
-    const int yr = div_d(sum.x), yi = div_d(sum.y);
-    if (EPI == SDRHIP_EPI_NONE) {
+    int yr = div_d(sum.x), yi = div_d(sum.y);
+    if (CS8) { yr = (signed char)yr; yi = (signed char)yi; }   // (the int8 node's output type)
+    if (EPI == SDRHIP_EPI_NONE && CS8) {
+      if (emits) reinterpret_cast<uint16_t *>(ac.out)[(long)cc * ac.out_stride + q] = (uint16_t)((yr & 0xff) | ((yi & 0xff) << 8));
+    } else if (EPI == SDRHIP_EPI_NONE) {
       if (emits) reinterpret_cast<uint32_t *>(ac.out)[(long)cc * ac.out_stride + q] = ((uint32_t)(uint16_t)yr) | ((uint32_t)(uint16_t)yi << 16);
     } else if (EPI == SDRHIP_EPI_AM) {
       const short o = am_i16(yr, yi);
@@ -1236,7 +1264,8 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       const int phi = fm_phi(yr, yi);
       const int prev = __builtin_amdgcn_ds_bpermute(4 * (((k - 1) << lsh) & 63), phi);   // the leader of team k - 1
       short o;
-      if (q == 0) o = (short)yr;                                   // index 0 is never written by FMDemod (in place)
+      if (q == 0) o = CS8 ? (short)((yr & 0xff) | ((yi & 0xff) << 8))   // FMDemod<int8_t,int16_t> in place: out[0] = the 2 bytes of in[0]
+                          : (short)yr;                             // index 0 is never written by FMDemod (in place)
       else if (q == 1) o = (short)((int)b.fm_old[cc] - phi);       // y[0] is never looked at: the previous call's last angle
       else o = (short)((k > 0 ? prev : 0) - phi);                  // (a slice's first group: the fix-up launch adds philast)
       if (HS_ON(ac)) {   // (kernel-uniform)
@@ -1335,17 +1364,19 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
             for (int j = 0; j < 8; j++) {
               const int rel = first + 8 * pp + j;
               // the sample's two high-plane bytes: AutoCast of the input bytes, or bytes 1 and 3 of a history dword
-              uint32_t hb = ((v[k][j] + 0x81u) & 0xffu) | ((v[k][j] + 0x8100u) & 0xff00u);
+              // (int8 chain: the input bytes themselves, or bytes 0 and 2 of a history dword — the sign-extended pair)
+              uint32_t hb = CS8 ? v[k][j] : ((v[k][j] + 0x81u) & 0xffu) | ((v[k][j] + 0x8100u) & 0xff00u);
               if (rel >= ac.N) hb = 0u;
               if (first < 0) {   // (wave-uniform: only the call's first slices reach into the history)
                 const uint32_t xh = hrow[max(b.HH + rel, 0)];
-                if (rel < 0) hb = (b.HH + rel >= 0) ? (((xh >> 8) & 0xffu) | ((xh >> 16) & 0xff00u)) : 0u;
+                if (rel < 0) hb = (b.HH + rel >= 0) ? (CS8 ? ((xh & 0xffu) | ((xh >> 8) & 0xff00u)) : (((xh >> 8) & 0xffu) | ((xh >> 16) & 0xff00u))) : 0u;
               }
               v[k][j] = hb;
             }
-            if (k < NDMA - 1 || l < LASTL)   // (the hot loop's byte order inside a dword: add129_rot)
-              *reinterpret_cast<uint4 *>(cb + dofs[k]) = make_uint4(ror8(v[k][0] | (v[k][1] << 16)), ror8(v[k][2] | (v[k][3] << 16)),
-                                                                    ror8(v[k][4] | (v[k][5] << 16)), ror8(v[k][6] | (v[k][7] << 16)));
+            auto rotb = [](uint32_t d) __attribute__((always_inline)) { return CS8 ? d : ror8(d); };   // (complex<uint8>: the hot loop's byte order inside a dword, add129_rot)
+            if (k < NDMA - 1 || l < LASTL)
+              *reinterpret_cast<uint4 *>(cb + dofs[k]) = make_uint4(rotb(v[k][0] | (v[k][1] << 16)), rotb(v[k][2] | (v[k][3] << 16)),
+                                                                    rotb(v[k][4] | (v[k][5] << 16)), rotb(v[k][6] | (v[k][7] << 16)));
           }
         } else {
           const uint32_t *row = reinterpret_cast<const uint32_t *>(ac.in) + (long)cc * ac.in_stride;
@@ -1417,7 +1448,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
           else if (!PART) cold_finish_gen(sum, cc, 4 * t + wv);
         } else {
           const int tb = ac.base0_rel + q0 * 8, rel0 = tb + 8 * gw + MF_BLK * n + 8 * h;
-          const int2 sum = group_sum<ROT, CU8, true, WIDE ? 2 : 1, FSH>(b, acc_hh, acc_mid, acc_ll, rel0);
+          const int2 sum = group_sum<ROT, CU8, true, WIDE ? 2 : 1, FSH, CS8>(b, acc_hh, acc_mid, acc_ll, rel0);
           group_finish(b, b.lut, cc, n, h, gw, q0, groups_here, sum);   // (its one table user, the stream's first sample, reads global memory)
         }
         asm volatile("" ::: "memory");
@@ -1532,7 +1563,7 @@ template <int S, int S0, int NH, int IN, int NW>
 void hot_launch_one(bool rot, int epi, const HotLaunch &hl, const HotArgs &ha, const IqbbArgs &b) {
   constexpr bool PAIR = hot_pair(IN, NW, false);
   const size_t lds = (size_t)hot_lds_bytes(S, NH, IN, NW, hot_wide(S, NH, IN, NW, 0, PAIR), PAIR);
-  if (lds > 64 * 1024) {   // (the pair variant's four window buffers per wave)
+  if constexpr (IN != HOT_CS8) if (lds > 64 * 1024) {   // (the pair variant's four window buffers per wave; long filters)
     static std::atomic<uint64_t> attr_set{0};
     once_per_device(attr_set, [&] {
 #define SDRHIP_HOT_ATTR(R_, E_) SDRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&iqbb_hot_kernel<S, S0, NH, R_, E_, IN, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
@@ -1545,8 +1576,8 @@ void hot_launch_one(bool rot, int epi, const HotLaunch &hl, const HotArgs &ha, c
 #define SDRHIP_HOT(R_, E_) hipLaunchKernelGGL((iqbb_hot_kernel<S, S0, NH, R_, E_, IN, NW>), grid, block, lds, hl.stream, ha, b)
 #define SDRHIP_HOT_E(R_) do { switch (epi) { \
     case SDRHIP_EPI_FM: SDRHIP_HOT(R_, SDRHIP_EPI_FM); break; \
-    case SDRHIP_EPI_AM: SDRHIP_HOT(R_, SDRHIP_EPI_AM); break; \
-    case SDRHIP_EPI_USB: SDRHIP_HOT(R_, SDRHIP_EPI_USB); break; \
+    case SDRHIP_EPI_AM: if constexpr (IN != HOT_CS8) SDRHIP_HOT(R_, SDRHIP_EPI_AM); break; \
+    case SDRHIP_EPI_USB: if constexpr (IN != HOT_CS8) SDRHIP_HOT(R_, SDRHIP_EPI_USB); break; \
     default: SDRHIP_HOT(R_, SDRHIP_EPI_NONE); break; } } while (0)
   if (rot) SDRHIP_HOT_E(true); else SDRHIP_HOT_E(false);
 #undef SDRHIP_HOT_E
@@ -1558,7 +1589,7 @@ void hot_launch_anyd_one(bool rot, int epi, const HotLaunch &hl, const HotArgs &
   const int extra = hot_anyd_extra(S, IN, rot, NW);
   const size_t lds = (size_t)hot_lds_bytes(S, NH, IN, NW, hot_wide(S, NH, IN, NW, extra)) + extra;
   static_assert(hot_lds_bytes(S, NH, IN, NW, false) + hot_anyd_extra(S, IN, false, NW) <= 163840, "any-D form: a workgroup's LDS");
-  if (NW > 4) {   // (beyond 64 KB of dynamic LDS: once per DEVICE and kernel)
+  if constexpr (IN != HOT_CS8) if (NW > 4) {   // (beyond 64 KB of dynamic LDS: once per DEVICE and kernel)
     static std::atomic<uint64_t> attr_set{0};
     once_per_device(attr_set, [] {
 #define SDRHIP_ANYD_ATTR(R_, E_) SDRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&iqbb_hot_anyd_kernel<S, S0, NH, R_, E_, IN, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, hot_lds_cap(NW, false, S) + hot_anyd_extra(S, IN, false, NW) > 163840 ? 163840 : hot_lds_cap(NW, false, S) + hot_anyd_extra(S, IN, false, NW)))
@@ -1572,9 +1603,9 @@ void hot_launch_anyd_one(bool rot, int epi, const HotLaunch &hl, const HotArgs &
 #define SDRHIP_ANYD(R_, E_) hipLaunchKernelGGL((iqbb_hot_anyd_kernel<S, S0, NH, R_, E_, IN, NW>), grid, block, lds, hl.stream, ha, b)
 #define SDRHIP_ANYD_E(R_) do { switch (epi) { \
     case SDRHIP_EPI_FM: SDRHIP_ANYD(R_, SDRHIP_EPI_FM); break; \
-    case SDRHIP_EPI_AM: SDRHIP_ANYD(R_, SDRHIP_EPI_AM); break; \
-    case SDRHIP_EPI_USB: SDRHIP_ANYD(R_, SDRHIP_EPI_USB); break; \
-    case HOT_EPI_PARTIAL: if constexpr (IN != HOT_REAL) SDRHIP_ANYD(R_, HOT_EPI_PARTIAL); break; \
+    case SDRHIP_EPI_AM: if constexpr (IN != HOT_CS8) SDRHIP_ANYD(R_, SDRHIP_EPI_AM); break; \
+    case SDRHIP_EPI_USB: if constexpr (IN != HOT_CS8) SDRHIP_ANYD(R_, SDRHIP_EPI_USB); break; \
+    case HOT_EPI_PARTIAL: if constexpr (IN != HOT_REAL && IN != HOT_CS8) SDRHIP_ANYD(R_, HOT_EPI_PARTIAL); break; \
     default: SDRHIP_ANYD(R_, SDRHIP_EPI_NONE); break; } } while (0)
   if (rot) SDRHIP_ANYD_E(true); else SDRHIP_ANYD_E(false);
 #undef SDRHIP_ANYD_E

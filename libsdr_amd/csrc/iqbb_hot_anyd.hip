@@ -6,6 +6,7 @@
 namespace sdrhip {
 void hot_launch_anyd(int S, int in, int range, bool rot, int epi, const HotLaunch &hl, const HotArgs &ha, const IqbbArgs &b) {
   if (in == HOT_REAL) { hot_launch_real_anyd(S, range, rot, epi, hl, ha, b); return; }
+  if (in == HOT_CS8) { hot_launch_anyd_cs8(S, range, rot, epi, hl, ha, b); return; }
   const bool cu8 = in == HOT_CU8;
   if (S == 2) {
     if (cu8) hot_launch_anyd_one<2, 0, 2, HOT_CU8>(rot, epi, hl, ha, b); else hot_launch_anyd_one<2, 0, 2, HOT_CS16>(rot, epi, hl, ha, b);

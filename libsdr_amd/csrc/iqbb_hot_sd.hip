@@ -5,6 +5,7 @@
 namespace sdrhip {
 int hot_launch_sd(int S, int in, int range, bool rot, int epi, const HotLaunch &hl, const HotArgs &ha, const IqbbArgs &b, bool dry) {
   if (in == HOT_REAL) return hot_launch_real_sd(S, range, rot, epi, hl, ha, b, dry);
+  if (in == HOT_CS8) return 0;   // (the int8 chain has no small-decimation form: the VALU kernel)
   const bool cu8 = in == HOT_CU8;
   if (S == 2) {
     return cu8 ? hot_launch_sd_one<2, 0, 2, HOT_CU8>(rot, epi, hl, ha, b, dry) : hot_launch_sd_one<2, 0, 2, HOT_CS16>(rot, epi, hl, ha, b, dry);

@@ -788,6 +788,7 @@ namespace {
 // the hot kernels live in one translation unit per filter-length class (iqbb_hot_s*.hip)
 void launch_hot(int S, int in, int range, bool rot, int epi, const HotLaunch &hl, const HotArgs &ha, const IqbbArgs &b) {
   if (in == HOT_REAL) { hot_launch_real(S, range, rot, epi, hl, ha, b); return; }
+  if (in == HOT_CS8) { hot_launch_cs8(S, range, rot, epi, hl, ha, b); return; }
   const bool cu8 = in == HOT_CU8;
   switch (S) {
     case 2: hot_launch_s2(in, range, rot, epi, hl, ha, b); break;
@@ -983,7 +984,7 @@ struct sdrhip_iqbb_i16 {
   // false: the call is too short to have a tile of hot slices; the general kernel runs it.
   bool launch_hot_call(IqbbArgs &a, const Geometry &g, const uint32_t *in_dev, size_t N, size_t in_stride, void *out_dev,
                        size_t out_stride, int tiles) {
-    const int kind = real ? HOT_REAL : in_cu8 ? HOT_CU8 : HOT_CS16, halo = hot_halo(S, kind), win = hot_win(S, kind);
+    const int kind = hot_kind(), halo = hot_halo(S, kind), win = hot_win(S, kind);
     auto host_hot = [&](int t, int w) { return slice_is_hot(halo, win, g.base0_rel, OG, ovl, (int)N, g.n_out, t, w); };
     long t = tiles - 1;   // the last tile always holds cold slices (history roll, state)
     while (t >= 2 && !(host_hot((int)t - 1, 0) && host_hot((int)t - 1, 1) && host_hot((int)t - 1, 2) && host_hot((int)t - 1, 3))) t--;
@@ -1078,17 +1079,18 @@ struct sdrhip_iqbb_i16 {
   // virtual (4-wave) workgroups per CU of the persistent grids: 4 = four waves per SIMD; the 33-step class (orders 258 ... 513) runs
   // one 8-wave workgroup per CU (SDRHIP_IQBB_WGPCU: tuning hook)
   int wgpcu() const { return env_wgpcu ? env_wgpcu : S >= 33 ? 2 : 4; }
-  bool long_filter() const { return (path == 1 || path == 3) && S >= 33; }   // no general MFMA kernel: short calls run the VALU kernel
+  bool long_filter() const { return (path == 1 || path == 3) && (S >= 33 || i8); }   // no general MFMA kernel (orders 258 ... 513; the int8 chain): short calls run the VALU kernel
   bool channel_units() const {
     if (env_fm_resident >= 0) return env_fm_resident != 0;   // tuning / test hook (SDRHIP_IQBB_FM_RESIDENT=0|1)
     const size_t nvwg = (size_t)wgpcu() * (size_t)ctx->prop.multiProcessorCount, rounds = ceil_div((size_t)C, nvwg);
     return (size_t)C * 100 >= rounds * nvwg * 97;
   }
   bool real_anyd() const { return path == 4 && D != R; }   // real input at a decimation other than 8: the any-D forms of the hot kernel
-  int hot_kind() const { return real ? HOT_REAL : in_cu8 ? HOT_CU8 : HOT_CS16; }
+  int hot_kind() const { return real ? HOT_REAL : i8 ? HOT_CS8 : in_cu8 ? HOT_CU8 : HOT_CS16; }
   bool anyd_plan() const {
-    if (!(((path == 3 && !i8 && !real) || real_anyd()) && use_hot && hot_range >= 0 && S <= 33)) return false;
+    if (!(((path == 3 && !real) || real_anyd()) && use_hot && hot_range >= 0 && S <= 33)) return false;
     if (D >= 9 && D <= 512) return true;
+    if (i8) return false;   // (the int8 chain: decimation 8 and 9 ... 512 on the matrix cores)
     // decimations 1 ... 7: the small-decimation form, where its sample arrays fit a workgroup's LDS (iqbb_hot.hpp, SD, hot_sd_nw)
     return D >= 1 && D <= 7 && hot_launch_sd(S, hot_kind(), hot_range, inc != 0, epi, HotLaunch{0, nullptr}, HotArgs{}, IqbbArgs{}, true) != 0;
   }
@@ -1359,7 +1361,9 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
       { const char *d = getenv("SDRHIP_IQBB_HOT"); if (d && d[0] == '0') h->use_hot = false; }
       // (orders 258 ... 513: the hot kernel's 33-step class only — no general matrix kernel; SDRHIP_IQBB_HOT=0 leaves them the VALU kernel)
       const int mfma_max_order = h->use_hot ? 513 : 257;
-      bool mfma_ok = !real && !i8 && (decim == R) && (order <= mfma_max_order);
+      // (IQBaseBand<int8_t>: hot forms only, up to 129 taps, decimation 8 and 9 ... 512)
+      const bool i8_hot = i8 && h->use_hot && order <= 129;
+      bool mfma_ok = !real && (!i8 || i8_hot) && (decim == R) && (order <= mfma_max_order);
       auto high_byte = [](int v) { const int al = ((v + 128) & 255) - 128; return (v - al) >> 8; };
       for (int i = 0; i < 2 * order && mfma_ok; i++)   // both v and -v are packed (Kr, -Ki / Ki, Kr)
         if (high_byte(taps[i]) > 127 || high_byte(-taps[i]) > 127) mfma_ok = false;
@@ -1371,7 +1375,7 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
       if (force && !strcmp(force, "valu")) mfma_ok = false;
       h->path = mfma_ok ? 1 : 0;
       // path 3: the same matrix part for any decimation (measured ahead of the VALU kernel at every order tried, 9 ... 257 taps)
-      bool mfmag_ok = !real && !i8 && decim != R && order <= mfma_max_order && (order <= 257 || decim >= 9);   // (the 33-step class has no small-decimation form)
+      bool mfmag_ok = !real && (!i8 || (i8_hot && decim >= 9 && decim <= 512)) && decim != R && order <= mfma_max_order && (order <= 257 || decim >= 9);   // (the 33-step class has no small-decimation form)
       for (int i = 0; i < 2 * order && mfmag_ok; i++)
         if (high_byte(taps[i]) > 127 || high_byte(-taps[i]) > 127) mfmag_ok = false;
       if (force && !strcmp(force, "valu")) mfmag_ok = false;
@@ -1393,7 +1397,7 @@ int create_baseband(sdrhip_ctx *ctx, const int32_t *taps, int order, const int32
         h->OP = decim == R ? 32 * h->S - 15 : (int)ceil_div((size_t)order, (size_t)TAPC) * TAPC;   // (other decimations: the VALU kernel's tap chunks)
       } else if (h->path == 1 || h->path == 3) {
         h->S = order <= 17 ? 2 : order <= 33 ? 3 : order <= 65 ? 5 : order <= 129 ? 9 : order <= 257 ? 17 : 33;
-        h->OP = h->S >= 33 ? (int)ceil_div((size_t)order, (size_t)TAPC) * TAPC : 16 * (h->S - 1) + 1;   // (33 steps: the VALU kernel's tap chunks — it runs the short calls)
+        h->OP = (h->S >= 33 || i8) ? (int)ceil_div((size_t)order, (size_t)TAPC) * TAPC : 16 * (h->S - 1) + 1;   // (33 steps, int8 chain: the VALU kernel's tap chunks — it runs the short calls)
       } else {
         h->OP = (int)ceil_div((size_t)order, (size_t)TAPC) * TAPC;
       }

@@ -395,7 +395,13 @@ def test_iqbb_path_selection(ctx, golden, monkeypatch):
     assert sa.IQBaseBandI16(ctx, taps, lut, 1365, 0, 5).path == 3          # other decimations, long filter -> MFMA + LDS windows
     assert sa.IQBaseBandI16(ctx, golden.load("g8_o21_d3_taps"), lut, 1365, 0, 3).path == 3
     assert sa.IQBaseBandI16(ctx, golden.load("g8_o255_d8_taps"), lut, 1365, 0, 8).path == 1   # 17 K steps
-    assert sa.IQBaseBandI16(ctx, sa.design_iqbb_taps(100e3, 50e3, FS, 300), lut, 1365, 0, 8).path == 0   # order > 257
+    long300 = sa.IQBaseBandI16(ctx, sa.design_iqbb_taps(100e3, 50e3, FS, 300), lut, 1365, 0, 8)   # orders 258 ... 513: 33 K steps, hot forms only
+    assert long300.path == 1 and long300.plan_info["S"] == 33 and long300.kernel_names == ["iqbb_hot_kernel"]
+    assert sa.IQBaseBandI16(ctx, sa.design_iqbb_taps(100e3, 50e3, FS, 300), lut, 1365, 0, 4).path == 0    # ... and no small-decimation form
+    assert sa.IQBaseBandI16(ctx, sa.design_iqbb_taps(100e3, 50e3, FS, 600), lut, 1365, 0, 8).path == 0    # order > 513
+    monkeypatch.setenv("SDRHIP_IQBB_HOT", "0")
+    assert sa.IQBaseBandI16(ctx, sa.design_iqbb_taps(100e3, 50e3, FS, 300), lut, 1365, 0, 8).path == 0    # (no general matrix kernel for that class)
+    monkeypatch.delenv("SDRHIP_IQBB_HOT")
     big = np.array(taps).reshape(-1, 2).copy(); big[5, 0] = 32700          # high byte would not fit int8
     assert sa.IQBaseBandI16(ctx, big, lut, 1365, 0, 8).path == 0
     monkeypatch.setenv("SDRHIP_IQBB_PATH", "valu")
@@ -452,6 +458,38 @@ def test_iqbb_i8_batched_random_vs_oracle(ctx, orc):
                 r = refs[c][1].process(r) if len(r) else np.zeros(0, np.int16)
                 assert np.array_equal(y[c], r), (order, D, c, n)
             off += n
+
+
+@pytest.mark.parametrize("epi", [sa.EPI_NONE, sa.EPI_FM])
+@pytest.mark.parametrize("order,decim,Fc", [(16, 24, 0.0), (21, 8, 100e3), (127, 8, -250e3), (64, 8, 0.0), (129, 8, 100e3), (16, 10, 0.0), (21, 125, 100e3),
+                                             (33, 62, -60e3), (100, 300, 41e3), (127, 9, 100e3), (9, 512, 0.0), (130, 8, 100e3), (21, 5, 100e3)])
+def test_iqbb_i8_long_calls_vs_oracle(ctx, orc, order, decim, Fc, epi, monkeypatch):
+    """IQBaseBand<int8_t> (-> FMDemod<int8_t,int16_t>) on the matrix cores: the complex<int8> sample IS one signed byte plane, so
+    the hot kernels take it without any conversion — decimation 8 and 9 ... 512, up to 129 taps (the reference's documented chain,
+    src/sdr.hh:225-240, is 16 taps unshifted at 2.4 MS/s -> 100 kS/s: decimation 24); everything else, and the calls too short for a
+    hot tile, the VALU kernel. Ragged long and short calls of full-scale random bytes, state carried."""
+    monkeypatch.delenv("SDRHIP_IQBB_HOT", raising=False)
+    monkeypatch.delenv("SDRHIP_IQBB_PATH", raising=False)
+    C = 3
+    rng = np.random.default_rng(order * 100 + decim)
+    taps, lut, inc = sa.design_iqbb_taps(Fc if Fc else 100e3, 50e3, FS, order), sa.design_freqshift_lut_i8(), sa.design_freqshift_inc(Fc, FS)
+    node = sa.IQBaseBandI8(ctx, taps, lut, inc, Fc < 0, decim, channels=C, max_in=70000, epilogue=epi)
+    on_matrix = order <= 129 and (decim == 8 or 9 <= decim <= 512)
+    if not on_matrix:
+        assert node.path == 0 and node.kernel_names == ["iqbb_i16_kernel"]
+    elif decim == 8:
+        assert node.path == 1 and node.kernel_names == ["iqbb_hot_kernel"]
+    else:
+        assert node.path == 3 and node.kernel_names[0] == "iqbb_hot_anyd_kernel"
+    refs = [(orc.IQBaseBandI8(taps, lut, inc, Fc < 0, decim), orc.FMDemodI8()) for _ in range(C)]
+    for n in (65536, 70000, 12345, 1, 40001, 2 * decim + 1, 0, 65535):
+        x = rng.integers(-128, 128, size=(C, n, 2)).astype(np.int8)
+        y = node.process(x)
+        for c in range(C):
+            r = refs[c][0].process(x[c])
+            if epi == sa.EPI_FM:
+                r = refs[c][1].process(r) if len(r) else np.zeros(0, np.int16)
+            assert y[c].shape == r.shape and np.array_equal(y[c], r), (n, c)
 
 
 class _GpuRetune:
