@@ -398,7 +398,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
     for (int k = 0; k < NDMA; k++) {
       if (k < NDMA - 1 || l < LASTL) {
         if (CS8) {   // (the bytes are the plane: only their place changes)
-          *reinterpret_cast<uint4 *>(cb + dofs[k]) = x[k];
+          *reinterpret_cast<uint4 *>(cb + dofs[k]) = make_uint4(x[k].x, x[k].y, x[k].z, x[k].w);   // (component-wise: the whole-struct copy went through scratch)
         } else if (CU8) {   // AutoCast: high byte (b + 129) mod 256, low byte 0 (no low plane at all)
           *reinterpret_cast<uint4 *>(cb + dofs[k]) = make_uint4(add129_rot(x[k].x), add129_rot(x[k].y), add129_rot(x[k].z), add129_rot(x[k].w));
         } else {
@@ -699,8 +699,8 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
         int x = WIDE ? mad24a(L[j][0], rr, mul24a(L[j][2], ri)) : sub32(mul24a(L[j][0], rr), mul24a(L[j][1], ri));
         int y = mad24a(L[j][0], ri, mul24a(L[j][1], rr));
         if (CS8) {   // the product wraps to int16 and is shifted by Traits<int8_t>::shift = 8: bits 8 .. 15, sign-extended
-          asm("v_bfe_i32 %0, %1, 8, 8" : "=v"(x) : "v"(x));
-          asm("v_bfe_i32 %0, %1, 8, 8" : "=v"(y) : "v"(y));
+          asm("v_bfe_i32 %0, %0, 8, 8" : "+v"(x));
+          asm("v_bfe_i32 %0, %0, 8, 8" : "+v"(y));
         }
         if (DG) { vx[j] = x; vy[j] = y; }
         else if (CS8) { sum.x += x; sum.y += y; }
