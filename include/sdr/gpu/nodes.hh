@@ -1054,7 +1054,7 @@ protected:
     // completed chunk of kChunk channels starts its H2D copy at once and the copies hide behind the memcpys of the chunks
     // that follow (measured through examples/bench_graph.cc: profiles/r18_host_path.txt)
     const size_t k = c / kChunk;
-    if (++_chunkHave[k] == std::min(kChunk, _C - k * kChunk)) _copyChunk(k);
+    if (++_chunkHave[k] == std::min<size_t>(kChunk, _C - k * kChunk)) _copyChunk(k);
     if (++_have < _C) return;
     _have = 0;
     std::fill(_pending.begin(), _pending.end(), false);
@@ -1094,7 +1094,7 @@ protected:
 
   /** H2D copy of the channels [k * kChunk, (k + 1) * kChunk) of the round being collected: each rank's part on that rank's stream. */
   void _copyChunk(size_t k) {
-    const size_t a = k * kChunk, b = std::min(_C, a + kChunk);
+    const size_t a = k * kChunk, b = std::min<size_t>(_C, a + kChunk);
     for (size_t r = 0; r < _ranks.size(); r++) {
       Rank &rk = _ranks[r];
       const size_t lo = std::max(a, rk.c0), hi = std::min(b, rk.c1);
@@ -1105,7 +1105,7 @@ protected:
     }
   }
 
-  static const size_t kChunk = 32;
+  enum { kChunk = 32 };   // channels per H2D chunk (an enumerator: no out-of-class definition needed when bound to a reference)
   std::vector<size_t> _chunkHave;
   bool _copyOk = true;
   size_t _C;

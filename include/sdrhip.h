@@ -138,13 +138,16 @@ int sdrhip_iqbb_i16_create(sdrhip_ctx *ctx, const int32_t *taps, int order, cons
                            uint32_t lut_inc, int negative, int decim, int channels, size_t max_in,
                            int epilogue, sdrhip_iqbb_i16 **out);
 /* which kernel formulation the plan selected: 0 = VALU v_dot2c_i32_i16 (any decim/order), 1 = int8-MFMA
- * block-Toeplitz GEMM on 32x32x32 tiles (decim 8, order <= 257; LDS-DMA fed, see kernel_names), 3 = the same matrix
- * part for any other decimation (order <= 257), 4 = the real-input node on the matrix cores; all bit-exact.
- * (2 was round 1's 16x16x64 shape, removed in round 4.) SDRHIP_IQBB_PATH=valu at create time selects the VALU kernel
- * for every plan (tests). */
+ * block-Toeplitz GEMM on 32x32x32 tiles (decim 8, order <= 513; LDS-DMA fed, see kernel_names), 3 = the same matrix
+ * part for any other decimation (order <= 257; 258 ... 513 from decimation 9 on), 4 = the real-input node on the matrix
+ * cores (any decimation up to 512, order <= 273); all bit-exact. Orders 258 ... 513 (33 K steps), the int8 chain
+ * (IQBaseBand<int8_t>, up to 129 taps, decimation 8 and 9 ... 512) and the real-input node at a decimation other than 8
+ * exist as forms of the hot kernel only: their calls too short to hold a hot tile — and, with SDRHIP_IQBB_HOT=0, the whole
+ * plan — run the VALU kernel. (2 was round 1's 16x16x64 shape, removed in round 4.) SDRHIP_IQBB_PATH=valu at create time
+ * selects the VALU kernel for every plan (tests). */
 int sdrhip_iqbb_i16_path(sdrhip_iqbb_i16 *h, int *path);
 /* Names of the kernels a call of this plan launches, dominant one first, comma separated (measurement aid: what to
- * look for in a rocprofv3 kernel trace). Path 1 (decim 8, order <= 257, complex<int16> or complex<uint8> input) runs
+ * look for in a rocprofv3 kernel trace). Path 1 (decim 8, order <= 513, complex<int16>, complex<uint8> or complex<int8> input) runs
  * ONE launch per call, "iqbb_hot_kernel": a persistent grid over the wave slices that touch no border of the call,
  * whose workgroups finish with the call's first and last slices, the state and the history roll (calls of fewer than
  * 3 tiles, about 6000 samples, run the general kernel "iqbb_i16_mfma_dma_kernel" / "iqbb_i16_mfma_kernel" instead).
@@ -157,6 +160,9 @@ int sdrhip_iqbb_i16_path(sdrhip_iqbb_i16 *h, int *path);
  * kernel emitting partial box sums per 512-sample slice + "iqbb_bigd_finish_kernel" (a group spans slices; beyond 2048,
  * with FM 1024, there is no general kernel: every call takes that form, and plans the hot kernel cannot serve — real or
  * int8 input, SDRHIP_IQBB_HOT=0 — are SDRHIP_E_UNSUPPORTED); other path 3 plans and short calls the general kernel "iqbb_i16_mfmag_kernel".
+ * The real-input node (path 4) runs "iqbb_hot_kernel" at decimation 8 and the same any-D / small-decimation forms at every other
+ * decimation up to 512 (round 6: the real-input tile hands every lane 8 consecutive samples, as the any-D forms' permuted
+ * complex tile does — one epilogue for both).
  * Tuning / test variables, all read at create time: SDRHIP_IQBB_HOT=0 (general kernels only), SDRHIP_IQBB_TPW (tiles per
  * work unit), SDRHIP_IQBB_WGPCU (workgroups per CU of the persistent grid), SDRHIP_IQBB_FM_RESIDENT=0|1 (FM at a
  * decimation other than 8: never / always whole channels as work units, i.e. the slices' first angle differences by a
