@@ -98,7 +98,9 @@ constexpr HotRange hot_ranges_3[] = {{1, 2, 4}, {0, 3, 4}};
 constexpr HotRange hot_ranges_5[] = {{1, 3, 4}, {0, 5, 4}};
 constexpr HotRange hot_ranges_9[] = {{3, 3, 4}, {2, 5, 4}, {1, 7, 4}, {0, 9, 4}};
 constexpr HotRange hot_ranges_17[] = {{6, 5, 8}, {4, 9, 8}, {0, 17, 16}};
-constexpr HotRange hot_ranges_33[] = {{12, 9, 8}, {8, 17, 8}, {0, 33, 8}};
+// (33 steps: the taps sit at the END of the 513-tap window — zero-padded at the front — so the steps that need the high plane
+// move with the order: 14 ... 18 at 513 taps, 17 ... 22 at 400, 20 ... 25 at 300, 22 ... 26 at 258)
+constexpr HotRange hot_ranges_33[] = {{12, 9, 8}, {16, 9, 8}, {18, 9, 8}, {8, 17, 8}, {0, 33, 8}};
 inline const HotRange *hot_ranges(int S, int *count) {
   switch (S) {
     case 2: *count = 1; return hot_ranges_2;
@@ -106,7 +108,7 @@ inline const HotRange *hot_ranges(int S, int *count) {
     case 5: *count = 2; return hot_ranges_5;
     case 9: *count = 4; return hot_ranges_9;
     case 17: *count = 3; return hot_ranges_17;
-    case 33: *count = 3; return hot_ranges_33;
+    case 33: *count = 5; return hot_ranges_33;
     default: *count = 0; return nullptr;
   }
 }

@@ -189,7 +189,7 @@ def test_eight_gpus_asked_of_a_smaller_box_is_one_error_line():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("workload", ["iqbb_fm", "iqbb_usb", "iqbb_fm_cu8", "bb_real_fm", "fir255_fm", "fbb_f32", "fftconv", "fftbank", "fm_demod", "subsample8"])
+@pytest.mark.parametrize("workload", ["iqbb_fm", "iqbb_usb", "iqbb_fm_cu8", "iqbb_fm_cs8", "bb_real_fm", "fir255_fm", "fir127_fm", "fbb_f32", "fftconv", "fftconv_ola", "fftbank", "fm_demod", "subsample8"])
 def test_every_workload_emits_its_line_and_verifies(workload):
     """Every `--workload` (the BASELINE configurations and the stand-alone kernels) runs on a small batch, prints one JSON
     line whose roofline names the kernel it timed, and the LAST timed step's output of the sampled channels equals the
@@ -331,3 +331,17 @@ def test_host_side_helpers_touch_no_gpu(tmp_path, monkeypatch):
     src = open(os.path.join(ROOT, "bench.py")).read()
     body = src[src.index("def spawn_ranks(a):"):src.index("def synth_cs16(")]
     assert "import torch" not in body and "libsdr_amd" not in body
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,extra", [("iqbb_fm", []), ("iqbb_usb", []), ("iqbb_fm_cu8", ["--order", "21", "--decim", "125", "--fs", "1e6", "--width", "12.5e3"]),
+                                            ("bb_real_fm", ["--decim", "20"]), ("bb_real_fm", [])])
+def test_multi_buffer_workloads_verify(workload, extra):
+    """`--buffers 4`: four reference-sized buffers per channel in ONE launch (sdrhip_iqbb_i16_process_dev_multi); the LAST buffer of
+    the last step against the oracle primed with the buffer before it — bit-exact, boundaries included."""
+    d = _bench(["--workload", workload, "--buffers", "4", "--batches", "2", "--channels", "16", "--samples", "32768", "--steps", "3", "--warmup", "2",
+                "--no-cpu-baseline", "--sustain-seconds", "0", "--verify-channels", "4"] + extra)
+    assert d["verified"] is True, d.get("verify")
+    assert "/B4/" in d["config"]["workload_key"] and d["config"]["samples_per_channel_per_step"] == 4 * 32768
+    if workload != "iqbb_usb":
+        assert d["roofline"]["kernels_per_step"][-1] == "iqbb_fm_multi_fixup_kernel"
