@@ -173,7 +173,9 @@ int sdrhip_iqbb_i16_kernel_names(sdrhip_iqbb_i16 *h, char *buf, size_t len);
  * 1 int8-MFMA at decimation 8, 3 int8-MFMA at any decimation, 4 real input on the matrix cores), info[1] = K steps S of 32
  * plane bytes per 512-sample slice, info[2], info[3] = first step and number of steps that also multiply the taps' high byte
  * plane, info[4] = waves per workgroup, info[5] = input kind (0 complex<int16>, 1 complex<uint8>, 2 real int16), info[6] =
- * padded filter length, info[7] = history samples kept per channel. n >= 8. */
+ * padded filter length, info[7] = history samples kept per channel. n >= 8; with n >= 9 also info[8] = the buffer boundaries the
+ * last one-launch sdrhip_iqbb_i16_process_dev_multi call left to its fix-up launch (0: the hot kernel wrote them all itself; -1: no
+ * such call yet). */
 int sdrhip_iqbb_i16_plan_info(sdrhip_iqbb_i16 *h, int *info, int n);
 /* outputs the next call of n_in samples will produce (does not advance the state) */
 int sdrhip_iqbb_i16_out_count(sdrhip_iqbb_i16 *h, size_t n_in, size_t *n_out);
@@ -189,7 +191,9 @@ int sdrhip_iqbb_i16_process_dev(sdrhip_iqbb_i16 *h, const int16_t *in_dev, size_
  * state runs on across buffers anyway (src/baseband.hh:198-219); the fused FMDemod starts every buffer anew (index 0 of a
  * buffer's output is the in-place value, index 1 takes the previous buffer's last angle: src/demod.hh:242-254, SURVEY §7
  * "the batched API must carry buffer boundaries"). One launch amortises the grid's ramp, the call's border slices and the
- * state hand-over over n_buffers buffers. n_out_per_buffer (n_buffers entries) and n_out_total may be NULL. */
+ * state hand-over over n_buffers buffers. FM at decimation 8: the hot kernel writes the per-buffer values itself wherever a
+ * boundary and the output behind it fall into one hot slice (equal buffers: always, unless the boundary sits on a slice's last
+ * lane); the other boundaries, and every other plan's, are patched by a second, tiny launch (iqbb_fm_multi_fixup_kernel). n_out_per_buffer (n_buffers entries) and n_out_total may be NULL. */
 int sdrhip_iqbb_i16_process_dev_multi(sdrhip_iqbb_i16 *h, const int16_t *in_dev, size_t n_buffers, size_t n_per_buffer, size_t in_stride,
                                       void *out_dev, size_t out_stride, size_t *n_out_per_buffer, size_t *n_out_total);
 /* Input sample format ("next" row). SDRHIP_IN_CU8: the buffers hold complex<uint8_t> (2 B per

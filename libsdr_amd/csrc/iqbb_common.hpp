@@ -80,6 +80,11 @@ struct HotArgs {
   int2 *part; int part_stride;
   int Dreal, base_real;                 // the plan's decimation, and the call-relative index its groups are counted from (boundaries: base_real + j Dreal, j >= 1)
   int fin_groups, fin_out, fin_epi;     // ... whole channels as units: the groups (touched / completed in this call) the workgroup finishes itself as its last step, the plan's demodulator; fin_groups = 0: iqbb_bigd_finish_kernel does
+  // multi-buffer calls with FM at decimation 8 (sdrhip_iqbb_i16_process_dev_multi): the buffers' first outputs are the groups
+  // mb_q1, mb_q1 + mb_p, ... <= mb_qlast of the long call (mb_p = 0: none). Where such a group and the one behind it lie in ONE hot
+  // slice (lanes 1 ... 62), the slice writes FMDemod's per-buffer values itself (iqbb_hot.hpp, stageF); the host leaves the other
+  // boundaries to iqbb_fm_multi_fixup_kernel. mb_magic = floor(2^32 / mb_p).
+  int mb_q1, mb_p, mb_qlast; unsigned mb_magic;
   unsigned long long *stamps;           // diagnostic builds (-DK1_STAMPS) only
 };
 

@@ -1050,7 +1050,10 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
   };
   // F: truncating division by 8, demodulator, store. orow: (scalar) the wave's first group of this slice; lanes below
   // glw_lo store nothing (FM: group 0 only supplies the previous angle)
-  auto stageF = [&](int2 sum, char *orow, int glw_lo) __attribute__((always_inline)) {
+  // (mb_bl, scalar, FM only: a buffer boundary of a multi-buffer call lies at lane mb_bl of this slice, 1 <= mb_bl <= 62 — that
+  // group is a buffer's index 0: FMDemod never writes it, in place it holds the real part; the group behind it takes the
+  // PREVIOUS buffer's last angle, two lanes back, src/demod.hh:242-254. 0: none)
+  auto stageF = [&](int2 sum, char *orow, int glw_lo, int mb_bl = 0) __attribute__((always_inline)) {
     const int glw = 2 * n + h;
     // libstdc++'s (s*8)/(8*8) (src/baseband.hh:214): |s| <= 9 * 2^17 (a window of 16-bit rotated values, or of 18-bit FIR
     // values when there is no shift), so nothing wraps and it is trunc(s / 8) + the int16 wrap of the assignment
@@ -1069,10 +1072,32 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
     } else {
       const int phi = fm_phi(yr, yi);
       const int prev = prev_group_value(phi, h);
-      if (glw >= glw_lo) reinterpret_cast<short *>(orow)[glw] = (short)(prev - phi);
+      int o = prev - phi;
+      if (!DG && !CS8 && mb_bl != 0) {   // (wave-uniform branch: one slice in 130 of a multi-buffer call)
+        const int prev2 = prev_group_value(prev, h);
+        if (glw == mb_bl) o = yr;
+        else if (glw == mb_bl + 1) o = prev2 - phi;
+      }
+      if (glw >= glw_lo) reinterpret_cast<short *>(orow)[glw] = (short)o;
     }
   };
   constexpr int GLW0 = EPI == SDRHIP_EPI_FM ? 1 : 0;
+  // the lane of this slice's buffer boundary (multi-buffer calls; scalar arithmetic: first stored group qs = tile * OG - ovl + gw + 1,
+  // boundaries at mb_q1 + j * mb_p): the smallest k >= 0 with (qs + k - mb_q1) % mb_p == 0, taken if the boundary AND the group
+  // behind it are stored lanes of this slice (k <= 61)
+  auto boundary_lane = [&](int tile_) __attribute__((always_inline)) {
+    if (!(EPI == SDRHIP_EPI_FM && !DG && !CS8) || a.mb_p == 0) return 0;
+    const int qs = tile_ * a.OG - a.ovl + gw + 1, lo = qs - a.mb_q1;
+    int k;
+    if (lo <= 0) k = -lo;
+    else {
+      const unsigned qq = (unsigned)(((unsigned long long)(unsigned)lo * a.mb_magic) >> 32);
+      unsigned r = (unsigned)lo - qq * (unsigned)a.mb_p;
+      if (r >= (unsigned)a.mb_p) r -= (unsigned)a.mb_p;
+      k = r ? a.mb_p - (int)r : 0;
+    }
+    return (k <= 61 && qs + k <= a.mb_qlast) ? k + 1 : 0;
+  };
   // Fairness: the SIMD arbitrates its waves by priority, then AGE, and in a persistent grid the ages never change —
   // the oldest wave of a SIMD ran at full speed and was done after 64 us, the youngest starved and finished alone
   // at 120 us (s_memrealtime stamps). The priority rotates over the SIMD's four wave slots, one step per slice.
@@ -1163,7 +1188,7 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
         park(sum);
         if (tile + 1 >= tend || npend + GS > 64) flush(c);   // the unit ends here (its tiles were consecutive), or the array is full
       } else {
-        stageF(sum, outb + (long)tile * tile_out_bytes, GLW0);
+        stageF(sum, outb + (long)tile * tile_out_bytes, GLW0, boundary_lane(tile));
       }
       K1_STAMP(5);
 #ifdef K1_STAMPS

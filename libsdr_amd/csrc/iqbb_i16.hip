@@ -998,6 +998,24 @@ struct sdrhip_iqbb_i16 {
     ha.base0_rel = g.base0_rel; ha.OG = OG; ha.ovl = ovl; ha.t_lo = 0; ha.t_hi = tiles; ha.cre = cre; ha.cim = cim;
     ha.N = (int)N; ha.n_out = g.n_out; ha.C = C; ha.stamps = nullptr;
     ha.D = 8; ha.GS = 64; ha.lpg_sh = 0; ha.inv_d = 0.125f; ha.philast = nullptr; ha.philast_stride = 0; ha.part = nullptr; ha.fin_groups = 0;   // (the any-D form's fields)
+    // multi-buffer call with FM (launch_multi): the hot slices write the buffers' first two outputs themselves where the boundary
+    // group and the one behind it are stored lanes of ONE hot slice; the others stay on the list for the fix-up launch
+    ha.mb_p = 0; ha.mb_q1 = 0; ha.mb_qlast = 0; ha.mb_magic = 0;
+    if (!mb_q.empty() && epi == SDRHIP_EPI_FM && !i8 && !hot_pair(kind, rg[hot_range].NW, false)) {
+      const int per = 64 - ovl;   // stored groups per slice
+      long P = mb_q.size() >= 2 ? (long)mb_q[1] - mb_q[0] : (long)1 << 30;
+      bool uniform = P >= 128;
+      for (size_t j = 2; j < mb_q.size(); j++) uniform = uniform && (long)mb_q[j] - mb_q[j - 1] == P;
+      if (uniform) {
+        ha.mb_q1 = mb_q[0]; ha.mb_p = (int)P; ha.mb_qlast = mb_q.back(); ha.mb_magic = (unsigned)((((unsigned long long)1) << 32) / (unsigned long long)P);
+        std::vector<int> left;
+        for (int q : mb_q) {
+          const int tl = q / OG, w = (q % OG) / per, lane = (q % OG) % per + ovl;   // the slice that STORES group q, and its lane there
+          if (!(lane <= 62 && host_hot(tl, w))) left.push_back(q);
+        }
+        mb_q.swap(left);   // what the fix-up launch still has to do
+      }
+    }
 #ifdef K1_STAMPS
     if (!k1_stamps.p) { k1_stamps.alloc(32768 * 16); k1_stamps.zero(ctx->stream); }
     ha.stamps = k1_stamps.p;
@@ -1292,6 +1310,9 @@ struct sdrhip_iqbb_i16 {
     last_args = a;
   }
   IqbbArgs last_args{};   // the argument block of the last launch (launch_multi's fix-up reads the same call)
+  int last_multi_left = -1;   // buffer boundaries the last one-launch multi call left to iqbb_fm_multi_fixup_kernel (-1: none made yet)
+  std::vector<int> mb_q;  // launch_multi -> launch: the long call's output indices of the buffers' first elements; on return: those no
+                          // kernel of the call has dealt with (the hot /8 kernel takes the ones inside its hot slices, launch_hot_call)
 
   // B consecutive buffers of nb samples per channel in one launch (sdrhip_iqbb_i16_process_dev_multi). IQBaseBand's own
   // state runs on across buffers, so the baseband part IS one long call; the buffer boundaries are only visible to the FM
@@ -1311,12 +1332,17 @@ struct sdrhip_iqbb_i16 {
                reinterpret_cast<char *>(out_dev) + qs[j] * ob, out_stride, nullptr);
       return;
     }
-    launch(in_dev, B * nb, in_stride, out_dev, out_stride, nullptr);
-    if (epi != SDRHIP_EPI_FM) return;
+    mb_q.clear();
+    if (epi == SDRHIP_EPI_FM) for (size_t j = 1; j < B; j++) mb_q.push_back((int)qs[j]);
+    try { launch(in_dev, B * nb, in_stride, out_dev, out_stride, nullptr); } catch (...) { mb_q.clear(); throw; }
+    std::vector<int> left;
+    left.swap(mb_q);   // (the boundaries no hot slice wrote: border slices, a boundary on a slice's last lane, plans of other kernels)
+    last_multi_left = (int)left.size();
+    if (left.empty()) return;
     MultiFix f{};
-    f.nb = (int)B - 1;
-    for (size_t j = 1; j < B; j++) f.q[j - 1] = (int)qs[j];
-    hipLaunchKernelGGL(iqbb_fm_multi_fixup_kernel, dim3((unsigned)(B - 1), (unsigned)C), dim3(256), 0, ctx->stream, last_args, f);
+    f.nb = (int)left.size();
+    for (size_t j = 0; j < left.size(); j++) f.q[j] = left[j];
+    hipLaunchKernelGGL(iqbb_fm_multi_fixup_kernel, dim3((unsigned)left.size(), (unsigned)C), dim3(256), 0, ctx->stream, last_args, f);
     SDRHIP_CHECK_HIP(hipGetLastError());
   }
 };
@@ -1513,6 +1539,7 @@ int sdrhip_iqbb_i16_plan_info(sdrhip_iqbb_i16 *h, int *info, int n) {
     const bool hot = h->hot_range >= 0 && h->hot_range < cnt;
     info[0] = h->path; info[1] = h->S; info[2] = hot ? rg[h->hot_range].S0 : 0; info[3] = hot ? rg[h->hot_range].NH : 0;
     info[4] = hot ? rg[h->hot_range].NW : 4; info[5] = h->hot_kind(); info[6] = h->OP; info[7] = h->HH;
+    if (n >= 9) info[8] = h->last_multi_left;
   });
 }
 

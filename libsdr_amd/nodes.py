@@ -244,9 +244,9 @@ class IQBaseBandI16(_Node):
     @property
     def plan_info(self):
         """{path, S, S0, NH, NW, kind, OP, HH} of the plan (sdrhip.h: sdrhip_iqbb_i16_plan_info)."""
-        v = (C.c_int * 8)()
-        check(abi.lib().sdrhip_iqbb_i16_plan_info(self._h, v, 8))
-        return dict(zip(("path", "S", "S0", "NH", "NW", "kind", "OP", "HH"), list(v)))
+        v = (C.c_int * 9)()
+        check(abi.lib().sdrhip_iqbb_i16_plan_info(self._h, v, 9))
+        return dict(zip(("path", "S", "S0", "NH", "NW", "kind", "OP", "HH", "multi_left"), list(v)))
 
     def out_count(self, n_in):
         n = C.c_size_t(0)

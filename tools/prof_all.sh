@@ -11,7 +11,7 @@ declare -A W=( [fm127]="" [fm16]="--order 16" [fm21]="--order 21" [fm64]="--orde
                [sdrfm]="--workload iqbb_fm_cu8 --order 21 --decim 125 --fs 1e6 --width 12.5e3" [cfg5g1]="--workload iqbb_usb --channels 8192 --batches 2"
                [cfg2c1]="--workload fbb_f32 --channels 1" [cfg1]="--workload fir127_fm" [multi4]="--buffers 4 --batches 2"
                [real5]="--workload bb_real_fm --decim 5" [real20]="--workload bb_real_fm --decim 20" [real125]="--workload bb_real_fm --decim 125"
-               [o300]="--order 300" [o513d20]="--workload iqbb_usb --order 513 --decim 20"
+               [o300]="--order 300" [o513d20]="--workload iqbb_usb --order 513 --decim 20" [i8doc]="--workload iqbb_fm_cs8 --order 16 --decim 24 --fc 0" [i8d8]="--workload iqbb_fm_cs8 --order 21"
                [sdrrec]="--workload iqbb_fm_cu8 --order 16 --decim 83 --fc 0"
                [sdrfmchain]="--workload iqbb_fm_cu8 --order 21 --decim 125 --deemph" [wfmchain]="--workload iqbb_fm_cu8 --order 16 --decim 20 --fc 0 --deemph"
                [pocsag]="--workload iqbb_fm_cu8 --order 21 --decim 45 --fc 0" [ssb]="--workload iqbb_usb --order 16 --decim 83 --fc 0"
