@@ -1109,6 +1109,9 @@ __device__ __forceinline__ void iqbb_hot_body(const HotArgs &a, const IqbbArgs &
       // tie goes to the older one and the drift feeds itself. The counter is read one slice ahead: its latency is hidden.)
       unsigned pv = prio_it++ + prio_slot;
       if (K1_PRIO_ROT == 4) { pv = prio_time + prio_slot; prio_time = (unsigned)(__builtin_amdgcn_s_memtime() >> K1_PRIO_SHIFT); }
+#ifdef K1_PRIO_BIAS   // (tuning variant: every K1_PRIO_BIAS-th slice the YOUNGER slots of a SIMD take the top priorities, whatever the rotation says)
+      if ((prio_it % K1_PRIO_BIAS) == 0) pv = prio_slot;
+#endif
       asm volatile("s_bitcmp1_b32 %0, 1\n\ts_cbranch_scc1 2f\n\ts_bitcmp1_b32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n\ts_branch 4f\n"
                    "1:\n\ts_setprio 1\n\ts_branch 4f\n"
                    "2:\n\ts_bitcmp1_b32 %0, 0\n\ts_cbranch_scc1 3f\n\ts_setprio 2\n\ts_branch 4f\n"
