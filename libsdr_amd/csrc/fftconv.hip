@@ -184,6 +184,31 @@ __device__ __forceinline__ void twiddles16(const FftDev &p, int q, int s, int j,
   for (int k = 1; k < 16; k++) w[k] = t[(k - 1) * s];
 }
 
+// the same 15 twiddles from the two seeds w1 = W^(j tw), w4 = W^(4 j tw) the 2-load form reads (already in registers)
+__device__ __forceinline__ void twiddles16_seeded(float2 w1, float2 w4, float2 *w) {
+  const float2 w2 = cmul(w1, w1), w8 = cmul(w4, w4);
+  w[1] = w1; w[2] = w2; w[4] = w4; w[8] = w8;
+  w[3] = cmul(w1, w2); w[5] = cmul(w4, w1); w[6] = cmul(w4, w2); w[7] = cmul(w4, w[3]);
+  w[9] = cmul(w8, w1); w[10] = cmul(w8, w2); w[11] = cmul(w8, w[3]); w[12] = cmul(w8, w4);
+  w[13] = cmul(w8, w[5]); w[14] = cmul(w8, w[6]); w[15] = cmul(w8, w[7]);
+}
+
+// ... and applied as they are made, v[k] *= w^k (CONJ: the conjugates): 8 twiddles live instead of 15 (the pipelined form holds the
+// next block's inputs in 32 registers through the passes that use this)
+template <bool CONJ>
+__device__ __forceinline__ void twiddle_apply_seeded(float2 *v, float2 w1, float2 w4) {
+  auto mul = [](float2 x, float2 w) { return CONJ ? cmulc(x, w) : cmul(x, w); };
+  const float2 w2 = cmul(w1, w1), w3 = cmul(w1, w2);
+  v[1] = mul(v[1], w1); v[2] = mul(v[2], w2); v[3] = mul(v[3], w3); v[4] = mul(v[4], w4);
+  const float2 w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3), w8 = cmul(w4, w4);
+  v[5] = mul(v[5], w5); v[6] = mul(v[6], w6); v[7] = mul(v[7], w7); v[8] = mul(v[8], w8);
+#ifdef K7_PIPE_SCHED
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+  v[9] = mul(v[9], cmul(w8, w1)); v[10] = mul(v[10], cmul(w8, w2)); v[11] = mul(v[11], cmul(w8, w3)); v[12] = mul(v[12], cmul(w8, w4));
+  v[13] = mul(v[13], cmul(w8, w5)); v[14] = mul(v[14], cmul(w8, w6)); v[15] = mul(v[15], cmul(w8, w7));
+}
+
 // forward, decimation in frequency: natural order in, digit-reversed order out
 __device__ void fft_forward_dif(float2 *x, const FftDev &p, int tid) {
   int n = p.L;
@@ -285,6 +310,11 @@ struct ConvArgs {
   int N, hop;
   int nb; long out_band;             // filter bank: bands sharing ONE forward transform; band b's rows start at out + b*out_band
   int lds_elems;                     // padded elements of one LDS image
+  int nblk, nchan;                   // (PIPE form) blocks per channel and channels: the launch's grid no longer says
+  float2 *dump;                      // (PIPE form) 128 bytes per wave of the launch where the masked lanes' stores go
+#ifdef K7_STAMPS
+  unsigned long long *stamps;        // diagnostic build: 16 words per workgroup (8 phase totals in shader clocks, turns, start, end)
+#endif
 };
 
 __global__ __launch_bounds__(FT) void fftconv_kernel(const ConvArgs a) {
@@ -345,8 +375,26 @@ constexpr int plan_radix(int lg, int pass) { return pass < lg / 4 ? 16 : ((lg % 
 // ACC: the block's kept samples are ADDED to what the output rows hold (partitioned convolution: a filter of more taps than one
 // 16384-point block can carry runs as two passes over the same input — tap partition 0, then partition 1 on the window 8192
 // samples earlier, accumulated: y = h0 (*) x + z^-8192 (h1 (*) x))
-template <int LG, bool BANK, int NT, bool ACC = false>
+// PIPE (16384 points, one band): a persistent workgroup per CU walks its blocks in a loop and the NEXT block's 16 inputs
+// per lane are in flight (32 registers) while the last two inverse passes of the current one run. Nothing else can overlap
+// the global phases of this kernel — one image fills the CU's LDS, so no second workgroup is resident — and no extra LDS is
+// needed: butterfly j of the last inverse pass READS the image elements j + 1024 k and butterfly j of the next block's pass 0
+// WRITES the same elements, both on lane j, so the hand-over between blocks is lane-private (no barrier; the block's stores
+// drain while the next pass 0 runs). vmcnt counts in issue order: every other global load of the tail (the twiddles of the
+// last two inverse passes) is issued BEFORE the prefetch, or waiting for it would wait for the prefetch as well. And the wait
+// counts the compiler inserts are only exact along straight-line code — where two paths with different numbers of outstanding
+// loads or stores join it waits for everything (first version: `s_waitcnt vmcnt(0)` at the top of inverse pass 1, the prefetch
+// waited for on the spot; measured +-0) — so from the prefetch to the next pass 0 every path issues the SAME loads and stores:
+// edge blocks (history, ragged end, no next block) select a pointer per lane (a harmless one for what is not there) instead of
+// branching around the load, mask at consumption, and masked stores go to a dump line instead of being skipped; the history
+// roll is a launch of its own.
+// PIPE = 4: 16-byte loads / stores by lane pairs (everything even: hop, history, strides, N, 16-byte aligned rows), 2: 8-byte
+// ones (any alignment). SKIP: the first SKIP stores of a lane are in front of the kept samples for every lane
+// (HH >= SKIP x 2048 resp. 1024) and do not exist.
+template <int LG, bool BANK, int NT, bool ACC = false, int PIPE = 0, int SKIP = 0>
 __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
+  static_assert(!PIPE || (LG == 14 && !BANK && NT == 1024 && !ACC), "the pipelined form exists for the 16384-point single-band plan");
+  constexpr bool PV = PIPE == 4;
   constexpr int FT = NT;   // (shadows the file-wide workgroup size)
   extern __shared__ __attribute__((aligned(16))) float2 xl[];
   const FftDev &p = a.fft;
@@ -374,17 +422,147 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
   // 0.508 ms for this kernel on the same box)
   // XCD-aware (channel, block) assignment (xcd_unit_order): consecutive blocks of a channel overlap by the filter's
   // history — a quarter of a 16384-point block with 4097 taps, half of a filter-bank block
-  int c, blk;
-#ifdef FFTCONV_NO_XCD   // (tuning: launch-order assignment)
-  c = blockIdx.y; blk = blockIdx.x;
-#else
-  xcd_unit_order(blk, c);
-#endif
+  int c = 0, blk = 0;
   const int tid0 = threadIdx.x;
   // (every phase starts from an opaque copy of the lane index: the lane's LDS and table addresses of all passes are
   // otherwise computed up front and, kept live across the phases, spill — 49 to 93 registers in the run-time-plan kernels)
   // (the compile-time 16384-point plan fits without: there the hoisted addresses are worth 5 %)
-  auto lane = [&]() { int t = tid0; if (LG == 0) asm volatile("" : "+v"(t)); return t; };
+  // (PIPE: opaque as well — inside the walk's loop everything derived from the lane index is loop-invariant, gets hoisted in front of
+  // the loop and spilled there: 79 registers' worth, reloaded one by one through scratch, i.e. through vmcnt)
+  auto lane = [&]() { int t = tid0; if (LG == 0 || PIPE) { asm volatile("" : "+v"(t)); __builtin_assume(t >= 0 && t < NT); } return t; };
+  // (K7_PRIO, 16384 points) between two barriers the waves of a SIMD run at their own pace and the arbiter prefers the oldest: wave 0
+  // arrives at the next barrier 12 600 clocks of a 32 300-clock turn before the last one (stamps), and the last one runs alone, its
+  // LDS latencies uncovered. Priority by progress — the further along, the lower — keeps the four together.
+// sites: forward passes 1, 2, the middle pass, inverse pass 2 (and behind its butterfly), inverse pass 1 (and in front of its
+// butterfly), the last pass (and behind its butterfly), pass 0 (and behind its butterfly); K7_PRIO picks the level table
+#ifndef K7_PRIO
+#define K7_PRIO 1   // (A/B on one box, 4097 taps: table 1 0.3868 ms, 3 0.3903, 2 0.3944, none 0.4135; -DK7_PRIO=0: none)
+#endif
+#if K7_PRIO
+  enum { S_F1, S_F2, S_MID, S_I2, S_I2B, S_I1, S_I1B, S_LAST, S_LASTB, S_P0, S_P0B };
+#if K7_PRIO == 1
+#define K7_PRIO_TAB {3, 2, 2, 1, 1, 0, 0, 3, 3, 1, 1}
+#elif K7_PRIO == 2
+#define K7_PRIO_TAB {3, 3, 2, 1, 1, 0, 0, 3, 2, 1, 0}
+#else
+#define K7_PRIO_TAB {3, 3, 3, 2, 1, 1, 0, 3, 2, 1, 0}
+#endif
+#define K7_SETPRIO(site_) do { if (LG == 14 && !BANK) { constexpr int tab_[] = K7_PRIO_TAB; __builtin_amdgcn_s_setprio(tab_[site_]); } } while (0)
+#else
+#define K7_SETPRIO(site_) do { } while (0)
+#endif
+#ifdef K7_STAMPS   // diagnostic build: wave 0 of every workgroup sums the shader clocks between its phase boundaries
+  const bool st_on = PIPE && __builtin_amdgcn_readfirstlane(tid0) == 0;
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime(), st_turns = 0;
+  const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();
+#define K7_STAMP(ph_, dep_) do { if (st_on) { asm volatile("" :: "v"(dep_) : "memory"); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    asm volatile("" ::: "memory"); st_acc[ph_] += now_ - st_t; st_t = now_; } } while (0)
+#else
+#define K7_STAMP(ph_, dep_) do { } while (0)
+#endif
+  // (PIPE) the workgroup's walk: with channels and workgroups in multiples of 8, XCD x = workgroup & 7 (round-robin dispatch) owns
+  // channels x, x + 8, ... and its workgroups take that list's (channel, block) units turn by turn — as xcd_unit_order, the two
+  // readers of a block overlap run on one XCD at about the same time
+  const bool pipe_xcd = PIPE && (a.nchan & 7) == 0 && (gridDim.x & 7u) == 0;
+  int uk = PIPE ? (pipe_xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x) : 0;
+  const int uk_step = PIPE ? (pipe_xcd ? (int)(gridDim.x >> 3) : (int)gridDim.x) : 1;
+  const int uk_end = PIPE ? (pipe_xcd ? (a.nchan >> 3) * a.nblk : a.nchan * a.nblk) : 1;
+  auto unit_of = [&](int k, int &ublk, int &uc) {
+    const int q = k / a.nblk;
+    ublk = k - q * a.nblk; uc = pipe_xcd ? (int)(blockIdx.x & 7u) + 8 * q : q;
+  };
+  float4 pfq[PIPE ? 8 : 1];   // the prefetched inputs of the lane's pass-0 butterfly: PV the raw lane-pair loads, else (element 2m, element 2m + 1)
+  int pf_state = 0;           // 0: nothing fetched (no next block), 1: an interior block, 2: an edge block (masks at consumption)
+  float2 pf_tw[4];            // twiddle seeds (w1, w4) of inverse pass 1 and of the last inverse pass, loaded ahead of the prefetch
+  auto prefetch = [&](int k, bool have) {
+    int ublk, uc;
+    unit_of(k, ublk, uc);
+    const int f = ublk * a.hop - a.HH - a.delay;
+    const bool interior = have && f >= 0 && f + L <= a.N;
+    pf_state = have ? (interior ? 1 : 2) : 0;
+    const float2 *in_c = a.in + (long)uc * a.in_stride, *hist_c = a.hist + (long)uc * a.HL, *safe = a.Kp;
+    const int j = lane(), s = L / 16, odd = j & 1, je = j & ~1;
+    // where element e of the block lives (edge blocks): the call's input, the history rows, or nowhere (zeros in front of the
+    // history / behind the call's end: `safe`, masked at consumption)
+    auto where = [&](int e) {
+      const int rel = f + e, h = a.HL + rel;
+      const float2 *q = rel >= 0 ? (rel < a.N ? in_c + rel : safe) : (h >= 0 ? hist_c + h : safe);
+      return have ? q : safe;
+    };
+    // the branch computes ADDRESSES only (no load on either side: the two sides of a branch are laid out one after the other
+    // behind a flag, and the path that runs neither — impossible, but in the flow graph — would set every later wait to zero)
+    constexpr int NP = PV ? 8 : 16;
+    const float2 *ptr[NP];
+    if (interior) {
+      const float2 *src = in_c + f + (PV ? je : j);
+#pragma unroll
+      for (int n = 0; n < NP; n++) ptr[n] = src + (PV ? 2 * n + odd : n) * s;
+    } else {
+#pragma unroll
+      for (int n = 0; n < NP; n++) ptr[n] = where((PV ? je + (2 * n + odd) * s : j + n * s));
+    }
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      if (PV) pfq[m] = *reinterpret_cast<const float4 *>(ptr[m]);
+      else { const float2 x = *ptr[2 * m], y = *ptr[2 * m + 1]; pfq[m] = make_float4(x.x, x.y, y.x, y.y); }
+    }
+  };
+  // (PIPE) pass 0 of the block whose inputs the prefetch brought: registers -> LDS. Runs at the END of a turn (and once in front
+  // of the loop), so that the prefetched registers are written and read inside one turn: carried around the loop's back edge the
+  // register allocator moved two of the 32 to other registers there — a copy of a register a load is still writing, i.e. a full wait
+  // (the two copies carry different marker comments: identical, the compiler merges them back into ONE at the loop's head)
+  auto pass0_pipe = [&](int first, bool in_loop) __attribute__((always_inline)) {
+    if (in_loop) asm volatile("; pass 0 of the next block (end of a turn)"); else asm volatile("; pass 0 of the first block");
+    K7_SETPRIO(S_P0);
+    const int j = lane(), s = L / 16;
+    float2 v[16];
+    if (PV) {
+      const int odd = j & 1;
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        const float4 q = pfq[m];
+        const float gx = odd ? q.x : q.z, gy = odd ? q.y : q.w;
+        const float rx = lane_xor1(gx), ry = lane_xor1(gy);
+        v[2 * m] = odd ? make_float2(rx, ry) : make_float2(q.x, q.y);
+        v[2 * m + 1] = odd ? make_float2(q.z, q.w) : make_float2(rx, ry);
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < 8; m++) { v[2 * m] = make_float2(pfq[m].x, pfq[m].y); v[2 * m + 1] = make_float2(pfq[m].z, pfq[m].w); }
+    }
+    K7_STAMP(6, v[15].x + v[14].y);
+    if (pf_state == 2) {   // an edge block: what lies in front of the history or behind the call's end is zero
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        const int rel = first + j + k * s;
+        if (rel >= a.N || rel < -a.HL) v[k] = make_float2(0.f, 0.f);
+      }
+    }
+    dft16<-1>(v);
+    K7_SETPRIO(S_P0B);
+    twiddle_apply_seeded<false>(v, pf_tw[2], pf_tw[3]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) xl[P(j + k * s)] = v[k];
+    __syncthreads();
+    K7_STAMP(7, j);
+  };
+  if (PIPE) {
+    // the seeds of the stride-L/16 passes (the last inverse pass and pass 0 use the same table row, conjugated or not) stay in
+    // registers for the whole walk
+    const float2 *t0 = p.T + p.toff[0] + lane();
+    pf_tw[2] = t0[0]; pf_tw[3] = t0[3 * (L / 16)];
+    if (uk < uk_end) {
+      prefetch(uk, true);
+      unit_of(uk, blk, c);
+      pass0_pipe(blk * a.hop - a.HH - a.delay, false);
+    }
+  } else {
+#ifdef FFTCONV_NO_XCD   // (tuning: launch-order assignment)
+    c = blockIdx.y; blk = blockIdx.x;
+#else
+    xcd_unit_order(blk, c);
+#endif
+  }
   // After the first radix-16 pass the transform splits into 16 independent segments of L/16 points, and with one
   // butterfly per lane (NT = L/16) the butterflies of a segment belong to consecutive lanes: for L = 16384 a segment is
   // exactly one WAVE's 64 lanes x 16 points. The passes between the first forward and the last inverse pass then touch
@@ -394,9 +572,13 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
   auto pass_sync = [&]() { if (WAVE_LOCAL) asm volatile("" ::: "memory"); else __syncthreads(); };
   // radix-4 butterfly q (0..3) of this lane: with WAVE_LOCAL the 256 butterflies of the wave's own segment
   auto bfly4_index = [&](int tid, int q) { return WAVE_LOCAL ? ((tid >> 6) * 256 + (tid & 63) + 64 * q) : (tid + q * FT); };
+  for (; uk < uk_end; uk += uk_step) {   // (one turn unless PIPE)
+  if (PIPE) unit_of(uk, blk, c);
   const int first = blk * a.hop - a.HH - a.delay;   // call-relative index of element 0
   // ---- forward pass 0 (radix 16, stride L/16): global -> registers -> LDS ----
-  {
+  if (PIPE) {
+    // (pass 0 of this block ran at the end of the previous turn — or in front of the loop)
+  } else {
     const int tid = lane();
     const int s = L / 16;
     // interior, 16-byte aligned block: a lane pair loads 16 bytes per lane (elements j&~1, (j&~1)+1 of every other k)
@@ -406,6 +588,12 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
     const bool vec_in = first >= 0 && first + L <= a.N && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && (s & 1) == 0 && s >= FT;
     for (int j = tid; j < s; j += FT) {
       float2 v[16], w[16];
+#ifdef K7_PROBE_NOLOAD   // (ceiling probe, results wrong: pass 0 makes its inputs up — what the block costs with its global loads hidden completely)
+      if (a.N > 0) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = make_float2((float)(j + k), (float)(tid - k));
+      } else
+#endif
       if (vec_in) {
         const int odd = j & 1, je = j & ~1;
 #pragma unroll
@@ -433,7 +621,8 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
   }
   // ---- forward passes 1 .. np-2 in LDS ----
   int n = L / 16;
-  for (int pass = 1; pass + 1 < np_lds; pass++) {
+  auto fwd_pass = [&](int pass) __attribute__((always_inline)) {
+    if (pass == 1) K7_SETPRIO(S_F1); else K7_SETPRIO(S_F2);
     const int tid = lane();
     const int r = radix_at(pass), s = n / r, tw = L / n;
     if (r == 16) {
@@ -463,7 +652,11 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
     }
     pass_sync();
     n = s;
-  }
+  };
+  // (PIPE: written out — inside the walk's loop the compiler no longer unrolls the pass loops of the compile-time plan by itself, and
+  // a rolled loop reads strides, radices and the twiddle form at run time)
+  if constexpr (PIPE) { fwd_pass(1); fwd_pass(2); }
+  else for (int pass = 1; pass + 1 < np_lds; pass++) fwd_pass(pass);
   // ---- filter bank (BANK): one forward transform per input block for all bands, as FilterSink feeds every FilterSource
   // from one FFT (reference src/filternode.hh:81-88,257-270). The workgroup has L / 16 lanes, so the last forward pass
   // leaves exactly 16 spectrum values per lane: they stay in REGISTERS across the bands (32 of them), every band
@@ -579,6 +772,7 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
     }
     __syncthreads();
   } else {
+    K7_SETPRIO(S_MID);
     const int tid = lane();
     const float2 *xs = xl;
     const int r = radix_at(np - 1);
@@ -614,21 +808,36 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
   }
   // ---- inverse passes np-2 .. 1 in LDS ----
   n = TAIL8 ? 8 : radix_at(np - 1);
-  for (int pass = np_lds - 2; pass >= 1; pass--) {
+  auto inv_pass = [&](int pass) __attribute__((always_inline)) {
+    if (pass == 2) K7_SETPRIO(S_I2); else K7_SETPRIO(S_I1);
     const int tid = lane();
     const int r = radix_at(pass), s = n;
     n *= r;
     const int tw = L / n;
+    if (PIPE && pass == 1) {   // the tail's own global loads first, then the next block's inputs (vmcnt is in issue order)
+      const float2 *t1 = p.T + p.toff[1] + (tid & (s - 1));
+      pf_tw[0] = t1[0]; pf_tw[1] = t1[3 * s];
+      K7_STAMP(0, tid);
+      __builtin_amdgcn_sched_barrier(0);
+      prefetch(uk + uk_step < uk_end ? uk + uk_step : uk, uk + uk_step < uk_end);
+      __builtin_amdgcn_sched_barrier(0);
+      K7_STAMP(1, tid);
+    }
     if (r == 16) {
       for (int b = tid; b < L / 16; b += FT) {
         const int j = b & (s - 1), base = (b / s) * n + j;
         float2 v[16], w[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) v[k] = xw[P(base + k * s)];
-        twiddles16(p, pass, s, j, w);
+        if (PIPE && pass == 1) twiddle_apply_seeded<true>(v, pf_tw[0], pf_tw[1]);
+        else {
+          twiddles16(p, pass, s, j, w);
 #pragma unroll
-        for (int k = 1; k < 16; k++) v[k] = cmulc(v[k], w[k]);
+          for (int k = 1; k < 16; k++) v[k] = cmulc(v[k], w[k]);
+        }
+        if (pass == 1) K7_SETPRIO(S_I1B);
         dft16<1>(v);
+        if (pass == 2) K7_SETPRIO(S_I2B);
 #pragma unroll
         for (int k = 0; k < 16; k++) xw[P(base + k * s)] = v[k];
       }
@@ -644,8 +853,19 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
         xw[P(base)] = X0; xw[P(base + s)] = X1; xw[P(base + 2 * s)] = X2; xw[P(base + 3 * s)] = X3;
       }
     }
-    if (pass > 1) pass_sync(); else __syncthreads();   // (the last inverse pass crosses the segments again)
-  }
+    if (pass > 1) pass_sync();
+    else {   // (the last inverse pass crosses the segments again)
+#ifdef K7_STAMPS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+      K7_STAMP(2, tid);
+      __syncthreads();
+      K7_SETPRIO(S_LAST);
+      K7_STAMP(3, tid);
+    }
+  };
+  if constexpr (PIPE) { inv_pass(2); inv_pass(1); }
+  else for (int pass = np_lds - 2; pass >= 1; pass--) inv_pass(pass);
   // ---- last inverse pass (radix 16, stride L/16): LDS -> registers -> global (only the hop kept samples) ----
   {
     const int tid = lane();
@@ -654,11 +874,53 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
       float2 v[16], w[16];
 #pragma unroll
       for (int k = 0; k < 16; k++) v[k] = xw[P(j + k * s)];
-      twiddles16(p, 0, s, j, w);
+      if (PIPE) twiddle_apply_seeded<true>(v, pf_tw[2], pf_tw[3]);
+      else {
+        twiddles16(p, 0, s, j, w);
 #pragma unroll
-      for (int k = 1; k < 16; k++) v[k] = cmulc(v[k], w[k]);
+        for (int k = 1; k < 16; k++) v[k] = cmulc(v[k], w[k]);
+      }
       dft16<1>(v);
+      K7_SETPRIO(S_LASTB);
       float2 *dst = outb + (long)c * a.out_stride + o0 - a.HH;   // element i of the block goes to dst[i] (i >= HH)
+      K7_STAMP(4, v[0].x + v[15].y);
+      if (PIPE) {   // every store is issued; lanes in front of the kept samples or behind the call's end write the wave's dump line
+        float2 *dump = a.dump + ((long)blockIdx.x * (NT / 64) + (tid >> 6)) * 16;
+        const int odd = j & 1, je = j & ~1;
+        constexpr int NS = PV ? 8 : 16;
+        float2 *to_[NS];
+        const bool whole = SKIP > 0 && a.HH == SKIP * (PV ? 2 : 1) * s && o0 + (L - a.HH) <= a.N;   // stores SKIP ... are all kept samples
+        if (whole) {
+#pragma unroll
+          for (int n = SKIP; n < NS; n++) to_[n] = dst + (PV ? je + (2 * n + odd) * s : j + n * s);
+        } else {
+#pragma unroll
+          for (int n = SKIP; n < NS; n++) {
+            const int i = PV ? je + (2 * n + odd) * s : j + n * s;
+            to_[n] = (i >= a.HH && o0 - a.HH + i < a.N) ? dst + i : dump;
+          }
+        }
+        if (PV) {
+#pragma unroll
+          for (int m = SKIP; m < 8; m++) {
+            // (values, not array slots: the select between two elements of v otherwise becomes a load from a selected ADDRESS and the
+            // whole array moves to scratch — whose loads and stores count in vmcnt)
+            float ex = v[2 * m].x, ey = v[2 * m].y, ox = v[2 * m + 1].x, oy = v[2 * m + 1].y;
+            asm("" : "+v"(ex), "+v"(ey), "+v"(ox), "+v"(oy));
+            const float rx = lane_xor1(odd ? ex : ox), ry = lane_xor1(odd ? ey : oy);
+            const float4 q = odd ? make_float4(rx, ry, ox, oy) : make_float4(ex, ey, rx, ry);
+            *reinterpret_cast<float4 *>(to_[m]) = q;
+          }
+        } else {
+#pragma unroll
+          for (int k = SKIP; k < 16; k++) *to_[k] = v[k];
+        }
+        K7_STAMP(5, tid);
+#ifdef K7_STAMPS
+        st_turns++;
+#endif
+        continue;
+      }
       const bool vec_out = ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) && (s & 1) == 0 && (a.HH & 1) == 0 && s >= FT &&
                            o0 + (L - a.HH) <= a.N;
       if (vec_out) {   // lane pairs swap halves and store 16 bytes per lane: 8 dwordx4 stores instead of 16 dwordx2
@@ -670,7 +932,11 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
           const float rx = lane_xor1(give.x), ry = lane_xor1(give.y);
           const float4 q = odd ? make_float4(rx, ry, v[2 * m + 1].x, v[2 * m + 1].y) : make_float4(v[2 * m].x, v[2 * m].y, rx, ry);
           const int i = je + (2 * m + odd) * s;
+#ifdef K7_PROBE_NOSTORE   // (ceiling probe, results missing: the stores sit behind a condition that is never true at run time)
+          if (i >= a.HH && a.N < 0) {
+#else
           if (i >= a.HH) {
+#endif
             if (ACC) { const float4 t = *reinterpret_cast<const float4 *>(dst + i); *reinterpret_cast<float4 *>(dst + i) = make_float4(q.x + t.x, q.y + t.y, q.z + t.z, q.w + t.w); }
             else *reinterpret_cast<float4 *>(dst + i) = q;
           }
@@ -692,12 +958,24 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
   }
   // the channel's last block rolls the overlap history forward (hist_new <- the last HH samples of concat(hist, in); `hist`
   // is only read, by this launch's first blocks): no separate launch
-  if (a.hist_new != nullptr && blk == (int)gridDim.x - 1) {
+  if (!PIPE && a.hist_new != nullptr && blk == (int)gridDim.x - 1) {   // (PIPE: a launch of its own — loads and stores on one path only)
     for (int k = tid0; k < a.HL; k += FT) {
       const long qq = (long)a.N + k;
       a.hist_new[(long)c * a.HL + k] = qq < a.HL ? a.hist[(long)c * a.HL + qq] : a.in[(long)c * a.in_stride + (qq - a.HL)];
     }
   }
+  if (PIPE && uk + uk_step < uk_end) {
+    int nblk_, nc_;
+    unit_of(uk + uk_step, nblk_, nc_);
+    pass0_pipe(nblk_ * a.hop - a.HH - a.delay, true);
+  }
+  }   // (the PIPE walk)
+#ifdef K7_STAMPS
+  if (PIPE && tid0 == 0) {
+    for (int q = 0; q < 8; q++) a.stamps[blockIdx.x * 16 + q] = st_acc[q];
+    a.stamps[blockIdx.x * 16 + 8] = st_turns; a.stamps[blockIdx.x * 16 + 9] = st_t0; a.stamps[blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 __global__ void hist_roll_kernel(const float2 *in, long in_stride, const float2 *hist_old, float2 *hist_new, int HH, int N) {
@@ -1111,6 +1389,8 @@ struct sdrhip_fftconv {
   DevBuf<float2> Kp;
   DevBuf<float2> hist[2];
   DevBuf<float2> stage_in, stage_out;
+  int stamps_grid = 0;   // (diagnostic builds)
+  DevBuf<float2> dump;   // (the pipelined 16384-point form) 128 bytes per wave of its grid for the stores of masked lanes
 
   // spectrum of one band -> the device layout (digit-reversed position order, pre-scaled by 1/L)
   void load_kernel(int band, const float *kernel) {
@@ -1153,6 +1433,14 @@ struct sdrhip_fftconv {
     SDRHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   }
 
+  // workgroups of the pipelined 16384-point form: one per CU (SDRHIP_K7_PIPE_GRID=n: tests walk small calls with few workgroups;
+  // 0: the one-block-per-workgroup kernel, the A/B hook). Read per launch: a call costs microseconds, getenv nanoseconds
+  static constexpr int kPipeGridMax = 1024;   // (the dump lines are allocated with the handle: nothing is allocated in a launch)
+  int pipe_grid() const {
+    const char *e = getenv("SDRHIP_K7_PIPE_GRID");
+    return std::min(e ? atoi(e) : ctx->prop.multiProcessorCount, kPipeGridMax);
+  }
+
   // bands a launch can serve from one forward transform: the bank kernel keeps the spectrum in registers, 16 values per
   // lane of an L/16-lane workgroup (L = 1024 .. 8192; 16384 points sit at the register cap of a 1024-lane workgroup)
   int bands_per_launch() const { return (plan.L >= 1024 && plan.L <= 8192) ? B : 1; }
@@ -1166,6 +1454,7 @@ struct sdrhip_fftconv {
     for (int b0 = 0; b0 < B; b0 += bpl) {   // (a plan too large for two LDS images transforms the input once per band)
     for (int part = 0; part < parts; part++) {
     ConvArgs a;
+    a.nblk = 0; a.nchan = 0; a.dump = nullptr;
     a.nb = std::min(bpl, B - b0); a.out_band = (long)out_band; a.lds_elems = (int)(plan.lds_bytes() / sizeof(float2));
     const size_t lds = plan.lds_bytes();
     a.fft = plan.dev; a.in = in_dev; a.in_stride = (long)in_stride;
@@ -1197,6 +1486,28 @@ struct sdrhip_fftconv {
     const bool ct = getenv("SDRHIP_K7_RUNTIME_PLAN") == nullptr;   // (tuning / tests: the run-time-plan kernel for every size)
     if (plan.L == 16384 && part > 0) {
       fused(fftconv_fused_kernel<14, false, 1024, true>, 1024);   // (a later tap partition: accumulated)
+    } else if (plan.L == 16384 && pipe_grid() > 0 && (long)blocks * C > pipe_grid()) {
+      // the pipelined form: one persistent workgroup per CU (more units than CUs: otherwise there is no next block to fetch);
+      // the history roll stays a launch of its own (hist_roll_kernel below)
+      const int grid = pipe_grid();
+      a.nblk = blocks; a.nchan = C;
+      a.dump = dump.p;
+#ifdef K7_STAMPS
+      a.stamps = reinterpret_cast<unsigned long long *>(dump.p + (size_t)grid * 16 * 16); stamps_grid = grid;
+#endif
+      auto even = [](size_t v) { return (v & 1) == 0; };
+      const bool pv = even(hop) && even(HH) && even(HL) && even(a.delay) && even(N) && even(in_stride) && even(out_stride) &&
+                      (reinterpret_cast<uintptr_t>(in_dev) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
+      auto go = [&](auto kernel) {
+        allow_big_lds(kernel, lds);
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(1024), lds, ctx->stream, a);
+      };
+      // (the two BASELINE shapes get their stores counted at compile time: 4097 taps keep 12288 of 16384, the reference mode's
+      // 8192 taps 8192)
+      if (pv && HH == 4096) go(fftconv_fused_kernel<14, false, 1024, false, 4, 2>);
+      else if (pv && HH == 8192) go(fftconv_fused_kernel<14, false, 1024, false, 4, 4>);
+      else if (pv) go(fftconv_fused_kernel<14, false, 1024, false, 4, 0>);
+      else go(fftconv_fused_kernel<14, false, 1024, false, 2, 0>);
     } else if (plan.L == 16384) {   // (never a bank: two images of 16384 points do not fit the LDS)
       fused(fftconv_fused_kernel<14, false, 1024>, 1024);   // (512 / 256 lanes measured 0.78x / 0.59x)
     } else if (ct && fusable && nt == 128 && plan_is(11)) {
@@ -1393,10 +1704,16 @@ int sdrhip_fftconv_create_bank(sdrhip_ctx *ctx, int mode, int fft_size, const fl
       else {
         SDRHIP_REQUIRE(n_taps >= 1 && n_taps <= L, SDRHIP_E_INVALID, "n_taps %d outside [1,%d]", n_taps, L);
         h->hop = L - n_taps + 1; h->n_taps = n_taps;
+        // an even hop (one more sample of history than the taps need) keeps every block of an aligned call 16-byte aligned: the
+        // lane-pair loads and stores of the first and last pass apply, and the pipelined form's 16-byte variant. The reference
+        // mode's 8192 taps on 16384 points: hop 8193 -> 8192, the same 8 blocks per 65536 samples. (SDRHIP_FFTCONV_ODD_HOP=1
+        // keeps L - n_taps + 1: tests of the unaligned paths.)
+        if ((h->hop & 1) && h->hop > 1 && !getenv("SDRHIP_FFTCONV_ODD_HOP")) h->hop -= 1;
       }
       h->HH = L - h->hop;
       h->HL = h->HH + (h->parts - 1) * h->part_taps;
       h->Kp.alloc((size_t)L * n_bands * h->parts);
+      if (L == 16384) h->dump.alloc((size_t)sdrhip_fftconv::kPipeGridMax * (16 * 16 + 16));   // (+ 16 words per workgroup: diagnostic builds' stamps)
       const size_t per_band = mode == SDRHIP_FFTCONV_OLA ? (size_t)2 * L : (size_t)2 * n_taps;   // floats per band in `kernels`
       for (int b = 0; b < n_bands; b++) h->load_kernel(b, kernels + (size_t)b * per_band);
       for (int p = 0; p < 2; p++) { h->hist[p].alloc((size_t)channels * std::max(1, h->HL)); h->hist[p].zero(ctx->stream); }
@@ -1627,3 +1944,11 @@ int sdrhip_fft_c2c(sdrhip_ctx *ctx, int n, int sign, int batch, const float *in_
 }
 
 }  // extern "C"
+
+#ifdef K7_STAMPS
+extern "C" int sdrhip_debug_k7_stamps(sdrhip_fftconv *h, unsigned long long *out, int words) {   // diagnostic builds only (tools/build_variant_k7.sh)
+  if (!h || !h->dump.p || !h->stamps_grid) return -3;
+  (void)hipStreamSynchronize(h->ctx->stream);
+  return hipMemcpy(out, h->dump.p + (size_t)h->stamps_grid * 16 * 16, (size_t)std::min(words, h->stamps_grid * 16) * 8, hipMemcpyDeviceToHost) == hipSuccess ? h->stamps_grid : -3;
+}
+#endif

@@ -1840,9 +1840,13 @@ def test_fftconv_ols_4097_vs_reference_fir(ctx, golden):
     assert rel_err(y, golden.load("g6_fir4097_cf32_out")) <= RTOL
 
 
-def test_fftconv_ols_even_taps_odd_hop(ctx, orc):
+@pytest.mark.parametrize("odd", [True, False])
+def test_fftconv_ols_even_taps_odd_hop(ctx, orc, odd, monkeypatch):
     """Overlap-save with an even tap count: hop = L - n_taps + 1 is odd, so blocks start on every alignment (the
-    16-byte load/store variants of the first and last pass must step aside)."""
+    16-byte load/store variants of the first and last pass must step aside). Plans round such a hop down to even by
+    themselves (one more sample of history); SDRHIP_FFTCONV_ODD_HOP keeps the odd one for this test."""
+    if odd:
+        monkeypatch.setenv("SDRHIP_FFTCONV_ODD_HOP", "1")
     rng = np.random.default_rng(12)
     n_taps, L, C = 1000, 16384, 3
     h = (rng.standard_normal((n_taps, 2)) * 0.05).astype(np.float32)
@@ -1854,6 +1858,37 @@ def test_fftconv_ols_even_taps_odd_hop(ctx, orc):
         xc = x[c, :, 0].astype(np.float64) + 1j * x[c, :, 1]
         ref = np.convolve(xc, hc)[:40000]
         got = y[c, :, 0] + 1j * y[c, :, 1]
+        assert np.abs(got - ref).max() / np.abs(ref).max() <= RTOL
+
+
+@pytest.mark.parametrize("C,n_taps,grid", [(3, 4097, 3), (3, 1000, 2), (16, 4097, 8), (16, 4097, 16), (8, 2049, 8), (8, 2050, 8), (5, 4097, 1), (24, 4097, 40), (4, 8192, 5), (4, 8193, 3)])
+def test_fftconv_pipelined_walk_equals_one_block_per_workgroup(ctx, golden, C, n_taps, grid, monkeypatch):
+    if n_taps in (1000, 2049 + 1):   # (the 8-byte variant of the pipelined form: an odd hop kept odd)
+        monkeypatch.setenv("SDRHIP_FFTCONV_ODD_HOP", "1")
+    """The 16384-point plan's pipelined form (persistent workgroups walking their blocks, the next block's inputs in flight
+    during the last two inverse passes; fftconv_fused_kernel PIPE) against the one-block-per-workgroup kernel: bit for bit
+    (same butterflies, same twiddle products), over three calls of ragged lengths with the history carried, aligned and
+    unaligned hops, the XCD-ordered walk (channels and workgroups in multiples of 8) and the plain one, one workgroup
+    walking everything, and more workgroups than some calls have blocks (those calls take the old kernel)."""
+    rng = np.random.default_rng(100 + C + n_taps)
+    if n_taps == 4097:
+        a = golden.load("g2_firlp_alpha4097")
+        h = np.stack([a[::-1], np.zeros_like(a)], axis=1).astype(np.float32)
+    else:
+        h = (rng.standard_normal((n_taps, 2)) * 0.05).astype(np.float32)
+    x = (rng.standard_normal((C, 90000, 2)) * 0.3).astype(np.float32)
+    cuts = [0, 50000, 50001, 90000]
+    ys = []
+    for g in (0, grid):
+        monkeypatch.setenv("SDRHIP_K7_PIPE_GRID", str(g))
+        node = sa.FFTConv(ctx, sa.FFTCONV_OLS, 16384, h, channels=C, max_in=50000)
+        ys.append(np.concatenate([node.process(x[:, cuts[i]:cuts[i + 1]]) for i in range(3)], axis=1))
+    assert np.array_equal(ys[0], ys[1])
+    hc = h[:, 0].astype(np.float64) + 1j * h[:, 1]
+    for c in (0, C - 1):
+        xc = x[c, :, 0].astype(np.float64) + 1j * x[c, :, 1]
+        ref = np.convolve(xc, hc)[:90000]
+        got = ys[1][c, :, 0] + 1j * ys[1][c, :, 1]
         assert np.abs(got - ref).max() / np.abs(ref).max() <= RTOL
 
 
