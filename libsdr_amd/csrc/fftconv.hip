@@ -387,7 +387,7 @@ constexpr int plan_radix(int lg, int pass) { return pass < lg / 4 ? 16 : ((lg % 
 // waited for on the spot; measured +-0) — so from the prefetch to the next pass 0 every path issues the SAME loads and stores:
 // edge blocks (history, ragged end, no next block) select a pointer per lane (a harmless one for what is not there) instead of
 // branching around the load, mask at consumption, and masked stores go to a dump line instead of being skipped; the history
-// roll is a launch of its own.
+// roll runs behind the walk.
 // PIPE = 4: 16-byte loads / stores by lane pairs (everything even: hop, history, strides, N, 16-byte aligned rows), 2: 8-byte
 // ones (any alignment). SKIP: the first SKIP stores of a lane are in front of the kept samples for every lane
 // (HH >= SKIP x 2048 resp. 1024) and do not exist.
@@ -958,7 +958,7 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
   }
   // the channel's last block rolls the overlap history forward (hist_new <- the last HH samples of concat(hist, in); `hist`
   // is only read, by this launch's first blocks): no separate launch
-  if (!PIPE && a.hist_new != nullptr && blk == (int)gridDim.x - 1) {   // (PIPE: a launch of its own — loads and stores on one path only)
+  if (!PIPE && a.hist_new != nullptr && blk == (int)gridDim.x - 1) {   // (PIPE: behind the walk — loads and stores on one path only)
     for (int k = tid0; k < a.HL; k += FT) {
       const long qq = (long)a.N + k;
       a.hist_new[(long)c * a.HL + k] = qq < a.HL ? a.hist[(long)c * a.HL + qq] : a.in[(long)c * a.in_stride + (qq - a.HL)];
@@ -970,6 +970,15 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
     pass0_pipe(nblk_ * a.hop - a.HH - a.delay, true);
   }
   }   // (the PIPE walk)
+  // (PIPE) the history roll BEHIND the walk (inside it, its loads and stores on one path only would set the loop's waits to zero):
+  // every workgroup copies the tails of its share of the channels
+  if (PIPE && a.hist_new != nullptr) {
+    for (int cc = blockIdx.x; cc < a.nchan; cc += gridDim.x)
+      for (int k = tid0; k < a.HL; k += FT) {
+        const long qq = (long)a.N + k;
+        a.hist_new[(long)cc * a.HL + k] = qq < a.HL ? a.hist[(long)cc * a.HL + qq] : a.in[(long)cc * a.in_stride + (qq - a.HL)];
+      }
+  }
 #ifdef K7_STAMPS
   if (PIPE && tid0 == 0) {
     for (int q = 0; q < 8; q++) a.stamps[blockIdx.x * 16 + q] = st_acc[q];
@@ -1487,8 +1496,8 @@ struct sdrhip_fftconv {
     if (plan.L == 16384 && part > 0) {
       fused(fftconv_fused_kernel<14, false, 1024, true>, 1024);   // (a later tap partition: accumulated)
     } else if (plan.L == 16384 && pipe_grid() > 0 && (long)blocks * C > pipe_grid()) {
-      // the pipelined form: one persistent workgroup per CU (more units than CUs: otherwise there is no next block to fetch);
-      // the history roll stays a launch of its own (hist_roll_kernel below)
+      // the pipelined form: one persistent workgroup per CU (more units than CUs: otherwise there is no next block to fetch)
+      if (HL > 0 && b0 + bpl >= B && part + 1 == parts) { a.hist_new = hist[par ^ 1].p; rolled = true; }   // the call's last launch
       const int grid = pipe_grid();
       a.nblk = blocks; a.nchan = C;
       a.dump = dump.p;
