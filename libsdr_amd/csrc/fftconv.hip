@@ -507,6 +507,17 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
       else { const float2 x = *ptr[2 * m], y = *ptr[2 * m + 1]; pfq[m] = make_float4(x.x, x.y, y.x, y.y); }
     }
   };
+  // (PIPE) the lane's LDS addresses of the four access patterns (stride 1024: pass 0 and the last pass; stride 64; stride 4; the
+  // middle pass's consecutive quadruples), computed ONCE in front of the walk: with the opaque lane index every pass of every turn
+  // recomputed them (1 427 vector instructions per wave and block against the one-block kernel's 1 278), and these four — unlike
+  // everything the compiler hoisted by itself — fit the registers that are free. Element base + off is lp[off + pad(off)] wherever
+  // (base mod 64) + (off mod 64) < 64, which holds for all four.
+  float2 *lp_s1024 = xl, *lp_s64 = xl, *lp_s4 = xl, *lp_mid = xl;
+  if (PIPE) {
+    lp_s1024 = xl + P(tid0); lp_s64 = xl + P((tid0 >> 6) * 1024 + (tid0 & 63)); lp_s4 = xl + P((tid0 >> 2) * 64 + (tid0 & 3));
+    lp_mid = xl + P(4 * ((tid0 >> 6) * 256 + (tid0 & 63)));
+  }
+  auto X = [&](float2 *lp, int base, int off) -> float2 & { return PIPE ? lp[off + ((off >> 6) << 2)] : xl[P(base + off)]; };
   // (PIPE) pass 0 of the block whose inputs the prefetch brought: registers -> LDS. Runs at the END of a turn (and once in front
   // of the loop), so that the prefetched registers are written and read inside one turn: carried around the loop's back edge the
   // register allocator moved two of the 32 to other registers there — a copy of a register a load is still writing, i.e. a full wait
@@ -542,7 +553,7 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
     K7_SETPRIO(S_P0B);
     twiddle_apply_seeded<false>(v, pf_tw[2], pf_tw[3]);
 #pragma unroll
-    for (int k = 0; k < 16; k++) xl[P(j + k * s)] = v[k];
+    for (int k = 0; k < 16; k++) X(lp_s1024, j, k * s) = v[k];
     __syncthreads();
     K7_STAMP(7, j);
   };
@@ -630,13 +641,13 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
         const int j = b & (s - 1), base = (b / s) * n + j;
         float2 v[16], w[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) v[k] = xl[P(base + k * s)];
+        for (int k = 0; k < 16; k++) v[k] = X(s == 64 ? lp_s64 : lp_s4, base, k * s);
         dft16<-1>(v);
         twiddles16(p, pass, s, j, w);
 #pragma unroll
         for (int k = 1; k < 16; k++) v[k] = cmul(v[k], w[k]);
 #pragma unroll
-        for (int k = 0; k < 16; k++) xl[P(base + k * s)] = v[k];
+        for (int k = 0; k < 16; k++) X(s == 64 ? lp_s64 : lp_s4, base, k * s) = v[k];
       }
     } else {   // radix 4 (a radix-2 pass can only be the last one)
       for (int b = tid; b < L / 4; b += FT) {   // (not reached by the 16384-point plan: its radix-4 pass is the last one)
@@ -791,11 +802,14 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
     } else if (r == 4) {
       for (int q = 0; q * FT + (WAVE_LOCAL ? 0 : tid) < L / 4; q++) {   // (small plans: fewer butterflies than lanes)
         const int b = bfly4_index(tid, q);
-        const float2 a0 = xs[P(4 * b)], a1 = xs[P(4 * b + 1)], a2 = xs[P(4 * b + 2)], a3 = xs[P(4 * b + 3)];
+        float2 a0, a1, a2, a3;
+        if (PIPE) { a0 = X(lp_mid, 0, 256 * q); a1 = X(lp_mid, 0, 256 * q + 1); a2 = X(lp_mid, 0, 256 * q + 2); a3 = X(lp_mid, 0, 256 * q + 3); }
+        else { a0 = xs[P(4 * b)]; a1 = xs[P(4 * b + 1)]; a2 = xs[P(4 * b + 2)]; a3 = xs[P(4 * b + 3)]; }
         float2 X0, X1, X2, X3, Z0, Z1, Z2, Z3;
         bfly4<-1>(a0, a1, a2, a3, X0, X1, X2, X3);
         bfly4<1>(cmul(X0, kp[4 * b]), cmul(X1, kp[4 * b + 1]), cmul(X2, kp[4 * b + 2]), cmul(X3, kp[4 * b + 3]), Z0, Z1, Z2, Z3);
-        xw[P(4 * b)] = Z0; xw[P(4 * b + 1)] = Z1; xw[P(4 * b + 2)] = Z2; xw[P(4 * b + 3)] = Z3;
+        if (PIPE) { X(lp_mid, 0, 256 * q) = Z0; X(lp_mid, 0, 256 * q + 1) = Z1; X(lp_mid, 0, 256 * q + 2) = Z2; X(lp_mid, 0, 256 * q + 3) = Z3; }
+        else { xw[P(4 * b)] = Z0; xw[P(4 * b + 1)] = Z1; xw[P(4 * b + 2)] = Z2; xw[P(4 * b + 3)] = Z3; }
       }
     } else {
       for (int b = tid; b < L / 2; b += FT) {
@@ -828,7 +842,7 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
         const int j = b & (s - 1), base = (b / s) * n + j;
         float2 v[16], w[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) v[k] = xw[P(base + k * s)];
+        for (int k = 0; k < 16; k++) v[k] = X(s == 64 ? lp_s64 : lp_s4, base, k * s);   // (xw is xl: one band)
         if (PIPE && pass == 1) twiddle_apply_seeded<true>(v, pf_tw[0], pf_tw[1]);
         else {
           twiddles16(p, pass, s, j, w);
@@ -839,7 +853,7 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
         dft16<1>(v);
         if (pass == 2) K7_SETPRIO(S_I2B);
 #pragma unroll
-        for (int k = 0; k < 16; k++) xw[P(base + k * s)] = v[k];
+        for (int k = 0; k < 16; k++) { if (PIPE) X(s == 64 ? lp_s64 : lp_s4, base, k * s) = v[k]; else xw[P(base + k * s)] = v[k]; }
       }
     } else {
       for (int b = tid; b < L / 4; b += FT) {
@@ -873,7 +887,7 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
     for (int j = tid; j < s; j += FT) {
       float2 v[16], w[16];
 #pragma unroll
-      for (int k = 0; k < 16; k++) v[k] = xw[P(j + k * s)];
+      for (int k = 0; k < 16; k++) v[k] = PIPE ? X(lp_s1024, j, k * s) : xw[P(j + k * s)];
       if (PIPE) twiddle_apply_seeded<true>(v, pf_tw[2], pf_tw[3]);
       else {
         twiddles16(p, 0, s, j, w);
