@@ -518,6 +518,21 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
     lp_mid = xl + P(4 * ((tid0 >> 6) * 256 + (tid0 & 63)));
   }
   auto X = [&](float2 *lp, int base, int off) -> float2 & { return PIPE ? lp[off + ((off >> 6) << 2)] : xl[P(base + off)]; };
+  // (PIPE, tuning variant -DK7_LDS_TW=1) the twiddles of the stride-64 and stride-4 passes in LDS behind the image (15 x 64 + 15 x 4
+  // entries, 8 KB of the 21 KB the image leaves), copied once per workgroup from the plan's tables: 15 ds_read_b64 per pass instead
+  // of 2 global loads + 11 complex products. Measured +-0 (0.3655 against 0.3636 ms, profiles/r18_k7_pipe_ab.txt) and no longer
+  // bit-identical to the one-block kernel (table entries against products): off.
+#ifndef K7_LDS_TW
+#define K7_LDS_TW 0
+#endif
+  constexpr bool LTW = PIPE && K7_LDS_TW;
+  float2 *ltw64 = xl, *ltw4 = xl;
+  if (LTW) {
+    float2 *tab = xl + (L + (L >> 6) * 4);
+    if (tid0 < 15 * 64) tab[tid0] = p.T[p.toff[1] + tid0];
+    if (tid0 < 15 * 4) tab[15 * 64 + tid0] = p.T[p.toff[2] + tid0];
+    ltw64 = tab + (tid0 & 63); ltw4 = tab + 15 * 64 + (tid0 & 3);   // (visible behind the barrier that closes the first pass 0)
+  }
   // (PIPE) pass 0 of the block whose inputs the prefetch brought: registers -> LDS. Runs at the END of a turn (and once in front
   // of the loop), so that the prefetched registers are written and read inside one turn: carried around the loop's back edge the
   // register allocator moved two of the 32 to other registers there — a copy of a register a load is still writing, i.e. a full wait
@@ -643,7 +658,10 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
 #pragma unroll
         for (int k = 0; k < 16; k++) v[k] = X(s == 64 ? lp_s64 : lp_s4, base, k * s);
         dft16<-1>(v);
-        twiddles16(p, pass, s, j, w);
+        if (LTW) {
+#pragma unroll
+          for (int k = 1; k < 16; k++) w[k] = (s == 64 ? ltw64 : ltw4)[(k - 1) * s];
+        } else twiddles16(p, pass, s, j, w);
 #pragma unroll
         for (int k = 1; k < 16; k++) v[k] = cmul(v[k], w[k]);
 #pragma unroll
@@ -829,8 +847,10 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
     n *= r;
     const int tw = L / n;
     if (PIPE && pass == 1) {   // the tail's own global loads first, then the next block's inputs (vmcnt is in issue order)
-      const float2 *t1 = p.T + p.toff[1] + (tid & (s - 1));
-      pf_tw[0] = t1[0]; pf_tw[1] = t1[3 * s];
+      if (!LTW) {
+        const float2 *t1 = p.T + p.toff[1] + (tid & (s - 1));
+        pf_tw[0] = t1[0]; pf_tw[1] = t1[3 * s];
+      }
       K7_STAMP(0, tid);
       __builtin_amdgcn_sched_barrier(0);
       prefetch(uk + uk_step < uk_end ? uk + uk_step : uk, uk + uk_step < uk_end);
@@ -843,7 +863,10 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
         float2 v[16], w[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) v[k] = X(s == 64 ? lp_s64 : lp_s4, base, k * s);   // (xw is xl: one band)
-        if (PIPE && pass == 1) twiddle_apply_seeded<true>(v, pf_tw[0], pf_tw[1]);
+        if (LTW) {
+#pragma unroll
+          for (int k = 1; k < 16; k++) v[k] = cmulc(v[k], (s == 64 ? ltw64 : ltw4)[(k - 1) * s]);
+        } else if (PIPE && pass == 1) twiddle_apply_seeded<true>(v, pf_tw[0], pf_tw[1]);
         else {
           twiddles16(p, pass, s, j, w);
 #pragma unroll
@@ -1520,16 +1543,20 @@ struct sdrhip_fftconv {
 #endif
       auto even = [](size_t v) { return (v & 1) == 0; };
       const bool pv = even(hop) && even(HH) && even(HL) && even(a.delay) && even(N) && even(in_stride) && even(out_stride) &&
-                      (reinterpret_cast<uintptr_t>(in_dev) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
+                      (reinterpret_cast<uintptr_t>(in_dev) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
+                      getenv("SDRHIP_K7_PIPE_X2") == nullptr;   // (A/B hook: the 8-byte form everywhere)
+      const size_t lds_p = lds + (15 * 64 + 15 * 4) * sizeof(float2);   // (+ room for the K7_LDS_TW variant's tables)
       auto go = [&](auto kernel) {
-        allow_big_lds(kernel, lds);
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(1024), lds, ctx->stream, a);
+        allow_big_lds(kernel, lds_p);
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(1024), lds_p, ctx->stream, a);
       };
       // (the two BASELINE shapes get their stores counted at compile time: 4097 taps keep 12288 of 16384, the reference mode's
       // 8192 taps 8192)
       if (pv && HH == 4096) go(fftconv_fused_kernel<14, false, 1024, false, 4, 2>);
       else if (pv && HH == 8192) go(fftconv_fused_kernel<14, false, 1024, false, 4, 4>);
       else if (pv) go(fftconv_fused_kernel<14, false, 1024, false, 4, 0>);
+      else if (HH == 4096) go(fftconv_fused_kernel<14, false, 1024, false, 2, 4>);
+      else if (HH == 8192) go(fftconv_fused_kernel<14, false, 1024, false, 2, 8>);
       else go(fftconv_fused_kernel<14, false, 1024, false, 2, 0>);
     } else if (plan.L == 16384) {   // (never a bank: two images of 16384 points do not fit the LDS)
       fused(fftconv_fused_kernel<14, false, 1024>, 1024);   // (512 / 256 lanes measured 0.78x / 0.59x)
