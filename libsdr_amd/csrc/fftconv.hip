@@ -430,6 +430,15 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
   // (PIPE: opaque as well — inside the walk's loop everything derived from the lane index is loop-invariant, gets hoisted in front of
   // the loop and spilled there: 79 registers' worth, reloaded one by one through scratch, i.e. through vmcnt)
   auto lane = [&]() { int t = tid0; if (LG == 0 || PIPE) { asm volatile("" : "+v"(t)); __builtin_assume(t >= 0 && t < NT); } return t; };
+  // WAVE_LOCAL: the passes between the first forward and the last inverse pass need no workgroup barrier (see below). 16384 points
+  // on 1024 lanes (a segment = one wave). -DK7_WL_MID=1: also 8192 points on 512 lanes and 4096 on 256 (a segment = 32 / 16 lanes of
+  // ONE wave; the radix-2 butterflies of the 8192-point middle pass re-mapped to the lane group's own segment) — parity green, time
+  // +-0 on FilterNode(2048) / (4096) / (1000) (0.114 / 0.096 / 0.087 ms either way: two to eight workgroups per CU cover each other's
+  // barriers), so they keep their barrier per pass
+#ifndef K7_WL_MID
+#define K7_WL_MID 0
+#endif
+  constexpr bool WAVE_LOCAL = !BANK && ((LG == 14 && NT == 1024) || (K7_WL_MID && ((LG == 13 && NT == 512) || (LG == 12 && NT == 256))));
   // (K7_PRIO, 16384 points) between two barriers the waves of a SIMD run at their own pace and the arbiter prefers the oldest: wave 0
   // arrives at the next barrier 12 600 clocks of a 32 300-clock turn before the last one (stamps), and the last one runs alone, its
   // LDS latencies uncovered. Priority by progress — the further along, the lower — keeps the four together.
@@ -447,7 +456,7 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
 #else
 #define K7_PRIO_TAB {3, 3, 3, 2, 1, 1, 0, 3, 2, 1, 0}
 #endif
-#define K7_SETPRIO(site_) do { if (LG == 14 && !BANK) { constexpr int tab_[] = K7_PRIO_TAB; __builtin_amdgcn_s_setprio(tab_[site_]); } } while (0)
+#define K7_SETPRIO(site_) do { if (WAVE_LOCAL) { constexpr int tab_[] = K7_PRIO_TAB; __builtin_amdgcn_s_setprio(tab_[site_]); } } while (0)
 #else
 #define K7_SETPRIO(site_) do { } while (0)
 #endif
@@ -594,10 +603,12 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
   // exactly one WAVE's 64 lanes x 16 points. The passes between the first forward and the last inverse pass then touch
   // only data the same wave wrote — LDS operations of one wave execute in order, so they need no workgroup barrier: 2
   // barriers per block instead of 7 (r08's counters: 44 % of the wave cycles parked at them, all 16 waves in lock step).
-  constexpr bool WAVE_LOCAL = !BANK && LG == 14 && NT == 1024;
   auto pass_sync = [&]() { if (WAVE_LOCAL) asm volatile("" ::: "memory"); else __syncthreads(); };
   // radix-4 butterfly q (0..3) of this lane: with WAVE_LOCAL the 256 butterflies of the wave's own segment
   auto bfly4_index = [&](int tid, int q) { return WAVE_LOCAL ? ((tid >> 6) * 256 + (tid & 63) + 64 * q) : (tid + q * FT); };
+  // radix-2 butterfly q (0..7) of this lane (8192 points on 512 lanes): with WAVE_LOCAL the L / 32 butterflies of the segment the
+  // lane's 32-lane group owns (in lane order a lane's eight butterflies lie in eight different segments)
+  auto bfly2_index = [&](int tid, int q) { return ((tid / (NT / 16)) * (L / 32) + (tid % (NT / 16)) + (NT / 16) * q); };
   for (; uk < uk_end; uk += uk_step) {   // (one turn unless PIPE)
   if (PIPE) unit_of(uk, blk, c);
   const int first = blk * a.hop - a.HH - a.delay;   // call-relative index of element 0
@@ -828,6 +839,14 @@ __global__ __launch_bounds__(NT) void fftconv_fused_kernel(const ConvArgs a) {
         bfly4<1>(cmul(X0, kp[4 * b]), cmul(X1, kp[4 * b + 1]), cmul(X2, kp[4 * b + 2]), cmul(X3, kp[4 * b + 3]), Z0, Z1, Z2, Z3);
         if (PIPE) { X(lp_mid, 0, 256 * q) = Z0; X(lp_mid, 0, 256 * q + 1) = Z1; X(lp_mid, 0, 256 * q + 2) = Z2; X(lp_mid, 0, 256 * q + 3) = Z3; }
         else { xw[P(4 * b)] = Z0; xw[P(4 * b + 1)] = Z1; xw[P(4 * b + 2)] = Z2; xw[P(4 * b + 3)] = Z3; }
+      }
+    } else if (WAVE_LOCAL) {
+#pragma unroll
+      for (int q = 0; q < (L / 2) / NT; q++) {
+        const int b = bfly2_index(tid, q);
+        const float2 a0 = xs[P(2 * b)], a1 = xs[P(2 * b + 1)];
+        const float2 y0 = cmul(cadd(a0, a1), kp[2 * b]), y1 = cmul(csub(a0, a1), kp[2 * b + 1]);
+        xw[P(2 * b)] = cadd(y0, y1); xw[P(2 * b + 1)] = csub(y0, y1);
       }
     } else {
       for (int b = tid; b < L / 2; b += FT) {
