@@ -1743,14 +1743,19 @@ int sdrhip_fftconv_create_bank(sdrhip_ctx *ctx, int mode, int fft_size, const fl
       // 2048-point plan (its last passes run in registers: 35.6 % against 33.8 % remapped) and not the banks (one forward transform
       // per block for all bands, tuned at these sizes: 32 % against 26 %). profiles/r17_bigconv_time.txt)
       const bool awkward = !is_pow2(fft_size) || fft_size < 4 || fft_size > 16384;
-      if (mode == SDRHIP_FFTCONV_OLA && (awkward || (n_bands == 1 && fft_size != 2048)) && fft_size % 2 == 0 && !getenv("SDRHIP_FFTCONV_LITERAL")) {
+      // (round 6: the 2048-point plan too where the call has blocks enough for the pipelined 16384-point kernel — FilterNode(1024) on
+      // 256 channels x 65536: 0.093 -> 0.078 ms)
+      const bool keep2048 = fft_size == 2048 && ols_fft_size(1024, (size_t)channels, max_in, ctx->prop.multiProcessorCount) != 16384;
+      if (mode == SDRHIP_FFTCONV_OLA && (awkward || (n_bands == 1 && !keep2048)) && fft_size % 2 == 0 && !getenv("SDRHIP_FFTCONV_LITERAL")) {
         // the same N taps by overlap-save on the best power of two (ola_spectrum_to_taps); SDRHIP_FFTCONV_LITERAL=1
         // keeps the 2N-point transform (tests of the general plans)
-        // (complex<float>: the tuned kernels' own ranking — 2048 points up to 512 taps, 4096 up to 2048, 16384 beyond — measured at
-        // 8 ... 4097 taps, tools/probes/fir_cf32_vs_fft.py; the operation count alone would pick 8192 points for 1000 taps: 0.41 ms
-        // against 0.35 ms on 4096)
+        // (complex<float>: the tuned kernels' own ranking, ols_fft_size — the operation count alone would pick 8192 points for
+        // 1000 taps: 0.39 ms against 0.34 on 16384 and 0.35 on 4096)
         // (12290 ... 16384 taps, one band: the same 16384-point kernel in two tap partitions — sdrhip_fftconv::parts)
-        const int N = fft_size / 2, lp = N <= 512 ? 2048 : N <= 2048 ? 4096 : N <= 12289 ? 16384 : (N <= 16384 && n_bands == 1 && !getenv("SDRHIP_FFTCONV_NO_PARTS")) ? 16384 : 0;
+        // (banks keep the ranking measured for them: one forward transform serves all bands up to 8192 points, not at 16384)
+        const int N = fft_size / 2, lp = N <= 12289 ? (n_bands == 1 ? ols_fft_size(N, (size_t)channels, max_in, ctx->prop.multiProcessorCount)
+                                                                     : N <= 512 ? 2048 : N <= 2048 ? 4096 : 16384)
+                                           : (N <= 16384 && n_bands == 1 && !getenv("SDRHIP_FFTCONV_NO_PARTS")) ? 16384 : 0;
         if (lp && N > 12289) { h->parts = 2; h->part_taps = 8192; }
         if (lp && lp != fft_size) {
           for (int b = 0; b < n_bands; b++) {

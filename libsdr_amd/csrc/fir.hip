@@ -796,7 +796,6 @@ static std::vector<float> fir_fft_taps(const double *alpha, int order) {
   for (int k = 0; k < order; k++) t[2 * k] = (float)alpha[order - 1 - k];
   return t;
 }
-static int fir_fft_size(int order) { return order <= 512 ? 2048 : order <= 2048 ? 4096 : 16384; }
 
 // (re)starts the fused shift's phasor at the CURRENT sample: exp(-2 pi i fc (n - n_now) / fs) from the next call on — what
 // FreqShiftBase::setFrequencyShift does to its LUT counter (src/freqshift.hh:78-87). FIR history (raw input samples),
@@ -864,7 +863,7 @@ int fir_create_impl(sdrhip_ctx *ctx, int kind, const double *alpha, int order, i
                  // is the faster one (4.6 - 6.8 us); everywhere else the FFT plan wins (127 taps: 7 against 14 us on ONE channel)
                  (order > 32 || (size_t)channels * max_in > ((size_t)1 << 18) || getenv("SDRHIP_FIR_FFT_ALWAYS"))) {
         const std::vector<float> t = fir_fft_taps(alpha, order);
-        const int rc = sdrhip_fftconv_create(ctx, SDRHIP_FFTCONV_OLS, fir_fft_size(order), t.data(), order, channels, max_in, &h->fftc);
+        const int rc = sdrhip_fftconv_create(ctx, SDRHIP_FFTCONV_OLS, ols_fft_size(order, (size_t)channels, max_in, ctx->prop.multiProcessorCount), t.data(), order, channels, max_in, &h->fftc);
         if (rc != SDRHIP_OK) throw Failure{rc};
       } else {
         // beta[m] = (1/D) * sum_k alpha[m-k], k in [0,D): FIR followed by the D-sample box average

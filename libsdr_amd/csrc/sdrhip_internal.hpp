@@ -64,6 +64,17 @@ static inline int guarded(F &&f) {
   }
 }
 
+// Transform size of an overlap-save plan for n_taps complex<float> taps (the tuned kernels' own ranking, measured on the
+// round-6 kernels at 16 ... 1024 channels x 65536 samples, tools/probes/fft_rank.py = profiles/r19_fft_rank.txt): the 2048-point
+// plan up to 768 taps; beyond, the pipelined 16384-point kernel wherever the call has blocks enough to walk (4 per CU: it then
+// beats the 4096-point plan by 3 % at 1024 taps and by 35 % at 2048) and the 4096-point plan up to 2048 taps where not.
+inline int ols_fft_size(int n_taps, size_t channels, size_t max_in, int cus) {
+  if (n_taps <= 768) return 2048;
+  const size_t units16 = channels * ((max_in + (size_t)(16384 - n_taps)) / (size_t)(16384 - n_taps + 1));
+  if (n_taps <= 12289 && units16 >= (size_t)4 * (size_t)cus) return 16384;
+  return n_taps <= 2048 ? 4096 : 16384;
+}
+
 }  // namespace sdrhip
 
 struct sdrhip_ctx {
