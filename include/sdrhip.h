@@ -277,7 +277,8 @@ int sdrhip_fir_process(sdrhip_fir *h, const void *in_host, size_t n_in, size_t i
 int sdrhip_fir_process_dev(sdrhip_fir *h, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev,
                            size_t out_stride, size_t *n_out);
 /* A complex<float> plan with decim = 1 and no epilogue (FIRLowPass<complex<float>>) runs as overlap-save FFT convolution on the
- * tuned FFT kernels behind this handle — a tolerance path either way (<= 1e-5), 6x faster at 127 taps and 130x at 4097 than
+ * tuned FFT kernels behind this handle (transform size as for sdrhip_fftconv_create's converted plans, see there) — a tolerance
+ * path either way (<= 1e-5), 6x faster at 127 taps and 145x at 4097 than
  * `order` multiply-adds per sample; SDRHIP_FIR_TIME_DOMAIN=1 in the environment keeps the time-domain kernel (tests). Below the
  * measured crossover — up to 32 taps on plans of at most 2^18 samples per call (channels x max_in) — the time-domain kernel stays
  * (a block transform costs a call 7 us however little it filters). On an FFT-backed plan sdrhip_fir_set_taps SYNCHRONISES the
@@ -336,7 +337,8 @@ int sdrhip_subsample_destroy(sdrhip_subsample *h);
 enum {
   SDRHIP_FFTCONV_OLA = 0, /* reference mode: block N, FFT 2N, kernel = 2N-point spectrum K,
                              out = last + IFFT(FFT([x,0]) * K)/2N  (overlap-add) */
-  SDRHIP_FFTCONV_OLS = 1  /* overlap-save with M real/complex taps, FFT size L, hop L-M+1
+  SDRHIP_FFTCONV_OLS = 1  /* overlap-save with M real/complex taps, FFT size L, hop L-M+1 (rounded down to even: one more
+                             sample of history keeps every block of an aligned call 16-byte aligned)
                              (BASELINE config 4: L=16384, M=4097); plain causal convolution */
 };
 /* OLA: fft_size = 2N, kernel = 2N cf32 spectrum (already normalised), n_taps ignored. The result is the
@@ -380,7 +382,11 @@ int sdrhip_fftconv_destroy(sdrhip_fftconv *h);
  * of the spectrum's inverse DFT, taken on the host in double) on the power of two that costs least per output — provided N
  * leaves such a block a quarter of its points (N <= 12289; 6144 in double). FilterNode<float>(1000), (1009), (12000) run the
  * tuned kernels that way — and so does a single band on a power of two other than 2048 (half of every 2N-point block is
- * overlap, a longer block keeps up to 7/8 of its points); filter banks and the 2048-point plan keep their own transform.
+ * overlap, a longer block keeps up to 7/8 of its points); filter banks keep their own transform, and so does the 2048-point
+ * plan unless the call has blocks enough for the 16384-point kernel's pipelined form (4 per CU). The transform size follows the
+ * taps and the blocks a call has (channels x max_in): 2048 points up to 768 taps; from there 16384 points wherever that form can
+ * walk, otherwise 4096 points up to 2048 taps and 16384 beyond (measured: profiles/r19_fft_rank.txt). Results agree within the
+ * tolerance whatever the size; two plans of different channels / max_in may therefore differ in the last bits.
  * SDRHIP_FFTCONV_LITERAL=1 in the environment keeps the 2N-point transform everywhere (tests).
  *
  * FilterNode<double> (the filter classes are templates over Scalar, src/filternode.hh:30-32,102-104,230-232): the same

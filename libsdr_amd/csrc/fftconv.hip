@@ -184,16 +184,8 @@ __device__ __forceinline__ void twiddles16(const FftDev &p, int q, int s, int j,
   for (int k = 1; k < 16; k++) w[k] = t[(k - 1) * s];
 }
 
-// the same 15 twiddles from the two seeds w1 = W^(j tw), w4 = W^(4 j tw) the 2-load form reads (already in registers)
-__device__ __forceinline__ void twiddles16_seeded(float2 w1, float2 w4, float2 *w) {
-  const float2 w2 = cmul(w1, w1), w8 = cmul(w4, w4);
-  w[1] = w1; w[2] = w2; w[4] = w4; w[8] = w8;
-  w[3] = cmul(w1, w2); w[5] = cmul(w4, w1); w[6] = cmul(w4, w2); w[7] = cmul(w4, w[3]);
-  w[9] = cmul(w8, w1); w[10] = cmul(w8, w2); w[11] = cmul(w8, w[3]); w[12] = cmul(w8, w4);
-  w[13] = cmul(w8, w[5]); w[14] = cmul(w8, w[6]); w[15] = cmul(w8, w[7]);
-}
-
-// ... and applied as they are made, v[k] *= w^k (CONJ: the conjugates): 8 twiddles live instead of 15 (the pipelined form holds the
+// the 15 twiddles of a radix-16 pass from the two seeds w1 = W^(j tw), w4 = W^(4 j tw) the 2-load form reads (already in registers),
+// applied as they are made, v[k] *= w^k (CONJ: the conjugates): 8 twiddles live instead of 15 (the pipelined form holds the
 // next block's inputs in 32 registers through the passes that use this)
 template <bool CONJ>
 __device__ __forceinline__ void twiddle_apply_seeded(float2 *v, float2 w1, float2 w4) {
@@ -202,9 +194,6 @@ __device__ __forceinline__ void twiddle_apply_seeded(float2 *v, float2 w1, float
   v[1] = mul(v[1], w1); v[2] = mul(v[2], w2); v[3] = mul(v[3], w3); v[4] = mul(v[4], w4);
   const float2 w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3), w8 = cmul(w4, w4);
   v[5] = mul(v[5], w5); v[6] = mul(v[6], w6); v[7] = mul(v[7], w7); v[8] = mul(v[8], w8);
-#ifdef K7_PIPE_SCHED
-  __builtin_amdgcn_sched_barrier(0);
-#endif
   v[9] = mul(v[9], cmul(w8, w1)); v[10] = mul(v[10], cmul(w8, w2)); v[11] = mul(v[11], cmul(w8, w3)); v[12] = mul(v[12], cmul(w8, w4));
   v[13] = mul(v[13], cmul(w8, w5)); v[14] = mul(v[14], cmul(w8, w6)); v[15] = mul(v[15], cmul(w8, w7));
 }
