@@ -574,11 +574,21 @@ __global__ __launch_bounds__(TPB, R == 4 ? 2 : 4) void fir_cf32_pipe_kernel(cons
     if (fast(t_begin)) { fetch(t_begin); commit(t_begin); } else stage_plain(t_begin);
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     __syncthreads();
+    // (tuning variant -DK3_PRIO=1: the short phases between the barriers — issuing the next tile's loads, staging it into LDS — at
+    // priority 3, the long multiply-add loop at 0, so that a workgroup in a memory phase is not queued behind the arithmetic of the
+    // other three on its CU. Measured +-0 on the float baseband, three interleaved runs: 0.1359 / 0.1362 against 0.1360 / 0.1357 /
+    // 0.1355 ms — what helped the one-workgroup-per-CU FFT kernel does nothing where four workgroups already interleave. Off.)
+#ifndef K3_PRIO
+#define K3_PRIO 0
+#endif
     for (int t = t_begin; t < t_end; t++) {
       const bool more = t + 1 < t_end, nf = more && fast(t + 1);
+      if (K3_PRIO) __builtin_amdgcn_s_setprio(3);
       if (nf) fetch(t + 1);   // in flight while this tile is computed
+      if (K3_PRIO) __builtin_amdgcn_s_setprio(0);
       compute(t);
       if (more) {
+        if (K3_PRIO) __builtin_amdgcn_s_setprio(3);
         __syncthreads();   // every lane is done with tile t's samples
         if (nf) commit(t + 1); else stage_plain(t + 1);
         // nothing of this iteration stays in flight across the back edge: the compiler's wait-count model merges the
