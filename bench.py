@@ -850,8 +850,11 @@ def main():
     except BenchError as e:
         if rank == 0:
             print(error_line(a, e, world=int(os.environ.get("WORLD_SIZE", "1"))), flush=True)
+            if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+                time.sleep(2.0)   # (the launcher tears the other ranks down as soon as one exits: give them the time to say why THEY stop)
         else:
             sys.stderr.write("bench.py rank %d: %s\n" % (rank, e))
+            sys.stderr.flush()
         raise SystemExit(2)
     except SystemExit:
         raise
